@@ -1,0 +1,25 @@
+# Builds the gfx950 product library (hipcc cross-compiles without a GPU) and the CPU oracle.
+HIPCC ?= /opt/rocm/bin/hipcc
+ARCH  ?= gfx950
+PKG   := multiple-quadrotor-slam_amd
+SRCS  := $(wildcard $(PKG)/csrc/*.hip)
+HDRS  := $(wildcard $(PKG)/csrc/*.h) include/mqslam.h
+LIB   := $(PKG)/libmqslam_hip.so
+HIPFLAGS ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-function -Wl,-rpath,/opt/rocm/lib
+
+all: $(LIB) oracle
+
+$(LIB): $(SRCS) $(HDRS)
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(SRCS)
+
+oracle:
+	$(MAKE) -s -C oracle/c
+
+tests/libhost_math.so: tests/host_math.cpp $(PKG)/csrc/tri_math.h
+	g++ -O2 -ffp-contract=off -fPIC -shared -o $@ tests/host_math.cpp
+
+clean:
+	rm -f $(LIB) tests/libhost_math.so
+	$(MAKE) -s -C oracle/c clean
+
+.PHONY: all oracle clean

@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""
+Benchmark of the MI355X hot path on BASELINE.json's headline configuration:
+1e6 landmarks x 4 cameras per GPU (configs[1]); synthetic scene of SURVEY.md 8(d).
+
+One STEP = one pass of the triangulation hot path over the rank's resident batch:
+linear-LS (DLT) + Hartley-Sturm iterative-LS over all landmarks, followed -- once the BA
+kernels are built in (see `ba` in the output) -- by one Gauss-Newton iteration of bundle
+adjustment (linearise + Schur + reduce + solve + back-substitute) on the same landmarks.
+Inputs are resident in HBM before the timed region.  `value` = landmarks (all ranks) / step.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--landmarks L] [--cams C]
+
+N > 1: launched by torch.distributed.run, one rank per GPU; landmarks shard across ranks
+(weak scaling: every rank holds L landmarks), no data-path collective for triangulation, one
+RCCL all-reduce of the reduced camera system per BA iteration.
+
+Extra objects on the JSON line:
+  roofline     -- dominant kernel (iterative-LS): algorithmic bytes per launch / average launch
+                  duration from hipEvents on the launch stream, against 8 TB/s HBM.
+  cpu_baseline -- the oracle's plain-C port of the reference kernel (oracle/c/tri_oracle.c),
+                  single thread as the reference ships it, same step on the same arrays
+                  (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--landmarks", type=int, default=1_000_000)
+    ap.add_argument("--cams", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ba", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import mqslam_amd
+
+    if not mqslam_amd.loaded:
+        raise SystemExit("libmqslam_hip.so is not available: %r" % (mqslam_amd._lib.load_error,))
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
+        args.gpus = world
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+
+    N, C = args.landmarks, args.cams
+    syn = mqslam_amd.synthetic
+    u, P, pts = syn.triangulation_problem(N, C, seed=syn.RSEED + 1000 * rank)
+    ud = torch.from_numpy(u).to(dev)
+    Pd = torch.from_numpy(np.ascontiguousarray(P)).to(dev)
+    x_ls = torch.empty((N, 3), dtype=torch.float64, device=dev)
+    x_it = torch.empty((N, 3), dtype=torch.float64, device=dev)
+    st = torch.empty((N,), dtype=torch.int32, device=dev)
+    D = mqslam_amd.device
+
+    ba = None
+    if not args.no_ba and hasattr(mqslam_amd, "bundle_adjustment"):
+        ba = mqslam_amd.bundle_adjustment.make_benchmark_problem(u, P, pts, dev, seed=syn.RSEED + rank)
+
+    def step():
+        D.linear_LS_triangulation(ud, Pd, out=x_ls)
+        D.iterative_LS_triangulation(ud, Pd, out=x_it, out_status=st)
+        if ba is not None:
+            ba.gauss_newton_iteration()
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = N * world / (elapsed / args.steps)
+
+    # ---- per-kernel durations with hipEvents on the launch stream (rank 0 reports) ----
+    reps = 20
+    ms_it = D.time_triangulation("iterative_ls", ud, Pd, reps=reps)
+    ms_ls = D.time_triangulation("linear_ls", ud, Pd, reps=reps)
+    ms_eg = D.time_triangulation("linear_eigen", ud, Pd, reps=reps)
+    bytes_it = N * (16 * C + 24 + 4)            # 92 B/landmark at C = 4
+    bytes_ls = N * (16 * C + 24)
+    bytes_eg = N * (16 * C + 24 + 1)
+    achieved = bytes_it / (ms_it * 1e-3) / 1e9
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc_path):
+        try:
+            rec = json.load(open(pmc_path))
+            if rec.get("landmarks") == N and rec.get("cams") == C:
+                traffic = rec.get("iterative_ls_hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "kernel": "tri_kernel<%d, iterative_ls>" % C, "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                "traffic": traffic, "algorithmic_bytes_per_launch": bytes_it,
+                "avg_launch_ms": round(ms_it, 5)}
+    kernels = {
+        "iterative_ls": {"ms": round(ms_it, 5), "landmarks_per_s": round(N / (ms_it * 1e-3)),
+                         "GBps": round(bytes_it / (ms_it * 1e-3) / 1e9, 1)},
+        "linear_ls": {"ms": round(ms_ls, 5), "landmarks_per_s": round(N / (ms_ls * 1e-3)),
+                      "GBps": round(bytes_ls / (ms_ls * 1e-3) / 1e9, 1)},
+        "linear_eigen": {"ms": round(ms_eg, 5), "landmarks_per_s": round(N / (ms_eg * 1e-3)),
+                         "GBps": round(bytes_eg / (ms_eg * 1e-3) / 1e9, 1)},
+    }
+    ba_out = None
+    if ba is not None:
+        ba_out = ba.benchmark_report(world, dist)
+
+    # ---- CPU baseline: the oracle's C port of the reference kernel, rank 0, N = 1 only ----
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import c_oracle
+        c_oracle.build()
+        ns = min(N, 1_000_000)
+        us = np.ascontiguousarray(u[:, :ns])
+        c_oracle.linear_LS_triangulation(us[:, :1000], P)           # page in
+        t0 = time.perf_counter()
+        c_oracle.linear_LS_triangulation(us, P)
+        xo, so = c_oracle.iterative_LS_triangulation(us, P)
+        t_cpu = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        c_oracle.linear_LS_triangulation(us, P, use_omp=True)
+        c_oracle.iterative_LS_triangulation(us, P, use_omp=True)
+        t_omp = time.perf_counter() - t0
+        # parity gate run with the benchmark: GPU result vs the baseline's
+        xg = x_it[:ns].cpu().numpy()
+        rel = np.linalg.norm(xg - xo, axis=1) / np.maximum(np.linalg.norm(xo, axis=1), 1.0)
+        cpu = {"value": round(ns / t_cpu), "unit": "landmarks/s", "cores": 1, "kind": "port",
+               "sample": "linear-LS + iterative-LS over %d landmarks x %d cams (the same arrays), 1 pass, "
+                         "oracle/c/tri_oracle.c, gcc -O2, single thread as the reference ships it" % (ns, C),
+               "all_cores": {"value": round(ns / t_omp), "cores": os.cpu_count(),
+                             "note": "same port with the reference's disabled `omp parallel for` enabled"},
+               "parity": {"rel_err_p99.9": float(np.quantile(rel, 0.999)), "rel_err_median": float(np.median(rel)),
+                          "status_mismatch_frac": float(np.mean(st[:ns].cpu().numpy() != so))}}
+
+    if rank == 0:
+        out = {
+            "metric": "triangulated landmarks/sec (linear-LS DLT + iterative-LS per landmark"
+                      + (" + 1 BA Gauss-Newton iteration" if ba is not None else "")
+                      + "), 1e6 pts x 4 cams per GPU; BA GN iters/sec in `ba`",
+            "value": round(value), "unit": "landmarks/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: %d landmarks x %d cameras per GPU, linear-LS + "
+                                   "iterative-LS (tol 3e-5, <=10 iterations)" % (N, C),
+                       "landmarks_per_gpu": N, "cameras": C, "sharding": "landmarks, %d-way" % world},
+            "roofline": roofline, "kernels": kernels, "ba": ba_out, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,181 @@
+/*
+ * mqslam.h -- C ABI of libmqslam_hip.so: the MI355X (gfx950) hot path of
+ * Multiple-Quadrotor-SLAM behind the reference's own native-extension boundary.
+ *
+ * Every entry point returns 0 on success or a negative MQS_E_* code; the message of the
+ * last failure on the calling thread is returned by mqs_last_error().  Nothing throws or
+ * exits across this boundary.  The caller owns every buffer; the library allocates only
+ * scratch that lives inside an mqs_ctx.
+ *
+ * Reference interfaces replaced (paths relative to the reference repository root):
+ *   - Work/python_libs/triangulation_c/triangulation.c:64-83   linear_LS_triangulation
+ *     (weave signature `linear_LS_triangulation(u1, P1, u2, P2, x)`,
+ *      Work/python_libs/triangulation_c/__init__.py:45)
+ *   - Work/python_libs/triangulation_c/triangulation.c:103-161 iterative_LS_triangulation
+ *     (weave signature `iterative_LS_triangulation(u1, P1, u2, P2, tolerance, x, x_status)`,
+ *      Work/python_libs/triangulation_c/__init__.py:84)
+ *   - Work/python_libs/triangulation.py:20  cv2.triangulatePoints call of
+ *     linear_eigen_triangulation
+ *   - Work/python_libs/cv2_helpers.py:300-306  cv2.batchDistance call of BFMatcher.radiusMatch
+ *   - Work/SLAM/tools/bundle_adjustment/bundle_adjust.cpp:289-298,323-324  projection-factor
+ *     graph + LevenbergMarquardtOptimizer::optimize (GTSAM 3.2.1): linearise, normal
+ *     equations, solve.
+ *
+ * Array layouts (all row-major, float64 unless stated):
+ *   u      [C][N][2]   normalised image coordinates, camera-major
+ *   P      [C][3][4]   camera matrices (top three rows; world -> camera)
+ *   x      [N][3]      triangulated points
+ *   status [N] int32   iterative-LS status code (see mqs_triangulate_iterative_ls)
+ *   ok     [N] uint8   linear-eigen finite flag
+ * N-view generalisation: SURVEY.md Appendix C; C == 2 reproduces the reference exactly.
+ */
+#ifndef MQSLAM_H
+#define MQSLAM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MQS_OK          0
+#define MQS_E_ARG      -1   /* bad argument (null pointer, C out of range, misaligned device ptr) */
+#define MQS_E_HIP      -2   /* HIP runtime error (message in mqs_last_error) */
+#define MQS_E_NOMEM    -3   /* device or host allocation failed */
+#define MQS_E_NODEVICE -4   /* no gfx950 device visible */
+
+#define MQS_MAX_CAMS    8
+#define MQS_TRI_MAX_ITER_DEFAULT 10        /* triangulation.c:125 */
+#define MQS_TRI_TOL_DEFAULT      3.e-5     /* triangulation_c/__init__.py:51 */
+#define MQS_TRI_MAX_COORD_DEFAULT 1.e16    /* triangulation.py:6 */
+
+typedef struct mqs_ctx mqs_ctx;            /* one ctx <-> one device <-> one stream; one ctx per thread */
+
+const char *mqs_last_error(void);
+const char *mqs_version(void);
+int  mqs_device_count(void);
+
+/* Context: owns device staging buffers used by the host-pointer entry points. */
+int  mqs_create(int device_id, mqs_ctx **out);
+void mqs_destroy(mqs_ctx *ctx);
+int  mqs_synchronize(mqs_ctx *ctx);
+
+/* ---------------------------------------------------------------------------------------
+ * Triangulation, host pointers (H2D copy, kernel, D2H copy; synchronous).
+ * ------------------------------------------------------------------------------------- */
+
+/* T1: x = argmin |A x - b| of the 2C x 3 inhomogeneous DLT system (triangulation.c:65-83). */
+int mqs_triangulate_linear_ls(mqs_ctx *ctx, const double *u, const double *P, int C, int64_t N,
+                              double *x);
+
+/* T2: Hartley-Sturm iterative re-weighted LS exactly as triangulation.c:104-161:
+ * status = (iters < max_iter && all d_c > 0); for each c with d_c <= 0: status -= 2^c. */
+int mqs_triangulate_iterative_ls(mqs_ctx *ctx, const double *u, const double *P, int C, int64_t N,
+                                 double tolerance, int max_iter, double *x, int32_t *status);
+
+/* T3: homogeneous 3C x 4 DLT of cv2.triangulatePoints, x = X[0:3]/X[3],
+ * ok = all |x_i| <= max_coord (triangulation.py:20-23). */
+int mqs_triangulate_linear_eigen(mqs_ctx *ctx, const double *u, const double *P, int C, int64_t N,
+                                 double max_coord, double *x, uint8_t *ok);
+
+/* Two-view forms with the reference extension's exact argument order
+ * (triangulation_c/__init__.py:45,84).  P1/P2 may be 3x4 or 4x4 row-major: only the first
+ * 12 doubles are read, as in triangulation.c:24-25. */
+int mqs_linear_LS_triangulation(mqs_ctx *ctx, const double *u1, const double *P1, const double *u2,
+                                const double *P2, int64_t N, double *x);
+int mqs_iterative_LS_triangulation(mqs_ctx *ctx, const double *u1, const double *P1, const double *u2,
+                                   const double *P2, int64_t N, double tolerance, double *x,
+                                   int32_t *x_status);
+
+/* ---------------------------------------------------------------------------------------
+ * Triangulation, device pointers (asynchronous on `stream`, a hipStream_t passed as void*;
+ * NULL = the null stream).  All device pointers must be 16-byte aligned.  P is a DEVICE
+ * pointer to [C][3][4].
+ * ------------------------------------------------------------------------------------- */
+int mqs_triangulate_linear_ls_dev(const double *u, const double *P, int C, int64_t N, double *x,
+                                  void *stream);
+int mqs_triangulate_iterative_ls_dev(const double *u, const double *P, int C, int64_t N,
+                                     double tolerance, int max_iter, double *x, int32_t *status,
+                                     void *stream);
+int mqs_triangulate_linear_eigen_dev(const double *u, const double *P, int C, int64_t N,
+                                     double max_coord, double *x, uint8_t *ok, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Brute-force descriptor matching (replaces cv2.batchDistance + the per-query loop of
+ * cv2_helpers.py:296-339): for every query row the two nearest train rows under L2, ties
+ * broken towards the LOWER train index.  idx [Nq][2] int32 (-1 when Nt < 2),
+ * dist [Nq][2] float32 (L2 distance, not squared; +inf where idx == -1).
+ * ------------------------------------------------------------------------------------- */
+
+/* Exact float32 path, any D >= 1 (the reference's use: D == 2 pixel coordinates).
+ * dist^2 accumulated in float32 in dimension order without fused multiply-add, then sqrtf. */
+int mqs_match_knn2_f32(mqs_ctx *ctx, const float *query, int64_t Nq, const float *train, int64_t Nt,
+                       int D, int32_t *idx, float *dist);
+int mqs_match_knn2_f32_dev(const float *query, int64_t Nq, const float *train, int64_t Nt, int D,
+                           int32_t *idx, float *dist, void *stream);
+
+/* MFMA path for binary descriptors expanded to {0,1} fp16 (IEEE half, passed as uint16_t),
+ * D a multiple of 32, D <= 2048: |q-t|^2 = |q|^2 + |t|^2 - 2 q.t with the contraction on
+ * v_mfma_f32_32x32x16_f16; exact because every partial sum is a small integer. */
+int mqs_match_knn2_f16(mqs_ctx *ctx, const uint16_t *query, int64_t Nq, const uint16_t *train,
+                       int64_t Nt, int D, int32_t *idx, float *dist);
+int mqs_match_knn2_f16_dev(const uint16_t *query, int64_t Nq, const uint16_t *train, int64_t Nt, int D,
+                           int32_t *idx, float *dist, void *workspace, int64_t workspace_bytes,
+                           void *stream);
+int64_t mqs_match_knn2_f16_workspace_bytes(int64_t Nq, int64_t Nt);
+
+/* ---------------------------------------------------------------------------------------
+ * Bundle adjustment: projection-factor linearisation + landmark Schur complement, and the
+ * landmark back-substitution (replaces the GTSAM work behind bundle_adjust.cpp:289-298,323).
+ *
+ *   poses  [C][12]  camera-to-world pose: R (row-major 3x3) then t (3)   (IO.hpp:221-227)
+ *   calib  [C][9]   fx fy s u0 v0 k1 k2 p1 p2  (Cal3DS2 order, IO.hpp:230-236)
+ *   sigma  [C]      isotropic pixel sigma of camera c's projection factors
+ *   points [N][3]   landmarks (world)
+ *   obs    [C][N][2] pixel measurements;  mask [C][N] uint8 (NULL = all visible)
+ *
+ * Pose tangent order [omega(3), v(3)], right perturbation T*Exp(xi) (GTSAM Pose3).
+ * Outputs of linearize: out[(6C)*(6C) + 6C + 2] = { S row-major (reduced camera matrix,
+ * JtJ form), g (= reduced -J^T r, i.e. S * dpose = g), cost = 0.5*sum|r/sigma|^2,
+ * number of valid (in front of camera, unmasked) factors }.  `out` is OVERWRITTEN.
+ * lambda: Levenberg-Marquardt damping added as lambda*diag(Hll) on landmark blocks before
+ * elimination (0 = Gauss-Newton).
+ * ------------------------------------------------------------------------------------- */
+int mqs_ba_linearize_dev(const double *poses, const double *calib, const double *sigma, int C,
+                         const double *points, const double *obs, const uint8_t *mask, int64_t N,
+                         double lambda, double *out, void *workspace, int64_t workspace_bytes,
+                         void *stream);
+int64_t mqs_ba_workspace_bytes(int C, int64_t N);
+
+/* points_out = points + dpoint, dpoint = Hll^-1 (gl - Hpl^T dpose) at the SAME linearisation
+ * point as the preceding linearize call (recomputed, not stored).  dpose [6C] device ptr. */
+int mqs_ba_backsub_dev(const double *poses, const double *calib, const double *sigma, int C,
+                       const double *points, const double *obs, const uint8_t *mask, int64_t N,
+                       double lambda, const double *dpose, double *points_out, void *stream);
+
+/* cost only (0.5*sum|r/sigma|^2 and valid count) at the given state: out[2]. */
+int mqs_ba_cost_dev(const double *poses, const double *calib, const double *sigma, int C,
+                    const double *points, const double *obs, const uint8_t *mask, int64_t N,
+                    double *out, void *workspace, int64_t workspace_bytes, void *stream);
+
+/* Host-pointer convenience wrappers (copy in, run, copy out; synchronous). */
+int mqs_ba_linearize(mqs_ctx *ctx, const double *poses, const double *calib, const double *sigma, int C,
+                     const double *points, const double *obs, const uint8_t *mask, int64_t N,
+                     double lambda, double *out);
+int mqs_ba_backsub(mqs_ctx *ctx, const double *poses, const double *calib, const double *sigma, int C,
+                   const double *points, const double *obs, const uint8_t *mask, int64_t N,
+                   double lambda, const double *dpose, double *points_out);
+
+/* ---------------------------------------------------------------------------------------
+ * Timing helper used by bench.py: average duration (ms) of `reps` back-to-back launches of
+ * one triangulation kernel measured with hipEvents on `stream` (kernel: 0 = linear_ls,
+ * 1 = iterative_ls, 2 = linear_eigen).
+ * ------------------------------------------------------------------------------------- */
+int mqs_time_triangulate_dev(int kernel, const double *u, const double *P, int C, int64_t N,
+                             double tolerance, int max_iter, double *x, int32_t *status, uint8_t *ok,
+                             int reps, void *stream, float *avg_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MQSLAM_H */

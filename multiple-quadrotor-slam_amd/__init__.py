@@ -1,0 +1,13 @@
+"""
+mqslam_amd -- MI355X (gfx950) native hot path of Multiple-Quadrotor-SLAM.
+
+The directory is named `multiple-quadrotor-slam_amd` (not an importable identifier); import it
+through the repo-root shim:  `import mqslam_amd`.
+"""
+from . import _lib                       # noqa: F401
+from . import triangulation_c            # noqa: F401
+from . import triangulation              # noqa: F401
+from . import synthetic                  # noqa: F401
+from . import device                     # noqa: F401
+
+loaded = _lib.loaded

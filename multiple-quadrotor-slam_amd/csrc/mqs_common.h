@@ -1,0 +1,48 @@
+// Internal helpers shared by the HIP translation units of libmqslam_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/mqslam.h"
+
+void mqs_set_error(const char *fmt, ...);
+
+#define MQS_HIP_CHECK(expr)                                                                   \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            mqs_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return MQS_E_HIP;                                                                 \
+        }                                                                                     \
+    } while (0)
+
+#define MQS_ARG_CHECK(cond, msg)                                                              \
+    do {                                                                                      \
+        if (!(cond)) {                                                                        \
+            mqs_set_error("bad argument: %s (%s)", msg, #cond);                               \
+            return MQS_E_ARG;                                                                 \
+        }                                                                                     \
+    } while (0)
+
+struct mqs_ctx {
+    int device;
+    hipStream_t stream;
+    void *dbuf;        // grow-only device scratch for the host-pointer entry points
+    size_t dbuf_bytes;
+};
+
+// Ensures ctx->dbuf holds at least `bytes`; returns MQS_OK or an error code.
+int mqs_ctx_reserve(mqs_ctx *ctx, size_t bytes);
+
+static inline bool mqs_aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// Grid for streaming one-thread-per-item kernels: enough blocks to cover `n` items, capped so
+// that the remainder is grid-strided (256 CUs x 8 blocks of 256 threads).
+static inline unsigned mqs_stream_grid(int64_t n, int block)
+{
+    int64_t g = (n + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > 2048) g = 2048;
+    return (unsigned)g;
+}

@@ -1,0 +1,257 @@
+// N-view landmark triangulation kernels for gfx950 (MI355X): linear-LS (T1), Hartley-Sturm
+// iterative-LS (T2) and the homogeneous "linear-eigen" DLT (T3).
+//
+// Replaces the per-point cvSolve/SVD loops of
+//   Work/python_libs/triangulation_c/triangulation.c:65-83,104-161 and the
+//   cv2.triangulatePoints call of Work/python_libs/triangulation.py:20
+// (reference paths; the arithmetic each line mirrors is cited in tri_math.h).
+//
+// Mapping to the machine
+//   * one thread per landmark, 256-thread workgroups, grid capped at 2048 groups and
+//     grid-strided beyond that;
+//   * camera matrices ([C][3][4], <= 768 B) are staged once per workgroup in LDS and read
+//     from there as wave-uniform broadcasts;
+//   * observations are camera-major ([C][N][2] f64): lane i reads 16 contiguous bytes per
+//     camera, a wave reads 1 KiB per load instruction;
+//   * results (24 B per landmark) are transposed through LDS so that the workgroup writes its
+//     6 KiB of output as 16-byte-per-lane fully coalesced stores; status codes are 4 B per
+//     lane contiguous;
+//   * all arithmetic is fp64 in registers (the reference ABI is float64 end to end);
+//     HBM traffic per landmark is the algorithmic minimum 16*C + 24 (+4 | +1) bytes.
+#include "mqs_common.h"
+#include "tri_math.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+enum TriKind { kLinearLS = 0, kIterativeLS = 1, kLinearEigen = 2 };
+
+template <int C, int KIND>
+__global__ __launch_bounds__(kBlock) void tri_kernel(const double *__restrict__ u, const double *__restrict__ P,
+                                                     int64_t N, double tol, int max_iter, double max_coord,
+                                                     double *__restrict__ x, int32_t *__restrict__ status,
+                                                     uint8_t *__restrict__ ok)
+{
+    __shared__ double sP[C * 12];
+    __shared__ double sX[kBlock * 3];
+
+    const int tid = threadIdx.x;
+    if (tid < C * 12) sP[tid] = P[tid];
+    __syncthreads();
+
+    const double2 *__restrict__ u2 = reinterpret_cast<const double2 *>(u);
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+
+    for (int64_t base = (int64_t)blockIdx.x * kBlock; base < N; base += stride) {
+        const int64_t i = base + tid;
+        const bool live = i < N;
+
+        double uv[C][2];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            double2 v = make_double2(0.0, 0.0);
+            if (live) v = u2[(int64_t)c * N + i];
+            uv[c][0] = v.x;
+            uv[c][1] = v.y;
+        }
+
+        mqs::Vec3 r;
+        if (KIND == kLinearLS) {
+            r = mqs::linear_ls_point<C>(uv, sP);
+        } else if (KIND == kIterativeLS) {
+            int32_t s;
+            r = mqs::iterative_ls_point<C>(uv, sP, tol, max_iter, s);
+            if (live) status[i] = s;
+        } else {
+            bool o;
+            r = mqs::linear_eigen_point<C>(uv, sP, max_coord, o);
+            if (live) ok[i] = o ? 1 : 0;
+        }
+
+        // LDS transpose: [thread][3] doubles -> workgroup-contiguous 16-byte pieces.
+        sX[tid * 3 + 0] = r.x;
+        sX[tid * 3 + 1] = r.y;
+        sX[tid * 3 + 2] = r.z;
+        __syncthreads();
+        const int64_t rem = N - base;
+        const int npts = rem < kBlock ? (int)rem : kBlock;
+        const int ndbl = npts * 3;                         // doubles this workgroup owns
+        double *__restrict__ xo = x + base * 3;            // 16-byte aligned: base % 256 == 0
+        const double2 *sX2 = reinterpret_cast<const double2 *>(sX);
+        double2 *xo2 = reinterpret_cast<double2 *>(xo);
+        const int npair = ndbl >> 1;
+        for (int p = tid; p < npair; p += kBlock) xo2[p] = sX2[p];
+        if ((ndbl & 1) && tid == 0) xo[ndbl - 1] = sX[ndbl - 1];
+        __syncthreads();
+    }
+}
+
+template <int KIND>
+int launch_tri(const double *u, const double *P, int C, int64_t N, double tol, int max_iter, double max_coord,
+               double *x, int32_t *status, uint8_t *ok, hipStream_t stream)
+{
+    MQS_ARG_CHECK(C >= 2 && C <= MQS_MAX_CAMS, "2 <= C <= MQS_MAX_CAMS");
+    MQS_ARG_CHECK(N >= 0, "N >= 0");
+    if (N == 0) return MQS_OK;
+    MQS_ARG_CHECK(u && P && x, "u, P, x must not be null");
+    MQS_ARG_CHECK(mqs_aligned16(u) && mqs_aligned16(x), "device pointers must be 16-byte aligned");
+    if (KIND == kIterativeLS) MQS_ARG_CHECK(status != nullptr, "status must not be null");
+    if (KIND == kLinearEigen) MQS_ARG_CHECK(ok != nullptr, "ok must not be null");
+    const dim3 grid(mqs_stream_grid(N, kBlock)), block(kBlock);
+    switch (C) {
+#define MQS_CASE(c)                                                                             \
+    case c:                                                                                     \
+        hipLaunchKernelGGL((tri_kernel<c, KIND>), grid, block, 0, stream, u, P, N, tol, max_iter, \
+                           max_coord, x, status, ok);                                           \
+        break;
+        MQS_CASE(2) MQS_CASE(3) MQS_CASE(4) MQS_CASE(5) MQS_CASE(6) MQS_CASE(7) MQS_CASE(8)
+#undef MQS_CASE
+    }
+    MQS_HIP_CHECK(hipGetLastError());
+    return MQS_OK;
+}
+
+// Host-pointer driver: stage inputs into the ctx scratch, run, copy back.
+template <int KIND>
+int run_host(mqs_ctx *ctx, const double *const *u_cams, const double *const *P_cams, int C, int64_t N, double tol,
+             int max_iter, double max_coord, double *x, int32_t *status, uint8_t *ok)
+{
+    MQS_ARG_CHECK(ctx != nullptr, "ctx must not be null");
+    MQS_ARG_CHECK(C >= 2 && C <= MQS_MAX_CAMS, "2 <= C <= MQS_MAX_CAMS");
+    MQS_ARG_CHECK(N >= 0, "N >= 0");
+    if (N == 0) return MQS_OK;
+    MQS_HIP_CHECK(hipSetDevice(ctx->device));
+    // layout of the scratch: [u: C*N*2 f64][x: N*3 f64][P: C*12 f64][status: N i32][ok: N u8], 256-B aligned pieces
+    auto up = [](size_t v) { return (v + 255) & ~size_t(255); };
+    const size_t o_u = 0;
+    const size_t o_x = up(o_u + (size_t)C * N * 16);
+    const size_t o_P = up(o_x + (size_t)N * 24);
+    const size_t o_s = up(o_P + (size_t)C * 96);
+    const size_t o_k = up(o_s + (size_t)N * 4);
+    const size_t total = up(o_k + (size_t)N);
+    int rc = mqs_ctx_reserve(ctx, total);
+    if (rc != MQS_OK) return rc;
+    char *d = static_cast<char *>(ctx->dbuf);
+    double *d_u = reinterpret_cast<double *>(d + o_u);
+    double *d_x = reinterpret_cast<double *>(d + o_x);
+    double *d_P = reinterpret_cast<double *>(d + o_P);
+    int32_t *d_s = reinterpret_cast<int32_t *>(d + o_s);
+    uint8_t *d_k = reinterpret_cast<uint8_t *>(d + o_k);
+    for (int c = 0; c < C; ++c) {
+        MQS_ARG_CHECK(u_cams[c] && P_cams[c], "per-camera pointers must not be null");
+        MQS_HIP_CHECK(hipMemcpyAsync(d_u + (size_t)c * N * 2, u_cams[c], (size_t)N * 16, hipMemcpyHostToDevice, ctx->stream));
+        MQS_HIP_CHECK(hipMemcpyAsync(d_P + c * 12, P_cams[c], 96, hipMemcpyHostToDevice, ctx->stream));
+    }
+    rc = launch_tri<KIND>(d_u, d_P, C, N, tol, max_iter, max_coord, d_x, d_s, d_k, ctx->stream);
+    if (rc != MQS_OK) return rc;
+    MQS_HIP_CHECK(hipMemcpyAsync(x, d_x, (size_t)N * 24, hipMemcpyDeviceToHost, ctx->stream));
+    if (KIND == kIterativeLS) MQS_HIP_CHECK(hipMemcpyAsync(status, d_s, (size_t)N * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (KIND == kLinearEigen) MQS_HIP_CHECK(hipMemcpyAsync(ok, d_k, (size_t)N, hipMemcpyDeviceToHost, ctx->stream));
+    MQS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return MQS_OK;
+}
+
+void split_packed(const double *u, const double *P, int C, int64_t N, const double **uc, const double **Pc)
+{
+    for (int c = 0; c < C && c < MQS_MAX_CAMS; ++c) {
+        uc[c] = u ? u + (size_t)c * N * 2 : nullptr;
+        Pc[c] = P ? P + c * 12 : nullptr;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int mqs_triangulate_linear_ls_dev(const double *u, const double *P, int C, int64_t N, double *x, void *stream)
+{
+    return launch_tri<kLinearLS>(u, P, C, N, 0.0, 0, 0.0, x, nullptr, nullptr, static_cast<hipStream_t>(stream));
+}
+
+int mqs_triangulate_iterative_ls_dev(const double *u, const double *P, int C, int64_t N, double tolerance, int max_iter,
+                                     double *x, int32_t *status, void *stream)
+{
+    return launch_tri<kIterativeLS>(u, P, C, N, tolerance, max_iter, 0.0, x, status, nullptr,
+                                    static_cast<hipStream_t>(stream));
+}
+
+int mqs_triangulate_linear_eigen_dev(const double *u, const double *P, int C, int64_t N, double max_coord, double *x,
+                                     uint8_t *ok, void *stream)
+{
+    return launch_tri<kLinearEigen>(u, P, C, N, 0.0, 0, max_coord, x, nullptr, ok, static_cast<hipStream_t>(stream));
+}
+
+int mqs_triangulate_linear_ls(mqs_ctx *ctx, const double *u, const double *P, int C, int64_t N, double *x)
+{
+    MQS_ARG_CHECK(C >= 2 && C <= MQS_MAX_CAMS, "2 <= C <= MQS_MAX_CAMS");
+    MQS_ARG_CHECK(N == 0 || (u && P && x), "u, P, x must not be null");
+    const double *uc[MQS_MAX_CAMS], *Pc[MQS_MAX_CAMS];
+    split_packed(u, P, C, N, uc, Pc);
+    return run_host<kLinearLS>(ctx, uc, Pc, C, N, 0.0, 0, 0.0, x, nullptr, nullptr);
+}
+
+int mqs_triangulate_iterative_ls(mqs_ctx *ctx, const double *u, const double *P, int C, int64_t N, double tolerance,
+                                 int max_iter, double *x, int32_t *status)
+{
+    MQS_ARG_CHECK(C >= 2 && C <= MQS_MAX_CAMS, "2 <= C <= MQS_MAX_CAMS");
+    MQS_ARG_CHECK(N == 0 || (u && P && x && status), "u, P, x, status must not be null");
+    const double *uc[MQS_MAX_CAMS], *Pc[MQS_MAX_CAMS];
+    split_packed(u, P, C, N, uc, Pc);
+    return run_host<kIterativeLS>(ctx, uc, Pc, C, N, tolerance, max_iter, 0.0, x, status, nullptr);
+}
+
+int mqs_triangulate_linear_eigen(mqs_ctx *ctx, const double *u, const double *P, int C, int64_t N, double max_coord,
+                                 double *x, uint8_t *ok)
+{
+    MQS_ARG_CHECK(C >= 2 && C <= MQS_MAX_CAMS, "2 <= C <= MQS_MAX_CAMS");
+    MQS_ARG_CHECK(N == 0 || (u && P && x && ok), "u, P, x, ok must not be null");
+    const double *uc[MQS_MAX_CAMS], *Pc[MQS_MAX_CAMS];
+    split_packed(u, P, C, N, uc, Pc);
+    return run_host<kLinearEigen>(ctx, uc, Pc, C, N, 0.0, 0, max_coord, x, nullptr, ok);
+}
+
+int mqs_linear_LS_triangulation(mqs_ctx *ctx, const double *u1, const double *P1, const double *u2, const double *P2,
+                                int64_t N, double *x)
+{
+    MQS_ARG_CHECK(N == 0 || (u1 && P1 && u2 && P2 && x), "arguments must not be null");
+    const double *uc[2] = {u1, u2}, *Pc[2] = {P1, P2};
+    return run_host<kLinearLS>(ctx, uc, Pc, 2, N, 0.0, 0, 0.0, x, nullptr, nullptr);
+}
+
+int mqs_iterative_LS_triangulation(mqs_ctx *ctx, const double *u1, const double *P1, const double *u2, const double *P2,
+                                   int64_t N, double tolerance, double *x, int32_t *x_status)
+{
+    MQS_ARG_CHECK(N == 0 || (u1 && P1 && u2 && P2 && x && x_status), "arguments must not be null");
+    const double *uc[2] = {u1, u2}, *Pc[2] = {P1, P2};
+    return run_host<kIterativeLS>(ctx, uc, Pc, 2, N, tolerance, MQS_TRI_MAX_ITER_DEFAULT, 0.0, x, x_status, nullptr);
+}
+
+int mqs_time_triangulate_dev(int kernel, const double *u, const double *P, int C, int64_t N, double tolerance,
+                             int max_iter, double *x, int32_t *status, uint8_t *ok, int reps, void *stream_,
+                             float *avg_ms)
+{
+    MQS_ARG_CHECK(kernel >= 0 && kernel <= 2, "kernel in {0,1,2}");
+    MQS_ARG_CHECK(reps >= 1 && avg_ms, "reps >= 1, avg_ms not null");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    hipEvent_t e0, e1;
+    MQS_HIP_CHECK(hipEventCreate(&e0));
+    MQS_HIP_CHECK(hipEventCreate(&e1));
+    int rc = MQS_OK;
+    MQS_HIP_CHECK(hipEventRecord(e0, stream));
+    for (int r = 0; r < reps && rc == MQS_OK; ++r) {
+        if (kernel == 0) rc = mqs_triangulate_linear_ls_dev(u, P, C, N, x, stream);
+        else if (kernel == 1) rc = mqs_triangulate_iterative_ls_dev(u, P, C, N, tolerance, max_iter, x, status, stream);
+        else rc = mqs_triangulate_linear_eigen_dev(u, P, C, N, MQS_TRI_MAX_COORD_DEFAULT, x, ok, stream);
+    }
+    MQS_HIP_CHECK(hipEventRecord(e1, stream));
+    MQS_HIP_CHECK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    MQS_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *avg_ms = ms / reps;
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,89 @@
+"""
+Device-resident entry points: torch tensors in, torch tensors out, no host round trip.
+torch is used only for device memory and the current HIP stream; the arithmetic is the
+library's HIP kernels, reached through the `*_dev` C-ABI functions with raw pointers.
+"""
+import ctypes
+
+from . import _lib
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def _stream_ptr():
+    torch = _torch()
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _check_dev(t, dtype, name):
+    torch = _torch()
+    if not (isinstance(t, torch.Tensor) and t.is_cuda):
+        raise ValueError("%s must be a device tensor" % name)
+    if t.dtype != dtype:
+        raise TypeError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError("%s must be contiguous" % name)
+    return t
+
+
+def _tri_args(u, P):
+    torch = _torch()
+    _check_dev(u, torch.float64, "u")
+    _check_dev(P, torch.float64, "P")
+    if u.dim() != 3 or u.shape[2] != 2:
+        raise ValueError("u must have shape (C, N, 2)")
+    if tuple(P.shape) != (u.shape[0], 3, 4):
+        raise ValueError("P must have shape (C, 3, 4)")
+    return int(u.shape[0]), int(u.shape[1])
+
+
+def linear_LS_triangulation(u, P, out=None):
+    """u (C,N,2) f64, P (C,3,4) f64 device tensors -> x (N,3) f64 (status is all-True by definition)."""
+    torch = _torch()
+    C, N = _tri_args(u, P)
+    x = out if out is not None else torch.empty((N, 3), dtype=torch.float64, device=u.device)
+    _lib.check(_lib.lib().mqs_triangulate_linear_ls_dev(u.data_ptr(), P.data_ptr(), C, N, x.data_ptr(),
+                                                        _stream_ptr()))
+    return x
+
+
+def iterative_LS_triangulation(u, P, tolerance=3.e-5, max_iter=10, out=None, out_status=None):
+    """-> x (N,3) f64, status (N,) int32 (codes of triangulation.c:154-159, N-view generalised)."""
+    torch = _torch()
+    C, N = _tri_args(u, P)
+    x = out if out is not None else torch.empty((N, 3), dtype=torch.float64, device=u.device)
+    st = out_status if out_status is not None else torch.empty((N,), dtype=torch.int32, device=u.device)
+    _lib.check(_lib.lib().mqs_triangulate_iterative_ls_dev(u.data_ptr(), P.data_ptr(), C, N, float(tolerance),
+                                                           int(max_iter), x.data_ptr(), st.data_ptr(),
+                                                           _stream_ptr()))
+    return x, st
+
+
+def linear_eigen_triangulation(u, P, max_coordinate_value=1.e16, out=None, out_ok=None):
+    """-> x (N,3) f64, ok (N,) uint8."""
+    torch = _torch()
+    C, N = _tri_args(u, P)
+    x = out if out is not None else torch.empty((N, 3), dtype=torch.float64, device=u.device)
+    ok = out_ok if out_ok is not None else torch.empty((N,), dtype=torch.uint8, device=u.device)
+    _lib.check(_lib.lib().mqs_triangulate_linear_eigen_dev(u.data_ptr(), P.data_ptr(), C, N,
+                                                           float(max_coordinate_value), x.data_ptr(),
+                                                           ok.data_ptr(), _stream_ptr()))
+    return x, ok
+
+
+def time_triangulation(kind, u, P, reps=20, tolerance=3.e-5, max_iter=10):
+    """Average kernel duration in ms over `reps` back-to-back launches (hipEvents on the current stream)."""
+    torch = _torch()
+    C, N = _tri_args(u, P)
+    x = torch.empty((N, 3), dtype=torch.float64, device=u.device)
+    st = torch.empty((N,), dtype=torch.int32, device=u.device)
+    ok = torch.empty((N,), dtype=torch.uint8, device=u.device)
+    ms = ctypes.c_float(0)
+    k = {"linear_ls": 0, "iterative_ls": 1, "linear_eigen": 2}[kind]
+    _lib.check(_lib.lib().mqs_time_triangulate_dev(k, u.data_ptr(), P.data_ptr(), C, N, float(tolerance),
+                                                   int(max_iter), x.data_ptr(), st.data_ptr(), ok.data_ptr(),
+                                                   int(reps), _stream_ptr(), ctypes.byref(ms)))
+    return float(ms.value)

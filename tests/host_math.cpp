@@ -1,0 +1,30 @@
+// TEST-ONLY: compiles the per-landmark device arithmetic (csrc/tri_math.h) for the host so
+// that the CPU test suite can check it against the oracle without a GPU.  Never shipped,
+// never loaded by the product package.
+#include <stdint.h>
+#include "../multiple-quadrotor-slam_amd/csrc/tri_math.h"
+
+template <int C> static void run(int kind, const double *u, const double *P, int64_t N, double tol,
+                                 int max_iter, double max_coord, double *x, int32_t *status, uint8_t *ok)
+{
+    for (int64_t i = 0; i < N; ++i) {
+        double uv[C][2];
+        for (int c = 0; c < C; ++c) { uv[c][0] = u[(c * N + i) * 2]; uv[c][1] = u[(c * N + i) * 2 + 1]; }
+        mqs::Vec3 r;
+        if (kind == 0) r = mqs::linear_ls_point<C>(uv, P);
+        else if (kind == 1) { int32_t s; r = mqs::iterative_ls_point<C>(uv, P, tol, max_iter, s); status[i] = s; }
+        else { bool o; r = mqs::linear_eigen_point<C>(uv, P, max_coord, o); ok[i] = o; }
+        x[3 * i] = r.x; x[3 * i + 1] = r.y; x[3 * i + 2] = r.z;
+    }
+}
+
+extern "C" int host_tri(int kind, const double *u, const double *P, int C, int64_t N, double tol, int max_iter,
+                        double max_coord, double *x, int32_t *status, uint8_t *ok)
+{
+    switch (C) {
+#define CASE(c) case c: run<c>(kind, u, P, N, tol, max_iter, max_coord, x, status, ok); return 0;
+    CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
+#undef CASE
+    }
+    return -1;
+}

@@ -1,0 +1,60 @@
+"""
+The C-ABI library loads on a machine without a GPU and exports every symbol that
+include/mqslam.h declares; the ctypes table in _lib.py covers the same set; compute calls
+fail loudly (RuntimeError) instead of falling back when no device is present.
+"""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "mqslam.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mqs_[A-Za-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_symbols():
+    syms = header_symbols()
+    assert "mqs_triangulate_iterative_ls" in syms and "mqs_linear_LS_triangulation" in syms
+    assert len(syms) >= 20
+
+
+def test_library_exports_every_declared_symbol(mqs):
+    assert mqs.loaded, "libmqslam_hip.so failed to load: %r" % (mqs._lib.load_error,)
+    out = subprocess.check_output(["nm", "-D", "--defined-only", mqs._lib.LIB_PATH]).decode()
+    exported = set(re.findall(r"\bT (mqs_[A-Za-z0-9_]+)", out))
+    missing = [s for s in header_symbols() if s not in exported]
+    assert not missing, "declared in mqslam.h but not exported: %s" % missing
+
+
+def test_ctypes_table_matches_header(mqs):
+    assert sorted(mqs._lib.SIGNATURES) == header_symbols()
+
+
+def test_version_and_error_strings(mqs):
+    lib = mqs._lib.lib()
+    assert b"gfx950" in lib.mqs_version()
+    assert isinstance(lib.mqs_last_error(), bytes)
+
+
+def test_no_cpu_fallback_without_device(mqs):
+    if mqs._lib.lib().mqs_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(RuntimeError):
+        mqs.triangulation.linear_LS_triangulation(np.zeros((3, 2)), np.eye(4), np.zeros((3, 2)), np.eye(4))
+
+
+def test_product_package_never_imports_oracle():
+    pkg = os.path.join(ROOT, "multiple-quadrotor-slam_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
+                assert "liboracle" not in text, f

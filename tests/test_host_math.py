@@ -1,0 +1,73 @@
+"""
+CPU check of the arithmetic the gfx950 kernels execute: csrc/tri_math.h compiled for the host
+(tests/host_math.cpp) against the oracle and against the reference's golden cells.  This is
+NOT a product path (nothing in the package can reach it); it lets the no-GPU suite catch
+arithmetic regressions before GPU time is spent.
+"""
+import ctypes
+import numpy as np
+import pytest
+
+from oracle import harness_np as H
+from util import random_scene, rel_err, stable_mask
+
+F64 = ctypes.POINTER(ctypes.c_double)
+
+
+def host_tri(lib, kind, u, P, tol=3e-5, max_iter=10, max_coord=1e16):
+    u = np.ascontiguousarray(u, dtype=np.float64)
+    P = np.ascontiguousarray(np.asarray(P)[:, :3], dtype=np.float64)
+    C, N, _ = u.shape
+    x = np.empty((N, 3))
+    st = np.zeros(N, np.int32)
+    ok = np.zeros(N, np.uint8)
+    rc = lib.host_tri(kind, u.ctypes.data_as(F64), P.ctypes.data_as(F64), C, ctypes.c_int64(N),
+                      ctypes.c_double(tol), max_iter, ctypes.c_double(max_coord), x.ctypes.data_as(F64),
+                      st.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+                      ok.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)))
+    assert rc == 0
+    return x, st, ok.astype(bool)
+
+
+@pytest.mark.parametrize("cell", [(0, 0, 8), (2, 1, 20), (3, 0, 8), (4, 0, 8), (4, 1, 39)])
+def test_device_math_reproduces_golden_cells(cell, golden3, host_math):
+    methods = [lambda u, P: host_tri(host_math, 2, u, P)[0::2],
+               lambda u, P: (host_tri(host_math, 0, u, P)[0], np.ones(u.shape[1], bool)),
+               lambda u, P: host_tri(host_math, 1, u, P)[0:2]]
+    tr, nt, si = cell
+    res = H.test_3_cell(tr, nt, golden3["noise_sigma_values"][si], methods, int(golden3["num_trials"]))
+    n = 257 * int(golden3["num_trials"])
+    for m in range(3):
+        assert res[m][0] == pytest.approx(golden3["err3D_mean_summary"][tr, nt, si, m], rel=1e-8)
+        assert res[m][1] == pytest.approx(golden3["err3D_median_summary"][tr, nt, si, m], rel=1e-8)
+        assert abs(res[m][2] - golden3["false_pos_summary"][tr, nt, si, m]) <= 3 / n
+        assert abs(res[m][3] - golden3["false_neg_summary"][tr, nt, si, m]) <= 3 / n
+
+
+@pytest.mark.parametrize("C", [2, 3, 4, 5, 8])
+def test_device_math_vs_oracle_nview(C, host_math, c_oracle):
+    u, P, _ = random_scene(3000, C, seed=100 + C, behind_frac=0.1)
+    for kind, fn in ((0, c_oracle.linear_LS_triangulation), (1, c_oracle.iterative_LS_triangulation),
+                     (2, c_oracle.linear_eigen_triangulation)):
+        xo, so = fn(u, P)
+        xh, sh, okh = host_tri(host_math, kind, u, P)
+        good = stable_mask(fn, u, P, xo, so if kind else None)
+        assert good.mean() > 0.99
+        assert np.max(rel_err(xh[good], xo[good])) < 1e-5          # the parity bar (north_star)
+        assert np.median(rel_err(xh[good], xo[good])) < 1e-11      # what fp64 actually delivers
+        if kind == 1:
+            np.testing.assert_array_equal(sh[good], so[good])
+        if kind == 2:
+            np.testing.assert_array_equal(okh[good], so[good])
+
+
+def test_rank_deficient_minimum_norm(host_math, c_oracle):
+    """Points on the common optical axis of two forward-displaced cameras: A has rank 2; both the
+    oracle (SVD cut) and the device arithmetic (eigen pseudo-inverse) return the minimum-norm x."""
+    P = np.stack([np.concatenate([np.eye(3), [[0], [0], [40.0]]], axis=1),
+                  np.concatenate([np.eye(3), [[0], [0], [28.0]]], axis=1)])
+    u = np.zeros((2, 5, 2))
+    xo, _ = c_oracle.linear_LS_triangulation(u, P)
+    xh, _, _ = host_tri(host_math, 0, u, P)
+    np.testing.assert_allclose(xh, xo, atol=1e-9)
+    assert np.all(np.isfinite(xh))
