@@ -12,7 +12,7 @@ import subprocess
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
-LIB_PATH = os.path.join(_PKG, "libmqslam_hip.so")
+LIB_PATH = os.environ.get("MQS_LIB_PATH", os.path.join(_PKG, "libmqslam_hip.so"))   # override: kernel A/B builds
 
 loaded = False
 load_error = None

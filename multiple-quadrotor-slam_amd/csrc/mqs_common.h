@@ -37,12 +37,13 @@ int mqs_ctx_reserve(mqs_ctx *ctx, size_t bytes);
 
 static inline bool mqs_aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-// Grid for streaming one-thread-per-item kernels: enough blocks to cover `n` items, capped so
-// that the remainder is grid-strided (256 CUs x 8 blocks of 256 threads).
+// Grid for streaming one-thread-per-item kernels: one workgroup per `block` items (the hardware
+// dispatcher load-balances them over the 256 CUs; a capped grid with a grid-stride loop left a
+// 2.67-round tail at 1e6 items); beyond 2^20 workgroups the kernels grid-stride.
 static inline unsigned mqs_stream_grid(int64_t n, int block)
 {
     int64_t g = (n + block - 1) / block;
     if (g < 1) g = 1;
-    if (g > 2048) g = 2048;
+    if (g > 1048576) g = 1048576;
     return (unsigned)g;
 }

@@ -20,6 +20,33 @@
 
 namespace mqs {
 
+// 1/d.  Device: v_rcp_f64 seed + two Newton steps (full double precision for normal inputs,
+// no v_div_scale/v_div_fmas/v_div_fixup sequence); 0, inf and NaN behave like IEEE division
+// for the uses below (a zero pivot fails the pivot test before its reciprocal is used).
+MQS_HD double rcp(double d)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(fma(-d, r, 1.0), r, r);
+    r = fma(fma(-d, r, 1.0), r, r);
+    return r;
+#else
+    return 1.0 / d;
+#endif
+}
+
+// Returns 0 in a way the optimiser cannot see through: added to an LDS index inside a loop it
+// keeps the loop-invariant camera-matrix reads IN the loop (re-read from LDS, ~free) instead of
+// being hoisted into dozens of live VGPRs.
+MQS_HD int opaque_zero()
+{
+    int z = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(z));
+#endif
+    return z;
+}
+
 constexpr double kEps = 2.220446049250313e-16;
 // A pivot of the 3x3 LDL^T below kPivotRel * trace(G) switches to the eigen pseudo-inverse.
 constexpr double kPivotRel = 1e-13;
@@ -96,15 +123,15 @@ MQS_HD Ldlt3 ldlt3(const Sym3 &G)
     Ldlt3 f;
     const double thr = kPivotRel * (G.xx + G.yy + G.zz);
     const double d0 = G.xx;
-    f.i0 = 1.0 / d0;
+    f.i0 = rcp(d0);
     f.l10 = G.xy * f.i0;
     f.l20 = G.xz * f.i0;
     const double d1 = fma(-f.l10, G.xy, G.yy);
-    f.i1 = 1.0 / d1;
+    f.i1 = rcp(d1);
     const double t21 = fma(-f.l20, G.xy, G.yz);
     f.l21 = t21 * f.i1;
     const double d2 = fma(-f.l21, t21, fma(-f.l20, G.xz, G.zz));
-    f.i2 = 1.0 / d2;
+    f.i2 = rcp(d2);
     f.ok = (d0 > thr) && (d1 > thr) && (d2 > thr);      // false for NaN as well
     return f;
 }
@@ -175,6 +202,71 @@ MQS_HD void smallest_eigvec4(const double n[10], double X[4])
     if (a33 <= lam) { lam = a33; X[0] = v03; X[1] = v13; X[2] = v23; X[3] = v33; }
 }
 
+// Fast path for the same eigenvector: LDL^T of N followed by inverse iteration
+// (v <- N^-1 v).  N is positive semi-definite and, for a triangulation problem, nearly singular
+// along the sought direction, which is exactly when inverse iteration converges in one or two
+// steps (rate lambda_4/lambda_3).  Returns false when the iterates have not settled to 1e-11
+// within kInvIterMax steps (clustered smallest eigenvalues: degenerate geometry) or a leading
+// pivot is not positive; the caller then falls back to the Jacobi iteration above.
+constexpr int kInvIterMax = 16;
+
+MQS_HD bool smallest_eigvec4_invit(const double n[10], double X[4])
+{
+    // unit lower-triangular L (l10 l20 l30 l21 l31 l32) and pivots d0..d3
+    const double d0 = n[0];
+    const double i0 = rcp(d0);
+    const double l10 = n[1] * i0, l20 = n[2] * i0, l30 = n[3] * i0;
+    const double d1 = fma(-l10, n[1], n[4]);
+    const double i1 = rcp(d1);
+    const double t21 = fma(-l20, n[1], n[5]);
+    const double t31 = fma(-l30, n[1], n[6]);
+    const double l21 = t21 * i1, l31 = t31 * i1;
+    const double d2 = fma(-l21, t21, fma(-l20, n[2], n[7]));
+    const double i2 = rcp(d2);
+    const double t32 = fma(-l31, t21, fma(-l30, n[2], n[8]));
+    const double l32 = t32 * i2;
+    double d3 = fma(-l32, t32, fma(-l31, t31, fma(-l30, n[3], n[9])));
+    const double tr = n[0] + n[4] + n[7] + n[9];
+    if (!((d0 > 0.0) && (d1 > 0.0) && (d2 > 0.0))) return false;
+    const double tiny = 1e-30 * tr;
+    if (!(fabs(d3) > tiny)) d3 = tiny;                   // exact data: lambda_4 == 0 to rounding
+    const double i3 = rcp(d3);
+    // first iterate: N^-1 e_3 = L^-T D^-1 L^-1 e_3 = L^-T (e_3 / d3)  -> direction L^-T e_3
+    double v3 = 1.0;
+    double v2 = -l32;
+    double v1 = -fma(l21, v2, l31);
+    double v0 = -fma(l10, v1, fma(l20, v2, l30));
+    bool done = false;
+    for (int it = 0; it < kInvIterMax; ++it) {
+        // normalise by an exact power of two (direction only matters), remember the iterate
+        const double m = fmax(fmax(fabs(v0), fabs(v1)), fmax(fabs(v2), fabs(v3)));
+        const double sc = ldexp(1.0, -ilogb(m));
+        v0 *= sc; v1 *= sc; v2 *= sc; v3 *= sc;
+        const double p0 = v0, p1 = v1, p2 = v2, p3 = v3;
+        // solve L y = v, z = D^-1 y, L^T w = z
+        const double y0 = v0;
+        const double y1 = fma(-l10, y0, v1);
+        const double y2 = fma(-l21, y1, fma(-l20, y0, v2));
+        const double y3 = fma(-l32, y2, fma(-l31, y1, fma(-l30, y0, v3)));
+        v3 = y3 * i3;
+        v2 = fma(-l32, v3, y2 * i2);
+        v1 = fma(-l31, v3, fma(-l21, v2, y1 * i1));
+        v0 = fma(-l30, v3, fma(-l20, v2, fma(-l10, v1, y0 * i0)));
+        // change of direction between the (scaled) previous iterate p and the new one v:
+        // |v - (v.p / p.p) p|_inf relative to |v|_inf
+        const double pp = fma(p0, p0, fma(p1, p1, fma(p2, p2, p3 * p3)));
+        const double vp = fma(v0, p0, fma(v1, p1, fma(v2, p2, v3 * p3)));
+        const double a = vp * rcp(pp);
+        const double e0 = fabs(fma(-a, p0, v0)), e1 = fabs(fma(-a, p1, v1));
+        const double e2 = fabs(fma(-a, p2, v2)), e3 = fabs(fma(-a, p3, v3));
+        const double err = fmax(fmax(e0, e1), fmax(e2, e3));
+        const double mag = fmax(fmax(fabs(v0), fabs(v1)), fmax(fabs(v2), fabs(v3)));
+        if (err <= 1e-11 * mag) { done = true; break; }
+    }
+    X[0] = v0; X[1] = v1; X[2] = v2; X[3] = v3;
+    return done;
+}
+
 // Adds the three rows of cv2.triangulatePoints for one camera to the 4x4 Gram matrix:
 // x*P[2]-P[0], y*P[2]-P[1], x*P[1]-y*P[0].  p0,p1,p2: rows of P (4 each).
 MQS_HD void accum_eigen_rows(double n[10], double x, double y, const double *p0, const double *p1,
@@ -208,9 +300,10 @@ MQS_HD Vec3 refine(const Vec3 &x0, const double (*uv)[2], const double *P, const
 {
     if (!f.ok) return x0;
     Vec3 r = {0, 0, 0};
+    const double *Pl = P + opaque_zero();
 #pragma unroll
     for (int c = 0; c < C; ++c) {
-        const double *p0 = P + 12 * c, *p1 = p0 + 4, *p2 = p0 + 8;
+        const double *p0 = Pl + 12 * c, *p1 = p0 + 4, *p2 = p0 + 8;
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const double *pk = k ? p1 : p0;
@@ -247,10 +340,21 @@ MQS_HD Vec3 linear_ls_point(const double (*uv)[2], const double *P)
     return refine<C>(x, uv, P, w2, G, f);
 }
 
-// T2.  Returns x and the status code of triangulation.c:154-159 generalised to C cameras.
+// T2 state handed from the iteration to the final refinement step.
 template <int C>
-MQS_HD Vec3 iterative_ls_point(const double (*uv)[2], const double *P, double tol, int max_iter,
-                               int32_t &status)
+struct IterResult {
+    Vec3 x;
+    double w2[C];      // squared cumulative row weights of the LAST solve
+    Ldlt3 f;           // its factorisation
+    int32_t status;    // triangulation.c:154-159 generalised to C cameras
+    bool solved;       // at least one solve happened (max_iter > 0)
+};
+
+// T2 iteration.  Does not keep `uv` alive past the Gram set-up, so that a kernel can re-read
+// the observations for refine<C>() instead of holding them in registers through the loop.
+template <int C>
+MQS_HD void iterative_ls_core(const double (*uv)[2], const double *P, double tol, int max_iter,
+                              IterResult<C> &out)
 {
     // Per-camera Gram pieces: the re-weighting of triangulation.c:143-146 multiplies camera
     // c's two rows (and b entries) by 1/d_c, i.e. its Gram contribution by 1/d_c^2, so the
@@ -269,20 +373,30 @@ MQS_HD Vec3 iterative_ls_point(const double (*uv)[2], const double *P, double to
     }
     Vec3 x = {0, 0, 0};
     Sym3 G;
-    Ldlt3 f;
+    Ldlt3 f = {0, 0, 0, 0, 0, 0, false};
     int i = 0;
     for (; i < max_iter; ++i) {
         if (i > 0) {
-            double dmax = 0.0;
+            // triangulation.c:143-150: camera c's rows are scaled by 1/d_c.  Only the RATIOS of
+            // the weights matter to the solution, so 1/d_c is replaced by prod_{j != c} d_j
+            // (= 1/d_c times the common factor prod_j d_j): no reciprocals.
+            double pre[C], suf[C];
+            pre[0] = 1.0;
 #pragma unroll
-            for (int c = 0; c < C; ++c) dmax = fmax(dmax, fabs(dn[c]));
+            for (int c = 1; c < C; ++c) pre[c] = pre[c - 1] * dn[c - 1];
+            suf[C - 1] = 1.0;
 #pragma unroll
-            for (int c = 0; c < C; ++c) {                  // :143-150 (the common factor dmax is
-                const double s = dmax / dn[c];             //  solution-neutral; keeps w2 in range)
-                w2[c] *= s * s;
+            for (int c = C - 2; c >= 0; --c) suf[c] = suf[c + 1] * dn[c + 1];
+            // common factor removed again by an exact power of two (camera 0's scale -> [1,2))
+            const double kappa = ldexp(1.0, -ilogb(suf[0]));
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const double sc = (pre[c] * suf[c]) * kappa;
+                w2[c] *= sc * sc;
                 d[c] = dn[c];
             }
         }
+        const double *Pl = P + opaque_zero();
         G = Sym3{0, 0, 0, 0, 0, 0};
         Vec3 h = {0, 0, 0};
 #pragma unroll
@@ -296,7 +410,7 @@ MQS_HD Vec3 iterative_ls_point(const double (*uv)[2], const double *P, double to
         bool conv = true, zero = false;
 #pragma unroll
         for (int c = 0; c < C; ++c) {                      // :133-134
-            const double *p2 = P + 12 * c + 8;
+            const double *p2 = Pl + 12 * c + 8;
             dn[c] = fma(p2[0], x.x, fma(p2[1], x.y, fma(p2[2], x.z, p2[3])));
             conv = conv && (fabs(dn[c] - d[c]) <= tol);
             zero = zero || (dn[c] == 0.0);
@@ -310,9 +424,25 @@ MQS_HD Vec3 iterative_ls_point(const double (*uv)[2], const double *P, double to
 #pragma unroll
     for (int c = 0; c < C; ++c)
         if (dn[c] <= 0.0) s -= (1 << c);                   // :156-159
-    status = s;
-    if (max_iter <= 0) return x;
-    return refine<C>(x, uv, P, w2, G, f);
+    out.status = s;
+    out.x = x;
+    out.f = f;
+    out.solved = max_iter > 0;
+#pragma unroll
+    for (int c = 0; c < C; ++c) out.w2[c] = w2[c];
+}
+
+// T2.  Returns x and the status code of triangulation.c:154-159 generalised to C cameras.
+template <int C>
+MQS_HD Vec3 iterative_ls_point(const double (*uv)[2], const double *P, double tol, int max_iter,
+                               int32_t &status)
+{
+    IterResult<C> r;
+    iterative_ls_core<C>(uv, P, tol, max_iter, r);
+    status = r.status;
+    if (!r.solved) return r.x;
+    const Sym3 unused = {0, 0, 0, 0, 0, 0};
+    return refine<C>(r.x, uv, P, r.w2, unused, r.f);
 }
 
 template <int C>
@@ -325,7 +455,7 @@ MQS_HD Vec3 linear_eigen_point(const double (*uv)[2], const double *P, double ma
         accum_eigen_rows(n, uv[c][0], uv[c][1], p0, p0 + 4, p0 + 8);
     }
     double X[4];
-    smallest_eigvec4(n, X);
+    if (!smallest_eigvec4_invit(n, X)) smallest_eigvec4(n, X);
     Vec3 x = {X[0] / X[3], X[1] / X[3], X[2] / X[3]};      // triangulation.py:22
     ok = (fabs(x.x) <= max_coord) && (fabs(x.y) <= max_coord) && (fabs(x.z) <= max_coord);   // :23
     return x;

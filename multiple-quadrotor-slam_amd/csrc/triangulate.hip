@@ -27,8 +27,16 @@ constexpr int kBlock = 256;
 
 enum TriKind { kLinearLS = 0, kIterativeLS = 1, kLinearEigen = 2 };
 
+// Minimum waves per SIMD requested from the register allocator per kernel kind (tuned on
+// MI355X, see DESIGN.md "Triangulation kernels"): the iterative kernel is fp64-VALU bound and
+// needs several resident waves per SIMD to cover dependent-FMA and v_rcp_f64 latency.
+#ifndef MQS_ITER_WAVES
+#define MQS_ITER_WAVES 3
+#endif
+constexpr int waves_for(int kind) { return kind == 1 ? MQS_ITER_WAVES : 2; }
+
 template <int C, int KIND>
-__global__ __launch_bounds__(kBlock) void tri_kernel(const double *__restrict__ u, const double *__restrict__ P,
+__global__ __launch_bounds__(kBlock, waves_for(KIND)) void tri_kernel(const double *__restrict__ u, const double *__restrict__ P,
                                                      int64_t N, double tol, int max_iter, double max_coord,
                                                      double *__restrict__ x, int32_t *__restrict__ status,
                                                      uint8_t *__restrict__ ok)
@@ -60,9 +68,25 @@ __global__ __launch_bounds__(kBlock) void tri_kernel(const double *__restrict__ 
         if (KIND == kLinearLS) {
             r = mqs::linear_ls_point<C>(uv, sP);
         } else if (KIND == kIterativeLS) {
-            int32_t s;
-            r = mqs::iterative_ls_point<C>(uv, sP, tol, max_iter, s);
-            if (live) status[i] = s;
+            mqs::IterResult<C> it;
+            mqs::iterative_ls_core<C>(uv, sP, tol, max_iter, it);
+            if (live) status[i] = it.status;
+            r = it.x;
+            if (it.solved) {
+                // re-read the observations (L2 / Infinity-Cache hits) for the refinement step
+                // rather than keeping 2C doubles live through the iteration
+                const int64_t j = i + mqs::opaque_zero();
+                double uv2[C][2];
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    double2 v = make_double2(0.0, 0.0);
+                    if (live) v = u2[(int64_t)c * N + j];
+                    uv2[c][0] = v.x;
+                    uv2[c][1] = v.y;
+                }
+                const mqs::Sym3 unused = {0, 0, 0, 0, 0, 0};
+                r = mqs::refine<C>(it.x, uv2, sP, it.w2, unused, it.f);
+            }
         } else {
             bool o;
             r = mqs::linear_eigen_point<C>(uv, sP, max_coord, o);

@@ -28,3 +28,26 @@ extern "C" int host_tri(int kind, const double *u, const double *P, int C, int64
     }
     return -1;
 }
+
+// fraction of landmarks for which the inverse-iteration fast path of T3 does not converge
+// (diagnostic for tests: the kernel then takes the Jacobi fallback)
+template <int C> static int64_t count_fallback(const double *u, const double *P, int64_t N)
+{
+    int64_t nf = 0;
+    for (int64_t i = 0; i < N; ++i) {
+        double n[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, X[4];
+        for (int c = 0; c < C; ++c)
+            mqs::accum_eigen_rows(n, u[(c * N + i) * 2], u[(c * N + i) * 2 + 1], P + 12 * c, P + 12 * c + 4, P + 12 * c + 8);
+        if (!mqs::smallest_eigvec4_invit(n, X)) ++nf;
+    }
+    return nf;
+}
+
+extern "C" int64_t host_eigen_fallbacks(const double *u, const double *P, int C, int64_t N)
+{
+    switch (C) {
+    case 2: return count_fallback<2>(u, P, N);
+    case 4: return count_fallback<4>(u, P, N);
+    }
+    return -1;
+}
