@@ -81,8 +81,12 @@ def main():
     D = mqslam_amd.device
 
     ba = None
-    if not args.no_ba and hasattr(mqslam_amd, "bundle_adjustment"):
-        ba = mqslam_amd.bundle_adjustment.make_benchmark_problem(u, P, pts, dev, seed=syn.RSEED + rank)
+    if not args.no_ba:
+        # initial landmarks = iterative-LS output; poses are replicated, so their
+        # perturbation uses the same seed on every rank
+        D.iterative_LS_triangulation(ud, Pd, out=x_it, out_status=st)
+        ba = mqslam_amd.bundle_adjustment.make_benchmark_problem(
+            u, P, x_it, dev, seed=syn.RSEED, process_group=True if world > 1 else None)
 
     def step():
         D.linear_LS_triangulation(ud, Pd, out=x_ls)

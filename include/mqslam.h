@@ -125,46 +125,67 @@ int mqs_match_knn2_f16_dev(const uint16_t *query, int64_t Nq, const uint16_t *tr
 int64_t mqs_match_knn2_f16_workspace_bytes(int64_t Nq, int64_t Nt);
 
 /* ---------------------------------------------------------------------------------------
- * Bundle adjustment: projection-factor linearisation + landmark Schur complement, and the
- * landmark back-substitution (replaces the GTSAM work behind bundle_adjust.cpp:289-298,323).
+ * Bundle adjustment: projection-factor linearisation + landmark Schur complement, the reduced
+ * camera solve, and the landmark back-substitution (replaces the GTSAM work behind
+ * bundle_adjust.cpp:268-298,323-324).
  *
  *   poses  [C][12]  camera-to-world pose: R (row-major 3x3) then t (3)   (IO.hpp:221-227)
  *   calib  [C][9]   fx fy s u0 v0 k1 k2 p1 p2  (Cal3DS2 order, IO.hpp:230-236)
  *   sigma  [C]      isotropic pixel sigma of camera c's projection factors
  *   points [N][3]   landmarks (world)
- *   obs    [C][N][2] pixel measurements;  mask [C][N] uint8 (NULL = all visible)
+ *   obs    [C][N][2] pixel measurements;  mask [C][N] uint8 (NULL = every landmark seen by
+ *                   every camera)
+ *   prior_w [N]     PriorFactor<Point3> weight 1/sigma^2 per landmark, 0 = none (NULL = none);
+ *   prior_xyz [N][3] prior positions (read only where prior_w > 0)     (bundle_adjust.cpp:277-281)
  *
- * Pose tangent order [omega(3), v(3)], right perturbation T*Exp(xi) (GTSAM Pose3).
- * Outputs of linearize: out[(6C)*(6C) + 6C + 2] = { S row-major (reduced camera matrix,
- * JtJ form), g (= reduced -J^T r, i.e. S * dpose = g), cost = 0.5*sum|r/sigma|^2,
- * number of valid (in front of camera, unmasked) factors }.  `out` is OVERWRITTEN.
- * lambda: Levenberg-Marquardt damping added as lambda*diag(Hll) on landmark blocks before
- * elimination (0 = Gauss-Newton).
+ * Pose tangent order [omega(3), v(3)], right perturbation T*Exp(xi) (GTSAM Pose3).  A factor whose
+ * landmark is not in front of its camera contributes the constant residual 2*fx/sigma*(1,1) and
+ * zero Jacobians (GenericProjectionFactor, throwCheirality = false).
+ * linearize writes out[(6C)*(6C) + 6C + 2] = { S row-major (reduced camera matrix, J^T J form),
+ * g (S * dpose = g), cost = 0.5*sum|r/sigma|^2 (+ point priors), number of valid factors }.
+ * `out` is overwritten.  lambda: Levenberg-Marquardt damping lambda*diag(Hll) on the landmark
+ * blocks before elimination (0 = Gauss-Newton).  The result is bitwise reproducible.
+ * All pointers are DEVICE pointers, 16-byte aligned; asynchronous on `stream`.
  * ------------------------------------------------------------------------------------- */
 int mqs_ba_linearize_dev(const double *poses, const double *calib, const double *sigma, int C,
-                         const double *points, const double *obs, const uint8_t *mask, int64_t N,
-                         double lambda, double *out, void *workspace, int64_t workspace_bytes,
-                         void *stream);
+                         const double *points, const double *obs, const uint8_t *mask,
+                         const double *prior_w, const double *prior_xyz, int64_t N, double lambda,
+                         double *out, void *workspace, int64_t workspace_bytes, void *stream);
 int64_t mqs_ba_workspace_bytes(int C, int64_t N);
 
-/* points_out = points + dpoint, dpoint = Hll^-1 (gl - Hpl^T dpose) at the SAME linearisation
- * point as the preceding linearize call (recomputed, not stored).  dpose [6C] device ptr. */
-int mqs_ba_backsub_dev(const double *poses, const double *calib, const double *sigma, int C,
-                       const double *points, const double *obs, const uint8_t *mask, int64_t N,
-                       double lambda, const double *dpose, double *points_out, void *stream);
+/* Reduced camera system: adds PriorFactor<Pose3> terms (prior_mask [C] uint8 or NULL,
+ * prior_poses [C][12], prior_sigmas [C][6] = rot x3, trans x3; e ~ (Log(R0^T R), R0^T (t - t0)),
+ * Jacobian ~ I) and lambda*diag(S) damping to lin = linearize's `out`, solves S dpose = g by
+ * Cholesky, writes dpose [6C], the retracted poses R <- R Exp(omega), t <- t + R v into
+ * poses_out [C][12] (NULL = skip) and info[2] = { pose-prior cost, 1.0 if S was not positive
+ * definite } (NULL = skip). */
+int mqs_ba_solve_dev(const double *lin, int C, const double *poses, const double *prior_poses,
+                     const double *prior_sigmas, const uint8_t *prior_mask, double lambda,
+                     double *dpose, double *poses_out, double *info, void *stream);
 
-/* cost only (0.5*sum|r/sigma|^2 and valid count) at the given state: out[2]. */
+/* points_out = points + dpoint, dpoint = Hll^-1 (gl - Hpl^T dpose) at the SAME linearisation
+ * point as the preceding linearize call (recomputed, not stored).  dpose [6C] device ptr.
+ * points_out may alias points. */
+int mqs_ba_backsub_dev(const double *poses, const double *calib, const double *sigma, int C,
+                       const double *points, const double *obs, const uint8_t *mask,
+                       const double *prior_w, const double *prior_xyz, int64_t N, double lambda,
+                       const double *dpose, double *points_out, void *stream);
+
+/* cost only: out[2] = { 0.5*sum|r/sigma|^2 (+ point priors), valid-factor count }. */
 int mqs_ba_cost_dev(const double *poses, const double *calib, const double *sigma, int C,
-                    const double *points, const double *obs, const uint8_t *mask, int64_t N,
-                    double *out, void *workspace, int64_t workspace_bytes, void *stream);
+                    const double *points, const double *obs, const uint8_t *mask,
+                    const double *prior_w, const double *prior_xyz, int64_t N, double *out,
+                    void *workspace, int64_t workspace_bytes, void *stream);
 
 /* Host-pointer convenience wrappers (copy in, run, copy out; synchronous). */
 int mqs_ba_linearize(mqs_ctx *ctx, const double *poses, const double *calib, const double *sigma, int C,
-                     const double *points, const double *obs, const uint8_t *mask, int64_t N,
-                     double lambda, double *out);
+                     const double *points, const double *obs, const uint8_t *mask,
+                     const double *prior_w, const double *prior_xyz, int64_t N, double lambda,
+                     double *out);
 int mqs_ba_backsub(mqs_ctx *ctx, const double *poses, const double *calib, const double *sigma, int C,
-                   const double *points, const double *obs, const uint8_t *mask, int64_t N,
-                   double lambda, const double *dpose, double *points_out);
+                   const double *points, const double *obs, const uint8_t *mask,
+                   const double *prior_w, const double *prior_xyz, int64_t N, double lambda,
+                   const double *dpose, double *points_out);
 
 /* ---------------------------------------------------------------------------------------
  * Timing helper used by bench.py: average duration (ms) of `reps` back-to-back launches of

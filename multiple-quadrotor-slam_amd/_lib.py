@@ -55,17 +55,19 @@ SIGNATURES = {
     "mqs_match_knn2_f16": (ctypes.c_int, [c_vp, c_u16p, c_i64, c_u16p, c_i64, ctypes.c_int, c_i32p, c_f32p]),
     "mqs_match_knn2_f16_dev": (ctypes.c_int, [c_vp, c_i64, c_vp, c_i64, ctypes.c_int, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "mqs_match_knn2_f16_workspace_bytes": (c_i64, [c_i64, c_i64]),
-    "mqs_ba_linearize_dev": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, c_vp, c_vp, c_vp, c_i64,
+    "mqs_ba_linearize_dev": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64,
                                             ctypes.c_double, c_vp, c_vp, c_i64, c_vp]),
     "mqs_ba_workspace_bytes": (c_i64, [ctypes.c_int, c_i64]),
-    "mqs_ba_backsub_dev": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, c_vp, c_vp, c_vp, c_i64,
+    "mqs_ba_solve_dev": (ctypes.c_int, [c_vp, ctypes.c_int, c_vp, c_vp, c_vp, c_vp, ctypes.c_double, c_vp, c_vp,
+                                        c_vp, c_vp]),
+    "mqs_ba_backsub_dev": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64,
                                           ctypes.c_double, c_vp, c_vp, c_vp]),
-    "mqs_ba_cost_dev": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp,
-                                       c_i64, c_vp]),
-    "mqs_ba_linearize": (ctypes.c_int, [c_vp, c_f64p, c_f64p, c_f64p, ctypes.c_int, c_f64p, c_f64p, c_u8p, c_i64,
-                                        ctypes.c_double, c_f64p]),
-    "mqs_ba_backsub": (ctypes.c_int, [c_vp, c_f64p, c_f64p, c_f64p, ctypes.c_int, c_f64p, c_f64p, c_u8p, c_i64,
-                                      ctypes.c_double, c_f64p, c_f64p]),
+    "mqs_ba_cost_dev": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp,
+                                       c_vp, c_i64, c_vp]),
+    "mqs_ba_linearize": (ctypes.c_int, [c_vp, c_f64p, c_f64p, c_f64p, ctypes.c_int, c_f64p, c_f64p, c_u8p, c_f64p,
+                                        c_f64p, c_i64, ctypes.c_double, c_f64p]),
+    "mqs_ba_backsub": (ctypes.c_int, [c_vp, c_f64p, c_f64p, c_f64p, ctypes.c_int, c_f64p, c_f64p, c_u8p, c_f64p,
+                                      c_f64p, c_i64, ctypes.c_double, c_f64p, c_f64p]),
     "mqs_time_triangulate_dev": (ctypes.c_int, [ctypes.c_int, c_vp, c_vp, ctypes.c_int, c_i64, ctypes.c_double,
                                                 ctypes.c_int, c_vp, c_vp, c_vp, ctypes.c_int, c_vp,
                                                 ctypes.POINTER(ctypes.c_float)]),

@@ -1,0 +1,662 @@
+// Bundle-adjustment kernels for gfx950 (MI355X): projection-factor linearisation with on-chip
+// landmark elimination (Schur complement), landmark back-substitution, cost evaluation, and the
+// small reduced-camera-system solve + pose retraction.
+//
+// Replaces the GTSAM work behind Work/SLAM/tools/bundle_adjustment/bundle_adjust.cpp:289-298
+// (GenericProjectionFactor graph) and :323-324 (LevenbergMarquardtOptimizer::optimize):
+// linearise all factors, build and solve the normal equations.  Arithmetic: ba_math.h.
+//
+// Mapping to the machine
+//   * one thread per landmark, 256-thread workgroups, grid-stride over landmark batches with a
+//     grid sized to the resident capacity (persistent waves keep their partial sums in registers);
+//   * the C camera blocks (pose, calibration, 1/sigma: 24 doubles each) are staged once per
+//     workgroup in LDS; landmarks (24 B) arrive as coalesced 16-byte pieces through an LDS
+//     transpose; observations are camera-major, 16 contiguous bytes per lane;
+//   * a landmark's contribution to the (6C)^2 reduced camera matrix is never stored: it is
+//     produced slot by slot (ba_math.h Layout) into a 32-entry register window, and every full
+//     window is summed over the wavefront with a TRANSPOSED shuffle reduction -- 32 values cost
+//     32 exchange+add steps (v_permlane32_swap / v_permlane16_swap for the 32- and 16-lane
+//     strides, DPP/ds_swizzle shuffles below) instead of 32 x 6 for independent butterflies --
+//     leaving lane l with the wave total of window entry l >> 1, accumulated in one register per
+//     window across all the batches the wave processes;
+//   * waves -> workgroup through LDS, workgroups -> device through a [groups][slots] partial
+//     array and a one-workgroup finalize kernel that also symmetrises S.  No atomics: the result
+//     is bitwise reproducible run to run.
+// Algorithmic HBM traffic per landmark per linearisation: 24 + 16*C bytes (+1*C with a mask,
+// +8 with priors); the kernel is bound by fp64 VALU issue, not by HBM.
+#include "mqs_common.h"
+#include "ba_math.h"
+
+namespace {
+
+using namespace mqs::ba;
+
+constexpr int kBlock = 256;
+constexpr int kWaves = kBlock / 64;
+
+__device__ __forceinline__ void swap32(double &a, double &b)
+{
+    // v_permlane32_swap: a[lanes 32..63] <-> b[lanes 0..31]
+    unsigned alo = __double2loint(a), ahi = __double2hiint(a), blo = __double2loint(b), bhi = __double2hiint(b);
+    auto rlo = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
+    auto rhi = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+    a = __hiloint2double(rhi[0], rlo[0]);
+    b = __hiloint2double(rhi[1], rlo[1]);
+}
+
+__device__ __forceinline__ void swap16(double &a, double &b)
+{
+    // v_permlane16_swap: odd 16-lane rows of a <-> even rows of b
+    unsigned alo = __double2loint(a), ahi = __double2hiint(a), blo = __double2loint(b), bhi = __double2hiint(b);
+    auto rlo = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
+    auto rhi = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+    a = __hiloint2double(rhi[0], rlo[0]);
+    b = __hiloint2double(rhi[1], rlo[1]);
+}
+
+// Transposed wavefront reduction of 32 values per lane: on return lane l holds the sum over
+// all 64 lanes of v[l >> 1].  v is destroyed.
+__device__ __forceinline__ double wave_reduce32(double (&v)[32], int lane)
+{
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { swap32(v[i], v[i + 16]); v[i] += v[i + 16]; }   // lane bit 5 selects i (+16)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { swap16(v[i], v[i + 8]); v[i] += v[i + 8]; }      // lane bit 4 selects i (+8)
+    const bool b3 = lane & 8, b2 = lane & 4, b1 = lane & 2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const double send = b3 ? v[i] : v[i + 4], keep = b3 ? v[i + 4] : v[i];
+        v[i] = keep + __shfl_xor(send, 8);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const double send = b2 ? v[i] : v[i + 2], keep = b2 ? v[i + 2] : v[i];
+        v[i] = keep + __shfl_xor(send, 4);
+    }
+    {
+        const double send = b1 ? v[0] : v[1], keep = b1 ? v[1] : v[0];
+        v[0] = keep + __shfl_xor(send, 2);
+    }
+    return v[0] + __shfl_xor(v[0], 1);
+}
+
+template <int NCH>
+struct WaveEmitter {
+    double buf[32];
+    double acc[NCH];
+    int lane;
+    __device__ __forceinline__ void put(int slot, double v)
+    {
+        buf[slot & 31] = v;
+        if ((slot & 31) == 31) acc[slot >> 5] += wave_reduce32(buf, lane);
+    }
+};
+
+// Cooperative load of this batch's landmarks: coalesced 16-byte pieces -> LDS -> 3 doubles per thread.
+__device__ __forceinline__ void load_points(const double *__restrict__ points, int64_t base, int64_t N, double *sX,
+                                            int tid, double &px, double &py, double &pz)
+{
+    const int64_t rem = N - base;
+    const int npts = rem < kBlock ? (int)rem : kBlock;
+    const int ndbl = npts * 3;
+    const double2 *src = reinterpret_cast<const double2 *>(points + base * 3);   // 16-B aligned: base % 256 == 0
+    double2 *dst = reinterpret_cast<double2 *>(sX);
+    const int npair = ndbl >> 1;
+    for (int p = tid; p < npair; p += kBlock) dst[p] = src[p];
+    if ((ndbl & 1) && tid == 0) sX[ndbl - 1] = points[base * 3 + ndbl - 1];
+    __syncthreads();
+    const bool live = tid < npts;
+    px = live ? sX[tid * 3 + 0] : 0.0;
+    py = live ? sX[tid * 3 + 1] : 0.0;
+    pz = live ? sX[tid * 3 + 2] : 0.0;
+}
+
+template <int C>
+__device__ __forceinline__ void stage_cams(const double *poses, const double *calib, const double *sigma, double *sCam, int tid)
+{
+    if (tid < C) stage_camera(sCam + kCamStride * tid, poses + 12 * tid, calib + 9 * tid, sigma[tid]);
+    __syncthreads();
+}
+
+template <int C>
+__device__ __forceinline__ void load_obs(const double *__restrict__ obs, const uint8_t *__restrict__ mask, int64_t i,
+                                         int64_t N, bool live, double (*uv)[2], bool *seen)
+{
+    const double2 *o2 = reinterpret_cast<const double2 *>(obs);
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        double2 v = make_double2(0.0, 0.0);
+        bool s = false;
+        if (live) {
+            v = o2[(int64_t)c * N + i];
+            s = mask ? (mask[(int64_t)c * N + i] != 0) : true;
+        }
+        uv[c][0] = v.x; uv[c][1] = v.y; seen[c] = s;
+    }
+}
+
+__device__ __forceinline__ void load_prior(const double *__restrict__ prior_w, const double *__restrict__ prior_xyz,
+                                           int64_t i, bool live, double px, double py, double pz, double &pw,
+                                           double &dx, double &dy, double &dz)
+{
+    pw = 0.0; dx = dy = dz = 0.0;
+    if (live && prior_w) {
+        pw = prior_w[i];
+        if (pw > 0.0) {
+            dx = px - prior_xyz[3 * i + 0];
+            dy = py - prior_xyz[3 * i + 1];
+            dz = pz - prior_xyz[3 * i + 2];
+        } else {
+            pw = 0.0;
+        }
+    }
+}
+
+template <int C>
+__global__ __launch_bounds__(kBlock, 2) void ba_linearize_kernel(
+    const double *__restrict__ poses, const double *__restrict__ calib, const double *__restrict__ sigma,
+    const double *__restrict__ points, const double *__restrict__ obs, const uint8_t *__restrict__ mask,
+    const double *__restrict__ prior_w, const double *__restrict__ prior_xyz, int64_t N, double lambda,
+    double *__restrict__ partials)
+{
+    using L = Layout<C>;
+    constexpr int NCH = L::kChunks;
+    __shared__ double sCam[C * kCamStride];
+    __shared__ double sX[kBlock * 3];
+    __shared__ double sRed[kWaves * NCH * 32];
+
+    const int tid = threadIdx.x;
+    stage_cams<C>(poses, calib, sigma, sCam, tid);
+
+    WaveEmitter<NCH> em;
+    em.lane = tid & 63;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) em.acc[k] = 0.0;
+
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t base = (int64_t)blockIdx.x * kBlock; base < N; base += stride) {
+        const int64_t i = base + tid;
+        const bool live = i < N;
+        double px, py, pz;
+        load_points(points, base, N, sX, tid, px, py, pz);
+        double uv[C][2];
+        bool seen[C];
+        load_obs<C>(obs, mask, i, N, live, uv, seen);
+        double pw, dx, dy, dz;
+        load_prior(prior_w, prior_xyz, i, live, px, py, pz, pw, dx, dy, dz);
+        landmark_contribution<C>(sCam, px, py, pz, uv, seen, pw, dx, dy, dz, lambda, live, em);
+        if ((L::kSlots & 31) != 0) em.acc[NCH - 1] += wave_reduce32(em.buf, em.lane);   // partial last window
+        __syncthreads();                                    // sX is reused by the next batch
+    }
+
+    // waves -> workgroup
+    const int wave = tid >> 6, lane = tid & 63;
+    if ((lane & 1) == 0) {
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) sRed[(wave * NCH + k) * 32 + (lane >> 1)] = em.acc[k];
+    }
+    __syncthreads();
+    for (int s = tid; s < NCH * 32; s += kBlock) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) t += sRed[w * NCH * 32 + s];
+        partials[(int64_t)blockIdx.x * (NCH * 32) + s] = t;
+    }
+}
+
+// Sums the per-workgroup partials (fixed order: reproducible) and scatters the slots into
+// out = [S | g | cost | count], mirroring S.
+template <int C>
+__global__ __launch_bounds__(kBlock) void ba_finalize_kernel(const double *__restrict__ partials, int nblocks,
+                                                             double *__restrict__ out)
+{
+    using L = Layout<C>;
+    constexpr int NCH = L::kChunks;
+    for (int s = threadIdx.x; s < L::kSlots; s += kBlock) {
+        double t = 0.0;
+        for (int b = 0; b < nblocks; ++b) t += partials[(int64_t)b * (NCH * 32) + s];
+        int o1, o2;
+        slot_to_out<C>(s, o1, o2);
+        if (o1 >= 0) out[o1] = t;
+        if (o2 >= 0) out[o2] = t;
+    }
+}
+
+template <int C>
+__global__ __launch_bounds__(kBlock, 2) void ba_backsub_kernel(
+    const double *__restrict__ poses, const double *__restrict__ calib, const double *__restrict__ sigma,
+    const double *__restrict__ points, const double *__restrict__ obs, const uint8_t *__restrict__ mask,
+    const double *__restrict__ prior_w, const double *__restrict__ prior_xyz, int64_t N, double lambda,
+    const double *__restrict__ dpose, double *__restrict__ points_out)
+{
+    __shared__ double sCam[C * kCamStride];
+    __shared__ double sX[kBlock * 3];
+    __shared__ double sD[6 * C];
+    const int tid = threadIdx.x;
+    if (tid < 6 * C) sD[tid] = dpose[tid];
+    stage_cams<C>(poses, calib, sigma, sCam, tid);
+
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t base = (int64_t)blockIdx.x * kBlock; base < N; base += stride) {
+        const int64_t i = base + tid;
+        const bool live = i < N;
+        double px, py, pz;
+        load_points(points, base, N, sX, tid, px, py, pz);
+        double uv[C][2];
+        bool seen[C];
+        load_obs<C>(obs, mask, i, N, live, uv, seen);
+        double pw, dx, dy, dz;
+        load_prior(prior_w, prior_xyz, i, live, px, py, pz, pw, dx, dy, dz);
+        const mqs::Vec3 dp = landmark_backsub<C>(sCam, px, py, pz, uv, seen, pw, dx, dy, dz, lambda, sD);
+        __syncthreads();                                    // every thread has read its point from sX
+        sX[tid * 3 + 0] = px + dp.x;
+        sX[tid * 3 + 1] = py + dp.y;
+        sX[tid * 3 + 2] = pz + dp.z;
+        __syncthreads();
+        const int64_t rem = N - base;
+        const int npts = rem < kBlock ? (int)rem : kBlock;
+        const int ndbl = npts * 3;
+        double2 *dst = reinterpret_cast<double2 *>(points_out + base * 3);
+        const double2 *src = reinterpret_cast<const double2 *>(sX);
+        for (int p = tid; p < (ndbl >> 1); p += kBlock) dst[p] = src[p];
+        if ((ndbl & 1) && tid == 0) points_out[base * 3 + ndbl - 1] = sX[ndbl - 1];
+        __syncthreads();
+    }
+}
+
+template <int C>
+__global__ __launch_bounds__(kBlock) void ba_cost_kernel(
+    const double *__restrict__ poses, const double *__restrict__ calib, const double *__restrict__ sigma,
+    const double *__restrict__ points, const double *__restrict__ obs, const uint8_t *__restrict__ mask,
+    const double *__restrict__ prior_w, const double *__restrict__ prior_xyz, int64_t N, double *__restrict__ partials)
+{
+    __shared__ double sCam[C * kCamStride];
+    __shared__ double sX[kBlock * 3];
+    __shared__ double sRed[2 * kWaves];
+    const int tid = threadIdx.x;
+    stage_cams<C>(poses, calib, sigma, sCam, tid);
+    double cost = 0.0, count = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t base = (int64_t)blockIdx.x * kBlock; base < N; base += stride) {
+        const int64_t i = base + tid;
+        const bool live = i < N;
+        double px, py, pz;
+        load_points(points, base, N, sX, tid, px, py, pz);
+        double uv[C][2];
+        bool seen[C];
+        load_obs<C>(obs, mask, i, N, live, uv, seen);
+        double pw, dx, dy, dz;
+        load_prior(prior_w, prior_xyz, i, live, px, py, pz, pw, dx, dy, dz);
+        double c1, n1;
+        landmark_cost<C>(sCam, px, py, pz, uv, seen, pw, dx, dy, dz, c1, n1);
+        if (live) { cost += c1; count += n1; }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int h = 32; h >= 1; h >>= 1) { cost += __shfl_xor(cost, h); count += __shfl_xor(count, h); }
+    if ((tid & 63) == 0) { sRed[2 * (tid >> 6)] = cost; sRed[2 * (tid >> 6) + 1] = count; }
+    __syncthreads();
+    if (tid == 0) {
+        double c = 0, n = 0;
+        for (int w = 0; w < kWaves; ++w) { c += sRed[2 * w]; n += sRed[2 * w + 1]; }
+        partials[2 * blockIdx.x] = c;
+        partials[2 * blockIdx.x + 1] = n;
+    }
+}
+
+__global__ void ba_cost_finalize_kernel(const double *__restrict__ partials, int nblocks, double *__restrict__ out)
+{
+    if (threadIdx.x < 2) {
+        double t = 0.0;
+        for (int b = 0; b < nblocks; ++b) t += partials[2 * b + threadIdx.x];
+        out[threadIdx.x] = t;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Reduced camera system: add pose priors (bundle_adjust.cpp:273) and damping, Cholesky solve,
+// retract the poses.  n = 6C <= 48: one wavefront, matrix in LDS.
+// ---------------------------------------------------------------------------------------
+constexpr int kMaxN6 = 6 * MQS_MAX_CAMS;
+
+__device__ void so3_log_dev(const double *R /*3x3 row-major*/, double w[3])
+{
+    const double tr = R[0] + R[4] + R[8];
+    double c = 0.5 * (tr - 1.0);
+    c = fmin(1.0, fmax(-1.0, c));
+    const double th = acos(c);
+    const double vx = R[7] - R[5], vy = R[2] - R[6], vz = R[3] - R[1];
+    const double k = (th < 1e-10) ? 0.5 : th / (2.0 * sin(th));
+    w[0] = k * vx; w[1] = k * vy; w[2] = k * vz;
+}
+
+__device__ void so3_exp_dev(const double w[3], double E[9])
+{
+    const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+    const double th = sqrt(th2);
+    double a, b;
+    if (th < 1e-10) { a = 1.0; b = 0.5; }
+    else { a = sin(th) / th; b = (1.0 - cos(th)) / th2; }
+    const double K[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
+    double K2[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) K2[3 * i + j] = K[3 * i] * K[j] + K[3 * i + 1] * K[3 + j] + K[3 * i + 2] * K[6 + j];
+    for (int i = 0; i < 9; ++i) E[i] = ((i % 4 == 0) ? 1.0 : 0.0) + a * K[i] + b * K2[i];
+}
+
+__global__ __launch_bounds__(64) void ba_solve_kernel(const double *__restrict__ lin, int C, const double *__restrict__ poses,
+                                                      const double *__restrict__ prior_poses,
+                                                      const double *__restrict__ prior_sigmas,
+                                                      const uint8_t *__restrict__ prior_mask, double lambda,
+                                                      double *__restrict__ dpose, double *__restrict__ poses_out,
+                                                      double *__restrict__ info)
+{
+    __shared__ double A[kMaxN6 * (kMaxN6 + 1)];
+    __shared__ double b[kMaxN6];
+    __shared__ double sInfo[2];
+    const int n = 6 * C, ld = n + 1, lane = threadIdx.x;
+    for (int k = lane; k < n * n; k += 64) A[(k / n) * ld + (k % n)] = lin[k];
+    if (lane < n) b[lane] = lin[n * n + lane];
+    if (lane == 0) { sInfo[0] = 0.0; sInfo[1] = 0.0; }
+    __syncthreads();
+    // pose priors: e = (Log(R0^T R), R0^T (t - t0)) / sigma, J ~ I
+    if (prior_mask && lane < C && prior_mask[lane]) {
+        const double *T0 = prior_poses + 12 * lane, *T = poses + 12 * lane, *sg = prior_sigmas + 6 * lane;
+        double Rr[9], w[3], e[6];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) Rr[3 * i + j] = T0[i] * T[j] + T0[3 + i] * T[3 + j] + T0[6 + i] * T[6 + j];
+        so3_log_dev(Rr, w);
+        const double dt[3] = {T[9] - T0[9], T[10] - T0[10], T[11] - T0[11]};
+        for (int i = 0; i < 3; ++i) {
+            e[i] = w[i];
+            e[3 + i] = T0[i] * dt[0] + T0[3 + i] * dt[1] + T0[6 + i] * dt[2];
+        }
+        double cst = 0.0;
+        for (int i = 0; i < 6; ++i) {
+            const double wi = 1.0 / (sg[i] * sg[i]);
+            A[(6 * lane + i) * ld + 6 * lane + i] += wi;
+            b[6 * lane + i] -= wi * e[i];
+            cst += 0.5 * wi * e[i] * e[i];
+        }
+        atomicAdd(&sInfo[0], cst);
+    }
+    __syncthreads();
+    if (lambda != 0.0 && lane < n) A[lane * ld + lane] *= (1.0 + lambda);
+    __syncthreads();
+    // in-place Cholesky (lower), column by column; lane r owns row r
+    for (int k = 0; k < n; ++k) {
+        const double dkk = A[k * ld + k];
+        if (lane == 0 && !(dkk > 0.0)) sInfo[1] = 1.0;        // not positive definite
+        const double piv = sqrt(dkk > 0.0 ? dkk : 1.0);
+        __syncthreads();
+        if (lane == k) A[k * ld + k] = piv;
+        if (lane > k && lane < n) A[lane * ld + k] /= piv;
+        __syncthreads();
+        if (lane > k && lane < n) {
+            const double lik = A[lane * ld + k];
+            for (int j = k + 1; j <= lane; ++j) A[lane * ld + j] -= lik * A[j * ld + k];
+        }
+        __syncthreads();
+    }
+    // forward / backward substitution by lane 0 (n <= 48)
+    if (lane == 0) {
+        for (int i = 0; i < n; ++i) {
+            double s = b[i];
+            for (int j = 0; j < i; ++j) s -= A[i * ld + j] * b[j];
+            b[i] = s / A[i * ld + i];
+        }
+        for (int i = n - 1; i >= 0; --i) {
+            double s = b[i];
+            for (int j = i + 1; j < n; ++j) s -= A[j * ld + i] * b[j];
+            b[i] = s / A[i * ld + i];
+        }
+    }
+    __syncthreads();
+    if (lane < n) dpose[lane] = b[lane];
+    if (poses_out && lane < C) {
+        const double *T = poses + 12 * lane;
+        double E[9], w[3] = {b[6 * lane], b[6 * lane + 1], b[6 * lane + 2]};
+        so3_exp_dev(w, E);
+        double *O = poses_out + 12 * lane;
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) O[3 * i + j] = T[3 * i] * E[j] + T[3 * i + 1] * E[3 + j] + T[3 * i + 2] * E[6 + j];
+        for (int i = 0; i < 3; ++i)
+            O[9 + i] = T[9 + i] + T[3 * i] * b[6 * lane + 3] + T[3 * i + 1] * b[6 * lane + 4] + T[3 * i + 2] * b[6 * lane + 5];
+    }
+    if (info && lane == 0) { info[0] = sInfo[0]; info[1] = sInfo[1]; }
+}
+
+// Grid: persistent workgroups, 2 per CU at <= 256 VGPRs (each keeps its partial sums in registers).
+int ba_grid(int64_t N)
+{
+    int64_t g = (N + kBlock - 1) / kBlock;
+    if (g < 1) g = 1;
+    if (g > 512) g = 512;
+    return (int)g;
+}
+
+template <int C>
+int64_t ws_doubles() { return (int64_t)512 * Layout<C>::kChunks * 32; }
+
+int64_t ws_doubles_rt(int C)
+{
+    switch (C) {
+#define MQS_CASE(c) case c: return ws_doubles<c>();
+        MQS_CASE(1) MQS_CASE(2) MQS_CASE(3) MQS_CASE(4) MQS_CASE(5) MQS_CASE(6) MQS_CASE(7) MQS_CASE(8)
+#undef MQS_CASE
+    }
+    return 0;
+}
+
+int check_common(const double *poses, const double *calib, const double *sigma, int C, const double *points,
+                 const double *obs, int64_t N)
+{
+    MQS_ARG_CHECK(C >= 1 && C <= MQS_MAX_CAMS, "1 <= C <= MQS_MAX_CAMS");
+    MQS_ARG_CHECK(N >= 0, "N >= 0");
+    MQS_ARG_CHECK(poses && calib && sigma, "poses, calib, sigma must not be null");
+    MQS_ARG_CHECK(N == 0 || (points && obs), "points, obs must not be null");
+    MQS_ARG_CHECK(mqs_aligned16(points) && mqs_aligned16(obs), "device pointers must be 16-byte aligned");
+    return MQS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t mqs_ba_workspace_bytes(int C, int64_t N)
+{
+    (void)N;
+    if (C < 1 || C > MQS_MAX_CAMS) return 0;
+    return ws_doubles_rt(C) * 8;
+}
+
+int mqs_ba_linearize_dev(const double *poses, const double *calib, const double *sigma, int C, const double *points,
+                         const double *obs, const uint8_t *mask, const double *prior_w, const double *prior_xyz,
+                         int64_t N, double lambda, double *out, void *workspace, int64_t workspace_bytes, void *stream_)
+{
+    int rc = check_common(poses, calib, sigma, C, points, obs, N);
+    if (rc != MQS_OK) return rc;
+    MQS_ARG_CHECK(out != nullptr && workspace != nullptr, "out and workspace must not be null");
+    MQS_ARG_CHECK(workspace_bytes >= mqs_ba_workspace_bytes(C, N), "workspace too small (mqs_ba_workspace_bytes)");
+    MQS_ARG_CHECK(!prior_w || prior_xyz, "prior_xyz required with prior_w");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int grid = ba_grid(N);
+    double *partials = static_cast<double *>(workspace);
+    switch (C) {
+#define MQS_CASE(c)                                                                                        \
+    case c:                                                                                                \
+        hipLaunchKernelGGL((ba_linearize_kernel<c>), dim3(grid), dim3(kBlock), 0, stream, poses, calib, sigma, \
+                           points, obs, mask, prior_w, prior_xyz, N, lambda, partials);                    \
+        hipLaunchKernelGGL((ba_finalize_kernel<c>), dim3(1), dim3(kBlock), 0, stream, partials, grid, out);   \
+        break;
+        MQS_CASE(1) MQS_CASE(2) MQS_CASE(3) MQS_CASE(4) MQS_CASE(5) MQS_CASE(6) MQS_CASE(7) MQS_CASE(8)
+#undef MQS_CASE
+    }
+    MQS_HIP_CHECK(hipGetLastError());
+    return MQS_OK;
+}
+
+int mqs_ba_backsub_dev(const double *poses, const double *calib, const double *sigma, int C, const double *points,
+                       const double *obs, const uint8_t *mask, const double *prior_w, const double *prior_xyz,
+                       int64_t N, double lambda, const double *dpose, double *points_out, void *stream_)
+{
+    int rc = check_common(poses, calib, sigma, C, points, obs, N);
+    if (rc != MQS_OK) return rc;
+    MQS_ARG_CHECK(dpose && (N == 0 || points_out), "dpose, points_out must not be null");
+    MQS_ARG_CHECK(mqs_aligned16(points_out), "points_out must be 16-byte aligned");
+    MQS_ARG_CHECK(!prior_w || prior_xyz, "prior_xyz required with prior_w");
+    if (N == 0) return MQS_OK;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const unsigned grid = mqs_stream_grid(N, kBlock);
+    switch (C) {
+#define MQS_CASE(c)                                                                                       \
+    case c:                                                                                               \
+        hipLaunchKernelGGL((ba_backsub_kernel<c>), dim3(grid), dim3(kBlock), 0, stream, poses, calib, sigma, \
+                           points, obs, mask, prior_w, prior_xyz, N, lambda, dpose, points_out);          \
+        break;
+        MQS_CASE(1) MQS_CASE(2) MQS_CASE(3) MQS_CASE(4) MQS_CASE(5) MQS_CASE(6) MQS_CASE(7) MQS_CASE(8)
+#undef MQS_CASE
+    }
+    MQS_HIP_CHECK(hipGetLastError());
+    return MQS_OK;
+}
+
+int mqs_ba_cost_dev(const double *poses, const double *calib, const double *sigma, int C, const double *points,
+                    const double *obs, const uint8_t *mask, const double *prior_w, const double *prior_xyz, int64_t N,
+                    double *out, void *workspace, int64_t workspace_bytes, void *stream_)
+{
+    int rc = check_common(poses, calib, sigma, C, points, obs, N);
+    if (rc != MQS_OK) return rc;
+    MQS_ARG_CHECK(out != nullptr && workspace != nullptr, "out and workspace must not be null");
+    MQS_ARG_CHECK(workspace_bytes >= 2 * 512 * 8, "workspace too small");
+    MQS_ARG_CHECK(!prior_w || prior_xyz, "prior_xyz required with prior_w");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int grid = ba_grid(N);
+    double *partials = static_cast<double *>(workspace);
+    switch (C) {
+#define MQS_CASE(c)                                                                                    \
+    case c:                                                                                            \
+        hipLaunchKernelGGL((ba_cost_kernel<c>), dim3(grid), dim3(kBlock), 0, stream, poses, calib, sigma, \
+                           points, obs, mask, prior_w, prior_xyz, N, partials);                        \
+        break;
+        MQS_CASE(1) MQS_CASE(2) MQS_CASE(3) MQS_CASE(4) MQS_CASE(5) MQS_CASE(6) MQS_CASE(7) MQS_CASE(8)
+#undef MQS_CASE
+    }
+    hipLaunchKernelGGL(ba_cost_finalize_kernel, dim3(1), dim3(64), 0, stream, partials, grid, out);
+    MQS_HIP_CHECK(hipGetLastError());
+    return MQS_OK;
+}
+
+int mqs_ba_solve_dev(const double *lin, int C, const double *poses, const double *prior_poses,
+                     const double *prior_sigmas, const uint8_t *prior_mask, double lambda, double *dpose,
+                     double *poses_out, double *info, void *stream_)
+{
+    MQS_ARG_CHECK(C >= 1 && C <= MQS_MAX_CAMS, "1 <= C <= MQS_MAX_CAMS");
+    MQS_ARG_CHECK(lin && poses && dpose, "lin, poses, dpose must not be null");
+    MQS_ARG_CHECK(!prior_mask || (prior_poses && prior_sigmas), "prior_poses/prior_sigmas required with prior_mask");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    hipLaunchKernelGGL(ba_solve_kernel, dim3(1), dim3(64), 0, stream, lin, C, poses, prior_poses, prior_sigmas,
+                       prior_mask, lambda, dpose, poses_out, info);
+    MQS_HIP_CHECK(hipGetLastError());
+    return MQS_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------
+// Host-pointer wrappers: stage everything in the ctx scratch, run, copy the result back.
+// ---------------------------------------------------------------------------------------
+namespace {
+
+struct BaStage {
+    double *poses, *calib, *sigma, *points, *obs, *prior_w, *prior_xyz, *dpose, *out, *points_out;
+    uint8_t *mask;
+    void *ws;
+    int64_t ws_bytes;
+};
+
+int ba_stage(mqs_ctx *ctx, const double *poses, const double *calib, const double *sigma, int C, const double *points,
+             const double *obs, const uint8_t *mask, const double *prior_w, const double *prior_xyz, int64_t N,
+             const double *dpose, BaStage &st)
+{
+    MQS_ARG_CHECK(ctx != nullptr, "ctx must not be null");
+    MQS_ARG_CHECK(C >= 1 && C <= MQS_MAX_CAMS, "1 <= C <= MQS_MAX_CAMS");
+    MQS_ARG_CHECK(N >= 0, "N >= 0");
+    MQS_ARG_CHECK(poses && calib && sigma && (N == 0 || (points && obs)), "inputs must not be null");
+    MQS_ARG_CHECK(!prior_w || prior_xyz, "prior_xyz required with prior_w");
+    MQS_HIP_CHECK(hipSetDevice(ctx->device));
+    auto up = [](size_t v) { return (v + 255) & ~size_t(255); };
+    const int n6 = 6 * C;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = up(off + bytes); return o; };
+    const size_t o_poses = take(C * 96), o_calib = take(C * 72), o_sigma = take(C * 8);
+    const size_t o_points = take((size_t)N * 24), o_obs = take((size_t)C * N * 16), o_mask = take((size_t)C * N);
+    const size_t o_pw = take((size_t)N * 8), o_px = take((size_t)N * 24), o_dpose = take(n6 * 8);
+    const size_t o_out = take(((size_t)n6 * n6 + n6 + 2) * 8), o_pout = take((size_t)N * 24);
+    const int64_t wsb = mqs_ba_workspace_bytes(C, N);
+    const size_t o_ws = take((size_t)wsb);
+    int rc = mqs_ctx_reserve(ctx, off);
+    if (rc != MQS_OK) return rc;
+    char *d = static_cast<char *>(ctx->dbuf);
+    st.poses = (double *)(d + o_poses); st.calib = (double *)(d + o_calib); st.sigma = (double *)(d + o_sigma);
+    st.points = (double *)(d + o_points); st.obs = (double *)(d + o_obs);
+    st.mask = mask ? (uint8_t *)(d + o_mask) : nullptr;
+    st.prior_w = prior_w ? (double *)(d + o_pw) : nullptr;
+    st.prior_xyz = prior_w ? (double *)(d + o_px) : nullptr;
+    st.dpose = (double *)(d + o_dpose); st.out = (double *)(d + o_out); st.points_out = (double *)(d + o_pout);
+    st.ws = d + o_ws; st.ws_bytes = wsb;
+    hipStream_t s = ctx->stream;
+    MQS_HIP_CHECK(hipMemcpyAsync(st.poses, poses, C * 96, hipMemcpyHostToDevice, s));
+    MQS_HIP_CHECK(hipMemcpyAsync(st.calib, calib, C * 72, hipMemcpyHostToDevice, s));
+    MQS_HIP_CHECK(hipMemcpyAsync(st.sigma, sigma, C * 8, hipMemcpyHostToDevice, s));
+    if (N > 0) {
+        MQS_HIP_CHECK(hipMemcpyAsync(st.points, points, (size_t)N * 24, hipMemcpyHostToDevice, s));
+        MQS_HIP_CHECK(hipMemcpyAsync(st.obs, obs, (size_t)C * N * 16, hipMemcpyHostToDevice, s));
+        if (mask) MQS_HIP_CHECK(hipMemcpyAsync(st.mask, mask, (size_t)C * N, hipMemcpyHostToDevice, s));
+        if (prior_w) {
+            MQS_HIP_CHECK(hipMemcpyAsync(st.prior_w, prior_w, (size_t)N * 8, hipMemcpyHostToDevice, s));
+            MQS_HIP_CHECK(hipMemcpyAsync(st.prior_xyz, prior_xyz, (size_t)N * 24, hipMemcpyHostToDevice, s));
+        }
+    }
+    if (dpose) MQS_HIP_CHECK(hipMemcpyAsync(st.dpose, dpose, n6 * 8, hipMemcpyHostToDevice, s));
+    return MQS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mqs_ba_linearize(mqs_ctx *ctx, const double *poses, const double *calib, const double *sigma, int C,
+                     const double *points, const double *obs, const uint8_t *mask, const double *prior_w,
+                     const double *prior_xyz, int64_t N, double lambda, double *out)
+{
+    MQS_ARG_CHECK(out != nullptr, "out must not be null");
+    BaStage st;
+    int rc = ba_stage(ctx, poses, calib, sigma, C, points, obs, mask, prior_w, prior_xyz, N, nullptr, st);
+    if (rc != MQS_OK) return rc;
+    rc = mqs_ba_linearize_dev(st.poses, st.calib, st.sigma, C, st.points, st.obs, st.mask, st.prior_w, st.prior_xyz, N,
+                              lambda, st.out, st.ws, st.ws_bytes, ctx->stream);
+    if (rc != MQS_OK) return rc;
+    const int n6 = 6 * C;
+    MQS_HIP_CHECK(hipMemcpyAsync(out, st.out, ((size_t)n6 * n6 + n6 + 2) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    MQS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return MQS_OK;
+}
+
+int mqs_ba_backsub(mqs_ctx *ctx, const double *poses, const double *calib, const double *sigma, int C,
+                   const double *points, const double *obs, const uint8_t *mask, const double *prior_w,
+                   const double *prior_xyz, int64_t N, double lambda, const double *dpose, double *points_out)
+{
+    MQS_ARG_CHECK(dpose != nullptr && (N == 0 || points_out != nullptr), "dpose, points_out must not be null");
+    BaStage st;
+    int rc = ba_stage(ctx, poses, calib, sigma, C, points, obs, mask, prior_w, prior_xyz, N, dpose, st);
+    if (rc != MQS_OK) return rc;
+    rc = mqs_ba_backsub_dev(st.poses, st.calib, st.sigma, C, st.points, st.obs, st.mask, st.prior_w, st.prior_xyz, N,
+                            lambda, st.dpose, st.points_out, ctx->stream);
+    if (rc != MQS_OK) return rc;
+    if (N > 0) MQS_HIP_CHECK(hipMemcpyAsync(points_out, st.points_out, (size_t)N * 24, hipMemcpyDeviceToHost, ctx->stream));
+    MQS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return MQS_OK;
+}
+
+}  // extern "C"

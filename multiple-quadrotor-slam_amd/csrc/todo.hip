@@ -8,10 +8,4 @@ int mqs_match_knn2_f32_dev(const float *, int64_t, const float *, int64_t, int, 
 int mqs_match_knn2_f16(mqs_ctx *, const uint16_t *, int64_t, const uint16_t *, int64_t, int, int32_t *, float *) { MQS_TODO("mqs_match_knn2_f16"); }
 int mqs_match_knn2_f16_dev(const uint16_t *, int64_t, const uint16_t *, int64_t, int, int32_t *, float *, void *, int64_t, void *) { MQS_TODO("mqs_match_knn2_f16_dev"); }
 int64_t mqs_match_knn2_f16_workspace_bytes(int64_t, int64_t) { return 0; }
-int mqs_ba_linearize_dev(const double *, const double *, const double *, int, const double *, const double *, const uint8_t *, int64_t, double, double *, void *, int64_t, void *) { MQS_TODO("mqs_ba_linearize_dev"); }
-int64_t mqs_ba_workspace_bytes(int, int64_t) { return 0; }
-int mqs_ba_backsub_dev(const double *, const double *, const double *, int, const double *, const double *, const uint8_t *, int64_t, double, const double *, double *, void *) { MQS_TODO("mqs_ba_backsub_dev"); }
-int mqs_ba_cost_dev(const double *, const double *, const double *, int, const double *, const double *, const uint8_t *, int64_t, double *, void *, int64_t, void *) { MQS_TODO("mqs_ba_cost_dev"); }
-int mqs_ba_linearize(mqs_ctx *, const double *, const double *, const double *, int, const double *, const double *, const uint8_t *, int64_t, double, double *) { MQS_TODO("mqs_ba_linearize"); }
-int mqs_ba_backsub(mqs_ctx *, const double *, const double *, const double *, int, const double *, const double *, const uint8_t *, int64_t, double, const double *, double *) { MQS_TODO("mqs_ba_backsub"); }
 }

@@ -18,6 +18,15 @@
 #define MQS_HD static inline
 #endif
 
+// Scheduling fence between the per-camera sections of the BA arithmetic: stops the machine
+// scheduler from interleaving all cameras' loads and temporaries (which multiplies the live
+// register count by C and spills).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MQS_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define MQS_SCHED_FENCE() ((void)0)
+#endif
+
 namespace mqs {
 
 // 1/d.  Device: v_rcp_f64 seed + two Newton steps (full double precision for normal inputs,
@@ -32,6 +41,20 @@ MQS_HD double rcp(double d)
     return r;
 #else
     return 1.0 / d;
+#endif
+}
+
+// 1/sqrt(d), d > 0.  Device: v_rsq_f64 seed + two Newton steps.
+MQS_HD double rsqrt_d(double d)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    double y = __builtin_amdgcn_rsq(d);
+    const double hd = 0.5 * d;
+    y = fma(y, fma(-hd * y, y, 0.5), y);
+    y = fma(y, fma(-hd * y, y, 0.5), y);
+    return y;
+#else
+    return 1.0 / sqrt(d);
 #endif
 }
 
@@ -353,9 +376,13 @@ struct IterResult {
 // T2 iteration.  Does not keep `uv` alive past the Gram set-up, so that a kernel can re-read
 // the observations for refine<C>() instead of holding them in registers through the loop.
 template <int C>
-MQS_HD void iterative_ls_core(const double (*uv)[2], const double *P, double tol, int max_iter,
-                              IterResult<C> &out)
+MQS_HD void iterative_ls_core(const double (*uv)[2], const double *P, const double *Pdepth, double tol,
+                              int max_iter, IterResult<C> &out)
 {
+    // P      : camera matrices for the Gram set-up (the kernels pass their LDS copy)
+    // Pdepth : the same matrices for the depth rows read in every iteration (the kernels pass
+    //          the read-only global pointer: wave-uniform address -> scalar loads, the rows live
+    //          in SGPRs instead of being re-read from LDS or pinned in VGPRs)
     // Per-camera Gram pieces: the re-weighting of triangulation.c:143-146 multiplies camera
     // c's two rows (and b entries) by 1/d_c, i.e. its Gram contribution by 1/d_c^2, so the
     // pieces are built once and only re-combined per iteration.
@@ -396,7 +423,6 @@ MQS_HD void iterative_ls_core(const double (*uv)[2], const double *P, double tol
                 d[c] = dn[c];
             }
         }
-        const double *Pl = P + opaque_zero();
         G = Sym3{0, 0, 0, 0, 0, 0};
         Vec3 h = {0, 0, 0};
 #pragma unroll
@@ -410,7 +436,7 @@ MQS_HD void iterative_ls_core(const double (*uv)[2], const double *P, double tol
         bool conv = true, zero = false;
 #pragma unroll
         for (int c = 0; c < C; ++c) {                      // :133-134
-            const double *p2 = Pl + 12 * c + 8;
+            const double *p2 = Pdepth + 12 * c + 8;
             dn[c] = fma(p2[0], x.x, fma(p2[1], x.y, fma(p2[2], x.z, p2[3])));
             conv = conv && (fabs(dn[c] - d[c]) <= tol);
             zero = zero || (dn[c] == 0.0);
@@ -438,7 +464,7 @@ MQS_HD Vec3 iterative_ls_point(const double (*uv)[2], const double *P, double to
                                int32_t &status)
 {
     IterResult<C> r;
-    iterative_ls_core<C>(uv, P, tol, max_iter, r);
+    iterative_ls_core<C>(uv, P, P, tol, max_iter, r);
     status = r.status;
     if (!r.solved) return r.x;
     const Sym3 unused = {0, 0, 0, 0, 0, 0};

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(kBlock, waves_for(KIND)) void tri_kernel(const doub
             r = mqs::linear_ls_point<C>(uv, sP);
         } else if (KIND == kIterativeLS) {
             mqs::IterResult<C> it;
-            mqs::iterative_ls_core<C>(uv, sP, tol, max_iter, it);
+            mqs::iterative_ls_core<C>(uv, sP, P, tol, max_iter, it);
             if (live) status[i] = it.status;
             r = it.x;
             if (it.solved) {

@@ -1,0 +1,186 @@
+"""
+GPU parity of the bundle-adjustment kernels (through the C ABI) against the BA oracle
+(oracle/ba_np.py): reduced camera system, gradient, cost, back-substitution, solve + retraction,
+the Gauss-Newton / LM loops, and full-size properties at 1e6 landmarks x 4 cameras.
+Tolerance: 1e-5 relative (north_star: "BA residual parity <= 1e-5"); observed ~1e-12.
+"""
+import ctypes
+import numpy as np
+import pytest
+
+from oracle import ba_np
+from ba_util import make_scene
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def to_dev(sc):
+    import torch
+    t = lambda a, dt=None: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    return dict(poses=t(sc["poses"]), calib=t(sc["calib"]), sigma=t(sc["sigma"]), points=t(sc["points"]),
+                obs=t(sc["obs"]), mask=t(sc["mask"]), prior_w=t(sc["prior_w"]), prior_xyz=t(sc["prior_xyz"]))
+
+
+def adjuster(gpu, sc, pose_prior=None):
+    import torch
+    d = to_dev(sc)
+    pp = None
+    if pose_prior is not None:
+        pp = tuple(torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in pose_prior)
+    return gpu.bundle_adjustment.BundleAdjuster(pose_prior=pp, **d)
+
+
+def split_lin(lin, C):
+    n6 = 6 * C
+    lin = lin.cpu().numpy()
+    return lin[:n6 * n6].reshape(n6, n6), lin[n6 * n6:n6 * n6 + n6], lin[-2], lin[-1]
+
+
+CASES = [dict(N=300, C=2), dict(N=513, C=3, distortion=True), dict(N=300, C=4, distortion=True, masked_frac=0.3),
+         dict(N=257, C=4, behind=9), dict(N=64, C=4), dict(N=1, C=2), dict(N=700, C=5), dict(N=300, C=6, distortion=True)]
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("lam", [0.0, 1e-3])
+def test_linearize_and_backsub_parity(case, lam, gpu):
+    import torch
+    kw = dict(case)
+    N, C = kw.pop("N"), kw.pop("C")
+    sc = make_scene(N, C, seed=N + C, **kw)
+    ba = adjuster(gpu, sc)
+    S, g, cost, nv = split_lin(ba.linearize(lam), C)
+    So, go, co, nvo, pieces = ba_np.linearize(sc["poses"], sc["calib"], sc["sigma"], sc["points"], sc["obs"],
+                                              sc["mask"], sc["prior_w"], sc["prior_xyz"], lam)
+    assert np.abs(S - So).max() <= TOL * np.abs(So).max()
+    assert np.abs(S - So).max() <= 1e-10 * np.abs(So).max()          # what fp64 delivers
+    assert np.abs(g - go).max() <= 1e-10 * np.abs(go).max()
+    assert cost == pytest.approx(co, rel=1e-12) and nv == nvo
+    np.testing.assert_array_equal(S, S.T)                              # symmetrised exactly
+    # back-substitution at the same linearisation point
+    dpose = np.linalg.solve(So + 1e-3 * np.diag(np.diag(So)), go)
+    ba.dpose.copy_(torch.from_numpy(dpose).cuda())
+    pts_new = ba.backsub(lam).cpu().numpy()
+    dp = ba_np.backsub(pieces, dpose)
+    assert np.abs(pts_new - (sc["points"] + dp)).max() <= 1e-9 * max(1.0, np.abs(dp).max())
+    # cost kernel agrees with the linearise kernel's cost
+    c2 = ba.cost().cpu().numpy()
+    assert c2[0] == pytest.approx(co, rel=1e-12) and c2[1] == nvo
+
+
+def test_solve_and_retract(gpu):
+    import torch
+    sc = make_scene(400, 4, seed=2)
+    pp = (sc["poses_true"], np.tile([0.02, 0.02, 0.02, 0.1, 0.1, 0.1], (4, 1)), np.array([1, 0, 1, 0], dtype=np.uint8))
+    ba = adjuster(gpu, sc, pp)
+    ba.linearize(0.0)
+    ba.solve(0.0)
+    S, g, _, _ = split_lin(ba.lin, 4)
+    Hp, gp, cp = ba_np.pose_prior_terms(sc["poses"], *pp)
+    d_ref = np.linalg.solve(S + Hp, g + gp)
+    d = ba.dpose.cpu().numpy()
+    assert np.abs(d - d_ref).max() <= 1e-9 * np.abs(d_ref).max()
+    info = ba.info.cpu().numpy()
+    assert info[0] == pytest.approx(cp, rel=1e-10) and info[1] == 0.0
+    new = ba.poses_new.cpu().numpy()
+    for c in range(4):
+        np.testing.assert_allclose(new[c], ba_np.retract_pose(sc["poses"][c], d_ref[6 * c:6 * c + 6]), atol=1e-10)
+        R = new[c, :9].reshape(3, 3)
+        np.testing.assert_allclose(R @ R.T, np.eye(3), atol=1e-12)
+    # damping
+    ba.solve(0.5)
+    A = S + Hp
+    d_lm = np.linalg.solve(A + 0.5 * np.diag(np.diag(A)), g + gp)
+    assert np.abs(ba.dpose.cpu().numpy() - d_lm).max() <= 1e-9 * np.abs(d_lm).max()
+
+
+def test_gauss_newton_matches_oracle_every_iteration(gpu):
+    """BA residual (cost) parity <= 1e-5 after each of the 10 Gauss-Newton iterations."""
+    sc = make_scene(500, 4, seed=11)
+    pp = (sc["poses_true"], np.tile([0.02, 0.02, 0.02, 0.1, 0.1, 0.1], (4, 1)), np.array([1, 0, 0, 0], dtype=np.uint8))
+    ba = adjuster(gpu, sc, pp)
+    hist = ba.optimize(iters=10, mode="gn")
+    poses_o, points_o, hist_o = ba_np.gauss_newton(sc["poses"], sc["calib"], sc["sigma"], sc["points"], sc["obs"],
+                                                   None, sc["prior_w"], sc["prior_xyz"], pp, iters=10)
+    assert len(hist) == 11
+    for a, b in zip(hist, hist_o):
+        assert a == pytest.approx(b, rel=TOL)
+    assert hist[-1] < 0.05 * hist[0]
+    assert np.abs(ba.points.cpu().numpy() - points_o).max() < 1e-6
+    assert np.abs(ba.poses.cpu().numpy() - poses_o).max() < 1e-7
+
+
+def test_levenberg_marquardt_decreases_cost(gpu):
+    sc = make_scene(400, 3, seed=5, distortion=True, pose_noise=(0.05, 0.4), point_noise=0.3)
+    pp = (sc["poses_true"], np.tile([0.02, 0.02, 0.02, 0.1, 0.1, 0.1], (3, 1)), np.array([1, 0, 0], dtype=np.uint8))
+    ba = adjuster(gpu, sc, pp)
+    hist = ba.optimize(iters=30, mode="lm")
+    assert all(b <= a for a, b in zip(hist, hist[1:]))
+    assert hist[-1] < 0.01 * hist[0]
+    assert hist[-1] / (400 * 3) < 1.5               # chi^2 per factor ~ noise level
+
+
+def test_host_pointer_abi(gpu):
+    sc = make_scene(300, 3, seed=8, masked_frac=0.2)
+    lib, ctx = gpu._lib.lib(), gpu._lib.default_context()
+    f64, u8 = gpu._lib.c_f64p, gpu._lib.c_u8p
+    P = lambda a, t=f64: None if a is None else np.ascontiguousarray(a).ctypes.data_as(t)
+    n6 = 18
+    out = np.zeros(n6 * n6 + n6 + 2)
+    args = [np.ascontiguousarray(sc[k]) for k in ("poses", "calib", "sigma", "points", "obs", "mask", "prior_w", "prior_xyz")]
+    gpu._lib.check(lib.mqs_ba_linearize(ctx.handle, P(args[0]), P(args[1]), P(args[2]), 3, P(args[3]), P(args[4]),
+                                        P(args[5], u8), P(args[6]), P(args[7]), 300, 0.0, P(out)))
+    So, go, co, nvo, pieces = ba_np.linearize(sc["poses"], sc["calib"], sc["sigma"], sc["points"], sc["obs"],
+                                              sc["mask"], sc["prior_w"], sc["prior_xyz"])
+    assert np.abs(out[:n6 * n6].reshape(n6, n6) - So).max() <= 1e-10 * np.abs(So).max()
+    dpose = np.linalg.solve(So + 1e-3 * np.eye(n6), go)
+    pout = np.zeros((300, 3))
+    gpu._lib.check(lib.mqs_ba_backsub(ctx.handle, P(args[0]), P(args[1]), P(args[2]), 3, P(args[3]), P(args[4]),
+                                      P(args[5], u8), P(args[6]), P(args[7]), 300, 0.0, P(dpose), P(pout)))
+    assert np.abs(pout - (sc["points"] + ba_np.backsub(pieces, dpose))).max() < 1e-9
+
+
+def test_bad_arguments_fail_loudly(gpu):
+    lib = gpu._lib.lib()
+    rc = lib.mqs_ba_linearize_dev(None, None, None, 4, None, None, None, None, None, 10, 0.0, None, None, 0, None)
+    assert rc < 0 and b"null" in lib.mqs_last_error()
+    rc = lib.mqs_ba_solve_dev(None, 9, None, None, None, None, 0.0, None, None, None, None)
+    assert rc < 0
+
+
+def test_full_size_properties_1e6x4(gpu):
+    """BASELINE configs[3] shape on one GPU: shard additivity (the multi-GPU contract: the sum of the
+    shards' systems equals the whole, <= 1e-10), bitwise determinism, oracle agreement on a sample,
+    and monotone cost over 10 GN iterations."""
+    import torch
+    N, C = 1_000_000, 4
+    syn = gpu.synthetic
+    u, P, pts = syn.triangulation_problem(N, C)
+    rng = np.random.default_rng(0)
+    init = pts + 0.05 * rng.standard_normal(pts.shape)
+    ba = gpu.bundle_adjustment.make_benchmark_problem(u, P, init, torch.device("cuda", 0), seed=1)
+    lin = ba.linearize(0.0).clone()
+    lin2 = ba.linearize(0.0).clone()
+    assert torch.equal(lin, lin2)                                   # reproducible: no atomics
+    h = N // 2 + 129
+    BA = gpu.bundle_adjustment.BundleAdjuster
+    parts = []
+    for sl in (slice(0, h), slice(h, N)):
+        sub = BA(ba.poses, ba.calib, ba.sigma, ba.points[sl].clone(), ba.obs[:, sl].clone(), None,
+                 ba.prior_w[sl].clone(), ba.prior_xyz[sl].clone())
+        parts.append(sub.linearize(0.0).clone())
+    tot = (parts[0] + parts[1]).cpu().numpy()
+    ref = lin.cpu().numpy()
+    assert np.abs(tot - ref).max() <= 1e-10 * np.abs(ref).max()
+    # oracle on the first 3000 landmarks
+    n = 3000
+    sub = BA(ba.poses, ba.calib, ba.sigma, ba.points[:n].clone(), ba.obs[:, :n].clone(), None,
+             ba.prior_w[:n].clone(), ba.prior_xyz[:n].clone())
+    S, g, cost, nv = split_lin(sub.linearize(0.0), C)
+    So, go, co, nvo, _ = ba_np.linearize(ba.poses.cpu().numpy(), ba.calib.cpu().numpy(), ba.sigma.cpu().numpy(),
+                                         ba.points[:n].cpu().numpy(), ba.obs[:, :n].cpu().numpy(), None,
+                                         ba.prior_w[:n].cpu().numpy(), ba.prior_xyz[:n].cpu().numpy())
+    assert np.abs(S - So).max() <= 1e-10 * np.abs(So).max() and cost == pytest.approx(co, rel=1e-12)
+    hist = ba.optimize(iters=10, mode="gn")
+    assert hist[-1] < hist[0] and all(b <= a * (1 + 1e-9) for a, b in zip(hist[1:], hist[2:]))
+    assert hist[-1] / (N * C) < 1.0                                  # chi^2 per factor at pixel-noise level

@@ -1,0 +1,60 @@
+"""Self-consistency of the BA oracle (oracle/ba_np.py): analytic Jacobians vs finite
+differences, Schur form vs the dense Gauss-Newton system, and convergence."""
+import numpy as np
+import pytest
+
+from oracle import ba_np
+from ba_util import make_scene
+
+
+@pytest.mark.parametrize("distortion", [False, True])
+def test_jacobians_match_finite_differences(distortion):
+    sc = make_scene(6, 3, seed=3, distortion=distortion)
+    h = 1e-6
+    for c in range(3):
+        for i in range(6):
+            pose, K, s, p, uv = sc["poses"][c], sc["calib"][c], sc["sigma"][c], sc["points"][i], sc["obs"][c, i]
+            e0, Jp, Jl, ok = ba_np.factor(pose, K, s, p, uv)
+            assert ok
+            for k in range(6):
+                d = np.zeros(6); d[k] = h
+                ep = ba_np.factor(ba_np.retract_pose(pose, d), K, s, p, uv)[0]
+                em = ba_np.factor(ba_np.retract_pose(pose, -d), K, s, p, uv)[0]
+                np.testing.assert_allclose((ep - em) / (2 * h), Jp[:, k], rtol=1e-5, atol=1e-5)
+            for k in range(3):
+                d = np.zeros(3); d[k] = h
+                ep = ba_np.factor(pose, K, s, p + d, uv)[0]
+                em = ba_np.factor(pose, K, s, p - d, uv)[0]
+                np.testing.assert_allclose((ep - em) / (2 * h), Jl[:, k], rtol=1e-5, atol=1e-5)
+
+
+def test_schur_equals_dense_system():
+    sc = make_scene(12, 3, seed=5, distortion=True)
+    S, g, cost, nv, pieces = ba_np.linearize(sc["poses"], sc["calib"], sc["sigma"], sc["points"], sc["obs"])
+    H, b = ba_np.dense_reference_step(sc["poses"], sc["calib"], sc["sigma"], sc["points"], sc["obs"])
+    H += 1e-9 * np.eye(len(H))                         # gauge freedom
+    n6 = 18
+    Hpp, Hpl, Hll = H[:n6, :n6], H[:n6, n6:], H[n6:, n6:]
+    Sd = Hpp - Hpl @ np.linalg.solve(Hll, Hpl.T)
+    gd = b[:n6] - Hpl @ np.linalg.solve(Hll, b[n6:])
+    np.testing.assert_allclose(S, Sd, rtol=1e-6, atol=1e-6 * np.abs(S).max())
+    np.testing.assert_allclose(g, gd, rtol=1e-6, atol=1e-6 * np.abs(g).max())
+    assert nv == 36 and cost > 0
+
+
+def test_gauss_newton_converges_with_gauge_priors():
+    sc = make_scene(40, 4, seed=7)
+    pp = (sc["poses_true"], np.tile([0.02, 0.02, 0.02, 0.1, 0.1, 0.1], (4, 1)), np.array([1, 0, 0, 0]))
+    poses, points, hist = ba_np.gauss_newton(sc["poses"], sc["calib"], sc["sigma"], sc["points"], sc["obs"],
+                                             prior_w=sc["prior_w"], prior_xyz=sc["prior_xyz"], pose_prior=pp, iters=8)
+    assert hist[-1] < 0.05 * hist[0]
+    assert abs(hist[-1] - hist[-2]) < 1e-6 * hist[-1]      # converged
+    # residual level ~ pixel noise: chi2 per factor ~ 1
+    assert hist[-1] / (40 * 4) < 1.5
+
+
+def test_cheirality_convention():
+    sc = make_scene(5, 2, seed=1, behind=2)
+    e, Jp, Jl, ok = ba_np.factor(sc["poses"][0], sc["calib"][0], 2.0, sc["points"][0], sc["obs"][0, 0])
+    assert not ok and np.all(Jp == 0) and np.all(Jl == 0)
+    np.testing.assert_allclose(e, np.full(2, 2 * 480.0) / 2.0)

@@ -164,8 +164,8 @@ def test_full_size_properties_1e6x4(gpu, c_oracle):
             np.testing.assert_array_equal(sg[good], so[good])
     # (b) + (c)
     h = N // 2 + 37
-    xa, sa = dev.iterative_LS_triangulation(ud[:, :h].contiguous(), Pd)
-    xb, sb = dev.iterative_LS_triangulation(ud[:, h:].contiguous(), Pd)
+    xa, sa = dev.iterative_LS_triangulation(ud[:, :h].clone(), Pd)
+    xb, sb = dev.iterative_LS_triangulation(ud[:, h:].clone(), Pd)
     x_again, s_again = dev.iterative_LS_triangulation(ud, Pd)
     torch.cuda.synchronize()
     assert torch.equal(torch.cat([xa, xb]), x_it) and torch.equal(torch.cat([sa, sb]), s_it)
