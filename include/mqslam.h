@@ -171,7 +171,8 @@ int mqs_ba_backsub_dev(const double *poses, const double *calib, const double *s
                        const double *prior_w, const double *prior_xyz, int64_t N, double lambda,
                        const double *dpose, double *points_out, void *stream);
 
-/* cost only: out[2] = { 0.5*sum|r/sigma|^2 (+ point priors), valid-factor count }. */
+/* cost only: out[2] = { 0.5*sum|r/sigma|^2 (+ point priors), valid-factor count }.
+ * workspace: at least 64 KiB. */
 int mqs_ba_cost_dev(const double *poses, const double *calib, const double *sigma, int C,
                     const double *points, const double *obs, const uint8_t *mask,
                     const double *prior_w, const double *prior_xyz, int64_t N, double *out,

@@ -105,7 +105,7 @@ class BundleAdjuster:
         self.poses_new = torch.empty_like(self.poses)
         self.points_new = torch.empty_like(self.points)
         ws = int(_lib.lib().mqs_ba_workspace_bytes(C, N))
-        self.ws = torch.empty(max(ws, 8192), dtype=torch.uint8, device=self.dev)
+        self.ws = torch.empty(max(ws, 65536), dtype=torch.uint8, device=self.dev)
         self.lam = 0.0
         self.cost_history = []
 

@@ -80,15 +80,45 @@ __device__ __forceinline__ double wave_reduce32(double (&v)[32], int lane)
     return v[0] + __shfl_xor(v[0], 1);
 }
 
-template <int NCH>
+// Per-wave emitter: a 32-entry register window; every completed window is reduced over the wave
+// and added to this lane's running total, kept in LDS (one double per window per thread) so that
+// the window index may be anything and no accumulator registers are pinned.
 struct WaveEmitter {
     double buf[32];
-    double acc[NCH];
+    double *acc;     // LDS, already offset by the thread index; stride kBlock per window
     int lane;
     __device__ __forceinline__ void put(int slot, double v)
     {
         buf[slot & 31] = v;
-        if ((slot & 31) == 31) acc[slot >> 5] += wave_reduce32(buf, lane);
+        if ((slot & 31) == 31) flush(slot >> 5);
+    }
+    __device__ __forceinline__ void flush(int window)
+    {
+#if defined(MQS_BA_ABLATE_REDUCE)      // timing experiment only: per-lane sum instead of the wave reduction
+        double t = 0.0;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) t += buf[i];
+        acc[window * kBlock] += t;
+#else
+        acc[window * kBlock] += wave_reduce32(buf, lane);
+#endif
+    }
+};
+
+// Measurement access for ba_math.h: re-reads from global memory (L2 hits after the first touch).
+struct DevObs {
+    const double2 *o2;
+    const uint8_t *mask;
+    int64_t i, N;
+    bool live;
+    __device__ __forceinline__ void get(int c, double &u, double &v, bool &seen) const
+    {
+        u = 0.0; v = 0.0; seen = false;
+        if (live) {
+            const double2 t = o2[(int64_t)c * N + i];
+            u = t.x; v = t.y;
+            seen = mask ? (mask[(int64_t)c * N + i] != 0) : true;
+        }
     }
 };
 
@@ -116,23 +146,6 @@ __device__ __forceinline__ void stage_cams(const double *poses, const double *ca
 {
     if (tid < C) stage_camera(sCam + kCamStride * tid, poses + 12 * tid, calib + 9 * tid, sigma[tid]);
     __syncthreads();
-}
-
-template <int C>
-__device__ __forceinline__ void load_obs(const double *__restrict__ obs, const uint8_t *__restrict__ mask, int64_t i,
-                                         int64_t N, bool live, double (*uv)[2], bool *seen)
-{
-    const double2 *o2 = reinterpret_cast<const double2 *>(obs);
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-        double2 v = make_double2(0.0, 0.0);
-        bool s = false;
-        if (live) {
-            v = o2[(int64_t)c * N + i];
-            s = mask ? (mask[(int64_t)c * N + i] != 0) : true;
-        }
-        uv[c][0] = v.x; uv[c][1] = v.y; seen[c] = s;
-    }
 }
 
 __device__ __forceinline__ void load_prior(const double *__restrict__ prior_w, const double *__restrict__ prior_xyz,
@@ -163,15 +176,16 @@ __global__ __launch_bounds__(kBlock, 2) void ba_linearize_kernel(
     constexpr int NCH = L::kChunks;
     __shared__ double sCam[C * kCamStride];
     __shared__ double sX[kBlock * 3];
-    __shared__ double sRed[kWaves * NCH * 32];
+    __shared__ double sAcc[NCH * kBlock];
 
     const int tid = threadIdx.x;
     stage_cams<C>(poses, calib, sigma, sCam, tid);
 
-    WaveEmitter<NCH> em;
+    WaveEmitter em;
     em.lane = tid & 63;
+    em.acc = sAcc + tid;
 #pragma unroll
-    for (int k = 0; k < NCH; ++k) em.acc[k] = 0.0;
+    for (int k = 0; k < NCH; ++k) sAcc[k * kBlock + tid] = 0.0;
 
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t base = (int64_t)blockIdx.x * kBlock; base < N; base += stride) {
@@ -179,51 +193,67 @@ __global__ __launch_bounds__(kBlock, 2) void ba_linearize_kernel(
         const bool live = i < N;
         double px, py, pz;
         load_points(points, base, N, sX, tid, px, py, pz);
-        double uv[C][2];
-        bool seen[C];
-        load_obs<C>(obs, mask, i, N, live, uv, seen);
+        const DevObs ob = {reinterpret_cast<const double2 *>(obs), mask, i, N, live};
         double pw, dx, dy, dz;
         load_prior(prior_w, prior_xyz, i, live, px, py, pz, pw, dx, dy, dz);
-        landmark_contribution<C>(sCam, px, py, pz, uv, seen, pw, dx, dy, dz, lambda, live, em);
-        if ((L::kSlots & 31) != 0) em.acc[NCH - 1] += wave_reduce32(em.buf, em.lane);   // partial last window
+        landmark_contribution<C>(sCam, ob, px, py, pz, pw, dx, dy, dz, lambda, live, em);
         __syncthreads();                                    // sX is reused by the next batch
     }
 
-    // waves -> workgroup
-    const int wave = tid >> 6, lane = tid & 63;
-    if ((lane & 1) == 0) {
-#pragma unroll
-        for (int k = 0; k < NCH; ++k) sRed[(wave * NCH + k) * 32 + (lane >> 1)] = em.acc[k];
-    }
+    // lanes -> workgroup: window k, entry j lives in lanes 2j (and 2j+1) of every wave
     __syncthreads();
     for (int s = tid; s < NCH * 32; s += kBlock) {
+        const int k = s >> 5, j = s & 31;
         double t = 0.0;
 #pragma unroll
-        for (int w = 0; w < kWaves; ++w) t += sRed[w * NCH * 32 + s];
+        for (int w = 0; w < kWaves; ++w) t += sAcc[k * kBlock + w * 64 + 2 * j];
         partials[(int64_t)blockIdx.x * (NCH * 32) + s] = t;
     }
 }
 
-// Sums the per-workgroup partials (fixed order: reproducible) and scatters the slots into
-// out = [S | g | cost | count], mirroring S.
+// Sums the per-workgroup partials in a fixed order (reproducible) and scatters the slots into
+// out = [S | g | cost | count], mirroring S.  One workgroup of 1024 threads per 64 slots: wave w
+// adds rows w, w+16, ... (64 consecutive slots per row read = one 512-byte coalesced load, eight
+// in flight), then the 16 waves combine through LDS.
+constexpr int kFinThreads = 1024;
+
 template <int C>
-__global__ __launch_bounds__(kBlock) void ba_finalize_kernel(const double *__restrict__ partials, int nblocks,
-                                                             double *__restrict__ out)
+__global__ __launch_bounds__(kFinThreads) void ba_finalize_kernel(const double *__restrict__ partials, int nblocks,
+                                                                  double *__restrict__ out)
 {
     using L = Layout<C>;
     constexpr int NCH = L::kChunks;
-    for (int s = threadIdx.x; s < L::kSlots; s += kBlock) {
-        double t = 0.0;
-        for (int b = 0; b < nblocks; ++b) t += partials[(int64_t)b * (NCH * 32) + s];
+    constexpr int kRow = NCH * 32;
+    __shared__ double sSum[16][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int s = blockIdx.x * 64 + lane;
+    double t = 0.0;
+    if (s < kRow) {
+        int b = wave;
+        for (; b + 16 * 7 < nblocks; b += 16 * 8) {
+            double v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = partials[(int64_t)(b + 16 * k) * kRow + s];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t += v[k];
+        }
+        for (; b < nblocks; b += 16) t += partials[(int64_t)b * kRow + s];
+    }
+    sSum[wave][lane] = t;
+    __syncthreads();
+    if (wave == 0 && s < L::kSlots) {
+        double r = 0.0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) r += sSum[w][lane];
         int o1, o2;
         slot_to_out<C>(s, o1, o2);
-        if (o1 >= 0) out[o1] = t;
-        if (o2 >= 0) out[o2] = t;
+        if (o1 >= 0) out[o1] = r;
+        if (o2 >= 0) out[o2] = r;
     }
 }
 
 template <int C>
-__global__ __launch_bounds__(kBlock, 2) void ba_backsub_kernel(
+__global__ __launch_bounds__(kBlock, 4) void ba_backsub_kernel(
     const double *__restrict__ poses, const double *__restrict__ calib, const double *__restrict__ sigma,
     const double *__restrict__ points, const double *__restrict__ obs, const uint8_t *__restrict__ mask,
     const double *__restrict__ prior_w, const double *__restrict__ prior_xyz, int64_t N, double lambda,
@@ -242,12 +272,10 @@ __global__ __launch_bounds__(kBlock, 2) void ba_backsub_kernel(
         const bool live = i < N;
         double px, py, pz;
         load_points(points, base, N, sX, tid, px, py, pz);
-        double uv[C][2];
-        bool seen[C];
-        load_obs<C>(obs, mask, i, N, live, uv, seen);
+        const DevObs ob = {reinterpret_cast<const double2 *>(obs), mask, i, N, live};
         double pw, dx, dy, dz;
         load_prior(prior_w, prior_xyz, i, live, px, py, pz, pw, dx, dy, dz);
-        const mqs::Vec3 dp = landmark_backsub<C>(sCam, px, py, pz, uv, seen, pw, dx, dy, dz, lambda, sD);
+        const mqs::Vec3 dp = landmark_backsub<C>(sCam, ob, px, py, pz, pw, dx, dy, dz, lambda, sD);
         __syncthreads();                                    // every thread has read its point from sX
         sX[tid * 3 + 0] = px + dp.x;
         sX[tid * 3 + 1] = py + dp.y;
@@ -282,13 +310,11 @@ __global__ __launch_bounds__(kBlock) void ba_cost_kernel(
         const bool live = i < N;
         double px, py, pz;
         load_points(points, base, N, sX, tid, px, py, pz);
-        double uv[C][2];
-        bool seen[C];
-        load_obs<C>(obs, mask, i, N, live, uv, seen);
+        const DevObs ob = {reinterpret_cast<const double2 *>(obs), mask, i, N, live};
         double pw, dx, dy, dz;
         load_prior(prior_w, prior_xyz, i, live, px, py, pz, pw, dx, dy, dz);
         double c1, n1;
-        landmark_cost<C>(sCam, px, py, pz, uv, seen, pw, dx, dy, dz, c1, n1);
+        landmark_cost<C>(sCam, ob, px, py, pz, pw, dx, dy, dz, c1, n1);
         if (live) { cost += c1; count += n1; }
         __syncthreads();
     }
@@ -304,20 +330,26 @@ __global__ __launch_bounds__(kBlock) void ba_cost_kernel(
     }
 }
 
-__global__ void ba_cost_finalize_kernel(const double *__restrict__ partials, int nblocks, double *__restrict__ out)
+__global__ __launch_bounds__(kBlock) void ba_cost_finalize_kernel(const double *__restrict__ partials, int nblocks,
+                                                                  double *__restrict__ out)
 {
-    if (threadIdx.x < 2) {
-        double t = 0.0;
-        for (int b = 0; b < nblocks; ++b) t += partials[2 * b + threadIdx.x];
-        out[threadIdx.x] = t;
+    __shared__ double sC[kBlock], sN[kBlock];
+    const int tid = threadIdx.x;
+    double c = 0.0, n = 0.0;
+    for (int b = tid; b < nblocks; b += kBlock) { c += partials[2 * b]; n += partials[2 * b + 1]; }
+    sC[tid] = c; sN[tid] = n;
+    __syncthreads();
+    for (int h = kBlock / 2; h >= 1; h >>= 1) {
+        if (tid < h) { sC[tid] += sC[tid + h]; sN[tid] += sN[tid + h]; }
+        __syncthreads();
     }
+    if (tid == 0) { out[0] = sC[0]; out[1] = sN[0]; }
 }
 
 // ---------------------------------------------------------------------------------------
 // Reduced camera system: add pose priors (bundle_adjust.cpp:273) and damping, Cholesky solve,
 // retract the poses.  n = 6C <= 48: one wavefront, matrix in LDS.
 // ---------------------------------------------------------------------------------------
-constexpr int kMaxN6 = 6 * MQS_MAX_CAMS;
 
 __device__ void so3_log_dev(const double *R /*3x3 row-major*/, double w[3])
 {
@@ -344,22 +376,33 @@ __device__ void so3_exp_dev(const double w[3], double E[9])
     for (int i = 0; i < 9; ++i) E[i] = ((i % 4 == 0) ? 1.0 : 0.0) + a * K[i] + b * K2[i];
 }
 
-__global__ __launch_bounds__(64) void ba_solve_kernel(const double *__restrict__ lin, int C, const double *__restrict__ poses,
+__device__ __forceinline__ double read_lane(double v, int lane)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane),
+                            __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+
+// One wavefront; lane r keeps row r of the (6C x 6C) system in registers.  Right-looking Cholesky
+// with v_readlane broadcasts (all register indices static), forward substitution the same way,
+// backward substitution through an LDS copy of L (needs columns).
+template <int C>
+__global__ __launch_bounds__(64) void ba_solve_kernel(const double *__restrict__ lin, const double *__restrict__ poses,
                                                       const double *__restrict__ prior_poses,
                                                       const double *__restrict__ prior_sigmas,
                                                       const uint8_t *__restrict__ prior_mask, double lambda,
                                                       double *__restrict__ dpose, double *__restrict__ poses_out,
                                                       double *__restrict__ info)
 {
-    __shared__ double A[kMaxN6 * (kMaxN6 + 1)];
-    __shared__ double b[kMaxN6];
+    constexpr int n = 6 * C, ld = n + 1;
+    __shared__ double sL[n * ld];
+    __shared__ double sE[n];          // pose-prior: weighted residual added to g
+    __shared__ double sW[n];          // pose-prior: weight added to the diagonal
     __shared__ double sInfo[2];
-    const int n = 6 * C, ld = n + 1, lane = threadIdx.x;
-    for (int k = lane; k < n * n; k += 64) A[(k / n) * ld + (k % n)] = lin[k];
-    if (lane < n) b[lane] = lin[n * n + lane];
+    const int lane = threadIdx.x;
+    if (lane < n) { sE[lane] = 0.0; sW[lane] = 0.0; }
     if (lane == 0) { sInfo[0] = 0.0; sInfo[1] = 0.0; }
     __syncthreads();
-    // pose priors: e = (Log(R0^T R), R0^T (t - t0)) / sigma, J ~ I
+    // pose priors: e = (Log(R0^T R), R0^T (t - t0)) / sigma, J ~ I  (bundle_adjust.cpp:273)
     if (prior_mask && lane < C && prior_mask[lane]) {
         const double *T0 = prior_poses + 12 * lane, *T = poses + 12 * lane, *sg = prior_sigmas + 6 * lane;
         double Rr[9], w[3], e[6];
@@ -374,56 +417,78 @@ __global__ __launch_bounds__(64) void ba_solve_kernel(const double *__restrict__
         double cst = 0.0;
         for (int i = 0; i < 6; ++i) {
             const double wi = 1.0 / (sg[i] * sg[i]);
-            A[(6 * lane + i) * ld + 6 * lane + i] += wi;
-            b[6 * lane + i] -= wi * e[i];
+            sW[6 * lane + i] = wi;
+            sE[6 * lane + i] = wi * e[i];
             cst += 0.5 * wi * e[i] * e[i];
         }
         atomicAdd(&sInfo[0], cst);
     }
     __syncthreads();
-    if (lambda != 0.0 && lane < n) A[lane * ld + lane] *= (1.0 + lambda);
-    __syncthreads();
-    // in-place Cholesky (lower), column by column; lane r owns row r
+    const bool rowlane = lane < n;
+    const int r = rowlane ? lane : 0;
+    double row[n];
+#pragma unroll
+    for (int j = 0; j < n; ++j) row[j] = lin[r * n + j];
+    double b = lin[n * n + r] - sE[r];
+    // diagonal: prior weight, then damping
+#pragma unroll
+    for (int j = 0; j < n; ++j)
+        if (j == r) row[j] = (row[j] + sW[r]) * (1.0 + lambda);
+    if (!rowlane) {
+        b = 0.0;
+#pragma unroll
+        for (int j = 0; j < n; ++j) row[j] = 0.0;
+    }
+    bool bad = false;
+    double dinv = 1.0;
+#pragma unroll
     for (int k = 0; k < n; ++k) {
-        const double dkk = A[k * ld + k];
-        if (lane == 0 && !(dkk > 0.0)) sInfo[1] = 1.0;        // not positive definite
-        const double piv = sqrt(dkk > 0.0 ? dkk : 1.0);
-        __syncthreads();
-        if (lane == k) A[k * ld + k] = piv;
-        if (lane > k && lane < n) A[lane * ld + k] /= piv;
-        __syncthreads();
-        if (lane > k && lane < n) {
-            const double lik = A[lane * ld + k];
-            for (int j = k + 1; j <= lane; ++j) A[lane * ld + j] -= lik * A[j * ld + k];
+        const double akk = read_lane(row[k], k);
+        bad = bad || !(akk > 0.0);
+        const double inv = 1.0 / sqrt(akk > 0.0 ? akk : 1.0);
+        const double lik = row[k] * inv;             // L[lane][k] for lane >= k (lane k: the pivot)
+        row[k] = lik;
+        if (lane == k) dinv = inv;
+#pragma unroll
+        for (int j = k + 1; j < n; ++j) {
+            const double ljk = read_lane(lik, j);
+            row[j] = fma(-lik, ljk, row[j]);         // only entries j <= lane are used later
         }
-        __syncthreads();
     }
-    // forward / backward substitution by lane 0 (n <= 48)
-    if (lane == 0) {
-        for (int i = 0; i < n; ++i) {
-            double s = b[i];
-            for (int j = 0; j < i; ++j) s -= A[i * ld + j] * b[j];
-            b[i] = s / A[i * ld + i];
-        }
-        for (int i = n - 1; i >= 0; --i) {
-            double s = b[i];
-            for (int j = i + 1; j < n; ++j) s -= A[j * ld + i] * b[j];
-            b[i] = s / A[i * ld + i];
-        }
+    // forward substitution L y = b
+#pragma unroll
+    for (int k = 0; k < n; ++k) {
+        const double t = b * dinv;
+        const double yk = read_lane(t, k);
+        b = (lane == k) ? t : ((lane > k) ? fma(-row[k], yk, b) : b);
+    }
+    // backward substitution L^T x = y through LDS (column access)
+    if (rowlane) {
+#pragma unroll
+        for (int j = 0; j < n; ++j) sL[lane * ld + j] = row[j];
     }
     __syncthreads();
-    if (lane < n) dpose[lane] = b[lane];
+#pragma unroll 1
+    for (int k = n - 1; k >= 0; --k) {
+        const double t = b * dinv;
+        const double xk = read_lane(t, k);
+        const double lki = (lane < k) ? sL[k * ld + lane] : 0.0;
+        b = (lane == k) ? t : fma(-lki, xk, b);
+    }
+    __shared__ double sX[n];
+    if (rowlane) { dpose[lane] = b; sX[lane] = b; }
+    __syncthreads();
     if (poses_out && lane < C) {
         const double *T = poses + 12 * lane;
-        double E[9], w[3] = {b[6 * lane], b[6 * lane + 1], b[6 * lane + 2]};
+        double E[9], w[3] = {sX[6 * lane], sX[6 * lane + 1], sX[6 * lane + 2]};
         so3_exp_dev(w, E);
         double *O = poses_out + 12 * lane;
         for (int i = 0; i < 3; ++i)
             for (int j = 0; j < 3; ++j) O[3 * i + j] = T[3 * i] * E[j] + T[3 * i + 1] * E[3 + j] + T[3 * i + 2] * E[6 + j];
         for (int i = 0; i < 3; ++i)
-            O[9 + i] = T[9 + i] + T[3 * i] * b[6 * lane + 3] + T[3 * i + 1] * b[6 * lane + 4] + T[3 * i + 2] * b[6 * lane + 5];
+            O[9 + i] = T[9 + i] + T[3 * i] * sX[6 * lane + 3] + T[3 * i + 1] * sX[6 * lane + 4] + T[3 * i + 2] * sX[6 * lane + 5];
     }
-    if (info && lane == 0) { info[0] = sInfo[0]; info[1] = sInfo[1]; }
+    if (info && lane == 0) { info[0] = sInfo[0]; info[1] = bad ? 1.0 : 0.0; }
 }
 
 // Grid: persistent workgroups, 2 per CU at <= 256 VGPRs (each keeps its partial sums in registers).
@@ -487,7 +552,7 @@ int mqs_ba_linearize_dev(const double *poses, const double *calib, const double 
     case c:                                                                                                \
         hipLaunchKernelGGL((ba_linearize_kernel<c>), dim3(grid), dim3(kBlock), 0, stream, poses, calib, sigma, \
                            points, obs, mask, prior_w, prior_xyz, N, lambda, partials);                    \
-        hipLaunchKernelGGL((ba_finalize_kernel<c>), dim3(1), dim3(kBlock), 0, stream, partials, grid, out);   \
+        hipLaunchKernelGGL((ba_finalize_kernel<c>), dim3((Layout<c>::kChunks * 32 + 63) / 64), dim3(kFinThreads), 0, stream, partials, grid, out);   \
         break;
         MQS_CASE(1) MQS_CASE(2) MQS_CASE(3) MQS_CASE(4) MQS_CASE(5) MQS_CASE(6) MQS_CASE(7) MQS_CASE(8)
 #undef MQS_CASE
@@ -528,10 +593,11 @@ int mqs_ba_cost_dev(const double *poses, const double *calib, const double *sigm
     int rc = check_common(poses, calib, sigma, C, points, obs, N);
     if (rc != MQS_OK) return rc;
     MQS_ARG_CHECK(out != nullptr && workspace != nullptr, "out and workspace must not be null");
-    MQS_ARG_CHECK(workspace_bytes >= 2 * 512 * 8, "workspace too small");
+    MQS_ARG_CHECK(workspace_bytes >= 2 * 4096 * 8, "workspace too small (64 KiB)");
     MQS_ARG_CHECK(!prior_w || prior_xyz, "prior_xyz required with prior_w");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    const int grid = ba_grid(N);
+    int64_t g64 = (N + kBlock - 1) / kBlock;          // latency-bound streaming kernel: fill the machine
+    const int grid = (int)(g64 < 1 ? 1 : (g64 > 4096 ? 4096 : g64));
     double *partials = static_cast<double *>(workspace);
     switch (C) {
 #define MQS_CASE(c)                                                                                    \
@@ -542,7 +608,7 @@ int mqs_ba_cost_dev(const double *poses, const double *calib, const double *sigm
         MQS_CASE(1) MQS_CASE(2) MQS_CASE(3) MQS_CASE(4) MQS_CASE(5) MQS_CASE(6) MQS_CASE(7) MQS_CASE(8)
 #undef MQS_CASE
     }
-    hipLaunchKernelGGL(ba_cost_finalize_kernel, dim3(1), dim3(64), 0, stream, partials, grid, out);
+    hipLaunchKernelGGL(ba_cost_finalize_kernel, dim3(1), dim3(kBlock), 0, stream, partials, grid, out);
     MQS_HIP_CHECK(hipGetLastError());
     return MQS_OK;
 }
@@ -555,8 +621,15 @@ int mqs_ba_solve_dev(const double *lin, int C, const double *poses, const double
     MQS_ARG_CHECK(lin && poses && dpose, "lin, poses, dpose must not be null");
     MQS_ARG_CHECK(!prior_mask || (prior_poses && prior_sigmas), "prior_poses/prior_sigmas required with prior_mask");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    hipLaunchKernelGGL(ba_solve_kernel, dim3(1), dim3(64), 0, stream, lin, C, poses, prior_poses, prior_sigmas,
-                       prior_mask, lambda, dpose, poses_out, info);
+    switch (C) {
+#define MQS_CASE(c)                                                                                     \
+    case c:                                                                                             \
+        hipLaunchKernelGGL((ba_solve_kernel<c>), dim3(1), dim3(64), 0, stream, lin, poses, prior_poses, \
+                           prior_sigmas, prior_mask, lambda, dpose, poses_out, info);                   \
+        break;
+        MQS_CASE(1) MQS_CASE(2) MQS_CASE(3) MQS_CASE(4) MQS_CASE(5) MQS_CASE(6) MQS_CASE(7) MQS_CASE(8)
+#undef MQS_CASE
+    }
     MQS_HIP_CHECK(hipGetLastError());
     return MQS_OK;
 }

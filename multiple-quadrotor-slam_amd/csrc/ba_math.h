@@ -23,12 +23,15 @@ namespace mqs {
 namespace ba {
 
 // Slot layout of the per-landmark contributions (and of the reduced partial sums):
-//   [camera c: 21 upper-triangle entries of S_cc (row-major, i <= j), then g_c (6)]  c = 0..C-1
+//   [camera c: 21 upper-triangle entries of S_cc (row-major, i <= j), then g_c (6), 5 unused]
+//       c = 0..C-1 -- one full 32-slot reduction window per camera, so that no window is open
+//       while the next camera's factor is being formed (register pressure)
 //   [camera pair (c,d), c < d, in order (0,1),(0,2),..: 36 entries of S_cd row-major]
 //   [cost] [number of valid factors]
 template <int C>
 struct Layout {
-    static constexpr int kDiag = 27;
+    static constexpr int kDiag = 32;
+    static constexpr int kDiagUsed = 27;
     static constexpr int kPairs = C * (C - 1) / 2;
     static constexpr int diag_off(int c) { return kDiag * c; }
     static constexpr int pair_index(int c, int d) { return c * (2 * C - c - 1) / 2 + (d - c - 1); }
@@ -200,42 +203,59 @@ MQS_HD void apply_Lt_inv(const PointSystem &ps, double &v0, double &v1, double &
     v0 = fma(-ps.l20, v2, fma(-ps.l10, v1, v0)) * ps.i00;
 }
 
-// Everything the landmark contributes to the reduced camera system, emitted slot by slot.
-// Emit must provide  void put(int slot, double value)  (slot is a compile-time constant after
-// unrolling; the device emitter relies on that to stay in registers).
-//   cams   : staged camera blocks [C][kCamStride]
-//   p      : landmark;  uv[c][2] measurements;  observed[c]
-template <int C, class Emit>
-MQS_HD void landmark_contribution(const double *cams, double px, double py, double pz, const double (*uv)[2],
-                                  const bool *observed, double prior_w, double dpx, double dpy, double dpz,
-                                  double lambda, bool live, Emit &em)
+// Observation access.  `Obs` provides  void get(int c, double &u, double &v, bool &seen) const;
+// the kernels re-read the measurement from global memory (L2-resident) at every use instead of
+// holding 2C doubles per landmark in registers; the host harness reads its arrays.
+
+// Accumulates camera c's factor into the landmark block; returns the factor.
+template <class Obs>
+MQS_HD Factor add_camera(const double *cam, const Obs &obs, int c, double px, double py, double pz, bool live,
+                         PointSystem &ps)
 {
-    using L = Layout<C>;
-    double cx[C], cy[C], cZ[C];
-    double F00[C], F01[C], F11[C], f0[C], f1[C];
-    PointSystem ps;
+    double u, v;
+    bool seen;
+    obs.get(c, u, v, seen);
+    const Factor fc = make_factor(cam, px, py, pz, u, v, seen && live);
+    double PR[2][3];
+    make_PR(cam, fc.x, fc.y, PR);
+    point_add_factor(ps, fc, PR);
+    return fc;
+}
+
+// Phase A shared by linearise / back-substitution: Hll, gl, cost, count over all cameras.
+// The camera loop is deliberately NOT unrolled (small live state, high occupancy).
+template <int C, class Obs>
+MQS_HD void landmark_point_system(const double *cams, const Obs &obs, double px, double py, double pz, bool live,
+                                  double prior_w, double dpx, double dpy, double dpz, double lambda,
+                                  PointSystem &ps, double &cost, double &count)
+{
     ps.H = Sym3{0, 0, 0, 0, 0, 0};
     ps.g = Vec3{0, 0, 0};
-    double cost = 0.5 * prior_w * fma(dpx, dpx, fma(dpy, dpy, dpz * dpz));
-    double count = 0.0;
-    // opaque_zero(): keep the (loop-invariant) camera-block reads inside each pass -- re-read
-    // from LDS -- instead of letting them be hoisted into ~24 live doubles per camera
-    const double *cams1 = cams + opaque_zero();
-#pragma unroll
+    cost = 0.5 * prior_w * fma(dpx, dpx, fma(dpy, dpy, dpz * dpz));
+    count = 0.0;
+#pragma unroll 1
     for (int c = 0; c < C; ++c) {
-        const double *cam = cams1 + kCamStride * c;
-        const Factor fc = make_factor(cam, px, py, pz, uv[c][0], uv[c][1], observed[c] && live);
-        double PR[2][3];
-        make_PR(cam, fc.x, fc.y, PR);
-        point_add_factor(ps, fc, PR);
-        cx[c] = fc.x; cy[c] = fc.y; cZ[c] = fc.Z;
-        F00[c] = fc.F00; F01[c] = fc.F01; F11[c] = fc.F11; f0[c] = fc.f0; f1[c] = fc.f1;
+        const Factor fc = add_camera(cams + kCamStride * c, obs, c, px, py, pz, live, ps);
         cost += fc.half_e2;
         count += fc.valid ? 1.0 : 0.0;
-        MQS_SCHED_FENCE();
     }
     if (!live) cost = 0.0;
     point_finish(ps, live ? prior_w : 0.0, dpx, dpy, dpz, lambda);
+}
+
+// Everything the landmark contributes to the reduced camera system, emitted slot by slot.
+// Emit must provide  void put(int slot, double value)  and  void flush(int window)  (slot / window
+// are compile-time constants after unrolling; the device emitter relies on that to keep its
+// 32-entry window in registers).
+template <int C, class Obs, class Emit>
+MQS_HD void landmark_contribution(const double *cams, const Obs &obs, double px, double py, double pz,
+                                  double prior_w, double dpx, double dpy, double dpz, double lambda, bool live,
+                                  Emit &em)
+{
+    using L = Layout<C>;
+    PointSystem ps;
+    double cost, count;
+    landmark_point_system<C>(cams, obs, px, py, pz, live, prior_w, dpx, dpy, dpz, lambda, ps, cost, count);
     const double m = ps.ok ? 1.0 : 0.0;          // unconstrained landmark: pose blocks keep only J_pose^T J_pose
     // w = L^-1 gl
     double w0 = ps.g.x * ps.i00;
@@ -243,17 +263,22 @@ MQS_HD void landmark_contribution(const double *cams, double px, double py, doub
     double w2 = fma(-ps.l21, w1, fma(-ps.l20, w0, ps.g.z)) * ps.i22;
     w0 *= m; w1 *= m; w2 *= m;
 
+    double cx[C], cy[C], cZ[C];
     double Uh[C][2][3];
-    // ---- diagonal blocks and gradient ----
-    const double *cams2 = cams + opaque_zero();
+    // ---- diagonal blocks and gradient: the factor is re-formed (cheaper than keeping it) ----
 #pragma unroll
     for (int c = 0; c < C; ++c) {
-        const double *cam = cams2 + kCamStride * c;
+        const double *cam = cams + kCamStride * c + opaque_zero();
+        double u, v;
+        bool seen;
+        obs.get(c, u, v, seen);
+        const Factor fc = make_factor(cam, px, py, pz, u, v, seen && live);
+        cx[c] = fc.x; cy[c] = fc.y; cZ[c] = fc.Z;
         double PR[2][3];
-        make_PR(cam, cx[c], cy[c], PR);
+        make_PR(cam, fc.x, fc.y, PR);
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-            const double Fa = r ? F01[c] : F00[c], Fb = r ? F11[c] : F01[c];
+            const double Fa = r ? fc.F01 : fc.F00, Fb = r ? fc.F11 : fc.F01;
             double u0 = fma(Fa, PR[0][0], Fb * PR[1][0]);
             double u1 = fma(Fa, PR[0][1], Fb * PR[1][1]);
             double u2 = fma(Fa, PR[0][2], Fb * PR[1][2]);
@@ -261,11 +286,12 @@ MQS_HD void landmark_contribution(const double *cams, double px, double py, doub
             Uh[c][r][0] = m * u0; Uh[c][r][1] = m * u1; Uh[c][r][2] = m * u2;
         }
         // k = F - Uh Uh^T (2x2 sym),  rh = -f - Uh w
-        const double k00 = F00[c] - fma(Uh[c][0][0], Uh[c][0][0], fma(Uh[c][0][1], Uh[c][0][1], Uh[c][0][2] * Uh[c][0][2]));
-        const double k01 = F01[c] - fma(Uh[c][0][0], Uh[c][1][0], fma(Uh[c][0][1], Uh[c][1][1], Uh[c][0][2] * Uh[c][1][2]));
-        const double k11 = F11[c] - fma(Uh[c][1][0], Uh[c][1][0], fma(Uh[c][1][1], Uh[c][1][1], Uh[c][1][2] * Uh[c][1][2]));
-        const double rh0 = -f0[c] - fma(Uh[c][0][0], w0, fma(Uh[c][0][1], w1, Uh[c][0][2] * w2));
-        const double rh1 = -f1[c] - fma(Uh[c][1][0], w0, fma(Uh[c][1][1], w1, Uh[c][1][2] * w2));
+        const double k00 = fc.F00 - fma(Uh[c][0][0], Uh[c][0][0], fma(Uh[c][0][1], Uh[c][0][1], Uh[c][0][2] * Uh[c][0][2]));
+        const double k01 = fc.F01 - fma(Uh[c][0][0], Uh[c][1][0], fma(Uh[c][0][1], Uh[c][1][1], Uh[c][0][2] * Uh[c][1][2]));
+        const double k11 = fc.F11 - fma(Uh[c][1][0], Uh[c][1][0], fma(Uh[c][1][1], Uh[c][1][1], Uh[c][1][2] * Uh[c][1][2]));
+        const double rh0 = -fc.f0 - fma(Uh[c][0][0], w0, fma(Uh[c][0][1], w1, Uh[c][0][2] * w2));
+        const double rh1 = -fc.f1 - fma(Uh[c][1][0], w0, fma(Uh[c][1][1], w1, Uh[c][1][2] * w2));
+        MQS_SCHED_FENCE();
         double Jg[2][6];
         make_Jg(cx[c], cy[c], cZ[c], Jg);
         double T[2][6];                           // T = k Jg
@@ -281,6 +307,7 @@ MQS_HD void landmark_contribution(const double *cams, double px, double py, doub
             for (int j = i; j < 6; ++j) em.put(slot++, fma(Jg[0][i], T[0][j], Jg[1][i] * T[1][j]));
 #pragma unroll
         for (int i = 0; i < 6; ++i) em.put(slot++, fma(Jg[0][i], rh0, Jg[1][i] * rh1));
+        em.flush(L::diag_off(c) >> 5);            // the camera's window (5 unused entries)
         MQS_SCHED_FENCE();
     }
     // ---- off-diagonal blocks: S_cd = -Jg_c^T (Uh_c Uh_d^T) Jg_d ----
@@ -311,25 +338,25 @@ MQS_HD void landmark_contribution(const double *cams, double px, double py, doub
     }
     em.put(L::kCost, cost);
     em.put(L::kCount, count);
+    if ((L::kSlots & 31) != 0) em.flush(L::kChunks - 1);   // partial last window
 }
 
 // Landmark update dp = Hll^-1 (gl - sum_c Hpl_c^T dxi_c) at the same linearisation point.
-template <int C>
-MQS_HD Vec3 landmark_backsub(const double *cams, double px, double py, double pz, const double (*uv)[2],
-                             const bool *observed, double prior_w, double dpx, double dpy, double dpz,
-                             double lambda, const double *dpose)
+template <int C, class Obs>
+MQS_HD Vec3 landmark_backsub(const double *cams, const Obs &obs, double px, double py, double pz, double prior_w,
+                             double dpx, double dpy, double dpz, double lambda, const double *dpose)
 {
     PointSystem ps;
     ps.H = Sym3{0, 0, 0, 0, 0, 0};
     ps.g = Vec3{0, 0, 0};
     double rx = 0, ry = 0, rz = 0;                 // sum_c Hpl_c^T dxi_c = sum_c PR^T F (Jg dxi)
-    const int oz = opaque_zero();
-    cams += oz;
-    dpose += oz;
-#pragma unroll
+#pragma unroll 1
     for (int c = 0; c < C; ++c) {
         const double *cam = cams + kCamStride * c;
-        const Factor fc = make_factor(cam, px, py, pz, uv[c][0], uv[c][1], observed[c]);
+        double u, v;
+        bool seen;
+        obs.get(c, u, v, seen);
+        const Factor fc = make_factor(cam, px, py, pz, u, v, seen);
         double PR[2][3];
         make_PR(cam, fc.x, fc.y, PR);
         point_add_factor(ps, fc, PR);
@@ -345,7 +372,6 @@ MQS_HD Vec3 landmark_backsub(const double *cams, double px, double py, double pz
         rx = fma(PR[0][0], t0, fma(PR[1][0], t1, rx));
         ry = fma(PR[0][1], t0, fma(PR[1][1], t1, ry));
         rz = fma(PR[0][2], t0, fma(PR[1][2], t1, rz));
-        MQS_SCHED_FENCE();
     }
     point_finish(ps, prior_w, dpx, dpy, dpz, lambda);
     double v0 = ps.g.x - rx, v1 = ps.g.y - ry, v2 = ps.g.z - rz;
@@ -359,17 +385,18 @@ MQS_HD Vec3 landmark_backsub(const double *cams, double px, double py, double pz
     return dp;
 }
 
-template <int C>
-MQS_HD void landmark_cost(const double *cams, double px, double py, double pz, const double (*uv)[2],
-                          const bool *observed, double prior_w, double dpx, double dpy, double dpz,
-                          double &cost, double &count)
+template <int C, class Obs>
+MQS_HD void landmark_cost(const double *cams, const Obs &obs, double px, double py, double pz, double prior_w,
+                          double dpx, double dpy, double dpz, double &cost, double &count)
 {
     cost = 0.5 * prior_w * fma(dpx, dpx, fma(dpy, dpy, dpz * dpz));
     count = 0.0;
-    cams += opaque_zero();
-#pragma unroll
+#pragma unroll 1
     for (int c = 0; c < C; ++c) {
-        const Factor fc = make_factor(cams + kCamStride * c, px, py, pz, uv[c][0], uv[c][1], observed[c]);
+        double u, v;
+        bool seen;
+        obs.get(c, u, v, seen);
+        const Factor fc = make_factor(cams + kCamStride * c, px, py, pz, u, v, seen);
         cost += fc.half_e2;
         count += fc.valid ? 1.0 : 0.0;
     }
@@ -377,6 +404,7 @@ MQS_HD void landmark_cost(const double *cams, double px, double py, double pz, c
 
 }  // namespace ba
 }  // namespace mqs
+
 
 namespace mqs {
 namespace ba {
@@ -393,6 +421,7 @@ MQS_HD void slot_to_out(int slot, int &o1, int &o2)
     o2 = -1;
     if (slot < L::kDiag * C) {
         const int c = slot / L::kDiag, r = slot % L::kDiag;
+        if (r >= L::kDiagUsed) return;
         if (r < 21) {
             int i = 0, rem = r;
             while (rem >= 6 - i) { rem -= 6 - i; ++i; }

@@ -61,6 +61,16 @@ extern "C" int64_t host_eigen_fallbacks(const double *u, const double *P, int C,
 struct FlatEmit {
     double *acc;
     void put(int slot, double v) { acc[slot] += v; }
+    void flush(int) {}
+};
+
+struct HostObs {
+    const double *obs; const uint8_t *mask; int64_t i, N;
+    void get(int c, double &u, double &v, bool &seen) const
+    {
+        u = obs[(c * N + i) * 2]; v = obs[(c * N + i) * 2 + 1];
+        seen = mask ? mask[c * N + i] != 0 : true;
+    }
 };
 
 template <int C> static void ba_lin(const double *poses, const double *calib, const double *sigma, const double *points,
@@ -73,15 +83,11 @@ template <int C> static void ba_lin(const double *poses, const double *calib, co
     std::vector<double> slots(L::kSlots, 0.0);
     FlatEmit em{slots.data()};
     for (int64_t i = 0; i < N; ++i) {
-        double uv[C][2]; bool seen[C];
-        for (int c = 0; c < C; ++c) {
-            uv[c][0] = obs[(c * N + i) * 2]; uv[c][1] = obs[(c * N + i) * 2 + 1];
-            seen[c] = mask ? mask[c * N + i] != 0 : true;
-        }
+        const HostObs ob = {obs, mask, i, N};
         const double pw = prior_w ? prior_w[i] : 0.0;
         double dx = 0, dy = 0, dz = 0;
         if (pw > 0) { dx = points[3 * i] - prior_xyz[3 * i]; dy = points[3 * i + 1] - prior_xyz[3 * i + 1]; dz = points[3 * i + 2] - prior_xyz[3 * i + 2]; }
-        mqs::ba::landmark_contribution<C>(cams, points[3 * i], points[3 * i + 1], points[3 * i + 2], uv, seen, pw, dx, dy, dz, lambda, true, em);
+        mqs::ba::landmark_contribution<C>(cams, ob, points[3 * i], points[3 * i + 1], points[3 * i + 2], pw, dx, dy, dz, lambda, true, em);
     }
     const int n6 = 6 * C;
     for (int k = 0; k < n6 * n6 + n6 + 2; ++k) out[k] = 0;
@@ -100,15 +106,11 @@ template <int C> static void ba_back(const double *poses, const double *calib, c
     double cams[C * mqs::ba::kCamStride];
     for (int c = 0; c < C; ++c) mqs::ba::stage_camera(cams + c * mqs::ba::kCamStride, poses + 12 * c, calib + 9 * c, sigma[c]);
     for (int64_t i = 0; i < N; ++i) {
-        double uv[C][2]; bool seen[C];
-        for (int c = 0; c < C; ++c) {
-            uv[c][0] = obs[(c * N + i) * 2]; uv[c][1] = obs[(c * N + i) * 2 + 1];
-            seen[c] = mask ? mask[c * N + i] != 0 : true;
-        }
+        const HostObs ob = {obs, mask, i, N};
         const double pw = prior_w ? prior_w[i] : 0.0;
         double dx = 0, dy = 0, dz = 0;
         if (pw > 0) { dx = points[3 * i] - prior_xyz[3 * i]; dy = points[3 * i + 1] - prior_xyz[3 * i + 1]; dz = points[3 * i + 2] - prior_xyz[3 * i + 2]; }
-        mqs::Vec3 dp = mqs::ba::landmark_backsub<C>(cams, points[3 * i], points[3 * i + 1], points[3 * i + 2], uv, seen, pw, dx, dy, dz, lambda, dpose);
+        mqs::Vec3 dp = mqs::ba::landmark_backsub<C>(cams, ob, points[3 * i], points[3 * i + 1], points[3 * i + 2], pw, dx, dy, dz, lambda, dpose);
         points_out[3 * i] = points[3 * i] + dp.x; points_out[3 * i + 1] = points[3 * i + 1] + dp.y; points_out[3 * i + 2] = points[3 * i + 2] + dp.z;
     }
 }
