@@ -1,0 +1,120 @@
+"""
+Brute-force matcher facade over the gfx950 kernels (csrc/match.hip) -- counterpart of the
+reference's `cv2_helpers.BFMatcher` (Work/python_libs/cv2_helpers.py:278-345): default
+construction = NORM_L2 without cross-check, `radiusMatch(query, train, maxDistance)` returns per
+query the (at most two) nearest train points within the radius, ascending, as DMatch-like tuples;
+`knnMatch(query, train, k=2)` the two nearest.  Ties go to the lower train index.
+
+`knn2(query, train)` is the array form used by the benchmark: idx (Nq,2) int32, dist (Nq,2) f32.
+float32 inputs take the exact path; float16 inputs (binary descriptors expanded to {0,1}) take the
+MFMA path.  No CPU fallback: a missing library raises RuntimeError.
+"""
+import ctypes
+from collections import namedtuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import c_f32p, c_i32p, c_u16p, c_i64
+
+DMatch = namedtuple("DMatch", ["queryIdx", "trainIdx", "distance"])
+
+NORM_L2 = 4          # cv2.NORM_L2
+
+
+def knn2(query, train):
+    query = np.asarray(query)
+    train = np.asarray(train)
+    if query.ndim != 2 or train.ndim != 2 or query.shape[1] != train.shape[1]:
+        raise ValueError("query (Nq, D) and train (Nt, D) must have the same D")
+    if query.dtype != train.dtype:
+        raise TypeError("query and train must have the same dtype")
+    Nq, D = query.shape
+    Nt = train.shape[0]
+    idx = np.empty((Nq, 2), dtype=np.int32)
+    dist = np.empty((Nq, 2), dtype=np.float32)
+    if query.dtype not in (np.float32, np.float16):
+        raise TypeError("descriptors must be float32 (exact path) or float16 {0,1} (MFMA path), got %s" % query.dtype)
+    ctx = _lib.default_context().handle
+    if query.dtype == np.float32:
+        q = np.ascontiguousarray(query)
+        t = np.ascontiguousarray(train)
+        _lib.check(_lib.lib().mqs_match_knn2_f32(ctx, q.ctypes.data_as(c_f32p), c_i64(Nq), t.ctypes.data_as(c_f32p),
+                                                 c_i64(Nt), int(D), idx.ctypes.data_as(c_i32p),
+                                                 dist.ctypes.data_as(c_f32p)))
+    elif query.dtype == np.float16:
+        q = np.ascontiguousarray(query).view(np.uint16)
+        t = np.ascontiguousarray(train).view(np.uint16)
+        _lib.check(_lib.lib().mqs_match_knn2_f16(ctx, q.ctypes.data_as(c_u16p), c_i64(Nq), t.ctypes.data_as(c_u16p),
+                                                 c_i64(Nt), int(D), idx.ctypes.data_as(c_i32p),
+                                                 dist.ctypes.data_as(c_f32p)))
+    else:
+        raise TypeError("descriptors must be float32 (exact path) or float16 {0,1} (MFMA path), got %s" % query.dtype)
+    return idx, dist
+
+
+def knn2_dev(query, train, out_idx=None, out_dist=None, workspace=None):
+    """Device-resident form: torch tensors (float32 or float16) in, torch tensors out."""
+    import torch
+    if not (query.is_cuda and train.is_cuda and query.is_contiguous() and train.is_contiguous()):
+        raise ValueError("query/train must be contiguous device tensors")
+    if query.dtype != train.dtype or query.dim() != 2 or train.dim() != 2 or query.shape[1] != train.shape[1]:
+        raise ValueError("query (Nq, D) and train (Nt, D) must match in dtype and D")
+    Nq, D = int(query.shape[0]), int(query.shape[1])
+    Nt = int(train.shape[0])
+    idx = out_idx if out_idx is not None else torch.empty((Nq, 2), dtype=torch.int32, device=query.device)
+    dist = out_dist if out_dist is not None else torch.empty((Nq, 2), dtype=torch.float32, device=query.device)
+    sp = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    if query.dtype == torch.float32:
+        _lib.check(_lib.lib().mqs_match_knn2_f32_dev(query.data_ptr(), Nq, train.data_ptr(), Nt, D, idx.data_ptr(),
+                                                     dist.data_ptr(), sp))
+    elif query.dtype == torch.float16:
+        need = int(_lib.lib().mqs_match_knn2_f16_workspace_bytes(Nq, Nt))
+        ws = workspace if workspace is not None else torch.empty(max(need, 16), dtype=torch.uint8, device=query.device)
+        _lib.check(_lib.lib().mqs_match_knn2_f16_dev(query.data_ptr(), Nq, train.data_ptr(), Nt, D, idx.data_ptr(),
+                                                     dist.data_ptr(), ws.data_ptr(), ws.numel(), sp))
+    else:
+        raise TypeError("descriptors must be float32 or float16")
+    return idx, dist
+
+
+class BFMatcher:
+    """cv2.BFMatcher()-shaped object (NORM_L2, no cross-check), cv2_helpers.py:282-345."""
+
+    def __init__(self, normType=NORM_L2, crossCheck=False):
+        if normType != NORM_L2 or crossCheck:
+            raise NotImplementedError("only the reference's configuration (NORM_L2, crossCheck=False) is accelerated")
+        self.normType = normType
+
+    def getInt(self, name):
+        if name == "normType":
+            return self.normType
+        raise KeyError(name)
+
+    def knnMatch(self, query_points, train_points, k=2):
+        if k not in (1, 2):
+            raise NotImplementedError("k must be 1 or 2")
+        idx, dist = knn2(np.asarray(query_points, dtype=np.float32), np.asarray(train_points, dtype=np.float32))
+        return [[DMatch(qi, int(idx[qi, j]), float(dist[qi, j])) for j in range(k) if idx[qi, j] >= 0]
+                for qi in range(len(idx))]
+
+    def radiusMatch(self, query_points, train_points, max_radius, **kwargs):
+        """kNN radius match with k=2 (cv2_helpers.py:296-339)."""
+        idx, dist = knn2(np.asarray(query_points, dtype=np.float32), np.asarray(train_points, dtype=np.float32))
+        return [[DMatch(qi, int(idx[qi, j]), float(dist[qi, j])) for j in range(2)
+                 if idx[qi, j] >= 0 and dist[qi, j] <= max_radius] for qi in range(len(idx))]
+
+
+def binary_descriptors(n, bits=256, seed=7, copies_of=None, copy_frac=0.5, flip_frac=0.1):
+    """SURVEY.md 8(d) matcher workload: n descriptors of `bits` i.i.d. Bernoulli(0.5) bits (PCG64(seed)),
+    optionally with `copy_frac` of the rows being copies of rows of `copies_of` with `flip_frac` of
+    their bits flipped.  Returns a (n, bits) float16 array of {0,1}."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    d = rng.integers(0, 2, size=(n, bits), dtype=np.uint8)
+    if copies_of is not None:
+        m = int(copy_frac * n)
+        rows = rng.choice(n, m, replace=False)
+        src = rng.integers(0, len(copies_of), m)
+        flips = rng.random((m, bits)) < flip_frac
+        d[rows] = np.asarray(copies_of[src], dtype=np.uint8) ^ flips.astype(np.uint8)
+    return d.astype(np.float16)

@@ -1,0 +1,121 @@
+"""Matcher: oracle logic on CPU, and GPU parity (match indices bit-exact: north_star)."""
+import numpy as np
+import pytest
+
+from oracle import matching_np as M
+
+
+def test_oracle_knn2_ties_and_order():
+    t = np.array([[0, 0], [1, 0], [0, 1], [1, 0], [5, 5]], dtype=np.float32)      # rows 1 and 3 identical
+    q = np.array([[1, 0], [0.5, 0.5], [10, 10]], dtype=np.float32)
+    idx, dist = M.knn2(q, t)
+    assert idx[0].tolist() == [1, 3] and dist[0].tolist() == [0.0, 0.0]              # tie -> lower index first
+    assert idx[1].tolist() == [0, 1]                                                  # three-way tie at sqrt(.5)
+    assert idx[2, 0] == 4
+    i1, d1 = M.knn2(q, t[:1])
+    assert i1[:, 1].tolist() == [-1, -1, -1] and np.isinf(d1[:, 1]).all()
+
+
+def test_oracle_radius_match_and_ratio_test():
+    rng = np.random.default_rng(0)
+    t = rng.uniform(0, 640, (300, 2)).astype(np.float32)
+    q = t[:100] + rng.normal(0, 0.7, (100, 2)).astype(np.float32)
+    ms = M.radius_match(q, t, 2.0)
+    assert len(ms) == 100 and all(len(m) <= 2 for m in ms)
+    assert all(m[0].distance <= 2.0 for m in ms if m)
+    assert all(m[0].distance <= m[1].distance for m in ms if len(m) == 2)
+    best = M.ratio_test_and_dedupe(ms, err=rng.random(100))
+    assert len(set(best.keys())) == len(best)
+
+
+def test_facade_validation(mqs):
+    with pytest.raises(ValueError):
+        mqs.matching.knn2(np.zeros((3, 2), np.float32), np.zeros((3, 3), np.float32))
+    with pytest.raises(TypeError):
+        mqs.matching.knn2(np.zeros((3, 2), np.float64), np.zeros((3, 2), np.float64))
+    with pytest.raises(NotImplementedError):
+        mqs.matching.BFMatcher(normType=6)
+    d = mqs.matching.binary_descriptors(100, 256, seed=3)
+    assert d.dtype == np.float16 and set(np.unique(d)) <= {0.0, 1.0}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(1, 1, 2), (5, 1, 2), (300, 1000, 2), (257, 513, 2), (1000, 300, 3), (64, 5000, 7),
+                                   (100, 100, 32), (33, 70, 130)])
+def test_f32_path_bit_exact(shape, gpu):
+    Nq, Nt, D = shape
+    rng = np.random.default_rng(Nq + Nt + D)
+    t = np.rint(rng.uniform(0, 64, (Nt, D))).astype(np.float32)            # integer grid: many exact ties
+    q = (t[rng.integers(0, Nt, Nq)] + np.rint(rng.normal(0, 1.2, (Nq, D)))).astype(np.float32)
+    idx, dist = gpu.matching.knn2(q, t)
+    io, do = M.knn2(q, t)
+    np.testing.assert_array_equal(idx, io)                                  # indices bit-exact incl. tie-breaks
+    np.testing.assert_array_equal(dist, do)                                 # and distances bit-exact
+    q2 = rng.uniform(0, 640, (Nq, D)).astype(np.float32)
+    t2 = rng.uniform(0, 640, (Nt, D)).astype(np.float32)
+    idx, dist = gpu.matching.knn2(q2, t2)
+    io, do = M.knn2(q2, t2)
+    np.testing.assert_array_equal(idx, io)
+    np.testing.assert_array_equal(dist, do)
+
+
+@pytest.mark.gpu
+def test_reference_shaped_radius_match(gpu):
+    """slam.py:101-125 usage: pixel coordinates, radius 2 / 4 px, ratio test + de-duplication."""
+    rng = np.random.default_rng(5)
+    fast = rng.uniform(0, 640, (800, 2)).astype(np.float32)
+    flow = fast[rng.integers(0, 800, 400)] + rng.normal(0, 0.8, (400, 2)).astype(np.float32)
+    m = gpu.matching.BFMatcher()
+    for radius in (2.0, 4.0):
+        got = m.radiusMatch(flow, fast, radius)
+        ref = M.radius_match(flow, fast, radius)
+        assert [[(x.queryIdx, x.trainIdx, x.distance) for x in ms] for ms in got] == \
+               [[(x.queryIdx, x.trainIdx, x.distance) for x in ms] for ms in ref]
+    err = rng.random(400)
+    assert M.ratio_test_and_dedupe(got, err).keys() == M.ratio_test_and_dedupe(ref, err).keys()
+    assert [len(x) for x in m.knnMatch(flow[:5], fast, k=1)] == [1] * 5
+    assert m.knnMatch(flow[:3], fast[:0]) == [[], [], []]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(1, 1, 256), (70, 5, 256), (256, 64, 256), (1000, 3000, 256), (513, 1029, 128),
+                                   (300, 700, 64), (300, 700, 32), (200, 500, 512)])
+def test_f16_mfma_path_bit_exact(shape, gpu):
+    Nq, Nt, D = shape
+    tb = gpu.matching.binary_descriptors(Nt, D, seed=8)
+    qb = gpu.matching.binary_descriptors(Nq, D, seed=9, copies_of=tb.astype(np.uint8))
+    idx, dist = gpu.matching.knn2(qb, tb)
+    io, do = M.knn2_hamming_bits(qb, tb)
+    np.testing.assert_array_equal(idx, io)
+    np.testing.assert_array_equal(dist, do)
+    # the exact float32 path agrees with the MFMA path on the same data
+    i32, d32 = gpu.matching.knn2(qb.astype(np.float32), tb.astype(np.float32))
+    np.testing.assert_array_equal(i32, idx)
+    np.testing.assert_array_equal(d32, dist)
+
+
+@pytest.mark.gpu
+def test_f16_full_size_properties_64k(gpu):
+    """BASELINE configs[2]: 65 536 x 65 536 x 256 bits, one camera pair.  Properties: planted copies are
+    found (a copy with 10 % flipped bits is nearer than any random descriptor), a sampled set of
+    rows equals the oracle, self-match returns identity with distance 0, and determinism."""
+    import torch
+    N, D = 65536, 256
+    tb = gpu.matching.binary_descriptors(N, D, seed=7)
+    qb = gpu.matching.binary_descriptors(N, D, seed=8, copies_of=tb.astype(np.uint8))
+    q = torch.from_numpy(qb).cuda()
+    t = torch.from_numpy(tb).cuda()
+    idx, dist = gpu.matching.knn2_dev(q, t)
+    idx2, dist2 = gpu.matching.knn2_dev(q, t)
+    torch.cuda.synchronize()
+    assert torch.equal(idx, idx2) and torch.equal(dist, dist2)
+    idx, dist = idx.cpu().numpy(), dist.cpu().numpy()
+    sample = np.random.default_rng(1).choice(N, 300, replace=False)
+    io, do = M.knn2_hamming_bits(qb[sample], tb)
+    np.testing.assert_array_equal(idx[sample], io)
+    np.testing.assert_array_equal(dist[sample], do)
+    assert (dist[:, 0] <= dist[:, 1]).all() and (idx >= 0).all() and (idx < N).all()
+    assert np.mean(dist[:, 0] ** 2 < 60) > 0.45          # ~half are planted copies at Hamming ~ 26
+    si, sd = gpu.matching.knn2_dev(t, t)
+    torch.cuda.synchronize()
+    assert torch.equal(si[:, 0].cpu(), torch.arange(N, dtype=torch.int32)) and float(sd[:, 0].abs().max()) == 0.0
