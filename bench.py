@@ -44,6 +44,8 @@ def main():
     ap.add_argument("--cams", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ba", action="store_true")
+    ap.add_argument("--no-match", action="store_true")
+    ap.add_argument("--descriptors", type=int, default=65536)
     args = ap.parse_args()
 
     import numpy as np
@@ -53,19 +55,14 @@ def main():
     if not mqslam_amd.loaded:
         raise SystemExit("libmqslam_hip.so is not available: %r" % (mqslam_amd._lib.load_error,))
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    rank, local_rank, world = mqslam_amd.sharding.init_from_env(backend="nccl")
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
         args.gpus = world
-    dist = None
     if world > 1:
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank if world > 1 else 0)
@@ -149,6 +146,33 @@ def main():
     if ba is not None:
         ba_out = ba.benchmark_report(world, dist)
 
+    # ---- matcher (BASELINE configs[2]): one 65 536 x 65 536 x 256-bit camera pair, rank 0 reports ----
+    match_out = None
+    if not args.no_match:
+        Mm = mqslam_amd.matching
+        nd, bits = args.descriptors, 256
+        tb = Mm.binary_descriptors(nd, bits, seed=7)
+        qb = Mm.binary_descriptors(nd, bits, seed=8 + rank, copies_of=tb.astype(np.uint8))
+        qd, td = torch.from_numpy(qb).to(dev), torch.from_numpy(tb).to(dev)
+        mi = torch.empty((nd, 2), dtype=torch.int32, device=dev)
+        md = torch.empty((nd, 2), dtype=torch.float32, device=dev)
+        mws = torch.empty(int(mqslam_amd._lib.lib().mqs_match_knn2_f16_workspace_bytes(nd, nd)), dtype=torch.uint8,
+                          device=dev)
+        Mm.knn2_dev(qd, td, mi, md, mws)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            Mm.knn2_dev(qd, td, mi, md, mws)
+        e1.record()
+        e1.synchronize()
+        ms_pair = e0.elapsed_time(e1) / 5
+        tf = 2.0 * nd * nd * bits / (ms_pair * 1e-3) / 1e12
+        match_out = {"workload": "%d x %d descriptors x %d bits as {0,1} fp16, kNN-2, one camera pair per GPU" % (nd, nd, bits),
+                     "ms_per_pair": round(ms_pair, 3), "query_rows_per_s": round(nd / (ms_pair * 1e-3)),
+                     "TFLOPs": round(tf, 1), "mfma_f16_dense_peak_TFLOPs": 2500.0, "frac_of_peak": round(tf / 2500.0, 4)}
+        del qd, td, mi, md, mws
+
     # ---- CPU baseline: the oracle's C port of the reference kernel, rank 0, N = 1 only ----
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -168,7 +192,21 @@ def main():
         # parity gate run with the benchmark: GPU result vs the baseline's
         xg = x_it[:ns].cpu().numpy()
         rel = np.linalg.norm(xg - xo, axis=1) / np.maximum(np.linalg.norm(xo, axis=1), 1.0)
-        cpu = {"value": round(ns / t_cpu), "unit": "landmarks/s", "cores": 1, "kind": "port",
+        ba_cpu = None
+        if ba is not None:
+            h = lambda t: t.cpu().numpy()
+            nb = min(N, 200_000)
+            bargs = (h(ba.poses), h(ba.calib), h(ba.sigma), h(ba.points[:nb]), np.ascontiguousarray(h(ba.obs)[:, :nb]))
+            t0 = time.perf_counter()
+            So, go, co, nvo = c_oracle.ba_linearize(*bargs, None, h(ba.prior_w[:nb]), h(ba.prior_xyz[:nb]), 0.0, use_omp=True)
+            dpo = np.linalg.solve(So + 1e-9 * np.eye(len(go)), go)
+            c_oracle.ba_backsub(*bargs, dpo, None, h(ba.prior_w[:nb]), h(ba.prior_xyz[:nb]), 0.0, use_omp=True)
+            t_ba = time.perf_counter() - t0
+            ba_cpu = {"gn_iters_per_s_at_1e6": round(1.0 / (t_ba * N / nb), 3), "cores": os.cpu_count(), "kind": "port",
+                      "sample": "1 GN iteration (linearise + Schur + solve + back-substitute) on %d landmarks x %d cams, "
+                                "oracle/c/ba_oracle.c with OpenMP on all host cores, scaled linearly to %d landmarks "
+                                "(CPU restatement, not GTSAM)" % (nb, C, N)}
+        cpu = {"value": round(ns / t_cpu), "unit": "landmarks/s", "cores": 1, "kind": "port", "ba": ba_cpu,
                "sample": "linear-LS + iterative-LS over %d landmarks x %d cams (the same arrays), 1 pass, "
                          "oracle/c/tri_oracle.c, gcc -O2, single thread as the reference ships it" % (ns, C),
                "all_cores": {"value": round(ns / t_omp), "cores": os.cpu_count(),
@@ -187,7 +225,7 @@ def main():
             "config": {"workload": "BASELINE configs[1]: %d landmarks x %d cameras per GPU, linear-LS + "
                                    "iterative-LS (tol 3e-5, <=10 iterations)" % (N, C),
                        "landmarks_per_gpu": N, "cameras": C, "sharding": "landmarks, %d-way" % world},
-            "roofline": roofline, "kernels": kernels, "ba": ba_out, "cpu_baseline": cpu,
+            "roofline": roofline, "kernels": kernels, "ba": ba_out, "match": match_out, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
     if dist is not None:

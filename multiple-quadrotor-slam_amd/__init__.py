@@ -11,5 +11,6 @@ from . import synthetic                  # noqa: F401
 from . import device                     # noqa: F401
 from . import bundle_adjustment          # noqa: F401
 from . import matching                   # noqa: F401
+from . import sharding                   # noqa: F401
 
 loaded = _lib.loaded

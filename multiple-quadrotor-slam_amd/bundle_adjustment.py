@@ -25,6 +25,7 @@ import time
 import numpy as np
 
 from . import _lib
+from . import sharding
 
 # LevenbergMarquardtParams defaults of GTSAM 3.2.1 [SURVEY.md 8(a) B4]
 LM_LAMBDA_INITIAL = 1e-5
@@ -119,8 +120,7 @@ class BundleAdjuster:
 
     def all_reduce(self):
         if self.pg is not None:
-            import torch.distributed as dist
-            dist.all_reduce(self.lin, op=dist.ReduceOp.SUM, group=self.pg if self.pg is not True else None)
+            sharding.all_reduce_sum_(self.lin, None if self.pg is True else self.pg)
 
     def solve(self, lam=0.0, retract_into=None):
         out = self.poses_new if retract_into is None else retract_into

@@ -68,3 +68,37 @@ def linear_eigen_triangulation(u, P, max_coordinate_value=1.e16, use_omp=False):
                                 ctypes.c_double(max_coordinate_value), _p(x, _f64p), _p(ok, _u8p), int(use_omp))
     assert rc == 0
     return x, ok.astype(bool)
+
+
+def _opt(a, t):
+    return None if a is None else _p(a, t)
+
+
+def ba_linearize(poses, calib, sigma, points, obs, mask=None, prior_w=None, prior_xyz=None, lam=0.0, use_omp=False):
+    """C restatement of oracle/ba_np.linearize: returns S, g, cost, nvalid."""
+    C, N = obs.shape[0], obs.shape[1]
+    arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in (poses, calib, sigma, points, obs)]
+    m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+    pw = None if prior_w is None else np.ascontiguousarray(prior_w, dtype=np.float64)
+    px = None if prior_xyz is None else np.ascontiguousarray(prior_xyz, dtype=np.float64)
+    n6 = 6 * C
+    out = np.zeros(n6 * n6 + n6 + 2)
+    rc = lib().orc_ba_linearize(_p(arrs[0], _f64p), _p(arrs[1], _f64p), _p(arrs[2], _f64p), C, _p(arrs[3], _f64p),
+                                _p(arrs[4], _f64p), _opt(m, _u8p), _opt(pw, _f64p), _opt(px, _f64p), ctypes.c_int64(N),
+                                ctypes.c_double(lam), _p(out, _f64p), int(use_omp))
+    assert rc == 0
+    return out[:n6 * n6].reshape(n6, n6), out[n6 * n6:n6 * n6 + n6], out[-2], int(out[-1])
+
+
+def ba_backsub(poses, calib, sigma, points, obs, dpose, mask=None, prior_w=None, prior_xyz=None, lam=0.0, use_omp=False):
+    C, N = obs.shape[0], obs.shape[1]
+    arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in (poses, calib, sigma, points, obs, dpose)]
+    m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+    pw = None if prior_w is None else np.ascontiguousarray(prior_w, dtype=np.float64)
+    px = None if prior_xyz is None else np.ascontiguousarray(prior_xyz, dtype=np.float64)
+    out = np.empty((N, 3))
+    rc = lib().orc_ba_backsub(_p(arrs[0], _f64p), _p(arrs[1], _f64p), _p(arrs[2], _f64p), C, _p(arrs[3], _f64p),
+                              _p(arrs[4], _f64p), _opt(m, _u8p), _opt(pw, _f64p), _opt(px, _f64p), ctypes.c_int64(N),
+                              ctypes.c_double(lam), _p(arrs[5], _f64p), _p(out, _f64p), int(use_omp))
+    assert rc == 0
+    return out

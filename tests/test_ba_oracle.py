@@ -58,3 +58,24 @@ def test_cheirality_convention():
     e, Jp, Jl, ok = ba_np.factor(sc["poses"][0], sc["calib"][0], 2.0, sc["points"][0], sc["obs"][0, 0])
     assert not ok and np.all(Jp == 0) and np.all(Jl == 0)
     np.testing.assert_allclose(e, np.full(2, 2 * 480.0) / 2.0)
+
+
+@pytest.mark.parametrize("kw", [dict(N=60, C=2), dict(N=80, C=4, distortion=True, masked_frac=0.3), dict(N=50, C=4, behind=5),
+                                dict(N=40, C=6, distortion=True)])
+def test_c_oracle_matches_numpy_oracle(kw, c_oracle):
+    kw = dict(kw)
+    N, C = kw.pop("N"), kw.pop("C")
+    sc = make_scene(N, C, seed=N, **kw)
+    for lam in (0.0, 1e-2):
+        S, g, cost, nv, pieces = ba_np.linearize(sc["poses"], sc["calib"], sc["sigma"], sc["points"], sc["obs"],
+                                                 sc["mask"], sc["prior_w"], sc["prior_xyz"], lam)
+        for omp in (False, True):
+            Sc, gc, cc, nvc = c_oracle.ba_linearize(sc["poses"], sc["calib"], sc["sigma"], sc["points"], sc["obs"],
+                                                    sc["mask"], sc["prior_w"], sc["prior_xyz"], lam, use_omp=omp)
+            assert np.abs(Sc - S).max() <= 1e-11 * np.abs(S).max()
+            assert np.abs(gc - g).max() <= 1e-11 * np.abs(g).max()
+            assert cc == pytest.approx(cost, rel=1e-12) and nvc == nv
+        dpose = np.linalg.solve(S + 1e-3 * np.diag(np.diag(S)), g)
+        po = c_oracle.ba_backsub(sc["poses"], sc["calib"], sc["sigma"], sc["points"], sc["obs"], dpose, sc["mask"],
+                                 sc["prior_w"], sc["prior_xyz"], lam)
+        np.testing.assert_allclose(po, sc["points"] + ba_np.backsub(pieces, dpose), atol=1e-9)
