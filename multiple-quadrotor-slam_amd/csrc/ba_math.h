@@ -130,6 +130,56 @@ MQS_HD void make_Jg(double x, double y, double Z, double Jg[2][6])
     Jg[1][3] = 0.0;                Jg[1][4] = -1.0;                Jg[1][5] = y;
 }
 
+// The geometric Jacobian is Jg = [A | B] with A = Z [[xy, -(1+x^2), y], [1+y^2, -xy, -x]] and
+// B = [[-1, 0, x], [0, -1, y]]: columns 3 and 4 are minus unit vectors.  The block products below use
+// that structure instead of multiplying by the literal 0 / -1 entries (which the compiler may not
+// fold without fast-math): rows 3 and 4 of Jg^T T are just -T[0][:] and -T[1][:].
+struct JgA { double a00, a01, a02, a10, a11, a12, x, y; };
+
+MQS_HD JgA make_JgA(double x, double y, double Z)
+{
+    JgA j;
+    j.a00 = Z * x * y;          j.a01 = -Z * fma(x, x, 1.0); j.a02 = Z * y;
+    j.a10 = Z * fma(y, y, 1.0); j.a11 = -Z * x * y;          j.a12 = -Z * x;
+    j.x = x; j.y = y;
+    return j;
+}
+
+// T = k Jg (2x6) for a general 2x2 k = [[k00,k01],[k10,k11]]
+MQS_HD void k_times_Jg(double k00, double k01, double k10, double k11, const JgA &j, double T[2][6])
+{
+    T[0][0] = fma(k00, j.a00, k01 * j.a10); T[0][1] = fma(k00, j.a01, k01 * j.a11); T[0][2] = fma(k00, j.a02, k01 * j.a12);
+    T[1][0] = fma(k10, j.a00, k11 * j.a10); T[1][1] = fma(k10, j.a01, k11 * j.a11); T[1][2] = fma(k10, j.a02, k11 * j.a12);
+    T[0][3] = -k00; T[0][4] = -k01; T[0][5] = fma(k00, j.x, k01 * j.y);
+    T[1][3] = -k10; T[1][4] = -k11; T[1][5] = fma(k10, j.x, k11 * j.y);
+}
+
+// entry (i, jj) of Jg^T T
+MQS_HD double JgT_T(const JgA &j, const double T[2][6], int i, int jj)
+{
+    switch (i) {
+    case 0: return fma(j.a00, T[0][jj], j.a10 * T[1][jj]);
+    case 1: return fma(j.a01, T[0][jj], j.a11 * T[1][jj]);
+    case 2: return fma(j.a02, T[0][jj], j.a12 * T[1][jj]);
+    case 3: return -T[0][jj];
+    case 4: return -T[1][jj];
+    default: return fma(j.x, T[0][jj], j.y * T[1][jj]);
+    }
+}
+
+// entry i of Jg^T r for a 2-vector r
+MQS_HD double JgT_r(const JgA &j, double r0, double r1, int i)
+{
+    switch (i) {
+    case 0: return fma(j.a00, r0, j.a10 * r1);
+    case 1: return fma(j.a01, r0, j.a11 * r1);
+    case 2: return fma(j.a02, r0, j.a12 * r1);
+    case 3: return -r0;
+    case 4: return -r1;
+    default: return fma(j.x, r0, j.y * r1);
+    }
+}
+
 // Landmark block and its Cholesky factor.
 struct PointSystem {
     Sym3 H;      // Hll (with prior and damping)
@@ -292,47 +342,37 @@ MQS_HD void landmark_contribution(const double *cams, const Obs &obs, double px,
         const double rh0 = -fc.f0 - fma(Uh[c][0][0], w0, fma(Uh[c][0][1], w1, Uh[c][0][2] * w2));
         const double rh1 = -fc.f1 - fma(Uh[c][1][0], w0, fma(Uh[c][1][1], w1, Uh[c][1][2] * w2));
         MQS_SCHED_FENCE();
-        double Jg[2][6];
-        make_Jg(cx[c], cy[c], cZ[c], Jg);
+        const JgA jg = make_JgA(cx[c], cy[c], cZ[c]);
         double T[2][6];                           // T = k Jg
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            T[0][j] = fma(k00, Jg[0][j], k01 * Jg[1][j]);
-            T[1][j] = fma(k01, Jg[0][j], k11 * Jg[1][j]);
-        }
+        k_times_Jg(k00, k01, k01, k11, jg, T);
         int slot = L::diag_off(c);
 #pragma unroll
         for (int i = 0; i < 6; ++i)
 #pragma unroll
-            for (int j = i; j < 6; ++j) em.put(slot++, fma(Jg[0][i], T[0][j], Jg[1][i] * T[1][j]));
+            for (int j = i; j < 6; ++j) em.put(slot++, JgT_T(jg, T, i, j));
 #pragma unroll
-        for (int i = 0; i < 6; ++i) em.put(slot++, fma(Jg[0][i], rh0, Jg[1][i] * rh1));
+        for (int i = 0; i < 6; ++i) em.put(slot++, JgT_r(jg, rh0, rh1, i));
         em.flush(L::diag_off(c) >> 5);            // the camera's window (5 unused entries)
         MQS_SCHED_FENCE();
     }
     // ---- off-diagonal blocks: S_cd = -Jg_c^T (Uh_c Uh_d^T) Jg_d ----
 #pragma unroll
     for (int c = 0; c < C; ++c) {
-        double Jc[2][6];
-        make_Jg(cx[c], cy[c], cZ[c], Jc);
+        const JgA jc = make_JgA(cx[c], cy[c], cZ[c]);
 #pragma unroll
         for (int d = c + 1; d < C; ++d) {
             const double k00 = -fma(Uh[c][0][0], Uh[d][0][0], fma(Uh[c][0][1], Uh[d][0][1], Uh[c][0][2] * Uh[d][0][2]));
             const double k01 = -fma(Uh[c][0][0], Uh[d][1][0], fma(Uh[c][0][1], Uh[d][1][1], Uh[c][0][2] * Uh[d][1][2]));
             const double k10 = -fma(Uh[c][1][0], Uh[d][0][0], fma(Uh[c][1][1], Uh[d][0][1], Uh[c][1][2] * Uh[d][0][2]));
             const double k11 = -fma(Uh[c][1][0], Uh[d][1][0], fma(Uh[c][1][1], Uh[d][1][1], Uh[c][1][2] * Uh[d][1][2]));
-            double Jd[2][6], T[2][6];
-            make_Jg(cx[d], cy[d], cZ[d], Jd);
-#pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                T[0][j] = fma(k00, Jd[0][j], k01 * Jd[1][j]);
-                T[1][j] = fma(k10, Jd[0][j], k11 * Jd[1][j]);
-            }
+            const JgA jd = make_JgA(cx[d], cy[d], cZ[d]);
+            double T[2][6];
+            k_times_Jg(k00, k01, k10, k11, jd, T);
             int slot = L::pair_off(c, d);
 #pragma unroll
             for (int i = 0; i < 6; ++i)
 #pragma unroll
-                for (int j = 0; j < 6; ++j) em.put(slot++, fma(Jc[0][i], T[0][j], Jc[1][i] * T[1][j]));
+                for (int j = 0; j < 6; ++j) em.put(slot++, JgT_T(jc, T, i, j));
             MQS_SCHED_FENCE();
         }
     }
