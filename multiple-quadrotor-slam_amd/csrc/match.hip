@@ -81,8 +81,18 @@ __global__ __launch_bounds__(kBlock) void knn2_f32_kernel(const float *__restric
 using half8 = __attribute__((ext_vector_type(8))) _Float16;
 using float16v = __attribute__((ext_vector_type(16))) float;
 
+#ifndef MQS_MATCH_AHEAD
+#define MQS_MATCH_AHEAD 4
+#endif
 constexpr int kStageRows = 64;                         // train rows per LDS stage (2 MFMA row tiles)
-constexpr unsigned kInvalidD2 = 2048;                  // sentinel squared distance of padding rows
+// Key = (|t|^2 + kBias - 2 q.t) << 20 | train index.  |q|^2 is constant per lane (one query per
+// lane), so it is left out of the running comparison and added back at the end; kBias keeps the
+// biased distance non-negative (q.t <= |t|^2 <= D <= 512).  Valid rows: <= 1024; padding rows
+// (|t|^2 := kPadNorm): in [2560, 3584]; 12 bits suffice.
+constexpr unsigned kBias = 512;
+constexpr unsigned kPadNorm = 3072;
+constexpr unsigned kInvalidD2 = 2048;                  // biased distances >= this are padding rows
+constexpr float kKeyScale = 1048576.0f;                // 2^20: float -> u32 conversion yields d2 << 20
 constexpr unsigned kIdxBits = 20;
 
 // squared norms (exact for {0,1} data): one thread per row
@@ -108,13 +118,14 @@ __global__ __launch_bounds__(kBlock) void knn2_f16_kernel(const _Float16 *__rest
                                                           int32_t *__restrict__ idx, float *__restrict__ dist)
 {
     constexpr int D = KS * 16;
-    constexpr int kRowBytes = D * 2 + 16;              // +16 B pad: ds_read_b128 of 32 rows conflict-free
+    constexpr int kRowBytes = D * 2;                   // unpadded: the LDS image is filled by LDS-DMA
     constexpr int kStageBytes = kStageRows * kRowBytes;
     constexpr int kVecPerRow = D * 2 / 16;             // 16-byte pieces per row
     constexpr int kVecPerThread = kStageRows * kVecPerRow / kBlock;
+    constexpr int kSwzMask = (kVecPerRow < 32 ? kVecPerRow : 32) - 1;   // XOR swizzle of the 16-B column
     static_assert(kStageRows * kVecPerRow % kBlock == 0, "stage must divide over the workgroup");
     __shared__ __attribute__((aligned(16))) unsigned char sTile[2 * kStageBytes];
-    __shared__ float sTn[2 * kStageRows];
+    __shared__ __attribute__((aligned(16))) float sTn[3 * kStageRows];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -142,77 +153,120 @@ __global__ __launch_bounds__(kBlock) void knn2_f16_kernel(const _Float16 *__rest
 
     const int64_t nstages = (Nt + kStageRows - 1) / kStageRows;
     const uint4 *tvec = reinterpret_cast<const uint4 *>(train);
-    const int64_t total_vec = Nt * kVecPerRow;
 
-    uint4 stage_regs[kVecPerThread];
-    auto stage_load = [&](int64_t s) {
+    // Stage fill by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write).  One
+    // wave-instruction writes 64 x 16 B = 1 KiB of LDS linearly (wave-uniform base + lane * 16), so
+    // the swizzle that makes the fragment reads bank-conflict free is applied to the per-lane
+    // SOURCE address: LDS piece (row, c') holds global piece (row, c' ^ (row & kSwzMask)); the
+    // reader applies the same XOR.  Rows past Nt re-read the last row (their |t|^2 sentinel keeps
+    // them out of the result).  Norms go to a 3-deep ring: a tile's scan runs one tile late.
+    auto stage_issue = [&](int64_t s) {
+        const int buf = (int)(s & 1);
 #pragma unroll
         for (int i = 0; i < kVecPerThread; ++i) {
-            const int64_t v = s * (kStageRows * kVecPerRow) + tid + i * kBlock;
-            stage_regs[i] = (v < total_vec) ? tvec[v] : make_uint4(0, 0, 0, 0);
-        }
-    };
-    auto stage_store = [&](int64_t s, int buf) {
-#pragma unroll
-        for (int i = 0; i < kVecPerThread; ++i) {
-            const int v = tid + i * kBlock;
-            const int row = v / kVecPerRow, col = v % kVecPerRow;
-            *reinterpret_cast<uint4 *>(sTile + buf * kStageBytes + row * kRowBytes + col * 16) = stage_regs[i];
+            const int piece0 = (i * 4 + wave) * 64;               // first 16-B piece of this wave-instruction
+            const int v = piece0 + lane;
+            const int row = v / kVecPerRow, colp = v % kVecPerRow;
+            const int col = colp ^ (row & kSwzMask);
+            int64_t grow = s * kStageRows + row;
+            grow = grow < Nt ? grow : Nt - 1;
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(tvec + grow * kVecPerRow + col),
+                (__attribute__((address_space(3))) void *)(sTile + buf * kStageBytes + piece0 * 16), 16, 0, 0);
         }
         if (tid < kStageRows) {
             const int64_t t = s * kStageRows + tid;
-            sTn[buf * kStageRows + tid] = (t < Nt) ? tnorm[t] : (float)kInvalidD2;
+            // (|t|^2 + kBias) * 2^20: the scan computes  key = u32(acc * (-2 * 2^20) + this) | index
+            sTn[(s % 3) * kStageRows + tid] = (((t < Nt) ? tnorm[t] : (float)kPadNorm) + (float)kBias) * kKeyScale;
         }
     };
 
-    stage_load(0);
-    stage_store(0, 0);
-    __syncthreads();
-
-    for (int64_t s = 0; s < nstages; ++s) {
-        const int buf = (int)(s & 1);
-        if (s + 1 < nstages) stage_load(s + 1);
-        const unsigned char *tile = sTile + buf * kStageBytes;
+    // MFMAs of tile (s, tt) into `acc`, interleaved one-for-one with the top-2 scan of the PREVIOUS
+    // tile's accumulators `prev` (32 MFMAs, 32 values): the scan's ~6 VALU instructions per value
+    // issue in the shadow of the MFMA they are paired with instead of after the tile.
+    auto tile_step = [&](const unsigned char *tile, int tt, float16v (&acc)[QT], const float16v (&prev)[QT],
+                         const float *ptn, unsigned pbase) {
 #pragma unroll
-        for (int tt = 0; tt < kStageRows / 32; ++tt) {
-            float16v acc[QT];
+        for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
-            for (int qt = 0; qt < QT; ++qt)
+            for (int e = 0; e < 16; ++e) acc[qt][e] = 0.0f;
+        const unsigned char *arow = tile + (tt * 32 + r) * kRowBytes;
+        const int swz = r & kSwzMask;                         // (tt * 32 + r) & kSwzMask
+        float tnv[16];
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc[qt][e] = 0.0f;
-            const unsigned char *arow = tile + (tt * 32 + r) * kRowBytes + h * 16;
+        for (int g = 0; g < 4; ++g) {
+            const float4 t4 = *reinterpret_cast<const float4 *>(ptn + 8 * g);
+            tnv[4 * g] = t4.x; tnv[4 * g + 1] = t4.y; tnv[4 * g + 2] = t4.z; tnv[4 * g + 3] = t4.w;
+        }
+        constexpr int kSteps = KS * QT;                       // MFMAs in this tile
+        constexpr int kVals = 16 * QT;                        // values to scan from the previous tile
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const half8 a = *reinterpret_cast<const half8 *>(arow + ks * 32);
+        for (int ks = 0; ks < KS; ++ks) {
+            const half8 a = *reinterpret_cast<const half8 *>(arow + (((2 * ks + h) ^ swz) << 4));
 #pragma unroll
-                for (int qt = 0; qt < QT; ++qt)
-                    acc[qt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qf[qt][ks], acc[qt], 0, 0, 0);
-            }
-            // epilogue: this lane's 16 train rows of the tile: row(e) = (e & 3) + 8 (e >> 2) + 4 h
-            const float *tn = sTn + buf * kStageRows + tt * 32 + 4 * h;
-            const unsigned ibase = (unsigned)(s * kStageRows + tt * 32 + 4 * h);
+            for (int qt = 0; qt < QT; ++qt) {
+                acc[qt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qf[qt][ks], acc[qt], 0, 0, 0);
+                // scan values [v0, v1) of the previous tile behind this MFMA
+                const int step = ks * QT + qt;
+                const int v0 = step * kVals / kSteps, v1 = (step + 1) * kVals / kSteps;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 tn4 = *reinterpret_cast<const float4 *>(tn + 8 * g);
-                const float tnv[4] = {tn4.x, tn4.y, tn4.z, tn4.w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const unsigned id = ibase + 8 * g + e;
-#pragma unroll
-                    for (int qt = 0; qt < QT; ++qt) {
-                        const float d2 = fmaf(-2.0f, acc[qt][4 * g + e], tnv[e] + qn[qt]);
-                        const unsigned key = ((unsigned)d2 << kIdxBits) | id;
-                        second[qt] = max(best[qt], min(second[qt], key));     // = med3 (best <= second)
-                        best[qt] = min(best[qt], key);
-                    }
+                for (int v = v0; v < v1; ++v) {
+                    const int pq = v / 16, e = v % 16;        // row(e) = (e & 3) + 8 (e >> 2) + 4 h
+                    const float kf = fmaf(prev[pq][e], -2.0f * kKeyScale, tnv[e]);
+                    const unsigned key = (unsigned)kf | (pbase + 8 * (e >> 2) + (e & 3));
+                    unsigned m;
+                    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(m) : "v"(best[pq]), "v"(second[pq]), "v"(key));
+                    second[pq] = m;
+                    best[pq] = min(best[pq], key);
                 }
             }
         }
-        if (s + 1 < nstages) stage_store(s + 1, buf ^ 1);
+    };
+
+    // slot 2 of the norm ring doubles as the "no previous tile" source for the very first step
+    if (tid < kStageRows) sTn[2 * kStageRows + tid] = ((float)kPadNorm + (float)kBias) * kKeyScale;
+    if (nstages > 0) stage_issue(0);                     // Nt == 0: nothing to read, every key stays invalid
+    __syncthreads();                                     // (waits for the LDS-DMA: vmcnt(0) + barrier)
+
+    float16v accA[QT], accB[QT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) accB[qt][e] = 0.0f;
+    const float *ptn = sTn + 2 * kStageRows + 4 * h;     // pending tile = none (all padding)
+    unsigned pbase = 4 * h;
+
+    for (int64_t s = 0; s < nstages; ++s) {
+        if (s + 1 < nstages) stage_issue(s + 1);          // lands while this stage is computed
+        const unsigned char *tile = sTile + (int)(s & 1) * kStageBytes;
+        const float *tn0 = sTn + (int)(s % 3) * kStageRows + 4 * h;
+        const unsigned base0 = (unsigned)(s * kStageRows) + 4 * h;
+        tile_step(tile, 0, accA, accB, ptn, pbase);       // tile 2s   <- scan of tile 2s-1
+        tile_step(tile, 1, accB, accA, tn0, base0);       // tile 2s+1 <- scan of tile 2s
+        ptn = tn0 + 32;
+        pbase = base0 + 32;
         __syncthreads();
     }
+    // scan of the last tile
+    if (nstages > 0) {
+        float tnv[16];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 t4 = *reinterpret_cast<const float4 *>(ptn + 8 * g);
+            tnv[4 * g] = t4.x; tnv[4 * g + 1] = t4.y; tnv[4 * g + 2] = t4.z; tnv[4 * g + 3] = t4.w;
+        }
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float kf = fmaf(accB[qt][e], -2.0f * kKeyScale, tnv[e]);
+                const unsigned key = (unsigned)kf | (pbase + 8 * (e >> 2) + (e & 3));
+                second[qt] = max(best[qt], min(second[qt], key));
+                best[qt] = min(best[qt], key);
+            }
+    }
 
-    // merge the two half-waves (same query, disjoint train rows) and write
+    // merge the two half-waves (same query, disjoint train rows), undo the bias, write
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
         const unsigned ob = __shfl_xor(best[qt], 32), os = __shfl_xor(second[qt], 32);
@@ -224,8 +278,8 @@ __global__ __launch_bounds__(kBlock) void knn2_f16_kernel(const _Float16 *__rest
             const bool vb = db < kInvalidD2, vs = ds < kInvalidD2;
             idx[2 * q] = vb ? (int32_t)(mb & ((1u << kIdxBits) - 1)) : -1;
             idx[2 * q + 1] = vs ? (int32_t)(ms & ((1u << kIdxBits) - 1)) : -1;
-            dist[2 * q] = vb ? sqrtf((float)db) : INFINITY;
-            dist[2 * q + 1] = vs ? sqrtf((float)ds) : INFINITY;
+            dist[2 * q] = vb ? sqrtf((float)db - (float)kBias + qn[qt]) : INFINITY;
+            dist[2 * q + 1] = vs ? sqrtf((float)ds - (float)kBias + qn[qt]) : INFINITY;
         }
     }
 }
