@@ -81,8 +81,12 @@ __global__ __launch_bounds__(kBlock) void knn2_f32_kernel(const float *__restric
 using half8 = __attribute__((ext_vector_type(8))) _Float16;
 using float16v = __attribute__((ext_vector_type(16))) float;
 
-#ifndef MQS_MATCH_AHEAD
-#define MQS_MATCH_AHEAD 4
+// D = 256 geometry (A/B-tuned on MI355X): query tiles per wave, waves per workgroup
+#ifndef MQS_MATCH_QT256
+#define MQS_MATCH_QT256 1
+#endif
+#ifndef MQS_MATCH_NW256
+#define MQS_MATCH_NW256 8
 #endif
 constexpr int kStageRows = 64;                         // train rows per LDS stage (2 MFMA row tiles)
 // Key = (|t|^2 + kBias - 2 q.t) << 20 | train index.  |q|^2 is constant per lane (one query per
@@ -110,8 +114,8 @@ __global__ void row_sqnorm_kernel(const _Float16 *__restrict__ x, int64_t n, int
     out[i] = s;
 }
 
-template <int KS /* D / 16 */, int QT /* 32-query column tiles per wave */>
-__global__ __launch_bounds__(kBlock) void knn2_f16_kernel(const _Float16 *__restrict__ query, int64_t Nq,
+template <int KS /* D / 16 */, int QT /* 32-query column tiles per wave */, int NW /* waves per workgroup */>
+__global__ __launch_bounds__(NW * 64) void knn2_f16_kernel(const _Float16 *__restrict__ query, int64_t Nq,
                                                           const _Float16 *__restrict__ train, int64_t Nt,
                                                           const float *__restrict__ qnorm,
                                                           const float *__restrict__ tnorm,
@@ -121,15 +125,16 @@ __global__ __launch_bounds__(kBlock) void knn2_f16_kernel(const _Float16 *__rest
     constexpr int kRowBytes = D * 2;                   // unpadded: the LDS image is filled by LDS-DMA
     constexpr int kStageBytes = kStageRows * kRowBytes;
     constexpr int kVecPerRow = D * 2 / 16;             // 16-byte pieces per row
-    constexpr int kVecPerThread = kStageRows * kVecPerRow / kBlock;
+    constexpr int kThreads = NW * 64;
+    constexpr int kVecPerThread = kStageRows * kVecPerRow / kThreads;
     constexpr int kSwzMask = (kVecPerRow < 32 ? kVecPerRow : 32) - 1;   // XOR swizzle of the 16-B column
-    static_assert(kStageRows * kVecPerRow % kBlock == 0, "stage must divide over the workgroup");
+    static_assert(kStageRows * kVecPerRow % kThreads == 0 && kVecPerThread >= 1, "stage must divide over the workgroup");
     __shared__ __attribute__((aligned(16))) unsigned char sTile[2 * kStageBytes];
     __shared__ __attribute__((aligned(16))) float sTn[3 * kStageRows];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int64_t qbase = (int64_t)blockIdx.x * (4 * QT * 32) + wave * (QT * 32);
+    const int64_t qbase = (int64_t)blockIdx.x * (NW * QT * 32) + wave * (QT * 32);
 
     // resident query fragments: B[k = 16 ks + 8 h + j][col r] = Q[qbase + 32 qt + r][...]
     half8 qf[QT][KS];
@@ -164,7 +169,7 @@ __global__ __launch_bounds__(kBlock) void knn2_f16_kernel(const _Float16 *__rest
         const int buf = (int)(s & 1);
 #pragma unroll
         for (int i = 0; i < kVecPerThread; ++i) {
-            const int piece0 = (i * 4 + wave) * 64;               // first 16-B piece of this wave-instruction
+            const int piece0 = (i * NW + wave) * 64;              // first 16-B piece of this wave-instruction
             const int v = piece0 + lane;
             const int row = v / kVecPerRow, colp = v % kVecPerRow;
             const int col = colp ^ (row & kSwzMask);
@@ -213,7 +218,7 @@ __global__ __launch_bounds__(kBlock) void knn2_f16_kernel(const _Float16 *__rest
                 for (int v = v0; v < v1; ++v) {
                     const int pq = v / 16, e = v % 16;        // row(e) = (e & 3) + 8 (e >> 2) + 4 h
                     const float kf = fmaf(prev[pq][e], -2.0f * kKeyScale, tnv[e]);
-                    const unsigned key = (unsigned)kf | (pbase + 8 * (e >> 2) + (e & 3));
+                    const unsigned key = (unsigned)kf | pbase | (unsigned)(8 * (e >> 2) + (e & 3));   // disjoint bits: one v_or3_b32
                     unsigned m;
                     asm("v_med3_u32 %0, %1, %2, %3" : "=v"(m) : "v"(best[pq]), "v"(second[pq]), "v"(key));
                     second[pq] = m;
@@ -260,7 +265,7 @@ __global__ __launch_bounds__(kBlock) void knn2_f16_kernel(const _Float16 *__rest
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const float kf = fmaf(accB[qt][e], -2.0f * kKeyScale, tnv[e]);
-                const unsigned key = (unsigned)kf | (pbase + 8 * (e >> 2) + (e & 3));
+                const unsigned key = (unsigned)kf | pbase | (unsigned)(8 * (e >> 2) + (e & 3));   // disjoint bits: one v_or3_b32
                 second[qt] = max(best[qt], min(second[qt], key));
                 best[qt] = min(best[qt], key);
             }
@@ -301,13 +306,13 @@ int launch_f32(const float *query, int64_t Nq, const float *train, int64_t Nt, i
     return MQS_OK;
 }
 
-template <int KS, int QT>
+template <int KS, int QT, int NW>
 void launch_f16_t(const _Float16 *q, int64_t Nq, const _Float16 *t, int64_t Nt, const float *qn, const float *tn,
                   int32_t *idx, float *dist, hipStream_t stream)
 {
-    const int64_t per_block = 4 * QT * 32;
-    hipLaunchKernelGGL((knn2_f16_kernel<KS, QT>), dim3((unsigned)((Nq + per_block - 1) / per_block)), dim3(kBlock), 0,
-                       stream, q, Nq, t, Nt, qn, tn, idx, dist);
+    const int64_t per_block = NW * QT * 32;
+    hipLaunchKernelGGL((knn2_f16_kernel<KS, QT, NW>), dim3((unsigned)((Nq + per_block - 1) / per_block)),
+                       dim3(NW * 64), 0, stream, q, Nq, t, Nt, qn, tn, idx, dist);
 }
 
 }  // namespace
@@ -345,11 +350,11 @@ int mqs_match_knn2_f16_dev(const uint16_t *query, int64_t Nq, const uint16_t *tr
     if (Nt > 0)
         hipLaunchKernelGGL(row_sqnorm_kernel, dim3((unsigned)((Nt + 255) / 256)), dim3(256), 0, stream, t, Nt, D, tn);
     switch (D) {
-    case 32: launch_f16_t<2, 2>(q, Nq, t, Nt, qn, tn, idx, dist, stream); break;
-    case 64: launch_f16_t<4, 2>(q, Nq, t, Nt, qn, tn, idx, dist, stream); break;
-    case 128: launch_f16_t<8, 2>(q, Nq, t, Nt, qn, tn, idx, dist, stream); break;
-    case 256: launch_f16_t<16, 2>(q, Nq, t, Nt, qn, tn, idx, dist, stream); break;
-    case 512: launch_f16_t<32, 1>(q, Nq, t, Nt, qn, tn, idx, dist, stream); break;
+    case 32: launch_f16_t<2, 2, 4>(q, Nq, t, Nt, qn, tn, idx, dist, stream); break;
+    case 64: launch_f16_t<4, 2, 4>(q, Nq, t, Nt, qn, tn, idx, dist, stream); break;
+    case 128: launch_f16_t<8, 2, 4>(q, Nq, t, Nt, qn, tn, idx, dist, stream); break;
+    case 256: launch_f16_t<16, MQS_MATCH_QT256, MQS_MATCH_NW256>(q, Nq, t, Nt, qn, tn, idx, dist, stream); break;
+    case 512: launch_f16_t<32, 1, 4>(q, Nq, t, Nt, qn, tn, idx, dist, stream); break;
     }
     MQS_HIP_CHECK(hipGetLastError());
     return MQS_OK;
