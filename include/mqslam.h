@@ -190,6 +190,26 @@ int mqs_ba_backsub(mqs_ctx *ctx, const double *poses, const double *calib, const
                    const double *dpose, double *points_out);
 
 /* ---------------------------------------------------------------------------------------
+ * Camera model either side of triangulation (the published OpenCV 2.4 pinhole + distortion model):
+ * intr[9] = fx, fy, cx, cy, k1, k2, p1, p2, k3.
+ *   mqs_undistort_points: pixels [N][2] -> normalised undistorted coordinates [N][2]
+ *       (cv2.undistortPoints(pts, K, dist) as called at slam2.py:551-552 and
+ *        triangulation_comparison.py:173; 5 fixed-point iterations like OpenCV 2.4)
+ *   mqs_project_points: world points [N][3] through P [3][4] (world -> camera) and the distortion
+ *       model to pixels uv_out [N][2] (NULL = skip), depth_out [N] (NULL = skip) and, when imgp [N][2]
+ *       and sqerr_out are given, sqerr_out[0] = sum |uv - imgp|^2 -- calibration_tools.py:116-124
+ *       reprojection_error = sqrt(sqerr / N) (cv2.projectPoints with P = [Rodrigues(rvec) | tvec]).
+ * ------------------------------------------------------------------------------------- */
+int mqs_undistort_points(mqs_ctx *ctx, const double *pixels, const double *intr, int64_t N, double *out);
+int mqs_undistort_points_dev(const double *pixels, const double *intr, int64_t N, double *out, void *stream);
+int mqs_project_points(mqs_ctx *ctx, const double *points, const double *P, const double *intr,
+                       const double *imgp, int64_t N, double *uv_out, double *depth_out, double *sqerr_out);
+int mqs_project_points_dev(const double *points, const double *P, const double *intr, const double *imgp,
+                           int64_t N, double *uv_out, double *depth_out, double *sqerr_out,
+                           void *workspace, int64_t workspace_bytes, void *stream);
+int64_t mqs_project_workspace_bytes(void);
+
+/* ---------------------------------------------------------------------------------------
  * Timing helper used by bench.py: average duration (ms) of `reps` back-to-back launches of
  * one triangulation kernel measured with hipEvents on `stream` (kernel: 0 = linear_ls,
  * 1 = iterative_ls, 2 = linear_eigen).

@@ -12,5 +12,6 @@ from . import device                     # noqa: F401
 from . import bundle_adjustment          # noqa: F401
 from . import matching                   # noqa: F401
 from . import sharding                   # noqa: F401
+from . import camera                     # noqa: F401
 
 loaded = _lib.loaded
