@@ -190,6 +190,41 @@ int mqs_ba_backsub(mqs_ctx *ctx, const double *poses, const double *calib, const
                    const double *dpose, double *points_out);
 
 /* ---------------------------------------------------------------------------------------
+ * General sparse-visibility bundle adjustment: P poses (pose_cam [P] = camera id of each pose),
+ * N landmarks, M observations in CSR by landmark (obs_ptr [N+1] int64, obs_pose [M] int32 sorted by
+ * pose within a landmark, obs_uv [M][2]), and the list of Q observation pairs (pair_a <= pair_b,
+ * global observation indices of one landmark, including a == b) that produce reduced-system blocks.
+ * This is the graph bundle_adjust.cpp:245-298 builds from the reference's file set (IO.hpp:366-406).
+ * All pointers are device pointers.
+ *   linearize: S [(6P)^2] row-major and g [6P] are overwritten with the reduced camera system
+ *     (J^T J form incl. PriorFactor<Pose3> terms of the n_pose_prior listed poses, bundle_adjust.cpp:273);
+ *     info[4] = {0.5*sum|r/sigma|^2 + point priors, valid-factor count, pose-prior cost, 0}.
+ *   solve: in place blocked Cholesky of (S + lambda*diag S), x (= g on entry) -> dpose; poses_out =
+ *     retract(poses, dpose) when not NULL; bad[0] = 1 when S was not positive definite.
+ *   backsub / cost as in the dense API.  Summation uses fp64 atomics: not bitwise reproducible.
+ * ------------------------------------------------------------------------------------- */
+int64_t mqs_sba_workspace_bytes(int64_t P, int64_t N, int64_t M);
+int mqs_sba_linearize_dev(const double *poses, const int32_t *pose_cam, int64_t P, const double *calib,
+                          const double *sigma, const double *points, int64_t N, const int64_t *obs_ptr,
+                          const int32_t *obs_pose, const double *obs_uv, int64_t M, const int64_t *pair_a,
+                          const int64_t *pair_b, int64_t Q, const double *prior_w, const double *prior_xyz,
+                          const int32_t *pose_prior_idx, const double *pose_prior_poses,
+                          const double *pose_prior_sigmas, int n_pose_prior, double lambda, double *S,
+                          double *g, double *info, void *workspace, int64_t workspace_bytes, void *stream);
+int mqs_sba_solve_dev(double *S, double *x, int64_t P, double lambda, const double *poses, double *poses_out,
+                      int *bad, void *stream);
+int mqs_sba_backsub_dev(const double *poses, const int32_t *pose_cam, int64_t P, const double *calib,
+                        const double *sigma, const double *points, int64_t N, const int64_t *obs_ptr,
+                        const int32_t *obs_pose, const double *obs_uv, int64_t M, const double *prior_w,
+                        const double *prior_xyz, double lambda, const double *dpose, double *points_out,
+                        void *workspace, int64_t workspace_bytes, void *stream);
+int mqs_sba_cost_dev(const double *poses, const int32_t *pose_cam, int64_t P, const double *calib,
+                     const double *sigma, const double *points, int64_t N, const int64_t *obs_ptr,
+                     const int32_t *obs_pose, const double *obs_uv, int64_t M, const double *prior_w,
+                     const double *prior_xyz, double *out, void *workspace, int64_t workspace_bytes,
+                     void *stream);
+
+/* ---------------------------------------------------------------------------------------
  * Camera model either side of triangulation (the published OpenCV 2.4 pinhole + distortion model):
  * intr[9] = fx, fy, cx, cy, k1, k2, p1, p2, k3.
  *   mqs_undistort_points: pixels [N][2] -> normalised undistorted coordinates [N][2]

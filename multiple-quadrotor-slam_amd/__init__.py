@@ -13,5 +13,7 @@ from . import bundle_adjustment          # noqa: F401
 from . import matching                   # noqa: F401
 from . import sharding                   # noqa: F401
 from . import camera                     # noqa: F401
+from . import ba_io                      # noqa: F401
+from . import sparse_ba                  # noqa: F401
 
 loaded = _lib.loaded

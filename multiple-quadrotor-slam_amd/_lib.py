@@ -68,6 +68,15 @@ SIGNATURES = {
                                         c_f64p, c_i64, ctypes.c_double, c_f64p]),
     "mqs_ba_backsub": (ctypes.c_int, [c_vp, c_f64p, c_f64p, c_f64p, ctypes.c_int, c_f64p, c_f64p, c_u8p, c_f64p,
                                       c_f64p, c_i64, ctypes.c_double, c_f64p, c_f64p]),
+    "mqs_sba_workspace_bytes": (c_i64, [c_i64, c_i64, c_i64]),
+    "mqs_sba_linearize_dev": (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp,
+                                             c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_int, ctypes.c_double,
+                                             c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "mqs_sba_solve_dev": (ctypes.c_int, [c_vp, c_vp, c_i64, ctypes.c_double, c_vp, c_vp, c_vp, c_vp]),
+    "mqs_sba_backsub_dev": (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp,
+                                           c_vp, ctypes.c_double, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "mqs_sba_cost_dev": (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp,
+                                        c_vp, c_vp, c_i64, c_vp]),
     "mqs_undistort_points": (ctypes.c_int, [c_vp, c_f64p, c_f64p, c_i64, c_f64p]),
     "mqs_undistort_points_dev": (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp, c_vp]),
     "mqs_project_points": (ctypes.c_int, [c_vp, c_f64p, c_f64p, c_f64p, c_f64p, c_i64, c_f64p, c_f64p, c_f64p]),

@@ -1,0 +1,588 @@
+// General (sparse-visibility) bundle adjustment for gfx950: any number of poses, each landmark
+// observed by an arbitrary subset (CSR by landmark).  This is the graph the reference's tool builds
+// from its file set (Work/SLAM/tools/bundle_adjustment/bundle_adjust.cpp:245-298: 186..881 poses,
+// 1k..13k landmarks, 7k..231k observations on the committed data sets), where the dense C <= 8
+// kernels of ba.hip do not apply.  Same factor arithmetic (ba_math.h).
+//
+// Launch structure per linearisation (all asynchronous on one stream):
+//   stage_pose_cams   one thread per pose: the 24-double camera block (pose + its camera's calibration)
+//   sparse_landmark   one thread per landmark: H_ll, g_l, Cholesky, then one 14-double record per
+//                     observation {x, y, Z, Uh (2x3), k (2x2 sym), rh (2)} -- everything a pose-pair
+//                     block needs from that observation
+//   sparse_pairs      one thread per (landmark, observation pair a <= b) from a precomputed pair list:
+//                     the 6x6 block  +/- Jg_a^T k Jg_b  added into the dense (6P)^2 matrix with fp64
+//                     global atomics (upper block triangle; pose(a) <= pose(b) by construction)
+//   sparse_finish     mirrors the upper triangle, adds pose priors and LM damping
+// The reduced system is then factored by the blocked Cholesky below (own kernels, fp64).
+// Results are NOT bitwise reproducible (atomic summation order), unlike the dense path.
+#include "mqs_common.h"
+#include "ba_math.h"
+
+namespace {
+
+using namespace mqs::ba;
+constexpr int kBlock = 256;
+constexpr int kRec = 14;      // doubles per observation record
+
+__global__ void stage_pose_cams_kernel(const double *__restrict__ poses, const int32_t *__restrict__ pose_cam,
+                                       const double *__restrict__ calib, const double *__restrict__ sigma, int P,
+                                       double *__restrict__ cams)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= P) return;
+    const int c = pose_cam[j];
+    stage_camera(cams + (int64_t)j * kCamStride, poses + (int64_t)j * 12, calib + 9 * c, sigma[c]);
+}
+
+__global__ __launch_bounds__(kBlock) void sparse_landmark_kernel(
+    const double *__restrict__ cams, const double *__restrict__ points, const int64_t *__restrict__ obs_ptr,
+    const int32_t *__restrict__ obs_pose, const double *__restrict__ obs_uv, const double *__restrict__ prior_w,
+    const double *__restrict__ prior_xyz, int64_t N, double lambda, double *__restrict__ rec,
+    double *__restrict__ cost_partials)
+{
+    __shared__ double sRed[2 * (kBlock / 64)];
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    double cost = 0.0, count = 0.0;
+    if (i < N) {
+        const double px = points[3 * i], py = points[3 * i + 1], pz = points[3 * i + 2];
+        double pw = 0.0, dx = 0.0, dy = 0.0, dz = 0.0;
+        if (prior_w && prior_w[i] > 0.0) {
+            pw = prior_w[i];
+            dx = px - prior_xyz[3 * i]; dy = py - prior_xyz[3 * i + 1]; dz = pz - prior_xyz[3 * i + 2];
+        }
+        PointSystem ps;
+        ps.H = mqs::Sym3{0, 0, 0, 0, 0, 0};
+        ps.g = mqs::Vec3{0, 0, 0};
+        cost = 0.5 * pw * (dx * dx + dy * dy + dz * dz);
+        const int64_t k0 = obs_ptr[i], k1 = obs_ptr[i + 1];
+        for (int64_t k = k0; k < k1; ++k) {
+            const double *cam = cams + (int64_t)obs_pose[k] * kCamStride;
+            const Factor fc = make_factor(cam, px, py, pz, obs_uv[2 * k], obs_uv[2 * k + 1], true);
+            double PR[2][3];
+            make_PR(cam, fc.x, fc.y, PR);
+            point_add_factor(ps, fc, PR);
+            cost += fc.half_e2;
+            count += fc.valid ? 1.0 : 0.0;
+        }
+        point_finish(ps, pw, dx, dy, dz, lambda);
+        const double m = ps.ok ? 1.0 : 0.0;
+        double w0 = ps.g.x * ps.i00;
+        double w1 = fma(-ps.l10, w0, ps.g.y) * ps.i11;
+        double w2 = fma(-ps.l21, w1, fma(-ps.l20, w0, ps.g.z)) * ps.i22;
+        w0 *= m; w1 *= m; w2 *= m;
+        for (int64_t k = k0; k < k1; ++k) {
+            const double *cam = cams + (int64_t)obs_pose[k] * kCamStride;
+            const Factor fc = make_factor(cam, px, py, pz, obs_uv[2 * k], obs_uv[2 * k + 1], true);
+            double PR[2][3];
+            make_PR(cam, fc.x, fc.y, PR);
+            double U[2][3];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const double Fa = r ? fc.F01 : fc.F00, Fb = r ? fc.F11 : fc.F01;
+                double u0 = fma(Fa, PR[0][0], Fb * PR[1][0]);
+                double u1 = fma(Fa, PR[0][1], Fb * PR[1][1]);
+                double u2 = fma(Fa, PR[0][2], Fb * PR[1][2]);
+                apply_LinvT(ps, u0, u1, u2);
+                U[r][0] = m * u0; U[r][1] = m * u1; U[r][2] = m * u2;
+            }
+            double *o = rec + k * kRec;
+            o[0] = fc.x; o[1] = fc.y; o[2] = fc.Z;
+            o[3] = U[0][0]; o[4] = U[0][1]; o[5] = U[0][2]; o[6] = U[1][0]; o[7] = U[1][1]; o[8] = U[1][2];
+            o[9] = fc.F00 - (U[0][0] * U[0][0] + U[0][1] * U[0][1] + U[0][2] * U[0][2]);
+            o[10] = fc.F01 - (U[0][0] * U[1][0] + U[0][1] * U[1][1] + U[0][2] * U[1][2]);
+            o[11] = fc.F11 - (U[1][0] * U[1][0] + U[1][1] * U[1][1] + U[1][2] * U[1][2]);
+            o[12] = -fc.f0 - (U[0][0] * w0 + U[0][1] * w1 + U[0][2] * w2);
+            o[13] = -fc.f1 - (U[1][0] * w0 + U[1][1] * w1 + U[1][2] * w2);
+        }
+    }
+#pragma unroll
+    for (int h = 32; h >= 1; h >>= 1) { cost += __shfl_xor(cost, h); count += __shfl_xor(count, h); }
+    if ((threadIdx.x & 63) == 0) { sRed[2 * (threadIdx.x >> 6)] = cost; sRed[2 * (threadIdx.x >> 6) + 1] = count; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double c = 0, n = 0;
+        for (int w = 0; w < kBlock / 64; ++w) { c += sRed[2 * w]; n += sRed[2 * w + 1]; }
+        cost_partials[2 * blockIdx.x] = c;
+        cost_partials[2 * blockIdx.x + 1] = n;
+    }
+}
+
+__device__ __forceinline__ void atomic_add_f64(double *p, double v) { unsafeAtomicAdd(p, v); }
+
+// pair (a, b): global observation indices of one landmark, pose(a) <= pose(b); a == b: diagonal block
+__global__ __launch_bounds__(kBlock) void sparse_pairs_kernel(const double *__restrict__ rec,
+                                                              const int32_t *__restrict__ obs_pose,
+                                                              const int64_t *__restrict__ pair_a,
+                                                              const int64_t *__restrict__ pair_b, int64_t Q, int n6,
+                                                              double *__restrict__ S, double *__restrict__ g)
+{
+    const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (q >= Q) return;
+    const int64_t a = pair_a[q], b = pair_b[q];
+    const double *ra = rec + a * kRec, *rb = rec + b * kRec;
+    const int ja = obs_pose[a], jb = obs_pose[b];
+    const JgA A = make_JgA(ra[0], ra[1], ra[2]);
+    double T[2][6];
+    if (a == b) {
+        k_times_Jg(ra[9], ra[10], ra[10], ra[11], A, T);
+        double *Sd = S + (int64_t)(6 * ja) * n6 + 6 * ja;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = i; j < 6; ++j) atomic_add_f64(Sd + (int64_t)i * n6 + j, JgT_T(A, T, i, j));
+#pragma unroll
+        for (int i = 0; i < 6; ++i) atomic_add_f64(g + 6 * ja + i, JgT_r(A, ra[12], ra[13], i));
+    } else {
+        const JgA B = make_JgA(rb[0], rb[1], rb[2]);
+        const double k00 = -(ra[3] * rb[3] + ra[4] * rb[4] + ra[5] * rb[5]);
+        const double k01 = -(ra[3] * rb[6] + ra[4] * rb[7] + ra[5] * rb[8]);
+        const double k10 = -(ra[6] * rb[3] + ra[7] * rb[4] + ra[8] * rb[5]);
+        const double k11 = -(ra[6] * rb[6] + ra[7] * rb[7] + ra[8] * rb[8]);
+        k_times_Jg(k00, k01, k10, k11, B, T);
+        if (ja != jb) {
+            double *Sd = S + (int64_t)(6 * ja) * n6 + 6 * jb;
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) atomic_add_f64(Sd + (int64_t)i * n6 + j, JgT_T(A, T, i, j));
+        } else {
+            // the same pose observes the landmark twice: block and its transpose land on one diagonal
+            // block whose upper triangle is what is kept
+            double *Sd = S + (int64_t)(6 * ja) * n6 + 6 * ja;
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    const double v = JgT_T(A, T, i, j);
+                    if (i <= j) atomic_add_f64(Sd + (int64_t)i * n6 + j, v);
+                    if (j <= i) atomic_add_f64(Sd + (int64_t)j * n6 + i, v);
+                }
+        }
+    }
+}
+
+__device__ void so3_log_s(const double *R, double w[3])
+{
+    double c = 0.5 * (R[0] + R[4] + R[8] - 1.0);
+    c = fmin(1.0, fmax(-1.0, c));
+    const double th = acos(c);
+    const double k = (th < 1e-10) ? 0.5 : th / (2.0 * sin(th));
+    w[0] = k * (R[7] - R[5]); w[1] = k * (R[2] - R[6]); w[2] = k * (R[3] - R[1]);
+}
+
+// mirror upper -> lower, then pose priors (thread per prior) and damping on the diagonal
+__global__ __launch_bounds__(kBlock) void sparse_mirror_kernel(double *__restrict__ S, int n6)
+{
+    const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= (int64_t)n6 * n6) return;
+    const int i = (int)(t / n6), j = (int)(t % n6);
+    if (j < i) S[t] = S[(int64_t)j * n6 + i];
+}
+
+__global__ void sparse_priors_kernel(double *__restrict__ S, double *__restrict__ g, int n6,
+                                     const double *__restrict__ poses, const int32_t *__restrict__ prior_idx,
+                                     const double *__restrict__ prior_poses, const double *__restrict__ prior_sigmas,
+                                     int nprior, double lambda, double *__restrict__ prior_cost)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < nprior) {
+        const int j = prior_idx[t];
+        const double *T0 = prior_poses + 12 * t, *T = poses + 12 * (int64_t)j, *sg = prior_sigmas + 6 * t;
+        double Rr[9], w[3], e[6];
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) Rr[3 * a + b] = T0[a] * T[b] + T0[3 + a] * T[3 + b] + T0[6 + a] * T[6 + b];
+        so3_log_s(Rr, w);
+        const double dt[3] = {T[9] - T0[9], T[10] - T0[10], T[11] - T0[11]};
+        for (int a = 0; a < 3; ++a) {
+            e[a] = w[a];
+            e[3 + a] = T0[a] * dt[0] + T0[3 + a] * dt[1] + T0[6 + a] * dt[2];
+        }
+        double c = 0.0;
+        for (int a = 0; a < 6; ++a) {
+            const double wi = 1.0 / (sg[a] * sg[a]);
+            atomic_add_f64(S + (int64_t)(6 * j + a) * n6 + 6 * j + a, wi);
+            atomic_add_f64(g + 6 * j + a, -wi * e[a]);
+            c += 0.5 * wi * e[a] * e[a];
+        }
+        atomic_add_f64(prior_cost, c);
+    }
+}
+
+__global__ void sparse_damp_kernel(double *__restrict__ S, int n6, double lambda)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n6) S[(int64_t)i * n6 + i] *= (1.0 + lambda);
+}
+
+__global__ __launch_bounds__(kBlock) void sparse_backsub_kernel(
+    const double *__restrict__ cams, const double *__restrict__ points, const int64_t *__restrict__ obs_ptr,
+    const int32_t *__restrict__ obs_pose, const double *__restrict__ obs_uv, const double *__restrict__ prior_w,
+    const double *__restrict__ prior_xyz, int64_t N, double lambda, const double *__restrict__ dpose,
+    double *__restrict__ points_out)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= N) return;
+    const double px = points[3 * i], py = points[3 * i + 1], pz = points[3 * i + 2];
+    double pw = 0.0, dx = 0.0, dy = 0.0, dz = 0.0;
+    if (prior_w && prior_w[i] > 0.0) {
+        pw = prior_w[i];
+        dx = px - prior_xyz[3 * i]; dy = py - prior_xyz[3 * i + 1]; dz = pz - prior_xyz[3 * i + 2];
+    }
+    PointSystem ps;
+    ps.H = mqs::Sym3{0, 0, 0, 0, 0, 0};
+    ps.g = mqs::Vec3{0, 0, 0};
+    double rx = 0, ry = 0, rz = 0;
+    for (int64_t k = obs_ptr[i]; k < obs_ptr[i + 1]; ++k) {
+        const int j = obs_pose[k];
+        const double *cam = cams + (int64_t)j * kCamStride;
+        const Factor fc = make_factor(cam, px, py, pz, obs_uv[2 * k], obs_uv[2 * k + 1], true);
+        double PR[2][3];
+        make_PR(cam, fc.x, fc.y, PR);
+        point_add_factor(ps, fc, PR);
+        double Jg[2][6];
+        make_Jg(fc.x, fc.y, fc.Z, Jg);
+        double s0 = 0, s1 = 0;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) { s0 = fma(Jg[0][c], dpose[6 * j + c], s0); s1 = fma(Jg[1][c], dpose[6 * j + c], s1); }
+        const double t0 = fma(fc.F00, s0, fc.F01 * s1), t1 = fma(fc.F01, s0, fc.F11 * s1);
+        rx = fma(PR[0][0], t0, fma(PR[1][0], t1, rx));
+        ry = fma(PR[0][1], t0, fma(PR[1][1], t1, ry));
+        rz = fma(PR[0][2], t0, fma(PR[1][2], t1, rz));
+    }
+    point_finish(ps, pw, dx, dy, dz, lambda);
+    double v0 = ps.g.x - rx, v1 = ps.g.y - ry, v2 = ps.g.z - rz;
+    v0 = v0 * ps.i00;
+    v1 = fma(-ps.l10, v0, v1) * ps.i11;
+    v2 = fma(-ps.l21, v1, fma(-ps.l20, v0, v2)) * ps.i22;
+    apply_Lt_inv(ps, v0, v1, v2);
+    const double m = ps.ok ? 1.0 : 0.0;
+    points_out[3 * i] = px + m * v0;
+    points_out[3 * i + 1] = py + m * v1;
+    points_out[3 * i + 2] = pz + m * v2;
+}
+
+__global__ __launch_bounds__(kBlock) void sparse_cost_kernel(
+    const double *__restrict__ cams, const double *__restrict__ points, const int64_t *__restrict__ obs_ptr,
+    const int32_t *__restrict__ obs_pose, const double *__restrict__ obs_uv, const double *__restrict__ prior_w,
+    const double *__restrict__ prior_xyz, int64_t N, double *__restrict__ cost_partials)
+{
+    __shared__ double sRed[2 * (kBlock / 64)];
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    double cost = 0.0, count = 0.0;
+    if (i < N) {
+        const double px = points[3 * i], py = points[3 * i + 1], pz = points[3 * i + 2];
+        if (prior_w && prior_w[i] > 0.0) {
+            const double dx = px - prior_xyz[3 * i], dy = py - prior_xyz[3 * i + 1], dz = pz - prior_xyz[3 * i + 2];
+            cost = 0.5 * prior_w[i] * (dx * dx + dy * dy + dz * dz);
+        }
+        for (int64_t k = obs_ptr[i]; k < obs_ptr[i + 1]; ++k) {
+            const Factor fc = make_factor(cams + (int64_t)obs_pose[k] * kCamStride, px, py, pz, obs_uv[2 * k],
+                                          obs_uv[2 * k + 1], true);
+            cost += fc.half_e2;
+            count += fc.valid ? 1.0 : 0.0;
+        }
+    }
+#pragma unroll
+    for (int h = 32; h >= 1; h >>= 1) { cost += __shfl_xor(cost, h); count += __shfl_xor(count, h); }
+    if ((threadIdx.x & 63) == 0) { sRed[2 * (threadIdx.x >> 6)] = cost; sRed[2 * (threadIdx.x >> 6) + 1] = count; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double c = 0, n = 0;
+        for (int w = 0; w < kBlock / 64; ++w) { c += sRed[2 * w]; n += sRed[2 * w + 1]; }
+        cost_partials[2 * blockIdx.x] = c;
+        cost_partials[2 * blockIdx.x + 1] = n;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void sum_cost_partials_kernel(const double *__restrict__ partials, int n,
+                                                                  double *__restrict__ out)
+{
+    __shared__ double sC[kBlock], sN[kBlock];
+    double c = 0, m = 0;
+    for (int i = threadIdx.x; i < n; i += kBlock) { c += partials[2 * i]; m += partials[2 * i + 1]; }
+    sC[threadIdx.x] = c; sN[threadIdx.x] = m;
+    __syncthreads();
+    for (int h = kBlock / 2; h >= 1; h >>= 1) {
+        if ((int)threadIdx.x < h) { sC[threadIdx.x] += sC[threadIdx.x + h]; sN[threadIdx.x] += sN[threadIdx.x + h]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out[0] = sC[0]; out[1] = sN[0]; }
+}
+
+__global__ void sparse_retract_kernel(const double *__restrict__ poses, const double *__restrict__ dpose, int P,
+                                      double *__restrict__ poses_out)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= P) return;
+    const double *T = poses + 12 * (int64_t)j, *d = dpose + 6 * (int64_t)j;
+    const double th2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2], th = sqrt(th2);
+    double a, b;
+    if (th < 1e-10) { a = 1.0; b = 0.5; } else { a = sin(th) / th; b = (1.0 - cos(th)) / th2; }
+    const double K[9] = {0, -d[2], d[1], d[2], 0, -d[0], -d[1], d[0], 0};
+    double E[9];
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+            const double k2 = K[3 * r] * K[c] + K[3 * r + 1] * K[3 + c] + K[3 * r + 2] * K[6 + c];
+            E[3 * r + c] = ((r == c) ? 1.0 : 0.0) + a * K[3 * r + c] + b * k2;
+        }
+    double *O = poses_out + 12 * (int64_t)j;
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) O[3 * r + c] = T[3 * r] * E[c] + T[3 * r + 1] * E[3 + c] + T[3 * r + 2] * E[6 + c];
+    for (int r = 0; r < 3; ++r) O[9 + r] = T[9 + r] + T[3 * r] * d[3] + T[3 * r + 1] * d[4] + T[3 * r + 2] * d[5];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Dense Cholesky solve of the reduced camera system, n = 6P up to a few thousand: right-looking,
+// block size 32, three kernels per block column (diagonal factor, panel triangular solve, trailing
+// symmetric update), then forward / backward substitution.  Lower triangle, in place, row-major.
+// ---------------------------------------------------------------------------------------------
+constexpr int NB = 32;
+
+__global__ __launch_bounds__(64) void chol_diag_kernel(double *__restrict__ A, int n, int k0, int *__restrict__ bad)
+{
+    __shared__ double sA[NB][NB + 1];
+    const int nb = (n - k0) < NB ? (n - k0) : NB;
+    const int lane = threadIdx.x;
+    for (int e = lane; e < nb * nb; e += 64) sA[e / nb][e % nb] = A[(int64_t)(k0 + e / nb) * n + k0 + e % nb];
+    __syncthreads();
+    for (int k = 0; k < nb; ++k) {
+        const double d = sA[k][k];
+        if (lane == 0 && !(d > 0.0)) *bad = 1;
+        const double piv = sqrt(d > 0.0 ? d : 1.0);
+        __syncthreads();
+        if (lane == k) sA[k][k] = piv;
+        if (lane > k && lane < nb) sA[lane][k] /= piv;
+        __syncthreads();
+        if (lane > k && lane < nb) {
+            const double lik = sA[lane][k];
+            for (int j = k + 1; j <= lane; ++j) sA[lane][j] -= lik * sA[j][k];
+        }
+        __syncthreads();
+    }
+    for (int e = lane; e < nb * nb; e += 64) {
+        const int r = e / nb, c = e % nb;
+        A[(int64_t)(k0 + r) * n + k0 + c] = (c <= r) ? sA[r][c] : 0.0;
+    }
+}
+
+// rows below the diagonal block: X L^T = A_panel  (one thread per row)
+__global__ __launch_bounds__(kBlock) void chol_panel_kernel(double *__restrict__ A, int n, int k0)
+{
+    __shared__ double sL[NB][NB + 1];
+    const int nb = (n - k0) < NB ? (n - k0) : NB;
+    for (int e = threadIdx.x; e < nb * nb; e += kBlock) sL[e / nb][e % nb] = A[(int64_t)(k0 + e / nb) * n + k0 + e % nb];
+    __syncthreads();
+    const int r = k0 + nb + blockIdx.x * kBlock + threadIdx.x;
+    if (r >= n) return;
+    double x[NB];
+    double *row = A + (int64_t)r * n + k0;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) x[j] = (j < nb) ? row[j] : 0.0;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        if (j < nb) {
+            double s = x[j];
+#pragma unroll
+            for (int k = 0; k < NB; ++k)
+                if (k < j) s -= x[k] * sL[j][k];
+            x[j] = s / sL[j][j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+        if (j < nb) row[j] = x[j];
+}
+
+// trailing update (lower triangle): A[i][j] -= sum_k L[i][k0+k] L[j][k0+k], 32x32 tiles
+__global__ __launch_bounds__(kBlock) void chol_update_kernel(double *__restrict__ A, int n, int k0)
+{
+    const int nb = (n - k0) < NB ? (n - k0) : NB;
+    const int t0 = k0 + nb;
+    const int bi = blockIdx.y, bj = blockIdx.x;
+    if (bj > bi) return;
+    __shared__ double sI[NB][NB + 1], sJ[NB][NB + 1];
+    const int i0 = t0 + bi * NB, j0 = t0 + bj * NB;
+    for (int e = threadIdx.x; e < NB * NB; e += kBlock) {
+        const int r = e / NB, c = e % NB;
+        sI[r][c] = (i0 + r < n && c < nb) ? A[(int64_t)(i0 + r) * n + k0 + c] : 0.0;
+        sJ[r][c] = (j0 + r < n && c < nb) ? A[(int64_t)(j0 + r) * n + k0 + c] : 0.0;
+    }
+    __syncthreads();
+    // 256 threads: each a 2x2 piece of the 32x32 tile
+    const int tr = (threadIdx.x / 16) * 2, tc = (threadIdx.x % 16) * 2;
+    double a00 = 0, a01 = 0, a10 = 0, a11 = 0;
+#pragma unroll 8
+    for (int k = 0; k < NB; ++k) {
+        const double i0v = sI[tr][k], i1v = sI[tr + 1][k], j0v = sJ[tc][k], j1v = sJ[tc + 1][k];
+        a00 = fma(i0v, j0v, a00); a01 = fma(i0v, j1v, a01); a10 = fma(i1v, j0v, a10); a11 = fma(i1v, j1v, a11);
+    }
+    const int r0 = i0 + tr, c0 = j0 + tc;
+    if (r0 < n && c0 < n && c0 <= r0) A[(int64_t)r0 * n + c0] -= a00;
+    if (r0 < n && c0 + 1 < n && c0 + 1 <= r0) A[(int64_t)r0 * n + c0 + 1] -= a01;
+    if (r0 + 1 < n && c0 < n && c0 <= r0 + 1) A[(int64_t)(r0 + 1) * n + c0] -= a10;
+    if (r0 + 1 < n && c0 + 1 < n && c0 + 1 <= r0 + 1) A[(int64_t)(r0 + 1) * n + c0 + 1] -= a11;
+}
+
+// L y = b then L^T x = y; one workgroup, blocked by 256 rows with a block-level dot product per row
+__global__ __launch_bounds__(kBlock) void chol_solve_kernel(const double *__restrict__ L, int n, double *__restrict__ x)
+{
+    __shared__ double sRed[kBlock];
+    const int tid = threadIdx.x;
+    // forward: x[i] = (b[i] - sum_{j<i} L[i][j] x[j]) / L[i][i]
+    for (int i = 0; i < n; ++i) {
+        double s = 0.0;
+        for (int j = tid; j < i; j += kBlock) s += L[(int64_t)i * n + j] * x[j];
+        sRed[tid] = s;
+        __syncthreads();
+        for (int h = kBlock / 2; h >= 1; h >>= 1) {
+            if (tid < h) sRed[tid] += sRed[tid + h];
+            __syncthreads();
+        }
+        if (tid == 0) x[i] = (x[i] - sRed[0]) / L[(int64_t)i * n + i];
+        __syncthreads();
+    }
+    // backward: x[i] = (y[i] - sum_{j>i} L[j][i] x[j]) / L[i][i]
+    for (int i = n - 1; i >= 0; --i) {
+        double s = 0.0;
+        for (int j = i + 1 + tid; j < n; j += kBlock) s += L[(int64_t)j * n + i] * x[j];
+        sRed[tid] = s;
+        __syncthreads();
+        for (int h = kBlock / 2; h >= 1; h >>= 1) {
+            if (tid < h) sRed[tid] += sRed[tid + h];
+            __syncthreads();
+        }
+        if (tid == 0) x[i] = (x[i] - sRed[0]) / L[(int64_t)i * n + i];
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t mqs_sba_workspace_bytes(int64_t P, int64_t N, int64_t M)
+{
+    if (P < 0 || N < 0 || M < 0) return 0;
+    const int64_t blocks = (N + kBlock - 1) / kBlock + 1;
+    return (P * kCamStride + M * kRec + 2 * blocks + 16) * (int64_t)sizeof(double);
+}
+
+// S [(6P)^2], g [6P], info[4] = {cost, valid count, pose-prior cost, 0}.  S and g are overwritten.
+int mqs_sba_linearize_dev(const double *poses, const int32_t *pose_cam, int64_t P, const double *calib,
+                          const double *sigma, const double *points, int64_t N, const int64_t *obs_ptr,
+                          const int32_t *obs_pose, const double *obs_uv, int64_t M, const int64_t *pair_a,
+                          const int64_t *pair_b, int64_t Q, const double *prior_w, const double *prior_xyz,
+                          const int32_t *pose_prior_idx, const double *pose_prior_poses,
+                          const double *pose_prior_sigmas, int n_pose_prior, double lambda, double *S, double *g,
+                          double *info, void *workspace, int64_t workspace_bytes, void *stream_)
+{
+    MQS_ARG_CHECK(P >= 1 && N >= 0 && M >= 0 && Q >= 0, "sizes must be non-negative, P >= 1");
+    MQS_ARG_CHECK(6 * P <= 46000, "6P too large for the dense reduced system");
+    MQS_ARG_CHECK(poses && pose_cam && calib && sigma && S && g && info && workspace, "pointers must not be null");
+    MQS_ARG_CHECK(N == 0 || (points && obs_ptr), "points, obs_ptr must not be null");
+    MQS_ARG_CHECK(M == 0 || (obs_pose && obs_uv), "obs arrays must not be null");
+    MQS_ARG_CHECK(Q == 0 || (pair_a && pair_b), "pair list must not be null");
+    MQS_ARG_CHECK(!prior_w || prior_xyz, "prior_xyz required with prior_w");
+    MQS_ARG_CHECK(n_pose_prior == 0 || (pose_prior_idx && pose_prior_poses && pose_prior_sigmas), "pose prior arrays");
+    MQS_ARG_CHECK(workspace_bytes >= mqs_sba_workspace_bytes(P, N, M), "workspace too small (mqs_sba_workspace_bytes)");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int n6 = (int)(6 * P);
+    double *cams = static_cast<double *>(workspace);
+    double *rec = cams + P * kCamStride;
+    double *partials = rec + M * kRec;
+    const int lm_blocks = (int)((N + kBlock - 1) / kBlock);
+    MQS_HIP_CHECK(hipMemsetAsync(S, 0, (size_t)n6 * n6 * sizeof(double), stream));
+    MQS_HIP_CHECK(hipMemsetAsync(g, 0, (size_t)n6 * sizeof(double), stream));
+    MQS_HIP_CHECK(hipMemsetAsync(info, 0, 4 * sizeof(double), stream));
+    hipLaunchKernelGGL(stage_pose_cams_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, stream, poses, pose_cam,
+                       calib, sigma, (int)P, cams);
+    if (N > 0) {
+        hipLaunchKernelGGL(sparse_landmark_kernel, dim3(lm_blocks), dim3(kBlock), 0, stream, cams, points, obs_ptr,
+                           obs_pose, obs_uv, prior_w, prior_xyz, N, lambda, rec, partials);
+        hipLaunchKernelGGL(sum_cost_partials_kernel, dim3(1), dim3(kBlock), 0, stream, partials, lm_blocks, info);
+    }
+    if (Q > 0)
+        hipLaunchKernelGGL(sparse_pairs_kernel, dim3((unsigned)((Q + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, rec,
+                           obs_pose, pair_a, pair_b, Q, n6, S, g);
+    if (n_pose_prior > 0)
+        hipLaunchKernelGGL(sparse_priors_kernel, dim3((n_pose_prior + 63) / 64), dim3(64), 0, stream, S, g, n6, poses,
+                           pose_prior_idx, pose_prior_poses, pose_prior_sigmas, n_pose_prior, lambda, info + 2);
+    hipLaunchKernelGGL(sparse_mirror_kernel, dim3((unsigned)(((int64_t)n6 * n6 + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                       stream, S, n6);
+    MQS_HIP_CHECK(hipGetLastError());
+    return MQS_OK;
+}
+
+// In place: S is replaced by its Cholesky factor (after lambda*diag(S) damping), x (= g on entry) by the
+// solution; poses_out (may be NULL) = retract(poses, x).  bad[0] (int, device) is set when S is not
+// positive definite.
+int mqs_sba_solve_dev(double *S, double *x, int64_t P, double lambda, const double *poses, double *poses_out,
+                      int *bad, void *stream_)
+{
+    MQS_ARG_CHECK(P >= 1 && S && x && bad, "arguments");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int n = (int)(6 * P);
+    MQS_HIP_CHECK(hipMemsetAsync(bad, 0, sizeof(int), stream));
+    if (lambda != 0.0) hipLaunchKernelGGL(sparse_damp_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, S, n, lambda);
+    for (int k0 = 0; k0 < n; k0 += NB) {
+        const int nb = (n - k0) < NB ? (n - k0) : NB;
+        hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(64), 0, stream, S, n, k0, bad);
+        const int rem = n - k0 - nb;
+        if (rem > 0) {
+            hipLaunchKernelGGL(chol_panel_kernel, dim3((rem + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, S, n, k0);
+            const int tiles = (rem + NB - 1) / NB;
+            hipLaunchKernelGGL(chol_update_kernel, dim3(tiles, tiles), dim3(kBlock), 0, stream, S, n, k0);
+        }
+    }
+    hipLaunchKernelGGL(chol_solve_kernel, dim3(1), dim3(kBlock), 0, stream, S, n, x);
+    if (poses_out)
+        hipLaunchKernelGGL(sparse_retract_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, stream, poses, x, (int)P,
+                           poses_out);
+    MQS_HIP_CHECK(hipGetLastError());
+    return MQS_OK;
+}
+
+int mqs_sba_backsub_dev(const double *poses, const int32_t *pose_cam, int64_t P, const double *calib,
+                        const double *sigma, const double *points, int64_t N, const int64_t *obs_ptr,
+                        const int32_t *obs_pose, const double *obs_uv, int64_t M, const double *prior_w,
+                        const double *prior_xyz, double lambda, const double *dpose, double *points_out,
+                        void *workspace, int64_t workspace_bytes, void *stream_)
+{
+    MQS_ARG_CHECK(P >= 1 && N >= 0 && M >= 0, "sizes");
+    MQS_ARG_CHECK(poses && pose_cam && calib && sigma && dpose && workspace, "pointers must not be null");
+    MQS_ARG_CHECK(workspace_bytes >= mqs_sba_workspace_bytes(P, N, M), "workspace too small");
+    if (N == 0) return MQS_OK;
+    MQS_ARG_CHECK(points && points_out && obs_ptr && (M == 0 || (obs_pose && obs_uv)), "landmark arrays");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    double *cams = static_cast<double *>(workspace);
+    hipLaunchKernelGGL(stage_pose_cams_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, stream, poses, pose_cam,
+                       calib, sigma, (int)P, cams);
+    hipLaunchKernelGGL(sparse_backsub_kernel, dim3((unsigned)((N + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, cams,
+                       points, obs_ptr, obs_pose, obs_uv, prior_w, prior_xyz, N, lambda, dpose, points_out);
+    MQS_HIP_CHECK(hipGetLastError());
+    return MQS_OK;
+}
+
+int mqs_sba_cost_dev(const double *poses, const int32_t *pose_cam, int64_t P, const double *calib, const double *sigma,
+                     const double *points, int64_t N, const int64_t *obs_ptr, const int32_t *obs_pose,
+                     const double *obs_uv, int64_t M, const double *prior_w, const double *prior_xyz, double *out,
+                     void *workspace, int64_t workspace_bytes, void *stream_)
+{
+    MQS_ARG_CHECK(P >= 1 && N >= 0 && M >= 0 && out && workspace, "arguments");
+    MQS_ARG_CHECK(workspace_bytes >= mqs_sba_workspace_bytes(P, N, M), "workspace too small");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    double *cams = static_cast<double *>(workspace);
+    double *partials = cams + P * kCamStride + M * kRec;
+    MQS_HIP_CHECK(hipMemsetAsync(out, 0, 2 * sizeof(double), stream));
+    if (N == 0) return MQS_OK;
+    const int lm_blocks = (int)((N + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(stage_pose_cams_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, stream, poses, pose_cam,
+                       calib, sigma, (int)P, cams);
+    hipLaunchKernelGGL(sparse_cost_kernel, dim3(lm_blocks), dim3(kBlock), 0, stream, cams, points, obs_ptr, obs_pose,
+                       obs_uv, prior_w, prior_xyz, N, partials);
+    hipLaunchKernelGGL(sum_cost_partials_kernel, dim3(1), dim3(kBlock), 0, stream, partials, lm_blocks, out);
+    MQS_HIP_CHECK(hipGetLastError());
+    return MQS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,192 @@
+"""
+General sparse-visibility bundle adjustment over the kernels of csrc/ba_sparse.hip -- the solver behind
+the CLI-compatible tool `tools/bundle_adjust.py`, i.e. the counterpart of
+`performBundleAdjustment` with iSAM_version = 0 (Work/SLAM/tools/bundle_adjustment/bundle_adjust.cpp:190-330:
+build the whole graph, one batch LevenbergMarquardtOptimizer::optimize() at the last step).
+
+Input: a `ba_io.SparseProblem` (poses, per-pose camera id, CSR observations, point / pose priors).
+Odometry BetweenFactors (bundle_adjust.cpp:301-309, off in the reference's working mode
+`useOdometry = 0`, ReadMe.txt:59-62) are not accelerated: requesting them raises NotImplementedError.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from .bundle_adjustment import (LM_ABS_TOL, LM_LAMBDA_FACTOR, LM_LAMBDA_INITIAL, LM_LAMBDA_UPPER, LM_MAX_ITERATIONS,
+                                LM_REL_TOL)
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def _sp():
+    return ctypes.c_void_p(_torch().cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def build_pairs(obs_ptr):
+    """All (a, b), a <= b, of observation indices within each landmark (observations are sorted by pose
+    inside a landmark, so pose(a) <= pose(b))."""
+    pa, pb = [], []
+    for i in range(len(obs_ptr) - 1):
+        k0, k = int(obs_ptr[i]), int(obs_ptr[i + 1] - obs_ptr[i])
+        if k == 0:
+            continue
+        r, c = np.triu_indices(k)
+        pa.append(k0 + r)
+        pb.append(k0 + c)
+    if not pa:
+        return np.zeros(0, np.int64), np.zeros(0, np.int64)
+    return np.concatenate(pa).astype(np.int64), np.concatenate(pb).astype(np.int64)
+
+
+def sort_observations_by_pose(problem):
+    """Returns a copy of the problem whose observations are sorted by pose index within each landmark."""
+    op = problem.obs_pose.copy()
+    uv = problem.obs_uv.copy()
+    for i in range(len(problem.obs_ptr) - 1):
+        a, b = int(problem.obs_ptr[i]), int(problem.obs_ptr[i + 1])
+        o = np.argsort(op[a:b], kind="stable")
+        op[a:b] = op[a:b][o]
+        uv[a:b] = uv[a:b][o]
+    return problem._replace(obs_pose=op, obs_uv=uv)
+
+
+class SparseBundleAdjuster:
+    def __init__(self, problem, device="cuda:0"):
+        torch = _torch()
+        if len(problem.odo_from):
+            raise NotImplementedError("odometry BetweenFactors are not part of the accelerated path")
+        pr = sort_observations_by_pose(problem)
+        self.problem = pr
+        dev = torch.device(device)
+        self.dev = dev
+        t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(dev).to(dt)
+        f64, i32, i64 = torch.float64, torch.int32, torch.int64
+        self.P, self.N, self.M = len(pr.poses), len(pr.points), len(pr.obs_pose)
+        self.poses = t(pr.poses, f64)
+        self.pose_cam = t(pr.pose_cam, i32)
+        self.calib = t(pr.calib, f64)
+        self.sigma = t(pr.sigma, f64)
+        self.points = t(pr.points, f64)
+        self.obs_ptr = t(pr.obs_ptr, i64)
+        self.obs_pose = t(pr.obs_pose, i32)
+        self.obs_uv = t(pr.obs_uv, f64)
+        pa, pb = build_pairs(pr.obs_ptr)
+        self.Q = len(pa)
+        self.pair_a, self.pair_b = t(pa, i64), t(pb, i64)
+        has_prior = pr.prior_w is not None and np.any(pr.prior_w > 0)
+        self.prior_w = t(pr.prior_w, f64) if has_prior else None
+        self.prior_xyz = t(pr.prior_xyz, f64) if has_prior else None
+        self.npp = len(pr.pose_prior_idx)
+        self.pp_idx = t(pr.pose_prior_idx, i32) if self.npp else None
+        self.pp_poses = t(pr.poses[pr.pose_prior_idx], f64) if self.npp else None      # prior = initial pose (:273)
+        self.pp_sigmas = t(pr.pose_prior_sigmas, f64) if self.npp else None
+        n6 = 6 * self.P
+        self.n6 = n6
+        self.S = torch.empty(n6 * n6, dtype=f64, device=dev)
+        self.g = torch.empty(n6, dtype=f64, device=dev)
+        self.info = torch.zeros(4, dtype=f64, device=dev)
+        self.cost_out = torch.zeros(2, dtype=f64, device=dev)
+        self.bad = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.poses_new = torch.empty_like(self.poses)
+        self.points_new = torch.empty_like(self.points)
+        self.ws = torch.empty(int(_lib.lib().mqs_sba_workspace_bytes(self.P, self.N, self.M)), dtype=torch.uint8,
+                              device=dev)
+
+    def linearize(self, lam=0.0):
+        _lib.check(_lib.lib().mqs_sba_linearize_dev(
+            _p(self.poses), _p(self.pose_cam), self.P, _p(self.calib), _p(self.sigma), _p(self.points), self.N,
+            _p(self.obs_ptr), _p(self.obs_pose), _p(self.obs_uv), self.M, _p(self.pair_a), _p(self.pair_b), self.Q,
+            _p(self.prior_w), _p(self.prior_xyz), _p(self.pp_idx), _p(self.pp_poses), _p(self.pp_sigmas), self.npp,
+            float(lam), _p(self.S), _p(self.g), _p(self.info), _p(self.ws), self.ws.numel(), _sp()))
+        return self.S.view(self.n6, self.n6), self.g
+
+    def solve(self, lam=0.0):
+        """Destroys S (replaced by its Cholesky factor) and g (replaced by dpose); retracts the poses."""
+        _lib.check(_lib.lib().mqs_sba_solve_dev(_p(self.S), _p(self.g), self.P, float(lam), _p(self.poses),
+                                                _p(self.poses_new), _p(self.bad), _sp()))
+        return self.g
+
+    def backsub(self, lam=0.0):
+        _lib.check(_lib.lib().mqs_sba_backsub_dev(
+            _p(self.poses), _p(self.pose_cam), self.P, _p(self.calib), _p(self.sigma), _p(self.points), self.N,
+            _p(self.obs_ptr), _p(self.obs_pose), _p(self.obs_uv), self.M, _p(self.prior_w), _p(self.prior_xyz),
+            float(lam), _p(self.g), _p(self.points_new), _p(self.ws), self.ws.numel(), _sp()))
+        return self.points_new
+
+    def cost(self, poses=None, points=None):
+        poses = self.poses if poses is None else poses
+        points = self.points if points is None else points
+        _lib.check(_lib.lib().mqs_sba_cost_dev(
+            _p(poses), _p(self.pose_cam), self.P, _p(self.calib), _p(self.sigma), _p(points), self.N, _p(self.obs_ptr),
+            _p(self.obs_pose), _p(self.obs_uv), self.M, _p(self.prior_w), _p(self.prior_xyz), _p(self.cost_out),
+            _p(self.ws), self.ws.numel(), _sp()))
+        c = float(self.cost_out[0].item())
+        if self.npp:
+            c += self._pose_prior_cost(poses)
+        return c
+
+    def _pose_prior_cost(self, poses):
+        P = poses.cpu().numpy()
+        pr = self.problem
+        cost = 0.0
+        for k, j in enumerate(pr.pose_prior_idx):
+            R0 = pr.poses[j, :9].reshape(3, 3)
+            R = P[j, :9].reshape(3, 3)
+            Rr = R0.T @ R
+            th = np.arccos(min(1.0, max(-1.0, 0.5 * (np.trace(Rr) - 1))))
+            v = np.array([Rr[2, 1] - Rr[1, 2], Rr[0, 2] - Rr[2, 0], Rr[1, 0] - Rr[0, 1]])
+            w = 0.5 * v if th < 1e-10 else v * th / (2 * np.sin(th))
+            e = np.concatenate([w, R0.T @ (P[j, 9:] - pr.poses[j, 9:])]) / pr.pose_prior_sigmas[k]
+            cost += 0.5 * float(e.dot(e))
+        return cost
+
+    def step(self, lam):
+        self.linearize(lam)
+        self.solve(lam)
+        self.backsub(lam)
+
+    def accept(self):
+        self.poses, self.poses_new = self.poses_new, self.poses
+        self.points, self.points_new = self.points_new, self.points
+
+    def optimize(self, iters=LM_MAX_ITERATIONS, mode="lm", verbose=False):
+        """mode "lm": GTSAM 3.2.1's default Levenberg-Marquardt schedule (bundle_adjust.cpp:323-324);
+        mode "gn": plain Gauss-Newton.  Returns the cost history."""
+        hist = [self.cost()]
+        if mode == "gn":
+            for _ in range(iters):
+                self.step(0.0)
+                self.accept()
+                hist.append(self.cost())
+            return hist
+        lam, cur = LM_LAMBDA_INITIAL, hist[0]
+        for _ in range(min(iters, LM_MAX_ITERATIONS)):
+            improved = False
+            while lam <= LM_LAMBDA_UPPER:
+                self.step(lam)
+                ok = int(self.bad.item()) == 0
+                new = self.cost(self.poses_new, self.points_new) if ok else float("inf")
+                if verbose:
+                    print("  lm lambda %.1e cost %.6e -> %.6e" % (lam, cur, new))
+                if new <= cur:
+                    self.accept()
+                    lam = max(lam / LM_LAMBDA_FACTOR, 1e-20)
+                    improved = True
+                    break
+                lam *= LM_LAMBDA_FACTOR
+            if not improved:
+                break
+            hist.append(new)
+            done = abs(cur - new) < LM_ABS_TOL or abs(cur - new) / max(cur, 1e-300) < LM_REL_TOL
+            cur = new
+            if done:
+                break
+        return hist

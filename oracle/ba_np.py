@@ -241,3 +241,94 @@ def dense_reference_step(poses, calib, sigma, points, obs):
             H += J.T @ J
             b -= J.T @ e
     return H, b
+
+
+# ---------------------------------------------------------------------------------------------
+# General (sparse-visibility) form: P poses, each with a camera id; observations listed per landmark
+# (CSR).  Same factor maths; this is the graph bundle_adjust.cpp:245-298 builds from the file set.
+# ---------------------------------------------------------------------------------------------
+
+def sparse_linearize(poses, pose_cam, calib, sigma, points, obs_ptr, obs_pose, obs_uv, prior_w=None, prior_xyz=None,
+                     lam=0.0):
+    """Returns S (6P,6P), g (6P,), cost, n_valid and per-landmark pieces for the back-substitution."""
+    P, N = len(poses), len(points)
+    S = np.zeros((6 * P, 6 * P))
+    g = np.zeros(6 * P)
+    cost = 0.0
+    nvalid = 0
+    pieces = []
+    for i in range(N):
+        Hll = np.zeros((3, 3))
+        gl = np.zeros(3)
+        rows = []
+        constrained = False
+        for k in range(obs_ptr[i], obs_ptr[i + 1]):
+            j = obs_pose[k]
+            c = pose_cam[j]
+            e, Jp, Jl, valid = factor(poses[j], calib[c], sigma[c], points[i], obs_uv[k])
+            cost += 0.5 * e.dot(e)
+            nvalid += int(valid)
+            constrained = constrained or valid
+            Hll += Jl.T @ Jl
+            gl -= Jl.T @ e
+            rows.append((j, Jp.T @ Jl, Jp.T @ Jp, -Jp.T @ e))
+        if prior_w is not None and prior_w[i] > 0:
+            d = points[i] - prior_xyz[i]
+            Hll += prior_w[i] * np.eye(3)
+            gl -= prior_w[i] * d
+            cost += 0.5 * prior_w[i] * d.dot(d)
+            constrained = True
+        if lam:
+            Hll = Hll + lam * np.diag(np.diag(Hll))
+        if constrained and np.linalg.eigvalsh(Hll)[0] > 1e-13 * np.trace(Hll):
+            Hi = np.linalg.inv(Hll)
+        else:
+            Hi = np.zeros((3, 3))
+        for (j, Hpl, Hpp, gp) in rows:
+            S[6 * j:6 * j + 6, 6 * j:6 * j + 6] += Hpp
+            g[6 * j:6 * j + 6] += gp - Hpl @ Hi @ gl
+            for (j2, Hpl2, _, _) in rows:
+                S[6 * j:6 * j + 6, 6 * j2:6 * j2 + 6] -= Hpl @ Hi @ Hpl2.T
+        pieces.append((Hi, gl, [(j, Hpl) for (j, Hpl, _, _) in rows]))
+    return S, g, cost, nvalid, pieces
+
+
+def sparse_backsub(pieces, dpose):
+    out = np.zeros((len(pieces), 3))
+    for i, (Hi, gl, rows) in enumerate(pieces):
+        r = gl.copy()
+        for (j, Hpl) in rows:
+            r -= Hpl.T @ dpose[6 * j:6 * j + 6]
+        out[i] = Hi @ r
+    return out
+
+
+def sparse_pose_prior_terms(poses, idx, prior_poses, sigmas):
+    """PriorFactor<Pose3> on poses idx[k] with prior prior_poses[k] and sigmas[k] (6)."""
+    n = 6 * len(poses)
+    H = np.zeros((n, n))
+    g = np.zeros(n)
+    cost = 0.0
+    for k, j in enumerate(idx):
+        R0 = prior_poses[k, :9].reshape(3, 3)
+        R = poses[j, :9].reshape(3, 3)
+        e = np.concatenate([so3_log(R0.T @ R), R0.T @ (poses[j, 9:] - prior_poses[k, 9:])])
+        w = 1.0 / sigmas[k] ** 2
+        H[6 * j:6 * j + 6, 6 * j:6 * j + 6] += np.diag(w)
+        g[6 * j:6 * j + 6] -= w * e
+        cost += 0.5 * float((w * e * e).sum())
+    return H, g, cost
+
+
+def sparse_cost(poses, pose_cam, calib, sigma, points, obs_ptr, obs_pose, obs_uv, prior_w=None, prior_xyz=None):
+    cost = 0.0
+    for i in range(len(points)):
+        for k in range(obs_ptr[i], obs_ptr[i + 1]):
+            j = obs_pose[k]
+            c = pose_cam[j]
+            e, _, _, _ = factor(poses[j], calib[c], sigma[c], points[i], obs_uv[k])
+            cost += 0.5 * e.dot(e)
+        if prior_w is not None and prior_w[i] > 0:
+            d = points[i] - prior_xyz[i]
+            cost += 0.5 * prior_w[i] * d.dot(d)
+    return cost

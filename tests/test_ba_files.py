@@ -1,0 +1,204 @@
+"""
+B5 + 8(f) rank 1: the reference's on-disk BA format and the general sparse solver.
+CPU: loaders / validators / writers on the reference's committed data files (tests/golden/ba_example,
+tests/golden/ba_svo are copies of those DATA files).  GPU: sparse kernels against the sparse oracle, the
+dense-vs-sparse equivalence, and the committed converged outputs as loose anchors.
+"""
+import os
+import numpy as np
+import pytest
+
+from oracle import ba_np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+EX = os.path.join(HERE, "golden", "ba_example")
+SVO = os.path.join(HERE, "golden", "ba_svo")
+
+
+def load(mqs, d, name, nc, fps):
+    io = mqs.ba_io
+    fn = io.create_filenames(d, name, nc)
+    data = io.load_data(fn, fps)
+    io.validate_data_integrity(data, nc)
+    return fn, data
+
+
+def test_example_files_load_and_validate(mqs):
+    io = mqs.ba_io
+    fn, data = load(mqs, EX, "synthetic", 2, 1)
+    assert len(data.points3D) == 8 and len(data.point3DAddedIdxs) == 20 and len(data.calibrations) == 2
+    assert np.abs(np.abs(data.points3D) - 10.0).max() < 0.5                 # noisy corners of the 20-unit cube
+    np.testing.assert_array_equal(np.abs(data.points3D[:4]), 10.0)         # step-0 points are exact
+    ok, log = io.validate_sufficiently_constrained(data, True)
+    assert ok and log[-1][1] == 3 * 8 + 6 * 40
+    pr = io.build_sparse_problem(data, use_odometry=True)
+    assert pr.poses.shape == (40, 12) and len(pr.obs_pose) == 320 and len(pr.odo_from) == 58
+    assert (pr.prior_w > 0).sum() == 4 and pr.prior_w.max() == pytest.approx(2 / 0.2 ** 2)   # seen by both cameras
+    for p in pr.poses:
+        R = p[:9].reshape(3, 3)
+        np.testing.assert_allclose(R @ R.T, np.eye(3), atol=1e-12)
+    np.testing.assert_allclose(pr.calib[0], [500, 500, 0, 320, 240, 0, 0, 0, 0])
+    assert fn.map_out.endswith("map_out-synthetic-BA.pcd")
+
+
+def test_svo_files_load(mqs):
+    io = mqs.ba_io
+    fn, data = load(mqs, SVO, "slam2", 1, 50)
+    pr = io.build_sparse_problem(data)
+    assert pr.poses.shape == (186, 12) and pr.points.shape == (1046, 3) and len(pr.obs_pose) == 7494
+    ok, _ = io.validate_sufficiently_constrained(data, False)
+    assert ok
+
+
+def test_validators_reject_bad_data(mqs):
+    io = mqs.ba_io
+    fn, data = load(mqs, EX, "synthetic", 2, 1)
+    data.point2D3DAssocs[0][3].append((5, 0, 0))            # looks into the future (frame 5 at step 3)
+    with pytest.raises(ValueError):
+        io.validate_data_integrity(data, 2)
+    fn, data = load(mqs, EX, "synthetic", 2, 1)
+    data.point3DAddedIdxs[2].append(0)                      # point 0 added twice
+    with pytest.raises(ValueError):
+        io.validate_sufficiently_constrained(data, False)
+
+
+def test_write_read_round_trip(mqs, tmp_path):
+    io = mqs.ba_io
+    fn, data = load(mqs, EX, "synthetic", 2, 1)
+    out = io.create_filenames(str(tmp_path), "synthetic", 2)
+    io.save_result(out._replace(map_out=out.map_in, trajectories_out=out.trajectories_in), data)
+    pts = io.load_map(out.map_in)
+    np.testing.assert_allclose(pts, data.points3D, rtol=1e-15)
+    tr = io.load_trajectory(out.trajectories_in[1])
+    assert len(tr) == 20
+    for (t0, p0), (t1, p1) in zip(tr, data.poses[1]):
+        assert t0 == t1
+        np.testing.assert_allclose(p0, p1, atol=1e-12)
+    q = io.R_to_quat(io.quat_to_R(0.1, -0.2, 0.3, 0.9))
+    np.testing.assert_allclose(q, np.array([0.1, -0.2, 0.3, 0.9]) / np.linalg.norm([0.1, -0.2, 0.3, 0.9]), atol=1e-15)
+
+
+def _lin_oracle(pr, lam=0.0):
+    S, g, cost, nv, pieces = ba_np.sparse_linearize(pr.poses, pr.pose_cam, pr.calib, pr.sigma, pr.points, pr.obs_ptr,
+                                                    pr.obs_pose, pr.obs_uv, pr.prior_w, pr.prior_xyz, lam)
+    Hp, gp, cp = ba_np.sparse_pose_prior_terms(pr.poses, pr.pose_prior_idx, pr.poses[pr.pose_prior_idx], pr.pose_prior_sigmas)
+    return S + Hp, g + gp, cost, nv, pieces, cp
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["example", "svo"])
+@pytest.mark.parametrize("lam", [0.0, 1e-3])
+def test_sparse_linearize_solve_backsub_parity(which, lam, gpu):
+    d, name, nc, fps = (EX, "synthetic", 2, 1) if which == "example" else (SVO, "slam2", 1, 50)
+    fn, data = load(gpu, d, name, nc, fps)
+    pr0 = gpu.ba_io.build_sparse_problem(data)
+    rng = np.random.default_rng(0)                                    # move off the files' 6-digit optimum
+    pr0 = pr0._replace(points=pr0.points + 0.01 * rng.standard_normal(pr0.points.shape))
+    ba = gpu.sparse_ba.SparseBundleAdjuster(pr0)
+    pr = ba.problem
+    S, g = ba.linearize(lam)
+    S, g = S.cpu().numpy().copy(), g.cpu().numpy().copy()
+    info = ba.info.cpu().numpy()
+    So, go, co, nvo, pieces, cp = _lin_oracle(pr, lam)
+    assert np.abs(S - So).max() <= 1e-9 * np.abs(So).max()
+    assert np.abs(g - go).max() <= 1e-9 * np.abs(go).max()
+    assert info[0] == pytest.approx(co, rel=1e-11) and info[1] == nvo and info[2] == pytest.approx(cp, rel=1e-9, abs=1e-12)
+    np.testing.assert_array_equal(S, S.T)
+    # blocked Cholesky solve (with damping), retraction, back-substitution
+    d_ref = np.linalg.solve(So + lam * np.diag(np.diag(So)) + (0 if lam else 1e-30) * np.eye(len(go)), go)
+    ba.solve(lam)
+    dpose = ba.g.cpu().numpy()
+    assert int(ba.bad.item()) == 0
+    assert np.abs(dpose - d_ref).max() <= 1e-6 * np.abs(d_ref).max()
+    new = ba.poses_new.cpu().numpy()
+    for j in (0, len(new) // 2, len(new) - 1):
+        np.testing.assert_allclose(new[j], ba_np.retract_pose(pr.poses[j], dpose[6 * j:6 * j + 6]), atol=1e-10)
+    pts = ba.backsub(lam).cpu().numpy()
+    dp = ba_np.sparse_backsub(pieces, dpose)
+    assert np.abs(pts - (pr.points + dp)).max() <= 1e-8 * max(1.0, np.abs(dp).max())
+    assert ba.cost() == pytest.approx(co + cp, rel=1e-10)
+
+
+@pytest.mark.gpu
+def test_sparse_equals_dense_kernels(gpu):
+    """The same 4-pose full-visibility scene through both code paths."""
+    import torch
+    from ba_util import make_scene
+    sc = make_scene(600, 4, seed=21, distortion=True, masked_frac=0.25)
+    d = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    dense = gpu.bundle_adjustment.BundleAdjuster(d(sc["poses"]), d(sc["calib"]), d(sc["sigma"]), d(sc["points"]), d(sc["obs"]),
+                                                 d(sc["mask"]), d(sc["prior_w"]), d(sc["prior_xyz"]))
+    lin = dense.linearize(0.0).cpu().numpy()
+    ptr, op, uv = [0], [], []
+    for i in range(600):
+        for c in range(4):
+            if sc["mask"][c, i]:
+                op.append(c); uv.append(sc["obs"][c, i])
+        ptr.append(len(op))
+    SP = gpu.ba_io.SparseProblem
+    e = np.zeros(0)
+    pr = SP(poses=sc["poses"], pose_cam=np.arange(4, dtype=np.int32), pose_key=[(c, 0) for c in range(4)], calib=sc["calib"],
+            sigma=sc["sigma"], points=sc["points"], obs_ptr=np.array(ptr, dtype=np.int64), obs_pose=np.array(op, dtype=np.int32),
+            obs_uv=np.array(uv), prior_w=sc["prior_w"], prior_xyz=sc["prior_xyz"], pose_prior_idx=np.zeros(0, np.int32),
+            pose_prior_sigmas=np.zeros((0, 6)), odo_from=e.astype(np.int32), odo_to=e.astype(np.int32),
+            odo_meas=np.zeros((0, 12)), odo_sigmas=np.zeros((0, 6)))
+    sp = gpu.sparse_ba.SparseBundleAdjuster(pr)
+    S, g = sp.linearize(0.0)
+    S, g = S.cpu().numpy(), g.cpu().numpy()
+    assert np.abs(S.reshape(-1) - lin[:576]).max() <= 1e-10 * np.abs(lin[:576]).max()
+    assert np.abs(g - lin[576:600]).max() <= 1e-10 * np.abs(lin[576:600]).max()
+    assert sp.info[0].item() == pytest.approx(lin[600], rel=1e-12)
+
+
+@pytest.mark.gpu
+def test_example_converges_near_committed_reference_output(gpu):
+    """Loose anchor: the committed *-BA outputs were produced with odometry + iSAM2 and
+    6-digit inputs, so only 'same basin' is asserted: the optimised map is the 20-unit cube and the
+    optimised trajectory stays within the reference's own correction magnitude of its -BA output."""
+    io = gpu.ba_io
+    fn, data = load(gpu, EX, "synthetic", 2, 1)
+    pr = io.build_sparse_problem(data)
+    ba = gpu.sparse_ba.SparseBundleAdjuster(pr)
+    hist = ba.optimize(mode="lm")
+    assert hist[-1] < hist[0] and all(b <= a for a, b in zip(hist, hist[1:]))
+    assert hist[-1] / len(pr.obs_pose) < 2.0                     # chi^2 per factor ~ 1 (pixel sigma 1)
+    pts = ba.points.cpu().numpy()
+    ref_pts = io.load_map(os.path.join(EX, "map_out-synthetic-BA.pcd"))
+    assert np.abs(pts - ref_pts).max() < 0.5                     # cube of edge 20
+    ref_tr = io.load_trajectory(os.path.join(EX, "traj_out.cam0-synthetic-BA.txt"))
+    in_tr = io.load_trajectory(os.path.join(EX, "traj_out.cam0-synthetic.txt"))
+    ours = ba.poses.cpu().numpy()
+    k = [i for i, key in enumerate(ba.problem.pose_key) if key[0] == 0]
+    d_ours = np.array([np.linalg.norm(ours[i][9:] - r[1][9:]) for i, r in zip(k, ref_tr)])
+    d_in = np.array([np.linalg.norm(a[1][9:] - r[1][9:]) for a, r in zip(in_tr, ref_tr)])
+    assert np.median(d_ours) < np.median(d_in)                   # closer to the reference's BA output than the input was
+
+
+@pytest.mark.gpu
+def test_svo_dataset_full_optimisation(gpu, tmp_path):
+    """The reference's real data set (186 poses, 1046 points, 7494 observations), file in -> file out through
+    the CLI-compatible tool; anchored on the committed slam2-BA output."""
+    import shutil, subprocess, sys
+    work = tmp_path / "svo"
+    shutil.copytree(SVO, work)
+    for f in ("traj_out.cam0-slam2-BA.txt", "map_out-slam2-BA.pcd"):
+        os.remove(work / f)
+    root = os.path.dirname(HERE)
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "bundle_adjust.py"), str(work), "slam2", "1", "50", "0", "1", "0", "1", "0"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    io = gpu.ba_io
+    ours = io.load_map(str(work / "map_out-slam2-BA.pcd"))
+    ref = io.load_map(os.path.join(SVO, "map_out-slam2-BA.pcd"))
+    inp = io.load_map(os.path.join(SVO, "map_out-slam2.pcd"))
+    assert ours.shape == ref.shape == (1046, 3)
+    d_ours = np.linalg.norm(ours - ref, axis=1)
+    d_in = np.linalg.norm(inp - ref, axis=1)
+    assert np.median(d_ours) < 0.25 * np.median(d_in)            # moved most of the way to the reference's optimum
+    tr = io.load_trajectory(str(work / "traj_out.cam0-slam2-BA.txt"))
+    rt = io.load_trajectory(os.path.join(SVO, "traj_out.cam0-slam2-BA.txt"))
+    it = io.load_trajectory(os.path.join(SVO, "traj_out.cam0-slam2.txt"))
+    assert len(tr) == len(rt) == 186
+    e_ours = np.median([np.linalg.norm(a[1][9:] - b[1][9:]) for a, b in zip(tr, rt)])
+    e_in = np.median([np.linalg.norm(a[1][9:] - b[1][9:]) for a, b in zip(it, rt)])
+    assert e_ours < 0.25 * e_in
