@@ -202,3 +202,13 @@ def test_svo_dataset_full_optimisation(gpu, tmp_path):
     e_ours = np.median([np.linalg.norm(a[1][9:] - b[1][9:]) for a, b in zip(tr, rt)])
     e_in = np.median([np.linalg.norm(a[1][9:] - b[1][9:]) for a, b in zip(it, rt)])
     assert e_ours < 0.25 * e_in
+    # the reference's published accuracy numbers: ATE rmse 0.395356 m before BA,
+    # 0.021598 m after the reference's (GTSAM) BA -- reproduced by the restated evaluate_ate on the committed
+    # files, and matched by this build's BA output
+    from util import ate_rmse
+    gt = [(t, p[9:]) for t, p in io.load_trajectory(os.path.join(SVO, "traj_groundtruth.txt"))]
+    xyz = lambda tr_: [(t, p[9:]) for t, p in tr_]
+    assert ate_rmse(xyz(it), gt)[0] == pytest.approx(0.395356, abs=1e-6)
+    assert ate_rmse(xyz(rt), gt)[0] == pytest.approx(0.021598, abs=1e-6)
+    ours_ate, npairs = ate_rmse(xyz(tr), gt)
+    assert npairs == 186 and ours_ate == pytest.approx(0.021598, rel=0.05)

@@ -50,3 +50,27 @@ def random_scene(N, C, seed=0, behind_frac=0.05, noise=1e-3):
         q = pts @ P[c, :, :3].T + P[c, :, 3]
         u[c] = q[:, :2] / q[:, 2:3] + noise * rng.standard_normal((N, 2))
     return u, P, pts
+
+
+def ate_rmse(traj_est, traj_gt, max_dt=0.02):
+    """Absolute trajectory error as the TUM benchmark's evaluate_ate.py computes it (restated:
+    nearest-timestamp association within max_dt, rigid Horn alignment without scale, RMSE of the
+    translational residuals).  traj_*: lists of (timestamp, xyz)."""
+    gt_t = np.array([t for t, _ in traj_gt])
+    pairs = []
+    for t, p in traj_est:
+        k = int(np.argmin(np.abs(gt_t - t)))
+        if abs(gt_t[k] - t) < max_dt:
+            pairs.append((p, traj_gt[k][1]))
+    A = np.array([a for a, _ in pairs]).T        # estimated, 3 x n
+    B = np.array([b for _, b in pairs]).T        # ground truth
+    Ac, Bc = A - A.mean(1, keepdims=True), B - B.mean(1, keepdims=True)
+    U, _, Vt = np.linalg.svd(Ac @ Bc.T)
+    D = np.eye(3)
+    if np.linalg.det(U) * np.linalg.det(Vt) < 0:
+        D[2, 2] = -1
+    R = U @ D @ Vt                               # rotates ground-truth-centred onto estimate: est ~ R^T ...
+    R = R.T
+    t = B.mean(1, keepdims=True) - R @ A.mean(1, keepdims=True)
+    err = R @ A + t - B
+    return float(np.sqrt(np.mean(np.sum(err ** 2, axis=0)))), len(pairs)
