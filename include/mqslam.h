@@ -100,6 +100,15 @@ int mqs_triangulate_iterative_ls_dev(const double *u, const double *P, int C, in
 int mqs_triangulate_linear_eigen_dev(const double *u, const double *P, int C, int64_t N,
                                      double max_coord, double *x, uint8_t *ok, void *stream);
 
+/* Fused form: observations given in PIXELS [C][N][2] with per-camera intrinsics intr [C][9]
+ * (fx fy cx cy k1 k2 p1 p2 k3); undistort + normalise (cv2.undistortPoints, slam2.py:551-552) happens on
+ * load inside the triangulation kernel.  kind: 0 linear_ls, 1 iterative_ls, 2 linear_eigen; status / ok
+ * may be NULL when the kind does not produce them.  Bitwise equal to mqs_undistort_points_dev followed by
+ * the matching mqs_triangulate_*_dev. */
+int mqs_triangulate_pixels_dev(int kind, const double *pixels, const double *intr, const double *P, int C,
+                               int64_t N, double tolerance, int max_iter, double max_coord, double *x,
+                               int32_t *status, uint8_t *ok, void *stream);
+
 /* ---------------------------------------------------------------------------------------
  * Brute-force descriptor matching (replaces cv2.batchDistance + the per-query loop of
  * cv2_helpers.py:296-339): for every query row the two nearest train rows under L2, ties

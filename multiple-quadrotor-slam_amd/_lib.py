@@ -50,6 +50,8 @@ SIGNATURES = {
                                                         ctypes.c_int, c_vp, c_vp, c_vp]),
     "mqs_triangulate_linear_eigen_dev": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, c_i64, ctypes.c_double, c_vp,
                                                         c_vp, c_vp]),
+    "mqs_triangulate_pixels_dev": (ctypes.c_int, [ctypes.c_int, c_vp, c_vp, c_vp, ctypes.c_int, c_i64, ctypes.c_double,
+                                                  ctypes.c_int, ctypes.c_double, c_vp, c_vp, c_vp, c_vp]),
     "mqs_match_knn2_f32": (ctypes.c_int, [c_vp, c_f32p, c_i64, c_f32p, c_i64, ctypes.c_int, c_i32p, c_f32p]),
     "mqs_match_knn2_f32_dev": (ctypes.c_int, [c_vp, c_i64, c_vp, c_i64, ctypes.c_int, c_vp, c_vp, c_vp]),
     "mqs_match_knn2_f16": (ctypes.c_int, [c_vp, c_u16p, c_i64, c_u16p, c_i64, ctypes.c_int, c_i32p, c_f32p]),

@@ -20,6 +20,7 @@
 //     HBM traffic per landmark is the algorithmic minimum 16*C + 24 (+4 | +1) bytes.
 #include "mqs_common.h"
 #include "tri_math.h"
+#include "cam_math.h"
 
 namespace {
 
@@ -35,17 +36,23 @@ enum TriKind { kLinearLS = 0, kIterativeLS = 1, kLinearEigen = 2 };
 #endif
 constexpr int waves_for(int kind) { return kind == 1 ? MQS_ITER_WAVES : 2; }
 
-template <int C, int KIND>
+// PIX: the observations are PIXELS and `intr` holds [C][9] intrinsics (fx fy cx cy k1 k2 p1 p2 k3): the
+// undistort + normalise step the reference runs right before triangulating (cv2.undistortPoints,
+// slam2.py:551-552) is applied on load, saving its 2 x 16*C bytes per landmark of HBM round trip.
+template <int C, int KIND, bool PIX>
 __global__ __launch_bounds__(kBlock, waves_for(KIND)) void tri_kernel(const double *__restrict__ u, const double *__restrict__ P,
+                                                                      const double *__restrict__ intr,
                                                      int64_t N, double tol, int max_iter, double max_coord,
                                                      double *__restrict__ x, int32_t *__restrict__ status,
                                                      uint8_t *__restrict__ ok)
 {
     __shared__ double sP[C * 12];
     __shared__ double sX[kBlock * 3];
+    __shared__ double sI[PIX ? C * 9 : 1];
 
     const int tid = threadIdx.x;
     if (tid < C * 12) sP[tid] = P[tid];
+    if (PIX && tid < C * 9) sI[tid] = intr[tid];
     __syncthreads();
 
     const double2 *__restrict__ u2 = reinterpret_cast<const double2 *>(u);
@@ -60,6 +67,7 @@ __global__ __launch_bounds__(kBlock, waves_for(KIND)) void tri_kernel(const doub
         for (int c = 0; c < C; ++c) {
             double2 v = make_double2(0.0, 0.0);
             if (live) v = u2[(int64_t)c * N + i];
+            if (PIX) mqs::cam::undistort_pixel(sI + 9 * c, v.x, v.y, v.x, v.y);
             uv[c][0] = v.x;
             uv[c][1] = v.y;
         }
@@ -81,6 +89,7 @@ __global__ __launch_bounds__(kBlock, waves_for(KIND)) void tri_kernel(const doub
                 for (int c = 0; c < C; ++c) {
                     double2 v = make_double2(0.0, 0.0);
                     if (live) v = u2[(int64_t)c * N + j];
+                    if (PIX) mqs::cam::undistort_pixel(sI + 9 * c, v.x, v.y, v.x, v.y);
                     uv2[c][0] = v.x;
                     uv2[c][1] = v.y;
                 }
@@ -113,7 +122,7 @@ __global__ __launch_bounds__(kBlock, waves_for(KIND)) void tri_kernel(const doub
 
 template <int KIND>
 int launch_tri(const double *u, const double *P, int C, int64_t N, double tol, int max_iter, double max_coord,
-               double *x, int32_t *status, uint8_t *ok, hipStream_t stream)
+               double *x, int32_t *status, uint8_t *ok, hipStream_t stream, const double *intr = nullptr)
 {
     MQS_ARG_CHECK(C >= 2 && C <= MQS_MAX_CAMS, "2 <= C <= MQS_MAX_CAMS");
     MQS_ARG_CHECK(N >= 0, "N >= 0");
@@ -126,8 +135,12 @@ int launch_tri(const double *u, const double *P, int C, int64_t N, double tol, i
     switch (C) {
 #define MQS_CASE(c)                                                                             \
     case c:                                                                                     \
-        hipLaunchKernelGGL((tri_kernel<c, KIND>), grid, block, 0, stream, u, P, N, tol, max_iter, \
-                           max_coord, x, status, ok);                                           \
+        if (intr)                                                                               \
+            hipLaunchKernelGGL((tri_kernel<c, KIND, true>), grid, block, 0, stream, u, P, intr, N, tol, \
+                               max_iter, max_coord, x, status, ok);                             \
+        else                                                                                    \
+            hipLaunchKernelGGL((tri_kernel<c, KIND, false>), grid, block, 0, stream, u, P, intr, N, tol, \
+                               max_iter, max_coord, x, status, ok);                             \
         break;
         MQS_CASE(2) MQS_CASE(3) MQS_CASE(4) MQS_CASE(5) MQS_CASE(6) MQS_CASE(7) MQS_CASE(8)
 #undef MQS_CASE
@@ -204,6 +217,18 @@ int mqs_triangulate_linear_eigen_dev(const double *u, const double *P, int C, in
                                      uint8_t *ok, void *stream)
 {
     return launch_tri<kLinearEigen>(u, P, C, N, 0.0, 0, max_coord, x, nullptr, ok, static_cast<hipStream_t>(stream));
+}
+
+int mqs_triangulate_pixels_dev(int kind, const double *pixels, const double *intr, const double *P, int C, int64_t N,
+                               double tolerance, int max_iter, double max_coord, double *x, int32_t *status, uint8_t *ok,
+                               void *stream)
+{
+    MQS_ARG_CHECK(kind >= 0 && kind <= 2, "kind in {0 linear_ls, 1 iterative_ls, 2 linear_eigen}");
+    MQS_ARG_CHECK(intr != nullptr, "intr must not be null");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (kind == 0) return launch_tri<kLinearLS>(pixels, P, C, N, 0.0, 0, 0.0, x, nullptr, nullptr, s, intr);
+    if (kind == 1) return launch_tri<kIterativeLS>(pixels, P, C, N, tolerance, max_iter, 0.0, x, status, nullptr, s, intr);
+    return launch_tri<kLinearEigen>(pixels, P, C, N, 0.0, 0, max_coord, x, nullptr, ok, s, intr);
 }
 
 int mqs_triangulate_linear_ls(mqs_ctx *ctx, const double *u, const double *P, int C, int64_t N, double *x)

@@ -87,3 +87,22 @@ def time_triangulation(kind, u, P, reps=20, tolerance=3.e-5, max_iter=10):
                                                    int(max_iter), x.data_ptr(), st.data_ptr(), ok.data_ptr(),
                                                    int(reps), _stream_ptr(), ctypes.byref(ms)))
     return float(ms.value)
+
+
+def triangulate_pixels(kind, pixels, intr, P, tolerance=3.e-5, max_iter=10, max_coordinate_value=1.e16):
+    """Fused undistort + normalise + triangulate: pixels (C,N,2) f64, intr (C,9) f64 = fx fy cx cy k1 k2 p1 p2 k3,
+    P (C,3,4).  Returns (x, status | ok | None) like the un-fused functions of the same `kind`."""
+    torch = _torch()
+    C, N = _tri_args(pixels, P)
+    _check_dev(intr, torch.float64, "intr")
+    if tuple(intr.shape) != (C, 9):
+        raise ValueError("intr must have shape (C, 9)")
+    k = {"linear_ls": 0, "iterative_ls": 1, "linear_eigen": 2}[kind]
+    x = torch.empty((N, 3), dtype=torch.float64, device=pixels.device)
+    st = torch.empty((N,), dtype=torch.int32, device=pixels.device) if k == 1 else None
+    ok = torch.empty((N,), dtype=torch.uint8, device=pixels.device) if k == 2 else None
+    _lib.check(_lib.lib().mqs_triangulate_pixels_dev(
+        k, pixels.data_ptr(), intr.data_ptr(), P.data_ptr(), C, N, float(tolerance), int(max_iter),
+        float(max_coordinate_value), x.data_ptr(), None if st is None else st.data_ptr(),
+        None if ok is None else ok.data_ptr(), _stream_ptr()))
+    return x, (st if k == 1 else ok)

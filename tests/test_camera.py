@@ -143,3 +143,39 @@ def test_gpu_distortion_tier_golden_cells_end_to_end(which, cell, golden3, golde
         tr, pi = cell
         res = H.test_1and2_cell(tr, pi, methods, int(golden12["num_trials"]))
         _check_cell(res, [golden12[k][tr, pi] for k in KEYS], 25700)
+
+
+@pytest.mark.gpu
+def test_fused_pixels_triangulation_equals_two_step(gpu):
+    """pixels -> (undistort on load) -> triangulate in ONE kernel == undistort kernel then triangulation kernel, bitwise."""
+    import torch
+    N, C = 20011, 4
+    u, P, pts = gpu.synthetic.triangulation_problem(N, C)
+    intr = np.tile(np.array([480.0, 470.0, 320.0, 240.0, 0.3, -0.05, 0.002, -0.001, 0.01]), (C, 1))
+    intr[:, 0] += np.arange(C)
+    xd = np.empty_like(u)
+    for c in range(C):                                    # distort the normalised observations, then to pixels
+        x, y = u[c, :, 0], u[c, :, 1]
+        r2 = x * x + y * y
+        g = 1 + intr[c, 4] * r2 + intr[c, 5] * r2 ** 2 + intr[c, 8] * r2 ** 3
+        xd[c, :, 0] = (x * g + 2 * intr[c, 6] * x * y + intr[c, 7] * (r2 + 2 * x * x)) * intr[c, 0] + intr[c, 2]
+        xd[c, :, 1] = (y * g + intr[c, 6] * (r2 + 2 * y * y) + 2 * intr[c, 7] * x * y) * intr[c, 1] + intr[c, 3]
+    pix = torch.from_numpy(xd).cuda()
+    Pd = torch.from_numpy(np.ascontiguousarray(P)).cuda()
+    intr_d = torch.from_numpy(intr).cuda()
+    un = torch.empty_like(pix)
+    sp = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for c in range(C):
+        gpu._lib.check(gpu._lib.lib().mqs_undistort_points_dev(pix[c].data_ptr(), intr_d[c].data_ptr(), N, un[c].data_ptr(), sp))
+    D = gpu.device
+    for kind, two_step in (("linear_ls", lambda: (D.linear_LS_triangulation(un, Pd), None)),
+                           ("iterative_ls", lambda: D.iterative_LS_triangulation(un, Pd)),
+                           ("linear_eigen", lambda: D.linear_eigen_triangulation(un, Pd))):
+        x2, s2 = two_step()
+        x1, s1 = D.triangulate_pixels(kind, pix, intr_d, Pd)
+        torch.cuda.synchronize()
+        assert torch.equal(x1, x2)
+        if s2 is not None:
+            assert torch.equal(s1, s2)
+    # and the fused result is the right answer: close to the scene (noise-limited)
+    assert float((x1.cpu() - torch.from_numpy(pts)).norm(dim=1).median()) < 0.2
