@@ -49,6 +49,11 @@ def init_from_env(backend="nccl"):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # test hooks: MQS_DIST_BACKEND=gloo runs the multi-rank code path without RCCL, and
+    # MQS_SHARED_GPU=1 puts every rank on device 0 (a 1-GPU box cannot host two RCCL ranks)
+    backend = os.environ.get("MQS_DIST_BACKEND", backend)
+    if os.environ.get("MQS_SHARED_GPU", "0") == "1":
+        local_rank = 0
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
@@ -56,5 +61,7 @@ def init_from_env(backend="nccl"):
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
+            if torch.cuda.is_available():
+                torch.cuda.set_device(local_rank)
             dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, local_rank, world
