@@ -71,3 +71,41 @@ def test_rank_deficient_minimum_norm(host_math, c_oracle):
     xh, _, _ = host_tri(host_math, 0, u, P)
     np.testing.assert_allclose(xh, xo, atol=1e-9)
     assert np.all(np.isfinite(xh))
+
+
+# ---------------------------------------------------------------------------------------
+# BA arithmetic (csrc/ba_math.h) compiled for the host vs the numpy oracle
+# ---------------------------------------------------------------------------------------
+def _p(a, t=ctypes.c_double):
+    return None if a is None else a.ctypes.data_as(ctypes.POINTER(t))
+
+
+@pytest.mark.parametrize("C,kw", [(2, {}), (3, dict(distortion=True)), (4, dict(behind=2, masked_frac=0.3)),
+                                  (5, dict(distortion=True, masked_frac=0.2)), (6, {})])
+def test_device_ba_math_vs_oracle(C, kw, host_math):
+    from oracle import ba_np
+    from ba_util import make_scene
+    N, lam = 37, 1e-3
+    sc = make_scene(N, C, seed=11 + C, **kw)
+    S, g, cost, nv, pieces = ba_np.linearize(sc["poses"], sc["calib"], sc["sigma"], sc["points"], sc["obs"], sc["mask"],
+                                             sc["prior_w"], sc["prior_xyz"], lam)
+    n6 = 6 * C
+    out = np.zeros(n6 * n6 + n6 + 2)
+    arrs = [np.ascontiguousarray(sc[k]) for k in ("poses", "calib", "sigma", "points", "obs")]
+    mask = None if sc["mask"] is None else np.ascontiguousarray(sc["mask"], dtype=np.uint8)
+    rc = host_math.host_ba_linearize(*[_p(a) for a in arrs[:3]], C, _p(arrs[3]), _p(arrs[4]), _p(mask, ctypes.c_uint8),
+                                     _p(sc["prior_w"]), _p(sc["prior_xyz"]), ctypes.c_int64(N), ctypes.c_double(lam), _p(out))
+    assert rc == 0
+    Sh, gh = out[:n6 * n6].reshape(n6, n6), out[n6 * n6:n6 * n6 + n6]
+    np.testing.assert_allclose(Sh, S, rtol=0, atol=1e-9 * np.abs(S).max())
+    np.testing.assert_allclose(gh, g, rtol=0, atol=1e-9 * np.abs(g).max())
+    np.testing.assert_allclose(out[-2], cost, rtol=1e-12)
+    assert out[-1] == nv
+    np.testing.assert_array_equal(Sh, Sh.T)
+    dpose = 1e-3 * np.random.default_rng(C).standard_normal(n6)
+    pts_new = np.empty((N, 3))
+    rc = host_math.host_ba_backsub(*[_p(a) for a in arrs[:3]], C, _p(arrs[3]), _p(arrs[4]), _p(mask, ctypes.c_uint8),
+                                   _p(sc["prior_w"]), _p(sc["prior_xyz"]), ctypes.c_int64(N), ctypes.c_double(lam),
+                                   _p(dpose), _p(pts_new))
+    assert rc == 0
+    np.testing.assert_allclose(pts_new - sc["points"], ba_np.backsub(pieces, dpose), rtol=0, atol=1e-9)
