@@ -15,7 +15,7 @@ $(LIB): $(SRCS) $(HDRS)
 oracle:
 	$(MAKE) -s -C oracle/c
 
-tests/libhost_math.so: tests/host_math.cpp $(PKG)/csrc/tri_math.h $(PKG)/csrc/ba_math.h $(PKG)/csrc/cam_math.h
+tests/libhost_math.so: tests/host_math.cpp $(PKG)/csrc/tri_math.h $(PKG)/csrc/ba_math.h $(PKG)/csrc/cam_math.h $(PKG)/csrc/pnp_math.h
 	g++ -O2 -ffp-contract=off -fPIC -shared -o $@ tests/host_math.cpp
 
 clean:

@@ -254,6 +254,43 @@ int mqs_project_points_dev(const double *points, const double *P, const double *
 int64_t mqs_project_workspace_bytes(void);
 
 /* ---------------------------------------------------------------------------------------
+ * Camera pose from 3D-2D correspondences: the pose step of the per-frame loop.
+ * Poses are P = [R | t] (3x4 row-major, world -> camera: OpenCV's [Rodrigues(rvec) | tvec]);
+ * objp [N][3] world points, imgp [N][2] pixel observations, intr as above (fx fy cx cy k1 k2 p1 p2 k3).
+ *
+ *   mqs_solve_pnp: replaces cv2.solvePnP(objp, imgp, K, dist[, rvec, tvec, useExtrinsicGuess=True])
+ *       (slam2.py:489-490, 576-577, 1156): Levenberg-Marquardt on the pixel reprojection error, started
+ *       from `pose` when use_guess != 0, else from a direct linear transform of the undistorted points
+ *       (N >= 6).  pose is updated in place.  info (may be NULL): [sum of squared residuals in px^2,
+ *       LM iterations, N, flags (bit 0: converged, bit 1: DLT start failed)].
+ *   mqs_pnp_refine_dev: B independent problems in one launch (one wavefront each).  Problem b uses the
+ *       correspondences idx[ptr[b] .. ptr[b+1]) (idx == NULL: the points ptr[b] .. ptr[b+1] themselves;
+ *       ptr == NULL with B == 1: all N points).  poses_in / poses_out [B][12], info [B][4] (may be NULL).
+ *   mqs_solve_pnp_ransac: replaces cv2.solvePnPRansac(objp, imgp, K, dist, minInliersCount=..,
+ *       reprojectionError=..) (slam2.py:453-454).  The caller draws the minimal samples
+ *       (samples [B][sample_size] int32 point indices, sample_size >= 6) so that runs are repeatable; all B
+ *       hypotheses are evaluated at once (DLT of the sample, `sample_iters` LM iterations on it, inlier =
+ *       in front of the camera and reprojection error <= reproj_error), the one with the most inliers
+ *       (lowest index on ties) is refined on its inliers like OpenCV's final solvePnP.  sel[0] = chosen
+ *       hypothesis (-1: none valid), sel[1] = number of inliers; mask [N] (may be NULL) marks them.
+ *       OpenCV's early exit at minInliersCount only shortens its serial loop; its accept / reject
+ *       decision on the returned inlier count stays with the caller (slam2.py:461-468).
+ * ------------------------------------------------------------------------------------- */
+int mqs_solve_pnp(mqs_ctx *ctx, const double *objp, const double *imgp, int64_t N, const double *intr, double *pose,
+                  int use_guess, int max_iter, double eps, double *info);
+int mqs_pnp_refine_dev(const double *objp, const double *imgp, int64_t N, const int32_t *idx, const int32_t *ptr, int B,
+                       const double *intr, const double *poses_in, int use_guess, int max_iter, double eps,
+                       double *poses_out, double *info, void *stream);
+int mqs_solve_pnp_ransac(mqs_ctx *ctx, const double *objp, const double *imgp, int64_t N, const double *intr,
+                         const int32_t *samples, int B, int sample_size, double reproj_error, int sample_iters,
+                         int max_iter, double eps, double *pose, int32_t *sel, uint8_t *mask, double *info);
+int mqs_pnp_ransac_dev(const double *objp, const double *imgp, int64_t N, const double *intr, const int32_t *samples,
+                       int B, int sample_size, double reproj_error, int sample_iters, int max_iter, double eps,
+                       double *pose_out, int32_t *sel_out, uint8_t *mask, double *info, void *workspace,
+                       int64_t workspace_bytes, void *stream);
+int64_t mqs_pnp_workspace_bytes(int64_t N, int B);
+
+/* ---------------------------------------------------------------------------------------
  * Timing helper used by bench.py: average duration (ms) of `reps` back-to-back launches of
  * one triangulation kernel measured with hipEvents on `stream` (kernel: 0 = linear_ls,
  * 1 = iterative_ls, 2 = linear_eigen).

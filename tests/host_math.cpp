@@ -154,3 +154,52 @@ extern "C" void host_project(const double *pts, const double *P, const double *i
     for (int64_t i = 0; i < N; ++i)
         depth[i] = mqs::cam::project(P, intr, pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], uv[2 * i], uv[2 * i + 1]);
 }
+
+// ---------------------------------------------------------------------------------------
+// pose from points (csrc/pnp_math.h) on the host: plain loops instead of the wave reduction
+// ---------------------------------------------------------------------------------------
+#include "../multiple-quadrotor-slam_amd/csrc/pnp_math.h"
+
+struct HostPnpEval {
+    const double *objp, *imgp, *intr; int64_t N;
+    void operator()(const double *P, double *acc) const
+    {
+        for (int k = 0; k < mqs::pnp::kAcc; ++k) acc[k] = 0.0;
+        for (int64_t i = 0; i < N; ++i)
+            mqs::pnp::accumulate_point(P, intr, objp[3 * i], objp[3 * i + 1], objp[3 * i + 2], imgp[2 * i], imgp[2 * i + 1], acc);
+    }
+};
+
+extern "C" int host_pnp_dlt(const double *objp, const double *imgp, int64_t N, const double *intr, double *P)
+{
+    double c[3] = {0, 0, 0};
+    for (int64_t i = 0; i < N; ++i) for (int k = 0; k < 3; ++k) c[k] += objp[3 * i + k];
+    for (int k = 0; k < 3; ++k) c[k] /= (double)N;
+    double sigma = 0;
+    for (int64_t i = 0; i < N; ++i) {
+        const double dx = objp[3 * i] - c[0], dy = objp[3 * i + 1] - c[1], dz = objp[3 * i + 2] - c[2];
+        sigma += sqrt(dx * dx + dy * dy + dz * dz);
+    }
+    sigma /= (double)N;
+    double acc[mqs::pnp::kDltAcc] = {0};
+    for (int64_t i = 0; i < N; ++i) {
+        double x, y;
+        mqs::cam::undistort_pixel(intr, imgp[2 * i], imgp[2 * i + 1], x, y);
+        mqs::pnp::dlt_accumulate((objp[3 * i] - c[0]) / sigma, (objp[3 * i + 1] - c[1]) / sigma, (objp[3 * i + 2] - c[2]) / sigma, x, y, acc);
+    }
+    double A[121], b[11];
+    mqs::pnp::dlt_assemble(acc, A, b);
+    const bool ok = mqs::pnp::chol_solve_small(A, b, 11);
+    return (ok && mqs::pnp::pose_from_dlt(b, c, sigma, P)) ? 0 : 1;
+}
+
+// info: [sqerr, iterations, converged]
+extern "C" int host_pnp_refine(const double *objp, const double *imgp, int64_t N, const double *intr, double *P,
+                               int use_guess, int max_iter, double eps, double *info)
+{
+    if (!use_guess && host_pnp_dlt(objp, imgp, N, intr, P) != 0) return 1;
+    HostPnpEval ev = {objp, imgp, intr, N};
+    const mqs::pnp::LmResult r = mqs::pnp::lm_refine(ev, P, max_iter, eps);
+    info[0] = r.sqerr; info[1] = r.iters; info[2] = r.converged ? 1.0 : 0.0;
+    return 0;
+}
