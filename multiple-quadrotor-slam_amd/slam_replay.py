@@ -75,3 +75,93 @@ def replay_keyframe_triangulation(data, cam=0, triangulate=gpu_triangulate):
         keyframes.append((s, f0, len(ids), dt))
     return dict(points=points, status=status, keyframes=keyframes,
                 n_triangulated=int(np.isfinite(points[:, 0]).sum()))
+
+
+# ---------------------------------------------------------------------------------------------------
+# Full per-frame replay: pose (solvePnP) -> triangulate -> refined pose -> re-triangulate
+# ---------------------------------------------------------------------------------------------------
+def camera_to_world(P):
+    """[R | t] (world -> camera) -> trajectory pose12 (camera-to-world R row-major, t)."""
+    R, t = P[:, :3], P[:, 3]
+    return np.concatenate([R.T.reshape(-1), -R.T @ t])
+
+
+def gpu_solve_pnp(objp, imgp, intr, P_start):
+    from . import pnp
+    return pnp.solve_pnp_pose(objp, imgp, intr, P_start)[0]
+
+
+def replay_frames(data, cam=0, solve_pnp=gpu_solve_pnp, triangulate=gpu_triangulate, chained=True):
+    """
+    Replays `handle_new_frame` (Work/SLAM/application/own/slam2.py:360-695) for every recorded frame from the
+    recorded 2-D tracks alone: the only 3-D input is the initial map (the landmarks of step 0) and the first pose.
+
+      every frame   pose = solvePnP(tracked already-triangulated landmarks, start = previous pose)   (:453-490; the
+                    recorded tracks hold the RANSAC inliers only, so the RANSAC pass itself has nothing to reject)
+      keyframes     (frames that add landmarks) triangulate the new points against the base keyframe with that pose
+                    (:551-555), keep status == 1 (:556), cast to float32 (:19), refine the pose on old + new points
+                    (:576-577), re-triangulate with the refined pose (:582-584) and keep status >= 0 (:589).
+
+    chained=True uses the replay's OWN poses / map throughout (errors may accumulate); False restarts every frame
+    from the recorded previous pose and recorded map (isolates the per-frame arithmetic).
+    Returns dict(poses (F, 12) camera-to-world, points (N, 3) with NaN where never triangulated, status,
+                 frames = [(frame, n tracked, n new, seconds)]).
+    """
+    cal = data.calibrations[cam]
+    if cal[2] != 0.0:
+        raise NotImplementedError("shear is not part of the OpenCV camera matrix used by slam2.py")
+    K = np.array([[cal[0], 0.0, cal[3]], [0.0, cal[1], cal[4]], [0.0, 0.0, 1.0]])
+    dist = np.array([cal[5], cal[6], cal[7], cal[8]])
+    intr = np.array([cal[0], cal[1], cal[3], cal[4], cal[5], cal[6], cal[7], cal[8], 0.0])
+    n = len(data.points3D)
+    F = len(data.point2D3DAssocs[cam])
+    points = np.full((n, 3), np.nan)
+    status = np.zeros(n, dtype=np.int32)
+    init = list(data.point3DAddedIdxs[0])
+    points[init] = data.points3D[init]                                  # the initial map (slam2.py:1150-1160)
+    recorded = np.array([data.poses[cam][f][1] for f in range(F)])
+    poses = np.full((F, 12), np.nan)
+    poses[0] = recorded[0]
+    added = {}
+    for s, ids in enumerate(data.point3DAddedIdxs):
+        for p in ids:
+            added[p] = s
+    frames = []
+    for f in range(1, F):
+        t0 = time.perf_counter()
+        assocs = data.point2D3DAssocs[cam][f]
+        old = [(i2, p3) for (fr, i2, p3) in assocs if fr == f and added[p3] < f]
+        ids_old = [p3 for _, p3 in old]
+        uv_old = np.array([data.points2D[cam][f][i2] for i2, _ in old], dtype=np.float64)
+        src_pts = points if chained else data.points3D
+        X_old = np.asarray(src_pts[ids_old], dtype=np.float64)
+        P_prev = world_to_camera(poses[f - 1] if chained else recorded[f - 1])
+        P1 = solve_pnp(X_old, uv_old, intr, P_prev)
+        new = data.point3DAddedIdxs[f]
+        n_new = 0
+        if new:
+            new_set = set(new)
+            asn = [a for a in assocs if a[2] in new_set]
+            f0 = min(a[0] for a in asn)                                 # tracking_history[0]: the base keyframe
+            o0 = {a[2]: data.points2D[cam][a[0]][a[1]] for a in asn if a[0] == f0}
+            o1 = {a[2]: data.points2D[cam][a[0]][a[1]] for a in asn if a[0] == f}
+            ids = [p for p in new if p in o0 and p in o1]
+            p0 = np.array([o0[p] for p in ids], dtype=np.float64)
+            p1 = np.array([o1[p] for p in ids], dtype=np.float64)
+            P0 = world_to_camera(poses[f0] if chained else recorded[f0])
+            x1, st1 = triangulate(p0, p1, K, dist, P0, P1)
+            ok = np.asarray(st1) == 1
+            X_all = np.concatenate([X_old, np.asarray(x1)[ok].astype(np.float32).astype(np.float64)])
+            uv_all = np.concatenate([uv_old, p1[ok]])
+            P2 = solve_pnp(X_all, uv_all, intr, P1)
+            ids_ok = [p for p, k in zip(ids, ok) if k]
+            x2, st2 = triangulate(p0[ok], p1[ok], K, dist, P0, P2)
+            keep = np.asarray(st2) >= 0
+            kept = [p for p, k in zip(ids_ok, keep) if k]
+            points[kept] = np.asarray(x2)[keep].astype(np.float32)
+            status[kept] = np.asarray(st2)[keep]
+            n_new = len(kept)
+            P1 = P2
+        poses[f] = camera_to_world(P1)
+        frames.append((f, len(old), n_new, time.perf_counter() - t0))
+    return dict(poses=poses, points=points, status=status, frames=frames)
