@@ -124,7 +124,7 @@ int mqs_match_knn2_f32_dev(const float *query, int64_t Nq, const float *train, i
                            int32_t *idx, float *dist, void *stream);
 
 /* MFMA path for binary descriptors expanded to {0,1} fp16 (IEEE half, passed as uint16_t),
- * D in {32, 64, 128, 256, 512}, Nt < 2^20: |q-t|^2 = |q|^2 + |t|^2 - 2 q.t with the contraction on
+ * D in {32, 64, 128, 256, 512}, Nt < 2^31: |q-t|^2 = |q|^2 + |t|^2 - 2 q.t with the contraction on
  * v_mfma_f32_32x32x16_f16; exact because every partial sum is a small integer (squared distances
  * are handled as integers < 2048: inputs must be {0,1}-valued; use the f32 path otherwise). */
 int mqs_match_knn2_f16(mqs_ctx *ctx, const uint16_t *query, int64_t Nq, const uint16_t *train,

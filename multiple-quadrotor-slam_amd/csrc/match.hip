@@ -83,21 +83,39 @@ using float16v = __attribute__((ext_vector_type(16))) float;
 
 // D = 256 geometry (A/B-tuned on MI355X): query tiles per wave, waves per workgroup
 #ifndef MQS_MATCH_QT256
-#define MQS_MATCH_QT256 1
+#define MQS_MATCH_QT256 2
+#endif
+#ifndef MQS_MATCH_SCHED
+#define MQS_MATCH_SCHED 0
+#endif
+#ifndef MQS_MATCH_NOPEEL
+#define MQS_MATCH_NOPEEL 1
+#endif
+#ifndef MQS_MATCH_NW512
+#define MQS_MATCH_NW512 8
+#endif
+#ifndef MQS_MATCH_PF
+#define MQS_MATCH_PF 4
 #endif
 #ifndef MQS_MATCH_NW256
 #define MQS_MATCH_NW256 8
 #endif
 constexpr int kStageRows = 64;                         // train rows per LDS stage (2 MFMA row tiles)
-// Key = (|t|^2 + kBias - 2 q.t) << 20 | train index.  |q|^2 is constant per lane (one query per
-// lane), so it is left out of the running comparison and added back at the end; kBias keeps the
-// biased distance non-negative (q.t <= |t|^2 <= D <= 512).  Valid rows: <= 1024; padding rows
-// (|t|^2 := kPadNorm): in [2560, 3584]; 12 bits suffice.
-constexpr unsigned kBias = 512;
-constexpr unsigned kPadNorm = 3072;
-constexpr unsigned kInvalidD2 = 2048;                  // biased distances >= this are padding rows
-constexpr float kKeyScale = 1048576.0f;                // 2^20: float -> u32 conversion yields d2 << 20
-constexpr unsigned kIdxBits = 20;
+// The running comparison is on ONE float per (query, train row),
+//     d' = kBias + |t|^2 - 2 q.t + tile / 256            (tile = (row >> 5) & 255)
+// produced by the MFMAs themselves: the queries are held pre-scaled by -2 and the accumulator of a
+// tile starts from kBias + |t|^2 + tile / 256 instead of zero.  |q|^2 is constant per lane (one query per
+// lane) and added back at the end.  For {0,1} data with D <= 512, d' lies in [512, 1537): as an IEEE float
+// its integer part needs <= 11 bits, so the 8 fraction bits 2^-1..2^-8 carry the tile and the 5 lowest
+// mantissa bits (<= 31 * 2^-13 < 2^-8) are free for the row inside the tile, OR-ed in.  The bit pattern of
+// a positive float orders like the float, so (distance, row index) is ONE unsigned key and a tile value
+// costs 3 VALU instructions (v_or3, v_med3_u32, v_min_u32).  Every kWindowTiles tiles (8192 rows) the
+// window's best two are decoded and merged into the running result (strict <: the lower row wins ties).
+constexpr float kBias = 1024.0f;
+constexpr float kPadNorm = 8192.0f;                    // padding rows: d' >= 8192 - 2 * 512
+constexpr float kInvalid = 2048.0f;                    // d' >= this: padding
+constexpr int kWindowTiles = 256;
+constexpr int kWindowStages = kWindowTiles * 32 / kStageRows;
 
 // squared norms (exact for {0,1} data): one thread per row
 __global__ void row_sqnorm_kernel(const _Float16 *__restrict__ x, int64_t n, int D, float *__restrict__ out)
@@ -119,24 +137,24 @@ __global__ __launch_bounds__(NW * 64) void knn2_f16_kernel(const _Float16 *__res
                                                           const _Float16 *__restrict__ train, int64_t Nt,
                                                           const float *__restrict__ qnorm,
                                                           const float *__restrict__ tnorm,
-                                                          int32_t *__restrict__ idx, float *__restrict__ dist)
+                                                          int32_t *__restrict__ idx, float *__restrict__ dist,
+                                                          float *__restrict__ part_d, int32_t *__restrict__ part_i)
 {
     constexpr int D = KS * 16;
-    constexpr int kRowBytes = D * 2;                   // unpadded: the LDS image is filled by LDS-DMA
-    constexpr int kStageBytes = kStageRows * kRowBytes;
-    constexpr int kVecPerRow = D * 2 / 16;             // 16-byte pieces per row
-    constexpr int kThreads = NW * 64;
-    constexpr int kVecPerThread = kStageRows * kVecPerRow / kThreads;
-    constexpr int kSwzMask = (kVecPerRow < 32 ? kVecPerRow : 32) - 1;   // XOR swizzle of the 16-B column
-    static_assert(kStageRows * kVecPerRow % kThreads == 0 && kVecPerThread >= 1, "stage must divide over the workgroup");
+    constexpr int kVecPerRow = D * 2 / 16;             // 16-byte pieces of data per row
+    constexpr int kPiecesPerRow = kVecPerRow + 1;      // + one piece of padding: row stride = 4 banks mod 64
+    constexpr int kRowBytes = kPiecesPerRow * 16;
+    constexpr int kStageBytes = kStageRows * kRowBytes;        // a whole number of 1-KiB LDS-DMA chunks (64 rows)
+    constexpr int kChunks = kStageBytes / 1024;
+    constexpr int kChunksPerWave = (kChunks + NW - 1) / NW;
     __shared__ __attribute__((aligned(16))) unsigned char sTile[2 * kStageBytes];
-    __shared__ __attribute__((aligned(16))) float sTn[3 * kStageRows];
+    __shared__ __attribute__((aligned(16))) float sTn[2 * kStageRows];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int64_t qbase = (int64_t)blockIdx.x * (NW * QT * 32) + wave * (QT * 32);
 
-    // resident query fragments: B[k = 16 ks + 8 h + j][col r] = Q[qbase + 32 qt + r][...]
+    // resident query fragments, scaled by -2 (exact): B[k = 16 ks + 8 h + j][col r] = -2 Q[qbase + 32 qt + r][...]
     half8 qf[QT][KS];
     float qn[QT];
 #pragma unroll
@@ -148,145 +166,219 @@ __global__ __launch_bounds__(NW * 64) void knn2_f16_kernel(const _Float16 *__res
         for (int ks = 0; ks < KS; ++ks) {
             half8 v = row[2 * ks + h];
             if (!ok) v = half8{0, 0, 0, 0, 0, 0, 0, 0};
-            qf[qt][ks] = v;
+            qf[qt][ks] = v * (_Float16)(-2.0f);
         }
         qn[qt] = ok ? qnorm[q] : 0.0f;
     }
-    unsigned best[QT], second[QT];
+    unsigned best[QT], second[QT];           // current window: keys
+    float gd0[QT], gd1[QT];                  // running result over the finished windows: kBias + |t|^2 - 2 q.t
+    int gi0[QT], gi1[QT];
 #pragma unroll
-    for (int qt = 0; qt < QT; ++qt) { best[qt] = 0xFFFFFFFFu; second[qt] = 0xFFFFFFFFu; }
+    for (int qt = 0; qt < QT; ++qt) {
+        best[qt] = 0xFFFFFFFFu; second[qt] = 0xFFFFFFFFu;
+        gd0[qt] = INFINITY; gd1[qt] = INFINITY; gi0[qt] = -1; gi1[qt] = -1;
+    }
 
-    const int64_t nstages = (Nt + kStageRows - 1) / kStageRows;
+    // gridDim.y > 1: the train rows are split over blockIdx.y in whole windows (a small query block cannot
+    // amortise the train stream it pulls from L2; two query tiles per wave can, but then Nq / 512 workgroups
+    // alone would leave CUs idle); each part writes its best two to part_d / part_i, merged by merge_parts_kernel
+    const int64_t nstages_all = (Nt + kStageRows - 1) / kStageRows;
+    const int64_t nwin = (nstages_all + kWindowStages - 1) / kWindowStages;
+    const int64_t win_per_part = (nwin + gridDim.y - 1) / gridDim.y;
+    const int64_t s_begin = blockIdx.y * win_per_part * kWindowStages;
+    const int64_t s_end_ = s_begin + win_per_part * kWindowStages;
+    const int64_t s_end = s_end_ < nstages_all ? s_end_ : nstages_all;
+    const int64_t nstages = s_end > s_begin ? s_end - s_begin : 0;
     const uint4 *tvec = reinterpret_cast<const uint4 *>(train);
 
     // Stage fill by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write).  One
-    // wave-instruction writes 64 x 16 B = 1 KiB of LDS linearly (wave-uniform base + lane * 16), so
-    // the swizzle that makes the fragment reads bank-conflict free is applied to the per-lane
-    // SOURCE address: LDS piece (row, c') holds global piece (row, c' ^ (row & kSwzMask)); the
-    // reader applies the same XOR.  Rows past Nt re-read the last row (their |t|^2 sentinel keeps
-    // them out of the result).  Norms go to a 3-deep ring: a tile's scan runs one tile late.
+    // wave-instruction writes 64 x 16 B = 1 KiB of LDS linearly (wave-uniform base + lane * 16); which
+    // global bytes land there is the per-lane SOURCE address, so the LDS image is laid out with padded
+    // rows (kPiecesPerRow pieces: the fragment reads of 16 consecutive rows then fall in 16 different
+    // bank groups, and their addresses are row base + an immediate: no address arithmetic in the loop);
+    // the padding piece of a row re-reads its first piece.  Rows past Nt re-read the last row (their start
+    // value keeps them out of the result).
     auto stage_issue = [&](int64_t s) {
         const int buf = (int)(s & 1);
 #pragma unroll
-        for (int i = 0; i < kVecPerThread; ++i) {
-            const int piece0 = (i * NW + wave) * 64;              // first 16-B piece of this wave-instruction
-            const int v = piece0 + lane;
-            const int row = v / kVecPerRow, colp = v % kVecPerRow;
-            const int col = colp ^ (row & kSwzMask);
-            int64_t grow = s * kStageRows + row;
-            grow = grow < Nt ? grow : Nt - 1;
-            __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void *)(tvec + grow * kVecPerRow + col),
-                (__attribute__((address_space(3))) void *)(sTile + buf * kStageBytes + piece0 * 16), 16, 0, 0);
+        for (int i = 0; i < kChunksPerWave; ++i) {
+            const int chunk = i * NW + wave;
+            if (chunk < kChunks) {
+                const int v = chunk * 64 + lane;
+                const int row = v / kPiecesPerRow, colp = v % kPiecesPerRow;
+                const int col = colp < kVecPerRow ? colp : 0;
+                int64_t grow = s * kStageRows + row;
+                grow = grow < Nt ? grow : Nt - 1;
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void *)(tvec + grow * kVecPerRow + col),
+                    (__attribute__((address_space(3))) void *)(sTile + buf * kStageBytes + chunk * 1024), 16, 0, 0);
+            }
         }
         if (tid < kStageRows) {
             const int64_t t = s * kStageRows + tid;
-            // (|t|^2 + kBias) * 2^20: the scan computes  key = u32(acc * (-2 * 2^20) + this) | index
-            sTn[(s % 3) * kStageRows + tid] = (((t < Nt) ? tnorm[t] : (float)kPadNorm) + (float)kBias) * kKeyScale;
+            // accumulator start value of this train row: kBias + |t|^2 + tile / 256
+            sTn[buf * kStageRows + tid] = (t < Nt) ? tnorm[t] + kBias + (float)((t >> 5) & (kWindowTiles - 1)) * (1.0f / kWindowTiles)
+                                                  : kPadNorm;
         }
     };
 
-    // MFMAs of tile (s, tt) into `acc`, interleaved one-for-one with the top-2 scan of the PREVIOUS
-    // tile's accumulators `prev` (32 MFMAs, 32 values): the scan's ~6 VALU instructions per value
-    // issue in the shadow of the MFMA they are paired with instead of after the tile.
-    auto tile_step = [&](const unsigned char *tile, int tt, float16v (&acc)[QT], const float16v (&prev)[QT],
-                         const float *ptn, unsigned pbase) {
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[qt][e] = 0.0f;
-        const unsigned char *arow = tile + (tt * 32 + r) * kRowBytes;
-        const int swz = r & kSwzMask;                         // (tt * 32 + r) & kSwzMask
-        float tnv[16];
+    // One step = the KS MFMAs of (train tile, query tile qt) into `acc` (started from the rows' start values
+    // `tn`), interleaved with the top-2 scan of the PREVIOUS step's accumulators `prev` (query tile pq): the
+    // scan's 3 VALU instructions per value issue in the shadow of the MFMAs instead of after them.  Steps
+    // run (tile 0, qt 0), (tile 0, qt 1), .., (tile 1, qt 0), ..: with QT >= 2 the accumulators simply
+    // rotate over the query tiles (no second set), and every train stage is amortised over QT * 32 queries
+    // per wave -- the LDS-DMA stream from L2, not the matrix pipe, is what a small query block runs out of.
+    auto tile_step = [&](const unsigned char *tile, int tt, int qt, float16v &acc, const float16v &prev, int pq, const float *tn) {
+        const unsigned char *arow = tile + (tt * 32 + r) * kRowBytes + 16 * h;   // fragment ks: + 32 ks (immediate)
+        float16v start;                                       // row(e) = (e & 3) + 8 (e >> 2) + 4 h
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const float4 t4 = *reinterpret_cast<const float4 *>(ptn + 8 * g);
-            tnv[4 * g] = t4.x; tnv[4 * g + 1] = t4.y; tnv[4 * g + 2] = t4.z; tnv[4 * g + 3] = t4.w;
+            const float4 t4 = *reinterpret_cast<const float4 *>(tn + 8 * g);
+            start[4 * g] = t4.x; start[4 * g + 1] = t4.y; start[4 * g + 2] = t4.z; start[4 * g + 3] = t4.w;
         }
-        constexpr int kSteps = KS * QT;                       // MFMAs in this tile
-        constexpr int kVals = 16 * QT;                        // values to scan from the previous tile
+        constexpr int PF = MQS_MATCH_PF < KS ? MQS_MATCH_PF : KS;     // fragment reads in flight ahead of their MFMA
+        half8 a[KS];
+#pragma unroll
+        for (int ks = 0; ks < PF; ++ks) a[ks] = *reinterpret_cast<const half8 *>(arow + 32 * ks);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            const half8 a = *reinterpret_cast<const half8 *>(arow + (((2 * ks + h) ^ swz) << 4));
+            if (ks + PF < KS) a[ks + PF] = *reinterpret_cast<const half8 *>(arow + 32 * (ks + PF));
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks], qf[qt][ks], ks == 0 ? start : acc, 0, 0, 0);
+            // scan values [v0, v1) of the previous step behind this MFMA
+            const int v0 = ks * 16 / KS, v1 = (ks + 1) * 16 / KS;
 #pragma unroll
-            for (int qt = 0; qt < QT; ++qt) {
-                acc[qt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qf[qt][ks], acc[qt], 0, 0, 0);
-                // scan values [v0, v1) of the previous tile behind this MFMA
-                const int step = ks * QT + qt;
-                const int v0 = step * kVals / kSteps, v1 = (step + 1) * kVals / kSteps;
-#pragma unroll
-                for (int v = v0; v < v1; ++v) {
-                    const int pq = v / 16, e = v % 16;        // row(e) = (e & 3) + 8 (e >> 2) + 4 h
-                    const float kf = fmaf(prev[pq][e], -2.0f * kKeyScale, tnv[e]);
-                    const unsigned key = (unsigned)kf | pbase | (unsigned)(8 * (e >> 2) + (e & 3));   // disjoint bits: one v_or3_b32
-                    unsigned m;
-                    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(m) : "v"(best[pq]), "v"(second[pq]), "v"(key));
-                    second[pq] = m;
-                    best[pq] = min(best[pq], key);
-                }
+            for (int e = v0; e < v1; ++e) {
+                const unsigned key = __float_as_uint(prev[e]) | (unsigned)(4 * h) | (unsigned)(8 * (e >> 2) + (e & 3));   // v_or3_b32
+                unsigned m;
+                asm("v_med3_u32 %0, %1, %2, %3" : "=v"(m) : "v"(best[pq]), "v"(second[pq]), "v"(key));
+                second[pq] = m;
+                best[pq] = min(best[pq], key);
             }
+        }
+        if (QT >= 2) __builtin_amdgcn_sched_barrier(0);       // keep the next step's loads out of this one (VGPRs)
+#if MQS_MATCH_SCHED
+        // issue order for the scheduler: the start values and the first fragment reads, then per k-step its
+        // MFMA, one more fragment read (several steps ahead of its use) and its share of the scan
+        __builtin_amdgcn_sched_group_barrier(0x100, 4 + MQS_MATCH_PF, 0);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 3 * 16 / KS, 0);
+        }
+#endif
+    };
+
+    // decode a window key: distance part, row index
+    auto push = [&](int qt, unsigned key, int64_t window_base) {
+        const float f = __uint_as_float(key);
+        if (!(f < kInvalid)) return;
+        const float d = floorf(f);
+        const int tile = (int)((f - d) * (float)kWindowTiles);
+        const int i = (int)window_base + tile * 32 + (int)(key & 31u);
+        if (d < gd0[qt]) { gd1[qt] = gd0[qt]; gi1[qt] = gi0[qt]; gd0[qt] = d; gi0[qt] = i; }
+        else if (d < gd1[qt]) { gd1[qt] = d; gi1[qt] = i; }
+    };
+    auto close_window = [&](int64_t window_base) {
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            push(qt, best[qt], window_base);
+            push(qt, second[qt], window_base);
+            best[qt] = 0xFFFFFFFFu; second[qt] = 0xFFFFFFFFu;
         }
     };
 
-    // slot 2 of the norm ring doubles as the "no previous tile" source for the very first step
-    if (tid < kStageRows) sTn[2 * kStageRows + tid] = ((float)kPadNorm + (float)kBias) * kKeyScale;
-    if (nstages > 0) stage_issue(0);                     // Nt == 0: nothing to read, every key stays invalid
+    if (nstages > 0) stage_issue(s_begin);               // Nt == 0: nothing to read, every key stays invalid
     __syncthreads();                                     // (waits for the LDS-DMA: vmcnt(0) + barrier)
 
-    float16v accA[QT], accB[QT];
+    constexpr int R = QT < 2 ? 2 : QT;                   // accumulator ring: step j writes acc[j % R], scans acc[(j - 1) % R]
+    static_assert((2 * QT) % R == 0, "the ring position must repeat every stage");
+    float16v acc[R];
 #pragma unroll
-    for (int qt = 0; qt < QT; ++qt)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) accB[qt][e] = 0.0f;
-    const float *ptn = sTn + 2 * kStageRows + 4 * h;     // pending tile = none (all padding)
-    unsigned pbase = 4 * h;
+    for (int e = 0; e < 16; ++e) acc[R - 1][e] = kPadNorm;    // "previous step" of the first one: nothing
 
-    for (int64_t s = 0; s < nstages; ++s) {
-        if (s + 1 < nstages) stage_issue(s + 1);          // lands while this stage is computed
+#if MQS_MATCH_NOPEEL
+#pragma clang loop unroll(disable)
+#endif
+    for (int64_t s = s_begin; s < s_end; ++s) {
+        if (s + 1 < s_end) stage_issue(s + 1);            // lands while this stage is computed
         const unsigned char *tile = sTile + (int)(s & 1) * kStageBytes;
-        const float *tn0 = sTn + (int)(s % 3) * kStageRows + 4 * h;
-        const unsigned base0 = (unsigned)(s * kStageRows) + 4 * h;
-        tile_step(tile, 0, accA, accB, ptn, pbase);       // tile 2s   <- scan of tile 2s-1
-        tile_step(tile, 1, accB, accA, tn0, base0);       // tile 2s+1 <- scan of tile 2s
-        ptn = tn0 + 32;
-        pbase = base0 + 32;
+        const float *tn0 = sTn + (int)(s & 1) * kStageRows + 4 * h;
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) {
+                const int j = tt * QT + qt;
+                tile_step(tile, tt, qt, acc[j % R], acc[(j + R - 1) % R], (qt + QT - 1) % QT, tn0 + 32 * tt);
+                // step 0 scanned the last (tile, query tile) of the previous stage: a window may end there
+                if (j == 0 && (s & (kWindowStages - 1)) == 0 && s > s_begin)
+                    close_window((s / kWindowStages - 1) * (int64_t)(kWindowTiles * 32));
+            }
         __syncthreads();
     }
-    // scan of the last tile
+    // scan of the last step, last window
     if (nstages > 0) {
-        float tnv[16];
+        constexpr int jl = 2 * QT - 1;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float4 t4 = *reinterpret_cast<const float4 *>(ptn + 8 * g);
-            tnv[4 * g] = t4.x; tnv[4 * g + 1] = t4.y; tnv[4 * g + 2] = t4.z; tnv[4 * g + 3] = t4.w;
+        for (int e = 0; e < 16; ++e) {
+            const unsigned key = __float_as_uint(acc[jl % R][e]) | (unsigned)(4 * h) | (unsigned)(8 * (e >> 2) + (e & 3));
+            second[QT - 1] = max(best[QT - 1], min(second[QT - 1], key));
+            best[QT - 1] = min(best[QT - 1], key);
         }
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const float kf = fmaf(accB[qt][e], -2.0f * kKeyScale, tnv[e]);
-                const unsigned key = (unsigned)kf | pbase | (unsigned)(8 * (e >> 2) + (e & 3));   // disjoint bits: one v_or3_b32
-                second[qt] = max(best[qt], min(second[qt], key));
-                best[qt] = min(best[qt], key);
-            }
+        close_window(((s_end - 1) / kWindowStages) * (int64_t)(kWindowTiles * 32));
     }
 
-    // merge the two half-waves (same query, disjoint train rows), undo the bias, write
+    // merge the two half-waves (same query, disjoint train rows; ties: the lower row), undo the bias, write
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
-        const unsigned ob = __shfl_xor(best[qt], 32), os = __shfl_xor(second[qt], 32);
-        const unsigned mb = min(best[qt], ob);
-        const unsigned ms = min(max(best[qt], ob), min(second[qt], os));
+        const float od0 = __shfl_xor(gd0[qt], 32), od1 = __shfl_xor(gd1[qt], 32);
+        const int oi0 = __shfl_xor(gi0[qt], 32), oi1 = __shfl_xor(gi1[qt], 32);
+        auto before = [](float da, int ia, float db, int ib) { return da < db || (da == db && (unsigned)ia < (unsigned)ib); };
+        float md0, md1; int mi0, mi1;
+        if (before(gd0[qt], gi0[qt], od0, oi0)) {
+            md0 = gd0[qt]; mi0 = gi0[qt];
+            if (before(gd1[qt], gi1[qt], od0, oi0)) { md1 = gd1[qt]; mi1 = gi1[qt]; } else { md1 = od0; mi1 = oi0; }
+        } else {
+            md0 = od0; mi0 = oi0;
+            if (before(od1, oi1, gd0[qt], gi0[qt])) { md1 = od1; mi1 = oi1; } else { md1 = gd0[qt]; mi1 = gi0[qt]; }
+        }
         const int64_t q = qbase + 32 * qt + r;
         if (h == 0 && q < Nq) {
-            const unsigned db = mb >> kIdxBits, ds = ms >> kIdxBits;
-            const bool vb = db < kInvalidD2, vs = ds < kInvalidD2;
-            idx[2 * q] = vb ? (int32_t)(mb & ((1u << kIdxBits) - 1)) : -1;
-            idx[2 * q + 1] = vs ? (int32_t)(ms & ((1u << kIdxBits) - 1)) : -1;
-            dist[2 * q] = vb ? sqrtf((float)db - (float)kBias + qn[qt]) : INFINITY;
-            dist[2 * q + 1] = vs ? sqrtf((float)ds - (float)kBias + qn[qt]) : INFINITY;
+            if (gridDim.y == 1) {
+                idx[2 * q] = mi0;
+                idx[2 * q + 1] = mi1;
+                dist[2 * q] = mi0 >= 0 ? sqrtf(md0 - kBias + qn[qt]) : INFINITY;
+                dist[2 * q + 1] = mi1 >= 0 ? sqrtf(md1 - kBias + qn[qt]) : INFINITY;
+            } else {
+                const int64_t o = ((int64_t)blockIdx.y * Nq + q) * 2;
+                part_d[o] = md0; part_d[o + 1] = md1;
+                part_i[o] = mi0; part_i[o + 1] = mi1;
+            }
         }
     }
+}
+
+// Best two over the parts of a split train set, parts in row order: strict < keeps the lower row on ties.
+__global__ void merge_parts_kernel(const float *__restrict__ part_d, const int32_t *__restrict__ part_i, int parts,
+                                   int64_t Nq, const float *__restrict__ qnorm, int32_t *__restrict__ idx,
+                                   float *__restrict__ dist)
+{
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= Nq) return;
+    float d0 = INFINITY, d1 = INFINITY;
+    int i0 = -1, i1 = -1;
+    for (int p = 0; p < parts; ++p)
+        for (int k = 0; k < 2; ++k) {
+            const float d = part_d[((int64_t)p * Nq + q) * 2 + k];
+            const int i = part_i[((int64_t)p * Nq + q) * 2 + k];
+            if (i < 0) continue;
+            if (d < d0) { d1 = d0; i1 = i0; d0 = d; i0 = i; }
+            else if (d < d1) { d1 = d; i1 = i; }
+        }
+    idx[2 * q] = i0;
+    idx[2 * q + 1] = i1;
+    dist[2 * q] = i0 >= 0 ? sqrtf(d0 - kBias + qnorm[q]) : INFINITY;
+    dist[2 * q + 1] = i1 >= 0 ? sqrtf(d1 - kBias + qnorm[q]) : INFINITY;
 }
 
 int launch_f32(const float *query, int64_t Nq, const float *train, int64_t Nt, int D, int32_t *idx, float *dist,
@@ -306,13 +398,34 @@ int launch_f32(const float *query, int64_t Nq, const float *train, int64_t Nt, i
     return MQS_OK;
 }
 
+constexpr int kMaxParts = 8;
+
+// Can workgroups of NW waves x 2 query tiles, times the parts the train set can be split into, occupy every CU?
+bool two_tiles_fill(int64_t Nq, int64_t Nt, int NW, int num_cus)
+{
+    const int64_t qblocks = (Nq + NW * 64 - 1) / (NW * 64);
+    int64_t nwin = (Nt + kWindowTiles * 32 - 1) / (kWindowTiles * 32);
+    if (nwin > kMaxParts) nwin = kMaxParts;
+    return qblocks * nwin >= num_cus;
+}
+
 template <int KS, int QT, int NW>
 void launch_f16_t(const _Float16 *q, int64_t Nq, const _Float16 *t, int64_t Nt, const float *qn, const float *tn,
-                  int32_t *idx, float *dist, hipStream_t stream)
+                  int32_t *idx, float *dist, float *part_d, int32_t *part_i, int num_cus, hipStream_t stream)
 {
     const int64_t per_block = NW * QT * 32;
-    hipLaunchKernelGGL((knn2_f16_kernel<KS, QT, NW>), dim3((unsigned)((Nq + per_block - 1) / per_block)),
-                       dim3(NW * 64), 0, stream, q, Nq, t, Nt, qn, tn, idx, dist);
+    const int64_t qblocks = (Nq + per_block - 1) / per_block;
+    // split the train rows (whole windows) until every CU has a workgroup
+    const int64_t nwin = (Nt + kWindowTiles * 32 - 1) / (kWindowTiles * 32);
+    int64_t parts = (num_cus + qblocks - 1) / qblocks;
+    if (parts > nwin) parts = nwin;
+    if (parts > kMaxParts) parts = kMaxParts;
+    if (parts < 1) parts = 1;
+    hipLaunchKernelGGL((knn2_f16_kernel<KS, QT, NW>), dim3((unsigned)qblocks, (unsigned)parts), dim3(NW * 64), 0, stream, q,
+                       Nq, t, Nt, qn, tn, idx, dist, part_d, part_i);
+    if (parts > 1)
+        hipLaunchKernelGGL(merge_parts_kernel, dim3((unsigned)((Nq + 255) / 256)), dim3(256), 0, stream, part_d, part_i,
+                           (int)parts, Nq, qn, idx, dist);
 }
 
 }  // namespace
@@ -328,7 +441,8 @@ int mqs_match_knn2_f32_dev(const float *query, int64_t Nq, const float *train, i
 int64_t mqs_match_knn2_f16_workspace_bytes(int64_t Nq, int64_t Nt)
 {
     if (Nq < 0 || Nt < 0) return 0;
-    return ((Nq + 63) / 64 * 64 + (Nt + 63) / 64 * 64) * (int64_t)sizeof(float);
+    // squared norms + the per-part best two of a split train set (distance, index)
+    return ((Nq + 63) / 64 * 64 + (Nt + 63) / 64 * 64) * (int64_t)sizeof(float) + (int64_t)kMaxParts * Nq * 2 * 8;
 }
 
 int mqs_match_knn2_f16_dev(const uint16_t *query, int64_t Nq, const uint16_t *train, int64_t Nt, int D, int32_t *idx,
@@ -336,7 +450,7 @@ int mqs_match_knn2_f16_dev(const uint16_t *query, int64_t Nq, const uint16_t *tr
 {
     MQS_ARG_CHECK(Nq >= 0 && Nt >= 0, "Nq, Nt >= 0");
     MQS_ARG_CHECK(D == 32 || D == 64 || D == 128 || D == 256 || D == 512, "D must be 32, 64, 128, 256 or 512");
-    MQS_ARG_CHECK(Nt < (1 << kIdxBits), "Nt must be < 2^20");
+    MQS_ARG_CHECK(Nt <= 0x7fffffff, "Nt must be < 2^31");
     if (Nq == 0) return MQS_OK;
     MQS_ARG_CHECK(query && idx && dist && workspace && (Nt == 0 || train), "pointers must not be null");
     MQS_ARG_CHECK(mqs_aligned16(query) && mqs_aligned16(train), "descriptor pointers must be 16-byte aligned");
@@ -346,15 +460,26 @@ int mqs_match_knn2_f16_dev(const uint16_t *query, int64_t Nq, const uint16_t *tr
     const _Float16 *t = reinterpret_cast<const _Float16 *>(train);
     float *qn = static_cast<float *>(workspace);
     float *tn = qn + (Nq + 63) / 64 * 64;
+    float *part_d = tn + (Nt + 63) / 64 * 64;
+    int32_t *part_i = reinterpret_cast<int32_t *>(part_d + (int64_t)kMaxParts * Nq * 2);
+    int dev = 0, num_cus = 256;
+    MQS_HIP_CHECK(hipGetDevice(&dev));
+    MQS_HIP_CHECK(hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, dev));
     hipLaunchKernelGGL(row_sqnorm_kernel, dim3((unsigned)((Nq + 255) / 256)), dim3(256), 0, stream, q, Nq, D, qn);
     if (Nt > 0)
         hipLaunchKernelGGL(row_sqnorm_kernel, dim3((unsigned)((Nt + 255) / 256)), dim3(256), 0, stream, t, Nt, D, tn);
     switch (D) {
-    case 32: launch_f16_t<2, 2, 4>(q, Nq, t, Nt, qn, tn, idx, dist, stream); break;
-    case 64: launch_f16_t<4, 2, 4>(q, Nq, t, Nt, qn, tn, idx, dist, stream); break;
-    case 128: launch_f16_t<8, 2, 4>(q, Nq, t, Nt, qn, tn, idx, dist, stream); break;
-    case 256: launch_f16_t<16, MQS_MATCH_QT256, MQS_MATCH_NW256>(q, Nq, t, Nt, qn, tn, idx, dist, stream); break;
-    case 512: launch_f16_t<32, 1, 4>(q, Nq, t, Nt, qn, tn, idx, dist, stream); break;
+    case 32: launch_f16_t<2, 2, 4>(q, Nq, t, Nt, qn, tn, idx, dist, part_d, part_i, num_cus, stream); break;
+    case 64: launch_f16_t<4, 2, 4>(q, Nq, t, Nt, qn, tn, idx, dist, part_d, part_i, num_cus, stream); break;
+    case 128: launch_f16_t<8, 2, 4>(q, Nq, t, Nt, qn, tn, idx, dist, part_d, part_i, num_cus, stream); break;
+    case 256:
+        // two query tiles per wave halve the train stream per MFMA; worth it once the split can still fill the CUs
+        if (MQS_MATCH_QT256 == 2 && two_tiles_fill(Nq, Nt, MQS_MATCH_NW256, num_cus))
+            launch_f16_t<16, 2, MQS_MATCH_NW256>(q, Nq, t, Nt, qn, tn, idx, dist, part_d, part_i, num_cus, stream);
+        else
+            launch_f16_t<16, 1, MQS_MATCH_NW256>(q, Nq, t, Nt, qn, tn, idx, dist, part_d, part_i, num_cus, stream);
+        break;
+    case 512: launch_f16_t<32, 1, MQS_MATCH_NW512>(q, Nq, t, Nt, qn, tn, idx, dist, part_d, part_i, num_cus, stream); break;
     }
     MQS_HIP_CHECK(hipGetLastError());
     return MQS_OK;

@@ -18,7 +18,7 @@ def timed(fn, reps=5):
     e1.record(); e1.synchronize()
     return e0.elapsed_time(e1) / reps
 out = {"lib": os.path.basename(mqslam_amd._lib.LIB_PATH), "N": N, "D": D}
-for rnd in range(3):
+for rnd in range(6):
     ms = timed(lambda: M.knn2_dev(q, t, idx, dist, ws))
     out.setdefault("f16_ms", []).append(round(ms, 3))
     out.setdefault("f16_TFLOPs", []).append(round(2.0 * N * N * D / (ms * 1e-3) / 1e12, 1))
