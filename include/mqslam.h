@@ -233,6 +233,15 @@ int mqs_sba_cost_dev(const double *poses, const int32_t *pose_cam, int64_t P, co
                      const double *prior_xyz, double *out, void *workspace, int64_t workspace_bytes,
                      void *stream);
 
+/* Odometry: BetweenFactor<Pose3> (bundle_adjust.cpp:301-309, `useOdometry`), GTSAM 3.2.1 conventions: error
+ * measured.localCoordinates(T_from^-1 T_to) = (Log(Rm^T Rh), Rm^T (th - tm)), Jacobians of `between`
+ * (-Ad(h^-1), I), whitened by odo_sigmas [n_odo][6] (rotation 3, translation 3).  odo_meas [n_odo][12] =
+ * R row-major + t.  Call after mqs_sba_linearize_dev: adds J^T J to S (both triangles), -J^T r to g and the
+ * factors' cost to cost[0].  S == g == NULL: cost only (LM trial evaluation). */
+int mqs_sba_between_dev(const double *poses, int64_t P, const int32_t *odo_from, const int32_t *odo_to,
+                        const double *odo_meas, const double *odo_sigmas, int64_t n_odo, double *S, double *g,
+                        double *cost, void *stream);
+
 /* ---------------------------------------------------------------------------------------
  * Camera model either side of triangulation (the published OpenCV 2.4 pinhole + distortion model):
  * intr[9] = fx, fy, cx, cy, k1, k2, p1, p2, k3.

@@ -79,6 +79,7 @@ SIGNATURES = {
                                            c_vp, ctypes.c_double, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "mqs_sba_cost_dev": (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp,
                                         c_vp, c_vp, c_i64, c_vp]),
+    "mqs_sba_between_dev": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
     "mqs_undistort_points": (ctypes.c_int, [c_vp, c_f64p, c_f64p, c_i64, c_f64p]),
     "mqs_undistort_points_dev": (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp, c_vp]),
     "mqs_project_points": (ctypes.c_int, [c_vp, c_f64p, c_f64p, c_f64p, c_f64p, c_i64, c_f64p, c_f64p, c_f64p]),

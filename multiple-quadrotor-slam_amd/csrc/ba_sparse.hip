@@ -208,6 +208,71 @@ __global__ void sparse_priors_kernel(double *__restrict__ S, double *__restrict_
     }
 }
 
+// Odometry: BetweenFactor<Pose3>(from, to, measured, sigmas) of bundle_adjust.cpp:301-309 with GTSAM 3.2.1's
+// conventions: h = T_from^-1 T_to, error = measured.localCoordinates(h) = (Log(Rm^T Rh), Rm^T (th - tm)) in the
+// first-order chart, Jacobians those of `between` only (H_from = -Ad(h^-1), H_to = I), whitened by the six sigmas.
+// One thread per factor; adds J^T J / -J^T r into the MIRRORED system (both triangles) and 0.5 |r|^2 into cost.
+// S == nullptr: cost only.
+__global__ void sparse_between_kernel(double *__restrict__ S, double *__restrict__ g, int n6,
+                                      const double *__restrict__ poses, const int32_t *__restrict__ from,
+                                      const int32_t *__restrict__ to, const double *__restrict__ meas,
+                                      const double *__restrict__ sigmas, int n, double *__restrict__ cost)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int a = from[t], b = to[t];
+    const double *T1 = poses + 12 * (int64_t)a, *T2 = poses + 12 * (int64_t)b, *Tm = meas + 12 * (int64_t)t;
+    double Rh[9], th[3], Re[9], w[3], e[6];
+    const double dt[3] = {T2[9] - T1[9], T2[10] - T1[10], T2[11] - T1[11]};
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) Rh[3 * i + j] = T1[i] * T2[j] + T1[3 + i] * T2[3 + j] + T1[6 + i] * T2[6 + j];
+        th[i] = T1[i] * dt[0] + T1[3 + i] * dt[1] + T1[6 + i] * dt[2];
+    }
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) Re[3 * i + j] = Tm[i] * Rh[j] + Tm[3 + i] * Rh[3 + j] + Tm[6 + i] * Rh[6 + j];
+    so3_log_s(Re, w);
+    for (int i = 0; i < 3; ++i) {
+        e[i] = w[i];
+        e[3 + i] = Tm[i] * (th[0] - Tm[9]) + Tm[3 + i] * (th[1] - Tm[10]) + Tm[6 + i] * (th[2] - Tm[11]);
+    }
+    double W[6], c = 0.0;
+    for (int i = 0; i < 6; ++i) {
+        W[i] = 1.0 / (sigmas[6 * t + i] * sigmas[6 * t + i]);
+        c += 0.5 * W[i] * e[i] * e[i];
+    }
+    atomic_add_f64(cost, c);
+    if (!S) return;
+    // H1 = -Ad(h^-1),  h^-1 = (Rh^T, tp = -Rh^T th):  Ad = [[Rh^T, 0], [[tp]x Rh^T, Rh^T]]   (order [omega, v])
+    double Rt[9], tp[3], H1[36];
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) Rt[3 * i + j] = Rh[3 * j + i];
+        tp[i] = -(Rh[i] * th[0] + Rh[3 + i] * th[1] + Rh[6 + i] * th[2]);
+    }
+    const double K[9] = {0.0, -tp[2], tp[1], tp[2], 0.0, -tp[0], -tp[1], tp[0], 0.0};
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            H1[6 * i + j] = -Rt[3 * i + j];
+            H1[6 * i + 3 + j] = 0.0;
+            H1[6 * (3 + i) + j] = -(K[3 * i] * Rt[j] + K[3 * i + 1] * Rt[3 + j] + K[3 * i + 2] * Rt[6 + j]);
+            H1[6 * (3 + i) + 3 + j] = -Rt[3 * i + j];
+        }
+    for (int i = 0; i < 6; ++i) {
+        double gi = 0.0;
+        for (int k = 0; k < 6; ++k) gi += H1[6 * k + i] * W[k] * e[k];
+        atomic_add_f64(g + 6 * a + i, -gi);
+        atomic_add_f64(g + 6 * b + i, -W[i] * e[i]);
+        atomic_add_f64(S + (int64_t)(6 * b + i) * n6 + 6 * b + i, W[i]);
+        for (int j = 0; j < 6; ++j) {
+            double sij = 0.0;
+            for (int k = 0; k < 6; ++k) sij += H1[6 * k + i] * W[k] * H1[6 * k + j];
+            atomic_add_f64(S + (int64_t)(6 * a + i) * n6 + 6 * a + j, sij);
+            const double cross = H1[6 * j + i] * W[j];                       // (H1^T W)[i][j]
+            atomic_add_f64(S + (int64_t)(6 * a + i) * n6 + 6 * b + j, cross);
+            atomic_add_f64(S + (int64_t)(6 * b + j) * n6 + 6 * a + i, cross);
+        }
+    }
+}
+
 __global__ void sparse_damp_kernel(double *__restrict__ S, int n6, double lambda)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -581,6 +646,22 @@ int mqs_sba_cost_dev(const double *poses, const int32_t *pose_cam, int64_t P, co
     hipLaunchKernelGGL(sparse_cost_kernel, dim3(lm_blocks), dim3(kBlock), 0, stream, cams, points, obs_ptr, obs_pose,
                        obs_uv, prior_w, prior_xyz, N, partials);
     hipLaunchKernelGGL(sum_cost_partials_kernel, dim3(1), dim3(kBlock), 0, stream, partials, lm_blocks, out);
+    MQS_HIP_CHECK(hipGetLastError());
+    return MQS_OK;
+}
+
+// Adds the odometry BetweenFactors to a linearised (mirrored) system; S == NULL: only cost[0] += their cost.
+int mqs_sba_between_dev(const double *poses, int64_t P, const int32_t *odo_from, const int32_t *odo_to,
+                        const double *odo_meas, const double *odo_sigmas, int64_t n_odo, double *S, double *g,
+                        double *cost, void *stream_)
+{
+    MQS_ARG_CHECK(P >= 1 && n_odo >= 0 && n_odo <= 0x7fffffff, "P >= 1, n_odo >= 0");
+    if (n_odo == 0) return MQS_OK;
+    MQS_ARG_CHECK(poses && odo_from && odo_to && odo_meas && odo_sigmas && cost, "pointers must not be null");
+    MQS_ARG_CHECK((S == nullptr) == (g == nullptr), "S and g go together");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    hipLaunchKernelGGL(sparse_between_kernel, dim3((unsigned)((n_odo + 63) / 64)), dim3(64), 0, stream, S, g, (int)(6 * P),
+                       poses, odo_from, odo_to, odo_meas, odo_sigmas, (int)n_odo, cost);
     MQS_HIP_CHECK(hipGetLastError());
     return MQS_OK;
 }

@@ -4,9 +4,9 @@ the CLI-compatible tool `tools/bundle_adjust.py`, i.e. the counterpart of
 `performBundleAdjustment` with iSAM_version = 0 (Work/SLAM/tools/bundle_adjustment/bundle_adjust.cpp:190-330:
 build the whole graph, one batch LevenbergMarquardtOptimizer::optimize() at the last step).
 
-Input: a `ba_io.SparseProblem` (poses, per-pose camera id, CSR observations, point / pose priors).
-Odometry BetweenFactors (bundle_adjust.cpp:301-309, off in the reference's working mode
-`useOdometry = 0`, ReadMe.txt:59-62) are not accelerated: requesting them raises NotImplementedError.
+Input: a `ba_io.SparseProblem` (poses, per-pose camera id, CSR observations, point / pose priors, and -- with
+`useOdometry` -- the odometry BetweenFactors of bundle_adjust.cpp:301-309, added to the reduced camera system by
+`mqs_sba_between_dev`).
 """
 import ctypes
 
@@ -61,8 +61,6 @@ def sort_observations_by_pose(problem):
 class SparseBundleAdjuster:
     def __init__(self, problem, device="cuda:0"):
         torch = _torch()
-        if len(problem.odo_from):
-            raise NotImplementedError("odometry BetweenFactors are not part of the accelerated path")
         pr = sort_observations_by_pose(problem)
         self.problem = pr
         dev = torch.device(device)
@@ -88,6 +86,11 @@ class SparseBundleAdjuster:
         self.pp_idx = t(pr.pose_prior_idx, i32) if self.npp else None
         self.pp_poses = t(pr.poses[pr.pose_prior_idx], f64) if self.npp else None      # prior = initial pose (:273)
         self.pp_sigmas = t(pr.pose_prior_sigmas, f64) if self.npp else None
+        self.n_odo = len(pr.odo_from)
+        if self.n_odo:
+            self.odo_from, self.odo_to = t(pr.odo_from, i32), t(pr.odo_to, i32)
+            self.odo_meas, self.odo_sigmas = t(pr.odo_meas, f64), t(pr.odo_sigmas, f64)
+            self.odo_cost = torch.zeros(1, dtype=f64, device=dev)
         n6 = 6 * self.P
         self.n6 = n6
         self.S = torch.empty(n6 * n6, dtype=f64, device=dev)
@@ -106,7 +109,15 @@ class SparseBundleAdjuster:
             _p(self.obs_ptr), _p(self.obs_pose), _p(self.obs_uv), self.M, _p(self.pair_a), _p(self.pair_b), self.Q,
             _p(self.prior_w), _p(self.prior_xyz), _p(self.pp_idx), _p(self.pp_poses), _p(self.pp_sigmas), self.npp,
             float(lam), _p(self.S), _p(self.g), _p(self.info), _p(self.ws), self.ws.numel(), _sp()))
+        if self.n_odo:
+            self._between(self.poses, self.S, self.g)
         return self.S.view(self.n6, self.n6), self.g
+
+    def _between(self, poses, S=None, g=None):
+        """Odometry factors at `poses`: into (S, g) when given; returns nothing (cost in self.odo_cost)."""
+        self.odo_cost.zero_()
+        _lib.check(_lib.lib().mqs_sba_between_dev(_p(poses), self.P, _p(self.odo_from), _p(self.odo_to), _p(self.odo_meas),
+                                                  _p(self.odo_sigmas), self.n_odo, _p(S), _p(g), _p(self.odo_cost), _sp()))
 
     def solve(self, lam=0.0):
         """Destroys S (replaced by its Cholesky factor) and g (replaced by dpose); retracts the poses."""
@@ -131,6 +142,9 @@ class SparseBundleAdjuster:
         c = float(self.cost_out[0].item())
         if self.npp:
             c += self._pose_prior_cost(poses)
+        if self.n_odo:
+            self._between(poses)
+            c += float(self.odo_cost.item())
         return c
 
     def _pose_prior_cost(self, poses):

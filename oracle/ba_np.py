@@ -332,3 +332,41 @@ def sparse_cost(poses, pose_cam, calib, sigma, points, obs_ptr, obs_pose, obs_uv
             d = points[i] - prior_xyz[i]
             cost += 0.5 * prior_w[i] * d.dot(d)
     return cost
+
+
+def between_error(T1, T2, Tm):
+    """BetweenFactor<Pose3>::evaluateError of GTSAM 3.2.1 (bundle_adjust.cpp:301-309): h = T1^-1 T2,
+    measured.localCoordinates(h) in the first-order chart = (Log(Rm^T Rh), Rm^T (th - tm)); order [omega, v].
+    Returns e (6), H1 (6,6), H2 (6,6): the Jacobians of `between` only (-Ad(h^-1), I), as GTSAM uses them."""
+    R1, t1 = T1[:9].reshape(3, 3), T1[9:]
+    R2, t2 = T2[:9].reshape(3, 3), T2[9:]
+    Rm, tm = Tm[:9].reshape(3, 3), Tm[9:]
+    Rh, th = R1.T @ R2, R1.T @ (t2 - t1)
+    e = np.concatenate([so3_log(Rm.T @ Rh), Rm.T @ (th - tm)])
+    Ri, ti = Rh.T, -Rh.T @ th                                  # h^-1
+    Ad = np.zeros((6, 6))
+    Ad[:3, :3] = Ri
+    Ad[3:, :3] = skew(ti) @ Ri
+    Ad[3:, 3:] = Ri
+    return e, -Ad, np.eye(6)
+
+
+def sparse_between_terms(poses, odo_from, odo_to, odo_meas, odo_sigmas):
+    """Normal-equation contribution (H, g = -J^T r, cost) of the odometry factors."""
+    n = 6 * len(poses)
+    H = np.zeros((n, n))
+    g = np.zeros(n)
+    cost = 0.0
+    for k in range(len(odo_from)):
+        a, b = int(odo_from[k]), int(odo_to[k])
+        e, H1, H2 = between_error(poses[a], poses[b], odo_meas[k])
+        W = np.diag(1.0 / odo_sigmas[k] ** 2)
+        sa, sb = slice(6 * a, 6 * a + 6), slice(6 * b, 6 * b + 6)
+        H[sa, sa] += H1.T @ W @ H1
+        H[sa, sb] += H1.T @ W @ H2
+        H[sb, sa] += H2.T @ W @ H1
+        H[sb, sb] += H2.T @ W @ H2
+        g[sa] -= H1.T @ W @ e
+        g[sb] -= H2.T @ W @ e
+        cost += 0.5 * float(e @ W @ e)
+    return H, g, cost

@@ -120,6 +120,48 @@ def test_sparse_linearize_solve_backsub_parity(which, lam, gpu):
 
 
 @pytest.mark.gpu
+def test_odometry_between_factors(gpu):
+    """B3 (bundle_adjust.cpp:301-309, useOdometry = 1) on the reference's example files: the odometry factors'
+    contribution to the reduced camera system and to the cost equals the oracle's, and LM with them converges."""
+    fn, data = load(gpu, EX, "synthetic", 2, 1)
+    pr0 = gpu.ba_io.build_sparse_problem(data, use_odometry=True)
+    assert len(pr0.odo_from) == sum(len(a) for a in data.odometryAssocs) > 0
+    rng = np.random.default_rng(1)
+    pr0 = pr0._replace(points=pr0.points + 0.01 * rng.standard_normal(pr0.points.shape))
+    ba = gpu.sparse_ba.SparseBundleAdjuster(pr0)
+    pr = ba.problem
+    S, g = ba.linearize(0.0)
+    S, g = S.cpu().numpy().copy(), g.cpu().numpy().copy()
+    So, go, co, nvo, pieces, cp = _lin_oracle(pr, 0.0)
+    Hb, gb, cb = ba_np.sparse_between_terms(pr.poses, pr.odo_from, pr.odo_to, pr.odo_meas, pr.odo_sigmas)
+    assert cb > 0 and np.abs(Hb).max() > 0
+    assert np.abs(S - (So + Hb)).max() <= 1e-9 * np.abs(So + Hb).max()
+    assert np.abs(g - (go + gb)).max() <= 1e-9 * np.abs(go + gb).max()
+    np.testing.assert_allclose(S, S.T, rtol=0, atol=1e-9 * np.abs(S).max())
+    assert ba.cost() == pytest.approx(co + cp + cb, rel=1e-10)
+    hist = ba.optimize(mode="lm")
+    assert hist[-1] < hist[0] and all(b <= a for a, b in zip(hist, hist[1:]))
+    # the committed -BA trajectory was produced WITH odometry: using it brings this build's output closer to it
+    io = gpu.ba_io
+    ref_tr = io.load_trajectory(os.path.join(EX, "traj_out.cam0-synthetic-BA.txt"))
+    k = [i for i, key in enumerate(ba.problem.pose_key) if key[0] == 0]
+    with_odo = np.median([np.linalg.norm(ba.poses.cpu().numpy()[i][9:] - r[1][9:]) for i, r in zip(k, ref_tr)])
+    ba0 = gpu.sparse_ba.SparseBundleAdjuster(io.build_sparse_problem(data, use_odometry=False))
+    ba0.optimize(mode="lm")
+    without = np.median([np.linalg.norm(ba0.poses.cpu().numpy()[i][9:] - r[1][9:]) for i, r in zip(k, ref_tr)])
+    print("median distance to the reference's -BA trajectory: with odometry %.4f, without %.4f" % (with_odo, without))
+    assert with_odo < 1e-3 < 0.05 < without                       # measured 2.7e-4 vs 0.108 (files carry 6 digits)
+    # ... and the optimised map IS the reference's GTSAM output (input map: 0.49 away)
+    ref_pts = io.load_map(os.path.join(EX, "map_out-synthetic-BA.pcd"))
+    assert np.abs(ba.points.cpu().numpy() - ref_pts).max() < 1e-3            # measured 2.2e-4
+    poses = ba.poses.cpu().numpy()
+    for c in (0, 1):
+        ref_c = io.load_trajectory(os.path.join(EX, "traj_out.cam%d-synthetic-BA.txt" % c))
+        kc = [i for i, key in enumerate(ba.problem.pose_key) if key[0] == c]
+        assert max(np.abs(poses[i][:9] - r[1][:9]).max() for i, r in zip(kc, ref_c)) < 3e-4      # rotations, measured 7e-5
+
+
+@pytest.mark.gpu
 def test_sparse_equals_dense_kernels(gpu):
     """The same 4-pose full-visibility scene through both code paths."""
     import torch

@@ -79,3 +79,23 @@ def test_c_oracle_matches_numpy_oracle(kw, c_oracle):
         po = c_oracle.ba_backsub(sc["poses"], sc["calib"], sc["sigma"], sc["points"], sc["obs"], dpose, sc["mask"],
                                  sc["prior_w"], sc["prior_xyz"], lam)
         np.testing.assert_allclose(po, sc["points"] + ba_np.backsub(pieces, dpose), atol=1e-9)
+
+
+def test_between_factor_jacobians_are_those_of_between():
+    """GTSAM's BetweenFactor uses the Jacobians of `between` (-Ad(h^-1), I); at zero error they are exact
+    derivatives of the first-order local coordinates under this build's retraction (R Exp(w), t + R v)."""
+    rng = np.random.default_rng(0)
+    for _ in range(5):
+        T1 = np.concatenate([ba_np.so3_exp(rng.normal(0, 0.5, 3)).reshape(-1), rng.normal(0, 2, 3)])
+        T2 = np.concatenate([ba_np.so3_exp(rng.normal(0, 0.5, 3)).reshape(-1), rng.normal(0, 2, 3)])
+        R1, R2 = T1[:9].reshape(3, 3), T2[:9].reshape(3, 3)
+        Tm = np.concatenate([(R1.T @ R2).reshape(-1), R1.T @ (T2[9:] - T1[9:])])
+        e, H1, H2 = ba_np.between_error(T1, T2, Tm)
+        assert np.abs(e).max() < 1e-12
+        h = 1e-6
+        for k in range(6):
+            d = np.zeros(6); d[k] = h
+            j1 = (ba_np.between_error(ba_np.retract_pose(T1, d), T2, Tm)[0] - ba_np.between_error(ba_np.retract_pose(T1, -d), T2, Tm)[0]) / (2 * h)
+            j2 = (ba_np.between_error(T1, ba_np.retract_pose(T2, d), Tm)[0] - ba_np.between_error(T1, ba_np.retract_pose(T2, -d), Tm)[0]) / (2 * h)
+            np.testing.assert_allclose(j1, H1[:, k], atol=1e-8)
+            np.testing.assert_allclose(j2, H2[:, k], atol=1e-8)

@@ -8,8 +8,9 @@ CLI-compatible counterpart of the reference's `bundle_adjust` tool
 
 Reads the BA_info.* / traj_out.* / map_out-*.pcd file set, runs the full (batch Levenberg-Marquardt)
 optimisation on the GPU -- the reference's iSAM_version = 0 mode, the one its ReadMe says works on slam2
-data -- and writes traj_out.camC-<baseName>-BA.txt and map_out-<baseName>-BA.pcd.  iSAM1/iSAM2,
-odometry factors and in-memory generation are outside the accelerated path.
+data -- and writes traj_out.camC-<baseName>-BA.txt and map_out-<baseName>-BA.pcd.  useOdometry adds the
+BetweenFactors of the odometry files (default 1, like the reference).  iSAM1/iSAM2 and in-memory
+generation are outside the accelerated path.
 """
 import os
 import sys
@@ -33,15 +34,13 @@ def main(argv):
     io = mqslam_amd.ba_io
     if isam != 0:
         print("note: iSAM%d is not accelerated; running the full optimisation (iSAM_version = 0)" % isam)
-    if use_odometry:
-        print("note: odometry factors are not accelerated; running with useOdometry = 0")
     fn = io.create_filenames(base_dir, base_name, nr_cameras)
     data = io.load_data(fn, fps, start_time, first_after)
     io.validate_data_integrity(data, nr_cameras)
-    ok, log = io.validate_sufficiently_constrained(data, False)
+    ok, log = io.validate_sufficiently_constrained(data, use_odometry)
     if not ok:
         print("Warning: num_unknowns > num_constraints at some step")
-    problem = io.build_sparse_problem(data, use_odometry=False)
+    problem = io.build_sparse_problem(data, use_odometry=use_odometry)
     print("Running full optimization (Levenberg-Marquardt) on %d 3D points and %d camera(s) with each %d frames."
           % (len(problem.points), nr_cameras, len(data.point3DAddedIdxs)))
     ba = mqslam_amd.sparse_ba.SparseBundleAdjuster(problem)
