@@ -160,6 +160,13 @@ MQS_HD LmResult lm_refine(Eval &eval, double *P, int max_iter, double eps)
         const bool pd = solve_step(acc, lambda, delta);
         bool accepted = false;
         if (pd) {
+            // a step below the resolution asked for: at the minimum (also ends the lambda escalation that
+            // follows the last successful step, where no trial can lower the cost any more)
+            double d2 = 0.0;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) d2 = fma(delta[k], delta[k], d2);
+            const double t2 = fma(P[3], P[3], fma(P[7], P[7], P[11] * P[11]));
+            if (d2 <= eps * eps * (1.0 + t2)) { res.converged = true; break; }
             retract(P, delta, trial);
             eval(trial, tacc);
             accepted = tacc[27] < acc[27];                 // NaN compares false: rejected
@@ -172,11 +179,7 @@ MQS_HD LmResult lm_refine(Eval &eval, double *P, int max_iter, double eps)
             for (int k = 0; k < kAcc; ++k) acc[k] = tacc[k];
             res.sqerr = acc[27];
             lambda = lambda > 1e-15 ? lambda * 0.1 : lambda;
-            double d2 = 0.0;
-#pragma unroll
-            for (int k = 0; k < 6; ++k) d2 = fma(delta[k], delta[k], d2);
-            const double t2 = fma(P[3], P[3], fma(P[7], P[7], P[11] * P[11]));
-            if (d2 <= eps * eps * (1.0 + t2) || gain <= 1e-15 * acc[27]) { res.converged = true; break; }
+            if (gain <= 1e-15 * acc[27]) { res.converged = true; break; }
         } else {
             lambda *= 10.0;
             if (lambda > 1e12) { res.converged = true; break; }     // no descent direction left: at the minimum

@@ -20,7 +20,7 @@ from ._lib import c_f64p, c_i32p, c_i64, c_u8p
 from .camera import _intr, rodrigues
 
 DEFAULT_MAX_ITER = 100          # LM iterations: run to convergence (OpenCV 2.4 stops at 20 or on a relative step of FLT_EPSILON)
-DEFAULT_EPS = 1e-12
+DEFAULT_EPS = 1e-10            # step size (relative to 1 + |t|) below which LM stops; OpenCV 2.4: FLT_EPSILON relative step
 RANSAC_HYPOTHESES = 256         # all evaluated in one launch
 RANSAC_SAMPLE_SIZE = 6          # direct linear transform needs 6 points (OpenCV 2.4 draws 5 and calls solvePnP on them)
 RANSAC_SAMPLE_ITERS = 5
