@@ -300,6 +300,36 @@ int mqs_pnp_ransac_dev(const double *objp, const double *imgp, int64_t N, const 
 int64_t mqs_pnp_workspace_bytes(int64_t N, int B);
 
 /* ---------------------------------------------------------------------------------------
+ * Image front-end of the per-frame loop.  Images are 8-bit, row-major, W x H, dense.
+ * OpenCV 2.4's published methods in float32 with a fixed operation order (oracle/features_np.py); parity with
+ * OpenCV itself is unpinned (the reference holds no images).
+ *
+ *   mqs_good_features_to_track: replaces cv2.goodFeaturesToTrack(img, maxCorners, qualityLevel, minDistance, None,
+ *       mask) (cv2_helpers.py:34-37; slam2.py:665, 1174): Shi-Tomasi minimum-eigenvalue response (Sobel 3, block 3),
+ *       candidates = thresholded 3x3 maxima under `mask` (may be NULL) off the 1-pixel border, ordered by response
+ *       (ties: row-major position), greedy minimum-distance selection.  out_xy [out_capacity][2] float32 (x, y),
+ *       out_n = number written (<= max_corners when max_corners > 0).
+ *   mqs_calc_optical_flow_pyr_lk: replaces cv2.calcOpticalFlowPyrLK(prev, next, prevPts) (slam2.py:381; defaults
+ *       21 x 21, maxLevel 3, 30 iterations, eps 0.01, minEigThreshold 1e-4).  next_pts [n][2], status [n] (1 = tracked),
+ *       err [n] (mean absolute window difference at level 0).  Points whose window leaves the image are reported lost
+ *       (OpenCV reads a replicated border there).
+ * ------------------------------------------------------------------------------------- */
+int mqs_good_features_to_track(mqs_ctx *ctx, const uint8_t *img, int W, int H, int max_corners, double quality_level,
+                               double min_distance, const uint8_t *mask, float *out_xy, int out_capacity, int32_t *out_n);
+int mqs_good_features_to_track_dev(const uint8_t *img, int W, int H, int max_corners, double quality_level,
+                                   double min_distance, const uint8_t *mask, float *out_xy, int out_capacity, int32_t *out_n,
+                                   void *workspace, int64_t workspace_bytes, void *stream);
+int64_t mqs_gftt_workspace_bytes(int W, int H);
+int mqs_calc_optical_flow_pyr_lk(mqs_ctx *ctx, const uint8_t *prev_img, const uint8_t *next_img, int W, int H,
+                                 const float *prev_pts, int n, int win_w, int win_h, int max_level, int max_iter, double eps,
+                                 double min_eig_threshold, float *next_pts, uint8_t *status, float *err);
+int mqs_calc_optical_flow_pyr_lk_dev(const uint8_t *prev_img, const uint8_t *next_img, int W, int H, const float *prev_pts,
+                                     int n, int win_w, int win_h, int max_level, int max_iter, double eps,
+                                     double min_eig_threshold, float *next_pts, uint8_t *status, float *err, void *workspace,
+                                     int64_t workspace_bytes, void *stream);
+int64_t mqs_lk_workspace_bytes(int W, int H, int max_level);
+
+/* ---------------------------------------------------------------------------------------
  * Timing helper used by bench.py: average duration (ms) of `reps` back-to-back launches of
  * one triangulation kernel measured with hipEvents on `stream` (kernel: 0 = linear_ls,
  * 1 = iterative_ls, 2 = linear_eigen).

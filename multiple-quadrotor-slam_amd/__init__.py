@@ -16,6 +16,7 @@ from . import camera                     # noqa: F401
 from . import ba_io                      # noqa: F401
 from . import sparse_ba                  # noqa: F401
 from . import pnp                        # noqa: F401
+from . import features                   # noqa: F401
 from . import slam_replay                # noqa: F401
 
 loaded = _lib.loaded

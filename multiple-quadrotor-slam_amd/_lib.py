@@ -96,6 +96,19 @@ SIGNATURES = {
                                           ctypes.c_int, ctypes.c_int, ctypes.c_double, c_vp, c_vp, c_vp, c_vp, c_vp,
                                           c_i64, c_vp]),
     "mqs_pnp_workspace_bytes": (c_i64, [c_i64, ctypes.c_int]),
+    "mqs_good_features_to_track": (ctypes.c_int, [c_vp, c_u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double,
+                                                  ctypes.c_double, c_u8p, c_f32p, ctypes.c_int, c_i32p]),
+    "mqs_good_features_to_track_dev": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double,
+                                                      ctypes.c_double, c_vp, c_vp, ctypes.c_int, c_vp, c_vp, c_i64, c_vp]),
+    "mqs_gftt_workspace_bytes": (c_i64, [ctypes.c_int, ctypes.c_int]),
+    "mqs_calc_optical_flow_pyr_lk": (ctypes.c_int, [c_vp, c_u8p, c_u8p, ctypes.c_int, ctypes.c_int, c_f32p, ctypes.c_int,
+                                                    ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double,
+                                                    ctypes.c_double, c_f32p, c_u8p, c_f32p]),
+    "mqs_calc_optical_flow_pyr_lk_dev": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, ctypes.c_int, c_vp, ctypes.c_int,
+                                                        ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                        ctypes.c_double, ctypes.c_double, c_vp, c_vp, c_vp, c_vp, c_i64,
+                                                        c_vp]),
+    "mqs_lk_workspace_bytes": (c_i64, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "mqs_time_triangulate_dev": (ctypes.c_int, [ctypes.c_int, c_vp, c_vp, ctypes.c_int, c_i64, ctypes.c_double,
                                                 ctypes.c_int, c_vp, c_vp, c_vp, ctypes.c_int, c_vp,
                                                 ctypes.POINTER(ctypes.c_float)]),

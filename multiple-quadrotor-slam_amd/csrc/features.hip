@@ -1,0 +1,543 @@
+// Image front-end of the per-frame loop on gfx950 (MI355X) -- SURVEY.md 8(f) rank 4:
+//   goodFeaturesToTrack   Work/python_libs/cv2_helpers.py:34-37; Work/SLAM/application/own/slam2.py:665, 1174
+//   calcOpticalFlowPyrLK  slam2.py:381
+// OpenCV 2.4 is not vendored; the kernels follow its published method as restated (float32, fixed operation
+// order) in oracle/features_np.py -- parity with OpenCV itself is unpinned (no images, no golden output in the
+// reference).  Integer stages (pyramid, Scharr derivatives) are bit-exact against the oracle, the corner response is
+// bit-exact float32 (no FMA contraction), the tracker agrees to float32 rounding of its window sums.
+//
+// Mapping to the machine
+//   * corner response: one thread per pixel, the 5x5 support read straight through L1/L2 (a VGA frame is 300 KB);
+//     two-stage max; candidates (thresholded 3x3 maxima under the mask) compacted with one atomic counter as 64-bit
+//     keys (response bits << 32 | ~position), sorted by rocPRIM's radix sort -- response descending, position
+//     ascending, so the result does not depend on the order the atomics happened in;
+//   * minimum-distance selection is inherently sequential in the candidates: one wavefront walks the sorted list,
+//     36 lanes test the 9 neighbouring grid cells x 4 slots of the accepted set (kept in LDS when it fits);
+//   * Lucas-Kanade: one wavefront per feature, lanes strided over the 21 x 21 window (7 pixels each, template and
+//     gradients in registers), all pyramid levels and all iterations inside one launch; window sums in fp64.
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+#include "mqs_common.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+constexpr int kBlock = 256;
+
+__device__ __forceinline__ int reflect101(int i, int n)
+{
+    if (n == 1) return 0;
+    if (i < 0) i = -i;
+    if (i >= n) i = 2 * (n - 1) - i;
+    return i;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// goodFeaturesToTrack
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void sobel_scaled(const uint8_t *__restrict__ img, int W, int H, int y, int x, float &dx, float &dy)
+{
+    const int ym = reflect101(y - 1, H), yp = reflect101(y + 1, H), xm = reflect101(x - 1, W), xp = reflect101(x + 1, W);
+    const float a = img[ym * W + xm], b = img[ym * W + x], c = img[ym * W + xp];
+    const float d = img[y * W + xm], f = img[y * W + xp];
+    const float g = img[yp * W + xm], h = img[yp * W + x], k = img[yp * W + xp];
+    const float scale = 1.0f / (4.0f * 3.0f * 255.0f);
+    dx = (((c - a) + 2.0f * (f - d)) + (k - g)) * scale;
+    dy = (((g - a) + 2.0f * (h - b)) + (k - c)) * scale;
+}
+
+__global__ __launch_bounds__(kBlock) void min_eig_kernel(const uint8_t *__restrict__ img, int W, int H, float *__restrict__ eig)
+{
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (x >= W || y >= H) return;
+    float rxx[3], rxy[3], ryy[3];
+#pragma unroll
+    for (int oy = -1; oy <= 1; ++oy) {
+        const int yy = reflect101(y + oy, H);
+        float pxx[3], pxy[3], pyy[3];
+#pragma unroll
+        for (int ox = -1; ox <= 1; ++ox) {
+            float dx, dy;
+            sobel_scaled(img, W, H, yy, reflect101(x + ox, W), dx, dy);
+            pxx[ox + 1] = dx * dx; pxy[ox + 1] = dx * dy; pyy[ox + 1] = dy * dy;
+        }
+        rxx[oy + 1] = (pxx[0] + pxx[1]) + pxx[2];
+        rxy[oy + 1] = (pxy[0] + pxy[1]) + pxy[2];
+        ryy[oy + 1] = (pyy[0] + pyy[1]) + pyy[2];
+    }
+    const float a = ((rxx[0] + rxx[1]) + rxx[2]) * 0.5f;
+    const float b = (rxy[0] + rxy[1]) + rxy[2];
+    const float c = ((ryy[0] + ryy[1]) + ryy[2]) * 0.5f;
+    const float d = a - c;
+    eig[y * W + x] = (a + c) - sqrtf(d * d + b * b);
+}
+
+__global__ __launch_bounds__(kBlock) void max_partial_kernel(const float *__restrict__ v, int64_t n, float *__restrict__ partial)
+{
+    __shared__ float s[kBlock];
+    float m = -INFINITY;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) m = fmaxf(m, v[i]);
+    s[threadIdx.x] = m;
+    __syncthreads();
+    for (int h = kBlock / 2; h >= 1; h >>= 1) {
+        if (threadIdx.x < h) s[threadIdx.x] = fmaxf(s[threadIdx.x], s[threadIdx.x + h]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = s[0];
+}
+
+__global__ __launch_bounds__(kBlock) void max_final_kernel(const float *__restrict__ partial, int n, float *__restrict__ out)
+{
+    __shared__ float s[kBlock];
+    float m = -INFINITY;
+    for (int i = threadIdx.x; i < n; i += kBlock) m = fmaxf(m, partial[i]);
+    s[threadIdx.x] = m;
+    __syncthreads();
+    for (int h = kBlock / 2; h >= 1; h >>= 1) {
+        if (threadIdx.x < h) s[threadIdx.x] = fmaxf(s[threadIdx.x], s[threadIdx.x + h]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = s[0];
+}
+
+// counter[0] = number of candidates appended (may exceed the capacity: the excess is dropped and reported)
+__global__ __launch_bounds__(kBlock) void candidates_kernel(const float *__restrict__ eig, int W, int H,
+                                                           const float *__restrict__ maxval, float quality,
+                                                           const uint8_t *__restrict__ mask, unsigned long long *__restrict__ keys,
+                                                           unsigned int capacity, unsigned int *__restrict__ counter)
+{
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (x <= 0 || y <= 0 || x >= W - 1 || y >= H - 1) return;
+    const float thr = maxval[0] * quality;
+    const float e = eig[y * W + x];
+    if (!(e > thr) || e == 0.0f) return;
+    if (mask && mask[y * W + x] == 0) return;
+    bool is_max = true;
+#pragma unroll
+    for (int oy = -1; oy <= 1; ++oy)
+#pragma unroll
+        for (int ox = -1; ox <= 1; ++ox) {
+            const float v = eig[(y + oy) * W + x + ox];          // in range: (x, y) is not on the border
+            if ((v > thr ? v : 0.0f) > e) is_max = false;
+        }
+    if (!is_max) return;
+    const unsigned int slot = atomicAdd(counter, 1u);
+    if (slot < capacity)
+        keys[slot] = ((unsigned long long)__float_as_uint(e) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)(y * W + x));
+}
+
+// One wavefront: greedy minimum-distance selection over the sorted candidates.
+// grid: cells x 4 slots (x | y << 16, 0xFFFFFFFF = empty), in LDS when `grid_global` is null.
+__global__ __launch_bounds__(64) void select_kernel(const unsigned long long *__restrict__ keys,
+                                                   const unsigned int *__restrict__ counter, unsigned int capacity, int W,
+                                                   int H, float min_distance, int max_corners, int out_capacity,
+                                                   unsigned int *__restrict__ grid_global, float *__restrict__ out_xy,
+                                                   int *__restrict__ out_n)
+{
+    extern __shared__ unsigned int sGrid[];
+    const int lane = threadIdx.x;
+    unsigned int n = counter[0];
+    if (n > capacity) n = capacity;
+    int accepted = 0;
+    const int limit = (max_corners > 0 && max_corners < out_capacity) ? max_corners : out_capacity;
+    if (min_distance < 1.0f) {
+        for (unsigned int i = lane; i < n && (int)i < limit; i += 64) {
+            const unsigned int pos = 0xFFFFFFFFu - (unsigned int)(keys[i] & 0xFFFFFFFFull);
+            out_xy[2 * i] = (float)(pos % W);
+            out_xy[2 * i + 1] = (float)(pos / W);
+        }
+        if (lane == 0) out_n[0] = (int)(n < (unsigned)limit ? n : (unsigned)limit);
+        return;
+    }
+    const int cell = (int)rintf(min_distance);
+    const int gw = (W + cell - 1) / cell, gh = (H + cell - 1) / cell;
+    unsigned int *grid = grid_global ? grid_global : sGrid;
+    for (int i = lane; i < gw * gh * 4; i += 64) grid[i] = 0xFFFFFFFFu;
+    __syncthreads();
+    const float md2 = min_distance * min_distance;
+    for (unsigned int i = 0; i < n && accepted < limit; ++i) {
+        const unsigned int pos = 0xFFFFFFFFu - (unsigned int)(keys[i] & 0xFFFFFFFFull);
+        const int x = (int)(pos % W), y = (int)(pos / W);
+        const int cx = x / cell, cy = y / cell;
+        bool clash = false;
+        unsigned int own = 0;
+        if (lane < 36) {
+            const int nb = lane >> 2, slot = lane & 3;
+            const int yy = cy + nb / 3 - 1, xx = cx + nb % 3 - 1;
+            if (yy >= 0 && yy < gh && xx >= 0 && xx < gw) {
+                const unsigned int v = grid[(yy * gw + xx) * 4 + slot];
+                if (nb == 4) own = v;
+                if (v != 0xFFFFFFFFu) {
+                    const float dx = (float)(x - (int)(v & 0xFFFFu)), dy = (float)(y - (int)(v >> 16));
+                    clash = dx * dx + dy * dy < md2;
+                }
+            }
+        }
+        if (__ballot(clash) != 0ull) continue;
+        // first empty slot of the own cell (lanes 16..19); a full cell cannot happen for points >= cell - 0.5 apart
+        const unsigned long long empties = __ballot(lane >= 16 && lane < 20 && own == 0xFFFFFFFFu);
+        if (empties != 0ull) {
+            const int first = __ffsll((long long)empties) - 1;
+            if (lane == first) grid[(cy * gw + cx) * 4 + (first - 16)] = (unsigned int)x | ((unsigned int)y << 16);
+        }
+        if (lane == 0) { out_xy[2 * accepted] = (float)x; out_xy[2 * accepted + 1] = (float)y; }
+        ++accepted;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    if (lane == 0) out_n[0] = accepted;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Pyramid and derivatives (integer, exact)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void pyr_down_kernel(const uint8_t *__restrict__ src, int W, int H, uint8_t *__restrict__ dst,
+                                                         int Wd, int Hd)
+{
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (x >= Wd || y >= Hd) return;
+    const int k[5] = {1, 4, 6, 4, 1};
+    int acc = 0;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const int yy = reflect101(2 * y + j - 2, H);
+        int row = 0;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) row += k[i] * (int)src[yy * W + reflect101(2 * x + i - 2, W)];
+        acc += k[j] * row;
+    }
+    dst[y * Wd + x] = (uint8_t)((acc + 128) >> 8);
+}
+
+__global__ __launch_bounds__(kBlock) void scharr_kernel(const uint8_t *__restrict__ src, int W, int H, short2 *__restrict__ d)
+{
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (x >= W || y >= H) return;
+    const int ym = reflect101(y - 1, H), yp = reflect101(y + 1, H), xm = reflect101(x - 1, W), xp = reflect101(x + 1, W);
+    const int a = src[ym * W + xm], b = src[ym * W + x], c = src[ym * W + xp];
+    const int e = src[y * W + xm], f = src[y * W + xp];
+    const int g = src[yp * W + xm], h = src[yp * W + x], k = src[yp * W + xp];
+    d[y * W + x] = make_short2((short)(3 * (c - a) + 10 * (f - e) + 3 * (k - g)), (short)(3 * (g - a) + 10 * (h - b) + 3 * (k - c)));
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Pyramidal Lucas-Kanade
+// ---------------------------------------------------------------------------------------------------
+constexpr int kMaxLevels = 8;
+constexpr int kMaxWinPixelsPerLane = 16;      // windows up to 31 x 31 (961 pixels / 64 lanes)
+
+struct LkLevels {
+    const uint8_t *I[kMaxLevels];
+    const uint8_t *J[kMaxLevels];
+    const short2 *dI[kMaxLevels];
+    int W[kMaxLevels], H[kMaxLevels];
+    int levels;                                // highest level index
+};
+
+__device__ __forceinline__ double wave_sum_d(double v)
+{
+#pragma unroll
+    for (int h = 32; h >= 1; h >>= 1) v += __shfl_xor(v, h);
+    return v;
+}
+
+__device__ __forceinline__ float bilinear_u8(const uint8_t *__restrict__ a, int W, int x, int y, float w00, float w01, float w10, float w11)
+{
+    const uint8_t *p = a + y * W + x;
+    return (((float)p[0] * w00 + (float)p[1] * w01) + (float)p[W] * w10) + (float)p[W + 1] * w11;
+}
+
+__global__ __launch_bounds__(64) void lk_kernel(LkLevels L, const float *__restrict__ prev_pts, int n, int ww, int wh,
+                                               int max_iter, float eps, float min_eig_threshold, float *__restrict__ next_pts,
+                                               uint8_t *__restrict__ status, float *__restrict__ err)
+{
+    const int k = blockIdx.x, lane = threadIdx.x;
+    if (k >= n) return;
+    const int npix = ww * wh;
+    const float halfx = (float)(ww - 1) * 0.5f, halfy = (float)(wh - 1) * 0.5f;
+    const float ppx = prev_pts[2 * k], ppy = prev_pts[2 * k + 1];
+    const float kFltScale = 1.0f / (float)(1 << 20);
+    float nx = 0.0f, ny = 0.0f;
+    bool ok = true;
+    float errv = 0.0f;
+    for (int level = L.levels; level >= 0; --level) {
+        const int W = L.W[level], H = L.H[level];
+        const float sc = 1.0f / (float)(1 << level);
+        float px = ppx * sc, py = ppy * sc;
+        if (level == L.levels) { nx = px; ny = py; } else { nx = nx * 2.0f; ny = ny * 2.0f; }
+        px -= halfx; py -= halfy;
+        const int ipx = (int)floorf(px), ipy = (int)floorf(py);
+        if (ipx < -ww || ipx >= W || ipy < -wh || ipy >= H || ipx < 0 || ipy < 0 || ipx + ww + 1 > W || ipy + wh + 1 > H) {
+            if (level == 0) { ok = false; errv = 0.0f; }
+            continue;
+        }
+        float Iw[kMaxWinPixelsPerLane], Ixw[kMaxWinPixelsPerLane], Iyw[kMaxWinPixelsPerLane];
+        double a11 = 0.0, a12 = 0.0, a22 = 0.0;
+        {
+            const float a = px - (float)ipx, b = py - (float)ipy;
+            const float w00 = (1.0f - a) * (1.0f - b), w01 = a * (1.0f - b), w10 = (1.0f - a) * b, w11 = a * b;
+            const uint8_t *I = L.I[level];
+            const short2 *dI = L.dI[level];
+#pragma unroll
+            for (int t = 0; t < kMaxWinPixelsPerLane; ++t) {
+                const int p = lane + 64 * t;
+                Iw[t] = 0.0f; Ixw[t] = 0.0f; Iyw[t] = 0.0f;
+                if (p < npix) {
+                    const int x = ipx + p % ww, y = ipy + p / ww;
+                    Iw[t] = bilinear_u8(I, W, x, y, w00, w01, w10, w11) * 32.0f;
+                    const short2 d00 = dI[y * W + x], d01 = dI[y * W + x + 1], d10 = dI[(y + 1) * W + x], d11 = dI[(y + 1) * W + x + 1];
+                    Ixw[t] = (((float)d00.x * w00 + (float)d01.x * w01) + (float)d10.x * w10) + (float)d11.x * w11;
+                    Iyw[t] = (((float)d00.y * w00 + (float)d01.y * w01) + (float)d10.y * w10) + (float)d11.y * w11;
+                    a11 += (double)Ixw[t] * (double)Ixw[t];
+                    a12 += (double)Ixw[t] * (double)Iyw[t];
+                    a22 += (double)Iyw[t] * (double)Iyw[t];
+                }
+            }
+        }
+        const float A11 = (float)wave_sum_d(a11) * kFltScale, A12 = (float)wave_sum_d(a12) * kFltScale,
+                    A22 = (float)wave_sum_d(a22) * kFltScale;
+        float D = A11 * A22 - A12 * A12;
+        const float min_eig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.0f * A12 * A12)) / (float)(2 * ww * wh);
+        if (min_eig < min_eig_threshold || D < 1.1920929e-07f) {
+            if (level == 0) ok = false;
+            continue;
+        }
+        D = 1.0f / D;
+        nx -= halfx; ny -= halfy;
+        float pdx = 0.0f, pdy = 0.0f;
+        const uint8_t *J = L.J[level];
+        for (int j = 0; j < max_iter; ++j) {
+            const int inx = (int)floorf(nx), iny = (int)floorf(ny);
+            if (inx < 0 || iny < 0 || inx + ww + 1 > W || iny + wh + 1 > H) {
+                if (level == 0) ok = false;
+                break;
+            }
+            const float a = nx - (float)inx, b = ny - (float)iny;
+            const float w00 = (1.0f - a) * (1.0f - b), w01 = a * (1.0f - b), w10 = (1.0f - a) * b, w11 = a * b;
+            double b1 = 0.0, b2 = 0.0;
+#pragma unroll
+            for (int t = 0; t < kMaxWinPixelsPerLane; ++t) {
+                const int p = lane + 64 * t;
+                if (p < npix) {
+                    const float diff = bilinear_u8(J, W, inx + p % ww, iny + p / ww, w00, w01, w10, w11) * 32.0f - Iw[t];
+                    b1 += (double)diff * (double)Ixw[t];
+                    b2 += (double)diff * (double)Iyw[t];
+                }
+            }
+            const float B1 = (float)wave_sum_d(b1) * kFltScale, B2 = (float)wave_sum_d(b2) * kFltScale;
+            const float dx = (A12 * B2 - A22 * B1) * D, dy = (A12 * B1 - A11 * B2) * D;
+            nx += dx; ny += dy;
+            if (dx * dx + dy * dy <= eps * eps) break;
+            if (j > 0 && fabsf(dx + pdx) < 0.01f && fabsf(dy + pdy) < 0.01f) {
+                nx -= dx * 0.5f; ny -= dy * 0.5f;
+                break;
+            }
+            pdx = dx; pdy = dy;
+        }
+        nx += halfx; ny += halfy;
+        if (ok && level == 0) {
+            const float qx = nx - halfx, qy = ny - halfy;
+            const int inx = (int)floorf(qx), iny = (int)floorf(qy);
+            if (inx < 0 || iny < 0 || inx + ww + 1 > W || iny + wh + 1 > H) {
+                ok = false;
+            } else {
+                const float a = qx - (float)inx, b = qy - (float)iny;
+                const float w00 = (1.0f - a) * (1.0f - b), w01 = a * (1.0f - b), w10 = (1.0f - a) * b, w11 = a * b;
+                double e = 0.0;
+#pragma unroll
+                for (int t = 0; t < kMaxWinPixelsPerLane; ++t) {
+                    const int p = lane + 64 * t;
+                    if (p < npix)
+                        e += fabs((double)(bilinear_u8(J, W, inx + p % ww, iny + p / ww, w00, w01, w10, w11) * 32.0f - Iw[t]));
+                }
+                errv = (float)(wave_sum_d(e) / (32.0 * (double)ww * (double)wh));
+            }
+        }
+    }
+    if (lane == 0) {
+        next_pts[2 * k] = nx;
+        next_pts[2 * k + 1] = ny;
+        status[k] = ok ? 1 : 0;
+        err[k] = ok ? errv : 0.0f;
+    }
+}
+
+dim3 grid2d(int W, int H) { return dim3((unsigned)((W + 31) / 32), (unsigned)((H + 7) / 8)); }
+
+size_t align_up(size_t v) { return (v + 255) & ~size_t(255); }
+
+}  // namespace
+
+extern "C" {
+
+int64_t mqs_gftt_workspace_bytes(int W, int H)
+{
+    if (W < 1 || H < 1) return 0;
+    const size_t npx = (size_t)W * H;
+    size_t sort_tmp = 0;
+    (void)rocprim::radix_sort_keys_desc(nullptr, sort_tmp, (unsigned long long *)nullptr, (unsigned long long *)nullptr, npx, 0, 64,
+                                        (hipStream_t)0);
+    // response, 2 key arrays, block maxima, max, counter, selection grid (worst case: cell = 1), sort scratch
+    return (int64_t)(align_up(npx * 4) + 2 * align_up(npx * 8) + align_up(1024 * 4) + 256 + 256 + align_up(npx * 16) +
+                     align_up(sort_tmp));
+}
+
+int mqs_good_features_to_track_dev(const uint8_t *img, int W, int H, int max_corners, double quality_level,
+                                   double min_distance, const uint8_t *mask, float *out_xy, int out_capacity, int32_t *out_n,
+                                   void *workspace, int64_t workspace_bytes, void *stream_)
+{
+    MQS_ARG_CHECK(img && out_xy && out_n && workspace, "pointers must not be null");
+    MQS_ARG_CHECK(W >= 3 && H >= 3 && W < 65536 && H < 65536, "3 <= W, H < 65536");
+    MQS_ARG_CHECK(max_corners >= 0 && out_capacity >= 1 && quality_level > 0.0 && min_distance >= 0.0, "parameter ranges");
+    MQS_ARG_CHECK(workspace_bytes >= mqs_gftt_workspace_bytes(W, H), "workspace too small (mqs_gftt_workspace_bytes)");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const size_t npx = (size_t)W * H;
+    char *w = static_cast<char *>(workspace);
+    float *eig = reinterpret_cast<float *>(w); w += align_up(npx * 4);
+    unsigned long long *keys = reinterpret_cast<unsigned long long *>(w); w += align_up(npx * 8);
+    unsigned long long *sorted = reinterpret_cast<unsigned long long *>(w); w += align_up(npx * 8);
+    float *partial = reinterpret_cast<float *>(w); w += align_up(1024 * 4);
+    float *maxval = reinterpret_cast<float *>(w); w += 256;
+    unsigned int *counter = reinterpret_cast<unsigned int *>(w); w += 256;
+    unsigned int *grid = reinterpret_cast<unsigned int *>(w); w += align_up(npx * 16);
+    void *sort_tmp = w;
+    size_t sort_bytes = 0;
+    (void)rocprim::radix_sort_keys_desc(nullptr, sort_bytes, keys, sorted, npx, 0, 64, stream);
+
+    hipLaunchKernelGGL(min_eig_kernel, grid2d(W, H), dim3(kBlock), 0, stream, img, W, H, eig);
+    const int nb = (int)((npx + kBlock * 8 - 1) / (kBlock * 8)) < 1024 ? (int)((npx + kBlock * 8 - 1) / (kBlock * 8)) : 1024;
+    hipLaunchKernelGGL(max_partial_kernel, dim3(nb), dim3(kBlock), 0, stream, eig, (int64_t)npx, partial);
+    hipLaunchKernelGGL(max_final_kernel, dim3(1), dim3(kBlock), 0, stream, partial, nb, maxval);
+    MQS_HIP_CHECK(hipMemsetAsync(counter, 0, 4, stream));
+    // unused key slots sort to the end (key 0 = response +0.0 can never be a candidate: candidates are > threshold >= 0)
+    MQS_HIP_CHECK(hipMemsetAsync(keys, 0, npx * 8, stream));
+    hipLaunchKernelGGL(candidates_kernel, grid2d(W, H), dim3(kBlock), 0, stream, eig, W, H, maxval, (float)quality_level, mask,
+                       keys, (unsigned int)npx, counter);
+    MQS_HIP_CHECK(rocprim::radix_sort_keys_desc(sort_tmp, sort_bytes, keys, sorted, npx, 0, 64, stream));
+    const int cell = min_distance >= 1.0 ? (int)rint(min_distance) : 1;
+    const size_t cells = (size_t)((W + cell - 1) / cell) * ((H + cell - 1) / cell);
+    const size_t lds = cells * 16;
+    const bool in_lds = min_distance >= 1.0 && lds <= 60 * 1024;
+    hipLaunchKernelGGL(select_kernel, dim3(1), dim3(64), in_lds ? lds : 0, stream, sorted, counter, (unsigned int)npx, W, H,
+                       (float)min_distance, max_corners, out_capacity, in_lds ? nullptr : grid, out_xy, out_n);
+    MQS_HIP_CHECK(hipGetLastError());
+    return MQS_OK;
+}
+
+int64_t mqs_lk_workspace_bytes(int W, int H, int max_level)
+{
+    if (W < 1 || H < 1 || max_level < 0 || max_level >= kMaxLevels) return 0;
+    size_t total = 0;
+    int w = W, h = H;
+    for (int l = 0; l <= max_level; ++l) {
+        // prev / next level images (level 0 is the caller's) and the derivative image of prev
+        if (l > 0) total += 2 * align_up((size_t)w * h);
+        total += align_up((size_t)w * h * 4);
+        if (w <= 2 || h <= 2) break;
+        w = (w + 1) / 2; h = (h + 1) / 2;
+    }
+    return (int64_t)total;
+}
+
+int mqs_calc_optical_flow_pyr_lk_dev(const uint8_t *prev_img, const uint8_t *next_img, int W, int H, const float *prev_pts,
+                                     int n, int win_w, int win_h, int max_level, int max_iter, double eps,
+                                     double min_eig_threshold, float *next_pts, uint8_t *status, float *err, void *workspace,
+                                     int64_t workspace_bytes, void *stream_)
+{
+    MQS_ARG_CHECK(prev_img && next_img && workspace, "pointers must not be null");
+    MQS_ARG_CHECK(n >= 0 && (n == 0 || (prev_pts && next_pts && status && err)), "point arrays must not be null");
+    MQS_ARG_CHECK(W >= 3 && H >= 3 && max_level >= 0 && max_level < kMaxLevels, "W, H >= 3; 0 <= max_level < 8");
+    MQS_ARG_CHECK(win_w >= 3 && win_h >= 3 && win_w * win_h <= 64 * kMaxWinPixelsPerLane, "3 <= window, at most 1024 pixels");
+    MQS_ARG_CHECK(max_iter >= 1 && eps >= 0.0, "max_iter >= 1, eps >= 0");
+    MQS_ARG_CHECK(workspace_bytes >= mqs_lk_workspace_bytes(W, H, max_level), "workspace too small (mqs_lk_workspace_bytes)");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    LkLevels L;
+    char *wsp = static_cast<char *>(workspace);
+    int w = W, h = H;
+    L.levels = 0;
+    for (int l = 0; l <= max_level; ++l) {
+        L.W[l] = w; L.H[l] = h;
+        if (l == 0) {
+            L.I[0] = prev_img; L.J[0] = next_img;
+        } else {
+            uint8_t *pi = reinterpret_cast<uint8_t *>(wsp); wsp += align_up((size_t)w * h);
+            uint8_t *pj = reinterpret_cast<uint8_t *>(wsp); wsp += align_up((size_t)w * h);
+            hipLaunchKernelGGL(pyr_down_kernel, grid2d(w, h), dim3(kBlock), 0, stream, L.I[l - 1], L.W[l - 1], L.H[l - 1], pi, w, h);
+            hipLaunchKernelGGL(pyr_down_kernel, grid2d(w, h), dim3(kBlock), 0, stream, L.J[l - 1], L.W[l - 1], L.H[l - 1], pj, w, h);
+            L.I[l] = pi; L.J[l] = pj;
+        }
+        short2 *d = reinterpret_cast<short2 *>(wsp); wsp += align_up((size_t)w * h * 4);
+        hipLaunchKernelGGL(scharr_kernel, grid2d(w, h), dim3(kBlock), 0, stream, L.I[l], w, h, d);
+        L.dI[l] = d;
+        L.levels = l;
+        if (w <= 2 || h <= 2) break;
+        w = (w + 1) / 2; h = (h + 1) / 2;
+    }
+    if (n > 0)
+        hipLaunchKernelGGL(lk_kernel, dim3(n), dim3(64), 0, stream, L, prev_pts, n, win_w, win_h, max_iter, (float)eps,
+                           (float)min_eig_threshold, next_pts, status, err);
+    MQS_HIP_CHECK(hipGetLastError());
+    return MQS_OK;
+}
+
+// ---- host-pointer wrappers ----
+int mqs_good_features_to_track(mqs_ctx *ctx, const uint8_t *img, int W, int H, int max_corners, double quality_level,
+                               double min_distance, const uint8_t *mask, float *out_xy, int out_capacity, int32_t *out_n)
+{
+    MQS_ARG_CHECK(ctx && img && out_xy && out_n, "pointers must not be null");
+    MQS_ARG_CHECK(W >= 3 && H >= 3 && out_capacity >= 1, "W, H >= 3, out_capacity >= 1");
+    MQS_HIP_CHECK(hipSetDevice(ctx->device));
+    const size_t npx = (size_t)W * H, wsb = (size_t)mqs_gftt_workspace_bytes(W, H);
+    const size_t o_img = 0, o_mask = align_up(npx), o_xy = o_mask + align_up(npx), o_n = o_xy + align_up((size_t)out_capacity * 8),
+                 o_ws = o_n + 256, total = o_ws + wsb;
+    int rc = mqs_ctx_reserve(ctx, total);
+    if (rc != MQS_OK) return rc;
+    char *d = static_cast<char *>(ctx->dbuf);
+    hipStream_t s = ctx->stream;
+    MQS_HIP_CHECK(hipMemcpyAsync(d + o_img, img, npx, hipMemcpyHostToDevice, s));
+    if (mask) MQS_HIP_CHECK(hipMemcpyAsync(d + o_mask, mask, npx, hipMemcpyHostToDevice, s));
+    rc = mqs_good_features_to_track_dev((uint8_t *)(d + o_img), W, H, max_corners, quality_level, min_distance,
+                                        mask ? (uint8_t *)(d + o_mask) : nullptr, (float *)(d + o_xy), out_capacity,
+                                        (int32_t *)(d + o_n), d + o_ws, (int64_t)wsb, s);
+    if (rc != MQS_OK) return rc;
+    MQS_HIP_CHECK(hipMemcpyAsync(out_n, d + o_n, 4, hipMemcpyDeviceToHost, s));
+    MQS_HIP_CHECK(hipMemcpyAsync(out_xy, d + o_xy, (size_t)out_capacity * 8, hipMemcpyDeviceToHost, s));
+    MQS_HIP_CHECK(hipStreamSynchronize(s));
+    return MQS_OK;
+}
+
+int mqs_calc_optical_flow_pyr_lk(mqs_ctx *ctx, const uint8_t *prev_img, const uint8_t *next_img, int W, int H,
+                                 const float *prev_pts, int n, int win_w, int win_h, int max_level, int max_iter, double eps,
+                                 double min_eig_threshold, float *next_pts, uint8_t *status, float *err)
+{
+    MQS_ARG_CHECK(ctx && prev_img && next_img, "pointers must not be null");
+    MQS_ARG_CHECK(W >= 3 && H >= 3 && n >= 0, "W, H >= 3, n >= 0");
+    if (n == 0) return MQS_OK;
+    MQS_ARG_CHECK(prev_pts && next_pts && status && err, "point arrays must not be null");
+    MQS_HIP_CHECK(hipSetDevice(ctx->device));
+    const size_t npx = (size_t)W * H, wsb = (size_t)mqs_lk_workspace_bytes(W, H, max_level);
+    MQS_ARG_CHECK(wsb > 0, "0 <= max_level < 8");
+    const size_t o_i = 0, o_j = align_up(npx), o_p = o_j + align_up(npx), o_q = o_p + align_up((size_t)n * 8),
+                 o_s = o_q + align_up((size_t)n * 8), o_e = o_s + align_up((size_t)n), o_ws = o_e + align_up((size_t)n * 4),
+                 total = o_ws + wsb;
+    int rc = mqs_ctx_reserve(ctx, total);
+    if (rc != MQS_OK) return rc;
+    char *d = static_cast<char *>(ctx->dbuf);
+    hipStream_t s = ctx->stream;
+    MQS_HIP_CHECK(hipMemcpyAsync(d + o_i, prev_img, npx, hipMemcpyHostToDevice, s));
+    MQS_HIP_CHECK(hipMemcpyAsync(d + o_j, next_img, npx, hipMemcpyHostToDevice, s));
+    MQS_HIP_CHECK(hipMemcpyAsync(d + o_p, prev_pts, (size_t)n * 8, hipMemcpyHostToDevice, s));
+    rc = mqs_calc_optical_flow_pyr_lk_dev((uint8_t *)(d + o_i), (uint8_t *)(d + o_j), W, H, (float *)(d + o_p), n, win_w, win_h,
+                                          max_level, max_iter, eps, min_eig_threshold, (float *)(d + o_q), (uint8_t *)(d + o_s),
+                                          (float *)(d + o_e), d + o_ws, (int64_t)wsb, s);
+    if (rc != MQS_OK) return rc;
+    MQS_HIP_CHECK(hipMemcpyAsync(next_pts, d + o_q, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+    MQS_HIP_CHECK(hipMemcpyAsync(status, d + o_s, (size_t)n, hipMemcpyDeviceToHost, s));
+    MQS_HIP_CHECK(hipMemcpyAsync(err, d + o_e, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    MQS_HIP_CHECK(hipStreamSynchronize(s));
+    return MQS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,173 @@
+"""
+Image front-end (goodFeaturesToTrack at slam2.py:665, calcOpticalFlowPyrLK at slam2.py:381).
+Parity with OpenCV is UNPINNED (no images / golden output in the reference, no cv2 here): the GPU kernels are
+checked against the numpy restatement of OpenCV 2.4's published method (oracle/features_np.py) and the oracle
+itself against analytic properties of synthetic frames (known sub-pixel shifts, known corner positions).
+"""
+import numpy as np
+import pytest
+
+from oracle import features_np as Fn
+
+
+def texture(H, W, shift=(0.0, 0.0), seed=0, blobs=400):
+    """Sum of Gaussian blobs: analytic, so a sub-pixel shifted copy is rendered exactly."""
+    rng = np.random.default_rng(seed)
+    cx, cy = rng.uniform(0, W, blobs), rng.uniform(0, H, blobs)
+    s, a = rng.uniform(1.5, 4.0, blobs), rng.uniform(-1, 1, blobs)
+    y, x = np.mgrid[0:H, 0:W].astype(np.float64)
+    x, y = x - shift[0], y - shift[1]
+    img = np.zeros((H, W))
+    for k in range(blobs):
+        img += a[k] * np.exp(-((x - cx[k]) ** 2 + (y - cy[k]) ** 2) / (2 * s[k] ** 2))
+    lo, hi = -6.0, 6.0                                     # fixed range: the shifted frame uses the same mapping
+    return np.clip(np.rint((img - lo) / (hi - lo) * 255), 0, 255).astype(np.uint8)
+
+
+def checkerboard(H, W, cell):
+    y, x = np.mgrid[0:H, 0:W]
+    return (((x // cell + y // cell) % 2) * 200 + 20).astype(np.uint8)
+
+
+# ---------------------------------------------------------------------------------------------------
+# CPU: the oracle against analytic truth
+# ---------------------------------------------------------------------------------------------------
+def test_oracle_corners_sit_on_checkerboard_crossings():
+    img = checkerboard(96, 128, 16)
+    pts = Fn.good_features_to_track(img, 0, 0.05, 5.0)
+    assert len(pts) == 5 * 7                                # interior crossings of a 6 x 8 board
+    # every corner within one pixel of a crossing (multiples of 16)
+    d = np.abs(pts - np.rint(pts / 16.0) * 16.0)
+    assert d.max() <= 1.0
+    # minimum distance honoured, order = decreasing response
+    e = Fn.corner_min_eigenval(img)
+    r = e[pts[:, 1].astype(int), pts[:, 0].astype(int)]
+    assert np.all(np.diff(r) <= 0)
+    dd = np.linalg.norm(pts[:, None] - pts[None], axis=2) + 1e9 * np.eye(len(pts))
+    assert dd.min() >= 5.0
+
+
+def test_oracle_mask_and_limits():
+    img = texture(120, 160, seed=3)
+    allp = Fn.good_features_to_track(img, 0, 0.01, 6.0)
+    assert len(allp) > 40
+    top = Fn.good_features_to_track(img, 10, 0.01, 6.0)
+    np.testing.assert_array_equal(top, allp[:10])
+    mask = np.ones(img.shape, np.uint8)
+    mask[:, :80] = 0
+    right = Fn.good_features_to_track(img, 0, 0.01, 6.0, mask)
+    assert len(right) > 10 and right[:, 0].min() >= 80
+
+
+def test_oracle_lk_recovers_known_shift():
+    I = texture(240, 320, seed=0)
+    for shift in [(3.3, -1.7), (-7.25, 4.5), (0.4, 0.3)]:
+        J = texture(240, 320, shift=shift, seed=0)
+        pts = Fn.good_features_to_track(I, 80, 0.01, 8.0)
+        nxt, st, err = Fn.calc_optical_flow_pyr_lk(I, J, pts)
+        ok = st == 1
+        assert ok.sum() >= 0.6 * len(pts)
+        flow = (nxt - pts)[ok]
+        assert np.abs(np.median(flow, axis=0) - shift).max() < 0.03
+        assert np.percentile(np.abs(flow - shift).max(axis=1), 90) < 0.15
+        assert np.median(err[ok]) < 2.0
+    # a feature whose window leaves the image is reported lost
+    nxt, st, err = Fn.calc_optical_flow_pyr_lk(I, I, np.array([[3.0, 3.0], [160.0, 120.0]], np.float32))
+    assert st.tolist() == [0, 1] and np.abs(nxt[1] - [160, 120]).max() < 1e-3
+
+
+def test_oracle_pyramid_and_derivatives():
+    img = texture(61, 83, seed=5)
+    p = Fn.pyr_down(img)
+    assert p.shape == (31, 42)
+    flat = np.full((40, 40), 77, np.uint8)
+    assert (Fn.pyr_down(flat) == 77).all()                  # kernel sums to 256, rounding
+    dx, dy = Fn.scharr_deriv(np.tile(np.arange(40, dtype=np.uint8) * 3, (40, 1)))
+    assert (dx[:, 1:-1] == 16 * 2 * 3).all() and (dy == 0).all()
+
+
+def test_facade_argument_errors(mqs):
+    with pytest.raises(ValueError):
+        mqs.features.goodFeaturesToTrack(np.zeros((10, 10), np.float32), 5, 0.01, 3)
+    with pytest.raises(ValueError):
+        mqs.features.calcOpticalFlowPyrLK(np.zeros((10, 10), np.uint8), np.zeros((10, 12), np.uint8), np.zeros((1, 2)))
+    assert mqs.features.goodFeaturesToTrack(np.zeros((10, 10), np.uint8), 0, 0.01, 3).shape == (0, 2)   # cv2_helpers.py:35-36
+
+
+# ---------------------------------------------------------------------------------------------------
+# GPU against the oracle
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,maxc,q,md,masked", [((120, 160), 50, 0.01, 6.0, False), ((240, 320), 300, 0.01, 7.0, True),
+                                                     ((97, 131), 0, 0.02, 1.0, False), ((480, 640), 300, 0.01, 7.0, True),
+                                                     ((64, 64), 20, 0.05, 0.0, False), ((200, 300), 1000, 0.001, 2.5, False)])
+def test_gpu_good_features_equal_oracle(shape, maxc, q, md, masked, gpu):
+    img = texture(shape[0], shape[1], seed=shape[0])
+    mask = None
+    if masked:                                              # slam2.py:29-40 keypoint_mask: discs around existing points cleared
+        mask = np.ones(shape, np.uint8)
+        rng = np.random.default_rng(1)
+        yy, xx = np.mgrid[0:shape[0], 0:shape[1]]
+        for cx, cy in zip(rng.uniform(0, shape[1], 25), rng.uniform(0, shape[0], 25)):
+            mask[(xx - cx) ** 2 + (yy - cy) ** 2 <= 49] = 0
+    ref = Fn.good_features_to_track(img, maxc, q, md, mask)
+    got = gpu.features.goodFeaturesToTrack(img, maxc, q, md, None, mask, capacity=max(len(ref) + 8, 1))
+    assert got.dtype == np.float32 and got.shape == ref.shape
+    np.testing.assert_array_equal(got, ref)                 # same corners in the same order: exact
+
+
+@pytest.mark.gpu
+def test_gpu_good_features_checkerboard_and_flat(gpu):
+    pts = gpu.features.goodFeaturesToTrack(checkerboard(96, 128, 16), 0, 0.05, 5.0, capacity=100)
+    np.testing.assert_array_equal(pts, Fn.good_features_to_track(checkerboard(96, 128, 16), 0, 0.05, 5.0))
+    assert len(gpu.features.goodFeaturesToTrack(np.full((50, 60), 9, np.uint8), 10, 0.01, 3.0)) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,shift", [((240, 320), (3.3, -1.7)), ((480, 640), (-9.5, 6.25)), ((120, 160), (0.4, 0.3))])
+def test_gpu_lk_equals_oracle_and_truth(shape, shift, gpu):
+    I = texture(shape[0], shape[1], seed=7, blobs=300 * shape[0] * shape[1] // (240 * 320))
+    J = texture(shape[0], shape[1], shift=shift, seed=7, blobs=300 * shape[0] * shape[1] // (240 * 320))
+    pts = Fn.good_features_to_track(I, 120, 0.01, 8.0)
+    pts = np.concatenate([pts, np.array([[2.0, 2.0], [shape[1] - 3.0, 5.0]], np.float32)])     # two lost at the border
+    rn, rs, re = Fn.calc_optical_flow_pyr_lk(I, J, pts)
+    gn, gs, ge = gpu.features.calcOpticalFlowPyrLK(I, J, pts)
+    assert gn.shape == pts.shape and gs.shape == (len(pts), 1) and ge.shape == (len(pts), 1)
+    np.testing.assert_array_equal(gs.ravel(), rs)            # same features tracked / lost
+    ok = rs == 1
+    assert np.abs(gn[ok] - rn[ok]).max() < 2e-3              # float32 window sums in a different order
+    np.testing.assert_allclose(ge.ravel()[ok], re[ok], rtol=1e-3, atol=1e-3)
+    flow = (gn - pts)[ok]
+    assert np.abs(np.median(flow, axis=0) - shift).max() < 0.05
+    # OpenCV-shaped input (n, 1, 2)
+    gn2, _, _ = gpu.features.calcOpticalFlowPyrLK(I, J, pts.reshape(-1, 1, 2))
+    assert gn2.shape == (len(pts), 1, 2)
+    np.testing.assert_array_equal(gn2.reshape(-1, 2), gn)
+
+
+@pytest.mark.gpu
+def test_gpu_detect_then_track_loop(gpu):
+    """slam2.py's front-end cycle on rendered frames: detect, track over 5 frames of accumulating motion, top up under
+    the coverage mask."""
+    I0 = texture(240, 320, seed=11)
+    pts = gpu.features.goodFeaturesToTrack(I0, 150, 0.01, 7.0)
+    assert len(pts) >= 100
+    cur, prev_img, total = pts.copy(), I0, np.zeros(2)
+    alive = np.ones(len(pts), bool)
+    for k in range(1, 6):
+        total += (1.7, -0.9)
+        img = texture(240, 320, shift=tuple(total), seed=11)
+        nxt, st, err = gpu.features.calcOpticalFlowPyrLK(prev_img, img, cur)
+        good = (st.ravel() == 1) & (err.ravel() < 7.0)      # slam2.py:382 max_OF_error
+        alive &= good
+        cur, prev_img = nxt, img
+    assert alive.mean() > 0.7
+    assert np.abs(np.median((cur - pts)[alive], axis=0) - total).max() < 0.1
+    mask = np.ones(I0.shape, np.uint8)
+    yy, xx = np.mgrid[0:240, 0:320]
+    for x, y in cur[alive]:
+        mask[(xx - x) ** 2 + (yy - y) ** 2 <= 49] = 0
+    extra = gpu.features.goodFeaturesToTrack(prev_img, 50, 0.01, 7.0, None, mask)
+    if len(extra):
+        d = np.linalg.norm(extra[:, None] - cur[alive][None], axis=2)
+        assert d.min() > 7.0
