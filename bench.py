@@ -19,6 +19,7 @@ Extra objects on the JSON line:
   roofline     -- dominant kernel (iterative-LS): algorithmic bytes per launch / average launch
                   duration from hipEvents on the launch stream, against 8 TB/s HBM.
   rooflines    -- the same for every kernel of the step, the BA kernels and the matcher (MFMA bound).
+  frontend     -- corner detection + pyramidal LK on a rendered VGA frame pair (kernel time).
   replay       -- the per-frame SLAM loop replayed from the reference's recorded tracks (frames/s).
   cpu_baseline -- the oracle's plain-C port of the reference kernel (oracle/c/tri_oracle.c),
                   single thread as the reference ships it, same step on the same arrays
@@ -48,6 +49,7 @@ def main():
     ap.add_argument("--no-ba", action="store_true")
     ap.add_argument("--no-match", action="store_true")
     ap.add_argument("--no-replay", action="store_true")
+    ap.add_argument("--no-frontend", action="store_true")
     ap.add_argument("--descriptors", type=int, default=65536)
     args = ap.parse_args()
 
@@ -217,6 +219,59 @@ def main():
                       "max_abs_pose_diff_vs_recorded": float(np.abs(rp["poses"] - rec).max()),
                       "landmarks_triangulated": int(np.isfinite(rp["points"][:, 0]).sum())}
 
+    # ---- image front-end on a rendered VGA frame pair: kernels only, device-resident ----
+    frontend_out = None
+    if rank == 0 and not args.no_frontend:
+        import ctypes
+        rng = np.random.default_rng(5)
+        Hh, Ww = 480, 640
+        yy, xx = np.mgrid[0:Hh, 0:Ww].astype(np.float32)
+        def render(sx, sy):
+            img = np.zeros((Hh, Ww), np.float32)
+            r2 = np.random.default_rng(6)
+            for _ in range(500):
+                cx, cy, s, a = r2.uniform(0, Ww), r2.uniform(0, Hh), r2.uniform(1.5, 4.0), r2.uniform(-1, 1)
+                x0, x1 = int(max(0, cx - 4 * s + sx)), int(min(Ww, cx + 4 * s + sx + 1))
+                y0, y1 = int(max(0, cy - 4 * s + sy)), int(min(Hh, cy + 4 * s + sy + 1))
+                img[y0:y1, x0:x1] += a * np.exp(-((xx[y0:y1, x0:x1] - cx - sx) ** 2 + (yy[y0:y1, x0:x1] - cy - sy) ** 2) / (2 * s * s))
+            return np.clip(np.rint((img + 4.0) / 8.0 * 255), 0, 255).astype(np.uint8)
+        I0, I1 = render(0.0, 0.0), render(2.3, -1.1)
+        Lb = mqslam_amd._lib
+        dI, dJ = torch.from_numpy(I0).to(dev), torch.from_numpy(I1).to(dev)
+        ws1 = torch.empty(int(Lb.lib().mqs_gftt_workspace_bytes(Ww, Hh)), dtype=torch.uint8, device=dev)
+        ws2 = torch.empty(int(Lb.lib().mqs_lk_workspace_bytes(Ww, Hh, 3)), dtype=torch.uint8, device=dev)
+        oxy = torch.zeros((300, 2), dtype=torch.float32, device=dev)
+        on = torch.zeros(1, dtype=torch.int32, device=dev)
+        sp = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        def gftt():
+            Lb.check(Lb.lib().mqs_good_features_to_track_dev(dI.data_ptr(), Ww, Hh, 300, ctypes.c_double(0.01), ctypes.c_double(7.0),
+                                                             None, oxy.data_ptr(), 300, on.data_ptr(), ws1.data_ptr(), ws1.numel(), sp))
+        gftt()
+        torch.cuda.synchronize()
+        nc = int(on.item())
+        nq = torch.empty((max(nc, 1), 2), dtype=torch.float32, device=dev)
+        stt = torch.empty(max(nc, 1), dtype=torch.uint8, device=dev)
+        er = torch.empty(max(nc, 1), dtype=torch.float32, device=dev)
+        def lk():
+            Lb.check(Lb.lib().mqs_calc_optical_flow_pyr_lk_dev(dI.data_ptr(), dJ.data_ptr(), Ww, Hh, oxy.data_ptr(), nc, 21, 21, 3, 30,
+                                                               ctypes.c_double(0.01), ctypes.c_double(1e-4), nq.data_ptr(),
+                                                               stt.data_ptr(), er.data_ptr(), ws2.data_ptr(), ws2.numel(), sp))
+        def timed_us(fn, reps=30):
+            fn(); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record(); e1.synchronize()
+            return e0.elapsed_time(e1) / reps * 1e3
+        us_g, us_l = timed_us(gftt), (timed_us(lk) if nc else 0.0)
+        flow = (nq[:nc] - oxy[:nc])[stt[:nc] == 1].cpu().numpy() if nc else np.zeros((0, 2))
+        frontend_out = {"workload": "640 x 480 rendered frame pair: goodFeaturesToTrack (300 corners, quality 0.01, min distance 7) + "
+                                    "pyramidal LK (21 x 21, 4 levels, <= 30 iterations) of those corners, device-resident",
+                        "corners": nc, "gftt_us": round(us_g, 1), "lk_us": round(us_l, 1),
+                        "tracked": int((stt[:nc] == 1).sum().item()) if nc else 0,
+                        "median_flow_error_px": float(np.abs(np.median(flow, axis=0) - [2.3, -1.1]).max()) if len(flow) else None}
+
     # ---- CPU baseline: the oracle's C port of the reference kernel, rank 0, N = 1 only ----
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -270,7 +325,7 @@ def main():
                                    "iterative-LS (tol 3e-5, <=10 iterations)" % (N, C),
                        "landmarks_per_gpu": N, "cameras": C, "sharding": "landmarks, %d-way" % world},
             "roofline": roofline, "rooflines": rooflines, "kernels": kernels, "ba": ba_out, "match": match_out,
-            "replay": replay_out, "cpu_baseline": cpu,
+            "replay": replay_out, "frontend": frontend_out, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
     if dist is not None:
