@@ -328,6 +328,15 @@ int mqs_calc_optical_flow_pyr_lk_dev(const uint8_t *prev_img, const uint8_t *nex
                                      double min_eig_threshold, float *next_pts, uint8_t *status, float *err, void *workspace,
                                      int64_t workspace_bytes, void *stream);
 int64_t mqs_lk_workspace_bytes(int W, int H, int max_level);
+/*   mqs_fast_detect: replaces cv2.FastFeatureDetector().detect(img) (slam.py:34, 62; FAST-9/16, default threshold 10,
+ *       non-maximum suppression on the OpenCV 2.4 corner score).  Corners in row-major scan order: out_xy [capacity][2],
+ *       out_score [capacity] (may be NULL); out_n = number FOUND (may exceed out_capacity: only the first
+ *       out_capacity are written).  Integer arithmetic: exact. */
+int mqs_fast_detect(mqs_ctx *ctx, const uint8_t *img, int W, int H, int threshold, int nonmax, float *out_xy,
+                    int32_t *out_score, int out_capacity, int32_t *out_n);
+int mqs_fast_detect_dev(const uint8_t *img, int W, int H, int threshold, int nonmax, float *out_xy, int32_t *out_score,
+                        int out_capacity, int32_t *out_n, void *workspace, int64_t workspace_bytes, void *stream);
+int64_t mqs_fast_workspace_bytes(int W, int H);
 
 /* ---------------------------------------------------------------------------------------
  * Timing helper used by bench.py: average duration (ms) of `reps` back-to-back launches of

@@ -109,6 +109,11 @@ SIGNATURES = {
                                                         ctypes.c_double, ctypes.c_double, c_vp, c_vp, c_vp, c_vp, c_i64,
                                                         c_vp]),
     "mqs_lk_workspace_bytes": (c_i64, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "mqs_fast_detect": (ctypes.c_int, [c_vp, c_u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_f32p, c_i32p,
+                                       ctypes.c_int, c_i32p]),
+    "mqs_fast_detect_dev": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp, c_vp,
+                                           ctypes.c_int, c_vp, c_vp, c_i64, c_vp]),
+    "mqs_fast_workspace_bytes": (c_i64, [ctypes.c_int, ctypes.c_int]),
     "mqs_time_triangulate_dev": (ctypes.c_int, [ctypes.c_int, c_vp, c_vp, ctypes.c_int, c_i64, ctypes.c_double,
                                                 ctypes.c_int, c_vp, c_vp, c_vp, ctypes.c_int, c_vp,
                                                 ctypes.POINTER(ctypes.c_float)]),

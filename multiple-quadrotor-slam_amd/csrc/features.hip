@@ -364,6 +364,134 @@ __global__ __launch_bounds__(64) void lk_kernel(LkLevels L, const float *__restr
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// FAST-9/16 (FastFeatureDetector, slam.py:34, 62): integer, exact against the oracle
+// ---------------------------------------------------------------------------------------------------
+__constant__ int kFastDx[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
+__constant__ int kFastDy[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
+
+// score[y][x] = 0 (no corner / border) or max over the 16 arcs of 9 contiguous ring pixels of the arc's smallest
+// sign-consistent |centre - ring| difference, minus 1 (OpenCV 2.4 cornerScore<16>), when that exceeds the threshold
+__global__ __launch_bounds__(kBlock) void fast_score_kernel(const uint8_t *__restrict__ img, int W, int H, int threshold,
+                                                           int *__restrict__ score)
+{
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (x >= W || y >= H) return;
+    int out = 0;
+    if (x >= 3 && y >= 3 && x < W - 3 && y < H - 3) {
+        const int c = img[y * W + x];
+        int d[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) d[k] = c - (int)img[(y + kFastDy[k]) * W + x + kFastDx[k]];
+        int best = -1000000;
+#pragma unroll
+        for (int s0 = 0; s0 < 16; ++s0) {
+            int lo = 1000000, hi = 1000000;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const int v = d[(s0 + k) & 15];
+                lo = min(lo, v);
+                hi = min(hi, -v);
+            }
+            best = max(best, max(lo, hi));
+        }
+        if (best > threshold) out = best - 1;
+    }
+    score[y * W + x] = out;
+}
+
+__device__ __forceinline__ bool fast_keep(const int *__restrict__ score, int W, int H, int x, int y, int nonmax)
+{
+    const int s = score[y * W + x];
+    if (s <= 0) return false;
+    if (!nonmax) return true;
+    for (int oy = -1; oy <= 1; ++oy)
+        for (int ox = -1; ox <= 1; ++ox) {
+            if (!oy && !ox) continue;
+            const int yy = y + oy, xx = x + ox;
+            const int v = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? score[yy * W + xx] : 0;
+            if (!(s > v)) return false;
+        }
+    return true;
+}
+
+// one workgroup per image row: number of kept corners in the row
+__global__ __launch_bounds__(kBlock) void fast_row_count_kernel(const int *__restrict__ score, int W, int H, int nonmax,
+                                                               int *__restrict__ row_count)
+{
+    __shared__ int s[kBlock];
+    const int y = blockIdx.x;
+    int c = 0;
+    for (int x = threadIdx.x; x < W; x += kBlock) c += fast_keep(score, W, H, x, y, nonmax) ? 1 : 0;
+    s[threadIdx.x] = c;
+    __syncthreads();
+    for (int h = kBlock / 2; h >= 1; h >>= 1) {
+        if (threadIdx.x < h) s[threadIdx.x] += s[threadIdx.x + h];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) row_count[y] = s[0];
+}
+
+// exclusive scan of the row counts (one workgroup); total -> out_n
+__global__ __launch_bounds__(kBlock) void fast_row_scan_kernel(const int *__restrict__ row_count, int H, int *__restrict__ row_offset,
+                                                              int *__restrict__ out_n)
+{
+    __shared__ int s[kBlock];
+    __shared__ int base;
+    if (threadIdx.x == 0) base = 0;
+    __syncthreads();
+    for (int y0 = 0; y0 < H; y0 += kBlock) {
+        const int y = y0 + threadIdx.x;
+        const int v = y < H ? row_count[y] : 0;
+        s[threadIdx.x] = v;
+        __syncthreads();
+        for (int h = 1; h < kBlock; h <<= 1) {                 // inclusive Hillis-Steele scan
+            const int t = threadIdx.x >= h ? s[threadIdx.x - h] : 0;
+            __syncthreads();
+            s[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (y < H) row_offset[y] = base + s[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 0) base += s[kBlock - 1];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out_n[0] = base;
+}
+
+// one workgroup per row: corners written in x order at the row's offset (row-major scan order overall)
+__global__ __launch_bounds__(kBlock) void fast_emit_kernel(const int *__restrict__ score, int W, int H, int nonmax,
+                                                          const int *__restrict__ row_offset, int capacity,
+                                                          float *__restrict__ out_xy, int *__restrict__ out_score)
+{
+    __shared__ int s[kBlock];
+    __shared__ int base;
+    const int y = blockIdx.x;
+    if (threadIdx.x == 0) base = row_offset[y];
+    __syncthreads();
+    for (int x0 = 0; x0 < W; x0 += kBlock) {
+        const int x = x0 + threadIdx.x;
+        const int f = (x < W && fast_keep(score, W, H, x, y, nonmax)) ? 1 : 0;
+        s[threadIdx.x] = f;
+        __syncthreads();
+        for (int h = 1; h < kBlock; h <<= 1) {
+            const int t = threadIdx.x >= h ? s[threadIdx.x - h] : 0;
+            __syncthreads();
+            s[threadIdx.x] += t;
+            __syncthreads();
+        }
+        const int pos = base + s[threadIdx.x] - f;
+        if (f && pos < capacity) {
+            out_xy[2 * pos] = (float)x;
+            out_xy[2 * pos + 1] = (float)y;
+            if (out_score) out_score[pos] = score[y * W + x];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) base += s[kBlock - 1];
+        __syncthreads();
+    }
+}
+
 dim3 grid2d(int W, int H) { return dim3((unsigned)((W + 31) / 32), (unsigned)((H + 7) / 8)); }
 
 size_t align_up(size_t v) { return (v + 255) & ~size_t(255); }
@@ -482,7 +610,61 @@ int mqs_calc_optical_flow_pyr_lk_dev(const uint8_t *prev_img, const uint8_t *nex
     return MQS_OK;
 }
 
+int64_t mqs_fast_workspace_bytes(int W, int H)
+{
+    if (W < 1 || H < 1) return 0;
+    return (int64_t)(align_up((size_t)W * H * 4) + 2 * align_up((size_t)H * 4));
+}
+
+int mqs_fast_detect_dev(const uint8_t *img, int W, int H, int threshold, int nonmax, float *out_xy, int32_t *out_score,
+                        int out_capacity, int32_t *out_n, void *workspace, int64_t workspace_bytes, void *stream_)
+{
+    MQS_ARG_CHECK(img && out_xy && out_n && workspace, "pointers must not be null");
+    MQS_ARG_CHECK(W >= 1 && H >= 1 && W < 65536 && H < 65536 && threshold >= 0 && out_capacity >= 1, "parameter ranges");
+    MQS_ARG_CHECK(workspace_bytes >= mqs_fast_workspace_bytes(W, H), "workspace too small (mqs_fast_workspace_bytes)");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    char *w = static_cast<char *>(workspace);
+    int *score = reinterpret_cast<int *>(w); w += align_up((size_t)W * H * 4);
+    int *row_count = reinterpret_cast<int *>(w); w += align_up((size_t)H * 4);
+    int *row_offset = reinterpret_cast<int *>(w);
+    hipLaunchKernelGGL(fast_score_kernel, grid2d(W, H), dim3(kBlock), 0, stream, img, W, H, threshold, score);
+    hipLaunchKernelGGL(fast_row_count_kernel, dim3(H), dim3(kBlock), 0, stream, score, W, H, nonmax, row_count);
+    hipLaunchKernelGGL(fast_row_scan_kernel, dim3(1), dim3(kBlock), 0, stream, row_count, H, row_offset, out_n);
+    hipLaunchKernelGGL(fast_emit_kernel, dim3(H), dim3(kBlock), 0, stream, score, W, H, nonmax, row_offset, out_capacity, out_xy,
+                       out_score);
+    MQS_HIP_CHECK(hipGetLastError());
+    return MQS_OK;
+}
+
 // ---- host-pointer wrappers ----
+int mqs_fast_detect(mqs_ctx *ctx, const uint8_t *img, int W, int H, int threshold, int nonmax, float *out_xy,
+                    int32_t *out_score, int out_capacity, int32_t *out_n)
+{
+    MQS_ARG_CHECK(ctx && img && out_xy && out_n, "pointers must not be null");
+    MQS_ARG_CHECK(W >= 1 && H >= 1 && out_capacity >= 1, "W, H, out_capacity >= 1");
+    MQS_HIP_CHECK(hipSetDevice(ctx->device));
+    const size_t npx = (size_t)W * H, wsb = (size_t)mqs_fast_workspace_bytes(W, H);
+    const size_t o_img = 0, o_xy = align_up(npx), o_sc = o_xy + align_up((size_t)out_capacity * 8),
+                 o_n = o_sc + align_up((size_t)out_capacity * 4), o_ws = o_n + 256, total = o_ws + wsb;
+    int rc = mqs_ctx_reserve(ctx, total);
+    if (rc != MQS_OK) return rc;
+    char *d = static_cast<char *>(ctx->dbuf);
+    hipStream_t s = ctx->stream;
+    MQS_HIP_CHECK(hipMemcpyAsync(d + o_img, img, npx, hipMemcpyHostToDevice, s));
+    rc = mqs_fast_detect_dev((uint8_t *)(d + o_img), W, H, threshold, nonmax, (float *)(d + o_xy), (int32_t *)(d + o_sc),
+                             out_capacity, (int32_t *)(d + o_n), d + o_ws, (int64_t)wsb, s);
+    if (rc != MQS_OK) return rc;
+    MQS_HIP_CHECK(hipMemcpyAsync(out_n, d + o_n, 4, hipMemcpyDeviceToHost, s));
+    MQS_HIP_CHECK(hipStreamSynchronize(s));
+    int n = out_n[0] < out_capacity ? out_n[0] : out_capacity;
+    if (n > 0) {
+        MQS_HIP_CHECK(hipMemcpyAsync(out_xy, d + o_xy, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+        if (out_score) MQS_HIP_CHECK(hipMemcpyAsync(out_score, d + o_sc, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+        MQS_HIP_CHECK(hipStreamSynchronize(s));
+    }
+    return MQS_OK;
+}
+
 int mqs_good_features_to_track(mqs_ctx *ctx, const uint8_t *img, int W, int H, int max_corners, double quality_level,
                                double min_distance, const uint8_t *mask, float *out_xy, int out_capacity, int32_t *out_n)
 {

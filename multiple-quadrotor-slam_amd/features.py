@@ -7,7 +7,10 @@ Image front-end of the per-frame loop on the gfx950 kernels of csrc/features.hip
   calcOpticalFlowPyrLK(prevImg, nextImg, prevPts, ...)   -> (nextPts, status, err)
       = cv2.calcOpticalFlowPyrLK as called at slam2.py:381 (defaults 21 x 21, maxLevel 3, 30 iterations / eps 0.01)
 
-Images: 2-D uint8 arrays.  No CPU fallback: the library must be loadable.  Parity with OpenCV itself is unpinned
+  FastFeatureDetector(threshold=10, nonmaxSuppression=True).detect(img)   -> list of KeyPoint(pt, size, response)
+      = cv2.FastFeatureDetector() as used at Work/SLAM/application/own/slam.py:34, 62
+
+Images: 2-D uint8 arrays (FastFeatureDetector also takes H x W x 3 BGR, like the reference passes it).  No CPU fallback: the library must be loadable.  Parity with OpenCV itself is unpinned
 (oracle/features_np.py restates its published method; the reference holds no images).
 """
 import ctypes
@@ -75,3 +78,51 @@ def calcOpticalFlowPyrLK(prevImg, nextImg, prevPts, nextPts=None, winSize=(21, 2
             ctypes.c_double(minEigThreshold), out.ctypes.data_as(c_f32p), status.ctypes.data_as(c_u8p),
             err.ctypes.data_as(c_f32p)))
     return out.reshape(shape), status.reshape(-1, 1), err.reshape(-1, 1)
+
+
+class KeyPoint(tuple):
+    """(pt = (x, y), size, response): the fields of cv2.KeyPoint the reference reads (`kp.pt`, slam.py:63)."""
+    __slots__ = ()
+    pt = property(lambda self: self[0])
+    size = property(lambda self: self[1])
+    response = property(lambda self: self[2])
+
+
+def bgr_to_gray(img):
+    """cv2.cvtColor(img, COLOR_BGR2GRAY) for 8-bit images (fixed point, like OpenCV)."""
+    a = np.asarray(img)
+    b, g, r = (a[..., k].astype(np.int32) for k in range(3))
+    return ((b * 1868 + g * 9617 + r * 4899 + 8192) >> 14).astype(np.uint8)
+
+
+class FastFeatureDetector:
+    def __init__(self, threshold=10, nonmaxSuppression=True):
+        self.threshold = int(threshold)
+        self.nonmax = bool(nonmaxSuppression)
+
+    def detect_arrays(self, img):
+        """Returns (points (n, 2) float32 in row-major scan order, scores (n,) int32)."""
+        a = np.asarray(img)
+        if a.ndim == 3 and a.shape[2] == 3 and a.dtype == np.uint8:
+            a = bgr_to_gray(a)
+        im = np.ascontiguousarray(a)
+        if im.ndim != 2 or im.dtype != np.uint8:
+            raise ValueError("img must be a uint8 grey or BGR image")
+        H, W = im.shape
+        cap = 4096
+        while True:
+            xy = np.zeros((cap, 2), dtype=np.float32)
+            sc = np.zeros(cap, dtype=np.int32)
+            n = np.zeros(1, dtype=np.int32)
+            _lib.check(_lib.lib().mqs_fast_detect(_lib.default_context().handle, im.ctypes.data_as(c_u8p), W, H, self.threshold,
+                                                  int(self.nonmax), xy.ctypes.data_as(c_f32p), sc.ctypes.data_as(c_i32p), cap,
+                                                  n.ctypes.data_as(c_i32p)))
+            if int(n[0]) <= cap:
+                return xy[:int(n[0])].copy(), sc[:int(n[0])].copy()
+            cap = int(n[0])
+
+    def detect(self, img, mask=None):
+        if mask is not None:
+            raise NotImplementedError("FastFeatureDetector.detect with a mask")
+        xy, sc = self.detect_arrays(img)
+        return [KeyPoint(((float(x), float(y)), 7.0, float(s))) for (x, y), s in zip(xy, sc)]

@@ -231,3 +231,53 @@ def calc_optical_flow_pyr_lk(prev_img, next_img, prev_pts, win_size=(21, 21), ma
                     Jw = _bilinear_window(J, inx, iny, a, b, ww, wh) * F(32.0)
                     err[k] = F(np.sum(np.abs((Jw - Iw).astype(np.float64))) / (32.0 * ww * wh))
     return next_pts, status, err
+
+
+# ---------------------------------------------------------------------------------------------------
+# FAST-9/16 (FastFeatureDetector(threshold=10, nonmaxSuppression=True), slam.py:34, 62)
+# ---------------------------------------------------------------------------------------------------
+FAST_CIRCLE = [(0, 3), (1, 3), (2, 2), (3, 1), (3, 0), (3, -1), (2, -2), (1, -3), (0, -3), (-1, -3), (-2, -2), (-3, -1),
+               (-3, 0), (-3, 1), (-2, 2), (-1, 3)]          # (dx, dy), OpenCV's makeOffsets order for patternSize 16
+
+
+def bgr_to_gray(img):
+    """cv2.cvtColor(BGR2GRAY) for 8-bit images: (B*1868 + G*9617 + R*4899 + 8192) >> 14."""
+    b, g, r = (img[..., k].astype(np.int32) for k in range(3))
+    return ((b * 1868 + g * 9617 + r * 4899 + 8192) >> 14).astype(np.uint8)
+
+
+def fast_score_image(gray, threshold):
+    """Per pixel: 0 when not a FAST-9 corner at `threshold` (or within 3 pixels of the border), else the corner
+    score of OpenCV 2.4's cornerScore<16>: the largest t for which the pixel is still a corner, i.e.
+    max over the 16 arcs of 9 contiguous circle pixels of min |difference| over the arc (sign-consistent), minus 1."""
+    H, W = gray.shape
+    g = gray.astype(np.int32)
+    score = np.zeros((H, W), dtype=np.int32)
+    if H < 7 or W < 7:
+        return score
+    c = g[3:H - 3, 3:W - 3]
+    d = np.stack([c - g[3 + dy:H - 3 + dy, 3 + dx:W - 3 + dx] for (dx, dy) in FAST_CIRCLE])    # centre - ring
+    best_dark = np.full(c.shape, -10 ** 9)                   # ring darker than centre: d > 0
+    best_bright = np.full(c.shape, -10 ** 9)                 # ring brighter: -d > 0
+    for s in range(16):
+        arc = np.stack([d[(s + k) % 16] for k in range(9)])
+        best_dark = np.maximum(best_dark, arc.min(axis=0))
+        best_bright = np.maximum(best_bright, (-arc).min(axis=0))
+    m = np.maximum(best_dark, best_bright)
+    score[3:H - 3, 3:W - 3] = np.where(m > threshold, m - 1, 0)
+    return score
+
+
+def fast_detect(gray, threshold=10, nonmax=True):
+    """Returns (n, 2) float32 (x, y) in row-major scan order and their scores (int32)."""
+    s = fast_score_image(gray, threshold)
+    H, W = s.shape
+    keep = s > 0
+    if nonmax:
+        p = np.pad(s, 1)
+        for oy in (-1, 0, 1):
+            for ox in (-1, 0, 1):
+                if oy or ox:
+                    keep &= s > p[1 + oy:1 + oy + H, 1 + ox:1 + ox + W]
+    ys, xs = np.nonzero(keep)
+    return np.stack([xs, ys], axis=1).astype(F), s[ys, xs]

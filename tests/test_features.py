@@ -171,3 +171,73 @@ def test_gpu_detect_then_track_loop(gpu):
     if len(extra):
         d = np.linalg.norm(extra[:, None] - cur[alive][None], axis=2)
         assert d.min() > 7.0
+
+
+# ---------------------------------------------------------------------------------------------------
+# FAST-9/16 (slam.py:34, 62)
+# ---------------------------------------------------------------------------------------------------
+def rectangles(H, W, seed=0, n=60):
+    """Random axis-aligned bright / dark rectangles on grey: plenty of L-corners (what FAST fires on)."""
+    rng = np.random.default_rng(seed)
+    img = np.full((H, W), 120, np.int32)
+    for _ in range(n):
+        x0, y0 = rng.integers(0, W - 12), rng.integers(0, H - 12)
+        w, h = rng.integers(8, 40), rng.integers(8, 40)
+        img[y0:y0 + h, x0:x0 + w] = rng.integers(0, 255)
+    img += rng.integers(-3, 4, img.shape)
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def test_oracle_fast_fires_on_rectangle_corners_not_edges():
+    img = np.full((60, 80), 50, np.int32)
+    img[20:40, 30:60] = 200
+    img += np.random.default_rng(0).integers(-4, 5, img.shape)       # break the exact score ties of a synthetic image
+    img = img.astype(np.uint8)
+    corners = np.array([[30, 20], [59, 20], [30, 39], [59, 39]])
+    raw, _ = Fn.fast_detect(img, 10, nonmax=False)
+    assert len(raw) >= 4 and all(np.abs(corners - p).max(axis=1).min() <= 2 for p in raw)     # only near the 4 corners
+    pts, sc = Fn.fast_detect(img, 10)
+    assert 4 <= len(pts) <= len(raw)
+    assert {int(np.abs(corners - p).max(axis=1).argmin()) for p in pts} == {0, 1, 2, 3}       # each corner found
+    assert (sc >= 10).all()
+    assert len(Fn.fast_detect(np.tile(np.arange(80, dtype=np.uint8) * 3, (60, 1)), 10)[0]) == 0     # a ramp has no corners
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,thr,nonmax", [((120, 160), 10, True), ((480, 640), 10, True), ((97, 131), 25, True),
+                                               ((240, 320), 5, False), ((7, 7), 10, True), ((5, 40), 10, True)])
+def test_gpu_fast_equals_oracle(shape, thr, nonmax, gpu):
+    img = rectangles(shape[0], shape[1], seed=shape[1]) if min(shape) > 20 else np.full(shape, 9, np.uint8)
+    ref_xy, ref_s = Fn.fast_detect(img, thr, nonmax)
+    det = gpu.features.FastFeatureDetector(thr, nonmax)
+    xy, sc = det.detect_arrays(img)
+    np.testing.assert_array_equal(xy, ref_xy)               # same corners, same (row-major) order
+    np.testing.assert_array_equal(sc, ref_s)
+    kps = det.detect(img)
+    assert len(kps) == len(ref_xy)
+    if len(kps):
+        assert kps[0].pt == (float(ref_xy[0, 0]), float(ref_xy[0, 1])) and kps[0].size == 7.0
+    if min(shape) > 20:
+        assert len(ref_xy) > 20
+
+
+@pytest.mark.gpu
+def test_gpu_fast_bgr_and_reference_pipeline(gpu):
+    """slam.py:62-104: FAST corners of the right image, LK from the left image, 2-NN radius match OF point -> FAST corner."""
+    left = rectangles(240, 320, seed=4)
+    right = np.roll(left, (2, 3), axis=(0, 1))              # integer shift: right(x + 3, y + 2) = left(x, y)
+    bgr = np.stack([right, right, right], axis=2)
+    det = gpu.features.FastFeatureDetector()
+    kp_bgr = det.detect(bgr)
+    xy_r, _ = det.detect_arrays(right)
+    assert np.array_equal(np.array([k.pt for k in kp_bgr], np.float32).reshape(-1, 2), xy_r)     # grey of equal channels = itself
+    xy_l, _ = det.detect_arrays(left)
+    inner = xy_l[(xy_l[:, 0] > 20) & (xy_l[:, 0] < 290) & (xy_l[:, 1] > 20) & (xy_l[:, 1] < 210)]
+    of, st, err = gpu.features.calcOpticalFlowPyrLK(left, right, inner)
+    good = (st.ravel() == 1) & (err.ravel() < 7.0)
+    assert good.mean() > 0.6
+    m = gpu.matching.BFMatcher().radiusMatch(of[good], xy_r, 2.0)        # slam.py:101-104
+    hit = [ms[0] for ms in m if ms]
+    assert len(hit) > 0.7 * good.sum()
+    d = np.array([xy_r[h.trainIdx] - (inner[good][h.queryIdx] + [3, 2]) for h in hit])
+    assert np.median(np.abs(d)) < 0.5                       # the matched FAST corner is the shifted left corner
