@@ -271,6 +271,11 @@ def main():
                         "corners": nc, "gftt_us": round(us_g, 1), "lk_us": round(us_l, 1),
                         "tracked": int((stt[:nc] == 1).sum().item()) if nc else 0,
                         "median_flow_error_px": float(np.abs(np.median(flow, axis=0) - [2.3, -1.1]).max()) if len(flow) else None}
+        # the whole loop (detect -> track -> pose -> triangulate) on the rendered plane sequence, host-pointer API
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import run_slam_loop
+        run_slam_loop.run(10)
+        frontend_out["end_to_end_loop"] = run_slam_loop.run(40)
 
     # ---- CPU baseline: the oracle's C port of the reference kernel, rank 0, N = 1 only ----
     cpu = None

@@ -18,5 +18,6 @@ from . import sparse_ba                  # noqa: F401
 from . import pnp                        # noqa: F401
 from . import features                   # noqa: F401
 from . import slam_replay                # noqa: F401
+from . import slam_loop                  # noqa: F401
 
 loaded = _lib.loaded

@@ -73,9 +73,50 @@ __device__ bool wave_dlt(const Problem &pr, const double *intr, int lane, double
         const double dx = pr.objp[3 * i] - c[0], dy = pr.objp[3 * i + 1] - c[1], dz = pr.objp[3 * i + 2] - c[2];
         dist += sqrt(fma(dx, dx, fma(dy, dy, dz * dz)));
     }
+    double cov[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int k = pr.begin + lane; k < pr.end; k += kWave) {
+        const int i = pr.point(k);
+        const double dx = pr.objp[3 * i] - c[0], dy = pr.objp[3 * i + 1] - c[1], dz = pr.objp[3 * i + 2] - c[2];
+        cov[0] += dx * dx; cov[1] += dx * dy; cov[2] += dx * dz; cov[3] += dy * dy; cov[4] += dy * dz; cov[5] += dz * dz;
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) cov[k] = wave_sum(cov[k]);
     double sigma = wave_sum(dist) * inv_n;
     if (!(sigma > 0.0)) sigma = 1.0;
     const double is = 1.0 / sigma;
+    double ew[3], E[9];
+    sym3_eigen(cov, ew, E);
+    if (ew[2] < 1e-3 * ew[1]) {
+        // planar (OpenCV: W[2] / W[1] < 1e-3): start from the plane-to-image homography (needs >= 4 points)
+        double hacc[kHomAcc];
+#pragma unroll
+        for (int k = 0; k < kHomAcc; ++k) hacc[k] = 0.0;
+        for (int k = pr.begin + lane; k < pr.end; k += kWave) {
+            const int i = pr.point(k);
+            const double dx = pr.objp[3 * i] - c[0], dy = pr.objp[3 * i + 1] - c[1], dz = pr.objp[3 * i + 2] - c[2];
+            double x, y;
+            mqs::cam::undistort_pixel(intr, pr.imgp[2 * i], pr.imgp[2 * i + 1], x, y);
+            hom_accumulate((E[0] * dx + E[1] * dy + E[2] * dz) * is, (E[3] * dx + E[4] * dy + E[5] * dz) * is, x, y, hacc);
+        }
+#pragma unroll
+        for (int k = 0; k < kHomAcc; ++k) hacc[k] = wave_sum(hacc[k]);
+        double *sb = sA + 64;
+        if (lane == 0) {
+            hom_assemble(hacc, sA, sb);
+            const bool ok = chol_solve_small(sA, sb, 8);
+            sA[0] = ok ? 1.0 : 0.0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        double hv[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) hv[k] = sb[k];
+        const bool solved = sA[0] != 0.0;
+        __builtin_amdgcn_wave_barrier();
+        const bool posed = pose_from_homography(hv, E, c, sigma, P);
+        return solved && posed;
+    }
     double acc[kDltAcc];
 #pragma unroll
     for (int k = 0; k < kDltAcc; ++k) acc[k] = 0.0;

@@ -321,5 +321,142 @@ MQS_HD bool pose_from_dlt(const double *p, const double *centroid, double sigma,
     return ok;
 }
 
+// ---------------------------------------------------------------------------------------
+// Planar configurations (OpenCV: third singular value of the centred point covariance below 1e-3 of the
+// second): the 3-D DLT is rank deficient there, the start comes from the plane-to-image homography instead.
+// Plane coordinates (a, b) = (e1, e2) . (X - c) / sigma with e1, e2 the two leading principal axes; homography
+// unknowns h = [h11 h12 h13 h21 h22 h23 h31 h32] (h33 = 1), two equations per point:
+//   h1.(a,b,1) - x (h31 a + h32 b) = x,   h2.(a,b,1) - y (h31 a + h32 b) = y.
+// ---------------------------------------------------------------------------------------
+
+// Jacobi eigen-decomposition of the symmetric 3x3 S = (xx, xy, xz, yy, yz, zz): eigenvalues w[3] in DESCENDING
+// order, eigenvectors as the ROWS of V (V[3 k + .] belongs to w[k]); V is a proper rotation.
+MQS_HD void sym3_eigen(const double *S, double *w, double *V)
+{
+    double a[3][3] = {{S[0], S[1], S[2]}, {S[1], S[3], S[4]}, {S[2], S[4], S[5]}};
+    double v[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int sweep = 0; sweep < 16; ++sweep) {
+        const double off = fabs(a[0][1]) + fabs(a[0][2]) + fabs(a[1][2]);
+        if (off <= 1e-300 || off <= 1e-17 * (fabs(a[0][0]) + fabs(a[1][1]) + fabs(a[2][2]))) break;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                if (a[p][q] == 0.0) continue;
+                const double theta = (a[q][q] - a[p][p]) / (2.0 * a[p][q]);
+                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+                for (int k = 0; k < 3; ++k) {                       // A <- A G
+                    const double kp = a[k][p], kq = a[k][q];
+                    a[k][p] = c * kp - sn * kq; a[k][q] = sn * kp + c * kq;
+                }
+                for (int k = 0; k < 3; ++k) {                       // A <- G^T A
+                    const double pk = a[p][k], qk = a[q][k];
+                    a[p][k] = c * pk - sn * qk; a[q][k] = sn * pk + c * qk;
+                }
+                for (int k = 0; k < 3; ++k) {                       // columns of v rotate
+                    const double kp = v[k][p], kq = v[k][q];
+                    v[k][p] = c * kp - sn * kq; v[k][q] = sn * kp + c * kq;
+                }
+            }
+    }
+    int o[3] = {0, 1, 2};
+    if (a[o[0]][o[0]] < a[o[1]][o[1]]) { const int t = o[0]; o[0] = o[1]; o[1] = t; }
+    if (a[o[1]][o[1]] < a[o[2]][o[2]]) { const int t = o[1]; o[1] = o[2]; o[2] = t; }
+    if (a[o[0]][o[0]] < a[o[1]][o[1]]) { const int t = o[0]; o[0] = o[1]; o[1] = t; }
+    for (int k = 0; k < 3; ++k) {
+        w[k] = a[o[k]][o[k]];
+        for (int i = 0; i < 3; ++i) V[3 * k + i] = v[i][o[k]];
+    }
+    // right-handed: third axis = first x second
+    V[6] = V[1] * V[5] - V[2] * V[4];
+    V[7] = V[2] * V[3] - V[0] * V[5];
+    V[8] = V[0] * V[4] - V[1] * V[3];
+}
+
+// 29 distinct sums of the 8 x 8 normal equations:
+//   [0..5]   sum q q^T upper triangle, q = (a, b, 1)            (blocks (h1,h1), (h2,h2))
+//   [6..11]  sum x q (a, b)   3x2 row-major,  [12..17] sum y q (a, b)      (-blocks (h1,h3), (h2,h3))
+//   [18..20] sum (x^2 + y^2) (a, b)(a, b)^T upper triangle               (block (h3,h3))
+//   [21..23] sum x q,  [24..26] sum y q,  [27..28] sum (x^2 + y^2) (a, b)   (right-hand side, last negated)
+constexpr int kHomAcc = 29;
+
+MQS_HD void hom_accumulate(double a, double b, double x, double y, double *acc)
+{
+    const double q[3] = {a, b, 1.0};
+    const double r = fma(x, x, y * y);
+    int s = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = i; j < 3; ++j) { acc[s] = fma(q[i], q[j], acc[s]); ++s; }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const double t = q[i] * q[j];
+            acc[6 + 2 * i + j] = fma(x, t, acc[6 + 2 * i + j]);
+            acc[12 + 2 * i + j] = fma(y, t, acc[12 + 2 * i + j]);
+        }
+    acc[18] = fma(r * a, a, acc[18]); acc[19] = fma(r * a, b, acc[19]); acc[20] = fma(r * b, b, acc[20]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        acc[21 + i] = fma(x, q[i], acc[21 + i]);
+        acc[24 + i] = fma(y, q[i], acc[24 + i]);
+    }
+    acc[27] = fma(r, a, acc[27]); acc[28] = fma(r, b, acc[28]);
+}
+
+MQS_HD void hom_assemble(const double *acc, double *A, double *rhs)
+{
+    for (int k = 0; k < 64; ++k) A[k] = 0.0;
+    int s = 0;
+    for (int i = 0; i < 3; ++i)
+        for (int j = i; j < 3; ++j) {
+            A[i * 8 + j] = A[j * 8 + i] = acc[s];
+            A[(3 + i) * 8 + 3 + j] = A[(3 + j) * 8 + 3 + i] = acc[s];
+            ++s;
+        }
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 2; ++j) {
+            A[i * 8 + 6 + j] = A[(6 + j) * 8 + i] = -acc[6 + 2 * i + j];
+            A[(3 + i) * 8 + 6 + j] = A[(6 + j) * 8 + 3 + i] = -acc[12 + 2 * i + j];
+        }
+    A[6 * 8 + 6] = acc[18]; A[6 * 8 + 7] = A[7 * 8 + 6] = acc[19]; A[7 * 8 + 7] = acc[20];
+    for (int i = 0; i < 3; ++i) { rhs[i] = acc[21 + i]; rhs[3 + i] = acc[24 + i]; }
+    rhs[6] = -acc[27]; rhs[7] = -acc[28];
+}
+
+// Pose from the homography of the normalised plane coordinates: H = lambda [sigma r1 | sigma r2 | t];
+// E = principal axes as rows (e1, e2, n).
+MQS_HD bool pose_from_homography(const double *h, const double *E, const double *centroid, double sigma, double *P)
+{
+    const double h1[3] = {h[0], h[3], h[6]}, h2[3] = {h[1], h[4], h[7]}, h3[3] = {h[2], h[5], 1.0};
+    const double n1 = sqrt(h1[0] * h1[0] + h1[1] * h1[1] + h1[2] * h1[2]);
+    const double n2 = sqrt(h2[0] * h2[0] + h2[1] * h2[1] + h2[2] * h2[2]);
+    if (!(n1 > 0.0) || !(n2 > 0.0)) return false;
+    double M[9];                                           // [r1 r2 r3] as columns
+    for (int i = 0; i < 3; ++i) { M[3 * i] = h1[i] / n1; M[3 * i + 1] = h2[i] / n2; }
+    M[2] = M[3] * M[7] - M[6] * M[4];                      // r3 = r1 x r2
+    M[5] = M[6] * M[1] - M[0] * M[7];
+    M[8] = M[0] * M[4] - M[3] * M[1];
+    const double sc = 2.0 * sigma / (n1 + n2);
+    const double tp[3] = {h3[0] * sc, h3[1] * sc, h3[2] * sc};
+    for (int it = 0; it < 12; ++it) {                      // polar decomposition (Newton)
+        const double c00 = M[4] * M[8] - M[5] * M[7], c01 = M[5] * M[6] - M[3] * M[8], c02 = M[3] * M[7] - M[4] * M[6];
+        const double det = M[0] * c00 + M[1] * c01 + M[2] * c02;
+        if (!(det > 1e-12)) return false;
+        const double id = 0.5 / det;
+        const double C[9] = {c00, c01, c02,
+                             M[2] * M[7] - M[1] * M[8], M[0] * M[8] - M[2] * M[6], M[1] * M[6] - M[0] * M[7],
+                             M[1] * M[5] - M[2] * M[4], M[2] * M[3] - M[0] * M[5], M[0] * M[4] - M[1] * M[3]};
+        for (int k = 0; k < 9; ++k) M[k] = C[k] * id + 0.5 * M[k];
+    }
+    // X_cam = M E (X - c) + tp
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) P[4 * i + j] = M[3 * i] * E[j] + M[3 * i + 1] * E[3 + j] + M[3 * i + 2] * E[6 + j];
+        P[4 * i + 3] = tp[i] - (P[4 * i] * centroid[0] + P[4 * i + 1] * centroid[1] + P[4 * i + 2] * centroid[2]);
+    }
+    return true;
+}
+
 }  // namespace pnp
 }  // namespace mqs

@@ -1,0 +1,220 @@
+"""
+The reference's monocular per-frame loop (Work/SLAM/application/own/slam2.py:360-695 `handle_new_frame`, :1021-1253
+`main`) on the gfx950 path end to end -- BASELINE configs[4]: detect -> track -> pose -> triangulate per keyframe.
+
+    frame      calcOpticalFlowPyrLK from the previous frame (:381), drop status == 0 / error >= max_OF_error (:382),
+               reject the frame when too many tracks are lost (:385-387) or < 8 triangulated points remain (:437);
+               solvePnPRansac on the already-triangulated tracks (:453-454), outlier-ratio gate (:461-468), solvePnP on
+               the inliers from the RANSAC pose (:489-490), reprojection-error gate (:493-497)
+    keyframe   (keyframe_test :43-59: homography between the base keyframe's and the current undistorted points is
+               far enough from a pure scaling, singular-value ratio w0 / w2 > 1.04)
+               undistort + iterative-LS triangulation of the not-yet-triangulated tracks against the base keyframe
+               (:551-555), keep status == 1 (:556), refine the pose on old + new points (:576-577), re-triangulate
+               (:582-584), keep status >= 0 (:589); then top the tracks up with goodFeaturesToTrack under the coverage
+               mask of the current points (:657-672) and make this frame the new base keyframe.
+
+Bookkeeping is restated with plain arrays (track id -> landmark id or -1) instead of the reference's index sets; the
+decisions and their thresholds are the reference's (:1070-1098).  Deviations, all because no image set / OpenCV run
+of the reference exists to compare with: the homography of the keyframe test is a normalised DLT over ALL tracked
+points (the reference: cv2.findHomography on a random quarter of them), RANSAC draws come from a seeded numpy
+generator.  Every numeric step runs on the GPU library (features, pnp, camera, triangulation); nothing falls back.
+"""
+import time
+
+import numpy as np
+
+from . import camera
+from . import features
+from . import pnp
+from . import triangulation
+
+# slam2.py:1070-1098
+MAX_OF_ERROR = 12.0
+MAX_LOST_TRACKS_RATIO = 0.5
+KEYPOINT_COVERAGE_RADIUS = int(MAX_OF_ERROR)
+MAX_AMOUNT_KEYPOINTS = 300
+CORNER_QUALITY_LEVEL = 0.01
+HOMOGRAPHY_CONDITION_THRESHOLD = 1.04
+MAX_SOLVEPNP_REPROJ_ERROR = 2.0
+MAX_SOLVEPNP_OUTLIER_RATIO = 0.33
+
+
+def keypoint_mask(shape, points, radius=KEYPOINT_COVERAGE_RADIUS):
+    """slam2.py:29-40: ones with a filled disc of zeros around every point."""
+    H, W = shape
+    mask = np.ones((H, W), dtype=np.uint8)
+    p = np.rint(np.asarray(points, dtype=np.float64).reshape(-1, 2)).astype(np.int64)
+    if len(p) == 0:
+        return mask
+    r = int(radius)
+    yy, xx = np.mgrid[-r:r + 1, -r:r + 1]
+    dy, dx = yy[(xx * xx + yy * yy) <= r * r], xx[(xx * xx + yy * yy) <= r * r]
+    X = (p[:, 0:1] + dx[None, :]).ravel()
+    Y = (p[:, 1:2] + dy[None, :]).ravel()
+    ok = (X >= 0) & (X < W) & (Y >= 0) & (Y < H)
+    mask[Y[ok], X[ok]] = 0
+    return mask
+
+
+def homography_dlt(p1, p2):
+    """Normalised DLT (least squares over all pairs): the estimator behind cv2.findHomography(method=0)."""
+    def norm(p):
+        c = p.mean(axis=0)
+        s = np.sqrt(2.0) / max(np.mean(np.linalg.norm(p - c, axis=1)), 1e-12)
+        T = np.array([[s, 0, -s * c[0]], [0, s, -s * c[1]], [0, 0, 1.0]])
+        return (p - c) * s, T
+    a, Ta = norm(np.asarray(p1, dtype=np.float64))
+    b, Tb = norm(np.asarray(p2, dtype=np.float64))
+    n = len(a)
+    A = np.zeros((2 * n, 9))
+    A[0::2, 0:2], A[0::2, 2] = a, 1.0
+    A[0::2, 6:8], A[0::2, 8] = -b[:, 0:1] * a, -b[:, 0]
+    A[1::2, 3:5], A[1::2, 5] = a, 1.0
+    A[1::2, 6:8], A[1::2, 8] = -b[:, 1:2] * a, -b[:, 1]
+    Hn = np.linalg.eigh(A.T @ A)[1][:, 0].reshape(3, 3)      # null vector of the 2n x 9 system
+    H = np.linalg.inv(Tb) @ Hn @ Ta
+    return H / H[2, 2]
+
+
+def keyframe_test(points1, points2, K, dist):
+    """slam2.py:43-59."""
+    if len(points1) < 4:
+        return False
+    u1 = camera.undistort_points(np.asarray(points1, dtype=np.float64), K, dist)
+    u2 = camera.undistort_points(np.asarray(points2, dtype=np.float64), K, dist)
+    w = np.linalg.svd(homography_dlt(u1, u2), compute_uv=False)
+    return w[0] / w[2] > HOMOGRAPHY_CONDITION_THRESHOLD
+
+
+class MonoSlam:
+    def __init__(self, cameraMatrix, distCoeffs, image_shape, seed=0, verbose=False):
+        self.K = np.asarray(cameraMatrix, dtype=np.float64)
+        self.dist = np.asarray(distCoeffs, dtype=np.float64).reshape(-1)[:4]
+        self.shape = tuple(image_shape)
+        H, W = self.shape
+        target = int(round(W * H / (np.pi * KEYPOINT_COVERAGE_RADIUS ** 2)))         # slam2.py:1081
+        self.target_keypoints = min(MAX_AMOUNT_KEYPOINTS, target)
+        self.rng = np.random.default_rng(seed)
+        self.verbose = verbose
+        self.objp = np.zeros((0, 3), dtype=np.float32)       # the map (float32 like slam2.py:19)
+        self.poses = []                                      # per frame: (rvec, tvec) or None when rejected
+        self.keyframes = []
+        self.timing = []
+
+    def _log(self, *a):
+        if self.verbose:
+            print(*a)
+
+    def _P(self, rvec, tvec):
+        return np.hstack([pnp.Rodrigues(rvec), np.asarray(tvec, dtype=np.float64).reshape(3, 1)])
+
+    def _top_up(self, img, pts):
+        to_add = max(0, self.target_keypoints - len(pts))
+        return features.goodFeaturesToTrack(img, to_add, CORNER_QUALITY_LEVEL, KEYPOINT_COVERAGE_RADIUS, None,
+                                            keypoint_mask(self.shape, pts))
+
+    def start(self, img, init_objp, init_imgp):
+        """slam2.py:1136-1180: pose of the first frame from known 3-D points, then the first batch of free tracks."""
+        self.objp = np.asarray(init_objp, dtype=np.float32).reshape(-1, 3)
+        imgp = np.asarray(init_imgp, dtype=np.float32).reshape(-1, 2)
+        ret, rvec, tvec = pnp.solvePnP(self.objp, imgp, self.K, self.dist)
+        self.poses.append((rvec, tvec))
+        self.keyframes.append(0)
+        self.rvec_keyfr, self.tvec_keyfr = rvec, tvec
+        extra = self._top_up(img, imgp)
+        self.pts = np.concatenate([imgp, extra])             # current image points of the live tracks
+        self.base_pts = self.pts.copy()                      # their image points in the base keyframe
+        self.lm = np.concatenate([np.arange(len(imgp)), -np.ones(len(extra), dtype=np.int64)])   # track -> landmark or -1
+        self.prev_img = img
+        return rvec, tvec
+
+    def handle_new_frame(self, img):
+        """Returns 0 (rejected), 1 (frame) or 2 (keyframe), like the reference's `ret`."""
+        t0 = time.perf_counter()
+        r = self._frame(img)
+        self.timing.append(time.perf_counter() - t0)
+        return r
+
+    def _frame(self, img):
+        K, dist = self.K, self.dist
+        new_pts, st, err = features.calcOpticalFlowPyrLK(self.prev_img, img, self.pts)
+        keep = (st.ravel() == 1) & (err.ravel() < MAX_OF_ERROR)
+        lost = 1.0 - keep.mean() if len(keep) else 1.0
+        if lost > MAX_LOST_TRACKS_RATIO:
+            self._log("REJECTED: lost track of too many points", lost)
+            self.poses.append(None)
+            return 0
+        pts, base, lm = new_pts[keep], self.base_pts[keep], self.lm[keep]
+        tri = lm >= 0
+        if tri.sum() < 8:
+            self._log("REJECTED: fewer than 8 triangulated tracks")
+            self.poses.append(None)
+            return 0
+        objp_t, imgp_t = self.objp[lm[tri]], pts[tri]
+        rvec_, tvec_, inliers = pnp.solvePnPRansac(objp_t, imgp_t, K, dist,
+                                                   minInliersCount=int(np.ceil((1 - MAX_SOLVEPNP_OUTLIER_RATIO) * tri.sum())),
+                                                   reprojectionError=MAX_SOLVEPNP_REPROJ_ERROR, seed=int(self.rng.integers(1 << 30)))
+        if inliers is None:
+            self.poses.append(None)
+            return 0
+        inliers = inliers.ravel()
+        outlier_ratio = (tri.sum() - len(inliers)) / float(tri.sum())
+        if outlier_ratio > MAX_SOLVEPNP_OUTLIER_RATIO or len(inliers) < 8:
+            self._log("REJECTED: PnP outlier ratio", outlier_ratio)
+            self.poses.append(None)
+            return 0
+        objp_i, imgp_i = objp_t[inliers], imgp_t[inliers]
+        ret, rvec, tvec = pnp.solvePnP(objp_i, imgp_i, K, dist, rvec_, tvec_, useExtrinsicGuess=True)
+        reproj, _ = camera.reprojection_error(objp_i.astype(np.float64), imgp_i.astype(np.float64), K, dist, rvec, tvec)
+        if reproj > MAX_SOLVEPNP_REPROJ_ERROR:
+            self._log("REJECTED: reprojection error", reproj)
+            self.poses.append(None)
+            return 0
+        # keep the inlier tracks and the not-yet-triangulated ones
+        tri_idx = np.nonzero(tri)[0]
+        sel = np.zeros(len(pts), dtype=bool)
+        sel[tri_idx[inliers]] = True
+        sel |= ~tri
+        pts, base, lm = pts[sel], base[sel], lm[sel]
+        tri = lm >= 0
+        result = 1
+        if keyframe_test(base, pts, K, dist):
+            result = 2
+            non = np.nonzero(~tri)[0]
+            if len(non):
+                imgp0, imgp1 = base[non].astype(np.float64), pts[non].astype(np.float64)
+                u0, u1 = camera.undistort_points(imgp0, K, dist), camera.undistort_points(imgp1, K, dist)
+                P0 = self._P(self.rvec_keyfr, self.tvec_keyfr)
+                x1, s1 = triangulation.iterative_LS_triangulation(u0, P0, u1, self._P(rvec, tvec))
+                ok = np.nonzero(np.asarray(s1) == 1)[0]
+                if len(ok):
+                    obj_all = np.concatenate([objp_i, np.asarray(x1)[ok].astype(np.float32)])
+                    img_all = np.concatenate([imgp_i, imgp1[ok].astype(np.float32)])
+                    ret, rvec, tvec = pnp.solvePnP(obj_all, img_all, K, dist, rvec, tvec, useExtrinsicGuess=True)
+                    x2, s2 = triangulation.iterative_LS_triangulation(u0[ok], P0, u1[ok], self._P(rvec, tvec))
+                    good = np.nonzero(np.asarray(s2) >= 0)[0]
+                    ids = len(self.objp) + np.arange(len(good))
+                    self.objp = np.concatenate([self.objp, np.asarray(x2)[good].astype(np.float32)])
+                    lm[non[ok[good]]] = ids
+                # tracks that failed to triangulate are dropped (slam2.py:596-612)
+                done = lm >= 0
+                pts, base, lm = pts[done], base[done], lm[done]
+            extra = self._top_up(img, pts)
+            pts = np.concatenate([pts, extra])
+            lm = np.concatenate([lm, -np.ones(len(extra), dtype=np.int64)])
+            base = pts.copy()                                 # rebase on this keyframe (slam2.py:673-674)
+            self.rvec_keyfr, self.tvec_keyfr = rvec, tvec
+            self.keyframes.append(len(self.poses))
+        self.pts, self.base_pts, self.lm = pts, base, lm
+        self.prev_img = img
+        self.poses.append((rvec, tvec))
+        return result
+
+    def trajectory(self):
+        """Camera centres (F, 3), NaN for rejected frames."""
+        out = np.full((len(self.poses), 3), np.nan)
+        for i, p in enumerate(self.poses):
+            if p is not None:
+                R = pnp.Rodrigues(p[0])
+                out[i] = (-R.T @ np.asarray(p[1]).reshape(3)).ravel()
+        return out

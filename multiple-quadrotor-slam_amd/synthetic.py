@@ -87,3 +87,90 @@ def triangulation_problem(N, C, sigma=NOISE_SIGMA, discretized=True, seed=RSEED)
     P = benchmark_cameras(C)
     pts = ball_points(N, seed=seed)
     return make_observations(pts, P, sigma, discretized, seed), P, pts
+
+
+# ---------------------------------------------------------------------------------------------------
+# Rendered image sequence for the end-to-end loop (BASELINE configs[4]; the reference's Blender-rendered set is
+# not in the repository): a textured plane seen by a moving pinhole camera with OpenCV-model distortion.
+# ---------------------------------------------------------------------------------------------------
+def plane_texture(size=2048, blobs=6000, seed=4):
+    """Sum of Gaussian blobs of mixed scale on a size x size grid, float32 in [0, 255]."""
+    rng = np.random.default_rng(seed)
+    tex = np.zeros((size, size), dtype=np.float32)
+    for _ in range(blobs):
+        cx, cy = rng.uniform(0, size, 2)
+        s = rng.choice([2.0, 3.5, 6.0, 10.0])
+        a = rng.uniform(-1, 1)
+        r = int(4 * s)
+        x0, x1, y0, y1 = int(max(0, cx - r)), int(min(size, cx + r + 1)), int(max(0, cy - r)), int(min(size, cy + r + 1))
+        yy, xx = np.mgrid[y0:y1, x0:x1].astype(np.float32)
+        tex[y0:y1, x0:x1] += a * np.exp(-((xx - cx) ** 2 + (yy - cy) ** 2) / (2 * s * s))
+    tex -= tex.min()
+    return tex * (255.0 / tex.max())
+
+
+class PlaneSequence:
+    """World plane z = 0 textured over [-extent, extent]^2; camera poses are world -> camera (R, t)."""
+
+    def __init__(self, image_size=(640, 480), f=480.0, dist=(-0.06, 0.01, 0.0005, -0.0003), extent=10.0, frames=40, seed=4):
+        W, H = image_size
+        self.W, self.H, self.extent = W, H, extent
+        self.K = np.array([[f, 0, W / 2.0], [0, f, H / 2.0], [0, 0, 1.0]])
+        self.dist = np.array(dist, dtype=np.float64)
+        self.tex = plane_texture(seed=seed)
+        # per-pixel undistorted normalised ray directions (fixed-point inverse of the distortion model)
+        v, u = np.mgrid[0:H, 0:W].astype(np.float64)
+        xd, yd = (u - W / 2.0) / f, (v - H / 2.0) / f
+        k1, k2, p1, p2 = self.dist
+        x, y = xd.copy(), yd.copy()
+        for _ in range(20):
+            r2 = x * x + y * y
+            g = 1 + k1 * r2 + k2 * r2 * r2
+            x = (xd - (2 * p1 * x * y + p2 * (r2 + 2 * x * x))) / g
+            y = (yd - (p1 * (r2 + 2 * y * y) + 2 * p2 * x * y)) / g
+        self.rays = np.stack([x, y, np.ones_like(x)], axis=-1)
+        # trajectory: sideways sweep with a slow yaw and a tilt so that the plane is not fronto-parallel
+        self.poses = []
+        for k in range(frames):
+            s = k / max(1, frames - 1)
+            C = np.array([-3.0 + 6.0 * s, 0.8 - 0.6 * s, -9.0 + 0.8 * np.sin(2.5 * s)])
+            yaw, pitch = 0.25 - 0.5 * s, 0.18
+            Ry = np.array([[np.cos(yaw), 0, np.sin(yaw)], [0, 1, 0], [-np.sin(yaw), 0, np.cos(yaw)]])
+            Rx = np.array([[1, 0, 0], [0, np.cos(pitch), -np.sin(pitch)], [0, np.sin(pitch), np.cos(pitch)]])
+            R = Rx @ Ry
+            self.poses.append((R, -R @ C))
+
+    def centres(self):
+        return np.array([-R.T @ t for R, t in self.poses])
+
+    def render(self, k):
+        R, t = self.poses[k]
+        C = -R.T @ t
+        d = self.rays @ R                                      # ray directions in the world frame (R^T applied to each ray)
+        lam = -C[2] / d[..., 2]
+        X = C[0] + lam * d[..., 0]
+        Y = C[1] + lam * d[..., 1]
+        n = self.tex.shape[0]
+        tx = (X + self.extent) * ((n - 1) / (2 * self.extent))
+        ty = (Y + self.extent) * ((n - 1) / (2 * self.extent))
+        inside = (lam > 0) & (tx >= 0) & (tx < n - 1) & (ty >= 0) & (ty < n - 1)
+        tx, ty = np.clip(tx, 0, n - 1.001), np.clip(ty, 0, n - 1.001)
+        ix, iy = tx.astype(np.int64), ty.astype(np.int64)
+        fx, fy = (tx - ix).astype(np.float32), (ty - iy).astype(np.float32)
+        T = self.tex
+        val = (T[iy, ix] * (1 - fx) * (1 - fy) + T[iy, ix + 1] * fx * (1 - fy) + T[iy + 1, ix] * (1 - fx) * fy
+               + T[iy + 1, ix + 1] * fx * fy)
+        return np.where(inside, np.clip(np.rint(val), 0, 255), 0).astype(np.uint8)
+
+    def project(self, k, pts3d):
+        """Exact pixel projections of world points in frame k (pinhole + distortion)."""
+        R, t = self.poses[k]
+        q = np.asarray(pts3d, dtype=np.float64) @ R.T + t
+        x, y = q[:, 0] / q[:, 2], q[:, 1] / q[:, 2]
+        k1, k2, p1, p2 = self.dist
+        r2 = x * x + y * y
+        g = 1 + k1 * r2 + k2 * r2 * r2
+        xd = x * g + 2 * p1 * x * y + p2 * (r2 + 2 * x * x)
+        yd = y * g + p1 * (r2 + 2 * y * y) + 2 * p2 * x * y
+        f = self.K[0, 0]
+        return np.stack([f * xd + self.W / 2.0, f * yd + self.H / 2.0], axis=1)

@@ -78,20 +78,38 @@ def residuals_and_jacobian(params, objp, imgp, intr):
 
 
 def dlt_pose(objp, imgp, intr):
-    """Direct linear transform start (>= 6 points): returns (R, t)."""
+    """Start pose without a guess (>= 6 points; >= 4 when planar): returns (R, t).  Planar point sets (OpenCV:
+    third singular value of the centred covariance < 1e-3 of the second) go through the plane-to-image
+    homography, the others through the direct linear transform."""
     fx, fy, cx, cy, k1, k2, p1, p2, k3 = intr
     if k3 != 0:
         raise NotImplementedError("k3 in the oracle's undistortion")
     x, y = undistort_normalized((imgp[:, 0] - cx) / fx, (imgp[:, 1] - cy) / fy, k1, k2, p1, p2)
     n = len(objp)
+    c = objp.mean(axis=0)
+    U, S, _ = np.linalg.svd((objp - c).T @ (objp - c))
+    if S[2] < 1e-3 * S[1]:
+        e1, e2 = U[:, 0], U[:, 1]
+        nrm = np.cross(e1, e2)
+        a, b = (objp - c) @ e1, (objp - c) @ e2
+        A = np.zeros((2 * n, 9))
+        A[0::2, 0], A[0::2, 1], A[0::2, 2] = a, b, 1
+        A[0::2, 6], A[0::2, 7], A[0::2, 8] = -x * a, -x * b, -x
+        A[1::2, 3], A[1::2, 4], A[1::2, 5] = a, b, 1
+        A[1::2, 6], A[1::2, 7], A[1::2, 8] = -y * a, -y * b, -y
+        Hm = np.linalg.svd(A)[2][-1].reshape(3, 3)
+        if Hm[2, 2] < 0:
+            Hm = -Hm                                           # the plane origin (centroid) lies in front of the camera
+        lam = 0.5 * (np.linalg.norm(Hm[:, 0]) + np.linalg.norm(Hm[:, 1]))
+        r1, r2 = Hm[:, 0] / np.linalg.norm(Hm[:, 0]), Hm[:, 1] / np.linalg.norm(Hm[:, 1])
+        M = np.stack([r1, r2, np.cross(r1, r2)], axis=1)
+        Uu, _, Vt = np.linalg.svd(M)
+        Rpc = Uu @ Vt
+        R = Rpc @ np.stack([e1, e2, nrm])
+        return R, Hm[:, 2] / lam - R @ c
     A = np.zeros((2 * n, 12))
     Xh = np.c_[objp, np.ones(n)]
-    A[0::2, 0:4] = Xh
-    A[0::2, 8:12] = -x[:, None] * Xh
-    A[1::2, 4:8] = Xh
-    A[1::2, 8:12] = -y[:, None] * Xh
     # condition the problem like any DLT: centroid / mean-distance normalisation of the world points
-    c = objp.mean(axis=0)
     s = np.mean(np.linalg.norm(objp - c, axis=1))
     T = np.eye(4)
     T[:3, :3] /= s

@@ -181,6 +181,26 @@ extern "C" int host_pnp_dlt(const double *objp, const double *imgp, int64_t N, c
         sigma += sqrt(dx * dx + dy * dy + dz * dz);
     }
     sigma /= (double)N;
+    double cov[6] = {0, 0, 0, 0, 0, 0};
+    for (int64_t i = 0; i < N; ++i) {
+        const double dx = objp[3 * i] - c[0], dy = objp[3 * i + 1] - c[1], dz = objp[3 * i + 2] - c[2];
+        cov[0] += dx * dx; cov[1] += dx * dy; cov[2] += dx * dz; cov[3] += dy * dy; cov[4] += dy * dz; cov[5] += dz * dz;
+    }
+    double ew[3], E[9];
+    mqs::pnp::sym3_eigen(cov, ew, E);
+    if (ew[2] < 1e-3 * ew[1]) {
+        double hacc[mqs::pnp::kHomAcc] = {0};
+        for (int64_t i = 0; i < N; ++i) {
+            const double dx = objp[3 * i] - c[0], dy = objp[3 * i + 1] - c[1], dz = objp[3 * i + 2] - c[2];
+            double x, y;
+            mqs::cam::undistort_pixel(intr, imgp[2 * i], imgp[2 * i + 1], x, y);
+            mqs::pnp::hom_accumulate((E[0] * dx + E[1] * dy + E[2] * dz) / sigma, (E[3] * dx + E[4] * dy + E[5] * dz) / sigma, x, y, hacc);
+        }
+        double A8[64], b8[8];
+        mqs::pnp::hom_assemble(hacc, A8, b8);
+        const bool ok8 = mqs::pnp::chol_solve_small(A8, b8, 8);
+        return (ok8 && mqs::pnp::pose_from_homography(b8, E, c, sigma, P)) ? 0 : 1;
+    }
     double acc[mqs::pnp::kDltAcc] = {0};
     for (int64_t i = 0; i < N; ++i) {
         double x, y;

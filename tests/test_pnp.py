@@ -93,6 +93,38 @@ def test_device_math_vs_oracle_with_and_without_start(n, dist, host_math):
         np.testing.assert_allclose(P[:, :3] @ P[:, :3].T, np.eye(3), atol=1e-12)
 
 
+def planar_problem(n, seed, noise=0.3):
+    rng = np.random.default_rng(seed)
+    intr = np.array([480.0, 480.0, 320.0, 240.0, -0.06, 0.01, 0.0005, -0.0003, 0.0])
+    rvec = np.array([0.2, -0.3, 0.1]) + rng.normal(0, 0.1, 3)
+    tvec = np.array([0.5, -0.3, 9.0])
+    a, b = rng.uniform(-3, 3, n), rng.uniform(-2, 2, n)
+    e1, e2 = np.array([0.8, 0.1, 0.59]), np.array([-0.2, 0.97, 0.1])
+    e1 /= np.linalg.norm(e1); e2 -= e1 * (e1 @ e2); e2 /= np.linalg.norm(e2)
+    X = np.array([1.0, -2.0, 0.5]) + a[:, None] * e1 + b[:, None] * e2          # a tilted plane, not through the origin
+    uv = pnp_np.project(rvec, tvec, X, intr) + noise * rng.standard_normal((n, 2))
+    return X, uv, intr, rvec, tvec
+
+
+@pytest.mark.parametrize("n", [6, 30])
+def test_device_math_planar_start(n, host_math):
+    """Coplanar points (chessboard / plane initialisation, slam2.py:1136-1157): the 3-D DLT is rank deficient; the start
+    comes from the plane homography, as in OpenCV."""
+    X, uv, intr, rvec, tvec = planar_problem(n, seed=n)
+    ro, to, cost_o, _ = pnp_np.solve_pnp(X, uv, intr)
+    P = np.zeros((3, 4)); info = np.zeros(3)
+    rc = host_math.host_pnp_refine(_p(np.ascontiguousarray(X)), _p(np.ascontiguousarray(uv)), ctypes.c_int64(n), _p(intr), _p(P), 0,
+                                   100, ctypes.c_double(1e-13), _p(info))
+    assert rc == 0
+    np.testing.assert_allclose(P[:, :3], pnp_np.rodrigues(ro), atol=2e-8)
+    np.testing.assert_allclose(P[:, 3], to, atol=2e-7)
+    np.testing.assert_allclose(P[:, :3], pnp_np.rodrigues(rvec), atol=0.05)      # and it is the true pose, not a mirror
+    Pd = np.zeros((3, 4))
+    assert host_math.host_pnp_dlt(_p(np.ascontiguousarray(X)), _p(np.ascontiguousarray(uv)), ctypes.c_int64(n), _p(intr), _p(Pd)) == 0
+    np.testing.assert_allclose(Pd[:, :3] @ Pd[:, :3].T, np.eye(3), atol=1e-10)
+    np.testing.assert_allclose(Pd[:, :3], pnp_np.rodrigues(rvec), atol=0.1)
+
+
 def test_device_dlt_vs_oracle_dlt(host_math):
     X, uv, intr, rvec, tvec = synthetic_problem(40, seed=3, noise=0.0)
     R, t = pnp_np.dlt_pose(X, uv, intr)
@@ -158,6 +190,24 @@ def test_gpu_solve_pnp_vs_oracle(n, dist, gpu):
     P, info = gpu.pnp.solve_pnp_pose(X.astype(np.float32), uv.astype(np.float32), intr)      # slam2.py:19 passes float32
     assert info[2] == n and int(info[3]) & 1
     np.testing.assert_allclose(info[0], pnp_np.solve_pnp(X.astype(np.float32), uv.astype(np.float32), intr)[2], rtol=1e-7)
+
+
+@pytest.mark.gpu
+def test_gpu_planar_points_and_planar_ransac(gpu):
+    X, uv, intr, rvec, tvec = planar_problem(80, seed=5)
+    ro, to, _, _ = pnp_np.solve_pnp(X, uv, intr)
+    P, info = gpu.pnp.solve_pnp_pose(X, uv, intr)
+    assert not int(info[3]) & 2                                                   # the start did not fail
+    np.testing.assert_allclose(P[:, :3], pnp_np.rodrigues(ro), atol=2e-8)
+    np.testing.assert_allclose(P[:, 3], to, atol=2e-7)
+    uv2 = uv.copy()
+    uv2[:20] += 40.0
+    samples = gpu.pnp.draw_samples(80, 64, 6, seed=2)
+    P2, mask, best, _ = gpu.pnp.solve_pnp_ransac_pose(X, uv2, intr, 2.0, samples=samples)
+    ro2, to2, mask_o, best_o = pnp_np.solve_pnp_ransac(X, uv2, intr, samples, 2.0)
+    assert best == best_o and not mask[:20].any() and mask[20:].mean() > 0.9
+    np.testing.assert_array_equal(mask, mask_o)
+    np.testing.assert_allclose(P2[:, 3], to2, atol=2e-7)
 
 
 @pytest.mark.gpu
