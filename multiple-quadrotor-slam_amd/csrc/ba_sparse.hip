@@ -16,6 +16,7 @@
 // The reduced system is then factored by the blocked Cholesky below (own kernels, fp64).
 // Results are NOT bitwise reproducible (atomic summation order), unlike the dense path.
 #include "mqs_common.h"
+#include <rocsolver/rocsolver.h>
 #include "ba_math.h"
 
 namespace {
@@ -397,9 +398,10 @@ __global__ void sparse_retract_kernel(const double *__restrict__ poses, const do
 }
 
 // ---------------------------------------------------------------------------------------------
-// Dense Cholesky solve of the reduced camera system, n = 6P up to a few thousand: right-looking,
-// block size 32, three kernels per block column (diagonal factor, panel triangular solve, trailing
-// symmetric update), then forward / backward substitution.  Lower triangle, in place, row-major.
+// Dense Cholesky solve of the reduced camera system, n = 6P: right-looking, block size 32, three kernels
+// per block column (diagonal factor, panel triangular solve, trailing symmetric update), then forward /
+// backward substitution.  Lower triangle, in place, row-major.  Used below kLibraryCholeskyMinN unknowns
+// (no library start-up, a handful of launches); larger systems go to rocSOLVER's POTRF / POTRS.
 // ---------------------------------------------------------------------------------------------
 constexpr int NB = 32;
 
@@ -521,6 +523,19 @@ __global__ __launch_bounds__(kBlock) void chol_solve_kernel(const double *__rest
     }
 }
 
+#ifndef MQS_SBA_LIBRARY_MIN_N
+#define MQS_SBA_LIBRARY_MIN_N 1536
+#endif
+constexpr int kLibraryCholeskyMinN = MQS_SBA_LIBRARY_MIN_N;
+
+// one rocBLAS handle per host thread, created on first use (the library keeps its own device workspace in it)
+rocblas_handle solver_handle()
+{
+    thread_local rocblas_handle h = nullptr;
+    if (!h && rocblas_create_handle(&h) != rocblas_status_success) h = nullptr;
+    return h;
+}
+
 }  // namespace
 
 extern "C" {
@@ -589,17 +604,31 @@ int mqs_sba_solve_dev(double *S, double *x, int64_t P, double lambda, const doub
     const int n = (int)(6 * P);
     MQS_HIP_CHECK(hipMemsetAsync(bad, 0, sizeof(int), stream));
     if (lambda != 0.0) hipLaunchKernelGGL(sparse_damp_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, S, n, lambda);
-    for (int k0 = 0; k0 < n; k0 += NB) {
-        const int nb = (n - k0) < NB ? (n - k0) : NB;
-        hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(64), 0, stream, S, n, k0, bad);
-        const int rem = n - k0 - nb;
-        if (rem > 0) {
-            hipLaunchKernelGGL(chol_panel_kernel, dim3((rem + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, S, n, k0);
-            const int tiles = (rem + NB - 1) / NB;
-            hipLaunchKernelGGL(chol_update_kernel, dim3(tiles, tiles), dim3(kBlock), 0, stream, S, n, k0);
+    if (n >= kLibraryCholeskyMinN) {
+        // a plain dense factorisation of a few thousand unknowns: the vendor's blocked POTRF / POTRS.  Column-major
+        // "upper" of this symmetric row-major matrix is the same memory as row-major "lower": the factor lands where
+        // the kernels below would put it.
+        rocblas_handle h = solver_handle();
+        MQS_ARG_CHECK(h != nullptr, "rocblas_create_handle failed");
+        if (rocblas_set_stream(h, stream) != rocblas_status_success ||
+            rocsolver_dpotrf(h, rocblas_fill_upper, n, S, n, bad) != rocblas_status_success ||
+            rocsolver_dpotrs(h, rocblas_fill_upper, n, 1, S, n, x, n) != rocblas_status_success) {
+            mqs_set_error("rocsolver potrf / potrs failed (n = %d)", n);
+            return MQS_E_HIP;
         }
+    } else {
+        for (int k0 = 0; k0 < n; k0 += NB) {
+            const int nb = (n - k0) < NB ? (n - k0) : NB;
+            hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(64), 0, stream, S, n, k0, bad);
+            const int rem = n - k0 - nb;
+            if (rem > 0) {
+                hipLaunchKernelGGL(chol_panel_kernel, dim3((rem + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, S, n, k0);
+                const int tiles = (rem + NB - 1) / NB;
+                hipLaunchKernelGGL(chol_update_kernel, dim3(tiles, tiles), dim3(kBlock), 0, stream, S, n, k0);
+            }
+        }
+        hipLaunchKernelGGL(chol_solve_kernel, dim3(1), dim3(kBlock), 0, stream, S, n, x);
     }
-    hipLaunchKernelGGL(chol_solve_kernel, dim3(1), dim3(kBlock), 0, stream, S, n, x);
     if (poses_out)
         hipLaunchKernelGGL(sparse_retract_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, stream, poses, x, (int)P,
                            poses_out);
