@@ -222,6 +222,12 @@ int mqs_sba_linearize_dev(const double *poses, const int32_t *pose_cam, int64_t 
                           double *g, double *info, void *workspace, int64_t workspace_bytes, void *stream);
 int mqs_sba_solve_dev(double *S, double *x, int64_t P, double lambda, const double *poses, double *poses_out,
                       int *bad, void *stream);
+/* The same solve for a reduced camera system known to be banded: S[i][j] == 0 for |i - j| > half_bandwidth (a
+ * sequence in which a landmark is seen by poses at most d apart, and odometry links at most d apart:
+ * half_bandwidth = 6 (d + 1) - 1).  The Cholesky factor has no fill outside the band; when the band is narrower than
+ * a third of the matrix the factorisation and the triangular solves stay inside it. */
+int mqs_sba_solve_banded_dev(double *S, double *x, int64_t P, int64_t half_bandwidth, double lambda, const double *poses,
+                             double *poses_out, int *bad, void *stream);
 int mqs_sba_backsub_dev(const double *poses, const int32_t *pose_cam, int64_t P, const double *calib,
                         const double *sigma, const double *points, int64_t N, const int64_t *obs_ptr,
                         const int32_t *obs_pose, const double *obs_uv, int64_t M, const double *prior_w,

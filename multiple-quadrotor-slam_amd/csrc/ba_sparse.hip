@@ -405,59 +405,86 @@ __global__ void sparse_retract_kernel(const double *__restrict__ poses, const do
 // ---------------------------------------------------------------------------------------------
 constexpr int NB = 32;
 
+__device__ __forceinline__ double read_lane_d(double v, int lane)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+
+// Diagonal block: one wavefront, lane r keeps row r of the 32 x 32 block in registers; right-looking Cholesky with
+// v_readlane broadcasts (all register indices static), then the inverse of the factor, one column per lane, by forward
+// substitution.  Writes L into the lower triangle (diagonal included) and inv(L)'s strictly lower part TRANSPOSED into
+// the block's strictly upper triangle (row c, columns c+1.. = column c of inv(L)): the panel kernel turns the
+// triangular solve into a product with it.  Rows beyond the matrix act as identity.
 __global__ __launch_bounds__(64) void chol_diag_kernel(double *__restrict__ A, int n, int k0, int *__restrict__ bad)
 {
-    __shared__ double sA[NB][NB + 1];
     const int nb = (n - k0) < NB ? (n - k0) : NB;
     const int lane = threadIdx.x;
-    for (int e = lane; e < nb * nb; e += 64) sA[e / nb][e % nb] = A[(int64_t)(k0 + e / nb) * n + k0 + e % nb];
-    __syncthreads();
-    for (int k = 0; k < nb; ++k) {
-        const double d = sA[k][k];
-        if (lane == 0 && !(d > 0.0)) *bad = 1;
-        const double piv = sqrt(d > 0.0 ? d : 1.0);
-        __syncthreads();
-        if (lane == k) sA[k][k] = piv;
-        if (lane > k && lane < nb) sA[lane][k] /= piv;
-        __syncthreads();
-        if (lane > k && lane < nb) {
-            const double lik = sA[lane][k];
-            for (int j = k + 1; j <= lane; ++j) sA[lane][j] -= lik * sA[j][k];
-        }
-        __syncthreads();
+    const bool live = lane < nb;
+    double row[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        double v = (j == lane) ? 1.0 : 0.0;
+        if (live && j < nb && j <= lane) v = A[(int64_t)(k0 + lane) * n + k0 + j];
+        row[j] = v;
     }
-    for (int e = lane; e < nb * nb; e += 64) {
-        const int r = e / nb, c = e % nb;
-        A[(int64_t)(k0 + r) * n + k0 + c] = (c <= r) ? sA[r][c] : 0.0;
+    bool notpd = false;
+    double dinv[NB];                                      // 1 / L[k][k], wave-uniform
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        const double akk = read_lane_d(row[k], k);
+        notpd = notpd || !(akk > 0.0);
+        const double inv = mqs::rsqrt_d(akk > 0.0 ? akk : 1.0);
+        dinv[k] = inv;
+        const double lik = row[k] * inv;                  // L[lane][k] for lane >= k
+        row[k] = lik;
+#pragma unroll
+        for (int j = k + 1; j < NB; ++j) row[j] = fma(-lik, read_lane_d(lik, j), row[j]);   // used for lane >= j only
+    }
+    if (lane == 0 && notpd) *bad = 1;
+    // inverse: lane c solves L y = e_c;  y[i] = (delta_ic - sum_{k<i} L[i][k] y[k]) / L[i][i]
+    double y[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        double sacc = (i == lane) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < i; ++k) sacc = fma(-read_lane_d(row[k], i), y[k], sacc);
+        y[i] = sacc * dinv[i];
+    }
+    if (live) {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            if (j < nb) {
+                if (j <= lane) A[(int64_t)(k0 + lane) * n + k0 + j] = row[j];
+                else A[(int64_t)(k0 + lane) * n + k0 + j] = y[j];          // inv(L)[j][lane], j > lane
+            }
+        }
     }
 }
 
-// rows below the diagonal block: X L^T = A_panel  (one thread per row)
+// rows below the diagonal block: X = A_panel inv(L)^T, X[r][j] = sum_{k <= j} A[r][k] inv(L)[j][k].  One workgroup per
+// 8 rows, one thread per output entry.
 __global__ __launch_bounds__(kBlock) void chol_panel_kernel(double *__restrict__ A, int n, int k0)
 {
-    __shared__ double sL[NB][NB + 1];
+    __shared__ double sLi[NB][NB + 1];      // inv(L), lower
+    __shared__ double sA[8][NB + 1];
     const int nb = (n - k0) < NB ? (n - k0) : NB;
-    for (int e = threadIdx.x; e < nb * nb; e += kBlock) sL[e / nb][e % nb] = A[(int64_t)(k0 + e / nb) * n + k0 + e % nb];
-    __syncthreads();
-    const int r = k0 + nb + blockIdx.x * kBlock + threadIdx.x;
-    if (r >= n) return;
-    double x[NB];
-    double *row = A + (int64_t)r * n + k0;
-#pragma unroll
-    for (int j = 0; j < NB; ++j) x[j] = (j < nb) ? row[j] : 0.0;
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-        if (j < nb) {
-            double s = x[j];
-#pragma unroll
-            for (int k = 0; k < NB; ++k)
-                if (k < j) s -= x[k] * sL[j][k];
-            x[j] = s / sL[j][j];
+    for (int e = threadIdx.x; e < NB * NB; e += kBlock) {
+        const int j = e / NB, k = e % NB;
+        double v = 0.0;
+        if (j < nb && k < nb) {
+            if (k < j) v = A[(int64_t)(k0 + k) * n + k0 + j];               // stored transposed in the upper triangle
+            else if (k == j) v = 1.0 / A[(int64_t)(k0 + j) * n + k0 + j];
         }
+        sLi[j][k] = v;
     }
+    const int rr = threadIdx.x / NB, j = threadIdx.x % NB;
+    const int r = k0 + nb + blockIdx.x * 8 + rr;
+    sA[rr][j] = (r < n && j < nb) ? A[(int64_t)r * n + k0 + j] : 0.0;
+    __syncthreads();
+    double sacc = 0.0;
 #pragma unroll
-    for (int j = 0; j < NB; ++j)
-        if (j < nb) row[j] = x[j];
+    for (int k = 0; k < NB; ++k) sacc = fma(sA[rr][k], sLi[j][k], sacc);       // inv(L)[j][k] = 0 for k > j
+    if (r < n && j < nb) A[(int64_t)r * n + k0 + j] = sacc;
 }
 
 // trailing update (lower triangle): A[i][j] -= sum_k L[i][k0+k] L[j][k0+k], 32x32 tiles
@@ -491,6 +518,75 @@ __global__ __launch_bounds__(kBlock) void chol_update_kernel(double *__restrict_
 }
 
 // L y = b then L^T x = y; one workgroup, blocked by 256 rows with a block-level dot product per row
+// Forward / backward substitution for a BANDED factor by one workgroup.  The unknowns live in LDS; the band is
+// streamed through LDS in slabs of kSlab columns (forward) / rows (backward), so global-memory latency is paid once per
+// slab.  Inside a slab wave 0 works column-oriented -- x_i = b_i / L_ii, then b_j -= L_ji x_i for the <= hb dependants,
+// one per lane -- so no cross-lane reduction sits on the serial chain.  LDS: n + kSlab * (hb + kSlab) doubles.
+constexpr int kSlab = 32;
+
+__global__ __launch_bounds__(kBlock) void chol_solve_banded_kernel(const double *__restrict__ L, int n, int hb, double *__restrict__ x)
+{
+    extern __shared__ double sMem[];
+    double *sXv = sMem;                    // [n]
+    double *sB = sMem + n;                 // slab: kSlab x (hb + kSlab)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wslab = hb + kSlab;
+    for (int i = tid; i < n; i += kBlock) sXv[i] = x[i];
+    __syncthreads();
+    // forward, columns i0 .. i0 + kSlab - 1: slab entry (r, c) = L[i0 + c][i0 + r], c = r .. r + hb
+    for (int i0 = 0; i0 < n; i0 += kSlab) {
+        for (int e = tid; e < kSlab * wslab; e += kBlock) {
+            const int c = e / kSlab, r = e % kSlab;                 // consecutive threads: consecutive columns of one row of L
+            const int j = i0 + c, i = i0 + r;
+            double v = (i < n && j < n && j >= i) ? L[(int64_t)j * n + i] : 0.0;
+            if (c == r && v != 0.0) v = 1.0 / v;                    // the diagonal is kept as its reciprocal
+            sB[r * wslab + c] = v;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            for (int r = 0; r < kSlab && i0 + r < n; ++r) {
+                const int i = i0 + r;
+                const double xi = sXv[i] * sB[r * wslab + r];
+                for (int c = r + 1 + lane; c <= r + hb && i0 + c < n; c += 64) sXv[i0 + c] = fma(-sB[r * wslab + c], xi, sXv[i0 + c]);
+                if (lane == 0) sXv[i] = xi;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+        }
+        __syncthreads();
+    }
+    // backward, rows i0 + kSlab - 1 .. i0: slab entry (r, c) = L[i0 + r][i0 - hb + c], c = r .. r + hb (the diagonal at c = r + hb)
+    for (int i0 = ((n - 1) / kSlab) * kSlab; i0 >= 0; i0 -= kSlab) {
+        const int c0 = i0 - hb;
+        for (int e = tid; e < kSlab * wslab; e += kBlock) {
+            const int r = e / wslab, c = e % wslab;
+            const int i = i0 + r, j = c0 + c;
+            double v = (i < n && j >= 0 && j <= i) ? L[(int64_t)i * n + j] : 0.0;
+            if (j == i && v != 0.0) v = 1.0 / v;
+            sB[e] = v;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            for (int r = kSlab - 1; r >= 0; --r) {
+                const int i = i0 + r;
+                if (i >= n) continue;
+                const double xi = sXv[i] * sB[r * wslab + hb + r];
+                for (int c = r + lane; c < r + hb; c += 64) {          // columns i - hb .. i - 1
+                    const int j = c0 + c;
+                    if (j >= 0) sXv[j] = fma(-sB[r * wslab + c], xi, sXv[j]);
+                }
+                if (lane == 0) sXv[i] = xi;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < n; i += kBlock) x[i] = sXv[i];
+}
+
 __global__ __launch_bounds__(kBlock) void chol_solve_kernel(const double *__restrict__ L, int n, double *__restrict__ x)
 {
     __shared__ double sRed[kBlock];
@@ -596,15 +692,18 @@ int mqs_sba_linearize_dev(const double *poses, const int32_t *pose_cam, int64_t 
 // In place: S is replaced by its Cholesky factor (after lambda*diag(S) damping), x (= g on entry) by the
 // solution; poses_out (may be NULL) = retract(poses, x).  bad[0] (int, device) is set when S is not
 // positive definite.
-int mqs_sba_solve_dev(double *S, double *x, int64_t P, double lambda, const double *poses, double *poses_out,
-                      int *bad, void *stream_)
+int mqs_sba_solve_banded_dev(double *S, double *x, int64_t P, int64_t half_bandwidth, double lambda, const double *poses,
+                             double *poses_out, int *bad, void *stream_)
 {
     MQS_ARG_CHECK(P >= 1 && S && x && bad, "arguments");
+    MQS_ARG_CHECK(half_bandwidth >= 0, "half_bandwidth >= 0");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int n = (int)(6 * P);
+    const int hb = half_bandwidth < n ? (int)half_bandwidth : n;
     MQS_HIP_CHECK(hipMemsetAsync(bad, 0, sizeof(int), stream));
     if (lambda != 0.0) hipLaunchKernelGGL(sparse_damp_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, S, n, lambda);
-    if (n >= kLibraryCholeskyMinN) {
+    const bool banded = 3 * (int64_t)hb < n;            // the band is worth exploiting
+    if (!banded && n >= kLibraryCholeskyMinN) {
         // a plain dense factorisation of a few thousand unknowns: the vendor's blocked POTRF / POTRS.  Column-major
         // "upper" of this symmetric row-major matrix is the same memory as row-major "lower": the factor lands where
         // the kernels below would put it.
@@ -617,23 +716,43 @@ int mqs_sba_solve_dev(double *S, double *x, int64_t P, double lambda, const doub
             return MQS_E_HIP;
         }
     } else {
+        // right-looking blocked Cholesky; rows further than hb below a block column are zero there and stay zero
+        // (no fill outside the band), so the panel and the trailing update stop hb rows below it
         for (int k0 = 0; k0 < n; k0 += NB) {
             const int nb = (n - k0) < NB ? (n - k0) : NB;
             hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(64), 0, stream, S, n, k0, bad);
-            const int rem = n - k0 - nb;
+            int rem = n - k0 - nb;
+            if (rem > hb) rem = hb;
             if (rem > 0) {
-                hipLaunchKernelGGL(chol_panel_kernel, dim3((rem + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, S, n, k0);
+                hipLaunchKernelGGL(chol_panel_kernel, dim3((rem + 7) / 8), dim3(kBlock), 0, stream, S, n, k0);
                 const int tiles = (rem + NB - 1) / NB;
                 hipLaunchKernelGGL(chol_update_kernel, dim3(tiles, tiles), dim3(kBlock), 0, stream, S, n, k0);
             }
         }
-        hipLaunchKernelGGL(chol_solve_kernel, dim3(1), dim3(kBlock), 0, stream, S, n, x);
+        const size_t lds = ((size_t)n + (size_t)kSlab * (hb + kSlab)) * 8;
+        if (banded && lds <= 150 * 1024) {
+            static bool lds_opt_in = false;                  // dynamic LDS above 64 KiB needs the opt-in once per process
+            if (!lds_opt_in) {
+                MQS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(chol_solve_banded_kernel),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+                lds_opt_in = true;
+            }
+            hipLaunchKernelGGL(chol_solve_banded_kernel, dim3(1), dim3(kBlock), lds, stream, S, n, hb, x);
+        }
+        else
+            hipLaunchKernelGGL(chol_solve_kernel, dim3(1), dim3(kBlock), 0, stream, S, n, x);
     }
     if (poses_out)
         hipLaunchKernelGGL(sparse_retract_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, stream, poses, x, (int)P,
                            poses_out);
     MQS_HIP_CHECK(hipGetLastError());
     return MQS_OK;
+}
+
+int mqs_sba_solve_dev(double *S, double *x, int64_t P, double lambda, const double *poses, double *poses_out, int *bad,
+                      void *stream_)
+{
+    return mqs_sba_solve_banded_dev(S, x, P, 6 * P, lambda, poses, poses_out, bad, stream_);
 }
 
 int mqs_sba_backsub_dev(const double *poses, const int32_t *pose_cam, int64_t P, const double *calib,

@@ -86,6 +86,14 @@ class SparseBundleAdjuster:
         self.pp_idx = t(pr.pose_prior_idx, i32) if self.npp else None
         self.pp_poses = t(pr.poses[pr.pose_prior_idx], f64) if self.npp else None      # prior = initial pose (:273)
         self.pp_sigmas = t(pr.pose_prior_sigmas, f64) if self.npp else None
+        # half bandwidth of the reduced camera system: poses coupled by a common landmark or an odometry link are at
+        # most `dmax` apart in pose index (observations are sorted by pose inside a landmark)
+        ptr = np.asarray(pr.obs_ptr)
+        has = ptr[1:] > ptr[:-1]
+        dmax = int((pr.obs_pose[ptr[1:][has] - 1] - pr.obs_pose[ptr[:-1][has]]).max()) if has.any() else 0
+        if len(pr.odo_from):
+            dmax = max(dmax, int(np.abs(np.asarray(pr.odo_from, dtype=np.int64) - np.asarray(pr.odo_to, dtype=np.int64)).max()))
+        self.half_bandwidth = 6 * (dmax + 1) - 1
         self.n_odo = len(pr.odo_from)
         if self.n_odo:
             self.odo_from, self.odo_to = t(pr.odo_from, i32), t(pr.odo_to, i32)
@@ -121,8 +129,8 @@ class SparseBundleAdjuster:
 
     def solve(self, lam=0.0):
         """Destroys S (replaced by its Cholesky factor) and g (replaced by dpose); retracts the poses."""
-        _lib.check(_lib.lib().mqs_sba_solve_dev(_p(self.S), _p(self.g), self.P, float(lam), _p(self.poses),
-                                                _p(self.poses_new), _p(self.bad), _sp()))
+        _lib.check(_lib.lib().mqs_sba_solve_banded_dev(_p(self.S), _p(self.g), self.P, self.half_bandwidth, float(lam),
+                                                       _p(self.poses), _p(self.poses_new), _p(self.bad), _sp()))
         return self.g
 
     def backsub(self, lam=0.0):

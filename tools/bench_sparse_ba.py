@@ -31,7 +31,7 @@ def timed(fn, reps=3):
     fn(); torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(reps): fn()
     torch.cuda.synchronize(); return round((time.perf_counter() - t0) / reps * 1e3, 3)
-out = {"P": P, "N": N, "M": len(op), "pairs": ba.Q, "setup_s": round(t_setup, 2)}
+out = {"P": P, "N": N, "M": len(op), "pairs": ba.Q, "setup_s": round(t_setup, 2), "half_bandwidth": ba.half_bandwidth, "n": ba.n6}
 out["linearize_ms"] = timed(lambda: ba.linearize(1e-4))
 def lin_solve(): ba.linearize(1e-4); ba.solve(1e-4)
 out["linearize+solve_ms"] = timed(lin_solve)
