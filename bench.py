@@ -177,7 +177,24 @@ def main():
         match_out = {"workload": "%d x %d descriptors x %d bits as {0,1} fp16, kNN-2, one camera pair per GPU" % (nd, nd, bits),
                      "ms_per_pair": round(ms_pair, 3), "query_rows_per_s": round(nd / (ms_pair * 1e-3)),
                      "TFLOPs": round(tf, 1), "mfma_f16_dense_peak_TFLOPs": 2500.0, "frac_of_peak": round(tf / 2500.0, 4)}
-        del qd, td, mi, md, mws
+        # the same camera pair as packed 256-bit descriptors on the int8 matrix pipe (identical results)
+        qp, tp = torch.from_numpy(Mm.pack_bits(qb)).to(dev), torch.from_numpy(Mm.pack_bits(tb)).to(dev)
+        mi8, md8 = torch.empty_like(mi), torch.empty_like(md)
+        mws8 = torch.empty(int(mqslam_amd._lib.lib().mqs_match_knn2_bits_workspace_bytes(nd, nd, bits)), dtype=torch.uint8, device=dev)
+        for _ in range(10):
+            Mm.knn2_bits_dev(qp, tp, mi8, md8, mws8)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(10):
+            Mm.knn2_bits_dev(qp, tp, mi8, md8, mws8)
+        e1.record()
+        e1.synchronize()
+        ms8 = e0.elapsed_time(e1) / 10
+        tops = 2.0 * nd * nd * bits / (ms8 * 1e-3) / 1e12
+        match_out["packed_bits_int8"] = {"ms_per_pair": round(ms8, 3), "Tops": round(tops, 1), "mfma_i8_dense_peak_Tops": 5000.0,
+                                         "frac_of_peak": round(tops / 5000.0, 4),
+                                         "equals_fp16_path": bool(torch.equal(mi, mi8) and torch.equal(md, md8))}
+        del qd, td, mi, md, mws, qp, tp, mi8, md8, mws8
 
     # ---- every kernel of the step against the bound that applies to it ----
     rooflines = {
@@ -200,6 +217,8 @@ def main():
     if match_out is not None:
         rooflines["match_knn2_f16"] = {"bound": "mfma", "achieved": match_out["TFLOPs"], "peak": 2500.0, "unit": "TFLOP/s",
                                        "frac": match_out["frac_of_peak"]}
+        rooflines["match_knn2_bits_i8"] = {"bound": "mfma", "achieved": match_out["packed_bits_int8"]["Tops"], "peak": 5000.0,
+                                           "unit": "Top/s", "frac": match_out["packed_bits_int8"]["frac_of_peak"]}
 
     # ---- BASELINE configs[4] counterpart: the per-frame loop replayed from the reference's recorded tracks
     #      (committed fixture tests/golden/ba_svo: 186 frames, 1046 landmarks), rank 0 reports ----

@@ -134,6 +134,16 @@ int mqs_match_knn2_f16_dev(const uint16_t *query, int64_t Nq, const uint16_t *tr
                            void *stream);
 int64_t mqs_match_knn2_f16_workspace_bytes(int64_t Nq, int64_t Nt);
 
+/* Packed binary descriptors as ORB / BRIEF produce them (D bits per row = D / 8 bytes, bit k of a descriptor = bit
+ * (k & 7) of byte k >> 3; D in {128, 256, 512}): Hamming distance = |q - t|^2 of the {0,1} vectors, contracted on the
+ * int8 matrix pipe (v_mfma_i32_32x32x32_i8).  Same outputs as the fp16 path: dist = sqrt(Hamming distance), ties
+ * towards the lower train index; bit-exact against it on the same descriptors. */
+int mqs_match_knn2_bits(mqs_ctx *ctx, const uint8_t *query_bits, int64_t Nq, const uint8_t *train_bits, int64_t Nt, int D,
+                        int32_t *idx, float *dist);
+int mqs_match_knn2_bits_dev(const uint8_t *query_bits, int64_t Nq, const uint8_t *train_bits, int64_t Nt, int D, int32_t *idx,
+                            float *dist, void *workspace, int64_t workspace_bytes, void *stream);
+int64_t mqs_match_knn2_bits_workspace_bytes(int64_t Nq, int64_t Nt, int D);
+
 /* ---------------------------------------------------------------------------------------
  * Bundle adjustment: projection-factor linearisation + landmark Schur complement, the reduced
  * camera solve, and the landmark back-substitution (replaces the GTSAM work behind

@@ -97,6 +97,9 @@ using float16v = __attribute__((ext_vector_type(16))) float;
 #ifndef MQS_MATCH_PF
 #define MQS_MATCH_PF 4
 #endif
+#ifndef MQS_MATCH_I8_QT
+#define MQS_MATCH_I8_QT 4
+#endif
 #ifndef MQS_MATCH_NW256
 #define MQS_MATCH_NW256 8
 #endif
@@ -114,8 +117,6 @@ constexpr int kStageRows = 64;                         // train rows per LDS sta
 constexpr float kBias = 1024.0f;
 constexpr float kPadNorm = 8192.0f;                    // padding rows: d' >= 8192 - 2 * 512
 constexpr float kInvalid = 2048.0f;                    // d' >= this: padding
-constexpr int kWindowTiles = 256;
-constexpr int kWindowStages = kWindowTiles * 32 / kStageRows;
 
 // squared norms (exact for {0,1} data): one thread per row
 __global__ void row_sqnorm_kernel(const _Float16 *__restrict__ x, int64_t n, int D, float *__restrict__ out)
@@ -132,41 +133,105 @@ __global__ void row_sqnorm_kernel(const _Float16 *__restrict__ x, int64_t n, int
     out[i] = s;
 }
 
-template <int KS /* D / 16 */, int QT /* 32-query column tiles per wave */, int NW /* waves per workgroup */>
-__global__ __launch_bounds__(NW * 64) void knn2_f16_kernel(const _Float16 *__restrict__ query, int64_t Nq,
-                                                          const _Float16 *__restrict__ train, int64_t Nt,
+using int4v = __attribute__((ext_vector_type(4))) int;
+using int16v = __attribute__((ext_vector_type(16))) int;
+
+// What differs between the two element types of the MFMA path.  A fragment is 16 bytes per lane either way
+// (8 halves: k = 16 ks + 8 h + j;  16 int8: k = 32 ks + 16 h + j), so the LDS image and its addressing are shared.
+struct F16Path {
+    using elem = _Float16;
+    using frag = half8;
+    using accv = float16v;
+    using start_t = float;
+    using start4 = __attribute__((ext_vector_type(4))) float;
+    static constexpr int kPerMfma = 16;                 // contraction depth of one MFMA
+    static constexpr int kWindowTiles = 256;            // 8 fraction bits carry the tile
+    static __device__ __forceinline__ frag prep_query(frag v) { return v * (_Float16)(-2.0f); }
+    static __device__ __forceinline__ accv mfma(frag a, frag b, accv c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ start_t start(float tnorm, int64_t t) { return tnorm + kBias + (float)((t >> 5) & (kWindowTiles - 1)) * (1.0f / kWindowTiles); }
+    static __device__ __forceinline__ start_t pad() { return kPadNorm; }
+    static __device__ __forceinline__ unsigned key(float v) { return __float_as_uint(v); }
+    // key -> (distance part kBias + |t|^2 - 2 q.t, tile in window, row in tile); false: padding
+    static __device__ __forceinline__ bool decode(unsigned k, float &d, int &tile, int &row)
+    {
+        const float f = __uint_as_float(k);
+        if (!(f < kInvalid)) return false;
+        d = floorf(f);
+        tile = (int)((f - d) * (float)kWindowTiles);
+        row = (int)(k & 31u);
+        return true;
+    }
+};
+
+// int8 {0,1} descriptors (the packed-bit entry point expands them): train bytes are stored as 0 / 64 and query bytes
+// as 0 / -128, so one MFMA unit contributes -2^13 = -2 * 2^12 and the int32 accumulator, started from
+// (kBias + |t|^2) << 12 | tile << 5, ends as  d' << 12 | tile << 5  with d' = kBias + |t|^2 - 2 q.t exactly;
+// 7 tile bits + 5 row bits fill the 12 low bits (windows of 128 tiles = 4096 rows).
+struct I8Path {
+    using elem = signed char;
+    using frag = int4v;
+    using accv = int16v;
+    using start_t = int;
+    using start4 = int4v;
+    static constexpr int kPerMfma = 32;
+    static constexpr int kWindowTiles = 128;
+    static __device__ __forceinline__ frag prep_query(frag v) { return v; }
+    static __device__ __forceinline__ accv mfma(frag a, frag b, accv c) { return __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ start_t start(float tnorm, int64_t t) { return (((int)tnorm + (int)kBias) << 12) | (int)(((t >> 5) & (kWindowTiles - 1)) << 5); }
+    static __device__ __forceinline__ start_t pad() { return ((int)kPadNorm) << 12; }
+    static __device__ __forceinline__ unsigned key(int v) { return (unsigned)v; }
+    static __device__ __forceinline__ bool decode(unsigned k, float &d, int &tile, int &row)
+    {
+        const unsigned dd = k >> 12;
+        if (dd >= (unsigned)kInvalid) return false;
+        d = (float)dd;
+        tile = (int)((k >> 5) & (kWindowTiles - 1));
+        row = (int)(k & 31u);
+        return true;
+    }
+};
+
+template <class TP /* F16Path or I8Path */, int KS /* MFMAs per (train tile, query tile) = D / TP::kPerMfma */,
+          int QT /* 32-query column tiles per wave */, int NW /* waves per workgroup */>
+__global__ __launch_bounds__(NW * 64) void knn2_mfma_kernel(const typename TP::elem *__restrict__ query, int64_t Nq,
+                                                           const typename TP::elem *__restrict__ train, int64_t Nt,
                                                           const float *__restrict__ qnorm,
                                                           const float *__restrict__ tnorm,
                                                           int32_t *__restrict__ idx, float *__restrict__ dist,
                                                           float *__restrict__ part_d, int32_t *__restrict__ part_i)
 {
-    constexpr int D = KS * 16;
-    constexpr int kVecPerRow = D * 2 / 16;             // 16-byte pieces of data per row
+    using frag_t = typename TP::frag;
+    using accv_t = typename TP::accv;
+    using start_t = typename TP::start_t;
+    constexpr int D = KS * TP::kPerMfma;
+    constexpr int kWindowTiles = TP::kWindowTiles;
+    constexpr int kWindowStages = kWindowTiles * 32 / kStageRows;
+    constexpr int kVecPerRow = 2 * KS;                 // 16-byte pieces of data per row (one per (k-step, lane half))
     constexpr int kPiecesPerRow = kVecPerRow + 1;      // + one piece of padding: row stride = 4 banks mod 64
     constexpr int kRowBytes = kPiecesPerRow * 16;
     constexpr int kStageBytes = kStageRows * kRowBytes;        // a whole number of 1-KiB LDS-DMA chunks (64 rows)
     constexpr int kChunks = kStageBytes / 1024;
     constexpr int kChunksPerWave = (kChunks + NW - 1) / NW;
     __shared__ __attribute__((aligned(16))) unsigned char sTile[2 * kStageBytes];
-    __shared__ __attribute__((aligned(16))) float sTn[2 * kStageRows];
+    __shared__ __attribute__((aligned(16))) start_t sTn[2 * kStageRows];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int64_t qbase = (int64_t)blockIdx.x * (NW * QT * 32) + wave * (QT * 32);
 
     // resident query fragments, scaled by -2 (exact): B[k = 16 ks + 8 h + j][col r] = -2 Q[qbase + 32 qt + r][...]
-    half8 qf[QT][KS];
+    frag_t qf[QT][KS];
     float qn[QT];
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
         const int64_t q = qbase + 32 * qt + r;
         const bool ok = q < Nq;
-        const half8 *row = reinterpret_cast<const half8 *>(query + (ok ? q : 0) * D);
+        const frag_t *row = reinterpret_cast<const frag_t *>(query + (ok ? q : 0) * D);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            half8 v = row[2 * ks + h];
-            if (!ok) v = half8{0, 0, 0, 0, 0, 0, 0, 0};
-            qf[qt][ks] = v * (_Float16)(-2.0f);
+            frag_t v = row[2 * ks + h];
+            if (!ok) v = frag_t{};
+            qf[qt][ks] = TP::prep_query(v);
         }
         qn[qt] = ok ? qnorm[q] : 0.0f;
     }
@@ -217,8 +282,7 @@ __global__ __launch_bounds__(NW * 64) void knn2_f16_kernel(const _Float16 *__res
         if (tid < kStageRows) {
             const int64_t t = s * kStageRows + tid;
             // accumulator start value of this train row: kBias + |t|^2 + tile / 256
-            sTn[buf * kStageRows + tid] = (t < Nt) ? tnorm[t] + kBias + (float)((t >> 5) & (kWindowTiles - 1)) * (1.0f / kWindowTiles)
-                                                  : kPadNorm;
+            sTn[buf * kStageRows + tid] = (t < Nt) ? TP::start(tnorm[t], t) : TP::pad();
         }
     };
 
@@ -228,27 +292,28 @@ __global__ __launch_bounds__(NW * 64) void knn2_f16_kernel(const _Float16 *__res
     // run (tile 0, qt 0), (tile 0, qt 1), .., (tile 1, qt 0), ..: with QT >= 2 the accumulators simply
     // rotate over the query tiles (no second set), and every train stage is amortised over QT * 32 queries
     // per wave -- the LDS-DMA stream from L2, not the matrix pipe, is what a small query block runs out of.
-    auto tile_step = [&](const unsigned char *tile, int tt, int qt, float16v &acc, const float16v &prev, int pq, const float *tn) {
+    auto tile_step = [&](const unsigned char *tile, int tt, int qt, accv_t &acc, const accv_t &prev, int pq, const start_t *tn) {
         const unsigned char *arow = tile + (tt * 32 + r) * kRowBytes + 16 * h;   // fragment ks: + 32 ks (immediate)
-        float16v start;                                       // row(e) = (e & 3) + 8 (e >> 2) + 4 h
+        accv_t start;                                         // row(e) = (e & 3) + 8 (e >> 2) + 4 h
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const float4 t4 = *reinterpret_cast<const float4 *>(tn + 8 * g);
-            start[4 * g] = t4.x; start[4 * g + 1] = t4.y; start[4 * g + 2] = t4.z; start[4 * g + 3] = t4.w;
+            const typename TP::start4 t4 = *reinterpret_cast<const typename TP::start4 *>(tn + 8 * g);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) start[4 * g + k] = t4[k];
         }
         constexpr int PF = MQS_MATCH_PF < KS ? MQS_MATCH_PF : KS;     // fragment reads in flight ahead of their MFMA
-        half8 a[KS];
+        frag_t a[KS];
 #pragma unroll
-        for (int ks = 0; ks < PF; ++ks) a[ks] = *reinterpret_cast<const half8 *>(arow + 32 * ks);
+        for (int ks = 0; ks < PF; ++ks) a[ks] = *reinterpret_cast<const frag_t *>(arow + 32 * ks);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            if (ks + PF < KS) a[ks + PF] = *reinterpret_cast<const half8 *>(arow + 32 * (ks + PF));
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks], qf[qt][ks], ks == 0 ? start : acc, 0, 0, 0);
+            if (ks + PF < KS) a[ks + PF] = *reinterpret_cast<const frag_t *>(arow + 32 * (ks + PF));
+            acc = TP::mfma(a[ks], qf[qt][ks], ks == 0 ? start : acc);
             // scan values [v0, v1) of the previous step behind this MFMA
             const int v0 = ks * 16 / KS, v1 = (ks + 1) * 16 / KS;
 #pragma unroll
             for (int e = v0; e < v1; ++e) {
-                const unsigned key = __float_as_uint(prev[e]) | (unsigned)(4 * h) | (unsigned)(8 * (e >> 2) + (e & 3));   // v_or3_b32
+                const unsigned key = TP::key(prev[e]) | (unsigned)(4 * h) | (unsigned)(8 * (e >> 2) + (e & 3));   // v_or3_b32
                 unsigned m;
                 asm("v_med3_u32 %0, %1, %2, %3" : "=v"(m) : "v"(best[pq]), "v"(second[pq]), "v"(key));
                 second[pq] = m;
@@ -271,11 +336,10 @@ __global__ __launch_bounds__(NW * 64) void knn2_f16_kernel(const _Float16 *__res
 
     // decode a window key: distance part, row index
     auto push = [&](int qt, unsigned key, int64_t window_base) {
-        const float f = __uint_as_float(key);
-        if (!(f < kInvalid)) return;
-        const float d = floorf(f);
-        const int tile = (int)((f - d) * (float)kWindowTiles);
-        const int i = (int)window_base + tile * 32 + (int)(key & 31u);
+        float d;
+        int tile, row;
+        if (!TP::decode(key, d, tile, row)) return;
+        const int i = (int)window_base + tile * 32 + row;
         if (d < gd0[qt]) { gd1[qt] = gd0[qt]; gi1[qt] = gi0[qt]; gd0[qt] = d; gi0[qt] = i; }
         else if (d < gd1[qt]) { gd1[qt] = d; gi1[qt] = i; }
     };
@@ -293,9 +357,9 @@ __global__ __launch_bounds__(NW * 64) void knn2_f16_kernel(const _Float16 *__res
 
     constexpr int R = QT < 2 ? 2 : QT;                   // accumulator ring: step j writes acc[j % R], scans acc[(j - 1) % R]
     static_assert((2 * QT) % R == 0, "the ring position must repeat every stage");
-    float16v acc[R];
+    accv_t acc[R];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[R - 1][e] = kPadNorm;    // "previous step" of the first one: nothing
+    for (int e = 0; e < 16; ++e) acc[R - 1][e] = TP::pad();   // "previous step" of the first one: nothing
 
 #if MQS_MATCH_NOPEEL
 #pragma clang loop unroll(disable)
@@ -303,7 +367,7 @@ __global__ __launch_bounds__(NW * 64) void knn2_f16_kernel(const _Float16 *__res
     for (int64_t s = s_begin; s < s_end; ++s) {
         if (s + 1 < s_end) stage_issue(s + 1);            // lands while this stage is computed
         const unsigned char *tile = sTile + (int)(s & 1) * kStageBytes;
-        const float *tn0 = sTn + (int)(s & 1) * kStageRows + 4 * h;
+        const start_t *tn0 = sTn + (int)(s & 1) * kStageRows + 4 * h;
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
@@ -321,7 +385,7 @@ __global__ __launch_bounds__(NW * 64) void knn2_f16_kernel(const _Float16 *__res
         constexpr int jl = 2 * QT - 1;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            const unsigned key = __float_as_uint(acc[jl % R][e]) | (unsigned)(4 * h) | (unsigned)(8 * (e >> 2) + (e & 3));
+            const unsigned key = TP::key(acc[jl % R][e]) | (unsigned)(4 * h) | (unsigned)(8 * (e >> 2) + (e & 3));
             second[QT - 1] = max(best[QT - 1], min(second[QT - 1], key));
             best[QT - 1] = min(best[QT - 1], key);
         }
@@ -400,32 +464,58 @@ int launch_f32(const float *query, int64_t Nq, const float *train, int64_t Nt, i
 
 constexpr int kMaxParts = 8;
 
-// Can workgroups of NW waves x 2 query tiles, times the parts the train set can be split into, occupy every CU?
-bool two_tiles_fill(int64_t Nq, int64_t Nt, int NW, int num_cus)
+// Can workgroups of NW waves x QT query tiles, times the parts the train set can be split into, occupy every CU?
+template <class TP>
+bool tiles_fill(int64_t Nq, int64_t Nt, int NW, int QT, int num_cus)
 {
-    const int64_t qblocks = (Nq + NW * 64 - 1) / (NW * 64);
-    int64_t nwin = (Nt + kWindowTiles * 32 - 1) / (kWindowTiles * 32);
+    const int64_t qblocks = (Nq + NW * QT * 32 - 1) / (NW * QT * 32);
+    int64_t nwin = (Nt + TP::kWindowTiles * 32 - 1) / (TP::kWindowTiles * 32);
     if (nwin > kMaxParts) nwin = kMaxParts;
     return qblocks * nwin >= num_cus;
 }
 
-template <int KS, int QT, int NW>
-void launch_f16_t(const _Float16 *q, int64_t Nq, const _Float16 *t, int64_t Nt, const float *qn, const float *tn,
-                  int32_t *idx, float *dist, float *part_d, int32_t *part_i, int num_cus, hipStream_t stream)
+template <class TP, int KS, int QT, int NW>
+void launch_mfma_t(const typename TP::elem *q, int64_t Nq, const typename TP::elem *t, int64_t Nt, const float *qn,
+                   const float *tn, int32_t *idx, float *dist, float *part_d, int32_t *part_i, int num_cus, hipStream_t stream)
 {
     const int64_t per_block = NW * QT * 32;
     const int64_t qblocks = (Nq + per_block - 1) / per_block;
     // split the train rows (whole windows) until every CU has a workgroup
-    const int64_t nwin = (Nt + kWindowTiles * 32 - 1) / (kWindowTiles * 32);
+    const int64_t nwin = (Nt + TP::kWindowTiles * 32 - 1) / (TP::kWindowTiles * 32);
     int64_t parts = (num_cus + qblocks - 1) / qblocks;
     if (parts > nwin) parts = nwin;
     if (parts > kMaxParts) parts = kMaxParts;
     if (parts < 1) parts = 1;
-    hipLaunchKernelGGL((knn2_f16_kernel<KS, QT, NW>), dim3((unsigned)qblocks, (unsigned)parts), dim3(NW * 64), 0, stream, q,
-                       Nq, t, Nt, qn, tn, idx, dist, part_d, part_i);
+    hipLaunchKernelGGL((knn2_mfma_kernel<TP, KS, QT, NW>), dim3((unsigned)qblocks, (unsigned)parts), dim3(NW * 64), 0, stream,
+                       q, Nq, t, Nt, qn, tn, idx, dist, part_d, part_i);
     if (parts > 1)
         hipLaunchKernelGGL(merge_parts_kernel, dim3((unsigned)((Nq + 255) / 256)), dim3(256), 0, stream, part_d, part_i,
                            (int)parts, Nq, qn, idx, dist);
+}
+
+// Packed descriptor bits -> the int8 operands of I8Path (`one` = 64 for train rows, -128 for query rows) and the
+// squared norm (= popcount).  One thread per row; `words` = D / 32 little-endian 32-bit words, bit k of the
+// descriptor = bit (k & 7) of byte k >> 3.
+__global__ void expand_bits_kernel(const uint8_t *__restrict__ bits, int64_t n, int D, int one, signed char *__restrict__ out,
+                                   float *__restrict__ norm)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t *src = bits + i * (D / 8);
+    signed char *dst = out + i * D;
+    int pop = 0;
+    for (int b = 0; b < D / 8; ++b) {
+        const unsigned v = src[b];
+        pop += __popc(v);
+        unsigned lo = 0, hi = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            lo |= ((v >> k) & 1u) ? ((unsigned)(one & 0xFF) << (8 * k)) : 0u;
+            hi |= ((v >> (4 + k)) & 1u) ? ((unsigned)(one & 0xFF) << (8 * k)) : 0u;
+        }
+        reinterpret_cast<uint2 *>(dst)[b] = make_uint2(lo, hi);
+    }
+    norm[i] = (float)pop;
 }
 
 }  // namespace
@@ -469,19 +559,94 @@ int mqs_match_knn2_f16_dev(const uint16_t *query, int64_t Nq, const uint16_t *tr
     if (Nt > 0)
         hipLaunchKernelGGL(row_sqnorm_kernel, dim3((unsigned)((Nt + 255) / 256)), dim3(256), 0, stream, t, Nt, D, tn);
     switch (D) {
-    case 32: launch_f16_t<2, 2, 4>(q, Nq, t, Nt, qn, tn, idx, dist, part_d, part_i, num_cus, stream); break;
-    case 64: launch_f16_t<4, 2, 4>(q, Nq, t, Nt, qn, tn, idx, dist, part_d, part_i, num_cus, stream); break;
-    case 128: launch_f16_t<8, 2, 4>(q, Nq, t, Nt, qn, tn, idx, dist, part_d, part_i, num_cus, stream); break;
+    case 32: launch_mfma_t<F16Path, 2, 2, 4>(q, Nq, t, Nt, qn, tn, idx, dist, part_d, part_i, num_cus, stream); break;
+    case 64: launch_mfma_t<F16Path, 4, 2, 4>(q, Nq, t, Nt, qn, tn, idx, dist, part_d, part_i, num_cus, stream); break;
+    case 128: launch_mfma_t<F16Path, 8, 2, 4>(q, Nq, t, Nt, qn, tn, idx, dist, part_d, part_i, num_cus, stream); break;
     case 256:
         // two query tiles per wave halve the train stream per MFMA; worth it once the split can still fill the CUs
-        if (MQS_MATCH_QT256 == 2 && two_tiles_fill(Nq, Nt, MQS_MATCH_NW256, num_cus))
-            launch_f16_t<16, 2, MQS_MATCH_NW256>(q, Nq, t, Nt, qn, tn, idx, dist, part_d, part_i, num_cus, stream);
+        if (MQS_MATCH_QT256 == 2 && tiles_fill<F16Path>(Nq, Nt, MQS_MATCH_NW256, 2, num_cus))
+            launch_mfma_t<F16Path, 16, 2, MQS_MATCH_NW256>(q, Nq, t, Nt, qn, tn, idx, dist, part_d, part_i, num_cus, stream);
         else
-            launch_f16_t<16, 1, MQS_MATCH_NW256>(q, Nq, t, Nt, qn, tn, idx, dist, part_d, part_i, num_cus, stream);
+            launch_mfma_t<F16Path, 16, 1, MQS_MATCH_NW256>(q, Nq, t, Nt, qn, tn, idx, dist, part_d, part_i, num_cus, stream);
         break;
-    case 512: launch_f16_t<32, 1, MQS_MATCH_NW512>(q, Nq, t, Nt, qn, tn, idx, dist, part_d, part_i, num_cus, stream); break;
+    case 512: launch_mfma_t<F16Path, 32, 1, MQS_MATCH_NW512>(q, Nq, t, Nt, qn, tn, idx, dist, part_d, part_i, num_cus, stream); break;
     }
     MQS_HIP_CHECK(hipGetLastError());
+    return MQS_OK;
+}
+
+// Packed binary descriptors (D bits per row, D / 8 bytes, D in {128, 256, 512}): Hamming distance = |q - t|^2 on the
+// int8 matrix pipe (v_mfma_i32_32x32x32_i8), same output contract as the fp16 path (dist = sqrt(Hamming)).
+int64_t mqs_match_knn2_bits_workspace_bytes(int64_t Nq, int64_t Nt, int D)
+{
+    if (Nq < 0 || Nt < 0 || D < 8) return 0;
+    const int64_t up = 255;
+    return (((Nq + 63) / 64 * 64 + (Nt + 63) / 64 * 64) * (int64_t)sizeof(float) + up) / 256 * 256 +
+           (int64_t)kMaxParts * Nq * 2 * 8 + ((Nq * D + up) / 256 * 256) + ((Nt * D + up) / 256 * 256) + 256;
+}
+
+int mqs_match_knn2_bits_dev(const uint8_t *query_bits, int64_t Nq, const uint8_t *train_bits, int64_t Nt, int D, int32_t *idx,
+                            float *dist, void *workspace, int64_t workspace_bytes, void *stream_)
+{
+    MQS_ARG_CHECK(Nq >= 0 && Nt >= 0, "Nq, Nt >= 0");
+    MQS_ARG_CHECK(D == 128 || D == 256 || D == 512, "D must be 128, 256 or 512 bits");
+    MQS_ARG_CHECK(Nt <= 0x7fffffff, "Nt must be < 2^31");
+    if (Nq == 0) return MQS_OK;
+    MQS_ARG_CHECK(query_bits && idx && dist && workspace && (Nt == 0 || train_bits), "pointers must not be null");
+    MQS_ARG_CHECK(workspace_bytes >= mqs_match_knn2_bits_workspace_bytes(Nq, Nt, D), "workspace too small");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    char *w = static_cast<char *>(workspace);
+    float *qn = reinterpret_cast<float *>(w);
+    float *tn = qn + (Nq + 63) / 64 * 64;
+    w += (((Nq + 63) / 64 * 64 + (Nt + 63) / 64 * 64) * (int64_t)sizeof(float) + 255) / 256 * 256;
+    float *part_d = reinterpret_cast<float *>(w);
+    int32_t *part_i = reinterpret_cast<int32_t *>(part_d + (int64_t)kMaxParts * Nq * 2);
+    w += (int64_t)kMaxParts * Nq * 2 * 8;
+    signed char *q8 = reinterpret_cast<signed char *>(w); w += (Nq * D + 255) / 256 * 256;
+    signed char *t8 = reinterpret_cast<signed char *>(w);
+    int dev = 0, num_cus = 256;
+    MQS_HIP_CHECK(hipGetDevice(&dev));
+    MQS_HIP_CHECK(hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, dev));
+    hipLaunchKernelGGL(expand_bits_kernel, dim3((unsigned)((Nq + 255) / 256)), dim3(256), 0, stream, query_bits, Nq, D, -128, q8, qn);
+    if (Nt > 0)
+        hipLaunchKernelGGL(expand_bits_kernel, dim3((unsigned)((Nt + 255) / 256)), dim3(256), 0, stream, train_bits, Nt, D, 64, t8, tn);
+    switch (D) {
+    case 128: launch_mfma_t<I8Path, 4, 2, 4>(q8, Nq, t8, Nt, qn, tn, idx, dist, part_d, part_i, num_cus, stream); break;
+    case 256:
+        if (tiles_fill<I8Path>(Nq, Nt, 8, MQS_MATCH_I8_QT, num_cus))
+            launch_mfma_t<I8Path, 8, MQS_MATCH_I8_QT, 8>(q8, Nq, t8, Nt, qn, tn, idx, dist, part_d, part_i, num_cus, stream);
+        else
+            launch_mfma_t<I8Path, 8, 1, 8>(q8, Nq, t8, Nt, qn, tn, idx, dist, part_d, part_i, num_cus, stream);
+        break;
+    case 512: launch_mfma_t<I8Path, 16, 2, 8>(q8, Nq, t8, Nt, qn, tn, idx, dist, part_d, part_i, num_cus, stream); break;
+    }
+    MQS_HIP_CHECK(hipGetLastError());
+    return MQS_OK;
+}
+
+int mqs_match_knn2_bits(mqs_ctx *ctx, const uint8_t *query_bits, int64_t Nq, const uint8_t *train_bits, int64_t Nt, int D,
+                        int32_t *idx, float *dist)
+{
+    MQS_ARG_CHECK(ctx != nullptr, "ctx must not be null");
+    MQS_ARG_CHECK(Nq >= 0 && Nt >= 0 && D >= 8 && D % 8 == 0, "Nq, Nt >= 0, D a multiple of 8");
+    if (Nq == 0) return MQS_OK;
+    MQS_ARG_CHECK(query_bits && idx && dist && (Nt == 0 || train_bits), "pointers must not be null");
+    MQS_HIP_CHECK(hipSetDevice(ctx->device));
+    auto up = [](size_t v) { return (v + 255) & ~size_t(255); };
+    const size_t wsb = (size_t)mqs_match_knn2_bits_workspace_bytes(Nq, Nt, D);
+    const size_t o_q = 0, o_t = up((size_t)Nq * D / 8), o_i = up(o_t + (size_t)Nt * D / 8), o_d = up(o_i + (size_t)Nq * 8);
+    const size_t o_w = up(o_d + (size_t)Nq * 8), total = up(o_w + wsb);
+    int rc = mqs_ctx_reserve(ctx, total);
+    if (rc != MQS_OK) return rc;
+    char *d = static_cast<char *>(ctx->dbuf);
+    MQS_HIP_CHECK(hipMemcpyAsync(d + o_q, query_bits, (size_t)Nq * D / 8, hipMemcpyHostToDevice, ctx->stream));
+    if (Nt > 0) MQS_HIP_CHECK(hipMemcpyAsync(d + o_t, train_bits, (size_t)Nt * D / 8, hipMemcpyHostToDevice, ctx->stream));
+    rc = mqs_match_knn2_bits_dev((const uint8_t *)(d + o_q), Nq, (const uint8_t *)(d + o_t), Nt, D, (int32_t *)(d + o_i),
+                                 (float *)(d + o_d), d + o_w, (int64_t)wsb, ctx->stream);
+    if (rc != MQS_OK) return rc;
+    MQS_HIP_CHECK(hipMemcpyAsync(idx, d + o_i, (size_t)Nq * 8, hipMemcpyDeviceToHost, ctx->stream));
+    MQS_HIP_CHECK(hipMemcpyAsync(dist, d + o_d, (size_t)Nq * 8, hipMemcpyDeviceToHost, ctx->stream));
+    MQS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return MQS_OK;
 }
 

@@ -78,6 +78,53 @@ def knn2_dev(query, train, out_idx=None, out_dist=None, workspace=None):
     return idx, dist
 
 
+def pack_bits(descriptors01):
+    """(n, D) array of 0/1 -> (n, D / 8) uint8, bit k of a descriptor = bit (k & 7) of byte k >> 3 (the layout of
+    OpenCV's binary descriptors read as little-endian bit strings)."""
+    d = np.asarray(descriptors01)
+    if d.ndim != 2 or d.shape[1] % 8:
+        raise ValueError("descriptors must be (n, D) with D a multiple of 8")
+    return np.packbits(d.astype(np.uint8), axis=1, bitorder="little")
+
+
+def knn2_bits(query_bits, train_bits):
+    """Two nearest train descriptors under the Hamming distance for packed binary descriptors ((n, D / 8) uint8,
+    D in {128, 256, 512}); returns idx (Nq, 2) int32 and dist (Nq, 2) float32 = sqrt(Hamming distance), exactly what
+    `knn2` returns for the same descriptors expanded to {0,1} float16."""
+    q = np.ascontiguousarray(query_bits)
+    t = np.ascontiguousarray(train_bits)
+    if q.dtype != np.uint8 or t.dtype != np.uint8 or q.ndim != 2 or t.ndim != 2 or q.shape[1] != t.shape[1]:
+        raise ValueError("query_bits (Nq, D / 8) and train_bits (Nt, D / 8) must be uint8 with the same width")
+    D = 8 * q.shape[1]
+    if D not in (128, 256, 512):
+        raise ValueError("D must be 128, 256 or 512 bits")
+    Nq, Nt = len(q), len(t)
+    idx = np.empty((Nq, 2), dtype=np.int32)
+    dist = np.empty((Nq, 2), dtype=np.float32)
+    _lib.check(_lib.lib().mqs_match_knn2_bits(_lib.default_context().handle, q.ctypes.data_as(_lib.c_u8p), c_i64(Nq),
+                                              t.ctypes.data_as(_lib.c_u8p), c_i64(Nt), D, idx.ctypes.data_as(c_i32p),
+                                              dist.ctypes.data_as(c_f32p)))
+    return idx, dist
+
+
+def knn2_bits_dev(query_bits, train_bits, out_idx=None, out_dist=None, workspace=None):
+    """Device-resident form: uint8 torch tensors (n, D / 8)."""
+    import torch
+    if not (query_bits.is_cuda and train_bits.is_cuda and query_bits.is_contiguous() and train_bits.is_contiguous()):
+        raise ValueError("query_bits / train_bits must be contiguous device tensors")
+    if query_bits.dtype != torch.uint8 or train_bits.dtype != torch.uint8 or query_bits.shape[1] != train_bits.shape[1]:
+        raise ValueError("packed descriptors must be uint8 (n, D / 8) with the same width")
+    Nq, Nt, D = int(query_bits.shape[0]), int(train_bits.shape[0]), 8 * int(query_bits.shape[1])
+    idx = out_idx if out_idx is not None else torch.empty((Nq, 2), dtype=torch.int32, device=query_bits.device)
+    dist = out_dist if out_dist is not None else torch.empty((Nq, 2), dtype=torch.float32, device=query_bits.device)
+    need = int(_lib.lib().mqs_match_knn2_bits_workspace_bytes(Nq, Nt, D))
+    ws = workspace if workspace is not None else torch.empty(max(need, 16), dtype=torch.uint8, device=query_bits.device)
+    _lib.check(_lib.lib().mqs_match_knn2_bits_dev(query_bits.data_ptr(), Nq, train_bits.data_ptr(), Nt, D, idx.data_ptr(),
+                                                  dist.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                  ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    return idx, dist
+
+
 class BFMatcher:
     """cv2.BFMatcher()-shaped object (NORM_L2, no cross-check), cv2_helpers.py:282-345."""
 

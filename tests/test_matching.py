@@ -28,6 +28,14 @@ def test_oracle_radius_match_and_ratio_test():
     assert len(set(best.keys())) == len(best)
 
 
+def test_pack_bits_layout(mqs):
+    d = np.zeros((2, 16), np.uint8)
+    d[0, 0] = 1; d[0, 9] = 1; d[1, 7] = 1
+    np.testing.assert_array_equal(mqs.matching.pack_bits(d), [[1, 2], [128, 0]])
+    with pytest.raises(ValueError):
+        mqs.matching.pack_bits(np.zeros((2, 12)))
+
+
 def test_facade_validation(mqs):
     with pytest.raises(ValueError):
         mqs.matching.knn2(np.zeros((3, 2), np.float32), np.zeros((3, 3), np.float32))
@@ -92,6 +100,23 @@ def test_f16_mfma_path_bit_exact(shape, gpu):
     i32, d32 = gpu.matching.knn2(qb.astype(np.float32), tb.astype(np.float32))
     np.testing.assert_array_equal(i32, idx)
     np.testing.assert_array_equal(d32, dist)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(1, 1, 256), (70, 5, 256), (256, 64, 256), (1000, 3000, 256), (513, 1029, 128),
+                                   (200, 500, 512), (300, 9000, 256), (4100, 4200, 256)])
+def test_packed_bits_int8_path_bit_exact(shape, gpu):
+    """Packed 256-bit descriptors on the int8 matrix pipe: identical to the oracle and to the fp16 path."""
+    Nq, Nt, D = shape
+    tb = gpu.matching.binary_descriptors(Nt, D, seed=18)
+    qb = gpu.matching.binary_descriptors(Nq, D, seed=19, copies_of=tb.astype(np.uint8))
+    idx, dist = gpu.matching.knn2_bits(gpu.matching.pack_bits(qb), gpu.matching.pack_bits(tb))
+    io, do = M.knn2_hamming_bits(qb, tb)
+    np.testing.assert_array_equal(idx, io)
+    np.testing.assert_array_equal(dist, do)
+    i16, d16 = gpu.matching.knn2(qb, tb)
+    np.testing.assert_array_equal(idx, i16)
+    np.testing.assert_array_equal(dist, d16)
 
 
 @pytest.mark.gpu

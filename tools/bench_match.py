@@ -22,4 +22,14 @@ for rnd in range(6):
     ms = timed(lambda: M.knn2_dev(q, t, idx, dist, ws))
     out.setdefault("f16_ms", []).append(round(ms, 3))
     out.setdefault("f16_TFLOPs", []).append(round(2.0 * N * N * D / (ms * 1e-3) / 1e12, 1))
+qp = torch.from_numpy(M.pack_bits(qb)).cuda(); tp = torch.from_numpy(M.pack_bits(tb)).cuda()
+if D in (128, 256, 512):
+    ws8 = torch.empty(int(mqslam_amd._lib.lib().mqs_match_knn2_bits_workspace_bytes(N, N, D)), dtype=torch.uint8, device="cuda")
+    idx8 = torch.empty_like(idx); dist8 = torch.empty_like(dist)
+    for rnd in range(6):
+        ms = timed(lambda: M.knn2_bits_dev(qp, tp, idx8, dist8, ws8))
+        out.setdefault("i8_ms", []).append(round(ms, 3))
+        out.setdefault("i8_Tops", []).append(round(2.0 * N * N * D / (ms * 1e-3) / 1e12, 1))
+    M.knn2_dev(q, t, idx, dist, ws)
+    out["i8_equals_f16"] = bool(torch.equal(idx, idx8) and torch.equal(dist, dist8))
 print(json.dumps(out))
