@@ -45,3 +45,66 @@ def test_end_to_end_loop_on_rendered_sequence(gpu):
     assert out["landmarks_triangulated"] >= 200
     assert out["trajectory_rmse"] < 0.01 * out["path_length"]                 # < 1 % of the path (measured 0.3 %)
     assert out["map_plane_median_abs_z"] < 0.15                                # landmarks lie on the plane z = 0 (depth ~ 9)
+
+
+def test_loop_host_logic_with_oracle_backends(mqs, c_oracle, monkeypatch):
+    """The state machine (gates, bookkeeping, keyframe logic) on the CPU: every GPU call replaced by the oracle's
+    restatement of the same step.  Small sequence so that the numpy tracker stays fast."""
+    from types import SimpleNamespace
+    from oracle import features_np as Fn, pnp_np, harness_np as H
+    L = mqs.slam_loop
+
+    def lk(prev, nxt, pts):
+        n, s, e = Fn.calc_optical_flow_pyr_lk(prev, nxt, pts)
+        return n, s.reshape(-1, 1), e.reshape(-1, 1)
+
+    def intr_of(K, dist):
+        return np.array([K[0, 0], K[1, 1], K[0, 2], K[1, 2], dist[0], dist[1], dist[2], dist[3], 0.0])
+
+    def solve_pnp(objp, imgp, K, dist, rvec=None, tvec=None, useExtrinsicGuess=False):
+        o, m = np.asarray(objp, np.float64), np.asarray(imgp, np.float64)
+        if useExtrinsicGuess:
+            rv, tv, _, _ = pnp_np.solve_pnp(o, m, intr_of(K, dist), np.asarray(rvec).ravel(), np.asarray(tvec).ravel())
+        else:
+            rv, tv, _, _ = pnp_np.solve_pnp(o, m, intr_of(K, dist))
+        return True, rv.reshape(3, 1), tv.reshape(3, 1)
+
+    def solve_pnp_ransac(objp, imgp, K, dist, minInliersCount=0, reprojectionError=2.0, seed=0):
+        o, m = np.asarray(objp, np.float64), np.asarray(imgp, np.float64)
+        samples = mqs.pnp.draw_samples(len(o), 16, 6, seed)
+        rv, tv, mask, best = pnp_np.solve_pnp_ransac(o, m, intr_of(K, dist), samples, reprojectionError)
+        return rv.reshape(3, 1), tv.reshape(3, 1), np.nonzero(mask)[0].astype(np.int32).reshape(-1, 1)
+
+    def undistort(p, K, dist):
+        x, y = H.undistort_normalized((p[:, 0] - K[0, 2]) / K[0, 0], (p[:, 1] - K[1, 2]) / K[1, 1], *dist)
+        return np.stack([x, y], 1)
+
+    def reproj(objp, imgp, K, dist, rvec, tvec):
+        uv = pnp_np.project(np.asarray(rvec).ravel(), np.asarray(tvec).ravel(), objp, intr_of(K, dist))
+        return float(np.sqrt(((uv - imgp) ** 2).sum() / len(imgp))), uv
+
+    def tri(u0, P0, u1, P1):
+        return c_oracle.iterative_LS_triangulation(np.stack([u0, u1]), np.stack([P0[:3], P1[:3]]))
+
+    monkeypatch.setattr(L, "features", SimpleNamespace(calcOpticalFlowPyrLK=lk, goodFeaturesToTrack=(
+        lambda img, n, q, md, c=None, mask=None: Fn.good_features_to_track(img, n, q, md, mask) if n else np.zeros((0, 2), np.float32))))
+    monkeypatch.setattr(L, "pnp", SimpleNamespace(solvePnP=solve_pnp, solvePnPRansac=solve_pnp_ransac,
+                                                 Rodrigues=lambda r: pnp_np.rodrigues(np.asarray(r).ravel())))
+    monkeypatch.setattr(L, "camera", SimpleNamespace(undistort_points=undistort, reprojection_error=reproj))
+    monkeypatch.setattr(L, "triangulation", SimpleNamespace(iterative_LS_triangulation=tri))
+
+    frames = 14
+    seq = mqs.synthetic.PlaneSequence(image_size=(320, 240), f=240.0, frames=4 * frames)     # quarter-speed motion
+    gx, gy = np.meshgrid(np.linspace(-5.0, 1.0, 8), np.linspace(-2.5, 2.0, 6))
+    objp = np.stack([gx.ravel(), gy.ravel(), np.zeros(gx.size)], axis=1)
+    imgp = seq.project(0, objp)
+    vis = (imgp[:, 0] > 14) & (imgp[:, 0] < seq.W - 14) & (imgp[:, 1] > 14) & (imgp[:, 1] < seq.H - 14)
+    slam = L.MonoSlam(seq.K, seq.dist, (seq.H, seq.W), seed=3)
+    slam.start(seq.render(0), objp[vis], imgp[vis])
+    rets = [slam.handle_new_frame(seq.render(k)) for k in range(1, frames)]
+    assert all(r in (1, 2) for r in rets) and rets.count(2) >= 1                 # every frame accepted, some keyframes
+    traj, gt = slam.trajectory(), seq.centres()[:frames]
+    assert np.linalg.norm(traj - gt, axis=1).max() < 0.08                        # path of ~0.35 units at depth ~9
+    new = slam.objp[int(vis.sum()):]
+    assert len(new) >= 10 and np.median(np.abs(new[:, 2])) < 0.6                 # short baselines: coarse, but on the plane
+    assert (slam.lm >= -1).all() and slam.lm.max() < len(slam.objp)
