@@ -549,9 +549,7 @@ __global__ __launch_bounds__(kBlock) void chol_solve_banded_kernel(const double 
                 const double xi = sXv[i] * sB[r * wslab + r];
                 for (int c = r + 1 + lane; c <= r + hb && i0 + c < n; c += 64) sXv[i0 + c] = fma(-sB[r * wslab + c], xi, sXv[i0 + c]);
                 if (lane == 0) sXv[i] = xi;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                mqs_wave_lds_sync();
             }
         }
         __syncthreads();
@@ -577,9 +575,7 @@ __global__ __launch_bounds__(kBlock) void chol_solve_banded_kernel(const double 
                     if (j >= 0) sXv[j] = fma(-sB[r * wslab + c], xi, sXv[j]);
                 }
                 if (lane == 0) sXv[i] = xi;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                mqs_wave_lds_sync();
             }
         }
         __syncthreads();

@@ -9,10 +9,11 @@
 // Mapping to the machine
 //   * corner response: one thread per pixel, the 5x5 support read straight through L1/L2 (a VGA frame is 300 KB);
 //     two-stage max; candidates (thresholded 3x3 maxima under the mask) compacted with one atomic counter as 64-bit
-//     keys (response bits << 32 | ~position), sorted by rocPRIM's radix sort -- response descending, position
+//     keys (response bits << 32 | ~(y << 16 | x)), sorted by rocPRIM's radix sort -- response descending, position
 //     ascending, so the result does not depend on the order the atomics happened in;
-//   * minimum-distance selection is inherently sequential in the candidates: one wavefront walks the sorted list,
-//     36 lanes test the 9 neighbouring grid cells x 4 slots of the accepted set (kept in LDS when it fits);
+//   * minimum-distance selection is inherently sequential in the candidates: one wavefront walks the sorted list
+//     seven candidates at a time (63 lanes = 7 candidates x 9 neighbouring grid cells of the accepted set, kept in
+//     LDS when it fits), then settles the seven among themselves in order;
 //   * Lucas-Kanade: one wavefront per feature, lanes strided over the 21 x 21 window (7 pixels each, template and
 //     gradients in registers), all pyramid levels and all iterations inside one launch; window sums in fp64.
 #include <cstring>
@@ -124,68 +125,143 @@ __global__ __launch_bounds__(kBlock) void candidates_kernel(const float *__restr
     if (!is_max) return;
     const unsigned int slot = atomicAdd(counter, 1u);
     if (slot < capacity)
-        keys[slot] = ((unsigned long long)__float_as_uint(e) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)(y * W + x));
+        // low word: ~(y << 16 | x) -- the same order as the row-major position, and no division to take apart
+        keys[slot] = ((unsigned long long)__float_as_uint(e) << 32) | (unsigned long long)(0xFFFFFFFFu - (((unsigned)y << 16) | (unsigned)x));
 }
 
-// One wavefront: greedy minimum-distance selection over the sorted candidates.
-// grid: cells x 4 slots (x | y << 16, 0xFFFFFFFF = empty), in LDS when `grid_global` is null.
-__global__ __launch_bounds__(64) void select_kernel(const unsigned long long *__restrict__ keys,
-                                                   const unsigned int *__restrict__ counter, unsigned int capacity, int W,
-                                                   int H, float min_distance, int max_corners, int out_capacity,
-                                                   unsigned int *__restrict__ grid_global, float *__restrict__ out_xy,
-                                                   int *__restrict__ out_n)
+// Greedy minimum-distance selection over the sorted candidates.  grid: cells x 4 slots (x | y << 16, 0xFFFFFFFF =
+// empty), in dynamic LDS (IN_LDS) or in the workspace.  The whole workgroup clears the grid; the walk itself is one
+// wavefront, kBatch candidates per step: lane = 9 c + nb tests candidate c against the 4 slots of its neighbouring cell
+// nb, then the candidates of the step are settled among themselves in order (wave-uniform, positions by v_readlane).
+// Candidate positions come through an LDS chunk (one global round trip per 64 steps instead of one per step) and the
+// accepted corners leave through another: the serial chain touches LDS only.
+template <bool IN_LDS>
+__global__ __launch_bounds__(kBlock) void select_kernel(const unsigned long long *__restrict__ keys,
+                                                       const unsigned int *__restrict__ counter, unsigned int capacity, int W,
+                                                       int H, float min_distance, int max_corners, int out_capacity,
+                                                       unsigned int *__restrict__ grid_global, float *__restrict__ out_xy,
+                                                       int *__restrict__ out_n)
 {
     extern __shared__ unsigned int sGrid[];
-    const int lane = threadIdx.x;
+    constexpr int kBatch = 7;
+    constexpr int kChunk = 64 * kBatch;
+    constexpr int kStage = 1024;
+    __shared__ unsigned int sKeys[kChunk];
+    __shared__ unsigned int sAccepted[kStage];
+    const int lane = threadIdx.x & 63;
     unsigned int n = counter[0];
     if (n > capacity) n = capacity;
     int accepted = 0;
     const int limit = (max_corners > 0 && max_corners < out_capacity) ? max_corners : out_capacity;
     if (min_distance < 1.0f) {
-        for (unsigned int i = lane; i < n && (int)i < limit; i += 64) {
+        for (unsigned int i = threadIdx.x; i < n && (int)i < limit; i += kBlock) {
             const unsigned int pos = 0xFFFFFFFFu - (unsigned int)(keys[i] & 0xFFFFFFFFull);
-            out_xy[2 * i] = (float)(pos % W);
-            out_xy[2 * i + 1] = (float)(pos / W);
+            out_xy[2 * i] = (float)(pos & 0xFFFFu);
+            out_xy[2 * i + 1] = (float)(pos >> 16);
         }
-        if (lane == 0) out_n[0] = (int)(n < (unsigned)limit ? n : (unsigned)limit);
+        if (threadIdx.x == 0) out_n[0] = (int)(n < (unsigned)limit ? n : (unsigned)limit);
         return;
     }
     const int cell = (int)rintf(min_distance);
     const int gw = (W + cell - 1) / cell, gh = (H + cell - 1) / cell;
-    unsigned int *grid = grid_global ? grid_global : sGrid;
-    for (int i = lane; i < gw * gh * 4; i += 64) grid[i] = 0xFFFFFFFFu;
+    auto slot_ref = [&](int i) -> unsigned int & {
+        if constexpr (IN_LDS) return sGrid[i];
+        else return grid_global[i];
+    };
+    for (int i = threadIdx.x; i < gw * gh * 4; i += kBlock) slot_ref(i) = 0xFFFFFFFFu;
     __syncthreads();
-    const float md2 = min_distance * min_distance;
-    for (unsigned int i = 0; i < n && accepted < limit; ++i) {
-        const unsigned int pos = 0xFFFFFFFFu - (unsigned int)(keys[i] & 0xFFFFFFFFull);
-        const int x = (int)(pos % W), y = (int)(pos / W);
-        const int cx = x / cell, cy = y / cell;
+    if (threadIdx.x >= 64) return;
+    const float md2 = min_distance * min_distance, inv_cell = 1.0f / (float)cell;
+    const int c = lane / 9, nb = lane % 9;
+    for (unsigned int i0 = 0; i0 < n && accepted < limit; i0 += kBatch) {
+        if (i0 % kChunk == 0) {
+#pragma unroll
+            for (int m = 0; m < kBatch; ++m) {
+                const unsigned int ci = i0 + (unsigned)(64 * m + lane);
+                sKeys[64 * m + lane] = ci < n ? (unsigned int)(keys[ci] & 0xFFFFFFFFull) : 0u;
+            }
+            mqs_wave_lds_sync();
+        }
+        const unsigned int ci = i0 + (unsigned)c;
+        const bool have = lane < 9 * kBatch && ci < n;
+        int x = 0, y = 0, first_empty = 4, own_cell = 0;
         bool clash = false;
-        unsigned int own = 0;
-        if (lane < 36) {
-            const int nb = lane >> 2, slot = lane & 3;
-            const int yy = cy + nb / 3 - 1, xx = cx + nb % 3 - 1;
+        if (have) {
+            const unsigned int pos = 0xFFFFFFFFu - sKeys[(i0 % kChunk) + c];
+            x = (int)(pos & 0xFFFFu); y = (int)(pos >> 16);
+            // floor(x / cell) without an integer division (x < 65536 is exact in float; one correction step)
+            int cxx = (int)((float)x * inv_cell), cyy = (int)((float)y * inv_cell);
+            cxx += ((cxx + 1) * cell <= x) - (cxx * cell > x);
+            cyy += ((cyy + 1) * cell <= y) - (cyy * cell > y);
+            own_cell = cyy * gw + cxx;
+            const int yy = cyy + nb / 3 - 1, xx = cxx + nb % 3 - 1;
             if (yy >= 0 && yy < gh && xx >= 0 && xx < gw) {
-                const unsigned int v = grid[(yy * gw + xx) * 4 + slot];
-                if (nb == 4) own = v;
-                if (v != 0xFFFFFFFFu) {
-                    const float dx = (float)(x - (int)(v & 0xFFFFu)), dy = (float)(y - (int)(v >> 16));
-                    clash = dx * dx + dy * dy < md2;
+                unsigned int v[4];
+#pragma unroll
+                for (int slot = 0; slot < 4; ++slot) v[slot] = slot_ref((yy * gw + xx) * 4 + slot);
+#pragma unroll
+                for (int slot = 3; slot >= 0; --slot) {
+                    if (v[slot] != 0xFFFFFFFFu) {
+                        const float dx = (float)(x - (int)(v[slot] & 0xFFFFu)), dy = (float)(y - (int)(v[slot] >> 16));
+                        clash = clash || (dx * dx + dy * dy < md2);
+                    } else {
+                        first_empty = slot;                          // slots fill from 0: the lowest empty one
+                    }
                 }
             }
         }
-        if (__ballot(clash) != 0ull) continue;
-        // first empty slot of the own cell (lanes 16..19); a full cell cannot happen for points >= cell - 0.5 apart
-        const unsigned long long empties = __ballot(lane >= 16 && lane < 20 && own == 0xFFFFFFFFu);
-        if (empties != 0ull) {
-            const int first = __ffsll((long long)empties) - 1;
-            if (lane == first) grid[(cy * gw + cx) * 4 + (first - 16)] = (unsigned int)x | ((unsigned int)y << 16);
+        const unsigned long long clashes = __ballot(clash);
+        int xs[kBatch], ys[kBatch], fe[kBatch], oc[kBatch];
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) {
+            xs[j] = __builtin_amdgcn_readlane(x, 9 * j);
+            ys[j] = __builtin_amdgcn_readlane(y, 9 * j);
+            oc[j] = __builtin_amdgcn_readlane(own_cell, 9 * j);
+            fe[j] = __builtin_amdgcn_readlane(first_empty, 9 * j + 4);   // the lane that looked at the candidate's own cell
         }
-        if (lane == 0) { out_xy[2 * accepted] = (float)x; out_xy[2 * accepted + 1] = (float)y; }
-        ++accepted;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        unsigned int taken = 0;
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) {
+            if (i0 + j < n && accepted < limit && ((clashes >> (9 * j)) & 0x1FFull) == 0ull) {
+                // branch-free over the earlier candidates of the step (scalar branches would dominate the serial chain)
+                unsigned int bad = 0;
+                int slot = fe[j];
+#pragma unroll
+                for (int k = 0; k < j; ++k) {
+                    const float dx = (float)(xs[j] - xs[k]), dy = (float)(ys[j] - ys[k]);
+                    const unsigned int tk = (taken >> k) & 1u;
+                    bad |= tk & (unsigned int)(dx * dx + dy * dy < md2);
+                    slot += (int)(tk & (unsigned int)(oc[k] == oc[j]));      // same cell, taken this step
+                }
+                if (!bad) {
+                    taken |= 1u << j;
+                    if (lane == 0) {
+                        const unsigned int packed = (unsigned int)xs[j] | ((unsigned int)ys[j] << 16);
+                        sAccepted[accepted % kStage] = packed;
+                        // (a full cell cannot happen for points >= cell - 0.5 apart)
+                        if (slot < 4) slot_ref(oc[j] * 4 + slot) = packed;
+                    }
+                    ++accepted;
+                    if (accepted % kStage == 0) {                    // flush a full block (wave-uniform)
+                        mqs_wave_lds_sync();
+                        for (int t = lane; t < kStage; t += 64) {
+                            const unsigned int v = sAccepted[t];
+                            out_xy[2 * (accepted - kStage + t)] = (float)(v & 0xFFFFu);
+                            out_xy[2 * (accepted - kStage + t) + 1] = (float)(v >> 16);
+                        }
+                    }
+                }
+            }
+        }
+        if constexpr (IN_LDS) mqs_wave_lds_sync();
+        else __threadfence_block();                                  // the grid lives in global memory here
+    }
+    mqs_wave_lds_sync();
+    const int tail = accepted % kStage;
+    for (int t = lane; t < tail; t += 64) {
+        const unsigned int v = sAccepted[t];
+        out_xy[2 * (accepted - tail + t)] = (float)(v & 0xFFFFu);
+        out_xy[2 * (accepted - tail + t) + 1] = (float)(v >> 16);
     }
     if (lane == 0) out_n[0] = accepted;
 }
@@ -547,9 +623,22 @@ int mqs_good_features_to_track_dev(const uint8_t *img, int W, int H, int max_cor
     const int cell = min_distance >= 1.0 ? (int)rint(min_distance) : 1;
     const size_t cells = (size_t)((W + cell - 1) / cell) * ((H + cell - 1) / cell);
     const size_t lds = cells * 16;
-    const bool in_lds = min_distance >= 1.0 && lds <= 60 * 1024;
-    hipLaunchKernelGGL(select_kernel, dim3(1), dim3(64), in_lds ? lds : 0, stream, sorted, counter, (unsigned int)npx, W, H,
-                       (float)min_distance, max_corners, out_capacity, in_lds ? nullptr : grid, out_xy, out_n);
+    const bool in_lds = min_distance < 1.0 || lds <= 140 * 1024;
+    if (in_lds) {
+        if (lds > 48 * 1024) {
+            static bool lds_opt_in = false;                  // dynamic LDS above 64 KiB needs the opt-in once per process
+            if (!lds_opt_in) {
+                MQS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(select_kernel<true>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+                lds_opt_in = true;
+            }
+        }
+        hipLaunchKernelGGL(select_kernel<true>, dim3(1), dim3(kBlock), min_distance < 1.0 ? 0 : lds, stream, sorted, counter,
+                           (unsigned int)npx, W, H, (float)min_distance, max_corners, out_capacity, grid, out_xy, out_n);
+    } else {
+        hipLaunchKernelGGL(select_kernel<false>, dim3(1), dim3(kBlock), 0, stream, sorted, counter, (unsigned int)npx, W, H,
+                           (float)min_distance, max_corners, out_capacity, grid, out_xy, out_n);
+    }
     MQS_HIP_CHECK(hipGetLastError());
     return MQS_OK;
 }

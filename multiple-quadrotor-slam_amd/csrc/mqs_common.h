@@ -35,6 +35,16 @@ struct mqs_ctx {
 // Ensures ctx->dbuf holds at least `bytes`; returns MQS_OK or an error code.
 int mqs_ctx_reserve(mqs_ctx *ctx, size_t bytes);
 
+// Wave-private LDS hand-off (one lane writes, other lanes of the SAME wavefront read later): the LDS pipe executes a
+// wavefront's accesses in order, so all that is needed is that the compiler keeps the order (memory clobber) and the
+// writes have been issued (lgkmcnt).  A C++ fence at wavefront scope also waits for every outstanding GLOBAL access
+// (s_waitcnt vmcnt(0)) -- which puts the latency of prefetches issued just before it on the serial chain.
+__device__ __forceinline__ void mqs_wave_lds_sync()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
 static inline bool mqs_aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // Grid for streaming one-thread-per-item kernels: one workgroup per `block` items (the hardware

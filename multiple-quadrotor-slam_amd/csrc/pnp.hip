@@ -106,9 +106,7 @@ __device__ bool wave_dlt(const Problem &pr, const double *intr, int lane, double
             const bool ok = chol_solve_small(sA, sb, 8);
             sA[0] = ok ? 1.0 : 0.0;
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        mqs_wave_lds_sync();
         double hv[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) hv[k] = sb[k];
@@ -135,9 +133,7 @@ __device__ bool wave_dlt(const Problem &pr, const double *intr, int lane, double
         const bool ok = chol_solve_small(sA, sb, 11);
         sA[0] = ok ? 1.0 : 0.0;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    mqs_wave_lds_sync();
     double p[11];
 #pragma unroll
     for (int k = 0; k < 11; ++k) p[k] = sb[k];
