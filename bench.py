@@ -138,7 +138,9 @@ def main():
     roofline = {"bound": "hbm", "kernel": "tri_kernel<%d, iterative_ls>" % C, "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                 "traffic": traffic, "algorithmic_bytes_per_launch": bytes_it,
-                "avg_launch_ms": round(ms_it, 5)}
+                "avg_launch_ms": round(ms_it, 5),
+                "note": "dominant kernel of the triangulation metric; by time the step's largest kernel is "
+                        "ba_linearize_kernel (see rooflines): both are bound by fp64 VALU issue, not HBM"}
     kernels = {
         "iterative_ls": {"ms": round(ms_it, 5), "landmarks_per_s": round(N / (ms_it * 1e-3)),
                          "GBps": round(bytes_it / (ms_it * 1e-3) / 1e9, 1)},
