@@ -144,6 +144,23 @@ int mqs_match_knn2_bits_dev(const uint8_t *query_bits, int64_t Nq, const uint8_t
                             float *dist, void *workspace, int64_t workspace_bytes, void *stream);
 int64_t mqs_match_knn2_bits_workspace_bytes(int64_t Nq, int64_t Nt, int D);
 
+/* Caller-side filter of the reference's matcher use (Work/SLAM/application/own/slam.py:108-125) on the output of any
+ * mqs_match_knn2_*: per query keep the nearest train row when it lies within max_radius (the radius filter of
+ * cv2_helpers.py:311-331, compared in float32) and passes the ratio test (it is the only one within the radius, or
+ * dist0 / dist1 < max_dist_ratio with the division in double as Python does it; a 0 / 0 ratio fails where the reference
+ * raises ZeroDivisionError); then one match per train row: the query with the smallest priority[q] wins (the reference's
+ * err_OF; NULL: the match distance), the EARLIER query on equal priority (the reference replaces on strict `<` only).
+ * query_of_train [Nt] int32 (-1: unmatched), dist_of_train [Nt] float32 or NULL (+inf where unmatched).
+ * Deterministic (64-bit atomicMin on priority|query keys).  workspace: 8-byte aligned. */
+int mqs_match_ratio_unique_dev(const int32_t *idx, const float *dist, int64_t Nq, int64_t Nt, float max_radius,
+                               double max_dist_ratio, const float *priority, int32_t *query_of_train,
+                               float *dist_of_train, void *workspace, int64_t workspace_bytes, void *stream);
+int64_t mqs_match_ratio_unique_workspace_bytes(int64_t Nt);
+/* radiusMatch + ratio test + de-duplication in one host-pointer call (slam.py:101-125), exact float32 distances. */
+int mqs_match_radius_ratio_unique(mqs_ctx *ctx, const float *query, int64_t Nq, const float *train, int64_t Nt, int D,
+                                  float max_radius, double max_dist_ratio, const float *priority, int32_t *query_of_train,
+                                  float *dist_of_train);
+
 /* ---------------------------------------------------------------------------------------
  * Bundle adjustment: projection-factor linearisation + landmark Schur complement, the reduced
  * camera solve, and the landmark back-substitution (replaces the GTSAM work behind

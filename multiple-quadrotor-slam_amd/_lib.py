@@ -118,6 +118,11 @@ SIGNATURES = {
     "mqs_match_knn2_bits": (ctypes.c_int, [c_vp, c_u8p, c_i64, c_u8p, c_i64, ctypes.c_int, c_i32p, c_f32p]),
     "mqs_match_knn2_bits_dev": (ctypes.c_int, [c_vp, c_i64, c_vp, c_i64, ctypes.c_int, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "mqs_match_knn2_bits_workspace_bytes": (c_i64, [c_i64, c_i64, ctypes.c_int]),
+    "mqs_match_ratio_unique_dev": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i64, ctypes.c_float, ctypes.c_double, c_vp, c_vp, c_vp,
+                                                  c_vp, c_i64, c_vp]),
+    "mqs_match_ratio_unique_workspace_bytes": (c_i64, [c_i64]),
+    "mqs_match_radius_ratio_unique": (ctypes.c_int, [c_vp, c_f32p, c_i64, c_f32p, c_i64, ctypes.c_int, ctypes.c_float,
+                                                     ctypes.c_double, c_f32p, c_i32p, c_f32p]),
     "mqs_time_triangulate_dev": (ctypes.c_int, [ctypes.c_int, c_vp, c_vp, ctypes.c_int, c_i64, ctypes.c_double,
                                                 ctypes.c_int, c_vp, c_vp, c_vp, ctypes.c_int, c_vp,
                                                 ctypes.POINTER(ctypes.c_float)]),

@@ -118,9 +118,12 @@ class BundleAdjuster:
             _sp()))
         return self.lin
 
-    def all_reduce(self):
+    def all_reduce(self, async_op=False):
+        """Sum of the reduced camera system over ranks.  async_op=True returns the collective's work handle (or
+        None on one rank): the reduce then runs on RCCL's stream and `wait()` orders the current stream after it."""
         if self.pg is not None:
-            sharding.all_reduce_sum_(self.lin, None if self.pg is True else self.pg)
+            return sharding.all_reduce_sum_(self.lin, None if self.pg is True else self.pg, async_op=async_op)
+        return None
 
     def solve(self, lam=0.0, retract_into=None):
         out = self.poses_new if retract_into is None else retract_into
@@ -146,10 +149,16 @@ class BundleAdjuster:
         return self.cost_out
 
     # ---- iterations --------------------------------------------------------------------
-    def gauss_newton_iteration(self, lam=0.0):
-        """One undamped (lam = 0) or fixed-damping iteration, fully asynchronous."""
+    def gauss_newton_iteration(self, lam=0.0, overlap=None):
+        """One undamped (lam = 0) or fixed-damping iteration, fully asynchronous.  `overlap`: a callable that
+        enqueues work independent of this problem on the current stream; it is issued between the start of the
+        all-reduce and the wait for it, so that the latency-bound collective (4.8 KB over xGMI) hides under it."""
         self.linearize(lam)
-        self.all_reduce()
+        work = self.all_reduce(async_op=True)
+        if overlap is not None:
+            overlap()
+        if work is not None:
+            work.wait()
         self.solve(lam)
         self.backsub(lam)
         self.poses, self.poses_new = self.poses_new, self.poses

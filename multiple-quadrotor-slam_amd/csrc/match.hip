@@ -518,9 +518,77 @@ __global__ void expand_bits_kernel(const uint8_t *__restrict__ bits, int64_t n, 
     norm[i] = (float)pop;
 }
 
+
+// ---- caller-side filter of the reference (Work/SLAM/application/own/slam.py:108-125) -------------------------------
+// Per query: the radius filter of radiusMatch (cv2_helpers.py:311-331), then the ratio test (a single match inside the
+// radius passes; two pass when d0 / d1 < ratio, the division in double like the Python floats of DMatch.distance), then one
+// match per train index: the query with the smallest priority wins, the earlier query on equal priority (the reference
+// replaces only on strict `<` while walking the queries in order).  One 64-bit atomicMin per passing query on the key
+// (order-preserving image of the priority) << 32 | query -- the result does not depend on the execution order.
+__device__ __forceinline__ uint32_t orderable_f32(float f)
+{
+    if (f != f) return 0xffffffffu;                     // NaN ranks last (never preferred)
+    const uint32_t b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+__global__ void __launch_bounds__(256)
+ratio_unique_scatter_kernel(const int32_t *__restrict__ idx, const float *__restrict__ dist, int64_t Nq, int64_t Nt,
+                            float max_radius, double max_ratio, const float *__restrict__ priority,
+                            unsigned long long *__restrict__ keys)
+{
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= Nq) return;
+    const int2 i2 = reinterpret_cast<const int2 *>(idx)[q];
+    const float2 d2 = reinterpret_cast<const float2 *>(dist)[q];
+    const bool in0 = i2.x >= 0 && i2.x < Nt && d2.x <= max_radius;
+    const bool in1 = i2.y >= 0 && d2.y <= max_radius;
+    if (!in0) return;
+    if (in1 && !((double)d2.x / (double)d2.y < max_ratio)) return;       // 0 / 0 (NaN) fails, like every NaN compare
+    const float pr = priority ? priority[q] : d2.x;
+    const unsigned long long key = ((unsigned long long)orderable_f32(pr) << 32) | (unsigned long long)(uint32_t)q;
+    atomicMin(&keys[i2.x], key);
+}
+
+__global__ void __launch_bounds__(256)
+ratio_unique_gather_kernel(const unsigned long long *__restrict__ keys, const float *__restrict__ dist, int64_t Nt,
+                           int32_t *__restrict__ query_of_train, float *__restrict__ dist_of_train)
+{
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= Nt) return;
+    const unsigned long long k = keys[t];
+    const bool has = k != ~0ull;
+    const uint32_t q = (uint32_t)(k & 0xffffffffull);
+    query_of_train[t] = has ? (int32_t)q : -1;
+    if (dist_of_train) dist_of_train[t] = has ? dist[2 * (int64_t)q] : __builtin_inff();
+}
+
 }  // namespace
 
 extern "C" {
+
+int64_t mqs_match_ratio_unique_workspace_bytes(int64_t Nt) { return Nt < 0 ? 0 : (Nt + 1) * 8; }
+
+int mqs_match_ratio_unique_dev(const int32_t *idx, const float *dist, int64_t Nq, int64_t Nt, float max_radius,
+                               double max_dist_ratio, const float *priority, int32_t *query_of_train,
+                               float *dist_of_train, void *workspace, int64_t workspace_bytes, void *stream_)
+{
+    MQS_ARG_CHECK(Nq >= 0 && Nt >= 0 && Nq <= 0x7fffffff, "0 <= Nq < 2^31, Nt >= 0");
+    if (Nt == 0) return MQS_OK;
+    MQS_ARG_CHECK(query_of_train && workspace && (Nq == 0 || (idx && dist)), "pointers must not be null");
+    MQS_ARG_CHECK((reinterpret_cast<uintptr_t>(workspace) & 7u) == 0, "workspace must be 8-byte aligned");
+    MQS_ARG_CHECK(workspace_bytes >= mqs_match_ratio_unique_workspace_bytes(Nt), "workspace too small");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    unsigned long long *keys = static_cast<unsigned long long *>(workspace);
+    MQS_HIP_CHECK(hipMemsetAsync(keys, 0xff, (size_t)Nt * 8, stream));
+    if (Nq > 0)
+        hipLaunchKernelGGL(ratio_unique_scatter_kernel, dim3((unsigned)((Nq + 255) / 256)), dim3(256), 0, stream, idx, dist, Nq,
+                           Nt, max_radius, max_dist_ratio, priority, keys);
+    hipLaunchKernelGGL(ratio_unique_gather_kernel, dim3((unsigned)((Nt + 255) / 256)), dim3(256), 0, stream, keys, dist, Nt,
+                       query_of_train, dist_of_train);
+    MQS_HIP_CHECK(hipGetLastError());
+    return MQS_OK;
+}
 
 int mqs_match_knn2_f32_dev(const float *query, int64_t Nq, const float *train, int64_t Nt, int D, int32_t *idx,
                            float *dist, void *stream)
@@ -698,6 +766,43 @@ int mqs_match_knn2_f16(mqs_ctx *ctx, const uint16_t *query, int64_t Nq, const ui
     if (rc != MQS_OK) return rc;
     MQS_HIP_CHECK(hipMemcpyAsync(idx, d + o_i, (size_t)Nq * 8, hipMemcpyDeviceToHost, ctx->stream));
     MQS_HIP_CHECK(hipMemcpyAsync(dist, d + o_d, (size_t)Nq * 8, hipMemcpyDeviceToHost, ctx->stream));
+    MQS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return MQS_OK;
+}
+
+// radiusMatch + ratio test + one match per train index in one call (slam.py:101-125), float32 exact path
+int mqs_match_radius_ratio_unique(mqs_ctx *ctx, const float *query, int64_t Nq, const float *train, int64_t Nt, int D,
+                                  float max_radius, double max_dist_ratio, const float *priority, int32_t *query_of_train,
+                                  float *dist_of_train)
+{
+    MQS_ARG_CHECK(ctx != nullptr, "ctx must not be null");
+    MQS_ARG_CHECK(Nq >= 0 && Nt >= 0 && D >= 1 && Nq <= 0x7fffffff, "0 <= Nq < 2^31, Nt >= 0, D >= 1");
+    if (Nt == 0) return MQS_OK;
+    MQS_ARG_CHECK(train && query_of_train && (Nq == 0 || query), "pointers must not be null");
+    MQS_HIP_CHECK(hipSetDevice(ctx->device));
+    auto up = [](size_t v) { return (v + 255) & ~size_t(255); };
+    const size_t o_q = 0, o_t = up((size_t)Nq * D * 4), o_i = up(o_t + (size_t)Nt * D * 4), o_d = up(o_i + (size_t)Nq * 8);
+    const size_t o_p = up(o_d + (size_t)Nq * 8), o_k = up(o_p + (size_t)Nq * 4), o_o = up(o_k + (size_t)(Nt + 1) * 8);
+    const size_t o_e = up(o_o + (size_t)Nt * 4), total = up(o_e + (size_t)Nt * 4);
+    int rc = mqs_ctx_reserve(ctx, total);
+    if (rc != MQS_OK) return rc;
+    char *d = static_cast<char *>(ctx->dbuf);
+    if (Nq > 0) {
+        MQS_HIP_CHECK(hipMemcpyAsync(d + o_q, query, (size_t)Nq * D * 4, hipMemcpyHostToDevice, ctx->stream));
+        if (priority) MQS_HIP_CHECK(hipMemcpyAsync(d + o_p, priority, (size_t)Nq * 4, hipMemcpyHostToDevice, ctx->stream));
+    }
+    MQS_HIP_CHECK(hipMemcpyAsync(d + o_t, train, (size_t)Nt * D * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (Nq > 0) {
+        rc = launch_f32((const float *)(d + o_q), Nq, (const float *)(d + o_t), Nt, D, (int32_t *)(d + o_i), (float *)(d + o_d),
+                        ctx->stream);
+        if (rc != MQS_OK) return rc;
+    }
+    rc = mqs_match_ratio_unique_dev((const int32_t *)(d + o_i), (const float *)(d + o_d), Nq, Nt, max_radius, max_dist_ratio,
+                                    priority ? (const float *)(d + o_p) : nullptr, (int32_t *)(d + o_o), (float *)(d + o_e),
+                                    d + o_k, (int64_t)((Nt + 1) * 8), ctx->stream);
+    if (rc != MQS_OK) return rc;
+    MQS_HIP_CHECK(hipMemcpyAsync(query_of_train, d + o_o, (size_t)Nt * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (dist_of_train) MQS_HIP_CHECK(hipMemcpyAsync(dist_of_train, d + o_e, (size_t)Nt * 4, hipMemcpyDeviceToHost, ctx->stream));
     MQS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return MQS_OK;
 }

@@ -152,6 +152,80 @@ class BFMatcher:
                  if idx[qi, j] >= 0 and dist[qi, j] <= max_radius] for qi in range(len(idx))]
 
 
+def match_radius_ratio_unique(query_points, train_points, max_radius, max_dist_ratio, priority=None):
+    """
+    The reference's whole matcher use in one call (Work/SLAM/application/own/slam.py:101-125): radiusMatch (k = 2),
+    ratio test (a single match within the radius passes, two pass when dist0 / dist1 < max_dist_ratio), then at most one
+    match per train point -- the query with the smallest `priority` (the reference's err_OF; default: the match
+    distance), the earlier query on equal priority.  Returns {trainIdx: DMatch(queryIdx, trainIdx, distance)} like
+    the reference's `best_dist_matches_by_trainIdx`.
+    """
+    q = np.ascontiguousarray(query_points, dtype=np.float32)
+    t = np.ascontiguousarray(train_points, dtype=np.float32)
+    if q.ndim != 2 or t.ndim != 2 or q.shape[1] != t.shape[1]:
+        raise ValueError("query (Nq, D) and train (Nt, D) must have the same D")
+    Nq, Nt, D = len(q), len(t), q.shape[1]
+    pr = None
+    if priority is not None:
+        pr = np.ascontiguousarray(priority, dtype=np.float32)
+        if pr.shape != (Nq,):
+            raise ValueError("priority must have one entry per query")
+    qot = np.full(Nt, -1, dtype=np.int32)
+    dot = np.full(Nt, np.inf, dtype=np.float32)
+    _lib.check(_lib.lib().mqs_match_radius_ratio_unique(
+        _lib.default_context().handle, q.ctypes.data_as(c_f32p), c_i64(Nq), t.ctypes.data_as(c_f32p), c_i64(Nt), int(D),
+        ctypes.c_float(max_radius), ctypes.c_double(max_dist_ratio), None if pr is None else pr.ctypes.data_as(c_f32p),
+        qot.ctypes.data_as(c_i32p), dot.ctypes.data_as(c_f32p)))
+    return {int(ti): DMatch(int(qot[ti]), int(ti), float(dot[ti])) for ti in np.nonzero(qot >= 0)[0]}
+
+
+def ratio_unique_dev(idx, dist, n_train, max_radius, max_dist_ratio, priority=None, workspace=None):
+    """Device-resident filter on the (idx, dist) of any knn2*_dev: returns (query_of_train (Nt,) int32 with -1 for
+    unmatched train rows, dist_of_train (Nt,) float32)."""
+    import torch
+    if not (idx.is_cuda and dist.is_cuda and idx.is_contiguous() and dist.is_contiguous()):
+        raise ValueError("idx / dist must be contiguous device tensors")
+    if idx.dtype != torch.int32 or dist.dtype != torch.float32 or idx.shape != dist.shape or idx.dim() != 2 or idx.shape[1] != 2:
+        raise ValueError("idx (Nq, 2) int32 and dist (Nq, 2) float32 as produced by knn2")
+    if priority is not None and not (priority.is_cuda and priority.dtype == torch.float32 and priority.is_contiguous()
+                                     and tuple(priority.shape) == (idx.shape[0],)):
+        raise ValueError("priority must be a contiguous float32 device tensor with one entry per query")
+    Nq, Nt = int(idx.shape[0]), int(n_train)
+    qot = torch.empty(Nt, dtype=torch.int32, device=idx.device)
+    dot = torch.empty(Nt, dtype=torch.float32, device=idx.device)
+    need = int(_lib.lib().mqs_match_ratio_unique_workspace_bytes(Nt))
+    ws = workspace if workspace is not None else torch.empty(max(need, 16) // 8 + 1, dtype=torch.int64, device=idx.device)
+    _lib.check(_lib.lib().mqs_match_ratio_unique_dev(
+        idx.data_ptr(), dist.data_ptr(), Nq, Nt, ctypes.c_float(max_radius), ctypes.c_double(max_dist_ratio),
+        None if priority is None else priority.data_ptr(), qot.data_ptr(), dot.data_ptr(), ws.data_ptr(),
+        ws.numel() * ws.element_size(), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    return qot, dot
+
+
+def camera_pairs(n_cams):
+    """The unordered camera pairs (a < b) of a cross-match, in the order they are dealt to ranks."""
+    return [(a, b) for a in range(n_cams) for b in range(a + 1, n_cams)]
+
+
+def cross_match_dev(descriptor_bits, rank=0, world=1, max_radius=float("inf"), max_dist_ratio=0.8):
+    """
+    BASELINE configs[2]: brute-force cross-match of the packed binary descriptors of every camera against every other
+    camera (list of (n_c, D / 8) uint8 device tensors).  For the pair (a, b), a < b, camera a's descriptors are the
+    queries and camera b's the train set.  The pairs are independent units: rank r of `world` handles the pairs
+    `sharding.unit_shard` deals to it (pair-major, no collective).  Returns
+    {(a, b): (idx (n_a, 2), dist (n_a, 2), query_of_train (n_b,), dist_of_train (n_b,))} for this rank's pairs.
+    """
+    from . import sharding
+    pairs = camera_pairs(len(descriptor_bits))
+    out = {}
+    for k in sharding.unit_shard(len(pairs), rank, world):
+        a, b = pairs[k]
+        idx, dist = knn2_bits_dev(descriptor_bits[a], descriptor_bits[b])
+        qot, dot = ratio_unique_dev(idx, dist, int(descriptor_bits[b].shape[0]), max_radius, max_dist_ratio)
+        out[(a, b)] = (idx, dist, qot, dot)
+    return out
+
+
 def binary_descriptors(n, bits=256, seed=7, copies_of=None, copy_frac=0.5, flip_frac=0.1):
     """SURVEY.md 8(d) matcher workload: n descriptors of `bits` i.i.d. Bernoulli(0.5) bits (PCG64(seed)),
     optionally with `copy_frac` of the rows being copies of rows of `copies_of` with `flip_frac` of

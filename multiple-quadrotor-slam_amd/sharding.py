@@ -21,6 +21,13 @@ def landmark_shard(N, rank, world):
     return (rank * N) // world, ((rank + 1) * N) // world
 
 
+def unit_shard(n_units, rank, world):
+    """Indices of the independent work units (matcher camera pairs, sequences) dealt round-robin to `rank`."""
+    if not (0 <= rank < world):
+        raise ValueError("rank %d out of range for world size %d" % (rank, world))
+    return list(range(rank, n_units, world))
+
+
 def shard_arrays(rank, world, points, obs, mask=None, prior_w=None, prior_xyz=None):
     """Slices the per-landmark arrays (numpy or torch; landmark axis = 0 for points/priors, 1 for
     obs/mask) for this rank.  Returns copies that start at a fresh (aligned) allocation."""
@@ -33,12 +40,14 @@ def shard_arrays(rank, world, points, obs, mask=None, prior_w=None, prior_xyz=No
             None if prior_w is None else cp(prior_w[a:b]), None if prior_xyz is None else cp(prior_xyz[a:b]))
 
 
-def all_reduce_sum_(tensor, group=None):
-    """In-place sum over ranks of the reduced camera system (no-op without an initialised group)."""
+def all_reduce_sum_(tensor, group=None, async_op=False):
+    """In-place sum over ranks of the reduced camera system (no-op without an initialised group).
+    Returns the tensor, or with async_op=True the work handle (None when there is nothing to wait for)."""
     import torch.distributed as dist
+    work = None
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=group)
-    return tensor
+        work = dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+    return work if async_op else tensor
 
 
 def init_from_env(backend="nccl"):

@@ -32,7 +32,13 @@ def _worker(rank, world, port, q):
                                                               sc["prior_w"], sc["prior_xyz"])
     S, g, cost, nv, pieces = ba_np.linearize(sc["poses"], sc["calib"], sc["sigma"], pts, obs, mask, pw, px)
     lin = torch.from_numpy(np.concatenate([S.reshape(-1), g, [cost, nv]]))
-    mqslam_amd.sharding.all_reduce_sum_(lin)
+    lin_sync = mqslam_amd.sharding.all_reduce_sum_(lin.clone())
+    # the overlapped form the GN iteration uses: start the reduce, do unrelated work, wait
+    work = mqslam_amd.sharding.all_reduce_sum_(lin, async_op=True)
+    assert work is not None
+    unrelated = float(np.square(obs).sum())
+    work.wait()
+    assert torch.equal(lin, lin_sync) and np.isfinite(unrelated)
     n6 = 18
     Sr = lin[:n6 * n6].numpy().reshape(n6, n6)
     gr = lin[n6 * n6:n6 * n6 + n6].numpy()

@@ -1,0 +1,102 @@
+"""
+The multi-rank path on the real kernels: two ranks share the one GPU of the test
+box (transport gloo -- one device cannot host two RCCL ranks; sharding.init_from_env's test hooks),
+each holds its landmark shard, and three Gauss-Newton iterations with the overlapped all-reduce of
+the reduced camera system give the poses and landmarks of the single-rank run to <= 1e-10.
+Also: bench.py under torch.distributed.run prints the contract's JSON line with n_gpus = 2.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+WORKER = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import torch
+import mqslam_amd
+from ba_util import make_scene
+rank, local_rank, world = mqslam_amd.sharding.init_from_env()
+dev = torch.device("cuda", 0)
+sc = make_scene(4001, 4, seed=11)
+pts, obs, mask, pw, px = mqslam_amd.sharding.shard_arrays(rank, world, sc["points"], sc["obs"], sc["mask"],
+                                                          sc["prior_w"], sc["prior_xyz"])
+t = lambda a, dt=torch.float64: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev).to(dt)
+C = 4
+pose_prior = (t(sc["poses_true"]), t(np.tile([0.02, 0.02, 0.02, 0.1, 0.1, 0.1], (C, 1))),
+              t(np.array([1, 0, 0, 0], dtype=np.uint8), torch.uint8))
+ba = mqslam_amd.bundle_adjustment.BundleAdjuster(t(sc["poses"]), t(sc["calib"]), t(sc["sigma"]), t(pts), t(obs), None,
+                                                 t(pw), t(px), pose_prior, True if world > 1 else None)
+u, P, _ = mqslam_amd.synthetic.triangulation_problem(5000, 4)
+ud, Pd = torch.from_numpy(u).to(dev), torch.from_numpy(np.ascontiguousarray(P)).to(dev)
+xo = torch.empty((5000, 3), dtype=torch.float64, device=dev)
+calls = []
+def other_work():
+    calls.append(1)
+    mqslam_amd.device.linear_LS_triangulation(ud, Pd, out=xo)
+costs = []
+for _ in range(3):
+    costs.append(ba.total_cost())
+    ba.gauss_newton_iteration(overlap=other_work)
+costs.append(ba.total_cost())
+assert len(calls) == 3
+np.savez(os.path.join({out!r}, "r%d_of_%d.npz" % (rank, world)), poses=ba.poses.cpu().numpy(),
+         points=ba.points.cpu().numpy(), costs=np.array(costs), x=xo.cpu().numpy())
+if world > 1:
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+"""
+
+
+def _run(world, tmp_path, script):
+    env = dict(os.environ, MQS_DIST_BACKEND="gloo", MQS_SHARED_GPU="1", MASTER_ADDR="127.0.0.1")
+    if world == 1:
+        cmd = [sys.executable, script]
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+               "--master-addr", "127.0.0.1", "--master-port", str(29600 + os.getpid() % 300), script]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return r
+
+
+def test_two_ranks_equal_one_rank(gpu, tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER.format(root=ROOT, out=str(tmp_path)))
+    _run(1, tmp_path, str(script))
+    _run(2, tmp_path, str(script))
+    one = np.load(tmp_path / "r0_of_1.npz")
+    two = [np.load(tmp_path / ("r%d_of_2.npz" % r)) for r in range(2)]
+    np.testing.assert_array_equal(two[0]["poses"], two[1]["poses"])              # same solve on every rank, no broadcast
+    assert np.abs(two[0]["poses"] - one["poses"]).max() <= 1e-10
+    pts = np.concatenate([two[0]["points"], two[1]["points"]])
+    assert pts.shape == one["points"].shape
+    assert np.abs(pts - one["points"]).max() <= 1e-10 * max(1.0, np.abs(one["points"]).max())
+    assert np.allclose(two[0]["costs"], one["costs"], rtol=1e-10, atol=0)
+    assert one["costs"][-1] < one["costs"][0]
+    np.testing.assert_array_equal(two[0]["x"], one["x"])                         # the overlapped work is untouched
+
+
+def test_bench_contract_two_ranks(gpu, tmp_path):
+    cmd = ["--gpus", "2", "--steps", "3", "--warmup", "1", "--landmarks", "20000", "--no-match", "--no-replay",
+           "--no-frontend", "--no-cpu-baseline"]
+    env = dict(os.environ, MQS_DIST_BACKEND="gloo", MQS_SHARED_GPU="1", MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(29300 + os.getpid() % 300),
+                        os.path.join(ROOT, "bench.py")] + cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                                       # rank 0 prints ONE line
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["steps"] == 3 and out["warmup"] == 1
+    assert out["value"] > 0 and out["config"]["landmarks_per_gpu"] == 20000
+    assert out["ba"]["landmarks_total"] == 40000
+    for key in ("roofline", "cpu_baseline", "vs_baseline", "dtype", "unit", "metric", "ms_per_step"):
+        assert key in out

@@ -144,3 +144,70 @@ def test_f16_full_size_properties_64k(gpu):
     si, sd = gpu.matching.knn2_dev(t, t)
     torch.cuda.synchronize()
     assert torch.equal(si[:, 0].cpu(), torch.arange(N, dtype=torch.int32)) and float(sd[:, 0].abs().max()) == 0.0
+
+
+def test_camera_pairs_deal_to_ranks(mqs):
+    pairs = mqs.matching.camera_pairs(4)
+    assert pairs == [(0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 3)]                 # BASELINE configs[2]: 6 unordered pairs
+    for world in (1, 2, 4, 8):
+        dealt = [k for r in range(world) for k in mqs.sharding.unit_shard(len(pairs), r, world)]
+        assert sorted(dealt) == list(range(6))                                       # every pair exactly once
+    assert mqs.sharding.unit_shard(6, 7, 8) == []                                    # more ranks than pairs: idle rank
+    with pytest.raises(ValueError):
+        mqs.sharding.unit_shard(6, 2, 2)
+
+
+def _as_tuples(best):
+    return {k: (m.queryIdx, m.trainIdx, m.distance) for k, m in best.items()}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(400, 800, 2.0, 0.7, "err"), (400, 800, 4.0, 0.9, "err"), (1000, 300, 3.0, 0.8, "ties"),
+                                  (300, 50, 6.0, 0.99, None), (5, 1, 2.0, 0.7, "err"), (0, 10, 2.0, 0.7, None),
+                                  (2000, 2000, 1.0, 0.5, "ties")])
+def test_radius_ratio_unique_equals_reference_loop(case, gpu):
+    """slam.py:101-125 in one call: radius filter, ratio test, one match per train point by priority, first query on ties."""
+    Nq, Nt, radius, ratio, pri = case
+    rng = np.random.default_rng(Nq + Nt)
+    train = np.rint(rng.uniform(0, 80, (Nt, 2)) * 2).astype(np.float32) / 2          # half-pixel grid: duplicates and exact ties
+    query = (train[rng.integers(0, Nt, Nq)] + np.rint(rng.normal(0, 1.0, (Nq, 2)) * 2) / 2).astype(np.float32)
+    if pri == "err":
+        err = rng.random(Nq).astype(np.float32)
+    elif pri == "ties":
+        err = rng.integers(0, 3, Nq).astype(np.float32)                               # many equal priorities
+    else:
+        err = None
+    got = gpu.matching.match_radius_ratio_unique(query, train, radius, ratio, err)
+    two = M.radius_match(query, train, radius)
+    # the reference divides by the second distance: exclude exact 0 / 0 pairs from the loop (it raises there; the kernel drops them)
+    two = [ms if not (len(ms) == 2 and ms[1].distance == 0.0) else [] for ms in two]
+    ref_err = err if err is not None else np.array([ms[0].distance if ms else np.inf for ms in two], dtype=np.float32)
+    ref = M.ratio_test_and_dedupe(two, ref_err, ratio)
+    assert _as_tuples(got) == _as_tuples(ref)
+    assert Nq == 0 or len(ref) > 0
+
+
+@pytest.mark.gpu
+def test_cross_match_all_camera_pairs(gpu):
+    """BASELINE configs[2] in small: every camera against every other one, pairs dealt to ranks, filter on the device."""
+    import torch
+    sizes = [700, 513, 300, 64]
+    base = gpu.matching.binary_descriptors(sizes[0], 256, seed=31)
+    bits = [base] + [gpu.matching.binary_descriptors(n, 256, seed=32 + c, copies_of=base.astype(np.uint8))
+                     for c, n in enumerate(sizes[1:])]
+    packed = [torch.from_numpy(gpu.matching.pack_bits(b)).cuda() for b in bits]
+    seen = {}
+    for rank in range(4):
+        seen.update(gpu.matching.cross_match_dev(packed, rank, 4, max_radius=9.0, max_dist_ratio=0.8))
+    assert sorted(seen) == gpu.matching.camera_pairs(4)
+    assert seen.keys() == gpu.matching.cross_match_dev(packed).keys()
+    for (a, b), (idx, dist, qot, dot) in seen.items():
+        io, do = M.knn2_hamming_bits(bits[a], bits[b])
+        np.testing.assert_array_equal(idx.cpu().numpy(), io)
+        np.testing.assert_array_equal(dist.cpu().numpy(), do)
+        two = [[M.DMatch(q, int(io[q, k]), float(do[q, k])) for k in range(2) if io[q, k] >= 0 and do[q, k] <= 9.0]
+               for q in range(len(io))]
+        ref = M.ratio_test_and_dedupe(two, do[:, 0], 0.8)
+        qn, dn = qot.cpu().numpy(), dot.cpu().numpy()
+        assert {int(t): (int(qn[t]), int(t), float(dn[t])) for t in np.nonzero(qn >= 0)[0]} == _as_tuples(ref)
+        assert len(ref) > 0
