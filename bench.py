@@ -133,18 +133,21 @@ def main():
     bytes_eg = N * (16 * C + 24 + 1)
     achieved = bytes_it / (ms_it * 1e-3) / 1e9
     traffic = None
+    valu = None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc_path):
         try:
             rec = json.load(open(pmc_path))
             if rec.get("landmarks") == N and rec.get("cams") == C:
                 traffic = rec.get("iterative_ls_hbm_bytes_per_launch")
+                valu = rec.get("valu")
         except Exception:
             traffic = None
     roofline = {"bound": "hbm", "kernel": "tri_kernel<%d, iterative_ls>" % C, "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                 "traffic": traffic, "algorithmic_bytes_per_launch": bytes_it,
                 "avg_launch_ms": round(ms_it, 5),
+                "valu_pmc": (valu or {}).get("iterative_ls"),
                 "note": "dominant kernel of the triangulation metric; by time the step's largest kernel is "
                         "ba_linearize_kernel (see rooflines): both are bound by fp64 VALU issue, not HBM"}
     kernels = {
@@ -236,6 +239,7 @@ def main():
         back_gbps = N * (24 + 16 * C + 24) / (ba_out["kernels_ms"]["backsub"] * 1e-3) / 1e9
         rooflines["ba_linearize_schur"] = {"bound": "hbm", "achieved": round(lin_gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                            "frac": round(lin_gbps / HBM_PEAK_GBPS, 4),
+                                           "valu_pmc": (valu or {}).get("ba_linearize_schur"),
                                            "note": "fp64 VALU issue binds before HBM (DESIGN.md)"}
         rooflines["ba_backsub"] = {"bound": "hbm", "achieved": round(back_gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                    "frac": round(back_gbps / HBM_PEAK_GBPS, 4)}

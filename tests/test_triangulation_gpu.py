@@ -184,3 +184,28 @@ def test_full_size_properties_1e6x4(gpu, c_oracle):
         assert np.all(np.sum((np.einsum("nij,nj->ni", A, xp) - b) ** 2, axis=1) >= r0 * (1 - 1e-12))
     # sanity: the triangulated cloud is close to the true one (noise-limited, not bug-limited)
     assert np.sqrt(np.mean(np.sum((x_ls_h - pts) ** 2, axis=1))) < 0.2
+
+
+def test_baseline_config0_10k_two_cameras(gpu, c_oracle):
+    """BASELINE configs[0]: the scaled synthetic generator at 10 000 landmarks x 2 cameras, all three methods through
+    the reference-shaped 2-view facade (the call `method(u1, cam1.P, u2, cam2.P)` of triangulation_comparison.py:468)
+    against the C oracle and, for the linear DLT, the numpy restatement of the reference's Python twin."""
+    from oracle import triangulation_np as T
+    u, P, pts = gpu.synthetic.triangulation_problem(10_000, 2)
+    t = gpu.triangulation
+    P4 = [np.vstack([P[c], [0, 0, 0, 1.0]]) for c in range(2)]                       # slam2.py:554-555 passes 4x4 matrices
+    for name, fn, oracle_fn in (("linear_eigen", t.linear_eigen_triangulation, c_oracle.linear_eigen_triangulation),
+                                ("linear_LS", t.linear_LS_triangulation, c_oracle.linear_LS_triangulation),
+                                ("iterative_LS", t.iterative_LS_triangulation, c_oracle.iterative_LS_triangulation)):
+        x, s = fn(u[0], P4[0], u[1], P4[1])
+        xo, so = oracle_fn(u, P)
+        assert x.shape == (10_000, 3) and np.max(rel_err(x, xo)) < TOL, name
+        good = stable_mask(oracle_fn, u, P, xo, None if name == "linear_LS" else so)
+        assert good.mean() > 0.995
+        np.testing.assert_array_equal(np.asarray(s)[good], np.asarray(so)[good].astype(np.asarray(s).dtype))
+        assert np.median(np.linalg.norm(x - pts[:, :3], axis=1)) < 0.5               # and it is the scene that was generated
+    xn, _ = T.linear_eigen_triangulation(u[:, :500], P)
+    assert np.max(rel_err(t.linear_eigen_triangulation(u[0, :500], P[0], u[1, :500], P[1])[0], xn)) < TOL
+    xl = T.linear_LS_triangulation(u[:, :500], P)
+    xl = xl[0] if isinstance(xl, tuple) else xl
+    assert np.max(rel_err(t.linear_LS_triangulation(u[0, :500], P[0], u[1, :500], P[1])[0], xl)) < TOL
