@@ -460,3 +460,143 @@ def save_result(filenames, data):
     save_map(filenames.map_out, data.points3D, data.colors)
     for c in range(len(data.poses)):
         save_trajectory(filenames.trajectories_out[c], data.poses[c])
+
+
+# ---- recorder + writer of the BA problem on the SLAM side (slam2.py:743-865) --------------------------------
+
+class BundleAdjustmentInfoContainer:
+    """
+    What the per-frame loop records for the bundle adjuster, step by step, and the writer of the `BA_info.*` file set --
+    same member functions, file names and line formats as the reference's class of this name
+    (Work/SLAM/application/own/slam2.py:743-865), so that `load_data` / tools/bundle_adjust.py (and the reference's own
+    `bundle_adjust` binary) read what `slam_loop.MonoSlam` writes.  One "step" per frame (`next_step`).
+    """
+
+    def __init__(self, base_dir, base_name, num_cams=1):
+        self.base_dir, self.base_name, self.num_cams = base_dir, base_name, num_cams
+        self.calibrations = [None] * num_cams
+        self.odometry, self.odometryAssocs = [], []
+        self.points2D = [[] for _ in range(num_cams)]
+        self.point2D3DAssocs = [[] for _ in range(num_cams)]
+        self.point3DAddedIdxs = []
+        self.step = -1
+        self.next_step()
+
+    def next_step(self):                                           # :761-768
+        self.odometry.append([])
+        self.odometryAssocs.append([])
+        for cam in range(self.num_cams):
+            self.points2D[cam].append(np.zeros((0, 2)))
+            self.point2D3DAssocs[cam].append(np.zeros((0, 3), dtype=np.int64))
+        self.point3DAddedIdxs.append([])
+        self.step += 1
+
+    def set_calibration(self, K, distCoeffs, cam=0):               # :770-771
+        self.calibrations[cam] = (np.asarray(K, dtype=np.float64), np.asarray(distCoeffs, dtype=np.float64).reshape(-1))
+
+    def add_odometry(self, odometry, from_frame, to_frame, from_cam=0, to_cam=0):      # :773-775
+        """odometry: 4x4 (or 3x4) transform P with P_to = P * P_from (world->camera matrices; trfm.delta_P)."""
+        self.odometry[self.step].append(np.asarray(odometry, dtype=np.float64))
+        self.odometryAssocs[self.step].append((from_cam, from_frame, to_cam, to_frame))
+
+    def add_points2D_3Dassoc(self, points2D, point3DIdxs, frame, cam=0):               # :777-786
+        points2D = np.asarray(points2D, dtype=np.float64).reshape(-1, 2)
+        assocs = np.empty((len(points2D), 3), dtype=np.int64)
+        assocs[:, 0] = frame
+        start = len(self.points2D[cam][frame])
+        assocs[:, 1] = np.arange(start, start + len(points2D))
+        assocs[:, 2] = point3DIdxs
+        self.points2D[cam][frame] = np.concatenate((self.points2D[cam][frame], points2D))
+        self.point2D3DAssocs[cam][self.step] = np.concatenate((self.point2D3DAssocs[cam][self.step], assocs))
+
+    def set_point3DAddedIdxs(self, point3DAddedIdxs):              # :788-790
+        self.point3DAddedIdxs[self.step] = [int(i) for i in point3DAddedIdxs]
+
+    # ---- writers (:792-865) ----
+    def _write(self, title, lines, cam=-1, omit_base_name=False):
+        name = "BA_info.%s%s%s.txt" % (title, (".cam%s" % cam) if cam > -1 else "", "" if omit_base_name else "-%s" % self.base_name)
+        with open(os.path.join(self.base_dir, name), "w") as f:
+            f.write("\n".join(lines + [""]))
+
+    def write_calibrations(self, cam):
+        K, d = self.calibrations[cam]
+        if len(d) > 4 and d[4] != 0.0:
+            raise AttributeError("the optimiser's camera model (Cal3DS2) has no 6th-order radial coefficient")
+        d4 = tuple(d[:4]) + (0.0,) * (4 - min(len(d), 4))
+        self._write("calibrations", ["# Format: fx fy shear u0 v0 k1 k2 p1 p2",
+                                     "%.16e %.16e %.16e %.16e %.16e %.16e %.16e %.16e %.16e"
+                                     % ((K[0, 0], K[1, 1], K[0, 1], K[0, 2], K[1, 2]) + d4)], cam, omit_base_name=True)
+
+    @staticmethod
+    def _steps(lines, per_step, fmt):
+        for step, items in enumerate(per_step):
+            if step:
+                lines.append("")
+            lines.extend(fmt(x) for x in items)
+        return lines
+
+    def write_odometry(self):
+        def fmt(P):                                                # trfm.pose_TUM_from_P: the INVERSE transform as location + quaternion
+            R, t = P[:3, :3], P[:3, 3]
+            q = R_to_quat(R.T)
+            return "%.16e %.16e %.16e %.16e %.16e %.16e %.16e" % (tuple(-R.T @ t) + tuple(q))
+        self._write("measurements.odometry", self._steps(
+            ["# Format: tx ty tz qx qy qz qw", "# Newline means next odometry; Empty line means next step"], self.odometry, fmt))
+
+    def write_odometryAssocs(self):
+        self._write("measurements.odometryAssocs", self._steps(
+            ["# Format: from_cam from_frame to_cam to_frame", "# Newline means next odometry; Empty line means next step"],
+            self.odometryAssocs, lambda a: " ".join(str(int(v)) for v in a)))
+
+    def write_points2D(self, cam):
+        self._write("measurements.points2D", self._steps(
+            ["# Format: x y", "# Newline means next feature; Empty line means next frame, first feature"],
+            self.points2D[cam], lambda p: "%.16e %.16e" % tuple(p)), cam)
+
+    def write_point2D3DAssocs(self, cam):
+        self._write("measurements.point2D3DAssocs", self._steps(
+            ["# Format: frameIdx point2DIdx point3DIdx", "# Newline means next feature; Empty line means next step, first feature"],
+            self.point2D3DAssocs[cam], lambda a: " ".join(str(int(v)) for v in a)), cam)
+
+    def write_point3DAddedIdxs(self):
+        self._write("measurements.point3DAddedIdxs", self._steps(
+            ["# Format: point3DIdx", "# Newline means next point; Empty line means next step"], self.point3DAddedIdxs, str))
+
+    def write_noise(self, pose=(0.002, 0.002, 0.002, 0.001, 0.001, 0.001), odometry=(0.05, 0.05, 0.05, 0.2, 0.2, 0.2),
+                    point3D=0.25, point2D=5.0):
+        """The four hand-written noise files of a data set (not produced by slam2.py; defaults = the values committed with
+        the reference's SVO run, datasets/SVO/sin2_tex2_h1_v8_d/BA_info.noise.*-slam2.txt)."""
+        head = lambda dim: ["# Format: noiseType noiseSpecificValues", "# The dimension of the noise is equal to %d." % dim]
+        diag = lambda v: "Diagonal " + " ".join("%.16g" % x for x in v)
+        for cam in range(self.num_cams):
+            self._write("noise.pose", head(6) + [diag(pose)], cam)
+            self._write("noise.point2D", head(2) + ["Isotropic %.16g" % point2D], cam)
+        rows = []
+        for a in range(self.num_cams):
+            if a:
+                rows.append("")
+            rows.extend(diag(odometry) for _ in range(self.num_cams))
+        self._write("noise.odometry", head(6) + rows)
+        self._write("noise.point3D", head(3) + ["Isotropic %.16g" % point3D])
+
+    def write_all(self):                                           # :856-865
+        for cam in range(self.num_cams):
+            self.write_calibrations(cam)
+            self.write_points2D(cam)
+            self.write_point2D3DAssocs(cam)
+        self.write_odometry()
+        self.write_odometryAssocs()
+        self.write_point3DAddedIdxs()
+
+
+def save_slam_output(filenames, fps, Ps, points3D, cam=0):
+    """slam2.py:698-741 `write_output`: the trajectory in TUM format (world->camera matrices Ps, None for rejected frames;
+    timestamp of frame i = (1 + i) / fps, dataset_tools.py:275-294) and the map as PCD."""
+    nodes = []
+    for i, P in enumerate(Ps):
+        if P is None:
+            continue
+        R, t = np.asarray(P)[:3, :3], np.asarray(P)[:3, 3]
+        nodes.append(((1.0 + i) / fps, np.concatenate([R.T.reshape(-1), -R.T @ t])))
+    save_trajectory(filenames.trajectories_in[cam], nodes)
+    save_map(filenames.map_in, np.asarray(points3D, dtype=np.float64))

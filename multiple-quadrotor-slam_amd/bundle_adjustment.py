@@ -291,6 +291,29 @@ class BundleAdjuster:
         }
 
 
+def bundle_adjust(poses, calib, sigma, points, obs, mask=None, prior_w=None, prior_xyz=None, pose_prior=None,
+                  iters=10, mode="gn", device=0):
+    """
+    numpy in / numpy out form of the optimiser (BA boundary (i)): uploads the problem, runs
+    `iters` Gauss-Newton iterations (mode="gn") or Levenberg-Marquardt with GTSAM's default schedule (mode="lm",
+    bundle_adjust.cpp:323-324) on the device and returns (poses (C,12), points (N,3), cost_history).
+    Shapes as in BundleAdjuster; pose_prior = (prior_poses (C,12), prior_sigmas (C,6), prior_mask (C,)) or None.
+    """
+    torch = _torch()
+    _lib.lib()                                                   # raises without the HIP library: no CPU path
+    dev = torch.device("cuda", int(device))
+    f64 = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev)
+    u8 = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a, dtype=np.uint8)).to(dev)
+    pp = None
+    if pose_prior is not None:
+        pp = (f64(pose_prior[0]), f64(pose_prior[1]), u8(pose_prior[2]))
+    with torch.cuda.device(dev):
+        ba = BundleAdjuster(f64(poses), f64(calib), f64(np.asarray(sigma, dtype=np.float64).reshape(-1)), f64(points), f64(obs),
+                            u8(mask), f64(prior_w), f64(prior_xyz), pp)
+        hist = ba.optimize(iters=iters, mode=mode)
+        return ba.poses.cpu().numpy(), ba.points.cpu().numpy(), hist
+
+
 def pose_from_world_to_camera(P):
     """3x4 world->camera matrix [R_wc | t_wc] -> camera-to-world pose12 (IO.hpp:221-227 convention)."""
     Rwc, twc = P[:, :3], P[:, 3]

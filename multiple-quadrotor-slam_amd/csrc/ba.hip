@@ -147,8 +147,8 @@ struct DevObs {
         u = 0.0; v = 0.0; seen = false;
         if (live) {
             const double2 t = o2[(int64_t)c * N + i];
-            u = t.x; v = t.y;
             seen = mask ? (mask[(int64_t)c * N + i] != 0) : true;
+            u = seen ? t.x : 0.0; v = seen ? t.y : 0.0;       // a masked slot may hold NaN
         }
     }
 };
@@ -472,18 +472,24 @@ __global__ __launch_bounds__(64) void ba_solve_kernel(const double *__restrict__
     }
     bool bad = false;
     double dinv = 1.0;
+    // Column k of L goes through LDS once per step and comes back as broadcast reads (one address for the whole wave,
+    // two entries per ds_read_b128): the v_readlane pair per (k, j) of the first version put ~550 scalar round trips on
+    // the serial chain.  One wave: the LDS pipe keeps its accesses in order, no barrier needed (mqs_wave_lds_sync).
+    __shared__ __attribute__((aligned(16))) double sCol[64];
 #pragma unroll
     for (int k = 0; k < n; ++k) {
         const double akk = read_lane(row[k], k);
         bad = bad || !(akk > 0.0);
-        const double inv = 1.0 / sqrt(akk > 0.0 ? akk : 1.0);
+        const double inv = mqs::rsqrt_d(akk > 0.0 ? akk : 1.0);
         const double lik = row[k] * inv;             // L[lane][k] for lane >= k (lane k: the pivot)
         row[k] = lik;
         if (lane == k) dinv = inv;
+        if (k + 1 < n) {
+            sCol[lane] = lik;
+            mqs_wave_lds_sync();
 #pragma unroll
-        for (int j = k + 1; j < n; ++j) {
-            const double ljk = read_lane(lik, j);
-            row[j] = fma(-lik, ljk, row[j]);         // only entries j <= lane are used later
+            for (int j = k + 1; j < n; ++j) row[j] = fma(-lik, sCol[j], row[j]);   // only entries j <= lane are used later
+            mqs_wave_lds_sync();
         }
     }
     // forward substitution L y = b

@@ -138,6 +138,10 @@ class BFMatcher:
             return self.normType
         raise KeyError(name)
 
+    def match(self, query_points, train_points):
+        """cv2.BFMatcher.match (forwarded by the reference's wrapper, cv2_helpers.py:341-345): the nearest train point."""
+        return [ms[0] for ms in self.knnMatch(query_points, train_points, k=1) if ms]
+
     def knnMatch(self, query_points, train_points, k=2):
         if k not in (1, 2):
             raise NotImplementedError("k must be 1 or 2")

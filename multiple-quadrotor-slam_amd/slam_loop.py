@@ -87,7 +87,9 @@ def keyframe_test(points1, points2, K, dist):
 
 
 class MonoSlam:
-    def __init__(self, cameraMatrix, distCoeffs, image_shape, seed=0, verbose=False):
+    def __init__(self, cameraMatrix, distCoeffs, image_shape, seed=0, verbose=False, ba_info=None):
+        """ba_info: an optional `ba_io.BundleAdjustmentInfoContainer`; the loop then records what the reference records
+        for the bundle adjuster (slam2.py:519-522, 634-641, 681-687, 1167-1169, 1204)."""
         self.K = np.asarray(cameraMatrix, dtype=np.float64)
         self.dist = np.asarray(distCoeffs, dtype=np.float64).reshape(-1)[:4]
         self.shape = tuple(image_shape)
@@ -100,6 +102,10 @@ class MonoSlam:
         self.poses = []                                      # per frame: (rvec, tvec) or None when rejected
         self.keyframes = []
         self.timing = []
+        self.ba_info = ba_info
+        self.history = []                                    # since the base keyframe: (frame, track ids, image points)
+        if ba_info is not None:
+            ba_info.set_calibration(self.K, self.dist)
 
     def _log(self, *a):
         if self.verbose:
@@ -125,7 +131,13 @@ class MonoSlam:
         self.pts = np.concatenate([imgp, extra])             # current image points of the live tracks
         self.base_pts = self.pts.copy()                      # their image points in the base keyframe
         self.lm = np.concatenate([np.arange(len(imgp)), -np.ones(len(extra), dtype=np.int64)])   # track -> landmark or -1
+        self.tid = np.arange(len(self.pts), dtype=np.int64)  # track ids (stable while a track lives)
+        self.next_tid = len(self.pts)
         self.prev_img = img
+        if self.ba_info is not None:                         # slam2.py:1167-1169, 1184-1185
+            self.ba_info.set_point3DAddedIdxs(np.arange(len(imgp)))
+            self.ba_info.add_points2D_3Dassoc(imgp, np.arange(len(imgp)), 0)
+            self.history = [(0, self.tid.copy(), self.pts.copy())]
         return rvec, tvec
 
     def handle_new_frame(self, img):
@@ -137,6 +149,9 @@ class MonoSlam:
 
     def _frame(self, img):
         K, dist = self.K, self.dist
+        frame_idx = len(self.poses)
+        if self.ba_info is not None:
+            self.ba_info.next_step()                         # slam2.py:1204: one step per frame, rejected ones included
         new_pts, st, err = features.calcOpticalFlowPyrLK(self.prev_img, img, self.pts)
         keep = (st.ravel() == 1) & (err.ravel() < MAX_OF_ERROR)
         lost = 1.0 - keep.mean() if len(keep) else 1.0
@@ -144,7 +159,7 @@ class MonoSlam:
             self._log("REJECTED: lost track of too many points", lost)
             self.poses.append(None)
             return 0
-        pts, base, lm = new_pts[keep], self.base_pts[keep], self.lm[keep]
+        pts, base, lm, tid = new_pts[keep], self.base_pts[keep], self.lm[keep], self.tid[keep]
         tri = lm >= 0
         if tri.sum() < 8:
             self._log("REJECTED: fewer than 8 triangulated tracks")
@@ -175,8 +190,11 @@ class MonoSlam:
         sel = np.zeros(len(pts), dtype=bool)
         sel[tri_idx[inliers]] = True
         sel |= ~tri
-        pts, base, lm = pts[sel], base[sel], lm[sel]
+        pts, base, lm, tid = pts[sel], base[sel], lm[sel], tid[sel]
         tri = lm >= 0
+        if self.ba_info is not None:                         # slam2.py:519-522
+            self.history.append((frame_idx, tid.copy(), pts.copy()))
+            self.ba_info.add_points2D_3Dassoc(pts[tri], lm[tri], frame_idx)
         result = 1
         if keyframe_test(base, pts, K, dist):
             result = 2
@@ -196,19 +214,38 @@ class MonoSlam:
                     ids = len(self.objp) + np.arange(len(good))
                     self.objp = np.concatenate([self.objp, np.asarray(x2)[good].astype(np.float32)])
                     lm[non[ok[good]]] = ids
+                    if self.ba_info is not None and len(good):
+                        # slam2.py:634-641: the new landmarks and their image points in every frame since the base keyframe
+                        new_tid = tid[non[ok[good]]]
+                        self.ba_info.set_point3DAddedIdxs(ids)
+                        for ev_frame, ev_tid, ev_pts in self.history:
+                            pos = {t: k for k, t in enumerate(ev_tid)}
+                            sel_ev = np.array([pos[t] for t in new_tid], dtype=np.int64)
+                            self.ba_info.add_points2D_3Dassoc(ev_pts[sel_ev], ids, ev_frame)
                 # tracks that failed to triangulate are dropped (slam2.py:596-612)
                 done = lm >= 0
-                pts, base, lm = pts[done], base[done], lm[done]
+                pts, base, lm, tid = pts[done], base[done], lm[done], tid[done]
             extra = self._top_up(img, pts)
             pts = np.concatenate([pts, extra])
             lm = np.concatenate([lm, -np.ones(len(extra), dtype=np.int64)])
+            tid = np.concatenate([tid, self.next_tid + np.arange(len(extra), dtype=np.int64)])
+            self.next_tid += len(extra)
             base = pts.copy()                                 # rebase on this keyframe (slam2.py:673-674)
+            if self.ba_info is not None:                      # slam2.py:681-687: odometry base keyframe -> this frame
+                P1 = np.vstack([self._P(rvec, tvec), [0, 0, 0, 1.0]])
+                P0 = np.vstack([self._P(self.rvec_keyfr, self.tvec_keyfr), [0, 0, 0, 1.0]])
+                self.ba_info.add_odometry(P1 @ np.linalg.inv(P0), self.history[0][0], frame_idx)     # trfm.delta_P(P1, P0)
+                self.history = [(frame_idx, tid.copy(), pts.copy())]
             self.rvec_keyfr, self.tvec_keyfr = rvec, tvec
             self.keyframes.append(len(self.poses))
-        self.pts, self.base_pts, self.lm = pts, base, lm
+        self.pts, self.base_pts, self.lm, self.tid = pts, base, lm, tid
         self.prev_img = img
         self.poses.append((rvec, tvec))
         return result
+
+    def projection_matrices(self):
+        """Per frame the 3x4 world->camera matrix, None for rejected frames (the `Ps` of slam2.py:703-708)."""
+        return [None if p is None else self._P(*p) for p in self.poses]
 
     def trajectory(self):
         """Camera centres (F, 3), NaN for rejected frames."""

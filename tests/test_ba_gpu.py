@@ -110,6 +110,22 @@ def test_gauss_newton_matches_oracle_every_iteration(gpu):
     assert np.abs(ba.poses.cpu().numpy() - poses_o).max() < 1e-7
 
 
+def test_numpy_bundle_adjust_entry_point(gpu):
+    """bundle_adjust(): numpy in / numpy out, same result as the oracle's Gauss-Newton loop; masked observations."""
+    sc = make_scene(300, 3, seed=21, masked_frac=0.15, distortion=True)
+    pp = (sc["poses_true"], np.tile([0.02, 0.02, 0.02, 0.1, 0.1, 0.1], (3, 1)), np.array([1, 0, 0], dtype=np.uint8))
+    poses, points, hist = gpu.bundle_adjustment.bundle_adjust(sc["poses"], sc["calib"], sc["sigma"], sc["points"], sc["obs"],
+                                                              sc["mask"], sc["prior_w"], sc["prior_xyz"], pp, iters=6, mode="gn")
+    poses_o, points_o, hist_o = ba_np.gauss_newton(sc["poses"], sc["calib"], sc["sigma"], sc["points"], sc["obs"],
+                                                   sc["mask"], sc["prior_w"], sc["prior_xyz"], pp, iters=6)
+    assert poses.shape == (3, 12) and points.shape == (300, 3) and len(hist) == 7
+    for a, b in zip(hist, hist_o):
+        assert a == pytest.approx(b, rel=TOL)
+    assert np.abs(points - points_o).max() < 1e-6 and np.abs(poses - poses_o).max() < 1e-7
+    with pytest.raises(ValueError):
+        gpu.bundle_adjustment.bundle_adjust(sc["poses"], sc["calib"], sc["sigma"], sc["points"][:10], sc["obs"])
+
+
 def test_levenberg_marquardt_decreases_cost(gpu):
     sc = make_scene(400, 3, seed=5, distortion=True, pose_noise=(0.05, 0.4), point_noise=0.3)
     pp = (sc["poses_true"], np.tile([0.02, 0.02, 0.02, 0.1, 0.1, 0.1], (3, 1)), np.array([1, 0, 0], dtype=np.uint8))

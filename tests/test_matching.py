@@ -82,6 +82,7 @@ def test_reference_shaped_radius_match(gpu):
     err = rng.random(400)
     assert M.ratio_test_and_dedupe(got, err).keys() == M.ratio_test_and_dedupe(ref, err).keys()
     assert [len(x) for x in m.knnMatch(flow[:5], fast, k=1)] == [1] * 5
+    assert [(x.queryIdx, x.trainIdx) for x in m.match(flow[:50], fast)] == [(ms[0].queryIdx, ms[0].trainIdx) for ms in m.knnMatch(flow[:50], fast)]
     assert m.knnMatch(flow[:3], fast[:0]) == [[], [], []]
 
 

@@ -38,6 +38,38 @@ def test_rendered_sequence_is_consistent(mqs):
 
 
 @pytest.mark.gpu
+def test_loop_to_bundle_adjustment_files_end_to_end(gpu, tmp_path):
+    """BASELINE configs[4] in full: detect -> track -> pose -> triangulate per keyframe on the GPU, the recorded BA problem
+    written as the reference's file set, the CLI-compatible bundle adjuster run on it, `-BA` files written."""
+    import subprocess
+    import run_slam_loop
+    io = gpu.ba_io
+    info = io.BundleAdjustmentInfoContainer(str(tmp_path), "loop", 1)
+    out = run_slam_loop.run(40, ba_info=info, out_files=(str(tmp_path), "loop", 30))
+    assert out["accepted"] == 40
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "bundle_adjust.py"), str(tmp_path), "loop", "1", "30", "1", "1", "0", "1", "0"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    fn = io.create_filenames(str(tmp_path), "loop", 1)
+    seq = gpu.synthetic.PlaneSequence(frames=40)
+    gt = seq.centres()
+    before = np.array([p[9:] for _, p in io.load_trajectory(fn.trajectories_in[0])])
+    after = np.array([p[9:] for _, p in io.load_trajectory(fn.trajectories_out[0])])
+    assert before.shape == after.shape == (40, 3)
+    e0 = np.sqrt(np.mean(np.sum((before - gt) ** 2, axis=1)))
+    e1 = np.sqrt(np.mean(np.sum((after - gt) ** 2, axis=1)))
+    path = np.linalg.norm(np.diff(gt, axis=0), axis=1).sum()
+    assert e1 < 0.01 * path and e1 < 1.5 * e0 + 1e-3                              # BA keeps (or improves) the accuracy
+    pts = io.load_map(fn.map_out)
+    n_init = len(pts) - out["landmarks_triangulated"]
+    assert np.median(np.abs(pts[n_init:, 2])) < 0.15                             # the adjusted map stays on the plane
+    line = [l for l in r.stdout.splitlines() if l.startswith("cost")][0]
+    c0, c1 = float(line.split()[1]), float(line.split()[3])
+    assert c1 < c0
+
+
+@pytest.mark.gpu
 def test_end_to_end_loop_on_rendered_sequence(gpu):
     import run_slam_loop
     out = run_slam_loop.run(40)
@@ -47,7 +79,7 @@ def test_end_to_end_loop_on_rendered_sequence(gpu):
     assert out["map_plane_median_abs_z"] < 0.15                                # landmarks lie on the plane z = 0 (depth ~ 9)
 
 
-def test_loop_host_logic_with_oracle_backends(mqs, c_oracle, monkeypatch):
+def test_loop_host_logic_with_oracle_backends(mqs, c_oracle, monkeypatch, tmp_path):
     """The state machine (gates, bookkeeping, keyframe logic) on the CPU: every GPU call replaced by the oracle's
     restatement of the same step.  Small sequence so that the numpy tracker stays fast."""
     from types import SimpleNamespace
@@ -99,7 +131,9 @@ def test_loop_host_logic_with_oracle_backends(mqs, c_oracle, monkeypatch):
     objp = np.stack([gx.ravel(), gy.ravel(), np.zeros(gx.size)], axis=1)
     imgp = seq.project(0, objp)
     vis = (imgp[:, 0] > 14) & (imgp[:, 0] < seq.W - 14) & (imgp[:, 1] > 14) & (imgp[:, 1] < seq.H - 14)
-    slam = L.MonoSlam(seq.K, seq.dist, (seq.H, seq.W), seed=3)
+    io = mqs.ba_io
+    info = io.BundleAdjustmentInfoContainer(str(tmp_path), "loop", 1)
+    slam = L.MonoSlam(seq.K, seq.dist, (seq.H, seq.W), seed=3, ba_info=info)
     slam.start(seq.render(0), objp[vis], imgp[vis])
     rets = [slam.handle_new_frame(seq.render(k)) for k in range(1, frames)]
     assert all(r in (1, 2) for r in rets) and rets.count(2) >= 1                 # every frame accepted, some keyframes
@@ -108,3 +142,29 @@ def test_loop_host_logic_with_oracle_backends(mqs, c_oracle, monkeypatch):
     new = slam.objp[int(vis.sum()):]
     assert len(new) >= 10 and np.median(np.abs(new[:, 2])) < 0.6                 # short baselines: coarse, but on the plane
     assert (slam.lm >= -1).all() and slam.lm.max() < len(slam.objp)
+    # what the loop recorded for the bundle adjuster (slam2.py:743-865): written in the reference's file set, read back by
+    # the reader of the CLI tool, accepted by both of its validators, and turned into a well-posed sparse problem
+    info.write_all()
+    info.write_noise(point2D=1.0)
+    fn = io.create_filenames(str(tmp_path), "loop", 1)
+    io.save_slam_output(fn, 30, slam.projection_matrices(), slam.objp)
+    data = io.load_data(fn, 30)
+    io.validate_data_integrity(data, 1)
+    ok, _ = io.validate_sufficiently_constrained(data, True)
+    assert ok
+    assert len(data.point3DAddedIdxs) == frames and sum(len(a) for a in data.point3DAddedIdxs) == len(slam.objp)
+    assert sorted(i for a in data.point3DAddedIdxs for i in a) == list(range(len(slam.objp)))
+    assert sum(len(o) for o in data.odometry) == rets.count(2)                   # one odometry edge per keyframe
+    pr = io.build_sparse_problem(data, use_odometry=True)
+    assert len(pr.poses) == frames and len(pr.points) == len(slam.objp)
+    # every recorded observation reprojects near its measurement through the recorded pose and landmark
+    from oracle import ba_np
+    res = []
+    for j in range(len(pr.points)):
+        for k in range(pr.obs_ptr[j], pr.obs_ptr[j + 1]):
+            uv, _, _, front = ba_np.project(pr.poses[pr.obs_pose[k]], pr.calib[0], pr.points[j])
+            assert front
+            res.append(np.linalg.norm(uv - pr.obs_uv[k]))
+    assert len(res) > 200 and np.median(res) < 1.0 and np.max(res) < 12.0
+    # every landmark added at a keyframe is observed in every frame since the previous keyframe (>= 2 views)
+    assert min(pr.obs_ptr[j + 1] - pr.obs_ptr[j] for j in range(int(vis.sum()), len(pr.points))) >= 2

@@ -6,7 +6,9 @@ import numpy as np
 import mqslam_amd
 
 
-def run(frames=60, verbose=False):
+def run(frames=60, verbose=False, ba_info=None, out_files=None):
+    """ba_info: a ba_io.BundleAdjustmentInfoContainer to record into; out_files = (dir, base_name, fps): also write the
+    BA_info.* set, the noise files, traj_out.cam0-<name>.txt and map_out-<name>.pcd (the input of tools/bundle_adjust.py)."""
     seq = mqslam_amd.synthetic.PlaneSequence(frames=frames)
     gx, gy = np.meshgrid(np.linspace(-4.5, 1.0, 8), np.linspace(-2.5, 2.0, 6))
     objp = np.stack([gx.ravel(), gy.ravel(), np.zeros(gx.size)], axis=1)
@@ -14,11 +16,16 @@ def run(frames=60, verbose=False):
     vis = (imgp[:, 0] > 15) & (imgp[:, 0] < seq.W - 15) & (imgp[:, 1] > 15) & (imgp[:, 1] < seq.H - 15)
     objp, imgp = objp[vis], imgp[vis]
     imgs = [seq.render(k) for k in range(frames)]
-    slam = mqslam_amd.slam_loop.MonoSlam(seq.K, seq.dist, (seq.H, seq.W), seed=1, verbose=verbose)
+    slam = mqslam_amd.slam_loop.MonoSlam(seq.K, seq.dist, (seq.H, seq.W), seed=1, verbose=verbose, ba_info=ba_info)
     slam.start(imgs[0], objp, imgp)
     rets = [2]
     for k in range(1, frames):
         rets.append(slam.handle_new_frame(imgs[k]))
+    if ba_info is not None and out_files is not None:
+        io = mqslam_amd.ba_io
+        ba_info.write_all()
+        ba_info.write_noise(point2D=1.0)
+        io.save_slam_output(io.create_filenames(out_files[0], out_files[1], 1), out_files[2], slam.projection_matrices(), slam.objp)
     traj, gt = slam.trajectory(), seq.centres()
     ok = np.isfinite(traj[:, 0])
     err = np.linalg.norm(traj[ok] - gt[ok], axis=1)
@@ -31,5 +38,34 @@ def run(frames=60, verbose=False):
             "frames_per_s": round((frames - 1) / sum(slam.timing), 1)}
 
 
+def run_with_ba(frames=60, work_dir=None):
+    """The loop, then the recorded problem through the file set into the sparse bundle adjuster (LM, odometry factors on):
+    detect -> track -> pose -> triangulate -> BA.  Returns the loop's report plus the trajectory error before / after BA."""
+    import tempfile
+    io = mqslam_amd.ba_io
+    with tempfile.TemporaryDirectory(dir=work_dir) as d:
+        info = io.BundleAdjustmentInfoContainer(d, "loop", 1)
+        out = run(frames, ba_info=info, out_files=(d, "loop", 30))
+        fn = io.create_filenames(d, "loop", 1)
+        t0 = time.perf_counter()
+        data = io.load_data(fn, 30)
+        io.validate_data_integrity(data, 1)
+        problem = io.build_sparse_problem(data, use_odometry=True)
+        t1 = time.perf_counter()
+        ba = mqslam_amd.sparse_ba.SparseBundleAdjuster(problem)
+        hist = ba.optimize(mode="lm")
+        poses = ba.poses.cpu().numpy()
+        t2 = time.perf_counter()
+    gt = mqslam_amd.synthetic.PlaneSequence(frames=frames).centres()
+    key = [f for (c, f) in ba.problem.pose_key]
+    rmse = lambda P: float(np.sqrt(np.mean(np.sum((P[:, 9:] - gt[key]) ** 2, axis=1))))
+    out["bundle_adjustment"] = {"poses": len(problem.poses), "points": len(problem.points), "observations": len(problem.obs_pose),
+                                "lm_iterations": len(hist) - 1, "cost_before": hist[0], "cost_after": hist[-1],
+                                "trajectory_rmse_before": rmse(np.asarray(problem.poses)), "trajectory_rmse_after": rmse(poses),
+                                "load_and_build_s": round(t1 - t0, 3), "optimise_s": round(t2 - t1, 3)}
+    return out
+
+
 if __name__ == "__main__":
-    print(json.dumps(run(int(sys.argv[1]) if len(sys.argv) > 1 else 60, verbose="-v" in sys.argv)))
+    n = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 60
+    print(json.dumps(run_with_ba(n) if "--ba" in sys.argv else run(n, verbose="-v" in sys.argv)))
