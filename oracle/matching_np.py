@@ -88,3 +88,25 @@ def ratio_test_and_dedupe(matches_twoNN, err, max_dist_ratio=0.7):
         if m.trainIdx not in best or err[m.queryIdx] < err[best[m.trainIdx].queryIdx]:
             best[m.trainIdx] = m
     return best
+
+
+def match_OF_based(right_OF_points, right_FAST_points, err_OF, status_OF, max_radius_OF_to_FAST, max_dist_ratio,
+                   left_point_idxs=None, max_OF_error=12.0):
+    """slam.py:81-127, statement by statement (the filter :84-90, radiusMatch :101-104, the loop :106-125)."""
+    kept = [(p, i) for i, p in enumerate(right_OF_points)
+            if status_OF[i] and err_OF[i] < max_OF_error and (left_point_idxs is None or i in left_point_idxs)]
+    if not kept:
+        return {}
+    pts, to_left = zip(*kept)
+    matches_twoNN = radius_match(np.array(pts), right_FAST_points, max_radius_OF_to_FAST)
+    best = {}
+    for query_matches in matches_twoNN:
+        if len(query_matches) > 1 and query_matches[1].distance == 0.0:
+            continue                                          # the reference divides by zero here (ZeroDivisionError)
+        if not (len(query_matches) == 1 or
+                (len(query_matches) > 1 and query_matches[0].distance / query_matches[1].distance < max_dist_ratio)):
+            continue
+        match = DMatch(to_left[query_matches[0].queryIdx], query_matches[0].trainIdx, query_matches[0].distance)
+        if match.trainIdx not in best or err_OF[match.queryIdx] < err_OF[best[match.trainIdx].queryIdx]:
+            best[match.trainIdx] = match
+    return best
