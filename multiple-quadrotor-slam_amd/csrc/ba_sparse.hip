@@ -615,6 +615,122 @@ __global__ __launch_bounds__(kBlock) void chol_solve_kernel(const double *__rest
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Forward / backward substitution for the banded factor in PRODUCT FORM, one workgroup of 1024 threads: chol_diag_kernel
+// left inv(L_kk) of every 32 x 32 diagonal block in that block's upper triangle, so a block of unknowns is a 32 x 32
+// mat-vec (x_blk = inv(L_kk) b_blk) and its <= hb dependants a panel mat-vec -- no per-unknown serial chain at all (the
+// column-oriented kernel above walks 2 n dependent steps; at n = 5286, hb = 101: 5 ms -> 1.3 ms).
+// LDS: inv(L_kk) 32 x 33, the panel hb x 33, 32 x 33 partial sums, the unknowns n.
+// (A whole-factorisation variant of this -- diagonal factor, panel and trailing update of every block column by the same
+// persistent workgroup -- was built and measured: 11.3 ms against 10.4 ms for the launches it replaced.  One wavefront
+// retires an instruction every 4-5 cycles at best, and with the 128-VGPR budget of a 1024-thread workgroup the 32 x 32
+// factor has to live in LDS (~300 instructions per pivot step, 23 us per block) where the stand-alone 64-thread kernel
+// keeps it in registers.)
+// ---------------------------------------------------------------------------------------------
+constexpr int kPT = 1024;
+constexpr int kLdT = NB + 1;
+
+static inline size_t banded_blocked_lds_bytes(int n, int hb)
+{
+    return ((size_t)2 * NB * kLdT + 64 + (size_t)hb * kLdT + (size_t)n + 8) * sizeof(double);
+}
+
+__device__ __forceinline__ void load_inv_diag(const double *__restrict__ A, int n, int k0, int nb, double *sLi, int tid)
+{
+    // inv(L_kk) as chol_diag_kernel stores it: strictly lower part transposed in the block's upper triangle, diagonal = 1 / L_jj
+    for (int e = tid; e < NB * NB; e += kPT) {
+        const int j = e >> 5, k = e & 31;
+        double v = 0.0;
+        if (j < nb && k < nb) {
+            if (k < j) v = A[(int64_t)(k0 + k) * n + k0 + j];
+            else if (k == j) v = 1.0 / A[(int64_t)(k0 + j) * n + k0 + j];
+        }
+        sLi[j * kLdT + k] = v;
+    }
+}
+
+__global__ __launch_bounds__(kPT) void chol_solve_banded_blocked_kernel(const double *__restrict__ A, int n, int hb,
+                                                                         double *__restrict__ x)
+{
+    extern __shared__ double sMem[];
+    double *sLi = sMem;                      // [NB][kLdT] inv(L_kk), lower
+    double *sQ = sLi + NB * kLdT;            // [NB][kLdT] partial sums of the backward substitution
+    double *sCol = sQ + NB * kLdT;           // [64]
+    double *sP = sCol + 64;                  // [hb][kLdT] panel below the diagonal block
+    double *sXv = sP + (size_t)hb * kLdT;    // [n] right-hand side -> solution
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < n; i += kPT) sXv[i] = x[i];
+
+    // ---- forward substitution L y = b, block by block ----
+    for (int k0 = 0; k0 < n; k0 += NB) {
+        const int nb = (n - k0) < NB ? (n - k0) : NB;
+        const int t0 = k0 + nb;
+        int m = n - t0;
+        if (m > hb) m = hb;
+        load_inv_diag(A, n, k0, nb, sLi, tid);
+        for (int e = tid; e < m * NB; e += kPT) {
+            const int r = e >> 5, c = e & 31;
+            sP[r * kLdT + c] = (c < nb) ? A[(int64_t)(t0 + r) * n + k0 + c] : 0.0;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            const int j = lane & 31;
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < NB; ++k) s = fma(sLi[j * kLdT + k], (k < nb) ? sXv[k0 + k] : 0.0, s);
+            mqs_wave_lds_sync();
+            if (lane < nb) sXv[k0 + lane] = s;
+        }
+        __syncthreads();
+        if (tid < m) {
+            double s = 0.0;
+#pragma unroll
+            for (int c = 0; c < NB; ++c) s = fma(sP[tid * kLdT + c], (c < nb) ? sXv[k0 + c] : 0.0, s);
+            sXv[t0 + tid] -= s;
+        }
+        __syncthreads();
+    }
+    // ---- backward substitution L^T x = y ----
+    for (int k0 = ((n - 1) / NB) * NB; k0 >= 0; k0 -= NB) {
+        const int nb = (n - k0) < NB ? (n - k0) : NB;
+        const int t0 = k0 + nb;
+        int m = n - t0;
+        if (m > hb) m = hb;
+        load_inv_diag(A, n, k0, nb, sLi, tid);
+        for (int e = tid; e < m * NB; e += kPT) {
+            const int r = e >> 5, c = e & 31;
+            sP[r * kLdT + c] = (c < nb) ? A[(int64_t)(t0 + r) * n + k0 + c] : 0.0;
+        }
+        __syncthreads();
+        {
+            // t_c = sum_r L[t0 + r][k0 + c] x[t0 + r]: 32 partial sums per column, then wave 0 combines them
+            const int c = tid & 31, part = tid >> 5;
+            double s = 0.0;
+            for (int r = part; r < m; r += kPT / NB) s = fma(sP[r * kLdT + c], sXv[t0 + r], s);
+            sQ[part * kLdT + c] = s;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            const int c = lane & 31;
+            double t = 0.0;
+#pragma unroll
+            for (int part = 0; part < kPT / NB; ++part) t += sQ[part * kLdT + c];
+            const double yc = (c < nb) ? sXv[k0 + c] - t : 0.0;
+            if (lane < NB) sCol[lane] = yc;
+            mqs_wave_lds_sync();
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < NB; ++k) s = fma(sLi[k * kLdT + c], sCol[k], s);     // inv(L)^T: zero for k < c
+            if (lane < nb) sXv[k0 + lane] = s;
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < n; i += kPT) x[i] = sXv[i];
+}
+
+#ifndef MQS_SBA_BLOCKED_SUBST
+#define MQS_SBA_BLOCKED_SUBST 1       // 0: the column-oriented substitution kernel (A/B builds)
+#endif
 #ifndef MQS_SBA_LIBRARY_MIN_N
 #define MQS_SBA_LIBRARY_MIN_N 1536
 #endif
@@ -726,7 +842,17 @@ int mqs_sba_solve_banded_dev(double *S, double *x, int64_t P, int64_t half_bandw
             }
         }
         const size_t lds = ((size_t)n + (size_t)kSlab * (hb + kSlab)) * 8;
-        if (banded && lds <= 150 * 1024) {
+        if (banded && MQS_SBA_BLOCKED_SUBST && banded_blocked_lds_bytes(n, hb) <= 150 * 1024) {
+            static bool lds_opt_in_b = false;                // dynamic LDS above 64 KiB needs the opt-in once per process
+            if (!lds_opt_in_b) {
+                MQS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(chol_solve_banded_blocked_kernel),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+                lds_opt_in_b = true;
+            }
+            hipLaunchKernelGGL(chol_solve_banded_blocked_kernel, dim3(1), dim3(kPT), banded_blocked_lds_bytes(n, hb), stream, S, n,
+                               hb, x);
+        }
+        else if (banded && lds <= 150 * 1024) {
             static bool lds_opt_in = false;                  // dynamic LDS above 64 KiB needs the opt-in once per process
             if (!lds_opt_in) {
                 MQS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(chol_solve_banded_kernel),
