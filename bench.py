@@ -323,7 +323,7 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import run_slam_loop
         run_slam_loop.run(10)
-        frontend_out["end_to_end_loop"] = run_slam_loop.run_with_ba(40)
+        frontend_out["end_to_end_loop"] = run_slam_loop.run_with_ba(60)
 
     # ---- CPU baseline: the oracle's C port of the reference kernel, rank 0, N = 1 only ----
     cpu = None
