@@ -74,6 +74,9 @@ SIGNATURES = {
     "mqs_sba_linearize_dev": (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp,
                                              c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_int, ctypes.c_double,
                                              c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "mqs_sba_linearize_grouped_dev": (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp,
+                                                     c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_int,
+                                                     ctypes.c_double, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "mqs_sba_solve_dev": (ctypes.c_int, [c_vp, c_vp, c_i64, ctypes.c_double, c_vp, c_vp, c_vp, c_vp]),
     "mqs_sba_solve_banded_dev": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i64, ctypes.c_double, c_vp, c_vp, c_vp, c_vp]),
     "mqs_sba_backsub_dev": (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp,

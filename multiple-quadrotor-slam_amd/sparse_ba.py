@@ -46,6 +46,20 @@ def build_pairs(obs_ptr):
     return np.concatenate(pa).astype(np.int64), np.concatenate(pb).astype(np.int64)
 
 
+def group_pairs(pair_a, pair_b, obs_pose, n_poses):
+    """Sorts the pair list by (pose of a, pose of b) -- stable, so the order inside a group is the landmark order -- and
+    returns (pair_a, pair_b, group_ptr): group k = pairs [group_ptr[k], group_ptr[k + 1]) all feed ONE 6 x 6 block of the
+    reduced system (mqs_sba_linearize_grouped_dev)."""
+    if len(pair_a) == 0:
+        return pair_a, pair_b, np.zeros(1, np.int64)
+    op = np.asarray(obs_pose, dtype=np.int64)
+    key = op[pair_a] * np.int64(n_poses) + op[pair_b]
+    order = np.argsort(key, kind="stable")
+    key = key[order]
+    cuts = np.nonzero(key[1:] != key[:-1])[0] + 1
+    return pair_a[order], pair_b[order], np.concatenate([[0], cuts, [len(key)]]).astype(np.int64)
+
+
 def sort_observations_by_pose(problem):
     """Returns a copy of the problem whose observations are sorted by pose index within each landmark."""
     op = problem.obs_pose.copy()
@@ -77,8 +91,9 @@ class SparseBundleAdjuster:
         self.obs_pose = t(pr.obs_pose, i32)
         self.obs_uv = t(pr.obs_uv, f64)
         pa, pb = build_pairs(pr.obs_ptr)
-        self.Q = len(pa)
-        self.pair_a, self.pair_b = t(pa, i64), t(pb, i64)
+        pa, pb, gp = group_pairs(pa, pb, pr.obs_pose, len(pr.poses))
+        self.Q, self.G = len(pa), len(gp) - 1
+        self.pair_a, self.pair_b, self.group_ptr = t(pa, i64), t(pb, i64), t(gp, i64)
         has_prior = pr.prior_w is not None and np.any(pr.prior_w > 0)
         self.prior_w = t(pr.prior_w, f64) if has_prior else None
         self.prior_xyz = t(pr.prior_xyz, f64) if has_prior else None
@@ -112,10 +127,10 @@ class SparseBundleAdjuster:
                               device=dev)
 
     def linearize(self, lam=0.0):
-        _lib.check(_lib.lib().mqs_sba_linearize_dev(
+        _lib.check(_lib.lib().mqs_sba_linearize_grouped_dev(
             _p(self.poses), _p(self.pose_cam), self.P, _p(self.calib), _p(self.sigma), _p(self.points), self.N,
             _p(self.obs_ptr), _p(self.obs_pose), _p(self.obs_uv), self.M, _p(self.pair_a), _p(self.pair_b), self.Q,
-            _p(self.prior_w), _p(self.prior_xyz), _p(self.pp_idx), _p(self.pp_poses), _p(self.pp_sigmas), self.npp,
+            _p(self.group_ptr), self.G, _p(self.prior_w), _p(self.prior_xyz), _p(self.pp_idx), _p(self.pp_poses), _p(self.pp_sigmas), self.npp,
             float(lam), _p(self.S), _p(self.g), _p(self.info), _p(self.ws), self.ws.numel(), _sp()))
         if self.n_odo:
             self._between(self.poses, self.S, self.g)

@@ -120,6 +120,37 @@ def test_sparse_linearize_solve_backsub_parity(which, lam, gpu):
 
 
 @pytest.mark.gpu
+def test_grouped_pair_blocks_are_reproducible_and_equal_the_atomic_path(gpu):
+    """The atomic-free pair stage (pairs grouped by pose pair, one writer per 6 x 6 block): bitwise identical from run to
+    run, equal to the atomic path to rounding, and the grouping tiles the pair list."""
+    import ctypes
+    fn, data = load(gpu, SVO, "slam2", 1, 50)
+    ba = gpu.sparse_ba.SparseBundleAdjuster(gpu.ba_io.build_sparse_problem(data))
+    gp = ba.group_ptr.cpu().numpy()
+    pa, pb, op = ba.pair_a.cpu().numpy(), ba.pair_b.cpu().numpy(), ba.obs_pose.cpu().numpy()
+    assert gp[0] == 0 and gp[-1] == ba.Q and (np.diff(gp) > 0).all()
+    keys = op[pa].astype(np.int64) * ba.P + op[pb]
+    assert (np.diff(keys) >= 0).all() and len(np.unique(keys)) == ba.G
+    assert all(len(np.unique(keys[gp[k]:gp[k + 1]])) == 1 for k in range(0, ba.G, max(1, ba.G // 50)))
+    S1, g1 = ba.linearize(1e-3)
+    S1, g1 = S1.clone(), g1.clone()
+    S2, g2 = ba.linearize(1e-3)
+    import torch
+    assert torch.equal(S1, S2) and torch.equal(g1, g2)                           # no atomics: bitwise reproducible
+    P = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
+    Sa, ga = torch.empty_like(ba.S), torch.empty_like(ba.g)
+    gpu._lib.check(gpu._lib.lib().mqs_sba_linearize_dev(
+        P(ba.poses), P(ba.pose_cam), ba.P, P(ba.calib), P(ba.sigma), P(ba.points), ba.N, P(ba.obs_ptr), P(ba.obs_pose),
+        P(ba.obs_uv), ba.M, P(ba.pair_a), P(ba.pair_b), ba.Q, P(ba.prior_w), P(ba.prior_xyz), P(ba.pp_idx), P(ba.pp_poses),
+        P(ba.pp_sigmas), ba.npp, 1e-3, P(Sa), P(ga), P(ba.info), P(ba.ws), ba.ws.numel(),
+        ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    scale = float(S1.abs().max())
+    assert float((Sa - S2.reshape(-1)).abs().max()) <= 1e-12 * scale
+    assert float((ga - g2).abs().max()) <= 1e-12 * float(g2.abs().max())
+
+
+@pytest.mark.gpu
 def test_odometry_between_factors(gpu):
     """B3 (bundle_adjust.cpp:301-309, useOdometry = 1) on the reference's example files: the odometry factors'
     contribution to the reduced camera system and to the cost equals the oracle's, and LM with them converges."""
