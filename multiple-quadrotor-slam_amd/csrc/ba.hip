@@ -485,11 +485,18 @@ __global__ __launch_bounds__(64) void ba_solve_kernel(const double *__restrict__
         row[k] = lik;
         if (lane == k) dinv = inv;
         if (k + 1 < n) {
-            sCol[lane] = lik;
-            mqs_wave_lds_sync();
+            if (n <= 36) {
+                sCol[lane] = lik;
+                mqs_wave_lds_sync();
 #pragma unroll
-            for (int j = k + 1; j < n; ++j) row[j] = fma(-lik, sCol[j], row[j]);   // only entries j <= lane are used later
-            mqs_wave_lds_sync();
+                for (int j = k + 1; j < n; ++j) row[j] = fma(-lik, sCol[j], row[j]);   // only entries j <= lane are used later
+                mqs_wave_lds_sync();
+            } else {
+                // 7 and 8 cameras: with 42 / 48 row registers the scheduler runs ahead on the pivot chain, parks every
+                // step's loaded column and spills -- the v_readlane form has nothing to park
+#pragma unroll
+                for (int j = k + 1; j < n; ++j) row[j] = fma(-lik, read_lane(lik, j), row[j]);
+            }
         }
     }
     // forward substitution L y = b
