@@ -723,9 +723,19 @@ __global__ __launch_bounds__(kBlock) void chol_solve_kernel(const double *__rest
 constexpr int kPT = 1024;
 constexpr int kLdT = NB + 1;
 
-static inline size_t banded_blocked_lds_bytes(int n, int hb)
+// panel rows held in LDS at a time: the whole band when it fits beside the unknowns, else as many as do (the dependants are
+// then processed in chunks)
+static inline int banded_blocked_cap(int n, int hb)
 {
-    return ((size_t)2 * NB * kLdT + 64 + (size_t)hb * kLdT + (size_t)n + 8) * sizeof(double);
+    const int64_t budget = (int64_t)(150 * 1024) / (int64_t)sizeof(double) - ((int64_t)2 * NB * kLdT + 64 + n + 8);
+    int64_t cap = budget / kLdT;
+    if (cap > hb) cap = hb;
+    return (int)(cap < 0 ? 0 : cap);
+}
+
+static inline size_t banded_blocked_lds_bytes(int n, int cap)
+{
+    return ((size_t)2 * NB * kLdT + 64 + (size_t)cap * kLdT + (size_t)n + 8) * sizeof(double);
 }
 
 __device__ __forceinline__ void load_inv_diag(const double *__restrict__ A, int n, int k0, int nb, double *sLi, int tid)
@@ -742,7 +752,8 @@ __device__ __forceinline__ void load_inv_diag(const double *__restrict__ A, int 
     }
 }
 
-__global__ __launch_bounds__(kPT) void chol_solve_banded_blocked_kernel(const double *__restrict__ A, int n, int hb,
+// The whole band's panel fits in LDS beside the unknowns (the usual banded case): one load phase per block.
+__global__ __launch_bounds__(kPT) void chol_solve_banded_blocked1_kernel(const double *__restrict__ A, int n, int hb,
                                                                          double *__restrict__ x)
 {
     extern __shared__ double sMem[];
@@ -808,6 +819,93 @@ __global__ __launch_bounds__(kPT) void chol_solve_banded_blocked_kernel(const do
             double t = 0.0;
 #pragma unroll
             for (int part = 0; part < kPT / NB; ++part) t += sQ[part * kLdT + c];
+            const double yc = (c < nb) ? sXv[k0 + c] - t : 0.0;
+            if (lane < NB) sCol[lane] = yc;
+            mqs_wave_lds_sync();
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < NB; ++k) s = fma(sLi[k * kLdT + c], sCol[k], s);     // inv(L)^T: zero for k < c
+            if (lane < nb) sXv[k0 + lane] = s;
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < n; i += kPT) x[i] = sXv[i];
+}
+
+// The same with the panel taken `cap` rows at a time (dense factors, very wide bands).
+__global__ __launch_bounds__(kPT) void chol_solve_banded_blocked_kernel(const double *__restrict__ A, int n, int hb, int cap,
+                                                                         double *__restrict__ x)
+{
+    extern __shared__ double sMem[];
+    double *sLi = sMem;                      // [NB][kLdT] inv(L_kk), lower
+    double *sQ = sLi + NB * kLdT;            // [NB][kLdT] partial sums of the backward substitution
+    double *sCol = sQ + NB * kLdT;           // [64]
+    double *sP = sCol + 64;                  // [cap][kLdT] panel below the diagonal block (cap rows at a time)
+    double *sXv = sP + (size_t)cap * kLdT;   // [n] right-hand side -> solution
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < n; i += kPT) sXv[i] = x[i];
+
+    // ---- forward substitution L y = b, block by block ----
+    for (int k0 = 0; k0 < n; k0 += NB) {
+        const int nb = (n - k0) < NB ? (n - k0) : NB;
+        const int t0 = k0 + nb;
+        int m = n - t0;
+        if (m > hb) m = hb;
+        load_inv_diag(A, n, k0, nb, sLi, tid);
+        for (int c0 = 0; c0 < m || c0 == 0; c0 += cap) {            // dependants, `cap` rows of the panel at a time
+            const int mc = (m - c0) < cap ? (m - c0) : cap;
+            for (int e = tid; e < mc * NB; e += kPT) {
+                const int r = e >> 5, c = e & 31;
+                sP[r * kLdT + c] = (c < nb) ? A[(int64_t)(t0 + c0 + r) * n + k0 + c] : 0.0;
+            }
+            __syncthreads();
+            if (c0 == 0) {                                            // the block itself, once, beside the first chunk's load
+                if (wave == 0) {
+                    const int j = lane & 31;
+                    double s = 0.0;
+#pragma unroll
+                    for (int k = 0; k < NB; ++k) s = fma(sLi[j * kLdT + k], (k < nb) ? sXv[k0 + k] : 0.0, s);
+                    mqs_wave_lds_sync();
+                    if (lane < nb) sXv[k0 + lane] = s;
+                }
+                __syncthreads();
+            }
+            for (int r = tid; r < mc; r += kPT) {
+                double s = 0.0;
+#pragma unroll
+                for (int c = 0; c < NB; ++c) s = fma(sP[r * kLdT + c], (c < nb) ? sXv[k0 + c] : 0.0, s);
+                sXv[t0 + c0 + r] -= s;
+            }
+            __syncthreads();
+        }
+    }
+    // ---- backward substitution L^T x = y ----
+    for (int k0 = ((n - 1) / NB) * NB; k0 >= 0; k0 -= NB) {
+        const int nb = (n - k0) < NB ? (n - k0) : NB;
+        const int t0 = k0 + nb;
+        int m = n - t0;
+        if (m > hb) m = hb;
+        load_inv_diag(A, n, k0, nb, sLi, tid);
+        // t_c = sum_r L[t0 + r][k0 + c] x[t0 + r]: 32 partial sums per column (over all chunks), then wave 0 combines them
+        const int pc = tid & 31, part = tid >> 5;
+        double ps = 0.0;
+        for (int c0 = 0; c0 < m; c0 += cap) {
+            const int mc = (m - c0) < cap ? (m - c0) : cap;
+            if (c0 > 0) __syncthreads();                              // the previous chunk has been consumed
+            for (int e = tid; e < mc * NB; e += kPT) {
+                const int r = e >> 5, c = e & 31;
+                sP[r * kLdT + c] = (c < nb) ? A[(int64_t)(t0 + c0 + r) * n + k0 + c] : 0.0;
+            }
+            __syncthreads();
+            for (int r = part; r < mc; r += kPT / NB) ps = fma(sP[r * kLdT + pc], sXv[t0 + c0 + r], ps);
+        }
+        sQ[part * kLdT + pc] = ps;
+        __syncthreads();
+        if (wave == 0) {
+            const int c = lane & 31;
+            double t = 0.0;
+#pragma unroll
+            for (int p2 = 0; p2 < kPT / NB; ++p2) t += sQ[p2 * kLdT + c];
             const double yc = (c < nb) ? sXv[k0 + c] - t : 0.0;
             if (lane < NB) sCol[lane] = yc;
             mqs_wave_lds_sync();
@@ -954,15 +1052,24 @@ int mqs_sba_solve_banded_dev(double *S, double *x, int64_t P, int64_t half_bandw
             }
         }
         const size_t lds = ((size_t)n + (size_t)kSlab * (hb + kSlab)) * 8;
-        if (banded && MQS_SBA_BLOCKED_SUBST && banded_blocked_lds_bytes(n, hb) <= 150 * 1024) {
+        const int hbs = banded ? hb : n;                     // the dense factor is a band of full width
+        const int cap = banded_blocked_cap(n, hbs);
+        if (MQS_SBA_BLOCKED_SUBST && cap >= (hbs < 64 ? hbs : 64)) {
             static bool lds_opt_in_b = false;                // dynamic LDS above 64 KiB needs the opt-in once per process
             if (!lds_opt_in_b) {
                 MQS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(chol_solve_banded_blocked_kernel),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
                 lds_opt_in_b = true;
             }
-            hipLaunchKernelGGL(chol_solve_banded_blocked_kernel, dim3(1), dim3(kPT), banded_blocked_lds_bytes(n, hb), stream, S, n,
-                               hb, x);
+            if (cap >= hbs && hbs > 0) {
+                MQS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(chol_solve_banded_blocked1_kernel),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+                hipLaunchKernelGGL(chol_solve_banded_blocked1_kernel, dim3(1), dim3(kPT), banded_blocked_lds_bytes(n, hbs), stream, S,
+                                   n, hbs, x);
+            } else {
+                hipLaunchKernelGGL(chol_solve_banded_blocked_kernel, dim3(1), dim3(kPT), banded_blocked_lds_bytes(n, cap > 0 ? cap : 1),
+                                   stream, S, n, hbs, cap > 0 ? cap : 1, x);
+            }
         }
         else if (banded && lds <= 150 * 1024) {
             static bool lds_opt_in = false;                  // dynamic LDS above 64 KiB needs the opt-in once per process

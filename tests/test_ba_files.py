@@ -151,6 +151,37 @@ def test_grouped_pair_blocks_are_reproducible_and_equal_the_atomic_path(gpu):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case", [(50, 300), (200, 101), (250, 1500), (100, 17), (1, 6), (300, 1800)])
+def test_reduced_system_solve_against_numpy(case, gpu):
+    """mqs_sba_solve_banded_dev on random symmetric positive definite systems: a narrow band (blocked factorisation +
+    product-form substitutions), dense systems small enough for one panel chunk in LDS, dense systems that need the chunked
+    substitution, and one above the library threshold; with and without damping."""
+    import ctypes
+    import torch
+    P_, hb = case
+    n = 6 * P_
+    rng = np.random.default_rng(n + hb)
+    B = rng.standard_normal((n, n))
+    i, j = np.indices((n, n))
+    B[np.abs(i - j) > hb] = 0.0
+    S = B @ B.T                                            # half bandwidth <= 2 hb ...
+    S[np.abs(i - j) > hb] = 0.0                            # ... cut back to hb, then made diagonally dominant
+    S = 0.5 * (S + S.T) + np.diag(np.abs(S).sum(1) + 1.0)
+    g = rng.standard_normal(n)
+    for lam in (0.0, 0.1):
+        Sd = torch.from_numpy(S.copy()).cuda().reshape(-1)
+        x = torch.from_numpy(g.copy()).cuda()
+        bad = torch.zeros(1, dtype=torch.int32, device="cuda")
+        poses = torch.zeros((P_, 12), dtype=torch.float64, device="cuda")
+        gpu._lib.check(gpu._lib.lib().mqs_sba_solve_banded_dev(
+            ctypes.c_void_p(Sd.data_ptr()), ctypes.c_void_p(x.data_ptr()), P_, min(hb, n), lam, ctypes.c_void_p(poses.data_ptr()),
+            None, ctypes.c_void_p(bad.data_ptr()), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        ref = np.linalg.solve(S + lam * np.diag(np.diag(S)), g)
+        assert int(bad.item()) == 0
+        assert np.abs(x.cpu().numpy() - ref).max() <= 1e-10 * np.abs(ref).max()
+
+
+@pytest.mark.gpu
 def test_odometry_between_factors(gpu):
     """B3 (bundle_adjust.cpp:301-309, useOdometry = 1) on the reference's example files: the odometry factors'
     contribution to the reduced camera system and to the cost equals the oracle's, and LM with them converges."""
