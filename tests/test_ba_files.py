@@ -78,6 +78,25 @@ def test_write_read_round_trip(mqs, tmp_path):
     np.testing.assert_allclose(q, np.array([0.1, -0.2, 0.3, 0.9]) / np.linalg.norm([0.1, -0.2, 0.3, 0.9]), atol=1e-15)
 
 
+def test_pair_grouping_host_logic(mqs):
+    """build_pairs / group_pairs: every (a <= b) pair of a landmark's observations once, sorted by pose pair, groups tile the
+    list, the order inside a group is the landmark order (what makes the device sum reproducible)."""
+    sb = mqs.sparse_ba
+    obs_ptr = np.array([0, 3, 3, 5, 6], dtype=np.int64)                 # landmarks with 3, 0, 2, 1 observations
+    obs_pose = np.array([0, 1, 4, 1, 4, 1], dtype=np.int32)            # sorted by pose inside each landmark
+    pa, pb = sb.build_pairs(obs_ptr)
+    assert len(pa) == 6 + 0 + 3 + 1 and (pa <= pb).all()
+    ga, gb, gp = sb.group_pairs(pa, pb, obs_pose, 5)
+    keys = obs_pose[ga].astype(np.int64) * 5 + obs_pose[gb]
+    assert (np.diff(keys) >= 0).all() and gp[0] == 0 and gp[-1] == len(pa)
+    assert [int(keys[a]) for a in gp[:-1]] == sorted(set(keys.tolist()))
+    assert sorted(zip(ga.tolist(), gb.tolist())) == sorted(zip(pa.tolist(), pb.tolist()))
+    k14 = np.nonzero(keys == 1 * 5 + 4)[0]                               # pose pair (1, 4): landmark 0 first, then landmark 2
+    assert list(zip(ga[k14], gb[k14])) == [(1, 2), (3, 4)]
+    e = sb.group_pairs(np.zeros(0, np.int64), np.zeros(0, np.int64), obs_pose, 5)
+    assert len(e[0]) == 0 and e[2].tolist() == [0]
+
+
 def _lin_oracle(pr, lam=0.0):
     S, g, cost, nv, pieces = ba_np.sparse_linearize(pr.poses, pr.pose_cam, pr.calib, pr.sigma, pr.points, pr.obs_ptr,
                                                     pr.obs_pose, pr.obs_uv, pr.prior_w, pr.prior_xyz, lam)
