@@ -20,5 +20,6 @@ from . import features                   # noqa: F401
 from . import slam_replay                # noqa: F401
 from . import slam_loop                  # noqa: F401
 from . import slam_frontend              # noqa: F401
+from . import triangulation_comparison   # noqa: F401
 
 loaded = _lib.loaded

@@ -46,8 +46,11 @@ MQS_HD double project(const double *P, const double *intr, double px, double py,
     const double X = fma(P[0], px, fma(P[1], py, fma(P[2], pz, P[3])));
     const double Y = fma(P[4], px, fma(P[5], py, fma(P[6], pz, P[7])));
     const double Z = fma(P[8], px, fma(P[9], py, fma(P[10], pz, P[11])));
+    // cvProjectPoints2 (OpenCV 2.4): `z = z ? 1./z : 1` -- a point in the camera's principal plane is projected with
+    // unit depth instead of dividing by zero (the rank-deficient cells of the reference's experiment hit this)
+    const double iz = (Z != 0.0) ? 1.0 / Z : 1.0;
     double xd, yd;
-    distort(intr, X / Z, Y / Z, xd, yd);
+    distort(intr, X * iz, Y * iz, xd, yd);
     u = fma(intr[0], xd, intr[2]);
     v = fma(intr[1], yd, intr[3]);
     return Z;
