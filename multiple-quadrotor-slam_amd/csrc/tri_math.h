@@ -227,64 +227,103 @@ MQS_HD void smallest_eigvec4(const double n[10], double X[4])
 
 // Fast path for the same eigenvector: LDL^T of N followed by inverse iteration
 // (v <- N^-1 v).  N is positive semi-definite and, for a triangulation problem, nearly singular
-// along the sought direction, which is exactly when inverse iteration converges in one or two
-// steps (rate lambda_4/lambda_3).  Returns false when the iterates have not settled to 1e-11
-// within kInvIterMax steps (clustered smallest eigenvalues: degenerate geometry) or a leading
-// pivot is not positive; the caller then falls back to the Jacobi iteration above.
-constexpr int kInvIterMax = 16;
+// along the sought direction, which is exactly when inverse iteration converges in a few steps
+// (rate rho = lambda_4 / lambda_3).  With four cameras rho is ~1e-3 and 4-6 steps reach 1e-11; with
+// two or three the weakly constrained depth direction gives rho up to 0.1-0.9 for a percent of the
+// landmarks, and since a wavefront runs as long as its slowest lane, those set the pace (and the
+// ones past the step limit sent their whole wave through the Jacobi fallback).  So after
+// kInvIterPlain plain steps a lane that has not settled shifts: mu = Rayleigh quotient of its
+// iterate (>= lambda_4, off by rho^(2k) lambda_3), N - mu (1 - 2^-10) I is factored again and the
+// rate becomes ~1e-3 rho or |mu - lambda_4| / lambda_3, whichever is larger -- two or three more steps.
+// Returns false when the iterates have not settled to 1e-11 (clustered smallest eigenvalues:
+// degenerate geometry) or a leading pivot is not positive; the caller then falls back to the Jacobi
+// iteration above.
+constexpr int kInvIterPlain = 5;
+constexpr int kInvIterShifted = 8;
+constexpr int kInvIterMax = kInvIterPlain + kInvIterShifted;
+
+struct Ldlt4 {
+    double l10, l20, l30, l21, l31, l32;    // unit lower-triangular factor
+    double i0, i1, i2, i3;                  // reciprocal pivots
+    bool ok;                                // leading pivots positive
+};
+
+// LDL^T of N - shift * I (no pivoting; the last pivot may have either sign and is kept away from zero)
+MQS_HD Ldlt4 ldlt4_shifted(const double n[10], double shift, double tiny)
+{
+    Ldlt4 f;
+    const double d0 = n[0] - shift;
+    f.i0 = rcp(d0);
+    f.l10 = n[1] * f.i0; f.l20 = n[2] * f.i0; f.l30 = n[3] * f.i0;
+    const double d1 = fma(-f.l10, n[1], n[4] - shift);
+    f.i1 = rcp(d1);
+    const double t21 = fma(-f.l20, n[1], n[5]);
+    const double t31 = fma(-f.l30, n[1], n[6]);
+    f.l21 = t21 * f.i1; f.l31 = t31 * f.i1;
+    const double d2 = fma(-f.l21, t21, fma(-f.l20, n[2], n[7] - shift));
+    f.i2 = rcp(d2);
+    const double t32 = fma(-f.l31, t21, fma(-f.l30, n[2], n[8]));
+    f.l32 = t32 * f.i2;
+    double d3 = fma(-f.l32, t32, fma(-f.l31, t31, fma(-f.l30, n[3], n[9] - shift)));
+    f.ok = (d0 > 0.0) && (d1 > 0.0) && (d2 > 0.0);
+    if (!(fabs(d3) > tiny)) d3 = tiny;                   // exact data: lambda_4 == 0 to rounding
+    f.i3 = rcp(d3);
+    return f;
+}
+
+// One inverse-iteration step on the power-of-two normalised iterate; returns true when the direction has settled.
+MQS_HD bool invit4_step(const Ldlt4 &f, double &v0, double &v1, double &v2, double &v3)
+{
+    // normalise by an exact power of two (direction only matters), remember the iterate
+    const double m = fmax(fmax(fabs(v0), fabs(v1)), fmax(fabs(v2), fabs(v3)));
+    const double sc = ldexp(1.0, -ilogb(m));
+    v0 *= sc; v1 *= sc; v2 *= sc; v3 *= sc;
+    const double p0 = v0, p1 = v1, p2 = v2, p3 = v3;
+    // solve L y = v, z = D^-1 y, L^T w = z
+    const double y0 = v0;
+    const double y1 = fma(-f.l10, y0, v1);
+    const double y2 = fma(-f.l21, y1, fma(-f.l20, y0, v2));
+    const double y3 = fma(-f.l32, y2, fma(-f.l31, y1, fma(-f.l30, y0, v3)));
+    v3 = y3 * f.i3;
+    v2 = fma(-f.l32, v3, y2 * f.i2);
+    v1 = fma(-f.l31, v3, fma(-f.l21, v2, y1 * f.i1));
+    v0 = fma(-f.l30, v3, fma(-f.l20, v2, fma(-f.l10, v1, y0 * f.i0)));
+    // change of direction between the (scaled) previous iterate p and the new one v:
+    // |v - (v.p / p.p) p|_inf relative to |v|_inf
+    const double pp = fma(p0, p0, fma(p1, p1, fma(p2, p2, p3 * p3)));
+    const double vp = fma(v0, p0, fma(v1, p1, fma(v2, p2, v3 * p3)));
+    const double a = vp * rcp(pp);
+    const double e0 = fabs(fma(-a, p0, v0)), e1 = fabs(fma(-a, p1, v1));
+    const double e2 = fabs(fma(-a, p2, v2)), e3 = fabs(fma(-a, p3, v3));
+    const double err = fmax(fmax(e0, e1), fmax(e2, e3));
+    const double mag = fmax(fmax(fabs(v0), fabs(v1)), fmax(fabs(v2), fabs(v3)));
+    return err <= 1e-11 * mag;
+}
 
 MQS_HD bool smallest_eigvec4_invit(const double n[10], double X[4])
 {
-    // unit lower-triangular L (l10 l20 l30 l21 l31 l32) and pivots d0..d3
-    const double d0 = n[0];
-    const double i0 = rcp(d0);
-    const double l10 = n[1] * i0, l20 = n[2] * i0, l30 = n[3] * i0;
-    const double d1 = fma(-l10, n[1], n[4]);
-    const double i1 = rcp(d1);
-    const double t21 = fma(-l20, n[1], n[5]);
-    const double t31 = fma(-l30, n[1], n[6]);
-    const double l21 = t21 * i1, l31 = t31 * i1;
-    const double d2 = fma(-l21, t21, fma(-l20, n[2], n[7]));
-    const double i2 = rcp(d2);
-    const double t32 = fma(-l31, t21, fma(-l30, n[2], n[8]));
-    const double l32 = t32 * i2;
-    double d3 = fma(-l32, t32, fma(-l31, t31, fma(-l30, n[3], n[9])));
     const double tr = n[0] + n[4] + n[7] + n[9];
-    if (!((d0 > 0.0) && (d1 > 0.0) && (d2 > 0.0))) return false;
     const double tiny = 1e-30 * tr;
-    if (!(fabs(d3) > tiny)) d3 = tiny;                   // exact data: lambda_4 == 0 to rounding
-    const double i3 = rcp(d3);
+    Ldlt4 f = ldlt4_shifted(n, 0.0, tiny);
+    if (!f.ok) return false;
     // first iterate: N^-1 e_3 = L^-T D^-1 L^-1 e_3 = L^-T (e_3 / d3)  -> direction L^-T e_3
     double v3 = 1.0;
-    double v2 = -l32;
-    double v1 = -fma(l21, v2, l31);
-    double v0 = -fma(l10, v1, fma(l20, v2, l30));
+    double v2 = -f.l32;
+    double v1 = -fma(f.l21, v2, f.l31);
+    double v0 = -fma(f.l10, v1, fma(f.l20, v2, f.l30));
     bool done = false;
-    for (int it = 0; it < kInvIterMax; ++it) {
-        // normalise by an exact power of two (direction only matters), remember the iterate
-        const double m = fmax(fmax(fabs(v0), fabs(v1)), fmax(fabs(v2), fabs(v3)));
-        const double sc = ldexp(1.0, -ilogb(m));
-        v0 *= sc; v1 *= sc; v2 *= sc; v3 *= sc;
-        const double p0 = v0, p1 = v1, p2 = v2, p3 = v3;
-        // solve L y = v, z = D^-1 y, L^T w = z
-        const double y0 = v0;
-        const double y1 = fma(-l10, y0, v1);
-        const double y2 = fma(-l21, y1, fma(-l20, y0, v2));
-        const double y3 = fma(-l32, y2, fma(-l31, y1, fma(-l30, y0, v3)));
-        v3 = y3 * i3;
-        v2 = fma(-l32, v3, y2 * i2);
-        v1 = fma(-l31, v3, fma(-l21, v2, y1 * i1));
-        v0 = fma(-l30, v3, fma(-l20, v2, fma(-l10, v1, y0 * i0)));
-        // change of direction between the (scaled) previous iterate p and the new one v:
-        // |v - (v.p / p.p) p|_inf relative to |v|_inf
-        const double pp = fma(p0, p0, fma(p1, p1, fma(p2, p2, p3 * p3)));
-        const double vp = fma(v0, p0, fma(v1, p1, fma(v2, p2, v3 * p3)));
-        const double a = vp * rcp(pp);
-        const double e0 = fabs(fma(-a, p0, v0)), e1 = fabs(fma(-a, p1, v1));
-        const double e2 = fabs(fma(-a, p2, v2)), e3 = fabs(fma(-a, p3, v3));
-        const double err = fmax(fmax(e0, e1), fmax(e2, e3));
-        const double mag = fmax(fmax(fabs(v0), fabs(v1)), fmax(fabs(v2), fabs(v3)));
-        if (err <= 1e-11 * mag) { done = true; break; }
+    for (int it = 0; it < kInvIterPlain && !done; ++it) done = invit4_step(f, v0, v1, v2, v3);
+    if (!done) {
+        // Rayleigh quotient of the current iterate, then the shifted factorisation
+        const double w0 = fma(n[0], v0, fma(n[1], v1, fma(n[2], v2, n[3] * v3)));
+        const double w1 = fma(n[1], v0, fma(n[4], v1, fma(n[5], v2, n[6] * v3)));
+        const double w2 = fma(n[2], v0, fma(n[5], v1, fma(n[7], v2, n[8] * v3)));
+        const double w3 = fma(n[3], v0, fma(n[6], v1, fma(n[8], v2, n[9] * v3)));
+        const double vv = fma(v0, v0, fma(v1, v1, fma(v2, v2, v3 * v3)));
+        const double mu = fma(v0, w0, fma(v1, w1, fma(v2, w2, v3 * w3))) * rcp(vv);
+        const Ldlt4 g = ldlt4_shifted(n, mu * (1.0 - 0x1p-10), tiny);
+        if (!g.ok) return false;
+        for (int it = 0; it < kInvIterShifted && !done; ++it) done = invit4_step(g, v0, v1, v2, v3);
     }
     X[0] = v0; X[1] = v1; X[2] = v2; X[3] = v3;
     return done;
