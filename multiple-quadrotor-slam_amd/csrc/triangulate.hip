@@ -34,13 +34,16 @@ enum TriKind { kLinearLS = 0, kIterativeLS = 1, kLinearEigen = 2 };
 #ifndef MQS_ITER_WAVES
 #define MQS_ITER_WAVES 3
 #endif
-constexpr int waves_for(int kind) { return kind == 1 ? MQS_ITER_WAVES : 2; }
+// The iteration keeps 12 doubles per camera live (Gram piece 6, right-hand side 3, weight and two depths): beyond four
+// cameras that no longer fits the 168 registers of three waves per SIMD (it spilled inside the loop: 5 / 6 / 8 cameras
+// ran 1.8x / 3.6x / 11x the 4-camera time instead of ~1.2x / 1.35x / 1.7x) -- fewer resident waves, no spills.
+constexpr int waves_for(int kind, int cams) { return kind != 1 ? 2 : (cams <= 4 ? MQS_ITER_WAVES : (cams <= 6 ? 2 : 1)); }
 
 // PIX: the observations are PIXELS and `intr` holds [C][9] intrinsics (fx fy cx cy k1 k2 p1 p2 k3): the
 // undistort + normalise step the reference runs right before triangulating (cv2.undistortPoints,
 // slam2.py:551-552) is applied on load, saving its 2 x 16*C bytes per landmark of HBM round trip.
 template <int C, int KIND, bool PIX>
-__global__ __launch_bounds__(kBlock, waves_for(KIND)) void tri_kernel(const double *__restrict__ u, const double *__restrict__ P,
+__global__ __launch_bounds__(kBlock, waves_for(KIND, C)) void tri_kernel(const double *__restrict__ u, const double *__restrict__ P,
                                                                       const double *__restrict__ intr,
                                                      int64_t N, double tol, int max_iter, double max_coord,
                                                      double *__restrict__ x, int32_t *__restrict__ status,
