@@ -100,3 +100,26 @@ def test_bench_contract_two_ranks(gpu, tmp_path):
     assert out["ba"]["landmarks_total"] == 40000
     for key in ("roofline", "cpu_baseline", "vs_baseline", "dtype", "unit", "metric", "ms_per_step"):
         assert key in out
+
+
+def test_bench_contract_single_gpu(gpu):
+    """`python bench.py` (N = 1) at a reduced size: ONE JSON line with the contract's keys, the roofline object of the
+    dominant kernel and the CPU baseline timed beside it."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--landmarks", "50000",
+                        "--descriptors", "4096", "--no-replay", "--no-frontend"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    for key, val in (("n_gpus", 1), ("steps", 3), ("warmup", 1), ("higher_is_better", True), ("scaling", "weak"), ("vs_baseline", None),
+                     ("dtype", "f64"), ("data", "synthetic"), ("unit", "landmarks/s")):
+        assert out[key] == val, key
+    assert out["value"] > 0 and out["ms_per_step"] > 0 and "workload" in out["config"]
+    rf = out["roofline"]
+    assert rf["bound"] in ("hbm", "mfma") and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert rf["frac"] == pytest.approx(rf["achieved"] / rf["peak"], rel=1e-3) and rf["achieved"] > 0
+    cb = out["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and cb["unit"] == "landmarks/s" and "sample" in cb
+    assert cb["parity"]["rel_err_p99.9"] < 1e-5 and cb["parity"]["status_mismatch_frac"] < 0.005
+    assert out["match"]["packed_bits_int8"]["equals_fp16_path"] is True
+    assert out["match"]["cross_match_4_cameras"]["pairs_this_rank"] == 6
