@@ -325,6 +325,15 @@ def main():
         run_slam_loop.run(10)
         frontend_out["end_to_end_loop"] = run_slam_loop.run_with_ba(60)
 
+    # ---- sparse-visibility BA (the reference's real problems: hundreds of poses) at the shape of its largest data set ----
+    sparse_out = None
+    if rank == 0 and not args.no_ba and not args.no_replay:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_sparse_ba
+        sparse_out = bench_sparse_ba.run()
+        sparse_out["workload"] = ("synthetic sequence shaped like ICL-NUIM kt2 (881 poses, 13 293 landmarks seen by 17 consecutive "
+                                  "poses each): linearise (grouped, atomic-free) + banded Cholesky solve + LM to convergence")
+
     # ---- CPU baseline: the oracle's C port of the reference kernel, rank 0, N = 1 only ----
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -378,7 +387,7 @@ def main():
                                    "iterative-LS (tol 3e-5, <=10 iterations)" % (N, C),
                        "landmarks_per_gpu": N, "cameras": C, "sharding": "landmarks, %d-way" % world},
             "roofline": roofline, "rooflines": rooflines, "kernels": kernels, "ba": ba_out, "match": match_out,
-            "replay": replay_out, "frontend": frontend_out, "cpu_baseline": cpu,
+            "replay": replay_out, "frontend": frontend_out, "sparse_ba": sparse_out, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
     if dist is not None:

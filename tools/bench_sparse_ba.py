@@ -4,39 +4,45 @@
 import os, sys, json, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, mqslam_amd
-P = int(sys.argv[1]) if len(sys.argv) > 1 else 881
-N = int(sys.argv[2]) if len(sys.argv) > 2 else 13293
-track = int(sys.argv[3]) if len(sys.argv) > 3 else 17
-rng = np.random.default_rng(0)
-# camera moving along x, looking down +z at a slab of points 8..12 units away
-poses = np.zeros((P, 12)); poses[:, [0, 4, 8]] = 1.0; poses[:, 9] = np.linspace(0, 0.05 * P, P)
-pts = np.stack([rng.uniform(-1, 0.05 * P + 1, N), rng.uniform(-3, 3, N), rng.uniform(8, 12, N)], 1)
-K = np.array([[481.2, 480.0, 0, 319.5, 239.5, 0, 0, 0, 0]])
-ptr, op, uv = [0], [], []
-for i in range(N):
-    c = int(np.clip(pts[i, 0] / 0.05, 0, P - 1)); a = max(0, min(P - track, c - track // 2))
-    for j in range(a, a + track):
-        q = pts[i] - poses[j, 9:]
-        op.append(j); uv.append([481.2 * q[0] / q[2] + 319.5, 480.0 * q[1] / q[2] + 239.5])
-    ptr.append(len(op))
-uv = np.array(uv) + rng.normal(0, 0.5, (len(op), 2))
-SP = mqslam_amd.ba_io.SparseProblem
-pr = SP(poses=poses + 0, pose_cam=np.zeros(P, np.int32), pose_key=[(0, j) for j in range(P)], calib=K, sigma=np.array([1.0]),
-        points=pts + rng.normal(0, 0.02, pts.shape), obs_ptr=np.array(ptr, np.int64), obs_pose=np.array(op, np.int32), obs_uv=uv,
-        prior_w=np.where(np.arange(N) < 100, 16.0, 0.0), prior_xyz=pts.copy(), pose_prior_idx=np.array([0], np.int32),
-        pose_prior_sigmas=np.array([[0.002] * 3 + [0.001] * 3]), odo_from=np.zeros(0, np.int32), odo_to=np.zeros(0, np.int32),
-        odo_meas=np.zeros((0, 12)), odo_sigmas=np.zeros((0, 6)))
-t0 = time.time(); ba = mqslam_amd.sparse_ba.SparseBundleAdjuster(pr); t_setup = time.time() - t0
-def timed(fn, reps=3):
-    fn(); torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(reps): fn()
-    torch.cuda.synchronize(); return round((time.perf_counter() - t0) / reps * 1e3, 3)
-out = {"P": P, "N": N, "M": len(op), "pairs": ba.Q, "setup_s": round(t_setup, 2), "half_bandwidth": ba.half_bandwidth, "n": ba.n6}
-out["linearize_ms"] = timed(lambda: ba.linearize(1e-4))
-def lin_solve(): ba.linearize(1e-4); ba.solve(1e-4)
-out["linearize+solve_ms"] = timed(lin_solve)
-out["backsub_ms"] = timed(lambda: ba.backsub(1e-4))
-out["cost_ms"] = timed(lambda: ba.cost())
-t0 = time.time(); hist = ba.optimize(mode="lm"); out["lm_s"] = round(time.time() - t0, 2); out["lm_iters"] = len(hist) - 1
-out["cost0"], out["cost1"] = hist[0], hist[-1]
-print(json.dumps(out))
+
+
+def run(P=881, N=13293, track=17):
+    rng = np.random.default_rng(0)
+    # camera moving along x, looking down +z at a slab of points 8..12 units away
+    poses = np.zeros((P, 12)); poses[:, [0, 4, 8]] = 1.0; poses[:, 9] = np.linspace(0, 0.05 * P, P)
+    pts = np.stack([rng.uniform(-1, 0.05 * P + 1, N), rng.uniform(-3, 3, N), rng.uniform(8, 12, N)], 1)
+    K = np.array([[481.2, 480.0, 0, 319.5, 239.5, 0, 0, 0, 0]])
+    c = np.clip((pts[:, 0] / 0.05).astype(np.int64), 0, P - 1)
+    a = np.maximum(0, np.minimum(P - track, c - track // 2))
+    op = (a[:, None] + np.arange(track)[None, :]).reshape(-1)                        # track consecutive poses per landmark
+    q = np.repeat(pts, track, axis=0) - poses[op, 9:]
+    uv = np.stack([481.2 * q[:, 0] / q[:, 2] + 319.5, 480.0 * q[:, 1] / q[:, 2] + 239.5], 1) + rng.normal(0, 0.5, (len(op), 2))
+    ptr = np.arange(N + 1, dtype=np.int64) * track
+    SP = mqslam_amd.ba_io.SparseProblem
+    pr = SP(poses=poses + 0, pose_cam=np.zeros(P, np.int32), pose_key=[(0, j) for j in range(P)], calib=K, sigma=np.array([1.0]),
+            points=pts + rng.normal(0, 0.02, pts.shape), obs_ptr=ptr, obs_pose=op.astype(np.int32), obs_uv=uv,
+            prior_w=np.where(np.arange(N) < 100, 16.0, 0.0), prior_xyz=pts.copy(), pose_prior_idx=np.array([0], np.int32),
+            pose_prior_sigmas=np.array([[0.002] * 3 + [0.001] * 3]), odo_from=np.zeros(0, np.int32), odo_to=np.zeros(0, np.int32),
+            odo_meas=np.zeros((0, 12)), odo_sigmas=np.zeros((0, 6)))
+    t0 = time.time(); ba = mqslam_amd.sparse_ba.SparseBundleAdjuster(pr); t_setup = time.time() - t0
+
+    def timed(fn, reps=3):
+        fn(); torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(reps): fn()
+        torch.cuda.synchronize(); return round((time.perf_counter() - t0) / reps * 1e3, 3)
+
+    out = {"P": P, "N": N, "M": len(op), "pairs": ba.Q, "pose_pair_groups": ba.G, "setup_s": round(t_setup, 2),
+           "half_bandwidth": ba.half_bandwidth, "n": ba.n6}
+    out["linearize_ms"] = timed(lambda: ba.linearize(1e-4))
+    def lin_solve(): ba.linearize(1e-4); ba.solve(1e-4)
+    out["linearize+solve_ms"] = timed(lin_solve)
+    out["backsub_ms"] = timed(lambda: ba.backsub(1e-4))
+    out["cost_ms"] = timed(lambda: ba.cost())
+    t0 = time.time(); hist = ba.optimize(mode="lm"); out["lm_s"] = round(time.time() - t0, 2); out["lm_iters"] = len(hist) - 1
+    out["cost0"], out["cost1"] = hist[0], hist[-1]
+    return out
+
+
+if __name__ == "__main__":
+    a = [int(v) for v in sys.argv[1:4]]
+    print(json.dumps(run(*a)))
