@@ -367,7 +367,38 @@ def main():
                       "sample": "1 GN iteration (linearise + Schur + solve + back-substitute) on %d landmarks x %d cams, "
                                 "oracle/c/ba_oracle.c with OpenMP on all host cores, scaled linearly to %d landmarks "
                                 "(CPU restatement, not GTSAM)" % (nb, C, N)}
-        cpu = {"value": round(ns / t_cpu), "unit": "landmarks/s", "cores": 1, "kind": "port", "ba": ba_cpu,
+        # BASELINE configs[0]: 10 000 landmarks x 2 cameras -- the reference's Python path (`ref_np`: one small SVD solve per
+        # point and iteration, oracle/triangulation_np.py's per-point loop, on a bounded sample) beside the same 2-view call
+        # through this build's host-pointer facade (PCIe and launch inclusive)
+        from oracle import triangulation_np as tnp
+        u2, P2, _ = syn.triangulation_problem(10_000, 2)
+        nsmp = 1500
+        t0 = time.perf_counter()
+        tnp.iterative_LS_triangulation_loop(u2[:, :nsmp], P2)
+        t_np = time.perf_counter() - t0
+        T = mqslam_amd.triangulation
+        T.iterative_LS_triangulation(u2[0], P2[0], u2[1], P2[1])
+        t0 = time.perf_counter()
+        for _ in range(20):
+            T.iterative_LS_triangulation(u2[0], P2[0], u2[1], P2[1])
+        t_call = (time.perf_counter() - t0) / 20
+        cfg0 = {"workload": "10 000 landmarks x 2 cameras, iterative-LS (BASELINE configs[0] shape)",
+                "ref_np_landmarks_per_s": round(nsmp / t_np), "ref_np_sample": "%d landmarks, per-point numpy loop, 1 thread" % nsmp,
+                "gpu_host_pointer_call_ms": round(1e3 * t_call, 4), "gpu_host_pointer_landmarks_per_s": round(10_000 / t_call)}
+        # matcher: numpy Hamming all-pairs with lowest-index tie-break (`match_np`) on a bounded block of query rows
+        match_cpu = None
+        if match_out is not None:
+            from oracle import matching_np
+            nd, nq = args.descriptors, 512
+            tbm = mqslam_amd.matching.binary_descriptors(nd, 256, seed=7)
+            qbm = mqslam_amd.matching.binary_descriptors(nq, 256, seed=8, copies_of=tbm.astype(np.uint8))
+            t0 = time.perf_counter()
+            matching_np.knn2_hamming_bits(qbm, tbm)
+            t_m = time.perf_counter() - t0
+            match_cpu = {"query_rows_per_s": round(nq / t_m), "sample": "%d query rows x %d train rows x 256 bits, numpy (BLAS default "
+                         "threads), oracle/matching_np.py" % (nq, nd), "cores": os.cpu_count()}
+        cpu = {"value": round(ns / t_cpu), "unit": "landmarks/s", "cores": 1, "kind": "port", "ba": ba_cpu, "configs0": cfg0,
+               "match": match_cpu,
                "sample": "linear-LS + iterative-LS over %d landmarks x %d cams (the same arrays), 1 pass, "
                          "oracle/c/tri_oracle.c, gcc -O2, single thread as the reference ships it" % (ns, C),
                "all_cores": {"value": round(ns / t_omp), "cores": os.cpu_count(),
