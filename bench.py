@@ -143,11 +143,16 @@ def main():
                 valu = rec.get("valu")
         except Exception:
             traffic = None
+    valu_it = dict((valu or {}).get("iterative_ls") or {})
+    if valu_it.get("fp64_flop_per_landmark_static_count"):
+        tf = valu_it["fp64_flop_per_landmark_static_count"] * N / (ms_it * 1e-3) / 1e12
+        valu_it["fp64_TFLOPs_at_measured_time"] = round(tf, 1)
+        valu_it["frac_of_fp64_vector_peak_78.6TF"] = round(tf / 78.6, 3)
     roofline = {"bound": "hbm", "kernel": "tri_kernel<%d, iterative_ls>" % C, "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                 "traffic": traffic, "algorithmic_bytes_per_launch": bytes_it,
                 "avg_launch_ms": round(ms_it, 5),
-                "valu_pmc": (valu or {}).get("iterative_ls"),
+                "valu_pmc": valu_it or None,
                 "note": "dominant kernel of the triangulation metric; by time the step's largest kernel is "
                         "ba_linearize_kernel (see rooflines): both are bound by fp64 VALU issue, not HBM"}
     kernels = {
