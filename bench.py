@@ -4,7 +4,7 @@ Benchmark of the MI355X hot path on BASELINE.json's headline configuration:
 1e6 landmarks x 4 cameras per GPU (configs[1]); synthetic scene of SURVEY.md 8(d).
 
 One STEP = one pass of the triangulation hot path over the rank's resident batch:
-linear-LS (DLT) + Hartley-Sturm iterative-LS over all landmarks, followed -- once the BA
+linear-LS (DLT) + Hartley-Sturm iterative-LS over all landmarks (one fused launch producing both), followed -- once the BA
 kernels are built in (see `ba` in the output) -- by one Gauss-Newton iteration of bundle
 adjustment (linearise + Schur + reduce + solve + back-substitute) on the same landmarks.
 Inputs are resident in HBM before the timed region.  `value` = landmarks (all ranks) / step.
@@ -91,8 +91,10 @@ def main():
             u, P, x_it, dev, seed=syn.RSEED, process_group=True if world > 1 else None)
 
     def triangulate():
-        D.linear_LS_triangulation(ud, Pd, out=x_ls)
-        D.iterative_LS_triangulation(ud, Pd, out=x_it, out_status=st)
+        # both least-squares methods in one pass over the observations: the first solve of the iteration (unit weights) is
+        # the linear-LS system, so x_ls costs one refinement step instead of a second read (bit-identical x_it / status,
+        # x_ls equal to the stand-alone kernel to rounding: tests/test_triangulation_gpu.py)
+        D.linear_and_iterative_LS_triangulation(ud, Pd, out_ls=x_ls, out_it=x_it, out_status=st)
 
     def step():
         # the triangulation launches do not depend on the BA state: issued between the start of the BA

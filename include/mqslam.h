@@ -99,6 +99,13 @@ int mqs_triangulate_iterative_ls_dev(const double *u, const double *P, int C, in
                                      void *stream);
 int mqs_triangulate_linear_eigen_dev(const double *u, const double *P, int C, int64_t N,
                                      double max_coord, double *x, uint8_t *ok, void *stream);
+/* linear_LS AND iterative_LS of the same observations in one pass (the reference's harness calls every method on the
+ * same inputs, triangulation_comparison.py:590): the first solve of the iteration, with unit weights, IS the linear-LS
+ * system (triangulation.c:65-83 vs :104-130), so x_ls costs one extra refinement step instead of a second read of the
+ * observations.  x_it / status as mqs_triangulate_iterative_ls_dev; x_ls equals mqs_triangulate_linear_ls_dev to rounding
+ * (the Gram matrix is summed camera by camera here).  max_iter >= 1. */
+int mqs_triangulate_ls_and_iterative_dev(const double *u, const double *P, int C, int64_t N, double tolerance,
+                                         int max_iter, double *x_ls, double *x_it, int32_t *status, void *stream);
 
 /* Fused form: observations given in PIXELS [C][N][2] with per-camera intrinsics intr [C][9]
  * (fx fy cx cy k1 k2 p1 p2 k3); undistort + normalise (cv2.undistortPoints, slam2.py:551-552) happens on

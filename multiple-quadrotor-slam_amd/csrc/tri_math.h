@@ -414,9 +414,16 @@ struct IterResult {
 
 // T2 iteration.  Does not keep `uv` alive past the Gram set-up, so that a kernel can re-read
 // the observations for refine<C>() instead of holding them in registers through the loop.
-template <int C>
+// Hook for callers that also want the FIRST solve of the iteration -- with unit weights it is the linear-LS system of
+// triangulation.c:65-83, so linear-LS comes for free from an iterative-LS pass (the fused kernel parks it in LDS: holding
+// it in registers through the loop would cost the loop its occupancy).
+struct NoFirstSolve {
+    MQS_HD void operator()(const Vec3 &, const Ldlt3 &) const {}
+};
+
+template <int C, class First = NoFirstSolve>
 MQS_HD void iterative_ls_core(const double (*uv)[2], const double *P, const double *Pdepth, double tol,
-                              int max_iter, IterResult<C> &out)
+                              int max_iter, IterResult<C> &out, const First &first = First())
 {
     // P      : camera matrices for the Gram set-up (the kernels pass their LDS copy)
     // Pdepth : the same matrices for the depth rows read in every iteration (the kernels pass
@@ -472,6 +479,7 @@ MQS_HD void iterative_ls_core(const double (*uv)[2], const double *P, const doub
             h.x = fma(w2[c], hc[c].x, h.x); h.y = fma(w2[c], hc[c].y, h.y); h.z = fma(w2[c], hc[c].z, h.z);
         }
         x = solve_normal3(G, h, f);                        // :130
+        if (i == 0) first(x, f);
         bool conv = true, zero = false;
 #pragma unroll
         for (int c = 0; c < C; ++c) {                      // :133-134

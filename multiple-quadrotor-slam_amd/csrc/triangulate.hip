@@ -26,7 +26,7 @@ namespace {
 
 constexpr int kBlock = 256;
 
-enum TriKind { kLinearLS = 0, kIterativeLS = 1, kLinearEigen = 2 };
+enum TriKind { kLinearLS = 0, kIterativeLS = 1, kLinearEigen = 2, kLsAndIterative = 3 };
 
 // Minimum waves per SIMD requested from the register allocator per kernel kind (tuned on
 // MI355X, see DESIGN.md "Triangulation kernels"): the iterative kernel is fp64-VALU bound and
@@ -37,7 +37,7 @@ enum TriKind { kLinearLS = 0, kIterativeLS = 1, kLinearEigen = 2 };
 // The iteration keeps 12 doubles per camera live (Gram piece 6, right-hand side 3, weight and two depths): beyond four
 // cameras that no longer fits the 168 registers of three waves per SIMD (it spilled inside the loop: 5 / 6 / 8 cameras
 // ran 1.8x / 3.6x / 11x the 4-camera time instead of ~1.2x / 1.35x / 1.7x) -- fewer resident waves, no spills.
-constexpr int waves_for(int kind, int cams) { return kind != 1 ? 2 : (cams <= 4 ? MQS_ITER_WAVES : (cams <= 6 ? 2 : 1)); }
+constexpr int waves_for(int kind, int cams) { return (kind != 1 && kind != 3) ? 2 : (cams <= 4 ? MQS_ITER_WAVES : (cams <= 6 ? 2 : 1)); }
 
 // PIX: the observations are PIXELS and `intr` holds [C][9] intrinsics (fx fy cx cy k1 k2 p1 p2 k3): the
 // undistort + normalise step the reference runs right before triangulating (cv2.undistortPoints,
@@ -47,11 +47,13 @@ __global__ __launch_bounds__(kBlock, waves_for(KIND, C)) void tri_kernel(const d
                                                                       const double *__restrict__ intr,
                                                      int64_t N, double tol, int max_iter, double max_coord,
                                                      double *__restrict__ x, int32_t *__restrict__ status,
-                                                     uint8_t *__restrict__ ok)
+                                                     uint8_t *__restrict__ ok, double *__restrict__ x_ls)
 {
     __shared__ double sP[C * 12];
     __shared__ double sX[kBlock * 3];
     __shared__ double sI[PIX ? C * 9 : 1];
+    // fused linear-LS + iterative-LS: the first solve (3) and its factor (6 + ok) wait here for the refinement step
+    __shared__ double sFirst[KIND == kLsAndIterative ? 10 * kBlock : 1];
 
     const int tid = threadIdx.x;
     if (tid < C * 12) sP[tid] = P[tid];
@@ -78,9 +80,24 @@ __global__ __launch_bounds__(kBlock, waves_for(KIND, C)) void tri_kernel(const d
         mqs::Vec3 r;
         if (KIND == kLinearLS) {
             r = mqs::linear_ls_point<C>(uv, sP);
-        } else if (KIND == kIterativeLS) {
+        } else if (KIND == kIterativeLS || KIND == kLsAndIterative) {
             mqs::IterResult<C> it;
-            mqs::iterative_ls_core<C>(uv, sP, P, tol, max_iter, it);
+            if (KIND == kLsAndIterative) {
+                struct Park {
+                    double *s;
+                    __device__ __forceinline__ void operator()(const mqs::Vec3 &x0, const mqs::Ldlt3 &f0) const
+                    {
+                        s[0 * kBlock] = x0.x; s[1 * kBlock] = x0.y; s[2 * kBlock] = x0.z;
+                        s[3 * kBlock] = f0.i0; s[4 * kBlock] = f0.i1; s[5 * kBlock] = f0.i2;
+                        s[6 * kBlock] = f0.l10; s[7 * kBlock] = f0.l20; s[8 * kBlock] = f0.l21;
+                        s[9 * kBlock] = f0.ok ? 1.0 : 0.0;
+                    }
+                };
+                const Park park = {sFirst + tid};
+                mqs::iterative_ls_core<C, Park>(uv, sP, P, tol, max_iter, it, park);
+            } else {
+                mqs::iterative_ls_core<C>(uv, sP, P, tol, max_iter, it);
+            }
             if (live) status[i] = it.status;
             r = it.x;
             if (it.solved) {
@@ -98,6 +115,31 @@ __global__ __launch_bounds__(kBlock, waves_for(KIND, C)) void tri_kernel(const d
                 }
                 const mqs::Sym3 unused = {0, 0, 0, 0, 0, 0};
                 r = mqs::refine<C>(it.x, uv2, sP, it.w2, unused, it.f);
+                if (KIND == kLsAndIterative) {
+                    // linear-LS = the first solve, refined with unit weights (linear_ls_point), written through the same
+                    // LDS transpose as the iterative result below
+                    const double *s = sFirst + tid;
+                    const mqs::Vec3 x0 = {s[0 * kBlock], s[1 * kBlock], s[2 * kBlock]};
+                    const mqs::Ldlt3 f0 = {s[3 * kBlock], s[4 * kBlock], s[5 * kBlock], s[6 * kBlock], s[7 * kBlock], s[8 * kBlock],
+                                           s[9 * kBlock] != 0.0};
+                    double ones[C];
+#pragma unroll
+                    for (int c = 0; c < C; ++c) ones[c] = 1.0;
+                    const mqs::Vec3 rl = mqs::refine<C>(x0, uv2, sP, ones, unused, f0);
+                    sX[tid * 3 + 0] = rl.x;
+                    sX[tid * 3 + 1] = rl.y;
+                    sX[tid * 3 + 2] = rl.z;
+                    __syncthreads();
+                    const int64_t rem = N - base;
+                    const int npts = rem < kBlock ? (int)rem : kBlock;
+                    const int ndbl = npts * 3;
+                    double *__restrict__ xo = x_ls + base * 3;
+                    const double2 *sX2 = reinterpret_cast<const double2 *>(sX);
+                    double2 *xo2 = reinterpret_cast<double2 *>(xo);
+                    for (int p = tid; p < (ndbl >> 1); p += kBlock) xo2[p] = sX2[p];
+                    if ((ndbl & 1) && tid == 0) xo[ndbl - 1] = sX[ndbl - 1];
+                    __syncthreads();
+                }
             }
         } else {
             bool o;
@@ -125,14 +167,19 @@ __global__ __launch_bounds__(kBlock, waves_for(KIND, C)) void tri_kernel(const d
 
 template <int KIND>
 int launch_tri(const double *u, const double *P, int C, int64_t N, double tol, int max_iter, double max_coord,
-               double *x, int32_t *status, uint8_t *ok, hipStream_t stream, const double *intr = nullptr)
+               double *x, int32_t *status, uint8_t *ok, hipStream_t stream, const double *intr = nullptr,
+               double *x_ls = nullptr)
 {
     MQS_ARG_CHECK(C >= 2 && C <= MQS_MAX_CAMS, "2 <= C <= MQS_MAX_CAMS");
     MQS_ARG_CHECK(N >= 0, "N >= 0");
     if (N == 0) return MQS_OK;
     MQS_ARG_CHECK(u && P && x, "u, P, x must not be null");
     MQS_ARG_CHECK(mqs_aligned16(u) && mqs_aligned16(x), "device pointers must be 16-byte aligned");
-    if (KIND == kIterativeLS) MQS_ARG_CHECK(status != nullptr, "status must not be null");
+    if (KIND == kIterativeLS || KIND == kLsAndIterative) MQS_ARG_CHECK(status != nullptr, "status must not be null");
+    if (KIND == kLsAndIterative) {
+        MQS_ARG_CHECK(x_ls != nullptr && mqs_aligned16(x_ls), "x_ls must not be null and 16-byte aligned");
+        MQS_ARG_CHECK(max_iter >= 1, "max_iter >= 1 (linear-LS is the first solve of the iteration)");
+    }
     if (KIND == kLinearEigen) MQS_ARG_CHECK(ok != nullptr, "ok must not be null");
     const dim3 grid(mqs_stream_grid(N, kBlock)), block(kBlock);
     switch (C) {
@@ -140,10 +187,10 @@ int launch_tri(const double *u, const double *P, int C, int64_t N, double tol, i
     case c:                                                                                     \
         if (intr)                                                                               \
             hipLaunchKernelGGL((tri_kernel<c, KIND, true>), grid, block, 0, stream, u, P, intr, N, tol, \
-                               max_iter, max_coord, x, status, ok);                             \
+                               max_iter, max_coord, x, status, ok, x_ls);                       \
         else                                                                                    \
             hipLaunchKernelGGL((tri_kernel<c, KIND, false>), grid, block, 0, stream, u, P, intr, N, tol, \
-                               max_iter, max_coord, x, status, ok);                             \
+                               max_iter, max_coord, x, status, ok, x_ls);                       \
         break;
         MQS_CASE(2) MQS_CASE(3) MQS_CASE(4) MQS_CASE(5) MQS_CASE(6) MQS_CASE(7) MQS_CASE(8)
 #undef MQS_CASE
@@ -214,6 +261,13 @@ int mqs_triangulate_iterative_ls_dev(const double *u, const double *P, int C, in
 {
     return launch_tri<kIterativeLS>(u, P, C, N, tolerance, max_iter, 0.0, x, status, nullptr,
                                     static_cast<hipStream_t>(stream));
+}
+
+int mqs_triangulate_ls_and_iterative_dev(const double *u, const double *P, int C, int64_t N, double tolerance, int max_iter,
+                                         double *x_ls, double *x_it, int32_t *status, void *stream)
+{
+    return launch_tri<kLsAndIterative>(u, P, C, N, tolerance, max_iter, 0.0, x_it, status, nullptr,
+                                       static_cast<hipStream_t>(stream), nullptr, x_ls);
 }
 
 int mqs_triangulate_linear_eigen_dev(const double *u, const double *P, int C, int64_t N, double max_coord, double *x,

@@ -62,6 +62,19 @@ def iterative_LS_triangulation(u, P, tolerance=3.e-5, max_iter=10, out=None, out
     return x, st
 
 
+def linear_and_iterative_LS_triangulation(u, P, tolerance=3.e-5, max_iter=10, out_ls=None, out_it=None, out_status=None):
+    """Both least-squares methods in ONE pass over the observations (mqs_triangulate_ls_and_iterative_dev): returns
+    (x_linear_LS, x_iterative_LS, status)."""
+    torch = _torch()
+    C, N = _tri_args(u, P)
+    x_ls = out_ls if out_ls is not None else torch.empty((N, 3), dtype=torch.float64, device=u.device)
+    x_it = out_it if out_it is not None else torch.empty((N, 3), dtype=torch.float64, device=u.device)
+    st = out_status if out_status is not None else torch.empty((N,), dtype=torch.int32, device=u.device)
+    _lib.check(_lib.lib().mqs_triangulate_ls_and_iterative_dev(u.data_ptr(), P.data_ptr(), C, N, float(tolerance), int(max_iter),
+                                                               x_ls.data_ptr(), x_it.data_ptr(), st.data_ptr(), _stream_ptr()))
+    return x_ls, x_it, st
+
+
 def linear_eigen_triangulation(u, P, max_coordinate_value=1.e16, out=None, out_ok=None):
     """-> x (N,3) f64, ok (N,) uint8."""
     torch = _torch()

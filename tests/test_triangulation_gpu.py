@@ -209,3 +209,26 @@ def test_baseline_config0_10k_two_cameras(gpu, c_oracle):
     xl = T.linear_LS_triangulation(u[:, :500], P)
     xl = xl[0] if isinstance(xl, tuple) else xl
     assert np.max(rel_err(t.linear_LS_triangulation(u[0, :500], P[0], u[1, :500], P[1])[0], xl)) < TOL
+
+
+@pytest.mark.parametrize("C", [2, 4, 7])
+def test_fused_linear_and_iterative_pass(C, gpu, c_oracle):
+    """mqs_triangulate_ls_and_iterative_dev: one pass, both least-squares methods.  The iterative result and the status
+    codes are the stand-alone kernel's bit for bit; linear-LS (the first solve of the iteration, unit weights) equals the
+    stand-alone kernel to rounding and the oracle to the parity bar."""
+    import torch
+    u, P, _ = random_scene(3001, C, seed=77 + C, behind_frac=0.05)
+    ud, Pd = torch.from_numpy(u).cuda(), torch.from_numpy(np.ascontiguousarray(P)).cuda()
+    D = gpu.device
+    x_ls, x_it, st = D.linear_and_iterative_LS_triangulation(ud, Pd)
+    xi, si = D.iterative_LS_triangulation(ud, Pd)
+    xl = D.linear_LS_triangulation(ud, Pd)
+    torch.cuda.synchronize()
+    assert torch.equal(x_it, xi) and torch.equal(st, si)
+    xo, _ = c_oracle.linear_LS_triangulation(u, P)
+    good = stable_mask(c_oracle.linear_LS_triangulation, u, P, xo, None)
+    assert good.mean() > 0.99
+    assert np.max(rel_err(x_ls.cpu().numpy()[good], xo[good])) < TOL
+    assert np.median(rel_err(x_ls.cpu().numpy()[good], xl.cpu().numpy()[good])) < 1e-13
+    with pytest.raises(RuntimeError):
+        D.linear_and_iterative_LS_triangulation(ud, Pd, max_iter=0)
