@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--cams", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ba", action="store_true")
+    ap.add_argument("--one-stream", action="store_true", help="triangulation and BA on one stream (A/B of the two-stream step)")
     ap.add_argument("--no-match", action="store_true")
     ap.add_argument("--no-replay", action="store_true")
     ap.add_argument("--no-frontend", action="store_true")
@@ -96,11 +97,19 @@ def main():
         # x_ls equal to the stand-alone kernel to rounding: tests/test_triangulation_gpu.py)
         D.linear_and_iterative_LS_triangulation(ud, Pd, out_ls=x_ls, out_it=x_it, out_status=st)
 
+    # The triangulation pass and the BA iteration of a step are independent pipelines (the BA state was seeded from an
+    # earlier triangulation): the triangulation goes to its own HIP stream, where it fills what the BA chain leaves idle
+    # -- the single-wavefront reduced-system solve (12 us), the 6-workgroup finalize, the all-reduce wait at N > 1, the
+    # launch gaps.  Both streams are drained by the device-wide synchronize that brackets the timed region.
+    side = torch.cuda.Stream(device=dev) if (ba is not None and not args.one_stream) else None
+
     def step():
-        # the triangulation launches do not depend on the BA state: issued between the start of the BA
-        # all-reduce and the wait for it, they hide the collective's latency (same work, same stream)
-        if ba is not None:
-            ba.gauss_newton_iteration(overlap=triangulate)
+        if side is not None:
+            with torch.cuda.stream(side):
+                triangulate()
+            ba.gauss_newton_iteration()
+        elif ba is not None:
+            ba.gauss_newton_iteration(overlap=triangulate)     # one stream: issued inside the all-reduce window
         else:
             triangulate()
 
