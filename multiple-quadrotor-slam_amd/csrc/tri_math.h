@@ -14,8 +14,10 @@
 
 #if defined(__HIPCC__)
 #define MQS_HD __host__ __device__ __forceinline__
+#define MQS_HD_MEMBER __host__ __device__ __forceinline__
 #else
 #define MQS_HD static inline
+#define MQS_HD_MEMBER inline
 #endif
 
 // Scheduling fence between the per-camera sections of the BA arithmetic: stops the machine
@@ -418,7 +420,7 @@ struct IterResult {
 // triangulation.c:65-83, so linear-LS comes for free from an iterative-LS pass (the fused kernel parks it in LDS: holding
 // it in registers through the loop would cost the loop its occupancy).
 struct NoFirstSolve {
-    MQS_HD void operator()(const Vec3 &, const Ldlt3 &) const {}
+    MQS_HD_MEMBER void operator()(const Vec3 &, const Ldlt3 &) const {}
 };
 
 template <int C, class First = NoFirstSolve>
