@@ -3,6 +3,10 @@
 #include <string.h>
 #include <new>
 
+#ifndef MQS_ZERO_COPY
+#define MQS_ZERO_COPY 1            // 0: always stage through the device scratch (A/B builds)
+#endif
+
 namespace {
 thread_local char g_err[512] = "";
 }
@@ -33,6 +37,28 @@ int mqs_ctx_reserve(mqs_ctx *ctx, size_t bytes)
     }
     ctx->dbuf_bytes = want;
     return MQS_OK;
+}
+
+int mqs_stage_begin(mqs_ctx *ctx, size_t bytes, mqs_stage *st)
+{
+    st->ctx = ctx;
+    st->n_out = 0;
+    st->zero_copy = false;
+    if (bytes <= kZeroCopyMax && MQS_ZERO_COPY) {
+        if (!ctx->hbuf) {
+            // coherent (fine-grained) pinned memory: kernel writes are visible to the host once the stream has drained
+            if (hipHostMalloc(&ctx->hbuf, kZeroCopyMax, hipHostMallocDefault) == hipSuccess) ctx->hbuf_bytes = kZeroCopyMax;
+            else { ctx->hbuf = nullptr; (void)hipGetLastError(); }
+        }
+        if (ctx->hbuf) {
+            st->base = static_cast<char *>(ctx->hbuf);
+            st->zero_copy = true;
+            return MQS_OK;
+        }
+    }
+    const int rc = mqs_ctx_reserve(ctx, bytes);
+    st->base = static_cast<char *>(ctx->dbuf);
+    return rc;
 }
 
 extern "C" {
@@ -67,6 +93,8 @@ int mqs_create(int device_id, mqs_ctx **out)
     ctx->device = device_id;
     ctx->dbuf = nullptr;
     ctx->dbuf_bytes = 0;
+    ctx->hbuf = nullptr;
+    ctx->hbuf_bytes = 0;
     hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         mqs_set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
@@ -83,6 +111,7 @@ void mqs_destroy(mqs_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->dbuf) (void)hipFree(ctx->dbuf);
+    if (ctx->hbuf) (void)hipHostFree(ctx->hbuf);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

@@ -133,15 +133,16 @@ int mqs_undistort_points(mqs_ctx *ctx, const double *pixels, const double *intr,
     MQS_HIP_CHECK(hipSetDevice(ctx->device));
     auto up = [](size_t v) { return (v + 255) & ~size_t(255); };
     const size_t o_p = 0, o_o = up((size_t)N * 16), o_i = up(o_o + (size_t)N * 16), total = up(o_i + 72);
-    int rc = mqs_ctx_reserve(ctx, total);
+    mqs_stage st;
+    int rc = mqs_stage_begin(ctx, total, &st);
     if (rc != MQS_OK) return rc;
-    char *d = static_cast<char *>(ctx->dbuf);
-    MQS_HIP_CHECK(hipMemcpyAsync(d + o_p, pixels, (size_t)N * 16, hipMemcpyHostToDevice, ctx->stream));
-    MQS_HIP_CHECK(hipMemcpyAsync(d + o_i, intr, 72, hipMemcpyHostToDevice, ctx->stream));
+    char *d = st.base;
+    MQS_HIP_CHECK(mqs_stage_in(&st, d + o_p, pixels, (size_t)N * 16));
+    MQS_HIP_CHECK(mqs_stage_in(&st, d + o_i, intr, 72));
     rc = mqs_undistort_points_dev((const double *)(d + o_p), (const double *)(d + o_i), N, (double *)(d + o_o), ctx->stream);
     if (rc != MQS_OK) return rc;
-    MQS_HIP_CHECK(hipMemcpyAsync(out, d + o_o, (size_t)N * 16, hipMemcpyDeviceToHost, ctx->stream));
-    MQS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    MQS_HIP_CHECK(mqs_stage_out(&st, out, d + o_o, (size_t)N * 16));
+    MQS_HIP_CHECK(mqs_stage_end(&st));
     return MQS_OK;
 }
 

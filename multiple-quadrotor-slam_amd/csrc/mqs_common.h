@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <string.h>
 #include "../../include/mqslam.h"
 
 void mqs_set_error(const char *fmt, ...);
@@ -30,10 +31,44 @@ struct mqs_ctx {
     hipStream_t stream;
     void *dbuf;        // grow-only device scratch for the host-pointer entry points
     size_t dbuf_bytes;
+    void *hbuf;        // pinned, GPU-visible host buffer for the small-call path (see mqs_stage)
+    size_t hbuf_bytes;
 };
 
 // Ensures ctx->dbuf holds at least `bytes`; returns MQS_OK or an error code.
 int mqs_ctx_reserve(mqs_ctx *ctx, size_t bytes);
+
+// Small-call path of the single-pass host-pointer entry points (the reference's real sizes: <= 300 points per call,
+// slam2.py:1080-1082).  Below kZeroCopyMax bytes the "device" buffer IS a pinned host buffer the kernel reads and writes
+// over the fabric: inputs are a CPU memcpy, outputs a CPU memcpy after the stream has drained -- no hipMemcpy calls at all
+// (each costs ~8-10 us from pageable memory; five of them made a 300-point call 66 us).  Only for kernels that touch
+// every byte once; iterative kernels (pose refinement) keep the device scratch.
+constexpr size_t kZeroCopyMax = 256 * 1024;
+struct mqs_stage {
+    mqs_ctx *ctx;
+    char *base;                 // where the call's layout lives (device scratch, or the pinned host buffer)
+    bool zero_copy;
+    int n_out;
+    struct { void *user; const void *src; size_t bytes; } out[6];
+};
+int mqs_stage_begin(mqs_ctx *ctx, size_t bytes, mqs_stage *st);
+inline hipError_t mqs_stage_in(mqs_stage *st, void *dst, const void *src, size_t bytes)
+{
+    if (st->zero_copy) { memcpy(dst, src, bytes); return hipSuccess; }
+    return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st->ctx->stream);
+}
+inline hipError_t mqs_stage_out(mqs_stage *st, void *user, const void *src, size_t bytes)
+{
+    if (st->zero_copy) { st->out[st->n_out].user = user; st->out[st->n_out].src = src; st->out[st->n_out].bytes = bytes; ++st->n_out; return hipSuccess; }
+    return hipMemcpyAsync(user, src, bytes, hipMemcpyDeviceToHost, st->ctx->stream);
+}
+inline hipError_t mqs_stage_end(mqs_stage *st)
+{
+    const hipError_t e = hipStreamSynchronize(st->ctx->stream);
+    if (e == hipSuccess && st->zero_copy)
+        for (int k = 0; k < st->n_out; ++k) memcpy(st->out[k].user, st->out[k].src, st->out[k].bytes);
+    return e;
+}
 
 // Wave-private LDS hand-off (one lane writes, other lanes of the SAME wavefront read later): the LDS pipe executes a
 // wavefront's accesses in order, so all that is needed is that the compiler keeps the order (memory clobber) and the

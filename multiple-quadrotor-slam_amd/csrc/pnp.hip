@@ -364,6 +364,31 @@ int mqs_solve_pnp(mqs_ctx *ctx, const double *objp, const double *imgp, int64_t 
     if (rc != MQS_OK) return rc;
     char *d = static_cast<char *>(ctx->dbuf);
     hipStream_t s = ctx->stream;
+    // Small problems (every real frame: <= 300 correspondences): the inputs are packed into the pinned host buffer by the
+    // CPU and travel as ONE copy; the kernel keeps them in device memory (it re-reads them in every LM iteration) and
+    // writes the 16 doubles of its result straight into the pinned buffer -- one hipMemcpy per call instead of six.
+    mqs_stage st;
+    st.zero_copy = false;
+    if (2 * total <= kZeroCopyMax) {
+        rc = mqs_stage_begin(ctx, 2 * total, &st);
+        if (rc != MQS_OK) return rc;
+    }
+    if (st.zero_copy) {
+        char *h = st.base;
+        memcpy(h + o_obj, objp, (size_t)N * 24);
+        memcpy(h + o_img, imgp, (size_t)N * 16);
+        memcpy(h + o_intr, intr, 72);
+        memcpy(h + o_pose, pose, 96);
+        MQS_HIP_CHECK(hipMemcpyAsync(d, h, o_pose + 96, hipMemcpyHostToDevice, s));
+        double *h_pose = reinterpret_cast<double *>(h + total + o_pose), *h_info = reinterpret_cast<double *>(h + total + o_info);
+        rc = mqs_pnp_refine_dev((double *)(d + o_obj), (double *)(d + o_img), N, nullptr, nullptr, 1, (double *)(d + o_intr),
+                                (double *)(d + o_pose), use_guess, max_iter, eps, h_pose, h_info, s);
+        if (rc != MQS_OK) return rc;
+        MQS_HIP_CHECK(hipStreamSynchronize(s));
+        memcpy(pose, h_pose, 96);
+        if (info) memcpy(info, h_info, 32);
+        return MQS_OK;
+    }
     MQS_HIP_CHECK(hipMemcpyAsync(d + o_obj, objp, (size_t)N * 24, hipMemcpyHostToDevice, s));
     MQS_HIP_CHECK(hipMemcpyAsync(d + o_img, imgp, (size_t)N * 16, hipMemcpyHostToDevice, s));
     MQS_HIP_CHECK(hipMemcpyAsync(d + o_intr, intr, 72, hipMemcpyHostToDevice, s));

@@ -217,9 +217,10 @@ int run_host(mqs_ctx *ctx, const double *const *u_cams, const double *const *P_c
     const size_t o_s = up(o_P + (size_t)C * 96);
     const size_t o_k = up(o_s + (size_t)N * 4);
     const size_t total = up(o_k + (size_t)N);
-    int rc = mqs_ctx_reserve(ctx, total);
+    mqs_stage st;
+    int rc = mqs_stage_begin(ctx, total, &st);
     if (rc != MQS_OK) return rc;
-    char *d = static_cast<char *>(ctx->dbuf);
+    char *d = st.base;
     double *d_u = reinterpret_cast<double *>(d + o_u);
     double *d_x = reinterpret_cast<double *>(d + o_x);
     double *d_P = reinterpret_cast<double *>(d + o_P);
@@ -227,15 +228,15 @@ int run_host(mqs_ctx *ctx, const double *const *u_cams, const double *const *P_c
     uint8_t *d_k = reinterpret_cast<uint8_t *>(d + o_k);
     for (int c = 0; c < C; ++c) {
         MQS_ARG_CHECK(u_cams[c] && P_cams[c], "per-camera pointers must not be null");
-        MQS_HIP_CHECK(hipMemcpyAsync(d_u + (size_t)c * N * 2, u_cams[c], (size_t)N * 16, hipMemcpyHostToDevice, ctx->stream));
-        MQS_HIP_CHECK(hipMemcpyAsync(d_P + c * 12, P_cams[c], 96, hipMemcpyHostToDevice, ctx->stream));
+        MQS_HIP_CHECK(mqs_stage_in(&st, d_u + (size_t)c * N * 2, u_cams[c], (size_t)N * 16));
+        MQS_HIP_CHECK(mqs_stage_in(&st, d_P + c * 12, P_cams[c], 96));
     }
     rc = launch_tri<KIND>(d_u, d_P, C, N, tol, max_iter, max_coord, d_x, d_s, d_k, ctx->stream);
     if (rc != MQS_OK) return rc;
-    MQS_HIP_CHECK(hipMemcpyAsync(x, d_x, (size_t)N * 24, hipMemcpyDeviceToHost, ctx->stream));
-    if (KIND == kIterativeLS) MQS_HIP_CHECK(hipMemcpyAsync(status, d_s, (size_t)N * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (KIND == kLinearEigen) MQS_HIP_CHECK(hipMemcpyAsync(ok, d_k, (size_t)N, hipMemcpyDeviceToHost, ctx->stream));
-    MQS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    MQS_HIP_CHECK(mqs_stage_out(&st, x, d_x, (size_t)N * 24));
+    if (KIND == kIterativeLS) MQS_HIP_CHECK(mqs_stage_out(&st, status, d_s, (size_t)N * 4));
+    if (KIND == kLinearEigen) MQS_HIP_CHECK(mqs_stage_out(&st, ok, d_k, (size_t)N));
+    MQS_HIP_CHECK(mqs_stage_end(&st));
     return MQS_OK;
 }
 
