@@ -162,6 +162,32 @@ int mqs_project_points(mqs_ctx *ctx, const double *points, const double *P, cons
     if (rc != MQS_OK) return rc;
     char *d = static_cast<char *>(ctx->dbuf);
     hipStream_t s = ctx->stream;
+    // small problems: one packed copy in (points, measurements, P, intrinsics), one copy out (uv, depth, error)
+    mqs_stage st;
+    st.zero_copy = false;
+    if (o_w <= kZeroCopyMax && N > 0) {
+        rc = mqs_stage_begin(ctx, o_w, &st);
+        if (rc != MQS_OK) return rc;
+    }
+    if (st.zero_copy) {
+        char *h = st.base;
+        memcpy(h + o_x, points, (size_t)N * 24);
+        if (imgp) memcpy(h + o_m, imgp, (size_t)N * 16);
+        memcpy(h + o_P, P, 96);
+        memcpy(h + o_i, intr, 72);
+        MQS_HIP_CHECK(hipMemcpyAsync(d, h, o_e, hipMemcpyHostToDevice, s));
+        rc = mqs_project_points_dev((const double *)(d + o_x), (const double *)(d + o_P), (const double *)(d + o_i),
+                                    imgp ? (const double *)(d + o_m) : nullptr, N, uv_out ? (double *)(d + o_uv) : nullptr,
+                                    depth_out ? (double *)(d + o_z) : nullptr, sqerr_out ? (double *)(d + o_e) : nullptr, d + o_w,
+                                    mqs_project_workspace_bytes(), s);
+        if (rc != MQS_OK) return rc;
+        MQS_HIP_CHECK(hipMemcpyAsync(h + o_uv, d + o_uv, o_w - o_uv, hipMemcpyDeviceToHost, s));
+        MQS_HIP_CHECK(hipStreamSynchronize(s));
+        if (uv_out) memcpy(uv_out, h + o_uv, (size_t)N * 16);
+        if (depth_out) memcpy(depth_out, h + o_z, (size_t)N * 8);
+        if (sqerr_out) memcpy(sqerr_out, h + o_e, 8);
+        return MQS_OK;
+    }
     if (N > 0) MQS_HIP_CHECK(hipMemcpyAsync(d + o_x, points, (size_t)N * 24, hipMemcpyHostToDevice, s));
     if (N > 0 && imgp) MQS_HIP_CHECK(hipMemcpyAsync(d + o_m, imgp, (size_t)N * 16, hipMemcpyHostToDevice, s));
     MQS_HIP_CHECK(hipMemcpyAsync(d + o_P, P, 96, hipMemcpyHostToDevice, s));

@@ -421,6 +421,34 @@ int mqs_solve_pnp_ransac(mqs_ctx *ctx, const double *objp, const double *imgp, i
     if (rc != MQS_OK) return rc;
     char *d = static_cast<char *>(ctx->dbuf);
     hipStream_t s = ctx->stream;
+    // small problems: inputs packed by the CPU into the pinned buffer and sent as one copy, the four small results fetched
+    // as one copy (two hipMemcpy per call instead of eight; the kernels themselves stay on device memory)
+    const size_t io_bytes = o_smp + (size_t)B * sample_size * 4;
+    mqs_stage st;
+    st.zero_copy = false;
+    if (io_bytes <= kZeroCopyMax) {
+        rc = mqs_stage_begin(ctx, io_bytes, &st);
+        if (rc != MQS_OK) return rc;
+    }
+    if (st.zero_copy) {
+        char *h = st.base;
+        memcpy(h + o_obj, objp, (size_t)N * 24);
+        memcpy(h + o_img, imgp, (size_t)N * 16);
+        memcpy(h + o_intr, intr, 72);
+        memcpy(h + o_smp, samples, (size_t)B * sample_size * 4);
+        MQS_HIP_CHECK(hipMemcpyAsync(d, h, io_bytes, hipMemcpyHostToDevice, s));
+        rc = mqs_pnp_ransac_dev((double *)(d + o_obj), (double *)(d + o_img), N, (double *)(d + o_intr), (int32_t *)(d + o_smp), B,
+                                sample_size, reproj_error, sample_iters, max_iter, eps, (double *)(d + o_pose),
+                                (int32_t *)(d + o_sel), (uint8_t *)(d + o_mask), (double *)(d + o_info), d + o_ws, (int64_t)wsb, s);
+        if (rc != MQS_OK) return rc;
+        MQS_HIP_CHECK(hipMemcpyAsync(h + o_pose, d + o_pose, o_smp - o_pose, hipMemcpyDeviceToHost, s));
+        MQS_HIP_CHECK(hipStreamSynchronize(s));
+        memcpy(pose, h + o_pose, 96);
+        memcpy(sel, h + o_sel, 8);
+        if (mask) memcpy(mask, h + o_mask, (size_t)N);
+        if (info) memcpy(info, h + o_info, 32);
+        return MQS_OK;
+    }
     MQS_HIP_CHECK(hipMemcpyAsync(d + o_obj, objp, (size_t)N * 24, hipMemcpyHostToDevice, s));
     MQS_HIP_CHECK(hipMemcpyAsync(d + o_img, imgp, (size_t)N * 16, hipMemcpyHostToDevice, s));
     MQS_HIP_CHECK(hipMemcpyAsync(d + o_intr, intr, 72, hipMemcpyHostToDevice, s));
