@@ -105,8 +105,20 @@ def solvePnP(objp, imgp, cameraMatrix, distCoeffs, rvec=None, tvec=None, useExtr
 def draw_samples(n_points, hypotheses=RANSAC_HYPOTHESES, sample_size=RANSAC_SAMPLE_SIZE, seed=0):
     """Minimal samples without replacement, [hypotheses][sample_size] int32 (numpy PCG64, repeatable)."""
     rng = np.random.default_rng(seed)
-    keys = rng.random((hypotheses, n_points))
-    return np.ascontiguousarray(np.argsort(keys, axis=1)[:, :sample_size].astype(np.int32))
+    if n_points < 8 * sample_size:
+        # few points: the head of a random permutation per hypothesis
+        keys = rng.random((hypotheses, n_points))
+        return np.ascontiguousarray(np.argsort(keys, axis=1)[:, :sample_size].astype(np.int32))
+    # many points: independent draws, rows with a repeated index drawn again (a permutation per hypothesis costs a
+    # millisecond of host time per frame at 300 points -- more than the GPU spends on the whole RANSAC)
+    smp = rng.integers(0, n_points, (hypotheses, sample_size))
+    for _ in range(64):
+        srt = np.sort(smp, axis=1)
+        bad = np.nonzero((srt[:, 1:] == srt[:, :-1]).any(axis=1))[0]
+        if len(bad) == 0:
+            break
+        smp[bad] = rng.integers(0, n_points, (len(bad), sample_size))
+    return np.ascontiguousarray(smp.astype(np.int32))
 
 
 def solve_pnp_ransac_pose(objp, imgp, intr, reproj_error, samples=None, hypotheses=RANSAC_HYPOTHESES, seed=0,
