@@ -139,6 +139,10 @@ def main():
     ms_it = D.time_triangulation("iterative_ls", ud, Pd, reps=reps)
     ms_ls = D.time_triangulation("linear_ls", ud, Pd, reps=reps)
     ms_eg = D.time_triangulation("linear_eigen", ud, Pd, reps=reps)
+    ud32 = ud.float()                             # "also report an fp32-u variant" (widened on load)
+    ms_ls32 = D.time_triangulation("linear_ls", ud32, Pd, reps=reps)
+    ms_it32 = D.time_triangulation("iterative_ls", ud32, Pd, reps=reps)
+    del ud32
     bytes_it = N * (16 * C + 24 + 4)            # 92 B/landmark at C = 4
     bytes_ls = N * (16 * C + 24)
     bytes_eg = N * (16 * C + 24 + 1)
@@ -173,6 +177,10 @@ def main():
                       "GBps": round(bytes_ls / (ms_ls * 1e-3) / 1e9, 1)},
         "linear_eigen": {"ms": round(ms_eg, 5), "landmarks_per_s": round(N / (ms_eg * 1e-3)),
                          "GBps": round(bytes_eg / (ms_eg * 1e-3) / 1e9, 1)},
+        "linear_ls_f32_observations": {"ms": round(ms_ls32, 5), "landmarks_per_s": round(N / (ms_ls32 * 1e-3)),
+                                       "GBps": round(N * (8 * C + 24) / (ms_ls32 * 1e-3) / 1e9, 1),
+                                       "algorithmic_bytes_per_landmark": 8 * C + 24},
+        "iterative_ls_f32_observations": {"ms": round(ms_it32, 5), "landmarks_per_s": round(N / (ms_it32 * 1e-3))},
     }
     ba_out = None
     if ba is not None:

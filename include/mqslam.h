@@ -99,6 +99,11 @@ int mqs_triangulate_iterative_ls_dev(const double *u, const double *P, int C, in
                                      void *stream);
 int mqs_triangulate_linear_eigen_dev(const double *u, const double *P, int C, int64_t N,
                                      double max_coord, double *x, uint8_t *ok, void *stream);
+/* float32 observations u [C][N][2] (slam2.py works in float32, slam2.py:19; the reference's wrapper widens them on the
+ * host, triangulation_c/__init__.py:32-33): widened on load, same results as the float64 entry points on the widened
+ * array, half the input traffic.  kind: 0 linear_ls, 1 iterative_ls, 2 linear_eigen; status / ok as for those. */
+int mqs_triangulate_f32_dev(int kind, const float *u, const double *P, int C, int64_t N, double tolerance, int max_iter,
+                            double max_coord, double *x, int32_t *status, uint8_t *ok, void *stream);
 /* linear_LS AND iterative_LS of the same observations in one pass (the reference's harness calls every method on the
  * same inputs, triangulation_comparison.py:590): the first solve of the iteration, with unit weights, IS the linear-LS
  * system (triangulation.c:65-83 vs :104-130), so x_ls costs one extra refinement step instead of a second read of the
@@ -393,7 +398,7 @@ int64_t mqs_fast_workspace_bytes(int W, int H);
 /* ---------------------------------------------------------------------------------------
  * Timing helper used by bench.py: average duration (ms) of `reps` back-to-back launches of
  * one triangulation kernel measured with hipEvents on `stream` (kernel: 0 = linear_ls,
- * 1 = iterative_ls, 2 = linear_eigen).
+ * 1 = iterative_ls, 2 = linear_eigen; 10 / 11 / 12: the same with `u` pointing at float32 observations).
  * ------------------------------------------------------------------------------------- */
 int mqs_time_triangulate_dev(int kernel, const double *u, const double *P, int C, int64_t N,
                              double tolerance, int max_iter, double *x, int32_t *status, uint8_t *ok,

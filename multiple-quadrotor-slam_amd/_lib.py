@@ -48,6 +48,8 @@ SIGNATURES = {
     "mqs_triangulate_linear_ls_dev": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, c_i64, c_vp, c_vp]),
     "mqs_triangulate_iterative_ls_dev": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, c_i64, ctypes.c_double,
                                                         ctypes.c_int, c_vp, c_vp, c_vp]),
+    "mqs_triangulate_f32_dev": (ctypes.c_int, [ctypes.c_int, c_vp, c_vp, ctypes.c_int, c_i64, ctypes.c_double, ctypes.c_int,
+                                               ctypes.c_double, c_vp, c_vp, c_vp, c_vp]),
     "mqs_triangulate_ls_and_iterative_dev": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, c_i64, ctypes.c_double, ctypes.c_int,
                                                             c_vp, c_vp, c_vp, c_vp]),
     "mqs_triangulate_linear_eigen_dev": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, c_i64, ctypes.c_double, c_vp,

@@ -42,7 +42,10 @@ constexpr int waves_for(int kind, int cams) { return (kind != 1 && kind != 3) ? 
 // PIX: the observations are PIXELS and `intr` holds [C][9] intrinsics (fx fy cx cy k1 k2 p1 p2 k3): the
 // undistort + normalise step the reference runs right before triangulating (cv2.undistortPoints,
 // slam2.py:551-552) is applied on load, saving its 2 x 16*C bytes per landmark of HBM round trip.
-template <int C, int KIND, bool PIX>
+// F32: the observations are float32 [C][N][2] (what slam2.py hands over: it works in float32, slam2.py:19, and the reference
+// wrapper widens them on the host, triangulation_c/__init__.py:32-33): widened on load instead -- the same doubles, half the
+// input bytes (linear-LS, the HBM-bound kernel: 88 -> 56 B per landmark at four cameras).
+template <int C, int KIND, bool PIX, bool F32 = false>
 __global__ __launch_bounds__(kBlock, waves_for(KIND, C)) void tri_kernel(const double *__restrict__ u, const double *__restrict__ P,
                                                                       const double *__restrict__ intr,
                                                      int64_t N, double tol, int max_iter, double max_coord,
@@ -71,7 +74,14 @@ __global__ __launch_bounds__(kBlock, waves_for(KIND, C)) void tri_kernel(const d
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             double2 v = make_double2(0.0, 0.0);
-            if (live) v = u2[(int64_t)c * N + i];
+            if (live) {
+                if (F32) {
+                    const float2 t = reinterpret_cast<const float2 *>(u)[(int64_t)c * N + i];
+                    v = make_double2((double)t.x, (double)t.y);
+                } else {
+                    v = u2[(int64_t)c * N + i];
+                }
+            }
             if (PIX) mqs::cam::undistort_pixel(sI + 9 * c, v.x, v.y, v.x, v.y);
             uv[c][0] = v.x;
             uv[c][1] = v.y;
@@ -108,7 +118,14 @@ __global__ __launch_bounds__(kBlock, waves_for(KIND, C)) void tri_kernel(const d
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
                     double2 v = make_double2(0.0, 0.0);
-                    if (live) v = u2[(int64_t)c * N + j];
+                    if (live) {
+                        if (F32) {
+                            const float2 t = reinterpret_cast<const float2 *>(u)[(int64_t)c * N + j];
+                            v = make_double2((double)t.x, (double)t.y);
+                        } else {
+                            v = u2[(int64_t)c * N + j];
+                        }
+                    }
                     if (PIX) mqs::cam::undistort_pixel(sI + 9 * c, v.x, v.y, v.x, v.y);
                     uv2[c][0] = v.x;
                     uv2[c][1] = v.y;
@@ -168,8 +185,9 @@ __global__ __launch_bounds__(kBlock, waves_for(KIND, C)) void tri_kernel(const d
 template <int KIND>
 int launch_tri(const double *u, const double *P, int C, int64_t N, double tol, int max_iter, double max_coord,
                double *x, int32_t *status, uint8_t *ok, hipStream_t stream, const double *intr = nullptr,
-               double *x_ls = nullptr)
+               double *x_ls = nullptr, bool u_is_f32 = false)
 {
+    MQS_ARG_CHECK(!u_is_f32 || (!intr && KIND != kLsAndIterative), "float32 observations: un-fused kinds only");
     MQS_ARG_CHECK(C >= 2 && C <= MQS_MAX_CAMS, "2 <= C <= MQS_MAX_CAMS");
     MQS_ARG_CHECK(N >= 0, "N >= 0");
     if (N == 0) return MQS_OK;
@@ -188,6 +206,9 @@ int launch_tri(const double *u, const double *P, int C, int64_t N, double tol, i
         if (intr)                                                                               \
             hipLaunchKernelGGL((tri_kernel<c, KIND, true>), grid, block, 0, stream, u, P, intr, N, tol, \
                                max_iter, max_coord, x, status, ok, x_ls);                       \
+        else if (u_is_f32)                                                                      \
+            hipLaunchKernelGGL((tri_kernel<c, (KIND == kLsAndIterative ? kLinearLS : KIND), false, true>), grid, block, 0, stream, u, P, \
+                               intr, N, tol, max_iter, max_coord, x, status, ok, x_ls);         \
         else                                                                                    \
             hipLaunchKernelGGL((tri_kernel<c, KIND, false>), grid, block, 0, stream, u, P, intr, N, tol, \
                                max_iter, max_coord, x, status, ok, x_ls);                       \
@@ -334,11 +355,22 @@ int mqs_iterative_LS_triangulation(mqs_ctx *ctx, const double *u1, const double 
     return run_host<kIterativeLS>(ctx, uc, Pc, 2, N, tolerance, MQS_TRI_MAX_ITER_DEFAULT, 0.0, x, x_status, nullptr);
 }
 
+int mqs_triangulate_f32_dev(int kind, const float *u, const double *P, int C, int64_t N, double tolerance, int max_iter,
+                            double max_coord, double *x, int32_t *status, uint8_t *ok, void *stream_)
+{
+    MQS_ARG_CHECK(kind >= 0 && kind <= 2, "kind in {0,1,2}");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const double *ud = reinterpret_cast<const double *>(u);        // typed again inside the F32 kernels
+    if (kind == 0) return launch_tri<kLinearLS>(ud, P, C, N, 0.0, 0, 0.0, x, nullptr, nullptr, stream, nullptr, nullptr, true);
+    if (kind == 1) return launch_tri<kIterativeLS>(ud, P, C, N, tolerance, max_iter, 0.0, x, status, nullptr, stream, nullptr, nullptr, true);
+    return launch_tri<kLinearEigen>(ud, P, C, N, 0.0, 0, max_coord, x, nullptr, ok, stream, nullptr, nullptr, true);
+}
+
 int mqs_time_triangulate_dev(int kernel, const double *u, const double *P, int C, int64_t N, double tolerance,
                              int max_iter, double *x, int32_t *status, uint8_t *ok, int reps, void *stream_,
                              float *avg_ms)
 {
-    MQS_ARG_CHECK(kernel >= 0 && kernel <= 2, "kernel in {0,1,2}");
+    MQS_ARG_CHECK((kernel >= 0 && kernel <= 2) || (kernel >= 10 && kernel <= 12), "kernel in {0,1,2} (float64 u) or {10,11,12} (float32 u)");
     MQS_ARG_CHECK(reps >= 1 && avg_ms, "reps >= 1, avg_ms not null");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     hipEvent_t e0, e1;
@@ -347,7 +379,10 @@ int mqs_time_triangulate_dev(int kernel, const double *u, const double *P, int C
     int rc = MQS_OK;
     MQS_HIP_CHECK(hipEventRecord(e0, stream));
     for (int r = 0; r < reps && rc == MQS_OK; ++r) {
-        if (kernel == 0) rc = mqs_triangulate_linear_ls_dev(u, P, C, N, x, stream);
+        if (kernel >= 10)
+            rc = mqs_triangulate_f32_dev(kernel - 10, reinterpret_cast<const float *>(u), P, C, N, tolerance, max_iter,
+                                         MQS_TRI_MAX_COORD_DEFAULT, x, status, ok, stream);
+        else if (kernel == 0) rc = mqs_triangulate_linear_ls_dev(u, P, C, N, x, stream);
         else if (kernel == 1) rc = mqs_triangulate_iterative_ls_dev(u, P, C, N, tolerance, max_iter, x, status, stream);
         else rc = mqs_triangulate_linear_eigen_dev(u, P, C, N, MQS_TRI_MAX_COORD_DEFAULT, x, ok, stream);
     }

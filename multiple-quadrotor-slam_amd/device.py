@@ -87,15 +87,40 @@ def linear_eigen_triangulation(u, P, max_coordinate_value=1.e16, out=None, out_o
     return x, ok
 
 
+def triangulate_f32(kind, u32, P, tolerance=3.e-5, max_iter=10, max_coordinate_value=1.e16):
+    """Float32 observations (C,N,2) widened on load: returns (x, status | ok | None) exactly as the float64 functions
+    return them for `u32.double()`."""
+    torch = _torch()
+    if not (u32.is_cuda and u32.dtype == torch.float32 and u32.is_contiguous() and u32.dim() == 3 and u32.shape[2] == 2):
+        raise ValueError("u32 must be a contiguous float32 device tensor (C, N, 2)")
+    _check_dev(P, torch.float64, "P")
+    C, N = int(u32.shape[0]), int(u32.shape[1])
+    if tuple(P.shape) != (C, 3, 4):
+        raise ValueError("P must have shape (C, 3, 4)")
+    k = {"linear_ls": 0, "iterative_ls": 1, "linear_eigen": 2}[kind]
+    x = torch.empty((N, 3), dtype=torch.float64, device=u32.device)
+    st = torch.empty((N,), dtype=torch.int32, device=u32.device) if k == 1 else None
+    ok = torch.empty((N,), dtype=torch.uint8, device=u32.device) if k == 2 else None
+    _lib.check(_lib.lib().mqs_triangulate_f32_dev(k, u32.data_ptr(), P.data_ptr(), C, N, float(tolerance), int(max_iter),
+                                                  float(max_coordinate_value), x.data_ptr(),
+                                                  None if st is None else st.data_ptr(), None if ok is None else ok.data_ptr(),
+                                                  _stream_ptr()))
+    return x, (st if k == 1 else ok)
+
+
 def time_triangulation(kind, u, P, reps=20, tolerance=3.e-5, max_iter=10):
     """Average kernel duration in ms over `reps` back-to-back launches (hipEvents on the current stream)."""
     torch = _torch()
-    C, N = _tri_args(u, P)
+    f32 = u.dtype == torch.float32                       # float32 observations: the widen-on-load kernels
+    if f32:
+        C, N = int(u.shape[0]), int(u.shape[1])
+    else:
+        C, N = _tri_args(u, P)
     x = torch.empty((N, 3), dtype=torch.float64, device=u.device)
     st = torch.empty((N,), dtype=torch.int32, device=u.device)
     ok = torch.empty((N,), dtype=torch.uint8, device=u.device)
     ms = ctypes.c_float(0)
-    k = {"linear_ls": 0, "iterative_ls": 1, "linear_eigen": 2}[kind]
+    k = {"linear_ls": 0, "iterative_ls": 1, "linear_eigen": 2}[kind] + (10 if f32 else 0)
     _lib.check(_lib.lib().mqs_time_triangulate_dev(k, u.data_ptr(), P.data_ptr(), C, N, float(tolerance),
                                                    int(max_iter), x.data_ptr(), st.data_ptr(), ok.data_ptr(),
                                                    int(reps), _stream_ptr(), ctypes.byref(ms)))

@@ -232,3 +232,25 @@ def test_fused_linear_and_iterative_pass(C, gpu, c_oracle):
     assert np.median(rel_err(x_ls.cpu().numpy()[good], xl.cpu().numpy()[good])) < 1e-13
     with pytest.raises(RuntimeError):
         D.linear_and_iterative_LS_triangulation(ud, Pd, max_iter=0)
+
+
+@pytest.mark.parametrize("C", [2, 4, 8])
+def test_float32_observations_widened_on_load(C, gpu):
+    """mqs_triangulate_f32_dev: float32 observations (what slam2.py passes) widened inside the kernel -- bit for bit what the
+    float64 entry points give for the host-widened array (the reference's `u.astype(float64)`, __init__.py:32-33)."""
+    import torch
+    u, P, _ = random_scene(2049, C, seed=5 + C, behind_frac=0.05)
+    u32 = torch.from_numpy(u.astype(np.float32)).cuda()
+    Pd = torch.from_numpy(np.ascontiguousarray(P)).cuda()
+    wide = u32.double()
+    D = gpu.device
+    for kind, ref in (("linear_ls", lambda: (D.linear_LS_triangulation(wide, Pd), None)),
+                      ("iterative_ls", lambda: D.iterative_LS_triangulation(wide, Pd)),
+                      ("linear_eigen", lambda: D.linear_eigen_triangulation(wide, Pd))):
+        x, s = D.triangulate_f32(kind, u32, Pd)
+        xr, sr = ref()
+        torch.cuda.synchronize()
+        assert torch.equal(x, xr), kind
+        assert (s is None and sr is None) or torch.equal(s, sr), kind
+    with pytest.raises(ValueError):
+        D.triangulate_f32("linear_ls", wide, Pd)
