@@ -153,6 +153,22 @@ struct DevObs {
     }
 };
 
+// F = E^T E and f = E^T e of every camera between the two passes of the lineariser: this thread's LDS column.
+struct LdsFactorStash {
+    static constexpr bool kEnabled = true;
+    double *s;          // entry (c, k) at s[(5 * c + k) * kBlock]
+    __device__ __forceinline__ void put(int c, double F00, double F01, double F11, double f0, double f1) const
+    {
+        double *p = s + 5 * c * kBlock;
+        p[0] = F00; p[kBlock] = F01; p[2 * kBlock] = F11; p[3 * kBlock] = f0; p[4 * kBlock] = f1;
+    }
+    __device__ __forceinline__ void get(int c, double &F00, double &F01, double &F11, double &f0, double &f1) const
+    {
+        const double *p = s + 5 * c * kBlock;
+        F00 = p[0]; F01 = p[kBlock]; F11 = p[2 * kBlock]; f0 = p[3 * kBlock]; f1 = p[4 * kBlock];
+    }
+};
+
 // Cooperative load of this batch's landmarks: coalesced 16-byte pieces -> LDS -> 3 doubles per thread.
 __device__ __forceinline__ void load_points(const double *__restrict__ points, int64_t base, int64_t N, double *sX,
                                             int tid, double &px, double &py, double &pz)
@@ -196,6 +212,9 @@ __device__ __forceinline__ void load_prior(const double *__restrict__ prior_w, c
     }
 }
 
+#ifndef MQS_BA_FACTOR_STASH
+#define MQS_BA_FACTOR_STASH 1
+#endif
 template <int C>
 __global__ __launch_bounds__(kBlock, 2) void ba_linearize_kernel(
     const double *__restrict__ poses, const double *__restrict__ calib, const double *__restrict__ sigma,
@@ -208,6 +227,8 @@ __global__ __launch_bounds__(kBlock, 2) void ba_linearize_kernel(
     __shared__ double sCam[C * kCamStride];
     __shared__ double sX[kBlock * 3];
     __shared__ double sAcc[NCH * kBlock];
+    constexpr bool kStash = MQS_BA_FACTOR_STASH && C <= 4;           // 5 C doubles per thread: fits beside sAcc up to 4 cameras
+    __shared__ double sF[kStash ? 5 * C * kBlock : 1];
 
     const int tid = threadIdx.x;
     stage_cams<C>(poses, calib, sigma, sCam, tid);
@@ -227,7 +248,12 @@ __global__ __launch_bounds__(kBlock, 2) void ba_linearize_kernel(
         const DevObs ob = {reinterpret_cast<const double2 *>(obs), mask, i, N, live};
         double pw, dx, dy, dz;
         load_prior(prior_w, prior_xyz, i, live, px, py, pz, pw, dx, dy, dz);
-        landmark_contribution<C>(sCam, ob, px, py, pz, pw, dx, dy, dz, lambda, live, em);
+        if (kStash) {
+            const LdsFactorStash stash = {sF + tid};
+            landmark_contribution<C, DevObs, WaveEmitter, LdsFactorStash>(sCam, ob, px, py, pz, pw, dx, dy, dz, lambda, live, em, stash);
+        } else {
+            landmark_contribution<C>(sCam, ob, px, py, pz, pw, dx, dy, dz, lambda, live, em);
+        }
         __syncthreads();                                    // sX is reused by the next batch
     }
 

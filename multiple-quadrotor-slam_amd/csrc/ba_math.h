@@ -257,6 +257,15 @@ MQS_HD void apply_Lt_inv(const PointSystem &ps, double &v0, double &v1, double &
 // the kernels re-read the measurement from global memory (L2-resident) at every use instead of
 // holding 2C doubles per landmark in registers; the host harness reads its arrays.
 
+// Optional per-thread parking place for what the first pass over the cameras knows and the second needs again (F = E^T E
+// and f = E^T e: 5 doubles per camera).  The second pass re-forms the factor from scratch without it (~100 instructions per
+// camera, of which ~70 are the residual, the distortion Jacobian and E); the device emitter parks them in LDS.
+struct NoFactorStash {
+    static constexpr bool kEnabled = false;
+    MQS_HD_MEMBER void put(int, double, double, double, double, double) const {}
+    MQS_HD_MEMBER void get(int, double &, double &, double &, double &, double &) const {}
+};
+
 // Accumulates camera c's factor into the landmark block; returns the factor.
 template <class Obs>
 MQS_HD Factor add_camera(const double *cam, const Obs &obs, int c, double px, double py, double pz, bool live,
@@ -274,10 +283,10 @@ MQS_HD Factor add_camera(const double *cam, const Obs &obs, int c, double px, do
 
 // Phase A shared by linearise / back-substitution: Hll, gl, cost, count over all cameras.
 // The camera loop is deliberately NOT unrolled (small live state, high occupancy).
-template <int C, class Obs>
+template <int C, class Obs, class Stash = NoFactorStash>
 MQS_HD void landmark_point_system(const double *cams, const Obs &obs, double px, double py, double pz, bool live,
                                   double prior_w, double dpx, double dpy, double dpz, double lambda,
-                                  PointSystem &ps, double &cost, double &count)
+                                  PointSystem &ps, double &cost, double &count, const Stash &stash = Stash())
 {
     ps.H = Sym3{0, 0, 0, 0, 0, 0};
     ps.g = Vec3{0, 0, 0};
@@ -286,6 +295,7 @@ MQS_HD void landmark_point_system(const double *cams, const Obs &obs, double px,
 #pragma unroll 1
     for (int c = 0; c < C; ++c) {
         const Factor fc = add_camera(cams + kCamStride * c, obs, c, px, py, pz, live, ps);
+        if (Stash::kEnabled) stash.put(c, fc.F00, fc.F01, fc.F11, fc.f0, fc.f1);
         cost += fc.half_e2;
         count += fc.valid ? 1.0 : 0.0;
     }
@@ -297,15 +307,15 @@ MQS_HD void landmark_point_system(const double *cams, const Obs &obs, double px,
 // Emit must provide  void put(int slot, double value)  and  void flush(int window)  (slot / window
 // are compile-time constants after unrolling; the device emitter relies on that to keep its
 // 32-entry window in registers).
-template <int C, class Obs, class Emit>
+template <int C, class Obs, class Emit, class Stash = NoFactorStash>
 MQS_HD void landmark_contribution(const double *cams, const Obs &obs, double px, double py, double pz,
                                   double prior_w, double dpx, double dpy, double dpz, double lambda, bool live,
-                                  Emit &em)
+                                  Emit &em, const Stash &stash = Stash())
 {
     using L = Layout<C>;
     PointSystem ps;
     double cost, count;
-    landmark_point_system<C>(cams, obs, px, py, pz, live, prior_w, dpx, dpy, dpz, lambda, ps, cost, count);
+    landmark_point_system<C, Obs, Stash>(cams, obs, px, py, pz, live, prior_w, dpx, dpy, dpz, lambda, ps, cost, count, stash);
     const double m = ps.ok ? 1.0 : 0.0;          // unconstrained landmark: pose blocks keep only J_pose^T J_pose
     // w = L^-1 gl
     double w0 = ps.g.x * ps.i00;
@@ -319,10 +329,25 @@ MQS_HD void landmark_contribution(const double *cams, const Obs &obs, double px,
 #pragma unroll
     for (int c = 0; c < C; ++c) {
         const double *cam = cams + kCamStride * c + opaque_zero();
-        double u, v;
-        bool seen;
-        obs.get(c, u, v, seen);
-        const Factor fc = make_factor(cam, px, py, pz, u, v, seen && live);
+        Factor fc;
+        if (Stash::kEnabled) {
+            // only the geometry is re-formed: x, y, Z exactly as make_factor computes them; F and f come back from the stash
+            // (exact zeros for an unused factor, so x, y, Z of such a factor only ever multiply zeros)
+            const double dx = px - cam[9], dy = py - cam[10], dz = pz - cam[11];
+            const double X = fma(cam[0], dx, fma(cam[3], dy, cam[6] * dz));
+            const double Y = fma(cam[1], dx, fma(cam[4], dy, cam[7] * dz));
+            const double Z = fma(cam[2], dx, fma(cam[5], dy, cam[8] * dz));
+            const bool front = Z > 0.0;
+            const double iz = rcp(front ? Z : 1.0);
+            stash.get(c, fc.F00, fc.F01, fc.F11, fc.f0, fc.f1);
+            const bool used = (fc.F00 != 0.0) || (fc.F11 != 0.0);
+            fc.x = used ? X * iz : 0.0; fc.y = used ? Y * iz : 0.0; fc.Z = used ? Z : 1.0;
+        } else {
+            double u, v;
+            bool seen;
+            obs.get(c, u, v, seen);
+            fc = make_factor(cam, px, py, pz, u, v, seen && live);
+        }
         cx[c] = fc.x; cy[c] = fc.y; cZ[c] = fc.Z;
         double PR[2][3];
         make_PR(cam, fc.x, fc.y, PR);
