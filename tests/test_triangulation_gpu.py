@@ -254,3 +254,33 @@ def test_float32_observations_widened_on_load(C, gpu):
         assert (s is None and sr is None) or torch.equal(s, sr), kind
     with pytest.raises(ValueError):
         D.triangulate_f32("linear_ls", wide, Pd)
+
+
+@pytest.mark.skipif(__import__("os").environ.get("MQS_HUGE", "0") != "1",
+                    reason="15 GB / ~200 s on the GPU box: opt-in with MQS_HUGE=1 (passed on MI355X when this test was added)")
+def test_beyond_one_pass_of_the_grid(gpu):
+    """2^28 + 999 landmarks x 2 cameras: more than the 2^20 workgroups one launch dispatches, so the kernels grid-stride and
+    every index is 64-bit.  Slices at the start, across the stride boundary and at the ragged end equal the same slices
+    triangulated on their own, bit for bit (device-generated observations: 8.6 GB in, 6.4 GB out)."""
+    import torch
+    N = (1 << 28) + 999
+    g = torch.Generator(device="cuda").manual_seed(5)
+    u = torch.empty((2, N, 2), dtype=torch.float64, device="cuda")
+    u.uniform_(-0.4, 0.4, generator=g)
+    u[1] += 0.05                                                              # a little disparity between the two views
+    P = np.stack([gpu.synthetic.camera_matrix(0.0, 0.0, 0.0), gpu.synthetic.camera_matrix(12.0, 0.0, 0.3)])
+    Pd = torch.from_numpy(np.ascontiguousarray(P)).cuda()
+    D = gpu.device
+    x_it, st = D.iterative_LS_triangulation(u, Pd)
+    x_ls = D.linear_LS_triangulation(u, Pd)
+    torch.cuda.synchronize()
+    for a in (0, (1 << 28) - 500, N - 1200):
+        sl = slice(a, a + 1200 if a + 1200 <= N else N)
+        us = u[:, sl].contiguous()
+        xi, si = D.iterative_LS_triangulation(us, Pd)
+        xl = D.linear_LS_triangulation(us, Pd)
+        torch.cuda.synchronize()
+        assert torch.equal(x_it[sl], xi) and torch.equal(st[sl], si) and torch.equal(x_ls[sl], xl), a
+    assert int((st == 1).sum().item()) > 0                                   # random rays: few intersect in front of both
+    del u, x_it, x_ls, st
+    torch.cuda.empty_cache()
