@@ -528,6 +528,7 @@ __global__ void expand_bits_kernel(const uint8_t *__restrict__ bits, int64_t n, 
 __device__ __forceinline__ uint32_t orderable_f32(float f)
 {
     if (f != f) return 0xffffffffu;                     // NaN ranks last (never preferred)
+    if (f == 0.0f) f = 0.0f;                            // -0.0 and +0.0 are equal for the reference's `<`
     const uint32_t b = __float_as_uint(f);
     return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
 }

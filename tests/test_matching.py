@@ -212,3 +212,23 @@ def test_cross_match_all_camera_pairs(gpu):
         qn, dn = qot.cpu().numpy(), dot.cpu().numpy()
         assert {int(t): (int(qn[t]), int(t), float(dn[t])) for t in np.nonzero(qn >= 0)[0]} == _as_tuples(ref)
         assert len(ref) > 0
+
+
+@pytest.mark.gpu
+def test_unique_filter_priority_ordering_edge_values(gpu):
+    """The priority key of the de-duplication is an order-preserving image of the float: negative values, zeros of both signs,
+    infinities and NaN (ranks last) order as the reference's `<` does; equal priorities keep the earlier query."""
+    train = np.array([[0.0, 0.0], [100.0, 100.0]], dtype=np.float32)
+    pri = np.array([3.0, -1.0, -np.inf, 0.0, -0.0, np.inf, np.nan, -1.0], dtype=np.float32)
+    query = np.tile(np.array([[0.25, 0.0]], dtype=np.float32), (len(pri), 1))          # every query matches train 0 at 0.25
+    for order in (np.arange(len(pri)), np.arange(len(pri))[::-1].copy()):
+        got = gpu.matching.match_radius_ratio_unique(query[order], train, 2.0, 0.7, pri[order])
+        assert list(got) == [0]
+        win = int(order[got[0].queryIdx])
+        assert pri[win] == -np.inf                                                   # the smallest priority wins in any order
+    got = gpu.matching.match_radius_ratio_unique(query[:2], train, 2.0, 0.7, np.array([np.nan, np.nan], dtype=np.float32))
+    assert got[0].queryIdx == 0                                                      # all NaN: the first query stays
+    eq = gpu.matching.match_radius_ratio_unique(query, train, 2.0, 0.7, np.zeros(len(pri), dtype=np.float32))
+    assert eq[0].queryIdx == 0 and eq[0].distance == 0.25
+    pm = gpu.matching.match_radius_ratio_unique(query[:2], train, 2.0, 0.7, np.array([0.0, -0.0], dtype=np.float32))
+    assert pm[0].queryIdx == 0                                                       # +0.0 / -0.0 are equal for `<`: the first query stays
