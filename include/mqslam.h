@@ -104,6 +104,11 @@ int mqs_triangulate_linear_eigen_dev(const double *u, const double *P, int C, in
  * array, half the input traffic.  kind: 0 linear_ls, 1 iterative_ls, 2 linear_eigen; status / ok as for those. */
 int mqs_triangulate_f32_dev(int kind, const float *u, const double *P, int C, int64_t N, double tolerance, int max_iter,
                             double max_coord, double *x, int32_t *status, uint8_t *ok, void *stream);
+/* The same through the host-pointer boundary: packed u [C][N][2] float32, and the reference's 2-view argument order. */
+int mqs_triangulate_f32(mqs_ctx *ctx, int kind, const float *u, const double *P, int C, int64_t N, double tolerance,
+                        int max_iter, double max_coord, double *x, int32_t *status, uint8_t *ok);
+int mqs_triangulation_2view_f32(mqs_ctx *ctx, int kind, const float *u1, const double *P1, const float *u2, const double *P2,
+                                int64_t N, double tolerance, double max_coord, double *x, int32_t *status, uint8_t *ok);
 /* linear_LS AND iterative_LS of the same observations in one pass (the reference's harness calls every method on the
  * same inputs, triangulation_comparison.py:590): the first solve of the iteration, with unit weights, IS the linear-LS
  * system (triangulation.c:65-83 vs :104-130), so x_ls costs one extra refinement step instead of a second read of the

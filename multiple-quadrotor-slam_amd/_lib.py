@@ -50,6 +50,10 @@ SIGNATURES = {
                                                         ctypes.c_int, c_vp, c_vp, c_vp]),
     "mqs_triangulate_f32_dev": (ctypes.c_int, [ctypes.c_int, c_vp, c_vp, ctypes.c_int, c_i64, ctypes.c_double, ctypes.c_int,
                                                ctypes.c_double, c_vp, c_vp, c_vp, c_vp]),
+    "mqs_triangulate_f32": (ctypes.c_int, [c_vp, ctypes.c_int, c_f32p, c_f64p, ctypes.c_int, c_i64, ctypes.c_double, ctypes.c_int,
+                                           ctypes.c_double, c_f64p, c_i32p, c_u8p]),
+    "mqs_triangulation_2view_f32": (ctypes.c_int, [c_vp, ctypes.c_int, c_f32p, c_f64p, c_f32p, c_f64p, c_i64, ctypes.c_double,
+                                                   ctypes.c_double, c_f64p, c_i32p, c_u8p]),
     "mqs_triangulate_ls_and_iterative_dev": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, c_i64, ctypes.c_double, ctypes.c_int,
                                                             c_vp, c_vp, c_vp, c_vp]),
     "mqs_triangulate_linear_eigen_dev": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, c_i64, ctypes.c_double, c_vp,

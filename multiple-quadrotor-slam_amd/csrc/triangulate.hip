@@ -221,10 +221,11 @@ int launch_tri(const double *u, const double *P, int C, int64_t N, double tol, i
 }
 
 // Host-pointer driver: stage inputs into the ctx scratch, run, copy back.
-template <int KIND>
-int run_host(mqs_ctx *ctx, const double *const *u_cams, const double *const *P_cams, int C, int64_t N, double tol,
+template <int KIND, typename TU = double>
+int run_host(mqs_ctx *ctx, const TU *const *u_cams, const double *const *P_cams, int C, int64_t N, double tol,
              int max_iter, double max_coord, double *x, int32_t *status, uint8_t *ok)
 {
+    constexpr bool kF32 = sizeof(TU) == 4;                 // float32 observations: half the bytes over the link, widened on load
     MQS_ARG_CHECK(ctx != nullptr, "ctx must not be null");
     MQS_ARG_CHECK(C >= 2 && C <= MQS_MAX_CAMS, "2 <= C <= MQS_MAX_CAMS");
     MQS_ARG_CHECK(N >= 0, "N >= 0");
@@ -233,7 +234,7 @@ int run_host(mqs_ctx *ctx, const double *const *u_cams, const double *const *P_c
     // layout of the scratch: [u: C*N*2 f64][x: N*3 f64][P: C*12 f64][status: N i32][ok: N u8], 256-B aligned pieces
     auto up = [](size_t v) { return (v + 255) & ~size_t(255); };
     const size_t o_u = 0;
-    const size_t o_x = up(o_u + (size_t)C * N * 16);
+    const size_t o_x = up(o_u + (size_t)C * N * 2 * sizeof(TU));
     const size_t o_P = up(o_x + (size_t)N * 24);
     const size_t o_s = up(o_P + (size_t)C * 96);
     const size_t o_k = up(o_s + (size_t)N * 4);
@@ -242,17 +243,18 @@ int run_host(mqs_ctx *ctx, const double *const *u_cams, const double *const *P_c
     int rc = mqs_stage_begin(ctx, total, &st);
     if (rc != MQS_OK) return rc;
     char *d = st.base;
-    double *d_u = reinterpret_cast<double *>(d + o_u);
+    TU *d_u = reinterpret_cast<TU *>(d + o_u);
     double *d_x = reinterpret_cast<double *>(d + o_x);
     double *d_P = reinterpret_cast<double *>(d + o_P);
     int32_t *d_s = reinterpret_cast<int32_t *>(d + o_s);
     uint8_t *d_k = reinterpret_cast<uint8_t *>(d + o_k);
     for (int c = 0; c < C; ++c) {
         MQS_ARG_CHECK(u_cams[c] && P_cams[c], "per-camera pointers must not be null");
-        MQS_HIP_CHECK(mqs_stage_in(&st, d_u + (size_t)c * N * 2, u_cams[c], (size_t)N * 16));
+        MQS_HIP_CHECK(mqs_stage_in(&st, d_u + (size_t)c * N * 2, u_cams[c], (size_t)N * 2 * sizeof(TU)));
         MQS_HIP_CHECK(mqs_stage_in(&st, d_P + c * 12, P_cams[c], 96));
     }
-    rc = launch_tri<KIND>(d_u, d_P, C, N, tol, max_iter, max_coord, d_x, d_s, d_k, ctx->stream);
+    rc = launch_tri<KIND>(reinterpret_cast<const double *>(d_u), d_P, C, N, tol, max_iter, max_coord, d_x, d_s, d_k, ctx->stream,
+                          nullptr, nullptr, kF32);
     if (rc != MQS_OK) return rc;
     MQS_HIP_CHECK(mqs_stage_out(&st, x, d_x, (size_t)N * 24));
     if (KIND == kIterativeLS) MQS_HIP_CHECK(mqs_stage_out(&st, status, d_s, (size_t)N * 4));
@@ -353,6 +355,34 @@ int mqs_iterative_LS_triangulation(mqs_ctx *ctx, const double *u1, const double 
     MQS_ARG_CHECK(N == 0 || (u1 && P1 && u2 && P2 && x && x_status), "arguments must not be null");
     const double *uc[2] = {u1, u2}, *Pc[2] = {P1, P2};
     return run_host<kIterativeLS>(ctx, uc, Pc, 2, N, tolerance, MQS_TRI_MAX_ITER_DEFAULT, 0.0, x, x_status, nullptr);
+}
+
+// float32 observations through the host-pointer boundary (slam2.py hands float32 points over; the reference's wrapper widens
+// them on the host, __init__.py:32-33 -- here they cross the link as float32 and are widened on load)
+int mqs_triangulate_f32(mqs_ctx *ctx, int kind, const float *u, const double *P, int C, int64_t N, double tolerance,
+                        int max_iter, double max_coord, double *x, int32_t *status, uint8_t *ok)
+{
+    MQS_ARG_CHECK(kind >= 0 && kind <= 2, "kind in {0,1,2}");
+    MQS_ARG_CHECK(C >= 2 && C <= MQS_MAX_CAMS, "2 <= C <= MQS_MAX_CAMS");
+    MQS_ARG_CHECK(N == 0 || (u && P && x), "u, P, x must not be null");
+    const float *uc[MQS_MAX_CAMS];
+    const double *Pc[MQS_MAX_CAMS];
+    for (int c = 0; c < C; ++c) { uc[c] = u + (size_t)c * N * 2; Pc[c] = P + c * 12; }
+    if (kind == 0) return run_host<kLinearLS, float>(ctx, uc, Pc, C, N, 0.0, 0, 0.0, x, nullptr, nullptr);
+    if (kind == 1) return run_host<kIterativeLS, float>(ctx, uc, Pc, C, N, tolerance, max_iter, 0.0, x, status, nullptr);
+    return run_host<kLinearEigen, float>(ctx, uc, Pc, C, N, 0.0, 0, max_coord, x, nullptr, ok);
+}
+
+int mqs_triangulation_2view_f32(mqs_ctx *ctx, int kind, const float *u1, const double *P1, const float *u2, const double *P2,
+                                int64_t N, double tolerance, double max_coord, double *x, int32_t *status, uint8_t *ok)
+{
+    MQS_ARG_CHECK(kind >= 0 && kind <= 2, "kind in {0,1,2}");
+    MQS_ARG_CHECK(N == 0 || (u1 && P1 && u2 && P2 && x), "arguments must not be null");
+    const float *uc[2] = {u1, u2};
+    const double *Pc[2] = {P1, P2};
+    if (kind == 0) return run_host<kLinearLS, float>(ctx, uc, Pc, 2, N, 0.0, 0, 0.0, x, nullptr, nullptr);
+    if (kind == 1) return run_host<kIterativeLS, float>(ctx, uc, Pc, 2, N, tolerance, MQS_TRI_MAX_ITER_DEFAULT, 0.0, x, status, nullptr);
+    return run_host<kLinearEigen, float>(ctx, uc, Pc, 2, N, 0.0, 0, max_coord, x, nullptr, ok);
 }
 
 int mqs_triangulate_f32_dev(int kind, const float *u, const double *P, int C, int64_t N, double tolerance, int max_iter,

@@ -26,6 +26,19 @@ def _as_f64_u(u):
     return np.ascontiguousarray(u.reshape(u.size).reshape(u.shape))
 
 
+def _as_u(u1, u2):
+    """The reference widens non-float64 observations on the host (__init__.py:32-33).  float32 pairs -- what slam2.py passes,
+    slam2.py:19 -- go over the link as they are and are widened inside the kernel: the same doubles, no host pass, half the
+    bytes.  Returns (u1, u2, is_float32)."""
+    a, b = np.asarray(u1), np.asarray(u2)
+    if a.dtype == np.float32 and b.dtype == np.float32:
+        for u in (a, b):
+            if u.ndim != 2 or u.shape[1] != 2:
+                raise ValueError("u must have shape (N, 2), got %r" % (u.shape,))
+        return np.ascontiguousarray(a), np.ascontiguousarray(b), True
+    return _as_f64_u(a), _as_f64_u(b), False
+
+
 def _as_P(P):
     # the reference does NOT cast P (weave raises TypeError on a non-float64 P) and accepts
     # 3x4 or 4x4: the kernel reads the first 12 doubles only (triangulation.c:24-25).
@@ -47,10 +60,15 @@ def linear_LS_triangulation(u1, P1, u2, P2):
     (u1, P1) is the reference pair of normalized image coordinates (x, y) and camera matrix,
     (u2, P2) the second pair.  The status-vector is True for all points.
     """
-    u1, u2, P1, P2 = _as_f64_u(u1), _as_f64_u(u2), _as_P(P1), _as_P(P2)
+    (u1, u2, f32), P1, P2 = _as_u(u1, u2), _as_P(P1), _as_P(P2)
     if len(u1) != len(u2):
         raise ValueError("u1 and u2 must have the same number of points")
     x = np.empty((len(u1), 3), dtype=np.float64)
+    if f32:
+        _lib.check(_lib.lib().mqs_triangulation_2view_f32(
+            _lib.default_context().handle, 0, _ptr(u1, _lib.c_f32p), _ptr(P1, c_f64p), _ptr(u2, _lib.c_f32p), _ptr(P2, c_f64p),
+            c_i64(len(u1)), ctypes.c_double(0.0), ctypes.c_double(0.0), _ptr(x, c_f64p), None, None))
+        return x, np.ones(len(u1), dtype=bool)
     _lib.check(_lib.lib().mqs_linear_LS_triangulation(
         _lib.default_context().handle, _ptr(u1, c_f64p), _ptr(P1, c_f64p), _ptr(u2, c_f64p), _ptr(P2, c_f64p),
         c_i64(len(u1)), _ptr(x, c_f64p)))
@@ -65,11 +83,16 @@ def iterative_LS_triangulation(u1, P1, u2, P2, tolerance=3.e-5):
         1 inlier in front of both cameras; 0 not converged but in front of both;
         -1 behind 1st camera; -2 behind 2nd camera; -3 behind both.
     """
-    u1, u2, P1, P2 = _as_f64_u(u1), _as_f64_u(u2), _as_P(P1), _as_P(P2)
+    (u1, u2, f32), P1, P2 = _as_u(u1, u2), _as_P(P1), _as_P(P2)
     if len(u1) != len(u2):
         raise ValueError("u1 and u2 must have the same number of points")
     x = np.empty((len(u1), 3), dtype=np.float64)
     x_status = np.empty(len(u1), dtype=np.int32)
+    if f32:
+        _lib.check(_lib.lib().mqs_triangulation_2view_f32(
+            _lib.default_context().handle, 1, _ptr(u1, _lib.c_f32p), _ptr(P1, c_f64p), _ptr(u2, _lib.c_f32p), _ptr(P2, c_f64p),
+            c_i64(len(u1)), ctypes.c_double(tolerance), ctypes.c_double(0.0), _ptr(x, c_f64p), _ptr(x_status, c_i32p), None))
+        return x, x_status
     _lib.check(_lib.lib().mqs_iterative_LS_triangulation(
         _lib.default_context().handle, _ptr(u1, c_f64p), _ptr(P1, c_f64p), _ptr(u2, c_f64p), _ptr(P2, c_f64p),
         c_i64(len(u1)), ctypes.c_double(tolerance), _ptr(x, c_f64p), _ptr(x_status, c_i32p)))

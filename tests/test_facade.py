@@ -66,3 +66,21 @@ def test_synthetic_generator_shapes(mqs):
     assert np.allclose(px, np.rint(px), atol=1e-9)
     u2, P2, _ = mqs.synthetic.triangulation_problem(1000, 2)
     np.testing.assert_array_equal(P2, P[:2])
+
+
+@pytest.mark.gpu
+def test_float32_observations_through_the_facade(gpu):
+    """slam2.py passes float32 image points (slam2.py:19): the facade sends them as float32 and the kernel widens them --
+    bit for bit what the reference's rule (widen on the host, triangulation_c/__init__.py:32-33) gives."""
+    u, P, _ = gpu.synthetic.triangulation_problem(5003, 2)
+    u32 = u.astype(np.float32)
+    wide = u32.astype(np.float64)
+    t = gpu.triangulation
+    for fn in (t.linear_LS_triangulation, t.iterative_LS_triangulation):
+        x32, s32 = fn(u32[0], P[0], u32[1], P[1])
+        xw, sw = fn(wide[0], P[0], wide[1], P[1])
+        np.testing.assert_array_equal(x32, xw)
+        np.testing.assert_array_equal(s32, sw)
+    # mixed dtypes fall back to the reference's host widening
+    xm, _ = t.linear_LS_triangulation(u32[0], P[0], wide[1], P[1])
+    np.testing.assert_array_equal(xm, t.linear_LS_triangulation(wide[0], P[0], wide[1], P[1])[0])
