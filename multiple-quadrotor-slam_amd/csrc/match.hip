@@ -36,41 +36,87 @@ constexpr int kBlock = 256;
 // exact float32 path
 // ---------------------------------------------------------------------------------------
 #pragma clang fp contract(off)
+// A query is shared by kLanesPerQuery lanes, each scanning every kLanesPerQuery-th train row of the LDS tile; the lanes'
+// top-2 are then merged in the order the reference's scan implies -- (distance, index) lexicographic: the smaller distance
+// first, the LOWER index among equal distances (batchDistance inserts on strict `<` while walking the rows in order).
+// One thread per query (the first version) left a 1000 x 1000 problem -- the reference's actual size -- on four
+// workgroups walking 1000 rows each: 211 us.  DS > 0: compile-time descriptor length (2 = pixel coordinates).
+constexpr int kLanesPerQuery = 16;
+
+__device__ __forceinline__ bool lex_less(float d1, int32_t i1, float d2, int32_t i2)
+{
+    return (d1 < d2) || (d1 == d2 && i1 < i2);
+}
+
+template <int DS>
 __global__ __launch_bounds__(kBlock) void knn2_f32_kernel(const float *__restrict__ query, int64_t Nq,
                                                           const float *__restrict__ train, int64_t Nt, int D,
                                                           int tile_rows, int32_t *__restrict__ idx,
                                                           float *__restrict__ dist)
 {
     extern __shared__ float sT[];                     // [tile_rows][D]
+    constexpr int kQPB = kBlock / kLanesPerQuery;     // queries per workgroup
+    constexpr int kEmpty = 0x7fffffff;
     const int tid = threadIdx.x;
-    const int64_t q = (int64_t)blockIdx.x * kBlock + tid;
+    const int g = tid / kLanesPerQuery, l = tid % kLanesPerQuery;
+    const int64_t q = (int64_t)blockIdx.x * kQPB + g;
     const bool live = q < Nq;
-    const float *qrow = query + (live ? q : 0) * D;
+    const int Dn = DS > 0 ? DS : D;
+    const float *qrow = query + (live ? q : 0) * Dn;
+    float qv[DS > 0 ? DS : 1];
+    if (DS > 0) {
+#pragma unroll
+        for (int k = 0; k < DS; ++k) qv[k] = qrow[k];
+    }
     float b0 = INFINITY, b1 = INFINITY;
-    int32_t i0 = -1, i1 = -1;
+    int32_t i0 = kEmpty, i1 = kEmpty;
     for (int64_t t0 = 0; t0 < Nt; t0 += tile_rows) {
         const int rows = (Nt - t0) < tile_rows ? (int)(Nt - t0) : tile_rows;
         __syncthreads();
-        for (int e = tid; e < rows * D; e += kBlock) sT[e] = train[t0 * D + e];
+        for (int e = tid; e < rows * Dn; e += kBlock) sT[e] = train[t0 * Dn + e];
         __syncthreads();
         if (live) {
-            for (int r = 0; r < rows; ++r) {
-                const float *trow = sT + r * D;
+            for (int r = l; r < rows; r += kLanesPerQuery) {
+                const float *trow = sT + r * Dn;
                 float s = 0.0f;
-                for (int k = 0; k < D; ++k) {
-                    const float d = qrow[k] - trow[k];
-                    s = s + d * d;                     // contract(off): separate multiply and add
+                if (DS > 0) {
+#pragma unroll
+                    for (int k = 0; k < DS; ++k) {
+                        const float d = qv[k] - trow[k];
+                        s = s + d * d;                 // contract(off): separate multiply and add
+                    }
+                } else {
+                    for (int k = 0; k < Dn; ++k) {
+                        const float d = qrow[k] - trow[k];
+                        s = s + d * d;
+                    }
                 }
-                const int32_t j = (int32_t)(t0 + r);
+                const int32_t j = (int32_t)(t0 + r);   // increasing within a lane: strict `<` keeps the lower index
                 if (s < b0) { b1 = b0; i1 = i0; b0 = s; i0 = j; }
                 else if (s < b1) { b1 = s; i1 = j; }
             }
         }
     }
-    if (live) {
-        idx[2 * q] = i0; idx[2 * q + 1] = i1;
-        dist[2 * q] = (i0 >= 0) ? sqrtf(b0) : INFINITY;
-        dist[2 * q + 1] = (i1 >= 0) ? sqrtf(b1) : INFINITY;
+    // merge the kLanesPerQuery sorted pairs of a query (xor butterfly inside its 16-lane group)
+#pragma unroll
+    for (int m = kLanesPerQuery / 2; m >= 1; m >>= 1) {
+        const float c0 = __shfl_xor(b0, m, 64), c1 = __shfl_xor(b1, m, 64);
+        const int32_t j0 = __shfl_xor(i0, m, 64), j1 = __shfl_xor(i1, m, 64);
+        const bool mine_first = lex_less(b0, i0, c0, j0) || (b0 == c0 && i0 == j0);
+        // first = the smaller head; second = the smaller of the loser's head and the winner's second
+        const float f0 = mine_first ? b0 : c0;
+        const int32_t g0 = mine_first ? i0 : j0;
+        const float x = mine_first ? b1 : c1, y = mine_first ? c0 : b0;
+        const int32_t xi = mine_first ? i1 : j1, yi = mine_first ? j0 : i0;
+        const bool x_first = lex_less(x, xi, y, yi);
+        b0 = f0; i0 = g0;
+        b1 = x_first ? x : y; i1 = x_first ? xi : yi;
+    }
+    if (live && l == 0) {
+        const bool h0 = i0 != kEmpty, h1 = i1 != kEmpty;
+        idx[2 * q] = h0 ? i0 : -1; idx[2 * q + 1] = h1 ? i1 : -1;
+        dist[2 * q] = h0 ? sqrtf(b0) : INFINITY;
+        dist[2 * q + 1] = h1 ? sqrtf(b1) : INFINITY;
     }
 }
 #pragma clang fp contract(fast)
@@ -456,8 +502,13 @@ int launch_f32(const float *query, int64_t Nq, const float *train, int64_t Nt, i
     if (tile_rows > 1024) tile_rows = 1024;
     if (tile_rows < 1) tile_rows = 1;
     const size_t lds = (size_t)tile_rows * D * sizeof(float);
-    hipLaunchKernelGGL(knn2_f32_kernel, dim3((unsigned)((Nq + kBlock - 1) / kBlock)), dim3(kBlock), lds, stream, query,
-                       Nq, train, Nt, D, tile_rows, idx, dist);
+    const unsigned grid = (unsigned)((Nq + kBlock / kLanesPerQuery - 1) / (kBlock / kLanesPerQuery));
+    switch (D) {
+    case 2: hipLaunchKernelGGL(knn2_f32_kernel<2>, dim3(grid), dim3(kBlock), lds, stream, query, Nq, train, Nt, D, tile_rows, idx, dist); break;
+    case 3: hipLaunchKernelGGL(knn2_f32_kernel<3>, dim3(grid), dim3(kBlock), lds, stream, query, Nq, train, Nt, D, tile_rows, idx, dist); break;
+    case 4: hipLaunchKernelGGL(knn2_f32_kernel<4>, dim3(grid), dim3(kBlock), lds, stream, query, Nq, train, Nt, D, tile_rows, idx, dist); break;
+    default: hipLaunchKernelGGL(knn2_f32_kernel<0>, dim3(grid), dim3(kBlock), lds, stream, query, Nq, train, Nt, D, tile_rows, idx, dist); break;
+    }
     MQS_HIP_CHECK(hipGetLastError());
     return MQS_OK;
 }
