@@ -513,7 +513,7 @@ int launch_f32(const float *query, int64_t Nq, const float *train, int64_t Nt, i
     return MQS_OK;
 }
 
-constexpr int kMaxParts = 8;
+constexpr int kMaxParts = 16;                            // int8 windows are 4096 rows: 16 parts of a 65 536-row train set for small query blocks
 
 // Can workgroups of NW waves x QT query tiles, times the parts the train set can be split into, occupy every CU?
 template <class TP>
