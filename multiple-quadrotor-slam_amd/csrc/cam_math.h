@@ -32,7 +32,7 @@ MQS_HD void undistort_pixel(const double *intr, double u, double v, double &x, d
     if (k1 == 0.0 && k2 == 0.0 && p1 == 0.0 && p2 == 0.0 && k3 == 0.0) return;
     for (int j = 0; j < kUndistortIters; ++j) {
         const double r2 = x * x + y * y;
-        const double icdist = 1.0 / (1.0 + r2 * (k1 + r2 * (k2 + r2 * k3)));
+        const double icdist = rcp(1.0 + r2 * (k1 + r2 * (k2 + r2 * k3)));     // v_rcp_f64 + two Newton steps on the device (no division sequence)
         const double dx = 2.0 * p1 * x * y + p2 * (r2 + 2.0 * x * x);
         const double dy = p1 * (r2 + 2.0 * y * y) + 2.0 * p2 * x * y;
         x = (x0 - dx) * icdist;

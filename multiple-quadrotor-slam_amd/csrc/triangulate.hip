@@ -57,6 +57,11 @@ __global__ __launch_bounds__(kBlock, waves_for(KIND, C)) void tri_kernel(const d
     __shared__ double sI[PIX ? C * 9 : 1];
     // fused linear-LS + iterative-LS: the first solve (3) and its factor (6 + ok) wait here for the refinement step
     __shared__ double sFirst[KIND == kLsAndIterative ? 10 * kBlock : 1];
+    // pixel input + an iterative kind: the undistorted observations wait here for the refinement step (undistorting is 5
+    // fixed-point iterations with a division each, ~200 instructions per camera: re-reading the pixels and undistorting
+    // them again cost the fused iterative kernel a quarter of its time)
+    constexpr bool kParkUV = PIX && (KIND == kIterativeLS || KIND == kLsAndIterative);
+    __shared__ double sUV[kParkUV ? 2 * C * kBlock : 1];
 
     const int tid = threadIdx.x;
     if (tid < C * 12) sP[tid] = P[tid];
@@ -83,6 +88,10 @@ __global__ __launch_bounds__(kBlock, waves_for(KIND, C)) void tri_kernel(const d
                 }
             }
             if (PIX) mqs::cam::undistort_pixel(sI + 9 * c, v.x, v.y, v.x, v.y);
+            if (kParkUV) {
+                sUV[(2 * c) * kBlock + tid] = v.x;
+                sUV[(2 * c + 1) * kBlock + tid] = v.y;
+            }
             uv[c][0] = v.x;
             uv[c][1] = v.y;
         }
@@ -118,7 +127,9 @@ __global__ __launch_bounds__(kBlock, waves_for(KIND, C)) void tri_kernel(const d
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
                     double2 v = make_double2(0.0, 0.0);
-                    if (live) {
+                    if (kParkUV) {
+                        v = make_double2(sUV[(2 * c) * kBlock + tid + (int)(j - i)], sUV[(2 * c + 1) * kBlock + tid + (int)(j - i)]);
+                    } else if (live) {
                         if (F32) {
                             const float2 t = reinterpret_cast<const float2 *>(u)[(int64_t)c * N + j];
                             v = make_double2((double)t.x, (double)t.y);
@@ -126,7 +137,6 @@ __global__ __launch_bounds__(kBlock, waves_for(KIND, C)) void tri_kernel(const d
                             v = u2[(int64_t)c * N + j];
                         }
                     }
-                    if (PIX) mqs::cam::undistort_pixel(sI + 9 * c, v.x, v.y, v.x, v.y);
                     uv2[c][0] = v.x;
                     uv2[c][1] = v.y;
                 }
