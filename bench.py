@@ -446,6 +446,7 @@ def main():
         }
         print(json.dumps(out))
     if dist is not None:
+        dist.barrier()                      # rank 0 reports alone for a few seconds: every rank leaves the group together
         dist.destroy_process_group()
 
 
