@@ -168,8 +168,10 @@ def main():
                 "traffic": traffic, "algorithmic_bytes_per_launch": bytes_it,
                 "avg_launch_ms": round(ms_it, 5),
                 "valu_pmc": valu_it or None,
-                "note": "dominant kernel of the triangulation metric; by time the step's largest kernel is "
-                        "ba_linearize_kernel (see rooflines): both are bound by fp64 VALU issue, not HBM"}
+                "note": "dominant kernel of the triangulation metric, timed stand-alone (20 back-to-back launches, hipEvents on "
+                        "the launch stream); inside the step the same arithmetic runs fused with linear-LS on a second stream beside "
+                        "the BA chain, where a per-launch duration is stretched by the kernels it shares the chip with.  By time the "
+                        "step's largest kernel is ba_linearize_kernel (see rooflines): both are bound by fp64 VALU issue, not HBM"}
     kernels = {
         "iterative_ls": {"ms": round(ms_it, 5), "landmarks_per_s": round(N / (ms_it * 1e-3)),
                          "GBps": round(bytes_it / (ms_it * 1e-3) / 1e9, 1)},
