@@ -532,43 +532,43 @@ __global__ __launch_bounds__(64) void chol_diag_kernel(double *__restrict__ A, i
     const int lane = threadIdx.x;
     const bool live = lane < nb;
     double row[NB];
+    double *Arow = A + (int64_t)(k0 + (live ? lane : nb - 1)) * n + k0;      // every lane loads from a valid row, selects after
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-        double v = (j == lane) ? 1.0 : 0.0;
-        if (live && j < nb && j <= lane) v = A[(int64_t)(k0 + lane) * n + k0 + j];
-        row[j] = v;
+        const double v = Arow[j < nb ? j : nb - 1];
+        row[j] = (live && j < nb && j <= lane) ? v : ((j == lane) ? 1.0 : 0.0);
     }
     bool notpd = false;
-    double dinv[NB];                                      // 1 / L[k][k], wave-uniform
+    // The inverse rides on the factorisation: lane c solves L y = e_c column-oriented, and step k of that substitution
+    // (y[j] -= L[j][k] y[k], j > k) needs exactly the broadcasts L[j][k] the trailing update of step k makes -- one
+    // v_readlane pair serves both, and the two independent FMA streams fill each other's latency (one wave per CU: nothing
+    // else hides it).  Same operations in the same order per accumulator as a separate forward substitution.
+    double y[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) y[j] = (j == lane) ? 1.0 : 0.0;
 #pragma unroll
     for (int k = 0; k < NB; ++k) {
         const double akk = read_lane_d(row[k], k);
         notpd = notpd || !(akk > 0.0);
         const double inv = mqs::rsqrt_d(akk > 0.0 ? akk : 1.0);
-        dinv[k] = inv;
         const double lik = row[k] * inv;                  // L[lane][k] for lane >= k
         row[k] = lik;
+        const double yk = y[k] * inv;                     // inv(L)[k][lane]
+        y[k] = yk;
 #pragma unroll
-        for (int j = k + 1; j < NB; ++j) row[j] = fma(-lik, read_lane_d(lik, j), row[j]);   // used for lane >= j only
+        for (int j = k + 1; j < NB; ++j) {
+            const double ljk = read_lane_d(lik, j);
+            row[j] = fma(-lik, ljk, row[j]);              // used for lane >= j only
+            y[j] = fma(-ljk, yk, y[j]);
+            asm volatile("" : "+v"(row[j]), "+v"(y[j]));   // pins both uses of the broadcast here: left alone, the compiler ran the two
+                                                            // FMA streams one after the other and kept 480 broadcasts alive in between (964 SGPR spills)
+        }
     }
     if (lane == 0 && notpd) *bad = 1;
-    // inverse: lane c solves L y = e_c;  y[i] = (delta_ic - sum_{k<i} L[i][k] y[k]) / L[i][i]
-    double y[NB];
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-        double sacc = (i == lane) ? 1.0 : 0.0;
-#pragma unroll
-        for (int k = 0; k < i; ++k) sacc = fma(-read_lane_d(row[k], i), y[k], sacc);
-        y[i] = sacc * dinv[i];
-    }
     if (live) {
 #pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            if (j < nb) {
-                if (j <= lane) A[(int64_t)(k0 + lane) * n + k0 + j] = row[j];
-                else A[(int64_t)(k0 + lane) * n + k0 + j] = y[j];          // inv(L)[j][lane], j > lane
-            }
-        }
+        for (int j = 0; j < NB; ++j)
+            if (j < nb) Arow[j] = (j <= lane) ? row[j] : y[j];             // y[j] = inv(L)[j][lane], j > lane
     }
 }
 
