@@ -789,8 +789,39 @@ __global__ __launch_bounds__(kPT) void chol_solve_banded_blocked1_kernel(const d
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < n; i += kPT) sXv[i] = x[i];
 
-    // ---- forward substitution L y = b, block by block ----
-    for (int k0 = 0; k0 < n; k0 += NB) {
+    // The factor entries of block k + 1 do not depend on the unknowns: they are fetched into registers (one inverse-block
+    // entry and up to kPre panel entries per thread) while block k's three phases run, and stored to LDS at the top of the
+    // next round -- the global-memory latency of a block step (about half of its 3.8 us) leaves the serial chain.
+    constexpr int kPre = 4;                                  // panel entries per thread held in flight: hb <= 128
+    const bool prefetch = hb * NB <= kPre * kPT;
+    double pLi = 0.0, pP[kPre] = {0.0, 0.0, 0.0, 0.0};
+    auto fetch = [&](int k0) {
+        const int nb = (n - k0) < NB ? (n - k0) : NB;
+        const int t0 = k0 + nb;
+        int m = n - t0;
+        if (m > hb) m = hb;
+        const int j = tid >> 5, k = tid & 31;
+        pLi = 0.0;
+        if (j < nb && k <= j) pLi = A[(int64_t)(k0 + k) * n + k0 + j];     // k == j: the diagonal itself, inverted at commit
+#pragma unroll
+        for (int u = 0; u < kPre; ++u) {
+            const int e = tid + u * kPT, r = e >> 5, c = e & 31;
+            pP[u] = (e < m * NB && c < nb) ? A[(int64_t)(t0 + r) * n + k0 + c] : 0.0;
+        }
+    };
+    auto commit = [&](int k0) {
+        const int nb = (n - k0) < NB ? (n - k0) : NB;
+        int m = n - (k0 + nb);
+        if (m > hb) m = hb;
+        const int j = tid >> 5, k = tid & 31;
+        sLi[j * kLdT + k] = (j < nb && k == j) ? 1.0 / pLi : pLi;
+#pragma unroll
+        for (int u = 0; u < kPre; ++u) {
+            const int e = tid + u * kPT;
+            if (e < m * NB) sP[(e >> 5) * kLdT + (e & 31)] = pP[u];
+        }
+    };
+    auto load_block = [&](int k0) {
         const int nb = (n - k0) < NB ? (n - k0) : NB;
         const int t0 = k0 + nb;
         int m = n - t0;
@@ -800,11 +831,22 @@ __global__ __launch_bounds__(kPT) void chol_solve_banded_blocked1_kernel(const d
             const int r = e >> 5, c = e & 31;
             sP[r * kLdT + c] = (c < nb) ? A[(int64_t)(t0 + r) * n + k0 + c] : 0.0;
         }
+    };
+
+    // ---- forward substitution L y = b, block by block ----
+    if (prefetch) fetch(0);
+    for (int k0 = 0; k0 < n; k0 += NB) {
+        const int nb = (n - k0) < NB ? (n - k0) : NB;
+        const int t0 = k0 + nb;
+        int m = n - t0;
+        if (m > hb) m = hb;
+        if (prefetch) commit(k0); else load_block(k0);
         __syncthreads();
+        if (prefetch && k0 + NB < n) fetch(k0 + NB);
         if (wave == 0) {
             const int j = lane & 31;
             double s = 0.0;
-#pragma unroll
+#pragma unroll 8
             for (int k = 0; k < NB; ++k) s = fma(sLi[j * kLdT + k], (k < nb) ? sXv[k0 + k] : 0.0, s);
             mqs_wave_lds_sync();
             if (lane < nb) sXv[k0 + lane] = s;
@@ -812,24 +854,23 @@ __global__ __launch_bounds__(kPT) void chol_solve_banded_blocked1_kernel(const d
         __syncthreads();
         if (tid < m) {
             double s = 0.0;
-#pragma unroll
+#pragma unroll 8
             for (int c = 0; c < NB; ++c) s = fma(sP[tid * kLdT + c], (c < nb) ? sXv[k0 + c] : 0.0, s);
             sXv[t0 + tid] -= s;
         }
         __syncthreads();
     }
     // ---- backward substitution L^T x = y ----
-    for (int k0 = ((n - 1) / NB) * NB; k0 >= 0; k0 -= NB) {
+    const int klast = ((n - 1) / NB) * NB;
+    if (prefetch) fetch(klast);
+    for (int k0 = klast; k0 >= 0; k0 -= NB) {
         const int nb = (n - k0) < NB ? (n - k0) : NB;
         const int t0 = k0 + nb;
         int m = n - t0;
         if (m > hb) m = hb;
-        load_inv_diag(A, n, k0, nb, sLi, tid);
-        for (int e = tid; e < m * NB; e += kPT) {
-            const int r = e >> 5, c = e & 31;
-            sP[r * kLdT + c] = (c < nb) ? A[(int64_t)(t0 + r) * n + k0 + c] : 0.0;
-        }
+        if (prefetch) commit(k0); else load_block(k0);
         __syncthreads();
+        if (prefetch && k0 >= NB) fetch(k0 - NB);
         {
             // t_c = sum_r L[t0 + r][k0 + c] x[t0 + r]: 32 partial sums per column, then wave 0 combines them
             const int c = tid & 31, part = tid >> 5;
@@ -841,13 +882,13 @@ __global__ __launch_bounds__(kPT) void chol_solve_banded_blocked1_kernel(const d
         if (wave == 0) {
             const int c = lane & 31;
             double t = 0.0;
-#pragma unroll
+#pragma unroll 8
             for (int part = 0; part < kPT / NB; ++part) t += sQ[part * kLdT + c];
             const double yc = (c < nb) ? sXv[k0 + c] - t : 0.0;
             if (lane < NB) sCol[lane] = yc;
             mqs_wave_lds_sync();
             double s = 0.0;
-#pragma unroll
+#pragma unroll 8
             for (int k = 0; k < NB; ++k) s = fma(sLi[k * kLdT + c], sCol[k], s);     // inv(L)^T: zero for k < c
             if (lane < nb) sXv[k0 + lane] = s;
         }
@@ -887,7 +928,7 @@ __global__ __launch_bounds__(kPT) void chol_solve_banded_blocked_kernel(const do
                 if (wave == 0) {
                     const int j = lane & 31;
                     double s = 0.0;
-#pragma unroll
+#pragma unroll 8
                     for (int k = 0; k < NB; ++k) s = fma(sLi[j * kLdT + k], (k < nb) ? sXv[k0 + k] : 0.0, s);
                     mqs_wave_lds_sync();
                     if (lane < nb) sXv[k0 + lane] = s;
@@ -896,7 +937,7 @@ __global__ __launch_bounds__(kPT) void chol_solve_banded_blocked_kernel(const do
             }
             for (int r = tid; r < mc; r += kPT) {
                 double s = 0.0;
-#pragma unroll
+#pragma unroll 8
                 for (int c = 0; c < NB; ++c) s = fma(sP[r * kLdT + c], (c < nb) ? sXv[k0 + c] : 0.0, s);
                 sXv[t0 + c0 + r] -= s;
             }
@@ -934,7 +975,7 @@ __global__ __launch_bounds__(kPT) void chol_solve_banded_blocked_kernel(const do
             if (lane < NB) sCol[lane] = yc;
             mqs_wave_lds_sync();
             double s = 0.0;
-#pragma unroll
+#pragma unroll 8
             for (int k = 0; k < NB; ++k) s = fma(sLi[k * kLdT + c], sCol[k], s);     // inv(L)^T: zero for k < c
             if (lane < nb) sXv[k0 + lane] = s;
         }
