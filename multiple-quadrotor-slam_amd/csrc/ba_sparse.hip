@@ -527,54 +527,49 @@ __device__ __forceinline__ double read_lane_d(double v, int lane)
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
 }
 
-// Diagonal block: one wavefront, lane r keeps row r of the 32 x 32 block in registers; right-looking Cholesky with
-// v_readlane broadcasts (all register indices static), then the inverse of the factor, one column per lane, by forward
-// substitution.  Writes L into the lower triangle (diagonal included) and inv(L)'s strictly lower part TRANSPOSED into
-// the block's strictly upper triangle (row c, columns c+1.. = column c of inv(L)): the panel kernel turns the
-// triangular solve into a product with it.  Rows beyond the matrix act as identity.
+// Diagonal block: one wavefront.  Lanes 0..31: lane r keeps row r of the 32 x 32 block in registers, right-looking Cholesky
+// with v_readlane broadcasts (all register indices static).  Lanes 32..63 compute the INVERSE of the factor at the same
+// time, in the same instructions: lane 32 + c solves L y = e_c column-oriented, and step k of that substitution,
+// y[j] -= L[j][k] y[k] (j > k), is the trailing update's row[j] -= L[lane][k] L[j][k] with y[k] in the place of L[lane][k]
+// -- so `v[k] *= 1 / L[k][k]; v[j] = fma(-v[k], broadcast(L[j][k]), v[j])` does the factorisation in the lower half-wave
+// and the substitution in the upper one.  (History: a separate substitution after the factorisation, 19.9 us per block, of
+// which 964 SGPR spills; fused as a second FMA per broadcast in the same lanes, 9.4 us; this form halves the FMAs.)
+// Writes L into the lower triangle (diagonal included) and inv(L)'s strictly lower part TRANSPOSED into the block's
+// strictly upper triangle (row c, columns c+1.. = column c of inv(L)): the panel kernel turns the triangular solve into a
+// product with it.  Rows beyond the matrix act as identity.
 __global__ __launch_bounds__(64) void chol_diag_kernel(double *__restrict__ A, int n, int k0, int *__restrict__ bad)
 {
     const int nb = (n - k0) < NB ? (n - k0) : NB;
-    const int lane = threadIdx.x;
-    const bool live = lane < nb;
-    double row[NB];
-    double *Arow = A + (int64_t)(k0 + (live ? lane : nb - 1)) * n + k0;      // every lane loads from a valid row, selects after
+    const int lane = threadIdx.x, r = lane & 31;
+    const bool upper = lane >= 32;                        // the half-wave that carries the inverse
+    const bool live = r < nb;
+    double v[NB];
+    double *Arow = A + (int64_t)(k0 + (live ? r : nb - 1)) * n + k0;         // every lane loads from a valid row, selects after
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-        const double v = Arow[j < nb ? j : nb - 1];
-        row[j] = (live && j < nb && j <= lane) ? v : ((j == lane) ? 1.0 : 0.0);
+        const double a = Arow[j < nb ? j : nb - 1];
+        v[j] = (!upper && live && j < nb && j <= r) ? a : ((j == r) ? 1.0 : 0.0);
     }
     bool notpd = false;
-    // The inverse rides on the factorisation: lane c solves L y = e_c column-oriented, and step k of that substitution
-    // (y[j] -= L[j][k] y[k], j > k) needs exactly the broadcasts L[j][k] the trailing update of step k makes -- one
-    // v_readlane pair serves both, and the two independent FMA streams fill each other's latency (one wave per CU: nothing
-    // else hides it).  Same operations in the same order per accumulator as a separate forward substitution.
-    double y[NB];
-#pragma unroll
-    for (int j = 0; j < NB; ++j) y[j] = (j == lane) ? 1.0 : 0.0;
 #pragma unroll
     for (int k = 0; k < NB; ++k) {
-        const double akk = read_lane_d(row[k], k);
+        const double akk = read_lane_d(v[k], k);
         notpd = notpd || !(akk > 0.0);
         const double inv = mqs::rsqrt_d(akk > 0.0 ? akk : 1.0);
-        const double lik = row[k] * inv;                  // L[lane][k] for lane >= k
-        row[k] = lik;
-        const double yk = y[k] * inv;                     // inv(L)[k][lane]
-        y[k] = yk;
+        const double m = v[k] * inv;                      // L[lane][k] (lane >= k) | inv(L)[k][c]
+        v[k] = m;
 #pragma unroll
         for (int j = k + 1; j < NB; ++j) {
-            const double ljk = read_lane_d(lik, j);
-            row[j] = fma(-lik, ljk, row[j]);              // used for lane >= j only
-            y[j] = fma(-ljk, yk, y[j]);
-            asm volatile("" : "+v"(row[j]), "+v"(y[j]));   // pins both uses of the broadcast here: left alone, the compiler ran the two
-                                                            // FMA streams one after the other and kept 480 broadcasts alive in between (964 SGPR spills)
+            v[j] = fma(-m, read_lane_d(m, j), v[j]);      // the broadcast is L[j][k]: lane j < 32
+            asm volatile("" : "+v"(v[j]));                // keeps the right-looking order (independent FMAs); the compiler
+                                                          // otherwise turns the unrolled nest left-looking: one dependent chain per column
         }
     }
     if (lane == 0 && notpd) *bad = 1;
     if (live) {
 #pragma unroll
         for (int j = 0; j < NB; ++j)
-            if (j < nb) Arow[j] = (j <= lane) ? row[j] : y[j];             // y[j] = inv(L)[j][lane], j > lane
+            if (j < nb && (upper ? j > r : j <= r)) Arow[j] = v[j];        // upper half: v[j] = inv(L)[j][r], j > r
     }
 }
 
