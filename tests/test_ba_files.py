@@ -156,6 +156,8 @@ def test_grouped_pair_blocks_are_reproducible_and_equal_the_atomic_path(gpu):
     S2, g2 = ba.linearize(1e-3)
     import torch
     assert torch.equal(S1, S2) and torch.equal(g1, g2)                           # no atomics: bitwise reproducible
+    Sm = S2.reshape(ba.n6, ba.n6)
+    assert torch.equal(Sm, Sm.T) and float(Sm.abs().max()) > 0                  # both triangles written by the pair stage itself
     P = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
     Sa, ga = torch.empty_like(ba.S), torch.empty_like(ba.g)
     gpu._lib.check(gpu._lib.lib().mqs_sba_linearize_dev(
