@@ -386,8 +386,13 @@ __global__ __launch_bounds__(NW * 64) void knn2_mfma_kernel(const typename TP::e
         int tile, row;
         if (!TP::decode(key, d, tile, row)) return;
         const int i = (int)window_base + tile * 32 + row;
-        if (d < gd0[qt]) { gd1[qt] = gd0[qt]; gi1[qt] = gi0[qt]; gd0[qt] = d; gi0[qt] = i; }
-        else if (d < gd1[qt]) { gd1[qt] = d; gi1[qt] = i; }
+        // selects, not branches: the compiler merged the two branch bodies into one store through a computed address, which
+        // put the index arrays in scratch memory
+        const bool lt0 = d < gd0[qt], lt1 = d < gd1[qt];
+        gd1[qt] = lt0 ? gd0[qt] : (lt1 ? d : gd1[qt]);
+        gi1[qt] = lt0 ? gi0[qt] : (lt1 ? i : gi1[qt]);
+        gd0[qt] = lt0 ? d : gd0[qt];
+        gi0[qt] = lt0 ? i : gi0[qt];
     };
     auto close_window = [&](int64_t window_base) {
 #pragma unroll
