@@ -267,7 +267,8 @@ int mqs_sba_linearize_dev(const double *poses, const int32_t *pose_cam, int64_t 
                           double *g, double *info, void *workspace, int64_t workspace_bytes, void *stream);
 /* The same linearisation with the pair list SORTED by (pose of pair_a, pose of pair_b) and cut into G groups of equal key
  * (group_ptr [G + 1] int64 offsets into the pair list): one wavefront per group sums its blocks in registers and writes the
- * 6 x 6 block once -- no atomics, bitwise reproducible, and about 15x faster on the pair stage. */
+ * 6 x 6 block once -- no atomics, bitwise reproducible, and about 15x faster on the pair stage.  It writes the block's
+ * mirror image too (no full-matrix mirror pass): this relies on the ordering above (pose of pair_a <= pose of pair_b). */
 int mqs_sba_linearize_grouped_dev(const double *poses, const int32_t *pose_cam, int64_t P, const double *calib,
                                   const double *sigma, const double *points, int64_t N, const int64_t *obs_ptr,
                                   const int32_t *obs_pose, const double *obs_uv, int64_t M, const int64_t *pair_a,
