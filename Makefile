@@ -10,8 +10,16 @@ LIBS     ?= -L/opt/rocm/lib -lrocsolver -lrocblas
 
 all: $(LIB) oracle
 
-$(LIB): $(SRCS) $(HDRS)
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(SRCS) $(LIBS)
+# one object per translation unit (kernels never call across files), so a change recompiles one file and `make -j` uses the cores
+OBJDIR := build/obj
+OBJS   := $(patsubst $(PKG)/csrc/%.hip,$(OBJDIR)/%.o,$(SRCS))
+
+$(OBJDIR)/%.o: $(PKG)/csrc/%.hip $(HDRS)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
+
+$(LIB): $(OBJS)
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(OBJS) $(LIBS)
 
 oracle:
 	$(MAKE) -s -C oracle/c

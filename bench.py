@@ -11,9 +11,14 @@ Inputs are resident in HBM before the timed region.  `value` = landmarks (all ra
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--landmarks L] [--cams C]
 
-N > 1: launched by torch.distributed.run, one rank per GPU; landmarks shard across ranks
-(weak scaling: every rank holds L landmarks), no data-path collective for triangulation, one
-RCCL all-reduce of the reduced camera system per BA iteration.
+N > 1: one rank per GPU.  `python bench.py --gpus N` starts its own ranks (child `python -m torch.distributed.run`, the
+parent never touches the GPU) unless it already runs under torch.distributed.run (WORLD_SIZE set).  Landmarks shard
+across ranks, no data-path collective for triangulation, one RCCL all-reduce of the reduced camera system per BA iteration,
+issued from C on the kernels' stream (mqs_ba_gn_iteration_dev; `transport` in the output).
+  --scaling weak    (default) every rank holds L landmarks of its own scene: BASELINE configs[1] per GPU.
+  --scaling strong  ONE scene of L landmarks, rank r holds sharding.landmark_shard(L, r, N): BASELINE configs[3].
+At N > 1 the weak run also reports configs[3] as `ba_strong`: the 1e6-landmark problem sharded N-way, 10 GN iterations,
+with the poses checked against the same problem solved by ONE rank (<= 1e-10).
 
 Extra objects on the JSON line:
   roofline     -- dominant kernel (iterative-LS): algorithmic bytes per launch / average launch
@@ -36,6 +41,83 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_VALU_PEAK_TFLOPS = 78.6    # same guide: 256 CUs x 4 SIMDs x 16 fp64 FMA lanes x 2 flop x 2.4 GHz (vector, not matrix)
+
+
+def kernel_flops():
+    """fp64 flop and VALU instructions per landmark of the fp64-bound kernels, counted from the gfx950 ISA by
+    tools/isa_mix.py (static count x loop trip counts; FMA = 2 flop): profiles/kernel_flops.json."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "kernel_flops.json")))
+    except Exception:
+        return {}
+
+
+def ba_strong_leg(mq, np, torch, total, C, rank, world, dev, group, dist, iters=10):
+    """BASELINE configs[3]: ONE scene of `total` landmarks x C cameras, rank r holds sharding.landmark_shard(total, r, world)
+    (contiguous ranges: the reference's `omp parallel for` axis, triangulation.c:70,109; graph bundle_adjust.cpp:289-298),
+    `iters` Gauss-Newton iterations with one all-reduce of the reduced camera system each.  The poses every rank ends with
+    are compared with the same problem solved by rank 0 alone."""
+    syn, sh, D = mq.synthetic, mq.sharding, mq.device
+    u_all, P, _ = syn.triangulation_problem(total, C, seed=syn.RSEED + 7)
+    Pd = torch.from_numpy(np.ascontiguousarray(P)).to(dev)
+
+    def problem(lo, hi, grp):
+        us = np.ascontiguousarray(u_all[:, lo:hi])
+        x0, _ = D.iterative_LS_triangulation(torch.from_numpy(us).to(dev), Pd)
+        return mq.bundle_adjustment.make_benchmark_problem(us, P, x0, dev, seed=syn.RSEED, process_group=grp,
+                                                           prior_first=4 if lo == 0 else 0)
+
+    def fence():
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    a, b = sh.landmark_shard(total, rank, world)
+    problem(a, b, group).gauss_newton_iterations(2)              # warm-up on a throw-away copy of the shard
+    ba = problem(a, b, group)
+    c0 = ba.total_cost()
+    fence()
+    t0 = time.perf_counter()
+    ba.gauss_newton_iterations(iters)
+    fence()
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    dt = float(dt.item())
+    c1 = ba.total_cost()
+    # the collective by itself: back-to-back all-reduces of the 602-double system on the kernels' stream
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    probe = torch.zeros_like(ba.lin)
+    red = (lambda: group.all_reduce_sum_(probe)) if isinstance(group, sh.CComm) else (lambda: dist.all_reduce(probe))
+    red()
+    fence()
+    e0.record()
+    for _ in range(20):
+        red()
+    e1.record()
+    e1.synchronize()
+    ar_us = e0.elapsed_time(e1) / 20 * 1e3
+    # every rank solved the same reduced system: identical poses everywhere, and equal to the one-rank solution
+    mine = ba.poses.clone()
+    lo_, hi_ = mine.clone(), mine.clone()
+    dist.all_reduce(lo_, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi_, op=dist.ReduceOp.MAX)
+    same = bool(torch.equal(lo_, hi_))
+    diff = cost_one = None
+    if rank == 0:
+        one = problem(0, total, None)
+        one.gauss_newton_iterations(iters)
+        torch.cuda.synchronize()
+        diff = float((one.poses - mine).abs().max().item())
+        cost_one = one.total_cost()
+    fence()
+    return {"workload": "BASELINE configs[3]: %d landmarks x %d cameras sharded %d-way (contiguous landmark ranges), %d Gauss-Newton "
+                        "iterations, one all-reduce of (6C)^2+6C+2 doubles per iteration" % (total, C, world, iters),
+            "landmarks_total": total, "landmarks_per_gpu": b - a, "iterations": iters, "ms_per_iter": round(1e3 * dt / iters, 4),
+            "gn_iters_per_s": round(iters / dt, 1), "landmarks_per_s": round(total * iters / dt),
+            "all_reduce_us": round(ar_us, 2), "rccl_world_size": dist.get_world_size(), "backend": dist.get_backend(),
+            "cost_before": c0, "cost_after": c1, "cost_after_one_rank": cost_one,
+            "poses_identical_on_all_ranks": same, "max_abs_pose_diff_vs_one_rank": diff,
+            "ok": (same and diff is not None and diff <= 1e-10) if rank == 0 else None}
 
 
 def main():
@@ -52,7 +134,30 @@ def main():
     ap.add_argument("--no-replay", action="store_true")
     ap.add_argument("--no-frontend", action="store_true")
     ap.add_argument("--descriptors", type=int, default=65536)
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--strong-landmarks", type=int, default=1_000_000, help="total landmarks of the ba_strong leg (N > 1)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started by hand: become the launcher.  Nothing here has touched HIP (no torch import, no library load), and the
+        # ranks are fresh child processes -- never an exec from a process that holds the GPU.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+    # everything that may need a compiler runs BEFORE the first GPU call (a child `make` started later would inherit an
+    # initialised-GPU parent's profiler preload); both builders are no-ops when their library is up to date
+    want_cpu = (not args.no_cpu_baseline) and int(os.environ.get("WORLD_SIZE", "1")) == 1
+    if want_cpu:
+        from oracle import c_oracle
+        c_oracle.build()
 
     import numpy as np
     import torch
@@ -62,20 +167,50 @@ def main():
         raise SystemExit("libmqslam_hip.so is not available: %r" % (mqslam_amd._lib.load_error,))
 
     dist = None
-    rank, local_rank, world = mqslam_amd.sharding.init_from_env(backend="nccl")
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
-        args.gpus = world
+    sh = mqslam_amd.sharding
+    rank, local_rank, world = sh.init_from_env(backend="nccl")
+    args.gpus = world
+    transport, group = None, None
     if world > 1:
         import torch.distributed as dist
+        group, transport = True, "torch.distributed(%s)" % dist.get_backend()
+        if dist.get_backend() == "nccl" and os.environ.get("MQS_TRANSPORT", "c") == "c":
+            # the library's own communicator: the all-reduce is issued from C between the kernels of an iteration.  It is
+            # verified against torch.distributed's sum before use; any failure keeps the torch transport (still RCCL).
+            try:
+                cc = sh.init_c_comm(rank, world, local_rank)
+                probe = torch.arange(602, dtype=torch.float64, device=torch.device("cuda", local_rank)) * (rank + 1)
+                want = probe.clone()
+                dist.all_reduce(want)
+                cc.all_reduce_sum_(probe)
+                torch.cuda.synchronize()
+                ok = torch.tensor([1.0 if torch.equal(probe, want) else 0.0], device=probe.device)
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if ok.item() == 1.0:
+                    group, transport = cc, "rccl via the C ABI (mqs_comm_*, all-reduce issued inside mqs_ba_gn_iteration_dev)"
+                else:
+                    transport += " (C-ABI communicator gave a different sum: not used)"
+            except Exception as e:                              # noqa: BLE001 -- reported, the run continues on torch's RCCL
+                transport += " (C-ABI communicator unavailable: %s)" % (str(e)[:120],)
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank if world > 1 else 0)
 
-    N, C = args.landmarks, args.cams
+    C = args.cams
     syn = mqslam_amd.synthetic
-    u, P, pts = syn.triangulation_problem(N, C, seed=syn.RSEED + 1000 * rank)
+    strong = args.scaling == "strong" and world > 1
+    if strong:
+        # one scene, rank r holds its contiguous landmark range (the reference's own `omp parallel for` axis, triangulation.c:70,109)
+        N_total = args.landmarks
+        a, b = sh.landmark_shard(N_total, rank, world)
+        u_all, P, pts_all = syn.triangulation_problem(N_total, C, seed=syn.RSEED)
+        u, pts = np.ascontiguousarray(u_all[:, a:b]), pts_all[a:b]
+        N = b - a
+        del u_all, pts_all
+    else:
+        N = args.landmarks
+        N_total = N * world
+        u, P, pts = syn.triangulation_problem(N, C, seed=syn.RSEED + 1000 * rank)
     ud = torch.from_numpy(u).to(dev)
     Pd = torch.from_numpy(np.ascontiguousarray(P)).to(dev)
     x_ls = torch.empty((N, 3), dtype=torch.float64, device=dev)
@@ -89,7 +224,8 @@ def main():
         # perturbation uses the same seed on every rank
         D.iterative_LS_triangulation(ud, Pd, out=x_it, out_status=st)
         ba = mqslam_amd.bundle_adjustment.make_benchmark_problem(
-            u, P, x_it, dev, seed=syn.RSEED, process_group=True if world > 1 else None)
+            u, P, x_it, dev, seed=syn.RSEED, process_group=group if world > 1 else None,
+            prior_first=4 if (rank == 0 or not strong) else 0)
 
     def triangulate():
         # both least-squares methods in one pass over the observations: the first solve of the iteration (unit weights) is
@@ -132,7 +268,7 @@ def main():
         elapsed = float(t.item())
 
     ms_per_step = 1e3 * elapsed / args.steps
-    value = N * world / (elapsed / args.steps)
+    value = N_total / (elapsed / args.steps)
 
     # ---- per-kernel durations with hipEvents on the launch stream (rank 0 reports) ----
     reps = 20
@@ -162,16 +298,11 @@ def main():
     if valu_it.get("fp64_flop_per_landmark_static_count"):
         tf = valu_it["fp64_flop_per_landmark_static_count"] * N / (ms_it * 1e-3) / 1e12
         valu_it["fp64_TFLOPs_at_measured_time"] = round(tf, 1)
-        valu_it["frac_of_fp64_vector_peak_78.6TF"] = round(tf / 78.6, 3)
-    roofline = {"bound": "hbm", "kernel": "tri_kernel<%d, iterative_ls>" % C, "achieved": round(achieved, 1),
-                "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                "traffic": traffic, "algorithmic_bytes_per_launch": bytes_it,
-                "avg_launch_ms": round(ms_it, 5),
-                "valu_pmc": valu_it or None,
-                "note": "dominant kernel of the triangulation metric, timed stand-alone (20 back-to-back launches, hipEvents on "
-                        "the launch stream); inside the step the same arithmetic runs fused with linear-LS on a second stream beside "
-                        "the BA chain, where a per-launch duration is stretched by the kernels it shares the chip with.  By time the "
-                        "step's largest kernel is ba_linearize_kernel (see rooflines): both are bound by fp64 VALU issue, not HBM"}
+        valu_it["frac_of_fp64_vector_peak_78.6TF"] = round(tf / FP64_VALU_PEAK_TFLOPS, 3)
+    roofline_it = {"bound": "hbm", "kernel": "tri_kernel<%d, iterative_ls>" % C, "achieved": round(achieved, 1),
+                   "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                   "traffic": traffic, "algorithmic_bytes_per_launch": bytes_it, "avg_launch_ms": round(ms_it, 5),
+                   "valu_pmc": valu_it or None}
     kernels = {
         "iterative_ls": {"ms": round(ms_it, 5), "landmarks_per_s": round(N / (ms_it * 1e-3)),
                          "GBps": round(bytes_it / (ms_it * 1e-3) / 1e9, 1)},
@@ -269,6 +400,36 @@ def main():
                                            "note": "fp64 VALU issue binds before HBM (DESIGN.md)"}
         rooflines["ba_backsub"] = {"bound": "hbm", "achieved": round(back_gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                    "frac": round(back_gbps / HBM_PEAK_GBPS, 4)}
+    rooflines["iterative_ls_standalone"] = roofline_it
+    roofline = roofline_it
+    if ba_out is not None and C == 4:
+        # the kernel with the largest share of the timed step is the BA lineariser; what binds it is fp64 vector issue
+        # (its 88 B/landmark would take 11 us at HBM rate), so the headline fraction is flop / time against the fp64 VALU
+        # peak, with the HBM fraction beside it.  flop per landmark: counted from the ISA (tools/isa_mix.py).
+        kf = kernel_flops().get("ba_linearize_kernel<4>", {})
+        ms_lin = ba_out["kernels_ms"].get("linearize_kernel_only", ba_out["kernels_ms"]["linearize_schur"])
+        flop = kf.get("fp64_flop_per_landmark")
+        bytes_lin = N * (24 + 16 * C) + (8 * N if ba.prior_w is not None else 0)
+        hbm = {"achieved": round(bytes_lin / (ms_lin * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+               "algorithmic_bytes_per_launch": bytes_lin, "traffic": (json.load(open(pmc_path)).get("ba_linearize_hbm_bytes_per_launch")
+                                                                       if os.path.exists(pmc_path) and N == 1_000_000 else None)}
+        hbm["frac"] = round(hbm["achieved"] / HBM_PEAK_GBPS, 4)
+        if flop:
+            tf = flop * N / (ms_lin * 1e-3) / 1e12
+            roofline = {"bound": "fp64_valu", "kernel": "ba_linearize_kernel<%d>" % C, "achieved": round(tf, 2),
+                        "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / FP64_VALU_PEAK_TFLOPS, 4),
+                        "traffic": hbm["traffic"], "avg_launch_ms": round(ms_lin, 5), "fp64_flop_per_landmark": flop,
+                        "valu_instructions_per_landmark": kf.get("valu_instructions_per_landmark"),
+                        "valu_issue_slots_per_landmark": kf.get("valu_issue_slots_per_landmark"), "hbm": hbm,
+                        "share_of_step": round(ms_lin / ms_per_step, 3),
+                        "note": "largest kernel of the timed step (hipEvents on the launch stream, stand-alone launches); bound by "
+                                "fp64 vector issue, not HBM: `frac` = counted fp64 flop / time against the 78.6 TFLOP/s vector peak; "
+                                "`hbm` is the same launch against the 8 TB/s roof SURVEY 8(d) assigns it"}
+        else:
+            roofline = dict(rooflines["ba_linearize_schur"], kernel="ba_linearize_kernel<%d>" % C, traffic=hbm["traffic"], hbm=hbm,
+                            avg_launch_ms=round(ms_lin, 5))
+    if "hbm" not in roofline:
+        roofline["hbm"] = {"achieved": roofline["achieved"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": roofline["frac"]}
     if match_out is not None:
         rooflines["match_knn2_f16"] = {"bound": "mfma", "achieved": match_out["TFLOPs"], "peak": 2500.0, "unit": "TFLOP/s",
                                        "frac": match_out["frac_of_peak"]}
@@ -432,6 +593,11 @@ def main():
                "parity": {"rel_err_p99.9": float(np.quantile(rel, 0.999)), "rel_err_median": float(np.median(rel)),
                           "status_mismatch_frac": float(np.mean(st[:ns].cpu().numpy() != so))}}
 
+    strong_out = None
+    if world > 1 and ba is not None:
+        strong_out = ba_strong_leg(mqslam_amd, np, torch, args.landmarks if strong else args.strong_landmarks, C, rank, world,
+                                   dev, group, dist)
+
     if rank == 0:
         out = {
             "metric": "triangulated landmarks/sec (linear-LS DLT + iterative-LS per landmark"
@@ -439,17 +605,22 @@ def main():
                       + "), 1e6 pts x 4 cams per GPU; BA GN iters/sec in `ba`",
             "value": round(value), "unit": "landmarks/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: %d landmarks x %d cameras per GPU, linear-LS + "
-                                   "iterative-LS (tol 3e-5, <=10 iterations)" % (N, C),
-                       "landmarks_per_gpu": N, "cameras": C, "sharding": "landmarks, %d-way" % world},
+            "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": ("BASELINE configs[3] shape: ONE scene of %d landmarks x %d cameras sharded %d-way, linear-LS + "
+                                    "iterative-LS + 1 GN iteration per step" % (N_total, C, world)) if strong else
+                                   ("BASELINE configs[1]: %d landmarks x %d cameras per GPU, linear-LS + "
+                                    "iterative-LS (tol 3e-5, <=10 iterations)" % (N, C)),
+                       "landmarks_per_gpu": N, "landmarks_total": N_total, "cameras": C, "sharding": "landmarks, %d-way" % world},
+            "transport": transport, "ba_strong": strong_out,
             "roofline": roofline, "rooflines": rooflines, "kernels": kernels, "ba": ba_out, "match": match_out,
             "replay": replay_out, "frontend": frontend_out, "sparse_ba": sparse_out, "cpu_baseline": cpu,
         }
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()                      # rank 0 reports alone for a few seconds: every rank leaves the group together
         dist.destroy_process_group()
+    if rank == 0 and strong_out is not None and strong_out["ok"] is False:
+        raise SystemExit("ba_strong: the sharded run does not reproduce the one-rank poses (%r)" % (strong_out,))
 
 
 if __name__ == "__main__":

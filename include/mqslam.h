@@ -43,6 +43,7 @@ extern "C" {
 #define MQS_E_HIP      -2   /* HIP runtime error (message in mqs_last_error) */
 #define MQS_E_NOMEM    -3   /* device or host allocation failed */
 #define MQS_E_NODEVICE -4   /* no gfx950 device visible */
+#define MQS_E_RCCL     -5   /* RCCL missing or a collective failed (message in mqs_last_error) */
 
 #define MQS_MAX_CAMS    8
 #define MQS_TRI_MAX_ITER_DEFAULT 10        /* triangulation.c:125 */
@@ -231,6 +232,50 @@ int mqs_ba_cost_dev(const double *poses, const double *calib, const double *sigm
                     const double *points, const double *obs, const uint8_t *mask,
                     const double *prior_w, const double *prior_xyz, int64_t N, double *out,
                     void *workspace, int64_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Multi-GPU transport: one process per GPU, one RCCL communicator per mqs_ctx.  The only collective
+ * of the hot path is the sum all-reduce of linearize's `out` ((6C)^2 + 6C + 2 doubles) once per optimiser iteration --
+ * the GTSAM counterpart has none: bundle_adjust.cpp:323-324 optimises one graph in one process.
+ * RCCL is bound at run time (the library loads without it).  Rank 0 calls mqs_comm_unique_id and the host program hands
+ * the 128 bytes to every rank (torch.distributed store, MPI, a file); every rank then calls mqs_comm_init_rank
+ * (collective).  mqs_comm_world_size: ranks of the context's communicator, 0 without one.
+ * ------------------------------------------------------------------------------------- */
+int mqs_comm_unique_id(uint8_t *id128);
+int mqs_comm_init_rank(mqs_ctx *ctx, const uint8_t *id128, int rank, int world);
+int mqs_comm_world_size(const mqs_ctx *ctx);
+int mqs_comm_destroy(mqs_ctx *ctx);
+/* in-place sum over the ranks of buf[n] (device pointer), asynchronous on `stream` */
+int mqs_comm_all_reduce_sum_f64_dev(mqs_ctx *ctx, double *buf, int64_t n, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * One optimiser iteration behind one call (the loop body of LevenbergMarquardtOptimizer::optimize,
+ * bundle_adjust.cpp:323-324, for the graph of :268-298 with every landmark visible in every camera).
+ * A problem binds the caller's DEVICE buffers (nothing is copied or owned): two pose buffers [C][12] and two landmark
+ * buffers [N][3] that alternate as current / next estimate, the constant inputs of mqs_ba_linearize_dev /
+ * mqs_ba_solve_dev, lin [(6C)^2 + 6C + 2], dpose [6C], info [2] (may be NULL) and a workspace of
+ * mqs_ba_workspace_bytes(C, N).  ctx: the context whose communicator sums `lin` over the ranks (NULL or a context
+ * without communicator: single GPU).  The estimate starts in poses_a / points_a (current = 0).
+ *   mqs_ba_gn_iteration_dev   linearise + Schur -> [all-reduce] -> solve + retract -> back-substitute, all enqueued on
+ *                             `stream` without a host round trip; the new estimate becomes current.
+ *   mqs_ba_gn_begin_dev / mqs_ba_gn_finish_dev   the same in two halves for a caller that sums `lin` itself between
+ *                             them (another transport) or decides acceptance (accept = 0: the step stays a trial in the
+ *                             other buffers -- Levenberg-Marquardt).
+ *   mqs_ba_gn_iterations_dev  `iters` iterations back to back.
+ * ------------------------------------------------------------------------------------- */
+typedef struct mqs_ba_problem mqs_ba_problem;
+int mqs_ba_problem_create(mqs_ctx *ctx, int C, int64_t N, double *poses_a, double *poses_b, const double *calib,
+                          const double *sigma, double *points_a, double *points_b, const double *obs, const uint8_t *mask,
+                          const double *prior_w, const double *prior_xyz, const double *prior_poses,
+                          const double *prior_sigmas, const uint8_t *prior_mask, double *lin, double *dpose, double *info,
+                          void *workspace, int64_t workspace_bytes, mqs_ba_problem **out);
+void mqs_ba_problem_destroy(mqs_ba_problem *p);
+int mqs_ba_problem_current(const mqs_ba_problem *p);              /* 0 / 1: which buffer pair holds the estimate */
+int mqs_ba_problem_set_current(mqs_ba_problem *p, int which);
+int mqs_ba_gn_begin_dev(mqs_ba_problem *p, double lambda, void *stream);
+int mqs_ba_gn_finish_dev(mqs_ba_problem *p, double lambda, int accept, void *stream);
+int mqs_ba_gn_iteration_dev(mqs_ba_problem *p, double lambda, void *stream);
+int mqs_ba_gn_iterations_dev(mqs_ba_problem *p, int iters, double lambda, void *stream);
 
 /* Host-pointer convenience wrappers (copy in, run, copy out; synchronous). */
 int mqs_ba_linearize(mqs_ctx *ctx, const double *poses, const double *calib, const double *sigma, int C,

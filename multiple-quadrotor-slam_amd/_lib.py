@@ -78,6 +78,19 @@ SIGNATURES = {
                                         c_f64p, c_i64, ctypes.c_double, c_f64p]),
     "mqs_ba_backsub": (ctypes.c_int, [c_vp, c_f64p, c_f64p, c_f64p, ctypes.c_int, c_f64p, c_f64p, c_u8p, c_f64p,
                                       c_f64p, c_i64, ctypes.c_double, c_f64p, c_f64p]),
+    "mqs_comm_unique_id": (ctypes.c_int, [c_u8p]),
+    "mqs_comm_init_rank": (ctypes.c_int, [c_vp, c_u8p, ctypes.c_int, ctypes.c_int]),
+    "mqs_comm_world_size": (ctypes.c_int, [c_vp]),
+    "mqs_comm_destroy": (ctypes.c_int, [c_vp]),
+    "mqs_comm_all_reduce_sum_f64_dev": (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp]),
+    "mqs_ba_problem_create": (ctypes.c_int, [c_vp, ctypes.c_int, c_i64] + [c_vp] * 17 + [c_i64, ctypes.POINTER(c_vp)]),
+    "mqs_ba_problem_destroy": (None, [c_vp]),
+    "mqs_ba_problem_current": (ctypes.c_int, [c_vp]),
+    "mqs_ba_problem_set_current": (ctypes.c_int, [c_vp, ctypes.c_int]),
+    "mqs_ba_gn_begin_dev": (ctypes.c_int, [c_vp, ctypes.c_double, c_vp]),
+    "mqs_ba_gn_finish_dev": (ctypes.c_int, [c_vp, ctypes.c_double, ctypes.c_int, c_vp]),
+    "mqs_ba_gn_iteration_dev": (ctypes.c_int, [c_vp, ctypes.c_double, c_vp]),
+    "mqs_ba_gn_iterations_dev": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_double, c_vp]),
     "mqs_sba_workspace_bytes": (c_i64, [c_i64, c_i64, c_i64]),
     "mqs_sba_linearize_dev": (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp,
                                              c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_int, ctypes.c_double,
@@ -140,9 +153,18 @@ SIGNATURES = {
 }
 
 
+def clean_child_env():
+    """Environment for child processes started after this process may have initialised the GPU: without the profiler's
+    preload (under `rocprofv3 --pmc` the preloaded tool initialises the GPU in every child before it can exec make / gcc /
+    hipcc, which this pool forbids) and without its ROCP_* / ROCPROF* configuration."""
+    env = {k: v for k, v in os.environ.items()
+           if k != "LD_PRELOAD" and not k.startswith(("ROCP_", "ROCPROF", "ROCTX_", "ROCPROFILER_"))}
+    return env
+
+
 def build():
     """Compile the gfx950 library in-tree (same recipe as `make`)."""
-    subprocess.check_call(["make", "-s", "-C", _ROOT, os.path.relpath(LIB_PATH, _ROOT)])
+    subprocess.check_call(["make", "-s", "-j8", "-C", _ROOT, os.path.relpath(LIB_PATH, _ROOT)], env=clean_child_env())
 
 
 def _try_load():

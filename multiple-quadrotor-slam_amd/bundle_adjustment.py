@@ -10,14 +10,17 @@ the reference's stand-alone tool `Work/SLAM/tools/bundle_adjustment/bundle_adjus
                     BASELINE.json's metric counts.
 
 All state lives in device tensors (torch is used for memory, the current stream and
-torch.distributed only).  One Gauss-Newton iteration is four asynchronous launches on the current
-stream with no host round trip:
+torch.distributed only).  One Gauss-Newton iteration is ONE call into the library
+(`mqs_ba_gn_iteration_dev`, csrc/ba_iter.hip) that enqueues, with no host round trip,
     linearise + on-chip Schur elimination  ->  [all-reduce of the 6C x 6C system across ranks]
     -> reduced camera solve + pose retraction  ->  landmark back-substitution.
 Multi-GPU: landmarks are sharded across ranks (poses, calibrations replicated); the only
 collective is ONE all-reduce (RCCL over xGMI) of (6C)^2 + 6C + 2 doubles per iteration; pose
 priors are added identically on every rank after the reduce, so every rank solves the same
-system and no broadcast is needed.
+system and no broadcast is needed.  Transport: `process_group=sharding.CComm` (an RCCL communicator
+inside the library's context: the all-reduce is issued from C between the launches) or a
+torch.distributed group / True (the collective is issued from Python between the two halves
+`mqs_ba_gn_begin_dev` / `mqs_ba_gn_finish_dev`; what the gloo tests use).
 """
 import ctypes
 import time
@@ -79,10 +82,10 @@ class BundleAdjuster:
         C, N = self.C, self.N
         if not (1 <= C <= 8):
             raise ValueError("number of cameras must be in [1, 8]")
-        self.poses = chk(poses, (C, 12), name="poses")
+        poses0 = chk(poses, (C, 12), name="poses")
         self.calib = chk(calib, (C, 9), name="calib")
         self.sigma = chk(sigma, (C,), name="sigma")
-        self.points = chk(points, (N, 3), name="points")
+        points0 = chk(points, (N, 3), name="points")
         self.obs = chk(obs, (C, N, 2), name="obs")
         self.mask = chk(mask, (C, N), torch.uint8, "mask")
         self.prior_w = chk(prior_w, (N,), name="prior_w")
@@ -96,19 +99,61 @@ class BundleAdjuster:
             self.prior_mask = chk(pm, (C,), torch.uint8, "prior_mask")
         else:
             self.prior_poses = self.prior_sigmas = self.prior_mask = None
-        self.pg = process_group
+        self.ccomm = process_group if isinstance(process_group, sharding.CComm) else None
+        self.pg = None if self.ccomm is not None else process_group
         n6 = 6 * C
         self.n6 = n6
         self.lin = torch.zeros(n6 * n6 + n6 + 2, dtype=f64, device=self.dev)
         self.dpose = torch.zeros(n6, dtype=f64, device=self.dev)
         self.info = torch.zeros(2, dtype=f64, device=self.dev)
         self.cost_out = torch.zeros(2, dtype=f64, device=self.dev)
-        self.poses_new = torch.empty_like(self.poses)
-        self.points_new = torch.empty_like(self.points)
+        # the estimate alternates between two buffer pairs; the library's problem handle knows which one is current
+        self._poses = [poses0, torch.empty_like(poses0)]
+        self._points = [points0, torch.empty_like(points0)]
         ws = int(_lib.lib().mqs_ba_workspace_bytes(C, N))
         self.ws = torch.empty(max(ws, 65536), dtype=torch.uint8, device=self.dev)
         self.lam = 0.0
         self.cost_history = []
+        self._h = None
+        self._h = ctypes.c_void_p()
+        _lib.check(_lib.lib().mqs_ba_problem_create(
+            self.ccomm.ctx.handle if self.ccomm is not None else None, C, N, _p(self._poses[0]), _p(self._poses[1]),
+            _p(self.calib), _p(self.sigma), _p(self._points[0]), _p(self._points[1]), _p(self.obs), _p(self.mask),
+            _p(self.prior_w), _p(self.prior_xyz), _p(self.prior_poses), _p(self.prior_sigmas), _p(self.prior_mask),
+            _p(self.lin), _p(self.dpose), _p(self.info), _p(self.ws), self.ws.numel(), ctypes.byref(self._h)))
+
+    def __del__(self):
+        try:
+            if self._h:
+                _lib.lib().mqs_ba_problem_destroy(self._h)
+                self._h = ctypes.c_void_p()
+        except Exception:
+            pass
+
+    # ---- current / next estimate (the handle owns the index) ---------------------------
+    @property
+    def _cur(self):
+        return int(_lib.lib().mqs_ba_problem_current(self._h))
+
+    @property
+    def poses(self):
+        return self._poses[self._cur]
+
+    @property
+    def points(self):
+        return self._points[self._cur]
+
+    @property
+    def poses_new(self):
+        return self._poses[1 - self._cur]
+
+    @property
+    def points_new(self):
+        return self._points[1 - self._cur]
+
+    def accept(self):
+        """Makes the trial estimate (poses_new / points_new) the current one."""
+        _lib.check(_lib.lib().mqs_ba_problem_set_current(self._h, 1 - self._cur))
 
     # ---- the four launches -------------------------------------------------------------
     def linearize(self, lam=0.0):
@@ -121,6 +166,9 @@ class BundleAdjuster:
     def all_reduce(self, async_op=False):
         """Sum of the reduced camera system over ranks.  async_op=True returns the collective's work handle (or
         None on one rank): the reduce then runs on RCCL's stream and `wait()` orders the current stream after it."""
+        if self.ccomm is not None:
+            self.ccomm.all_reduce_sum_(self.lin)                 # on the current stream, in order: nothing to wait for
+            return None
         if self.pg is not None:
             return sharding.all_reduce_sum_(self.lin, None if self.pg is True else self.pg, async_op=async_op)
         return None
@@ -153,22 +201,33 @@ class BundleAdjuster:
         """One undamped (lam = 0) or fixed-damping iteration, fully asynchronous.  `overlap`: a callable that
         enqueues work independent of this problem on the current stream; it is issued between the start of the
         all-reduce and the wait for it, so that the latency-bound collective (4.8 KB over xGMI) hides under it."""
-        self.linearize(lam)
+        L = _lib.lib()
+        if self.pg is None and overlap is None:
+            _lib.check(L.mqs_ba_gn_iteration_dev(self._h, float(lam), _sp()))          # one call: C issues everything
+            return
+        _lib.check(L.mqs_ba_gn_begin_dev(self._h, float(lam), _sp()))
         work = self.all_reduce(async_op=True)
         if overlap is not None:
             overlap()
         if work is not None:
             work.wait()
-        self.solve(lam)
-        self.backsub(lam)
-        self.poses, self.poses_new = self.poses_new, self.poses
-        self.points, self.points_new = self.points_new, self.points
+        _lib.check(L.mqs_ba_gn_finish_dev(self._h, float(lam), 1, _sp()))
+
+    def gauss_newton_iterations(self, iters, lam=0.0):
+        """`iters` iterations enqueued by one library call (single GPU or the C-level communicator)."""
+        if self.pg is not None:
+            for _ in range(iters):
+                self.gauss_newton_iteration(lam)
+            return
+        _lib.check(_lib.lib().mqs_ba_gn_iterations_dev(self._h, int(iters), float(lam), _sp()))
 
     def total_cost(self, poses=None, points=None):
         """Host float: projection + point-prior cost summed over ranks, plus pose-prior cost."""
         torch = _torch()
         c = self.cost(poses, points).clone()
-        if self.pg is not None:
+        if self.ccomm is not None:
+            self.ccomm.all_reduce_sum_(c)
+        elif self.pg is not None:
             import torch.distributed as dist
             dist.all_reduce(c, op=dist.ReduceOp.SUM, group=self.pg if self.pg is not True else None)
         total = float(c[0].item())
@@ -225,8 +284,7 @@ class BundleAdjuster:
                     if verbose:
                         print("  lm lambda %.1e cost %.6e -> %.6e" % (lam, cur, new))
                     if new <= cur:
-                        self.poses, self.poses_new = self.poses_new, self.poses
-                        self.points, self.points_new = self.points_new, self.points
+                        self.accept()
                         lam = max(lam / LM_LAMBDA_FACTOR, 1e-20)
                         improved = True
                         break
@@ -328,13 +386,14 @@ def _so3_exp(w):
     return np.eye(3) + (np.sin(th) / th) * K + ((1 - np.cos(th)) / th ** 2) * K @ K
 
 
-def make_benchmark_problem(u, P, points_init, dev, seed=0, process_group=None, pixel_sigma=1.0):
+def make_benchmark_problem(u, P, points_init, dev, seed=0, process_group=None, pixel_sigma=1.0, prior_first=4):
     """
     SURVEY.md 8(d) BA benchmark scene: observations = the triangulation benchmark's (noisy,
     pixel-discretised) measurements in pixels; initial poses = truth o Exp(N(0, diag(0.02 rad x3,
     0.1 x3))) (sigmas of GenerateData.hpp:108-109); Cal3DS2(480,480,0,320,240,0,0,0,0); sigma_pixel 1;
     gauge: pose prior on camera 0, point priors (sigma 0.2, GenerateData.hpp:123) on the first 4
-    landmarks.  `points_init`: (N,3) initial landmarks (numpy or device tensor).
+    landmarks (`prior_first`; a rank that holds a later shard of ONE scene passes 0).  `points_init`: (N,3) initial
+    landmarks (numpy or device tensor).
     """
     torch = _torch()
     from . import synthetic as syn
@@ -354,7 +413,7 @@ def make_benchmark_problem(u, P, points_init, dev, seed=0, process_group=None, p
     else:
         pts = points_init.clone()
     prior_w = np.zeros(N)
-    prior_w[:4] = 1.0 / 0.2 ** 2
+    prior_w[:prior_first] = 1.0 / 0.2 ** 2
     prior_xyz = pts.clone()
     t = lambda a, dt=torch.float64: torch.from_numpy(np.ascontiguousarray(a)).to(dev).to(dt)
     pose_prior = (t(poses_true), t(np.tile([0.02, 0.02, 0.02, 0.1, 0.1, 0.1], (C, 1))),

@@ -95,6 +95,9 @@ int mqs_create(int device_id, mqs_ctx **out)
     ctx->dbuf_bytes = 0;
     ctx->hbuf = nullptr;
     ctx->hbuf_bytes = 0;
+    ctx->comm = nullptr;
+    ctx->comm_rank = 0;
+    ctx->comm_world = 1;
     hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         mqs_set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
@@ -110,6 +113,7 @@ void mqs_destroy(mqs_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    mqs_comm_release(ctx);
     if (ctx->dbuf) (void)hipFree(ctx->dbuf);
     if (ctx->hbuf) (void)hipHostFree(ctx->hbuf);
     (void)hipStreamDestroy(ctx->stream);

@@ -1,0 +1,115 @@
+// One Gauss-Newton / fixed-damping iteration of the dense-visibility bundle adjustment behind ONE call:
+//   linearise + on-chip Schur elimination -> finalize -> [sum all-reduce of the reduced camera system over the ranks]
+//   -> reduced solve + pose retraction -> landmark back-substitution,
+// enqueued back to back on the caller's stream with no host round trip and no interpreter between the launches
+// (the optimiser loop of bundle_adjust.cpp:323-324 with the graph of :268-298; kernels in ba.hip, transport in comm.hip).
+// At 125 k landmarks per GPU (BASELINE configs[3], 1e6 landmarks sharded 8-way) the kernels of an iteration take ~50 us:
+// five ctypes calls and a torch.distributed call per iteration would set the iteration time, this call does not.
+#include "mqs_common.h"
+#include <new>
+
+struct mqs_ba_problem {
+    mqs_ctx *ctx;           // may be null (single GPU, no collective)
+    int C;
+    int64_t N;
+    double *poses[2], *points[2];
+    const double *calib, *sigma, *obs, *prior_w, *prior_xyz, *prior_poses, *prior_sigmas;
+    const uint8_t *mask, *prior_mask;
+    double *lin, *dpose, *info;
+    void *ws;
+    int64_t ws_bytes;
+    int cur;                // which of poses[] / points[] holds the current estimate
+};
+
+extern "C" {
+
+int mqs_ba_problem_create(mqs_ctx *ctx, int C, int64_t N, double *poses_a, double *poses_b, const double *calib,
+                          const double *sigma, double *points_a, double *points_b, const double *obs, const uint8_t *mask,
+                          const double *prior_w, const double *prior_xyz, const double *prior_poses,
+                          const double *prior_sigmas, const uint8_t *prior_mask, double *lin, double *dpose, double *info,
+                          void *workspace, int64_t workspace_bytes, mqs_ba_problem **out)
+{
+    MQS_ARG_CHECK(out != nullptr, "out must not be null");
+    *out = nullptr;
+    MQS_ARG_CHECK(C >= 1 && C <= MQS_MAX_CAMS, "1 <= C <= MQS_MAX_CAMS");
+    MQS_ARG_CHECK(N >= 0, "N >= 0");
+    MQS_ARG_CHECK(poses_a && poses_b && poses_a != poses_b && calib && sigma, "poses_a, poses_b (distinct), calib, sigma must not be null");
+    MQS_ARG_CHECK(N == 0 || (points_a && points_b && points_a != points_b && obs), "points_a, points_b (distinct), obs must not be null");
+    MQS_ARG_CHECK(lin && dpose && workspace, "lin, dpose, workspace must not be null");
+    MQS_ARG_CHECK(workspace_bytes >= mqs_ba_workspace_bytes(C, N), "workspace too small (mqs_ba_workspace_bytes)");
+    MQS_ARG_CHECK(!prior_w || prior_xyz, "prior_xyz required with prior_w");
+    MQS_ARG_CHECK(!prior_mask || (prior_poses && prior_sigmas), "prior_poses/prior_sigmas required with prior_mask");
+    MQS_ARG_CHECK(mqs_aligned16(points_a) && mqs_aligned16(points_b) && mqs_aligned16(obs), "device pointers must be 16-byte aligned");
+    mqs_ba_problem *p = new (std::nothrow) mqs_ba_problem();
+    if (!p) {
+        mqs_set_error("out of host memory");
+        return MQS_E_NOMEM;
+    }
+    p->ctx = ctx; p->C = C; p->N = N;
+    p->poses[0] = poses_a; p->poses[1] = poses_b; p->points[0] = points_a; p->points[1] = points_b;
+    p->calib = calib; p->sigma = sigma; p->obs = obs; p->mask = mask; p->prior_w = prior_w; p->prior_xyz = prior_xyz;
+    p->prior_poses = prior_poses; p->prior_sigmas = prior_sigmas; p->prior_mask = prior_mask;
+    p->lin = lin; p->dpose = dpose; p->info = info; p->ws = workspace; p->ws_bytes = workspace_bytes;
+    p->cur = 0;
+    *out = p;
+    return MQS_OK;
+}
+
+void mqs_ba_problem_destroy(mqs_ba_problem *p) { delete p; }
+
+int mqs_ba_problem_current(const mqs_ba_problem *p) { return p ? p->cur : -1; }
+
+int mqs_ba_problem_set_current(mqs_ba_problem *p, int which)
+{
+    MQS_ARG_CHECK(p != nullptr && (which == 0 || which == 1), "which must be 0 or 1");
+    p->cur = which;
+    return MQS_OK;
+}
+
+// first half: linearise the current estimate into `lin` (this rank's partial reduced system)
+int mqs_ba_gn_begin_dev(mqs_ba_problem *p, double lambda, void *stream)
+{
+    MQS_ARG_CHECK(p != nullptr, "problem must not be null");
+    return mqs_ba_linearize_dev(p->poses[p->cur], p->calib, p->sigma, p->C, p->points[p->cur], p->obs, p->mask, p->prior_w,
+                                p->prior_xyz, p->N, lambda, p->lin, p->ws, p->ws_bytes, stream);
+}
+
+// second half (after `lin` holds the sum over ranks): solve + retract into the other pose buffer, back-substitute into the
+// other point buffer.  accept != 0 makes the new estimate current (Gauss-Newton); 0 leaves it as a trial (LM decides).
+int mqs_ba_gn_finish_dev(mqs_ba_problem *p, double lambda, int accept, void *stream)
+{
+    MQS_ARG_CHECK(p != nullptr, "problem must not be null");
+    const int c = p->cur, o = 1 - c;
+    int rc = mqs_ba_solve_dev(p->lin, p->C, p->poses[c], p->prior_poses, p->prior_sigmas, p->prior_mask, lambda, p->dpose,
+                              p->poses[o], p->info, stream);
+    if (rc != MQS_OK) return rc;
+    rc = mqs_ba_backsub_dev(p->poses[c], p->calib, p->sigma, p->C, p->points[c], p->obs, p->mask, p->prior_w, p->prior_xyz,
+                            p->N, lambda, p->dpose, p->points[o], stream);
+    if (rc != MQS_OK) return rc;
+    if (accept) p->cur = o;
+    return MQS_OK;
+}
+
+int mqs_ba_gn_iteration_dev(mqs_ba_problem *p, double lambda, void *stream)
+{
+    int rc = mqs_ba_gn_begin_dev(p, lambda, stream);
+    if (rc != MQS_OK) return rc;
+    if (p->ctx && mqs_comm_world_size(p->ctx) > 1) {
+        rc = mqs_comm_all_reduce_sum_f64_dev(p->ctx, p->lin, (int64_t)36 * p->C * p->C + 6 * p->C + 2, stream);
+        if (rc != MQS_OK) return rc;
+    }
+    return mqs_ba_gn_finish_dev(p, lambda, 1, stream);
+}
+
+// `iters` iterations back to back (the benchmark's and the GN driver's inner loop): still no host synchronisation.
+int mqs_ba_gn_iterations_dev(mqs_ba_problem *p, int iters, double lambda, void *stream)
+{
+    MQS_ARG_CHECK(p != nullptr && iters >= 0, "problem must not be null, iters >= 0");
+    for (int k = 0; k < iters; ++k) {
+        const int rc = mqs_ba_gn_iteration_dev(p, lambda, stream);
+        if (rc != MQS_OK) return rc;
+    }
+    return MQS_OK;
+}
+
+}  // extern "C"

@@ -33,7 +33,12 @@ struct mqs_ctx {
     size_t dbuf_bytes;
     void *hbuf;        // pinned, GPU-visible host buffer for the small-call path (see mqs_stage)
     size_t hbuf_bytes;
+    void *comm;        // RCCL communicator of this rank (comm.hip), or null: one process per GPU, one ctx per process
+    int comm_rank, comm_world;
 };
+
+// comm.hip: releases ctx->comm (called by mqs_destroy)
+void mqs_comm_release(mqs_ctx *ctx);
 
 // Ensures ctx->dbuf holds at least `bytes`; returns MQS_OK or an error code.
 int mqs_ctx_reserve(mqs_ctx *ctx, size_t bytes);

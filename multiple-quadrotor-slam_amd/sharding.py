@@ -74,3 +74,53 @@ def init_from_env(backend="nccl"):
                 torch.cuda.set_device(local_rank)
             dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, local_rank, world
+
+
+class CComm:
+    """The library-level transport: an RCCL communicator held by an `mqs_ctx` (csrc/comm.hip), so that the one collective
+    of the hot path -- the sum of the reduced camera system -- is issued from C between the kernels of an iteration
+    (`mqs_ba_gn_iteration_dev`) instead of from the interpreter.  One per process (one process per GPU)."""
+
+    def __init__(self, ctx, rank, world):
+        self.ctx, self.rank, self.world = ctx, rank, world
+
+    def all_reduce_sum_(self, tensor):
+        """In-place sum over the ranks of a float64 device tensor, asynchronous on the current stream."""
+        import ctypes
+        import torch
+        from . import _lib
+        if tensor.dtype != torch.float64 or not tensor.is_cuda or not tensor.is_contiguous():
+            raise ValueError("all_reduce_sum_ takes a contiguous float64 device tensor")
+        _lib.check(_lib.lib().mqs_comm_all_reduce_sum_f64_dev(
+            self.ctx.handle, ctypes.c_void_p(tensor.data_ptr()), tensor.numel(),
+            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        return tensor
+
+    def close(self):
+        from . import _lib
+        if self.ctx is not None:
+            _lib.check(_lib.lib().mqs_comm_destroy(self.ctx.handle))
+            self.ctx.close()
+            self.ctx = None
+
+
+def init_c_comm(rank, world, device_index):
+    """Creates this rank's library context on `device_index` and joins the RCCL communicator of `world` ranks.  The 128-byte
+    unique id is made on rank 0 and carried to the other ranks by the torch.distributed group that `init_from_env`
+    initialised (any host-side channel would do: the C ABI only sees the bytes).  Collective: every rank must call it."""
+    import ctypes
+    import torch
+    import torch.distributed as dist
+    from . import _lib
+    L = _lib.lib()
+    ident = (ctypes.c_uint8 * 128)()
+    if rank == 0:
+        _lib.check(L.mqs_comm_unique_id(ident))
+    if world > 1:
+        on_gpu = dist.get_backend() == "nccl"
+        t = torch.tensor(list(ident), dtype=torch.uint8, device=torch.device("cuda", device_index) if on_gpu else "cpu")
+        dist.broadcast(t, src=0)
+        ident = (ctypes.c_uint8 * 128)(*t.cpu().tolist())
+    ctx = _lib.Context(device_index)
+    _lib.check(L.mqs_comm_init_rank(ctx.handle, ident, rank, world))
+    return CComm(ctx, rank, world)

@@ -18,8 +18,22 @@ _i32p = ctypes.POINTER(ctypes.c_int32)
 _u8p = ctypes.POINTER(ctypes.c_uint8)
 
 
+def _stale():
+    if not os.path.exists(_SO):
+        return True
+    t = os.path.getmtime(_SO)
+    cdir = os.path.join(_HERE, "c")
+    return any(os.path.getmtime(os.path.join(cdir, f)) > t for f in os.listdir(cdir) if f.endswith((".c", ".h")) or f == "Makefile")
+
+
 def build():
-    subprocess.check_call(["make", "-s", "-C", os.path.join(_HERE, "c")])
+    """Builds liboracle.so when a source is newer than it.  No child process at all when it is up to date; when one is
+    needed it runs without a profiler preload (LD_PRELOAD / ROCP_*): under `rocprofv3 --pmc` every child would otherwise
+    initialise the GPU before exec'ing gcc, which the GPU pool forbids."""
+    if not _stale():
+        return
+    env = {k: v for k, v in os.environ.items() if k != "LD_PRELOAD" and not k.startswith(("ROCP_", "ROCPROF", "ROCPROFILER_"))}
+    subprocess.check_call(["make", "-s", "-C", os.path.join(_HERE, "c")], env=env)
 
 
 def lib():

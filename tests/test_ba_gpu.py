@@ -200,3 +200,58 @@ def test_full_size_properties_1e6x4(gpu):
     hist = ba.optimize(iters=10, mode="gn")
     assert hist[-1] < hist[0] and all(b <= a * (1 + 1e-9) for a, b in zip(hist[1:], hist[2:]))
     assert hist[-1] / (N * C) < 1.0                                  # chi^2 per factor at pixel-noise level
+
+
+def test_one_call_iteration_equals_the_four_launches(gpu):
+    """mqs_ba_gn_iteration_dev (one library call per Gauss-Newton iteration) == linearise, solve, back-substitute issued one
+    by one, bit for bit; mqs_ba_gn_iterations_dev == the same call repeated; the buffer pair alternates."""
+    import torch
+    sc = make_scene(777, 4, seed=3, distortion=True)
+    pp = (sc["poses_true"], np.tile([0.02, 0.02, 0.02, 0.1, 0.1, 0.1], (4, 1)), np.array([1, 0, 0, 0], dtype=np.uint8))
+    a, b, c = adjuster(gpu, sc, pp), adjuster(gpu, sc, pp), adjuster(gpu, sc, pp)
+    for it in range(3):
+        a.gauss_newton_iteration(0.0)
+        assert a._cur == (it + 1) % 2
+        b.linearize(0.0)
+        b.solve(0.0)
+        b.backsub(0.0)
+        b.accept()
+    c.gauss_newton_iterations(3)
+    torch.cuda.synchronize()
+    assert torch.equal(a.poses, b.poses) and torch.equal(a.points, b.points)
+    assert torch.equal(a.poses, c.poses) and torch.equal(a.points, c.points)
+    assert torch.equal(a.lin, b.lin)
+    # the split form with a trial step: nothing becomes current until accepted (Levenberg-Marquardt)
+    L = gpu._lib.lib()
+    sp = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    before = a.poses.clone()
+    gpu._lib.check(L.mqs_ba_gn_begin_dev(a._h, 1e-3, sp))
+    gpu._lib.check(L.mqs_ba_gn_finish_dev(a._h, 1e-3, 0, sp))
+    torch.cuda.synchronize()
+    assert torch.equal(a.poses, before) and not torch.equal(a.poses_new, before)
+
+
+def test_c_abi_communicator_single_rank(gpu):
+    """The library's RCCL communicator (mqs_comm_*) with one rank: the all-reduce is the identity, and a BundleAdjuster bound
+    to it runs the one-call iteration with the collective issued from C (the N-rank case needs N GPUs: bench.py --gpus N)."""
+    import torch
+    cc = gpu.sharding.init_c_comm(0, 1, 0)
+    try:
+        assert gpu._lib.lib().mqs_comm_world_size(cc.ctx.handle) == 1
+        t = torch.arange(602, dtype=torch.float64, device="cuda")
+        cc.all_reduce_sum_(t)
+        torch.cuda.synchronize()
+        assert torch.equal(t, torch.arange(602, dtype=torch.float64, device="cuda"))
+        with pytest.raises(ValueError):
+            cc.all_reduce_sum_(t.float())
+        sc = make_scene(300, 3, seed=8)
+        d = to_dev(sc)
+        ba = gpu.bundle_adjustment.BundleAdjuster(process_group=cc, **d)
+        ref = adjuster(gpu, sc)
+        ba.gauss_newton_iterations(2)
+        ref.gauss_newton_iterations(2)
+        torch.cuda.synchronize()
+        assert torch.equal(ba.poses, ref.poses) and torch.equal(ba.points, ref.points)
+        assert ba.total_cost() == ref.total_cost()
+    finally:
+        cc.close()
