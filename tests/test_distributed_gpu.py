@@ -129,8 +129,8 @@ def test_bench_contract_single_gpu(gpu):
     assert out["value"] > 0 and out["ms_per_step"] > 0 and "workload" in out["config"]
     rf = out["roofline"]
     assert rf["bound"] in ("hbm", "mfma", "fp64_valu") and rf["unit"] in ("GB/s", "TFLOP/s") and rf["peak"] > 0
-    assert rf["frac"] == pytest.approx(rf["achieved"] / rf["peak"], rel=1e-3) and rf["achieved"] > 0
-    assert rf["hbm"]["peak"] == 8000.0 and rf["hbm"]["frac"] == pytest.approx(rf["hbm"]["achieved"] / 8000.0, rel=1e-3)
+    assert rf["frac"] == pytest.approx(rf["achieved"] / rf["peak"], rel=1e-2) and rf["achieved"] > 0     # both are rounded
+    assert rf["hbm"]["peak"] == 8000.0 and rf["hbm"]["frac"] == pytest.approx(rf["hbm"]["achieved"] / 8000.0, rel=1e-2)
     cb = out["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and cb["unit"] == "landmarks/s" and "sample" in cb
     assert cb["parity"]["rel_err_p99.9"] < 1e-5 and cb["parity"]["status_mismatch_frac"] < 0.005
