@@ -277,6 +277,14 @@ int mqs_ba_gn_finish_dev(mqs_ba_problem *p, double lambda, int accept, void *str
 int mqs_ba_gn_iteration_dev(mqs_ba_problem *p, double lambda, void *stream);
 int mqs_ba_gn_iterations_dev(mqs_ba_problem *p, int iters, double lambda, void *stream);
 
+/* Timing helper used by bench.py: average duration (ms) of `reps` back-to-back launches of ONE kernel of the iteration,
+ * hipEvents on `stream` (what: 0 = the lineariser kernel alone, 1 = its finalize kernel alone, 2 = solve + retract,
+ * 3 = back-substitution).  Buffers as for the calls above; lin must hold a linearisation for what = 2. */
+int mqs_ba_time_dev(int what, const double *poses, const double *calib, const double *sigma, int C, const double *points,
+                    const double *obs, const uint8_t *mask, const double *prior_w, const double *prior_xyz, int64_t N,
+                    double lambda, double *lin, double *dpose, double *poses_out, double *points_out, void *workspace,
+                    int64_t workspace_bytes, int reps, void *stream, float *avg_ms);
+
 /* Host-pointer convenience wrappers (copy in, run, copy out; synchronous). */
 int mqs_ba_linearize(mqs_ctx *ctx, const double *poses, const double *calib, const double *sigma, int C,
                      const double *points, const double *obs, const uint8_t *mask,

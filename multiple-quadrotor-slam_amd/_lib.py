@@ -78,6 +78,9 @@ SIGNATURES = {
                                         c_f64p, c_i64, ctypes.c_double, c_f64p]),
     "mqs_ba_backsub": (ctypes.c_int, [c_vp, c_f64p, c_f64p, c_f64p, ctypes.c_int, c_f64p, c_f64p, c_u8p, c_f64p,
                                       c_f64p, c_i64, ctypes.c_double, c_f64p, c_f64p]),
+    "mqs_ba_time_dev": (ctypes.c_int, [ctypes.c_int, c_vp, c_vp, c_vp, ctypes.c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64,
+                                       ctypes.c_double, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, ctypes.c_int, c_vp,
+                                       ctypes.POINTER(ctypes.c_float)]),
     "mqs_comm_unique_id": (ctypes.c_int, [c_u8p]),
     "mqs_comm_init_rank": (ctypes.c_int, [c_vp, c_u8p, ctypes.c_int, ctypes.c_int]),
     "mqs_comm_world_size": (ctypes.c_int, [c_vp]),

@@ -302,6 +302,17 @@ class BundleAdjuster:
         return hist
 
     # ---- benchmark helpers (bench.py) --------------------------------------------------
+    def time_kernel(self, what, reps=20, lam=0.0):
+        """Average launch duration (ms) of one kernel of the iteration, hipEvents on the current stream:
+        what = "linearize" (the kernel alone), "finalize", "solve", "backsub".  The estimate is not advanced."""
+        code = {"linearize": 0, "finalize": 1, "solve": 2, "backsub": 3}[what]
+        ms = ctypes.c_float(0.0)
+        _lib.check(_lib.lib().mqs_ba_time_dev(
+            code, _p(self.poses), _p(self.calib), _p(self.sigma), self.C, _p(self.points), _p(self.obs), _p(self.mask),
+            _p(self.prior_w), _p(self.prior_xyz), self.N, float(lam), _p(self.lin), _p(self.dpose), _p(self.poses_new),
+            _p(self.points_new), _p(self.ws), self.ws.numel(), int(reps), _sp(), ctypes.byref(ms)))
+        return float(ms.value)
+
     def benchmark_report(self, world, dist):
         torch = _torch()
         reps = 10
@@ -335,14 +346,18 @@ class BundleAdjuster:
         c1 = self.total_cost()
         C, N = self.C, self.N
         ms_lin = timed(lambda: self.linearize(0.0))
-        ms_solve = timed(lambda: self.solve(0.0))
-        ms_back = timed(lambda: self.backsub(0.0))
+        ms_lin_k = self.time_kernel("linearize")
+        ms_fin_k = self.time_kernel("finalize")
+        self.linearize(0.0)
+        ms_solve = self.time_kernel("solve")
+        ms_back = self.time_kernel("backsub")
         ms_ar = timed(self.all_reduce) if dist is not None else 0.0
         bytes_iter = N * (2 * (24 + 16 * C) + 24)
         return {
             "gn_iters_per_s": round(reps / dt, 1), "ms_per_iter": round(1e3 * dt / reps, 4),
             "landmarks_total": N * world, "cameras": C, "iterations_timed": reps,
-            "kernels_ms": {"linearize_schur": round(ms_lin, 4), "solve_retract": round(ms_solve, 4),
+            "kernels_ms": {"linearize_schur": round(ms_lin, 4), "linearize_kernel_only": round(ms_lin_k, 5),
+                           "finalize_kernel_only": round(ms_fin_k, 5), "solve_retract": round(ms_solve, 4),
                            "backsub": round(ms_back, 4), "all_reduce": round(ms_ar, 4)},
             "algorithmic_GBps_per_gpu": round(bytes_iter / (1e-3 * (ms_lin + ms_back)) / 1e9, 1),
             "cost_before": c0, "cost_after_%d_more_iterations" % reps: c1,

@@ -26,6 +26,7 @@
 // +8 with priors); the kernel is bound by fp64 VALU issue, not by HBM.
 #include "mqs_common.h"
 #include "ba_math.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -265,6 +266,461 @@ __global__ __launch_bounds__(kBlock, 2) void ba_linearize_kernel(
 #pragma unroll
         for (int w = 0; w < kWaves; ++w) t += sAcc[k * kBlock + w * 64 + 2 * j];
         partials[(int64_t)blockIdx.x * (NCH * 32) + s] = t;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Wave-level lineariser (C <= 4): up to three landmarks per lane share every window reduction.
+//
+// What the one-landmark-per-lane kernel above spends (ISA histogram, profiles/r02): of ~3 960 vector issue slots per landmark
+// ~1 940 are the cross-lane reduction of its 11 windows (v_permlane*_swap issues in two passes), i.e. half of a kernel that
+// is bound by vector issue.  A window is a sum over landmarks, so nothing forces one reduction per landmark: here a lane
+// walks L landmarks through each window, ADDING their contributions in the window registers (the add rides in the last FMA
+// of every entry, so it is free), and the wave reduces once -- 1 940 / L slots per landmark.
+//   * one workgroup of four waves per CU, one wave per SIMD (256 VGPRs + accumulator registers), so that the workgroup
+//     owns the CU's LDS: what a landmark needs again in a later window lives in its lane's LDS column (six doubles per
+//     (landmark, camera): F = E^T E and f = E^T e between the two passes, then Uh = F PR L^-T for the off-diagonal windows);
+//     only x, y, Z of each factor stay in registers;
+//   * windows follow the blocks: one 32-entry window per camera (21 + 6 entries; cost and count ride in camera 0's), and
+//     per camera pair a 32-entry window plus a 4-entry one (36 = 32 + 4), so that no block straddles a window and no
+//     window is open while another one fills;
+//   * a wave owns a contiguous range of 64-landmark rows and walks it in chunks of three rows; nothing is shared between
+//     waves until the end, so there is no barrier inside the loop; the next chunk's cache lines are requested (L2 warm-up
+//     loads that nobody waits for) while the off-diagonal windows of the current one are computed.
+// Results: same formulas as landmark_contribution (ba_math.h), sums in a different, still fixed, order -- bitwise
+// reproducible run to run.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kWaveLinMaxL = 3;
+
+// sum over the 64 lanes of 4 values per lane: lane l ends with the total of v[l >> 4]
+__device__ __forceinline__ double wave_reduce4(double (&v)[4], int lane)
+{
+    (void)lane;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { swap32(v[i], v[i + 2]); v[i] += v[i + 2]; }
+    swap16(v[0], v[1]);
+    v[0] += v[1];
+    double t = v[0];
+    t += xor_lane<8>(t);
+    t += xor_lane<4>(t);
+    t += xor_lane<2>(t);
+    t += xor_lane<1>(t);
+    return t;
+}
+
+template <bool FIRST>
+__device__ __forceinline__ void wl_acc2(double &dst, double a, double b, double c, double d)
+{
+    dst = FIRST ? fma(a, b, c * d) : fma(a, b, fma(c, d, dst));
+}
+template <bool FIRST>
+__device__ __forceinline__ void wl_sub(double &dst, double t) { dst = FIRST ? -t : dst - t; }
+
+struct WlJg { double a00, a01, a02, a10, a11, a12, x, y; };   // JgA of ba_math.h, five multiplies
+__device__ __forceinline__ WlJg wl_make_jg(double x, double y, double Z)
+{
+    WlJg j;
+    const double zx = Z * x, zy = Z * y;
+    j.a00 = zx * y;  j.a01 = -fma(zx, x, Z); j.a02 = zy;
+    j.a10 = fma(zy, y, Z); j.a11 = -j.a00;   j.a12 = -zx;
+    j.x = x; j.y = y;
+    return j;
+}
+
+// entry (i, jj) of Jg^T T added to dst; T = k Jg(d) given by its 2 x 6 entries (columns 3, 4 are -k)
+template <bool FIRST, int I>
+__device__ __forceinline__ void wl_entry(double &dst, const WlJg &j, double t0, double t1)
+{
+    if (I == 0) wl_acc2<FIRST>(dst, j.a00, t0, j.a10, t1);
+    else if (I == 1) wl_acc2<FIRST>(dst, j.a01, t0, j.a11, t1);
+    else if (I == 2) wl_acc2<FIRST>(dst, j.a02, t0, j.a12, t1);
+    else if (I == 3) wl_sub<FIRST>(dst, t0);
+    else if (I == 4) wl_sub<FIRST>(dst, t1);
+    else wl_acc2<FIRST>(dst, j.x, t0, j.y, t1);
+}
+
+__device__ __forceinline__ void wl_k_times_jg(double k00, double k01, double k10, double k11, const WlJg &j, double (&T0)[6],
+                                              double (&T1)[6])
+{
+    T0[0] = fma(k00, j.a00, k01 * j.a10); T0[1] = fma(k00, j.a01, k01 * j.a11); T0[2] = fma(k00, j.a02, k01 * j.a12);
+    T1[0] = fma(k10, j.a00, k11 * j.a10); T1[1] = fma(k10, j.a01, k11 * j.a11); T1[2] = fma(k10, j.a02, k11 * j.a12);
+    T0[3] = -k00; T0[4] = -k01; T0[5] = fma(k00, j.x, k01 * j.y);
+    T1[3] = -k10; T1[4] = -k11; T1[5] = fma(k10, j.x, k11 * j.y);
+}
+
+// the lane's LDS column: element e (a double2) of this thread at st[e * kBlock]
+struct WlStash {
+    double2 *st;
+    __device__ __forceinline__ void put(int slot, int k, double a, double b) const { st[(slot * 3 + k) * kBlock] = make_double2(a, b); }
+    __device__ __forceinline__ double2 get(int slot, int k) const { return st[(slot * 3 + k) * kBlock]; }
+};
+
+// A load nobody waits for: requests the line for the next chunk (it ends in the L2 / the vector cache) while there is still
+// half of the off-diagonal work to do.  The data goes to a dummy LDS word of this wave through the LDS-DMA path, so there is
+// no destination register that a late return could clobber and nothing the compiler has to track: m0 <- LDS offset, then
+// global_load_lds_dword.  (A plain load into a scratch VGPR is NOT safe here: the register allocator may reuse or move
+// the register while the load is still in flight.)
+#ifndef MQS_WL_TOUCH
+#define MQS_WL_TOUCH 0
+#endif
+__device__ __forceinline__ void wl_touch(const void *p, unsigned lds_off)
+{
+#if MQS_WL_TOUCH
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(p), "s"(lds_off) : "memory", "m0");
+#else
+    (void)p; (void)lds_off;
+#endif
+}
+
+// A double that lives in two accumulation registers (a0..a255: at one wave per SIMD a wave owns 256 of them beside its 256
+// vector registers).  VALU instructions cannot read them, so a value costs one v_accvgpr_read/write per half and access:
+// the place for what is touched rarely -- x, y, Z of every factor (read once per window) and the window totals.  The
+// compiler allocates and tracks them through the "a" constraint; left to itself it spilled ~1 200 halves per chunk there.
+struct AReg { int lo, hi; };
+__device__ __forceinline__ void a_put(AReg &r, double v)
+{
+    asm("v_accvgpr_write_b32 %0, %1" : "=a"(r.lo) : "v"(__double2loint(v)));
+    asm("v_accvgpr_write_b32 %0, %1" : "=a"(r.hi) : "v"(__double2hiint(v)));
+}
+__device__ __forceinline__ double a_get(const AReg &r)
+{
+    int lo, hi;
+    asm("v_accvgpr_read_b32 %0, %1" : "=v"(lo) : "a"(r.lo));
+    asm("v_accvgpr_read_b32 %0, %1" : "=v"(hi) : "a"(r.hi));
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ void a_add(AReg &r, double v) { a_put(r, a_get(r) + v); }
+
+// make_factor of ba_math.h with ONE select where that one has sixteen: an unused factor (masked, or behind its camera) gets
+// the scale 0, which makes E, F and f exact zeros, and its x, y, Z -- finite by construction: a point behind the camera is
+// divided by 1 -- then only ever multiply zeros downstream (Uh = F PR L^-T = 0, k = 0, T = 0).  u, v must be finite.
+__device__ __forceinline__ Factor wl_make_factor(const double *cam, double px, double py, double pz, double u, double v, bool seen)
+{
+    Factor o;
+    const double dx = px - cam[9], dy = py - cam[10], dz = pz - cam[11];
+    const double X = fma(cam[0], dx, fma(cam[3], dy, cam[6] * dz));
+    const double Y = fma(cam[1], dx, fma(cam[4], dy, cam[7] * dz));
+    const double Z = fma(cam[2], dx, fma(cam[5], dy, cam[8] * dz));
+    const bool front = Z > 0.0;
+    const double iz = mqs::rcp(front ? Z : 1.0);
+    const double x = X * iz, y = Y * iz;
+    const double fx = cam[12], fy = cam[13], sk = cam[14], u0 = cam[15], v0 = cam[16];
+    const double k1 = cam[17], k2 = cam[18], p1 = cam[19], p2 = cam[20], isig = cam[21];
+    const double xx = x * x, yy = y * y, xy = x * y;
+    const double r2 = xx + yy;
+    const double g = fma(r2, fma(k2, r2, k1), 1.0);
+    const double dg = fma(2.0 * k2, r2, k1);
+    const double xd = fma(g, x, fma(2.0 * p1, xy, p2 * fma(2.0, xx, r2)));
+    const double yd = fma(g, y, fma(2.0 * p2, xy, p1 * fma(2.0, yy, r2)));
+    const double eu = (fma(fx, xd, fma(sk, yd, u0)) - u) * isig;
+    const double ev = (fma(fy, yd, v0) - v) * isig;
+    const double a = fma(2.0 * xx, dg, g) + 2.0 * p1 * y + 6.0 * p2 * x;
+    const double b = fma(2.0 * xy, dg, 2.0 * p1 * x) + 2.0 * p2 * y;
+    const double d = fma(2.0 * yy, dg, g) + 2.0 * p2 * x + 6.0 * p1 * y;
+    const bool ok = seen && front;
+    const double sc = ok ? isig * iz : 0.0;
+    const double E00 = fma(fx, a, sk * b) * sc, E01 = fma(fx, b, sk * d) * sc;
+    const double E10 = fy * b * sc, E11 = fy * d * sc;
+    o.x = x; o.y = y; o.Z = front ? Z : 1.0;
+    o.F00 = fma(E00, E00, E10 * E10);
+    o.F01 = fma(E00, E01, E10 * E11);
+    o.F11 = fma(E01, E01, E11 * E11);
+    o.f0 = fma(E00, eu, E10 * ev);
+    o.f1 = fma(E01, eu, E11 * ev);
+    const double ce = cam[22];
+    o.half_e2 = seen ? (front ? 0.5 * fma(eu, eu, ev * ev) : ce * ce) : 0.0;
+    o.valid = ok;
+    return o;
+}
+
+// Makes a value materialise HERE: without it the compiler sinks the landmark-block sums of pass A (and every product that
+// feeds them: 4 cameras x 3 landmarks x 15 doubles) down to their first use after the loop and parks them in between.
+__device__ __forceinline__ void wl_pin(double &x) { asm volatile("" : "+v"(x)); }
+
+template <int C, int L>
+__device__ __forceinline__ void wl_chunk(const double *sCam, const WlStash stash, const double *__restrict__ points,
+                                         const double2 *__restrict__ obs2, const uint8_t *__restrict__ mask,
+                                         const double *__restrict__ prior_w, const double *__restrict__ prior_xyz, int64_t N,
+                                         double lambda, int64_t row0, int64_t next_row0, int lane, AReg (&acc)[C * C],
+                                         unsigned touch_lds)
+{
+    double px[L], py[L], pz[L];
+    bool live[L];
+    int64_t idx[L];
+    PointSystem ps[L];
+    double cost = 0.0, count = 0.0;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        const int64_t i = (row0 + l) * 64 + lane;
+        live[l] = i < N;
+        idx[l] = live[l] ? i : 0;
+        px[l] = points[3 * idx[l] + 0]; py[l] = points[3 * idx[l] + 1]; pz[l] = points[3 * idx[l] + 2];
+    }
+    double2 ob[2][L];                       // this camera's and the next one's measurements
+#pragma unroll
+    for (int l = 0; l < L; ++l) ob[0][l] = obs2[idx[l]];
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        // PriorFactor<Point3>: enters the landmark block at its start (H = w I, g = -w (p - p0)), so nothing of it stays live
+        double pw = 0.0, ddx = 0.0, ddy = 0.0, ddz = 0.0;
+        if (prior_w) {
+            const double w = prior_w[idx[l]];
+            if (live[l] && w > 0.0) {
+                pw = w;
+                ddx = px[l] - prior_xyz[3 * idx[l] + 0];
+                ddy = py[l] - prior_xyz[3 * idx[l] + 1];
+                ddz = pz[l] - prior_xyz[3 * idx[l] + 2];
+            }
+        }
+        ps[l].H = mqs::Sym3{pw, 0, 0, pw, 0, pw};
+        ps[l].g = mqs::Vec3{-pw * ddx, -pw * ddy, -pw * ddz};
+        cost += 0.5 * pw * fma(ddx, ddx, fma(ddy, ddy, ddz * ddz));
+    }
+
+    // ---- pass A: every factor once; landmark blocks; F, f parked in LDS; x, y, Z kept ----
+    AReg X[L][C], Y[L][C], Z[L][C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const double *cam = sCam + kCamStride * c;
+        if (c + 1 < C) {
+#pragma unroll
+            for (int l = 0; l < L; ++l) ob[(c + 1) & 1][l] = obs2[(int64_t)(c + 1) * N + idx[l]];
+        }
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            const bool seen = live[l] && (mask ? mask[(int64_t)c * N + idx[l]] != 0 : true);
+            // a masked slot may hold NaN: selects, not products
+            const double u = seen ? ob[c & 1][l].x : 0.0, v = seen ? ob[c & 1][l].y : 0.0;
+            const Factor fc = wl_make_factor(cam, px[l], py[l], pz[l], u, v, seen);
+            double PR[2][3];
+            make_PR(cam, fc.x, fc.y, PR);
+            point_add_factor(ps[l], fc, PR);
+            a_put(X[l][c], fc.x); a_put(Y[l][c], fc.y); a_put(Z[l][c], fc.Z);
+            stash.put(l * C + c, 0, fc.F00, fc.F01);
+            stash.put(l * C + c, 1, fc.F11, fc.f0);
+            stash.put(l * C + c, 2, fc.f1, 0.0);
+            cost += fc.half_e2;
+            count += fc.valid ? 1.0 : 0.0;
+            wl_pin(ps[l].H.xx); wl_pin(ps[l].H.xy); wl_pin(ps[l].H.xz); wl_pin(ps[l].H.yy); wl_pin(ps[l].H.yz); wl_pin(ps[l].H.zz);
+            wl_pin(ps[l].g.x); wl_pin(ps[l].g.y); wl_pin(ps[l].g.z);
+            wl_pin(cost); wl_pin(count);
+            MQS_SCHED_FENCE();
+        }
+    }
+    asm volatile("; MQS_MARK pass_a_done");
+    double w0[L], w1[L], w2[L];
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        point_finish(ps[l], 0.0, 0.0, 0.0, 0.0, lambda);
+        if (!ps[l].ok) { ps[l].i00 = 0.0; ps[l].i11 = 0.0; ps[l].i22 = 0.0; }      // unconstrained: Uh = 0, w = 0
+        w0[l] = ps[l].g.x * ps[l].i00;
+        w1[l] = fma(-ps[l].l10, w0[l], ps[l].g.y) * ps[l].i11;
+        w2[l] = fma(-ps[l].l21, w1[l], fma(-ps[l].l20, w0[l], ps[l].g.z)) * ps[l].i22;
+    }
+
+    // ---- diagonal blocks and gradient: one window per camera ----
+    asm volatile("; MQS_MARK finish_done");
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const double *cam = sCam + kCamStride * c;
+        double buf[32];
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            const double2 s0 = stash.get(l * C + c, 0), s1 = stash.get(l * C + c, 1), s2 = stash.get(l * C + c, 2);
+            const double F00 = s0.x, F01 = s0.y, F11 = s1.x, f0 = s1.y, f1 = s2.x;
+            const double xc = a_get(X[l][c]), yc = a_get(Y[l][c]), zc = a_get(Z[l][c]);
+            double PR[2][3];
+            make_PR(cam, xc, yc, PR);
+            double U[2][3];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const double Fa = r ? F01 : F00, Fb = r ? F11 : F01;
+                double u0 = fma(Fa, PR[0][0], Fb * PR[1][0]);
+                double u1 = fma(Fa, PR[0][1], Fb * PR[1][1]);
+                double u2 = fma(Fa, PR[0][2], Fb * PR[1][2]);
+                apply_LinvT(ps[l], u0, u1, u2);
+                U[r][0] = u0; U[r][1] = u1; U[r][2] = u2;
+            }
+            stash.put(l * C + c, 0, U[0][0], U[0][1]);
+            stash.put(l * C + c, 1, U[0][2], U[1][0]);
+            stash.put(l * C + c, 2, U[1][1], U[1][2]);
+            const double k00 = F00 - fma(U[0][0], U[0][0], fma(U[0][1], U[0][1], U[0][2] * U[0][2]));
+            const double k01 = F01 - fma(U[0][0], U[1][0], fma(U[0][1], U[1][1], U[0][2] * U[1][2]));
+            const double k11 = F11 - fma(U[1][0], U[1][0], fma(U[1][1], U[1][1], U[1][2] * U[1][2]));
+            const double rh0 = -f0 - fma(U[0][0], w0[l], fma(U[0][1], w1[l], U[0][2] * w2[l]));
+            const double rh1 = -f1 - fma(U[1][0], w0[l], fma(U[1][1], w1[l], U[1][2] * w2[l]));
+            const WlJg jg = wl_make_jg(xc, yc, zc);
+            double T0[6], T1[6];
+            wl_k_times_jg(k00, k01, k01, k11, jg, T0, T1);
+#define MQS_WL_DIAG(FIRST)                                                                                         \
+    {                                                                                                              \
+        wl_entry<FIRST, 0>(buf[0], jg, T0[0], T1[0]); wl_entry<FIRST, 0>(buf[1], jg, T0[1], T1[1]);               \
+        wl_entry<FIRST, 0>(buf[2], jg, T0[2], T1[2]); wl_entry<FIRST, 0>(buf[3], jg, T0[3], T1[3]);               \
+        wl_entry<FIRST, 0>(buf[4], jg, T0[4], T1[4]); wl_entry<FIRST, 0>(buf[5], jg, T0[5], T1[5]);               \
+        wl_entry<FIRST, 1>(buf[6], jg, T0[1], T1[1]); wl_entry<FIRST, 1>(buf[7], jg, T0[2], T1[2]);               \
+        wl_entry<FIRST, 1>(buf[8], jg, T0[3], T1[3]); wl_entry<FIRST, 1>(buf[9], jg, T0[4], T1[4]);               \
+        wl_entry<FIRST, 1>(buf[10], jg, T0[5], T1[5]);                                                            \
+        wl_entry<FIRST, 2>(buf[11], jg, T0[2], T1[2]); wl_entry<FIRST, 2>(buf[12], jg, T0[3], T1[3]);             \
+        wl_entry<FIRST, 2>(buf[13], jg, T0[4], T1[4]); wl_entry<FIRST, 2>(buf[14], jg, T0[5], T1[5]);             \
+        wl_entry<FIRST, 3>(buf[15], jg, T0[3], T1[3]); wl_entry<FIRST, 3>(buf[16], jg, T0[4], T1[4]);             \
+        wl_entry<FIRST, 3>(buf[17], jg, T0[5], T1[5]);                                                            \
+        wl_entry<FIRST, 4>(buf[18], jg, T0[4], T1[4]); wl_entry<FIRST, 4>(buf[19], jg, T0[5], T1[5]);             \
+        wl_entry<FIRST, 5>(buf[20], jg, T0[5], T1[5]);                                                            \
+        wl_entry<FIRST, 0>(buf[21], jg, rh0, rh1); wl_entry<FIRST, 1>(buf[22], jg, rh0, rh1);                     \
+        wl_entry<FIRST, 2>(buf[23], jg, rh0, rh1); wl_entry<FIRST, 3>(buf[24], jg, rh0, rh1);                     \
+        wl_entry<FIRST, 4>(buf[25], jg, rh0, rh1); wl_entry<FIRST, 5>(buf[26], jg, rh0, rh1);                     \
+    }
+            if (l == 0) MQS_WL_DIAG(true) else MQS_WL_DIAG(false)
+#undef MQS_WL_DIAG
+            MQS_SCHED_FENCE();
+        }
+        asm volatile("; MQS_MARK diag_entries_done");
+        buf[27] = (c == 0) ? cost : 0.0;
+        buf[28] = (c == 0) ? count : 0.0;
+        buf[29] = 0.0; buf[30] = 0.0; buf[31] = 0.0;
+        a_add(acc[c], wave_reduce32(buf, lane));
+        MQS_SCHED_FENCE();
+    }
+
+    // ---- off-diagonal blocks S_cd = -Jg_c^T (Uh_c Uh_d^T) Jg_d: a 32-entry and a 4-entry window per pair ----
+    int pair = 0;
+    asm volatile("; MQS_MARK diag_done");
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+#pragma unroll
+        for (int d = c + 1; d < C; ++d) {
+            double buf[32], b4[4];
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                const double2 a0 = stash.get(l * C + c, 0), a1 = stash.get(l * C + c, 1), a2 = stash.get(l * C + c, 2);
+                const double2 e0 = stash.get(l * C + d, 0), e1 = stash.get(l * C + d, 1), e2 = stash.get(l * C + d, 2);
+                // Uc = [[a0.x a0.y a1.x],[a1.y a2.x a2.y]], Ud likewise
+                const double k00 = -fma(a0.x, e0.x, fma(a0.y, e0.y, a1.x * e1.x));
+                const double k01 = -fma(a0.x, e1.y, fma(a0.y, e2.x, a1.x * e2.y));
+                const double k10 = -fma(a1.y, e0.x, fma(a2.x, e0.y, a2.y * e1.x));
+                const double k11 = -fma(a1.y, e1.y, fma(a2.x, e2.x, a2.y * e2.y));
+                const WlJg jd = wl_make_jg(a_get(X[l][d]), a_get(Y[l][d]), a_get(Z[l][d]));
+                double T0[6], T1[6];
+                wl_k_times_jg(k00, k01, k10, k11, jd, T0, T1);
+                const WlJg jc = wl_make_jg(a_get(X[l][c]), a_get(Y[l][c]), a_get(Z[l][c]));
+#define MQS_WL_ROW(FIRST, I, B)                                                                                    \
+    wl_entry<FIRST, I>(B[0], jc, T0[0], T1[0]); wl_entry<FIRST, I>(B[1], jc, T0[1], T1[1]);                       \
+    wl_entry<FIRST, I>(B[2], jc, T0[2], T1[2]); wl_entry<FIRST, I>(B[3], jc, T0[3], T1[3]);                       \
+    wl_entry<FIRST, I>(B[4], jc, T0[4], T1[4]); wl_entry<FIRST, I>(B[5], jc, T0[5], T1[5]);
+#define MQS_WL_PAIR(FIRST)                                                                                         \
+    {                                                                                                              \
+        double *r0 = buf, *r1 = buf + 6, *r2 = buf + 12, *r3 = buf + 18, *r4 = buf + 24;                           \
+        MQS_WL_ROW(FIRST, 0, r0) MQS_WL_ROW(FIRST, 1, r1) MQS_WL_ROW(FIRST, 2, r2) MQS_WL_ROW(FIRST, 3, r3)        \
+        MQS_WL_ROW(FIRST, 4, r4)                                                                                   \
+        wl_entry<FIRST, 5>(buf[30], jc, T0[0], T1[0]); wl_entry<FIRST, 5>(buf[31], jc, T0[1], T1[1]);             \
+        wl_entry<FIRST, 5>(b4[0], jc, T0[2], T1[2]); wl_entry<FIRST, 5>(b4[1], jc, T0[3], T1[3]);                 \
+        wl_entry<FIRST, 5>(b4[2], jc, T0[4], T1[4]); wl_entry<FIRST, 5>(b4[3], jc, T0[5], T1[5]);                 \
+    }
+                if (l == 0) MQS_WL_PAIR(true) else MQS_WL_PAIR(false)
+#undef MQS_WL_PAIR
+#undef MQS_WL_ROW
+                MQS_SCHED_FENCE();
+            }
+            asm volatile("; MQS_MARK pair_entries_done");
+            a_add(acc[C + 2 * pair], wave_reduce32(buf, lane));
+            a_add(acc[C + 2 * pair + 1], wave_reduce4(b4, lane));
+            asm volatile("; MQS_MARK pair_reduced");
+            ++pair;
+            if (pair == (C * (C - 1) / 2 + 1) / 2 && next_row0 >= 0) {
+                // half of the off-diagonal work is still ahead: request the next chunk's lines now
+#pragma unroll
+                for (int l = 0; l < kWaveLinMaxL; ++l) {
+                    int64_t i = (next_row0 + l) * 64 + lane;
+                    if (i >= N) i = N - 1;
+                    wl_touch(points + 3 * i, touch_lds);
+                    wl_touch(points + 3 * i + 2, touch_lds);
+#pragma unroll
+                    for (int cc = 0; cc < C; ++cc) wl_touch(obs2 + (int64_t)cc * N + i, touch_lds);
+                    if (prior_w) wl_touch(prior_w + i, touch_lds);
+                }
+            }
+            MQS_SCHED_FENCE();
+        }
+    }
+}
+
+template <int C>
+__global__ __launch_bounds__(kBlock, 1) void ba_linearize_wave_kernel(
+    const double *__restrict__ poses, const double *__restrict__ calib, const double *__restrict__ sigma,
+    const double *__restrict__ points, const double *__restrict__ obs, const uint8_t *__restrict__ mask,
+    const double *__restrict__ prior_w, const double *__restrict__ prior_xyz, int64_t N, double lambda,
+    double *__restrict__ partials)
+{
+    using L = Layout<C>;
+    constexpr int NCH = L::kChunks;
+    constexpr int kRow = NCH * 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char wl_smem[];
+    double *sCam = reinterpret_cast<double *>(wl_smem);                                   // C * 24 doubles (<= 768 B)
+    double2 *sStash = reinterpret_cast<double2 *>(wl_smem + 1024);                         // [kWaveLinMaxL * C * 3][kBlock]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    stage_cams<C>(poses, calib, sigma, sCam, tid);
+
+    AReg acc[C * C];
+#pragma unroll
+    for (int k = 0; k < C * C; ++k) a_put(acc[k], 0.0);
+
+    // contiguous rows of 64 landmarks per wave, walked in chunks of up to kWaveLinMaxL rows
+    const int64_t rows = (N + 63) / 64;
+    const int64_t nw = (int64_t)gridDim.x * kWaves, gw = (int64_t)blockIdx.x * kWaves + wave;
+    const int64_t r_begin = rows * gw / nw, r_end = rows * (gw + 1) / nw;
+    const WlStash stash = {sStash + tid};
+    const double2 *obs2 = reinterpret_cast<const double2 *>(obs);
+    // dummy LDS words of this wave for the warm-up loads (never read): behind the stash
+    const unsigned touch_lds = (unsigned)__builtin_amdgcn_readfirstlane(
+        (int)(1024u + (unsigned)(kWaveLinMaxL * C * 3 * kBlock * sizeof(double2)) + (unsigned)wave * 256u));
+    for (int64_t r = r_begin; r < r_end;) {
+        const int64_t left = r_end - r;
+        const int nl = left >= kWaveLinMaxL ? kWaveLinMaxL : (int)left;
+        const int64_t nxt = (r + nl < r_end) ? r + nl : -1;
+#if defined(MQS_WL_ONLY_L3)      // ISA counting only (tools/isa_mix.py --define MQS_WL_ONLY_L3): one body in the listing
+        wl_chunk<C, 3>(sCam, stash, points, obs2, mask, prior_w, prior_xyz, N, lambda, r, nxt, lane, acc, touch_lds);
+#else
+        if (nl == 3) wl_chunk<C, 3>(sCam, stash, points, obs2, mask, prior_w, prior_xyz, N, lambda, r, nxt, lane, acc, touch_lds);
+        else if (nl == 2) wl_chunk<C, 2>(sCam, stash, points, obs2, mask, prior_w, prior_xyz, N, lambda, r, nxt, lane, acc, touch_lds);
+        else wl_chunk<C, 1>(sCam, stash, points, obs2, mask, prior_w, prior_xyz, N, lambda, r, nxt, lane, acc, touch_lds);
+#endif
+        r += nl;
+    }
+    // waves -> workgroup -> this workgroup's row of partials, in the slot numbering of Layout<C> (so that
+    // ba_finalize_kernel serves both linearisers)
+    __syncthreads();                                                  // every wave is done with its stash
+    double *sRed = reinterpret_cast<double *>(wl_smem + 1024);        // [kWaves][kRow]
+    for (int s = tid; s < kWaves * kRow; s += kBlock) sRed[s] = 0.0;
+    __syncthreads();
+    double *mine = sRed + wave * kRow;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        if ((lane & 1) == 0) {
+            const int j = lane >> 1;
+            const double t = a_get(acc[c]);
+            if (j < L::kDiagUsed) mine[L::diag_off(c) + j] = t;
+            else if (c == 0 && j == 27) mine[L::kCost] = t;
+            else if (c == 0 && j == 28) mine[L::kCount] = t;
+        }
+    }
+    {
+        int pair = 0;
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+#pragma unroll
+            for (int d = c + 1; d < C; ++d) {
+                if ((lane & 1) == 0) mine[L::pair_off(c, d) + (lane >> 1)] = a_get(acc[C + 2 * pair]);
+                if ((lane & 15) == 0) mine[L::pair_off(c, d) + 32 + (lane >> 4)] = a_get(acc[C + 2 * pair + 1]);
+                ++pair;
+            }
+    }
+    __syncthreads();
+    for (int s = tid; s < kRow; s += kBlock) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) t += sRed[w * kRow + s];
+        partials[(int64_t)blockIdx.x * kRow + s] = t;
     }
 }
 
@@ -583,6 +1039,17 @@ int64_t ws_doubles_rt(int C)
     return 0;
 }
 
+// A/B switch for measurements: MQS_BA_LINEARIZER=lane selects the one-landmark-per-lane kernel for every C
+bool wave_lineariser_enabled()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("MQS_BA_LINEARIZER");
+        v = (e && strcmp(e, "lane") == 0) ? 0 : 1;
+    }
+    return v == 1;
+}
+
 int check_common(const double *poses, const double *calib, const double *sigma, int C, const double *points,
                  const double *obs, int64_t N)
 {
@@ -605,9 +1072,24 @@ int64_t mqs_ba_workspace_bytes(int C, int64_t N)
     return ws_doubles_rt(C) * 8;
 }
 
+// parts: bit 0 = the lineariser kernel, bit 1 = the finalize kernel (mqs_ba_time_dev times them one by one)
+static int ba_linearize_parts(const double *poses, const double *calib, const double *sigma, int C, const double *points,
+                              const double *obs, const uint8_t *mask, const double *prior_w, const double *prior_xyz,
+                              int64_t N, double lambda, double *out, void *workspace, int64_t workspace_bytes, void *stream_,
+                              int parts);
+
 int mqs_ba_linearize_dev(const double *poses, const double *calib, const double *sigma, int C, const double *points,
                          const double *obs, const uint8_t *mask, const double *prior_w, const double *prior_xyz,
                          int64_t N, double lambda, double *out, void *workspace, int64_t workspace_bytes, void *stream_)
+{
+    return ba_linearize_parts(poses, calib, sigma, C, points, obs, mask, prior_w, prior_xyz, N, lambda, out, workspace,
+                              workspace_bytes, stream_, 3);
+}
+
+static int ba_linearize_parts(const double *poses, const double *calib, const double *sigma, int C, const double *points,
+                              const double *obs, const uint8_t *mask, const double *prior_w, const double *prior_xyz,
+                              int64_t N, double lambda, double *out, void *workspace, int64_t workspace_bytes, void *stream_,
+                              int parts)
 {
     int rc = check_common(poses, calib, sigma, C, points, obs, N);
     if (rc != MQS_OK) return rc;
@@ -615,14 +1097,47 @@ int mqs_ba_linearize_dev(const double *poses, const double *calib, const double 
     MQS_ARG_CHECK(workspace_bytes >= mqs_ba_workspace_bytes(C, N), "workspace too small (mqs_ba_workspace_bytes)");
     MQS_ARG_CHECK(!prior_w || prior_xyz, "prior_xyz required with prior_w");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    const int grid = ba_grid(N);
     double *partials = static_cast<double *>(workspace);
+    if (C >= 2 && C <= 4 && wave_lineariser_enabled()) {
+        // one workgroup per CU (its LDS holds the lanes' columns), as many as there are 64-landmark rows to hand out
+        const int64_t rows = (N + 63) / 64;
+        int grid = (int)((rows + kWaves - 1) / kWaves);
+        if (grid < 1) grid = 1;
+        if (grid > 256) grid = 256;
+        const size_t lds = 1024 + (size_t)kWaveLinMaxL * C * 3 * kBlock * sizeof(double2) + kWaves * 256;
+        switch (C) {
+#define MQS_CASE(c)                                                                                        \
+    case c: {                                                                                              \
+        static bool opt_in[64] = {};                    /* per device: dynamic LDS above 64 KiB needs the opt-in */ \
+        int dev = 0;                                                                                       \
+        MQS_HIP_CHECK(hipGetDevice(&dev));                                                                 \
+        if (dev < 0 || dev >= 64 || !opt_in[dev]) {                                                        \
+            MQS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ba_linearize_wave_kernel<c>), \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      \
+            if (dev >= 0 && dev < 64) opt_in[dev] = true;                                                  \
+        }                                                                                                  \
+        if (parts & 1)                                                                                     \
+            hipLaunchKernelGGL((ba_linearize_wave_kernel<c>), dim3(grid), dim3(kBlock), lds, stream, poses, calib, sigma, \
+                               points, obs, mask, prior_w, prior_xyz, N, lambda, partials);                \
+        if (parts & 2)                                                                                     \
+            hipLaunchKernelGGL((ba_finalize_kernel<c>), dim3((Layout<c>::kChunks * 32 + 63) / 64), dim3(kFinThreads), 0, stream, partials, grid, out);   \
+        break;                                                                                             \
+    }
+            MQS_CASE(2) MQS_CASE(3) MQS_CASE(4)
+#undef MQS_CASE
+        }
+        MQS_HIP_CHECK(hipGetLastError());
+        return MQS_OK;
+    }
+    const int grid = ba_grid(N);
     switch (C) {
 #define MQS_CASE(c)                                                                                        \
     case c:                                                                                                \
-        hipLaunchKernelGGL((ba_linearize_kernel<c>), dim3(grid), dim3(kBlock), 0, stream, poses, calib, sigma, \
-                           points, obs, mask, prior_w, prior_xyz, N, lambda, partials);                    \
-        hipLaunchKernelGGL((ba_finalize_kernel<c>), dim3((Layout<c>::kChunks * 32 + 63) / 64), dim3(kFinThreads), 0, stream, partials, grid, out);   \
+        if (parts & 1)                                                                                     \
+            hipLaunchKernelGGL((ba_linearize_kernel<c>), dim3(grid), dim3(kBlock), 0, stream, poses, calib, sigma, \
+                               points, obs, mask, prior_w, prior_xyz, N, lambda, partials);                \
+        if (parts & 2)                                                                                     \
+            hipLaunchKernelGGL((ba_finalize_kernel<c>), dim3((Layout<c>::kChunks * 32 + 63) / 64), dim3(kFinThreads), 0, stream, partials, grid, out);   \
         break;
         MQS_CASE(1) MQS_CASE(2) MQS_CASE(3) MQS_CASE(4) MQS_CASE(5) MQS_CASE(6) MQS_CASE(7) MQS_CASE(8)
 #undef MQS_CASE
@@ -702,6 +1217,42 @@ int mqs_ba_solve_dev(const double *lin, int C, const double *poses, const double
     }
     MQS_HIP_CHECK(hipGetLastError());
     return MQS_OK;
+}
+
+// Average duration (ms) of `reps` back-to-back launches of ONE kernel of the iteration, hipEvents on `stream`
+// (what: 0 lineariser kernel alone, 1 finalize alone, 2 solve + retract, 3 back-substitution).
+int mqs_ba_time_dev(int what, const double *poses, const double *calib, const double *sigma, int C, const double *points,
+                    const double *obs, const uint8_t *mask, const double *prior_w, const double *prior_xyz, int64_t N,
+                    double lambda, double *lin, double *dpose, double *poses_out, double *points_out, void *workspace,
+                    int64_t workspace_bytes, int reps, void *stream_, float *avg_ms)
+{
+    MQS_ARG_CHECK(what >= 0 && what <= 3 && reps >= 1 && avg_ms != nullptr, "what in 0..3, reps >= 1, avg_ms must not be null");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    auto once = [&]() -> int {
+        switch (what) {
+        case 0: case 1:
+            return ba_linearize_parts(poses, calib, sigma, C, points, obs, mask, prior_w, prior_xyz, N, lambda, lin, workspace,
+                                      workspace_bytes, stream_, what == 0 ? 1 : 2);
+        case 2: return mqs_ba_solve_dev(lin, C, poses, nullptr, nullptr, nullptr, lambda, dpose, poses_out, nullptr, stream_);
+        default: return mqs_ba_backsub_dev(poses, calib, sigma, C, points, obs, mask, prior_w, prior_xyz, N, lambda, dpose,
+                                           points_out, stream_);
+        }
+    };
+    int rc = once();                                  // warm-up (and the argument checks)
+    if (rc != MQS_OK) return rc;
+    hipEvent_t e0, e1;
+    MQS_HIP_CHECK(hipEventCreate(&e0));
+    MQS_HIP_CHECK(hipEventCreate(&e1));
+    MQS_HIP_CHECK(hipEventRecord(e0, stream));
+    for (int k = 0; k < reps && rc == MQS_OK; ++k) rc = once();
+    MQS_HIP_CHECK(hipEventRecord(e1, stream));
+    MQS_HIP_CHECK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    MQS_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *avg_ms = ms / reps;
+    return rc;
 }
 
 }  // extern "C"

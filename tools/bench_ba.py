@@ -17,6 +17,7 @@ def timed(fn, reps=10):
 out = {"lib": os.path.basename(mqslam_amd._lib.LIB_PATH), "N": N, "C": C}
 for rnd in range(2):
     out.setdefault("linearize_us", []).append(timed(lambda: ba.linearize(0.0)))
+    out.setdefault("linearize_kernel_only_us", []).append(round(1e3 * ba.time_kernel("linearize"), 1))
     out.setdefault("solve_us", []).append(timed(lambda: ba.solve(0.0)))
     out.setdefault("backsub_us", []).append(timed(lambda: ba.backsub(0.0)))
     out.setdefault("cost_us", []).append(timed(lambda: ba.cost()))
