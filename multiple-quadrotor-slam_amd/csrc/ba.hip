@@ -348,29 +348,22 @@ __device__ __forceinline__ void wl_k_times_jg(double k00, double k01, double k10
     T1[3] = -k10; T1[4] = -k11; T1[5] = fma(k10, j.x, k11 * j.y);
 }
 
+// camera pair number p (order (0,1), (0,2), .., (1,2), ..) -> its cameras
+template <int C> __device__ __forceinline__ constexpr int wl_pair_c(int p)
+{
+    return C == 4 ? (p < 3 ? 0 : (p < 5 ? 1 : 2)) : (C == 3 ? (p < 2 ? 0 : 1) : 0);
+}
+template <int C> __device__ __forceinline__ constexpr int wl_pair_d(int p)
+{
+    return C == 4 ? (p < 3 ? p + 1 : (p < 5 ? p - 1 : 3)) : (C == 3 ? (p < 2 ? p + 1 : 2) : 1);
+}
+
 // the lane's LDS column: element e (a double2) of this thread at st[e * kBlock]
 struct WlStash {
     double2 *st;
     __device__ __forceinline__ void put(int slot, int k, double a, double b) const { st[(slot * 3 + k) * kBlock] = make_double2(a, b); }
     __device__ __forceinline__ double2 get(int slot, int k) const { return st[(slot * 3 + k) * kBlock]; }
 };
-
-// A load nobody waits for: requests the line for the next chunk (it ends in the L2 / the vector cache) while there is still
-// half of the off-diagonal work to do.  The data goes to a dummy LDS word of this wave through the LDS-DMA path, so there is
-// no destination register that a late return could clobber and nothing the compiler has to track: m0 <- LDS offset, then
-// global_load_lds_dword.  (A plain load into a scratch VGPR is NOT safe here: the register allocator may reuse or move
-// the register while the load is still in flight.)
-#ifndef MQS_WL_TOUCH
-#define MQS_WL_TOUCH 0
-#endif
-__device__ __forceinline__ void wl_touch(const void *p, unsigned lds_off)
-{
-#if MQS_WL_TOUCH
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(p), "s"(lds_off) : "memory", "m0");
-#else
-    (void)p; (void)lds_off;
-#endif
-}
 
 // A double that lives in two accumulation registers (a0..a255: at one wave per SIMD a wave owns 256 of them beside its 256
 // vector registers).  VALU instructions cannot read them, so a value costs one v_accvgpr_read/write per half and access:
@@ -390,6 +383,58 @@ __device__ __forceinline__ double a_get(const AReg &r)
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ void a_add(AReg &r, double v) { a_put(r, a_get(r) + v); }
+
+// The inputs of a wave's NEXT chunk (points, measurements, prior weights of up to kWaveLinMaxL rows), loaded straight into
+// accumulation registers while the off-diagonal windows of the current chunk are computed: on gfx950 a global load may
+// name AGPRs as its destination, so the ~2 us of HBM latency that a wave alone on its SIMD cannot hide costs no vector
+// register and no LDS.  The compiler does not know these loads are in flight (inline asm), which is safe because
+//   * nothing reads the destination registers before wl_stage_wait, whose "+a" operands make every later use depend on it,
+//   * loads return in order, so the compiler's own vmcnt bookkeeping for ITS loads stays conservative, never short.
+typedef int wl_i2 __attribute__((ext_vector_type(2)));
+typedef int wl_i4 __attribute__((ext_vector_type(4)));
+template <int C>
+struct WlStage {
+    wl_i2 p[kWaveLinMaxL][3];
+    wl_i4 o[C][kWaveLinMaxL];
+    wl_i2 w[kWaveLinMaxL];
+};
+
+template <int C>
+__device__ __forceinline__ void wl_stage_issue(WlStage<C> &st, const double *__restrict__ points, const double2 *__restrict__ obs2,
+                                               const double *__restrict__ prior_w, int64_t N, int64_t row0, int lane)
+{
+#pragma unroll
+    for (int l = 0; l < kWaveLinMaxL; ++l) {
+        int64_t i = (row0 + l) * 64 + lane;
+        i = i < N ? i : N - 1;                     // rows past the end re-read the last landmark (ignored by the consumer)
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            asm volatile("global_load_dwordx2 %0, %1, off" : "=a"(st.p[l][k]) : "v"(points + 3 * i + k));
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(st.o[c][l]) : "v"(obs2 + (int64_t)c * N + i));
+        const double *pw = prior_w ? prior_w + i : points + 3 * i;          // no prior array: any valid word, never used
+        asm volatile("global_load_dwordx2 %0, %1, off" : "=a"(st.w[l]) : "v"(pw));
+    }
+}
+
+template <int C>
+__device__ __forceinline__ void wl_stage_wait(WlStage<C> &st)
+{
+#pragma unroll
+    for (int l = 0; l < kWaveLinMaxL; ++l) {
+        if (C == 4)
+            asm volatile("s_waitcnt vmcnt(0)" : "+a"(st.p[l][0]), "+a"(st.p[l][1]), "+a"(st.p[l][2]), "+a"(st.w[l]),
+                         "+a"(st.o[0][l]), "+a"(st.o[C > 1 ? 1 : 0][l]), "+a"(st.o[C > 2 ? 2 : 0][l]), "+a"(st.o[C > 3 ? 3 : 0][l]));
+        else if (C == 3)
+            asm volatile("s_waitcnt vmcnt(0)" : "+a"(st.p[l][0]), "+a"(st.p[l][1]), "+a"(st.p[l][2]), "+a"(st.w[l]),
+                         "+a"(st.o[0][l]), "+a"(st.o[C > 1 ? 1 : 0][l]), "+a"(st.o[C > 2 ? 2 : 0][l]));
+        else
+            asm volatile("s_waitcnt vmcnt(0)" : "+a"(st.p[l][0]), "+a"(st.p[l][1]), "+a"(st.p[l][2]), "+a"(st.w[l]),
+                         "+a"(st.o[0][l]), "+a"(st.o[C > 1 ? 1 : 0][l]));
+    }
+}
+__device__ __forceinline__ double wl_dbl(wl_i2 v) { return __hiloint2double(v.y, v.x); }
 
 // make_factor of ba_math.h with ONE select where that one has sixteen: an unused factor (masked, or behind its camera) gets
 // the scale 0, which makes E, F and f exact zeros, and its x, y, Z -- finite by construction: a point behind the camera is
@@ -441,9 +486,10 @@ template <int C, int L>
 __device__ __forceinline__ void wl_chunk(const double *sCam, const WlStash stash, const double *__restrict__ points,
                                          const double2 *__restrict__ obs2, const uint8_t *__restrict__ mask,
                                          const double *__restrict__ prior_w, const double *__restrict__ prior_xyz, int64_t N,
-                                         double lambda, int64_t row0, int64_t next_row0, int lane, AReg (&acc)[C * C],
-                                         unsigned touch_lds)
+                                         double lambda, int64_t row0, int64_t next_row0, int lane, double *tot,
+                                         WlStage<C> &st)
 {
+    using LT = Layout<C>;
     double px[L], py[L], pz[L];
     bool live[L];
     int64_t idx[L];
@@ -454,17 +500,14 @@ __device__ __forceinline__ void wl_chunk(const double *sCam, const WlStash stash
         const int64_t i = (row0 + l) * 64 + lane;
         live[l] = i < N;
         idx[l] = live[l] ? i : 0;
-        px[l] = points[3 * idx[l] + 0]; py[l] = points[3 * idx[l] + 1]; pz[l] = points[3 * idx[l] + 2];
+        px[l] = wl_dbl(st.p[l][0]); py[l] = wl_dbl(st.p[l][1]); pz[l] = wl_dbl(st.p[l][2]);
     }
-    double2 ob[2][L];                       // this camera's and the next one's measurements
-#pragma unroll
-    for (int l = 0; l < L; ++l) ob[0][l] = obs2[idx[l]];
 #pragma unroll
     for (int l = 0; l < L; ++l) {
         // PriorFactor<Point3>: enters the landmark block at its start (H = w I, g = -w (p - p0)), so nothing of it stays live
         double pw = 0.0, ddx = 0.0, ddy = 0.0, ddz = 0.0;
         if (prior_w) {
-            const double w = prior_w[idx[l]];
+            const double w = wl_dbl(st.w[l]);
             if (live[l] && w > 0.0) {
                 pw = w;
                 ddx = px[l] - prior_xyz[3 * idx[l] + 0];
@@ -482,15 +525,12 @@ __device__ __forceinline__ void wl_chunk(const double *sCam, const WlStash stash
 #pragma unroll
     for (int c = 0; c < C; ++c) {
         const double *cam = sCam + kCamStride * c;
-        if (c + 1 < C) {
-#pragma unroll
-            for (int l = 0; l < L; ++l) ob[(c + 1) & 1][l] = obs2[(int64_t)(c + 1) * N + idx[l]];
-        }
 #pragma unroll
         for (int l = 0; l < L; ++l) {
             const bool seen = live[l] && (mask ? mask[(int64_t)c * N + idx[l]] != 0 : true);
             // a masked slot may hold NaN: selects, not products
-            const double u = seen ? ob[c & 1][l].x : 0.0, v = seen ? ob[c & 1][l].y : 0.0;
+            const wl_i4 o4 = st.o[c][l];
+            const double u = seen ? __hiloint2double(o4.y, o4.x) : 0.0, v = seen ? __hiloint2double(o4.w, o4.z) : 0.0;
             const Factor fc = wl_make_factor(cam, px[l], py[l], pz[l], u, v, seen);
             double PR[2][3];
             make_PR(cam, fc.x, fc.y, PR);
@@ -508,6 +548,10 @@ __device__ __forceinline__ void wl_chunk(const double *sCam, const WlStash stash
         }
     }
     asm volatile("; MQS_MARK pass_a_done");
+    // This chunk's inputs are consumed: request the next chunk's now, with the whole second pass ahead to cover the latency.
+    // They are waited for at the END of this chunk, so that no in-flight register is ever carried over the loop's back
+    // edge, where the compiler may insert register-to-register copies.
+    if (next_row0 >= 0) wl_stage_issue<C>(st, points, obs2, prior_w, N, next_row0, lane);
     double w0[L], w1[L], w2[L];
 #pragma unroll
     for (int l = 0; l < L; ++l) {
@@ -520,13 +564,24 @@ __device__ __forceinline__ void wl_chunk(const double *sCam, const WlStash stash
 
     // ---- diagonal blocks and gradient: one window per camera ----
     asm volatile("; MQS_MARK finish_done");
+    // A wave alone on its SIMD hides no LDS latency by itself: every block's stash reads are issued one block ahead
+    // (double-buffered in registers), so that they land while the previous block's arithmetic issues.
+    double2 dq[2][3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) dq[0][k] = stash.get(0, k);
 #pragma unroll
     for (int c = 0; c < C; ++c) {
         const double *cam = sCam + kCamStride * c;
         double buf[32];
 #pragma unroll
         for (int l = 0; l < L; ++l) {
-            const double2 s0 = stash.get(l * C + c, 0), s1 = stash.get(l * C + c, 1), s2 = stash.get(l * C + c, 2);
+            const int step = c * L + l, cur = step & 1;
+            if (step + 1 < C * L) {
+                const int nl = (l + 1 < L) ? l + 1 : 0, nc = (l + 1 < L) ? c : c + 1;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) dq[cur ^ 1][k] = stash.get(nl * C + nc, k);
+            }
+            const double2 s0 = dq[cur][0], s1 = dq[cur][1], s2 = dq[cur][2];
             const double F00 = s0.x, F01 = s0.y, F11 = s1.x, f0 = s1.y, f1 = s2.x;
             const double xc = a_get(X[l][c]), yc = a_get(Y[l][c]), zc = a_get(Z[l][c]);
             double PR[2][3];
@@ -578,22 +633,40 @@ __device__ __forceinline__ void wl_chunk(const double *sCam, const WlStash stash
         buf[27] = (c == 0) ? cost : 0.0;
         buf[28] = (c == 0) ? count : 0.0;
         buf[29] = 0.0; buf[30] = 0.0; buf[31] = 0.0;
-        a_add(acc[c], wave_reduce32(buf, lane));
+        {
+            // window total -> this wave's row of totals in LDS (Layout<C> numbering; lanes 2j and 2j+1 hold entry j); the old
+            // total is read before the reduction so that its latency hides under it
+            const int j = lane >> 1;
+            const int slot = (j < LT::kDiagUsed) ? LT::diag_off(c) + j : ((c == 0 && j == 27) ? LT::kCost : ((c == 0 && j == 28) ? LT::kCount : LT::kCount + 1));
+            const double old = tot[slot];                            // kCount + 1: a spare word of the row
+            const double t = wave_reduce32(buf, lane);
+            if ((lane & 1) == 0) tot[slot] = old + t;
+        }
         MQS_SCHED_FENCE();
     }
 
     // ---- off-diagonal blocks S_cd = -Jg_c^T (Uh_c Uh_d^T) Jg_d: a 32-entry and a 4-entry window per pair ----
-    int pair = 0;
     asm volatile("; MQS_MARK diag_done");
+    constexpr int NP = C * (C - 1) / 2;
+    double2 pq[2][6];
 #pragma unroll
-    for (int c = 0; c < C; ++c) {
+    for (int k = 0; k < 3; ++k) { pq[0][k] = stash.get(0, k); pq[0][3 + k] = stash.get(1, k); }      // pair (0, 1), landmark 0
 #pragma unroll
-        for (int d = c + 1; d < C; ++d) {
+    for (int pair = 0; pair < NP; ++pair) {
+        {
+            const int c = wl_pair_c<C>(pair), d = wl_pair_d<C>(pair);
             double buf[32], b4[4];
 #pragma unroll
             for (int l = 0; l < L; ++l) {
-                const double2 a0 = stash.get(l * C + c, 0), a1 = stash.get(l * C + c, 1), a2 = stash.get(l * C + c, 2);
-                const double2 e0 = stash.get(l * C + d, 0), e1 = stash.get(l * C + d, 1), e2 = stash.get(l * C + d, 2);
+                const int step = pair * L + l, cur = step & 1;
+                if (step + 1 < NP * L) {
+                    const int nl = (l + 1 < L) ? l + 1 : 0, np = (l + 1 < L) ? pair : pair + 1;
+                    const int nc = wl_pair_c<C>(np), nd = wl_pair_d<C>(np);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) { pq[cur ^ 1][k] = stash.get(nl * C + nc, k); pq[cur ^ 1][3 + k] = stash.get(nl * C + nd, k); }
+                }
+                const double2 a0 = pq[cur][0], a1 = pq[cur][1], a2 = pq[cur][2];
+                const double2 e0 = pq[cur][3], e1 = pq[cur][4], e2 = pq[cur][5];
                 // Uc = [[a0.x a0.y a1.x],[a1.y a2.x a2.y]], Ud likewise
                 const double k00 = -fma(a0.x, e0.x, fma(a0.y, e0.y, a1.x * e1.x));
                 const double k01 = -fma(a0.x, e1.y, fma(a0.y, e2.x, a1.x * e2.y));
@@ -622,26 +695,17 @@ __device__ __forceinline__ void wl_chunk(const double *sCam, const WlStash stash
                 MQS_SCHED_FENCE();
             }
             asm volatile("; MQS_MARK pair_entries_done");
-            a_add(acc[C + 2 * pair], wave_reduce32(buf, lane));
-            a_add(acc[C + 2 * pair + 1], wave_reduce4(b4, lane));
-            asm volatile("; MQS_MARK pair_reduced");
-            ++pair;
-            if (pair == (C * (C - 1) / 2 + 1) / 2 && next_row0 >= 0) {
-                // half of the off-diagonal work is still ahead: request the next chunk's lines now
-#pragma unroll
-                for (int l = 0; l < kWaveLinMaxL; ++l) {
-                    int64_t i = (next_row0 + l) * 64 + lane;
-                    if (i >= N) i = N - 1;
-                    wl_touch(points + 3 * i, touch_lds);
-                    wl_touch(points + 3 * i + 2, touch_lds);
-#pragma unroll
-                    for (int cc = 0; cc < C; ++cc) wl_touch(obs2 + (int64_t)cc * N + i, touch_lds);
-                    if (prior_w) wl_touch(prior_w + i, touch_lds);
-                }
+            {
+                const double old32 = tot[LT::pair_off(c, d) + (lane >> 1)], old4 = tot[LT::pair_off(c, d) + 32 + (lane >> 4)];
+                const double t32 = wave_reduce32(buf, lane), t4 = wave_reduce4(b4, lane);
+                if ((lane & 1) == 0) tot[LT::pair_off(c, d) + (lane >> 1)] = old32 + t32;
+                if ((lane & 15) == 0) tot[LT::pair_off(c, d) + 32 + (lane >> 4)] = old4 + t4;
             }
+            asm volatile("; MQS_MARK pair_reduced");
             MQS_SCHED_FENCE();
         }
     }
+    if (next_row0 >= 0) wl_stage_wait<C>(st);
 }
 
 template <int C>
@@ -654,16 +718,20 @@ __global__ __launch_bounds__(kBlock, 1) void ba_linearize_wave_kernel(
     using L = Layout<C>;
     constexpr int NCH = L::kChunks;
     constexpr int kRow = NCH * 32;
+    // the camera blocks are a separate (static) LDS object: the compiler then knows that a stash write cannot change them
+    // and keeps a camera's constants in registers over its three landmarks instead of re-reading them after every write
+    __shared__ double sCam[C * kCamStride];
     extern __shared__ __attribute__((aligned(16))) unsigned char wl_smem[];
-    double *sCam = reinterpret_cast<double *>(wl_smem);                                   // C * 24 doubles (<= 768 B)
-    double2 *sStash = reinterpret_cast<double2 *>(wl_smem + 1024);                         // [kWaveLinMaxL * C * 3][kBlock]
+    double2 *sStash = reinterpret_cast<double2 *>(wl_smem);                                // [kWaveLinMaxL * C * 3][kBlock]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     stage_cams<C>(poses, calib, sigma, sCam, tid);
 
-    AReg acc[C * C];
-#pragma unroll
-    for (int k = 0; k < C * C; ++k) a_put(acc[k], 0.0);
+    // window totals of this wave: a row in Layout<C> numbering behind the stash (entry j of a window lives in lanes 2j, 2j+1)
+    double *sTot = reinterpret_cast<double *>(wl_smem + sizeof(double2) * kWaveLinMaxL * C * 3 * kBlock);   // [kWaves][kRow]
+    double *tot = sTot + wave * kRow;
+    for (int k = lane; k < kRow; k += 64) tot[k] = 0.0;
+    mqs_wave_lds_sync();
 
     // contiguous rows of 64 landmarks per wave, walked in chunks of up to kWaveLinMaxL rows
     const int64_t rows = (N + 63) / 64;
@@ -671,55 +739,28 @@ __global__ __launch_bounds__(kBlock, 1) void ba_linearize_wave_kernel(
     const int64_t r_begin = rows * gw / nw, r_end = rows * (gw + 1) / nw;
     const WlStash stash = {sStash + tid};
     const double2 *obs2 = reinterpret_cast<const double2 *>(obs);
-    // dummy LDS words of this wave for the warm-up loads (never read): behind the stash
-    const unsigned touch_lds = (unsigned)__builtin_amdgcn_readfirstlane(
-        (int)(1024u + (unsigned)(kWaveLinMaxL * C * 3 * kBlock * sizeof(double2)) + (unsigned)wave * 256u));
+    WlStage<C> st;
+    wl_stage_issue<C>(st, points, obs2, prior_w, N, r_begin < r_end ? r_begin : 0, lane);
+    wl_stage_wait<C>(st);
     for (int64_t r = r_begin; r < r_end;) {
         const int64_t left = r_end - r;
         const int nl = left >= kWaveLinMaxL ? kWaveLinMaxL : (int)left;
         const int64_t nxt = (r + nl < r_end) ? r + nl : -1;
 #if defined(MQS_WL_ONLY_L3)      // ISA counting only (tools/isa_mix.py --define MQS_WL_ONLY_L3): one body in the listing
-        wl_chunk<C, 3>(sCam, stash, points, obs2, mask, prior_w, prior_xyz, N, lambda, r, nxt, lane, acc, touch_lds);
+        wl_chunk<C, 3>(sCam, stash, points, obs2, mask, prior_w, prior_xyz, N, lambda, r, nxt, lane, tot, st);
 #else
-        if (nl == 3) wl_chunk<C, 3>(sCam, stash, points, obs2, mask, prior_w, prior_xyz, N, lambda, r, nxt, lane, acc, touch_lds);
-        else if (nl == 2) wl_chunk<C, 2>(sCam, stash, points, obs2, mask, prior_w, prior_xyz, N, lambda, r, nxt, lane, acc, touch_lds);
-        else wl_chunk<C, 1>(sCam, stash, points, obs2, mask, prior_w, prior_xyz, N, lambda, r, nxt, lane, acc, touch_lds);
+        if (nl == 3) wl_chunk<C, 3>(sCam, stash, points, obs2, mask, prior_w, prior_xyz, N, lambda, r, nxt, lane, tot, st);
+        else if (nl == 2) wl_chunk<C, 2>(sCam, stash, points, obs2, mask, prior_w, prior_xyz, N, lambda, r, nxt, lane, tot, st);
+        else wl_chunk<C, 1>(sCam, stash, points, obs2, mask, prior_w, prior_xyz, N, lambda, r, nxt, lane, tot, st);
 #endif
         r += nl;
     }
-    // waves -> workgroup -> this workgroup's row of partials, in the slot numbering of Layout<C> (so that
-    // ba_finalize_kernel serves both linearisers)
-    __syncthreads();                                                  // every wave is done with its stash
-    double *sRed = reinterpret_cast<double *>(wl_smem + 1024);        // [kWaves][kRow]
-    for (int s = tid; s < kWaves * kRow; s += kBlock) sRed[s] = 0.0;
-    __syncthreads();
-    double *mine = sRed + wave * kRow;
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-        if ((lane & 1) == 0) {
-            const int j = lane >> 1;
-            const double t = a_get(acc[c]);
-            if (j < L::kDiagUsed) mine[L::diag_off(c) + j] = t;
-            else if (c == 0 && j == 27) mine[L::kCost] = t;
-            else if (c == 0 && j == 28) mine[L::kCount] = t;
-        }
-    }
-    {
-        int pair = 0;
-#pragma unroll
-        for (int c = 0; c < C; ++c)
-#pragma unroll
-            for (int d = c + 1; d < C; ++d) {
-                if ((lane & 1) == 0) mine[L::pair_off(c, d) + (lane >> 1)] = a_get(acc[C + 2 * pair]);
-                if ((lane & 15) == 0) mine[L::pair_off(c, d) + 32 + (lane >> 4)] = a_get(acc[C + 2 * pair + 1]);
-                ++pair;
-            }
-    }
+    // waves -> workgroup -> this workgroup's row of partials (Layout<C> numbering: ba_finalize_kernel serves both linearisers)
     __syncthreads();
     for (int s = tid; s < kRow; s += kBlock) {
         double t = 0.0;
 #pragma unroll
-        for (int w = 0; w < kWaves; ++w) t += sRed[w * kRow + s];
+        for (int w = 0; w < kWaves; ++w) t += sTot[w * kRow + s];
         partials[(int64_t)blockIdx.x * kRow + s] = t;
     }
 }
@@ -1104,7 +1145,7 @@ static int ba_linearize_parts(const double *poses, const double *calib, const do
         int grid = (int)((rows + kWaves - 1) / kWaves);
         if (grid < 1) grid = 1;
         if (grid > 256) grid = 256;
-        const size_t lds = 1024 + (size_t)kWaveLinMaxL * C * 3 * kBlock * sizeof(double2) + kWaves * 256;
+        const size_t lds = (size_t)kWaveLinMaxL * C * 3 * kBlock * sizeof(double2) + (size_t)kWaves * 352 * sizeof(double);   // 352 = Layout<4>'s row, the largest here
         switch (C) {
 #define MQS_CASE(c)                                                                                        \
     case c: {                                                                                              \
