@@ -384,58 +384,6 @@ __device__ __forceinline__ double a_get(const AReg &r)
 }
 __device__ __forceinline__ void a_add(AReg &r, double v) { a_put(r, a_get(r) + v); }
 
-// The inputs of a wave's NEXT chunk (points, measurements, prior weights of up to kWaveLinMaxL rows), loaded straight into
-// accumulation registers while the off-diagonal windows of the current chunk are computed: on gfx950 a global load may
-// name AGPRs as its destination, so the ~2 us of HBM latency that a wave alone on its SIMD cannot hide costs no vector
-// register and no LDS.  The compiler does not know these loads are in flight (inline asm), which is safe because
-//   * nothing reads the destination registers before wl_stage_wait, whose "+a" operands make every later use depend on it,
-//   * loads return in order, so the compiler's own vmcnt bookkeeping for ITS loads stays conservative, never short.
-typedef int wl_i2 __attribute__((ext_vector_type(2)));
-typedef int wl_i4 __attribute__((ext_vector_type(4)));
-template <int C>
-struct WlStage {
-    wl_i2 p[kWaveLinMaxL][3];
-    wl_i4 o[C][kWaveLinMaxL];
-    wl_i2 w[kWaveLinMaxL];
-};
-
-template <int C>
-__device__ __forceinline__ void wl_stage_issue(WlStage<C> &st, const double *__restrict__ points, const double2 *__restrict__ obs2,
-                                               const double *__restrict__ prior_w, int64_t N, int64_t row0, int lane)
-{
-#pragma unroll
-    for (int l = 0; l < kWaveLinMaxL; ++l) {
-        int64_t i = (row0 + l) * 64 + lane;
-        i = i < N ? i : N - 1;                     // rows past the end re-read the last landmark (ignored by the consumer)
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-            asm volatile("global_load_dwordx2 %0, %1, off" : "=a"(st.p[l][k]) : "v"(points + 3 * i + k));
-#pragma unroll
-        for (int c = 0; c < C; ++c)
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(st.o[c][l]) : "v"(obs2 + (int64_t)c * N + i));
-        const double *pw = prior_w ? prior_w + i : points + 3 * i;          // no prior array: any valid word, never used
-        asm volatile("global_load_dwordx2 %0, %1, off" : "=a"(st.w[l]) : "v"(pw));
-    }
-}
-
-template <int C>
-__device__ __forceinline__ void wl_stage_wait(WlStage<C> &st)
-{
-#pragma unroll
-    for (int l = 0; l < kWaveLinMaxL; ++l) {
-        if (C == 4)
-            asm volatile("s_waitcnt vmcnt(0)" : "+a"(st.p[l][0]), "+a"(st.p[l][1]), "+a"(st.p[l][2]), "+a"(st.w[l]),
-                         "+a"(st.o[0][l]), "+a"(st.o[C > 1 ? 1 : 0][l]), "+a"(st.o[C > 2 ? 2 : 0][l]), "+a"(st.o[C > 3 ? 3 : 0][l]));
-        else if (C == 3)
-            asm volatile("s_waitcnt vmcnt(0)" : "+a"(st.p[l][0]), "+a"(st.p[l][1]), "+a"(st.p[l][2]), "+a"(st.w[l]),
-                         "+a"(st.o[0][l]), "+a"(st.o[C > 1 ? 1 : 0][l]), "+a"(st.o[C > 2 ? 2 : 0][l]));
-        else
-            asm volatile("s_waitcnt vmcnt(0)" : "+a"(st.p[l][0]), "+a"(st.p[l][1]), "+a"(st.p[l][2]), "+a"(st.w[l]),
-                         "+a"(st.o[0][l]), "+a"(st.o[C > 1 ? 1 : 0][l]));
-    }
-}
-__device__ __forceinline__ double wl_dbl(wl_i2 v) { return __hiloint2double(v.y, v.x); }
-
 // make_factor of ba_math.h with ONE select where that one has sixteen: an unused factor (masked, or behind its camera) gets
 // the scale 0, which makes E, F and f exact zeros, and its x, y, Z -- finite by construction: a point behind the camera is
 // divided by 1 -- then only ever multiply zeros downstream (Uh = F PR L^-T = 0, k = 0, T = 0).  u, v must be finite.
@@ -486,8 +434,7 @@ template <int C, int L>
 __device__ __forceinline__ void wl_chunk(const double *sCam, const WlStash stash, const double *__restrict__ points,
                                          const double2 *__restrict__ obs2, const uint8_t *__restrict__ mask,
                                          const double *__restrict__ prior_w, const double *__restrict__ prior_xyz, int64_t N,
-                                         double lambda, int64_t row0, int64_t next_row0, int lane, double *tot,
-                                         WlStage<C> &st)
+                                         double lambda, int64_t row0, int lane, double *tot)
 {
     using LT = Layout<C>;
     double px[L], py[L], pz[L];
@@ -500,14 +447,17 @@ __device__ __forceinline__ void wl_chunk(const double *sCam, const WlStash stash
         const int64_t i = (row0 + l) * 64 + lane;
         live[l] = i < N;
         idx[l] = live[l] ? i : 0;
-        px[l] = wl_dbl(st.p[l][0]); py[l] = wl_dbl(st.p[l][1]); pz[l] = wl_dbl(st.p[l][2]);
+        px[l] = points[3 * idx[l] + 0]; py[l] = points[3 * idx[l] + 1]; pz[l] = points[3 * idx[l] + 2];
     }
+    double2 ob[2][L];                       // this camera's and the next one's measurements
+#pragma unroll
+    for (int l = 0; l < L; ++l) ob[0][l] = obs2[idx[l]];
 #pragma unroll
     for (int l = 0; l < L; ++l) {
         // PriorFactor<Point3>: enters the landmark block at its start (H = w I, g = -w (p - p0)), so nothing of it stays live
         double pw = 0.0, ddx = 0.0, ddy = 0.0, ddz = 0.0;
         if (prior_w) {
-            const double w = wl_dbl(st.w[l]);
+            const double w = prior_w[idx[l]];
             if (live[l] && w > 0.0) {
                 pw = w;
                 ddx = px[l] - prior_xyz[3 * idx[l] + 0];
@@ -525,12 +475,15 @@ __device__ __forceinline__ void wl_chunk(const double *sCam, const WlStash stash
 #pragma unroll
     for (int c = 0; c < C; ++c) {
         const double *cam = sCam + kCamStride * c;
+        if (c + 1 < C) {
+#pragma unroll
+            for (int l = 0; l < L; ++l) ob[(c + 1) & 1][l] = obs2[(int64_t)(c + 1) * N + idx[l]];
+        }
 #pragma unroll
         for (int l = 0; l < L; ++l) {
             const bool seen = live[l] && (mask ? mask[(int64_t)c * N + idx[l]] != 0 : true);
             // a masked slot may hold NaN: selects, not products
-            const wl_i4 o4 = st.o[c][l];
-            const double u = seen ? __hiloint2double(o4.y, o4.x) : 0.0, v = seen ? __hiloint2double(o4.w, o4.z) : 0.0;
+            const double u = seen ? ob[c & 1][l].x : 0.0, v = seen ? ob[c & 1][l].y : 0.0;
             const Factor fc = wl_make_factor(cam, px[l], py[l], pz[l], u, v, seen);
             double PR[2][3];
             make_PR(cam, fc.x, fc.y, PR);
@@ -548,10 +501,6 @@ __device__ __forceinline__ void wl_chunk(const double *sCam, const WlStash stash
         }
     }
     asm volatile("; MQS_MARK pass_a_done");
-    // This chunk's inputs are consumed: request the next chunk's now, with the whole second pass ahead to cover the latency.
-    // They are waited for at the END of this chunk, so that no in-flight register is ever carried over the loop's back
-    // edge, where the compiler may insert register-to-register copies.
-    if (next_row0 >= 0) wl_stage_issue<C>(st, points, obs2, prior_w, N, next_row0, lane);
     double w0[L], w1[L], w2[L];
 #pragma unroll
     for (int l = 0; l < L; ++l) {
@@ -705,7 +654,6 @@ __device__ __forceinline__ void wl_chunk(const double *sCam, const WlStash stash
             MQS_SCHED_FENCE();
         }
     }
-    if (next_row0 >= 0) wl_stage_wait<C>(st);
 }
 
 template <int C>
@@ -739,19 +687,15 @@ __global__ __launch_bounds__(kBlock, 1) void ba_linearize_wave_kernel(
     const int64_t r_begin = rows * gw / nw, r_end = rows * (gw + 1) / nw;
     const WlStash stash = {sStash + tid};
     const double2 *obs2 = reinterpret_cast<const double2 *>(obs);
-    WlStage<C> st;
-    wl_stage_issue<C>(st, points, obs2, prior_w, N, r_begin < r_end ? r_begin : 0, lane);
-    wl_stage_wait<C>(st);
     for (int64_t r = r_begin; r < r_end;) {
         const int64_t left = r_end - r;
         const int nl = left >= kWaveLinMaxL ? kWaveLinMaxL : (int)left;
-        const int64_t nxt = (r + nl < r_end) ? r + nl : -1;
 #if defined(MQS_WL_ONLY_L3)      // ISA counting only (tools/isa_mix.py --define MQS_WL_ONLY_L3): one body in the listing
-        wl_chunk<C, 3>(sCam, stash, points, obs2, mask, prior_w, prior_xyz, N, lambda, r, nxt, lane, tot, st);
+        wl_chunk<C, 3>(sCam, stash, points, obs2, mask, prior_w, prior_xyz, N, lambda, r, lane, tot);
 #else
-        if (nl == 3) wl_chunk<C, 3>(sCam, stash, points, obs2, mask, prior_w, prior_xyz, N, lambda, r, nxt, lane, tot, st);
-        else if (nl == 2) wl_chunk<C, 2>(sCam, stash, points, obs2, mask, prior_w, prior_xyz, N, lambda, r, nxt, lane, tot, st);
-        else wl_chunk<C, 1>(sCam, stash, points, obs2, mask, prior_w, prior_xyz, N, lambda, r, nxt, lane, tot, st);
+        if (nl == 3) wl_chunk<C, 3>(sCam, stash, points, obs2, mask, prior_w, prior_xyz, N, lambda, r, lane, tot);
+        else if (nl == 2) wl_chunk<C, 2>(sCam, stash, points, obs2, mask, prior_w, prior_xyz, N, lambda, r, lane, tot);
+        else wl_chunk<C, 1>(sCam, stash, points, obs2, mask, prior_w, prior_xyz, N, lambda, r, lane, tot);
 #endif
         r += nl;
     }
