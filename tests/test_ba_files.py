@@ -319,14 +319,18 @@ def test_svo_dataset_full_optimisation(gpu, tmp_path):
     assert ours.shape == ref.shape == (1046, 3)
     d_ours = np.linalg.norm(ours - ref, axis=1)
     d_in = np.linalg.norm(inp - ref, axis=1)
-    assert np.median(d_ours) < 0.25 * np.median(d_in)            # moved most of the way to the reference's optimum
+    # measured (tools/svo_measure.py, round 2): median 5.6e-4, 90 % 1.4e-3 against an input 0.65 away -- the reference's own
+    # optimum to the precision GTSAM's stop rule (relative decrease 1e-5) leaves; pinned ~2x above the measurement
+    assert np.median(d_ours) < 1.2e-3 and np.quantile(d_ours, 0.9) < 3e-3 and np.median(d_in) > 0.5
     tr = io.load_trajectory(str(work / "traj_out.cam0-slam2-BA.txt"))
     rt = io.load_trajectory(os.path.join(SVO, "traj_out.cam0-slam2-BA.txt"))
     it = io.load_trajectory(os.path.join(SVO, "traj_out.cam0-slam2.txt"))
     assert len(tr) == len(rt) == 186
     e_ours = np.median([np.linalg.norm(a[1][9:] - b[1][9:]) for a, b in zip(tr, rt)])
     e_in = np.median([np.linalg.norm(a[1][9:] - b[1][9:]) for a, b in zip(it, rt)])
-    assert e_ours < 0.25 * e_in
+    assert e_ours < 1.3e-3 and e_in > 0.5                         # measured 6.5e-4 (input 0.76)
+    assert max(np.linalg.norm(a[1][9:] - b[1][9:]) for a, b in zip(tr, rt)) < 0.04           # measured 0.020
+    assert np.median([np.abs(a[1][:9] - b[1][:9]).max() for a, b in zip(tr, rt)]) < 1.5e-4      # rotations: measured 7.1e-5
     # the reference's published accuracy numbers: ATE rmse 0.395356 m before BA,
     # 0.021598 m after the reference's (GTSAM) BA -- reproduced by the restated evaluate_ate on the committed
     # files, and matched by this build's BA output
@@ -336,4 +340,4 @@ def test_svo_dataset_full_optimisation(gpu, tmp_path):
     assert ate_rmse(xyz(it), gt)[0] == pytest.approx(0.395356, abs=1e-6)
     assert ate_rmse(xyz(rt), gt)[0] == pytest.approx(0.021598, abs=1e-6)
     ours_ate, npairs = ate_rmse(xyz(tr), gt)
-    assert npairs == 186 and ours_ate == pytest.approx(0.021598, rel=0.05)
+    assert npairs == 186 and ours_ate == pytest.approx(0.021598, rel=0.015)                   # measured 0.021446

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from oracle import harness_np as H
-from util import random_scene, rel_err, stable_mask
+from util import random_scene, rel_err, stable_mask, assert_excluded_explained
 
 F64 = ctypes.POINTER(ctypes.c_double)
 
@@ -51,7 +51,7 @@ def test_device_math_vs_oracle_nview(C, host_math, c_oracle):
                      (2, c_oracle.linear_eigen_triangulation)):
         xo, so = fn(u, P)
         xh, sh, okh = host_tri(host_math, kind, u, P)
-        good = stable_mask(fn, u, P, xo, so if kind else None)
+        good = assert_excluded_explained(fn, u, P, xo, so if kind else None, xh, (sh if kind == 1 else okh) if kind else None)
         assert good.mean() > 0.99
         assert np.max(rel_err(xh[good], xo[good])) < 1e-5          # the parity bar (north_star)
         assert np.median(rel_err(xh[good], xo[good])) < 1e-11      # what fp64 actually delivers
@@ -109,3 +109,26 @@ def test_device_ba_math_vs_oracle(C, kw, host_math):
                                    _p(dpose), _p(pts_new))
     assert rc == 0
     np.testing.assert_allclose(pts_new - sc["points"], ba_np.backsub(pieces, dpose), rtol=0, atol=1e-9)
+
+
+def test_unstable_points_are_explained_not_just_counted(c_oracle):
+    """The helper that guards the parity tests' exclusions, on a scene built to have unstable points: landmarks almost on the
+    baseline of two cameras (rank-adjacent DLT systems).  A result equal to the perturbed oracle passes; a result that is
+    wrong on a WELL-conditioned point, or by more than the oracle's own sensitivity on an unstable one, fails."""
+    rng = np.random.default_rng(3)
+    P = np.stack([np.concatenate([np.eye(3), [[0.0], [0.0], [40.0]]], axis=1),
+                  np.concatenate([np.eye(3), [[-12.0], [0.0], [40.0]]], axis=1)])
+    pts = rng.uniform(-3, 3, (400, 3))
+    pts[:12] = np.array([[-200.0, 0.0, -40.0]]) + 1e-7 * rng.standard_normal((12, 3))      # on the baseline: depth ~ 0 in both views
+    u = np.stack([(pts @ P[c, :, :3].T + P[c, :, 3])[:, :2] / (pts @ P[c, :, :3].T + P[c, :, 3])[:, 2:3] for c in range(2)])
+    fn = c_oracle.linear_LS_triangulation
+    xo, _ = fn(u, P)
+    good, xp, _ = stable_mask(fn, u, P, xo, None, return_perturbed=True)
+    assert 0 < (~good).sum() <= 12 and good[12:].all()
+    assert_excluded_explained(fn, u, P, xo, None, xp, None, max_frac=0.05)                 # inside the oracle's own sensitivity
+    wrong = xo.copy()
+    wrong[np.flatnonzero(~good)[0]] += 1e6 * (1.0 + np.abs(xo[np.flatnonzero(~good)[0]]))
+    with pytest.raises(AssertionError):
+        assert_excluded_explained(fn, u, P, xo, None, wrong, None, max_frac=0.05)
+    with pytest.raises(AssertionError):
+        assert_excluded_explained(fn, u, P, xo, None, xp, None, max_frac=1e-4)             # and the count is still bounded

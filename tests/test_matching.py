@@ -145,6 +145,19 @@ def test_f16_full_size_properties_64k(gpu):
     si, sd = gpu.matching.knn2_dev(t, t)
     torch.cuda.synchronize()
     assert torch.equal(si[:, 0].cpu(), torch.arange(N, dtype=torch.int32)) and float(sd[:, 0].abs().max()) == 0.0
+    # the packed 256-bit descriptors on the int8 matrix pipe at the same size: the same sampled rows against the oracle
+    # directly, every row against the fp16 path, and determinism
+    qp = torch.from_numpy(gpu.matching.pack_bits(qb)).cuda()
+    tp = torch.from_numpy(gpu.matching.pack_bits(tb)).cuda()
+    i8, d8 = gpu.matching.knn2_bits_dev(qp, tp)
+    i8b, d8b = gpu.matching.knn2_bits_dev(qp, tp)
+    torch.cuda.synchronize()
+    assert torch.equal(i8, i8b) and torch.equal(d8, d8b)
+    i8, d8 = i8.cpu().numpy(), d8.cpu().numpy()
+    np.testing.assert_array_equal(i8[sample], io)
+    np.testing.assert_array_equal(d8[sample], do)
+    np.testing.assert_array_equal(i8, idx)
+    np.testing.assert_array_equal(d8, dist)
 
 
 def test_camera_pairs_deal_to_ranks(mqs):

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from oracle import harness_np as H
-from util import random_scene, rel_err, stable_mask
+from util import random_scene, rel_err, stable_mask, assert_excluded_explained
 
 pytestmark = pytest.mark.gpu
 
@@ -32,6 +32,67 @@ def test_gpu_reproduces_reference_golden_cells(cell, golden3, gpu):
         assert abs(res[m][3] - golden3["false_neg_summary"][tr, nt, si, m]) <= 3 / n
 
 
+def _facade_methods(gpu):
+    t = gpu.triangulation
+    return [lambda u, P: t.linear_eigen_triangulation(u[0], P[0], u[1], P[1]),
+            lambda u, P: t.linear_LS_triangulation(u[0], P[0], u[1], P[1]),
+            lambda u, P: t.iterative_LS_triangulation(u[0], P[0], u[1], P[1])]
+
+
+@pytest.mark.parametrize("traj", [0, 2, 3, 4])
+def test_gpu_golden_sweep_every_usable_cell_through_the_facade(traj, golden3, gpu):
+    """ALL usable cells of the reference's known-answer file test_3.mat (4 trajectories x noise types 0, 1 x 40 sigmas x 3
+    methods = 960 method-cells, 25 700 points each) through the drop-in 2-view facade -- one host-pointer call per trial and
+    method, exactly as the reference's harness calls the extension (triangulation_comparison.py:590).  The k1 = 0.3 tier
+    (noise type 2) runs in tests/test_camera.py and tests/test_triangulation_comparison.py."""
+    methods = _facade_methods(gpu)
+    nt_trials = int(golden3["num_trials"])
+    n = 257 * nt_trials
+    for nt in (0, 1):
+        for si in range(40):
+            res = H.test_3_cell(traj, nt, golden3["noise_sigma_values"][si], methods, nt_trials)
+            for m in range(3):
+                where = (traj, nt, si, m)
+                assert res[m][0] == pytest.approx(golden3["err3D_mean_summary"][traj, nt, si, m], rel=1e-8), where
+                assert res[m][1] == pytest.approx(golden3["err3D_median_summary"][traj, nt, si, m], rel=1e-8), where
+                # <= 3 status flips of 25 700 (the .5 absorbs the rounding of the difference of two fractions)
+                assert abs(res[m][2] - golden3["false_pos_summary"][traj, nt, si, m]) <= 3.5 / n, where
+                assert abs(res[m][3] - golden3["false_neg_summary"][traj, nt, si, m]) <= 3.5 / n, where
+
+
+def test_gpu_golden_sweep_rank_deficient_trajectory(golden3, gpu):
+    """Trajectory 1 ("towards"): the landmarks on the common optical axis give rank-deficient systems whose answer depends on
+    the SVD implementation (the reference's own file holds NaN means for linear_eigen there): medians of every cell, 2 %."""
+    methods = _facade_methods(gpu)
+    for nt in (0, 1):
+        for si in range(0, 40, 3):
+            res = H.test_3_cell(1, nt, golden3["noise_sigma_values"][si], methods, int(golden3["num_trials"]))
+            for m in range(3):
+                assert res[m][1] == pytest.approx(golden3["err3D_median_summary"][1, nt, si, m], rel=0.02), (nt, si, m)
+
+
+@pytest.mark.parametrize("traj", [0, 2, 3, 4])
+def test_gpu_golden_sweep_test_1and2_through_the_facade(traj, gpu):
+    """Every pose with a baseline of the reference's test_1and2.mat (k1 = 0.3, sigma 0.8 px, discretised; 40 poses per
+    trajectory) through the 2-view facade; the undistortion of the observations is the oracle harness's (pinned on the
+    same file in tests/test_camera.py)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "test_1and2_golden.npz"))
+    methods = _facade_methods(gpu)
+    nt_trials = int(g["num_trials"])
+    for pi in range(1 if traj in (0, 3) else 0, 40):         # first pose of trajectories 0 and 3: the cameras coincide
+        res = H.test_1and2_cell(traj, pi, methods, nt_trials)
+        for m in range(3):
+            where = (traj, pi, m)
+            sound = g["err3D_median_summary"][traj, pi, m] < 2.0
+            if g["err3D_mean_summary"][traj, pi, m] < 100.0:   # tiny baselines: the mean is a handful of near-singular points
+                assert res[m][0] == pytest.approx(g["err3D_mean_summary"][traj, pi, m], rel=1e-6), where
+            assert res[m][1] == pytest.approx(g["err3D_median_summary"][traj, pi, m], rel=1e-6), where
+            tol = 6.5 / (257 * nt_trials) if sound else 2e-3
+            assert abs(res[m][2] - g["false_pos_summary"][traj, pi, m]) <= tol, where
+            assert abs(res[m][3] - g["false_neg_summary"][traj, pi, m]) <= tol, where
+
+
 @pytest.mark.parametrize("C", [2, 3, 4, 5, 6, 7, 8])
 def test_nview_parity_host_abi(C, gpu, c_oracle):
     u, P, _ = random_scene(5000, C, seed=200 + C, behind_frac=0.1)
@@ -41,7 +102,7 @@ def test_nview_parity_host_abi(C, gpu, c_oracle):
                                 ("eigen", tc.linear_eigen_triangulation_nview, c_oracle.linear_eigen_triangulation)):
         xo, so = fn_or(u, P)
         xg, sg = fn_gpu(u, P)
-        good = stable_mask(fn_or, u, P, xo, None if name == "ls" else so)
+        good = assert_excluded_explained(fn_or, u, P, xo, None if name == "ls" else so, xg, None if name == "ls" else sg)
         assert good.mean() > 0.99, name
         assert np.max(rel_err(xg[good], xo[good])) < TOL, name
         assert np.median(rel_err(xg[good], xo[good])) < 1e-11, name
@@ -97,7 +158,7 @@ def test_status_codes_and_tolerance(gpu, c_oracle):
     for tol in (3e-5, 1e-9, 1e-2):
         xo, so = c_oracle.iterative_LS_triangulation(u, P, tolerance=tol)
         xg, sg = gpu.triangulation.iterative_LS_triangulation(u[0], P[0], u[1], P[1], tolerance=tol)
-        good = stable_mask(lambda a, b: c_oracle.iterative_LS_triangulation(a, b, tolerance=tol), u, P, xo, so)
+        good = assert_excluded_explained(lambda a, b: c_oracle.iterative_LS_triangulation(a, b, tolerance=tol), u, P, xo, so, xg, sg)
         assert good.mean() > 0.99
         np.testing.assert_array_equal(sg[good], so[good])
         assert set(np.unique(sg)).issubset({1, 0, -1, -2, -3})
@@ -157,7 +218,7 @@ def test_full_size_properties_1e6x4(gpu, c_oracle):
                        (c_oracle.linear_LS_triangulation, x_ls_h[idx], None),
                        (c_oracle.linear_eigen_triangulation, x_eg_h[idx], None)):
         xo, so = fn(us, P)
-        good = stable_mask(fn, us, P, xo, so if sg is not None else None)
+        good = assert_excluded_explained(fn, us, P, xo, so if sg is not None else None, xg, sg, max_frac=0.005)
         assert good.mean() > 0.995
         assert np.max(rel_err(xg[good], xo[good])) < TOL
         if sg is not None:
@@ -200,7 +261,8 @@ def test_baseline_config0_10k_two_cameras(gpu, c_oracle):
         x, s = fn(u[0], P4[0], u[1], P4[1])
         xo, so = oracle_fn(u, P)
         assert x.shape == (10_000, 3) and np.max(rel_err(x, xo)) < TOL, name
-        good = stable_mask(oracle_fn, u, P, xo, None if name == "linear_LS" else so)
+        good = assert_excluded_explained(oracle_fn, u, P, xo, None if name == "linear_LS" else so, x,
+                                         None if name == "linear_LS" else np.asarray(s).astype(np.asarray(so).dtype), max_frac=0.005)
         assert good.mean() > 0.995
         np.testing.assert_array_equal(np.asarray(s)[good], np.asarray(so)[good].astype(np.asarray(s).dtype))
         assert np.median(np.linalg.norm(x - pts[:, :3], axis=1)) < 0.5               # and it is the scene that was generated
@@ -226,7 +288,7 @@ def test_fused_linear_and_iterative_pass(C, gpu, c_oracle):
     torch.cuda.synchronize()
     assert torch.equal(x_it, xi) and torch.equal(st, si)
     xo, _ = c_oracle.linear_LS_triangulation(u, P)
-    good = stable_mask(c_oracle.linear_LS_triangulation, u, P, xo, None)
+    good = assert_excluded_explained(c_oracle.linear_LS_triangulation, u, P, xo, None, x_ls.cpu().numpy(), None)
     assert good.mean() > 0.99
     assert np.max(rel_err(x_ls.cpu().numpy()[good], xo[good])) < TOL
     assert np.median(rel_err(x_ls.cpu().numpy()[good], xl.cpu().numpy()[good])) < 1e-13
