@@ -198,8 +198,10 @@ int mqs_match_radius_ratio_unique(mqs_ctx *ctx, const float *query, int64_t Nq, 
  * zero Jacobians (GenericProjectionFactor, throwCheirality = false).
  * linearize writes out[(6C)*(6C) + 6C + 2] = { S row-major (reduced camera matrix, J^T J form),
  * g (S * dpose = g), cost = 0.5*sum|r/sigma|^2 (+ point priors), number of valid factors }.
- * `out` is overwritten.  lambda: Levenberg-Marquardt damping lambda*diag(Hll) on the landmark
- * blocks before elimination (0 = Gauss-Newton).  The result is bitwise reproducible.
+ * `out` is overwritten.  lambda ("damping", the same convention in every BA entry point below): 0 = Gauss-Newton;
+ * lambda > 0 = Marquardt scaling, lambda*diag(Hll) on the landmark blocks before elimination and lambda*diag(S) in the
+ * solve; lambda < 0 = Levenberg damping |lambda|*I on both, which is what GTSAM 3.2.1's default LevenbergMarquardtParams
+ * (diagonalDamping = false, bundle_adjust.cpp:323) adds to every variable.  The result is bitwise reproducible.
  * All pointers are DEVICE pointers, 16-byte aligned; asynchronous on `stream`.
  * ------------------------------------------------------------------------------------- */
 int mqs_ba_linearize_dev(const double *poses, const double *calib, const double *sigma, int C,
@@ -304,7 +306,7 @@ int mqs_ba_backsub(mqs_ctx *ctx, const double *poses, const double *calib, const
  * All pointers are device pointers.
  *   linearize: S [(6P)^2] row-major and g [6P] are overwritten with the reduced camera system
  *     (J^T J form incl. PriorFactor<Pose3> terms of the n_pose_prior listed poses, bundle_adjust.cpp:273);
- *     info[4] = {0.5*sum|r/sigma|^2 + point priors, valid-factor count, pose-prior cost, 0}.
+ *     info[4] = {0.5*sum|r/sigma|^2 + point priors, valid-factor count, pose-prior cost, 0 (grouped entry point: see there)}.
  *   solve: in place blocked Cholesky of (S + lambda*diag S), x (= g on entry) -> dpose; poses_out =
  *     retract(poses, dpose) when not NULL; bad[0] = 1 when S was not positive definite.
  *   backsub / cost as in the dense API.  mqs_sba_linearize_dev sums with fp64 atomics (not bitwise reproducible);
@@ -321,7 +323,9 @@ int mqs_sba_linearize_dev(const double *poses, const int32_t *pose_cam, int64_t 
 /* The same linearisation with the pair list SORTED by (pose of pair_a, pose of pair_b) and cut into G groups of equal key
  * (group_ptr [G + 1] int64 offsets into the pair list): one wavefront per group sums its blocks in registers and writes the
  * 6 x 6 block once -- no atomics, bitwise reproducible, and about 15x faster on the pair stage.  It writes the block's
- * mirror image too (no full-matrix mirror pass): this relies on the ordering above (pose of pair_a <= pose of pair_b). */
+ * mirror image too (no full-matrix mirror pass): this relies on a CANONICAL grouping -- pose(pair_a) <= pose(pair_b) inside
+ * every group, one group per pose pair, groups in increasing (pose_a, pose_b) order.  The grouping is checked on the device
+ * (no host round trip): info[3] = number of groups that violate it; S must not be used when it is not 0. */
 int mqs_sba_linearize_grouped_dev(const double *poses, const int32_t *pose_cam, int64_t P, const double *calib,
                                   const double *sigma, const double *points, int64_t N, const int64_t *obs_ptr,
                                   const int32_t *obs_pose, const double *obs_uv, int64_t M, const int64_t *pair_a,

@@ -467,7 +467,7 @@ def save_result(filenames, data):
 class BundleAdjustmentInfoContainer:
     """
     What the per-frame loop records for the bundle adjuster, step by step, and the writer of the `BA_info.*` file set --
-    same member functions, file names and line formats as the reference's class of this name
+    same member-function names, file names and line formats (the on-disk contract) as the reference's class of this name
     (Work/SLAM/application/own/slam2.py:743-865), so that `load_data` / tools/bundle_adjust.py (and the reference's own
     `bundle_adjust` binary) read what `slam_loop.MonoSlam` writes.  One "step" per frame (`next_step`).
     """
@@ -475,42 +475,45 @@ class BundleAdjustmentInfoContainer:
     def __init__(self, base_dir, base_name, num_cams=1):
         self.base_dir, self.base_name, self.num_cams = base_dir, base_name, num_cams
         self.calibrations = [None] * num_cams
-        self.odometry, self.odometryAssocs = [], []
-        self.points2D = [[] for _ in range(num_cams)]
-        self.point2D3DAssocs = [[] for _ in range(num_cams)]
-        self.point3DAddedIdxs = []
-        self.step = -1
-        self.next_step()
+        # Flat event logs, each row tagged with the step (or frame) it belongs to; the nested per-step lists of the file
+        # formats are formed when writing (`_grouped`).  Rows:
+        self._odometry = []                                   # (step, from_cam, from_frame, to_cam, to_frame, P 4x4)
+        self._features = [[] for _ in range(num_cams)]        # per camera: (frame, x, y) in arrival order
+        self._feature_count = [dict() for _ in range(num_cams)]    # per camera: frame -> features recorded so far
+        self._assocs = [[] for _ in range(num_cams)]          # per camera: (step, frame, point2DIdx, point3DIdx)
+        self._added = {}                                      # step -> landmark indices created in that step
+        self.step = 0
 
-    def next_step(self):                                           # :761-768
-        self.odometry.append([])
-        self.odometryAssocs.append([])
-        for cam in range(self.num_cams):
-            self.points2D[cam].append(np.zeros((0, 2)))
-            self.point2D3DAssocs[cam].append(np.zeros((0, 3), dtype=np.int64))
-        self.point3DAddedIdxs.append([])
+    def next_step(self):                                      # slam2.py:761-768: one step per frame
         self.step += 1
 
-    def set_calibration(self, K, distCoeffs, cam=0):               # :770-771
+    def set_calibration(self, K, distCoeffs, cam=0):          # :770-771
         self.calibrations[cam] = (np.asarray(K, dtype=np.float64), np.asarray(distCoeffs, dtype=np.float64).reshape(-1))
 
     def add_odometry(self, odometry, from_frame, to_frame, from_cam=0, to_cam=0):      # :773-775
         """odometry: 4x4 (or 3x4) transform P with P_to = P * P_from (world->camera matrices; trfm.delta_P)."""
-        self.odometry[self.step].append(np.asarray(odometry, dtype=np.float64))
-        self.odometryAssocs[self.step].append((from_cam, from_frame, to_cam, to_frame))
+        self._odometry.append((self.step, int(from_cam), int(from_frame), int(to_cam), int(to_frame),
+                               np.asarray(odometry, dtype=np.float64)))
 
     def add_points2D_3Dassoc(self, points2D, point3DIdxs, frame, cam=0):               # :777-786
+        """Appends features to `frame`'s list (their indices continue that frame's numbering) and ties each to its landmark."""
         points2D = np.asarray(points2D, dtype=np.float64).reshape(-1, 2)
-        assocs = np.empty((len(points2D), 3), dtype=np.int64)
-        assocs[:, 0] = frame
-        start = len(self.points2D[cam][frame])
-        assocs[:, 1] = np.arange(start, start + len(points2D))
-        assocs[:, 2] = point3DIdxs
-        self.points2D[cam][frame] = np.concatenate((self.points2D[cam][frame], points2D))
-        self.point2D3DAssocs[cam][self.step] = np.concatenate((self.point2D3DAssocs[cam][self.step], assocs))
+        frame = int(frame)
+        first = self._feature_count[cam].get(frame, 0)
+        self._feature_count[cam][frame] = first + len(points2D)
+        for k, ((x, y), lm) in enumerate(zip(points2D, np.asarray(point3DIdxs).reshape(-1))):
+            self._features[cam].append((frame, float(x), float(y)))
+            self._assocs[cam].append((self.step, frame, first + k, int(lm)))
 
-    def set_point3DAddedIdxs(self, point3DAddedIdxs):              # :788-790
-        self.point3DAddedIdxs[self.step] = [int(i) for i in point3DAddedIdxs]
+    def set_point3DAddedIdxs(self, point3DAddedIdxs):         # :788-790
+        self._added[self.step] = [int(i) for i in point3DAddedIdxs]
+
+    def _grouped(self, rows, key, count):
+        """rows -> `count` lists, row r in list key(r), arrival order kept inside a list."""
+        out = [[] for _ in range(count)]
+        for r in rows:
+            out[key(r)].append(r)
+        return out
 
     # ---- writers (:792-865) ----
     def _write(self, title, lines, cam=-1, omit_base_name=False):
@@ -540,27 +543,30 @@ class BundleAdjustmentInfoContainer:
             R, t = P[:3, :3], P[:3, 3]
             q = R_to_quat(R.T)
             return "%.16e %.16e %.16e %.16e %.16e %.16e %.16e" % (tuple(-R.T @ t) + tuple(q))
+        per_step = self._grouped(self._odometry, lambda r: r[0], self.step + 1)
         self._write("measurements.odometry", self._steps(
-            ["# Format: tx ty tz qx qy qz qw", "# Newline means next odometry; Empty line means next step"], self.odometry, fmt))
+            ["# Format: tx ty tz qx qy qz qw", "# Newline means next odometry; Empty line means next step"], per_step,
+            lambda r: fmt(r[5])))
 
     def write_odometryAssocs(self):
         self._write("measurements.odometryAssocs", self._steps(
             ["# Format: from_cam from_frame to_cam to_frame", "# Newline means next odometry; Empty line means next step"],
-            self.odometryAssocs, lambda a: " ".join(str(int(v)) for v in a)))
+            self._grouped(self._odometry, lambda r: r[0], self.step + 1), lambda r: "%d %d %d %d" % r[1:5]))
 
     def write_points2D(self, cam):
         self._write("measurements.points2D", self._steps(
             ["# Format: x y", "# Newline means next feature; Empty line means next frame, first feature"],
-            self.points2D[cam], lambda p: "%.16e %.16e" % tuple(p)), cam)
+            self._grouped(self._features[cam], lambda r: r[0], self.step + 1), lambda r: "%.16e %.16e" % r[1:3]), cam)
 
     def write_point2D3DAssocs(self, cam):
         self._write("measurements.point2D3DAssocs", self._steps(
             ["# Format: frameIdx point2DIdx point3DIdx", "# Newline means next feature; Empty line means next step, first feature"],
-            self.point2D3DAssocs[cam], lambda a: " ".join(str(int(v)) for v in a)), cam)
+            self._grouped(self._assocs[cam], lambda r: r[0], self.step + 1), lambda r: "%d %d %d" % r[1:4]), cam)
 
     def write_point3DAddedIdxs(self):
         self._write("measurements.point3DAddedIdxs", self._steps(
-            ["# Format: point3DIdx", "# Newline means next point; Empty line means next step"], self.point3DAddedIdxs, str))
+            ["# Format: point3DIdx", "# Newline means next point; Empty line means next step"],
+            [self._added.get(k, []) for k in range(self.step + 1)], str))
 
     def write_noise(self, pose=(0.002, 0.002, 0.002, 0.001, 0.001, 0.001), odometry=(0.05, 0.05, 0.05, 0.2, 0.2, 0.2),
                     point3D=0.25, point2D=5.0):

@@ -256,13 +256,16 @@ class BundleAdjuster:
             cost += 0.5 * float(e.dot(e))
         return cost
 
-    def optimize(self, iters=10, mode="gn", verbose=False):
+    def optimize(self, iters=10, mode="gn", verbose=False, damping="marquardt"):
         """
         mode="gn": `iters` Gauss-Newton iterations (cost recorded before each and at the end).
         mode="lm": Levenberg-Marquardt with GTSAM 3.2.1's default schedule (lambda0 1e-5, factor
         10, relative/absolute error tolerance 1e-5, <= 100 iterations): bundle_adjust.cpp:323-324.
-        Returns the cost history (host floats).
+        damping: "marquardt" scales the diagonals by (1 + lambda) (this build's default: invariant to the units of the
+        variables); "gtsam" adds lambda * I, GTSAM 3.2.1's default (diagonalDamping = false) -- the same optimum, the
+        reference's iterate path.  Returns the cost history (host floats).
         """
+        sgn = {"marquardt": 1.0, "gtsam": -1.0}[damping]
         hist = []
         if mode == "gn":
             for _ in range(iters):
@@ -276,10 +279,10 @@ class BundleAdjuster:
             for _ in range(min(iters, LM_MAX_ITERATIONS)):
                 improved = False
                 while lam <= LM_LAMBDA_UPPER:
-                    self.linearize(lam)
+                    self.linearize(sgn * lam)
                     self.all_reduce()
-                    self.solve(lam)
-                    self.backsub(lam)
+                    self.solve(sgn * lam)
+                    self.backsub(sgn * lam)
                     new = self.total_cost(self.poses_new, self.points_new)
                     if verbose:
                         print("  lm lambda %.1e cost %.6e -> %.6e" % (lam, cur, new))

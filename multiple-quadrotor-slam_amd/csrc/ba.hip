@@ -931,7 +931,7 @@ __global__ __launch_bounds__(64) void ba_solve_kernel(const double *__restrict__
     // diagonal: prior weight, then damping
 #pragma unroll
     for (int j = 0; j < n; ++j)
-        if (j == r) row[j] = (row[j] + sW[r]) * (1.0 + lambda);
+        if (j == r) row[j] = (lambda >= 0.0) ? (row[j] + sW[r]) * (1.0 + lambda) : (row[j] + sW[r]) - lambda;
     if (!rowlane) {
         b = 0.0;
 #pragma unroll
@@ -1093,14 +1093,8 @@ static int ba_linearize_parts(const double *poses, const double *calib, const do
         switch (C) {
 #define MQS_CASE(c)                                                                                        \
     case c: {                                                                                              \
-        static bool opt_in[64] = {};                    /* per device: dynamic LDS above 64 KiB needs the opt-in */ \
-        int dev = 0;                                                                                       \
-        MQS_HIP_CHECK(hipGetDevice(&dev));                                                                 \
-        if (dev < 0 || dev >= 64 || !opt_in[dev]) {                                                        \
-            MQS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ba_linearize_wave_kernel<c>), \
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      \
-            if (dev >= 0 && dev < 64) opt_in[dev] = true;                                                  \
-        }                                                                                                  \
+        static mqs_lds_opt_in opt;                      /* per device: dynamic LDS above 64 KiB needs the opt-in */ \
+        MQS_HIP_CHECK(mqs_lds_opt_in_once(opt, reinterpret_cast<const void *>(ba_linearize_wave_kernel<c>), lds));             \
         if (parts & 1)                                                                                     \
             hipLaunchKernelGGL((ba_linearize_wave_kernel<c>), dim3(grid), dim3(kBlock), lds, stream, poses, calib, sigma, \
                                points, obs, mask, prior_w, prior_xyz, N, lambda, partials);                \

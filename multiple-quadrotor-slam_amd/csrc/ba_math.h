@@ -209,7 +209,7 @@ MQS_HD void point_add_factor(PointSystem &ps, const Factor &fc, const double PR[
     ps.g.z -= fma(PR[0][2], fc.f0, PR[1][2] * fc.f1);
 }
 
-// Adds prior w*(p - p0) and LM damping lambda*diag(H), then factors.  A landmark without any
+// Adds prior w*(p - p0) and the LM damping (lambda*diag(H), or |lambda|*I for lambda < 0), then factors.  A landmark without any
 // constraint (all factors masked/behind, no prior) gets ok == false: it contributes nothing to
 // the reduced system and is left unchanged by the back-substitution.
 MQS_HD void point_finish(PointSystem &ps, double prior_w, double dpx, double dpy, double dpz, double lambda)
@@ -218,9 +218,12 @@ MQS_HD void point_finish(PointSystem &ps, double prior_w, double dpx, double dpy
     ps.g.x = fma(-prior_w, dpx, ps.g.x);
     ps.g.y = fma(-prior_w, dpy, ps.g.y);
     ps.g.z = fma(-prior_w, dpz, ps.g.z);
-    ps.H.xx = fma(lambda, ps.H.xx, ps.H.xx);
-    ps.H.yy = fma(lambda, ps.H.yy, ps.H.yy);
-    ps.H.zz = fma(lambda, ps.H.zz, ps.H.zz);
+    // lambda >= 0: Marquardt scaling lambda * diag(H);  lambda < 0: Levenberg damping |lambda| * I, what GTSAM 3.2.1's
+    // LevenbergMarquardtParams default (diagonalDamping = false) adds to every variable (include/mqslam.h, "damping")
+    const double mul = lambda > 0.0 ? lambda : 0.0, add = lambda < 0.0 ? -lambda : 0.0;
+    ps.H.xx = fma(mul, ps.H.xx, ps.H.xx) + add;
+    ps.H.yy = fma(mul, ps.H.yy, ps.H.yy) + add;
+    ps.H.zz = fma(mul, ps.H.zz, ps.H.zz) + add;
     const double thr = 1e-14 * (ps.H.xx + ps.H.yy + ps.H.zz);
     const double d0 = ps.H.xx;
     const double r0 = (d0 > 0.0) ? rsqrt_d(d0) : 0.0;      // 1/l00

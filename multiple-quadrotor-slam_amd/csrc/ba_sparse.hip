@@ -279,6 +279,30 @@ __global__ __launch_bounds__(kBlock) void sparse_pair_groups_kernel(const double
     }
 }
 
+// The grouped pair stage has ONE writer per 6 x 6 block and its mirror image.  That holds only if the caller's grouping is
+// canonical: pose(pair_a) <= pose(pair_b) for the group's pairs and no two groups with the same pose pair (the key
+// pose_a * P + pose_b strictly increases from group to group).  Checked here per group, without a host round trip: the
+// number of violating groups is reported in info[3] (0 for a valid grouping; S is not to be trusted otherwise).
+__global__ __launch_bounds__(kBlock) void sparse_check_groups_kernel(const int32_t *__restrict__ obs_pose,
+                                                                     const int64_t *__restrict__ pair_a,
+                                                                     const int64_t *__restrict__ pair_b,
+                                                                     const int64_t *__restrict__ group_ptr, int64_t G, int64_t P,
+                                                                     double *__restrict__ violations)
+{
+    const int64_t grp = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (grp >= G) return;
+    const int64_t q0 = group_ptr[grp], q1 = group_ptr[grp + 1];
+    if (q1 <= q0) return;
+    const int64_t ja = obs_pose[pair_a[q0]], jb = obs_pose[pair_b[q0]];
+    bool bad = ja > jb || obs_pose[pair_a[q1 - 1]] != ja || obs_pose[pair_b[q1 - 1]] != jb;
+    if (grp > 0 && group_ptr[grp] > group_ptr[grp - 1]) {
+        const int64_t p0 = group_ptr[grp - 1];
+        const int64_t ka = obs_pose[pair_a[p0]], kb = obs_pose[pair_b[p0]];
+        bad = bad || !(ka * P + kb < ja * P + jb);
+    }
+    if (bad) atomic_add_f64(violations, 1.0);
+}
+
 __device__ void so3_log_s(const double *R, double w[3])
 {
     double c = 0.5 * (R[0] + R[4] + R[8] - 1.0);
@@ -394,7 +418,10 @@ __global__ void sparse_between_kernel(double *__restrict__ S, double *__restrict
 __global__ void sparse_damp_kernel(double *__restrict__ S, int n6, double lambda)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n6) S[(int64_t)i * n6 + i] *= (1.0 + lambda);
+    if (i < n6) {
+        double &d = S[(int64_t)i * n6 + i];
+        d = (lambda >= 0.0) ? d * (1.0 + lambda) : d - lambda;       // lambda < 0: |lambda| * I (GTSAM 3.2.1's default damping)
+    }
 }
 
 __global__ __launch_bounds__(kBlock) void sparse_backsub_kernel(
@@ -987,12 +1014,14 @@ __global__ __launch_bounds__(kPT) void chol_solve_banded_blocked_kernel(const do
 #endif
 constexpr int kLibraryCholeskyMinN = MQS_SBA_LIBRARY_MIN_N;
 
-// one rocBLAS handle per host thread, created on first use (the library keeps its own device workspace in it)
+// one rocBLAS handle per host thread AND device, created on first use (the library keeps its own device workspace in it)
 rocblas_handle solver_handle()
 {
-    thread_local rocblas_handle h = nullptr;
-    if (!h && rocblas_create_handle(&h) != rocblas_status_success) h = nullptr;
-    return h;
+    thread_local rocblas_handle h[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (!h[dev] && rocblas_create_handle(&h[dev]) != rocblas_status_success) h[dev] = nullptr;
+    return h[dev];
 }
 
 }  // namespace
@@ -1006,7 +1035,8 @@ int64_t mqs_sba_workspace_bytes(int64_t P, int64_t N, int64_t M)
     return (P * kCamStride + M * kRec + 2 * blocks + 16) * (int64_t)sizeof(double);
 }
 
-// S [(6P)^2], g [6P], info[4] = {cost, valid count, pose-prior cost, 0}.  S and g are overwritten.
+// S [(6P)^2], g [6P], info[4] = {cost, valid count, pose-prior cost, groups that violate the canonical ordering}.  S and g are
+// overwritten.
 int mqs_sba_linearize_grouped_dev(const double *poses, const int32_t *pose_cam, int64_t P, const double *calib,
                                   const double *sigma, const double *points, int64_t N, const int64_t *obs_ptr,
                                   const int32_t *obs_pose, const double *obs_uv, int64_t M, const int64_t *pair_a,
@@ -1042,9 +1072,12 @@ int mqs_sba_linearize_grouped_dev(const double *poses, const int32_t *pose_cam, 
                            obs_pose, obs_uv, prior_w, prior_xyz, N, lambda, rec, partials);
         hipLaunchKernelGGL(sum_cost_partials_kernel, dim3(1), dim3(kBlock), 0, stream, partials, lm_blocks, info);
     }
-    if (Q > 0 && G > 0)
+    if (Q > 0 && G > 0) {
+        hipLaunchKernelGGL(sparse_check_groups_kernel, dim3((unsigned)((G + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream,
+                           obs_pose, pair_a, pair_b, group_ptr, G, P, info + 3);
         hipLaunchKernelGGL(sparse_pair_groups_kernel, dim3((unsigned)((G + kBlock / 64 - 1) / (kBlock / 64))), dim3(kBlock), 0,
                            stream, rec, obs_pose, pair_a, pair_b, group_ptr, G, n6, S, g);
+    }
     else if (Q > 0)
         hipLaunchKernelGGL(sparse_pairs_kernel, dim3((unsigned)((Q + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, rec,
                            obs_pose, pair_a, pair_b, Q, n6, S, g);
@@ -1116,15 +1149,10 @@ int mqs_sba_solve_banded_dev(double *S, double *x, int64_t P, int64_t half_bandw
         const int hbs = banded ? hb : n;                     // the dense factor is a band of full width
         const int cap = banded_blocked_cap(n, hbs);
         if (MQS_SBA_BLOCKED_SUBST && cap >= (hbs < 64 ? hbs : 64)) {
-            static bool lds_opt_in_b = false;                // dynamic LDS above 64 KiB needs the opt-in once per process
-            if (!lds_opt_in_b) {
-                MQS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(chol_solve_banded_blocked_kernel),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-                lds_opt_in_b = true;
-            }
+            static mqs_lds_opt_in opt_b, opt_b1;            // per device
+            MQS_HIP_CHECK(mqs_lds_opt_in_once(opt_b, reinterpret_cast<const void *>(chol_solve_banded_blocked_kernel), 150 * 1024));
             if (cap >= hbs && hbs > 0) {
-                MQS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(chol_solve_banded_blocked1_kernel),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+                MQS_HIP_CHECK(mqs_lds_opt_in_once(opt_b1, reinterpret_cast<const void *>(chol_solve_banded_blocked1_kernel), 150 * 1024));
                 hipLaunchKernelGGL(chol_solve_banded_blocked1_kernel, dim3(1), dim3(kPT), banded_blocked_lds_bytes(n, hbs), stream, S,
                                    n, hbs, x);
             } else {
@@ -1133,12 +1161,8 @@ int mqs_sba_solve_banded_dev(double *S, double *x, int64_t P, int64_t half_bandw
             }
         }
         else if (banded && lds <= 150 * 1024) {
-            static bool lds_opt_in = false;                  // dynamic LDS above 64 KiB needs the opt-in once per process
-            if (!lds_opt_in) {
-                MQS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(chol_solve_banded_kernel),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-                lds_opt_in = true;
-            }
+            static mqs_lds_opt_in opt;                       // per device
+            MQS_HIP_CHECK(mqs_lds_opt_in_once(opt, reinterpret_cast<const void *>(chol_solve_banded_kernel), 150 * 1024));
             hipLaunchKernelGGL(chol_solve_banded_kernel, dim3(1), dim3(kBlock), lds, stream, S, n, hb, x);
         }
         else

@@ -626,12 +626,8 @@ int mqs_good_features_to_track_dev(const uint8_t *img, int W, int H, int max_cor
     const bool in_lds = min_distance < 1.0 || lds <= 140 * 1024;
     if (in_lds) {
         if (lds > 48 * 1024) {
-            static bool lds_opt_in = false;                  // dynamic LDS above 64 KiB needs the opt-in once per process
-            if (!lds_opt_in) {
-                MQS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(select_kernel<true>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
-                lds_opt_in = true;
-            }
+            static mqs_lds_opt_in opt;                       // per device
+            MQS_HIP_CHECK(mqs_lds_opt_in_once(opt, reinterpret_cast<const void *>(select_kernel<true>), 140 * 1024));
         }
         hipLaunchKernelGGL(select_kernel<true>, dim3(1), dim3(kBlock), min_distance < 1.0 ? 0 : lds, stream, sorted, counter,
                            (unsigned int)npx, W, H, (float)min_distance, max_corners, out_capacity, grid, out_xy, out_n);

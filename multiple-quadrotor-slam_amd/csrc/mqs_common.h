@@ -85,6 +85,19 @@ __device__ __forceinline__ void mqs_wave_lds_sync()
     __builtin_amdgcn_wave_barrier();
 }
 
+// Dynamic LDS above 64 KiB needs hipFuncSetAttribute once per (kernel, device): `flags` is that kernel's per-device record.
+struct mqs_lds_opt_in { bool done[64] = {}; };
+static inline hipError_t mqs_lds_opt_in_once(mqs_lds_opt_in &flags, const void *kernel, size_t bytes)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 64 && flags.done[dev]) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess && dev >= 0 && dev < 64) flags.done[dev] = true;
+    return e;
+}
+
 static inline bool mqs_aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // Grid for streaming one-thread-per-item kernels: one workgroup per `block` items (the hardware

@@ -360,9 +360,10 @@ int mqs_solve_pnp(mqs_ctx *ctx, const double *objp, const double *imgp, int64_t 
     auto up = [](size_t v) { return (v + 255) & ~size_t(255); };
     const size_t o_obj = 0, o_img = up((size_t)N * 24), o_intr = o_img + up((size_t)N * 16), o_pose = o_intr + 256,
                  o_info = o_pose + 256, total = o_info + 256;
-    rc = mqs_ctx_reserve(ctx, total);
+    // 2 * total up front: should the pinned buffer be unavailable, mqs_stage_begin falls back to the device scratch with that
+    // size -- reserving it here means the scratch can no longer move after `d` has been read
+    rc = mqs_ctx_reserve(ctx, 2 * total);
     if (rc != MQS_OK) return rc;
-    char *d = static_cast<char *>(ctx->dbuf);
     hipStream_t s = ctx->stream;
     // Small problems (every real frame: <= 300 correspondences): the inputs are packed into the pinned host buffer by the
     // CPU and travel as ONE copy; the kernel keeps them in device memory (it re-reads them in every LM iteration) and
@@ -373,6 +374,7 @@ int mqs_solve_pnp(mqs_ctx *ctx, const double *objp, const double *imgp, int64_t 
         rc = mqs_stage_begin(ctx, 2 * total, &st);
         if (rc != MQS_OK) return rc;
     }
+    char *d = static_cast<char *>(ctx->dbuf);          // read AFTER every call that may (re)allocate the scratch
     if (st.zero_copy) {
         char *h = st.base;
         memcpy(h + o_obj, objp, (size_t)N * 24);

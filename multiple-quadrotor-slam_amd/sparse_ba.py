@@ -53,6 +53,11 @@ def group_pairs(pair_a, pair_b, obs_pose, n_poses):
     if len(pair_a) == 0:
         return pair_a, pair_b, np.zeros(1, np.int64)
     op = np.asarray(obs_pose, dtype=np.int64)
+    # canonical orientation: the pose of a is never after the pose of b (the grouped stage has ONE writer per block and its
+    # mirror image; with observations in any order inside a landmark, (ja, jb) and (jb, ja) would be two writers)
+    swap = op[pair_a] > op[pair_b]
+    if swap.any():
+        pair_a, pair_b = np.where(swap, pair_b, pair_a), np.where(swap, pair_a, pair_b)
     key = op[pair_a] * np.int64(n_poses) + op[pair_b]
     order = np.argsort(key, kind="stable")
     key = key[order]
@@ -194,13 +199,20 @@ class SparseBundleAdjuster:
         self.poses, self.poses_new = self.poses_new, self.poses
         self.points, self.points_new = self.points_new, self.points
 
-    def optimize(self, iters=LM_MAX_ITERATIONS, mode="lm", verbose=False):
+    def optimize(self, iters=LM_MAX_ITERATIONS, mode="lm", verbose=False, damping="marquardt"):
         """mode "lm": GTSAM 3.2.1's default Levenberg-Marquardt schedule (bundle_adjust.cpp:323-324);
-        mode "gn": plain Gauss-Newton.  Returns the cost history."""
+        mode "gn": plain Gauss-Newton.  damping: "marquardt" scales the diagonals by (1 + lambda) (default here);
+        "gtsam" adds lambda * I as GTSAM 3.2.1's default parameters do (diagonalDamping = false): same optimum, the
+        reference's iterate path.  Returns the cost history."""
+        sgn = {"marquardt": 1.0, "gtsam": -1.0}[damping]
         hist = [self.cost()]
         if mode == "gn":
-            for _ in range(iters):
+            for it in range(iters):
                 self.step(0.0)
+                if int(self.bad.item()) != 0:
+                    # the undamped reduced system was not positive definite: the step is garbage, nothing is accepted
+                    raise RuntimeError("Gauss-Newton iteration %d: the reduced camera system is not positive definite "
+                                       "(gauge not fixed, or degenerate geometry); use mode='lm'" % it)
                 self.accept()
                 hist.append(self.cost())
             return hist
@@ -208,7 +220,7 @@ class SparseBundleAdjuster:
         for _ in range(min(iters, LM_MAX_ITERATIONS)):
             improved = False
             while lam <= LM_LAMBDA_UPPER:
-                self.step(lam)
+                self.step(sgn * lam)
                 ok = int(self.bad.item()) == 0
                 new = self.cost(self.poses_new, self.points_new) if ok else float("inf")
                 if verbose:

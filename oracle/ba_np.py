@@ -140,8 +140,10 @@ def linearize(poses, calib, sigma, points, obs, mask=None, prior_w=None, prior_x
             gl -= prior_w[i] * d
             cost += 0.5 * prior_w[i] * d.dot(d)
             constrained = True
-        if lam:
+        if lam > 0:
             Hll = Hll + lam * np.diag(np.diag(Hll))
+        elif lam < 0:                                        # GTSAM 3.2.1's default damping: |lam| * I on every variable
+            Hll = Hll - lam * np.eye(3)
         # a landmark whose 3x3 block is not positive definite (fewer than two valid views and no
         # prior; the reference asserts >= 2 factors per landmark, bundle_adjust.cpp:158) is
         # unconstrained: it is left where it is and eliminates nothing (the library applies the
@@ -216,8 +218,10 @@ def gauss_newton(poses, calib, sigma, points, obs, mask=None, prior_w=None, prio
             g = g + gp
             cost += cp
         hist.append(cost)
-        if lam:
+        if lam > 0:
             S = S + lam * np.diag(np.diag(S))
+        elif lam < 0:
+            S = S - lam * np.eye(len(S))
         dpose = np.linalg.solve(S, g)
         dpts = backsub(pieces, dpose)
         for c in range(poses.shape[0]):

@@ -95,6 +95,14 @@ def test_pair_grouping_host_logic(mqs):
     assert list(zip(ga[k14], gb[k14])) == [(1, 2), (3, 4)]
     e = sb.group_pairs(np.zeros(0, np.int64), np.zeros(0, np.int64), obs_pose, 5)
     assert len(e[0]) == 0 and e[2].tolist() == [0]
+    # observations in ANY order inside a landmark: the pairs are oriented so that pose(a) <= pose(b) before grouping, so that
+    # a pose pair has exactly one group (one writer of its block)
+    unsorted_pose = np.array([4, 0, 1, 4, 1, 1], dtype=np.int32)
+    ga, gb, gp = sb.group_pairs(pa, pb, unsorted_pose, 5)
+    assert (unsorted_pose[ga] <= unsorted_pose[gb]).all()
+    keys = unsorted_pose[ga].astype(np.int64) * 5 + unsorted_pose[gb]
+    assert (np.diff(keys) >= 0).all() and [int(keys[a]) for a in gp[:-1]] == sorted(set(keys.tolist()))
+    assert sorted(zip(np.minimum(ga, gb).tolist(), np.maximum(ga, gb).tolist())) == sorted(zip(pa.tolist(), pb.tolist()))
 
 
 def _lin_oracle(pr, lam=0.0):
@@ -169,6 +177,19 @@ def test_grouped_pair_blocks_are_reproducible_and_equal_the_atomic_path(gpu):
     scale = float(S1.abs().max())
     assert float((Sa - S2.reshape(-1)).abs().max()) <= 1e-12 * scale
     assert float((ga - g2).abs().max()) <= 1e-12 * float(g2.abs().max())
+    # the device-side check of the grouping (info[3]): 0 for the helper's canonical grouping, > 0 when a caller hands over
+    # pairs whose orientation is reversed (two groups would write one block)
+    ba.linearize(0.0)
+    torch.cuda.synchronize()
+    assert float(ba.info[3].item()) == 0.0
+    rev_a, rev_b = ba.pair_b.clone(), ba.pair_a.clone()
+    gpu._lib.check(gpu._lib.lib().mqs_sba_linearize_grouped_dev(
+        P(ba.poses), P(ba.pose_cam), ba.P, P(ba.calib), P(ba.sigma), P(ba.points), ba.N, P(ba.obs_ptr), P(ba.obs_pose),
+        P(ba.obs_uv), ba.M, P(rev_a), P(rev_b), ba.Q, P(ba.group_ptr), ba.G, P(ba.prior_w), P(ba.prior_xyz), P(ba.pp_idx),
+        P(ba.pp_poses), P(ba.pp_sigmas), ba.npp, 0.0, P(Sa), P(ga), P(ba.info), P(ba.ws), ba.ws.numel(),
+        ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    assert float(ba.info[3].item()) > 0.0
 
 
 @pytest.mark.gpu
@@ -341,3 +362,34 @@ def test_svo_dataset_full_optimisation(gpu, tmp_path):
     assert ate_rmse(xyz(rt), gt)[0] == pytest.approx(0.021598, abs=1e-6)
     ours_ate, npairs = ate_rmse(xyz(tr), gt)
     assert npairs == 186 and ours_ate == pytest.approx(0.021598, rel=0.015)                   # measured 0.021446
+
+
+def test_recorder_writes_what_the_loader_reads(mqs, tmp_path):
+    """BundleAdjustmentInfoContainer (the SLAM-side recorder, slam2.py:743-865) -> BA_info.* files -> load_data: features keep
+    their per-frame numbering when a frame receives features in several steps, steps without events are empty blocks."""
+    io = mqs.ba_io
+    info = io.BundleAdjustmentInfoContainer(str(tmp_path), "rec", 1)
+    info.set_calibration(np.array([[480.0, 0.5, 320.0], [0, 470.0, 240.0], [0, 0, 1.0]]), [0.01, -0.002, 1e-4, 2e-4])
+    info.set_point3DAddedIdxs([0, 1, 2])
+    info.add_points2D_3Dassoc([[10, 11], [20, 21], [30, 31]], [0, 1, 2], 0)
+    info.next_step()                                                     # frame 1: nothing recorded
+    info.next_step()                                                     # frame 2: tracks + a new landmark seen in frames 0 and 2
+    info.add_points2D_3Dassoc([[12, 13], [22, 23]], [0, 1], 2)
+    info.set_point3DAddedIdxs([3])
+    info.add_points2D_3Dassoc([[40, 41]], [3], 0)                        # appended to frame 0's list: index 3 there
+    info.add_points2D_3Dassoc([[42, 43]], [3], 2)
+    P = np.eye(4)
+    P[:3, 3] = [0.1, -0.2, 0.3]
+    info.add_odometry(P, 0, 2)
+    info.write_all()
+    info.write_noise(point2D=1.0)
+    text = lambda name: open(os.path.join(str(tmp_path), name)).read().split("\n")
+    assert text("BA_info.measurements.points2D.cam0-rec.txt")[2:] == [
+        "%.16e %.16e" % (10, 11), "%.16e %.16e" % (20, 21), "%.16e %.16e" % (30, 31), "%.16e %.16e" % (40, 41), "", "",
+        "%.16e %.16e" % (12, 13), "%.16e %.16e" % (22, 23), "%.16e %.16e" % (42, 43), ""]
+    assert text("BA_info.measurements.point2D3DAssocs.cam0-rec.txt")[2:] == ["0 0 0", "0 1 1", "0 2 2", "", "", "2 0 0", "2 1 1", "0 3 3", "2 2 3", ""]
+    assert text("BA_info.measurements.point3DAddedIdxs-rec.txt")[2:] == ["0", "1", "2", "", "", "3", ""]
+    assert text("BA_info.measurements.odometryAssocs-rec.txt")[2:] == ["", "", "0 0 0 2", ""]
+    od = text("BA_info.measurements.odometry-rec.txt")[2:]
+    assert od[:2] == ["", ""] and [float(v) for v in od[2].split()] == pytest.approx([-0.1, 0.2, -0.3, 0, 0, 0, 1])
+    assert [float(v) for v in text("BA_info.calibrations.cam0.txt")[1].split()] == [480.0, 470.0, 0.5, 320.0, 240.0, 0.01, -0.002, 1e-4, 2e-4]

@@ -255,3 +255,32 @@ def test_c_abi_communicator_single_rank(gpu):
         assert ba.total_cost() == ref.total_cost()
     finally:
         cc.close()
+
+
+def test_gtsam_style_damping(gpu):
+    """lambda < 0 in the C ABI = Levenberg damping |lambda| * I on the landmark blocks and on the reduced system -- GTSAM
+    3.2.1's default (diagonalDamping = false).  The damped system equals the oracle's un-eliminated one with lambda * I
+    added to every variable, and LM with either damping lands on the same optimum."""
+    sc = make_scene(120, 3, seed=17, distortion=True)
+    lam = 0.37
+    ba = adjuster(gpu, sc)
+    S, g, cost, nv = split_lin(ba.linearize(-lam), 3)
+    So, go, co, nvo, _ = ba_np.linearize(sc["poses"], sc["calib"], sc["sigma"], sc["points"], sc["obs"], None,
+                                         sc["prior_w"], sc["prior_xyz"], -lam)       # the oracle's Hll + lam * I, eliminated
+    assert np.abs(S - So).max() <= 1e-10 * np.abs(So).max()
+    assert np.abs(g - go).max() <= 1e-10 * np.abs(go).max() and cost == pytest.approx(co, rel=1e-12)
+    Sm, _, _, _, _ = ba_np.linearize(sc["poses"], sc["calib"], sc["sigma"], sc["points"], sc["obs"], None,
+                                     sc["prior_w"], sc["prior_xyz"], lam)
+    assert np.abs(Sm - So).max() > 1e-3 * np.abs(So).max()                            # and it is not the Marquardt scaling
+    # the solve adds lambda to the diagonal of S (not a scaling)
+    ba.solve(-lam)
+    dp = ba.dpose.cpu().numpy()
+    np.testing.assert_allclose(dp, np.linalg.solve(S + lam * np.eye(18), g), rtol=1e-8, atol=1e-12)
+    pp = (sc["poses_true"], np.tile([0.02, 0.02, 0.02, 0.1, 0.1, 0.1], (3, 1)), np.array([1, 0, 0], dtype=np.uint8))
+    a, b = adjuster(gpu, sc, pp), adjuster(gpu, sc, pp)
+    ha = a.optimize(iters=40, mode="lm", damping="marquardt")
+    hb = b.optimize(iters=40, mode="lm", damping="gtsam")
+    # GTSAM's stop rule (relative decrease < 1e-5) leaves each run within ~1e-3 of the optimum's cost
+    assert hb[-1] == pytest.approx(ha[-1], rel=3e-3), (ha[-1], hb[-1])
+    assert all(y <= x for x, y in zip(hb, hb[1:])) and hb[-1] < 0.05 * hb[0]
+    assert np.abs(a.poses.cpu().numpy() - b.poses.cpu().numpy()).max() < 2e-2
