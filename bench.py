@@ -331,7 +331,7 @@ def main():
         md = torch.empty((nd, 2), dtype=torch.float32, device=dev)
         mws = torch.empty(int(mqslam_amd._lib.lib().mqs_match_knn2_f16_workspace_bytes(nd, nd)), dtype=torch.uint8,
                           device=dev)
-        for _ in range(10):                               # the matrix-pipe clock settles over the first launches
+        for _ in range(30):                               # the clock under matrix load settles over the first ~30 launches
             Mm.knn2_dev(qd, td, mi, md, mws)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -349,7 +349,7 @@ def main():
         qp, tp = torch.from_numpy(Mm.pack_bits(qb)).to(dev), torch.from_numpy(Mm.pack_bits(tb)).to(dev)
         mi8, md8 = torch.empty_like(mi), torch.empty_like(md)
         mws8 = torch.empty(int(mqslam_amd._lib.lib().mqs_match_knn2_bits_workspace_bytes(nd, nd, bits)), dtype=torch.uint8, device=dev)
-        for _ in range(10):
+        for _ in range(30):
             Mm.knn2_bits_dev(qp, tp, mi8, md8, mws8)
         torch.cuda.synchronize()
         e0.record()

@@ -149,7 +149,20 @@ using float16v = __attribute__((ext_vector_type(16))) float;
 #ifndef MQS_MATCH_NW256
 #define MQS_MATCH_NW256 8
 #endif
-constexpr int kStageRows = 64;                         // train rows per LDS stage (2 MFMA row tiles)
+#ifndef MQS_MATCH_STAGE_ROWS
+#define MQS_MATCH_STAGE_ROWS 128
+#endif
+// Train rows per LDS stage (a whole number of 32-row MFMA tiles): the largest of MQS_MATCH_STAGE_ROWS, its half, .. 64 of
+// which two stages fit the LDS.  Every stage ends in a workgroup barrier behind which all eight waves start again with the
+// latency of their first fragment reads exposed; at 64 rows (64 MFMAs per wave and stage) that was 8 % of the fp16 kernel's
+// time (1.41 -> 1.30 ms at 128 rows, same box) -- a stage should be as long as the LDS allows.
+constexpr int stage_bytes(int rows, int ks) { return rows * (2 * ks + 1) * 16; }
+constexpr int stage_rows(int ks)
+{
+    int rows = MQS_MATCH_STAGE_ROWS;
+    while (rows > 64 && 2 * stage_bytes(rows, ks) > 150 * 1024) rows /= 2;
+    return rows;
+}
 // The running comparison is on ONE float per (query, train row),
 //     d' = kBias + |t|^2 - 2 q.t + tile / 256            (tile = (row >> 5) & 255)
 // produced by the MFMAs themselves: the queries are held pre-scaled by -2 and the accumulator of a
@@ -194,6 +207,11 @@ struct F16Path {
     static constexpr int kWindowTiles = 256;            // 8 fraction bits carry the tile
     static __device__ __forceinline__ frag prep_query(frag v) { return v * (_Float16)(-2.0f); }
     static __device__ __forceinline__ accv mfma(frag a, frag b, accv c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+    // d' crosses a binade (512 .. 1537), so the row bits are OR-ed in after the sum.  (Keeping the sum in one binade -- bias
+    // 2560, windows of 128 tiles, tile and row both in the start value -- removes the v_or3 but measured the same 1.342 ms on the
+    // same box: at 3 vector instructions per MFMA the fp16 kernel is not bound by vector issue; the int8 one, at 6, was.)
+    static constexpr bool kRowInStart = false;
+    static constexpr float kBiasV = kBias;
     static __device__ __forceinline__ start_t start(float tnorm, int64_t t) { return tnorm + kBias + (float)((t >> 5) & (kWindowTiles - 1)) * (1.0f / kWindowTiles); }
     static __device__ __forceinline__ start_t pad() { return kPadNorm; }
     static __device__ __forceinline__ unsigned key(float v) { return __float_as_uint(v); }
@@ -223,7 +241,11 @@ struct I8Path {
     static constexpr int kWindowTiles = 128;
     static __device__ __forceinline__ frag prep_query(frag v) { return v; }
     static __device__ __forceinline__ accv mfma(frag a, frag b, accv c) { return __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, 0, 0, 0); }
-    static __device__ __forceinline__ start_t start(float tnorm, int64_t t) { return (((int)tnorm + (int)kBias) << 12) | (int)(((t >> 5) & (kWindowTiles - 1)) << 5); }
+    // the row inside its tile rides in the start value too (the int32 accumulator only ever adds multiples of 2^13 to it),
+    // so the finished accumulator IS the key: the scan costs v_med3_u32 + v_min_u32 per value, no v_or3
+    static constexpr bool kRowInStart = true;
+    static constexpr float kBiasV = kBias;
+    static __device__ __forceinline__ start_t start(float tnorm, int64_t t) { return (((int)tnorm + (int)kBias) << 12) | (int)(((t >> 5) & (kWindowTiles - 1)) << 5) | (int)(t & 31); }
     static __device__ __forceinline__ start_t pad() { return ((int)kPadNorm) << 12; }
     static __device__ __forceinline__ unsigned key(int v) { return (unsigned)v; }
     static __device__ __forceinline__ bool decode(unsigned k, float &d, int &tile, int &row)
@@ -251,6 +273,8 @@ __global__ __launch_bounds__(NW * 64) void knn2_mfma_kernel(const typename TP::e
     using start_t = typename TP::start_t;
     constexpr int D = KS * TP::kPerMfma;
     constexpr int kWindowTiles = TP::kWindowTiles;
+    constexpr int kStageRows = stage_rows(KS);
+    constexpr int kStageTiles = kStageRows / 32;
     constexpr int kWindowStages = kWindowTiles * 32 / kStageRows;
     constexpr int kVecPerRow = 2 * KS;                 // 16-byte pieces of data per row (one per (k-step, lane half))
     constexpr int kPiecesPerRow = kVecPerRow + 1;      // + one piece of padding: row stride = 4 banks mod 64
@@ -359,7 +383,8 @@ __global__ __launch_bounds__(NW * 64) void knn2_mfma_kernel(const typename TP::e
             const int v0 = ks * 16 / KS, v1 = (ks + 1) * 16 / KS;
 #pragma unroll
             for (int e = v0; e < v1; ++e) {
-                const unsigned key = TP::key(prev[e]) | (unsigned)(4 * h) | (unsigned)(8 * (e >> 2) + (e & 3));   // v_or3_b32
+                const unsigned key = TP::kRowInStart ? TP::key(prev[e])
+                                                     : (TP::key(prev[e]) | (unsigned)(4 * h) | (unsigned)(8 * (e >> 2) + (e & 3)));   // v_or3_b32
                 unsigned m;
                 asm("v_med3_u32 %0, %1, %2, %3" : "=v"(m) : "v"(best[pq]), "v"(second[pq]), "v"(key));
                 second[pq] = m;
@@ -407,7 +432,7 @@ __global__ __launch_bounds__(NW * 64) void knn2_mfma_kernel(const typename TP::e
     __syncthreads();                                     // (waits for the LDS-DMA: vmcnt(0) + barrier)
 
     constexpr int R = QT < 2 ? 2 : QT;                   // accumulator ring: step j writes acc[j % R], scans acc[(j - 1) % R]
-    static_assert((2 * QT) % R == 0, "the ring position must repeat every stage");
+    static_assert((kStageTiles * QT) % R == 0, "the ring position must repeat every stage");
     accv_t acc[R];
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[R - 1][e] = TP::pad();   // "previous step" of the first one: nothing
@@ -420,7 +445,7 @@ __global__ __launch_bounds__(NW * 64) void knn2_mfma_kernel(const typename TP::e
         const unsigned char *tile = sTile + (int)(s & 1) * kStageBytes;
         const start_t *tn0 = sTn + (int)(s & 1) * kStageRows + 4 * h;
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt)
+        for (int tt = 0; tt < kStageTiles; ++tt)
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) {
                 const int j = tt * QT + qt;
@@ -433,10 +458,11 @@ __global__ __launch_bounds__(NW * 64) void knn2_mfma_kernel(const typename TP::e
     }
     // scan of the last step, last window
     if (nstages > 0) {
-        constexpr int jl = 2 * QT - 1;
+        constexpr int jl = kStageTiles * QT - 1;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            const unsigned key = TP::key(acc[jl % R][e]) | (unsigned)(4 * h) | (unsigned)(8 * (e >> 2) + (e & 3));
+            const unsigned key = TP::kRowInStart ? TP::key(acc[jl % R][e])
+                                                 : (TP::key(acc[jl % R][e]) | (unsigned)(4 * h) | (unsigned)(8 * (e >> 2) + (e & 3)));
             second[QT - 1] = max(best[QT - 1], min(second[QT - 1], key));
             best[QT - 1] = min(best[QT - 1], key);
         }
@@ -462,11 +488,11 @@ __global__ __launch_bounds__(NW * 64) void knn2_mfma_kernel(const typename TP::e
             if (gridDim.y == 1) {
                 idx[2 * q] = mi0;
                 idx[2 * q + 1] = mi1;
-                dist[2 * q] = mi0 >= 0 ? sqrtf(md0 - kBias + qn[qt]) : INFINITY;
-                dist[2 * q + 1] = mi1 >= 0 ? sqrtf(md1 - kBias + qn[qt]) : INFINITY;
+                dist[2 * q] = mi0 >= 0 ? sqrtf(md0 - TP::kBiasV + qn[qt]) : INFINITY;
+                dist[2 * q + 1] = mi1 >= 0 ? sqrtf(md1 - TP::kBiasV + qn[qt]) : INFINITY;
             } else {
                 const int64_t o = ((int64_t)blockIdx.y * Nq + q) * 2;
-                part_d[o] = md0; part_d[o + 1] = md1;
+                part_d[o] = md0 - TP::kBiasV + kBias; part_d[o + 1] = md1 - TP::kBiasV + kBias;      // parts carry the common bias (merge_parts_kernel)
                 part_i[o] = mi0; part_i[o + 1] = mi1;
             }
         }
