@@ -750,6 +750,9 @@ __global__ __launch_bounds__(kFinThreads) void ba_finalize_kernel(const double *
     }
 }
 
+#ifndef MQS_BA_BACKSUB_DIRECT
+#define MQS_BA_BACKSUB_DIRECT 1
+#endif
 template <int C>
 __global__ __launch_bounds__(kBlock, 4) void ba_backsub_kernel(
     const double *__restrict__ poses, const double *__restrict__ calib, const double *__restrict__ sigma,
@@ -769,11 +772,27 @@ __global__ __launch_bounds__(kBlock, 4) void ba_backsub_kernel(
         const int64_t i = base + tid;
         const bool live = i < N;
         double px, py, pz;
+#if MQS_BA_BACKSUB_DIRECT
+        // Each lane reads and writes its own 24-byte landmark: three 8-byte accesses per lane that together cover whole cache
+        // lines across the wave.  The LDS transpose of the first version made them 16-byte coalesced at the price of three
+        // workgroup barriers per batch -- in a kernel that is short of work to hide latency, not of bandwidth.
+        const int64_t ii = live ? i : 0;
+        px = points[3 * ii + 0]; py = points[3 * ii + 1]; pz = points[3 * ii + 2];
+        if (!live) { px = 0.0; py = 0.0; pz = 0.0; }
+#else
         load_points(points, base, N, sX, tid, px, py, pz);
+#endif
         const DevObs ob = {reinterpret_cast<const double2 *>(obs), mask, i, N, live};
         double pw, dx, dy, dz;
         load_prior(prior_w, prior_xyz, i, live, px, py, pz, pw, dx, dy, dz);
         const mqs::Vec3 dp = landmark_backsub<C>(sCam, ob, px, py, pz, pw, dx, dy, dz, lambda, sD);
+#if MQS_BA_BACKSUB_DIRECT
+        if (live) {
+            points_out[3 * i + 0] = px + dp.x;
+            points_out[3 * i + 1] = py + dp.y;
+            points_out[3 * i + 2] = pz + dp.z;
+        }
+#else
         __syncthreads();                                    // every thread has read its point from sX
         sX[tid * 3 + 0] = px + dp.x;
         sX[tid * 3 + 1] = py + dp.y;
@@ -787,6 +806,7 @@ __global__ __launch_bounds__(kBlock, 4) void ba_backsub_kernel(
         for (int p = tid; p < (ndbl >> 1); p += kBlock) dst[p] = src[p];
         if ((ndbl & 1) && tid == 0) points_out[base * 3 + ndbl - 1] = sX[ndbl - 1];
         __syncthreads();
+#endif
     }
 }
 
