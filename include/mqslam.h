@@ -405,6 +405,17 @@ int64_t mqs_project_workspace_bytes(void);
  *       OpenCV's early exit at minInliersCount only shortens its serial loop; its accept / reject
  *       decision on the returned inlier count stays with the caller (slam2.py:461-468).
  * ------------------------------------------------------------------------------------- */
+/* One keyframe step of the per-frame loop (slam2.py handle_new_frame :453-490, 541-590) in ONE launch: pose of the frame from
+ * its n_old tracked landmarks (start P_prev), two-view iterative-LS triangulation of the n_new not-yet-triangulated pixel
+ * tracks p0 (base keyframe, pose P0) / p1 (this frame) after cv2.undistortPoints, the points with status 1 cast to float32
+ * and added to the pose problem, the refined pose, and the re-triangulation of those points with it.  Replaces two
+ * cv2.solvePnP, four cv2.undistortPoints and two iterative_LS_triangulation calls (:489-490, 551-555, 576-577, 582-584) with
+ * the same results.  poses [2][12] = first and refined pose ([R | t], world -> camera; equal when n_new == 0);
+ * x [n_new][3], status [n_new] = second-pass status (keep >= 0, :589) or -128 for a point the first pass did not keep (x = NaN);
+ * info [8] = {sqerr, iterations, points, converged} of the two pose solves (may be NULL).  n_new == 0: pose only. */
+int mqs_keyframe_step(mqs_ctx *ctx, const double *objp, const double *imgp, int64_t n_old, const double *p0, const double *p1,
+                      int64_t n_new, const double *intr, const double *P_prev, const double *P0, double tolerance, int max_iter,
+                      double eps, double *poses, double *x, int32_t *status, double *info);
 int mqs_solve_pnp(mqs_ctx *ctx, const double *objp, const double *imgp, int64_t N, const double *intr, double *pose,
                   int use_guess, int max_iter, double eps, double *info);
 int mqs_pnp_refine_dev(const double *objp, const double *imgp, int64_t N, const int32_t *idx, const int32_t *ptr, int B,

@@ -113,6 +113,8 @@ SIGNATURES = {
     "mqs_project_points": (ctypes.c_int, [c_vp, c_f64p, c_f64p, c_f64p, c_f64p, c_i64, c_f64p, c_f64p, c_f64p]),
     "mqs_project_points_dev": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "mqs_project_workspace_bytes": (c_i64, []),
+    "mqs_keyframe_step": (ctypes.c_int, [c_vp, c_f64p, c_f64p, c_i64, c_f64p, c_f64p, c_i64, c_f64p, c_f64p, c_f64p,
+                                         ctypes.c_double, ctypes.c_int, ctypes.c_double, c_f64p, c_f64p, c_i32p, c_f64p]),
     "mqs_solve_pnp": (ctypes.c_int, [c_vp, c_f64p, c_f64p, c_i64, c_f64p, c_f64p, ctypes.c_int, ctypes.c_int,
                                      ctypes.c_double, c_f64p]),
     "mqs_pnp_refine_dev": (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, ctypes.c_int, c_vp, c_vp, ctypes.c_int,

@@ -14,6 +14,7 @@
 // Every sum has a fixed order: results are bitwise reproducible.
 #include "mqs_common.h"
 #include "pnp_math.h"
+#include "cam_math.h"
 
 namespace {
 
@@ -280,6 +281,163 @@ int check_points(const double *objp, const double *imgp, int64_t N, const double
     return MQS_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// One keyframe step of slam2.py's handle_new_frame (:453-490, 541-590) in ONE launch (one workgroup of four waves):
+//   pose P1 = solvePnP(tracked landmarks, start = previous pose)                                      (:489-490)
+//   triangulate the not-yet-triangulated tracks against the base keyframe with (P0, P1): undistort both pixel sets
+//   (cv2.undistortPoints :551-552), iterative-LS (:553-555), keep status == 1 (:556), cast to float32 (:19)
+//   refined pose P2 = solvePnP(old + new points, start = P1)                                            (:576-577)
+//   re-triangulate the kept points with (P0, P2) (:582-584); the caller keeps status >= 0 (:589).
+// The host-pointer path needs eight calls for this (two pose solves, four undistortions, two triangulations) at <= 300
+// points each: launch and copy latency, not arithmetic.  Same device functions as the single kernels (pnp_math.h lm_refine,
+// cam_math.h undistort_pixel, tri_math.h iterative_ls_point<2>); the kept points are compacted in index order behind the
+// old ones.  The pose sums run over four waves instead of one (a different, still fixed, order): the results equal the
+// eight-call path's to rounding (1e-12 asserted, tests/test_replay.py).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int32_t kKfDropped = -128;              // status of a point the first pass did not keep
+
+constexpr int kKfThreads = 256;                   // four waves share a frame: <= 300 correspondences are one or two sweeps
+constexpr int kKfWaves = kKfThreads / kWave;
+
+// eval over two segments (the tracked landmarks, then the compacted new points), summed over the WORKGROUP in a fixed order:
+// every thread ends with the same sums, so the Levenberg-Marquardt loop around it runs redundantly and in step in all of them
+struct KfEval {
+    const double *objp, *imgp;
+    int n_old;
+    const double *cx, *cuv;                       // compacted new points: [n_ok][3] (float32-rounded), [n_ok][2]
+    int n_ok;
+    const double *intr;
+    double *red;                                  // LDS [kKfWaves][kAcc]
+    int tid;
+    __device__ __forceinline__ void operator()(const double *P, double *acc) const
+    {
+#pragma unroll
+        for (int k = 0; k < kAcc; ++k) acc[k] = 0.0;
+        const int n = n_old + n_ok;
+        for (int k = tid; k < n; k += kKfThreads) {
+            const bool old = k < n_old;
+            const double *X = old ? objp + 3 * k : cx + 3 * (k - n_old);
+            const double *U = old ? imgp + 2 * k : cuv + 2 * (k - n_old);
+            accumulate_point(P, intr, X[0], X[1], X[2], U[0], U[1], acc);
+        }
+#pragma unroll
+        for (int k = 0; k < kAcc; ++k) acc[k] = wave_sum(acc[k]);
+        __syncthreads();                          // the previous call's sums have been read by everyone
+        if ((tid & 63) == 0) {
+#pragma unroll
+            for (int k = 0; k < kAcc; ++k) red[(tid >> 6) * kAcc + k] = acc[k];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kAcc; ++k) {
+            double t = red[k];
+#pragma unroll
+            for (int w = 1; w < kKfWaves; ++w) t += red[w * kAcc + k];
+            acc[k] = t;
+        }
+    }
+};
+
+__global__ __launch_bounds__(kKfThreads) void keyframe_step_kernel(
+    const double *objp, const double *imgp, int n_old, const double *__restrict__ p0,
+    const double *__restrict__ p1, int n_new, const double *__restrict__ intr, const double *__restrict__ P_prev,
+    const double *__restrict__ P0, double tol, int max_iter, double eps, int lds_ok, double *scratch /* 9 n_new + 1 doubles */,
+    double *__restrict__ pose_out /* 24: first pose, final pose */, double *__restrict__ x_out, int32_t *__restrict__ status_out,
+    double *__restrict__ info /* 8: the two solves' info */)
+{
+    __shared__ double sI[9];
+    __shared__ double sP[24];                     // P0 | the frame's pose, as the 2-view triangulation wants them
+    __shared__ double sRed[kKfWaves * kAcc];
+    __shared__ int sCnt[kKfWaves];
+    extern __shared__ __attribute__((aligned(16))) double kf_lds[];      // correspondences + scratch when the step fits (lds_ok)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < 9) sI[tid] = intr[tid];
+    if (tid < 12) sP[tid] = P0[tid];
+    if (lds_ok) {
+        // Real frames (<= 300 correspondences, slam2.py:1080-1082) fit the LDS: the correspondences are read once and every
+        // LM iteration then sweeps LDS instead of global memory; the scratch arrays live there too.
+        double *so = kf_lds, *si = so + 3 * n_old;
+        for (int k = tid; k < 3 * n_old; k += kKfThreads) so[k] = objp[k];
+        for (int k = tid; k < 2 * n_old; k += kKfThreads) si[k] = imgp[k];
+        objp = so; imgp = si;
+        scratch = si + 2 * n_old;
+    }
+    __syncthreads();
+    double P[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) P[k] = P_prev[k];
+    KfEval ev = {objp, imgp, n_old, nullptr, nullptr, 0, sI, sRed, tid};
+    LmResult r = lm_refine(ev, P, max_iter, eps);
+    if (tid < 12) { pose_out[tid] = P[tid]; pose_out[12 + tid] = P[tid]; }
+    if (tid == 0) { info[0] = r.sqerr; info[1] = (double)r.iters; info[2] = (double)n_old; info[3] = r.converged ? 1.0 : 0.0;
+                    info[4] = 0.0; info[5] = 0.0; info[6] = 0.0; info[7] = 0.0; }
+    if (n_new <= 0) return;
+
+    double *un = scratch;                         // [n_new][4] undistorted (x0, y0, x1, y1)
+    double *cx = scratch + 4 * (size_t)n_new;     // [n_ok][3]
+    double *cuv = cx + 3 * (size_t)n_new;         // [n_ok][2]
+    int32_t *cidx = reinterpret_cast<int32_t *>(cuv + 2 * (size_t)n_new);   // [n_ok]
+    if (tid < 12) sP[12 + tid] = P[tid];
+    __syncthreads();
+    // first triangulation; the kept points are compacted in index order (ballot ranks per wave, wave offsets through LDS),
+    // float32-rounded
+    int n_ok = 0;
+    for (int base = 0; base < n_new; base += kKfThreads) {
+        const int k = base + tid;
+        bool ok = false;
+        mqs::Vec3 x = {0, 0, 0};
+        if (k < n_new) {
+            double uv[2][2];
+            mqs::cam::undistort_pixel(sI, p0[2 * k], p0[2 * k + 1], uv[0][0], uv[0][1]);
+            mqs::cam::undistort_pixel(sI, p1[2 * k], p1[2 * k + 1], uv[1][0], uv[1][1]);
+            un[4 * k + 0] = uv[0][0]; un[4 * k + 1] = uv[0][1]; un[4 * k + 2] = uv[1][0]; un[4 * k + 3] = uv[1][1];
+            int32_t st;
+            x = mqs::iterative_ls_point<2>(uv, sP, tol, MQS_TRI_MAX_ITER_DEFAULT, st);
+            ok = st == 1;
+            if (!ok) {
+                status_out[k] = kKfDropped;
+                x_out[3 * k] = x_out[3 * k + 1] = x_out[3 * k + 2] = __builtin_nan("");
+            }
+        }
+        const unsigned long long m = __ballot(ok);
+        if (lane == 0) sCnt[wave] = __popcll(m);
+        __syncthreads();
+        int before = n_ok, total = 0;
+#pragma unroll
+        for (int w = 0; w < kKfWaves; ++w) {
+            if (w < wave) before += sCnt[w];
+            total += sCnt[w];
+        }
+        const int rank = before + __popcll(m & ((1ull << lane) - 1ull));
+        if (ok) {
+            cx[3 * rank + 0] = (double)(float)x.x; cx[3 * rank + 1] = (double)(float)x.y; cx[3 * rank + 2] = (double)(float)x.z;
+            cuv[2 * rank + 0] = p1[2 * k]; cuv[2 * rank + 1] = p1[2 * k + 1];
+            cidx[rank] = k;
+        }
+        n_ok += total;
+        __syncthreads();
+    }
+    __threadfence_block();
+    __syncthreads();
+    // refined pose on old + kept points
+    KfEval ev2 = {objp, imgp, n_old, cx, cuv, n_ok, sI, sRed, tid};
+    r = lm_refine(ev2, P, max_iter, eps);
+    __syncthreads();
+    if (tid < 12) { pose_out[12 + tid] = P[tid]; sP[12 + tid] = P[tid]; }
+    if (tid == 0) { info[4] = r.sqerr; info[5] = (double)r.iters; info[6] = (double)(n_old + n_ok); info[7] = r.converged ? 1.0 : 0.0; }
+    __syncthreads();
+    // second triangulation of the kept points with the refined pose
+    for (int j = tid; j < n_ok; j += kKfThreads) {
+        const int k = cidx[j];
+        double uv[2][2] = {{un[4 * k + 0], un[4 * k + 1]}, {un[4 * k + 2], un[4 * k + 3]}};
+        int32_t st;
+        const mqs::Vec3 x = mqs::iterative_ls_point<2>(uv, sP, tol, MQS_TRI_MAX_ITER_DEFAULT, st);
+        x_out[3 * k + 0] = x.x; x_out[3 * k + 1] = x.y; x_out[3 * k + 2] = x.z;
+        status_out[k] = st;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -400,6 +558,87 @@ int mqs_solve_pnp(mqs_ctx *ctx, const double *objp, const double *imgp, int64_t 
     if (rc != MQS_OK) return rc;
     MQS_HIP_CHECK(hipMemcpyAsync(pose, d + o_pose, 96, hipMemcpyDeviceToHost, s));
     if (info) MQS_HIP_CHECK(hipMemcpyAsync(info, d + o_info, 32, hipMemcpyDeviceToHost, s));
+    MQS_HIP_CHECK(hipStreamSynchronize(s));
+    return MQS_OK;
+}
+
+int mqs_keyframe_step(mqs_ctx *ctx, const double *objp, const double *imgp, int64_t n_old, const double *p0, const double *p1,
+                      int64_t n_new, const double *intr, const double *P_prev, const double *P0, double tolerance, int max_iter,
+                      double eps, double *poses /* [2][12]: first, refined */, double *x, int32_t *status, double *info)
+{
+    MQS_ARG_CHECK(ctx != nullptr && poses != nullptr && intr != nullptr && P_prev != nullptr, "ctx, poses, intr, P_prev must not be null");
+    MQS_ARG_CHECK(n_old >= 3 && objp && imgp, "a pose needs >= 3 tracked landmarks (objp, imgp)");
+    MQS_ARG_CHECK(n_new >= 0 && n_old < (1 << 24) && n_new < (1 << 24), "sizes");
+    MQS_ARG_CHECK(n_new == 0 || (p0 && p1 && P0 && x && status), "p0, p1, P0, x, status must not be null when there are new points");
+    MQS_ARG_CHECK(max_iter >= 1, "max_iter >= 1");
+    MQS_HIP_CHECK(hipSetDevice(ctx->device));
+    auto up = [](size_t v) { return (v + 255) & ~size_t(255); };
+    // inputs (one copy) | scratch | outputs (read back, or written straight into the pinned buffer)
+    const size_t o_obj = 0, o_img = o_obj + up((size_t)n_old * 24), o_p0 = o_img + up((size_t)n_old * 16),
+                 o_p1 = o_p0 + up((size_t)n_new * 16), o_intr = o_p1 + up((size_t)n_new * 16), o_pp = o_intr + 256, o_pb = o_pp + 256,
+                 in_bytes = o_pb + 256;
+    const size_t o_scr = in_bytes, scr_bytes = up((size_t)n_new * (9 * 8 + 4) + 64);
+    const size_t o_pose = o_scr + scr_bytes, o_x = o_pose + 256, o_st = o_x + up((size_t)n_new * 24), o_info = o_st + up((size_t)n_new * 4),
+                 total = o_info + 256;
+    int rc = mqs_ctx_reserve(ctx, 2 * total);
+    if (rc != MQS_OK) return rc;
+    hipStream_t s = ctx->stream;
+    mqs_stage st;
+    st.zero_copy = false;
+    if (2 * total <= kZeroCopyMax) {
+        rc = mqs_stage_begin(ctx, 2 * total, &st);
+        if (rc != MQS_OK) return rc;
+    }
+    char *d = static_cast<char *>(ctx->dbuf);
+    const double dummyP[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    const size_t lds_bytes = ((size_t)5 * n_old + (size_t)9 * n_new + 2) * 8 + (size_t)n_new * 4;   // correspondences | un, cx, cuv | cidx
+    const bool lds_ok = lds_bytes <= 56 * 1024;
+    auto launch = [&](const char *inb, char *outb) {
+        hipLaunchKernelGGL(keyframe_step_kernel, dim3(1), dim3(kKfThreads), lds_ok ? lds_bytes : 0, s, (const double *)(inb + o_obj),
+                           (const double *)(inb + o_img), (int)n_old, (const double *)(inb + o_p0), (const double *)(inb + o_p1), (int)n_new,
+                           (const double *)(inb + o_intr), (const double *)(inb + o_pp), (const double *)(inb + o_pb), tolerance, max_iter,
+                           eps, (int)lds_ok, (double *)(d + o_scr), (double *)(outb + o_pose), (double *)(outb + o_x),
+                           (int32_t *)(outb + o_st), (double *)(outb + o_info));
+    };
+    if (st.zero_copy) {
+        // the inputs are packed in the pinned buffer by the CPU and travel as ONE copy (the kernel re-reads them in every LM
+        // iteration: they stay in device memory); the outputs are written straight into the pinned buffer's second half
+        char *h = st.base;
+        memcpy(h + o_obj, objp, (size_t)n_old * 24);
+        memcpy(h + o_img, imgp, (size_t)n_old * 16);
+        if (n_new) { memcpy(h + o_p0, p0, (size_t)n_new * 16); memcpy(h + o_p1, p1, (size_t)n_new * 16); }
+        memcpy(h + o_intr, intr, 72);
+        memcpy(h + o_pp, P_prev, 96);
+        memcpy(h + o_pb, P0 ? P0 : dummyP, 96);
+        // (letting the single wave pull the inputs over the fabric itself, straight into LDS, measured slower than this
+        // copy: 113 vs 104 us per frame)
+        MQS_HIP_CHECK(hipMemcpyAsync(d, h, in_bytes, hipMemcpyHostToDevice, s));
+        launch(d, h + total);
+        MQS_HIP_CHECK(hipGetLastError());
+        MQS_HIP_CHECK(hipStreamSynchronize(s));
+        const char *o = h + total;
+        memcpy(poses, o + o_pose, 192);
+        if (n_new) { memcpy(x, o + o_x, (size_t)n_new * 24); memcpy(status, o + o_st, (size_t)n_new * 4); }
+        if (info) memcpy(info, o + o_info, 64);
+        return MQS_OK;
+    }
+    MQS_HIP_CHECK(hipMemcpyAsync(d + o_obj, objp, (size_t)n_old * 24, hipMemcpyHostToDevice, s));
+    MQS_HIP_CHECK(hipMemcpyAsync(d + o_img, imgp, (size_t)n_old * 16, hipMemcpyHostToDevice, s));
+    if (n_new) {
+        MQS_HIP_CHECK(hipMemcpyAsync(d + o_p0, p0, (size_t)n_new * 16, hipMemcpyHostToDevice, s));
+        MQS_HIP_CHECK(hipMemcpyAsync(d + o_p1, p1, (size_t)n_new * 16, hipMemcpyHostToDevice, s));
+    }
+    MQS_HIP_CHECK(hipMemcpyAsync(d + o_intr, intr, 72, hipMemcpyHostToDevice, s));
+    MQS_HIP_CHECK(hipMemcpyAsync(d + o_pp, P_prev, 96, hipMemcpyHostToDevice, s));
+    MQS_HIP_CHECK(hipMemcpyAsync(d + o_pb, P0 ? P0 : dummyP, 96, hipMemcpyHostToDevice, s));
+    launch(d, d);
+    MQS_HIP_CHECK(hipGetLastError());
+    MQS_HIP_CHECK(hipMemcpyAsync(poses, d + o_pose, 192, hipMemcpyDeviceToHost, s));
+    if (n_new) {
+        MQS_HIP_CHECK(hipMemcpyAsync(x, d + o_x, (size_t)n_new * 24, hipMemcpyDeviceToHost, s));
+        MQS_HIP_CHECK(hipMemcpyAsync(status, d + o_st, (size_t)n_new * 4, hipMemcpyDeviceToHost, s));
+    }
+    if (info) MQS_HIP_CHECK(hipMemcpyAsync(info, d + o_info, 64, hipMemcpyDeviceToHost, s));
     MQS_HIP_CHECK(hipStreamSynchronize(s));
     return MQS_OK;
 }

