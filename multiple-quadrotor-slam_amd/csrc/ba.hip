@@ -270,7 +270,7 @@ __global__ __launch_bounds__(kBlock, 2) void ba_linearize_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Wave-level lineariser (C <= 4): up to three landmarks per lane share every window reduction.
+// Wave-level lineariser (C <= 4): up to four landmarks per lane share every window reduction.
 //
 // What the one-landmark-per-lane kernel above spends (ISA histogram, profiles/r02): of ~3 960 vector issue slots per landmark
 // ~1 940 are the cross-lane reduction of its 11 windows (v_permlane*_swap issues in two passes), i.e. half of a kernel that
@@ -284,13 +284,15 @@ __global__ __launch_bounds__(kBlock, 2) void ba_linearize_kernel(
 //   * windows follow the blocks: one 32-entry window per camera (21 + 6 entries; cost and count ride in camera 0's), and
 //     per camera pair a 32-entry window plus a 4-entry one (36 = 32 + 4), so that no block straddles a window and no
 //     window is open while another one fills;
-//   * a wave owns a contiguous range of 64-landmark rows and walks it in chunks of three rows; nothing is shared between
-//     waves until the end, so there is no barrier inside the loop; the next chunk's cache lines are requested (L2 warm-up
-//     loads that nobody waits for) while the off-diagonal windows of the current one are computed.
+//   * a wave owns a contiguous range of 64-landmark rows (15 or 16 at 1e6 landmarks) and walks it in chunks of four rows:
+//     four reductions per wave instead of sixteen; the LDS holds three landmarks' columns, the fourth landmark's six doubles
+//     per camera live in accumulation registers (three rows per chunk: 113-119 us, four: 107-114 us at 1e6 x 4);
+//     nothing is shared between waves until the end, so there is no barrier inside the loop.
 // Results: same formulas as landmark_contribution (ba_math.h), sums in a different, still fixed, order -- bitwise
 // reproducible run to run.
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int kWaveLinMaxL = 3;
+constexpr int kWaveLinMaxL = 4;            // landmarks per lane and chunk
+constexpr int kWaveLinLdsL = 3;            // of which this many park their six doubles per camera in LDS; the fourth one's live in AGPRs
 
 // sum over the 64 lanes of 4 values per lane: lane l ends with the total of v[l >> 4]
 __device__ __forceinline__ double wave_reduce4(double (&v)[4], int lane)
@@ -437,6 +439,17 @@ __device__ __forceinline__ void wl_chunk(const double *sCam, const WlStash stash
                                          double lambda, int64_t row0, int lane, double *tot)
 {
     using LT = Layout<C>;
+    // the stash of landmark l, camera c: LDS for the first kWaveLinLdsL landmarks, accumulation registers for the fourth (the
+    // LDS holds three landmarks' worth; l, c, k are compile-time after unrolling, so the choice costs nothing)
+    AReg a3[C][6];
+    auto sput = [&](int l, int c, int k, double a, double b) {
+        if (l < kWaveLinLdsL) stash.put(l * C + c, k, a, b);
+        else { a_put(a3[c][2 * k], a); a_put(a3[c][2 * k + 1], b); }
+    };
+    auto sget = [&](int l, int c, int k) -> double2 {
+        if (l < kWaveLinLdsL) return stash.get(l * C + c, k);
+        return make_double2(a_get(a3[c][2 * k]), a_get(a3[c][2 * k + 1]));
+    };
     double px[L], py[L], pz[L];
     bool live[L];
     int64_t idx[L];
@@ -489,9 +502,9 @@ __device__ __forceinline__ void wl_chunk(const double *sCam, const WlStash stash
             make_PR(cam, fc.x, fc.y, PR);
             point_add_factor(ps[l], fc, PR);
             a_put(X[l][c], fc.x); a_put(Y[l][c], fc.y); a_put(Z[l][c], fc.Z);
-            stash.put(l * C + c, 0, fc.F00, fc.F01);
-            stash.put(l * C + c, 1, fc.F11, fc.f0);
-            stash.put(l * C + c, 2, fc.f1, 0.0);
+            sput(l, c, 0, fc.F00, fc.F01);
+            sput(l, c, 1, fc.F11, fc.f0);
+            sput(l, c, 2, fc.f1, 0.0);
             cost += fc.half_e2;
             count += fc.valid ? 1.0 : 0.0;
             wl_pin(ps[l].H.xx); wl_pin(ps[l].H.xy); wl_pin(ps[l].H.xz); wl_pin(ps[l].H.yy); wl_pin(ps[l].H.yz); wl_pin(ps[l].H.zz);
@@ -517,7 +530,7 @@ __device__ __forceinline__ void wl_chunk(const double *sCam, const WlStash stash
     // (double-buffered in registers), so that they land while the previous block's arithmetic issues.
     double2 dq[2][3];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) dq[0][k] = stash.get(0, k);
+    for (int k = 0; k < 3; ++k) dq[0][k] = sget(0, 0, k);
 #pragma unroll
     for (int c = 0; c < C; ++c) {
         const double *cam = sCam + kCamStride * c;
@@ -528,7 +541,7 @@ __device__ __forceinline__ void wl_chunk(const double *sCam, const WlStash stash
             if (step + 1 < C * L) {
                 const int nl = (l + 1 < L) ? l + 1 : 0, nc = (l + 1 < L) ? c : c + 1;
 #pragma unroll
-                for (int k = 0; k < 3; ++k) dq[cur ^ 1][k] = stash.get(nl * C + nc, k);
+                for (int k = 0; k < 3; ++k) dq[cur ^ 1][k] = sget(nl, nc, k);
             }
             const double2 s0 = dq[cur][0], s1 = dq[cur][1], s2 = dq[cur][2];
             const double F00 = s0.x, F01 = s0.y, F11 = s1.x, f0 = s1.y, f1 = s2.x;
@@ -545,9 +558,9 @@ __device__ __forceinline__ void wl_chunk(const double *sCam, const WlStash stash
                 apply_LinvT(ps[l], u0, u1, u2);
                 U[r][0] = u0; U[r][1] = u1; U[r][2] = u2;
             }
-            stash.put(l * C + c, 0, U[0][0], U[0][1]);
-            stash.put(l * C + c, 1, U[0][2], U[1][0]);
-            stash.put(l * C + c, 2, U[1][1], U[1][2]);
+            sput(l, c, 0, U[0][0], U[0][1]);
+            sput(l, c, 1, U[0][2], U[1][0]);
+            sput(l, c, 2, U[1][1], U[1][2]);
             const double k00 = F00 - fma(U[0][0], U[0][0], fma(U[0][1], U[0][1], U[0][2] * U[0][2]));
             const double k01 = F01 - fma(U[0][0], U[1][0], fma(U[0][1], U[1][1], U[0][2] * U[1][2]));
             const double k11 = F11 - fma(U[1][0], U[1][0], fma(U[1][1], U[1][1], U[1][2] * U[1][2]));
@@ -599,7 +612,7 @@ __device__ __forceinline__ void wl_chunk(const double *sCam, const WlStash stash
     constexpr int NP = C * (C - 1) / 2;
     double2 pq[2][6];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { pq[0][k] = stash.get(0, k); pq[0][3 + k] = stash.get(1, k); }      // pair (0, 1), landmark 0
+    for (int k = 0; k < 3; ++k) { pq[0][k] = sget(0, 0, k); pq[0][3 + k] = sget(0, 1, k); }      // pair (0, 1), landmark 0
 #pragma unroll
     for (int pair = 0; pair < NP; ++pair) {
         {
@@ -612,7 +625,7 @@ __device__ __forceinline__ void wl_chunk(const double *sCam, const WlStash stash
                     const int nl = (l + 1 < L) ? l + 1 : 0, np = (l + 1 < L) ? pair : pair + 1;
                     const int nc = wl_pair_c<C>(np), nd = wl_pair_d<C>(np);
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) { pq[cur ^ 1][k] = stash.get(nl * C + nc, k); pq[cur ^ 1][3 + k] = stash.get(nl * C + nd, k); }
+                    for (int k = 0; k < 3; ++k) { pq[cur ^ 1][k] = sget(nl, nc, k); pq[cur ^ 1][3 + k] = sget(nl, nd, k); }
                 }
                 const double2 a0 = pq[cur][0], a1 = pq[cur][1], a2 = pq[cur][2];
                 const double2 e0 = pq[cur][3], e1 = pq[cur][4], e2 = pq[cur][5];
@@ -670,13 +683,13 @@ __global__ __launch_bounds__(kBlock, 1) void ba_linearize_wave_kernel(
     // and keeps a camera's constants in registers over its three landmarks instead of re-reading them after every write
     __shared__ double sCam[C * kCamStride];
     extern __shared__ __attribute__((aligned(16))) unsigned char wl_smem[];
-    double2 *sStash = reinterpret_cast<double2 *>(wl_smem);                                // [kWaveLinMaxL * C * 3][kBlock]
+    double2 *sStash = reinterpret_cast<double2 *>(wl_smem);                                // [kWaveLinLdsL * C * 3][kBlock]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     stage_cams<C>(poses, calib, sigma, sCam, tid);
 
     // window totals of this wave: a row in Layout<C> numbering behind the stash (entry j of a window lives in lanes 2j, 2j+1)
-    double *sTot = reinterpret_cast<double *>(wl_smem + sizeof(double2) * kWaveLinMaxL * C * 3 * kBlock);   // [kWaves][kRow]
+    double *sTot = reinterpret_cast<double *>(wl_smem + sizeof(double2) * kWaveLinLdsL * C * 3 * kBlock);   // [kWaves][kRow]
     double *tot = sTot + wave * kRow;
     for (int k = lane; k < kRow; k += 64) tot[k] = 0.0;
     mqs_wave_lds_sync();
@@ -692,8 +705,11 @@ __global__ __launch_bounds__(kBlock, 1) void ba_linearize_wave_kernel(
         const int nl = left >= kWaveLinMaxL ? kWaveLinMaxL : (int)left;
 #if defined(MQS_WL_ONLY_L3)      // ISA counting only (tools/isa_mix.py --define MQS_WL_ONLY_L3): one body in the listing
         wl_chunk<C, 3>(sCam, stash, points, obs2, mask, prior_w, prior_xyz, N, lambda, r, lane, tot);
+#elif defined(MQS_WL_ONLY_L4)
+        wl_chunk<C, 4>(sCam, stash, points, obs2, mask, prior_w, prior_xyz, N, lambda, r, lane, tot);
 #else
-        if (nl == 3) wl_chunk<C, 3>(sCam, stash, points, obs2, mask, prior_w, prior_xyz, N, lambda, r, lane, tot);
+        if (nl == 4) wl_chunk<C, 4>(sCam, stash, points, obs2, mask, prior_w, prior_xyz, N, lambda, r, lane, tot);
+        else if (nl == 3) wl_chunk<C, 3>(sCam, stash, points, obs2, mask, prior_w, prior_xyz, N, lambda, r, lane, tot);
         else if (nl == 2) wl_chunk<C, 2>(sCam, stash, points, obs2, mask, prior_w, prior_xyz, N, lambda, r, lane, tot);
         else wl_chunk<C, 1>(sCam, stash, points, obs2, mask, prior_w, prior_xyz, N, lambda, r, lane, tot);
 #endif
@@ -1109,7 +1125,7 @@ static int ba_linearize_parts(const double *poses, const double *calib, const do
         int grid = (int)((rows + kWaves - 1) / kWaves);
         if (grid < 1) grid = 1;
         if (grid > 256) grid = 256;
-        const size_t lds = (size_t)kWaveLinMaxL * C * 3 * kBlock * sizeof(double2) + (size_t)kWaves * 352 * sizeof(double);   // 352 = Layout<4>'s row, the largest here
+        const size_t lds = (size_t)kWaveLinLdsL * C * 3 * kBlock * sizeof(double2) + (size_t)kWaves * 352 * sizeof(double);   // 352 = Layout<4>'s row, the largest here
         switch (C) {
 #define MQS_CASE(c)                                                                                        \
     case c: {                                                                                              \
