@@ -107,20 +107,29 @@ class CComm:
 def init_c_comm(rank, world, device_index):
     """Creates this rank's library context on `device_index` and joins the RCCL communicator of `world` ranks.  The 128-byte
     unique id is made on rank 0 and carried to the other ranks by the torch.distributed group that `init_from_env`
-    initialised (any host-side channel would do: the C ABI only sees the bytes).  Collective: every rank must call it."""
+    initialised (any host-side channel would do: the C ABI only sees the bytes).  Collective: every rank must call it.
+    Before the (blocking, collective) communicator set-up every rank checks locally that RCCL can be bound and the ranks
+    agree on that over the torch group, so that a rank without it makes ALL ranks raise instead of leaving the others
+    waiting inside the collective."""
     import ctypes
     import torch
     import torch.distributed as dist
     from . import _lib
     L = _lib.lib()
     ident = (ctypes.c_uint8 * 128)()
-    if rank == 0:
-        _lib.check(L.mqs_comm_unique_id(ident))
+    rc = L.mqs_comm_unique_id(ident)                  # binds RCCL (dlopen) and makes an id: only rank 0's is used
     if world > 1:
         on_gpu = dist.get_backend() == "nccl"
-        t = torch.tensor(list(ident), dtype=torch.uint8, device=torch.device("cuda", device_index) if on_gpu else "cpu")
+        dev = torch.device("cuda", device_index) if on_gpu else torch.device("cpu")
+        ok = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) != 1:
+            raise RuntimeError("RCCL is not available on every rank (%s)" % (L.mqs_last_error().decode() if rc else "another rank",))
+        t = torch.tensor(list(ident), dtype=torch.uint8, device=dev)
         dist.broadcast(t, src=0)
         ident = (ctypes.c_uint8 * 128)(*t.cpu().tolist())
+    else:
+        _lib.check(rc)
     ctx = _lib.Context(device_index)
     _lib.check(L.mqs_comm_init_rank(ctx.handle, ident, rank, world))
     return CComm(ctx, rank, world)
