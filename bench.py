@@ -171,7 +171,8 @@ def main():
     rank, local_rank, world = sh.init_from_env(backend="nccl")
     args.gpus = world
     transport, group = None, None
-    if world > 1:
+    multi = world > 1 or os.environ.get("MQS_FORCE_DIST", "0") == "1"       # the latter: the N-GPU code path with one rank (tests)
+    if multi:
         import torch.distributed as dist
         group, transport = True, "torch.distributed(%s)" % dist.get_backend()
         if dist.get_backend() == "nccl" and os.environ.get("MQS_TRANSPORT", "c") == "c":
@@ -195,6 +196,8 @@ def main():
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank if world > 1 else 0)
+    if multi and world == 1:
+        torch.cuda.set_device(0)
 
     C = args.cams
     syn = mqslam_amd.synthetic
@@ -224,7 +227,7 @@ def main():
         # perturbation uses the same seed on every rank
         D.iterative_LS_triangulation(ud, Pd, out=x_it, out_status=st)
         ba = mqslam_amd.bundle_adjustment.make_benchmark_problem(
-            u, P, x_it, dev, seed=syn.RSEED, process_group=group if world > 1 else None,
+            u, P, x_it, dev, seed=syn.RSEED, process_group=group if multi else None,
             prior_first=4 if (rank == 0 or not strong) else 0)
 
     def triangulate():
@@ -594,7 +597,7 @@ def main():
                           "status_mismatch_frac": float(np.mean(st[:ns].cpu().numpy() != so))}}
 
     strong_out = None
-    if world > 1 and ba is not None:
+    if multi and ba is not None:
         strong_out = ba_strong_leg(mqslam_amd, np, torch, args.landmarks if strong else args.strong_landmarks, C, rank, world,
                                    dev, group, dist)
 

@@ -63,7 +63,9 @@ def init_from_env(backend="nccl"):
     backend = os.environ.get("MQS_DIST_BACKEND", backend)
     if os.environ.get("MQS_SHARED_GPU", "0") == "1":
         local_rank = 0
-    if world > 1 and not dist.is_initialized():
+    # MQS_FORCE_DIST=1: initialise the group even for ONE rank, so that a 1-GPU box can run the N-GPU code path of bench.py
+    # (transport probe, C-ABI communicator, ba_strong) on the real backend
+    if (world > 1 or os.environ.get("MQS_FORCE_DIST", "0") == "1") and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         if backend == "nccl":
@@ -118,7 +120,7 @@ def init_c_comm(rank, world, device_index):
     L = _lib.lib()
     ident = (ctypes.c_uint8 * 128)()
     rc = L.mqs_comm_unique_id(ident)                  # binds RCCL (dlopen) and makes an id: only rank 0's is used
-    if world > 1:
+    if dist.is_available() and dist.is_initialized():
         on_gpu = dist.get_backend() == "nccl"
         dev = torch.device("cuda", device_index) if on_gpu else torch.device("cpu")
         ok = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32, device=dev)
@@ -128,6 +130,8 @@ def init_c_comm(rank, world, device_index):
         t = torch.tensor(list(ident), dtype=torch.uint8, device=dev)
         dist.broadcast(t, src=0)
         ident = (ctypes.c_uint8 * 128)(*t.cpu().tolist())
+    elif world > 1:
+        raise RuntimeError("init_c_comm needs an initialised torch.distributed group to carry the communicator id")
     else:
         _lib.check(rc)
     ctx = _lib.Context(device_index)

@@ -136,3 +136,58 @@ def test_bench_contract_single_gpu(gpu):
     assert cb["parity"]["rel_err_p99.9"] < 1e-5 and cb["parity"]["status_mismatch_frac"] < 0.005
     assert out["match"]["packed_bits_int8"]["equals_fp16_path"] is True
     assert out["match"]["cross_match_4_cameras"]["pairs_this_rank"] == 6
+
+
+def test_nccl_backend_plumbing_single_rank(gpu, tmp_path):
+    """What a 1-GPU box can run of the N-GPU path with the REAL backend: a torch.distributed group on `nccl` (= RCCL) with one
+    rank, the communicator id agreed and broadcast over it (sharding.init_c_comm), the library's own RCCL communicator, a
+    sharded-API BundleAdjuster on it, and bench.py's transport probe.  (Two RCCL ranks cannot share one device.)"""
+    script = tmp_path / "nccl1.py"
+    script.write_text(r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29700 + os.getpid() %% 200))
+import torch, torch.distributed as dist
+import mqslam_amd
+from ba_util import make_scene
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+cc = mqslam_amd.sharding.init_c_comm(0, 1, 0)
+probe = torch.arange(602, dtype=torch.float64, device="cuda")
+want = probe.clone(); dist.all_reduce(want)
+cc.all_reduce_sum_(probe); torch.cuda.synchronize()
+assert torch.equal(probe, want)
+sc = make_scene(500, 4, seed=2)
+t = lambda a, dt=torch.float64: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).cuda().to(dt)
+mk = lambda pg: mqslam_amd.bundle_adjustment.BundleAdjuster(t(sc["poses"]), t(sc["calib"]), t(sc["sigma"]), t(sc["points"]), t(sc["obs"]),
+                                                           None, t(sc["prior_w"]), t(sc["prior_xyz"]), None, pg)
+a, b, c = mk(cc), mk(True), mk(None)
+for ba in (a, b, c):
+    ba.gauss_newton_iterations(3)
+torch.cuda.synchronize()
+assert torch.equal(a.poses, c.poses) and torch.equal(b.poses, c.poses) and torch.equal(a.points, c.points)
+assert a.total_cost() == c.total_cost() == b.total_cost()
+dist.barrier(); cc.close(); dist.destroy_process_group()
+print("nccl-ok")
+""" % (ROOT, ROOT))
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600,
+                       env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+    assert r.returncode == 0 and "nccl-ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_bench_multi_gpu_code_path_on_the_real_backend(gpu):
+    """bench.py's N-GPU branch (nccl process group, the library's RCCL communicator verified against torch's sum, the one-call
+    iteration with the collective issued from C, the ba_strong leg) with ONE rank: everything a 1-GPU box can run of what
+    `python bench.py --gpus 8` runs."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MQS_DIST_BACKEND", "MQS_SHARED_GPU")}
+    env.update(MQS_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29900 + os.getpid() % 90))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--landmarks", "20000",
+                        "--strong-landmarks", "30001", "--no-match", "--no-replay", "--no-frontend", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 1 and out["transport"].startswith("rccl via the C ABI"), out["transport"]
+    bs = out["ba_strong"]
+    assert bs["ok"] is True and bs["backend"] == "nccl" and bs["rccl_world_size"] == 1 and bs["all_reduce_us"] > 0
+    assert bs["max_abs_pose_diff_vs_one_rank"] == 0.0          # one rank: the sharded run IS the one-rank run
