@@ -193,11 +193,14 @@ def test_grouped_pair_blocks_are_reproducible_and_equal_the_atomic_path(gpu):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", [(50, 300), (200, 101), (250, 1500), (100, 17), (1, 6), (300, 1800)])
+@pytest.mark.parametrize("case", [(50, 300), (200, 101), (250, 1500), (100, 17), (1, 6), (300, 1800), (881, 101), (97, 102), (90, 35),
+                                  (333, 65), (120, 103)])
 def test_reduced_system_solve_against_numpy(case, gpu):
     """mqs_sba_solve_banded_dev on random symmetric positive definite systems: a narrow band (blocked factorisation +
     product-form substitutions), dense systems small enough for one panel chunk in LDS, dense systems that need the chunked
-    substitution, and one above the library threshold; with and without damping."""
+    substitution, and one above the library threshold; with and without damping.  Half bandwidths <= 102 take the persistent
+    LDS-window factorisation (n = 5286 / hb = 101 is the ICL kt2 shape; sizes that are not multiples of the 32-wide block,
+    bands narrower than a block, the last window shorter than the band), 103 the three-launch form."""
     import ctypes
     import torch
     P_, hb = case
