@@ -284,3 +284,55 @@ def test_gtsam_style_damping(gpu):
     assert hb[-1] == pytest.approx(ha[-1], rel=3e-3), (ha[-1], hb[-1])
     assert all(y <= x for x, y in zip(hb, hb[1:])) and hb[-1] < 0.05 * hb[0]
     assert np.abs(a.poses.cpu().numpy() - b.poses.cpu().numpy()).max() < 2e-2
+
+
+@pytest.mark.parametrize("case", [dict(N=180_001, C=4), dict(N=150_000, C=3, masked=True), dict(N=70_000, C=2),
+                                  dict(N=262_144 + 63, C=4, masked=True, lam=1e-3)])
+def test_wave_lineariser_every_chunk_size_against_the_c_oracle(case, gpu, c_oracle):
+    """Sizes at which a wave of the wave-level lineariser owns 1 to 5 rows of 64 landmarks, i.e. walks chunks of 1, 2, 3 and 4
+    landmarks per lane (the 1e6 test only sees chunks of 4 and 3; the small cases only chunks of 1): reduced system, gradient,
+    cost and count against the oracle's C port on the whole problem, priors on scattered landmarks, a mask with unseen
+    factors and NaN measurements behind it, and the round-1 kernel (MQS_BA_LINEARIZER=lane is a process-wide switch, so it
+    is compared through shard additivity instead: the sum of two shards' systems equals the whole)."""
+    import torch
+    N, C = case["N"], case["C"]
+    syn = gpu.synthetic
+    u, P, pts = syn.triangulation_problem(N, C)
+    rng = np.random.default_rng(N)
+    ba = gpu.bundle_adjustment.make_benchmark_problem(u, P, pts + 0.03 * rng.standard_normal(pts.shape), torch.device("cuda", 0), seed=2)
+    pw = np.zeros(N)
+    sel = rng.choice(N, 5000, replace=False)
+    pw[sel] = rng.uniform(1.0, 30.0, 5000)
+    ba.prior_w.copy_(torch.from_numpy(pw))
+    mask = None
+    if case.get("masked"):
+        mask = (rng.random((C, N)) > 0.2).astype(np.uint8)
+        mask[:2] = 1
+        obs = ba.obs.cpu().numpy()
+        obs[mask == 0] = np.nan                                # a masked slot may hold anything
+        ba.obs.copy_(torch.from_numpy(obs))
+        BA = gpu.bundle_adjustment.BundleAdjuster
+        ba = BA(ba.poses, ba.calib, ba.sigma, ba.points, ba.obs, torch.from_numpy(mask).cuda(), ba.prior_w, ba.prior_xyz)
+    lam = case.get("lam", 0.0)
+    S, g, cost, nv = split_lin(ba.linearize(lam), C)
+    h = lambda t: None if t is None else t.cpu().numpy()
+    obs_h = np.nan_to_num(h(ba.obs))                           # the oracle multiplies masked slots by 0
+    So, go, co, nvo = c_oracle.ba_linearize(h(ba.poses), h(ba.calib), h(ba.sigma), h(ba.points), obs_h, mask, h(ba.prior_w),
+                                            h(ba.prior_xyz), lam, use_omp=True)
+    assert np.abs(S - So).max() <= 1e-10 * np.abs(So).max()
+    assert np.abs(g - go).max() <= 1e-10 * np.abs(go).max()
+    assert cost == pytest.approx(co, rel=1e-11) and nv == nvo
+    np.testing.assert_array_equal(S, S.T)
+    lin2 = ba.linearize(lam).clone()
+    assert torch.equal(lin2, ba.linearize(lam))                  # bitwise reproducible
+    # shard additivity at an uneven cut (the shards walk different chunk patterns than the whole)
+    cut = N // 3 + 17
+    BA = gpu.bundle_adjustment.BundleAdjuster
+    parts = []
+    for sl in (slice(0, cut), slice(cut, N)):
+        m = None if ba.mask is None else ba.mask[:, sl].clone()
+        sub = BA(ba.poses, ba.calib, ba.sigma, ba.points[sl].clone(), ba.obs[:, sl].clone(), m, ba.prior_w[sl].clone(),
+                 ba.prior_xyz[sl].clone())
+        parts.append(sub.linearize(lam).clone())
+    tot = (parts[0] + parts[1]).cpu().numpy()
+    assert np.abs(tot - lin2.cpu().numpy()).max() <= 1e-10 * np.abs(lin2.cpu().numpy()).max()
