@@ -291,6 +291,9 @@ __global__ __launch_bounds__(kBlock, 2) void ba_linearize_kernel(
 // Results: same formulas as landmark_contribution (ba_math.h), sums in a different, still fixed, order -- bitwise
 // reproducible run to run.
 // ---------------------------------------------------------------------------------------------------------------------
+#ifndef MQS_WL_ONLY_NODIST
+#define MQS_WL_ONLY_NODIST 0
+#endif
 constexpr int kWaveLinMaxL = 4;            // landmarks per lane and chunk
 constexpr int kWaveLinLdsL = 3;            // of which this many park their six doubles per camera in LDS; the fourth one's live in AGPRs
 
@@ -389,6 +392,7 @@ __device__ __forceinline__ void a_add(AReg &r, double v) { a_put(r, a_get(r) + v
 // make_factor of ba_math.h with ONE select where that one has sixteen: an unused factor (masked, or behind its camera) gets
 // the scale 0, which makes E, F and f exact zeros, and its x, y, Z -- finite by construction: a point behind the camera is
 // divided by 1 -- then only ever multiply zeros downstream (Uh = F PR L^-T = 0, k = 0, T = 0).  u, v must be finite.
+template <bool NODIST>
 __device__ __forceinline__ Factor wl_make_factor(const double *cam, double px, double py, double pz, double u, double v, bool seen)
 {
     Factor o;
@@ -400,27 +404,41 @@ __device__ __forceinline__ Factor wl_make_factor(const double *cam, double px, d
     const double iz = mqs::rcp(front ? Z : 1.0);
     const double x = X * iz, y = Y * iz;
     const double fx = cam[12], fy = cam[13], sk = cam[14], u0 = cam[15], v0 = cam[16];
-    const double k1 = cam[17], k2 = cam[18], p1 = cam[19], p2 = cam[20], isig = cam[21];
-    const double xx = x * x, yy = y * y, xy = x * y;
-    const double r2 = xx + yy;
-    const double g = fma(r2, fma(k2, r2, k1), 1.0);
-    const double dg = fma(2.0 * k2, r2, k1);
-    const double xd = fma(g, x, fma(2.0 * p1, xy, p2 * fma(2.0, xx, r2)));
-    const double yd = fma(g, y, fma(2.0 * p2, xy, p1 * fma(2.0, yy, r2)));
-    const double eu = (fma(fx, xd, fma(sk, yd, u0)) - u) * isig;
-    const double ev = (fma(fy, yd, v0) - v) * isig;
-    const double a = fma(2.0 * xx, dg, g) + 2.0 * p1 * y + 6.0 * p2 * x;
-    const double b = fma(2.0 * xy, dg, 2.0 * p1 * x) + 2.0 * p2 * y;
-    const double d = fma(2.0 * yy, dg, g) + 2.0 * p2 * x + 6.0 * p1 * y;
+    const double isig = cam[21];
     const bool ok = seen && front;
     const double sc = ok ? isig * iz : 0.0;
-    const double E00 = fma(fx, a, sk * b) * sc, E01 = fma(fx, b, sk * d) * sc;
-    const double E10 = fy * b * sc, E11 = fy * d * sc;
+    double eu, ev, E00, E01, E10, E11;
+    if (NODIST) {                                  // no lens distortion on any camera (kernel-uniform): E = K / (sigma Z)
+        eu = (fma(fx, x, fma(sk, y, u0)) - u) * isig;
+        ev = (fma(fy, y, v0) - v) * isig;
+        E00 = fx * sc; E01 = sk * sc; E10 = 0.0; E11 = fy * sc;
+    } else {
+        const double k1 = cam[17], k2 = cam[18], p1 = cam[19], p2 = cam[20];
+        const double xx = x * x, yy = y * y, xy = x * y;
+        const double r2 = xx + yy;
+        const double g = fma(r2, fma(k2, r2, k1), 1.0);
+        const double dg = fma(2.0 * k2, r2, k1);
+        const double xd = fma(g, x, fma(2.0 * p1, xy, p2 * fma(2.0, xx, r2)));
+        const double yd = fma(g, y, fma(2.0 * p2, xy, p1 * fma(2.0, yy, r2)));
+        eu = (fma(fx, xd, fma(sk, yd, u0)) - u) * isig;
+        ev = (fma(fy, yd, v0) - v) * isig;
+        const double a = fma(2.0 * xx, dg, g) + 2.0 * p1 * y + 6.0 * p2 * x;
+        const double b = fma(2.0 * xy, dg, 2.0 * p1 * x) + 2.0 * p2 * y;
+        const double d = fma(2.0 * yy, dg, g) + 2.0 * p2 * x + 6.0 * p1 * y;
+        E00 = fma(fx, a, sk * b) * sc; E01 = fma(fx, b, sk * d) * sc;
+        E10 = fy * b * sc; E11 = fy * d * sc;
+    }
     o.x = x; o.y = y; o.Z = front ? Z : 1.0;
-    o.F00 = fma(E00, E00, E10 * E10);
-    o.F01 = fma(E00, E01, E10 * E11);
+    if (NODIST) {                                  // E10 = 0
+        o.F00 = E00 * E00;
+        o.F01 = E00 * E01;
+        o.f0 = E00 * eu;
+    } else {
+        o.F00 = fma(E00, E00, E10 * E10);
+        o.F01 = fma(E00, E01, E10 * E11);
+        o.f0 = fma(E00, eu, E10 * ev);
+    }
     o.F11 = fma(E01, E01, E11 * E11);
-    o.f0 = fma(E00, eu, E10 * ev);
     o.f1 = fma(E01, eu, E11 * ev);
     const double ce = cam[22];
     o.half_e2 = seen ? (front ? 0.5 * fma(eu, eu, ev * ev) : ce * ce) : 0.0;
@@ -432,7 +450,7 @@ __device__ __forceinline__ Factor wl_make_factor(const double *cam, double px, d
 // feeds them: 4 cameras x 3 landmarks x 15 doubles) down to their first use after the loop and parks them in between.
 __device__ __forceinline__ void wl_pin(double &x) { asm volatile("" : "+v"(x)); }
 
-template <int C, int L>
+template <int C, int L, bool NODIST>
 __device__ __forceinline__ void wl_chunk(const double *sCam, const WlStash stash, const double *__restrict__ points,
                                          const double2 *__restrict__ obs2, const uint8_t *__restrict__ mask,
                                          const double *__restrict__ prior_w, const double *__restrict__ prior_xyz, int64_t N,
@@ -497,7 +515,7 @@ __device__ __forceinline__ void wl_chunk(const double *sCam, const WlStash stash
             const bool seen = live[l] && (mask ? mask[(int64_t)c * N + idx[l]] != 0 : true);
             // a masked slot may hold NaN: selects, not products
             const double u = seen ? ob[c & 1][l].x : 0.0, v = seen ? ob[c & 1][l].y : 0.0;
-            const Factor fc = wl_make_factor(cam, px[l], py[l], pz[l], u, v, seen);
+            const Factor fc = wl_make_factor<NODIST>(cam, px[l], py[l], pz[l], u, v, seen);
             double PR[2][3];
             make_PR(cam, fc.x, fc.y, PR);
             point_add_factor(ps[l], fc, PR);
@@ -700,19 +718,28 @@ __global__ __launch_bounds__(kBlock, 1) void ba_linearize_wave_kernel(
     const int64_t r_begin = rows * gw / nw, r_end = rows * (gw + 1) / nw;
     const WlStash stash = {sStash + tid};
     const double2 *obs2 = reinterpret_cast<const double2 *>(obs);
+    bool nodist = true;
+#pragma unroll
+    for (int c = 0; c < C; ++c) nodist = nodist && camera_without_distortion(sCam + kCamStride * c);
     for (int64_t r = r_begin; r < r_end;) {
         const int64_t left = r_end - r;
         const int nl = left >= kWaveLinMaxL ? kWaveLinMaxL : (int)left;
-#if defined(MQS_WL_ONLY_L3)      // ISA counting only (tools/isa_mix.py --define MQS_WL_ONLY_L3): one body in the listing
-        wl_chunk<C, 3>(sCam, stash, points, obs2, mask, prior_w, prior_xyz, N, lambda, r, lane, tot);
-#elif defined(MQS_WL_ONLY_L4)
-        wl_chunk<C, 4>(sCam, stash, points, obs2, mask, prior_w, prior_xyz, N, lambda, r, lane, tot);
+        // cameras without lens distortion (all of them: decided once per kernel, wave-uniform) take bodies without the distortion
+        // model; the bodies are whole chunks, so the instruction stream of a launch never contains the other variant
+#define MQS_WL_CALL(LL)                                                                                                   \
+    do {                                                                                                                  \
+        if (nodist) wl_chunk<C, LL, true>(sCam, stash, points, obs2, mask, prior_w, prior_xyz, N, lambda, r, lane, tot);  \
+        else wl_chunk<C, LL, false>(sCam, stash, points, obs2, mask, prior_w, prior_xyz, N, lambda, r, lane, tot);        \
+    } while (0)
+#if defined(MQS_WL_ONLY_L4)      // ISA counting only (tools/isa_mix.py --define MQS_WL_ONLY_L4 [--define MQS_WL_ONLY_NODIST=1]): one body
+        wl_chunk<C, 4, MQS_WL_ONLY_NODIST>(sCam, stash, points, obs2, mask, prior_w, prior_xyz, N, lambda, r, lane, tot);
 #else
-        if (nl == 4) wl_chunk<C, 4>(sCam, stash, points, obs2, mask, prior_w, prior_xyz, N, lambda, r, lane, tot);
-        else if (nl == 3) wl_chunk<C, 3>(sCam, stash, points, obs2, mask, prior_w, prior_xyz, N, lambda, r, lane, tot);
-        else if (nl == 2) wl_chunk<C, 2>(sCam, stash, points, obs2, mask, prior_w, prior_xyz, N, lambda, r, lane, tot);
-        else wl_chunk<C, 1>(sCam, stash, points, obs2, mask, prior_w, prior_xyz, N, lambda, r, lane, tot);
+        if (nl == 4) MQS_WL_CALL(4);
+        else if (nl == 3) MQS_WL_CALL(3);
+        else if (nl == 2) MQS_WL_CALL(2);
+        else MQS_WL_CALL(1);
 #endif
+#undef MQS_WL_CALL
         r += nl;
     }
     // waves -> workgroup -> this workgroup's row of partials (Layout<C> numbering: ba_finalize_kernel serves both linearisers)

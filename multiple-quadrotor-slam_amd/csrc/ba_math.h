@@ -52,7 +52,22 @@ MQS_HD void stage_camera(double *dst, const double *pose12, const double *calib9
     for (int k = 0; k < 9; ++k) dst[12 + k] = calib9[k];
     dst[21] = 1.0 / sigma;
     dst[22] = 2.0 * calib9[0] / sigma;
-    dst[23] = 0.0;
+    // a camera without lens distortion (k1 = k2 = p1 = p2 = 0: the benchmark's Cal3DS2(480, 480, 0, 320, 240, 0, 0, 0, 0) and every
+    // rectified data set): flagged once here, so that the kernels whose camera is wave-uniform can skip the distortion model
+    // and its 2 x 2 Jacobian (~ 40 of a factor's ~ 100 instructions) -- see make_factor
+    dst[23] = (calib9[5] == 0.0 && calib9[6] == 0.0 && calib9[7] == 0.0 && calib9[8] == 0.0) ? 1.0 : 0.0;
+}
+
+// The flag of a camera block as a wave-uniform value (a scalar branch on the device).  ONLY for kernels in which every lane of a
+// wave works on the same camera (the dense-visibility kernels); the sparse kernels, where the camera follows the observation,
+// pass false to make_factor.
+MQS_HD bool camera_without_distortion(const double *cam)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_readfirstlane((int)(cam[23] != 0.0)) != 0;
+#else
+    return cam[23] != 0.0;
+#endif
 }
 
 // One projection factor, reduced to what the elimination needs.
@@ -65,8 +80,10 @@ struct Factor {
 };
 
 // cam: staged camera block.  uv: measurement.  observed == false -> contributes nothing.
+// nodist: the camera has no lens distortion (must be wave-uniform on the device): g = 1 and the distortion Jacobian is the
+// identity, so E = K / (sigma Z).  Same values as the general path (it multiplies by exact ones and zeros there).
 MQS_HD Factor make_factor(const double *cam, const double px, const double py, const double pz, double u,
-                          double v, bool observed)
+                          double v, bool observed, bool nodist = false)
 {
     Factor o;
     const double dx = px - cam[9], dy = py - cam[10], dz = pz - cam[11];
@@ -78,23 +95,31 @@ MQS_HD Factor make_factor(const double *cam, const double px, const double py, c
     const double iz = rcp(front ? Z : 1.0);
     const double x = X * iz, y = Y * iz;
     const double fx = cam[12], fy = cam[13], sk = cam[14], u0 = cam[15], v0 = cam[16];
-    const double k1 = cam[17], k2 = cam[18], p1 = cam[19], p2 = cam[20], isig = cam[21];
-    const double xx = x * x, yy = y * y, xy = x * y;
-    const double r2 = xx + yy;
-    const double g = fma(r2, fma(k2, r2, k1), 1.0);
-    const double dg = fma(2.0 * k2, r2, k1);
-    const double xd = fma(g, x, fma(2.0 * p1, xy, p2 * fma(2.0, xx, r2)));
-    const double yd = fma(g, y, fma(2.0 * p2, xy, p1 * fma(2.0, yy, r2)));
-    const double eu = (fma(fx, xd, fma(sk, yd, u0)) - u) * isig;
-    const double ev = (fma(fy, yd, v0) - v) * isig;
-    // 2x2 distortion Jacobian
-    const double a = fma(2.0 * xx, dg, g) + 2.0 * p1 * y + 6.0 * p2 * x;
-    const double b = fma(2.0 * xy, dg, 2.0 * p1 * x) + 2.0 * p2 * y;
-    const double d = fma(2.0 * yy, dg, g) + 2.0 * p2 * x + 6.0 * p1 * y;
-    // E = [[fx, sk],[0, fy]] * [[a, b],[b, d]] * (isig / Z)
+    const double isig = cam[21];
     const double sc = isig * iz;
-    const double E00 = fma(fx, a, sk * b) * sc, E01 = fma(fx, b, sk * d) * sc;
-    const double E10 = fy * b * sc, E11 = fy * d * sc;
+    double eu, ev, E00, E01, E10, E11;
+    if (nodist) {
+        eu = (fma(fx, x, fma(sk, y, u0)) - u) * isig;
+        ev = (fma(fy, y, v0) - v) * isig;
+        E00 = fx * sc; E01 = sk * sc; E10 = 0.0; E11 = fy * sc;
+    } else {
+        const double k1 = cam[17], k2 = cam[18], p1 = cam[19], p2 = cam[20];
+        const double xx = x * x, yy = y * y, xy = x * y;
+        const double r2 = xx + yy;
+        const double g = fma(r2, fma(k2, r2, k1), 1.0);
+        const double dg = fma(2.0 * k2, r2, k1);
+        const double xd = fma(g, x, fma(2.0 * p1, xy, p2 * fma(2.0, xx, r2)));
+        const double yd = fma(g, y, fma(2.0 * p2, xy, p1 * fma(2.0, yy, r2)));
+        eu = (fma(fx, xd, fma(sk, yd, u0)) - u) * isig;
+        ev = (fma(fy, yd, v0) - v) * isig;
+        // 2x2 distortion Jacobian
+        const double a = fma(2.0 * xx, dg, g) + 2.0 * p1 * y + 6.0 * p2 * x;
+        const double b = fma(2.0 * xy, dg, 2.0 * p1 * x) + 2.0 * p2 * y;
+        const double d = fma(2.0 * yy, dg, g) + 2.0 * p2 * x + 6.0 * p1 * y;
+        // E = [[fx, sk],[0, fy]] * [[a, b],[b, d]] * (isig / Z)
+        E00 = fma(fx, a, sk * b) * sc; E01 = fma(fx, b, sk * d) * sc;
+        E10 = fy * b * sc; E11 = fy * d * sc;
+    }
     const bool ok = observed && front;
     // selects, not multiplications by 0: masked / behind-camera slots may hold NaN measurements
     o.x = ok ? x : 0.0; o.y = ok ? y : 0.0; o.Z = ok ? Z : 1.0;
@@ -277,7 +302,7 @@ MQS_HD Factor add_camera(const double *cam, const Obs &obs, int c, double px, do
     double u, v;
     bool seen;
     obs.get(c, u, v, seen);
-    const Factor fc = make_factor(cam, px, py, pz, u, v, seen && live);
+    const Factor fc = make_factor(cam, px, py, pz, u, v, seen && live, camera_without_distortion(cam));
     double PR[2][3];
     make_PR(cam, fc.x, fc.y, PR);
     point_add_factor(ps, fc, PR);
@@ -349,7 +374,7 @@ MQS_HD void landmark_contribution(const double *cams, const Obs &obs, double px,
             double u, v;
             bool seen;
             obs.get(c, u, v, seen);
-            fc = make_factor(cam, px, py, pz, u, v, seen && live);
+            fc = make_factor(cam, px, py, pz, u, v, seen && live, camera_without_distortion(cam));
         }
         cx[c] = fc.x; cy[c] = fc.y; cZ[c] = fc.Z;
         double PR[2][3];
@@ -424,7 +449,7 @@ MQS_HD Vec3 landmark_backsub(const double *cams, const Obs &obs, double px, doub
         double u, v;
         bool seen;
         obs.get(c, u, v, seen);
-        const Factor fc = make_factor(cam, px, py, pz, u, v, seen);
+        const Factor fc = make_factor(cam, px, py, pz, u, v, seen, camera_without_distortion(cam));
         double PR[2][3];
         make_PR(cam, fc.x, fc.y, PR);
         point_add_factor(ps, fc, PR);
@@ -464,7 +489,7 @@ MQS_HD void landmark_cost(const double *cams, const Obs &obs, double px, double 
         double u, v;
         bool seen;
         obs.get(c, u, v, seen);
-        const Factor fc = make_factor(cams + kCamStride * c, px, py, pz, u, v, seen);
+        const Factor fc = make_factor(cams + kCamStride * c, px, py, pz, u, v, seen, camera_without_distortion(cams + kCamStride * c));
         cost += fc.half_e2;
         count += fc.valid ? 1.0 : 0.0;
     }
