@@ -656,6 +656,130 @@ __global__ __launch_bounds__(kBlock) void chol_update_kernel(double *__restrict_
     if (r0 + 1 < n && c0 + 1 < n && c0 + 1 <= r0 + 1) A[(int64_t)(r0 + 1) * n + c0 + 1] -= a11;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// One launch per block column instead of three: panel, trailing update AND the next diagonal block's factorisation.
+//
+// The three-launch form costs 8.8 + 6.3 + 7.2 us per block column, each launch starting cold.  Fused, the dependency
+// between the panel (X = A inv(L)^T) and the update that consumes it crosses workgroups -- so every update tile forms the
+// two panel blocks it needs itself (2 x 32 x 32 x 32 FMAs: nothing next to a launch), and the tile that IS the next
+// diagonal block factors it on the spot (wave 0, the chol_diag_kernel arithmetic on the tile it has just updated in LDS).
+// What makes this race-free without a grid-wide barrier is where a step READS its panel input: from the mirror image in
+// the upper triangle (every update writes its tile to both triangles; the symmetric input has both), while the finished
+// panel X -- the final L entries -- is WRITTEN to the lower triangle by the tiles of the first tile column.  Nobody reads
+// what another workgroup of the same launch writes.  Diagonal blocks keep the established layout (L below, inv(L)^T above).
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void chol_step_kernel(double *__restrict__ A, int n, int k0, int hb, int *__restrict__ bad)
+{
+    const int bi = blockIdx.y, bj = blockIdx.x;
+    if (bj > bi) return;
+    const int nb = (n - k0) < NB ? (n - k0) : NB;
+    const int t0 = k0 + nb;
+    int rem = n - t0;
+    if (rem > hb) rem = hb;
+    const int i0 = t0 + bi * NB, j0 = t0 + bj * NB;             // first rows of the two panel blocks / the tile's origin
+    const int lim = t0 + rem;                                    // rows [t0, lim) take part
+    __shared__ double sLi[NB][NB + 1], sAi[NB][NB + 1], sAj[NB][NB + 1], sXi[NB][NB + 1], sXj[NB][NB + 1];
+    const int tid = threadIdx.x;
+    for (int e = tid; e < NB * NB; e += kBlock) {
+        const int a = e / NB, b = e % NB;
+        // inv(L)[a][b], lower: strictly lower part stored transposed in the diagonal block's upper triangle
+        double v = 0.0;
+        if (a < nb && b < nb) v = (b < a) ? A[(int64_t)(k0 + b) * n + k0 + a] : ((b == a) ? 1.0 / A[(int64_t)(k0 + a) * n + k0 + a] : 0.0);
+        sLi[a][b] = v;
+        // panel input rows from the MIRROR: A[i0 + r][k0 + c] = S[k0 + c][i0 + r]; here a = c (row of S), b = r (column)
+        sAi[b][a] = (a < nb && i0 + b < lim) ? A[(int64_t)(k0 + a) * n + i0 + b] : 0.0;
+        sAj[b][a] = (a < nb && j0 + b < lim) ? A[(int64_t)(k0 + a) * n + j0 + b] : 0.0;
+    }
+    __syncthreads();
+    {
+        // X = A inv(L)^T for both blocks: a thread owns a 1 x 4 strip (row r, columns 4 jq ..), so every LDS read of A feeds four
+        // FMAs, and the k loop stops at the strip's last column (inv(L) is lower triangular)
+        const int r = tid / (NB / 4), jq = (tid % (NB / 4)) * 4;
+        double xi[4] = {0, 0, 0, 0}, xj[4] = {0, 0, 0, 0};
+        for (int k = 0; k < jq + 4; ++k) {
+            const double ai = sAi[r][k], aj = sAj[r][k];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const double li = sLi[jq + c][k];
+                xi[c] = fma(ai, li, xi[c]);
+                xj[c] = fma(aj, li, xj[c]);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            sXi[r][jq + c] = xi[c];
+            sXj[r][jq + c] = xj[c];
+            if (bj == 0 && i0 + r < lim && jq + c < nb) A[(int64_t)(i0 + r) * n + k0 + jq + c] = xi[c];      // the panel: final entries of L
+        }
+    }
+    __syncthreads();
+    // tile update, 2 x 2 per thread; the new values go to both triangles (the mirror is the next steps' panel input)
+    const int tr = (tid / 16) * 2, tc = (tid % 16) * 2;
+    double a00 = 0, a01 = 0, a10 = 0, a11 = 0;
+#pragma unroll 8
+    for (int k = 0; k < NB; ++k) {
+        const double i0v = sXi[tr][k], i1v = sXi[tr + 1][k], j0v = sXj[tc][k], j1v = sXj[tc + 1][k];
+        a00 = fma(i0v, j0v, a00); a01 = fma(i0v, j1v, a01); a10 = fma(i1v, j0v, a10); a11 = fma(i1v, j1v, a11);
+    }
+    const bool next_diag = bi == 0 && bj == 0;                  // this tile is the next diagonal block
+    double *sT = &sAi[0][0];                                    // reused: the updated tile for the factorisation
+    __syncthreads();                                             // sAi is free
+    {
+        const double acc[2][2] = {{a00, a01}, {a10, a11}};
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int r = i0 + tr + a, c = j0 + tc + b;
+                if (next_diag) {
+                    // the whole next diagonal block goes to LDS for the factorisation below: updated inside the band's reach
+                    // (rows < lim), as it stands beyond it (a band narrower than a block: no fill there)
+                    if (r < n && c <= r) sT[(tr + a) * (NB + 1) + tc + b] = A[(int64_t)r * n + c] - ((r < lim && c < lim) ? acc[a][b] : 0.0);
+                } else if (r < lim && c < lim && c <= r) {
+                    const double v = A[(int64_t)r * n + c] - acc[a][b];
+                    A[(int64_t)r * n + c] = v;
+                    if (bi != bj) A[(int64_t)c * n + r] = v;
+                }
+            }
+    }
+    if (!next_diag) return;
+    __syncthreads();
+    if (tid >= 64) return;
+    // ---- the next diagonal block (origin t0): chol_diag_kernel's arithmetic on the tile in LDS ----
+    {
+        const int nb2 = (n - t0) < NB ? (n - t0) : NB;
+        const int lane = tid, r = lane & 31;
+        const bool upper = lane >= 32, live = r < nb2;
+        double v[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const double a = sT[(live ? r : nb2 - 1) * (NB + 1) + (j < nb2 ? j : nb2 - 1)];
+            v[j] = (!upper && live && j < nb2 && j <= r) ? a : ((j == r) ? 1.0 : 0.0);
+        }
+        bool notpd = false;
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const double akk = read_lane_d(v[k], k);
+            notpd = notpd || !(akk > 0.0);
+            const double inv = mqs::rsqrt_d(akk > 0.0 ? akk : 1.0);
+            const double m = v[k] * inv;
+            v[k] = m;
+#pragma unroll
+            for (int j = k + 1; j < NB; ++j) {
+                v[j] = fma(-m, read_lane_d(m, j), v[j]);
+                asm volatile("" : "+v"(v[j]));
+            }
+        }
+        if (lane == 0 && notpd) *bad = 1;
+        if (live) {
+            double *Arow = A + (int64_t)(t0 + r) * n + t0;
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+                if (j < nb2 && (upper ? j > r : j <= r)) Arow[j] = v[j];
+        }
+    }
+}
+
 // L y = b then L^T x = y; one workgroup, blocked by 256 rows with a block-level dot product per row
 // Forward / backward substitution for a BANDED factor by one workgroup.  The unknowns live in LDS; the band is
 // streamed through LDS in slabs of kSlab columns (forward) / rows (backward), so global-memory latency is paid once per
@@ -1006,6 +1130,9 @@ __global__ __launch_bounds__(kPT) void chol_solve_banded_blocked_kernel(const do
     for (int i = tid; i < n; i += kPT) x[i] = sXv[i];
 }
 
+#ifndef MQS_SBA_FUSED_STEP
+#define MQS_SBA_FUSED_STEP 1          // 0: diagonal block, panel and update as three launches per block column (A/B builds)
+#endif
 #ifndef MQS_SBA_BLOCKED_SUBST
 #define MQS_SBA_BLOCKED_SUBST 1       // 0: the column-oriented substitution kernel (A/B builds)
 #endif
@@ -1134,6 +1261,20 @@ int mqs_sba_solve_banded_dev(double *S, double *x, int64_t P, int64_t half_bandw
     } else {
         // right-looking blocked Cholesky; rows further than hb below a block column are zero there and stay zero
         // (no fill outside the band), so the panel and the trailing update stop hb rows below it
+#if MQS_SBA_FUSED_STEP
+        // one launch per block column: the first diagonal block, then panel + update + next diagonal block fused (see
+        // chol_step_kernel).  The input must hold BOTH triangles (it does: the linearisers write both).
+        hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(64), 0, stream, S, n, 0, bad);
+        for (int k0 = 0; k0 < n; k0 += NB) {
+            const int nb = (n - k0) < NB ? (n - k0) : NB;
+            int rem = n - k0 - nb;
+            if (rem > hb) rem = hb;
+            if (rem > 0) {
+                const int tiles = (rem + NB - 1) / NB;
+                hipLaunchKernelGGL(chol_step_kernel, dim3(tiles, tiles), dim3(kBlock), 0, stream, S, n, k0, hb, bad);
+            }
+        }
+#else
         for (int k0 = 0; k0 < n; k0 += NB) {
             const int nb = (n - k0) < NB ? (n - k0) : NB;
             hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(64), 0, stream, S, n, k0, bad);
@@ -1145,6 +1286,7 @@ int mqs_sba_solve_banded_dev(double *S, double *x, int64_t P, int64_t half_bandw
                 hipLaunchKernelGGL(chol_update_kernel, dim3(tiles, tiles), dim3(kBlock), 0, stream, S, n, k0);
             }
         }
+#endif
         const size_t lds = ((size_t)n + (size_t)kSlab * (hb + kSlab)) * 8;
         const int hbs = banded ? hb : n;                     // the dense factor is a band of full width
         const int cap = banded_blocked_cap(n, hbs);
