@@ -342,6 +342,16 @@ int mqs_sba_solve_dev(double *S, double *x, int64_t P, double lambda, const doub
  * a third of the matrix the factorisation and the triangular solves stay inside it. */
 int mqs_sba_solve_banded_dev(double *S, double *x, int64_t P, int64_t half_bandwidth, double lambda, const double *poses,
                              double *poses_out, int *bad, void *stream);
+/* How the banded solve above orders its work for a system of n6 = 6P unknowns (no GPU involved; host only).  Long narrow
+ * bands are cut into 2^d independent chunks separated by ceil(half_bandwidth / 32)-block separators (nested dissection;
+ * csrc/chol_nd.hip), `parts` = 0 lets the library choose as the solve does (environment MQS_SBA_PARTS overrides there),
+ * 1 = no cut.  The plan comes back as int32: header[8] = {stages, descriptors, lazy tiles, contributions, lazy vectors,
+ * columns, parts, 0}; per stage 8 ints {fronts, steps, descriptor offset, lazy-tile offset, lazy tiles, lazy-vector offset,
+ * lazy vectors, longest front in blocks}; descriptors (32 ints: pivot block | -1, structure size, own-front blocks, tiles,
+ * structure[28]); lazy tiles (8 ints: x1, x2, first contribution, count, factor flag, first partial tile, partial tiles, 0); contributions; lazy vectors
+ * (4 ints: block, first column, count, 0); columns.  Returns the ints needed (0 = the solve takes the natural order for this
+ * shape) and fills `out` when `cap` is large enough.  tests/test_chol_plan.py replays a plan with numpy. */
+int64_t mqs_sba_solve_plan_dump(int64_t n6, int64_t half_bandwidth, int parts, int32_t *out, int64_t cap);
 int mqs_sba_backsub_dev(const double *poses, const int32_t *pose_cam, int64_t P, const double *calib,
                         const double *sigma, const double *points, int64_t N, const int64_t *obs_ptr,
                         const int32_t *obs_pose, const double *obs_uv, int64_t M, const double *prior_w,

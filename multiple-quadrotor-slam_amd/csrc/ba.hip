@@ -804,7 +804,9 @@ __global__ __launch_bounds__(kBlock, 4) void ba_backsub_kernel(
     const double *__restrict__ dpose, double *__restrict__ points_out)
 {
     __shared__ double sCam[C * kCamStride];
+#if !MQS_BA_BACKSUB_DIRECT
     __shared__ double sX[kBlock * 3];
+#endif
     __shared__ double sD[6 * C];
     const int tid = threadIdx.x;
     if (tid < 6 * C) sD[tid] = dpose[tid];

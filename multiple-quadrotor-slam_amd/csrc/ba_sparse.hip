@@ -1246,6 +1246,8 @@ int mqs_sba_solve_banded_dev(double *S, double *x, int64_t P, int64_t half_bandw
     MQS_HIP_CHECK(hipMemsetAsync(bad, 0, sizeof(int), stream));
     if (lambda != 0.0) hipLaunchKernelGGL(sparse_damp_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, S, n, lambda);
     const bool banded = 3 * (int64_t)hb < n;            // the band is worth exploiting
+    bool nd_done = false;
+    int rc_nd = MQS_OK;
     if (!banded && n >= kLibraryCholeskyMinN) {
         // a plain dense factorisation of a few thousand unknowns: the vendor's blocked POTRF / POTRS.  Column-major
         // "upper" of this symmetric row-major matrix is the same memory as row-major "lower": the factor lands where
@@ -1258,6 +1260,9 @@ int mqs_sba_solve_banded_dev(double *S, double *x, int64_t P, int64_t half_bandw
             mqs_set_error("rocsolver potrf / potrs failed (n = %d)", n);
             return MQS_E_HIP;
         }
+    } else if (banded && (rc_nd = mqs_chol_nd_solve(S, x, n, hb, bad, stream, &nd_done), rc_nd != MQS_OK || nd_done)) {
+        // the band cut into independent chunks (chol_nd.hip): ~40 dependent launches instead of one per block column
+        if (rc_nd != MQS_OK) return rc_nd;
     } else {
         // right-looking blocked Cholesky; rows further than hb below a block column are zero there and stay zero
         // (no fill outside the band), so the panel and the trailing update stop hb rows below it

@@ -1,0 +1,78 @@
+// Pieces the blocked Cholesky kernels share (ba_sparse.hip: the banded factorisation in natural order; chol_nd.hip: the
+// same band cut into independent chunks).  Block size 32, fp64, lower triangle, row-major, in place.
+#pragma once
+#include "mqs_common.h"
+#include "tri_math.h"
+
+namespace mqs {
+namespace chol {
+
+constexpr int NB = 32;
+constexpr int kLd = NB + 1;          // LDS row stride of a 32 x 32 tile
+
+__device__ __forceinline__ double read_lane_d(double v, int lane)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+
+// The 32 x 32 diagonal block at origin t0, taken from LDS (sT, row stride kLd, lower triangle valid) and written to global
+// memory factored: one wavefront (`lane` 0..63).  Lanes 0..31: lane r keeps row r in registers, right-looking Cholesky with
+// v_readlane broadcasts (all register indices static).  Lanes 32..63 compute the INVERSE of the factor at the same time, in
+// the same instructions: lane 32 + c solves L y = e_c column-oriented, and step k of that substitution,
+// y[j] -= L[j][k] y[k] (j > k), is the trailing update's row[j] -= L[lane][k] L[j][k] with y[k] in the place of L[lane][k].
+// Output layout: L in the lower triangle (diagonal included), inv(L)'s strictly lower part TRANSPOSED in the block's
+// strictly upper triangle (row c, columns c+1.. = column c of inv(L)).  Rows beyond the matrix act as identity.
+__device__ __forceinline__ void factor_diag_block_from_lds(const double *sT, double *__restrict__ A, int n, int t0,
+                                                           int *__restrict__ bad, int lane)
+{
+    const int nb2 = (n - t0) < NB ? (n - t0) : NB;
+    const int r = lane & 31;
+    const bool upper = lane >= 32, live = r < nb2;
+    double v[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const double a = sT[(live ? r : nb2 - 1) * kLd + (j < nb2 ? j : nb2 - 1)];
+        v[j] = (!upper && live && j < nb2 && j <= r) ? a : ((j == r) ? 1.0 : 0.0);
+    }
+    bool notpd = false;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        const double akk = read_lane_d(v[k], k);
+        notpd = notpd || !(akk > 0.0);
+        const double inv = mqs::rsqrt_d(akk > 0.0 ? akk : 1.0);
+        const double m = v[k] * inv;                      // L[lane][k] (lane >= k) | inv(L)[k][c]
+        v[k] = m;
+#pragma unroll
+        for (int j = k + 1; j < NB; ++j) {
+            v[j] = fma(-m, read_lane_d(m, j), v[j]);      // the broadcast is L[j][k]: lane j < 32
+            asm volatile("" : "+v"(v[j]));                // keeps the right-looking order (independent FMAs); the compiler
+                                                          // otherwise turns the unrolled nest left-looking: one dependent chain per column
+        }
+    }
+    if (lane == 0 && notpd) *bad = 1;
+    if (live) {
+        double *Arow = A + (int64_t)(t0 + r) * n + t0;
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+            if (j < nb2 && (upper ? j > r : j <= r)) Arow[j] = v[j];        // upper half: v[j] = inv(L)[j][r], j > r
+    }
+}
+
+// inv(L_kk) of the diagonal block at origin k0 (nb live rows) into LDS as a plain lower-triangular 32 x 32 matrix
+// (sLi[j * kLd + k] = inv(L)[j][k], zero above the diagonal), from the layout above.
+__device__ __forceinline__ void load_inv_diag_block(const double *__restrict__ A, int n, int k0, int nb, double *sLi, int tid,
+                                                    int nthreads)
+{
+    for (int e = tid; e < NB * NB; e += nthreads) {
+        const int j = e >> 5, k = e & 31;
+        double v = 0.0;
+        if (j < nb && k < nb) {
+            if (k < j) v = A[(int64_t)(k0 + k) * n + k0 + j];
+            else if (k == j) v = 1.0 / A[(int64_t)(k0 + j) * n + k0 + j];
+        }
+        sLi[j * kLd + k] = v;
+    }
+}
+
+}  // namespace chol
+}  // namespace mqs

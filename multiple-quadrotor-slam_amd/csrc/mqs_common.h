@@ -40,6 +40,9 @@ struct mqs_ctx {
 // comm.hip: releases ctx->comm (called by mqs_destroy)
 void mqs_comm_release(mqs_ctx *ctx);
 
+// chol_nd.hip: banded SPD solve with the band cut into independent chunks; *done = false when it does not apply
+int mqs_chol_nd_solve(double *S, double *x, int n, int hb, int *bad, hipStream_t stream, bool *done);
+
 // Ensures ctx->dbuf holds at least `bytes`; returns MQS_OK or an error code.
 int mqs_ctx_reserve(mqs_ctx *ctx, size_t bytes);
 

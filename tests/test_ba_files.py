@@ -198,9 +198,10 @@ def test_grouped_pair_blocks_are_reproducible_and_equal_the_atomic_path(gpu):
 def test_reduced_system_solve_against_numpy(case, gpu):
     """mqs_sba_solve_banded_dev on random symmetric positive definite systems: a narrow band (blocked factorisation +
     product-form substitutions), dense systems small enough for one panel chunk in LDS, dense systems that need the chunked
-    substitution, and one above the library threshold; with and without damping.  Half bandwidths <= 102 take the persistent
-    LDS-window factorisation (n = 5286 / hb = 101 is the ICL kt2 shape; sizes that are not multiples of the 32-wide block,
-    bands narrower than a block, the last window shorter than the band), 103 the three-launch form."""
+    substitution, and one above the library threshold; with and without damping.  Long narrow bands are cut into independent
+    chunks (csrc/chol_nd.hip: n = 5286 / hb = 101, the ICL kt2 shape, into 8; 1998 / 65 into 4; 1200 / 101, 720 / 103 and
+    540 / 35 into 2; 600 / 17 into 4); sizes that are not multiples of the 32-wide block and bands narrower than a block are
+    among them."""
     import ctypes
     import torch
     P_, hb = case
@@ -224,6 +225,64 @@ def test_reduced_system_solve_against_numpy(case, gpu):
         ref = np.linalg.solve(S + lam * np.diag(np.diag(S)), g)
         assert int(bad.item()) == 0
         assert np.abs(x.cpu().numpy() - ref).max() <= 1e-10 * np.abs(ref).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(881, 101), (333, 65), (150, 17), (500, 7)])
+def test_chunked_cholesky_equals_the_natural_order(case, gpu, monkeypatch):
+    """The same banded system solved with the band cut into 1 (natural order), 2, 4, 8 and 16 chunks (MQS_SBA_PARTS): every
+    cut reproduces numpy's solve, agrees with the natural order to rounding, and is bit-reproducible run to run (no atomics,
+    one writer per tile in every launch: tests/test_chol_plan.py checks that property of the plan on the CPU)."""
+    import ctypes
+    import torch
+    P_, hb = case
+    n = 6 * P_
+    rng = np.random.default_rng(7 * n + hb)
+    S = np.zeros((n, n))
+    for d in range(1, hb + 1):
+        S[np.arange(n - d), np.arange(d, n)] = rng.standard_normal(n - d)
+    S = S + S.T
+    S[np.arange(n), np.arange(n)] = np.abs(S).sum(axis=1) + 1.0 + rng.random(n)
+    g = rng.standard_normal(n)
+    ref = np.linalg.solve(S, g)
+    lib = gpu._lib.lib()
+
+    def solve():
+        Sd = torch.from_numpy(S.copy()).cuda().reshape(-1)
+        x = torch.from_numpy(g.copy()).cuda()
+        bad = torch.zeros(1, dtype=torch.int32, device="cuda")
+        poses = torch.zeros((P_, 12), dtype=torch.float64, device="cuda")
+        gpu._lib.check(lib.mqs_sba_solve_banded_dev(
+            ctypes.c_void_p(Sd.data_ptr()), ctypes.c_void_p(x.data_ptr()), P_, hb, 0.0, ctypes.c_void_p(poses.data_ptr()), None,
+            ctypes.c_void_p(bad.data_ptr()), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        torch.cuda.synchronize()
+        assert int(bad.item()) == 0
+        return x.cpu().numpy()
+
+    results = {}
+    for parts in (1, 2, 4, 8, 16):
+        monkeypatch.setenv("MQS_SBA_PARTS", str(parts))
+        a, b = solve(), solve()
+        np.testing.assert_array_equal(a, b)
+        assert np.abs(a - ref).max() <= 1e-11 * np.abs(ref).max(), parts
+        results[parts] = a
+    for parts in (2, 4, 8, 16):
+        assert np.abs(results[parts] - results[1]).max() <= 1e-12 * np.abs(ref).max()
+    need = {parts: lib.mqs_sba_solve_plan_dump(n, hb, parts, None, 0) for parts in (1, 2, 8)}
+    assert need[1] == 0 and need[2] > 0                                     # the cut does apply to these shapes
+    # a matrix that is not positive definite is reported, cut or not
+    monkeypatch.setenv("MQS_SBA_PARTS", "0")
+    Sbad = S.copy()
+    Sbad[n // 2, n // 2] = -1.0
+    Sd = torch.from_numpy(Sbad).cuda().reshape(-1)
+    x = torch.from_numpy(g.copy()).cuda()
+    bad = torch.zeros(1, dtype=torch.int32, device="cuda")
+    poses = torch.zeros((P_, 12), dtype=torch.float64, device="cuda")
+    gpu._lib.check(lib.mqs_sba_solve_banded_dev(
+        ctypes.c_void_p(Sd.data_ptr()), ctypes.c_void_p(x.data_ptr()), P_, hb, 0.0, ctypes.c_void_p(poses.data_ptr()), None,
+        ctypes.c_void_p(bad.data_ptr()), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    assert int(bad.item()) == 1
 
 
 @pytest.mark.gpu

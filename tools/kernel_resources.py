@@ -34,8 +34,10 @@ def report(src):
 
 
 def demangle(names):
+    if not names:                      # c++filt without arguments would wait on stdin
+        return names
     try:
-        out = subprocess.run(["c++filt"] + names, capture_output=True, text=True).stdout.splitlines()
+        out = subprocess.run(["c++filt"] + names, capture_output=True, text=True, stdin=subprocess.DEVNULL).stdout.splitlines()
         return out if len(out) == len(names) else names
     except OSError:
         return names
