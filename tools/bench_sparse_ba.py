@@ -38,7 +38,18 @@ def run(P=881, N=13293, track=17):
     out["linearize+solve_ms"] = timed(lin_solve)
     out["backsub_ms"] = timed(lambda: ba.backsub(1e-4))
     out["cost_ms"] = timed(lambda: ba.cost())
-    t0 = time.time(); hist = ba.optimize(mode="lm"); out["lm_s"] = round(time.time() - t0, 2); out["lm_iters"] = len(hist) - 1
+    t0 = time.time(); hist = ba.optimize(mode="lm"); out["lm_ms"] = round((time.time() - t0) * 1e3, 2); out["lm_iters"] = len(hist) - 1
+    import ctypes
+    need = mqslam_amd._lib.lib().mqs_sba_solve_plan_dump(ba.n6, ba.half_bandwidth, int(os.environ.get("MQS_SBA_PARTS", "0") or 0), None, 0)
+    if need:
+        buf = np.zeros(need, np.int32)
+        mqslam_amd._lib.lib().mqs_sba_solve_plan_dump(ba.n6, ba.half_bandwidth, int(os.environ.get("MQS_SBA_PARTS", "0") or 0),
+                                                       buf.ctypes.data_as(ctypes.c_void_p), need)
+        st = buf[8:8 + 8 * int(buf[0])].reshape(-1, 8)
+        out["solve_order"] = {"chunks": int(buf[6]), "levels": int(buf[0]), "dependent_factor_steps": int(st[:, 1].sum()),
+                              "block_columns": (ba.n6 + 31) // 32}
+    else:
+        out["solve_order"] = {"chunks": 1, "dependent_factor_steps": (ba.n6 + 31) // 32, "block_columns": (ba.n6 + 31) // 32}
     out["cost0"], out["cost1"] = hist[0], hist[-1]
     return out
 
