@@ -143,6 +143,12 @@ using float16v = __attribute__((ext_vector_type(16))) float;
 #ifndef MQS_MATCH_PF
 #define MQS_MATCH_PF 4
 #endif
+#ifndef MQS_MATCH_PRUNE_I8
+#define MQS_MATCH_PRUNE_I8 1           // early reject of tile values that cannot enter the best two (see tile_step): int8 path
+#endif
+#ifndef MQS_MATCH_PRUNE_F16
+#define MQS_MATCH_PRUNE_F16 0          // the same on the fp16 path (not bound by vector issue: measured)
+#endif
 #ifndef MQS_MATCH_I8_QT
 #define MQS_MATCH_I8_QT 4
 #endif
@@ -211,6 +217,9 @@ struct F16Path {
     // 2560, windows of 128 tiles, tile and row both in the start value -- removes the v_or3 but measured the same 1.342 ms on the
     // same box: at 3 vector instructions per MFMA the fp16 kernel is not bound by vector issue; the int8 one, at 6, was.)
     static constexpr bool kRowInStart = false;
+    static constexpr bool kPrune = MQS_MATCH_PRUNE_F16 != 0;
+    // smallest key a value at distance part >= d can have (positive floats order like their bit patterns)
+    static __device__ __forceinline__ unsigned key_floor(float d) { return __float_as_uint(d); }
     static constexpr float kBiasV = kBias;
     static __device__ __forceinline__ start_t start(float tnorm, int64_t t) { return tnorm + kBias + (float)((t >> 5) & (kWindowTiles - 1)) * (1.0f / kWindowTiles); }
     static __device__ __forceinline__ start_t pad() { return kPadNorm; }
@@ -244,6 +253,8 @@ struct I8Path {
     // the row inside its tile rides in the start value too (the int32 accumulator only ever adds multiples of 2^13 to it),
     // so the finished accumulator IS the key: the scan costs v_med3_u32 + v_min_u32 per value, no v_or3
     static constexpr bool kRowInStart = true;
+    static constexpr bool kPrune = MQS_MATCH_PRUNE_I8 != 0;
+    static __device__ __forceinline__ unsigned key_floor(float d) { return d < kInvalid ? ((unsigned)d << 12) : 0xFFFFFFFFu; }
     static constexpr float kBiasV = kBias;
     static __device__ __forceinline__ start_t start(float tnorm, int64_t t) { return (((int)tnorm + (int)kBias) << 12) | (int)(((t >> 5) & (kWindowTiles - 1)) << 5) | (int)(t & 31); }
     static __device__ __forceinline__ start_t pad() { return ((int)kPadNorm) << 12; }
@@ -306,11 +317,18 @@ __global__ __launch_bounds__(NW * 64) void knn2_mfma_kernel(const typename TP::e
         qn[qt] = ok ? qnorm[q] : 0.0f;
     }
     unsigned best[QT], second[QT];           // current window: keys
+    // Early reject (TP::kPrune).  A value can only end among a query's best two if its key is below BOTH the window's
+    // current second key and every key at the distance of the running second-best over the finished windows (later rows
+    // lose ties).  thr = the smaller of the two; four values are reduced with v_min3 + v_min, compared with thr, and the
+    // wave skips their scan when no lane has a candidate -- after the first few hundred rows that is the usual case, and
+    // the per-value cost falls from 2 (int8) / 3 (fp16) vector instructions to 3/4.
+    unsigned thr[QT];
     float gd0[QT], gd1[QT];                  // running result over the finished windows: kBias + |t|^2 - 2 q.t
     int gi0[QT], gi1[QT];
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
         best[qt] = 0xFFFFFFFFu; second[qt] = 0xFFFFFFFFu;
+        thr[qt] = 0xFFFFFFFFu;
         gd0[qt] = INFINITY; gd1[qt] = INFINITY; gi0[qt] = -1; gi1[qt] = -1;
     }
 
@@ -379,6 +397,30 @@ __global__ __launch_bounds__(NW * 64) void knn2_mfma_kernel(const typename TP::e
         for (int ks = 0; ks < KS; ++ks) {
             if (ks + PF < KS) a[ks + PF] = *reinterpret_cast<const frag_t *>(arow + 32 * (ks + PF));
             acc = TP::mfma(a[ks], qf[qt][ks], ks == 0 ? start : acc);
+            if constexpr (TP::kPrune && KS % 4 == 0) {
+                // group g = values 4g .. 4g + 3 of the previous step, behind the last MFMA of its quarter of the k-steps
+                if (ks % (KS / 4) == KS / 4 - 1) {
+                    const int g = ks / (KS / 4);
+                    const unsigned k0 = TP::key(prev[4 * g]), k1 = TP::key(prev[4 * g + 1]), k2 = TP::key(prev[4 * g + 2]),
+                                   k3 = TP::key(prev[4 * g + 3]);
+                    unsigned m3;
+                    asm("v_min3_u32 %0, %1, %2, %3" : "=v"(m3) : "v"(k0), "v"(k1), "v"(k2));
+                    const unsigned m4 = min(m3, k3);
+                    // without the row bits a key can only be smaller: the test errs on the side of scanning
+                    if (__builtin_amdgcn_ballot_w64(m4 < thr[pq]) != 0) {
+#pragma unroll
+                        for (int e = 4 * g; e < 4 * g + 4; ++e) {
+                            const unsigned key = TP::kRowInStart ? TP::key(prev[e])
+                                                                 : (TP::key(prev[e]) | (unsigned)(4 * h) | (unsigned)(8 * (e >> 2) + (e & 3)));
+                            unsigned m;
+                            asm("v_med3_u32 %0, %1, %2, %3" : "=v"(m) : "v"(best[pq]), "v"(second[pq]), "v"(key));
+                            second[pq] = m;
+                            best[pq] = min(best[pq], key);
+                        }
+                        thr[pq] = min(second[pq], TP::key_floor(gd1[pq]));
+                    }
+                }
+            } else {
             // scan values [v0, v1) of the previous step behind this MFMA
             const int v0 = ks * 16 / KS, v1 = (ks + 1) * 16 / KS;
 #pragma unroll
@@ -389,6 +431,7 @@ __global__ __launch_bounds__(NW * 64) void knn2_mfma_kernel(const typename TP::e
                 asm("v_med3_u32 %0, %1, %2, %3" : "=v"(m) : "v"(best[pq]), "v"(second[pq]), "v"(key));
                 second[pq] = m;
                 best[pq] = min(best[pq], key);
+            }
             }
         }
         if (QT >= 2) __builtin_amdgcn_sched_barrier(0);       // keep the next step's loads out of this one (VGPRs)
@@ -425,6 +468,7 @@ __global__ __launch_bounds__(NW * 64) void knn2_mfma_kernel(const typename TP::e
             push(qt, best[qt], window_base);
             push(qt, second[qt], window_base);
             best[qt] = 0xFFFFFFFFu; second[qt] = 0xFFFFFFFFu;
+            thr[qt] = TP::key_floor(gd1[qt]);
         }
     };
 
