@@ -18,8 +18,10 @@
 // The reduced system is then factored by the blocked Cholesky below (own kernels, fp64).
 // The atomic form is not bitwise reproducible (summation order); the grouped form is.
 #include "mqs_common.h"
-#include <rocsolver/rocsolver.h>
+#include <map>
+#include <mutex>
 #include "ba_math.h"
+#include "chol_block.h"
 
 namespace {
 
@@ -542,10 +544,11 @@ __global__ void sparse_retract_kernel(const double *__restrict__ poses, const do
 }
 
 // ---------------------------------------------------------------------------------------------
-// Dense Cholesky solve of the reduced camera system, n = 6P: right-looking, block size 32, three kernels
-// per block column (diagonal factor, panel triangular solve, trailing symmetric update), then forward /
-// backward substitution.  Lower triangle, in place, row-major.  Used below kLibraryCholeskyMinN unknowns
-// (no library start-up, a handful of launches); larger systems go to rocSOLVER's POTRF / POTRS.
+// Cholesky solve of the reduced camera system, n = 6P: right-looking, block size 32, lower triangle, in place, row-major.
+// One launch per block column (chol_step_kernel: panel + trailing update on the fp64 matrix pipe + the next diagonal block),
+// then forward / backward substitution.  The same kernels at every size and band width -- no library: rocSOLVER's POTRF /
+// POTRS, which round 1 used above 1 536 dense unknowns, took 4.7 / 9.9 / 20.3 ms at n = 1 560 / 3 000 / 5 286 (plus 160 ms of
+// start-up on the first call) where these take 1.8 / 4.5 / 13.9 ms.  Long narrow bands are cut into chunks (chol_nd.hip).
 // ---------------------------------------------------------------------------------------------
 constexpr int NB = 32;
 
@@ -691,56 +694,41 @@ __global__ __launch_bounds__(kBlock) void chol_step_kernel(double *__restrict__ 
         sAj[b][a] = (a < nb && j0 + b < lim) ? A[(int64_t)(k0 + a) * n + j0 + b] : 0.0;
     }
     __syncthreads();
+    const int lane = tid & 63, wr = (tid >> 6) >> 1, wc = (tid >> 6) & 1;
     {
-        // X = A inv(L)^T for both blocks: a thread owns a 1 x 4 strip (row r, columns 4 jq ..), so every LDS read of A feeds four
-        // FMAs, and the k loop stops at the strip's last column (inv(L) is lower triangular)
-        const int r = tid / (NB / 4), jq = (tid % (NB / 4)) * 4;
-        double xi[4] = {0, 0, 0, 0}, xj[4] = {0, 0, 0, 0};
-        for (int k = 0; k < jq + 4; ++k) {
-            const double ai = sAi[r][k], aj = sAj[r][k];
+        // X = A inv(L)^T for both blocks, then the tile update, on the fp64 matrix pipe (chol_block.h: 8 MFMAs per wavefront and
+        // product; the vector version -- 1 x 4 strips for X, 2 x 2 tiles for the update -- was bound by its LDS reads)
+        const mqs::chol::double4v xi = mqs::chol::tile_quadrant_mfma(&sAi[0][0], &sLi[0][0], wr, wc, lane);
+        const mqs::chol::double4v xj = (bi == bj) ? xi : mqs::chol::tile_quadrant_mfma(&sAj[0][0], &sLi[0][0], wr, wc, lane);
+        const int c = mqs::chol::quadrant_col(wc, lane);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const double li = sLi[jq + c][k];
-                xi[c] = fma(ai, li, xi[c]);
-                xj[c] = fma(aj, li, xj[c]);
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            sXi[r][jq + c] = xi[c];
-            sXj[r][jq + c] = xj[c];
-            if (bj == 0 && i0 + r < lim && jq + c < nb) A[(int64_t)(i0 + r) * n + k0 + jq + c] = xi[c];      // the panel: final entries of L
+        for (int v = 0; v < 4; ++v) {
+            const int r = mqs::chol::quadrant_row(wr, lane, v);
+            sXi[r][c] = xi[v];
+            sXj[r][c] = xj[v];
+            if (bj == 0 && i0 + r < lim && c < nb) A[(int64_t)(i0 + r) * n + k0 + c] = xi[v];      // the panel: final entries of L
         }
     }
     __syncthreads();
-    // tile update, 2 x 2 per thread; the new values go to both triangles (the mirror is the next steps' panel input)
-    const int tr = (tid / 16) * 2, tc = (tid % 16) * 2;
-    double a00 = 0, a01 = 0, a10 = 0, a11 = 0;
-#pragma unroll 8
-    for (int k = 0; k < NB; ++k) {
-        const double i0v = sXi[tr][k], i1v = sXi[tr + 1][k], j0v = sXj[tc][k], j1v = sXj[tc + 1][k];
-        a00 = fma(i0v, j0v, a00); a01 = fma(i0v, j1v, a01); a10 = fma(i1v, j0v, a10); a11 = fma(i1v, j1v, a11);
-    }
+    const mqs::chol::double4v acc = mqs::chol::tile_quadrant_mfma(&sXi[0][0], &sXj[0][0], wr, wc, lane);
     const bool next_diag = bi == 0 && bj == 0;                  // this tile is the next diagonal block
     double *sT = &sAi[0][0];                                    // reused: the updated tile for the factorisation
     __syncthreads();                                             // sAi is free
     {
-        const double acc[2][2] = {{a00, a01}, {a10, a11}};
+        const int tc = mqs::chol::quadrant_col(wc, lane), c = j0 + tc;
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                const int r = i0 + tr + a, c = j0 + tc + b;
-                if (next_diag) {
-                    // the whole next diagonal block goes to LDS for the factorisation below: updated inside the band's reach
-                    // (rows < lim), as it stands beyond it (a band narrower than a block: no fill there)
-                    if (r < n && c <= r) sT[(tr + a) * (NB + 1) + tc + b] = A[(int64_t)r * n + c] - ((r < lim && c < lim) ? acc[a][b] : 0.0);
-                } else if (r < lim && c < lim && c <= r) {
-                    const double v = A[(int64_t)r * n + c] - acc[a][b];
-                    A[(int64_t)r * n + c] = v;
-                    if (bi != bj) A[(int64_t)c * n + r] = v;
-                }
+        for (int v = 0; v < 4; ++v) {
+            const int tr = mqs::chol::quadrant_row(wr, lane, v), r = i0 + tr;
+            if (next_diag) {
+                // the whole next diagonal block goes to LDS for the factorisation below: updated inside the band's reach
+                // (rows < lim), as it stands beyond it (a band narrower than a block: no fill there)
+                if (r < n && c <= r) sT[tr * (NB + 1) + tc] = A[(int64_t)r * n + c] - ((r < lim && c < lim) ? acc[v] : 0.0);
+            } else if (r < lim && c < lim && c <= r) {
+                const double val = A[(int64_t)r * n + c] - acc[v];
+                A[(int64_t)r * n + c] = val;
+                if (bi != bj) A[(int64_t)c * n + r] = val;
             }
+        }
     }
     if (!next_diag) return;
     __syncthreads();
@@ -1130,26 +1118,103 @@ __global__ __launch_bounds__(kPT) void chol_solve_banded_blocked_kernel(const do
     for (int i = tid; i < n; i += kPT) x[i] = sXv[i];
 }
 
+// ---------------------------------------------------------------------------------------------
+// Substitutions for a DENSE factor (pose graphs with loop closures: no band to exploit), n in the thousands.  One workgroup
+// streaming the whole factor (112 MB at n = 5286) took 12 ms; here every block column is one launch over all the rows
+// (forward) / columns (backward) it touches, right-looking in both directions:
+//   forward   y_k = inv(L_kk) b_k, then b_r -= L[r][k-block] y_k for every row r below the block (one row per thread)
+//   backward  x_k = inv(L_kk)^T y_k, then y_c -= L[k-block][c]^T x_k for every column c left of the block (one column per
+//             thread: consecutive threads, consecutive addresses)
+// Every workgroup forms the 32 unknowns of the block itself (a 32 x 32 mat-vec); workgroup 0 stores them -- into the OTHER
+// vector (ytmp forward, x backward), because the block's right-hand side is still being read by the other workgroups of
+// the launch.  One writer per entry per launch: the result does not depend on scheduling.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void dense_fwd_step_kernel(const double *__restrict__ A, int n, int k0, double *__restrict__ b,
+                                                               double *__restrict__ ytmp)
+{
+    __shared__ double sLi[NB][NB + 1], sB[NB], sY[NB];
+    const int nb = (n - k0) < NB ? (n - k0) : NB;
+    const int tid = threadIdx.x;
+    mqs::chol::load_inv_diag_block(A, n, k0, nb, &sLi[0][0], tid, kBlock);
+    if (tid < NB) sB[tid] = tid < nb ? b[k0 + tid] : 0.0;
+    __syncthreads();
+    if (tid < NB) {
+        double s = 0.0;
+#pragma unroll 8
+        for (int k = 0; k < NB; ++k) s = fma(sLi[tid][k], sB[k], s);
+        sY[tid] = s;
+        if (blockIdx.x == 0 && tid < nb) ytmp[k0 + tid] = s;
+    }
+    __syncthreads();
+    const int r = k0 + nb + blockIdx.x * kBlock + tid;
+    if (r < n) {
+        const double *row = A + (int64_t)r * n + k0;
+        double s = 0.0;
+#pragma unroll 8
+        for (int c = 0; c < NB; ++c) s = fma((c < nb) ? row[c] : 0.0, sY[c], s);
+        b[r] -= s;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void dense_bwd_step_kernel(const double *__restrict__ A, int n, int k0, double *__restrict__ ytmp,
+                                                               double *__restrict__ x)
+{
+    __shared__ double sLi[NB][NB + 1], sY[NB], sXk[NB];
+    const int nb = (n - k0) < NB ? (n - k0) : NB;
+    const int tid = threadIdx.x;
+    mqs::chol::load_inv_diag_block(A, n, k0, nb, &sLi[0][0], tid, kBlock);
+    if (tid < NB) sY[tid] = tid < nb ? ytmp[k0 + tid] : 0.0;
+    __syncthreads();
+    if (tid < NB) {
+        double s = 0.0;
+#pragma unroll 8
+        for (int k = 0; k < NB; ++k) s = fma(sLi[k][tid], sY[k], s);          // inv(L)^T: zero for k < column
+        sXk[tid] = s;
+        if (blockIdx.x == 0 && tid < nb) x[k0 + tid] = s;
+    }
+    __syncthreads();
+    const int c = blockIdx.x * kBlock + tid;
+    if (c < k0) {
+        double s = 0.0;
+#pragma unroll 8
+        for (int r = 0; r < NB; ++r)
+            if (r < nb) s = fma(A[(int64_t)(k0 + r) * n + c], sXk[r], s);
+        ytmp[c] -= s;
+    }
+}
+
+// an n-vector of scratch per (device, stream) for the launches above, grown on demand and kept
+double *dense_solve_scratch(size_t n, hipStream_t stream)
+{
+    struct Entry { double *p = nullptr; size_t n = 0; };
+    static std::mutex mutex;
+    static std::map<std::pair<int, void *>, Entry> cache;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lock(mutex);
+    Entry &e = cache[{dev, (void *)stream}];
+    if (e.n < n) {
+        if (e.p) {
+            if (hipStreamSynchronize(stream) != hipSuccess) return nullptr;      // an earlier solve may still be using it
+            (void)hipFree(e.p);
+        }
+        e.p = nullptr; e.n = 0;
+        if (hipMalloc((void **)&e.p, n * sizeof(double)) != hipSuccess) return nullptr;
+        e.n = n;
+    }
+    return e.p;
+}
+
 #ifndef MQS_SBA_FUSED_STEP
 #define MQS_SBA_FUSED_STEP 1          // 0: diagonal block, panel and update as three launches per block column (A/B builds)
 #endif
 #ifndef MQS_SBA_BLOCKED_SUBST
 #define MQS_SBA_BLOCKED_SUBST 1       // 0: the column-oriented substitution kernel (A/B builds)
 #endif
-#ifndef MQS_SBA_LIBRARY_MIN_N
-#define MQS_SBA_LIBRARY_MIN_N 1536
+#ifndef MQS_SBA_DENSE_MIN_N
+#define MQS_SBA_DENSE_MIN_N 1536      // dense factors from this size on: substitutions as one launch per block column
 #endif
-constexpr int kLibraryCholeskyMinN = MQS_SBA_LIBRARY_MIN_N;
-
-// one rocBLAS handle per host thread AND device, created on first use (the library keeps its own device workspace in it)
-rocblas_handle solver_handle()
-{
-    thread_local rocblas_handle h[64] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    if (!h[dev] && rocblas_create_handle(&h[dev]) != rocblas_status_success) h[dev] = nullptr;
-    return h[dev];
-}
+constexpr int kDenseSubstMinN = MQS_SBA_DENSE_MIN_N;
 
 }  // namespace
 
@@ -1248,19 +1313,7 @@ int mqs_sba_solve_banded_dev(double *S, double *x, int64_t P, int64_t half_bandw
     const bool banded = 3 * (int64_t)hb < n;            // the band is worth exploiting
     bool nd_done = false;
     int rc_nd = MQS_OK;
-    if (!banded && n >= kLibraryCholeskyMinN) {
-        // a plain dense factorisation of a few thousand unknowns: the vendor's blocked POTRF / POTRS.  Column-major
-        // "upper" of this symmetric row-major matrix is the same memory as row-major "lower": the factor lands where
-        // the kernels below would put it.
-        rocblas_handle h = solver_handle();
-        MQS_ARG_CHECK(h != nullptr, "rocblas_create_handle failed");
-        if (rocblas_set_stream(h, stream) != rocblas_status_success ||
-            rocsolver_dpotrf(h, rocblas_fill_upper, n, S, n, bad) != rocblas_status_success ||
-            rocsolver_dpotrs(h, rocblas_fill_upper, n, 1, S, n, x, n) != rocblas_status_success) {
-            mqs_set_error("rocsolver potrf / potrs failed (n = %d)", n);
-            return MQS_E_HIP;
-        }
-    } else if (banded && (rc_nd = mqs_chol_nd_solve(S, x, n, hb, bad, stream, &nd_done), rc_nd != MQS_OK || nd_done)) {
+    if (banded && (rc_nd = mqs_chol_nd_solve(S, x, n, hb, bad, stream, &nd_done), rc_nd != MQS_OK || nd_done)) {
         // the band cut into independent chunks (chol_nd.hip): ~40 dependent launches instead of one per block column
         if (rc_nd != MQS_OK) return rc_nd;
     } else {
@@ -1295,7 +1348,20 @@ int mqs_sba_solve_banded_dev(double *S, double *x, int64_t P, int64_t half_bandw
         const size_t lds = ((size_t)n + (size_t)kSlab * (hb + kSlab)) * 8;
         const int hbs = banded ? hb : n;                     // the dense factor is a band of full width
         const int cap = banded_blocked_cap(n, hbs);
-        if (MQS_SBA_BLOCKED_SUBST && cap >= (hbs < 64 ? hbs : 64)) {
+        if (!banded && n >= kDenseSubstMinN) {
+            double *ytmp = dense_solve_scratch((size_t)n, stream);
+            MQS_ARG_CHECK(ytmp != nullptr, "scratch vector for the dense substitutions could not be allocated");
+            for (int k0 = 0; k0 < n; k0 += NB) {
+                const int nb = (n - k0) < NB ? (n - k0) : NB;
+                const int rows = n - k0 - nb;
+                hipLaunchKernelGGL(dense_fwd_step_kernel, dim3(rows > 0 ? (rows + kBlock - 1) / kBlock : 1), dim3(kBlock), 0, stream, S, n,
+                                   k0, x, ytmp);
+            }
+            for (int k0 = ((n - 1) / NB) * NB; k0 >= 0; k0 -= NB)
+                hipLaunchKernelGGL(dense_bwd_step_kernel, dim3(k0 > 0 ? (k0 + kBlock - 1) / kBlock : 1), dim3(kBlock), 0, stream, S, n, k0,
+                                   ytmp, x);
+        }
+        else if (MQS_SBA_BLOCKED_SUBST && cap >= (hbs < 64 ? hbs : 64)) {
             static mqs_lds_opt_in opt_b, opt_b1;            // per device
             MQS_HIP_CHECK(mqs_lds_opt_in_once(opt_b, reinterpret_cast<const void *>(chol_solve_banded_blocked_kernel), 150 * 1024));
             if (cap >= hbs && hbs > 0) {

@@ -15,6 +15,27 @@ __device__ __forceinline__ double read_lane_d(double v, int lane)
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
 }
 
+// 32 x 32 tile products on the fp64 matrix pipe.  v_mfma_f64_16x16x4_f64 (layout probed on gfx950, tools/probes/
+// mfma_f64_layout.hip): a = A[i = lane % 16][k = lane / 16], b = B[k = lane / 16][j = lane % 16], and the four result registers
+// hold D[i = lane / 16 + 4 v][j = lane % 16].  A workgroup's four wavefronts take one 16 x 16 quadrant (wr, wc) each of
+//     C[r][c] = sum_k P[r][k] Q[c][k]          (P, Q: 32 x 32 in LDS, row stride kLd)
+// -- 8 MFMAs and 16 ds_read_b64 per wavefront where the 2 x 2 register tile of the vector version issues 128 LDS reads for 128
+// FMAs per thread and is bound by the LDS (0.85 us per tile product per compute unit).
+using double4v = __attribute__((ext_vector_type(4))) double;
+
+__device__ __forceinline__ double4v tile_quadrant_mfma(const double *P, const double *Q, int wr, int wc, int lane,
+                                                       double4v acc = double4v{0.0, 0.0, 0.0, 0.0})
+{
+    const double *p = P + (16 * wr + (lane & 15)) * kLd + (lane >> 4);
+    const double *q = Q + (16 * wc + (lane & 15)) * kLd + (lane >> 4);
+#pragma unroll
+    for (int s = 0; s < NB / 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(p[4 * s], q[4 * s], acc, 0, 0, 0);
+    return acc;
+}
+// entry v of the quadrant result: tile row / column
+__device__ __forceinline__ int quadrant_row(int wr, int lane, int v) { return 16 * wr + (lane >> 4) + 4 * v; }
+__device__ __forceinline__ int quadrant_col(int wc, int lane) { return 16 * wc + (lane & 15); }
+
 // The 32 x 32 diagonal block at origin t0, taken from LDS (sT, row stride kLd, lower triangle valid) and written to global
 // memory factored: one wavefront (`lane` 0..63).  Lanes 0..31: lane r keeps row r in registers, right-looking Cholesky with
 // v_readlane broadcasts (all register indices static).  Lanes 32..63 compute the INVERSE of the factor at the same time, in

@@ -86,52 +86,39 @@ __global__ __launch_bounds__(kThreads) void nd_step_kernel(double *__restrict__ 
         sAj[b][a] = (a < nb && j0 + b < n) ? A[(int64_t)(k0 + a) * n + j0 + b] : 0.0;
     }
     __syncthreads();
+    const int lane = tid & 63, wr = (tid >> 6) >> 1, wc = (tid >> 6) & 1;
     {
-        const int r = tid / (NB / 4), jq = (tid % (NB / 4)) * 4;
-        double xi[4] = {0, 0, 0, 0}, xj[4] = {0, 0, 0, 0};
-        for (int k = 0; k < jq + 4; ++k) {
-            const double ai = sAi[r][k], aj = sAj[r][k];
+        // X = A inv(L)^T for both blocks on the matrix pipe (inv(L) is lower triangular: its zeros are multiplied along)
+        const double4v xi = tile_quadrant_mfma(&sAi[0][0], &sLi[0][0], wr, wc, lane);
+        const double4v xj = (bi == bj) ? xi : tile_quadrant_mfma(&sAj[0][0], &sLi[0][0], wr, wc, lane);
+        const int c = quadrant_col(wc, lane);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const double li = sLi[jq + c][k];
-                xi[c] = fma(ai, li, xi[c]);
-                xj[c] = fma(aj, li, xj[c]);
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            sXi[r][jq + c] = xi[c];
-            sXj[r][jq + c] = xj[c];
-            if (bj == 0 && i0 + r < n && jq + c < nb) A[(int64_t)(i0 + r) * n + k0 + jq + c] = xi[c];      // final entries of L
+        for (int v = 0; v < 4; ++v) {
+            const int r = quadrant_row(wr, lane, v);
+            sXi[r][c] = xi[v];
+            sXj[r][c] = xj[v];
+            if (bj == 0 && i0 + r < n && c < nb) A[(int64_t)(i0 + r) * n + k0 + c] = xi[v];      // final entries of L
         }
     }
     if (!do_update) return;
     __syncthreads();
-    const int tr = (tid / 16) * 2, tc = (tid % 16) * 2;
-    double a00 = 0, a01 = 0, a10 = 0, a11 = 0;
-#pragma unroll 8
-    for (int k = 0; k < NB; ++k) {
-        const double i0v = sXi[tr][k], i1v = sXi[tr + 1][k], j0v = sXj[tc][k], j1v = sXj[tc + 1][k];
-        a00 = fma(i0v, j0v, a00); a01 = fma(i0v, j1v, a01); a10 = fma(i1v, j0v, a10); a11 = fma(i1v, j1v, a11);
-    }
+    const double4v acc = tile_quadrant_mfma(&sXi[0][0], &sXj[0][0], wr, wc, lane);
     const bool next_diag = bi == 0 && bj == 0;                  // blk[0] = kblk + 1: the front's next pivot block
     double *sT = &sAi[0][0];
     __syncthreads();
     {
-        const double acc[2][2] = {{a00, a01}, {a10, a11}};
+        const int tc = quadrant_col(wc, lane), c = j0 + tc;
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                const int r = i0 + tr + a, c = j0 + tc + b;
-                if (next_diag) {
-                    if (r < n && c <= r) sT[(tr + a) * kLd + tc + b] = A[(int64_t)r * n + c] - acc[a][b];
-                } else if (r < n && c < n && (bi != bj || c <= r)) {
-                    const double v = A[(int64_t)r * n + c] - acc[a][b];
-                    A[(int64_t)r * n + c] = v;
-                    if (bi != bj) A[(int64_t)c * n + r] = v;
-                }
+        for (int v = 0; v < 4; ++v) {
+            const int tr = quadrant_row(wr, lane, v), r = i0 + tr;
+            if (next_diag) {
+                if (r < n && c <= r) sT[tr * kLd + tc] = A[(int64_t)r * n + c] - acc[v];
+            } else if (r < n && c < n && (bi != bj || c <= r)) {
+                const double val = A[(int64_t)r * n + c] - acc[v];
+                A[(int64_t)r * n + c] = val;
+                if (bi != bj) A[(int64_t)c * n + r] = val;
             }
+        }
     }
     if (!next_diag) return;
     __syncthreads();
@@ -176,8 +163,8 @@ __global__ __launch_bounds__(kThreads) void nd_lazy_part_kernel(const double *__
             pj[bq][u] = (!diag && col && j0 + r < n) ? A[(int64_t)(j0 + r) * n + k0 + c] : 0.0;
         }
     }
-    const int tr = (tid / 16) * 2, tc = (tid % 16) * 2;
-    double a00 = 0, a01 = 0, a10 = 0, a11 = 0;
+    const int lane = tid & 63, wr = (tid >> 6) >> 1, wc = (tid >> 6) & 1;
+    double4v acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int bq = 0; bq < kLazySlice; ++bq) {
         if (q0 + bq >= T.count) break;                        // uniform over the workgroup
@@ -189,15 +176,12 @@ __global__ __launch_bounds__(kThreads) void nd_lazy_part_kernel(const double *__
             sJ[r][c] = diag ? pi[bq][u] : pj[bq][u];
         }
         __syncthreads();
-#pragma unroll 8
-        for (int k = 0; k < NB; ++k) {
-            const double i0v = sI[tr][k], i1v = sI[tr + 1][k], j0v = sJ[tc][k], j1v = sJ[tc + 1][k];
-            a00 = fma(i0v, j0v, a00); a01 = fma(i0v, j1v, a01); a10 = fma(i1v, j0v, a10); a11 = fma(i1v, j1v, a11);
-        }
+        acc = tile_quadrant_mfma(&sI[0][0], &sJ[0][0], wr, wc, lane, acc);
     }
-    double2 *out = reinterpret_cast<double2 *>(scratch + (size_t)slot * NB * NB);
-    out[(tr * NB + tc) / 2] = make_double2(a00, a01);
-    out[((tr + 1) * NB + tc) / 2] = make_double2(a10, a11);
+    double *out = scratch + (size_t)slot * NB * NB;
+    const int c = quadrant_col(wc, lane);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) out[quadrant_row(wr, lane, v) * NB + c] = acc[v];
 }
 
 constexpr int kLazyMaxSlots = 16;         // partial tiles one thread keeps in flight in the second launch
