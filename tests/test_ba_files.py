@@ -198,7 +198,8 @@ def test_grouped_pair_blocks_are_reproducible_and_equal_the_atomic_path(gpu):
 def test_reduced_system_solve_against_numpy(case, gpu):
     """mqs_sba_solve_banded_dev on random symmetric positive definite systems: a narrow band (blocked factorisation +
     product-form substitutions), dense systems small enough for one panel chunk in LDS, dense systems that need the chunked
-    substitution, and one above the library threshold; with and without damping.  Long narrow bands are cut into independent
+    substitution, and one large enough for the dense substitution launches (n = 1800; round 1 sent it to rocSOLVER); with and
+    without damping.  Long narrow bands are cut into independent
     chunks (csrc/chol_nd.hip: n = 5286 / hb = 101, the ICL kt2 shape, into 8; 1998 / 65 into 4; 1200 / 101, 720 / 103 and
     540 / 35 into 2; 600 / 17 into 4); sizes that are not multiples of the 32-wide block and bands narrower than a block are
     among them."""
