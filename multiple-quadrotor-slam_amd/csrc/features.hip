@@ -9,15 +9,18 @@
 // Mapping to the machine
 //   * corner response: one thread per pixel, the 5x5 support read straight through L1/L2 (a VGA frame is 300 KB);
 //     two-stage max; candidates (thresholded 3x3 maxima under the mask) compacted with one atomic counter as 64-bit
-//     keys (response bits << 32 | ~(y << 16 | x)), sorted by rocPRIM's radix sort -- response descending, position
-//     ascending, so the result does not depend on the order the atomics happened in;
+//     keys (response bits << 32 | ~(y << 16 | x)), sorted by the selection kernel's own workgroup (bitonic network in
+//     LDS, 16 384 keys at a time, merged when there are more) -- response descending, position ascending, so the
+//     result does not depend on the order the atomics happened in.  (Round 1 called rocPRIM's radix sort over all
+//     W x H key slots: eight passes over 307 200 keys for the few thousand candidates of a VGA frame, ~100 us in a
+//     dozen launches; the library is gone from the product.)  The response maximum is an atomic max of order-
+//     preserving keys inside the response kernel: no separate reduction launches;
 //   * minimum-distance selection is inherently sequential in the candidates: one wavefront walks the sorted list
 //     seven candidates at a time (63 lanes = 7 candidates x 9 neighbouring grid cells of the accepted set, kept in
 //     LDS when it fits), then settles the seven among themselves in order;
 //   * Lucas-Kanade: one wavefront per feature, lanes strided over the 21 x 21 window (7 pixels each, template and
 //     gradients in registers), all pyramid levels and all iterations inside one launch; window sums in fp64.
 #include <cstring>
-#include <rocprim/device/device_radix_sort.hpp>
 #include "mqs_common.h"
 
 #pragma clang fp contract(off)
@@ -48,69 +51,73 @@ __device__ __forceinline__ void sobel_scaled(const uint8_t *__restrict__ img, in
     dy = (((g - a) + 2.0f * (h - b)) + (k - c)) * scale;
 }
 
-__global__ __launch_bounds__(kBlock) void min_eig_kernel(const uint8_t *__restrict__ img, int W, int H, float *__restrict__ eig)
+// float <-> unsigned key with the same order (negative responses can only come from rounding; they must still lose)
+__device__ __forceinline__ unsigned int float_order_key(float v)
 {
+    const unsigned int b = __float_as_uint(v);
+    return b ^ ((unsigned int)((int)b >> 31) | 0x80000000u);
+}
+__device__ __forceinline__ float float_from_order_key(unsigned int k)
+{
+    return __uint_as_float((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k);
+}
+
+// eig = the smaller eigenvalue of the 3 x 3 box sum of the gradient products; maxkey[0] (zeroed by the caller) ends as the
+// order key of the frame's largest response: one atomic per workgroup.
+__global__ __launch_bounds__(kBlock) void min_eig_kernel(const uint8_t *__restrict__ img, int W, int H, float *__restrict__ eig,
+                                                        unsigned int *__restrict__ maxkey)
+{
+    __shared__ unsigned int sMax[kBlock / 64];
     const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
-    if (x >= W || y >= H) return;
-    float rxx[3], rxy[3], ryy[3];
+    unsigned int key = 0u;
+    if (x < W && y < H) {
+        float rxx[3], rxy[3], ryy[3];
 #pragma unroll
-    for (int oy = -1; oy <= 1; ++oy) {
-        const int yy = reflect101(y + oy, H);
-        float pxx[3], pxy[3], pyy[3];
+        for (int oy = -1; oy <= 1; ++oy) {
+            const int yy = reflect101(y + oy, H);
+            float pxx[3], pxy[3], pyy[3];
 #pragma unroll
-        for (int ox = -1; ox <= 1; ++ox) {
-            float dx, dy;
-            sobel_scaled(img, W, H, yy, reflect101(x + ox, W), dx, dy);
-            pxx[ox + 1] = dx * dx; pxy[ox + 1] = dx * dy; pyy[ox + 1] = dy * dy;
+            for (int ox = -1; ox <= 1; ++ox) {
+                float dx, dy;
+                sobel_scaled(img, W, H, yy, reflect101(x + ox, W), dx, dy);
+                pxx[ox + 1] = dx * dx; pxy[ox + 1] = dx * dy; pyy[ox + 1] = dy * dy;
+            }
+            rxx[oy + 1] = (pxx[0] + pxx[1]) + pxx[2];
+            rxy[oy + 1] = (pxy[0] + pxy[1]) + pxy[2];
+            ryy[oy + 1] = (pyy[0] + pyy[1]) + pyy[2];
         }
-        rxx[oy + 1] = (pxx[0] + pxx[1]) + pxx[2];
-        rxy[oy + 1] = (pxy[0] + pxy[1]) + pxy[2];
-        ryy[oy + 1] = (pyy[0] + pyy[1]) + pyy[2];
+        const float a = ((rxx[0] + rxx[1]) + rxx[2]) * 0.5f;
+        const float b = (rxy[0] + rxy[1]) + rxy[2];
+        const float c = ((ryy[0] + ryy[1]) + ryy[2]) * 0.5f;
+        const float d = a - c;
+        const float e = (a + c) - sqrtf(d * d + b * b);
+        eig[y * W + x] = e;
+        key = float_order_key(e);
     }
-    const float a = ((rxx[0] + rxx[1]) + rxx[2]) * 0.5f;
-    const float b = (rxy[0] + rxy[1]) + rxy[2];
-    const float c = ((ryy[0] + ryy[1]) + ryy[2]) * 0.5f;
-    const float d = a - c;
-    eig[y * W + x] = (a + c) - sqrtf(d * d + b * b);
-}
-
-__global__ __launch_bounds__(kBlock) void max_partial_kernel(const float *__restrict__ v, int64_t n, float *__restrict__ partial)
-{
-    __shared__ float s[kBlock];
-    float m = -INFINITY;
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) m = fmaxf(m, v[i]);
-    s[threadIdx.x] = m;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const unsigned int o = (unsigned int)__shfl_xor((int)key, off, 64);
+        key = key > o ? key : o;
+    }
+    if ((threadIdx.x & 63) == 0) sMax[threadIdx.x >> 6] = key;
     __syncthreads();
-    for (int h = kBlock / 2; h >= 1; h >>= 1) {
-        if (threadIdx.x < h) s[threadIdx.x] = fmaxf(s[threadIdx.x], s[threadIdx.x + h]);
-        __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned int m = sMax[0];
+#pragma unroll
+        for (int w = 1; w < kBlock / 64; ++w) m = m > sMax[w] ? m : sMax[w];
+        atomicMax(maxkey, m);
     }
-    if (threadIdx.x == 0) partial[blockIdx.x] = s[0];
-}
-
-__global__ __launch_bounds__(kBlock) void max_final_kernel(const float *__restrict__ partial, int n, float *__restrict__ out)
-{
-    __shared__ float s[kBlock];
-    float m = -INFINITY;
-    for (int i = threadIdx.x; i < n; i += kBlock) m = fmaxf(m, partial[i]);
-    s[threadIdx.x] = m;
-    __syncthreads();
-    for (int h = kBlock / 2; h >= 1; h >>= 1) {
-        if (threadIdx.x < h) s[threadIdx.x] = fmaxf(s[threadIdx.x], s[threadIdx.x + h]);
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) out[0] = s[0];
 }
 
 // counter[0] = number of candidates appended (may exceed the capacity: the excess is dropped and reported)
 __global__ __launch_bounds__(kBlock) void candidates_kernel(const float *__restrict__ eig, int W, int H,
-                                                           const float *__restrict__ maxval, float quality,
+                                                           const unsigned int *__restrict__ maxkey, float quality,
                                                            const uint8_t *__restrict__ mask, unsigned long long *__restrict__ keys,
                                                            unsigned int capacity, unsigned int *__restrict__ counter)
 {
     const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
     if (x <= 0 || y <= 0 || x >= W - 1 || y >= H - 1) return;
-    const float thr = maxval[0] * quality;
+    const float thr = float_from_order_key(maxkey[0]) * quality;
     const float e = eig[y * W + x];
     if (!(e > thr) || e == 0.0f) return;
     if (mask && mask[y * W + x] == 0) return;
@@ -135,14 +142,91 @@ __global__ __launch_bounds__(kBlock) void candidates_kernel(const float *__restr
 // nb, then the candidates of the step are settled among themselves in order (wave-uniform, positions by v_readlane).
 // Candidate positions come through an LDS chunk (one global round trip per 64 steps instead of one per step) and the
 // accepted corners leave through another: the serial chain touches LDS only.
-template <bool IN_LDS>
-__global__ __launch_bounds__(kBlock) void select_kernel(const unsigned long long *__restrict__ keys,
-                                                       const unsigned int *__restrict__ counter, unsigned int capacity, int W,
-                                                       int H, float min_distance, int max_corners, int out_capacity,
-                                                       unsigned int *__restrict__ grid_global, float *__restrict__ out_xy,
-                                                       int *__restrict__ out_n)
+// The sort comes first, by the same (single) workgroup: the candidates arrive in the order their atomics happened.  Up to
+// kSortChunk keys are sorted in LDS by a bitonic network (descending; the keys are distinct); more than that -- a frame of
+// noise -- chunk by chunk into `keys` itself, then merged pairwise between `keys` and `tmp` (merge path: every thread finds
+// its share of the output by bisection).  The LDS the network used is then the selection grid.
+constexpr int kSelThreads = 1024;
+constexpr int kSortChunk = 16384;         // 128 KB of 64-bit keys
+
+__device__ __forceinline__ void bitonic_sort_desc_lds(unsigned long long *sK, int m /* power of two */, int tid)
 {
-    extern __shared__ unsigned int sGrid[];
+    for (int k = 2; k <= m; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < m / 2; i += kSelThreads) {
+                const int lo = 2 * i - (i & (j - 1)), hi = lo + j;         // lo has bit j clear
+                const unsigned long long a = sK[lo], b = sK[hi];
+                const bool desc = (lo & k) == 0;                            // this run is sorted descending
+                if ((a < b) == desc) { sK[lo] = b; sK[hi] = a; }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// merges the descending runs src[a0 .. a0 + la) and src[a0 + la .. a0 + la + lb) into dst[a0 ..): all threads
+__device__ __forceinline__ void merge_runs_desc(const unsigned long long *__restrict__ src, unsigned long long *__restrict__ dst,
+                                                unsigned int a0, unsigned int la, unsigned int lb, int tid)
+{
+    const unsigned long long *A = src + a0, *B = src + a0 + la;
+    const unsigned int L = la + lb;
+    const unsigned int d0 = (unsigned int)(((unsigned long long)L * tid) / kSelThreads);
+    const unsigned int d1 = (unsigned int)(((unsigned long long)L * (tid + 1)) / kSelThreads);
+    if (d0 == d1) return;
+    unsigned int lo = d0 > lb ? d0 - lb : 0u, hi = d0 < la ? d0 : la;      // elements of A among the first d0 outputs
+    while (lo < hi) {
+        const unsigned int mid = (lo + hi) >> 1;
+        if (A[mid] > B[d0 - 1 - mid]) lo = mid + 1; else hi = mid;
+    }
+    unsigned int i = lo, j = d0 - lo;
+    for (unsigned int d = d0; d < d1; ++d) {
+        const bool takeA = j >= lb || (i < la && A[i] > B[j]);
+        dst[a0 + d] = takeA ? A[i] : B[j];
+        i += takeA; j += !takeA;
+    }
+}
+
+template <bool IN_LDS>
+__global__ __launch_bounds__(kSelThreads) void sort_select_kernel(unsigned long long *__restrict__ keys_io,
+                                                                  unsigned long long *__restrict__ tmp,
+                                                                  const unsigned int *__restrict__ counter, unsigned int capacity, int W,
+                                                                  int H, float min_distance, int max_corners, int out_capacity,
+                                                                  unsigned int *__restrict__ grid_global, float *__restrict__ out_xy,
+                                                                  int *__restrict__ out_n)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned int sGrid[];
+    const unsigned long long *keys = keys_io;
+    {
+        unsigned long long *sK = reinterpret_cast<unsigned long long *>(sGrid);
+        unsigned int cnt = counter[0];
+        if (cnt > capacity) cnt = capacity;
+        const int tid = threadIdx.x;
+        for (unsigned int c0 = 0; c0 < cnt; c0 += kSortChunk) {
+            const unsigned int len = cnt - c0 < (unsigned)kSortChunk ? cnt - c0 : (unsigned)kSortChunk;
+            int m = 2;
+            while ((unsigned)m < len) m <<= 1;
+            for (int i = tid; i < m; i += kSelThreads) sK[i] = (unsigned)i < len ? keys_io[c0 + i] : 0ull;   // 0 sorts last, is no key
+            __syncthreads();
+            bitonic_sort_desc_lds(sK, m, tid);
+            for (unsigned int i = tid; i < len; i += kSelThreads) keys_io[c0 + i] = sK[i];
+            __syncthreads();
+        }
+        if (cnt > (unsigned)kSortChunk) {
+            unsigned long long *src = keys_io, *dst = tmp;
+            __threadfence_block();
+            for (unsigned int run = kSortChunk; run < cnt; run <<= 1) {
+                __syncthreads();
+                for (unsigned int a0 = 0; a0 < cnt; a0 += 2 * run) {
+                    const unsigned int la = cnt - a0 < run ? cnt - a0 : run;
+                    const unsigned int lb = cnt - a0 - la < run ? cnt - a0 - la : run;
+                    merge_runs_desc(src, dst, a0, la, lb, tid);
+                }
+                unsigned long long *t = src; src = dst; dst = t;
+            }
+            keys = src;
+        }
+        __syncthreads();                                   // the sorted keys are in global memory; the LDS is free
+    }
     constexpr int kBatch = 7;
     constexpr int kChunk = 64 * kBatch;
     constexpr int kStage = 1024;
@@ -154,7 +238,7 @@ __global__ __launch_bounds__(kBlock) void select_kernel(const unsigned long long
     int accepted = 0;
     const int limit = (max_corners > 0 && max_corners < out_capacity) ? max_corners : out_capacity;
     if (min_distance < 1.0f) {
-        for (unsigned int i = threadIdx.x; i < n && (int)i < limit; i += kBlock) {
+        for (unsigned int i = threadIdx.x; i < n && (int)i < limit; i += kSelThreads) {
             const unsigned int pos = 0xFFFFFFFFu - (unsigned int)(keys[i] & 0xFFFFFFFFull);
             out_xy[2 * i] = (float)(pos & 0xFFFFu);
             out_xy[2 * i + 1] = (float)(pos >> 16);
@@ -168,7 +252,7 @@ __global__ __launch_bounds__(kBlock) void select_kernel(const unsigned long long
         if constexpr (IN_LDS) return sGrid[i];
         else return grid_global[i];
     };
-    for (int i = threadIdx.x; i < gw * gh * 4; i += kBlock) slot_ref(i) = 0xFFFFFFFFu;
+    for (int i = threadIdx.x; i < gw * gh * 4; i += kSelThreads) slot_ref(i) = 0xFFFFFFFFu;
     __syncthreads();
     if (threadIdx.x >= 64) return;
     const float md2 = min_distance * min_distance, inv_cell = 1.0f / (float)cell;
@@ -580,12 +664,8 @@ int64_t mqs_gftt_workspace_bytes(int W, int H)
 {
     if (W < 1 || H < 1) return 0;
     const size_t npx = (size_t)W * H;
-    size_t sort_tmp = 0;
-    (void)rocprim::radix_sort_keys_desc(nullptr, sort_tmp, (unsigned long long *)nullptr, (unsigned long long *)nullptr, npx, 0, 64,
-                                        (hipStream_t)0);
-    // response, 2 key arrays, block maxima, max, counter, selection grid (worst case: cell = 1), sort scratch
-    return (int64_t)(align_up(npx * 4) + 2 * align_up(npx * 8) + align_up(1024 * 4) + 256 + 256 + align_up(npx * 16) +
-                     align_up(sort_tmp));
+    // response, 2 key arrays (candidates / merge buffer), maximum + counter, selection grid (worst case: cell = 1)
+    return (int64_t)(align_up(npx * 4) + 2 * align_up(npx * 8) + 256 + align_up(npx * 16));
 }
 
 int mqs_good_features_to_track_dev(const uint8_t *img, int W, int H, int max_corners, double quality_level,
@@ -601,39 +681,32 @@ int mqs_good_features_to_track_dev(const uint8_t *img, int W, int H, int max_cor
     char *w = static_cast<char *>(workspace);
     float *eig = reinterpret_cast<float *>(w); w += align_up(npx * 4);
     unsigned long long *keys = reinterpret_cast<unsigned long long *>(w); w += align_up(npx * 8);
-    unsigned long long *sorted = reinterpret_cast<unsigned long long *>(w); w += align_up(npx * 8);
-    float *partial = reinterpret_cast<float *>(w); w += align_up(1024 * 4);
-    float *maxval = reinterpret_cast<float *>(w); w += 256;
-    unsigned int *counter = reinterpret_cast<unsigned int *>(w); w += 256;
-    unsigned int *grid = reinterpret_cast<unsigned int *>(w); w += align_up(npx * 16);
-    void *sort_tmp = w;
-    size_t sort_bytes = 0;
-    (void)rocprim::radix_sort_keys_desc(nullptr, sort_bytes, keys, sorted, npx, 0, 64, stream);
+    unsigned long long *tmp = reinterpret_cast<unsigned long long *>(w); w += align_up(npx * 8);
+    unsigned int *maxkey = reinterpret_cast<unsigned int *>(w);          // [0] order key of the largest response, [1] candidate count
+    unsigned int *counter = maxkey + 1; w += 256;
+    unsigned int *grid = reinterpret_cast<unsigned int *>(w);
 
-    hipLaunchKernelGGL(min_eig_kernel, grid2d(W, H), dim3(kBlock), 0, stream, img, W, H, eig);
-    const int nb = (int)((npx + kBlock * 8 - 1) / (kBlock * 8)) < 1024 ? (int)((npx + kBlock * 8 - 1) / (kBlock * 8)) : 1024;
-    hipLaunchKernelGGL(max_partial_kernel, dim3(nb), dim3(kBlock), 0, stream, eig, (int64_t)npx, partial);
-    hipLaunchKernelGGL(max_final_kernel, dim3(1), dim3(kBlock), 0, stream, partial, nb, maxval);
-    MQS_HIP_CHECK(hipMemsetAsync(counter, 0, 4, stream));
-    // unused key slots sort to the end (key 0 = response +0.0 can never be a candidate: candidates are > threshold >= 0)
-    MQS_HIP_CHECK(hipMemsetAsync(keys, 0, npx * 8, stream));
-    hipLaunchKernelGGL(candidates_kernel, grid2d(W, H), dim3(kBlock), 0, stream, eig, W, H, maxval, (float)quality_level, mask,
+    // four launches: clear, response (+ maximum), candidates, sort + selection
+    MQS_HIP_CHECK(hipMemsetAsync(maxkey, 0, 8, stream));
+    hipLaunchKernelGGL(min_eig_kernel, grid2d(W, H), dim3(kBlock), 0, stream, img, W, H, eig, maxkey);
+    hipLaunchKernelGGL(candidates_kernel, grid2d(W, H), dim3(kBlock), 0, stream, eig, W, H, maxkey, (float)quality_level, mask,
                        keys, (unsigned int)npx, counter);
-    MQS_HIP_CHECK(rocprim::radix_sort_keys_desc(sort_tmp, sort_bytes, keys, sorted, npx, 0, 64, stream));
     const int cell = min_distance >= 1.0 ? (int)rint(min_distance) : 1;
     const size_t cells = (size_t)((W + cell - 1) / cell) * ((H + cell - 1) / cell);
-    const size_t lds = cells * 16;
-    const bool in_lds = min_distance < 1.0 || lds <= 140 * 1024;
+    const size_t sort_lds = (size_t)kSortChunk * sizeof(unsigned long long);
+    const size_t grid_lds = cells * 16;
+    const bool in_lds = min_distance < 1.0 || grid_lds <= 140 * 1024;
+    const size_t lds = (in_lds && min_distance >= 1.0 && grid_lds > sort_lds) ? grid_lds : sort_lds;
     if (in_lds) {
-        if (lds > 48 * 1024) {
-            static mqs_lds_opt_in opt;                       // per device
-            MQS_HIP_CHECK(mqs_lds_opt_in_once(opt, reinterpret_cast<const void *>(select_kernel<true>), 140 * 1024));
-        }
-        hipLaunchKernelGGL(select_kernel<true>, dim3(1), dim3(kBlock), min_distance < 1.0 ? 0 : lds, stream, sorted, counter,
-                           (unsigned int)npx, W, H, (float)min_distance, max_corners, out_capacity, grid, out_xy, out_n);
+        static mqs_lds_opt_in opt;                           // per device
+        MQS_HIP_CHECK(mqs_lds_opt_in_once(opt, reinterpret_cast<const void *>(sort_select_kernel<true>), 140 * 1024));
+        hipLaunchKernelGGL(sort_select_kernel<true>, dim3(1), dim3(kSelThreads), lds, stream, keys, tmp, counter, (unsigned int)npx, W,
+                           H, (float)min_distance, max_corners, out_capacity, grid, out_xy, out_n);
     } else {
-        hipLaunchKernelGGL(select_kernel<false>, dim3(1), dim3(kBlock), 0, stream, sorted, counter, (unsigned int)npx, W, H,
-                           (float)min_distance, max_corners, out_capacity, grid, out_xy, out_n);
+        static mqs_lds_opt_in opt;                           // per device
+        MQS_HIP_CHECK(mqs_lds_opt_in_once(opt, reinterpret_cast<const void *>(sort_select_kernel<false>), 140 * 1024));
+        hipLaunchKernelGGL(sort_select_kernel<false>, dim3(1), dim3(kSelThreads), sort_lds, stream, keys, tmp, counter,
+                           (unsigned int)npx, W, H, (float)min_distance, max_corners, out_capacity, grid, out_xy, out_n);
     }
     MQS_HIP_CHECK(hipGetLastError());
     return MQS_OK;

@@ -117,6 +117,21 @@ def test_gpu_good_features_equal_oracle(shape, maxc, q, md, masked, gpu):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("md", [0.0, 3.0])
+def test_gpu_good_features_more_candidates_than_one_sort_chunk(md, gpu):
+    """A frame of noise: 20 342 local maxima pass the quality level, more than the 16 384 keys the selection kernel sorts in
+    LDS at a time, so its chunks are merged.  Same corners in the same order as the oracle."""
+    rng = np.random.default_rng(12)
+    img = rng.integers(0, 256, (480, 640), dtype=np.uint8)
+    ref = Fn.good_features_to_track(img, 0, 1e-4, md)
+    assert len(ref) > 16384 if md == 0.0 else len(ref) > 5000
+    got = gpu.features.goodFeaturesToTrack(img, 0, 1e-4, md, capacity=len(ref) + 8)
+    np.testing.assert_array_equal(got, ref)
+    top = gpu.features.goodFeaturesToTrack(img, 300, 1e-4, md)
+    np.testing.assert_array_equal(top, ref[:300])
+
+
+@pytest.mark.gpu
 def test_gpu_good_features_checkerboard_and_flat(gpu):
     pts = gpu.features.goodFeaturesToTrack(checkerboard(96, 128, 16), 0, 0.05, 5.0, capacity=100)
     np.testing.assert_array_equal(pts, Fn.good_features_to_track(checkerboard(96, 128, 16), 0, 0.05, 5.0))
