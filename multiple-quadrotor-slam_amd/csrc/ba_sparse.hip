@@ -550,113 +550,20 @@ __global__ void sparse_retract_kernel(const double *__restrict__ poses, const do
 // POTRS, which round 1 used above 1 536 dense unknowns, took 4.7 / 9.9 / 20.3 ms at n = 1 560 / 3 000 / 5 286 (plus 160 ms of
 // start-up on the first call) where these take 1.8 / 4.5 / 13.9 ms.  Long narrow bands are cut into chunks (chol_nd.hip).
 // ---------------------------------------------------------------------------------------------
-constexpr int NB = 32;
+constexpr int NB = mqs::chol::NB;
 
-__device__ __forceinline__ double read_lane_d(double v, int lane)
-{
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
-}
-
-// Diagonal block: one wavefront.  Lanes 0..31: lane r keeps row r of the 32 x 32 block in registers, right-looking Cholesky
-// with v_readlane broadcasts (all register indices static).  Lanes 32..63 compute the INVERSE of the factor at the same
-// time, in the same instructions: lane 32 + c solves L y = e_c column-oriented, and step k of that substitution,
-// y[j] -= L[j][k] y[k] (j > k), is the trailing update's row[j] -= L[lane][k] L[j][k] with y[k] in the place of L[lane][k]
-// -- so `v[k] *= 1 / L[k][k]; v[j] = fma(-v[k], broadcast(L[j][k]), v[j])` does the factorisation in the lower half-wave
-// and the substitution in the upper one.  (History: a separate substitution after the factorisation, 19.9 us per block, of
-// which 964 SGPR spills; fused as a second FMA per broadcast in the same lanes, 9.4 us; this form halves the FMAs.)
-// Writes L into the lower triangle (diagonal included) and inv(L)'s strictly lower part TRANSPOSED into the block's
-// strictly upper triangle (row c, columns c+1.. = column c of inv(L)): the panel kernel turns the triangular solve into a
-// product with it.  Rows beyond the matrix act as identity.
+// The first diagonal block (the later ones are factored inside chol_step_kernel): one wavefront, the block staged through LDS
+// for mqs::chol::factor_diag_block_from_lds (chol_block.h: L below the diagonal, inv(L)^T above it).
 __global__ __launch_bounds__(64) void chol_diag_kernel(double *__restrict__ A, int n, int k0, int *__restrict__ bad)
 {
+    __shared__ double sT[NB * mqs::chol::kLd];
     const int nb = (n - k0) < NB ? (n - k0) : NB;
-    const int lane = threadIdx.x, r = lane & 31;
-    const bool upper = lane >= 32;                        // the half-wave that carries the inverse
-    const bool live = r < nb;
-    double v[NB];
-    double *Arow = A + (int64_t)(k0 + (live ? r : nb - 1)) * n + k0;         // every lane loads from a valid row, selects after
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-        const double a = Arow[j < nb ? j : nb - 1];
-        v[j] = (!upper && live && j < nb && j <= r) ? a : ((j == r) ? 1.0 : 0.0);
-    }
-    bool notpd = false;
-#pragma unroll
-    for (int k = 0; k < NB; ++k) {
-        const double akk = read_lane_d(v[k], k);
-        notpd = notpd || !(akk > 0.0);
-        const double inv = mqs::rsqrt_d(akk > 0.0 ? akk : 1.0);
-        const double m = v[k] * inv;                      // L[lane][k] (lane >= k) | inv(L)[k][c]
-        v[k] = m;
-#pragma unroll
-        for (int j = k + 1; j < NB; ++j) {
-            v[j] = fma(-m, read_lane_d(m, j), v[j]);      // the broadcast is L[j][k]: lane j < 32
-            asm volatile("" : "+v"(v[j]));                // keeps the right-looking order (independent FMAs); the compiler
-                                                          // otherwise turns the unrolled nest left-looking: one dependent chain per column
-        }
-    }
-    if (lane == 0 && notpd) *bad = 1;
-    if (live) {
-#pragma unroll
-        for (int j = 0; j < NB; ++j)
-            if (j < nb && (upper ? j > r : j <= r)) Arow[j] = v[j];        // upper half: v[j] = inv(L)[j][r], j > r
-    }
-}
-
-// rows below the diagonal block: X = A_panel inv(L)^T, X[r][j] = sum_{k <= j} A[r][k] inv(L)[j][k].  One workgroup per
-// 8 rows, one thread per output entry.
-__global__ __launch_bounds__(kBlock) void chol_panel_kernel(double *__restrict__ A, int n, int k0)
-{
-    __shared__ double sLi[NB][NB + 1];      // inv(L), lower
-    __shared__ double sA[8][NB + 1];
-    const int nb = (n - k0) < NB ? (n - k0) : NB;
-    for (int e = threadIdx.x; e < NB * NB; e += kBlock) {
-        const int j = e / NB, k = e % NB;
-        double v = 0.0;
-        if (j < nb && k < nb) {
-            if (k < j) v = A[(int64_t)(k0 + k) * n + k0 + j];               // stored transposed in the upper triangle
-            else if (k == j) v = 1.0 / A[(int64_t)(k0 + j) * n + k0 + j];
-        }
-        sLi[j][k] = v;
-    }
-    const int rr = threadIdx.x / NB, j = threadIdx.x % NB;
-    const int r = k0 + nb + blockIdx.x * 8 + rr;
-    sA[rr][j] = (r < n && j < nb) ? A[(int64_t)r * n + k0 + j] : 0.0;
-    __syncthreads();
-    double sacc = 0.0;
-#pragma unroll
-    for (int k = 0; k < NB; ++k) sacc = fma(sA[rr][k], sLi[j][k], sacc);       // inv(L)[j][k] = 0 for k > j
-    if (r < n && j < nb) A[(int64_t)r * n + k0 + j] = sacc;
-}
-
-// trailing update (lower triangle): A[i][j] -= sum_k L[i][k0+k] L[j][k0+k], 32x32 tiles
-__global__ __launch_bounds__(kBlock) void chol_update_kernel(double *__restrict__ A, int n, int k0)
-{
-    const int nb = (n - k0) < NB ? (n - k0) : NB;
-    const int t0 = k0 + nb;
-    const int bi = blockIdx.y, bj = blockIdx.x;
-    if (bj > bi) return;
-    __shared__ double sI[NB][NB + 1], sJ[NB][NB + 1];
-    const int i0 = t0 + bi * NB, j0 = t0 + bj * NB;
-    for (int e = threadIdx.x; e < NB * NB; e += kBlock) {
+    for (int e = threadIdx.x; e < NB * NB; e += 64) {
         const int r = e / NB, c = e % NB;
-        sI[r][c] = (i0 + r < n && c < nb) ? A[(int64_t)(i0 + r) * n + k0 + c] : 0.0;
-        sJ[r][c] = (j0 + r < n && c < nb) ? A[(int64_t)(j0 + r) * n + k0 + c] : 0.0;
+        if (r < nb && c <= r) sT[r * mqs::chol::kLd + c] = A[(int64_t)(k0 + r) * n + k0 + c];
     }
-    __syncthreads();
-    // 256 threads: each a 2x2 piece of the 32x32 tile
-    const int tr = (threadIdx.x / 16) * 2, tc = (threadIdx.x % 16) * 2;
-    double a00 = 0, a01 = 0, a10 = 0, a11 = 0;
-#pragma unroll 8
-    for (int k = 0; k < NB; ++k) {
-        const double i0v = sI[tr][k], i1v = sI[tr + 1][k], j0v = sJ[tc][k], j1v = sJ[tc + 1][k];
-        a00 = fma(i0v, j0v, a00); a01 = fma(i0v, j1v, a01); a10 = fma(i1v, j0v, a10); a11 = fma(i1v, j1v, a11);
-    }
-    const int r0 = i0 + tr, c0 = j0 + tc;
-    if (r0 < n && c0 < n && c0 <= r0) A[(int64_t)r0 * n + c0] -= a00;
-    if (r0 < n && c0 + 1 < n && c0 + 1 <= r0) A[(int64_t)r0 * n + c0 + 1] -= a01;
-    if (r0 + 1 < n && c0 < n && c0 <= r0 + 1) A[(int64_t)(r0 + 1) * n + c0] -= a10;
-    if (r0 + 1 < n && c0 + 1 < n && c0 + 1 <= r0 + 1) A[(int64_t)(r0 + 1) * n + c0 + 1] -= a11;
+    mqs_wave_lds_sync();
+    mqs::chol::factor_diag_block_from_lds(sT, A, n, k0, bad, threadIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -733,39 +640,7 @@ __global__ __launch_bounds__(kBlock) void chol_step_kernel(double *__restrict__ 
     if (!next_diag) return;
     __syncthreads();
     if (tid >= 64) return;
-    // ---- the next diagonal block (origin t0): chol_diag_kernel's arithmetic on the tile in LDS ----
-    {
-        const int nb2 = (n - t0) < NB ? (n - t0) : NB;
-        const int lane = tid, r = lane & 31;
-        const bool upper = lane >= 32, live = r < nb2;
-        double v[NB];
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            const double a = sT[(live ? r : nb2 - 1) * (NB + 1) + (j < nb2 ? j : nb2 - 1)];
-            v[j] = (!upper && live && j < nb2 && j <= r) ? a : ((j == r) ? 1.0 : 0.0);
-        }
-        bool notpd = false;
-#pragma unroll
-        for (int k = 0; k < NB; ++k) {
-            const double akk = read_lane_d(v[k], k);
-            notpd = notpd || !(akk > 0.0);
-            const double inv = mqs::rsqrt_d(akk > 0.0 ? akk : 1.0);
-            const double m = v[k] * inv;
-            v[k] = m;
-#pragma unroll
-            for (int j = k + 1; j < NB; ++j) {
-                v[j] = fma(-m, read_lane_d(m, j), v[j]);
-                asm volatile("" : "+v"(v[j]));
-            }
-        }
-        if (lane == 0 && notpd) *bad = 1;
-        if (live) {
-            double *Arow = A + (int64_t)(t0 + r) * n + t0;
-#pragma unroll
-            for (int j = 0; j < NB; ++j)
-                if (j < nb2 && (upper ? j > r : j <= r)) Arow[j] = v[j];
-        }
-    }
+    mqs::chol::factor_diag_block_from_lds(sT, A, n, t0, bad, tid);      // the next diagonal block (origin t0)
 }
 
 // L y = b then L^T x = y; one workgroup, blocked by 256 rows with a block-level dot product per row
@@ -1205,9 +1080,6 @@ double *dense_solve_scratch(size_t n, hipStream_t stream)
     return e.p;
 }
 
-#ifndef MQS_SBA_FUSED_STEP
-#define MQS_SBA_FUSED_STEP 1          // 0: diagonal block, panel and update as three launches per block column (A/B builds)
-#endif
 #ifndef MQS_SBA_BLOCKED_SUBST
 #define MQS_SBA_BLOCKED_SUBST 1       // 0: the column-oriented substitution kernel (A/B builds)
 #endif
@@ -1319,7 +1191,6 @@ int mqs_sba_solve_banded_dev(double *S, double *x, int64_t P, int64_t half_bandw
     } else {
         // right-looking blocked Cholesky; rows further than hb below a block column are zero there and stay zero
         // (no fill outside the band), so the panel and the trailing update stop hb rows below it
-#if MQS_SBA_FUSED_STEP
         // one launch per block column: the first diagonal block, then panel + update + next diagonal block fused (see
         // chol_step_kernel).  The input must hold BOTH triangles (it does: the linearisers write both).
         hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(64), 0, stream, S, n, 0, bad);
@@ -1332,19 +1203,6 @@ int mqs_sba_solve_banded_dev(double *S, double *x, int64_t P, int64_t half_bandw
                 hipLaunchKernelGGL(chol_step_kernel, dim3(tiles, tiles), dim3(kBlock), 0, stream, S, n, k0, hb, bad);
             }
         }
-#else
-        for (int k0 = 0; k0 < n; k0 += NB) {
-            const int nb = (n - k0) < NB ? (n - k0) : NB;
-            hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(64), 0, stream, S, n, k0, bad);
-            int rem = n - k0 - nb;
-            if (rem > hb) rem = hb;
-            if (rem > 0) {
-                hipLaunchKernelGGL(chol_panel_kernel, dim3((rem + 7) / 8), dim3(kBlock), 0, stream, S, n, k0);
-                const int tiles = (rem + NB - 1) / NB;
-                hipLaunchKernelGGL(chol_update_kernel, dim3(tiles, tiles), dim3(kBlock), 0, stream, S, n, k0);
-            }
-        }
-#endif
         const size_t lds = ((size_t)n + (size_t)kSlab * (hb + kSlab)) * 8;
         const int hbs = banded ? hb : n;                     // the dense factor is a band of full width
         const int cap = banded_blocked_cap(n, hbs);
