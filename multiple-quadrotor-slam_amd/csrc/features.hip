@@ -353,33 +353,37 @@ __global__ __launch_bounds__(kSelThreads) void sort_select_kernel(unsigned long 
 // ---------------------------------------------------------------------------------------------------
 // Pyramid and derivatives (integer, exact)
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void pyr_down_kernel(const uint8_t *__restrict__ src, int W, int H, uint8_t *__restrict__ dst,
-                                                         int Wd, int Hd)
+// One launch per pyramid level instead of three: blockIdx.z = 0 takes the Scharr derivatives of level l of the previous
+// image, z = 1 / 2 reduce level l of the previous / next image to level l + 1 (all three only read level l).  The grid is
+// sized for the derivative image; the two reductions use its first quarter.
+__global__ __launch_bounds__(kBlock) void pyr_level_kernel(const uint8_t *__restrict__ I, const uint8_t *__restrict__ J, int W, int H,
+                                                          short2 *__restrict__ dI, uint8_t *__restrict__ Id, uint8_t *__restrict__ Jd,
+                                                          int Wd, int Hd)
 {
     const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
-    if (x >= Wd || y >= Hd) return;
-    const int k[5] = {1, 4, 6, 4, 1};
+    if (blockIdx.z == 0) {
+        if (x >= W || y >= H) return;
+        const int ym = reflect101(y - 1, H), yp = reflect101(y + 1, H), xm = reflect101(x - 1, W), xp = reflect101(x + 1, W);
+        const int a = I[ym * W + xm], b = I[ym * W + x], c = I[ym * W + xp];
+        const int e = I[y * W + xm], f = I[y * W + xp];
+        const int g = I[yp * W + xm], h = I[yp * W + x], k = I[yp * W + xp];
+        dI[y * W + x] = make_short2((short)(3 * (c - a) + 10 * (f - e) + 3 * (k - g)), (short)(3 * (g - a) + 10 * (h - b) + 3 * (k - c)));
+        return;
+    }
+    if (Id == nullptr || x >= Wd || y >= Hd) return;
+    const uint8_t *src = blockIdx.z == 1 ? I : J;
+    uint8_t *dst = blockIdx.z == 1 ? Id : Jd;
+    const int k5[5] = {1, 4, 6, 4, 1};
     int acc = 0;
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
         const int yy = reflect101(2 * y + j - 2, H);
         int row = 0;
 #pragma unroll
-        for (int i = 0; i < 5; ++i) row += k[i] * (int)src[yy * W + reflect101(2 * x + i - 2, W)];
-        acc += k[j] * row;
+        for (int i = 0; i < 5; ++i) row += k5[i] * (int)src[yy * W + reflect101(2 * x + i - 2, W)];
+        acc += k5[j] * row;
     }
     dst[y * Wd + x] = (uint8_t)((acc + 128) >> 8);
-}
-
-__global__ __launch_bounds__(kBlock) void scharr_kernel(const uint8_t *__restrict__ src, int W, int H, short2 *__restrict__ d)
-{
-    const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
-    if (x >= W || y >= H) return;
-    const int ym = reflect101(y - 1, H), yp = reflect101(y + 1, H), xm = reflect101(x - 1, W), xp = reflect101(x + 1, W);
-    const int a = src[ym * W + xm], b = src[ym * W + x], c = src[ym * W + xp];
-    const int e = src[y * W + xm], f = src[y * W + xp];
-    const int g = src[yp * W + xm], h = src[yp * W + x], k = src[yp * W + xp];
-    d[y * W + x] = make_short2((short)(3 * (c - a) + 10 * (f - e) + 3 * (k - g)), (short)(3 * (g - a) + 10 * (h - b) + 3 * (k - c)));
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -743,23 +747,26 @@ int mqs_calc_optical_flow_pyr_lk_dev(const uint8_t *prev_img, const uint8_t *nex
     char *wsp = static_cast<char *>(workspace);
     int w = W, h = H;
     L.levels = 0;
+    L.I[0] = prev_img; L.J[0] = next_img;
     for (int l = 0; l <= max_level; ++l) {
         L.W[l] = w; L.H[l] = h;
-        if (l == 0) {
-            L.I[0] = prev_img; L.J[0] = next_img;
-        } else {
-            uint8_t *pi = reinterpret_cast<uint8_t *>(wsp); wsp += align_up((size_t)w * h);
-            uint8_t *pj = reinterpret_cast<uint8_t *>(wsp); wsp += align_up((size_t)w * h);
-            hipLaunchKernelGGL(pyr_down_kernel, grid2d(w, h), dim3(kBlock), 0, stream, L.I[l - 1], L.W[l - 1], L.H[l - 1], pi, w, h);
-            hipLaunchKernelGGL(pyr_down_kernel, grid2d(w, h), dim3(kBlock), 0, stream, L.J[l - 1], L.W[l - 1], L.H[l - 1], pj, w, h);
-            L.I[l] = pi; L.J[l] = pj;
-        }
         short2 *d = reinterpret_cast<short2 *>(wsp); wsp += align_up((size_t)w * h * 4);
-        hipLaunchKernelGGL(scharr_kernel, grid2d(w, h), dim3(kBlock), 0, stream, L.I[l], w, h, d);
         L.dI[l] = d;
         L.levels = l;
-        if (w <= 2 || h <= 2) break;
-        w = (w + 1) / 2; h = (h + 1) / 2;
+        const bool last = l == max_level || w <= 2 || h <= 2;
+        const int wd = (w + 1) / 2, hd = (h + 1) / 2;
+        uint8_t *pi = nullptr, *pj = nullptr;
+        if (!last) {
+            pi = reinterpret_cast<uint8_t *>(wsp); wsp += align_up((size_t)wd * hd);
+            pj = reinterpret_cast<uint8_t *>(wsp); wsp += align_up((size_t)wd * hd);
+            L.I[l + 1] = pi; L.J[l + 1] = pj;
+        }
+        // derivatives of this level and, beside them, both images' next level: one launch
+        dim3 g = grid2d(w, h);
+        g.z = last ? 1 : 3;
+        hipLaunchKernelGGL(pyr_level_kernel, g, dim3(kBlock), 0, stream, L.I[l], L.J[l], w, h, d, pi, pj, wd, hd);
+        if (last) break;
+        w = wd; h = hd;
     }
     if (n > 0)
         hipLaunchKernelGGL(lk_kernel, dim3(n), dim3(64), 0, stream, L, prev_pts, n, win_w, win_h, max_iter, (float)eps,
