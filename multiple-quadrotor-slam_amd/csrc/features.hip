@@ -15,9 +15,10 @@
 //     W x H key slots: eight passes over 307 200 keys for the few thousand candidates of a VGA frame, ~100 us in a
 //     dozen launches; the library is gone from the product.)  The response maximum is an atomic max of order-
 //     preserving keys inside the response kernel: no separate reduction launches;
-//   * minimum-distance selection is inherently sequential in the candidates: one wavefront walks the sorted list
-//     seven candidates at a time (63 lanes = 7 candidates x 9 neighbouring grid cells of the accepted set, kept in
-//     LDS when it fits), then settles the seven among themselves in order;
+//   * minimum-distance selection: the greedy rule (a candidate is a corner unless a stronger corner is closer than
+//     min_distance) is sequential as written; its result is reached as a parallel fixed point, 1024 candidates per round:
+//     pre-filter against the corners of earlier rounds (grid of accepted corners, in LDS when it fits), then sweeps in
+//     which every undecided survivor looks at the stronger survivors near it;
 //   * Lucas-Kanade: one wavefront per feature, lanes strided over the 21 x 21 window (7 pixels each, template and
 //     gradients in registers), all pyramid levels and all iterations inside one launch; window sums in fp64.
 #include <cstring>
@@ -136,12 +137,9 @@ __global__ __launch_bounds__(kBlock) void candidates_kernel(const float *__restr
         keys[slot] = ((unsigned long long)__float_as_uint(e) << 32) | (unsigned long long)(0xFFFFFFFFu - (((unsigned)y << 16) | (unsigned)x));
 }
 
-// Greedy minimum-distance selection over the sorted candidates.  grid: cells x 4 slots (x | y << 16, 0xFFFFFFFF =
-// empty), in dynamic LDS (IN_LDS) or in the workspace.  The whole workgroup clears the grid; the walk itself is one
-// wavefront, kBatch candidates per step: lane = 9 c + nb tests candidate c against the 4 slots of its neighbouring cell
-// nb, then the candidates of the step are settled among themselves in order (wave-uniform, positions by v_readlane).
-// Candidate positions come through an LDS chunk (one global round trip per 64 steps instead of one per step) and the
-// accepted corners leave through another: the serial chain touches LDS only.
+// Minimum-distance selection over the sorted candidates (one workgroup).  grid: cells x 4 slots (x | y << 16, 0xFFFFFFFF =
+// empty) holding the accepted corners, in dynamic LDS (IN_LDS) or in the workspace.  The greedy rule is evaluated as a
+// parallel fixed point, 1024 candidates per round -- see the comment inside the kernel.
 // The sort comes first, by the same (single) workgroup: the candidates arrive in the order their atomics happened.  Up to
 // kSortChunk keys are sorted in LDS by a bitonic network (descending; the keys are distinct); more than that -- a frame of
 // noise -- chunk by chunk into `keys` itself, then merged pairwise between `keys` and `tmp` (merge path: every thread finds
@@ -227,15 +225,18 @@ __global__ __launch_bounds__(kSelThreads) void sort_select_kernel(unsigned long 
         }
         __syncthreads();                                   // the sorted keys are in global memory; the LDS is free
     }
-    constexpr int kBatch = 7;
-    constexpr int kChunk = 64 * kBatch;
-    constexpr int kStage = 1024;
-    __shared__ unsigned int sKeys[kChunk];
-    __shared__ unsigned int sAccepted[kStage];
-    const int lane = threadIdx.x & 63;
+    constexpr int kBuckets = 2048;                         // hash table of the round's survivors by grid cell
+    __shared__ unsigned int sSurv[kSelThreads];            // survivors of the pre-filter, in candidate order: x | y << 16
+    __shared__ int sState[kSelThreads];                    // 0 undecided, 1 accepted, 2 rejected
+    __shared__ short sNext[kSelThreads];
+    __shared__ short sHead[kBuckets];
+    constexpr int kNbr = 8;
+    __shared__ short sNbr[kSelThreads * kNbr];
+    __shared__ int sWaveCount[kSelThreads / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned int n = counter[0];
     if (n > capacity) n = capacity;
-    int accepted = 0;
+    int accepted = 0;                                      // the same value in every thread
     const int limit = (max_corners > 0 && max_corners < out_capacity) ? max_corners : out_capacity;
     if (min_distance < 1.0f) {
         for (unsigned int i = threadIdx.x; i < n && (int)i < limit; i += kSelThreads) {
@@ -248,106 +249,178 @@ __global__ __launch_bounds__(kSelThreads) void sort_select_kernel(unsigned long 
     }
     const int cell = (int)rintf(min_distance);
     const int gw = (W + cell - 1) / cell, gh = (H + cell - 1) / cell;
-    auto slot_ref = [&](int i) -> unsigned int & {
-        if constexpr (IN_LDS) return sGrid[i];
-        else return grid_global[i];
+    auto slot_ptr = [&](int i) -> unsigned int * {
+        if constexpr (IN_LDS) return &sGrid[i];
+        else return &grid_global[i];
     };
-    for (int i = threadIdx.x; i < gw * gh * 4; i += kSelThreads) slot_ref(i) = 0xFFFFFFFFu;
+    for (int i = threadIdx.x; i < gw * gh * 4; i += kSelThreads) *slot_ptr(i) = 0xFFFFFFFFu;
     __syncthreads();
-    if (threadIdx.x >= 64) return;
     const float md2 = min_distance * min_distance, inv_cell = 1.0f / (float)cell;
-    const int c = lane / 9, nb = lane % 9;
-    for (unsigned int i0 = 0; i0 < n && accepted < limit; i0 += kBatch) {
-        if (i0 % kChunk == 0) {
-#pragma unroll
-            for (int m = 0; m < kBatch; ++m) {
-                const unsigned int ci = i0 + (unsigned)(64 * m + lane);
-                sKeys[64 * m + lane] = ci < n ? (unsigned int)(keys[ci] & 0xFFFFFFFFull) : 0u;
-            }
-            mqs_wave_lds_sync();
-        }
-        const unsigned int ci = i0 + (unsigned)c;
-        const bool have = lane < 9 * kBatch && ci < n;
-        int x = 0, y = 0, first_empty = 4, own_cell = 0;
-        bool clash = false;
-        if (have) {
-            const unsigned int pos = 0xFFFFFFFFu - sKeys[(i0 % kChunk) + c];
+    // floor(v / cell) without an integer division (v < 65536 is exact in float; one correction step)
+    auto cell_of = [&](int v) {
+        int c = (int)((float)v * inv_cell);
+        c += ((c + 1) * cell <= v) - (c * cell > v);
+        return c;
+    };
+    auto bucket_of = [&](int cxx, int cyy) { return (int)(((unsigned int)(cyy * gw + cxx) * 2654435761u) >> 21); };   // 11 bits
+    // The greedy rule -- a candidate is a corner unless a STRONGER corner lies closer than min_distance -- is sequential as
+    // written, but its result is a fixed point that can be reached in parallel.  kSelThreads candidates per round, one per
+    // thread, in order of strength:
+    //   1. pre-filter: a candidate closer than min_distance to a corner of an EARLIER round is out (the grid of accepted
+    //      corners, four slots per cell, nine cells to look at);
+    //   2. the survivors go into a hash table by cell, and every undecided one looks at the stronger survivors near it: one
+    //      accepted -> rejected; all rejected (or none) -> accepted; otherwise wait.  The strongest undecided survivor always
+    //      decides, so the sweeps end; on images they end after a handful;
+    //   3. the accepted ones, in order, up to the limit, go to the output and into the grid.
+    // (History: one wavefront walking the sorted list seven candidates at a time, 85 us for the ~1100 candidates a VGA frame
+    // needs for 300 corners; the pre-filter alone changed nothing, the strongest 1024 all survive an empty grid.)
+    for (unsigned int base = 0; base < n && accepted < limit; base += kSelThreads) {
+        const unsigned int ci = base + threadIdx.x;
+        bool survive = false;
+        unsigned int pos = 0u;
+        int x = 0, y = 0, cxx = 0, cyy = 0;
+        if (ci < n) {
+            pos = 0xFFFFFFFFu - (unsigned int)(keys[ci] & 0xFFFFFFFFull);
             x = (int)(pos & 0xFFFFu); y = (int)(pos >> 16);
-            // floor(x / cell) without an integer division (x < 65536 is exact in float; one correction step)
-            int cxx = (int)((float)x * inv_cell), cyy = (int)((float)y * inv_cell);
-            cxx += ((cxx + 1) * cell <= x) - (cxx * cell > x);
-            cyy += ((cyy + 1) * cell <= y) - (cyy * cell > y);
-            own_cell = cyy * gw + cxx;
-            const int yy = cyy + nb / 3 - 1, xx = cxx + nb % 3 - 1;
-            if (yy >= 0 && yy < gh && xx >= 0 && xx < gw) {
-                unsigned int v[4];
+            cxx = cell_of(x); cyy = cell_of(y);
+            bool clash = false;
 #pragma unroll
-                for (int slot = 0; slot < 4; ++slot) v[slot] = slot_ref((yy * gw + xx) * 4 + slot);
+            for (int k = 0; k < 9; ++k) {
+                const int xx = cxx + k % 3 - 1, yy = cyy + k / 3 - 1;
+                if (yy >= 0 && yy < gh && xx >= 0 && xx < gw) {
 #pragma unroll
-                for (int slot = 3; slot >= 0; --slot) {
-                    if (v[slot] != 0xFFFFFFFFu) {
-                        const float dx = (float)(x - (int)(v[slot] & 0xFFFFu)), dy = (float)(y - (int)(v[slot] >> 16));
-                        clash = clash || (dx * dx + dy * dy < md2);
-                    } else {
-                        first_empty = slot;                          // slots fill from 0: the lowest empty one
-                    }
-                }
-            }
-        }
-        const unsigned long long clashes = __ballot(clash);
-        int xs[kBatch], ys[kBatch], fe[kBatch], oc[kBatch];
-#pragma unroll
-        for (int j = 0; j < kBatch; ++j) {
-            xs[j] = __builtin_amdgcn_readlane(x, 9 * j);
-            ys[j] = __builtin_amdgcn_readlane(y, 9 * j);
-            oc[j] = __builtin_amdgcn_readlane(own_cell, 9 * j);
-            fe[j] = __builtin_amdgcn_readlane(first_empty, 9 * j + 4);   // the lane that looked at the candidate's own cell
-        }
-        unsigned int taken = 0;
-#pragma unroll
-        for (int j = 0; j < kBatch; ++j) {
-            if (i0 + j < n && accepted < limit && ((clashes >> (9 * j)) & 0x1FFull) == 0ull) {
-                // branch-free over the earlier candidates of the step (scalar branches would dominate the serial chain)
-                unsigned int bad = 0;
-                int slot = fe[j];
-#pragma unroll
-                for (int k = 0; k < j; ++k) {
-                    const float dx = (float)(xs[j] - xs[k]), dy = (float)(ys[j] - ys[k]);
-                    const unsigned int tk = (taken >> k) & 1u;
-                    bad |= tk & (unsigned int)(dx * dx + dy * dy < md2);
-                    slot += (int)(tk & (unsigned int)(oc[k] == oc[j]));      // same cell, taken this step
-                }
-                if (!bad) {
-                    taken |= 1u << j;
-                    if (lane == 0) {
-                        const unsigned int packed = (unsigned int)xs[j] | ((unsigned int)ys[j] << 16);
-                        sAccepted[accepted % kStage] = packed;
-                        // (a full cell cannot happen for points >= cell - 0.5 apart)
-                        if (slot < 4) slot_ref(oc[j] * 4 + slot) = packed;
-                    }
-                    ++accepted;
-                    if (accepted % kStage == 0) {                    // flush a full block (wave-uniform)
-                        mqs_wave_lds_sync();
-                        for (int t = lane; t < kStage; t += 64) {
-                            const unsigned int v = sAccepted[t];
-                            out_xy[2 * (accepted - kStage + t)] = (float)(v & 0xFFFFu);
-                            out_xy[2 * (accepted - kStage + t) + 1] = (float)(v >> 16);
+                    for (int slot = 0; slot < 4; ++slot) {
+                        const unsigned int v = *slot_ptr((yy * gw + xx) * 4 + slot);
+                        if (v != 0xFFFFFFFFu) {
+                            const float dx = (float)(x - (int)(v & 0xFFFFu)), dy = (float)(y - (int)(v >> 16));
+                            clash = clash || (dx * dx + dy * dy < md2);
                         }
                     }
                 }
             }
+            survive = !clash;
         }
-        if constexpr (IN_LDS) mqs_wave_lds_sync();
-        else __threadfence_block();                                  // the grid lives in global memory here
+        for (int b = threadIdx.x; b < kBuckets; b += kSelThreads) sHead[b] = -1;
+        const unsigned long long mask = __ballot(survive);
+        if (lane == 0) sWaveCount[wave] = __popcll(mask);
+        __syncthreads();
+        int offset = 0, total = 0;
+#pragma unroll
+        for (int w2 = 0; w2 < kSelThreads / 64; ++w2) {
+            const int cnt = sWaveCount[w2];
+            offset += w2 < wave ? cnt : 0;
+            total += cnt;
+        }
+        const int me = offset + __popcll(mask & ((1ull << lane) - 1ull));      // this survivor's rank = its priority in the round
+        if (survive) {
+            sSurv[me] = pos;
+            sState[me] = 0;
+        }
+        __syncthreads();
+        // chain the survivors of a bucket: lists are built by one thread per bucket walking nobody -- instead every survivor
+        // pushes itself with an atomic exchange on the bucket head (int heads would double the table; the exchange is on the
+        // 32-bit word holding two 16-bit heads, so it is done with a CAS loop on that word)
+        if (survive) {
+            const int b = bucket_of(cxx, cyy);
+            unsigned int *word = reinterpret_cast<unsigned int *>(sHead) + (b >> 1);
+            const int shift = (b & 1) * 16;
+            unsigned int old = *word, assumed;
+            do {
+                assumed = old;
+                const unsigned int repl = (assumed & ~(0xFFFFu << shift)) | ((unsigned int)(unsigned short)me << shift);
+                old = atomicCAS(word, assumed, repl);
+            } while (old != assumed);
+            sNext[me] = (short)((old >> shift) & 0xFFFFu);
+        }
+        __syncthreads();
+        // the stronger survivors within min_distance of this one, found once (the sweeps only re-read their states); a
+        // survivor with more than kNbr of them walks the buckets again in every sweep
+        int nnbr = 0;
+        bool overflow = false;
+        if (survive) {
+#pragma unroll 1
+            for (int k = 0; k < 9; ++k) {
+                const int xx = cxx + k % 3 - 1, yy = cyy + k / 3 - 1;
+                if (yy < 0 || yy >= gh || xx < 0 || xx >= gw) continue;
+                const int b = bucket_of(xx, yy);
+                bool seen = false;                                       // two of the nine cells in one bucket: walk it once
+                for (int k2 = 0; k2 < k; ++k2) {
+                    const int x2 = cxx + k2 % 3 - 1, y2 = cyy + k2 / 3 - 1;
+                    seen = seen || (y2 >= 0 && y2 < gh && x2 >= 0 && x2 < gw && bucket_of(x2, y2) == b);
+                }
+                if (seen) continue;
+                for (int j = sHead[b]; j >= 0; j = sNext[j]) {
+                    if (j >= me) continue;                               // only stronger survivors matter
+                    const unsigned int pj = sSurv[j];
+                    const float dx = (float)(x - (int)(pj & 0xFFFFu)), dy = (float)(y - (int)(pj >> 16));
+                    if (dx * dx + dy * dy < md2) {
+                        if (nnbr < kNbr) sNbr[me * kNbr + nnbr++] = (short)j;
+                        else overflow = true;
+                    }
+                }
+            }
+        }
+        // sweeps
+        int state = survive ? 0 : 2;
+        for (;;) {
+            if (state == 0) {
+                bool rejected = false, pending = false;
+                for (int t = 0; t < nnbr; ++t) {
+                    const int sj = sState[sNbr[me * kNbr + t]];
+                    rejected = rejected || sj == 1;
+                    pending = pending || sj == 0;
+                }
+                if (overflow) {
+#pragma unroll 1
+                    for (int k = 0; k < 9; ++k) {
+                        const int xx = cxx + k % 3 - 1, yy = cyy + k / 3 - 1;
+                        if (yy < 0 || yy >= gh || xx < 0 || xx >= gw) continue;
+                        for (int j = sHead[bucket_of(xx, yy)]; j >= 0; j = sNext[j]) {
+                            if (j >= me) continue;
+                            const unsigned int pj = sSurv[j];
+                            const float dx = (float)(x - (int)(pj & 0xFFFFu)), dy = (float)(y - (int)(pj >> 16));
+                            if (dx * dx + dy * dy < md2) {
+                                const int sj = sState[j];
+                                rejected = rejected || sj == 1;
+                                pending = pending || sj == 0;
+                            }
+                        }
+                    }
+                }
+                if (rejected) state = 2;
+                else if (!pending) state = 1;
+            }
+            __syncthreads();                                     // every read of this sweep has happened
+            if (survive) sState[me] = state;
+            if (!__syncthreads_or(state == 0)) break;
+        }
+        // the accepted survivors in order
+        const bool acc = survive && state == 1;
+        const unsigned long long amask = __ballot(acc);
+        __syncthreads();
+        if (lane == 0) sWaveCount[wave] = __popcll(amask);
+        __syncthreads();
+        int aoff = 0, atotal = 0;
+#pragma unroll
+        for (int w2 = 0; w2 < kSelThreads / 64; ++w2) {
+            const int cnt = sWaveCount[w2];
+            aoff += w2 < wave ? cnt : 0;
+            atotal += cnt;
+        }
+        const int arank = accepted + aoff + __popcll(amask & ((1ull << lane) - 1ull));
+        if (acc && arank < limit) {
+            out_xy[2 * arank] = (float)x;
+            out_xy[2 * arank + 1] = (float)y;
+            // a free slot of the corner's cell (corners >= cell - 0.5 apart: at most four per cell)
+            unsigned int *slots = slot_ptr((cyy * gw + cxx) * 4);
+            for (int slot = 0; slot < 4; ++slot)
+                if (atomicCAS(slots + slot, 0xFFFFFFFFu, pos) == 0xFFFFFFFFu) break;
+        }
+        accepted += atotal;
+        if (accepted > limit) accepted = limit;
+        __syncthreads();                                         // the grid is complete before the next round's pre-filter
     }
-    mqs_wave_lds_sync();
-    const int tail = accepted % kStage;
-    for (int t = lane; t < tail; t += 64) {
-        const unsigned int v = sAccepted[t];
-        out_xy[2 * (accepted - tail + t)] = (float)(v & 0xFFFFu);
-        out_xy[2 * (accepted - tail + t) + 1] = (float)(v >> 16);
-    }
-    if (lane == 0) out_n[0] = accepted;
+    if (threadIdx.x == 0) out_n[0] = accepted;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -699,16 +772,16 @@ int mqs_good_features_to_track_dev(const uint8_t *img, int W, int H, int max_cor
     const size_t cells = (size_t)((W + cell - 1) / cell) * ((H + cell - 1) / cell);
     const size_t sort_lds = (size_t)kSortChunk * sizeof(unsigned long long);
     const size_t grid_lds = cells * 16;
-    const bool in_lds = min_distance < 1.0 || grid_lds <= 140 * 1024;
-    const size_t lds = (in_lds && min_distance >= 1.0 && grid_lds > sort_lds) ? grid_lds : sort_lds;
+    const bool in_lds = min_distance < 1.0 || grid_lds <= sort_lds;      // the grid takes the sort buffer's place
+    const size_t lds = sort_lds;
     if (in_lds) {
         static mqs_lds_opt_in opt;                           // per device
-        MQS_HIP_CHECK(mqs_lds_opt_in_once(opt, reinterpret_cast<const void *>(sort_select_kernel<true>), 140 * 1024));
+        MQS_HIP_CHECK(mqs_lds_opt_in_once(opt, reinterpret_cast<const void *>(sort_select_kernel<true>), (int)sort_lds));
         hipLaunchKernelGGL(sort_select_kernel<true>, dim3(1), dim3(kSelThreads), lds, stream, keys, tmp, counter, (unsigned int)npx, W,
                            H, (float)min_distance, max_corners, out_capacity, grid, out_xy, out_n);
     } else {
         static mqs_lds_opt_in opt;                           // per device
-        MQS_HIP_CHECK(mqs_lds_opt_in_once(opt, reinterpret_cast<const void *>(sort_select_kernel<false>), 140 * 1024));
+        MQS_HIP_CHECK(mqs_lds_opt_in_once(opt, reinterpret_cast<const void *>(sort_select_kernel<false>), (int)sort_lds));
         hipLaunchKernelGGL(sort_select_kernel<false>, dim3(1), dim3(kSelThreads), sort_lds, stream, keys, tmp, counter,
                            (unsigned int)npx, W, H, (float)min_distance, max_corners, out_capacity, grid, out_xy, out_n);
     }
