@@ -100,7 +100,11 @@ def test_facade_argument_errors(mqs):
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape,maxc,q,md,masked", [((120, 160), 50, 0.01, 6.0, False), ((240, 320), 300, 0.01, 7.0, True),
                                                      ((97, 131), 0, 0.02, 1.0, False), ((480, 640), 300, 0.01, 7.0, True),
-                                                     ((64, 64), 20, 0.05, 0.0, False), ((200, 300), 1000, 0.001, 2.5, False)])
+                                                     ((64, 64), 20, 0.05, 0.0, False), ((200, 300), 1000, 0.001, 2.5, False),
+                                                     # wide minimum distances: every candidate has many stronger ones nearby
+                                                     # (more than the selection's per-candidate neighbour list holds)
+                                                     ((240, 320), 0, 0.001, 25.0, False), ((480, 640), 40, 0.0005, 60.0, True),
+                                                     ((480, 640), 0, 0.001, 1.0, False)])
 def test_gpu_good_features_equal_oracle(shape, maxc, q, md, masked, gpu):
     img = texture(shape[0], shape[1], seed=shape[0])
     mask = None
