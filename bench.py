@@ -362,11 +362,14 @@ def main():
         e1.synchronize()
         ms8 = e0.elapsed_time(e1) / 10
         tops = 2.0 * nd * nd * bits / (ms8 * 1e-3) / 1e12
-        match_out["packed_bits_int8"] = {"ms_per_pair": round(ms8, 3), "Tops": round(tops, 1), "mfma_i8_dense_peak_Tops": 5000.0,
-                                         "frac_of_peak": round(tops / 5000.0, 4),
+        # packed descriptors run on the FP4 matrix instruction (v_mfma_f32_32x32x64_f8f6f4, ~10 PF dense on MI355X); the key
+        # keeps its round-1 name, `int8_peak_equivalent` prices the same work against the 5 P int8 peak it was measured on before
+        match_out["packed_bits_int8"] = {"ms_per_pair": round(ms8, 3), "Tops": round(tops, 1), "matrix_path": "fp4 (E2M1), fp32 accumulate",
+                                         "mfma_fp4_dense_peak_Tops": 10000.0, "frac_of_peak": round(tops / 10000.0, 4),
+                                         "int8_peak_equivalent": round(tops / 5000.0, 4),
                                          "equals_fp16_path": bool(torch.equal(mi, mi8) and torch.equal(md, md8))}
-        # BASELINE configs[2] in full: 4 cameras x `nd` descriptors, every unordered camera pair (6), kNN-2 on the int8
-        # matrix pipe + the reference's ratio test / one-match-per-train-row filter on the device; pairs deal to ranks
+        # BASELINE configs[2] in full: 4 cameras x `nd` descriptors, every unordered camera pair (6), kNN-2 on the FP4
+        # matrix path + the reference's ratio test / one-match-per-train-row filter on the device; pairs deal to ranks
         cams = [tp] + [torch.from_numpy(Mm.pack_bits(Mm.binary_descriptors(nd, bits, seed=20 + c, copies_of=tb.astype(np.uint8)))).to(dev)
                        for c in range(1, 4)]
         res = Mm.cross_match_dev(cams, rank, world, max_radius=8.0, max_dist_ratio=0.8)
@@ -436,8 +439,8 @@ def main():
     if match_out is not None:
         rooflines["match_knn2_f16"] = {"bound": "mfma", "achieved": match_out["TFLOPs"], "peak": 2500.0, "unit": "TFLOP/s",
                                        "frac": match_out["frac_of_peak"]}
-        rooflines["match_knn2_bits_i8"] = {"bound": "mfma", "achieved": match_out["packed_bits_int8"]["Tops"], "peak": 5000.0,
-                                           "unit": "Top/s", "frac": match_out["packed_bits_int8"]["frac_of_peak"]}
+        rooflines["match_knn2_bits_fp4"] = {"bound": "mfma", "achieved": match_out["packed_bits_int8"]["Tops"], "peak": 10000.0,
+                                            "unit": "Top/s", "frac": match_out["packed_bits_int8"]["frac_of_peak"]}
 
     # ---- BASELINE configs[4] counterpart: the per-frame loop replayed from the reference's recorded tracks
     #      (committed fixture tests/golden/ba_svo: 186 frames, 1046 landmarks), rank 0 reports ----

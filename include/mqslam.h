@@ -154,8 +154,10 @@ int64_t mqs_match_knn2_f16_workspace_bytes(int64_t Nq, int64_t Nt);
 
 /* Packed binary descriptors as ORB / BRIEF produce them (D bits per row = D / 8 bytes, bit k of a descriptor = bit
  * (k & 7) of byte k >> 3; D in {128, 256, 512}): Hamming distance = |q - t|^2 of the {0,1} vectors, contracted on the
- * int8 matrix pipe (v_mfma_i32_32x32x32_i8).  Same outputs as the fp16 path: dist = sqrt(Hamming distance), ties
- * towards the lower train index; bit-exact against it on the same descriptors. */
+ * matrix pipe as FP4 operands (v_mfma_f32_32x32x64_f8f6f4 with E2M1 nibbles 0 / 1 and 0 / -2: every partial sum is a small
+ * integer, exact in the fp32 accumulator; round 1 and the first half of round 2 used int8, v_mfma_i32_32x32x32_i8, which
+ * csrc/match.hip still carries behind MQS_MATCH_BITS_FP4=0).  Same outputs as the fp16 path: dist = sqrt(Hamming distance),
+ * ties towards the lower train index; bit-exact against it on the same descriptors. */
 int mqs_match_knn2_bits(mqs_ctx *ctx, const uint8_t *query_bits, int64_t Nq, const uint8_t *train_bits, int64_t Nt, int D,
                         int32_t *idx, float *dist);
 int mqs_match_knn2_bits_dev(const uint8_t *query_bits, int64_t Nq, const uint8_t *train_bits, int64_t Nt, int D, int32_t *idx,

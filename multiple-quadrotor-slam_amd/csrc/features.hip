@@ -304,13 +304,9 @@ __global__ __launch_bounds__(kSelThreads) void sort_select_kernel(unsigned long 
         const unsigned long long mask = __ballot(survive);
         if (lane == 0) sWaveCount[wave] = __popcll(mask);
         __syncthreads();
-        int offset = 0, total = 0;
+        int offset = 0;
 #pragma unroll
-        for (int w2 = 0; w2 < kSelThreads / 64; ++w2) {
-            const int cnt = sWaveCount[w2];
-            offset += w2 < wave ? cnt : 0;
-            total += cnt;
-        }
+        for (int w2 = 0; w2 < kSelThreads / 64; ++w2) offset += w2 < wave ? sWaveCount[w2] : 0;
         const int me = offset + __popcll(mask & ((1ull << lane) - 1ull));      // this survivor's rank = its priority in the round
         if (survive) {
             sSurv[me] = pos;

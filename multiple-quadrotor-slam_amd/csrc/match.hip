@@ -149,6 +149,21 @@ using float16v = __attribute__((ext_vector_type(16))) float;
 #ifndef MQS_MATCH_PRUNE_F16
 #define MQS_MATCH_PRUNE_F16 0          // the same on the fp16 path (not bound by vector issue: measured)
 #endif
+#ifndef MQS_MATCH_BITS_FP4
+#define MQS_MATCH_BITS_FP4 1           // packed-bit descriptors on the FP4 matrix path (F4Path) instead of int8 (I8Path)
+#endif
+#ifndef MQS_MATCH_F4_QT
+#define MQS_MATCH_F4_QT 4
+#endif
+#ifndef MQS_MATCH_F4_NW
+#define MQS_MATCH_F4_NW 8
+#endif
+#ifndef MQS_MATCH_F4_GROUP
+#define MQS_MATCH_F4_GROUP 2
+#endif
+#ifndef MQS_MATCH_PRUNE_F4
+#define MQS_MATCH_PRUNE_F4 1
+#endif
 #ifndef MQS_MATCH_I8_QT
 #define MQS_MATCH_I8_QT 4
 #endif
@@ -163,9 +178,9 @@ using float16v = __attribute__((ext_vector_type(16))) float;
 // latency of their first fragment reads exposed; at 64 rows (64 MFMAs per wave and stage) that was 8 % of the fp16 kernel's
 // time (1.41 -> 1.30 ms at 128 rows, same box) -- a stage should be as long as the LDS allows.
 constexpr int stage_bytes(int rows, int ks) { return rows * (2 * ks + 1) * 16; }
-constexpr int stage_rows(int ks)
+constexpr int stage_rows(int ks, int rows_max = MQS_MATCH_STAGE_ROWS)
 {
-    int rows = MQS_MATCH_STAGE_ROWS;
+    int rows = rows_max;
     while (rows > 64 && 2 * stage_bytes(rows, ks) > 150 * 1024) rows /= 2;
     return rows;
 }
@@ -218,6 +233,8 @@ struct F16Path {
     // same box: at 3 vector instructions per MFMA the fp16 kernel is not bound by vector issue; the int8 one, at 6, was.)
     static constexpr bool kRowInStart = false;
     static constexpr bool kPrune = MQS_MATCH_PRUNE_F16 != 0;
+    static constexpr int kGroup = 1;
+    static constexpr int kStageRowsMax = MQS_MATCH_STAGE_ROWS;
     // smallest key a value at distance part >= d can have (positive floats order like their bit patterns)
     static __device__ __forceinline__ unsigned key_floor(float d) { return __float_as_uint(d); }
     static constexpr float kBiasV = kBias;
@@ -254,6 +271,8 @@ struct I8Path {
     // so the finished accumulator IS the key: the scan costs v_med3_u32 + v_min_u32 per value, no v_or3
     static constexpr bool kRowInStart = true;
     static constexpr bool kPrune = MQS_MATCH_PRUNE_I8 != 0;
+    static constexpr int kGroup = 1;
+    static constexpr int kStageRowsMax = MQS_MATCH_STAGE_ROWS;
     static __device__ __forceinline__ unsigned key_floor(float d) { return d < kInvalid ? ((unsigned)d << 12) : 0xFFFFFFFFu; }
     static constexpr float kBiasV = kBias;
     static __device__ __forceinline__ start_t start(float tnorm, int64_t t) { return (((int)tnorm + (int)kBias) << 12) | (int)(((t >> 5) & (kWindowTiles - 1)) << 5) | (int)(t & 31); }
@@ -270,7 +289,30 @@ struct I8Path {
     }
 };
 
-template <class TP /* F16Path or I8Path */, int KS /* MFMAs per (train tile, query tile) = D / TP::kPerMfma */,
+// {0,1} descriptors as FP4 (E2M1) on the block-scaled matrix instruction without scales, v_mfma_f32_32x32x64_f8f6f4 cbsz:4
+// blgp:4: 64 contraction steps per instruction at the cycles of the 16-step fp16 / 32-step int8 forms (MI355X: ~10 PF dense),
+// half the LDS bytes of the int8 image.  Train nibbles are 0 / 1.0 (0x2), query nibbles 0 / -2.0 (0xC): every product and
+// every partial sum is a small integer, exact in the fp32 accumulator, which starts from kBias + |t|^2 + tile / 256 as on the
+// fp16 path -- the key, its decoding and the windows are F16Path's.  A fragment is 32 nibbles = 16 bytes per lane; which
+// contraction index a nibble position stands for does not matter as long as query and train rows are packed alike (they are:
+// the same expansion kernel), and the parity tests against the oracle would show a mismatch.
+using int8v = __attribute__((ext_vector_type(8))) int;
+struct F4Path : F16Path {
+    using elem = signed char;                           // two nibbles per byte: 32 bytes of a row per MFMA
+    using frag = int4v;
+    static constexpr int kPerMfma = 32;
+    static constexpr bool kPrune = MQS_MATCH_PRUNE_F4 != 0;
+    static constexpr int kGroup = MQS_MATCH_F4_GROUP;      // query tiles per train-fragment read (see group_step)
+    static constexpr int kStageRowsMax = 256;              // 36 KB stages (A/B: 128 rows + 3 %, 512 rows + 5 % time)
+    static __device__ __forceinline__ frag prep_query(frag v) { return v; }
+    static __device__ __forceinline__ accv mfma(frag a, frag b, accv c)
+    {
+        return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(int8v{a[0], a[1], a[2], a[3], 0, 0, 0, 0},
+                                                               int8v{b[0], b[1], b[2], b[3], 0, 0, 0, 0}, c, 4, 4, 0, 0, 0, 0);
+    }
+};
+
+template <class TP /* F16Path, I8Path or F4Path */, int KS /* MFMAs per (train tile, query tile) = D / TP::kPerMfma */,
           int QT /* 32-query column tiles per wave */, int NW /* waves per workgroup */>
 __global__ __launch_bounds__(NW * 64) void knn2_mfma_kernel(const typename TP::elem *__restrict__ query, int64_t Nq,
                                                            const typename TP::elem *__restrict__ train, int64_t Nt,
@@ -284,7 +326,7 @@ __global__ __launch_bounds__(NW * 64) void knn2_mfma_kernel(const typename TP::e
     using start_t = typename TP::start_t;
     constexpr int D = KS * TP::kPerMfma;
     constexpr int kWindowTiles = TP::kWindowTiles;
-    constexpr int kStageRows = stage_rows(KS);
+    constexpr int kStageRows = stage_rows(KS, TP::kStageRowsMax);
     constexpr int kStageTiles = kStageRows / 32;
     constexpr int kWindowStages = kWindowTiles * 32 / kStageRows;
     constexpr int kVecPerRow = 2 * KS;                 // 16-byte pieces of data per row (one per (k-step, lane half))
@@ -343,6 +385,8 @@ __global__ __launch_bounds__(NW * 64) void knn2_mfma_kernel(const typename TP::e
     const int64_t s_end = s_end_ < nstages_all ? s_end_ : nstages_all;
     const int64_t nstages = s_end > s_begin ? s_end - s_begin : 0;
     const uint4 *tvec = reinterpret_cast<const uint4 *>(train);
+
+    constexpr int G = (TP::kGroup > 1 && QT % TP::kGroup == 0) ? TP::kGroup : 1;     // query tiles per fragment read (group_step)
 
     // Stage fill by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write).  One
     // wave-instruction writes 64 x 16 B = 1 KiB of LDS linearly (wave-uniform base + lane * 16); which
@@ -448,6 +492,67 @@ __global__ __launch_bounds__(NW * 64) void knn2_mfma_kernel(const typename TP::e
 #endif
     };
 
+    // G query tiles per train-fragment read.  A step above re-reads the tile's KS fragments and its 16 start values for every
+    // query tile: (KS + 4) / KS LDS instructions per MFMA -- 2.0 on the FP4 path, where an MFMA covers 64 contraction steps, and
+    // with four SIMDs sharing the LDS (256 B/clk: 4 cycles per ds_read_b128) that is 32 of every 32 cycles of a saturated matrix
+    // pipe.  Here a fragment feeds G MFMAs (independent accumulators) and the start values are read once per tile by the caller:
+    // 1 / G LDS instructions per MFMA.  The accumulators form QT / G groups (two sets of one group when G == QT); step j writes
+    // group j % NG and scans the previous one.
+    auto group_step = [&](const unsigned char *tile, int tt, const accv_t &start, accv_t *acc, int cur0, int prev0, int curq0, int prevq0) {
+        if constexpr (G > 1) {
+        const unsigned char *arow = tile + (tt * 32 + r) * kRowBytes + 16 * h;
+        constexpr int PF = MQS_MATCH_PF < KS ? MQS_MATCH_PF : KS;
+        frag_t a[KS];
+#pragma unroll
+        for (int ks = 0; ks < PF; ++ks) a[ks] = *reinterpret_cast<const frag_t *>(arow + 32 * ks);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if (ks + PF < KS) a[ks + PF] = *reinterpret_cast<const frag_t *>(arow + 32 * (ks + PF));
+#pragma unroll
+            for (int u = 0; u < G; ++u) acc[cur0 + u] = TP::mfma(a[ks], qf[curq0 + u][ks], ks == 0 ? start : acc[cur0 + u]);
+            // the previous group's 16 G values, 16 G / KS behind each k-step
+            constexpr int kPer = 16 * G / KS;
+            static_assert(16 * G % KS == 0 && (!TP::kPrune || kPer % 4 == 0), "scan shares");
+            if constexpr (TP::kPrune) {
+#pragma unroll
+                for (int gq = 0; gq < kPer / 4; ++gq) {
+                    const int v0 = ks * kPer + 4 * gq, which = v0 >> 4, e0 = v0 & 15, pq = prevq0 + which;
+                    const accv_t &prev = acc[prev0 + which];
+                    const unsigned k0 = TP::key(prev[e0]), k1 = TP::key(prev[e0 + 1]), k2 = TP::key(prev[e0 + 2]), k3 = TP::key(prev[e0 + 3]);
+                    unsigned m3;
+                    asm("v_min3_u32 %0, %1, %2, %3" : "=v"(m3) : "v"(k0), "v"(k1), "v"(k2));
+                    const unsigned m4 = min(m3, k3);
+                    if (__builtin_amdgcn_ballot_w64(m4 < thr[pq]) != 0) {
+#pragma unroll
+                        for (int e = e0; e < e0 + 4; ++e) {
+                            const unsigned key = TP::kRowInStart ? TP::key(prev[e])
+                                                                 : (TP::key(prev[e]) | (unsigned)(4 * h) | (unsigned)(8 * (e >> 2) + (e & 3)));
+                            unsigned m;
+                            asm("v_med3_u32 %0, %1, %2, %3" : "=v"(m) : "v"(best[pq]), "v"(second[pq]), "v"(key));
+                            second[pq] = m;
+                            best[pq] = min(best[pq], key);
+                        }
+                        thr[pq] = min(second[pq], TP::key_floor(gd1[pq]));
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int v = ks * kPer; v < (ks + 1) * kPer; ++v) {
+                    const int which = v >> 4, e = v & 15, pq = prevq0 + which;
+                    const accv_t &prev = acc[prev0 + which];
+                    const unsigned key = TP::kRowInStart ? TP::key(prev[e])
+                                                         : (TP::key(prev[e]) | (unsigned)(4 * h) | (unsigned)(8 * (e >> 2) + (e & 3)));
+                    unsigned m;
+                    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(m) : "v"(best[pq]), "v"(second[pq]), "v"(key));
+                    second[pq] = m;
+                    best[pq] = min(best[pq], key);
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
     // decode a window key: distance part, row index
     auto push = [&](int qt, unsigned key, int64_t window_base) {
         float d;
@@ -475,11 +580,15 @@ __global__ __launch_bounds__(NW * 64) void knn2_mfma_kernel(const typename TP::e
     if (nstages > 0) stage_issue(s_begin);               // Nt == 0: nothing to read, every key stays invalid
     __syncthreads();                                     // (waits for the LDS-DMA: vmcnt(0) + barrier)
 
-    constexpr int R = QT < 2 ? 2 : QT;                   // accumulator ring: step j writes acc[j % R], scans acc[(j - 1) % R]
-    static_assert((kStageTiles * QT) % R == 0, "the ring position must repeat every stage");
+    constexpr int NG = QT / G;                           // accumulator groups; one group alone needs a second set to scan
+    constexpr int NSETS = G > 1 ? (NG < 2 ? 2 : NG) : (QT < 2 ? 2 : QT);
+    constexpr int R = G > 1 ? NSETS * G : NSETS;         // accumulator ring: step j writes set j % NSETS, scans set (j - 1) % NSETS
+    static_assert((kStageTiles * (G > 1 ? NG : QT)) % NSETS == 0, "the ring position must repeat every stage");
     accv_t acc[R];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[R - 1][e] = TP::pad();   // "previous step" of the first one: nothing
+    for (int e = 0; e < 16; ++e)
+#pragma unroll
+        for (int u = 0; u < G; ++u) acc[R - 1 - u][e] = TP::pad();   // "previous step" of the first one: nothing
 
 #if MQS_MATCH_NOPEEL
 #pragma clang loop unroll(disable)
@@ -488,6 +597,25 @@ __global__ __launch_bounds__(NW * 64) void knn2_mfma_kernel(const typename TP::e
         if (s + 1 < s_end) stage_issue(s + 1);            // lands while this stage is computed
         const unsigned char *tile = sTile + (int)(s & 1) * kStageBytes;
         const start_t *tn0 = sTn + (int)(s & 1) * kStageRows + 4 * h;
+        if constexpr (G > 1) {
+#pragma unroll
+            for (int tt = 0; tt < kStageTiles; ++tt) {
+                accv_t start;                                 // row(e) = (e & 3) + 8 (e >> 2) + 4 h: once per tile
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const typename TP::start4 t4 = *reinterpret_cast<const typename TP::start4 *>(tn0 + 32 * tt + 8 * g4);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) start[4 * g4 + k] = t4[k];
+                }
+#pragma unroll
+                for (int gi = 0; gi < NG; ++gi) {
+                    const int j = tt * NG + gi;
+                    group_step(tile, tt, start, acc, (j % NSETS) * G, ((j + NSETS - 1) % NSETS) * G, gi * G, ((gi + NG - 1) % NG) * G);
+                    if (j == 0 && (s & (kWindowStages - 1)) == 0 && s > s_begin)
+                        close_window((s / kWindowStages - 1) * (int64_t)(kWindowTiles * 32));
+                }
+            }
+        } else {
 #pragma unroll
         for (int tt = 0; tt < kStageTiles; ++tt)
 #pragma unroll
@@ -498,17 +626,24 @@ __global__ __launch_bounds__(NW * 64) void knn2_mfma_kernel(const typename TP::e
                 if (j == 0 && (s & (kWindowStages - 1)) == 0 && s > s_begin)
                     close_window((s / kWindowStages - 1) * (int64_t)(kWindowTiles * 32));
             }
+        }
         __syncthreads();
     }
     // scan of the last step, last window
     if (nstages > 0) {
-        constexpr int jl = kStageTiles * QT - 1;
+        // the last step's accumulators: set (steps per stage - 1) % NSETS, query tiles QT - G ..
+        constexpr int jl = kStageTiles * (G > 1 ? NG : QT) - 1;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const unsigned key = TP::kRowInStart ? TP::key(acc[jl % R][e])
-                                                 : (TP::key(acc[jl % R][e]) | (unsigned)(4 * h) | (unsigned)(8 * (e >> 2) + (e & 3)));
-            second[QT - 1] = max(best[QT - 1], min(second[QT - 1], key));
-            best[QT - 1] = min(best[QT - 1], key);
+        for (int u = 0; u < G; ++u) {
+            const accv_t &last = acc[G > 1 ? (jl % NSETS) * G + u : jl % R];
+            const int qt = QT - G + u;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const unsigned key = TP::kRowInStart ? TP::key(last[e])
+                                                     : (TP::key(last[e]) | (unsigned)(4 * h) | (unsigned)(8 * (e >> 2) + (e & 3)));
+                second[qt] = max(best[qt], min(second[qt], key));
+                best[qt] = min(best[qt], key);
+            }
         }
         close_window(((s_end - 1) / kWindowStages) * (int64_t)(kWindowTiles * 32));
     }
@@ -647,6 +782,28 @@ __global__ void expand_bits_kernel(const uint8_t *__restrict__ bits, int64_t n, 
 }
 
 
+// The same for F4Path: nibble k of the expanded row = bit k of the descriptor ? `code` : 0 (`code` = 0x2: 1.0 for train
+// rows, 0xC: -2.0 for query rows), two nibbles per byte; `Dout` bits wide, zero beyond D.
+__global__ void expand_bits_fp4_kernel(const uint8_t *__restrict__ bits, int64_t n, int D, int Dout, unsigned code,
+                                       signed char *__restrict__ out, float *__restrict__ norm)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t *src = bits + i * (D / 8);
+    unsigned *dst = reinterpret_cast<unsigned *>(out + i * (Dout / 2));
+    for (int b = D / 8; b < Dout / 8; ++b) dst[b] = 0u;
+    int pop = 0;
+    for (int b = 0; b < D / 8; ++b) {
+        const unsigned v = src[b];
+        pop += __popc(v);
+        unsigned w = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) w |= ((v >> k) & 1u) ? (code << (4 * k)) : 0u;
+        dst[b] = w;
+    }
+    norm[i] = (float)pop;
+}
+
 // ---- caller-side filter of the reference (Work/SLAM/application/own/slam.py:108-125) -------------------------------
 // Per query: the radius filter of radiusMatch (cv2_helpers.py:311-331), then the ratio test (a single match inside the
 // radius passes; two pass when d0 / d1 < ratio, the division in double like the Python floats of DMatch.distance), then one
@@ -773,7 +930,8 @@ int mqs_match_knn2_f16_dev(const uint16_t *query, int64_t Nq, const uint16_t *tr
 }
 
 // Packed binary descriptors (D bits per row, D / 8 bytes, D in {128, 256, 512}): Hamming distance = |q - t|^2 on the
-// int8 matrix pipe (v_mfma_i32_32x32x32_i8), same output contract as the fp16 path (dist = sqrt(Hamming)).
+// FP4 matrix path (F4Path; the int8 path, I8Path, with MQS_MATCH_BITS_FP4=0), same output contract as the fp16 path
+// (dist = sqrt(Hamming)).  65 536^2 x 256 bits: fp16 1.33 ms, int8 0.70 ms, FP4 0.49-0.51 ms on the same boxes.
 int64_t mqs_match_knn2_bits_workspace_bytes(int64_t Nq, int64_t Nt, int D)
 {
     if (Nq < 0 || Nt < 0 || D < 8) return 0;
@@ -808,6 +966,22 @@ int mqs_match_knn2_bits_dev(const uint8_t *query_bits, int64_t Nq, const uint8_t
     // 128-bit descriptors run on the 256-column kernel, zero-padded: that instantiation (8 waves, four query tiles per wave)
     // is faster on twice the columns than the 128-column one was on its own (0.85 vs 1.31 ms per 65 536^2 pair)
     const int De = (D == 128) ? 256 : D;
+#if MQS_MATCH_BITS_FP4
+    hipLaunchKernelGGL(expand_bits_fp4_kernel, dim3((unsigned)((Nq + 255) / 256)), dim3(256), 0, stream, query_bits, Nq, D, De, 0xCu, q8, qn);
+    if (Nt > 0)
+        hipLaunchKernelGGL(expand_bits_fp4_kernel, dim3((unsigned)((Nt + 255) / 256)), dim3(256), 0, stream, train_bits, Nt, D, De, 0x2u, t8, tn);
+    switch (De) {
+    case 256:
+        if (tiles_fill<F4Path>(Nq, Nt, MQS_MATCH_F4_NW, MQS_MATCH_F4_QT, num_cus))
+            launch_mfma_t<F4Path, 4, MQS_MATCH_F4_QT, MQS_MATCH_F4_NW>(q8, Nq, t8, Nt, qn, tn, idx, dist, part_d, part_i, num_cus, stream);
+        else
+            launch_mfma_t<F4Path, 4, 1, 8>(q8, Nq, t8, Nt, qn, tn, idx, dist, part_d, part_i, num_cus, stream);
+        break;
+    case 512: launch_mfma_t<F4Path, 8, 2, 8>(q8, Nq, t8, Nt, qn, tn, idx, dist, part_d, part_i, num_cus, stream); break;
+    }
+    MQS_HIP_CHECK(hipGetLastError());
+    return MQS_OK;
+#endif
     hipLaunchKernelGGL(expand_bits_kernel, dim3((unsigned)((Nq + 255) / 256)), dim3(256), 0, stream, query_bits, Nq, D, De, -128, q8, qn);
     if (Nt > 0)
         hipLaunchKernelGGL(expand_bits_kernel, dim3((unsigned)((Nt + 255) / 256)), dim3(256), 0, stream, train_bits, Nt, D, De, 64, t8, tn);
