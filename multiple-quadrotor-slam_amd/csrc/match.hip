@@ -967,10 +967,17 @@ int mqs_match_knn2_bits_dev(const uint8_t *query_bits, int64_t Nq, const uint8_t
     // is faster on twice the columns than the 128-column one was on its own (0.85 vs 1.31 ms per 65 536^2 pair)
     const int De = (D == 128) ? 256 : D;
 #if MQS_MATCH_BITS_FP4
-    hipLaunchKernelGGL(expand_bits_fp4_kernel, dim3((unsigned)((Nq + 255) / 256)), dim3(256), 0, stream, query_bits, Nq, D, De, 0xCu, q8, qn);
+    // (no padding of 128-bit descriptors here: two FP4 MFMAs per tile cover them)
+    hipLaunchKernelGGL(expand_bits_fp4_kernel, dim3((unsigned)((Nq + 255) / 256)), dim3(256), 0, stream, query_bits, Nq, D, D, 0xCu, q8, qn);
     if (Nt > 0)
-        hipLaunchKernelGGL(expand_bits_fp4_kernel, dim3((unsigned)((Nt + 255) / 256)), dim3(256), 0, stream, train_bits, Nt, D, De, 0x2u, t8, tn);
-    switch (De) {
+        hipLaunchKernelGGL(expand_bits_fp4_kernel, dim3((unsigned)((Nt + 255) / 256)), dim3(256), 0, stream, train_bits, Nt, D, D, 0x2u, t8, tn);
+    switch (D) {
+    case 128:
+        if (tiles_fill<F4Path>(Nq, Nt, MQS_MATCH_F4_NW, MQS_MATCH_F4_QT, num_cus))
+            launch_mfma_t<F4Path, 2, MQS_MATCH_F4_QT, MQS_MATCH_F4_NW>(q8, Nq, t8, Nt, qn, tn, idx, dist, part_d, part_i, num_cus, stream);
+        else
+            launch_mfma_t<F4Path, 2, 1, 8>(q8, Nq, t8, Nt, qn, tn, idx, dist, part_d, part_i, num_cus, stream);
+        break;
     case 256:
         if (tiles_fill<F4Path>(Nq, Nt, MQS_MATCH_F4_NW, MQS_MATCH_F4_QT, num_cus))
             launch_mfma_t<F4Path, 4, MQS_MATCH_F4_QT, MQS_MATCH_F4_NW>(q8, Nq, t8, Nt, qn, tn, idx, dist, part_d, part_i, num_cus, stream);
