@@ -28,8 +28,8 @@ if D in (128, 256, 512):
     idx8 = torch.empty_like(idx); dist8 = torch.empty_like(dist)
     for rnd in range(6):
         ms = timed(lambda: M.knn2_bits_dev(qp, tp, idx8, dist8, ws8))
-        out.setdefault("i8_ms", []).append(round(ms, 3))
-        out.setdefault("i8_Tops", []).append(round(2.0 * N * N * D / (ms * 1e-3) / 1e12, 1))
+        out.setdefault("bits_ms", []).append(round(ms, 3))
+        out.setdefault("bits_Tops", []).append(round(2.0 * N * N * D / (ms * 1e-3) / 1e12, 1))
     M.knn2_dev(q, t, idx, dist, ws)
-    out["i8_equals_f16"] = bool(torch.equal(idx, idx8) and torch.equal(dist, dist8))
+    out["bits_equals_f16"] = bool(torch.equal(idx, idx8) and torch.equal(dist, dist8))
 print(json.dumps(out))
