@@ -229,7 +229,7 @@ def test_reduced_system_solve_against_numpy(case, gpu):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", [(881, 101), (333, 65), (150, 17), (500, 7)])
+@pytest.mark.parametrize("case", [(881, 101), (333, 65), (150, 17), (500, 7), (107, 31), (219, 33), (214, 64), (186, 35)])
 def test_chunked_cholesky_equals_the_natural_order(case, gpu, monkeypatch):
     """The same banded system solved with the band cut into 1 (natural order), 2, 4, 8 and 16 chunks (MQS_SBA_PARTS): every
     cut reproduces numpy's solve, agrees with the natural order to rounding, and is bit-reproducible run to run (no atomics,

@@ -175,6 +175,33 @@ def test_plan_replay_solves_the_system(mqs, n, hb, parts):
         assert plan["parts"] <= parts
 
 
+def _edge_shapes():
+    rng = np.random.default_rng(2024)
+    shapes = [(32 * 20, 31, 0), (32 * 20, 32, 0), (32 * 20 + 1, 33, 0), (32 * 20 - 1, 1, 4), (32 * 41 + 31, 64, 0), (32 * 41 + 1, 65, 8),
+              (1116, 35, 0), (1116, 101, 0)]
+    for _ in range(10):
+        hb = int(rng.integers(1, 130))
+        w = (hb - 1) // 32 + 1
+        nblk = int(rng.integers(3 * w + 2, 60))
+        shapes.append((32 * nblk - int(rng.integers(0, 32)), hb, int(rng.choice([0, 0, 2, 4, 8, 16]))))
+    return shapes
+
+
+@pytest.mark.parametrize("n,hb,parts", _edge_shapes())
+def test_plan_replay_on_block_boundaries_and_random_shapes(mqs, n, hb, parts):
+    """Half bandwidths on and around multiples of the block size, sizes one off a multiple of 32, random shapes: whenever the
+    library decides to cut, the replayed plan solves the system; when it declines (0 ints), that is the natural order."""
+    lib = mqs._lib.lib()
+    plan = _plan(lib, n, hb, parts)
+    if plan is None:
+        return
+    S = _banded_spd(n, hb, seed=3 * n + hb)
+    b = np.random.default_rng(n).standard_normal(n)
+    x = _replay(S, b, plan)
+    ref = np.linalg.solve(S, b)
+    assert np.abs(x - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max())
+
+
 def test_auto_cut_of_the_kt2_shape(mqs):
     """881 poses, landmarks seen by 17 consecutive poses: 166 dependent block columns become 16 chunks of <= 7 + 4 separator
     levels of 4: 23 steps (and 8 chunks, 18 + 3 x 4, when asked for)."""
