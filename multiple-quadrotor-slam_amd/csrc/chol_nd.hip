@@ -56,11 +56,23 @@ struct LazyVec { int32_t x, start, count, pad; };
 // factor step: panel + eager trailing update of one block column per front, and the front's next diagonal block
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kThreads) void nd_step_kernel(double *__restrict__ A, int n, const StepDesc *__restrict__ descs,
-                                                           int *__restrict__ bad)
+                                                           int *__restrict__ bad, int nfronts, int max_tiles, int xcd_pin)
 {
-    const StepDesc &d = descs[blockIdx.y];
+    // front and tile of this workgroup.  Workgroups go to the eight XCDs round-robin by their linear id, and an XCD's L2 is its
+    // own: with the fronts a multiple of 8, all tiles of a front are given ids of ONE residue, so what a front's step wrote is
+    // read back by its next step from the same L2 (MQS_ND_XCD_PIN, A/B in DESIGN.md).
+    int f, t;
+    if (xcd_pin) {
+        const int L = blockIdx.x, xcd = L & 7, seq = L >> 3;
+        f = xcd + 8 * (seq / max_tiles);
+        t = seq % max_tiles;
+        if (f >= nfronts) return;
+    } else {
+        f = blockIdx.y;
+        t = blockIdx.x;
+    }
+    const StepDesc &d = descs[f];
     if (d.kblk < 0 || d.cnt == 0) return;
-    int t = blockIdx.x;
     if (t >= d.tiles) return;
     const bool do_update = d.eager > 0;
     const int ecols = do_update ? d.eager : 1;          // a column without own-front dependants still has its panel to write
@@ -672,6 +684,12 @@ std::mutex g_plan_mutex;
 // one plan per (device, stream, shape): a plan owns the scratch memory of its lazy sums, and solves on different streams may overlap
 std::map<std::tuple<int, void *, int, int, int>, Plan *> g_plans;
 
+bool xcd_pin_enabled()
+{
+    const char *e = getenv("MQS_ND_XCD_PIN");
+    return !(e && e[0] == '0');
+}
+
 int parts_from_env()
 {
     const char *e = getenv("MQS_SBA_PARTS");
@@ -719,8 +737,12 @@ int mqs_chol_nd_solve(double *S, double *x, int n, int hb, int *bad, hipStream_t
                                plan->d_scratch, bad);
         for (int t = 0; t < sp.nsteps; ++t)
             if (sp.max_tiles[t] > 0)
-                hipLaunchKernelGGL(nd_step_kernel, dim3(sp.max_tiles[t], sp.nfronts), dim3(kThreads), 0, stream, S, n,
-                                   plan->d_descs + sp.desc_off + (size_t)t * sp.nfronts, bad);
+            {
+                const bool pin = xcd_pin_enabled() && sp.nfronts % 8 == 0;
+                const dim3 grid = pin ? dim3((unsigned)(sp.max_tiles[t] * sp.nfronts)) : dim3(sp.max_tiles[t], sp.nfronts);
+                hipLaunchKernelGGL(nd_step_kernel, grid, dim3(kThreads), 0, stream, S, n,
+                                   plan->d_descs + sp.desc_off + (size_t)t * sp.nfronts, bad, sp.nfronts, sp.max_tiles[t], pin ? 1 : 0);
+            }
     }
     for (const StagePlan &sp : plan->stages) {
         if (sp.nvec > 0)
