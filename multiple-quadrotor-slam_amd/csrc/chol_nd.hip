@@ -738,8 +738,11 @@ int mqs_chol_nd_solve(double *S, double *x, int n, int hb, int *bad, hipStream_t
         for (int t = 0; t < sp.nsteps; ++t)
             if (sp.max_tiles[t] > 0)
             {
-                const bool pin = xcd_pin_enabled() && sp.nfronts % 8 == 0;
-                const dim3 grid = pin ? dim3((unsigned)(sp.max_tiles[t] * sp.nfronts)) : dim3(sp.max_tiles[t], sp.nfronts);
+                // fewer than 8 fronts: one XCD each (its 32 compute units take a level's ~60 tiles in two rounds, still inside
+                // the time of the tile that factors the next diagonal block)
+                const bool pin = xcd_pin_enabled() && (sp.nfronts % 8 == 0 || sp.nfronts < 8);
+                const int slots = sp.nfronts < 8 ? 8 : sp.nfronts;
+                const dim3 grid = pin ? dim3((unsigned)(sp.max_tiles[t] * slots)) : dim3(sp.max_tiles[t], sp.nfronts);
                 hipLaunchKernelGGL(nd_step_kernel, grid, dim3(kThreads), 0, stream, S, n,
                                    plan->d_descs + sp.desc_off + (size_t)t * sp.nfronts, bad, sp.nfronts, sp.max_tiles[t], pin ? 1 : 0);
             }
