@@ -26,6 +26,7 @@
 // +8 with priors); the kernel is bound by fp64 VALU issue, not by HBM.
 #include "mqs_common.h"
 #include "ba_math.h"
+#include "wave_reduce.h"
 #include <stdlib.h>
 
 namespace {
@@ -35,82 +36,10 @@ using namespace mqs::ba;
 constexpr int kBlock = 256;
 constexpr int kWaves = kBlock / 64;
 
-__device__ __forceinline__ void swap32(double &a, double &b)
-{
-    // v_permlane32_swap: a[lanes 32..63] <-> b[lanes 0..31]
-    unsigned alo = __double2loint(a), ahi = __double2hiint(a), blo = __double2loint(b), bhi = __double2hiint(b);
-    auto rlo = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
-    auto rhi = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
-    a = __hiloint2double(rhi[0], rlo[0]);
-    b = __hiloint2double(rhi[1], rlo[1]);
-}
-
-__device__ __forceinline__ void swap16(double &a, double &b)
-{
-    // v_permlane16_swap: odd 16-lane rows of a <-> even rows of b
-    unsigned alo = __double2loint(a), ahi = __double2hiint(a), blo = __double2loint(b), bhi = __double2hiint(b);
-    auto rlo = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
-    auto rhi = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
-    a = __hiloint2double(rhi[0], rlo[0]);
-    b = __hiloint2double(rhi[1], rlo[1]);
-}
-
-// Lane exchange v[lane ^ STRIDE] for STRIDE in {8, 4, 2, 1} with DPP moves (VALU latency; no LDS
-// crossbar round trip as with ds_bpermute, which sat on the reduction's critical path).
-template <int CTRL, int BANK_MASK>
-__device__ __forceinline__ unsigned dpp_mov(unsigned old, unsigned src)
-{
-    return (unsigned)__builtin_amdgcn_update_dpp((int)old, (int)src, CTRL, 0xf, BANK_MASK, false);
-}
-
-template <int STRIDE>
-__device__ __forceinline__ double xor_lane(double v)
-{
-    unsigned lo = __double2loint(v), hi = __double2hiint(v);
-    if (STRIDE == 8) {                       // row_ror:8 within each row of 16 lanes
-        lo = dpp_mov<0x128, 0xf>(lo, lo);
-        hi = dpp_mov<0x128, 0xf>(hi, hi);
-    } else if (STRIDE == 4) {                // banks {0,2} take lane+4 (row_shl:4), banks {1,3} lane-4 (row_shr:4)
-        const unsigned l0 = lo, h0 = hi;
-        lo = dpp_mov<0x104, 0x5>(l0, l0);
-        lo = dpp_mov<0x114, 0xa>(lo, l0);
-        hi = dpp_mov<0x104, 0x5>(h0, h0);
-        hi = dpp_mov<0x114, 0xa>(hi, h0);
-    } else if (STRIDE == 2) {                // quad_perm [2,3,0,1]
-        lo = dpp_mov<0x4e, 0xf>(lo, lo);
-        hi = dpp_mov<0x4e, 0xf>(hi, hi);
-    } else {                                 // quad_perm [1,0,3,2]
-        lo = dpp_mov<0xb1, 0xf>(lo, lo);
-        hi = dpp_mov<0xb1, 0xf>(hi, hi);
-    }
-    return __hiloint2double(hi, lo);
-}
-
-// Transposed wavefront reduction of 32 values per lane: on return lane l holds the sum over
-// all 64 lanes of v[l >> 1].  v is destroyed.
-__device__ __forceinline__ double wave_reduce32(double (&v)[32], int lane)
-{
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { swap32(v[i], v[i + 16]); v[i] += v[i + 16]; }   // lane bit 5 selects i (+16)
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { swap16(v[i], v[i + 8]); v[i] += v[i + 8]; }      // lane bit 4 selects i (+8)
-    const bool b3 = lane & 8, b2 = lane & 4, b1 = lane & 2;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const double send = b3 ? v[i] : v[i + 4], keep = b3 ? v[i + 4] : v[i];
-        v[i] = keep + xor_lane<8>(send);
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const double send = b2 ? v[i] : v[i + 2], keep = b2 ? v[i + 2] : v[i];
-        v[i] = keep + xor_lane<4>(send);
-    }
-    {
-        const double send = b1 ? v[0] : v[1], keep = b1 ? v[1] : v[0];
-        v[0] = keep + xor_lane<2>(send);
-    }
-    return v[0] + xor_lane<1>(v[0]);
-}
+using mqs::wave::swap32;
+using mqs::wave::swap16;
+using mqs::wave::xor_lane;
+using mqs::wave::wave_reduce32;
 
 // Per-wave emitter: a 32-entry register window; every completed window is reduced over the wave
 // and added to this lane's running total, kept in LDS (one double per window per thread) so that

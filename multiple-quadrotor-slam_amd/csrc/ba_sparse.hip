@@ -22,6 +22,7 @@
 #include <mutex>
 #include "ba_math.h"
 #include "chol_block.h"
+#include "wave_reduce.h"
 
 namespace {
 
@@ -253,8 +254,15 @@ __global__ __launch_bounds__(kBlock) void sparse_pair_groups_kernel(const double
             }
         }
     }
+    // 36 sums over the wavefront: the first 32 by the transposed reduction of the dense lineariser (wave_reduce.h: 32 exchange-
+    // and-add steps, lane l ends with the total of entry l >> 1), the last four by butterflies -- 36 butterflies were 216
+    // exchange steps, more vector instructions than the pairs' arithmetic of a typical group (about 140 pairs)
+    double first32[32];
 #pragma unroll
-    for (int e = 0; e < 36; ++e) acc[e] = wave_sum(acc[e]);
+    for (int e = 0; e < 32; ++e) first32[e] = acc[e];
+    const double t32 = mqs::wave::wave_reduce32(first32, lane);
+#pragma unroll
+    for (int e = 32; e < 36; ++e) acc[e] = wave_sum(acc[e]);
     double *Sd = S + (int64_t)(6 * ja) * n6 + 6 * jb;
     if (ja == jb) {
 #pragma unroll
@@ -266,11 +274,16 @@ __global__ __launch_bounds__(kBlock) void sparse_pair_groups_kernel(const double
             g[6 * ja + lane] = gv;
         }
     }
-    if (lane < 36) {
-        double v = acc[0];
+    // entry e < 32 is on lane 2 e; entries 32..35 (every lane has them) are written by the odd lanes 1, 3, 5, 7
+    const int e_out = (lane & 1) ? 32 + (lane >> 1) : (lane >> 1);
+    if (!(lane & 1) || lane < 8) {
+        double v = t32;
+        if (lane & 1) {
+            v = acc[32];
 #pragma unroll
-        for (int e = 1; e < 36; ++e) v = (lane == e) ? acc[e] : v;
-        const int i = lane / 6, j = lane % 6;
+            for (int e = 33; e < 36; ++e) v = (e_out == e) ? acc[e] : v;
+        }
+        const int i = e_out / 6, j = e_out % 6;
         // the block and its mirror image: pairs are ordered (ja <= jb: observations sorted by pose inside a landmark), so the
         // transposed block is nobody else's -- a full-matrix mirror pass afterwards (n^2 reads and writes: 137 us of the
         // 340 us linearisation at n = 5286) is not needed on this path
