@@ -63,29 +63,39 @@ __device__ __forceinline__ float float_from_order_key(unsigned int k)
     return __uint_as_float((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k);
 }
 
-// eig = the smaller eigenvalue of the 3 x 3 box sum of the gradient products; maxkey[0] (zeroed by the caller) ends as the
-// order key of the frame's largest response: one atomic per workgroup.
+// eig = the smaller eigenvalue of the 3 x 3 box sum of the gradient products; maxkey[0 .. kMaxSlots) (zeroed by the caller) end
+// as order keys whose maximum is the frame's largest response: one atomic per workgroup, spread over kMaxSlots words -- 1 200
+// atomics on ONE word took 11 of this kernel's 17 us (same-address atomics retire one every ~10 ns).
+constexpr int kMaxSlots = 256;
 __global__ __launch_bounds__(kBlock) void min_eig_kernel(const uint8_t *__restrict__ img, int W, int H, float *__restrict__ eig,
                                                         unsigned int *__restrict__ maxkey)
 {
+    // A 32 x 8 pixel tile per workgroup.  The gradient products of the tile and its one-pixel halo (34 x 10) are formed once,
+    // in LDS: one Sobel evaluation per halo pixel (1.33 per thread) instead of nine per pixel (72 image loads per thread,
+    // 17.5 us per VGA frame).  Same float32 expressions in the same order.
+    __shared__ float sXX[10][34], sXY[10][34], sYY[10][34];
     __shared__ unsigned int sMax[kBlock / 64];
-    const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int x0 = blockIdx.x * 32, y0 = blockIdx.y * 8;
+    // gradient products at halo position (hy, hx) <-> image pixel (reflect(y0 - 1 + hy), reflect(x0 - 1 + hx))
+    for (int e = threadIdx.x; e < 10 * 34; e += kBlock) {
+        const int hy = e / 34, hx = e % 34;
+        const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+        float dx = 0.0f, dy = 0.0f;
+        if (gy >= -1 && gy <= H && gx >= -1 && gx <= W)           // what some pixel of the image needs (a tile may overhang it)
+            sobel_scaled(img, W, H, reflect101(gy, H), reflect101(gx, W), dx, dy);
+        sXX[hy][hx] = dx * dx; sXY[hy][hx] = dx * dy; sYY[hy][hx] = dy * dy;
+    }
+    __syncthreads();
+    const int x = x0 + tx, y = y0 + ty;
     unsigned int key = 0u;
     if (x < W && y < H) {
         float rxx[3], rxy[3], ryy[3];
 #pragma unroll
-        for (int oy = -1; oy <= 1; ++oy) {
-            const int yy = reflect101(y + oy, H);
-            float pxx[3], pxy[3], pyy[3];
-#pragma unroll
-            for (int ox = -1; ox <= 1; ++ox) {
-                float dx, dy;
-                sobel_scaled(img, W, H, yy, reflect101(x + ox, W), dx, dy);
-                pxx[ox + 1] = dx * dx; pxy[ox + 1] = dx * dy; pyy[ox + 1] = dy * dy;
-            }
-            rxx[oy + 1] = (pxx[0] + pxx[1]) + pxx[2];
-            rxy[oy + 1] = (pxy[0] + pxy[1]) + pxy[2];
-            ryy[oy + 1] = (pyy[0] + pyy[1]) + pyy[2];
+        for (int oy = 0; oy < 3; ++oy) {
+            rxx[oy] = (sXX[ty + oy][tx] + sXX[ty + oy][tx + 1]) + sXX[ty + oy][tx + 2];
+            rxy[oy] = (sXY[ty + oy][tx] + sXY[ty + oy][tx + 1]) + sXY[ty + oy][tx + 2];
+            ryy[oy] = (sYY[ty + oy][tx] + sYY[ty + oy][tx + 1]) + sYY[ty + oy][tx + 2];
         }
         const float a = ((rxx[0] + rxx[1]) + rxx[2]) * 0.5f;
         const float b = (rxy[0] + rxy[1]) + rxy[2];
@@ -106,41 +116,70 @@ __global__ __launch_bounds__(kBlock) void min_eig_kernel(const uint8_t *__restri
         unsigned int m = sMax[0];
 #pragma unroll
         for (int w = 1; w < kBlock / 64; ++w) m = m > sMax[w] ? m : sMax[w];
-        atomicMax(maxkey, m);
+        atomicMax(maxkey + ((blockIdx.y * gridDim.x + blockIdx.x) & (kMaxSlots - 1)), m);
     }
 }
 
-// counter[0] = number of candidates appended (may exceed the capacity: the excess is dropped and reported)
+// Candidates (thresholded 3 x 3 maxima under the mask) of a 32 x 8 tile go to the tile's OWN segment of 256 key slots, in
+// thread order, and the tile's count to wg_count[tile]: no global counter (3 000 atomics on one word were 13 of this kernel's
+// 16 us).  The selection kernel gathers the segments.
 __global__ __launch_bounds__(kBlock) void candidates_kernel(const float *__restrict__ eig, int W, int H,
                                                            const unsigned int *__restrict__ maxkey, float quality,
                                                            const uint8_t *__restrict__ mask, unsigned long long *__restrict__ keys,
-                                                           unsigned int capacity, unsigned int *__restrict__ counter)
+                                                           unsigned int *__restrict__ wg_count)
 {
+    __shared__ unsigned int sRed[kBlock / 64];
+    __shared__ int sCnt[kBlock / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // the frame's largest response: maximum over the slots
+    unsigned int mk = maxkey[threadIdx.x & (kMaxSlots - 1)];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const unsigned int o = (unsigned int)__shfl_xor((int)mk, off, 64);
+        mk = mk > o ? mk : o;
+    }
+    if (lane == 0) sRed[wave] = mk;
+    __syncthreads();
+#pragma unroll
+    for (int w2 = 0; w2 < kBlock / 64; ++w2) mk = mk > sRed[w2] ? mk : sRed[w2];
+    const float thr = float_from_order_key(mk) * quality;
     const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
-    if (x <= 0 || y <= 0 || x >= W - 1 || y >= H - 1) return;
-    const float thr = float_from_order_key(maxkey[0]) * quality;
-    const float e = eig[y * W + x];
-    if (!(e > thr) || e == 0.0f) return;
-    if (mask && mask[y * W + x] == 0) return;
-    bool is_max = true;
+    bool cand = false;
+    float e = 0.0f;
+    if (!(x <= 0 || y <= 0 || x >= W - 1 || y >= H - 1)) {
+        e = eig[y * W + x];
+        cand = (e > thr) && e != 0.0f && !(mask && mask[y * W + x] == 0);
+        if (cand) {
 #pragma unroll
-    for (int oy = -1; oy <= 1; ++oy)
+            for (int oy = -1; oy <= 1; ++oy)
 #pragma unroll
-        for (int ox = -1; ox <= 1; ++ox) {
-            const float v = eig[(y + oy) * W + x + ox];          // in range: (x, y) is not on the border
-            if ((v > thr ? v : 0.0f) > e) is_max = false;
+                for (int ox = -1; ox <= 1; ++ox) {
+                    const float v = eig[(y + oy) * W + x + ox];          // in range: (x, y) is not on the border
+                    if ((v > thr ? v : 0.0f) > e) cand = false;
+                }
         }
-    if (!is_max) return;
-    const unsigned int slot = atomicAdd(counter, 1u);
-    if (slot < capacity)
+    }
+    const unsigned long long m = __ballot(cand);
+    if (lane == 0) sCnt[wave] = __popcll(m);
+    __syncthreads();
+    int off = 0, total = 0;
+#pragma unroll
+    for (int w2 = 0; w2 < kBlock / 64; ++w2) {
+        off += w2 < wave ? sCnt[w2] : 0;
+        total += sCnt[w2];
+    }
+    const unsigned int tile = blockIdx.y * gridDim.x + blockIdx.x;
+    if (cand)
         // low word: ~(y << 16 | x) -- the same order as the row-major position, and no division to take apart
-        keys[slot] = ((unsigned long long)__float_as_uint(e) << 32) | (unsigned long long)(0xFFFFFFFFu - (((unsigned)y << 16) | (unsigned)x));
+        keys[(size_t)tile * kBlock + off + __popcll(m & ((1ull << lane) - 1ull))] =
+            ((unsigned long long)__float_as_uint(e) << 32) | (unsigned long long)(0xFFFFFFFFu - (((unsigned)y << 16) | (unsigned)x));
+    if (threadIdx.x == 0) wg_count[tile] = (unsigned int)total;
 }
 
 // Minimum-distance selection over the sorted candidates (one workgroup).  grid: cells x 4 slots (x | y << 16, 0xFFFFFFFF =
 // empty) holding the accepted corners, in dynamic LDS (IN_LDS) or in the workspace.  The greedy rule is evaluated as a
 // parallel fixed point, 1024 candidates per round -- see the comment inside the kernel.
-// The sort comes first, by the same (single) workgroup: the candidates arrive in the order their atomics happened.  Up to
+// First the gather of the tiles' candidate segments (prefix sum of their counts) and the sort, by the same (single) workgroup.  Up to
 // kSortChunk keys are sorted in LDS by a bitonic network (descending; the keys are distinct); more than that -- a frame of
 // noise -- chunk by chunk into `keys` itself, then merged pairwise between `keys` and `tmp` (merge path: every thread finds
 // its share of the output by bisection).  The LDS the network used is then the selection grid.
@@ -185,19 +224,48 @@ __device__ __forceinline__ void merge_runs_desc(const unsigned long long *__rest
 }
 
 template <bool IN_LDS>
-__global__ __launch_bounds__(kSelThreads) void sort_select_kernel(unsigned long long *__restrict__ keys_io,
-                                                                  unsigned long long *__restrict__ tmp,
-                                                                  const unsigned int *__restrict__ counter, unsigned int capacity, int W,
+__global__ __launch_bounds__(kSelThreads) void sort_select_kernel(unsigned long long *__restrict__ keys_seg,
+                                                                  unsigned long long *__restrict__ keys_io,
+                                                                  const unsigned int *__restrict__ wg_count, unsigned int ntiles, int W,
                                                                   int H, float min_distance, int max_corners, int out_capacity,
                                                                   unsigned int *__restrict__ grid_global, float *__restrict__ out_xy,
                                                                   int *__restrict__ out_n)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned int sGrid[];
     const unsigned long long *keys = keys_io;
+    __shared__ unsigned int sScan[kSelThreads / 64];
+    __shared__ unsigned int sTotal;
+    unsigned long long *tmp = keys_seg;                    // the segments are free once gathered: merge buffer
+    {
+        // gather the tiles' segments into keys_io, tile after tile: thread t owns a contiguous range of tiles
+        const int tid = threadIdx.x;
+        const unsigned int per = (ntiles + kSelThreads - 1) / kSelThreads;
+        const unsigned int t0 = tid * per, t1 = t0 + per < ntiles ? t0 + per : ntiles;
+        unsigned int mine = 0;
+        for (unsigned int t = t0; t < t1; ++t) mine += wg_count[t];
+        unsigned int incl = mine;                          // inclusive scan over the workgroup
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned int o = (unsigned int)__shfl_up((int)incl, off, 64);
+            if ((tid & 63) >= off) incl += o;
+        }
+        if ((tid & 63) == 63) sScan[tid >> 6] = incl;
+        __syncthreads();
+        unsigned int base = 0;
+#pragma unroll
+        for (int w2 = 0; w2 < kSelThreads / 64; ++w2) base += w2 < (tid >> 6) ? sScan[w2] : 0u;
+        if (tid == kSelThreads - 1) sTotal = base + incl;
+        unsigned int pos = base + incl - mine;
+        for (unsigned int t = t0; t < t1; ++t) {
+            const unsigned int c = wg_count[t];
+            for (unsigned int k = 0; k < c; ++k) keys_io[pos + k] = keys_seg[(size_t)t * kBlock + k];
+            pos += c;
+        }
+        __syncthreads();
+    }
     {
         unsigned long long *sK = reinterpret_cast<unsigned long long *>(sGrid);
-        unsigned int cnt = counter[0];
-        if (cnt > capacity) cnt = capacity;
+        const unsigned int cnt = sTotal;
         const int tid = threadIdx.x;
         for (unsigned int c0 = 0; c0 < cnt; c0 += kSortChunk) {
             const unsigned int len = cnt - c0 < (unsigned)kSortChunk ? cnt - c0 : (unsigned)kSortChunk;
@@ -234,8 +302,7 @@ __global__ __launch_bounds__(kSelThreads) void sort_select_kernel(unsigned long 
     __shared__ short sNbr[kSelThreads * kNbr];
     __shared__ int sWaveCount[kSelThreads / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    unsigned int n = counter[0];
-    if (n > capacity) n = capacity;
+    const unsigned int n = sTotal;
     int accepted = 0;                                      // the same value in every thread
     const int limit = (max_corners > 0 && max_corners < out_capacity) ? max_corners : out_capacity;
     if (min_distance < 1.0f) {
@@ -737,8 +804,11 @@ int64_t mqs_gftt_workspace_bytes(int W, int H)
 {
     if (W < 1 || H < 1) return 0;
     const size_t npx = (size_t)W * H;
-    // response, 2 key arrays (candidates / merge buffer), maximum + counter, selection grid (worst case: cell = 1)
-    return (int64_t)(align_up(npx * 4) + 2 * align_up(npx * 8) + 256 + align_up(npx * 16));
+    const size_t ntiles = (size_t)((W + 31) / 32) * ((H + 7) / 8);
+    // response, the tiles' candidate segments (256 slots each), the gathered keys, slots of the maximum + tile counts,
+    // selection grid (worst case: cell = 1)
+    return (int64_t)(align_up(npx * 4) + align_up(ntiles * kBlock * 8) + align_up(npx * 8) + align_up((kMaxSlots + ntiles) * 4) +
+                     align_up(npx * 16));
 }
 
 int mqs_good_features_to_track_dev(const uint8_t *img, int W, int H, int max_corners, double quality_level,
@@ -751,19 +821,20 @@ int mqs_good_features_to_track_dev(const uint8_t *img, int W, int H, int max_cor
     MQS_ARG_CHECK(workspace_bytes >= mqs_gftt_workspace_bytes(W, H), "workspace too small (mqs_gftt_workspace_bytes)");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const size_t npx = (size_t)W * H;
+    const size_t ntiles = (size_t)((W + 31) / 32) * ((H + 7) / 8);
     char *w = static_cast<char *>(workspace);
     float *eig = reinterpret_cast<float *>(w); w += align_up(npx * 4);
+    unsigned long long *keys_seg = reinterpret_cast<unsigned long long *>(w); w += align_up(ntiles * kBlock * 8);
     unsigned long long *keys = reinterpret_cast<unsigned long long *>(w); w += align_up(npx * 8);
-    unsigned long long *tmp = reinterpret_cast<unsigned long long *>(w); w += align_up(npx * 8);
-    unsigned int *maxkey = reinterpret_cast<unsigned int *>(w);          // [0] order key of the largest response, [1] candidate count
-    unsigned int *counter = maxkey + 1; w += 256;
+    unsigned int *maxkey = reinterpret_cast<unsigned int *>(w);          // [kMaxSlots] order keys of the largest response
+    unsigned int *wg_count = maxkey + kMaxSlots; w += align_up((kMaxSlots + ntiles) * 4);
     unsigned int *grid = reinterpret_cast<unsigned int *>(w);
 
-    // four launches: clear, response (+ maximum), candidates, sort + selection
-    MQS_HIP_CHECK(hipMemsetAsync(maxkey, 0, 8, stream));
+    // four launches: clear, response (+ maximum), candidates, gather + sort + selection
+    MQS_HIP_CHECK(hipMemsetAsync(maxkey, 0, kMaxSlots * 4, stream));
     hipLaunchKernelGGL(min_eig_kernel, grid2d(W, H), dim3(kBlock), 0, stream, img, W, H, eig, maxkey);
     hipLaunchKernelGGL(candidates_kernel, grid2d(W, H), dim3(kBlock), 0, stream, eig, W, H, maxkey, (float)quality_level, mask,
-                       keys, (unsigned int)npx, counter);
+                       keys_seg, wg_count);
     const int cell = min_distance >= 1.0 ? (int)rint(min_distance) : 1;
     const size_t cells = (size_t)((W + cell - 1) / cell) * ((H + cell - 1) / cell);
     const size_t sort_lds = (size_t)kSortChunk * sizeof(unsigned long long);
@@ -773,13 +844,13 @@ int mqs_good_features_to_track_dev(const uint8_t *img, int W, int H, int max_cor
     if (in_lds) {
         static mqs_lds_opt_in opt;                           // per device
         MQS_HIP_CHECK(mqs_lds_opt_in_once(opt, reinterpret_cast<const void *>(sort_select_kernel<true>), (int)sort_lds));
-        hipLaunchKernelGGL(sort_select_kernel<true>, dim3(1), dim3(kSelThreads), lds, stream, keys, tmp, counter, (unsigned int)npx, W,
+        hipLaunchKernelGGL(sort_select_kernel<true>, dim3(1), dim3(kSelThreads), lds, stream, keys_seg, keys, wg_count, (unsigned int)ntiles, W,
                            H, (float)min_distance, max_corners, out_capacity, grid, out_xy, out_n);
     } else {
         static mqs_lds_opt_in opt;                           // per device
         MQS_HIP_CHECK(mqs_lds_opt_in_once(opt, reinterpret_cast<const void *>(sort_select_kernel<false>), (int)sort_lds));
-        hipLaunchKernelGGL(sort_select_kernel<false>, dim3(1), dim3(kSelThreads), sort_lds, stream, keys, tmp, counter,
-                           (unsigned int)npx, W, H, (float)min_distance, max_corners, out_capacity, grid, out_xy, out_n);
+        hipLaunchKernelGGL(sort_select_kernel<false>, dim3(1), dim3(kSelThreads), sort_lds, stream, keys_seg, keys, wg_count,
+                           (unsigned int)ntiles, W, H, (float)min_distance, max_corners, out_capacity, grid, out_xy, out_n);
     }
     MQS_HIP_CHECK(hipGetLastError());
     return MQS_OK;
