@@ -14,6 +14,7 @@
 // Every sum has a fixed order: results are bitwise reproducible.
 #include "mqs_common.h"
 #include "pnp_math.h"
+#include "wave_reduce.h"
 #include "cam_math.h"
 
 namespace {
@@ -51,8 +52,16 @@ struct WaveEval {
             accumulate_point(P, intr, pr.objp[3 * i], pr.objp[3 * i + 1], pr.objp[3 * i + 2], pr.imgp[2 * i],
                              pr.imgp[2 * i + 1], acc);
         }
+        // transposed reduction (lane 2 e ends with entry e), then every entry to every lane by v_readlane: 32 exchange steps
+        // and 56 scalar reads instead of 28 butterflies of six steps -- on a six-point RANSAC hypothesis the butterflies were
+        // most of an evaluation
+        double v[32];
 #pragma unroll
-        for (int k = 0; k < kAcc; ++k) acc[k] = wave_sum(acc[k]);
+        for (int k = 0; k < 32; ++k) v[k] = k < kAcc ? acc[k] : 0.0;
+        const double tot = mqs::wave::wave_reduce32(v, lane);
+#pragma unroll
+        for (int k = 0; k < kAcc; ++k)
+            acc[k] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(tot), 2 * k), __builtin_amdgcn_readlane(__double2loint(tot), 2 * k));
     }
 };
 
@@ -321,13 +330,15 @@ struct KfEval {
             const double *U = old ? imgp + 2 * k : cuv + 2 * (k - n_old);
             accumulate_point(P, intr, X[0], X[1], X[2], U[0], U[1], acc);
         }
+        // the wave's 28 sums by the transposed reduction (wave_reduce.h: 32 exchange-and-add steps, lane 2 e ends with entry e)
+        // instead of 28 butterflies of six steps each: with one or two points per thread the butterflies were three quarters of
+        // an evaluation's instructions
+        double v[32];
 #pragma unroll
-        for (int k = 0; k < kAcc; ++k) acc[k] = wave_sum(acc[k]);
+        for (int k = 0; k < 32; ++k) v[k] = k < kAcc ? acc[k] : 0.0;
+        const double tot = mqs::wave::wave_reduce32(v, tid & 63);
         __syncthreads();                          // the previous call's sums have been read by everyone
-        if ((tid & 63) == 0) {
-#pragma unroll
-            for (int k = 0; k < kAcc; ++k) red[(tid >> 6) * kAcc + k] = acc[k];
-        }
+        if (!(tid & 1) && ((tid & 63) >> 1) < kAcc) red[(tid >> 6) * kAcc + ((tid & 63) >> 1)] = tot;
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < kAcc; ++k) {
