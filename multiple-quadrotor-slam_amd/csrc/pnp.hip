@@ -30,6 +30,26 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
+// K sums over the wavefront, every lane ending with all of them: chunks of 32 through the transposed reduction of
+// wave_reduce.h (32 exchange-and-add steps per chunk; lane 2 e ends with entry e), then each total to every lane by a
+// v_readlane pair -- against K butterflies of six exchange steps each.
+template <int K>
+__device__ __forceinline__ void wave_sum_all(double (&acc)[K], int lane)
+{
+#pragma unroll
+    for (int c0 = 0; c0 < K; c0 += 32) {
+        double v[32];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) v[k] = (c0 + k < K) ? acc[c0 + k] : 0.0;
+        const double tot = mqs::wave::wave_reduce32(v, lane);
+#pragma unroll
+        for (int k = 0; k < 32; ++k)
+            if (c0 + k < K)
+                acc[c0 + k] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(tot), 2 * k),
+                                               __builtin_amdgcn_readlane(__double2loint(tot), 2 * k));
+    }
+}
+
 // One problem's correspondences: points idx[begin..end) of (objp, imgp), or begin..end directly.
 struct Problem {
     const double *objp, *imgp;
@@ -52,16 +72,8 @@ struct WaveEval {
             accumulate_point(P, intr, pr.objp[3 * i], pr.objp[3 * i + 1], pr.objp[3 * i + 2], pr.imgp[2 * i],
                              pr.imgp[2 * i + 1], acc);
         }
-        // transposed reduction (lane 2 e ends with entry e), then every entry to every lane by v_readlane: 32 exchange steps
-        // and 56 scalar reads instead of 28 butterflies of six steps -- on a six-point RANSAC hypothesis the butterflies were
-        // most of an evaluation
-        double v[32];
-#pragma unroll
-        for (int k = 0; k < 32; ++k) v[k] = k < kAcc ? acc[k] : 0.0;
-        const double tot = mqs::wave::wave_reduce32(v, lane);
-#pragma unroll
-        for (int k = 0; k < kAcc; ++k)
-            acc[k] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(tot), 2 * k), __builtin_amdgcn_readlane(__double2loint(tot), 2 * k));
+        // (on a six-point RANSAC hypothesis 28 butterflies were most of an evaluation)
+        wave_sum_all(*reinterpret_cast<double (*)[kAcc]>(acc), lane);
     }
 };
 
@@ -108,8 +120,7 @@ __device__ bool wave_dlt(const Problem &pr, const double *intr, int lane, double
             mqs::cam::undistort_pixel(intr, pr.imgp[2 * i], pr.imgp[2 * i + 1], x, y);
             hom_accumulate((E[0] * dx + E[1] * dy + E[2] * dz) * is, (E[3] * dx + E[4] * dy + E[5] * dz) * is, x, y, hacc);
         }
-#pragma unroll
-        for (int k = 0; k < kHomAcc; ++k) hacc[k] = wave_sum(hacc[k]);
+        wave_sum_all(hacc, lane);
         double *sb = sA + 64;
         if (lane == 0) {
             hom_assemble(hacc, sA, sb);
@@ -134,8 +145,7 @@ __device__ bool wave_dlt(const Problem &pr, const double *intr, int lane, double
         mqs::cam::undistort_pixel(intr, pr.imgp[2 * i], pr.imgp[2 * i + 1], x, y);
         dlt_accumulate((pr.objp[3 * i] - c[0]) * is, (pr.objp[3 * i + 1] - c[1]) * is, (pr.objp[3 * i + 2] - c[2]) * is, x, y, acc);
     }
-#pragma unroll
-    for (int k = 0; k < kDltAcc; ++k) acc[k] = wave_sum(acc[k]);
+    wave_sum_all(acc, lane);
     // 11 x 11 solve: serial, one lane, matrix in LDS (dynamic indexing), result broadcast through LDS
     double *sb = sA + 121;
     if (lane == 0) {
