@@ -31,10 +31,11 @@ __device__ __forceinline__ double wave_sum(double v)
 }
 
 // K sums over the wavefront, every lane ending with all of them: chunks of 32 through the transposed reduction of
-// wave_reduce.h (32 exchange-and-add steps per chunk; lane 2 e ends with entry e), then each total to every lane by a
-// v_readlane pair -- against K butterflies of six exchange steps each.
+// wave_reduce.h (32 exchange-and-add steps per chunk; lane 2 e ends with entry e), then through 32 doubles of LDS (`scr`, the
+// wave's own) back to every lane as broadcast reads -- against K butterflies of six exchange steps each.  (Broadcasting with
+// v_readlane pairs instead kept up to 102 scalar registers alive: 177 spilled SGPRs in the refinement kernel.)
 template <int K>
-__device__ __forceinline__ void wave_sum_all(double (&acc)[K], int lane)
+__device__ __forceinline__ void wave_sum_all(double (&acc)[K], int lane, double *scr)
 {
 #pragma unroll
     for (int c0 = 0; c0 < K; c0 += 32) {
@@ -42,11 +43,12 @@ __device__ __forceinline__ void wave_sum_all(double (&acc)[K], int lane)
 #pragma unroll
         for (int k = 0; k < 32; ++k) v[k] = (c0 + k < K) ? acc[c0 + k] : 0.0;
         const double tot = mqs::wave::wave_reduce32(v, lane);
+        mqs_wave_lds_sync();                              // earlier readers of scr are done
+        if (!(lane & 1)) scr[lane >> 1] = tot;
+        mqs_wave_lds_sync();
 #pragma unroll
         for (int k = 0; k < 32; ++k)
-            if (c0 + k < K)
-                acc[c0 + k] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(tot), 2 * k),
-                                               __builtin_amdgcn_readlane(__double2loint(tot), 2 * k));
+            if (c0 + k < K) acc[c0 + k] = scr[k];
     }
 }
 
@@ -63,6 +65,7 @@ struct WaveEval {
     Problem pr;
     const double *intr;     // LDS
     int lane;
+    double *scr;            // LDS, 32 doubles of the wave's own (wave_sum_all)
     __device__ __forceinline__ void operator()(const double *P, double *acc) const
     {
 #pragma unroll
@@ -73,7 +76,7 @@ struct WaveEval {
                              pr.imgp[2 * i + 1], acc);
         }
         // (on a six-point RANSAC hypothesis 28 butterflies were most of an evaluation)
-        wave_sum_all(*reinterpret_cast<double (*)[kAcc]>(acc), lane);
+        wave_sum_all(*reinterpret_cast<double (*)[kAcc]>(acc), lane, scr);
     }
 };
 
@@ -120,7 +123,7 @@ __device__ bool wave_dlt(const Problem &pr, const double *intr, int lane, double
             mqs::cam::undistort_pixel(intr, pr.imgp[2 * i], pr.imgp[2 * i + 1], x, y);
             hom_accumulate((E[0] * dx + E[1] * dy + E[2] * dz) * is, (E[3] * dx + E[4] * dy + E[5] * dz) * is, x, y, hacc);
         }
-        wave_sum_all(hacc, lane);
+        wave_sum_all(hacc, lane, sA);                      // sA is free until hom_assemble fills it
         double *sb = sA + 64;
         if (lane == 0) {
             hom_assemble(hacc, sA, sb);
@@ -145,7 +148,7 @@ __device__ bool wave_dlt(const Problem &pr, const double *intr, int lane, double
         mqs::cam::undistort_pixel(intr, pr.imgp[2 * i], pr.imgp[2 * i + 1], x, y);
         dlt_accumulate((pr.objp[3 * i] - c[0]) * is, (pr.objp[3 * i + 1] - c[1]) * is, (pr.objp[3 * i + 2] - c[2]) * is, x, y, acc);
     }
-    wave_sum_all(acc, lane);
+    wave_sum_all(acc, lane, sA);                           // sA is free until dlt_assemble fills it
     // 11 x 11 solve: serial, one lane, matrix in LDS (dynamic indexing), result broadcast through LDS
     double *sb = sA + 121;
     if (lane == 0) {
@@ -190,7 +193,7 @@ __global__ __launch_bounds__(kWave) void pnp_refine_kernel(const double *__restr
             flags |= 2;
         }
     }
-    WaveEval ev = {pr, sI, lane};
+    WaveEval ev = {pr, sI, lane, sA};
     const LmResult r = lm_refine(ev, P, max_iter, eps);
     if (r.converged) flags |= 1;
     if (lane < 12) poses_out[12 * b + lane] = P[lane];
@@ -218,7 +221,7 @@ __global__ __launch_bounds__(kWave) void pnp_hypothesis_kernel(const double *__r
     double P[12];
     int count = -1;
     if (wave_dlt(pr, sI, lane, sA, P)) {
-        WaveEval ev = {pr, sI, lane};
+        WaveEval ev = {pr, sI, lane, sA};
         lm_refine(ev, P, sample_iters, 1e-10);
         int c = 0;
         for (int i = lane; i < N; i += kWave) {
