@@ -431,7 +431,7 @@ def main():
         hbm["frac"] = round(hbm["achieved"] / HBM_PEAK_GBPS, 4)
         if flop:
             tf = flop * N / (ms_lin * 1e-3) / 1e12
-            roofline = {"bound": "fp64_valu", "kernel": "ba_linearize_kernel<%d>" % C, "achieved": round(tf, 2),
+            roofline = {"bound": "fp64_valu", "kernel": "ba_linearize_wave_kernel<%d>" % C, "achieved": round(tf, 2),
                         "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / FP64_VALU_PEAK_TFLOPS, 4),
                         "traffic": hbm["traffic"], "avg_launch_ms": round(ms_lin, 5), "fp64_flop_per_landmark": flop,
                         "valu_instructions_per_landmark": kf.get("valu_instructions_per_landmark"),
