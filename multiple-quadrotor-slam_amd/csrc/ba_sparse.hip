@@ -602,6 +602,7 @@ __global__ __launch_bounds__(kBlock) void chol_step_kernel(double *__restrict__ 
     const int i0 = t0 + bi * NB, j0 = t0 + bj * NB;             // first rows of the two panel blocks / the tile's origin
     const int lim = t0 + rem;                                    // rows [t0, lim) take part
     __shared__ double sLi[NB][NB + 1], sAi[NB][NB + 1], sAj[NB][NB + 1], sXi[NB][NB + 1], sXj[NB][NB + 1];
+    __shared__ double sM[128];
     const int tid = threadIdx.x;
     for (int e = tid; e < NB * NB; e += kBlock) {
         const int a = e / NB, b = e % NB;
@@ -652,8 +653,7 @@ __global__ __launch_bounds__(kBlock) void chol_step_kernel(double *__restrict__ 
     }
     if (!next_diag) return;
     __syncthreads();
-    if (tid >= 64) return;
-    mqs::chol::factor_diag_block_from_lds(sT, A, n, t0, bad, tid);      // the next diagonal block (origin t0)
+    mqs::chol::factor_diag_block_from_lds_4w(sT, A, n, t0, bad, tid, sM);      // the next diagonal block (origin t0), four waves
 }
 
 // L y = b then L^T x = y; one workgroup, blocked by 256 rows with a block-level dot product per row

@@ -87,6 +87,7 @@ __global__ __launch_bounds__(kThreads) void nd_step_kernel(double *__restrict__ 
     const int nb = (n - k0) < NB ? (n - k0) : NB;
     const int i0 = d.blk[bi] * NB, j0 = d.blk[bj] * NB;
     __shared__ double sLi[NB][kLd], sAi[NB][kLd], sAj[NB][kLd], sXi[NB][kLd], sXj[NB][kLd];
+    __shared__ double sM[128];                              // pivot columns of the four-wave diagonal factorisation
     const int tid = threadIdx.x;
     for (int e = tid; e < NB * NB; e += kThreads) {
         const int a = e / NB, b = e % NB;
@@ -134,8 +135,7 @@ __global__ __launch_bounds__(kThreads) void nd_step_kernel(double *__restrict__ 
     }
     if (!next_diag) return;
     __syncthreads();
-    if (tid >= 64) return;
-    factor_diag_block_from_lds(sT, A, n, i0, bad, tid);
+    factor_diag_block_from_lds_4w(sT, A, n, i0, bad, tid, sM);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -205,6 +205,7 @@ __global__ __launch_bounds__(kThreads) void nd_lazy_apply_kernel(double *__restr
     const int i0 = T.x1 * NB, j0 = T.x2 * NB;
     const bool diag = T.x1 == T.x2;
     __shared__ double sT[NB * kLd];
+    __shared__ double sM[128];
     const int tid = threadIdx.x;
     const int tr = (tid / 16) * 2, tc = (tid % 16) * 2;
     double cur[2][2];
@@ -250,8 +251,7 @@ __global__ __launch_bounds__(kThreads) void nd_lazy_apply_kernel(double *__restr
         }
     if (!T.factor) return;
     __syncthreads();
-    if (tid >= 64) return;
-    factor_diag_block_from_lds(sT, A, n, i0, bad, tid);
+    factor_diag_block_from_lds_4w(sT, A, n, i0, bad, tid, sM);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
