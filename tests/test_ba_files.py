@@ -287,6 +287,50 @@ def test_chunked_cholesky_equals_the_natural_order(case, gpu, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_chunked_cholesky_on_two_streams_at_once(gpu):
+    """Two banded systems of the same shape solved concurrently on two HIP streams, five times over: the plans (and the scratch
+    memory of their deferred sums) are per stream, so the solves do not disturb each other -- every result equals numpy's and
+    repeats bit for bit."""
+    import ctypes
+    import torch
+    P_, hb = 333, 65
+    n = 6 * P_
+    lib = gpu._lib.lib()
+    systems = []
+    for seed in (1, 2):
+        rng = np.random.default_rng(seed)
+        S = np.zeros((n, n))
+        for d in range(1, hb + 1):
+            S[np.arange(n - d), np.arange(d, n)] = rng.standard_normal(n - d)
+        S = S + S.T
+        S[np.arange(n), np.arange(n)] = np.abs(S).sum(axis=1) + 1.0
+        g = rng.standard_normal(n)
+        systems.append((S, g, np.linalg.solve(S, g)))
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    poses = torch.zeros((P_, 12), dtype=torch.float64, device="cuda")
+    first = [None, None]
+    for rep in range(5):
+        outs = []
+        for k, (S, g, ref) in enumerate(systems):
+            with torch.cuda.stream(streams[k]):
+                Sd = torch.from_numpy(S.copy()).cuda().reshape(-1)
+                x = torch.from_numpy(g.copy()).cuda()
+                bad = torch.zeros(1, dtype=torch.int32, device="cuda")
+                gpu._lib.check(lib.mqs_sba_solve_banded_dev(
+                    ctypes.c_void_p(Sd.data_ptr()), ctypes.c_void_p(x.data_ptr()), P_, hb, 0.0, ctypes.c_void_p(poses.data_ptr()), None,
+                    ctypes.c_void_p(bad.data_ptr()), ctypes.c_void_p(streams[k].cuda_stream)))
+                outs.append((Sd, x, bad))
+        torch.cuda.synchronize()
+        for k, (Sd, x, bad) in enumerate(outs):
+            xs = x.cpu().numpy()
+            assert int(bad.item()) == 0
+            assert np.abs(xs - systems[k][2]).max() <= 1e-11 * np.abs(systems[k][2]).max()
+            if first[k] is None:
+                first[k] = xs
+            np.testing.assert_array_equal(xs, first[k])
+
+
+@pytest.mark.gpu
 def test_odometry_between_factors(gpu):
     """B3 (bundle_adjust.cpp:301-309, useOdometry = 1) on the reference's example files: the odometry factors'
     contribution to the reduced camera system and to the cost equals the oracle's, and LM with them converges."""
