@@ -310,7 +310,10 @@ int mqs_ba_backsub(mqs_ctx *ctx, const double *poses, const double *calib, const
  *     (J^T J form incl. PriorFactor<Pose3> terms of the n_pose_prior listed poses, bundle_adjust.cpp:273);
  *     info[4] = {0.5*sum|r/sigma|^2 + point priors, valid-factor count, pose-prior cost, 0 (grouped entry point: see there)}.
  *   solve: in place blocked Cholesky of (S + lambda*diag S), x (= g on entry) -> dpose; poses_out =
- *     retract(poses, dpose) when not NULL; bad[0] = 1 when S was not positive definite.
+ *     retract(poses, dpose) when not NULL; bad[0] = 1 when S was not positive definite.  Input contract: the LOWER
+ *     triangle of S (with the diagonal), as for any Cholesky routine; the strict upper triangle is overwritten (the
+ *     solve mirrors lower -> upper inside the band first: its factor kernels read panel input from the mirror image).
+ *     On return the lower triangle holds L, the upper triangle work values.
  *   backsub / cost as in the dense API.  mqs_sba_linearize_dev sums with fp64 atomics (not bitwise reproducible);
  *   the grouped form below does not.
  * ------------------------------------------------------------------------------------- */
@@ -354,6 +357,9 @@ int mqs_sba_solve_banded_dev(double *S, double *x, int64_t P, int64_t half_bandw
  * (4 ints: block, first column, count, 0); columns.  Returns the ints needed (0 = the solve takes the natural order for this
  * shape) and fills `out` when `cap` is large enough.  tests/test_chol_plan.py replays a plan with numpy. */
 int64_t mqs_sba_solve_plan_dump(int64_t n6, int64_t half_bandwidth, int parts, int32_t *out, int64_t cap);
+/* Plans (and their device scratch) are cached per (device, stream, n6, half_bandwidth) in a small LRU: a session whose
+ * pose count grows with every keyframe does not accumulate them.  Returns how many are alive (diagnostic; <= 8). */
+int mqs_sba_solve_plan_cache_size(void);
 int mqs_sba_backsub_dev(const double *poses, const int32_t *pose_cam, int64_t P, const double *calib,
                         const double *sigma, const double *points, int64_t N, const int64_t *obs_ptr,
                         const int32_t *obs_pose, const double *obs_uv, int64_t M, const double *prior_w,

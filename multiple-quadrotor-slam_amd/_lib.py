@@ -104,6 +104,7 @@ SIGNATURES = {
     "mqs_sba_solve_dev": (ctypes.c_int, [c_vp, c_vp, c_i64, ctypes.c_double, c_vp, c_vp, c_vp, c_vp]),
     "mqs_sba_solve_banded_dev": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i64, ctypes.c_double, c_vp, c_vp, c_vp, c_vp]),
     "mqs_sba_solve_plan_dump": (ctypes.c_int64, [c_i64, c_i64, ctypes.c_int, c_vp, c_i64]),
+    "mqs_sba_solve_plan_cache_size": (ctypes.c_int, []),
     "mqs_sba_backsub_dev": (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp,
                                            c_vp, ctypes.c_double, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "mqs_sba_cost_dev": (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp,

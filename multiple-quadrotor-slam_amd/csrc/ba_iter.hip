@@ -94,7 +94,9 @@ int mqs_ba_gn_iteration_dev(mqs_ba_problem *p, double lambda, void *stream)
 {
     int rc = mqs_ba_gn_begin_dev(p, lambda, stream);
     if (rc != MQS_OK) return rc;
-    if (p->ctx && mqs_comm_world_size(p->ctx) > 1) {
+    // issued whenever the context holds a communicator -- also a one-rank one, where the sum is the identity: the single-GPU
+    // tests then run the very call sequence an N-GPU iteration runs (lineariser, ncclAllReduce on the same stream, solve)
+    if (p->ctx && mqs_comm_world_size(p->ctx) >= 1) {
         rc = mqs_comm_all_reduce_sum_f64_dev(p->ctx, p->lin, (int64_t)36 * p->C * p->C + 6 * p->C + 2, stream);
         if (rc != MQS_OK) return rc;
     }

@@ -439,6 +439,31 @@ __global__ void sparse_damp_kernel(double *__restrict__ S, int n6, double lambda
     }
 }
 
+// The solve's input contract is the usual one of a Cholesky routine: the LOWER triangle (with the diagonal).  The factor
+// kernels read their panel input from the mirror image in the upper triangle (chol_step_kernel, nd_step_kernel), so the
+// solve first copies lower -> upper inside the band: 32 x 32 tiles through LDS, one workgroup per tile, grid = block rows x
+// (band tiles + 1).  A caller that hands over both triangles (the linearisers here do) gets the same bits as before.
+__global__ __launch_bounds__(256) void sparse_mirror_lower_kernel(double *__restrict__ S, int n6)
+{
+    __shared__ double sT[32][33];
+    const int br = blockIdx.x, off = blockIdx.y, bc = br - off;
+    if (bc < 0) return;
+    const int r0 = 32 * br, c0 = 32 * bc;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = r0 + ty + 8 * k, c = c0 + tx;
+        sT[ty + 8 * k][tx] = (r < n6 && c < n6) ? S[(int64_t)r * n6 + c] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        // element (c0 + ty', r0 + tx) of the upper triangle = element (r0 + tx, c0 + ty') of the lower one
+        const int c = c0 + ty + 8 * k, r = r0 + tx;
+        if (r < n6 && c < n6 && r > c) S[(int64_t)c * n6 + r] = sT[tx][ty + 8 * k];     // whole tiles: the factor kernels work on 32 x 32 blocks
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void sparse_backsub_kernel(
     const double *__restrict__ cams, const double *__restrict__ points, const int64_t *__restrict__ obs_ptr,
     const int32_t *__restrict__ obs_pose, const double *__restrict__ obs_uv, const double *__restrict__ prior_w,
@@ -1194,6 +1219,10 @@ int mqs_sba_solve_banded_dev(double *S, double *x, int64_t P, int64_t half_bandw
     const int n = (int)(6 * P);
     const int hb = half_bandwidth < n ? (int)half_bandwidth : n;
     MQS_HIP_CHECK(hipMemsetAsync(bad, 0, sizeof(int), stream));
+    if (n > 1 && hb > 0) {
+        const int brows = (n + 31) / 32, boffs = (hb + 31) / 32 + 1;
+        hipLaunchKernelGGL(sparse_mirror_lower_kernel, dim3(brows, boffs < brows ? boffs : brows), dim3(256), 0, stream, S, n);
+    }
     if (lambda != 0.0) hipLaunchKernelGGL(sparse_damp_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, S, n, lambda);
     const bool banded = 3 * (int64_t)hb < n;            // the band is worth exploiting
     bool nd_done = false;
@@ -1205,7 +1234,7 @@ int mqs_sba_solve_banded_dev(double *S, double *x, int64_t P, int64_t half_bandw
         // right-looking blocked Cholesky; rows further than hb below a block column are zero there and stay zero
         // (no fill outside the band), so the panel and the trailing update stop hb rows below it
         // one launch per block column: the first diagonal block, then panel + update + next diagonal block fused (see
-        // chol_step_kernel).  The input must hold BOTH triangles (it does: the linearisers write both).
+        // chol_step_kernel).  Both triangles are valid here: sparse_mirror_lower_kernel above.
         hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(64), 0, stream, S, n, 0, bad);
         for (int k0 = 0; k0 < n; k0 += NB) {
             const int nb = (n - k0) < NB ? (n - k0) : NB;

@@ -24,6 +24,7 @@
 // Diagonal blocks: L below, inv(L)^T strictly above (chol_block.h).
 #include "chol_block.h"
 #include <algorithm>
+#include <list>
 #include <map>
 #include <mutex>
 #include <tuple>
@@ -653,6 +654,16 @@ bool build_plan_host(Plan &plan, int n, int hb, int parts)
     return true;
 }
 
+void free_plan_device(Plan &plan)
+{
+    void **ptrs[] = {(void **)&plan.d_descs, (void **)&plan.d_lazy, (void **)&plan.d_contrib, (void **)&plan.d_slot_tile,
+                     (void **)&plan.d_scratch, (void **)&plan.d_vecs, (void **)&plan.d_cols};
+    for (void **p : ptrs) {
+        if (*p) (void)hipFree(*p);                 // hipFree waits for the device: a solve still in flight on the plan finishes first
+        *p = nullptr;
+    }
+}
+
 bool build_plan(Plan &plan, int n, int hb, int parts)
 {
     if (!build_plan_host(plan, n, hb, parts)) return false;
@@ -663,26 +674,38 @@ bool build_plan(Plan &plan, int n, int hb, int parts)
     const std::vector<int32_t> &cols = plan.cols;
     auto up = [](const void *src, size_t bytes, void **dst) -> bool {
         if (bytes == 0) bytes = 8;
-        if (hipMalloc(dst, bytes) != hipSuccess) return false;
+        if (hipMalloc(dst, bytes) != hipSuccess) { *dst = nullptr; return false; }
         return src == nullptr || hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess;
     };
-    if (!up(descs.data(), descs.size() * sizeof(StepDesc), (void **)&plan.d_descs)) return false;
-    if (!up(lazy.data(), lazy.size() * sizeof(LazyTile), (void **)&plan.d_lazy)) return false;
-    if (!up(contrib.empty() ? nullptr : contrib.data(), contrib.size() * sizeof(int32_t), (void **)&plan.d_contrib)) return false;
-    if (!up(plan.slot_tile.empty() ? nullptr : plan.slot_tile.data(), plan.slot_tile.size() * sizeof(int32_t), (void **)&plan.d_slot_tile))
-        return false;
     size_t max_slots = 1;
     for (const StagePlan &sp : plan.stages) max_slots = std::max(max_slots, (size_t)sp.nslots);
-    if (hipMalloc((void **)&plan.d_scratch, max_slots * NB * NB * sizeof(double)) != hipSuccess) return false;
-    if (!up(vecs.empty() ? nullptr : vecs.data(), vecs.size() * sizeof(LazyVec), (void **)&plan.d_vecs)) return false;
-    if (!up(cols.empty() ? nullptr : cols.data(), cols.size() * sizeof(int32_t), (void **)&plan.d_cols)) return false;
+    const bool ok = up(descs.data(), descs.size() * sizeof(StepDesc), (void **)&plan.d_descs) &&
+                    up(lazy.data(), lazy.size() * sizeof(LazyTile), (void **)&plan.d_lazy) &&
+                    up(contrib.empty() ? nullptr : contrib.data(), contrib.size() * sizeof(int32_t), (void **)&plan.d_contrib) &&
+                    up(plan.slot_tile.empty() ? nullptr : plan.slot_tile.data(), plan.slot_tile.size() * sizeof(int32_t),
+                       (void **)&plan.d_slot_tile) &&
+                    up(nullptr, max_slots * NB * NB * sizeof(double), (void **)&plan.d_scratch) &&
+                    up(vecs.empty() ? nullptr : vecs.data(), vecs.size() * sizeof(LazyVec), (void **)&plan.d_vecs) &&
+                    up(cols.empty() ? nullptr : cols.data(), cols.size() * sizeof(int32_t), (void **)&plan.d_cols);
+    if (!ok) {
+        // out of device memory part-way: give back what was taken and clear the error, so that the natural-order solve the
+        // caller falls back to does not trip over it in its own hipGetLastError()
+        free_plan_device(plan);
+        (void)hipGetLastError();
+        return false;
+    }
     plan.usable = true;
     return true;
 }
 
 std::mutex g_plan_mutex;
-// one plan per (device, stream, shape): a plan owns the scratch memory of its lazy sums, and solves on different streams may overlap
-std::map<std::tuple<int, void *, int, int, int>, Plan *> g_plans;
+// Plans are cached per (device, stream, shape): a plan owns the scratch memory of its lazy sums, and solves on different
+// streams may overlap.  In a SLAM session 6P grows with every keyframe, so the cache is a small LRU -- the least recently
+// used plan's device memory is freed when a new shape arrives (kMaxPlans shapes alive at a time; a bundle adjustment calls
+// the solve tens of times per shape, the plan costs ~1 ms of host work to rebuild).
+constexpr size_t kMaxPlans = 8;
+struct PlanEntry { std::tuple<int, void *, int, int, int> key; Plan *plan; };
+std::list<PlanEntry> g_plans;                     // most recently used first
 
 bool xcd_pin_enabled()
 {
@@ -704,13 +727,28 @@ Plan *get_plan(int n, int hb, hipStream_t stream)
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
     const int parts = parts_from_env();
     std::lock_guard<std::mutex> lock(g_plan_mutex);
-    auto key = std::make_tuple(dev, (void *)stream, n, hb, parts);
-    auto it = g_plans.find(key);
-    if (it != g_plans.end()) return it->second;
+    const auto key = std::make_tuple(dev, (void *)stream, n, hb, parts);
+    for (auto it = g_plans.begin(); it != g_plans.end(); ++it)
+        if (it->key == key) {
+            g_plans.splice(g_plans.begin(), g_plans, it);
+            return g_plans.front().plan;
+        }
+    while (g_plans.size() >= kMaxPlans) {
+        Plan *old = g_plans.back().plan;
+        g_plans.pop_back();
+        free_plan_device(*old);
+        delete old;
+    }
     Plan *p = new Plan();
     if (!build_plan(*p, n, hb, parts)) p->usable = false;
-    g_plans[key] = p;
+    g_plans.push_front({key, p});
     return p;
+}
+
+int plan_cache_size()
+{
+    std::lock_guard<std::mutex> lock(g_plan_mutex);
+    return (int)g_plans.size();
 }
 
 }  // namespace
@@ -765,6 +803,9 @@ int mqs_chol_nd_solve(double *S, double *x, int n, int hb, int *bad, hipStream_t
     *done = true;
     return MQS_OK;
 }
+
+// How many chunked-solve plans (with their device memory) the process holds: bounded by the LRU above.
+extern "C" int mqs_sba_solve_plan_cache_size(void) { return mqs::chol::plan_cache_size(); }
 
 // The plan as plain integers, for inspection and for the CPU test that replays it with numpy (no GPU involved):
 // header[8] = {stages, descs, lazy tiles, contributions, lazy vectors, columns, parts, 0}, then per stage 8 ints

@@ -143,14 +143,8 @@ using float16v = __attribute__((ext_vector_type(16))) float;
 #ifndef MQS_MATCH_PF
 #define MQS_MATCH_PF 4
 #endif
-#ifndef MQS_MATCH_PRUNE_I8
-#define MQS_MATCH_PRUNE_I8 1           // early reject of tile values that cannot enter the best two (see tile_step): int8 path
-#endif
 #ifndef MQS_MATCH_PRUNE_F16
 #define MQS_MATCH_PRUNE_F16 0          // the same on the fp16 path (not bound by vector issue: measured)
-#endif
-#ifndef MQS_MATCH_BITS_FP4
-#define MQS_MATCH_BITS_FP4 1           // packed-bit descriptors on the FP4 matrix path (F4Path) instead of int8 (I8Path)
 #endif
 #ifndef MQS_MATCH_F4_QT
 #define MQS_MATCH_F4_QT 4
@@ -163,9 +157,6 @@ using float16v = __attribute__((ext_vector_type(16))) float;
 #endif
 #ifndef MQS_MATCH_PRUNE_F4
 #define MQS_MATCH_PRUNE_F4 1
-#endif
-#ifndef MQS_MATCH_I8_QT
-#define MQS_MATCH_I8_QT 4
 #endif
 #ifndef MQS_MATCH_NW256
 #define MQS_MATCH_NW256 8
@@ -214,10 +205,9 @@ __global__ void row_sqnorm_kernel(const _Float16 *__restrict__ x, int64_t n, int
 }
 
 using int4v = __attribute__((ext_vector_type(4))) int;
-using int16v = __attribute__((ext_vector_type(16))) int;
 
 // What differs between the two element types of the MFMA path.  A fragment is 16 bytes per lane either way
-// (8 halves: k = 16 ks + 8 h + j;  16 int8: k = 32 ks + 16 h + j), so the LDS image and its addressing are shared.
+// (8 halves: k = 16 ks + 8 h + j;  32 FP4 nibbles: k = 64 ks + 32 h + j), so the LDS image and its addressing are shared.
 struct F16Path {
     using elem = _Float16;
     using frag = half8;
@@ -230,8 +220,7 @@ struct F16Path {
     static __device__ __forceinline__ accv mfma(frag a, frag b, accv c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
     // d' crosses a binade (512 .. 1537), so the row bits are OR-ed in after the sum.  (Keeping the sum in one binade -- bias
     // 2560, windows of 128 tiles, tile and row both in the start value -- removes the v_or3 but measured the same 1.342 ms on the
-    // same box: at 3 vector instructions per MFMA the fp16 kernel is not bound by vector issue; the int8 one, at 6, was.)
-    static constexpr bool kRowInStart = false;
+    // same box: at 3 vector instructions per MFMA the fp16 kernel is not bound by vector issue.)
     static constexpr bool kPrune = MQS_MATCH_PRUNE_F16 != 0;
     static constexpr int kGroup = 1;
     static constexpr int kStageRowsMax = MQS_MATCH_STAGE_ROWS;
@@ -248,42 +237,6 @@ struct F16Path {
         if (!(f < kInvalid)) return false;
         d = floorf(f);
         tile = (int)((f - d) * (float)kWindowTiles);
-        row = (int)(k & 31u);
-        return true;
-    }
-};
-
-// int8 {0,1} descriptors (the packed-bit entry point expands them): train bytes are stored as 0 / 64 and query bytes
-// as 0 / -128, so one MFMA unit contributes -2^13 = -2 * 2^12 and the int32 accumulator, started from
-// (kBias + |t|^2) << 12 | tile << 5, ends as  d' << 12 | tile << 5  with d' = kBias + |t|^2 - 2 q.t exactly;
-// 7 tile bits + 5 row bits fill the 12 low bits (windows of 128 tiles = 4096 rows).
-struct I8Path {
-    using elem = signed char;
-    using frag = int4v;
-    using accv = int16v;
-    using start_t = int;
-    using start4 = int4v;
-    static constexpr int kPerMfma = 32;
-    static constexpr int kWindowTiles = 128;
-    static __device__ __forceinline__ frag prep_query(frag v) { return v; }
-    static __device__ __forceinline__ accv mfma(frag a, frag b, accv c) { return __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, 0, 0, 0); }
-    // the row inside its tile rides in the start value too (the int32 accumulator only ever adds multiples of 2^13 to it),
-    // so the finished accumulator IS the key: the scan costs v_med3_u32 + v_min_u32 per value, no v_or3
-    static constexpr bool kRowInStart = true;
-    static constexpr bool kPrune = MQS_MATCH_PRUNE_I8 != 0;
-    static constexpr int kGroup = 1;
-    static constexpr int kStageRowsMax = MQS_MATCH_STAGE_ROWS;
-    static __device__ __forceinline__ unsigned key_floor(float d) { return d < kInvalid ? ((unsigned)d << 12) : 0xFFFFFFFFu; }
-    static constexpr float kBiasV = kBias;
-    static __device__ __forceinline__ start_t start(float tnorm, int64_t t) { return (((int)tnorm + (int)kBias) << 12) | (int)(((t >> 5) & (kWindowTiles - 1)) << 5) | (int)(t & 31); }
-    static __device__ __forceinline__ start_t pad() { return ((int)kPadNorm) << 12; }
-    static __device__ __forceinline__ unsigned key(int v) { return (unsigned)v; }
-    static __device__ __forceinline__ bool decode(unsigned k, float &d, int &tile, int &row)
-    {
-        const unsigned dd = k >> 12;
-        if (dd >= (unsigned)kInvalid) return false;
-        d = (float)dd;
-        tile = (int)((k >> 5) & (kWindowTiles - 1));
         row = (int)(k & 31u);
         return true;
     }
@@ -312,7 +265,7 @@ struct F4Path : F16Path {
     }
 };
 
-template <class TP /* F16Path, I8Path or F4Path */, int KS /* MFMAs per (train tile, query tile) = D / TP::kPerMfma */,
+template <class TP /* F16Path or F4Path */, int KS /* MFMAs per (train tile, query tile) = D / TP::kPerMfma */,
           int QT /* 32-query column tiles per wave */, int NW /* waves per workgroup */>
 __global__ __launch_bounds__(NW * 64) void knn2_mfma_kernel(const typename TP::elem *__restrict__ query, int64_t Nq,
                                                            const typename TP::elem *__restrict__ train, int64_t Nt,
@@ -363,7 +316,7 @@ __global__ __launch_bounds__(NW * 64) void knn2_mfma_kernel(const typename TP::e
     // current second key and every key at the distance of the running second-best over the finished windows (later rows
     // lose ties).  thr = the smaller of the two; four values are reduced with v_min3 + v_min, compared with thr, and the
     // wave skips their scan when no lane has a candidate -- after the first few hundred rows that is the usual case, and
-    // the per-value cost falls from 2 (int8) / 3 (fp16) vector instructions to 3/4.
+    // the per-value cost falls from 3 vector instructions to 3/4.
     unsigned thr[QT];
     float gd0[QT], gd1[QT];                  // running result over the finished windows: kBias + |t|^2 - 2 q.t
     int gi0[QT], gi1[QT];
@@ -454,8 +407,7 @@ __global__ __launch_bounds__(NW * 64) void knn2_mfma_kernel(const typename TP::e
                     if (__builtin_amdgcn_ballot_w64(m4 < thr[pq]) != 0) {
 #pragma unroll
                         for (int e = 4 * g; e < 4 * g + 4; ++e) {
-                            const unsigned key = TP::kRowInStart ? TP::key(prev[e])
-                                                                 : (TP::key(prev[e]) | (unsigned)(4 * h) | (unsigned)(8 * (e >> 2) + (e & 3)));
+                            const unsigned key = TP::key(prev[e]) | (unsigned)(4 * h) | (unsigned)(8 * (e >> 2) + (e & 3));
                             unsigned m;
                             asm("v_med3_u32 %0, %1, %2, %3" : "=v"(m) : "v"(best[pq]), "v"(second[pq]), "v"(key));
                             second[pq] = m;
@@ -469,8 +421,7 @@ __global__ __launch_bounds__(NW * 64) void knn2_mfma_kernel(const typename TP::e
             const int v0 = ks * 16 / KS, v1 = (ks + 1) * 16 / KS;
 #pragma unroll
             for (int e = v0; e < v1; ++e) {
-                const unsigned key = TP::kRowInStart ? TP::key(prev[e])
-                                                     : (TP::key(prev[e]) | (unsigned)(4 * h) | (unsigned)(8 * (e >> 2) + (e & 3)));   // v_or3_b32
+                const unsigned key = TP::key(prev[e]) | (unsigned)(4 * h) | (unsigned)(8 * (e >> 2) + (e & 3));   // v_or3_b32
                 unsigned m;
                 asm("v_med3_u32 %0, %1, %2, %3" : "=v"(m) : "v"(best[pq]), "v"(second[pq]), "v"(key));
                 second[pq] = m;
@@ -525,8 +476,7 @@ __global__ __launch_bounds__(NW * 64) void knn2_mfma_kernel(const typename TP::e
                     if (__builtin_amdgcn_ballot_w64(m4 < thr[pq]) != 0) {
 #pragma unroll
                         for (int e = e0; e < e0 + 4; ++e) {
-                            const unsigned key = TP::kRowInStart ? TP::key(prev[e])
-                                                                 : (TP::key(prev[e]) | (unsigned)(4 * h) | (unsigned)(8 * (e >> 2) + (e & 3)));
+                            const unsigned key = TP::key(prev[e]) | (unsigned)(4 * h) | (unsigned)(8 * (e >> 2) + (e & 3));
                             unsigned m;
                             asm("v_med3_u32 %0, %1, %2, %3" : "=v"(m) : "v"(best[pq]), "v"(second[pq]), "v"(key));
                             second[pq] = m;
@@ -540,8 +490,7 @@ __global__ __launch_bounds__(NW * 64) void knn2_mfma_kernel(const typename TP::e
                 for (int v = ks * kPer; v < (ks + 1) * kPer; ++v) {
                     const int which = v >> 4, e = v & 15, pq = prevq0 + which;
                     const accv_t &prev = acc[prev0 + which];
-                    const unsigned key = TP::kRowInStart ? TP::key(prev[e])
-                                                         : (TP::key(prev[e]) | (unsigned)(4 * h) | (unsigned)(8 * (e >> 2) + (e & 3)));
+                    const unsigned key = TP::key(prev[e]) | (unsigned)(4 * h) | (unsigned)(8 * (e >> 2) + (e & 3));
                     unsigned m;
                     asm("v_med3_u32 %0, %1, %2, %3" : "=v"(m) : "v"(best[pq]), "v"(second[pq]), "v"(key));
                     second[pq] = m;
@@ -639,8 +588,7 @@ __global__ __launch_bounds__(NW * 64) void knn2_mfma_kernel(const typename TP::e
             const int qt = QT - G + u;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const unsigned key = TP::kRowInStart ? TP::key(last[e])
-                                                     : (TP::key(last[e]) | (unsigned)(4 * h) | (unsigned)(8 * (e >> 2) + (e & 3)));
+                const unsigned key = TP::key(last[e]) | (unsigned)(4 * h) | (unsigned)(8 * (e >> 2) + (e & 3));
                 second[qt] = max(best[qt], min(second[qt], key));
                 best[qt] = min(best[qt], key);
             }
@@ -723,7 +671,7 @@ int launch_f32(const float *query, int64_t Nq, const float *train, int64_t Nt, i
     return MQS_OK;
 }
 
-constexpr int kMaxParts = 16;                            // int8 windows are 4096 rows: 16 parts of a 65 536-row train set for small query blocks
+constexpr int kMaxParts = 16;                            // parts of the train set (whole windows each) when the query blocks alone cannot fill the CUs
 
 // Can workgroups of NW waves x QT query tiles, times the parts the train set can be split into, occupy every CU?
 template <class TP>
@@ -754,35 +702,8 @@ void launch_mfma_t(const typename TP::elem *q, int64_t Nq, const typename TP::el
                            (int)parts, Nq, qn, idx, dist);
 }
 
-// Packed descriptor bits -> the int8 operands of I8Path (`one` = 64 for train rows, -128 for query rows) and the
-// squared norm (= popcount).  One thread per row; `words` = D / 32 little-endian 32-bit words, bit k of the
-// descriptor = bit (k & 7) of byte k >> 3.
-// `Dout` >= D: width of the expanded row; the columns beyond D are zero (a zero column adds nothing to a Hamming distance).
-__global__ void expand_bits_kernel(const uint8_t *__restrict__ bits, int64_t n, int D, int Dout, int one,
-                                   signed char *__restrict__ out, float *__restrict__ norm)
-{
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint8_t *src = bits + i * (D / 8);
-    signed char *dst = out + i * Dout;
-    for (int b = D / 8; b < Dout / 8; ++b) reinterpret_cast<uint2 *>(dst)[b] = make_uint2(0u, 0u);
-    int pop = 0;
-    for (int b = 0; b < D / 8; ++b) {
-        const unsigned v = src[b];
-        pop += __popc(v);
-        unsigned lo = 0, hi = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            lo |= ((v >> k) & 1u) ? ((unsigned)(one & 0xFF) << (8 * k)) : 0u;
-            hi |= ((v >> (4 + k)) & 1u) ? ((unsigned)(one & 0xFF) << (8 * k)) : 0u;
-        }
-        reinterpret_cast<uint2 *>(dst)[b] = make_uint2(lo, hi);
-    }
-    norm[i] = (float)pop;
-}
-
-
-// The same for F4Path: nibble k of the expanded row = bit k of the descriptor ? `code` : 0 (`code` = 0x2: 1.0 for train
+// Packed descriptor bits -> the FP4 operands of F4Path and the squared norm (= popcount): nibble k of the expanded row =
+// bit k of the descriptor ? `code` : 0 (`code` = 0x2: 1.0 for train
 // rows, 0xC: -2.0 for query rows), two nibbles per byte.  One thread per descriptor BYTE (one output dword): consecutive
 // threads read consecutive bytes and write consecutive dwords (one thread per row wrote 128-byte rows 128 bytes apart:
 // 17 us per 65 536 rows, 7 % of a matcher call; now 3-4); the row's popcount is summed over its D / 8 threads by shuffles.
@@ -931,12 +852,12 @@ int mqs_match_knn2_f16_dev(const uint16_t *query, int64_t Nq, const uint16_t *tr
 }
 
 // Packed binary descriptors (D bits per row, D / 8 bytes, D in {128, 256, 512}): Hamming distance = |q - t|^2 on the
-// FP4 matrix path (F4Path; the int8 path, I8Path, with MQS_MATCH_BITS_FP4=0), same output contract as the fp16 path
-// (dist = sqrt(Hamming)).  65 536^2 x 256 bits: fp16 1.33 ms, int8 0.70 ms, FP4 0.49-0.51 ms on the same boxes.
+// FP4 matrix path (F4Path), same output contract as the fp16 path (dist = sqrt(Hamming)).  65 536^2 x 256 bits: fp16 1.33 ms,
+// FP4 0.45 ms (the int8 form this path had until round 2 -- v_mfma_i32_32x32x32_i8, 0.70 ms -- is gone from the source).
 int64_t mqs_match_knn2_bits_workspace_bytes(int64_t Nq, int64_t Nt, int D)
 {
     if (Nq < 0 || Nt < 0 || D < 8) return 0;
-    if (D == 128) D = 256;                                  // expanded rows are zero-padded to 256 columns
+    if (D == 128) D = 256;                                  // (sized for one byte per bit, as the ABI promised before FP4: an upper bound)
     const int64_t up = 255;
     return (((Nq + 63) / 64 * 64 + (Nt + 63) / 64 * 64) * (int64_t)sizeof(float) + up) / 256 * 256 +
            (int64_t)kMaxParts * Nq * 2 * 8 + ((Nq * D + up) / 256 * 256) + ((Nt * D + up) / 256 * 256) + 256;
@@ -964,11 +885,7 @@ int mqs_match_knn2_bits_dev(const uint8_t *query_bits, int64_t Nq, const uint8_t
     int dev = 0, num_cus = 256;
     MQS_HIP_CHECK(hipGetDevice(&dev));
     MQS_HIP_CHECK(hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, dev));
-    // 128-bit descriptors run on the 256-column kernel, zero-padded: that instantiation (8 waves, four query tiles per wave)
-    // is faster on twice the columns than the 128-column one was on its own (0.85 vs 1.31 ms per 65 536^2 pair)
-    const int De = (D == 128) ? 256 : D;
-#if MQS_MATCH_BITS_FP4
-    // (no padding of 128-bit descriptors here: two FP4 MFMAs per tile cover them)
+    // expanded rows are D / 2 bytes (two nibbles per byte); 128-bit descriptors need no padding: two FP4 MFMAs per tile cover them
     hipLaunchKernelGGL(expand_bits_fp4_kernel, dim3((unsigned)((Nq * (D / 8) + 255) / 256)), dim3(256), 0, stream, query_bits, Nq, D, 0xCu,
                        q8, qn);
     if (Nt > 0)
@@ -988,21 +905,6 @@ int mqs_match_knn2_bits_dev(const uint8_t *query_bits, int64_t Nq, const uint8_t
             launch_mfma_t<F4Path, 4, 1, 8>(q8, Nq, t8, Nt, qn, tn, idx, dist, part_d, part_i, num_cus, stream);
         break;
     case 512: launch_mfma_t<F4Path, 8, 2, 8>(q8, Nq, t8, Nt, qn, tn, idx, dist, part_d, part_i, num_cus, stream); break;
-    }
-    MQS_HIP_CHECK(hipGetLastError());
-    return MQS_OK;
-#endif
-    hipLaunchKernelGGL(expand_bits_kernel, dim3((unsigned)((Nq + 255) / 256)), dim3(256), 0, stream, query_bits, Nq, D, De, -128, q8, qn);
-    if (Nt > 0)
-        hipLaunchKernelGGL(expand_bits_kernel, dim3((unsigned)((Nt + 255) / 256)), dim3(256), 0, stream, train_bits, Nt, D, De, 64, t8, tn);
-    switch (De) {
-    case 256:
-        if (tiles_fill<I8Path>(Nq, Nt, 8, MQS_MATCH_I8_QT, num_cus))
-            launch_mfma_t<I8Path, 8, MQS_MATCH_I8_QT, 8>(q8, Nq, t8, Nt, qn, tn, idx, dist, part_d, part_i, num_cus, stream);
-        else
-            launch_mfma_t<I8Path, 8, 1, 8>(q8, Nq, t8, Nt, qn, tn, idx, dist, part_d, part_i, num_cus, stream);
-        break;
-    case 512: launch_mfma_t<I8Path, 16, 2, 8>(q8, Nq, t8, Nt, qn, tn, idx, dist, part_d, part_i, num_cus, stream); break;
     }
     MQS_HIP_CHECK(hipGetLastError());
     return MQS_OK;

@@ -226,6 +226,45 @@ def test_reduced_system_solve_against_numpy(case, gpu):
         ref = np.linalg.solve(S + lam * np.diag(np.diag(S)), g)
         assert int(bad.item()) == 0
         assert np.abs(x.cpu().numpy() - ref).max() <= 1e-10 * np.abs(ref).max()
+        # the input contract is the LOWER triangle (include/mqslam.h): the same system with its strict upper triangle poisoned
+        # gives the same bits
+        Sp = S.copy()
+        Sp[np.triu_indices(n, 1)] = np.nan
+        Sd2 = torch.from_numpy(Sp).cuda().reshape(-1)
+        x2 = torch.from_numpy(g.copy()).cuda()
+        gpu._lib.check(gpu._lib.lib().mqs_sba_solve_banded_dev(
+            ctypes.c_void_p(Sd2.data_ptr()), ctypes.c_void_p(x2.data_ptr()), P_, min(hb, n), lam, ctypes.c_void_p(poses.data_ptr()),
+            None, ctypes.c_void_p(bad.data_ptr()), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        assert int(bad.item()) == 0 and torch.equal(x2, x)
+
+
+@pytest.mark.gpu
+def test_chunked_solve_plan_cache_is_bounded(gpu):
+    """A session whose pose count grows with every keyframe asks for a new chunked-solve plan per shape: the cache is an LRU
+    (csrc/chol_nd.hip) -- it never holds more than 8 plans, and a shape that was evicted is rebuilt and still solves."""
+    import ctypes
+    import torch
+    L = gpu._lib.lib()
+    rng = np.random.default_rng(5)
+    first = None
+    for k, P_ in enumerate(list(range(100, 112)) + [100]):
+        n, hb = 6 * P_, 17
+        S = np.zeros((n, n))
+        for d in range(1, hb + 1):
+            S[np.arange(n - d), np.arange(d, n)] = rng.standard_normal(n - d)
+        S = S + S.T
+        S[np.arange(n), np.arange(n)] = np.abs(S).sum(axis=1) + 1.0
+        g = rng.standard_normal(n)
+        Sd, x = torch.from_numpy(S.copy()).cuda().reshape(-1), torch.from_numpy(g.copy()).cuda()
+        bad = torch.zeros(1, dtype=torch.int32, device="cuda")
+        poses = torch.zeros((P_, 12), dtype=torch.float64, device="cuda")
+        gpu._lib.check(L.mqs_sba_solve_banded_dev(ctypes.c_void_p(Sd.data_ptr()), ctypes.c_void_p(x.data_ptr()), P_, hb, 0.0,
+                                                  ctypes.c_void_p(poses.data_ptr()), None, ctypes.c_void_p(bad.data_ptr()),
+                                                  ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        ref = np.linalg.solve(S, g)
+        assert int(bad.item()) == 0 and np.abs(x.cpu().numpy() - ref).max() <= 1e-10 * np.abs(ref).max()
+        assert 1 <= L.mqs_sba_solve_plan_cache_size() <= 8
+    assert L.mqs_sba_solve_plan_cache_size() == 8
 
 
 @pytest.mark.gpu

@@ -164,7 +164,7 @@ def test_bad_arguments_fail_loudly(gpu):
     assert rc < 0
 
 
-def test_full_size_properties_1e6x4(gpu):
+def test_full_size_properties_1e6x4(gpu, c_oracle):
     """BASELINE configs[3] shape on one GPU: shard additivity (the multi-GPU contract: the sum of the
     shards' systems equals the whole, <= 1e-10), bitwise determinism, oracle agreement on a sample,
     and monotone cost over 10 GN iterations."""
@@ -197,6 +197,19 @@ def test_full_size_properties_1e6x4(gpu):
                                          ba.points[:n].cpu().numpy(), ba.obs[:, :n].cpu().numpy(), None,
                                          ba.prior_w[:n].cpu().numpy(), ba.prior_xyz[:n].cpu().numpy())
     assert np.abs(S - So).max() <= 1e-10 * np.abs(So).max() and cost == pytest.approx(co, rel=1e-12)
+    # the WHOLE 1e6 x 4 reduced system, gradient, cost, count and a back-substitution against the oracle's C port (OpenMP)
+    hh = lambda t: t.cpu().numpy()
+    Sw, gw, cw, nw = split_lin(lin, C)
+    Sc, gc, cc, nc = c_oracle.ba_linearize(hh(ba.poses), hh(ba.calib), hh(ba.sigma), hh(ba.points), hh(ba.obs), None,
+                                           hh(ba.prior_w), hh(ba.prior_xyz), 0.0, use_omp=True)
+    assert np.abs(Sw - Sc).max() <= 1e-10 * np.abs(Sc).max() and np.abs(gw - gc).max() <= 1e-10 * np.abs(gc).max()
+    assert cw == pytest.approx(cc, rel=1e-11) and nw == nc
+    dpose = np.linalg.solve(Sc + 1e-3 * np.diag(np.diag(Sc)), gc)
+    ba.dpose.copy_(torch.from_numpy(dpose).cuda())
+    pts_new = ba.backsub(0.0).cpu().numpy()
+    pts_o = c_oracle.ba_backsub(hh(ba.poses), hh(ba.calib), hh(ba.sigma), hh(ba.points), hh(ba.obs), dpose, None,
+                                hh(ba.prior_w), hh(ba.prior_xyz), 0.0, use_omp=True)
+    assert np.abs(pts_new - pts_o).max() <= 1e-9 * max(1.0, np.abs(pts_o - hh(ba.points)).max())
     hist = ba.optimize(iters=10, mode="gn")
     assert hist[-1] < hist[0] and all(b <= a * (1 + 1e-9) for a, b in zip(hist[1:], hist[2:]))
     assert hist[-1] / (N * C) < 1.0                                  # chi^2 per factor at pixel-noise level
@@ -286,8 +299,37 @@ def test_gtsam_style_damping(gpu):
     assert np.abs(a.poses.cpu().numpy() - b.poses.cpu().numpy()).max() < 2e-2
 
 
-@pytest.mark.parametrize("case", [dict(N=180_001, C=4), dict(N=150_000, C=3, masked=True), dict(N=70_000, C=2),
-                                  dict(N=262_144 + 63, C=4, masked=True, lam=1e-3)])
+def distort_observations(obs_px, calib):
+    """Pixels of an ideal pinhole camera -> pixels of the same camera with the Cal3DS2 lens model in `calib`
+    (IO.hpp:230-236 loads fx fy s u0 v0 k1 k2 p1 p2), so that a distorted calibration sees consistent measurements."""
+    out = np.empty_like(obs_px)
+    for c in range(obs_px.shape[0]):
+        fx, fy, s, u0, v0, k1, k2, p1, p2 = calib[c]
+        y = (obs_px[c, :, 1] - v0) / fy
+        x = (obs_px[c, :, 0] - u0 - s * y) / fx
+        r2 = x * x + y * y
+        g = 1 + k1 * r2 + k2 * r2 * r2
+        xd = g * x + 2 * p1 * x * y + p2 * (r2 + 2 * x * x)
+        yd = g * y + 2 * p2 * x * y + p1 * (r2 + 2 * y * y)
+        out[c, :, 0] = fx * xd + s * yd + u0
+        out[c, :, 1] = fy * yd + v0
+    return out
+
+
+# k1 = 0.3: the lens of triangulation_comparison.py:127-147; the second set exercises every coefficient and the skew
+DIST_K1 = [0.0, 0.3, 0.0, 0.0, 0.0]
+DIST_ALL = [0.7, 0.08, -0.02, 0.001, -0.0015]
+WAVE_CASES = [dict(N=180_001, C=4), dict(N=150_000, C=3, masked=True), dict(N=70_000, C=2),
+              dict(N=262_144 + 63, C=4, masked=True, lam=1e-3)]
+# the same walks with lens distortion: wl_chunk<C, 1..4, NODIST = false> (csrc/ba.hip), masked and unmasked, C = 2, 3, 4
+WAVE_CASES += [dict(N=n, C=c, masked=m, dist=d) for n, c, m, d in [
+    (70_000, 4, False, DIST_K1), (70_000, 2, True, DIST_ALL), (150_000, 3, False, DIST_ALL), (150_000, 4, True, DIST_K1),
+    (180_001, 4, False, DIST_ALL), (180_001, 2, False, DIST_K1), (180_001, 3, True, DIST_K1),
+    (262_144 + 63, 4, True, DIST_ALL), (262_144 + 63, 3, False, DIST_K1), (262_144 + 63, 2, True, DIST_ALL)]]
+
+
+@pytest.mark.parametrize("case", WAVE_CASES, ids=lambda c: "N%d-C%d%s%s" % (c["N"], c["C"], "-masked" if c.get("masked") else "",
+                                                                             "-dist" if c.get("dist") else ""))
 def test_wave_lineariser_every_chunk_size_against_the_c_oracle(case, gpu, c_oracle):
     """Sizes at which a wave of the wave-level lineariser owns 1 to 5 rows of 64 landmarks, i.e. walks chunks of 1, 2, 3 and 4
     landmarks per lane (the 1e6 test only sees chunks of 4 and 3; the small cases only chunks of 1): reduced system, gradient,
@@ -300,6 +342,13 @@ def test_wave_lineariser_every_chunk_size_against_the_c_oracle(case, gpu, c_orac
     u, P, pts = syn.triangulation_problem(N, C)
     rng = np.random.default_rng(N)
     ba = gpu.bundle_adjustment.make_benchmark_problem(u, P, pts + 0.03 * rng.standard_normal(pts.shape), torch.device("cuda", 0), seed=2)
+    if case.get("dist"):
+        cal = ba.calib.cpu().numpy()
+        cal[:, 2] = case["dist"][0]
+        cal[:, 5:] = case["dist"][1:]
+        cal[C - 1, 5:] *= 0.5                                   # cameras need not share a lens
+        ba.obs.copy_(torch.from_numpy(distort_observations(ba.obs.cpu().numpy(), cal)))
+        ba.calib.copy_(torch.from_numpy(cal))
     pw = np.zeros(N)
     sel = rng.choice(N, 5000, replace=False)
     pw[sel] = rng.uniform(1.0, 30.0, 5000)
@@ -336,3 +385,10 @@ def test_wave_lineariser_every_chunk_size_against_the_c_oracle(case, gpu, c_orac
         parts.append(sub.linearize(lam).clone())
     tot = (parts[0] + parts[1]).cpu().numpy()
     assert np.abs(tot - lin2.cpu().numpy()).max() <= 1e-10 * np.abs(lin2.cpu().numpy()).max()
+    # back-substitution of the same problem (its distortion branch is per kernel too) against the oracle's C port
+    dpose = np.linalg.solve(So + 1e-3 * np.diag(np.diag(So)), go)
+    ba.dpose.copy_(torch.from_numpy(dpose).cuda())
+    pts_new = ba.backsub(lam).cpu().numpy()
+    pts_o = c_oracle.ba_backsub(h(ba.poses), h(ba.calib), h(ba.sigma), h(ba.points), obs_h, dpose, mask, h(ba.prior_w),
+                                h(ba.prior_xyz), lam, use_omp=True)
+    assert np.abs(pts_new - pts_o).max() <= 1e-9 * max(1.0, np.abs(pts_o - h(ba.points)).max())

@@ -106,8 +106,9 @@ def test_f16_mfma_path_bit_exact(shape, gpu):
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape", [(1, 1, 256), (70, 5, 256), (256, 64, 256), (1000, 3000, 256), (513, 1029, 128),
                                    (200, 500, 512), (300, 9000, 256), (4100, 4200, 256)])
-def test_packed_bits_int8_path_bit_exact(shape, gpu):
-    """Packed 256-bit descriptors on the int8 matrix pipe: identical to the oracle and to the fp16 path."""
+def test_packed_bits_fp4_path_bit_exact(shape, gpu):
+    """Packed binary descriptors on the FP4 matrix path (F4Path, v_mfma_scale_f32_32x32x64_f8f6f4): identical to the oracle and
+    to the fp16 path."""
     Nq, Nt, D = shape
     tb = gpu.matching.binary_descriptors(Nt, D, seed=18)
     qb = gpu.matching.binary_descriptors(Nq, D, seed=19, copies_of=tb.astype(np.uint8))

@@ -223,6 +223,15 @@ def test_full_size_properties_1e6x4(gpu, c_oracle):
         assert np.max(rel_err(xg[good], xo[good])) < TOL
         if sg is not None:
             np.testing.assert_array_equal(sg[good], so[good])
+    # (a') the bench step's fused pass (tri_kernel<4, 3>: both least-squares methods in one launch) on the same sample:
+    # x_it and the status codes are the stand-alone kernel's bits, x_ls meets the oracle at the parity bar
+    f_ls, f_it, f_st = dev.linear_and_iterative_LS_triangulation(ud, Pd)
+    torch.cuda.synchronize()
+    assert torch.equal(f_it, x_it) and torch.equal(f_st, s_it)
+    xo, _ = c_oracle.linear_LS_triangulation(us, P)
+    good = assert_excluded_explained(c_oracle.linear_LS_triangulation, us, P, xo, None, f_ls.cpu().numpy()[idx], None, max_frac=0.005)
+    assert good.mean() > 0.995 and np.max(rel_err(f_ls.cpu().numpy()[idx][good], xo[good])) < TOL
+    assert np.median(rel_err(f_ls.cpu().numpy(), x_ls_h)) < 1e-13
     # (b) + (c)
     h = N // 2 + 37
     xa, sa = dev.iterative_LS_triangulation(ud[:, :h].clone(), Pd)
