@@ -229,6 +229,14 @@ int mqs_ba_backsub_dev(const double *poses, const double *calib, const double *s
                        const double *points, const double *obs, const uint8_t *mask,
                        const double *prior_w, const double *prior_xyz, int64_t N, double lambda,
                        const double *dpose, double *points_out, void *stream);
+/* The tail of an iteration in ONE launch (C <= 4; two launches beyond): reduced solve + pose retraction (as mqs_ba_solve_dev)
+ * and the landmark back-substitution with the dpose it has just produced (as mqs_ba_backsub_dev), bit-identical to the two
+ * calls.  Every workgroup solves the 6C x 6C system itself, so no launch boundary separates the solve from its consumers. */
+int mqs_ba_solve_backsub_dev(const double *lin, int C, const double *poses, const double *calib, const double *sigma,
+                             const double *points, const double *obs, const uint8_t *mask, const double *prior_w,
+                             const double *prior_xyz, int64_t N, double lambda, const double *prior_poses,
+                             const double *prior_sigmas, const uint8_t *prior_mask, double *dpose, double *poses_out,
+                             double *info, double *points_out, void *stream);
 
 /* cost only: out[2] = { 0.5*sum|r/sigma|^2 (+ point priors), valid-factor count }.
  * workspace: at least 64 KiB. */
@@ -249,8 +257,26 @@ int mqs_comm_unique_id(uint8_t *id128);
 int mqs_comm_init_rank(mqs_ctx *ctx, const uint8_t *id128, int rank, int world);
 int mqs_comm_world_size(const mqs_ctx *ctx);
 int mqs_comm_destroy(mqs_ctx *ctx);
-/* in-place sum over the ranks of buf[n] (device pointer), asynchronous on `stream` */
+/* in-place sum over the ranks of buf[n] (device pointer), asynchronous on `stream`.  With a peer transport (below) and
+ * n <= 2560 the sum is the peers' rows added in rank order by one small kernel; otherwise ncclAllReduce. */
 int mqs_comm_all_reduce_sum_f64_dev(mqs_ctx *ctx, double *buf, int64_t n, void *stream);
+
+/* Peer transport: the same collective as plain stores over xGMI into receive buffers the ranks map from each other
+ * (hipIpc), for a message this small (4.8 KB) a launch-free alternative to RCCL: inside mqs_ba_gn_iteration_dev the
+ * lineariser's finalize kernel stores the rank's row into every peer and the fused solve/back-substitution kernel waits for
+ * the rows and adds them in rank order (bit-identical on every rank).  Set-up mirrors the unique id: every rank calls
+ * mqs_comm_peer_export (allocates its receive buffer, returns an opaque MQS_PEER_HANDLE_BYTES blob), the host program
+ * gathers the blobs of all ranks in rank order, every rank calls mqs_comm_peer_open.  Independent of the RCCL communicator:
+ * a context may hold either or both (RCCL then serves buffers that do not fit a row).
+ * mqs_comm_peer_state: 0 none, 1 open (a peer shares this GPU: consumers wait in a kernel of their own), 2 open (fused wait).
+ * mqs_comm_peer_timed_out: *timed_out = 1 when a consumer gave up waiting for a row (2 s); synchronises `stream`. */
+#define MQS_PEER_MAX_WORLD 8
+#define MQS_PEER_HANDLE_BYTES 128
+int mqs_comm_peer_export(mqs_ctx *ctx, int rank, int world, uint8_t *handle);
+int mqs_comm_peer_open(mqs_ctx *ctx, const uint8_t *handles);
+int mqs_comm_peer_close(mqs_ctx *ctx);
+int mqs_comm_peer_state(const mqs_ctx *ctx);
+int mqs_comm_peer_timed_out(mqs_ctx *ctx, void *stream, int *timed_out);
 
 /* ---------------------------------------------------------------------------------------
  * One optimiser iteration behind one call (the loop body of LevenbergMarquardtOptimizer::optimize,

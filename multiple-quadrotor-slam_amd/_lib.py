@@ -27,6 +27,8 @@ c_i64 = ctypes.c_int64
 c_vp = ctypes.c_void_p
 
 MQS_OK = 0
+MQS_PEER_MAX_WORLD = 8          # include/mqslam.h
+MQS_PEER_HANDLE_BYTES = 128
 
 # name -> (restype, argtypes); must list every symbol include/mqslam.h declares
 # (tests/test_abi.py parses the header and checks this table and the .so against it).
@@ -72,6 +74,7 @@ SIGNATURES = {
                                         c_vp, c_vp]),
     "mqs_ba_backsub_dev": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64,
                                           ctypes.c_double, c_vp, c_vp, c_vp]),
+    "mqs_ba_solve_backsub_dev": (ctypes.c_int, [c_vp, ctypes.c_int] + [c_vp] * 8 + [c_i64, ctypes.c_double] + [c_vp] * 8),
     "mqs_ba_cost_dev": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp,
                                        c_vp, c_i64, c_vp]),
     "mqs_ba_linearize": (ctypes.c_int, [c_vp, c_f64p, c_f64p, c_f64p, ctypes.c_int, c_f64p, c_f64p, c_u8p, c_f64p,
@@ -86,6 +89,11 @@ SIGNATURES = {
     "mqs_comm_world_size": (ctypes.c_int, [c_vp]),
     "mqs_comm_destroy": (ctypes.c_int, [c_vp]),
     "mqs_comm_all_reduce_sum_f64_dev": (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp]),
+    "mqs_comm_peer_export": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_int, c_u8p]),
+    "mqs_comm_peer_open": (ctypes.c_int, [c_vp, c_u8p]),
+    "mqs_comm_peer_close": (ctypes.c_int, [c_vp]),
+    "mqs_comm_peer_state": (ctypes.c_int, [c_vp]),
+    "mqs_comm_peer_timed_out": (ctypes.c_int, [c_vp, c_vp, ctypes.POINTER(ctypes.c_int)]),
     "mqs_ba_problem_create": (ctypes.c_int, [c_vp, ctypes.c_int, c_i64] + [c_vp] * 17 + [c_i64, ctypes.POINTER(c_vp)]),
     "mqs_ba_problem_destroy": (None, [c_vp]),
     "mqs_ba_problem_current": (ctypes.c_int, [c_vp]),

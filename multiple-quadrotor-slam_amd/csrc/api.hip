@@ -96,6 +96,7 @@ int mqs_create(int device_id, mqs_ctx **out)
     ctx->hbuf = nullptr;
     ctx->hbuf_bytes = 0;
     ctx->comm = nullptr;
+    ctx->peer = nullptr;
     ctx->comm_rank = 0;
     ctx->comm_world = 1;
     hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);

@@ -27,6 +27,7 @@
 #include "mqs_common.h"
 #include "ba_math.h"
 #include "wave_reduce.h"
+#include "peer_dev.h"
 #include <stdlib.h>
 
 namespace {
@@ -689,7 +690,7 @@ constexpr int kFinThreads = 1024;
 
 template <int C>
 __global__ __launch_bounds__(kFinThreads) void ba_finalize_kernel(const double *__restrict__ partials, int nblocks,
-                                                                  double *__restrict__ out)
+                                                                  double *__restrict__ out, mqs_peer_push push)
 {
     using L = Layout<C>;
     constexpr int NCH = L::kChunks;
@@ -719,7 +720,14 @@ __global__ __launch_bounds__(kFinThreads) void ba_finalize_kernel(const double *
         slot_to_out<C>(s, o1, o2);
         if (o1 >= 0) out[o1] = r;
         if (o2 >= 0) out[o2] = r;
+        // peer transport (comm.hip): the same entries into slot [rank] of every rank's receive buffer -- this IS the send side
+        // of the iteration's all-reduce
+        for (int q = 0; q < push.world; ++q) {
+            if (o1 >= 0) push.dst[q][o1] = r;
+            if (o2 >= 0) push.dst[q][o2] = r;
+        }
     }
+    if (wave == 0 && push.world > 0) mqs::peer::publish_piece(push, blockIdx.x, lane);
 }
 
 #ifndef MQS_BA_BACKSUB_DIRECT
@@ -996,6 +1004,221 @@ __global__ __launch_bounds__(64) void ba_solve_kernel(const double *__restrict__
     if (info && lane == 0) { info[0] = sInfo[0]; info[1] = bad ? 1.0 : 0.0; }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Reduced camera system for C <= 4 cameras (n = 6C <= 24): ONE wavefront, the whole solve inside the factorisation loop.
+//
+// The kernel above walks three dependent chains (24 pivots, 24 forward steps, 24 backward steps through LDS columns) and is
+// a launch of its own: 10-12 us of an iteration whose other kernels take 30 us at 125 k landmarks.  Here
+//   * lanes 0..n-1 hold the rows of S (they become the rows of L), lanes 32..32+n-1 the unit vectors e_c and lane 56 the
+//     right-hand side: the forward substitution  v_k <- v_k / L_kk,  v_j <- v_j - v_k L_jk  IS the trailing update
+//     row_j <- row_j - L_ik L_jk  with v_k in the place of L_ik, so every lane runs the same instruction stream and the loop
+//     ends with L^-1 (one column per lane 32 + c) and y = L^-1 b (lane 56) in registers; x = L^-T y is then one dot
+//     product per lane -- no substitution chain at all;
+//   * the pivot chain does not go through LDS: step k needs column k of L broadcast to every lane, but the NEXT pivot and the
+//     next column only need L[k+1][k], which comes back through a v_readlane pair; the other entries of the column take the
+//     LDS round trip (double-buffered) behind the reciprocal square root of the next pivot.
+// The function is executed by one full wavefront; every array argument is LDS.  Used by the stand-alone solve kernel and by
+// the fused tail of an iteration below (same arithmetic, same bits).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kSolveInvLane0 = 32, kSolveRhsLane = 56;
+
+// pose priors of the cameras (bundle_adjust.cpp:273): lanes c < C; e = (Log(R0^T R), R0^T (t - t0)) / sigma, J ~ I
+template <int C>
+__device__ __forceinline__ void pose_prior_terms(const double *__restrict__ poses, const double *__restrict__ prior_poses,
+                                                 const double *__restrict__ prior_sigmas, const uint8_t *__restrict__ prior_mask,
+                                                 int lane, double *sE, double *sW, double *sInfo)
+{
+    constexpr int n = 6 * C;
+    if (lane < n) { sE[lane] = 0.0; sW[lane] = 0.0; }
+    if (lane == 0) { sInfo[0] = 0.0; sInfo[1] = 0.0; }
+    mqs_wave_lds_sync();
+    if (prior_mask && lane < C && prior_mask[lane]) {
+        const double *T0 = prior_poses + 12 * lane, *T = poses + 12 * lane, *sg = prior_sigmas + 6 * lane;
+        double Rr[9], w[3], e[6];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) Rr[3 * i + j] = T0[i] * T[j] + T0[3 + i] * T[3 + j] + T0[6 + i] * T[6 + j];
+        so3_log_dev(Rr, w);
+        const double dt[3] = {T[9] - T0[9], T[10] - T0[10], T[11] - T0[11]};
+        for (int i = 0; i < 3; ++i) {
+            e[i] = w[i];
+            e[3 + i] = T0[i] * dt[0] + T0[3 + i] * dt[1] + T0[6 + i] * dt[2];
+        }
+        double cst = 0.0;
+        for (int i = 0; i < 6; ++i) {
+            const double wi = 1.0 / (sg[i] * sg[i]);
+            sW[6 * lane + i] = wi;
+            sE[6 * lane + i] = wi * e[i];
+            cst += 0.5 * wi * e[i] * e[i];
+        }
+        atomicAdd(&sInfo[0], cst);
+    }
+    mqs_wave_lds_sync();
+}
+
+template <int C>
+__device__ __forceinline__ void reduced_solve_wave(const double *sLin, const double *sE, const double *sW, double lambda,
+                                                   double *sCol /*[2][64]*/, double *sY /*[n]*/, double *sX /*[n]*/, int lane,
+                                                   bool &bad)
+{
+    constexpr int n = 6 * C;
+    static_assert(n <= 24, "rows, inverse columns and the right-hand side share one wavefront");
+    const bool isL = lane < n, isI = lane >= kSolveInvLane0 && lane < kSolveInvLane0 + n, isB = lane == kSolveRhsLane;
+    const int r = isL ? lane : 0, ci = lane - kSolveInvLane0;
+    double row[n];
+#pragma unroll
+    for (int j = 0; j < n; ++j) {
+        const double a = sLin[r * n + j], b = sLin[n * n + j] - sE[j];
+        double v = isL ? a : (isB ? b : ((isI && j == ci) ? 1.0 : 0.0));
+        if (isL && j == r) v = (lambda >= 0.0) ? (v + sW[r]) * (1.0 + lambda) : (v + sW[r]) - lambda;   // prior weight, then damping
+        row[j] = v;
+    }
+    bad = false;
+    double akk = read_lane(row[0], 0);
+#pragma unroll
+    for (int k = 0; k < n; ++k) {
+        bad = bad || !(akk > 0.0);
+        const double inv = mqs::rsqrt_d(akk > 0.0 ? akk : 1.0);
+        const double lik = row[k] * inv;             // rows: L[lane][k] (lanes >= k);  inverse / rhs lanes: v_k
+        row[k] = lik;
+        if (k + 1 < n) {
+            double *col = sCol + 64 * (k & 1);
+            col[lane] = lik;
+            // the entry the next pivot and the next column wait for, without the LDS round trip
+            const double lnext = read_lane(lik, k + 1);
+            row[k + 1] = fma(-lik, lnext, row[k + 1]);
+            akk = read_lane(row[k + 1], k + 1);
+            mqs_wave_lds_sync();
+#pragma unroll
+            for (int j = k + 2; j < n; ++j) row[j] = fma(-lik, col[j], row[j]);   // only entries j <= lane matter for the rows of L
+        }
+    }
+    // lane 56 holds y = L^-1 b, lane 32 + c column c of L^-1:  x_c = sum_j (L^-1)[j][c] y_j
+    if (isB) {
+#pragma unroll
+        for (int j = 0; j < n; ++j) sY[j] = row[j];
+    }
+    mqs_wave_lds_sync();
+    double x = 0.0;
+#pragma unroll
+    for (int j = 0; j < n; ++j) x = fma(row[j], sY[j], x);
+    if (isI) sX[ci] = x;
+    mqs_wave_lds_sync();
+}
+
+// retraction R <- R Exp(w), t <- t + R v of camera `c` (one lane per camera)
+__device__ __forceinline__ void retract_pose_dev(const double *__restrict__ T, const double *d6, double *__restrict__ O)
+{
+    double E[9], w[3] = {d6[0], d6[1], d6[2]};
+    so3_exp_dev(w, E);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) O[3 * i + j] = T[3 * i] * E[j] + T[3 * i + 1] * E[3 + j] + T[3 * i + 2] * E[6 + j];
+    for (int i = 0; i < 3; ++i) O[9 + i] = T[9 + i] + T[3 * i] * d6[3] + T[3 * i + 1] * d6[4] + T[3 * i + 2] * d6[5];
+}
+
+template <int C>
+struct SolveLds {
+    static constexpr int n = 6 * C;
+    double lin[n * n + n + 2];
+    double e[n], w[n], y[n], x[n];
+    __attribute__((aligned(16))) double col[128];
+    double info[2];
+};
+
+// what wave 0 of a workgroup does with the reduced system in sm.lin: priors, solve, and (when `publish`) dpose, the retracted
+// poses and info to global memory
+template <int C>
+__device__ __forceinline__ void solve_and_publish(SolveLds<C> &sm, const double *__restrict__ poses,
+                                                  const double *__restrict__ prior_poses, const double *__restrict__ prior_sigmas,
+                                                  const uint8_t *__restrict__ prior_mask, double lambda, int lane, bool publish,
+                                                  double *__restrict__ dpose, double *__restrict__ poses_out,
+                                                  double *__restrict__ info)
+{
+    constexpr int n = 6 * C;
+    pose_prior_terms<C>(poses, prior_poses, prior_sigmas, prior_mask, lane, sm.e, sm.w, sm.info);
+    bool bad;
+    reduced_solve_wave<C>(sm.lin, sm.e, sm.w, lambda, sm.col, sm.y, sm.x, lane, bad);
+    if (publish) {
+        if (lane < n) dpose[lane] = sm.x[lane];
+        if (poses_out && lane < C) retract_pose_dev(poses + 12 * lane, sm.x + 6 * lane, poses_out + 12 * lane);
+        if (info && lane == 0) { info[0] = sm.info[0]; info[1] = bad ? 1.0 : 0.0; }
+    }
+}
+
+template <int C>
+__global__ __launch_bounds__(64) void ba_solve_small_kernel(const double *__restrict__ lin, const double *__restrict__ poses,
+                                                            const double *__restrict__ prior_poses,
+                                                            const double *__restrict__ prior_sigmas,
+                                                            const uint8_t *__restrict__ prior_mask, double lambda,
+                                                            double *__restrict__ dpose, double *__restrict__ poses_out,
+                                                            double *__restrict__ info)
+{
+    constexpr int n = 6 * C;
+    __shared__ SolveLds<C> sm;
+    const int lane = threadIdx.x;
+    for (int k = lane; k < n * n + n + 2; k += 64) sm.lin[k] = lin[k];
+    mqs_wave_lds_sync();
+    solve_and_publish<C>(sm, poses, prior_poses, prior_sigmas, prior_mask, lambda, lane, true, dpose, poses_out, info);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The tail of an iteration in ONE launch: reduced solve + pose retraction + landmark back-substitution.
+// Every workgroup solves the 24 x 24 system itself (wave 0, ~2 us, from the reduced system every workgroup reads anyway)
+// while its other waves have the camera blocks staged, then back-substitutes its contiguous range of landmarks; workgroup 0
+// also publishes dpose, the retracted poses and info.  A persistent grid (<= 4 workgroups per CU) so that the solve is paid
+// once per resident workgroup, ranges cut in rows of 64 landmarks so that the workgroups finish together.
+// With a peer communicator (comm.hip) `lin` is this rank's receive buffer: `world` rows written by the ranks' finalize
+// kernels over xGMI; the workgroup waits for the rows' flags and sums them in rank order -- the all-reduce of the iteration
+// without a launch of its own.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(kBlock, 4) void ba_tail_kernel(
+    const double *__restrict__ lin, mqs_peer_recv pr, const double *__restrict__ poses, const double *__restrict__ calib,
+    const double *__restrict__ sigma, const double *__restrict__ points, const double *__restrict__ obs,
+    const uint8_t *__restrict__ mask, const double *__restrict__ prior_w, const double *__restrict__ prior_xyz, int64_t N,
+    double lambda, const double *__restrict__ prior_poses, const double *__restrict__ prior_sigmas,
+    const uint8_t *__restrict__ prior_mask, double *__restrict__ lin_out, double *__restrict__ dpose,
+    double *__restrict__ poses_out, double *__restrict__ info, double *__restrict__ points_out)
+{
+    constexpr int n = 6 * C, nlin = n * n + n + 2;
+    __shared__ double sCam[C * kCamStride];
+    __shared__ SolveLds<C> sm;
+    const int tid = threadIdx.x;
+    if (pr.rows) {
+        mqs::peer::wait_and_sum(sm.lin, nlin, pr, tid, kBlock);
+        if (blockIdx.x == 0 && lin_out) {
+            __syncthreads();
+            for (int k = tid; k < nlin; k += kBlock) lin_out[k] = sm.lin[k];
+        }
+    } else {
+        for (int k = tid; k < nlin; k += kBlock) sm.lin[k] = lin[k];
+    }
+    stage_cams<C>(poses, calib, sigma, sCam, tid);                  // ends in a workgroup barrier
+    if (tid < 64)
+        solve_and_publish<C>(sm, poses, prior_poses, prior_sigmas, prior_mask, lambda, tid, blockIdx.x == 0, dpose, poses_out, info);
+    __syncthreads();
+
+    const int64_t rows64 = (N + 63) / 64;
+    const int64_t r_begin = rows64 * blockIdx.x / gridDim.x, r_end = rows64 * (blockIdx.x + 1) / gridDim.x;
+    int64_t end = r_end * 64;
+    if (end > N) end = N;
+    for (int64_t base = r_begin * 64; base < end; base += kBlock) {
+        const int64_t i = base + tid;
+        const bool live = i < end;
+        const int64_t ii = live ? i : 0;
+        double px = points[3 * ii + 0], py = points[3 * ii + 1], pz = points[3 * ii + 2];
+        if (!live) { px = 0.0; py = 0.0; pz = 0.0; }
+        const DevObs ob = {reinterpret_cast<const double2 *>(obs), mask, i, N, live};
+        double pw, dx, dy, dz;
+        load_prior(prior_w, prior_xyz, i, live, px, py, pz, pw, dx, dy, dz);
+        const mqs::Vec3 dp = landmark_backsub<C>(sCam, ob, px, py, pz, pw, dx, dy, dz, lambda, sm.x);
+        if (live) {
+            points_out[3 * i + 0] = px + dp.x;
+            points_out[3 * i + 1] = py + dp.y;
+            points_out[3 * i + 2] = pz + dp.z;
+        }
+    }
+}
+
 // Grid: persistent workgroups, 2 per CU at <= 256 VGPRs (each keeps its partial sums in registers).
 int ba_grid(int64_t N)
 {
@@ -1029,6 +1252,17 @@ bool wave_lineariser_enabled()
     return v == 1;
 }
 
+// A/B switch for measurements: MQS_BA_TAIL=split issues solve and back-substitution as two launches for every C
+bool tail_fusion_enabled()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("MQS_BA_TAIL");
+        v = (e && strcmp(e, "split") == 0) ? 0 : 1;
+    }
+    return v == 1;
+}
+
 int check_common(const double *poses, const double *calib, const double *sigma, int C, const double *points,
                  const double *obs, int64_t N)
 {
@@ -1055,7 +1289,7 @@ int64_t mqs_ba_workspace_bytes(int C, int64_t N)
 static int ba_linearize_parts(const double *poses, const double *calib, const double *sigma, int C, const double *points,
                               const double *obs, const uint8_t *mask, const double *prior_w, const double *prior_xyz,
                               int64_t N, double lambda, double *out, void *workspace, int64_t workspace_bytes, void *stream_,
-                              int parts);
+                              int parts, const mqs_peer_push *push = nullptr);
 
 int mqs_ba_linearize_dev(const double *poses, const double *calib, const double *sigma, int C, const double *points,
                          const double *obs, const uint8_t *mask, const double *prior_w, const double *prior_xyz,
@@ -1068,10 +1302,12 @@ int mqs_ba_linearize_dev(const double *poses, const double *calib, const double 
 static int ba_linearize_parts(const double *poses, const double *calib, const double *sigma, int C, const double *points,
                               const double *obs, const uint8_t *mask, const double *prior_w, const double *prior_xyz,
                               int64_t N, double lambda, double *out, void *workspace, int64_t workspace_bytes, void *stream_,
-                              int parts)
+                              int parts, const mqs_peer_push *push)
 {
     int rc = check_common(poses, calib, sigma, C, points, obs, N);
     if (rc != MQS_OK) return rc;
+    mqs_peer_push pp = {};
+    if (push) pp = *push;
     MQS_ARG_CHECK(out != nullptr && workspace != nullptr, "out and workspace must not be null");
     MQS_ARG_CHECK(workspace_bytes >= mqs_ba_workspace_bytes(C, N), "workspace too small (mqs_ba_workspace_bytes)");
     MQS_ARG_CHECK(!prior_w || prior_xyz, "prior_xyz required with prior_w");
@@ -1093,7 +1329,7 @@ static int ba_linearize_parts(const double *poses, const double *calib, const do
             hipLaunchKernelGGL((ba_linearize_wave_kernel<c>), dim3(grid), dim3(kBlock), lds, stream, poses, calib, sigma, \
                                points, obs, mask, prior_w, prior_xyz, N, lambda, partials);                \
         if (parts & 2)                                                                                     \
-            hipLaunchKernelGGL((ba_finalize_kernel<c>), dim3((Layout<c>::kChunks * 32 + 63) / 64), dim3(kFinThreads), 0, stream, partials, grid, out);   \
+            hipLaunchKernelGGL((ba_finalize_kernel<c>), dim3((Layout<c>::kChunks * 32 + 63) / 64), dim3(kFinThreads), 0, stream, partials, grid, out, pp);   \
         break;                                                                                             \
     }
             MQS_CASE(2) MQS_CASE(3) MQS_CASE(4)
@@ -1110,7 +1346,7 @@ static int ba_linearize_parts(const double *poses, const double *calib, const do
             hipLaunchKernelGGL((ba_linearize_kernel<c>), dim3(grid), dim3(kBlock), 0, stream, poses, calib, sigma, \
                                points, obs, mask, prior_w, prior_xyz, N, lambda, partials);                \
         if (parts & 2)                                                                                     \
-            hipLaunchKernelGGL((ba_finalize_kernel<c>), dim3((Layout<c>::kChunks * 32 + 63) / 64), dim3(kFinThreads), 0, stream, partials, grid, out);   \
+            hipLaunchKernelGGL((ba_finalize_kernel<c>), dim3((Layout<c>::kChunks * 32 + 63) / 64), dim3(kFinThreads), 0, stream, partials, grid, out, pp);   \
         break;
         MQS_CASE(1) MQS_CASE(2) MQS_CASE(3) MQS_CASE(4) MQS_CASE(5) MQS_CASE(6) MQS_CASE(7) MQS_CASE(8)
 #undef MQS_CASE
@@ -1118,6 +1354,29 @@ static int ba_linearize_parts(const double *poses, const double *calib, const do
     MQS_HIP_CHECK(hipGetLastError());
     return MQS_OK;
 }
+
+}  // extern "C"
+
+int mqs_ba_linearize_push(const double *poses, const double *calib, const double *sigma, int C, const double *points,
+                          const double *obs, const uint8_t *mask, const double *prior_w, const double *prior_xyz, int64_t N,
+                          double lambda, double *out, void *workspace, int64_t workspace_bytes, hipStream_t stream,
+                          const mqs_peer_push *push)
+{
+    return ba_linearize_parts(poses, calib, sigma, C, points, obs, mask, prior_w, prior_xyz, N, lambda, out, workspace,
+                              workspace_bytes, stream, 3, push);
+}
+
+int mqs_ba_finalize_groups(int C)
+{
+    switch (C) {
+#define MQS_CASE(c) case c: return (Layout<c>::kChunks * 32 + 63) / 64;
+        MQS_CASE(1) MQS_CASE(2) MQS_CASE(3) MQS_CASE(4) MQS_CASE(5) MQS_CASE(6) MQS_CASE(7) MQS_CASE(8)
+#undef MQS_CASE
+    }
+    return 0;
+}
+
+extern "C" {
 
 int mqs_ba_backsub_dev(const double *poses, const double *calib, const double *sigma, int C, const double *points,
                        const double *obs, const uint8_t *mask, const double *prior_w, const double *prior_xyz,
@@ -1182,24 +1441,89 @@ int mqs_ba_solve_dev(const double *lin, int C, const double *poses, const double
     switch (C) {
 #define MQS_CASE(c)                                                                                     \
     case c:                                                                                             \
+        hipLaunchKernelGGL((ba_solve_small_kernel<c>), dim3(1), dim3(64), 0, stream, lin, poses, prior_poses, \
+                           prior_sigmas, prior_mask, lambda, dpose, poses_out, info);                   \
+        break;
+        MQS_CASE(1) MQS_CASE(2) MQS_CASE(3) MQS_CASE(4)
+#undef MQS_CASE
+#define MQS_CASE(c)                                                                                     \
+    case c:                                                                                             \
         hipLaunchKernelGGL((ba_solve_kernel<c>), dim3(1), dim3(64), 0, stream, lin, poses, prior_poses, \
                            prior_sigmas, prior_mask, lambda, dpose, poses_out, info);                   \
         break;
-        MQS_CASE(1) MQS_CASE(2) MQS_CASE(3) MQS_CASE(4) MQS_CASE(5) MQS_CASE(6) MQS_CASE(7) MQS_CASE(8)
+        MQS_CASE(5) MQS_CASE(6) MQS_CASE(7) MQS_CASE(8)
 #undef MQS_CASE
     }
     MQS_HIP_CHECK(hipGetLastError());
     return MQS_OK;
 }
 
+}  // extern "C"
+
+// The fused tail; `peer` (comm.hip) non-null: the reduced system is the sum of the peers' rows in this rank's receive buffer.
+int mqs_ba_tail_launch(const double *lin, const mqs_peer_recv *peer, int C, const double *poses, const double *calib,
+                       const double *sigma, const double *points, const double *obs, const uint8_t *mask, const double *prior_w,
+                       const double *prior_xyz, int64_t N, double lambda, const double *prior_poses, const double *prior_sigmas,
+                       const uint8_t *prior_mask, double *lin_out, double *dpose, double *poses_out, double *info,
+                       double *points_out, hipStream_t stream)
+{
+    mqs_peer_recv pr = {};
+    if (peer) pr = *peer;
+    // persistent grid: at most 4 workgroups per CU (each solves the reduced system once), one batch of 256 landmarks per
+    // workgroup below that
+    const int64_t rows64 = (N + 63) / 64;
+    int64_t g = (rows64 + 3) / 4;
+    if (g < 1) g = 1;
+    if (g > 1024) g = 1024;
+    switch (C) {
+#define MQS_CASE(c)                                                                                                      \
+    case c:                                                                                                              \
+        hipLaunchKernelGGL((ba_tail_kernel<c>), dim3((unsigned)g), dim3(kBlock), 0, stream, lin, pr, poses, calib, sigma, points, obs, \
+                           mask, prior_w, prior_xyz, N, lambda, prior_poses, prior_sigmas, prior_mask, lin_out, dpose, poses_out, \
+                           info, points_out);                                                                            \
+        break;
+        MQS_CASE(1) MQS_CASE(2) MQS_CASE(3) MQS_CASE(4)
+#undef MQS_CASE
+    default:
+        mqs_set_error("the fused tail serves 1..4 cameras");
+        return MQS_E_ARG;
+    }
+    MQS_HIP_CHECK(hipGetLastError());
+    return MQS_OK;
+}
+
+extern "C" {
+
+int mqs_ba_solve_backsub_dev(const double *lin, int C, const double *poses, const double *calib, const double *sigma,
+                             const double *points, const double *obs, const uint8_t *mask, const double *prior_w,
+                             const double *prior_xyz, int64_t N, double lambda, const double *prior_poses,
+                             const double *prior_sigmas, const uint8_t *prior_mask, double *dpose, double *poses_out,
+                             double *info, double *points_out, void *stream_)
+{
+    int rc = check_common(poses, calib, sigma, C, points, obs, N);
+    if (rc != MQS_OK) return rc;
+    MQS_ARG_CHECK(lin && dpose && (N == 0 || points_out), "lin, dpose, points_out must not be null");
+    MQS_ARG_CHECK(mqs_aligned16(points_out), "points_out must be 16-byte aligned");
+    MQS_ARG_CHECK(!prior_w || prior_xyz, "prior_xyz required with prior_w");
+    MQS_ARG_CHECK(!prior_mask || (prior_poses && prior_sigmas), "prior_poses/prior_sigmas required with prior_mask");
+    if (C <= 4 && tail_fusion_enabled())
+        return mqs_ba_tail_launch(lin, nullptr, C, poses, calib, sigma, points, obs, mask, prior_w, prior_xyz, N, lambda, prior_poses,
+                                  prior_sigmas, prior_mask, nullptr, dpose, poses_out, info, points_out,
+                                  static_cast<hipStream_t>(stream_));
+    rc = mqs_ba_solve_dev(lin, C, poses, prior_poses, prior_sigmas, prior_mask, lambda, dpose, poses_out, info, stream_);
+    if (rc != MQS_OK) return rc;
+    return mqs_ba_backsub_dev(poses, calib, sigma, C, points, obs, mask, prior_w, prior_xyz, N, lambda, dpose, points_out, stream_);
+}
+
 // Average duration (ms) of `reps` back-to-back launches of ONE kernel of the iteration, hipEvents on `stream`
-// (what: 0 lineariser kernel alone, 1 finalize alone, 2 solve + retract, 3 back-substitution).
+// (what: 0 lineariser kernel alone, 1 finalize alone, 2 solve + retract, 3 back-substitution, 4 solve + retract +
+// back-substitution as the iteration issues them: one launch for C <= 4).
 int mqs_ba_time_dev(int what, const double *poses, const double *calib, const double *sigma, int C, const double *points,
                     const double *obs, const uint8_t *mask, const double *prior_w, const double *prior_xyz, int64_t N,
                     double lambda, double *lin, double *dpose, double *poses_out, double *points_out, void *workspace,
                     int64_t workspace_bytes, int reps, void *stream_, float *avg_ms)
 {
-    MQS_ARG_CHECK(what >= 0 && what <= 3 && reps >= 1 && avg_ms != nullptr, "what in 0..3, reps >= 1, avg_ms must not be null");
+    MQS_ARG_CHECK(what >= 0 && what <= 4 && reps >= 1 && avg_ms != nullptr, "what in 0..4, reps >= 1, avg_ms must not be null");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     auto once = [&]() -> int {
         switch (what) {
@@ -1207,8 +1531,10 @@ int mqs_ba_time_dev(int what, const double *poses, const double *calib, const do
             return ba_linearize_parts(poses, calib, sigma, C, points, obs, mask, prior_w, prior_xyz, N, lambda, lin, workspace,
                                       workspace_bytes, stream_, what == 0 ? 1 : 2);
         case 2: return mqs_ba_solve_dev(lin, C, poses, nullptr, nullptr, nullptr, lambda, dpose, poses_out, nullptr, stream_);
-        default: return mqs_ba_backsub_dev(poses, calib, sigma, C, points, obs, mask, prior_w, prior_xyz, N, lambda, dpose,
-                                           points_out, stream_);
+        case 3: return mqs_ba_backsub_dev(poses, calib, sigma, C, points, obs, mask, prior_w, prior_xyz, N, lambda, dpose,
+                                          points_out, stream_);
+        default: return mqs_ba_solve_backsub_dev(lin, C, poses, calib, sigma, points, obs, mask, prior_w, prior_xyz, N, lambda, nullptr,
+                                                 nullptr, nullptr, dpose, poses_out, nullptr, points_out, stream_);
         }
     };
     int rc = once();                                  // warm-up (and the argument checks)

@@ -80,11 +80,10 @@ int mqs_ba_gn_finish_dev(mqs_ba_problem *p, double lambda, int accept, void *str
 {
     MQS_ARG_CHECK(p != nullptr, "problem must not be null");
     const int c = p->cur, o = 1 - c;
-    int rc = mqs_ba_solve_dev(p->lin, p->C, p->poses[c], p->prior_poses, p->prior_sigmas, p->prior_mask, lambda, p->dpose,
-                              p->poses[o], p->info, stream);
-    if (rc != MQS_OK) return rc;
-    rc = mqs_ba_backsub_dev(p->poses[c], p->calib, p->sigma, p->C, p->points[c], p->obs, p->mask, p->prior_w, p->prior_xyz,
-                            p->N, lambda, p->dpose, p->points[o], stream);
+    // solve + retract + back-substitute: one launch for C <= 4 (ba_tail_kernel), two beyond
+    int rc = mqs_ba_solve_backsub_dev(p->lin, p->C, p->poses[c], p->calib, p->sigma, p->points[c], p->obs, p->mask, p->prior_w,
+                                      p->prior_xyz, p->N, lambda, p->prior_poses, p->prior_sigmas, p->prior_mask, p->dpose,
+                                      p->poses[o], p->info, p->points[o], stream);
     if (rc != MQS_OK) return rc;
     if (accept) p->cur = o;
     return MQS_OK;
@@ -92,12 +91,37 @@ int mqs_ba_gn_finish_dev(mqs_ba_problem *p, double lambda, int accept, void *str
 
 int mqs_ba_gn_iteration_dev(mqs_ba_problem *p, double lambda, void *stream)
 {
+    MQS_ARG_CHECK(p != nullptr, "problem must not be null");
+    const int64_t nlin = (int64_t)36 * p->C * p->C + 6 * p->C + 2;
+    // Peer transport (comm.hip): no collective launch at all.  The finalize kernel of the lineariser stores this rank's
+    // reduced system into every rank's receive buffer; the fused tail waits for all rows and adds them in rank order before
+    // it solves.  (C <= 4: the fused tail; ranks that share a GPU -- tests -- wait in a one-workgroup kernel instead.)
+    mqs_peer_push push;
+    mqs_peer_recv recv;
+    int fused_wait = 0;
+    if (p->ctx && mqs_comm_peer_next(p->ctx, nlin, mqs_ba_finalize_groups(p->C), &push, &recv, &fused_wait)) {
+        int rc = mqs_ba_linearize_push(p->poses[p->cur], p->calib, p->sigma, p->C, p->points[p->cur], p->obs, p->mask, p->prior_w,
+                                       p->prior_xyz, p->N, lambda, p->lin, p->ws, p->ws_bytes, static_cast<hipStream_t>(stream), &push);
+        if (rc != MQS_OK) return rc;
+        const int c = p->cur, o = 1 - c;
+        if (fused_wait && p->C <= 4) {
+            rc = mqs_ba_tail_launch(nullptr, &recv, p->C, p->poses[c], p->calib, p->sigma, p->points[c], p->obs, p->mask, p->prior_w,
+                                    p->prior_xyz, p->N, lambda, p->prior_poses, p->prior_sigmas, p->prior_mask, p->lin, p->dpose,
+                                    p->poses[o], p->info, p->points[o], static_cast<hipStream_t>(stream));
+            if (rc != MQS_OK) return rc;
+            p->cur = o;
+            return MQS_OK;
+        }
+        rc = mqs_comm_peer_gather(&recv, p->lin, nlin, static_cast<hipStream_t>(stream));
+        if (rc != MQS_OK) return rc;
+        return mqs_ba_gn_finish_dev(p, lambda, 1, stream);
+    }
     int rc = mqs_ba_gn_begin_dev(p, lambda, stream);
     if (rc != MQS_OK) return rc;
     // issued whenever the context holds a communicator -- also a one-rank one, where the sum is the identity: the single-GPU
     // tests then run the very call sequence an N-GPU iteration runs (lineariser, ncclAllReduce on the same stream, solve)
     if (p->ctx && mqs_comm_world_size(p->ctx) >= 1) {
-        rc = mqs_comm_all_reduce_sum_f64_dev(p->ctx, p->lin, (int64_t)36 * p->C * p->C + 6 * p->C + 2, stream);
+        rc = mqs_comm_all_reduce_sum_f64_dev(p->ctx, p->lin, nlin, stream);
         if (rc != MQS_OK) return rc;
     }
     return mqs_ba_gn_finish_dev(p, lambda, 1, stream);

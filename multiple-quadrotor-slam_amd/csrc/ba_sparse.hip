@@ -440,9 +440,10 @@ __global__ void sparse_damp_kernel(double *__restrict__ S, int n6, double lambda
 }
 
 // The solve's input contract is the usual one of a Cholesky routine: the LOWER triangle (with the diagonal).  The factor
-// kernels read their panel input from the mirror image in the upper triangle (chol_step_kernel, nd_step_kernel), so the
+// kernels read their panel input from the mirror image in the upper triangle (chol_step_kernel), so the natural-order
 // solve first copies lower -> upper inside the band: 32 x 32 tiles through LDS, one workgroup per tile, grid = block rows x
 // (band tiles + 1).  A caller that hands over both triangles (the linearisers here do) gets the same bits as before.
+// (The chunked solve has its own pass over the tiles of its plan: nd_mirror_kernel, chol_nd.hip.)
 __global__ __launch_bounds__(256) void sparse_mirror_lower_kernel(double *__restrict__ S, int n6)
 {
     __shared__ double sT[32][33];
@@ -1219,10 +1220,6 @@ int mqs_sba_solve_banded_dev(double *S, double *x, int64_t P, int64_t half_bandw
     const int n = (int)(6 * P);
     const int hb = half_bandwidth < n ? (int)half_bandwidth : n;
     MQS_HIP_CHECK(hipMemsetAsync(bad, 0, sizeof(int), stream));
-    if (n > 1 && hb > 0) {
-        const int brows = (n + 31) / 32, boffs = (hb + 31) / 32 + 1;
-        hipLaunchKernelGGL(sparse_mirror_lower_kernel, dim3(brows, boffs < brows ? boffs : brows), dim3(256), 0, stream, S, n);
-    }
     if (lambda != 0.0) hipLaunchKernelGGL(sparse_damp_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, S, n, lambda);
     const bool banded = 3 * (int64_t)hb < n;            // the band is worth exploiting
     bool nd_done = false;
@@ -1231,6 +1228,10 @@ int mqs_sba_solve_banded_dev(double *S, double *x, int64_t P, int64_t half_bandw
         // the band cut into independent chunks (chol_nd.hip): ~40 dependent launches instead of one per block column
         if (rc_nd != MQS_OK) return rc_nd;
     } else {
+        if (n > 1 && hb > 0) {                      // input contract: the lower triangle (see sparse_mirror_lower_kernel)
+            const int brows = (n + 31) / 32, boffs = (hb + 31) / 32 + 1;
+            hipLaunchKernelGGL(sparse_mirror_lower_kernel, dim3(brows, boffs < brows ? boffs : brows), dim3(256), 0, stream, S, n);
+        }
         // right-looking blocked Cholesky; rows further than hb below a block column are zero there and stay zero
         // (no fill outside the band), so the panel and the trailing update stop hb rows below it
         // one launch per block column: the first diagonal block, then panel + update + next diagonal block fused (see

@@ -54,6 +54,36 @@ struct LazyTile {                       // tile (x1, x2): contributions contrib[
 struct LazyVec { int32_t x, start, count, pad; };
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Input contract = the LOWER triangle of S (natural indexing).  The elimination order of the plan is not the natural one,
+// so the kernels below read and write tiles on both sides of the diagonal; every tile they ever touch is a (pivot block,
+// structure block) pair of some block column, so one pass over the descriptors makes both images of every such tile valid:
+// the one above the diagonal becomes the transpose of the one below (zero fill included), diagonal tiles are symmetrised.
+// Workgroup (d, 0): the diagonal tile of column d; (d, 1 + i): the tile of structure entry i.  One writer per tile.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void nd_mirror_kernel(double *__restrict__ A, int n, const StepDesc *__restrict__ descs)
+{
+    const StepDesc &d = descs[blockIdx.x];
+    if (d.kblk < 0) return;
+    const int y = blockIdx.y;
+    if (y > d.cnt) return;
+    const int other = (y == 0) ? d.kblk : d.blk[y - 1];
+    const int lo = other > d.kblk ? other : d.kblk, hi = other > d.kblk ? d.kblk : other;     // tile (lo, hi) is below the diagonal
+    __shared__ double sT[NB][NB + 1];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = lo * NB + ty + 8 * k, c = hi * NB + tx;
+        sT[ty + 8 * k][tx] = (r < n && c < n) ? A[(int64_t)r * n + c] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = hi * NB + ty + 8 * k, r = lo * NB + tx;          // element (c, r) above the diagonal = element (r, c) below it
+        if (r < n && c < n && r > c) A[(int64_t)c * n + r] = sT[tx][ty + 8 * k];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // factor step: panel + eager trailing update of one block column per front, and the front's next diagonal block
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kThreads) void nd_step_kernel(double *__restrict__ A, int n, const StepDesc *__restrict__ descs,
@@ -766,6 +796,7 @@ int mqs_chol_nd_solve(double *S, double *x, int n, int hb, int *bad, hipStream_t
     static mqs_lds_opt_in opt_f, opt_b;                 // per device
     MQS_HIP_CHECK(mqs_lds_opt_in_once(opt_f, reinterpret_cast<const void *>(nd_fwd_front_kernel), 150 * 1024));
     MQS_HIP_CHECK(mqs_lds_opt_in_once(opt_b, reinterpret_cast<const void *>(nd_bwd_front_kernel), 150 * 1024));
+    hipLaunchKernelGGL(nd_mirror_kernel, dim3((unsigned)plan->descs.size(), kMaxList + 1), dim3(kThreads), 0, stream, S, n, plan->d_descs);
     for (const StagePlan &sp : plan->stages) {
         if (sp.nslots > 0)
             hipLaunchKernelGGL(nd_lazy_part_kernel, dim3(sp.nslots), dim3(kThreads), 0, stream, S, n, plan->d_lazy + sp.lazy_off,

@@ -34,8 +34,38 @@ struct mqs_ctx {
     void *hbuf;        // pinned, GPU-visible host buffer for the small-call path (see mqs_stage)
     size_t hbuf_bytes;
     void *comm;        // RCCL communicator of this rank (comm.hip), or null: one process per GPU, one ctx per process
+    void *peer;        // peer transport of this rank (comm.hip: receive buffer + the peers' mapped buffers), or null
     int comm_rank, comm_world;
 };
+
+// comm.hip <-> ba.hip / ba_iter.hip: one reduction over the peer transport (see comm.hip).  push = where this rank's row goes
+// in every rank's receive buffer (slot [rank] of the current parity) and the flags behind it; recv = this rank's own buffer.
+struct mqs_peer_push {
+    double *dst[MQS_PEER_MAX_WORLD];
+    unsigned long long *flag[MQS_PEER_MAX_WORLD];
+    int world;
+    unsigned long long seq;
+};
+struct mqs_peer_recv {
+    const double *rows;                  // [world][row_stride]
+    const unsigned long long *flags;     // [world][flags_stride]; the first flags_per_rank of a rank are in use: >= seq when its piece landed
+    int world, row_stride, flags_per_rank, flags_stride;
+    unsigned long long seq;
+    int *timeout_flag;                   // device int, set when a row did not arrive within the spin bound
+};
+int mqs_comm_peer_next(mqs_ctx *ctx, int64_t n, int flags_used, mqs_peer_push *push, mqs_peer_recv *recv, int *fused_wait);
+int mqs_comm_peer_gather(const mqs_peer_recv *recv, double *out, int64_t n, hipStream_t stream);
+// ba.hip: the lineariser with its finalize kernel storing the rank's reduced system into the peers' buffers (push != null)
+int mqs_ba_linearize_push(const double *poses, const double *calib, const double *sigma, int C, const double *points,
+                          const double *obs, const uint8_t *mask, const double *prior_w, const double *prior_xyz, int64_t N,
+                          double lambda, double *out, void *workspace, int64_t workspace_bytes, hipStream_t stream,
+                          const mqs_peer_push *push);
+int mqs_ba_finalize_groups(int C);       // workgroups of the finalize kernel = flags a rank sets per reduction
+int mqs_ba_tail_launch(const double *lin, const mqs_peer_recv *peer, int C, const double *poses, const double *calib,
+                       const double *sigma, const double *points, const double *obs, const uint8_t *mask, const double *prior_w,
+                       const double *prior_xyz, int64_t N, double lambda, const double *prior_poses, const double *prior_sigmas,
+                       const uint8_t *prior_mask, double *lin_out, double *dpose, double *poses_out, double *info,
+                       double *points_out, hipStream_t stream);
 
 // comm.hip: releases ctx->comm (called by mqs_destroy)
 void mqs_comm_release(mqs_ctx *ctx);

@@ -79,12 +79,28 @@ def init_from_env(backend="nccl"):
 
 
 class CComm:
-    """The library-level transport: an RCCL communicator held by an `mqs_ctx` (csrc/comm.hip), so that the one collective
-    of the hot path -- the sum of the reduced camera system -- is issued from C between the kernels of an iteration
-    (`mqs_ba_gn_iteration_dev`) instead of from the interpreter.  One per process (one process per GPU)."""
+    """The library-level transport: an RCCL communicator and / or the peer transport (plain stores into receive buffers the
+    ranks map from each other) held by an `mqs_ctx` (csrc/comm.hip), so that the one collective of the hot path -- the sum of
+    the reduced camera system -- is issued from C between the kernels of an iteration (`mqs_ba_gn_iteration_dev`) or, over
+    the peer transport, INSIDE them, instead of from the interpreter.  One per process (one process per GPU)."""
 
-    def __init__(self, ctx, rank, world):
-        self.ctx, self.rank, self.world = ctx, rank, world
+    def __init__(self, ctx, rank, world, transport="rccl"):
+        self.ctx, self.rank, self.world, self.transport = ctx, rank, world, transport
+
+    def peer_state(self):
+        """0: no peer transport, 1: open with a stand-alone wait kernel (a peer shares this GPU), 2: open, fused wait."""
+        from . import _lib
+        return int(_lib.lib().mqs_comm_peer_state(self.ctx.handle))
+
+    def peer_timed_out(self):
+        """True when a consumer kernel gave up waiting for a peer's row (2 s): the results since are not sums."""
+        import ctypes
+        import torch
+        from . import _lib
+        flag = ctypes.c_int(0)
+        _lib.check(_lib.lib().mqs_comm_peer_timed_out(self.ctx.handle, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream),
+                                                      ctypes.byref(flag)))
+        return flag.value != 0
 
     def all_reduce_sum_(self, tensor):
         """In-place sum over the ranks of a float64 device tensor, asynchronous on the current stream."""
@@ -101,12 +117,73 @@ class CComm:
     def close(self):
         from . import _lib
         if self.ctx is not None:
-            _lib.check(_lib.lib().mqs_comm_destroy(self.ctx.handle))
+            _lib.check(_lib.lib().mqs_comm_destroy(self.ctx.handle))      # releases the peer transport too
             self.ctx.close()
             self.ctx = None
 
 
-def init_c_comm(rank, world, device_index):
+def _agree(ok, dev):
+    """True only if `ok` holds on every rank (one MIN all-reduce over the torch group; no group: the local value)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return bool(ok)
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return int(t.item()) == 1
+
+
+def open_peer_transport(ctx, rank, world, device_index):
+    """Gives the library context `ctx` the peer transport of csrc/comm.hip: this rank's receive buffer is exported as an
+    opaque blob, the blobs of all ranks travel over the torch.distributed group (any host channel would do), every rank maps
+    the others' buffers.  Collective: every rank must call it.  The ranks agree on success after each step, so a rank that
+    cannot export or map makes ALL ranks return False (and none is left waiting); the context is then unchanged."""
+    import ctypes
+    import torch
+    import torch.distributed as dist
+    from . import _lib
+    L = _lib.lib()
+    grouped = dist.is_available() and dist.is_initialized()
+    if world > 1 and not grouped:
+        raise RuntimeError("open_peer_transport needs an initialised torch.distributed group to carry the buffer handles")
+    on_gpu = grouped and dist.get_backend() == "nccl"
+    dev = torch.device("cuda", device_index) if on_gpu else torch.device("cpu")
+    nb = int(_lib.MQS_PEER_HANDLE_BYTES)
+    blob = (ctypes.c_uint8 * nb)()
+    rc = L.mqs_comm_peer_export(ctx.handle, rank, world, blob) if world <= int(_lib.MQS_PEER_MAX_WORLD) else -1
+    if not _agree(rc == 0, dev):
+        if rc == 0:
+            L.mqs_comm_peer_close(ctx.handle)
+        return False
+    mine = torch.tensor(list(blob), dtype=torch.uint8, device=dev)
+    if grouped:
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine)
+        allb = torch.cat(parts).cpu().numpy().tobytes()
+    else:
+        allb = bytes(blob)
+    handles = (ctypes.c_uint8 * (nb * world)).from_buffer_copy(allb)
+    rc = L.mqs_comm_peer_open(ctx.handle, handles)
+    if not _agree(rc == 0, dev):
+        L.mqs_comm_peer_close(ctx.handle)
+        return False
+    if grouped:
+        dist.barrier()                    # every rank has mapped every buffer before anyone stores into one
+    return True
+
+
+def init_peer_comm(rank, world, device_index):
+    """A library context with the peer transport only (no RCCL communicator): what the two-processes-on-one-GPU tests use,
+    and any host program whose ranks can exchange 128 bytes each.  Raises if the transport cannot be opened on every rank."""
+    from . import _lib
+    ctx = _lib.Context(device_index)
+    if not open_peer_transport(ctx, rank, world, device_index):
+        ctx.close()
+        raise RuntimeError("the peer transport could not be opened on every rank (%s)" % (_lib.lib().mqs_last_error().decode(),))
+    return CComm(ctx, rank, world, transport="peer")
+
+
+def init_c_comm(rank, world, device_index, peer=False):
     """Creates this rank's library context on `device_index` and joins the RCCL communicator of `world` ranks.  The 128-byte
     unique id is made on rank 0 and carried to the other ranks by the torch.distributed group that `init_from_env`
     initialised (any host-side channel would do: the C ABI only sees the bytes).  Collective: every rank must call it.
@@ -136,4 +213,7 @@ def init_c_comm(rank, world, device_index):
         _lib.check(rc)
     ctx = _lib.Context(device_index)
     _lib.check(L.mqs_comm_init_rank(ctx.handle, ident, rank, world))
-    return CComm(ctx, rank, world)
+    cc = CComm(ctx, rank, world)
+    if peer and open_peer_transport(ctx, rank, world, device_index):
+        cc.transport = "peer+rccl"        # the BA system travels as peer stores; RCCL serves what does not fit a row
+    return cc

@@ -94,6 +94,56 @@ def test_solve_and_retract(gpu):
     assert np.abs(ba.dpose.cpu().numpy() - d_lm).max() <= 1e-9 * np.abs(d_lm).max()
 
 
+@pytest.mark.parametrize("C", [1, 2, 3, 4, 5, 8])
+@pytest.mark.parametrize("cond", [1e2, 1e8])
+def test_reduced_solve_on_random_systems(C, cond, gpu):
+    """mqs_ba_solve_dev on random symmetric positive definite systems of prescribed condition number, with and without
+    damping and pose priors.  C <= 4 runs the one-wavefront solve that carries L^-1 and L^-1 b through the factorisation loop
+    (ba_solve_small_kernel: no substitution chains), C > 4 the row-per-lane kernel with its LDS substitutions."""
+    import torch
+    n = 6 * C
+    rng = np.random.default_rng(100 * C + int(np.log10(cond)))
+    Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    S = (Q * np.geomspace(1.0, cond, n)) @ Q.T
+    S = 0.5 * (S + S.T)
+    g = rng.standard_normal(n) * np.sqrt(cond)
+    L = gpu._lib.lib()
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    poses = np.tile(np.concatenate([np.eye(3).reshape(-1), [0.0, 0.0, 0.0]]), (C, 1))
+    poses += 0.0
+    pd = torch.from_numpy(poses).cuda()
+    prior_poses = torch.from_numpy(np.stack([ba_np.retract_pose(poses[c], 0.01 * rng.standard_normal(6)) for c in range(C)])).cuda()
+    prior_sig = torch.from_numpy(np.tile([0.02, 0.02, 0.02, 0.1, 0.1, 0.1], (C, 1))).cuda()
+    prior_mask = torch.from_numpy((np.arange(C) % 2 == 0).astype(np.uint8)).cuda()
+    sp = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for lam, with_prior in ((0.0, False), (1e-3, False), (-0.5, False), (0.0, True)):
+        lin = torch.from_numpy(np.concatenate([S.reshape(-1), g, [0.0, 0.0]])).cuda()
+        dpose = torch.zeros(n, dtype=torch.float64, device="cuda")
+        out = torch.zeros((C, 12), dtype=torch.float64, device="cuda")
+        info = torch.zeros(2, dtype=torch.float64, device="cuda")
+        gpu._lib.check(L.mqs_ba_solve_dev(p(lin), C, p(pd), p(prior_poses) if with_prior else None, p(prior_sig) if with_prior else None,
+                                          p(prior_mask) if with_prior else None, lam, p(dpose), p(out), p(info), sp))
+        A, b = S.copy(), g.copy()
+        if with_prior:
+            Hp, gp, cp = ba_np.pose_prior_terms(poses, prior_poses.cpu().numpy(), prior_sig.cpu().numpy(), prior_mask.cpu().numpy())
+            A, b = A + Hp, b + gp
+            assert info.cpu().numpy()[0] == pytest.approx(cp, rel=1e-10)
+        A = A + (lam * np.diag(np.diag(A)) if lam >= 0 else -lam * np.eye(n))
+        ref = np.linalg.solve(A, b)
+        d = dpose.cpu().numpy()
+        # forward error of a Cholesky solve ~ cond * eps; the residual is the sharper check
+        assert np.abs(d - ref).max() <= 50 * np.linalg.cond(A) * 2.2e-16 * np.abs(ref).max() + 1e-300
+        assert np.abs(A @ d - b).max() <= 1e-9 * (np.abs(A).max() * np.abs(d).max() + np.abs(b).max())
+        assert info.cpu().numpy()[1] == 0.0
+        new = out.cpu().numpy()
+        for c in range(C):
+            np.testing.assert_allclose(new[c], ba_np.retract_pose(poses[c], d[6 * c:6 * c + 6]), atol=1e-9 * max(1.0, np.abs(d).max()))
+    # not positive definite: flagged, no NaN escapes into the poses' rotation part being non-finite is acceptable, the flag is not optional
+    lin = torch.from_numpy(np.concatenate([(-S).reshape(-1), g, [0.0, 0.0]])).cuda()
+    gpu._lib.check(L.mqs_ba_solve_dev(p(lin), C, p(pd), None, None, None, 0.0, p(dpose), p(out), p(info), sp))
+    assert info.cpu().numpy()[1] == 1.0
+
+
 def test_gauss_newton_matches_oracle_every_iteration(gpu):
     """BA residual (cost) parity <= 1e-5 after each of the 10 Gauss-Newton iterations."""
     sc = make_scene(500, 4, seed=11)

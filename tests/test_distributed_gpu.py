@@ -167,6 +167,8 @@ for ba in (a, b, c):
     ba.gauss_newton_iterations(3)
 torch.cuda.synchronize()
 assert torch.equal(a.poses, c.poses) and torch.equal(b.poses, c.poses) and torch.equal(a.points, c.points)
+# ncclAllReduce enqueued by the library between the lineariser and the solve (a) == torch's all_reduce between the two halves (b)
+assert torch.equal(a.lin, b.lin) and torch.equal(a.lin, c.lin)
 assert a.total_cost() == c.total_cost() == b.total_cost()
 dist.barrier(); cc.close(); dist.destroy_process_group()
 print("nccl-ok")
@@ -191,3 +193,112 @@ def test_bench_multi_gpu_code_path_on_the_real_backend(gpu):
     bs = out["ba_strong"]
     assert bs["ok"] is True and bs["backend"] == "nccl" and bs["rccl_world_size"] == 1 and bs["all_reduce_us"] > 0
     assert bs["max_abs_pose_diff_vs_one_rank"] == 0.0          # one rank: the sharded run IS the one-rank run
+
+
+PEER_WORKER = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import torch
+import mqslam_amd
+from ba_util import make_scene
+sh = mqslam_amd.sharding
+rank, local_rank, world = sh.init_from_env()
+dev = torch.device("cuda", 0)
+cc = sh.init_peer_comm(rank, world, 0)
+assert cc.peer_state() == (1 if world > 1 else 2), cc.peer_state()       # two processes on one GPU: stand-alone wait kernel
+# (a) the collective by itself: 40 back-to-back reductions of exactly representable values
+for it in range(40):
+    n = 602 if it % 2 == 0 else 2
+    buf = (torch.arange(n, dtype=torch.float64, device=dev) + 1000.0 * it) * (rank + 1)
+    cc.all_reduce_sum_(buf)
+    want = (torch.arange(n, dtype=torch.float64, device=dev) + 1000.0 * it) * (world * (world + 1) // 2)
+    torch.cuda.synchronize()
+    assert torch.equal(buf, want), (it, rank)
+# (b) Gauss-Newton on the sharded scene, one library call per iteration: the finalize kernel stores the rank's reduced system
+#     into both receive buffers, the consumer adds the rows in rank order
+sc = make_scene(4001, 4, seed=11, distortion=True)
+pts, obs, mask, pw, px = sh.shard_arrays(rank, world, sc["points"], sc["obs"], sc["mask"], sc["prior_w"], sc["prior_xyz"])
+t = lambda a, dt=torch.float64: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev).to(dt)
+C = 4
+pose_prior = (t(sc["poses_true"]), t(np.tile([0.02, 0.02, 0.02, 0.1, 0.1, 0.1], (C, 1))),
+              t(np.array([1, 0, 0, 0], dtype=np.uint8), torch.uint8))
+ba = mqslam_amd.bundle_adjustment.BundleAdjuster(t(sc["poses"]), t(sc["calib"]), t(sc["sigma"]), t(pts), t(obs), None,
+                                                 t(pw), t(px), pose_prior, cc)
+costs = [ba.total_cost()]
+ba.gauss_newton_iterations(2)
+ba.gauss_newton_iteration()
+costs.append(ba.total_cost())
+hist = ba.optimize(iters=6, mode="lm")                   # the split form: linearise, all-reduce, solve, back-substitute
+torch.cuda.synchronize()
+assert not cc.peer_timed_out()
+np.savez(os.path.join({out!r}, "peer_{tag}_r%d_of_%d.npz" % (rank, world)), poses=ba.poses.cpu().numpy(),
+         points=ba.points.cpu().numpy(), costs=np.array(costs + hist), lin=ba.lin.cpu().numpy())
+if world > 1:
+    torch.distributed.barrier()
+cc.close()
+if world > 1:
+    torch.distributed.destroy_process_group()
+print("peer-ok")
+"""
+
+
+def test_peer_transport_two_processes_on_one_gpu(gpu, tmp_path):
+    """The one-shot all-reduce over peer-mapped receive buffers (csrc/comm.hip) with two PROCESSES on the one GPU of the test
+    box: the buffers are exchanged as hipIpc handles over the gloo group, every reduction is the ranks' rows added in rank
+    order.  Checked: the collective alone (exact integers), the one-call Gauss-Newton iteration whose finalize kernel is the
+    send side, the LM loop on the split form -- against the same scene solved by ONE process, with the stand-alone wait
+    kernel (the default when ranks share a GPU) and with the wait fused into the solve / back-substitution kernel
+    (MQS_PEER_FUSED=1: what ranks on separate GPUs run; small enough here that the waiting kernel does not fill the chip)."""
+    outs = {}
+    for tag, fused in (("gather", "0"), ("fused", "1")):
+        script = tmp_path / ("peer_%s.py" % tag)
+        script.write_text(PEER_WORKER.format(root=ROOT, out=str(tmp_path), tag=tag))
+        env = dict(os.environ, MQS_DIST_BACKEND="gloo", MQS_SHARED_GPU="1", MASTER_ADDR="127.0.0.1", MQS_PEER_FUSED=fused)
+        for world in (1, 2):
+            if world == 1:
+                cmd = [sys.executable, str(script)]
+                e = {k: v for k, v in env.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MQS_PEER_FUSED")}
+            else:
+                cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                       "127.0.0.1", "--master-port", str(29300 + os.getpid() % 250), str(script)]
+                e = env
+            r = subprocess.run(cmd, env=e, capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0 and "peer-ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+        one = np.load(tmp_path / ("peer_%s_r0_of_1.npz" % tag))
+        two = [np.load(tmp_path / ("peer_%s_r%d_of_2.npz" % (tag, r))) for r in range(2)]
+        np.testing.assert_array_equal(two[0]["poses"], two[1]["poses"])          # rank-ordered sum: the same bits on every rank
+        np.testing.assert_array_equal(two[0]["lin"], two[1]["lin"])
+        assert np.abs(two[0]["poses"] - one["poses"]).max() <= 1e-9
+        pts = np.concatenate([two[0]["points"], two[1]["points"]])
+        assert np.abs(pts - one["points"]).max() <= 1e-9 * max(1.0, np.abs(one["points"]).max())
+        assert np.allclose(two[0]["costs"][:2], one["costs"][:2], rtol=1e-10, atol=0)
+        assert one["costs"][1] < one["costs"][0]
+        outs[tag] = two
+    # where the wait happens does not change a bit
+    for r in range(2):
+        for key in ("poses", "points", "lin", "costs"):
+            np.testing.assert_array_equal(outs["gather"][r][key], outs["fused"][r][key])
+
+
+def test_peer_transport_single_rank_is_the_plain_iteration(gpu):
+    """One rank over the peer transport (its own receive buffer, fused wait): the iteration equals the plain one bit for bit --
+    the single-GPU run of the exact launch sequence N ranks on N GPUs issue."""
+    import torch
+    from ba_util import make_scene
+    cc = gpu.sharding.init_peer_comm(0, 1, 0)
+    try:
+        assert cc.peer_state() == 2 and gpu._lib.lib().mqs_comm_world_size(cc.ctx.handle) == 1
+        sc = make_scene(3000, 3, seed=4, masked_frac=0.2)
+        t = lambda a, dt=torch.float64: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).cuda().to(dt)
+        mk = lambda pg: gpu.bundle_adjustment.BundleAdjuster(t(sc["poses"]), t(sc["calib"]), t(sc["sigma"]), t(sc["points"]),
+                                                             t(sc["obs"]), t(sc["mask"], torch.uint8), t(sc["prior_w"]),
+                                                             t(sc["prior_xyz"]), None, pg)
+        a, b = mk(cc), mk(None)
+        a.gauss_newton_iterations(3)
+        b.gauss_newton_iterations(3)
+        torch.cuda.synchronize()
+        assert torch.equal(a.poses, b.poses) and torch.equal(a.points, b.points) and torch.equal(a.lin, b.lin)
+        assert not cc.peer_timed_out()
+    finally:
+        cc.close()
