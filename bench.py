@@ -177,24 +177,39 @@ def main():
     if multi:
         import torch.distributed as dist
         group, transport = True, "torch.distributed(%s)" % dist.get_backend()
-        if dist.get_backend() == "nccl" and os.environ.get("MQS_TRANSPORT", "c") == "c":
-            # the library's own communicator: the all-reduce is issued from C between the kernels of an iteration.  It is
-            # verified against torch.distributed's sum before use; any failure keeps the torch transport (still RCCL).
+        if dist.get_backend() == "nccl" and os.environ.get("MQS_TRANSPORT", "c") in ("c", "rccl"):
+            # the library's own transport: the reduced system travels as plain stores into receive buffers the ranks map from each
+            # other (csrc/comm.hip: the send side rides in the lineariser's finalize kernel, the wait and the rank-ordered sum in the
+            # fused solve / back-substitution kernel -- no collective launch), with an RCCL communicator in the same context for
+            # what does not fit a row.  It is verified against torch.distributed's sum before use.  Every rank records its own
+            # outcome and the ranks AGREE on it in collectives that all of them reach (a rank-local exception must not leave the
+            # others waiting inside one); any failure keeps the torch transport (still RCCL).
+            dev0 = torch.device("cuda", local_rank)
+            cc, err = None, ""
             try:
-                cc = sh.init_c_comm(rank, world, local_rank)
-                probe = torch.arange(602, dtype=torch.float64, device=torch.device("cuda", local_rank)) * (rank + 1)
-                want = probe.clone()
-                dist.all_reduce(want)
-                cc.all_reduce_sum_(probe)
-                torch.cuda.synchronize()
-                ok = torch.tensor([1.0 if torch.equal(probe, want) else 0.0], device=probe.device)
-                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-                if ok.item() == 1.0:
-                    group, transport = cc, "rccl via the C ABI (mqs_comm_*, all-reduce issued inside mqs_ba_gn_iteration_dev)"
-                else:
-                    transport += " (C-ABI communicator gave a different sum: not used)"
-            except Exception as e:                              # noqa: BLE001 -- reported, the run continues on torch's RCCL
-                transport += " (C-ABI communicator unavailable: %s)" % (str(e)[:120],)
+                cc = sh.init_c_comm(rank, world, local_rank, peer=os.environ.get("MQS_TRANSPORT", "c") == "c")
+            except Exception as e:                              # noqa: BLE001 -- init_c_comm itself agrees before it raises
+                err = str(e)[:120]
+            probe = torch.arange(602, dtype=torch.float64, device=dev0) * (rank + 1)
+            want = probe.clone()
+            dist.all_reduce(want)
+            same = 0.0
+            if cc is not None:
+                try:
+                    cc.all_reduce_sum_(probe)
+                    torch.cuda.synchronize()
+                    same = 1.0 if (torch.equal(probe, want) and not (cc.peer_state() and cc.peer_timed_out())) else 0.0
+                except Exception as e:                          # noqa: BLE001
+                    err = str(e)[:120]
+            ok = torch.tensor([same], device=dev0)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if ok.item() == 1.0:
+                group = cc
+                transport = ("peer stores over xGMI via the C ABI (mqs_comm_peer_*: send side in the finalize kernel, wait + rank-ordered "
+                             "sum in the fused tail of mqs_ba_gn_iteration_dev; RCCL communicator beside it)" if cc.peer_state() else
+                             "rccl via the C ABI (mqs_comm_*, all-reduce issued inside mqs_ba_gn_iteration_dev)")
+            else:
+                transport += " (C-ABI transport not used: %s)" % (err or "its sum differs from torch.distributed's on some rank",)
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank if world > 1 else 0)
@@ -259,28 +274,39 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # Clock settling.  The part raises its clock over the first ~50-100 ms of sustained load: 0.223 ms per step over steps 6..55
-    # of a fresh process, 0.197 ms from about the hundredth step on (same box, `--warmup 5` against `--warmup 400`).  The
-    # contract's W warm-up steps end inside that ramp, so a fixed number of untimed steps -- the same steps as the timed
-    # ones -- runs first; `clock_settle_steps` in the line says how many.
+    def timed_steps(k):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            step()
+        fence()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    # Two timed regions, both W untimed warm-up steps followed by exactly K steps between barrier + synchronize, MAX over ranks:
+    #   cold     what a fresh process gives right after the contract's W warm-up steps (`ms_per_step_cold`, `value_cold`);
+    #   settled  the same after `--settle-steps` further untimed steps (the same steps as the timed ones).  The part raises its
+    #            clock over the first ~50-100 ms of sustained load: W = 5 warm-up steps end inside that ramp (0.223 against 0.199
+    #            ms per step in round 2).  `value` / `ms_per_step` are the SETTLED figures -- the steady state a job that runs for
+    #            more than a tenth of a second sees; `value_from` says so in the line and the cold figure stands beside it.
+    for _ in range(args.warmup):
+        step()
+    elapsed_cold = timed_steps(args.steps)
     for _ in range(args.settle_steps):
         step()
     fence()
     for _ in range(args.warmup):
         step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = timed_steps(args.steps)
 
     ms_per_step = 1e3 * elapsed / args.steps
     value = N_total / (elapsed / args.steps)
+    ms_per_step_cold = 1e3 * elapsed_cold / args.steps
+    value_cold = N_total / (elapsed_cold / args.steps)
 
     # ---- per-kernel durations with hipEvents on the launch stream (rank 0 reports) ----
     reps = 20
@@ -330,6 +356,13 @@ def main():
     ba_out = None
     if ba is not None:
         ba_out = ba.benchmark_report(world, dist)
+        if rank == 0 and world == 1 and N >= 8:
+            # what ONE rank of the 8-way sharded configs[3] run holds, on this GPU alone: the serial floor of strong scaling
+            ns = N // 8
+            sub = mqslam_amd.bundle_adjustment.make_benchmark_problem(np.ascontiguousarray(u[:, :ns]), P, x_it[:ns].clone(), dev,
+                                                                      seed=syn.RSEED)
+            ba_out["shard_proxy"] = mqslam_amd.bundle_adjustment.shard_proxy_report(sub)
+            del sub
 
     # ---- matcher (BASELINE configs[2]): one 65 536 x 65 536 x 256-bit camera pair, rank 0 reports ----
     match_out = None
@@ -371,9 +404,9 @@ def main():
         e1.synchronize()
         ms8 = e0.elapsed_time(e1) / 20
         tops = 2.0 * nd * nd * bits / (ms8 * 1e-3) / 1e12
-        # packed descriptors run on the FP4 matrix instruction (v_mfma_f32_32x32x64_f8f6f4, ~10 PF dense on MI355X); the key
-        # keeps its round-1 name, `int8_peak_equivalent` prices the same work against the 5 P int8 peak it was measured on before
-        match_out["packed_bits_int8"] = {"ms_per_pair": round(ms8, 3), "Tops": round(tops, 1), "matrix_path": "fp4 (E2M1), fp32 accumulate",
+        # packed descriptors run on the FP4 matrix instruction (v_mfma_f32_32x32x64_f8f6f4, ~10 PF dense on MI355X);
+        # `int8_peak_equivalent` prices the same work against the 5 P int8 peak it ran against until round 2
+        match_out["packed_bits_fp4"] = {"ms_per_pair": round(ms8, 3), "Tops": round(tops, 1), "matrix_path": "fp4 (E2M1), fp32 accumulate",
                                          "mfma_fp4_dense_peak_Tops": 10000.0, "frac_of_peak": round(tops / 10000.0, 4),
                                          "int8_peak_equivalent": round(tops / 5000.0, 4),
                                          "equals_fp16_path": bool(torch.equal(mi, mi8) and torch.equal(md, md8))}
@@ -448,8 +481,8 @@ def main():
     if match_out is not None:
         rooflines["match_knn2_f16"] = {"bound": "mfma", "achieved": match_out["TFLOPs"], "peak": 2500.0, "unit": "TFLOP/s",
                                        "frac": match_out["frac_of_peak"]}
-        rooflines["match_knn2_bits_fp4"] = {"bound": "mfma", "achieved": match_out["packed_bits_int8"]["Tops"], "peak": 10000.0,
-                                            "unit": "Top/s", "frac": match_out["packed_bits_int8"]["frac_of_peak"]}
+        rooflines["match_knn2_bits_fp4"] = {"bound": "mfma", "achieved": match_out["packed_bits_fp4"]["Tops"], "peak": 10000.0,
+                                            "unit": "Top/s", "frac": match_out["packed_bits_fp4"]["frac_of_peak"]}
 
     # ---- BASELINE configs[4] counterpart: the per-frame loop replayed from the reference's recorded tracks
     #      (committed fixture tests/golden/ba_svo: 186 frames, 1046 landmarks), rank 0 reports ----
@@ -628,7 +661,11 @@ def main():
                       + (" + 1 BA Gauss-Newton iteration" if ba is not None else "")
                       + "), 1e6 pts x 4 cams per GPU; BA GN iters/sec in `ba`",
             "value": round(value), "unit": "landmarks/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "clock_settle_steps": args.settle_steps, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "warmup": args.warmup, "clock_settle_steps": args.settle_steps, "ms_per_step": round(ms_per_step, 4),
+            "ms_per_step_cold": round(ms_per_step_cold, 4), "value_cold": round(value_cold),
+            "value_from": "ms_per_step: %d warm-up + %d timed steps after %d untimed clock-settling steps; ms_per_step_cold / value_cold: "
+                          "the same %d + %d steps first thing in the process" % (args.warmup, args.steps, args.settle_steps, args.warmup, args.steps),
+            "higher_is_better": True,
             "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": ("BASELINE configs[3] shape: ONE scene of %d landmarks x %d cameras sharded %d-way, linear-LS + "
                                     "iterative-LS + 1 GN iteration per step" % (N_total, C, world)) if strong else

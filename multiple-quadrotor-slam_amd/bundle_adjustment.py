@@ -307,8 +307,9 @@ class BundleAdjuster:
     # ---- benchmark helpers (bench.py) --------------------------------------------------
     def time_kernel(self, what, reps=20, lam=0.0):
         """Average launch duration (ms) of one kernel of the iteration, hipEvents on the current stream:
-        what = "linearize" (the kernel alone), "finalize", "solve", "backsub".  The estimate is not advanced."""
-        code = {"linearize": 0, "finalize": 1, "solve": 2, "backsub": 3}[what]
+        what = "linearize" (the kernel alone), "finalize", "solve", "backsub", "solve_backsub" (the tail of an iteration as
+        mqs_ba_gn_iteration_dev issues it: ONE launch for C <= 4).  The estimate is not advanced."""
+        code = {"linearize": 0, "finalize": 1, "solve": 2, "backsub": 3, "solve_backsub": 4}[what]
         ms = ctypes.c_float(0.0)
         _lib.check(_lib.lib().mqs_ba_time_dev(
             code, _p(self.poses), _p(self.calib), _p(self.sigma), self.C, _p(self.points), _p(self.obs), _p(self.mask),
@@ -354,6 +355,7 @@ class BundleAdjuster:
         self.linearize(0.0)
         ms_solve = self.time_kernel("solve")
         ms_back = self.time_kernel("backsub")
+        ms_tail = self.time_kernel("solve_backsub")
         ms_ar = timed(self.all_reduce) if dist is not None else 0.0
         bytes_iter = N * (2 * (24 + 16 * C) + 24)
         return {
@@ -361,10 +363,35 @@ class BundleAdjuster:
             "landmarks_total": N * world, "cameras": C, "iterations_timed": reps,
             "kernels_ms": {"linearize_schur": round(ms_lin, 4), "linearize_kernel_only": round(ms_lin_k, 5),
                            "finalize_kernel_only": round(ms_fin_k, 5), "solve_retract": round(ms_solve, 4),
-                           "backsub": round(ms_back, 4), "all_reduce": round(ms_ar, 4)},
+                           "backsub": round(ms_back, 4), "solve_retract_backsub_one_launch": round(ms_tail, 4),
+                           "all_reduce": round(ms_ar, 4)},
+            "launches_per_iteration": 3 if C <= 4 else 4,
             "algorithmic_GBps_per_gpu": round(bytes_iter / (1e-3 * (ms_lin + ms_back)) / 1e9, 1),
             "cost_before": c0, "cost_after_%d_more_iterations" % reps: c1,
         }
+
+
+def shard_proxy_report(ba, iters=200):
+    """Gauss-Newton iterations per second of a single-GPU problem sized like ONE rank's shard of a strong-scaling run
+    (BASELINE configs[3]: 1e6 landmarks over 8 GPUs = 125 000 per rank), through the one-call iteration, with the kernels of
+    an iteration timed one by one beside it: the serial floor of the sharded run before any collective costs anything."""
+    torch = _torch()
+    ba.gauss_newton_iterations(60)                                  # clock and caches
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    ba.gauss_newton_iterations(iters)
+    e1.record()
+    e1.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    k = {"linearize_kernel_only": ba.time_kernel("linearize", reps=50), "finalize_kernel_only": ba.time_kernel("finalize", reps=50)}
+    ba.linearize(0.0)
+    k["solve_retract"] = ba.time_kernel("solve", reps=50)
+    k["backsub"] = ba.time_kernel("backsub", reps=50)
+    k["solve_retract_backsub_one_launch"] = ba.time_kernel("solve_backsub", reps=50)
+    return {"landmarks": ba.N, "cameras": ba.C, "ms_per_iter": round(ms, 5), "gn_iters_per_s": round(1e3 / ms, 1),
+            "launches_per_iteration": 3 if ba.C <= 4 else 4, "kernels_ms": {n: round(v, 5) for n, v in k.items()},
+            "sum_of_the_launches_ms": round(k["linearize_kernel_only"] + k["finalize_kernel_only"] + k["solve_retract_backsub_one_launch"], 5)}
 
 
 def bundle_adjust(poses, calib, sigma, points, obs, mask=None, prior_w=None, prior_xyz=None, pose_prior=None,

@@ -127,6 +127,7 @@ def test_bench_contract_single_gpu(gpu):
                      ("dtype", "f64"), ("data", "synthetic"), ("unit", "landmarks/s")):
         assert out[key] == val, key
     assert out["value"] > 0 and out["ms_per_step"] > 0 and "workload" in out["config"]
+    assert out["ms_per_step_cold"] > 0 and out["value_cold"] > 0 and "value_from" in out
     rf = out["roofline"]
     assert rf["bound"] in ("hbm", "mfma", "fp64_valu") and rf["unit"] in ("GB/s", "TFLOP/s") and rf["peak"] > 0
     assert rf["frac"] == pytest.approx(rf["achieved"] / rf["peak"], rel=1e-2) and rf["achieved"] > 0     # both are rounded
@@ -134,7 +135,7 @@ def test_bench_contract_single_gpu(gpu):
     cb = out["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and cb["unit"] == "landmarks/s" and "sample" in cb
     assert cb["parity"]["rel_err_p99.9"] < 1e-5 and cb["parity"]["status_mismatch_frac"] < 0.005
-    assert out["match"]["packed_bits_int8"]["equals_fp16_path"] is True
+    assert out["match"]["packed_bits_fp4"]["equals_fp16_path"] is True
     assert out["match"]["cross_match_4_cameras"]["pairs_this_rank"] == 6
 
 
@@ -189,7 +190,7 @@ def test_bench_multi_gpu_code_path_on_the_real_backend(gpu):
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert out["n_gpus"] == 1 and out["transport"].startswith("rccl via the C ABI"), out["transport"]
+    assert out["n_gpus"] == 1 and out["transport"].startswith("peer stores over xGMI via the C ABI"), out["transport"]
     bs = out["ba_strong"]
     assert bs["ok"] is True and bs["backend"] == "nccl" and bs["rccl_world_size"] == 1 and bs["all_reduce_us"] > 0
     assert bs["max_abs_pose_diff_vs_one_rank"] == 0.0          # one rank: the sharded run IS the one-rank run
