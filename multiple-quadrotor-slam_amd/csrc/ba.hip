@@ -1056,42 +1056,79 @@ __device__ __forceinline__ void pose_prior_terms(const double *__restrict__ pose
 }
 
 template <int C>
-__device__ __forceinline__ void reduced_solve_wave(const double *sLin, const double *sE, const double *sW, double lambda,
-                                                   double *sCol /*[2][64]*/, double *sY /*[n]*/, double *sX /*[n]*/, int lane,
-                                                   bool &bad)
+__device__ __forceinline__ void reduced_solve_wave(const double *sM /*[64][n]*/, double *sCol /*[2][64]*/, double *sY /*[n]*/,
+                                                   double *sX /*[n]*/, int lane, bool &bad)
 {
     constexpr int n = 6 * C;
     static_assert(n <= 24, "rows, inverse columns and the right-hand side share one wavefront");
-    const bool isL = lane < n, isI = lane >= kSolveInvLane0 && lane < kSolveInvLane0 + n, isB = lane == kSolveRhsLane;
-    const int r = isL ? lane : 0, ci = lane - kSolveInvLane0;
+    const bool isI = lane >= kSolveInvLane0 && lane < kSolveInvLane0 + n, isB = lane == kSolveRhsLane;
+    const int ci = lane - kSolveInvLane0;
+    // this lane's starting vector: a row of the damped system, a unit vector, or the right-hand side (build_solve_matrix)
     double row[n];
 #pragma unroll
-    for (int j = 0; j < n; ++j) {
-        const double a = sLin[r * n + j], b = sLin[n * n + j] - sE[j];
-        double v = isL ? a : (isB ? b : ((isI && j == ci) ? 1.0 : 0.0));
-        if (isL && j == r) v = (lambda >= 0.0) ? (v + sW[r]) * (1.0 + lambda) : (v + sW[r]) - lambda;   // prior weight, then damping
-        row[j] = v;
+    for (int j = 0; j < n; j += 2) {
+        const double2 v = *reinterpret_cast<const double2 *>(sM + lane * n + j);
+        row[j] = v.x; row[j + 1] = v.y;
     }
-    bad = false;
-    double akk = read_lane(row[0], 0);
+    // A lone wave issues one instruction per ~5 cycles and hides no latency by itself, so the loop is written as the machine
+    // should run it: per pivot k a short CRITICAL part -- L[.][k] = row[k] / L_kk, the two entries of that column the next two
+    // pivots wait for fetched by v_readlane (no LDS round trip), the next pivot, the seed of its reciprocal square root --
+    // and, in the shadow of that seed's Newton steps, the part nobody waits for yet: the rest of the PREVIOUS pivot's column
+    // (read back from LDS a whole step ago) applied to rows k + 2 and beyond.  sched_barriers keep the compiler from sinking
+    // the critical part behind the LDS waits (it did: 6.1 us for the 24 pivots, tools/probes/tail_phases.hip).
+    // A pivot that is not positive gives NaN / Inf from here on; `chk` collects that without a branch on the chain.
+    double cb[n], lprev = 0.0;                       // the far entries of the previous pivot's column as read back from LDS
+#pragma unroll
+    for (int j = 0; j < n; ++j) cb[j] = 0.0;
+    double inv = mqs::rsqrt_d(read_lane(row[0], 0));
+    double chk = 0.0;                                // 0 * (1 / L_kk) summed over the pivots: NaN as soon as one pivot was not positive
 #pragma unroll
     for (int k = 0; k < n; ++k) {
-        bad = bad || !(akk > 0.0);
-        const double inv = mqs::rsqrt_d(akk > 0.0 ? akk : 1.0);
         const double lik = row[k] * inv;             // rows: L[lane][k] (lanes >= k);  inverse / rhs lanes: v_k
         row[k] = lik;
+        chk = fma(inv, 0.0, chk);                    // rsq(0) = inf, rsq(< 0) = NaN: 0 * either is NaN
         if (k + 1 < n) {
             double *col = sCol + 64 * (k & 1);
             col[lane] = lik;
-            // the entry the next pivot and the next column wait for, without the LDS round trip
-            const double lnext = read_lane(lik, k + 1);
-            row[k + 1] = fma(-lik, lnext, row[k + 1]);
-            akk = read_lane(row[k + 1], k + 1);
-            mqs_wave_lds_sync();
+            asm volatile("" ::: "memory");           // the LDS pipe keeps a wavefront's accesses in order: no wait needed before the reads below
+            row[k + 1] = fma(-lik, read_lane(lik, k + 1), row[k + 1]);
+            if (k + 2 < n) row[k + 2] = fma(-lik, read_lane(lik, k + 2), row[k + 2]);
+            const double akk = read_lane(row[k + 1], k + 1);
+            double y = __builtin_amdgcn_rsq(akk);
+            const double hd = 0.5 * akk;
+            __builtin_amdgcn_sched_barrier(0);
+            // Newton steps of the seed (six dependent instructions) with the previous column's updates between them
+            constexpr int kStages = 6;
+            double t = 0.0, e = 0.0;
 #pragma unroll
-            for (int j = k + 2; j < n; ++j) row[j] = fma(-lik, col[j], row[j]);   // only entries j <= lane matter for the rows of L
+            for (int st = 0; st < kStages; ++st) {
+                if (st == 0) t = hd * y;
+                else if (st == 1) e = fma(-t, y, 0.5);
+                else if (st == 2) y = fma(y, e, y);
+                else if (st == 3) t = hd * y;
+                else if (st == 4) e = fma(-t, y, 0.5);
+                else y = fma(y, e, y);
+                if (k >= 1) {
+#pragma unroll
+                    for (int j = k + 2 + st; j < n; j += kStages) row[j] = fma(-lprev, cb[j], row[j]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            inv = y;
+            lprev = lik;
+            // this column's far entries: requested now that the previous column's registers are free (one buffer live at a time: the fused
+            // tail runs at 128 registers), consumed in the next step's shadow
+#pragma unroll
+            for (int j = (k + 3) & ~1; j < n; j += 2) {
+                // pairs (one ds_read_b128; also keeps the loop from being recognised as a memcpy, which lands in scratch memory)
+                const double2 v = *reinterpret_cast<const double2 *>(col + j);
+                if (j >= k + 3) cb[j] = v.x;
+                cb[j + 1] = v.y;
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
+    bad = !(chk == 0.0);                             // wave-uniform
     // lane 56 holds y = L^-1 b, lane 32 + c column c of L^-1:  x_c = sum_j (L^-1)[j][c] y_j
     if (isB) {
 #pragma unroll
@@ -1118,30 +1155,47 @@ __device__ __forceinline__ void retract_pose_dev(const double *__restrict__ T, c
 template <int C>
 struct SolveLds {
     static constexpr int n = 6 * C;
+    __attribute__((aligned(16))) double m[64 * n];          // the 64 lanes' starting vectors (build_solve_matrix)
+    __attribute__((aligned(16))) double col[128];
     double lin[n * n + n + 2];
     double e[n], w[n], y[n], x[n];
-    __attribute__((aligned(16))) double col[128];
     double info[2];
 };
 
-// what wave 0 of a workgroup does with the reduced system in sm.lin: priors, solve, and (when `publish`) dpose, the retracted
-// poses and info to global memory
+// The starting vectors of the solve wave's 64 lanes, written by ALL threads of the workgroup (`nthreads`; the lone solve wave
+// spent 240 of its ~1 700 instructions selecting them): lane r < n: row r of S with the prior weight and the damping on the
+// diagonal; lane 32 + c: e_c; lane 56: g - prior residual; others 0.
 template <int C>
-__device__ __forceinline__ void solve_and_publish(SolveLds<C> &sm, const double *__restrict__ poses,
-                                                  const double *__restrict__ prior_poses, const double *__restrict__ prior_sigmas,
-                                                  const uint8_t *__restrict__ prior_mask, double lambda, int lane, bool publish,
-                                                  double *__restrict__ dpose, double *__restrict__ poses_out,
-                                                  double *__restrict__ info)
+__device__ __forceinline__ void build_solve_matrix(SolveLds<C> &sm, double lambda, int tid, int nthreads)
 {
     constexpr int n = 6 * C;
-    pose_prior_terms<C>(poses, prior_poses, prior_sigmas, prior_mask, lane, sm.e, sm.w, sm.info);
-    bool bad;
-    reduced_solve_wave<C>(sm.lin, sm.e, sm.w, lambda, sm.col, sm.y, sm.x, lane, bad);
-    if (publish) {
-        if (lane < n) dpose[lane] = sm.x[lane];
-        if (poses_out && lane < C) retract_pose_dev(poses + 12 * lane, sm.x + 6 * lane, poses_out + 12 * lane);
-        if (info && lane == 0) { info[0] = sm.info[0]; info[1] = bad ? 1.0 : 0.0; }
+    // four threads per lane vector, every fourth entry each (no division by n)
+    for (int q = tid; q < 256; q += nthreads)
+    for (int j = q & 3; j < n; j += 4) {
+        const int lane = q >> 2, idx = lane * n + j;
+        double v = 0.0;
+        if (lane < n) {
+            v = sm.lin[lane * n + j];
+            if (j == lane) v = (lambda >= 0.0) ? (v + sm.w[lane]) * (1.0 + lambda) : (v + sm.w[lane]) - lambda;
+        } else if (lane >= kSolveInvLane0 && lane < kSolveInvLane0 + n) {
+            v = (j == lane - kSolveInvLane0) ? 1.0 : 0.0;
+        } else if (lane == kSolveRhsLane) {
+            v = sm.lin[n * n + j] - sm.e[j];
+        }
+        sm.m[idx] = v;
     }
+}
+
+// what the publishing workgroup's first wave does with the solution in sm.x
+template <int C>
+__device__ __forceinline__ void publish_solution(const SolveLds<C> &sm, const double *__restrict__ poses, bool bad, int lane,
+                                                 double *__restrict__ dpose, double *__restrict__ poses_out,
+                                                 double *__restrict__ info)
+{
+    constexpr int n = 6 * C;
+    if (lane < n) dpose[lane] = sm.x[lane];
+    if (poses_out && lane < C) retract_pose_dev(poses + 12 * lane, sm.x + 6 * lane, poses_out + 12 * lane);
+    if (info && lane == 0) { info[0] = sm.info[0]; info[1] = bad ? 1.0 : 0.0; }
 }
 
 template <int C>
@@ -1157,7 +1211,12 @@ __global__ __launch_bounds__(64) void ba_solve_small_kernel(const double *__rest
     const int lane = threadIdx.x;
     for (int k = lane; k < n * n + n + 2; k += 64) sm.lin[k] = lin[k];
     mqs_wave_lds_sync();
-    solve_and_publish<C>(sm, poses, prior_poses, prior_sigmas, prior_mask, lambda, lane, true, dpose, poses_out, info);
+    pose_prior_terms<C>(poses, prior_poses, prior_sigmas, prior_mask, lane, sm.e, sm.w, sm.info);
+    build_solve_matrix<C>(sm, lambda, lane, 64);
+    mqs_wave_lds_sync();
+    bool bad;
+    reduced_solve_wave<C>(sm.m, sm.col, sm.y, sm.x, lane, bad);
+    publish_solution<C>(sm, poses, bad, lane, dpose, poses_out, info);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1185,7 +1244,7 @@ __global__ __launch_bounds__(kBlock, 4) void ba_tail_kernel(
     const int tid = threadIdx.x;
     if (pr.rows) {
         mqs::peer::wait_and_sum(sm.lin, nlin, pr, tid, kBlock);
-        if (blockIdx.x == 0 && lin_out) {
+        if (blockIdx.x == gridDim.x - 1 && lin_out) {
             __syncthreads();
             for (int k = tid; k < nlin; k += kBlock) lin_out[k] = sm.lin[k];
         }
@@ -1193,12 +1252,24 @@ __global__ __launch_bounds__(kBlock, 4) void ba_tail_kernel(
         for (int k = tid; k < nlin; k += kBlock) sm.lin[k] = lin[k];
     }
     stage_cams<C>(poses, calib, sigma, sCam, tid);                  // ends in a workgroup barrier
-    if (tid < 64)
-        solve_and_publish<C>(sm, poses, prior_poses, prior_sigmas, prior_mask, lambda, tid, blockIdx.x == 0, dpose, poses_out, info);
+    if (tid < 64) pose_prior_terms<C>(poses, prior_poses, prior_sigmas, prior_mask, tid, sm.e, sm.w, sm.info);
+    __syncthreads();
+    build_solve_matrix<C>(sm, lambda, tid, kBlock);
+    __syncthreads();
+    // the LAST workgroup of the grid has no landmarks: it publishes dpose, the retracted poses and info (the trigonometry of
+    // the retraction, ~1 us on one wave, would otherwise sit on the path of a workgroup that also back-substitutes)
+    const bool publisher = blockIdx.x == gridDim.x - 1;
+    if (tid < 64) {
+        bool bad;
+        reduced_solve_wave<C>(sm.m, sm.col, sm.y, sm.x, tid, bad);
+        if (publisher) publish_solution<C>(sm, poses, bad, tid, dpose, poses_out, info);
+    }
+    if (publisher) return;
     __syncthreads();
 
     const int64_t rows64 = (N + 63) / 64;
-    const int64_t r_begin = rows64 * blockIdx.x / gridDim.x, r_end = rows64 * (blockIdx.x + 1) / gridDim.x;
+    const int64_t nwg = gridDim.x - 1;
+    const int64_t r_begin = rows64 * blockIdx.x / nwg, r_end = rows64 * (blockIdx.x + 1) / nwg;
     int64_t end = r_end * 64;
     if (end > N) end = N;
     for (int64_t base = r_begin * 64; base < end; base += kBlock) {
@@ -1470,15 +1541,15 @@ int mqs_ba_tail_launch(const double *lin, const mqs_peer_recv *peer, int C, cons
     mqs_peer_recv pr = {};
     if (peer) pr = *peer;
     // persistent grid: at most 4 workgroups per CU (each solves the reduced system once), one batch of 256 landmarks per
-    // workgroup below that
+    // workgroup below that; plus the publishing workgroup
     const int64_t rows64 = (N + 63) / 64;
     int64_t g = (rows64 + 3) / 4;
     if (g < 1) g = 1;
-    if (g > 1024) g = 1024;
+    if (g > 1023) g = 1023;
     switch (C) {
 #define MQS_CASE(c)                                                                                                      \
     case c:                                                                                                              \
-        hipLaunchKernelGGL((ba_tail_kernel<c>), dim3((unsigned)g), dim3(kBlock), 0, stream, lin, pr, poses, calib, sigma, points, obs, \
+        hipLaunchKernelGGL((ba_tail_kernel<c>), dim3((unsigned)g + 1), dim3(kBlock), 0, stream, lin, pr, poses, calib, sigma, points, obs, \
                            mask, prior_w, prior_xyz, N, lambda, prior_poses, prior_sigmas, prior_mask, lin_out, dpose, poses_out, \
                            info, points_out);                                                                            \
         break;
