@@ -363,6 +363,19 @@ def main():
                                                                       seed=syn.RSEED)
             ba_out["shard_proxy"] = mqslam_amd.bundle_adjustment.shard_proxy_report(sub)
             del sub
+            # the same shard through the peer transport with this GPU as the only rank: the launch sequence N ranks issue (finalize
+            # kernel stores the row into the receive buffer, the tail waits for its flags and adds the rows) minus the xGMI hop
+            try:
+                cc1 = sh.init_peer_comm(0, 1, 0)
+                sub = mqslam_amd.bundle_adjustment.make_benchmark_problem(np.ascontiguousarray(u[:, :ns]), P, x_it[:ns].clone(), dev,
+                                                                          seed=syn.RSEED, process_group=cc1)
+                ba_out["shard_proxy"]["ms_per_iter_over_the_peer_transport_one_rank"] = round(
+                    mqslam_amd.bundle_adjustment.time_iterations(sub), 5)
+                ba_out["shard_proxy"]["peer_timed_out"] = cc1.peer_timed_out()
+                del sub
+                cc1.close()
+            except Exception as e:                              # noqa: BLE001 -- a secondary figure
+                ba_out["shard_proxy"]["peer_transport_error"] = str(e)[:160]
 
     # ---- matcher (BASELINE configs[2]): one 65 536 x 65 536 x 256-bit camera pair, rank 0 reports ----
     match_out = None

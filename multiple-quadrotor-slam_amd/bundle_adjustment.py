@@ -371,19 +371,24 @@ class BundleAdjuster:
         }
 
 
-def shard_proxy_report(ba, iters=200):
-    """Gauss-Newton iterations per second of a single-GPU problem sized like ONE rank's shard of a strong-scaling run
-    (BASELINE configs[3]: 1e6 landmarks over 8 GPUs = 125 000 per rank), through the one-call iteration, with the kernels of
-    an iteration timed one by one beside it: the serial floor of the sharded run before any collective costs anything."""
+def time_iterations(ba, iters=200, warm=60):
+    """ms per one-call Gauss-Newton iteration (hipEvents on the current stream around `iters` back-to-back iterations)."""
     torch = _torch()
-    ba.gauss_newton_iterations(60)                                  # clock and caches
+    ba.gauss_newton_iterations(warm)                                # clock and caches
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     ba.gauss_newton_iterations(iters)
     e1.record()
     e1.synchronize()
-    ms = e0.elapsed_time(e1) / iters
+    return e0.elapsed_time(e1) / iters
+
+
+def shard_proxy_report(ba, iters=200):
+    """Gauss-Newton iterations per second of a single-GPU problem sized like ONE rank's shard of a strong-scaling run
+    (BASELINE configs[3]: 1e6 landmarks over 8 GPUs = 125 000 per rank), through the one-call iteration, with the kernels of
+    an iteration timed one by one beside it: the serial floor of the sharded run before any collective costs anything."""
+    ms = time_iterations(ba, iters)
     k = {"linearize_kernel_only": ba.time_kernel("linearize", reps=50), "finalize_kernel_only": ba.time_kernel("finalize", reps=50)}
     ba.linearize(0.0)
     k["solve_retract"] = ba.time_kernel("solve", reps=50)

@@ -722,12 +722,13 @@ __global__ __launch_bounds__(kFinThreads) void ba_finalize_kernel(const double *
         if (o2 >= 0) out[o2] = r;
         // peer transport (comm.hip): the same entries into slot [rank] of every rank's receive buffer -- this IS the send side
         // of the iteration's all-reduce
-        for (int q = 0; q < push.world; ++q) {
-            if (o1 >= 0) push.dst[q][o1] = r;
-            if (o2 >= 0) push.dst[q][o2] = r;
-        }
+        if (o1 >= 0) mqs::peer::push_entry(push, o1, r);
+        if (o2 >= 0) mqs::peer::push_entry(push, o2, r);
     }
-    if (wave == 0 && push.world > 0) mqs::peer::publish_piece(push, blockIdx.x, lane);
+    if (push.world > 0) {
+        __syncthreads();                              // the stores above have landed (vmcnt(0) rides in the barrier)
+        if (wave == 0) mqs::peer::publish_piece(push, blockIdx.x, lane);
+    }
 }
 
 #ifndef MQS_BA_BACKSUB_DIRECT

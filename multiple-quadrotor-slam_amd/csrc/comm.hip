@@ -114,12 +114,10 @@ size_t peer_bytes(int world) { return peer_timeout_off(world) + 256; }
 __global__ __launch_bounds__(256) void peer_all_reduce_kernel(double *__restrict__ buf, int n, mqs_peer_push push, mqs_peer_recv recv)
 {
     const int tid = threadIdx.x;
-    for (int q = 0; q < push.world; ++q)
-        for (int i = tid; i < n; i += 256) push.dst[q][i] = buf[i];
-    __threadfence_system();
-    __syncthreads();
+    for (int i = tid; i < n; i += 256) mqs::peer::push_entry(push, i, buf[i]);
+    __syncthreads();                     // vmcnt(0) + barrier: the row has landed everywhere before its flags go up (peer_dev.h)
     if (tid < push.world * recv.flags_per_rank)
-        __hip_atomic_store(push.flag[tid / recv.flags_per_rank] + tid % recv.flags_per_rank, push.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(push.flag[tid / recv.flags_per_rank] + tid % recv.flags_per_rank, push.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     mqs::peer::wait_and_sum(buf, n, recv, tid, 256);
 }
 

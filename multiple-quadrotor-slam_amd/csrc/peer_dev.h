@@ -8,10 +8,15 @@ namespace peer {
 
 constexpr long long kSpinTicks = 200000000ll;       // 2 s of the 100 MHz wall clock: a peer that never arrives must not hang the GPU
 
+// Every access to a receive buffer is a relaxed system-scope atomic: the buffers are fine-grained memory (not cached by this
+// GPU), so coherence is per access and no cache-wide write-back / invalidate (what a system-scope FENCE costs on this part: the
+// whole L2, serialised per XCD) is ever needed; ordering comes from completion: the sender's stores are acknowledged (s_waitcnt
+// vmcnt(0), which the barrier carries) before it stores the flag, the receiver issues its data loads after its flag loads have
+// returned the sequence number.
 __device__ __forceinline__ bool spin_until(const unsigned long long *flag, unsigned long long seq)
 {
     const long long t0 = wall_clock64();
-    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
         if (wall_clock64() - t0 > kSpinTicks) return false;
         __builtin_amdgcn_s_sleep(2);
     }
@@ -26,21 +31,26 @@ __device__ __forceinline__ void wait_and_sum(double *out, int n, const mqs_peer_
     for (int f = tid; f < rv.world * rv.flags_per_rank; f += nthreads)
         ok = spin_until(rv.flags + (f / rv.flags_per_rank) * rv.flags_stride + f % rv.flags_per_rank, rv.seq) && ok;
     if (!ok) *rv.timeout_flag = 1;
-    __syncthreads();
-    __threadfence_system();
-    const volatile double *r = rv.rows;
+    __syncthreads();                     // also keeps the compiler from moving the data loads above the flag loads
     for (int i = tid; i < n; i += nthreads) {
         double t = 0.0;
-        for (int q = 0; q < rv.world; ++q) t += r[(size_t)q * rv.row_stride + i];
+        for (int q = 0; q < rv.world; ++q)
+            t += __hip_atomic_load(rv.rows + (size_t)q * rv.row_stride + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         out[i] = t;
     }
 }
 
-// after this thread's stores of its piece of the row: make them visible system-wide, then raise the piece's flag in every rank
+// store of one entry of this rank's row into every rank's receive buffer
+__device__ __forceinline__ void push_entry(const mqs_peer_push &push, int i, double v)
+{
+    for (int q = 0; q < push.world; ++q) __hip_atomic_store(push.dst[q] + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// after a barrier behind the stores of a piece of the row (s_waitcnt vmcnt(0) + s_barrier: they have landed): raise the
+// piece's flag in every rank (lanes 0 .. world-1 of one wave)
 __device__ __forceinline__ void publish_piece(const mqs_peer_push &push, int piece, int lane)
 {
-    __threadfence_system();
-    if (lane < push.world) __hip_atomic_store(push.flag[lane] + piece, push.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (lane < push.world) __hip_atomic_store(push.flag[lane] + piece, push.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 }  // namespace peer
