@@ -256,14 +256,14 @@ class BundleAdjuster:
             cost += 0.5 * float(e.dot(e))
         return cost
 
-    def optimize(self, iters=10, mode="gn", verbose=False, damping="marquardt"):
+    def optimize(self, iters=10, mode="gn", verbose=False, damping="gtsam"):
         """
         mode="gn": `iters` Gauss-Newton iterations (cost recorded before each and at the end).
         mode="lm": Levenberg-Marquardt with GTSAM 3.2.1's default schedule (lambda0 1e-5, factor
         10, relative/absolute error tolerance 1e-5, <= 100 iterations): bundle_adjust.cpp:323-324.
-        damping: "marquardt" scales the diagonals by (1 + lambda) (this build's default: invariant to the units of the
-        variables); "gtsam" adds lambda * I, GTSAM 3.2.1's default (diagonalDamping = false) -- the same optimum, the
-        reference's iterate path.  Returns the cost history (host floats).
+        damping: "gtsam" (default) adds lambda * I, GTSAM 3.2.1's default (diagonalDamping = false): the reference's iterate
+        path; "marquardt" scales the diagonals by (1 + lambda) (invariant to the units of the variables; the default until
+        round 3) -- the same optimum.  Returns the cost history (host floats).
         """
         sgn = {"marquardt": 1.0, "gtsam": -1.0}[damping]
         hist = []

@@ -224,8 +224,15 @@ __global__ __launch_bounds__(kBlock, 2) void ba_linearize_kernel(
 #ifndef MQS_WL_ONLY_NODIST
 #define MQS_WL_ONLY_NODIST 0
 #endif
-constexpr int kWaveLinMaxL = 4;            // landmarks per lane and chunk
-constexpr int kWaveLinLdsL = 3;            // of which this many park their six doubles per camera in LDS; the fourth one's live in AGPRs
+#ifndef MQS_WL_MAXL                        // A/B builds: MQS_WL_MAXL=2 MQS_WL_LDSL=1 MQS_WL_OCC=2 = two waves per SIMD, two landmarks per lane
+#define MQS_WL_MAXL 4
+#define MQS_WL_LDSL 3
+#define MQS_WL_OCC 1
+#endif
+constexpr int kWaveLinMaxL = MQS_WL_MAXL;  // landmarks per lane and chunk
+constexpr int kWaveLinLdsL = MQS_WL_LDSL;  // of which this many park their six doubles per camera in LDS; the last one's live in AGPRs
+constexpr int kWaveLinOcc = MQS_WL_OCC;    // workgroups per CU (waves per SIMD)
+static_assert(kWaveLinMaxL <= kWaveLinLdsL + 1, "one landmark's stash fits the accumulation registers");
 
 // sum over the 64 lanes of 4 values per lane: lane l ends with the total of v[l >> 4]
 __device__ __forceinline__ double wave_reduce4(double (&v)[4], int lane)
@@ -618,7 +625,7 @@ __device__ __forceinline__ void wl_chunk(const double *sCam, const WlStash stash
 }
 
 template <int C>
-__global__ __launch_bounds__(kBlock, 1) void ba_linearize_wave_kernel(
+__global__ __launch_bounds__(kBlock, kWaveLinOcc) void ba_linearize_wave_kernel(
     const double *__restrict__ poses, const double *__restrict__ calib, const double *__restrict__ sigma,
     const double *__restrict__ points, const double *__restrict__ obs, const uint8_t *__restrict__ mask,
     const double *__restrict__ prior_w, const double *__restrict__ prior_xyz, int64_t N, double lambda,
@@ -664,9 +671,13 @@ __global__ __launch_bounds__(kBlock, 1) void ba_linearize_wave_kernel(
 #if defined(MQS_WL_ONLY_L4)      // ISA counting only (tools/isa_mix.py --define MQS_WL_ONLY_L4 [--define MQS_WL_ONLY_NODIST=1]): one body
         wl_chunk<C, 4, MQS_WL_ONLY_NODIST>(sCam, stash, points, obs2, mask, prior_w, prior_xyz, N, lambda, r, lane, tot);
 #else
-        if (nl == 4) MQS_WL_CALL(4);
-        else if (nl == 3) MQS_WL_CALL(3);
-        else if (nl == 2) MQS_WL_CALL(2);
+#if MQS_WL_MAXL >= 4
+        if (nl == 4) MQS_WL_CALL(4); else
+#endif
+#if MQS_WL_MAXL >= 3
+        if (nl == 3) MQS_WL_CALL(3); else
+#endif
+        if (nl == 2) MQS_WL_CALL(2);
         else MQS_WL_CALL(1);
 #endif
 #undef MQS_WL_CALL
@@ -1390,7 +1401,7 @@ static int ba_linearize_parts(const double *poses, const double *calib, const do
         const int64_t rows = (N + 63) / 64;
         int grid = (int)((rows + kWaves - 1) / kWaves);
         if (grid < 1) grid = 1;
-        if (grid > 256) grid = 256;
+        if (grid > 256 * kWaveLinOcc) grid = 256 * kWaveLinOcc;
         const size_t lds = (size_t)kWaveLinLdsL * C * 3 * kBlock * sizeof(double2) + (size_t)kWaves * 352 * sizeof(double);   // 352 = Layout<4>'s row, the largest here
         switch (C) {
 #define MQS_CASE(c)                                                                                        \

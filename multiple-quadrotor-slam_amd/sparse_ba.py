@@ -199,11 +199,13 @@ class SparseBundleAdjuster:
         self.poses, self.poses_new = self.poses_new, self.poses
         self.points, self.points_new = self.points_new, self.points
 
-    def optimize(self, iters=LM_MAX_ITERATIONS, mode="lm", verbose=False, damping="marquardt"):
+    def optimize(self, iters=LM_MAX_ITERATIONS, mode="lm", verbose=False, damping="gtsam"):
         """mode "lm": GTSAM 3.2.1's default Levenberg-Marquardt schedule (bundle_adjust.cpp:323-324);
-        mode "gn": plain Gauss-Newton.  damping: "marquardt" scales the diagonals by (1 + lambda) (default here);
-        "gtsam" adds lambda * I as GTSAM 3.2.1's default parameters do (diagonalDamping = false): same optimum, the
-        reference's iterate path.  Returns the cost history."""
+        mode "gn": plain Gauss-Newton.  damping: "gtsam" (default) adds lambda * I to the landmark blocks and to the reduced
+        system, as GTSAM 3.2.1's default LevenbergMarquardtParams do (diagonalDamping = false) -- what the optimiser of
+        bundle_adjust.cpp:323-324 runs; "marquardt" scales the diagonals by (1 + lambda) instead (invariant to the units of
+        the variables; this build's default until round 3): the same optimum by a different iterate path.
+        Returns the cost history."""
         sgn = {"marquardt": 1.0, "gtsam": -1.0}[damping]
         hist = [self.cost()]
         if mode == "gn":

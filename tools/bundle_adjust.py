@@ -9,7 +9,8 @@ CLI-compatible counterpart of the reference's `bundle_adjust` tool
 Reads the BA_info.* / traj_out.* / map_out-*.pcd file set, runs the full (batch Levenberg-Marquardt)
 optimisation on the GPU -- the reference's iSAM_version = 0 mode, the one its ReadMe says works on slam2
 data -- and writes traj_out.camC-<baseName>-BA.txt and map_out-<baseName>-BA.pcd.  useOdometry adds the
-BetweenFactors of the odometry files (default 1, like the reference).  iSAM1/iSAM2 and in-memory
+BetweenFactors of the odometry files (default 1, like the reference).  The damping is GTSAM's default additive form
+(environment MQS_BA_DAMPING=marquardt: diagonal scaling).  iSAM1/iSAM2 and in-memory
 generation are outside the accelerated path.
 """
 import os
@@ -44,7 +45,9 @@ def main(argv):
     print("Running full optimization (Levenberg-Marquardt) on %d 3D points and %d camera(s) with each %d frames."
           % (len(problem.points), nr_cameras, len(data.point3DAddedIdxs)))
     ba = mqslam_amd.sparse_ba.SparseBundleAdjuster(problem)
-    hist = ba.optimize(mode="lm", verbose=False)
+    # Levenberg-Marquardt with GTSAM 3.2.1's default parameters, additive damping included (diagonalDamping = false): what
+    # bundle_adjust.cpp:323-324 runs.  MQS_BA_DAMPING=marquardt selects the diagonal scaling instead (same optimum).
+    hist = ba.optimize(mode="lm", verbose=False, damping=os.environ.get("MQS_BA_DAMPING", "gtsam"))
     print("cost %.6e -> %.6e in %d iterations" % (hist[0], hist[-1], len(hist) - 1))
     io.update_data_with_estimate(data, ba.problem, ba.poses.cpu().numpy(), ba.points.cpu().numpy())
     io.save_result(fn, data)
