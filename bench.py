@@ -44,13 +44,42 @@ HBM_PEAK_GBPS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 
 FP64_VALU_PEAK_TFLOPS = 78.6    # same guide: 256 CUs x 4 SIMDs x 16 fp64 FMA lanes x 2 flop x 2.4 GHz (vector, not matrix)
 
 
+def _evidence():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import evidence_stamp
+    return evidence_stamp
+
+
 def kernel_flops():
     """fp64 flop and VALU instructions per landmark of the fp64-bound kernels, counted from the gfx950 ISA by
-    tools/isa_mix.py (static count x loop trip counts; FMA = 2 flop): profiles/kernel_flops.json."""
+    tools/isa_mix.py (static count x loop trip counts; FMA = 2 flop): profiles/kernel_flops.json.  A record whose `source`
+    digest no longer matches the kernel sources of this tree is dropped (tools/evidence_stamp.py): the caller then reports
+    the figure as null instead of a constant that has outlived its kernel."""
     try:
-        return json.load(open(os.path.join(ROOT, "profiles", "kernel_flops.json")))
+        data = json.load(open(os.path.join(ROOT, "profiles", "kernel_flops.json")))
+        ev = _evidence()
+        return {k: v for k, v in data.items() if isinstance(v, dict) and ev.is_current(v.get("source"))}
     except Exception:
         return {}
+
+
+def pmc_traffic():
+    """profiles/pmc_traffic.json with the per-kernel-family figures whose sources have changed since the PMC pass removed:
+    (record, stale_families)."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        ev = _evidence()
+        stale = [fam for fam in ("ba", "tri") if not ev.is_current(rec.get("sources", {}).get(fam))]
+        for key in list(rec):
+            if (key.startswith("ba_") and "ba" in stale) or (key.startswith(("iterative_ls", "linear_ls", "linear_eigen")) and "tri" in stale):
+                rec[key] = None
+        if "tri" in stale and isinstance(rec.get("valu"), dict):
+            rec["valu"]["iterative_ls"] = None
+        if "ba" in stale and isinstance(rec.get("valu"), dict):
+            rec["valu"]["ba_linearize_schur"] = None
+        return rec, stale
+    except Exception:
+        return {}, ["ba", "tri"]
 
 
 def ba_strong_leg(mq, np, torch, total, C, rank, world, dev, group, dist, iters=10):
@@ -323,15 +352,10 @@ def main():
     achieved = bytes_it / (ms_it * 1e-3) / 1e9
     traffic = None
     valu = None
-    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc_path):
-        try:
-            rec = json.load(open(pmc_path))
-            if rec.get("landmarks") == N and rec.get("cams") == C:
-                traffic = rec.get("iterative_ls_hbm_bytes_per_launch")
-                valu = rec.get("valu")
-        except Exception:
-            traffic = None
+    pmc_rec, pmc_stale = pmc_traffic()
+    if pmc_rec.get("landmarks") == N and pmc_rec.get("cams") == C:
+        traffic = pmc_rec.get("iterative_ls_hbm_bytes_per_launch")
+        valu = pmc_rec.get("valu")
     valu_it = dict((valu or {}).get("iterative_ls") or {})
     if valu_it.get("fp64_flop_per_landmark_static_count"):
         tf = valu_it["fp64_flop_per_landmark_static_count"] * N / (ms_it * 1e-3) / 1e12
@@ -472,8 +496,8 @@ def main():
         flop = kf.get("fp64_flop_per_landmark")
         bytes_lin = N * (24 + 16 * C) + (8 * N if ba.prior_w is not None else 0)
         hbm = {"achieved": round(bytes_lin / (ms_lin * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-               "algorithmic_bytes_per_launch": bytes_lin, "traffic": (json.load(open(pmc_path)).get("ba_linearize_hbm_bytes_per_launch")
-                                                                       if os.path.exists(pmc_path) and N == 1_000_000 else None)}
+               "algorithmic_bytes_per_launch": bytes_lin,
+               "traffic": pmc_rec.get("ba_linearize_hbm_bytes_per_launch") if (pmc_rec.get("landmarks") == N and pmc_rec.get("cams") == C) else None}
         hbm["frac"] = round(hbm["achieved"] / HBM_PEAK_GBPS, 4)
         if flop:
             tf = flop * N / (ms_lin * 1e-3) / 1e12
@@ -487,8 +511,11 @@ def main():
                                 "fp64 vector issue, not HBM: `frac` = counted fp64 flop / time against the 78.6 TFLOP/s vector peak; "
                                 "`hbm` is the same launch against the 8 TB/s roof SURVEY 8(d) assigns it"}
         else:
-            roofline = dict(rooflines["ba_linearize_schur"], kernel="ba_linearize_kernel<%d>" % C, traffic=hbm["traffic"], hbm=hbm,
-                            avg_launch_ms=round(ms_lin, 5))
+            # no current flop count for this tree's kernel (profiles/kernel_flops.json is stale or missing): the HBM view only
+            roofline = dict(rooflines["ba_linearize_schur"], kernel="ba_linearize_wave_kernel<%d>" % C, traffic=hbm["traffic"], hbm=hbm,
+                            avg_launch_ms=round(ms_lin, 5), fp64_flop_per_landmark=None,
+                            stale="profiles/kernel_flops.json does not match the kernel sources (tools/evidence_stamp.py)")
+        roofline["static_evidence_stale"] = pmc_stale or None
     if "hbm" not in roofline:
         roofline["hbm"] = {"achieved": roofline["achieved"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": roofline["frac"]}
     if match_out is not None:

@@ -514,6 +514,39 @@ int mqs_fast_detect_dev(const uint8_t *img, int W, int H, int threshold, int non
 int64_t mqs_fast_workspace_bytes(int W, int H);
 
 /* ---------------------------------------------------------------------------------------
+ * The per-frame loop resident on the device (BASELINE configs[4]; slam2.py handle_new_frame :360-695, main :1136-1253):
+ * the live tracks, their base-keyframe positions, the map (float32 values, :19) and the poses stay in device memory; a frame
+ * is ONE call that enqueues pyramidal LK of the live tracks, the status / error filter and the two early gates, all RANSAC
+ * hypotheses + selection + solvePnP on the inliers, the outlier-ratio and reprojection gates, the commit of the kept tracks
+ * and the keyframe test, waits for a 320-byte result block, and on a keyframe enqueues -- without waiting -- the keyframe
+ * step (triangulate the free tracks, refine the pose, re-triangulate), the map update, the coverage mask, goodFeaturesToTrack
+ * and the top-up of the tracks.  Thresholds default to slam2.py:1070-1098.  Images are DEVICE pointers (8-bit, W x H, dense)
+ * that must stay valid until the next call returns.  csrc/slam_frame.hip.
+ *   mqs_slam_start   first frame: pose from n0 known 3-D points (HOST float32 objp0 [n0][3], imgp0 [n0][2]), which become
+ *                    the first landmarks and tracks; the other tracks from goodFeaturesToTrack.  pose_out [12] host.
+ *   mqs_slam_track   result [40] host doubles: [0] decision (0 rejected, 1 frame, 2 keyframe), [1] rejection reason (1 lost
+ *                    tracks, 2 < 8 landmark tracks, 3 no RANSAC model, 4 outlier ratio, 5 reprojection error), [2] tracks kept,
+ *                    [3] landmark tracks, [4] inliers, [5] / [6] old / new point sets of the keyframe step, [7] lost ratio,
+ *                    [8] outlier ratio, [9] reprojection RMS, [10] homography w0 / w2, [11] landmarks, [12..23] pose (3x4
+ *                    world -> camera; a keyframe's before refinement); [24..39]: the report of the PREVIOUS call's keyframe
+ *                    branch, which runs behind the call that started it -- [24] valid, [25] landmarks added, [26] tracks
+ *                    after the top-up, [27] landmarks, [28..39] refined pose.  mqs_slam_flush: that block once the stream
+ *                    has drained (after the last frame).
+ *   mqs_slam_read_tracks / _read_map   the state, for recorders and tests (synchronise the handle's stream).
+ * ------------------------------------------------------------------------------------- */
+typedef struct mqs_slam mqs_slam;
+int mqs_slam_create(int device, int W, int H, const double *intr, int target_keypoints, double coverage_radius,
+                    double quality_level, int max_landmarks, uint64_t seed, mqs_slam **out);
+void mqs_slam_destroy(mqs_slam *s);
+int mqs_slam_set_thresholds(mqs_slam *s, double max_of_error, double max_lost_tracks_ratio, double max_reproj_error,
+                            double max_outlier_ratio, double homography_condition_threshold);
+int mqs_slam_start(mqs_slam *s, const uint8_t *img_dev, const float *objp0, const float *imgp0, int n0, double *pose_out);
+int mqs_slam_track(mqs_slam *s, const uint8_t *prev_img_dev, const uint8_t *img_dev, double *result);
+int mqs_slam_flush(mqs_slam *s, double *result);
+int mqs_slam_read_tracks(mqs_slam *s, float *pts, float *base, int32_t *lm, int32_t *tid, int cap, int32_t *n);
+int mqs_slam_read_map(mqs_slam *s, float *objp, int cap, int32_t *n);
+
+/* ---------------------------------------------------------------------------------------
  * Timing helper used by bench.py: average duration (ms) of `reps` back-to-back launches of
  * one triangulation kernel measured with hipEvents on `stream` (kernel: 0 = linear_ls,
  * 1 = iterative_ls, 2 = linear_eigen; 10 / 11 / 12: the same with `u` pointing at float32 observations).

@@ -19,6 +19,7 @@ from . import pnp                        # noqa: F401
 from . import features                   # noqa: F401
 from . import slam_replay                # noqa: F401
 from . import slam_loop                  # noqa: F401
+from . import slam_device                # noqa: F401
 from . import slam_frontend              # noqa: F401
 from . import triangulation_comparison   # noqa: F401
 

@@ -162,6 +162,15 @@ SIGNATURES = {
     "mqs_match_ratio_unique_workspace_bytes": (c_i64, [c_i64]),
     "mqs_match_radius_ratio_unique": (ctypes.c_int, [c_vp, c_f32p, c_i64, c_f32p, c_i64, ctypes.c_int, ctypes.c_float,
                                                      ctypes.c_double, c_f32p, c_i32p, c_f32p]),
+    "mqs_slam_create": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_f64p, ctypes.c_int, ctypes.c_double, ctypes.c_double,
+                                       ctypes.c_int, ctypes.c_uint64, ctypes.POINTER(c_vp)]),
+    "mqs_slam_destroy": (None, [c_vp]),
+    "mqs_slam_set_thresholds": (ctypes.c_int, [c_vp] + [ctypes.c_double] * 5),
+    "mqs_slam_start": (ctypes.c_int, [c_vp, c_vp, c_f32p, c_f32p, ctypes.c_int, c_f64p]),
+    "mqs_slam_track": (ctypes.c_int, [c_vp, c_vp, c_vp, c_f64p]),
+    "mqs_slam_flush": (ctypes.c_int, [c_vp, c_f64p]),
+    "mqs_slam_read_tracks": (ctypes.c_int, [c_vp, c_f32p, c_f32p, c_i32p, c_i32p, ctypes.c_int, c_i32p]),
+    "mqs_slam_read_map": (ctypes.c_int, [c_vp, c_f32p, ctypes.c_int, c_i32p]),
     "mqs_time_triangulate_dev": (ctypes.c_int, [ctypes.c_int, c_vp, c_vp, ctypes.c_int, c_i64, ctypes.c_double,
                                                 ctypes.c_int, c_vp, c_vp, c_vp, ctypes.c_int, c_vp,
                                                 ctypes.POINTER(ctypes.c_float)]),

@@ -549,11 +549,12 @@ __device__ __forceinline__ float bilinear_u8(const uint8_t *__restrict__ a, int 
     return (((float)p[0] * w00 + (float)p[1] * w01) + (float)p[W] * w10) + (float)p[W + 1] * w11;
 }
 
-__global__ __launch_bounds__(64) void lk_kernel(LkLevels L, const float *__restrict__ prev_pts, int n, int ww, int wh,
-                                               int max_iter, float eps, float min_eig_threshold, float *__restrict__ next_pts,
-                                               uint8_t *__restrict__ status, float *__restrict__ err)
+__global__ __launch_bounds__(64) void lk_kernel(LkLevels L, const float *__restrict__ prev_pts, int n, const int32_t *__restrict__ n_dev,
+                                               int ww, int wh, int max_iter, float eps, float min_eig_threshold,
+                                               float *__restrict__ next_pts, uint8_t *__restrict__ status, float *__restrict__ err)
 {
     const int k = blockIdx.x, lane = threadIdx.x;
+    if (n_dev) n = min(n, *n_dev);                  // the device-resident loop: the number of live tracks is device state
     if (k >= n) return;
     const int npix = ww * wh;
     const float halfx = (float)(ww - 1) * 0.5f, halfy = (float)(wh - 1) * 0.5f;
@@ -876,13 +877,23 @@ int mqs_calc_optical_flow_pyr_lk_dev(const uint8_t *prev_img, const uint8_t *nex
                                      double min_eig_threshold, float *next_pts, uint8_t *status, float *err, void *workspace,
                                      int64_t workspace_bytes, void *stream_)
 {
+    return mqs_lk_launch(prev_img, next_img, W, H, prev_pts, n, nullptr, win_w, win_h, max_level, max_iter, eps, min_eig_threshold,
+                         next_pts, status, err, workspace, workspace_bytes, static_cast<hipStream_t>(stream_));
+}
+
+}  // extern "C"
+
+// n = capacity of the point arrays (one wavefront each is launched); n_dev (device, may be null): the live count
+int mqs_lk_launch(const uint8_t *prev_img, const uint8_t *next_img, int W, int H, const float *prev_pts, int n, const int32_t *n_dev,
+                  int win_w, int win_h, int max_level, int max_iter, double eps, double min_eig_threshold, float *next_pts,
+                  uint8_t *status, float *err, void *workspace, int64_t workspace_bytes, hipStream_t stream)
+{
     MQS_ARG_CHECK(prev_img && next_img && workspace, "pointers must not be null");
     MQS_ARG_CHECK(n >= 0 && (n == 0 || (prev_pts && next_pts && status && err)), "point arrays must not be null");
     MQS_ARG_CHECK(W >= 3 && H >= 3 && max_level >= 0 && max_level < kMaxLevels, "W, H >= 3; 0 <= max_level < 8");
     MQS_ARG_CHECK(win_w >= 3 && win_h >= 3 && win_w * win_h <= 64 * kMaxWinPixelsPerLane, "3 <= window, at most 1024 pixels");
     MQS_ARG_CHECK(max_iter >= 1 && eps >= 0.0, "max_iter >= 1, eps >= 0");
     MQS_ARG_CHECK(workspace_bytes >= mqs_lk_workspace_bytes(W, H, max_level), "workspace too small (mqs_lk_workspace_bytes)");
-    hipStream_t stream = static_cast<hipStream_t>(stream_);
     LkLevels L;
     char *wsp = static_cast<char *>(workspace);
     int w = W, h = H;
@@ -909,11 +920,13 @@ int mqs_calc_optical_flow_pyr_lk_dev(const uint8_t *prev_img, const uint8_t *nex
         w = wd; h = hd;
     }
     if (n > 0)
-        hipLaunchKernelGGL(lk_kernel, dim3(n), dim3(64), 0, stream, L, prev_pts, n, win_w, win_h, max_iter, (float)eps,
+        hipLaunchKernelGGL(lk_kernel, dim3(n), dim3(64), 0, stream, L, prev_pts, n, n_dev, win_w, win_h, max_iter, (float)eps,
                            (float)min_eig_threshold, next_pts, status, err);
     MQS_HIP_CHECK(hipGetLastError());
     return MQS_OK;
 }
+
+extern "C" {
 
 int64_t mqs_fast_workspace_bytes(int W, int H)
 {

@@ -67,6 +67,19 @@ int mqs_ba_tail_launch(const double *lin, const mqs_peer_recv *peer, int C, cons
                        const uint8_t *prior_mask, double *lin_out, double *dpose, double *poses_out, double *info,
                        double *points_out, hipStream_t stream);
 
+// Launchers the device-resident frame loop (slam_frame.hip) shares with the public entry points.  `n` / `N` are CAPACITIES
+// (grids and workspaces are sized for them); n_dev (device memory, may be null) holds the live count the kernels use.
+int mqs_lk_launch(const uint8_t *prev_img, const uint8_t *next_img, int W, int H, const float *prev_pts, int n, const int32_t *n_dev,
+                  int win_w, int win_h, int max_level, int max_iter, double eps, double min_eig_threshold, float *next_pts,
+                  uint8_t *status, float *err, void *workspace, int64_t workspace_bytes, hipStream_t stream);
+int mqs_pnp_ransac_launch(const double *objp, const double *imgp, int N, const int32_t *n_dev, const double *intr,
+                          const int32_t *samples, int B, int sample_size, double reproj_error, int sample_iters, int max_iter,
+                          double eps, double *pose_out, int32_t *sel_out, uint8_t *mask, double *info, void *workspace,
+                          hipStream_t stream);
+int mqs_keyframe_step_launch(const double *objp, const double *imgp, int n_old, const double *p0, const double *p1, int n_new,
+                             const double *intr, const double *P_prev, const double *P0, double tolerance, int max_iter, double eps,
+                             double *scratch, double *pose_out, double *x_out, int32_t *status_out, double *info, hipStream_t stream);
+
 // comm.hip: releases ctx->comm (called by mqs_destroy)
 void mqs_comm_release(mqs_ctx *ctx);
 

@@ -183,6 +183,11 @@ __global__ __launch_bounds__(kWave) void pnp_refine_kernel(const double *__restr
     double P[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) P[k] = poses_in ? poses_in[12 * b + k] : ((k % 5 == 0) ? 1.0 : 0.0);
+    if (pr.end - pr.begin < 3) {                    // no problem (a rejected frame of the device-resident loop): the start pose
+        if (lane < 12) poses_out[12 * b + lane] = P[lane];
+        if (info && lane < 4) info[4 * b + lane] = lane == 3 ? 2.0 : 0.0;
+        return;
+    }
     int flags = 0;
     if (!use_guess) {
         double Pd[12];
@@ -207,7 +212,8 @@ __global__ __launch_bounds__(kWave) void pnp_refine_kernel(const double *__restr
 
 // One RANSAC hypothesis per wave: DLT of its sample, LM on the sample, inlier count over all N points.
 __global__ __launch_bounds__(kWave) void pnp_hypothesis_kernel(const double *__restrict__ objp, const double *__restrict__ imgp,
-                                                              int N, const double *__restrict__ intr,
+                                                              int N, const int32_t *__restrict__ n_dev,
+                                                              const double *__restrict__ intr,
                                                               const int32_t *__restrict__ samples, int sample_size,
                                                               int sample_iters, double thr2, double *__restrict__ poses,
                                                               int32_t *__restrict__ counts)
@@ -215,6 +221,13 @@ __global__ __launch_bounds__(kWave) void pnp_hypothesis_kernel(const double *__r
     __shared__ double sI[9];
     __shared__ double sA[132];
     const int lane = threadIdx.x, h = blockIdx.x;
+    if (n_dev) {                                     // the device-resident loop: the number of correspondences is device state
+        N = *n_dev;
+        if (N < sample_size) {                       // the frame was rejected before the pose step: nothing to do
+            if (lane == 0) counts[h] = -1;
+            return;
+        }
+    }
     if (lane < 9) sI[lane] = intr[lane];
     __syncthreads();
     const Problem pr = {objp, imgp, samples, h * sample_size, (h + 1) * sample_size};
@@ -242,7 +255,8 @@ __global__ __launch_bounds__(kWave) void pnp_hypothesis_kernel(const double *__r
 // out_sel: [0] best hypothesis (-1: none valid), [1] inlier count; ptr2 = {0, inlier count}.
 constexpr int kSelBlock = 256;
 __global__ __launch_bounds__(kSelBlock) void pnp_select_kernel(const double *__restrict__ objp, const double *__restrict__ imgp,
-                                                              int N, const double *__restrict__ intr,
+                                                              int N, const int32_t *__restrict__ n_dev,
+                                                              const double *__restrict__ intr,
                                                               const double *__restrict__ poses, const int32_t *__restrict__ counts,
                                                               int B, double thr2, double *__restrict__ best_pose,
                                                               int32_t *__restrict__ out_sel, int32_t *__restrict__ ptr2,
@@ -251,6 +265,7 @@ __global__ __launch_bounds__(kSelBlock) void pnp_select_kernel(const double *__r
     __shared__ double sI[9], sP[12];
     __shared__ int sBestC[kSelBlock], sBestH[kSelBlock], sWave[kSelBlock / 64], sBase;
     const int tid = threadIdx.x;
+    if (n_dev) N = *n_dev;
     if (tid < 9) sI[tid] = intr[tid];
     int bc = -1, bh = -1;
     for (int h = tid; h < B; h += kSelBlock)
@@ -504,7 +519,18 @@ int mqs_pnp_ransac_dev(const double *objp, const double *imgp, int64_t N, const 
     MQS_ARG_CHECK(reproj_error >= 0.0 && sample_iters >= 0 && max_iter >= 0 && eps >= 0.0, "non-negative parameters");
     MQS_ARG_CHECK(pose_out && sel_out, "pose_out, sel_out must not be null");
     MQS_ARG_CHECK(workspace && workspace_bytes >= mqs_pnp_workspace_bytes(N, B), "workspace too small (mqs_pnp_workspace_bytes)");
-    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    return mqs_pnp_ransac_launch(objp, imgp, (int)N, nullptr, intr, samples, B, sample_size, reproj_error, sample_iters, max_iter, eps,
+                                 pose_out, sel_out, mask, info, workspace, static_cast<hipStream_t>(stream_));
+}
+
+}  // extern "C"
+
+// N = capacity (workspace sized for it); n_dev (device, may be null): the live number of correspondences
+int mqs_pnp_ransac_launch(const double *objp, const double *imgp, int N, const int32_t *n_dev, const double *intr,
+                          const int32_t *samples, int B, int sample_size, double reproj_error, int sample_iters, int max_iter,
+                          double eps, double *pose_out, int32_t *sel_out, uint8_t *mask, double *info, void *workspace,
+                          hipStream_t stream)
+{
     auto up = [](int64_t v) { return (v + 255) & ~int64_t(255); };
     char *w = static_cast<char *>(workspace);
     double *poses = reinterpret_cast<double *>(w); w += up((int64_t)B * 96);
@@ -512,19 +538,30 @@ int mqs_pnp_ransac_dev(const double *objp, const double *imgp, int64_t N, const 
     int32_t *ptr2 = reinterpret_cast<int32_t *>(w); w += up(8);
     int32_t *inl = reinterpret_cast<int32_t *>(w);
     const double thr2 = reproj_error * reproj_error;
-    hipLaunchKernelGGL(pnp_hypothesis_kernel, dim3(B), dim3(kWave), 0, stream, objp, imgp, (int)N, intr, samples,
+    hipLaunchKernelGGL(pnp_hypothesis_kernel, dim3(B), dim3(kWave), 0, stream, objp, imgp, N, n_dev, intr, samples,
                        sample_size, sample_iters, thr2, poses, counts);
     // best hypothesis -> pose_out (used as the start of the final refinement), inliers -> inl / mask
-    hipLaunchKernelGGL(pnp_select_kernel, dim3(1), dim3(kSelBlock), 0, stream, objp, imgp, (int)N, intr, poses, counts, B,
+    hipLaunchKernelGGL(pnp_select_kernel, dim3(1), dim3(kSelBlock), 0, stream, objp, imgp, N, n_dev, intr, poses, counts, B,
                        thr2, pose_out, sel_out, ptr2, inl, mask);
     // OpenCV 2.4 solvePnPRansac ends with solvePnP on the inliers, started from the best model
-    hipLaunchKernelGGL(pnp_refine_kernel, dim3(1), dim3(kWave), 0, stream, objp, imgp, (int)N, inl, ptr2, intr, pose_out, 1,
+    hipLaunchKernelGGL(pnp_refine_kernel, dim3(1), dim3(kWave), 0, stream, objp, imgp, N, inl, ptr2, intr, pose_out, 1,
                        max_iter, eps, pose_out, info);
     MQS_HIP_CHECK(hipGetLastError());
     return MQS_OK;
 }
 
-}  // extern "C"
+// the keyframe step on device-resident inputs (scratch: 9 n_new + 1 doubles + n_new ints when the step does not fit the LDS)
+int mqs_keyframe_step_launch(const double *objp, const double *imgp, int n_old, const double *p0, const double *p1, int n_new,
+                             const double *intr, const double *P_prev, const double *P0, double tolerance, int max_iter, double eps,
+                             double *scratch, double *pose_out, double *x_out, int32_t *status_out, double *info, hipStream_t stream)
+{
+    const size_t lds_bytes = ((size_t)5 * n_old + (size_t)9 * n_new + 2) * 8 + (size_t)n_new * 4;
+    const bool lds_ok = lds_bytes <= 56 * 1024;
+    hipLaunchKernelGGL(keyframe_step_kernel, dim3(1), dim3(kKfThreads), lds_ok ? lds_bytes : 0, stream, objp, imgp, n_old, p0, p1, n_new,
+                       intr, P_prev, P0, tolerance, max_iter, eps, (int)lds_ok, scratch, pose_out, x_out, status_out, info);
+    MQS_HIP_CHECK(hipGetLastError());
+    return MQS_OK;
+}
 
 // ---------------------------------------------------------------------------------------
 // Host-pointer wrappers

@@ -1,0 +1,759 @@
+// The per-frame loop of the reference resident on the device (gfx950): Work/SLAM/application/own/slam2.py
+// handle_new_frame (:360-695) with the state -- live tracks, their base-keyframe positions, the map, the poses -- kept in
+// device memory, so that a frame is ONE library call that enqueues
+//     pyramids + Scharr derivatives -> pyramidal LK of the live tracks                          (:381)      features.hip
+//     frame_filter_kernel: status / error filter, lost-tracks gate, >= 8 landmarks gate,        (:382-437)
+//                          the 3D-2D correspondences of the triangulated tracks, RANSAC samples
+//     all RANSAC hypotheses -> selection + inliers -> solvePnP on the inliers                   (:453-490)  pnp.hip
+//     frame_decide_kernel: outlier-ratio and reprojection gates, the kept tracks committed,     (:461-522, 43-59)
+//                          keyframe test (homography base keyframe -> frame, w0 / w2 > 1.04)
+// reads back one 320-byte result block (decision, pose, counts) and, on a keyframe, enqueues WITHOUT waiting
+//     keyframe_step_kernel: triangulate the free tracks, refine the pose, re-triangulate       (:541-590)  pnp.hip
+//     keyframe_commit_kernel: new landmarks into the map (float32, :19), failed tracks dropped  (:589-612)
+//     coverage mask -> goodFeaturesToTrack -> append_tracks_kernel: top-up, rebase             (:657-674)  features.hip
+// The host-driven loop (slam_loop.py) spends 1.2-1.4 ms per frame on ~10 host-pointer calls for ~0.25 ms of kernels; here the
+// host's share is one call and one wait.
+//
+// Deviations from the reference, as in slam_loop.py (no image set / OpenCV run of the reference exists to compare with): the
+// homography of the keyframe test is the normalised DLT over ALL kept tracks (cv2.findHomography on a random quarter of them
+// there), RANSAC samples come from a counter-based generator on the device (splitmix64 of seed, frame, hypothesis).
+#include "mqs_common.h"
+#include "pnp_math.h"
+#include "cam_math.h"
+#include "wave_reduce.h"
+#include <new>
+
+namespace {
+
+constexpr int kMaxTracks = 512;                 // capacity of the live-track arrays (the reference tops up to <= 300)
+constexpr int kHyp = 256, kSample = 6;          // RANSAC: hypotheses per frame, points per minimal sample (pnp.py)
+constexpr int kSampleIters = 5, kPnpIters = 100;
+constexpr double kPnpEps = 1e-10;
+constexpr int kRes = 40;                        // doubles in the result block
+
+// counters in device memory
+enum { C_N = 0, C_NLAND, C_NEXT_TID, C_FRAME, C_NTRI, C_NKEEP, C_KF_PENDING, C_SPARE, C_COUNT };
+// result block (doubles)
+enum { R_DECISION = 0, R_REASON, R_NTRACKS, R_NTRI, R_NINL, R_NOLD, R_NNEW, R_LOST, R_OUTLIER, R_REPROJ, R_HOMOGRAPHY, R_NLAND,
+       R_POSE = 12, R_KF_VALID = 24, R_KF_NGOOD, R_KF_NTRACKS, R_KF_NLAND, R_KF_POSE = 28 };
+
+struct SlamDev {
+    int32_t *cnt;
+    float *pts, *base;
+    int32_t *lm, *tid;
+    double *map;
+    double *pose_key, *pose_prev, *intr;
+    float *lk_pts, *lk_err;
+    uint8_t *lk_st;
+    float *t_pts, *t_base;
+    int32_t *t_lm, *t_tid;
+    double *objp_t, *imgp_t;
+    int32_t *tri_pos, *samples;
+    double *pose_r;
+    int32_t *sel;
+    uint8_t *inl_mask;
+    double *pnp_info;
+    double *kf_objp, *kf_imgp, *kf_p0, *kf_p1;
+    int32_t *kf_pos;
+    double *kf_scratch, *kf_pose, *kf_x, *kf_info;
+    int32_t *kf_status;
+    uint8_t *mask;
+    float *gf_xy;
+    int32_t *gf_n;
+    double *res;
+};
+
+struct SlamParams {
+    int W, H, target, max_landmarks;
+    double radius, quality;
+    double max_of_error, max_lost_ratio, max_reproj, max_outlier_ratio, homography_threshold;
+    unsigned long long seed;
+};
+
+// rank of this thread among the flagged threads of the workgroup (thread order), and their number; two barriers
+__device__ __forceinline__ int block_rank(bool flag, int tid, int *sWave, int &total)
+{
+    const unsigned long long bal = __ballot(flag);
+    const int lane = tid & 63, wave = tid >> 6;
+    const int before = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) sWave[wave] = __popcll(bal);
+    __syncthreads();
+    int off = 0;
+    total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        if (w < wave) off += sWave[w];
+        total += sWave[w];
+    }
+    __syncthreads();
+    return off + before;
+}
+
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long &x)
+{
+    unsigned long long z = (x += 0x9e3779b97f4a7c15ull);
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// after LK: which tracks survive (slam2.py:382), the two early gates (:385-387, :437), the pose problem, the samples
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void frame_filter_kernel(SlamDev d, SlamParams p)
+{
+    __shared__ int sWave[4];
+    const int tid = threadIdx.x;
+    const int n = d.cnt[C_N];
+    int n_keep = 0;
+    for (int b = 0; b < n; b += 256) {
+        const int i = b + tid;
+        const bool keep = i < n && d.lk_st[i] == 1 && d.lk_err[i] < (float)p.max_of_error;
+        int total;
+        const int r = n_keep + block_rank(keep, tid, sWave, total);
+        if (keep) {
+            d.t_pts[2 * r] = d.lk_pts[2 * i]; d.t_pts[2 * r + 1] = d.lk_pts[2 * i + 1];
+            d.t_base[2 * r] = d.base[2 * i]; d.t_base[2 * r + 1] = d.base[2 * i + 1];
+            d.t_lm[r] = d.lm[i]; d.t_tid[r] = d.tid[i];
+        }
+        n_keep += total;
+    }
+    __threadfence_block();
+    __syncthreads();
+    const double lost = n > 0 ? 1.0 - (double)n_keep / (double)n : 1.0;
+    int n_tri = 0;
+    for (int b = 0; b < n_keep; b += 256) {
+        const int k = b + tid;
+        const bool tri = k < n_keep && d.t_lm[k] >= 0;
+        int total;
+        const int j = n_tri + block_rank(tri, tid, sWave, total);
+        if (tri) {
+            const int l = d.t_lm[k];
+            d.objp_t[3 * j] = d.map[3 * l]; d.objp_t[3 * j + 1] = d.map[3 * l + 1]; d.objp_t[3 * j + 2] = d.map[3 * l + 2];
+            d.imgp_t[2 * j] = (double)d.t_pts[2 * k]; d.imgp_t[2 * j + 1] = (double)d.t_pts[2 * k + 1];
+            d.tri_pos[j] = k;
+        }
+        n_tri += total;
+    }
+    int reason = 0;
+    if (lost > p.max_lost_ratio) reason = 1;                       // "lost track of too many points"
+    else if (n_tri < 8) reason = 2;                                // fewer than 8 triangulated tracks
+    if (tid == 0) {
+        d.cnt[C_NKEEP] = n_keep;
+        d.cnt[C_NTRI] = reason ? 0 : n_tri;                        // 0 switches the pose kernels off
+        d.res[R_DECISION] = reason ? 0.0 : -1.0;                   // -1: undecided
+        d.res[R_REASON] = (double)reason;
+        d.res[R_LOST] = lost;
+        d.res[R_NTRI] = (double)n_tri;
+    }
+    if (reason) return;
+    // minimal samples without replacement, one hypothesis per thread and pass
+    const int frame = d.cnt[C_FRAME];
+    for (int h = tid; h < kHyp; h += 256) {
+        unsigned long long s = p.seed ^ ((unsigned long long)frame << 24) ^ ((unsigned long long)h * 0x632be59bd9b4e019ull);
+        int pick[kSample];
+#pragma unroll
+        for (int j = 0; j < kSample; ++j) {
+            int v;
+            bool dup;
+            do {
+                v = (int)(splitmix64(s) % (unsigned long long)n_tri);
+                dup = false;
+#pragma unroll
+                for (int q = 0; q < kSample; ++q) dup = dup || (q < j && pick[q] == v);
+            } while (dup);
+            pick[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < kSample; ++j) d.samples[h * kSample + j] = pick[j];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 9 x 9 symmetric eigen-decomposition by parallel cyclic Jacobi (one wavefront; lanes = 4 disjoint rotations x 9 rows), for the
+// null vector of the homography system; 3 x 3 by a single lane for the singular values of the homography.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void jacobi_angle(double app, double aqq, double apq, double &c, double &s)
+{
+    if (fabs(apq) <= 1e-300) { c = 1.0; s = 0.0; return; }
+    const double tau = (aqq - app) / (2.0 * apq);
+    const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+    c = 1.0 / sqrt(1.0 + t * t);
+    s = t * c;
+}
+
+// A, V: LDS [9][9]; on return A's diagonal holds the eigenvalues, V's columns the eigenvectors.  Called by one full wavefront.
+__device__ void jacobi9(double *A, double *V, int lane)
+{
+    const int g = lane / 9, k = lane - 9 * g;                      // rotation slot 0..3 (lanes 36..63 idle), row / column index
+    const bool act = lane < 36;
+    if (lane < 81) V[lane] = (lane % 10 == 0) ? 1.0 : 0.0;
+    if (lane + 64 < 81) V[lane + 64] = ((lane + 64) % 10 == 0) ? 1.0 : 0.0;
+    mqs_wave_lds_sync();
+    for (int sweep = 0; sweep < 8; ++sweep) {
+        for (int r = 0; r < 9; ++r) {
+            // round-robin round r of 9 players: slot g pairs (r + g + 1, r - g - 1) mod 9, player r rests
+            int pa = (r + g + 1) % 9, pb = (r + 9 - g - 1) % 9;
+            const int pp = pa < pb ? pa : pb, q = pa < pb ? pb : pa;
+            double c = 1.0, s = 0.0;
+            if (act) jacobi_angle(A[pp * 9 + pp], A[q * 9 + q], A[pp * 9 + q], c, s);
+            mqs_wave_lds_sync();
+            if (act) {                                             // A <- A J: columns pp, q of row k
+                const double akp = A[k * 9 + pp], akq = A[k * 9 + q];
+                A[k * 9 + pp] = c * akp - s * akq;
+                A[k * 9 + q] = s * akp + c * akq;
+                const double vkp = V[k * 9 + pp], vkq = V[k * 9 + q];
+                V[k * 9 + pp] = c * vkp - s * vkq;
+                V[k * 9 + q] = s * vkp + c * vkq;
+            }
+            mqs_wave_lds_sync();
+            if (act) {                                             // A <- J^T A: rows pp, q of column k
+                const double apk = A[pp * 9 + k], aqk = A[q * 9 + k];
+                A[pp * 9 + k] = c * apk - s * aqk;
+                A[q * 9 + k] = s * apk + c * aqk;
+            }
+            mqs_wave_lds_sync();
+        }
+    }
+}
+
+// eigenvalues of a symmetric 3 x 3 (a: 9 doubles, destroyed), single thread
+__device__ void jacobi3(double *a, double *w)
+{
+    for (int sweep = 0; sweep < 10; ++sweep) {
+        for (int pq = 0; pq < 3; ++pq) {
+            const int p = pq == 2 ? 1 : 0, q = pq == 0 ? 1 : 2;
+            double c, s;
+            jacobi_angle(a[p * 3 + p], a[q * 3 + q], a[p * 3 + q], c, s);
+            for (int k = 0; k < 3; ++k) {
+                const double akp = a[k * 3 + p], akq = a[k * 3 + q];
+                a[k * 3 + p] = c * akp - s * akq; a[k * 3 + q] = s * akp + c * akq;
+            }
+            for (int k = 0; k < 3; ++k) {
+                const double apk = a[p * 3 + k], aqk = a[q * 3 + k];
+                a[p * 3 + k] = c * apk - s * aqk; a[q * 3 + k] = s * apk + c * aqk;
+            }
+        }
+    }
+    w[0] = a[0]; w[1] = a[4]; w[2] = a[8];
+}
+
+// sum over the workgroup, the same value in every thread, fixed order (wave butterflies, then the four waves in order)
+__device__ __forceinline__ double block_sum(double v, int tid, double *sRed /*[4]*/)
+{
+#pragma unroll
+    for (int h = 32; h >= 1; h >>= 1) v += __shfl_xor(v, h);
+    if ((tid & 63) == 0) sRed[tid >> 6] = v;
+    __syncthreads();
+    const double t = ((sRed[0] + sRed[1]) + sRed[2]) + sRed[3];
+    __syncthreads();
+    return t;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// after the pose: gates (slam2.py:461-468, 493-497), commit of the kept tracks (:499-522), keyframe test (:43-59)
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void frame_decide_kernel(SlamDev d, SlamParams p)
+{
+    __shared__ int sWave[4];
+    __shared__ double sRed[4];
+    __shared__ uint8_t sInl[kMaxTracks];
+    __shared__ double sU1[kMaxTracks * 2], sU2[kMaxTracks * 2];
+    __shared__ double sAcc[4][48];
+    __shared__ double sA[81], sV[81];
+    __shared__ double sI[9], sP[12];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) { d.res[R_NTRACKS] = (double)d.cnt[C_N]; d.res[R_NLAND] = (double)d.cnt[C_NLAND]; d.cnt[C_FRAME] += 1; }
+    if (d.res[R_DECISION] == 0.0) return;                          // rejected by the filter: the state is untouched
+    const int n_tri = d.cnt[C_NTRI], n_keep = d.cnt[C_NKEEP];
+    const int best = d.sel[0], ninl = d.sel[1];
+    if (tid < 9) sI[tid] = d.intr[tid];
+    if (tid < 12) sP[tid] = d.pose_r[tid];
+    __syncthreads();
+    const double outlier = n_tri > 0 ? (double)(n_tri - ninl) / (double)n_tri : 1.0;
+    int reason = 0;
+    if (best < 0) reason = 3;                                      // no valid RANSAC model
+    else if (outlier > p.max_outlier_ratio || ninl < 8) reason = 4;
+    // reprojection RMS of the inliers under the refined pose (calibration_tools.py:116-124)
+    double e2 = 0.0;
+    for (int j = tid; j < n_tri; j += 256)
+        if (d.inl_mask[j])
+            e2 += mqs::pnp::reproj_sqerr(sP, sI, d.objp_t[3 * j], d.objp_t[3 * j + 1], d.objp_t[3 * j + 2], d.imgp_t[2 * j], d.imgp_t[2 * j + 1]);
+    const double sq = block_sum(e2, tid, sRed);
+    const double rms = ninl > 0 ? sqrt(sq / (double)ninl) : 0.0;
+    if (!reason && !(rms <= p.max_reproj)) reason = 5;
+    if (tid == 0) {
+        d.res[R_NINL] = (double)ninl; d.res[R_OUTLIER] = outlier; d.res[R_REPROJ] = rms;
+        if (reason) { d.res[R_DECISION] = 0.0; d.res[R_REASON] = (double)reason; }
+    }
+    if (reason) return;
+
+    // commit: inlier landmark tracks and the free tracks stay, in order; the keyframe step's two point sets beside them
+    for (int k = tid; k < n_keep; k += 256) sInl[k] = 1;
+    __syncthreads();
+    for (int j = tid; j < n_tri; j += 256) sInl[d.tri_pos[j]] = d.inl_mask[j];
+    __syncthreads();
+    int n_acc = 0, n_old = 0, n_new = 0;
+    for (int b = 0; b < n_keep; b += 256) {
+        const int k = b + tid;
+        const bool in = k < n_keep && sInl[k] != 0;
+        const bool tri = in && d.t_lm[k] >= 0, fre = in && d.t_lm[k] < 0;
+        int tot, tot_o, tot_n;
+        const int r = n_acc + block_rank(in, tid, sWave, tot);
+        const int ro = n_old + block_rank(tri, tid, sWave, tot_o);
+        const int rn = n_new + block_rank(fre, tid, sWave, tot_n);
+        if (in) {
+            const float px = d.t_pts[2 * k], py = d.t_pts[2 * k + 1], bx = d.t_base[2 * k], by = d.t_base[2 * k + 1];
+            d.pts[2 * r] = px; d.pts[2 * r + 1] = py;
+            d.base[2 * r] = bx; d.base[2 * r + 1] = by;
+            d.lm[r] = d.t_lm[k]; d.tid[r] = d.t_tid[k];
+            if (tri) {
+                const int l = d.t_lm[k];
+                d.kf_objp[3 * ro] = d.map[3 * l]; d.kf_objp[3 * ro + 1] = d.map[3 * l + 1]; d.kf_objp[3 * ro + 2] = d.map[3 * l + 2];
+                d.kf_imgp[2 * ro] = (double)px; d.kf_imgp[2 * ro + 1] = (double)py;
+            } else {
+                d.kf_p0[2 * rn] = (double)bx; d.kf_p0[2 * rn + 1] = (double)by;
+                d.kf_p1[2 * rn] = (double)px; d.kf_p1[2 * rn + 1] = (double)py;
+                d.kf_pos[rn] = r;
+            }
+            // keyframe test inputs: both ends of the track, undistorted
+            mqs::cam::undistort_pixel(sI, (double)bx, (double)by, sU1[2 * r], sU1[2 * r + 1]);
+            mqs::cam::undistort_pixel(sI, (double)px, (double)py, sU2[2 * r], sU2[2 * r + 1]);
+        }
+        n_acc += tot; n_old += tot_o; n_new += tot_n;
+    }
+    __syncthreads();
+    if (tid < 12) d.pose_prev[tid] = sP[tid];
+    if (tid == 0) d.cnt[C_N] = n_acc;
+
+    // normalised DLT homography u2 ~ H u1 over all kept tracks
+    double ratio = 1.0;
+    if (n_acc >= 4) {
+        double c1x = 0, c1y = 0, c2x = 0, c2y = 0;
+        for (int k = tid; k < n_acc; k += 256) { c1x += sU1[2 * k]; c1y += sU1[2 * k + 1]; c2x += sU2[2 * k]; c2y += sU2[2 * k + 1]; }
+        const double inv_n = 1.0 / (double)n_acc;
+        c1x = block_sum(c1x, tid, sRed) * inv_n; c1y = block_sum(c1y, tid, sRed) * inv_n;
+        c2x = block_sum(c2x, tid, sRed) * inv_n; c2y = block_sum(c2y, tid, sRed) * inv_n;
+        double d1 = 0, d2 = 0;
+        for (int k = tid; k < n_acc; k += 256) {
+            d1 += sqrt((sU1[2 * k] - c1x) * (sU1[2 * k] - c1x) + (sU1[2 * k + 1] - c1y) * (sU1[2 * k + 1] - c1y));
+            d2 += sqrt((sU2[2 * k] - c2x) * (sU2[2 * k] - c2x) + (sU2[2 * k + 1] - c2y) * (sU2[2 * k + 1] - c2y));
+        }
+        const double s1 = 1.4142135623730951 / fmax(block_sum(d1, tid, sRed) * inv_n, 1e-12);
+        const double s2 = 1.4142135623730951 / fmax(block_sum(d2, tid, sRed) * inv_n, 1e-12);
+        // the 45 distinct sums of A^T A (rows [a 1 0 0 0 -bx a -bx], [0 0 0 a 1 -by a -by]), per thread, then over the workgroup
+        double acc[45];
+#pragma unroll
+        for (int e = 0; e < 45; ++e) acc[e] = 0.0;
+        for (int k = tid; k < n_acc; k += 256) {
+            const double ax = (sU1[2 * k] - c1x) * s1, ay = (sU1[2 * k + 1] - c1y) * s1;
+            const double bx = (sU2[2 * k] - c2x) * s2, by = (sU2[2 * k + 1] - c2y) * s2;
+            const double r1[9] = {ax, ay, 1.0, 0.0, 0.0, 0.0, -bx * ax, -bx * ay, -bx};
+            const double r2[9] = {0.0, 0.0, 0.0, ax, ay, 1.0, -by * ax, -by * ay, -by};
+            int e = 0;
+#pragma unroll
+            for (int i = 0; i < 9; ++i)
+#pragma unroll
+                for (int j = i; j < 9; ++j, ++e) acc[e] = fma(r1[i], r1[j], fma(r2[i], r2[j], acc[e]));
+        }
+        {
+            double v[32];
+#pragma unroll
+            for (int e = 0; e < 32; ++e) v[e] = acc[e];
+            const double t0 = mqs::wave::wave_reduce32(v, lane);
+#pragma unroll
+            for (int e = 0; e < 32; ++e) v[e] = e < 13 ? acc[32 + e] : 0.0;
+            const double t1 = mqs::wave::wave_reduce32(v, lane);
+            if (!(lane & 1)) { sAcc[wave][lane >> 1] = t0; if ((lane >> 1) < 13) sAcc[wave][32 + (lane >> 1)] = t1; }
+        }
+        __syncthreads();
+        if (tid < 45) {
+            const double t = ((sAcc[0][tid] + sAcc[1][tid]) + sAcc[2][tid]) + sAcc[3][tid];
+            // entry tid = (i, j), i <= j, row-major over the upper triangle
+            int i = 0, rem = tid;
+            while (rem >= 9 - i) { rem -= 9 - i; ++i; }
+            const int j = i + rem;
+            sA[i * 9 + j] = t; sA[j * 9 + i] = t;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            jacobi9(sA, sV, lane);
+            if (lane == 0) {
+                int im = 0;
+                for (int i = 1; i < 9; ++i) if (sA[i * 9 + i] < sA[im * 9 + im]) im = i;
+                double hn[9], h[9], t[9];
+                for (int i = 0; i < 9; ++i) hn[i] = sV[i * 9 + im];
+                // H = inv(Tb) Hn Ta,  Ta = [s1 0 -s1 c1x; 0 s1 -s1 c1y; 0 0 1],  inv(Tb) = [1/s2 0 c2x; 0 1/s2 c2y; 0 0 1]
+                for (int r = 0; r < 3; ++r) {
+                    t[3 * r + 0] = hn[3 * r + 0] * s1;
+                    t[3 * r + 1] = hn[3 * r + 1] * s1;
+                    t[3 * r + 2] = hn[3 * r + 2] - s1 * (hn[3 * r + 0] * c1x + hn[3 * r + 1] * c1y);
+                }
+                for (int c = 0; c < 3; ++c) {
+                    h[c] = t[c] / s2 + c2x * t[6 + c];
+                    h[3 + c] = t[3 + c] / s2 + c2y * t[6 + c];
+                    h[6 + c] = t[6 + c];
+                }
+                double gm[9], w[3];
+                for (int i = 0; i < 3; ++i)
+                    for (int j = 0; j < 3; ++j) gm[3 * i + j] = h[i] * h[j] + h[3 + i] * h[3 + j] + h[6 + i] * h[6 + j];
+                jacobi3(gm, w);
+                const double wmax = fmax(w[0], fmax(w[1], w[2])), wmin = fmin(w[0], fmin(w[1], w[2]));
+                sRed[0] = wmin > 0.0 ? sqrt(wmax / wmin) : 1e300;
+            }
+        }
+        __syncthreads();
+        ratio = sRed[0];
+    }
+    if (tid == 0) {
+        const bool key = n_acc >= 4 && ratio > p.homography_threshold;
+        d.res[R_DECISION] = key ? 2.0 : 1.0;
+        d.res[R_REASON] = 0.0;
+        d.res[R_NTRACKS] = (double)n_acc; d.res[R_NOLD] = (double)n_old; d.res[R_NNEW] = (double)n_new;
+        d.res[R_HOMOGRAPHY] = ratio;
+        d.cnt[C_KF_PENDING] = key ? 1 : 0;
+    }
+    if (tid < 12) d.res[R_POSE + tid] = sP[tid];
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// keyframe: the new landmarks into the map, the tracks that did not triangulate dropped (slam2.py:589-612)
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void keyframe_commit_kernel(SlamDev d, SlamParams p, int n_new)
+{
+    __shared__ int sWave[4];
+    const int tid = threadIdx.x;
+    const int n = d.cnt[C_N], nl = d.cnt[C_NLAND];
+    int n_good = 0;
+    for (int b = 0; b < n_new; b += 256) {
+        const int j = b + tid;
+        const bool good = j < n_new && d.kf_status[j] >= 0;
+        int tot;
+        const int r = n_good + block_rank(good, tid, sWave, tot);
+        if (good && nl + r < p.max_landmarks) {
+            const int id = nl + r;
+            d.map[3 * id] = (double)(float)d.kf_x[3 * j]; d.map[3 * id + 1] = (double)(float)d.kf_x[3 * j + 1];
+            d.map[3 * id + 2] = (double)(float)d.kf_x[3 * j + 2];
+            d.lm[d.kf_pos[j]] = id;
+        }
+        n_good += tot;
+    }
+    if (nl + n_good > p.max_landmarks) n_good = p.max_landmarks - nl;
+    __threadfence_block();
+    __syncthreads();
+    // drop the free tracks that did not become landmarks: through the temporaries, back in order
+    for (int k = tid; k < n; k += 256) {
+        d.t_pts[2 * k] = d.pts[2 * k]; d.t_pts[2 * k + 1] = d.pts[2 * k + 1];
+        d.t_lm[k] = d.lm[k]; d.t_tid[k] = d.tid[k];
+    }
+    __threadfence_block();
+    __syncthreads();
+    int n2 = 0;
+    for (int b = 0; b < n; b += 256) {
+        const int k = b + tid;
+        const bool in = k < n && d.t_lm[k] >= 0;
+        int tot;
+        const int r = n2 + block_rank(in, tid, sWave, tot);
+        if (in) { d.pts[2 * r] = d.t_pts[2 * k]; d.pts[2 * r + 1] = d.t_pts[2 * k + 1]; d.lm[r] = d.t_lm[k]; d.tid[r] = d.t_tid[k]; }
+        n2 += tot;
+    }
+    // the refined pose of the keyframe step is the frame's pose and the new base keyframe's
+    const double *pf = n_new > 0 ? d.kf_pose + 12 : d.pose_prev;
+    double v = tid < 12 ? pf[tid] : 0.0;
+    __syncthreads();
+    if (tid < 12) { d.pose_prev[tid] = v; d.pose_key[tid] = v; d.res[R_KF_POSE + tid] = v; }
+    if (tid == 0) {
+        d.cnt[C_N] = n2; d.cnt[C_NLAND] = nl + n_good;
+        d.res[R_KF_VALID] = 1.0; d.res[R_KF_NGOOD] = (double)n_good; d.res[R_KF_NLAND] = (double)(nl + n_good);
+    }
+}
+
+// coverage mask (slam2.py:29-40): the mask was set to 1; a filled disc of zeros around every live track
+__global__ __launch_bounds__(64) void coverage_disc_kernel(SlamDev d, SlamParams p)
+{
+    const int k = blockIdx.x, lane = threadIdx.x;
+    if (k >= d.cnt[C_N]) return;
+    const int cx = (int)rintf(d.pts[2 * k]), cy = (int)rintf(d.pts[2 * k + 1]);
+    const int r = (int)p.radius, side = 2 * r + 1;
+    for (int e = lane; e < side * side; e += 64) {
+        const int dy = e / side - r, dx = e % side - r;
+        const int x = cx + dx, y = cy + dy;
+        if (dx * dx + dy * dy <= r * r && x >= 0 && x < p.W && y >= 0 && y < p.H) d.mask[(size_t)y * p.W + x] = 0;
+    }
+}
+
+// top-up (slam2.py:657-672) and rebase (:673-674): the strongest new corners up to the target, every track's base = its position
+__global__ __launch_bounds__(256) void append_tracks_kernel(SlamDev d, SlamParams p)
+{
+    const int tid = threadIdx.x;
+    const int n = d.cnt[C_N], found = d.gf_n[0], next = d.cnt[C_NEXT_TID];
+    int add = p.target - n;
+    if (add > found) add = found;
+    if (add > kMaxTracks - n) add = kMaxTracks - n;
+    if (add < 0) add = 0;
+    for (int i = tid; i < add; i += 256) {
+        d.pts[2 * (n + i)] = d.gf_xy[2 * i]; d.pts[2 * (n + i) + 1] = d.gf_xy[2 * i + 1];
+        d.lm[n + i] = -1; d.tid[n + i] = next + i;
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int k = tid; k < n + add; k += 256) { d.base[2 * k] = d.pts[2 * k]; d.base[2 * k + 1] = d.pts[2 * k + 1]; }
+    if (tid == 0) { d.cnt[C_N] = n + add; d.cnt[C_NEXT_TID] = next + add; d.cnt[C_KF_PENDING] = 0; d.res[R_KF_NTRACKS] = (double)(n + add); }
+}
+
+// first frame: the given correspondences become the first tracks and landmarks (slam2.py:1136-1180)
+__global__ __launch_bounds__(256) void start_kernel(SlamDev d, const float *objp0, const float *imgp0, int n0)
+{
+    const int tid = threadIdx.x;
+    for (int k = tid; k < n0; k += 256) {
+        d.pts[2 * k] = imgp0[2 * k]; d.pts[2 * k + 1] = imgp0[2 * k + 1];
+        d.lm[k] = k; d.tid[k] = k;
+        d.map[3 * k] = (double)objp0[3 * k]; d.map[3 * k + 1] = (double)objp0[3 * k + 1]; d.map[3 * k + 2] = (double)objp0[3 * k + 2];
+        d.kf_objp[3 * k] = (double)objp0[3 * k]; d.kf_objp[3 * k + 1] = (double)objp0[3 * k + 1]; d.kf_objp[3 * k + 2] = (double)objp0[3 * k + 2];
+        d.kf_imgp[2 * k] = (double)imgp0[2 * k]; d.kf_imgp[2 * k + 1] = (double)imgp0[2 * k + 1];
+    }
+    if (tid == 0) {
+        d.cnt[C_N] = n0; d.cnt[C_NLAND] = n0; d.cnt[C_NEXT_TID] = n0; d.cnt[C_FRAME] = 1; d.cnt[C_NTRI] = 0; d.cnt[C_NKEEP] = 0;
+        d.cnt[C_KF_PENDING] = 0;
+    }
+}
+
+__global__ void start_pose_kernel(SlamDev d)
+{
+    const int tid = threadIdx.x;
+    if (tid < 12) { const double v = d.pose_r[tid]; d.pose_prev[tid] = v; d.pose_key[tid] = v; d.res[R_POSE + tid] = v; }
+}
+
+}  // namespace
+
+struct mqs_slam {
+    int device;
+    hipStream_t stream;
+    SlamDev d;
+    SlamParams p;
+    char *arena;
+    double *res_host;                // pinned
+    void *ws_lk, *ws_gftt, *ws_pnp;
+    int64_t ws_lk_bytes, ws_gftt_bytes;
+    bool started;
+};
+
+namespace {
+
+int topup(mqs_slam *s, const uint8_t *img)
+{
+    MQS_HIP_CHECK(hipMemsetAsync(s->d.mask, 1, (size_t)s->p.W * s->p.H, s->stream));
+    hipLaunchKernelGGL(coverage_disc_kernel, dim3(kMaxTracks), dim3(64), 0, s->stream, s->d, s->p);
+    int rc = mqs_good_features_to_track_dev(img, s->p.W, s->p.H, s->p.target, s->p.quality, s->p.radius, s->d.mask, s->d.gf_xy,
+                                            kMaxTracks, s->d.gf_n, s->ws_gftt, s->ws_gftt_bytes, s->stream);
+    if (rc != MQS_OK) return rc;
+    hipLaunchKernelGGL(append_tracks_kernel, dim3(1), dim3(256), 0, s->stream, s->d, s->p);
+    MQS_HIP_CHECK(hipGetLastError());
+    return MQS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mqs_slam_create(int device, int W, int H, const double *intr, int target_keypoints, double coverage_radius,
+                    double quality_level, int max_landmarks, uint64_t seed, mqs_slam **out)
+{
+    MQS_ARG_CHECK(out != nullptr && intr != nullptr, "out, intr must not be null");
+    *out = nullptr;
+    MQS_ARG_CHECK(W >= 16 && H >= 16 && W < 65536 && H < 65536, "16 <= W, H < 65536");
+    MQS_ARG_CHECK(target_keypoints >= 8 && target_keypoints <= kMaxTracks, "8 <= target_keypoints <= 512");
+    MQS_ARG_CHECK(coverage_radius >= 1.0 && coverage_radius <= 64.0 && quality_level > 0.0 && max_landmarks >= 64, "parameter ranges");
+    MQS_HIP_CHECK(hipSetDevice(device));
+    mqs_slam *s = new (std::nothrow) mqs_slam();
+    if (!s) { mqs_set_error("out of host memory"); return MQS_E_NOMEM; }
+    s->device = device;
+    s->started = false;
+    s->p = SlamParams{W, H, target_keypoints, max_landmarks, coverage_radius, quality_level,
+                      12.0, 0.5, 2.0, 0.33, 1.04, (unsigned long long)seed};        // slam2.py:1070-1098
+    s->ws_lk_bytes = mqs_lk_workspace_bytes(W, H, 3);
+    s->ws_gftt_bytes = mqs_gftt_workspace_bytes(W, H);
+    const int64_t ws_pnp_bytes = mqs_pnp_workspace_bytes(kMaxTracks, kHyp);
+    auto up = [](size_t v) { return (v + 255) & ~size_t(255); };
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off = up(off + bytes); return o; };
+    const size_t T = kMaxTracks;
+    const size_t o_cnt = take(C_COUNT * 4), o_pts = take(T * 8), o_base = take(T * 8), o_lm = take(T * 4), o_tid = take(T * 4),
+                 o_map = take((size_t)max_landmarks * 24), o_pk = take(96), o_pp = take(96), o_intr = take(72),
+                 o_lkp = take(T * 8), o_lke = take(T * 4), o_lks = take(T), o_tp = take(T * 8), o_tb = take(T * 8), o_tl = take(T * 4),
+                 o_tt = take(T * 4), o_ot = take(T * 24), o_it = take(T * 16), o_tpos = take(T * 4), o_smp = take((size_t)kHyp * kSample * 4),
+                 o_pr = take(96), o_sel = take(8), o_im = take(T), o_pi = take(32), o_ko = take(T * 24), o_ki = take(T * 16),
+                 o_k0 = take(T * 16), o_k1 = take(T * 16), o_kp = take(T * 4), o_ks = take(T * 80 + 64), o_kpose = take(192),
+                 o_kx = take(T * 24), o_kinfo = take(64), o_kst = take(T * 4), o_mask = take((size_t)W * H), o_gxy = take(T * 8),
+                 o_gn = take(4), o_res = take(kRes * 8), o_wl = take((size_t)s->ws_lk_bytes), o_wg = take((size_t)s->ws_gftt_bytes),
+                 o_wp = take((size_t)ws_pnp_bytes);
+    hipError_t e = hipMalloc((void **)&s->arena, off);
+    if (e != hipSuccess) { delete s; mqs_set_error("hipMalloc(%zu) failed: %s", off, hipGetErrorString(e)); return MQS_E_NOMEM; }
+    char *a = s->arena;
+    SlamDev &d = s->d;
+    d.cnt = (int32_t *)(a + o_cnt); d.pts = (float *)(a + o_pts); d.base = (float *)(a + o_base); d.lm = (int32_t *)(a + o_lm);
+    d.tid = (int32_t *)(a + o_tid); d.map = (double *)(a + o_map); d.pose_key = (double *)(a + o_pk); d.pose_prev = (double *)(a + o_pp);
+    d.intr = (double *)(a + o_intr); d.lk_pts = (float *)(a + o_lkp); d.lk_err = (float *)(a + o_lke); d.lk_st = (uint8_t *)(a + o_lks);
+    d.t_pts = (float *)(a + o_tp); d.t_base = (float *)(a + o_tb); d.t_lm = (int32_t *)(a + o_tl); d.t_tid = (int32_t *)(a + o_tt);
+    d.objp_t = (double *)(a + o_ot); d.imgp_t = (double *)(a + o_it); d.tri_pos = (int32_t *)(a + o_tpos); d.samples = (int32_t *)(a + o_smp);
+    d.pose_r = (double *)(a + o_pr); d.sel = (int32_t *)(a + o_sel); d.inl_mask = (uint8_t *)(a + o_im); d.pnp_info = (double *)(a + o_pi);
+    d.kf_objp = (double *)(a + o_ko); d.kf_imgp = (double *)(a + o_ki); d.kf_p0 = (double *)(a + o_k0); d.kf_p1 = (double *)(a + o_k1);
+    d.kf_pos = (int32_t *)(a + o_kp); d.kf_scratch = (double *)(a + o_ks); d.kf_pose = (double *)(a + o_kpose); d.kf_x = (double *)(a + o_kx);
+    d.kf_info = (double *)(a + o_kinfo); d.kf_status = (int32_t *)(a + o_kst); d.mask = (uint8_t *)(a + o_mask); d.gf_xy = (float *)(a + o_gxy);
+    d.gf_n = (int32_t *)(a + o_gn); d.res = (double *)(a + o_res);
+    s->ws_lk = a + o_wl; s->ws_gftt = a + o_wg; s->ws_pnp = a + o_wp;
+    e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&s->res_host, kRes * 8, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMemsetAsync(s->arena, 0, o_wl, s->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d.intr, intr, 72, hipMemcpyHostToDevice, s->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+    if (e != hipSuccess) {
+        mqs_set_error("mqs_slam_create: %s", hipGetErrorString(e));
+        (void)hipFree(s->arena);
+        delete s;
+        return MQS_E_HIP;
+    }
+    *out = s;
+    return MQS_OK;
+}
+
+void mqs_slam_destroy(mqs_slam *s)
+{
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    (void)hipStreamSynchronize(s->stream);
+    (void)hipFree(s->arena);
+    if (s->res_host) (void)hipHostFree(s->res_host);
+    (void)hipStreamDestroy(s->stream);
+    delete s;
+}
+
+int mqs_slam_set_thresholds(mqs_slam *s, double max_of_error, double max_lost_tracks_ratio, double max_reproj_error,
+                            double max_outlier_ratio, double homography_condition_threshold)
+{
+    MQS_ARG_CHECK(s != nullptr, "handle must not be null");
+    s->p.max_of_error = max_of_error; s->p.max_lost_ratio = max_lost_tracks_ratio; s->p.max_reproj = max_reproj_error;
+    s->p.max_outlier_ratio = max_outlier_ratio; s->p.homography_threshold = homography_condition_threshold;
+    return MQS_OK;
+}
+
+// first frame (slam2.py:1136-1180): pose from n0 known 3-D points, those points become the first landmarks and tracks, the rest
+// of the tracks come from goodFeaturesToTrack under their coverage mask.  objp0 [n0][3], imgp0 [n0][2]: HOST float32.
+int mqs_slam_start(mqs_slam *s, const uint8_t *img_dev, const float *objp0, const float *imgp0, int n0, double *pose_out)
+{
+    MQS_ARG_CHECK(s != nullptr && img_dev && objp0 && imgp0 && pose_out, "pointers must not be null");
+    MQS_ARG_CHECK(n0 >= 6 && n0 <= s->p.target, "6 <= n0 <= target_keypoints");
+    MQS_HIP_CHECK(hipSetDevice(s->device));
+    // staged through the keyframe-step output arrays (free at this point)
+    float *o_dev = reinterpret_cast<float *>(s->d.kf_x), *i_dev = reinterpret_cast<float *>(s->d.kf_scratch);
+    MQS_HIP_CHECK(hipMemcpyAsync(o_dev, objp0, (size_t)n0 * 12, hipMemcpyHostToDevice, s->stream));
+    MQS_HIP_CHECK(hipMemcpyAsync(i_dev, imgp0, (size_t)n0 * 8, hipMemcpyHostToDevice, s->stream));
+    hipLaunchKernelGGL(start_kernel, dim3(1), dim3(256), 0, s->stream, s->d, o_dev, i_dev, n0);
+    int rc = mqs_pnp_refine_dev(s->d.kf_objp, s->d.kf_imgp, n0, nullptr, nullptr, 1, s->d.intr, nullptr, 0, kPnpIters, kPnpEps, s->d.pose_r,
+                                s->d.pnp_info, s->stream);
+    if (rc != MQS_OK) return rc;
+    hipLaunchKernelGGL(start_pose_kernel, dim3(1), dim3(64), 0, s->stream, s->d);
+    rc = topup(s, img_dev);
+    if (rc != MQS_OK) return rc;
+    MQS_HIP_CHECK(hipMemcpyAsync(s->res_host, s->d.res, kRes * 8, hipMemcpyDeviceToHost, s->stream));
+    MQS_HIP_CHECK(hipStreamSynchronize(s->stream));
+    memcpy(pose_out, s->res_host + R_POSE, 96);
+    s->started = true;
+    return MQS_OK;
+}
+
+// One frame.  result [40] doubles: decision (0 rejected, 1 frame, 2 keyframe), reason of a rejection (1 lost tracks, 2 fewer
+// than 8 landmark tracks, 3 no RANSAC model, 4 outlier ratio, 5 reprojection error), tracks kept, landmark tracks, inliers,
+// |old|, |new| point sets of the keyframe step, lost ratio, outlier ratio, reprojection RMS, homography w0 / w2, landmarks,
+// pose [12] (3x4 world -> camera; of a keyframe: before its refinement); from [24]: what the PREVIOUS call's keyframe branch
+// left -- valid flag, landmarks added, tracks after the top-up, landmarks, refined pose [12] -- because that branch runs
+// behind the call that started it.  mqs_slam_flush returns the same block once the stream has drained.
+int mqs_slam_track(mqs_slam *s, const uint8_t *prev_img_dev, const uint8_t *img_dev, double *result)
+{
+    MQS_ARG_CHECK(s != nullptr && prev_img_dev && img_dev && result, "pointers must not be null");
+    MQS_ARG_CHECK(s->started, "mqs_slam_start first");
+    MQS_HIP_CHECK(hipSetDevice(s->device));
+    SlamDev &d = s->d;
+    int rc = mqs_lk_launch(prev_img_dev, img_dev, s->p.W, s->p.H, d.pts, kMaxTracks, d.cnt + C_N, 21, 21, 3, 30, 0.01, 1e-4, d.lk_pts,
+                           d.lk_st, d.lk_err, s->ws_lk, s->ws_lk_bytes, s->stream);
+    if (rc != MQS_OK) return rc;
+    hipLaunchKernelGGL(frame_filter_kernel, dim3(1), dim3(256), 0, s->stream, d, s->p);
+    rc = mqs_pnp_ransac_launch(d.objp_t, d.imgp_t, kMaxTracks, d.cnt + C_NTRI, d.intr, d.samples, kHyp, kSample, s->p.max_reproj,
+                               kSampleIters, kPnpIters, kPnpEps, d.pose_r, d.sel, d.inl_mask, d.pnp_info, s->ws_pnp, s->stream);
+    if (rc != MQS_OK) return rc;
+    hipLaunchKernelGGL(frame_decide_kernel, dim3(1), dim3(256), 0, s->stream, d, s->p);
+    MQS_HIP_CHECK(hipGetLastError());
+    MQS_HIP_CHECK(hipMemcpyAsync(s->res_host, d.res, kRes * 8, hipMemcpyDeviceToHost, s->stream));
+    // the previous keyframe's report has been copied with this block: clear its flag on the device for the next one
+    MQS_HIP_CHECK(hipMemsetAsync(d.res + R_KF_VALID, 0, 8, s->stream));
+    MQS_HIP_CHECK(hipStreamSynchronize(s->stream));
+    memcpy(result, s->res_host, kRes * 8);
+    if (result[R_DECISION] == 2.0) {
+        const int n_old = (int)result[R_NOLD], n_new = (int)result[R_NNEW];
+        if (n_new > 0) {
+            rc = mqs_keyframe_step_launch(d.kf_objp, d.kf_imgp, n_old, d.kf_p0, d.kf_p1, n_new, d.intr, d.pose_prev, d.pose_key, 3.e-5,
+                                          kPnpIters, kPnpEps, d.kf_scratch, d.kf_pose, d.kf_x, d.kf_status, d.kf_info, s->stream);
+            if (rc != MQS_OK) return rc;
+        }
+        hipLaunchKernelGGL(keyframe_commit_kernel, dim3(1), dim3(256), 0, s->stream, d, s->p, n_new);
+        rc = topup(s, img_dev);
+        if (rc != MQS_OK) return rc;
+    }
+    return MQS_OK;
+}
+
+int mqs_slam_flush(mqs_slam *s, double *result)
+{
+    MQS_ARG_CHECK(s != nullptr && result, "pointers must not be null");
+    MQS_HIP_CHECK(hipSetDevice(s->device));
+    MQS_HIP_CHECK(hipMemcpyAsync(s->res_host, s->d.res, kRes * 8, hipMemcpyDeviceToHost, s->stream));
+    MQS_HIP_CHECK(hipMemsetAsync(s->d.res + R_KF_VALID, 0, 8, s->stream));
+    MQS_HIP_CHECK(hipStreamSynchronize(s->stream));
+    memcpy(result, s->res_host, kRes * 8);
+    return MQS_OK;
+}
+
+// the live tracks (host arrays of capacity `cap`): positions, base-keyframe positions, landmark id or -1, track id
+int mqs_slam_read_tracks(mqs_slam *s, float *pts, float *base, int32_t *lm, int32_t *tid, int cap, int32_t *n)
+{
+    MQS_ARG_CHECK(s != nullptr && n != nullptr && cap >= 0, "handle, n");
+    MQS_HIP_CHECK(hipSetDevice(s->device));
+    int32_t cnt[C_COUNT];
+    MQS_HIP_CHECK(hipMemcpyAsync(cnt, s->d.cnt, sizeof(cnt), hipMemcpyDeviceToHost, s->stream));
+    MQS_HIP_CHECK(hipStreamSynchronize(s->stream));
+    const int m = cnt[C_N] < cap ? cnt[C_N] : cap;
+    *n = cnt[C_N];
+    if (m > 0) {
+        if (pts) MQS_HIP_CHECK(hipMemcpyAsync(pts, s->d.pts, (size_t)m * 8, hipMemcpyDeviceToHost, s->stream));
+        if (base) MQS_HIP_CHECK(hipMemcpyAsync(base, s->d.base, (size_t)m * 8, hipMemcpyDeviceToHost, s->stream));
+        if (lm) MQS_HIP_CHECK(hipMemcpyAsync(lm, s->d.lm, (size_t)m * 4, hipMemcpyDeviceToHost, s->stream));
+        if (tid) MQS_HIP_CHECK(hipMemcpyAsync(tid, s->d.tid, (size_t)m * 4, hipMemcpyDeviceToHost, s->stream));
+        MQS_HIP_CHECK(hipStreamSynchronize(s->stream));
+    }
+    return MQS_OK;
+}
+
+// the map as the reference keeps it: float32 [n][3]
+int mqs_slam_read_map(mqs_slam *s, float *objp, int cap, int32_t *n)
+{
+    MQS_ARG_CHECK(s != nullptr && n != nullptr && cap >= 0, "handle, n");
+    MQS_HIP_CHECK(hipSetDevice(s->device));
+    int32_t cnt[C_COUNT];
+    MQS_HIP_CHECK(hipMemcpyAsync(cnt, s->d.cnt, sizeof(cnt), hipMemcpyDeviceToHost, s->stream));
+    MQS_HIP_CHECK(hipStreamSynchronize(s->stream));
+    *n = cnt[C_NLAND];
+    const int m = cnt[C_NLAND] < cap ? cnt[C_NLAND] : cap;
+    if (m > 0 && objp) {
+        double *tmp = new (std::nothrow) double[(size_t)m * 3];
+        if (!tmp) { mqs_set_error("out of host memory"); return MQS_E_NOMEM; }
+        hipError_t e = hipMemcpyAsync(tmp, s->d.map, (size_t)m * 24, hipMemcpyDeviceToHost, s->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+        if (e == hipSuccess)
+            for (size_t k = 0; k < (size_t)m * 3; ++k) objp[k] = (float)tmp[k];
+        delete[] tmp;
+        MQS_HIP_CHECK(e);
+    }
+    return MQS_OK;
+}
+
+}  // extern "C"

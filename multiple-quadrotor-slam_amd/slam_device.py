@@ -1,0 +1,155 @@
+"""
+The reference's monocular per-frame loop (Work/SLAM/application/own/slam2.py:360-695 `handle_new_frame`, :1021-1253
+`main`; BASELINE configs[4]) with its state RESIDENT ON THE DEVICE: the live tracks, their base-keyframe positions, the map
+and the poses never leave the GPU; a frame is one library call (`mqs_slam_track`, csrc/slam_frame.hip) that enqueues
+
+    pyramidal LK of the live tracks -> status / error filter + the two early gates -> RANSAC hypotheses, selection, solvePnP
+    on the inliers -> outlier-ratio and reprojection gates, commit of the kept tracks, keyframe test
+
+waits for one small result block and, on a keyframe, enqueues without waiting the keyframe step (triangulate the free
+tracks against the base keyframe, refine the pose, re-triangulate), the map update, the coverage mask, goodFeaturesToTrack
+and the top-up.  `slam_loop.MonoSlam` is the same state machine driven from the host (about ten host-pointer calls per
+frame): same gates and thresholds (slam2.py:1070-1098), same deviations (all-points homography in the keyframe test, seeded
+RANSAC draws -- here from a counter-based generator on the device).
+
+Images are device tensors (torch uint8, H x W, contiguous); a live system would upload them on a side stream while the
+previous frame is tracked.
+"""
+import ctypes
+import time
+
+import numpy as np
+
+from . import _lib
+from .camera import _intr
+from .slam_loop import (CORNER_QUALITY_LEVEL, HOMOGRAPHY_CONDITION_THRESHOLD, KEYPOINT_COVERAGE_RADIUS, MAX_AMOUNT_KEYPOINTS,
+                        MAX_LOST_TRACKS_RATIO, MAX_OF_ERROR, MAX_SOLVEPNP_OUTLIER_RATIO, MAX_SOLVEPNP_REPROJ_ERROR)
+
+REASONS = {0: "", 1: "lost track of too many points", 2: "fewer than 8 triangulated tracks", 3: "no RANSAC model",
+           4: "PnP outlier ratio", 5: "reprojection error"}
+
+
+class DeviceMonoSlam:
+    def __init__(self, cameraMatrix, distCoeffs, image_shape, seed=0, device=0, max_landmarks=1 << 16, verbose=False):
+        self.K = np.asarray(cameraMatrix, dtype=np.float64)
+        self.dist = np.asarray(distCoeffs, dtype=np.float64).reshape(-1)[:4]
+        self.shape = tuple(image_shape)
+        H, W = self.shape
+        target = int(round(W * H / (np.pi * KEYPOINT_COVERAGE_RADIUS ** 2)))         # slam2.py:1081
+        self.target_keypoints = min(MAX_AMOUNT_KEYPOINTS, target)
+        self.verbose = verbose
+        self._intr = np.ascontiguousarray(_intr(self.K, self.dist), dtype=np.float64)
+        self._h = ctypes.c_void_p()
+        L = _lib.lib()
+        _lib.check(L.mqs_slam_create(int(device), W, H, self._intr.ctypes.data_as(_lib.c_f64p), self.target_keypoints,
+                                     float(KEYPOINT_COVERAGE_RADIUS), float(CORNER_QUALITY_LEVEL), int(max_landmarks),
+                                     ctypes.c_uint64(int(seed)), ctypes.byref(self._h)))
+        _lib.check(L.mqs_slam_set_thresholds(self._h, MAX_OF_ERROR, MAX_LOST_TRACKS_RATIO, MAX_SOLVEPNP_REPROJ_ERROR,
+                                             MAX_SOLVEPNP_OUTLIER_RATIO, HOMOGRAPHY_CONDITION_THRESHOLD))
+        self._track = L.mqs_slam_track
+        self._res = np.zeros(40)
+        self._pres = self._res.ctypes.data_as(_lib.c_f64p)
+        self.poses = []                  # per frame: 3x4 world -> camera matrix, None for a rejected frame
+        self.keyframes = []
+        self.timing = []
+        self.reports = []                # per frame: the first 12 result fields
+        self._pending_keyframe = None    # frame index whose refined pose arrives with the next result block
+        self._prev = None
+        self._max_landmarks = int(max_landmarks)
+
+    def close(self):
+        if self._h:
+            _lib.lib().mqs_slam_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def _img_ptr(img, shape):
+        import torch
+        if not (isinstance(img, torch.Tensor) and img.is_cuda and img.dtype == torch.uint8 and img.is_contiguous()
+                and tuple(img.shape) == tuple(shape)):
+            raise ValueError("images are contiguous uint8 device tensors of shape %r" % (tuple(shape),))
+        return ctypes.c_void_p(img.data_ptr())
+
+    def start(self, img, init_objp, init_imgp):
+        """slam2.py:1136-1180: pose of the first frame from known 3-D points, then the first batch of free tracks."""
+        o = np.ascontiguousarray(init_objp, dtype=np.float32).reshape(-1, 3)
+        m = np.ascontiguousarray(init_imgp, dtype=np.float32).reshape(-1, 2)
+        pose = np.zeros(12)
+        _lib.check(_lib.lib().mqs_slam_start(self._h, self._img_ptr(img, self.shape), o.ctypes.data_as(_lib.c_f32p),
+                                             m.ctypes.data_as(_lib.c_f32p), len(o), pose.ctypes.data_as(_lib.c_f64p)))
+        self.poses.append(pose.reshape(3, 4).copy())
+        self.keyframes.append(0)
+        self._prev = img
+        return self.poses[0]
+
+    def _take_keyframe_report(self):
+        r = self._res
+        if r[24] != 0.0 and self._pending_keyframe is not None:
+            self.poses[self._pending_keyframe] = r[28:40].reshape(3, 4).copy()
+            self._pending_keyframe = None
+
+    def handle_new_frame(self, img):
+        """Returns 0 (rejected), 1 (frame) or 2 (keyframe), like the reference's `ret`."""
+        t0 = time.perf_counter()
+        rc = self._track(self._h, self._img_ptr(self._prev, self.shape), self._img_ptr(img, self.shape), self._pres)
+        if rc != 0:
+            _lib.check(rc)
+        r = self._res
+        self._take_keyframe_report()
+        decision = int(r[0])
+        if decision == 0:
+            if self.verbose:
+                print("REJECTED:", REASONS.get(int(r[1]), "?"))
+            self.poses.append(None)
+        else:
+            self.poses.append(r[12:24].reshape(3, 4).copy())
+            if decision == 2:
+                self._pending_keyframe = len(self.poses) - 1
+                self.keyframes.append(len(self.poses) - 1)
+            self._prev = img             # slam2.py keeps the previous image of a rejected frame
+        self.reports.append(r[:12].copy())
+        self.timing.append(time.perf_counter() - t0)
+        return decision
+
+    def finish(self):
+        """Waits for the last keyframe branch and takes its report."""
+        _lib.check(_lib.lib().mqs_slam_flush(self._h, self._pres))
+        self._take_keyframe_report()
+
+    # ---- state read-back (tests, recorders) --------------------------------------------
+    def tracks(self):
+        """(pts (n, 2) f32, base (n, 2) f32, landmark id or -1 (n,), track id (n,))."""
+        cap = 512
+        pts, base = np.zeros((cap, 2), np.float32), np.zeros((cap, 2), np.float32)
+        lm, tid = np.zeros(cap, np.int32), np.zeros(cap, np.int32)
+        n = ctypes.c_int32(0)
+        _lib.check(_lib.lib().mqs_slam_read_tracks(self._h, pts.ctypes.data_as(_lib.c_f32p), base.ctypes.data_as(_lib.c_f32p),
+                                                   lm.ctypes.data_as(_lib.c_i32p), tid.ctypes.data_as(_lib.c_i32p), cap, ctypes.byref(n)))
+        k = min(n.value, cap)
+        return pts[:k], base[:k], lm[:k], tid[:k]
+
+    @property
+    def objp(self):
+        """The map, float32 (n, 3) like slam2.py:19."""
+        n = ctypes.c_int32(0)
+        _lib.check(_lib.lib().mqs_slam_read_map(self._h, None, 0, ctypes.byref(n)))
+        out = np.zeros((max(n.value, 1), 3), np.float32)
+        _lib.check(_lib.lib().mqs_slam_read_map(self._h, out.ctypes.data_as(_lib.c_f32p), n.value, ctypes.byref(n)))
+        return out[:n.value]
+
+    def projection_matrices(self):
+        return [None if p is None else p.copy() for p in self.poses]
+
+    def trajectory(self):
+        """Camera centres (F, 3), NaN for rejected frames."""
+        out = np.full((len(self.poses), 3), np.nan)
+        for i, P in enumerate(self.poses):
+            if P is not None:
+                out[i] = -P[:, :3].T @ P[:, 3]
+        return out

@@ -168,3 +168,47 @@ def test_loop_host_logic_with_oracle_backends(mqs, c_oracle, monkeypatch, tmp_pa
     assert len(res) > 200 and np.median(res) < 1.0 and np.max(res) < 12.0
     # every landmark added at a keyframe is observed in every frame since the previous keyframe (>= 2 views)
     assert min(pr.obs_ptr[j + 1] - pr.obs_ptr[j] for j in range(int(vis.sum()), len(pr.points))) >= 2
+
+
+@pytest.mark.gpu
+def test_device_resident_loop_on_rendered_sequence(gpu):
+    """slam_device.DeviceMonoSlam (csrc/slam_frame.hip): the same state machine with its state on the GPU and one library
+    call per frame -- the accuracy bars of the host-driven loop, and the two loops agree on what they build (they draw
+    different RANSAC samples, so not bit for bit: same number of accepted frames, keyframes within two, trajectories within
+    0.2 % of the path of each other)."""
+    import run_slam_loop
+    dev = run_slam_loop.run_device(40)
+    host = run_slam_loop.run(40)
+    assert dev["accepted"] == 40 and dev["keyframes"] >= 8
+    assert dev["landmarks_triangulated"] >= 200
+    assert dev["trajectory_rmse"] < 0.01 * dev["path_length"]
+    assert dev["map_plane_median_abs_z"] < 0.15
+    assert abs(dev["keyframes"] - host["keyframes"]) <= 2
+    assert abs(dev["trajectory_rmse"] - host["trajectory_rmse"]) < 0.002 * dev["path_length"]
+    assert dev["tracks_at_the_end"] >= 100
+
+
+@pytest.mark.gpu
+def test_device_loop_rejects_a_broken_frame_and_recovers(gpu):
+    """A frame that shares nothing with its predecessor (noise) is rejected by the lost-tracks gate without touching the state;
+    the following frame is tracked from the last good image."""
+    import torch
+    seq = gpu.synthetic.PlaneSequence(frames=12)
+    gx, gy = np.meshgrid(np.linspace(-4.5, 1.0, 8), np.linspace(-2.5, 2.0, 6))
+    objp = np.stack([gx.ravel(), gy.ravel(), np.zeros(gx.size)], axis=1)
+    imgp = seq.project(0, objp)
+    vis = (imgp[:, 0] > 15) & (imgp[:, 0] < seq.W - 15) & (imgp[:, 1] > 15) & (imgp[:, 1] < seq.H - 15)
+    imgs = [torch.from_numpy(seq.render(k)).cuda() for k in range(12)]
+    noise = torch.from_numpy(np.random.default_rng(0).integers(0, 255, (seq.H, seq.W), dtype=np.uint8)).cuda()
+    slam = gpu.slam_device.DeviceMonoSlam(seq.K, seq.dist, (seq.H, seq.W), seed=3)
+    slam.start(imgs[0], objp[vis], imgp[vis])
+    rets = [slam.handle_new_frame(imgs[k]) for k in range(1, 5)]
+    n_before = len(slam.tracks()[0])
+    assert all(r in (1, 2) for r in rets)
+    assert slam.handle_new_frame(noise) == 0 and slam.poses[-1] is None and int(slam.reports[-1][1]) in (1, 2, 3, 4, 5)
+    assert len(slam.tracks()[0]) == n_before                    # untouched
+    assert slam.handle_new_frame(imgs[5]) in (1, 2)              # tracked from frame 4's image
+    slam.finish()
+    with pytest.raises(ValueError):
+        slam.handle_new_frame(imgs[6].cpu())
+    slam.close()

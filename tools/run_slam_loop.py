@@ -38,6 +38,49 @@ def run(frames=60, verbose=False, ba_info=None, out_files=None):
             "frames_per_s": round((frames - 1) / sum(slam.timing), 1)}
 
 
+def run_device(frames=60, verbose=False, repeats=1):
+    """The same sequence through slam_device.DeviceMonoSlam: the loop's state resident on the GPU, one library call per frame
+    (images uploaded beforehand, as a capture thread would have them).  `repeats` > 1: the run is repeated on a fresh handle and
+    the fastest pass is timed (the first pass pays the first-launch costs of every kernel)."""
+    import torch
+    seq = mqslam_amd.synthetic.PlaneSequence(frames=frames)
+    gx, gy = np.meshgrid(np.linspace(-4.5, 1.0, 8), np.linspace(-2.5, 2.0, 6))
+    objp = np.stack([gx.ravel(), gy.ravel(), np.zeros(gx.size)], axis=1)
+    imgp = seq.project(0, objp)
+    vis = (imgp[:, 0] > 15) & (imgp[:, 0] < seq.W - 15) & (imgp[:, 1] > 15) & (imgp[:, 1] < seq.H - 15)
+    objp, imgp = objp[vis], imgp[vis]
+    imgs = [torch.from_numpy(seq.render(k)).cuda() for k in range(frames)]
+    torch.cuda.synchronize()
+    best = None
+    for _ in range(max(1, repeats)):
+        slam = mqslam_amd.slam_device.DeviceMonoSlam(seq.K, seq.dist, (seq.H, seq.W), seed=1, verbose=verbose)
+        slam.start(imgs[0], objp, imgp)
+        t0 = time.perf_counter()
+        rets = [2]
+        for k in range(1, frames):
+            rets.append(slam.handle_new_frame(imgs[k]))
+        slam.finish()
+        dt = time.perf_counter() - t0
+        if best is None or dt < best[0]:
+            best = (dt, slam, rets)
+        else:
+            slam.close()
+    dt, slam, rets = best
+    traj, gt = slam.trajectory(), seq.centres()
+    ok = np.isfinite(traj[:, 0])
+    err = np.linalg.norm(traj[ok] - gt[ok], axis=1)
+    new = slam.objp[len(objp):]
+    out = {"frames": frames, "accepted": int(ok.sum()), "keyframes": int(sum(r == 2 for r in rets)),
+           "landmarks_triangulated": int(len(new)), "trajectory_rmse": float(np.sqrt(np.mean(err ** 2))),
+           "trajectory_max_err": float(err.max()), "path_length": float(np.linalg.norm(np.diff(gt, axis=0), axis=1).sum()),
+           "map_plane_median_abs_z": float(np.median(np.abs(new[:, 2]))) if len(new) else None,
+           "map_plane_p90_abs_z": float(np.percentile(np.abs(new[:, 2]), 90)) if len(new) else None,
+           "frames_per_s": round((frames - 1) / dt, 1), "ms_per_frame_median": round(1e3 * float(np.median(slam.timing)), 4),
+           "tracks_at_the_end": int(len(slam.tracks()[0]))}
+    slam.close()
+    return out
+
+
 def run_with_ba(frames=60, work_dir=None):
     """The loop, then the recorded problem through the file set into the sparse bundle adjuster (LM, odometry factors on):
     detect -> track -> pose -> triangulate -> BA.  Returns the loop's report plus the trajectory error before / after BA."""
@@ -68,4 +111,7 @@ def run_with_ba(frames=60, work_dir=None):
 
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 60
-    print(json.dumps(run_with_ba(n) if "--ba" in sys.argv else run(n, verbose="-v" in sys.argv)))
+    if "--device" in sys.argv:
+        print(json.dumps(run_device(n, verbose="-v" in sys.argv, repeats=3)))
+    else:
+        print(json.dumps(run_with_ba(n) if "--ba" in sys.argv else run(n, verbose="-v" in sys.argv)))
