@@ -603,6 +603,8 @@ def main():
             import run_slam_loop
             run_slam_loop.run(10)
             frontend_out["end_to_end_loop"] = run_slam_loop.run_with_ba(60)
+            # the same loop with its state resident on the device, one library call per frame (csrc/slam_frame.hip)
+            frontend_out["end_to_end_loop_device_resident"] = run_slam_loop.run_device(60, repeats=3)
         except Exception as e:                                  # noqa: BLE001 -- a secondary leg must not cost the bench line
             frontend_out = {"error": "%s: %s" % (type(e).__name__, e)}
 

@@ -365,6 +365,17 @@ int mqs_sba_linearize_grouped_dev(const double *poses, const int32_t *pose_cam, 
                                   const double *pose_prior_poses, const double *pose_prior_sigmas, int n_pose_prior,
                                   double lambda, double *S, double *g, double *info, void *workspace,
                                   int64_t workspace_bytes, void *stream);
+/* The grouped pair list itself, built on the device (csrc/pair_group.hip): every (a, b), a <= b, of observation indices inside
+ * a landmark -- observations sorted by pose inside every landmark, so pose(a) <= pose(b) -- sorted by (pose of a, pose of b),
+ * stably (a group's pairs stay in landmark order), with the group offsets.  pair_off [N + 1] = exclusive prefix sums of
+ * k (k + 1) / 2 over the landmarks' observation counts k (pair_off[N] = Q).  All pointers are device pointers; n_groups[0]
+ * (device) receives the number of groups G, group_ptr [G + 1 <= group_cap] their offsets (group_ptr[G] = Q);
+ * G <= min(Q, P (P + 1) / 2).  Generation, a stable least-significant-digit radix sort and an ordered compaction: ~0.3 ms for
+ * the 2.0 M pairs of an 881-pose sequence, where numpy took 0.2 s. */
+int64_t mqs_sba_group_pairs_workspace_bytes(int64_t Q);
+int mqs_sba_group_pairs_dev(const int64_t *obs_ptr, const int32_t *obs_pose, int64_t N, const int64_t *pair_off, int64_t Q, int64_t P,
+                            int64_t *pair_a, int64_t *pair_b, int64_t *group_ptr, int64_t group_cap, int64_t *n_groups,
+                            void *workspace, int64_t workspace_bytes, void *stream);
 int mqs_sba_solve_dev(double *S, double *x, int64_t P, double lambda, const double *poses, double *poses_out,
                       int *bad, void *stream);
 /* The same solve for a reduced camera system known to be banded: S[i][j] == 0 for |i - j| > half_bandwidth (a

@@ -539,3 +539,46 @@ def test_recorder_writes_what_the_loader_reads(mqs, tmp_path):
     od = text("BA_info.measurements.odometry-rec.txt")[2:]
     assert od[:2] == ["", ""] and [float(v) for v in od[2].split()] == pytest.approx([-0.1, 0.2, -0.3, 0, 0, 0, 1])
     assert [float(v) for v in text("BA_info.calibrations.cam0.txt")[1].split()] == [480.0, 470.0, 0.5, 320.0, 240.0, 0.01, -0.002, 1e-4, 2e-4]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(40, 300, 9), (200, 5000, 17), (881, 13293, 17), (7, 50, 7), (70000 // 100, 3, 2)])
+def test_pair_grouping_on_the_device_equals_numpy(shape, gpu):
+    """mqs_sba_group_pairs_dev (csrc/pair_group.hip: generation, stable radix sort by pose pair, ordered compaction of the
+    group boundaries) returns the lists of sparse_ba.build_pairs + group_pairs (numpy stable argsort) element for element:
+    a small problem, a mid-size one, the ICL-kt2 shape (2.0 M pairs), landmarks seen by every pose, a tiny one."""
+    import torch
+    P_, N_, span = shape
+    rng = np.random.default_rng(P_ * 7 + N_)
+    S = gpu.sparse_ba
+    ptr, poses = [0], []
+    for i in range(N_):
+        first = int(rng.integers(0, max(1, P_ - span + 1)))
+        seen = np.sort(rng.choice(np.arange(first, min(P_, first + span)), size=int(rng.integers(0, min(span, P_) + 1)), replace=False))
+        poses.extend(seen.tolist())
+        ptr.append(len(poses))
+    obs_ptr, obs_pose = np.array(ptr, dtype=np.int64), np.array(poses, dtype=np.int32)
+    pa, pb = S.build_pairs(obs_ptr)
+    pa, pb, gp = S.group_pairs(pa, pb, obs_pose, P_)
+    da, db, dg = S.group_pairs_dev(obs_ptr, torch.from_numpy(obs_ptr).cuda(), torch.from_numpy(obs_pose).cuda(), P_)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(da.cpu().numpy(), pa)
+    np.testing.assert_array_equal(db.cpu().numpy(), pb)
+    np.testing.assert_array_equal(dg.cpu().numpy(), gp)
+
+
+def test_observation_sort_is_the_stable_per_landmark_sort(mqs):
+    """sparse_ba.sort_observations_by_pose (one vectorised lexsort) against the per-landmark stable argsort it replaces."""
+    import collections
+    rng = np.random.default_rng(3)
+    Pr = collections.namedtuple("Pr", "obs_ptr obs_pose obs_uv")
+    k = rng.integers(0, 9, 400)
+    ptr = np.concatenate([[0], np.cumsum(k)]).astype(np.int64)
+    op = rng.integers(0, 12, int(ptr[-1])).astype(np.int32)                    # repeated poses: stability matters
+    uv = rng.standard_normal((int(ptr[-1]), 2))
+    out = mqs.sparse_ba.sort_observations_by_pose(Pr(ptr, op, uv))
+    for i in range(len(k)):
+        a, b = int(ptr[i]), int(ptr[i + 1])
+        o = np.argsort(op[a:b], kind="stable")
+        np.testing.assert_array_equal(out.obs_pose[a:b], op[a:b][o])
+        np.testing.assert_array_equal(out.obs_uv[a:b], uv[a:b][o])

@@ -193,12 +193,12 @@ def test_device_loop_rejects_a_broken_frame_and_recovers(gpu):
     """A frame that shares nothing with its predecessor (noise) is rejected by the lost-tracks gate without touching the state;
     the following frame is tracked from the last good image."""
     import torch
-    seq = gpu.synthetic.PlaneSequence(frames=12)
+    seq = gpu.synthetic.PlaneSequence(frames=60)
     gx, gy = np.meshgrid(np.linspace(-4.5, 1.0, 8), np.linspace(-2.5, 2.0, 6))
     objp = np.stack([gx.ravel(), gy.ravel(), np.zeros(gx.size)], axis=1)
     imgp = seq.project(0, objp)
     vis = (imgp[:, 0] > 15) & (imgp[:, 0] < seq.W - 15) & (imgp[:, 1] > 15) & (imgp[:, 1] < seq.H - 15)
-    imgs = [torch.from_numpy(seq.render(k)).cuda() for k in range(12)]
+    imgs = [torch.from_numpy(seq.render(k)).cuda() for k in range(8)]
     noise = torch.from_numpy(np.random.default_rng(0).integers(0, 255, (seq.H, seq.W), dtype=np.uint8)).cuda()
     slam = gpu.slam_device.DeviceMonoSlam(seq.K, seq.dist, (seq.H, seq.W), seed=3)
     slam.start(imgs[0], objp[vis], imgp[vis])
