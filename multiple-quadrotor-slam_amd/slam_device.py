@@ -30,7 +30,11 @@ REASONS = {0: "", 1: "lost track of too many points", 2: "fewer than 8 triangula
 
 
 class DeviceMonoSlam:
-    def __init__(self, cameraMatrix, distCoeffs, image_shape, seed=0, device=0, max_landmarks=1 << 16, verbose=False):
+    def __init__(self, cameraMatrix, distCoeffs, image_shape, seed=0, device=0, max_landmarks=1 << 16, verbose=False,
+                 ba_info=None):
+        """ba_info: an optional `ba_io.BundleAdjustmentInfoContainer`; the loop then records what the reference records for
+        the bundle adjuster (slam2.py:519-522, 634-641, 681-687, 1167-1169, 1204).  Recording reads the live tracks back
+        after every frame (one more synchronisation per frame): the recorder's lists live on the host."""
         self.K = np.asarray(cameraMatrix, dtype=np.float64)
         self.dist = np.asarray(distCoeffs, dtype=np.float64).reshape(-1)[:4]
         self.shape = tuple(image_shape)
@@ -56,6 +60,11 @@ class DeviceMonoSlam:
         self._pending_keyframe = None    # frame index whose refined pose arrives with the next result block
         self._prev = None
         self._max_landmarks = int(max_landmarks)
+        self.ba_info = ba_info
+        self.history = []                # since the base keyframe: (frame, track ids, image points)
+        self._key_pose = None
+        if ba_info is not None:
+            ba_info.set_calibration(self.K, self.dist)
 
     def close(self):
         if self._h:
@@ -86,6 +95,12 @@ class DeviceMonoSlam:
         self.poses.append(pose.reshape(3, 4).copy())
         self.keyframes.append(0)
         self._prev = img
+        if self.ba_info is not None:                         # slam2.py:1167-1169, 1184-1185
+            pts, _, _, tid = self.tracks()
+            self.ba_info.set_point3DAddedIdxs(np.arange(len(o)))
+            self.ba_info.add_points2D_3Dassoc(m, np.arange(len(o)), 0)
+            self.history = [(0, tid.copy(), pts.copy())]
+            self._key_pose = self.poses[0]
         return self.poses[0]
 
     def _take_keyframe_report(self):
@@ -97,12 +112,23 @@ class DeviceMonoSlam:
     def handle_new_frame(self, img):
         """Returns 0 (rejected), 1 (frame) or 2 (keyframe), like the reference's `ret`."""
         t0 = time.perf_counter()
+        if self.ba_info is not None:
+            self.ba_info.next_step()                         # slam2.py:1204: one step per frame, rejected ones included
         rc = self._track(self._h, self._img_ptr(self._prev, self.shape), self._img_ptr(img, self.shape), self._pres)
         if rc != 0:
             _lib.check(rc)
         r = self._res
         self._take_keyframe_report()
         decision = int(r[0])
+        if decision and self.ba_info is not None:
+            self.poses.append(r[12:24].reshape(3, 4).copy())
+            if decision == 2:
+                self.keyframes.append(len(self.poses) - 1)
+            self._record(decision, int(r[11]))
+            self._prev = img
+            self.reports.append(r[:12].copy())
+            self.timing.append(time.perf_counter() - t0)
+            return decision
         if decision == 0:
             if self.verbose:
                 print("REJECTED:", REASONS.get(int(r[1]), "?"))
@@ -116,6 +142,36 @@ class DeviceMonoSlam:
         self.reports.append(r[:12].copy())
         self.timing.append(time.perf_counter() - t0)
         return decision
+
+    def _record(self, decision, landmarks_before):
+        """The recorder's share of a frame (see MonoSlam._frame), from the tracks as the frame -- and, on a keyframe, its
+        keyframe branch -- left them."""
+        frame_idx = len(self.poses) - 1
+        if decision == 2:
+            rep = np.zeros(40)
+            _lib.check(_lib.lib().mqs_slam_flush(self._h, rep.ctypes.data_as(_lib.c_f64p)))      # the keyframe branch has run
+            if rep[24] != 0.0:
+                self.poses[frame_idx] = rep[28:40].reshape(3, 4).copy()
+        pts, _, lm, tid = self.tracks()
+        old = (lm >= 0) & (lm < landmarks_before)            # landmark tracks as the frame's pose saw them (slam2.py:519-522)
+        self.history.append((frame_idx, tid.copy(), pts.copy()))
+        self.ba_info.add_points2D_3Dassoc(pts[old], lm[old], frame_idx)
+        if decision != 2:
+            return
+        new = lm >= landmarks_before
+        if new.any():
+            # slam2.py:634-641: the new landmarks and their image points in every frame since the base keyframe
+            ids, new_tid = lm[new].astype(np.int64), tid[new]
+            self.ba_info.set_point3DAddedIdxs(ids)
+            for ev_frame, ev_tid, ev_pts in self.history:
+                pos = {t: k for k, t in enumerate(ev_tid)}
+                sel = np.array([pos[t] for t in new_tid], dtype=np.int64)
+                self.ba_info.add_points2D_3Dassoc(ev_pts[sel], ids, ev_frame)
+        P1 = np.vstack([self.poses[frame_idx], [0, 0, 0, 1.0]])                                   # slam2.py:681-687
+        P0 = np.vstack([self._key_pose, [0, 0, 0, 1.0]])
+        self.ba_info.add_odometry(P1 @ np.linalg.inv(P0), self.history[0][0], frame_idx)
+        self.history = [(frame_idx, tid.copy(), pts.copy())]
+        self._key_pose = self.poses[frame_idx]
 
     def finish(self):
         """Waits for the last keyframe branch and takes its report."""

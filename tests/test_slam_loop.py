@@ -212,3 +212,34 @@ def test_device_loop_rejects_a_broken_frame_and_recovers(gpu):
     with pytest.raises(ValueError):
         slam.handle_new_frame(imgs[6].cpu())
     slam.close()
+
+
+@pytest.mark.gpu
+def test_device_loop_to_bundle_adjustment_files_end_to_end(gpu, tmp_path):
+    """The device-resident loop with the recorder on: the BA_info.* / traj_out / map_out set it writes passes the reader's two
+    validators and the CLI-compatible bundle adjuster improves on it -- BASELINE configs[4] end to end, the loop's state on the
+    GPU."""
+    import subprocess
+    import run_slam_loop
+    io = gpu.ba_io
+    info = io.BundleAdjustmentInfoContainer(str(tmp_path), "dloop", 1)
+    out = run_slam_loop.run_device(40, ba_info=info, out_files=(str(tmp_path), "dloop", 30))
+    assert out["accepted"] == 40
+    fn = io.create_filenames(str(tmp_path), "dloop", 1)
+    data = io.load_data(fn, 30)
+    io.validate_data_integrity(data, 1)
+    ok, _ = io.validate_sufficiently_constrained(data, True)
+    assert ok
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "bundle_adjust.py"), str(tmp_path), "dloop", "1", "30", "1", "1", "0", "1", "0"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    gt = gpu.synthetic.PlaneSequence(frames=40).centres()
+    before = np.array([p[9:] for _, p in io.load_trajectory(fn.trajectories_in[0])])
+    after = np.array([p[9:] for _, p in io.load_trajectory(fn.trajectories_out[0])])
+    e0 = np.sqrt(np.mean(np.sum((before - gt) ** 2, axis=1)))
+    e1 = np.sqrt(np.mean(np.sum((after - gt) ** 2, axis=1)))
+    path = np.linalg.norm(np.diff(gt, axis=0), axis=1).sum()
+    assert e1 < 0.01 * path and e1 < 1.5 * e0 + 1e-3
+    line = [l for l in r.stdout.splitlines() if l.startswith("cost")][0]
+    assert float(line.split()[3]) < float(line.split()[1])

@@ -38,7 +38,7 @@ def run(frames=60, verbose=False, ba_info=None, out_files=None):
             "frames_per_s": round((frames - 1) / sum(slam.timing), 1)}
 
 
-def run_device(frames=60, verbose=False, repeats=1):
+def run_device(frames=60, verbose=False, repeats=1, ba_info=None, out_files=None):
     """The same sequence through slam_device.DeviceMonoSlam: the loop's state resident on the GPU, one library call per frame
     (images uploaded beforehand, as a capture thread would have them).  `repeats` > 1: the run is repeated on a fresh handle and
     the fastest pass is timed (the first pass pays the first-launch costs of every kernel)."""
@@ -53,7 +53,7 @@ def run_device(frames=60, verbose=False, repeats=1):
     torch.cuda.synchronize()
     best = None
     for _ in range(max(1, repeats)):
-        slam = mqslam_amd.slam_device.DeviceMonoSlam(seq.K, seq.dist, (seq.H, seq.W), seed=1, verbose=verbose)
+        slam = mqslam_amd.slam_device.DeviceMonoSlam(seq.K, seq.dist, (seq.H, seq.W), seed=1, verbose=verbose, ba_info=ba_info)
         slam.start(imgs[0], objp, imgp)
         t0 = time.perf_counter()
         rets = [2]
@@ -66,6 +66,11 @@ def run_device(frames=60, verbose=False, repeats=1):
         else:
             slam.close()
     dt, slam, rets = best
+    if ba_info is not None and out_files is not None:
+        io = mqslam_amd.ba_io
+        ba_info.write_all()
+        ba_info.write_noise(point2D=1.0)
+        io.save_slam_output(io.create_filenames(out_files[0], out_files[1], 1), out_files[2], slam.projection_matrices(), slam.objp)
     traj, gt = slam.trajectory(), seq.centres()
     ok = np.isfinite(traj[:, 0])
     err = np.linalg.norm(traj[ok] - gt[ok], axis=1)
