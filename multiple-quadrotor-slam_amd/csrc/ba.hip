@@ -516,11 +516,12 @@ __device__ __forceinline__ void wl_chunk(const double *sCam, const WlStash stash
             sput(l, c, 0, U[0][0], U[0][1]);
             sput(l, c, 1, U[0][2], U[1][0]);
             sput(l, c, 2, U[1][1], U[1][2]);
-            const double k00 = F00 - fma(U[0][0], U[0][0], fma(U[0][1], U[0][1], U[0][2] * U[0][2]));
-            const double k01 = F01 - fma(U[0][0], U[1][0], fma(U[0][1], U[1][1], U[0][2] * U[1][2]));
-            const double k11 = F11 - fma(U[1][0], U[1][0], fma(U[1][1], U[1][1], U[1][2] * U[1][2]));
-            const double rh0 = -f0 - fma(U[0][0], w0[l], fma(U[0][1], w1[l], U[0][2] * w2[l]));
-            const double rh1 = -f1 - fma(U[1][0], w0[l], fma(U[1][1], w1[l], U[1][2] * w2[l]));
+            // F - U U^T and -(f + U w) as chains of three FMAs each (no separate product and subtraction)
+            const double k00 = fma(-U[0][2], U[0][2], fma(-U[0][1], U[0][1], fma(-U[0][0], U[0][0], F00)));
+            const double k01 = fma(-U[0][2], U[1][2], fma(-U[0][1], U[1][1], fma(-U[0][0], U[1][0], F01)));
+            const double k11 = fma(-U[1][2], U[1][2], fma(-U[1][1], U[1][1], fma(-U[1][0], U[1][0], F11)));
+            const double rh0 = fma(-U[0][2], w2[l], fma(-U[0][1], w1[l], fma(-U[0][0], w0[l], -f0)));
+            const double rh1 = fma(-U[1][2], w2[l], fma(-U[1][1], w1[l], fma(-U[1][0], w0[l], -f1)));
             const WlJg jg = wl_make_jg(xc, yc, zc);
             double T0[6], T1[6];
             wl_k_times_jg(k00, k01, k01, k11, jg, T0, T1);
