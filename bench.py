@@ -164,6 +164,8 @@ def main():
     ap.add_argument("--no-match", action="store_true")
     ap.add_argument("--no-replay", action="store_true")
     ap.add_argument("--no-frontend", action="store_true")
+    ap.add_argument("--no-shard-proxy", action="store_true",
+                    help="skip the 125 k-landmark legs of `ba` (profiler runs: every BA kernel then sees ONE problem size)")
     ap.add_argument("--descriptors", type=int, default=65536)
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--strong-landmarks", type=int, default=1_000_000, help="total landmarks of the ba_strong leg (N > 1)")
@@ -380,7 +382,7 @@ def main():
     ba_out = None
     if ba is not None:
         ba_out = ba.benchmark_report(world, dist)
-        if rank == 0 and world == 1 and N >= 8:
+        if rank == 0 and world == 1 and N >= 8 and not args.no_shard_proxy:
             # what ONE rank of the 8-way sharded configs[3] run holds, on this GPU alone: the serial floor of strong scaling
             ns = N // 8
             sub = mqslam_amd.bundle_adjustment.make_benchmark_problem(np.ascontiguousarray(u[:, :ns]), P, x_it[:ns].clone(), dev,

@@ -190,7 +190,16 @@ __device__ void jacobi9(double *A, double *V, int lane)
     if (lane < 81) V[lane] = (lane % 10 == 0) ? 1.0 : 0.0;
     if (lane + 64 < 81) V[lane + 64] = ((lane + 64) % 10 == 0) ? 1.0 : 0.0;
     mqs_wave_lds_sync();
-    for (int sweep = 0; sweep < 8; ++sweep) {
+    for (int sweep = 0; sweep < 10; ++sweep) {
+        // converged when the off-diagonal mass is at rounding level of the diagonal (usually after 5 or 6 sweeps)
+        double off = 0.0, dia = 0.0;
+        if (act) {
+#pragma unroll
+            for (int j = 0; j < 9; ++j) { const double a = A[k * 9 + j]; if (g == 0) { if (j == k) dia += a * a; else off += a * a; } }
+        }
+#pragma unroll
+        for (int h = 32; h >= 1; h >>= 1) { off += __shfl_xor(off, h); dia += __shfl_xor(dia, h); }
+        if (off <= 1e-30 * dia) break;
         for (int r = 0; r < 9; ++r) {
             // round-robin round r of 9 players: slot g pairs (r + g + 1, r - g - 1) mod 9, player r rests
             int pa = (r + g + 1) % 9, pb = (r + 9 - g - 1) % 9;
@@ -221,6 +230,8 @@ __device__ void jacobi9(double *A, double *V, int lane)
 __device__ void jacobi3(double *a, double *w)
 {
     for (int sweep = 0; sweep < 10; ++sweep) {
+        const double off3 = a[1] * a[1] + a[2] * a[2] + a[5] * a[5], dia3 = a[0] * a[0] + a[4] * a[4] + a[8] * a[8];
+        if (off3 <= 1e-30 * dia3) break;
         for (int pq = 0; pq < 3; ++pq) {
             const int p = pq == 2 ? 1 : 0, q = pq == 0 ? 1 : 2;
             double c, s;
