@@ -869,9 +869,26 @@ __device__ void so3_log_dev(const double *R /*3x3 row-major*/, double w[3])
     const double tr = R[0] + R[4] + R[8];
     double c = 0.5 * (tr - 1.0);
     c = fmin(1.0, fmax(-1.0, c));
-    const double th = acos(c);
     const double vx = R[7] - R[5], vy = R[2] - R[6], vz = R[3] - R[1];
-    const double k = (th < 1e-10) ? 0.5 : th / (2.0 * sin(th));
+    // w = theta / (2 sin theta) * vee(R - R^T), |vee| = 2 sin theta.  A prior sits close to its pose: below 0.1 rad the factor
+    // is asin(s) / (2 s) as a series in s^2 = sin^2 theta (seven terms: 1.4e-16 relative at the switch) -- more accurate there
+    // than acos of a cosine next to 1, and seven FMAs instead of acos + sin (the log map is on the path of every workgroup of
+    // the fused tail when a pose prior is present: ~1 us of a lone wave).
+    const double s2 = 0.25 * fma(vx, vx, fma(vy, vy, vz * vz));
+    double k;
+    if (c > 0.0 && s2 < 0.01) {
+        double p = 143.0 / 10240.0;
+        p = fma(p, s2, 231.0 / 13312.0);
+        p = fma(p, s2, 63.0 / 2816.0);
+        p = fma(p, s2, 35.0 / 1152.0);
+        p = fma(p, s2, 5.0 / 112.0);
+        p = fma(p, s2, 3.0 / 40.0);
+        p = fma(p, s2, 1.0 / 6.0);
+        k = 0.5 * fma(p, s2, 1.0);
+    } else {
+        const double th = acos(c);
+        k = (th < 1e-10) ? 0.5 : th / (2.0 * sin(th));
+    }
     w[0] = k * vx; w[1] = k * vy; w[2] = k * vz;
 }
 
@@ -1175,6 +1192,12 @@ struct SolveLds {
     double info[2];
 };
 
+// diagonal of the solved system: the prior weight, then the damping (Marquardt scaling for lambda >= 0, |lambda| I below)
+__device__ __forceinline__ double damped_diagonal(double v, double w, double lambda)
+{
+    return (lambda >= 0.0) ? (v + w) * (1.0 + lambda) : (v + w) - lambda;
+}
+
 // The starting vectors of the solve wave's 64 lanes, written by ALL threads of the workgroup (`nthreads`; the lone solve wave
 // spent 240 of its ~1 700 instructions selecting them): lane r < n: row r of S with the prior weight and the damping on the
 // diagonal; lane 32 + c: e_c; lane 56: g - prior residual; others 0.
@@ -1189,13 +1212,38 @@ __device__ __forceinline__ void build_solve_matrix(SolveLds<C> &sm, double lambd
         double v = 0.0;
         if (lane < n) {
             v = sm.lin[lane * n + j];
-            if (j == lane) v = (lambda >= 0.0) ? (v + sm.w[lane]) * (1.0 + lambda) : (v + sm.w[lane]) - lambda;
+            if (j == lane) v = damped_diagonal(v, sm.w[lane], lambda);
         } else if (lane >= kSolveInvLane0 && lane < kSolveInvLane0 + n) {
             v = (j == lane - kSolveInvLane0) ? 1.0 : 0.0;
         } else if (lane == kSolveRhsLane) {
             v = sm.lin[n * n + j] - sm.e[j];
         }
         sm.m[idx] = v;
+    }
+}
+
+// The same starting vectors straight from the registers the reduced system was loaded into (thread t holds entries t, t + 256,
+// t + 512 of [S | g | cost | count]): the fused tail's path -- no LDS round trip of the system between the load and the solve.
+// Same values as build_solve_matrix, entry for entry.
+template <int C>
+__device__ __forceinline__ void build_solve_matrix_from_registers(SolveLds<C> &sm, const double (&v)[3], double lambda, int tid)
+{
+    constexpr int n = 6 * C;
+    static_assert(n * n + n + 2 <= 3 * kBlock, "three entries per thread hold the system");
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int k = tid + kBlock * q;
+        if (k < n * n) {
+            const int r = k / n, j = k - r * n;
+            sm.m[k] = (j == r) ? damped_diagonal(v[q], sm.w[r], lambda) : v[q];
+        } else if (k < n * n + n) {
+            const int j = k - n * n;
+            sm.m[kSolveRhsLane * n + j] = v[q] - sm.e[j];
+        }
+    }
+    for (int idx = n * n + tid; idx < 64 * n; idx += kBlock) {          // lanes n .. 63 except the right-hand side's: constants
+        const int lane = idx / n, j = idx - lane * n;
+        if (lane != kSolveRhsLane) sm.m[idx] = (lane >= kSolveInvLane0 && lane < kSolveInvLane0 + n && j == lane - kSolveInvLane0) ? 1.0 : 0.0;
     }
 }
 
@@ -1255,6 +1303,7 @@ __global__ __launch_bounds__(kBlock, 4) void ba_tail_kernel(
     __shared__ double sCam[C * kCamStride];
     __shared__ SolveLds<C> sm;
     const int tid = threadIdx.x;
+    double v[3] = {0.0, 0.0, 0.0};
     if (pr.rows) {
         mqs::peer::wait_and_sum(sm.lin, nlin, pr, tid, kBlock);
         if (blockIdx.x == gridDim.x - 1 && lin_out) {
@@ -1262,12 +1311,16 @@ __global__ __launch_bounds__(kBlock, 4) void ba_tail_kernel(
             for (int k = tid; k < nlin; k += kBlock) lin_out[k] = sm.lin[k];
         }
     } else {
-        for (int k = tid; k < nlin; k += kBlock) sm.lin[k] = lin[k];
+        // the reduced system straight into registers: the loads are in flight while the camera blocks are staged and the
+        // prior terms computed
+#pragma unroll
+        for (int q = 0; q < 3; ++q) v[q] = (tid + kBlock * q < nlin) ? lin[tid + kBlock * q] : 0.0;
     }
     stage_cams<C>(poses, calib, sigma, sCam, tid);                  // ends in a workgroup barrier
     if (tid < 64) pose_prior_terms<C>(poses, prior_poses, prior_sigmas, prior_mask, tid, sm.e, sm.w, sm.info);
     __syncthreads();
-    build_solve_matrix<C>(sm, lambda, tid, kBlock);
+    if (pr.rows) build_solve_matrix<C>(sm, lambda, tid, kBlock);
+    else build_solve_matrix_from_registers<C>(sm, v, lambda, tid);
     __syncthreads();
     // the LAST workgroup of the grid has no landmarks: it publishes dpose, the retracted poses and info (the trigonometry of
     // the retraction, ~1 us on one wave, would otherwise sit on the path of a workgroup that also back-substitutes)

@@ -152,6 +152,9 @@ using float16v = __attribute__((ext_vector_type(16))) float;
 #ifndef MQS_MATCH_F4_NW
 #define MQS_MATCH_F4_NW 8
 #endif
+#ifndef MQS_MATCH_F4_REJECT16
+#define MQS_MATCH_F4_REJECT16 0        // A/B: early reject per accumulator (16 values) instead of per four values (group_step)
+#endif
 #ifndef MQS_MATCH_F4_GROUP
 #define MQS_MATCH_F4_GROUP 2
 #endif
@@ -464,7 +467,46 @@ __global__ __launch_bounds__(NW * 64) void knn2_mfma_kernel(const typename TP::e
             // the previous group's 16 G values, 16 G / KS behind each k-step
             constexpr int kPer = 16 * G / KS;
             static_assert(16 * G % KS == 0 && (!TP::kPrune || kPer % 4 == 0), "scan shares");
-            if constexpr (TP::kPrune) {
+            if constexpr (TP::kPrune && MQS_MATCH_F4_REJECT16 && KS % G == 0) {
+                // one early-reject test per ACCUMULATOR of the previous group (16 values: a tree of five v_min3, two v_min3, one
+                // v_min -- 8 instructions + the compare, where four tests of four values cost 16), behind the k-step at which its
+                // share of the scan would start; only a wave that holds a candidate among the 16 falls back to the groups of four
+                if (ks % (KS / G) == 0) {
+                    const int which = ks / (KS / G), pq = prevq0 + which;
+                    const accv_t &prev = acc[prev0 + which];
+                    unsigned k[16];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) k[e] = TP::key(prev[e]);
+                    unsigned a0, a1, a2, a3, a4, b0, b1;
+                    asm("v_min3_u32 %0, %1, %2, %3" : "=v"(a0) : "v"(k[0]), "v"(k[1]), "v"(k[2]));
+                    asm("v_min3_u32 %0, %1, %2, %3" : "=v"(a1) : "v"(k[3]), "v"(k[4]), "v"(k[5]));
+                    asm("v_min3_u32 %0, %1, %2, %3" : "=v"(a2) : "v"(k[6]), "v"(k[7]), "v"(k[8]));
+                    asm("v_min3_u32 %0, %1, %2, %3" : "=v"(a3) : "v"(k[9]), "v"(k[10]), "v"(k[11]));
+                    asm("v_min3_u32 %0, %1, %2, %3" : "=v"(a4) : "v"(k[12]), "v"(k[13]), "v"(k[14]));
+                    asm("v_min3_u32 %0, %1, %2, %3" : "=v"(b0) : "v"(a0), "v"(a1), "v"(a2));
+                    asm("v_min3_u32 %0, %1, %2, %3" : "=v"(b1) : "v"(a3), "v"(a4), "v"(k[15]));
+                    const unsigned m16 = min(b0, b1);
+                    if (__builtin_amdgcn_ballot_w64(m16 < thr[pq]) != 0) {
+#pragma unroll
+                        for (int e0 = 0; e0 < 16; e0 += 4) {
+                            unsigned m3;
+                            asm("v_min3_u32 %0, %1, %2, %3" : "=v"(m3) : "v"(k[e0]), "v"(k[e0 + 1]), "v"(k[e0 + 2]));
+                            const unsigned m4 = min(m3, k[e0 + 3]);
+                            if (__builtin_amdgcn_ballot_w64(m4 < thr[pq]) != 0) {
+#pragma unroll
+                                for (int e = e0; e < e0 + 4; ++e) {
+                                    const unsigned key = k[e] | (unsigned)(4 * h) | (unsigned)(8 * (e >> 2) + (e & 3));
+                                    unsigned m;
+                                    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(m) : "v"(best[pq]), "v"(second[pq]), "v"(key));
+                                    second[pq] = m;
+                                    best[pq] = min(best[pq], key);
+                                }
+                                thr[pq] = min(second[pq], TP::key_floor(gd1[pq]));
+                            }
+                        }
+                    }
+                }
+            } else if constexpr (TP::kPrune) {
 #pragma unroll
                 for (int gq = 0; gq < kPer / 4; ++gq) {
                     const int v0 = ks * kPer + 4 * gq, which = v0 >> 4, e0 = v0 & 15, pq = prevq0 + which;
