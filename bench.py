@@ -696,8 +696,23 @@ def main():
 
     strong_out = None
     if multi and ba is not None:
-        strong_out = ba_strong_leg(mqslam_amd, np, torch, args.landmarks if strong else args.strong_landmarks, C, rank, world,
-                                   dev, group, dist)
+        total_strong = args.landmarks if strong else args.strong_landmarks
+        strong_out = ba_strong_leg(mqslam_amd, np, torch, total_strong, C, rank, world, dev, group, dist)
+        if isinstance(group, sh.CComm):
+            strong_out["transport"] = group.transport
+            if group.peer_state():
+                # the peer transport has never seen an xGMI hop before the run it is timed on: if the sharded solve over it does not
+                # reproduce the one-rank poses (or a peer's row timed out), the leg is run again over the RCCL communicator alone,
+                # both outcomes are reported, and `ba_strong` is the one that holds.  All ranks take the same branch.
+                flag = torch.tensor([1.0 if (rank != 0 or strong_out["ok"]) and not group.peer_timed_out() else 0.0], device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if flag.item() != 1.0:
+                    failed = strong_out
+                    rccl_only = sh.init_c_comm(rank, world, local_rank, peer=False)
+                    strong_out = ba_strong_leg(mqslam_amd, np, torch, total_strong, C, rank, world, dev, rccl_only, dist)
+                    strong_out["transport"] = "rccl (the peer transport did not reproduce the one-rank poses; its leg is in `peer_transport_leg`)"
+                    strong_out["peer_transport_leg"] = failed
+                    transport += "; ba_strong fell back to RCCL"
 
     if rank == 0:
         out = {
