@@ -58,3 +58,21 @@ def test_product_package_never_imports_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
                 assert "liboracle" not in text, f
+
+
+def test_static_evidence_is_stamped_with_the_sources_it_was_taken_from():
+    """profiles/kernel_flops.json and pmc_traffic.json carry the digest of the kernel sources they describe
+    (tools/evidence_stamp.py); bench.py drops a record whose digest no longer matches.  This test keeps the committed evidence
+    in step with the committed kernels: re-emit (tools/emit_kernel_flops.py, tools/emit_pmc_traffic.py) when it fails."""
+    import json
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import evidence_stamp
+    kf = json.load(open(os.path.join(ROOT, "profiles", "kernel_flops.json")))
+    assert evidence_stamp.is_current(kf["ba_linearize_kernel<4>"]["source"]), "profiles/kernel_flops.json is stale"
+    pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    for fam in ("ba", "tri"):
+        assert evidence_stamp.is_current(pm["sources"][fam]), "profiles/pmc_traffic.json (%s) is stale" % fam
+    # and a changed source is noticed
+    stale = dict(kf["ba_linearize_kernel<4>"]["source"], sha256_16="0" * 16)
+    assert not evidence_stamp.is_current(stale)
