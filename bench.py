@@ -221,26 +221,61 @@ def main():
                 cc = sh.init_c_comm(rank, world, local_rank, peer=os.environ.get("MQS_TRANSPORT", "c") == "c")
             except Exception as e:                              # noqa: BLE001 -- init_c_comm itself agrees before it raises
                 err = str(e)[:120]
-            probe = torch.arange(602, dtype=torch.float64, device=dev0) * (rank + 1)
-            want = probe.clone()
-            dist.all_reduce(want)
-            same = 0.0
-            if cc is not None:
+            def agreed(flag):
+                t = torch.tensor([1.0 if flag else 0.0], device=dev0)
+                dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                return t.item() == 1.0
+
+            def collective_verifies():
+                """The library's all-reduce (whatever transports the context holds) against torch.distributed's, exact integers."""
+                probe = torch.arange(602, dtype=torch.float64, device=dev0) * (rank + 1)
+                want = probe.clone()
+                dist.all_reduce(want)
+                good = False
+                if cc is not None:
+                    try:
+                        cc.all_reduce_sum_(probe)
+                        torch.cuda.synchronize()
+                        good = bool(torch.equal(probe, want)) and not (cc.peer_state() and cc.peer_timed_out())
+                    except Exception as e:                      # noqa: BLE001
+                        nonlocal_err.append(str(e)[:120])
+                return agreed(good)
+
+            def fused_iteration_verifies():
+                """Three one-call Gauss-Newton iterations of a small sharded problem over the context's transport -- over the peer
+                transport that is the path with the send side in the finalize kernel and the wait in the tail -- against the same
+                iterations with torch.distributed's all-reduce between the two halves: poses equal to 1e-9, no timed-out row."""
+                good = False
                 try:
-                    cc.all_reduce_sum_(probe)
+                    us, Ps, ps = mqslam_amd.synthetic.triangulation_problem(4096, 4, seed=mqslam_amd.synthetic.RSEED + 31 * rank)
+                    mk = lambda pg: mqslam_amd.bundle_adjustment.make_benchmark_problem(
+                        us, Ps, ps + 0.01, dev0, seed=mqslam_amd.synthetic.RSEED, process_group=pg, prior_first=4 if rank == 0 else 0)
+                    a, b = mk(cc), mk(True)
+                    a.gauss_newton_iterations(3)
+                    b.gauss_newton_iterations(3)
                     torch.cuda.synchronize()
-                    same = 1.0 if (torch.equal(probe, want) and not (cc.peer_state() and cc.peer_timed_out())) else 0.0
+                    good = float((a.poses - b.poses).abs().max().item()) <= 1e-9 and not (cc.peer_state() and cc.peer_timed_out())
                 except Exception as e:                          # noqa: BLE001
-                    err = str(e)[:120]
-            ok = torch.tensor([same], device=dev0)
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if ok.item() == 1.0:
+                    nonlocal_err.append(str(e)[:120])
+                return agreed(good)
+
+            nonlocal_err = [err] if err else []
+            use = collective_verifies()
+            if use and cc.peer_state() and not fused_iteration_verifies():
+                # the collective by itself is right but the fused path is not: drop the peer transport, keep the RCCL communicator
+                mqslam_amd._lib.lib().mqs_comm_peer_close(cc.ctx.handle)
+                cc.transport = "rccl"
+                nonlocal_err.append("the fused peer path did not reproduce torch.distributed's iterations: peer transport closed")
+                use = collective_verifies()
+            if use:
                 group = cc
                 transport = ("peer stores over xGMI via the C ABI (mqs_comm_peer_*: send side in the finalize kernel, wait + rank-ordered "
                              "sum in the fused tail of mqs_ba_gn_iteration_dev; RCCL communicator beside it)" if cc.peer_state() else
                              "rccl via the C ABI (mqs_comm_*, all-reduce issued inside mqs_ba_gn_iteration_dev)")
+                if nonlocal_err:
+                    transport += " [%s]" % "; ".join(nonlocal_err)
             else:
-                transport += " (C-ABI transport not used: %s)" % (err or "its sum differs from torch.distributed's on some rank",)
+                transport += " (C-ABI transport not used: %s)" % ("; ".join(nonlocal_err) or "its sum differs from torch.distributed's on some rank",)
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank if world > 1 else 0)
