@@ -577,6 +577,8 @@ def main():
                                       "triangulate + refined solvePnP + re-triangulate (host-pointer C ABI, one frame at a time)",
                           "frames": len(rp["frames"]), "keyframes": sum(1 for fr in rp["frames"] if fr[2] > 0),
                           "frames_per_s": round(len(rp["frames"]) / secs, 1),
+                          "frames_per_s_including_the_decoding_of_the_recording": round(len(rp["frames"]) / (secs + rp.get("prep_seconds", 0.0)), 1),
+                          "decode_seconds": round(rp.get("prep_seconds", 0.0), 4),
                           "max_abs_pose_diff_vs_recorded": float(np.abs(rp["poses"] - rec).max()),
                           "landmarks_triangulated": int(np.isfinite(rp["points"][:, 0]).sum())}
         except Exception as e:                                  # noqa: BLE001 -- a secondary leg must not cost the bench line

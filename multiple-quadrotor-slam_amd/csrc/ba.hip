@@ -669,6 +669,12 @@ __global__ __launch_bounds__(kBlock, kWaveLinOcc) void ba_linearize_wave_kernel(
         if (nodist) wl_chunk<C, LL, true>(sCam, stash, points, obs2, mask, prior_w, prior_xyz, N, lambda, r, lane, tot);  \
         else wl_chunk<C, LL, false>(sCam, stash, points, obs2, mask, prior_w, prior_xyz, N, lambda, r, lane, tot);        \
     } while (0)
+        // Which GPU test reaches which chunk body (tests/test_ba_gpu.py): wl_chunk<C, 1..4, true> (no lens distortion):
+        // test_wave_lineariser_every_chunk_size_against_the_c_oracle, the four cases without `dist` (N = 70 000 / 150 000 / 180 001 /
+        // 262 207: a wave owns 1 to 5 rows, i.e. chunks of 1, 2, 3, 4) and test_full_size_properties_1e6x4 (chunks of 4 and 3);
+        // wl_chunk<C, 1..4, false> (k1 = 0.3, or the full Cal3DS2 coefficient set): the ten `-dist` cases of the same test, C = 2, 3, 4,
+        // masked and unmasked; wl_chunk<C, 1, *> alone: every small case of test_linearize_and_backsub_parity.  All against the C
+        // oracle at 1e-10 on S, g, cost, count and, from the same linearisation point, a back-substitution.
 #if defined(MQS_WL_ONLY_L4)      // ISA counting only (tools/isa_mix.py --define MQS_WL_ONLY_L4 [--define MQS_WL_ONLY_NODIST=1]): one body
         wl_chunk<C, 4, MQS_WL_ONLY_NODIST>(sCam, stash, points, obs2, mask, prior_w, prior_xyz, N, lambda, r, lane, tot);
 #else

@@ -32,6 +32,7 @@ struct Rccl {
     fn_all_reduce all_reduce = nullptr;
     fn_error_string error_string = nullptr;
     bool tried = false;
+    char why[256] = "";                  // the loader's message of the first failed attempt (dlerror() is consumed by reading it)
 };
 Rccl g_rccl;
 
@@ -54,13 +55,17 @@ int rccl_load()
             g_rccl.comm_destroy = (fn_comm_destroy)dlsym(h, "ncclCommDestroy");
             g_rccl.error_string = (fn_error_string)dlsym(h, "ncclGetErrorString");
             g_rccl.all_reduce = (fn_all_reduce)dlsym(h, "ncclAllReduce");
-            if (!(g_rccl.get_unique_id && g_rccl.comm_init_rank && g_rccl.comm_destroy && g_rccl.error_string))
+            if (!(g_rccl.get_unique_id && g_rccl.comm_init_rank && g_rccl.comm_destroy && g_rccl.error_string && g_rccl.all_reduce)) {
                 g_rccl.all_reduce = nullptr;
+                snprintf(g_rccl.why, sizeof(g_rccl.why), "a symbol of the RCCL API is missing in the loaded library");
+            }
+        } else {
+            const char *why = dlerror();
+            snprintf(g_rccl.why, sizeof(g_rccl.why), "%s", why ? why : "dlopen failed");
         }
     }
     if (!g_rccl.all_reduce) {
-        const char *why = dlerror();
-        mqs_set_error("RCCL is not available (librccl.so.1 could not be loaded: %s)", why ? why : "symbols missing");
+        mqs_set_error("RCCL is not available (librccl.so.1: %s)", g_rccl.why);
         return MQS_E_RCCL;
     }
     return MQS_OK;

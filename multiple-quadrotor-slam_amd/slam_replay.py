@@ -137,6 +137,7 @@ def replay_frames(data, cam=0, solve_pnp=gpu_solve_pnp, triangulate=gpu_triangul
         # call, scatter the new landmarks.
         from . import pnp as _pnp
         prep = []
+        t_prep0 = time.perf_counter()
         for f in range(1, F):
             assocs = data.point2D3DAssocs[cam][f]
             old = [(i2, p3) for (fr, i2, p3) in assocs if fr == f and added[p3] < f]
@@ -156,6 +157,7 @@ def replay_frames(data, cam=0, solve_pnp=gpu_solve_pnp, triangulate=gpu_triangul
                                p0=np.array([o0[p] for p in ids], dtype=np.float64),
                                p1=np.array([o1[p] for p in ids], dtype=np.float64))
             prep.append(rec)
+        prep_seconds = time.perf_counter() - t_prep0             # decoding the recording: reported beside the frames' times
         src_pts = points if chained else data.points3D
         step = _pnp.KeyframeStepper(intr)                      # the library call with its buffers and pointers set up once
         Pw = np.full((F, 3, 4), np.nan)                        # world -> camera matrices of the poses so far
@@ -183,7 +185,7 @@ def replay_frames(data, cam=0, solve_pnp=gpu_solve_pnp, triangulate=gpu_triangul
             poses[f, :9] = R.T.reshape(-1)
             poses[f, 9:] = -R.T @ P1[:, 3]
             frames.append((f, len(rec["ids_old"]), n_new, time.perf_counter() - t0))
-        return dict(poses=poses, points=points, status=status, frames=frames)
+        return dict(poses=poses, points=points, status=status, frames=frames, prep_seconds=prep_seconds)
     for f in range(1, F):
         t0 = time.perf_counter()
         assocs = data.point2D3DAssocs[cam][f]
