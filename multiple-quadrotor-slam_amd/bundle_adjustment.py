@@ -202,8 +202,10 @@ class BundleAdjuster:
         enqueues work independent of this problem on the current stream; it is issued between the start of the
         all-reduce and the wait for it, so that the latency-bound collective (4.8 KB over xGMI) hides under it."""
         L = _lib.lib()
-        if self.pg is None and overlap is None:
+        if self.pg is None:
             _lib.check(L.mqs_ba_gn_iteration_dev(self._h, float(lam), _sp()))          # one call: C issues everything
+            if overlap is not None:
+                overlap()                                                              # no host-side collective to hide it under
             return
         _lib.check(L.mqs_ba_gn_begin_dev(self._h, float(lam), _sp()))
         work = self.all_reduce(async_op=True)

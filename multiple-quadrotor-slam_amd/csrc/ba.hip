@@ -29,6 +29,7 @@
 #include "wave_reduce.h"
 #include "peer_dev.h"
 #include <stdlib.h>
+#include <atomic>
 
 namespace {
 
@@ -700,11 +701,31 @@ __global__ __launch_bounds__(kBlock, kWaveLinOcc) void ba_linearize_wave_kernel(
     }
 }
 
-// Sums the per-workgroup partials in a fixed order (reproducible) and scatters the slots into
-// out = [S | g | cost | count], mirroring S.  One workgroup of 1024 threads per 64 slots: wave w
-// adds rows w, w+16, ... (64 consecutive slots per row read = one 512-byte coalesced load, eight
-// in flight), then the 16 waves combine through LDS.
+// Sums the per-workgroup partials in a fixed order (reproducible: piece_part_sum below) and scatters the slots into
+// out = [S | g | cost | count], mirroring S.  One workgroup of 1024 threads per 64 slots: sixteen waves over kFinPieces pieces x
+// four parts (64 consecutive slots per row read = one 512-byte coalesced load, eight in flight), combined through LDS.
 constexpr int kFinThreads = 1024;
+
+// The order in which partial rows are added, shared by ba_finalize_kernel and the finalizer workgroups of the fused tail
+// (ba_tail_kernel) so that both give the same bits: the rows are cut into kFinPieces PIECES of ceil(rows / kFinPieces)
+// consecutive rows; inside a piece, part w (0..3) adds rows first + w, first + w + 4, ... in order; a piece's sum is
+// ((p0 + p1) + p2) + p3 and the total the left fold (((P0 + P1) + P2) + ...) over the pieces.
+constexpr int kFinPieces = MQS_FIN_PIECES;
+__device__ __forceinline__ double piece_part_sum(const double *__restrict__ partials, int nrows, int row_stride, int piece, int w, int slot)
+{
+    const int rq = (nrows + kFinPieces - 1) / kFinPieces, r0 = piece * rq, r1 = min(nrows, r0 + rq);
+    double t = 0.0;
+    int b = r0 + w;
+    for (; b + 4 * 7 < r1; b += 4 * 8) {                           // eight loads in flight, added in order
+        double v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = partials[(int64_t)(b + 4 * k) * row_stride + slot];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += v[k];
+    }
+    for (; b < r1; b += 4) t += partials[(int64_t)b * row_stride + slot];
+    return t;
+}
 
 template <int C>
 __global__ __launch_bounds__(kFinThreads) void ba_finalize_kernel(const double *__restrict__ partials, int nblocks,
@@ -713,33 +734,24 @@ __global__ __launch_bounds__(kFinThreads) void ba_finalize_kernel(const double *
     using L = Layout<C>;
     constexpr int NCH = L::kChunks;
     constexpr int kRow = NCH * 32;
-    __shared__ double sSum[16][64];
+    __shared__ double sSum[4 * kFinPieces][64];                        // [4 * piece + part]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int s = blockIdx.x * 64 + lane;
-    double t = 0.0;
-    if (s < kRow) {
-        int b = wave;
-        for (; b + 16 * 7 < nblocks; b += 16 * 8) {
-            double v[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = partials[(int64_t)(b + 16 * k) * kRow + s];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) t += v[k];
-        }
-        for (; b < nblocks; b += 16) t += partials[(int64_t)b * kRow + s];
-    }
-    sSum[wave][lane] = t;
+    for (int pw = wave; pw < 4 * kFinPieces; pw += kFinThreads / 64)
+        sSum[pw][lane] = (s < kRow) ? piece_part_sum(partials, nblocks, kRow, pw >> 2, pw & 3, s) : 0.0;
     __syncthreads();
     if (wave == 0 && s < L::kSlots) {
         double r = 0.0;
 #pragma unroll
-        for (int w = 0; w < 16; ++w) r += sSum[w][lane];
+        for (int q = 0; q < kFinPieces; ++q) {
+            const double ps = ((sSum[4 * q][lane] + sSum[4 * q + 1][lane]) + sSum[4 * q + 2][lane]) + sSum[4 * q + 3][lane];
+            r = q == 0 ? ps : r + ps;
+        }
         int o1, o2;
         slot_to_out<C>(s, o1, o2);
         if (o1 >= 0) out[o1] = r;
         if (o2 >= 0) out[o2] = r;
-        // peer transport (comm.hip): the same entries into slot [rank] of every rank's receive buffer -- this IS the send side
-        // of the iteration's all-reduce
+        // peer transport (comm.hip), ranks that share a GPU: the same entries into slot [rank] of every rank's receive buffer
         if (o1 >= 0) mqs::peer::push_entry(push, o1, r);
         if (o2 >= 0) mqs::peer::push_entry(push, o2, r);
     }
@@ -1296,9 +1308,27 @@ __global__ __launch_bounds__(64) void ba_solve_small_kernel(const double *__rest
 // kernels over xGMI; the workgroup waits for the rows' flags and sums them in rank order -- the all-reduce of the iteration
 // without a launch of its own.
 // ---------------------------------------------------------------------------------------------------------------------
+// The finalize inside the tail (one launch less per iteration: 4.3 us of 34 at 125 k landmarks).  The first kFinPieces * ceil(kRow / 64)
+// workgroups of the tail first add one PIECE (an eighth) of the lineariser's partial rows for 64 slots each (piece_part_sum: the
+// order of ba_finalize_kernel, the same bits), write the piece sums in [S | g | cost | count] numbering and raise a flag stamped
+// with the launch's epoch; every workgroup then stages its cameras and prior terms, waits for the flags (bounded spin) and folds
+// the pieces in order.  The finalizers have the lowest workgroup indices: they are resident before any workgroup that waits
+// for them.  Quarter sums and flags are written and read with agent-scope atomic accesses (coherent per access across the
+// XCDs' L2s; no fence: a fence costs a whole-L2 write-back / invalidate).  With a peer transport the finalizers also store
+// their quarters into every rank's receive buffer and the wait is for every rank's flags: the all-reduce without any launch.
+struct TailFin {
+    const double *partials;           // null: no fused finalize
+    int nrows;
+    double *quarters;                 // the piece sums: [kFinPieces][kQuarterStride]
+    unsigned long long *flags;        // [kFinPieces * slot groups]
+    unsigned long long epoch;
+    mqs_peer_push push;               // world = 0: single GPU
+};
+constexpr int kQuarterStride = MQS_PEER_QUARTER_STRIDE;
+
 template <int C>
 __global__ __launch_bounds__(kBlock, 4) void ba_tail_kernel(
-    const double *__restrict__ lin, mqs_peer_recv pr, const double *__restrict__ poses, const double *__restrict__ calib,
+    const double *__restrict__ lin, mqs_peer_recv pr, TailFin fin, const double *__restrict__ poses, const double *__restrict__ calib,
     const double *__restrict__ sigma, const double *__restrict__ points, const double *__restrict__ obs,
     const uint8_t *__restrict__ mask, const double *__restrict__ prior_w, const double *__restrict__ prior_xyz, int64_t N,
     double lambda, const double *__restrict__ prior_poses, const double *__restrict__ prior_sigmas,
@@ -1310,7 +1340,28 @@ __global__ __launch_bounds__(kBlock, 4) void ba_tail_kernel(
     __shared__ SolveLds<C> sm;
     const int tid = threadIdx.x;
     double v[3] = {0.0, 0.0, 0.0};
-    if (pr.rows) {
+    constexpr int kRowT = Layout<C>::kChunks * 32, kSlotGroups = (kRowT + 63) / 64, kFinalizers = kFinPieces * kSlotGroups;
+    if (fin.partials) {
+        if ((int)blockIdx.x < kFinalizers) {
+            __shared__ double sQ[4][64];
+            const int sg = blockIdx.x % kSlotGroups, q = blockIdx.x / kSlotGroups, lane = tid & 63, wave = tid >> 6;
+            const int slot = 64 * sg + lane;
+            sQ[wave][lane] = (slot < kRowT) ? piece_part_sum(fin.partials, fin.nrows, kRowT, q, wave, slot) : 0.0;
+            __syncthreads();
+            if (wave == 0 && slot < Layout<C>::kSlots) {
+                const double qs = ((sQ[0][lane] + sQ[1][lane]) + sQ[2][lane]) + sQ[3][lane];
+                int o1, o2;
+                slot_to_out<C>(slot, o1, o2);
+                if (o1 >= 0) __hip_atomic_store(fin.quarters + q * kQuarterStride + o1, qs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (o2 >= 0) __hip_atomic_store(fin.quarters + q * kQuarterStride + o2, qs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (o1 >= 0) mqs::peer::push_entry(fin.push, q * kQuarterStride + o1, qs);
+                if (o2 >= 0) mqs::peer::push_entry(fin.push, q * kQuarterStride + o2, qs);
+            }
+            __syncthreads();                          // vmcnt(0) + barrier: the quarter's entries have landed, here and in the peers
+            if (tid == 0) __hip_atomic_store(fin.flags + blockIdx.x, fin.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            mqs::peer::publish_piece(fin.push, blockIdx.x, tid);      // lanes 0 .. world - 1 (none on a single GPU)
+        }
+    } else if (pr.rows) {
         mqs::peer::wait_and_sum(sm.lin, nlin, pr, tid, kBlock);
         if (blockIdx.x == gridDim.x - 1 && lin_out) {
             __syncthreads();
@@ -1325,8 +1376,55 @@ __global__ __launch_bounds__(kBlock, 4) void ba_tail_kernel(
     stage_cams<C>(poses, calib, sigma, sCam, tid);                  // ends in a workgroup barrier
     if (tid < 64) pose_prior_terms<C>(poses, prior_poses, prior_sigmas, prior_mask, tid, sm.e, sm.w, sm.info);
     __syncthreads();
-    if (pr.rows) build_solve_matrix<C>(sm, lambda, tid, kBlock);
-    else build_solve_matrix_from_registers<C>(sm, v, lambda, tid);
+    if (fin.partials) {
+        // the quarters of this launch (and, over the peer transport, of every rank's): wait, then add in the fixed order
+        if (fin.push.world > 0) {
+            mqs::peer::wait_flags(pr, tid, kBlock);
+        } else {
+            if (tid < kFinalizers) {
+                const long long t0 = wall_clock64();
+                while (__hip_atomic_load(fin.flags + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != fin.epoch) {
+                    if (wall_clock64() - t0 > mqs::peer::kSpinTicks) break;           // never expected: the finalizers run first
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int q3 = 0; q3 < 3; ++q3) {
+            const int k = tid + kBlock * q3;
+            if (k < nlin) {
+                if (fin.push.world > 0) {
+                    double t = 0.0;
+                    for (int rk = 0; rk < pr.world; ++rk) {            // rank order; a rank's pieces folded in the finalize's order
+                        const double *row = pr.rows + (size_t)rk * pr.row_stride + k;
+                        double pv[kFinPieces];
+#pragma unroll
+                        for (int q = 0; q < kFinPieces; ++q) pv[q] = __hip_atomic_load(row + q * kQuarterStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        double r = pv[0];
+#pragma unroll
+                        for (int q = 1; q < kFinPieces; ++q) r += pv[q];
+                        t += r;
+                    }
+                    v[q3] = t;
+                } else {
+                    double pv[kFinPieces];
+#pragma unroll
+                    for (int q = 0; q < kFinPieces; ++q) pv[q] = __hip_atomic_load(fin.quarters + q * kQuarterStride + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    double r = pv[0];
+#pragma unroll
+                    for (int q = 1; q < kFinPieces; ++q) r += pv[q];
+                    v[q3] = r;
+                }
+                if (blockIdx.x == gridDim.x - 1 && lin_out) lin_out[k] = v[q3];
+            }
+        }
+        build_solve_matrix_from_registers<C>(sm, v, lambda, tid);
+    } else if (pr.rows) {
+        build_solve_matrix<C>(sm, lambda, tid, kBlock);
+    } else {
+        build_solve_matrix_from_registers<C>(sm, v, lambda, tid);
+    }
     __syncthreads();
     // the LAST workgroup of the grid has no landmarks: it publishes dpose, the retracted poses and info (the trigonometry of
     // the retraction, ~1 us on one wave, would otherwise sit on the path of a workgroup that also back-substitutes)
@@ -1451,11 +1549,15 @@ static int ba_linearize_parts(const double *poses, const double *calib, const do
     if (rc != MQS_OK) return rc;
     mqs_peer_push pp = {};
     if (push) pp = *push;
-    MQS_ARG_CHECK(out != nullptr && workspace != nullptr, "out and workspace must not be null");
+    MQS_ARG_CHECK(workspace != nullptr && ((parts & 2) == 0 || out != nullptr), "out and workspace must not be null");
     MQS_ARG_CHECK(workspace_bytes >= mqs_ba_workspace_bytes(C, N), "workspace too small (mqs_ba_workspace_bytes)");
     MQS_ARG_CHECK(!prior_w || prior_xyz, "prior_xyz required with prior_w");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     double *partials = static_cast<double *>(workspace);
+    {
+        static const bool skip_fin = getenv("MQS_EXPERIMENT_SKIP_FINALIZE") != nullptr;      // timing experiment only (wrong results)
+        if (skip_fin) parts &= ~2;
+    }
     if (C >= 2 && C <= 4 && wave_lineariser_enabled()) {
         // one workgroup per CU (its LDS holds the lanes' columns), as many as there are 64-landmark rows to hand out
         const int64_t rows = (N + 63) / 64;
@@ -1507,6 +1609,46 @@ int mqs_ba_linearize_push(const double *poses, const double *calib, const double
 {
     return ba_linearize_parts(poses, calib, sigma, C, points, obs, mask, prior_w, prior_xyz, N, lambda, out, workspace,
                               workspace_bytes, stream, 3, push);
+}
+
+// The wave lineariser alone (C in 2..4), and where the fused tail finds its partial rows, writes its quarters and raises its flags
+// (all inside the caller's workspace; the epoch is unique per call, so nothing needs initialising).
+std::atomic<unsigned long long> g_fin_epoch{1};
+
+int mqs_ba_linearize_for_fused_tail(const double *poses, const double *calib, const double *sigma, int C, const double *points,
+                                    const double *obs, const uint8_t *mask, const double *prior_w, const double *prior_xyz, int64_t N,
+                                    double lambda, void *workspace, int64_t workspace_bytes, hipStream_t stream, mqs_ba_fin *fin)
+{
+    MQS_ARG_CHECK(mqs_ba_wave_path(C), "the fused finalize serves the wave lineariser (2..4 cameras)");
+    int rc = ba_linearize_parts(poses, calib, sigma, C, points, obs, mask, prior_w, prior_xyz, N, lambda, nullptr, workspace,
+                                workspace_bytes, stream, 1, nullptr);
+    if (rc != MQS_OK) return rc;
+    const int64_t kRow = ws_doubles_rt(C) / 512;
+    const int64_t rows = (N + 63) / 64;
+    int grid = (int)((rows + kWaves - 1) / kWaves);
+    if (grid < 1) grid = 1;
+    if (grid > 256 * kWaveLinOcc) grid = 256 * kWaveLinOcc;
+    double *partials = static_cast<double *>(workspace);
+    double *tail = partials + 512 * kRow - (kFinPieces * kQuarterStride + 64);      // the workspace's last 5 184 doubles: rows 256.. are unused here
+    fin->partials = partials;
+    fin->nrows = grid;
+    fin->quarters = tail;
+    fin->flags = reinterpret_cast<unsigned long long *>(tail + kFinPieces * kQuarterStride);
+    fin->epoch = g_fin_epoch.fetch_add(1);
+    fin->push = nullptr;
+    return MQS_OK;
+}
+
+bool mqs_ba_wave_path(int C) { return C >= 2 && C <= 4 && wave_lineariser_enabled() && tail_fusion_enabled(); }
+
+bool mqs_ba_fused_finalize_enabled()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("MQS_BA_FINALIZE");
+        v = (e && strcmp(e, "kernel") == 0) ? 0 : 1;
+    }
+    return v == 1;
 }
 
 int mqs_ba_finalize_groups(int C)
@@ -1604,7 +1746,7 @@ int mqs_ba_solve_dev(const double *lin, int C, const double *poses, const double
 }  // extern "C"
 
 // The fused tail; `peer` (comm.hip) non-null: the reduced system is the sum of the peers' rows in this rank's receive buffer.
-int mqs_ba_tail_launch(const double *lin, const mqs_peer_recv *peer, int C, const double *poses, const double *calib,
+int mqs_ba_tail_launch(const double *lin, const mqs_peer_recv *peer, const mqs_ba_fin *fin_, int C, const double *poses, const double *calib,
                        const double *sigma, const double *points, const double *obs, const uint8_t *mask, const double *prior_w,
                        const double *prior_xyz, int64_t N, double lambda, const double *prior_poses, const double *prior_sigmas,
                        const uint8_t *prior_mask, double *lin_out, double *dpose, double *poses_out, double *info,
@@ -1612,16 +1754,23 @@ int mqs_ba_tail_launch(const double *lin, const mqs_peer_recv *peer, int C, cons
 {
     mqs_peer_recv pr = {};
     if (peer) pr = *peer;
+    TailFin fin = {};
+    if (fin_) {
+        fin.partials = fin_->partials; fin.nrows = fin_->nrows; fin.quarters = fin_->quarters; fin.flags = fin_->flags;
+        fin.epoch = fin_->epoch;
+        if (fin_->push) fin.push = *fin_->push;
+    }
     // persistent grid: at most 4 workgroups per CU (each solves the reduced system once), one batch of 256 landmarks per
     // workgroup below that; plus the publishing workgroup
     const int64_t rows64 = (N + 63) / 64;
     int64_t g = (rows64 + 3) / 4;
     if (g < 1) g = 1;
     if (g > 1023) g = 1023;
+    if (fin_ && g < 64) g = 64;                      // the finalizer pieces are the first kFinPieces * ceil(kRow / 64) <= 48 workgroups
     switch (C) {
 #define MQS_CASE(c)                                                                                                      \
     case c:                                                                                                              \
-        hipLaunchKernelGGL((ba_tail_kernel<c>), dim3((unsigned)g + 1), dim3(kBlock), 0, stream, lin, pr, poses, calib, sigma, points, obs, \
+        hipLaunchKernelGGL((ba_tail_kernel<c>), dim3((unsigned)g + 1), dim3(kBlock), 0, stream, lin, pr, fin, poses, calib, sigma, points, obs, \
                            mask, prior_w, prior_xyz, N, lambda, prior_poses, prior_sigmas, prior_mask, lin_out, dpose, poses_out, \
                            info, points_out);                                                                            \
         break;
@@ -1650,7 +1799,7 @@ int mqs_ba_solve_backsub_dev(const double *lin, int C, const double *poses, cons
     MQS_ARG_CHECK(!prior_w || prior_xyz, "prior_xyz required with prior_w");
     MQS_ARG_CHECK(!prior_mask || (prior_poses && prior_sigmas), "prior_poses/prior_sigmas required with prior_mask");
     if (C <= 4 && tail_fusion_enabled())
-        return mqs_ba_tail_launch(lin, nullptr, C, poses, calib, sigma, points, obs, mask, prior_w, prior_xyz, N, lambda, prior_poses,
+        return mqs_ba_tail_launch(lin, nullptr, nullptr, C, poses, calib, sigma, points, obs, mask, prior_w, prior_xyz, N, lambda, prior_poses,
                                   prior_sigmas, prior_mask, nullptr, dpose, poses_out, info, points_out,
                                   static_cast<hipStream_t>(stream_));
     rc = mqs_ba_solve_dev(lin, C, poses, prior_poses, prior_sigmas, prior_mask, lambda, dpose, poses_out, info, stream_);

@@ -89,42 +89,64 @@ int mqs_ba_gn_finish_dev(mqs_ba_problem *p, double lambda, int accept, void *str
     return MQS_OK;
 }
 
-int mqs_ba_gn_iteration_dev(mqs_ba_problem *p, double lambda, void *stream)
+int mqs_ba_gn_iteration_dev(mqs_ba_problem *p, double lambda, void *stream_)
 {
     MQS_ARG_CHECK(p != nullptr, "problem must not be null");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int64_t nlin = (int64_t)36 * p->C * p->C + 6 * p->C + 2;
-    // Peer transport (comm.hip): no collective launch at all.  The finalize kernel of the lineariser stores this rank's
-    // reduced system into every rank's receive buffer; the fused tail waits for all rows and adds them in rank order before
-    // it solves.  (C <= 4: the fused tail; ranks that share a GPU -- tests -- wait in a one-workgroup kernel instead.)
+    const int c = p->cur, o = 1 - c;
+    const bool has_comm = p->ctx && mqs_comm_world_size(p->ctx) >= 1;
     mqs_peer_push push;
     mqs_peer_recv recv;
     int fused_wait = 0;
-    if (p->ctx && mqs_comm_peer_next(p->ctx, nlin, mqs_ba_finalize_groups(p->C), &push, &recv, &fused_wait)) {
-        int rc = mqs_ba_linearize_push(p->poses[p->cur], p->calib, p->sigma, p->C, p->points[p->cur], p->obs, p->mask, p->prior_w,
-                                       p->prior_xyz, p->N, lambda, p->lin, p->ws, p->ws_bytes, static_cast<hipStream_t>(stream), &push);
-        if (rc != MQS_OK) return rc;
-        const int c = p->cur, o = 1 - c;
-        if (fused_wait && p->C <= 4) {
-            rc = mqs_ba_tail_launch(nullptr, &recv, p->C, p->poses[c], p->calib, p->sigma, p->points[c], p->obs, p->mask, p->prior_w,
-                                    p->prior_xyz, p->N, lambda, p->prior_poses, p->prior_sigmas, p->prior_mask, p->lin, p->dpose,
-                                    p->poses[o], p->info, p->points[o], static_cast<hipStream_t>(stream));
+    // TWO launches (C in 2..4): the wave lineariser, then the tail -- whose first workgroups add the lineariser's partial rows
+    // (the finalize, inside the launch), and which then solves, retracts and back-substitutes.  Without a communicator, or over
+    // the peer transport with ranks on separate GPUs: there the finalizer pieces also store their quarter sums into every rank's
+    // receive buffer and every workgroup waits for all ranks' pieces -- the all-reduce without any launch of its own.
+    if (mqs_ba_wave_path(p->C) && mqs_ba_fused_finalize_enabled()) {
+        const int pieces = MQS_FIN_PIECES * mqs_ba_finalize_groups(p->C);
+        const bool peer = has_comm && mqs_comm_peer_fused(p->ctx) && mqs_comm_peer_next(p->ctx, MQS_FIN_PIECES * MQS_PEER_QUARTER_STRIDE, pieces, &push, &recv, &fused_wait);
+        if (!has_comm || peer) {
+            mqs_ba_fin fin;
+            int rc = mqs_ba_linearize_for_fused_tail(p->poses[c], p->calib, p->sigma, p->C, p->points[c], p->obs, p->mask, p->prior_w,
+                                                     p->prior_xyz, p->N, lambda, p->ws, p->ws_bytes, stream, &fin);
+            if (rc != MQS_OK) return rc;
+            if (peer) fin.push = &push;
+            rc = mqs_ba_tail_launch(nullptr, peer ? &recv : nullptr, &fin, p->C, p->poses[c], p->calib, p->sigma, p->points[c], p->obs,
+                                    p->mask, p->prior_w, p->prior_xyz, p->N, lambda, p->prior_poses, p->prior_sigmas, p->prior_mask, p->lin,
+                                    p->dpose, p->poses[o], p->info, p->points[o], stream);
             if (rc != MQS_OK) return rc;
             p->cur = o;
             return MQS_OK;
         }
-        rc = mqs_comm_peer_gather(&recv, p->lin, nlin, static_cast<hipStream_t>(stream));
-        if (rc != MQS_OK) return rc;
-        return mqs_ba_gn_finish_dev(p, lambda, 1, stream);
     }
-    int rc = mqs_ba_gn_begin_dev(p, lambda, stream);
+    // Peer transport with ranks that share a GPU (tests), or the finalize kept as a launch: the finalize kernel stores this rank's
+    // reduced system into every rank's receive buffer, a one-workgroup kernel (or, MQS_PEER_FUSED=1, the tail) waits and adds.
+    if (p->ctx && mqs_comm_peer_next(p->ctx, nlin, mqs_ba_finalize_groups(p->C), &push, &recv, &fused_wait)) {
+        int rc = mqs_ba_linearize_push(p->poses[c], p->calib, p->sigma, p->C, p->points[c], p->obs, p->mask, p->prior_w,
+                                       p->prior_xyz, p->N, lambda, p->lin, p->ws, p->ws_bytes, stream, &push);
+        if (rc != MQS_OK) return rc;
+        if (fused_wait && p->C <= 4) {
+            rc = mqs_ba_tail_launch(nullptr, &recv, nullptr, p->C, p->poses[c], p->calib, p->sigma, p->points[c], p->obs, p->mask, p->prior_w,
+                                    p->prior_xyz, p->N, lambda, p->prior_poses, p->prior_sigmas, p->prior_mask, p->lin, p->dpose,
+                                    p->poses[o], p->info, p->points[o], stream);
+            if (rc != MQS_OK) return rc;
+            p->cur = o;
+            return MQS_OK;
+        }
+        rc = mqs_comm_peer_gather(&recv, p->lin, nlin, stream);
+        if (rc != MQS_OK) return rc;
+        return mqs_ba_gn_finish_dev(p, lambda, 1, stream_);
+    }
+    int rc = mqs_ba_gn_begin_dev(p, lambda, stream_);
     if (rc != MQS_OK) return rc;
     // issued whenever the context holds a communicator -- also a one-rank one, where the sum is the identity: the single-GPU
     // tests then run the very call sequence an N-GPU iteration runs (lineariser, ncclAllReduce on the same stream, solve)
-    if (p->ctx && mqs_comm_world_size(p->ctx) >= 1) {
-        rc = mqs_comm_all_reduce_sum_f64_dev(p->ctx, p->lin, nlin, stream);
+    if (has_comm) {
+        rc = mqs_comm_all_reduce_sum_f64_dev(p->ctx, p->lin, nlin, stream_);
         if (rc != MQS_OK) return rc;
     }
-    return mqs_ba_gn_finish_dev(p, lambda, 1, stream);
+    return mqs_ba_gn_finish_dev(p, lambda, 1, stream_);
 }
 
 // `iters` iterations back to back (the benchmark's and the GN driver's inner loop): still no host synchronisation.

@@ -96,12 +96,12 @@ int rccl_load()
 // for any buffer of up to kPeerRowDoubles doubles.
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int kPeerMaxWorld = MQS_PEER_MAX_WORLD;
-constexpr int kPeerRowDoubles = 2560;                   // >= (6 * 8)^2 + 6 * 8 + 2, a multiple of 32
-constexpr int kPeerFlagsPerRank = 8;                    // one per finalize workgroup (<= 7 at 8 cameras)
+constexpr int kPeerRowDoubles = MQS_FIN_PIECES * MQS_PEER_QUARTER_STRIDE;   // a rank's slot: 5 120 doubles (the fused finalize's piece rows; any row <= that)
+constexpr int kPeerFlagsPerRank = 64;                   // one per piece of a rank's row: 6 finalize workgroups, or the fused tail's 48 finalizer pieces
 
 struct PeerComm {
     int rank = 0, world = 1;
-    bool shared_device = false;          // a peer lives on this rank's GPU (tests): never spin inside a chip-filling kernel
+    bool shared_device = false;          // two ranks live on one GPU (tests): never spin inside a chip-filling kernel
     char *mine = nullptr;                // this rank's receive buffer
     char *peer[kPeerMaxWorld] = {};      // rank q's receive buffer as mapped here (peer[rank] == mine)
     bool opened[kPeerMaxWorld] = {};
@@ -185,6 +185,14 @@ int mqs_comm_peer_next(mqs_ctx *ctx, int64_t n, int flags_used, mqs_peer_push *p
         *fused_wait = (e && *e) ? (e[0] != '0') : !pc->shared_device;
     }
     return 1;
+}
+
+bool mqs_comm_peer_fused(const mqs_ctx *ctx)
+{
+    const PeerComm *pc = peer_of(ctx);
+    if (!pc || !pc->open) return false;
+    const char *e = getenv("MQS_PEER_FUSED");
+    return (e && *e) ? (e[0] != '0') : !pc->shared_device;
 }
 
 int mqs_comm_peer_gather(const mqs_peer_recv *recv, double *out, int64_t n, hipStream_t stream)
@@ -279,10 +287,15 @@ int mqs_comm_peer_open(mqs_ctx *ctx, const uint8_t *handles)
     MQS_ARG_CHECK(pc != nullptr && handles != nullptr, "mqs_comm_peer_export first; handles must not be null");
     MQS_ARG_CHECK(!pc->open, "the peer transport is already open");
     MQS_HIP_CHECK(hipSetDevice(ctx->device));
+    // do ANY two ranks share a GPU?  Decided from all handles, so that every rank reaches the same answer (the answer selects the
+    // protocol of an iteration: ranks must not disagree on it)
+    for (int a = 0; a < pc->world; ++a)
+        for (int b = a + 1; b < pc->world; ++b)
+            if (memcmp(handles + (size_t)a * MQS_PEER_HANDLE_BYTES + 64, handles + (size_t)b * MQS_PEER_HANDLE_BYTES + 64, 32) == 0)
+                pc->shared_device = true;
     for (int q = 0; q < pc->world; ++q) {
         const uint8_t *hq = handles + (size_t)q * MQS_PEER_HANDLE_BYTES;
         if (q == pc->rank) { pc->peer[q] = pc->mine; continue; }
-        if (memcmp(hq + 64, pc->bus_id, 32) == 0) pc->shared_device = true;
         hipIpcMemHandle_t h;
         memcpy(&h, hq, sizeof(h));
         void *p = nullptr;

@@ -55,13 +55,31 @@ struct mqs_peer_recv {
 };
 int mqs_comm_peer_next(mqs_ctx *ctx, int64_t n, int flags_used, mqs_peer_push *push, mqs_peer_recv *recv, int *fused_wait);
 int mqs_comm_peer_gather(const mqs_peer_recv *recv, double *out, int64_t n, hipStream_t stream);
+// an open peer transport whose consumers may wait inside their own kernel (no two ranks share a GPU; MQS_PEER_FUSED overrides)
+bool mqs_comm_peer_fused(const mqs_ctx *ctx);
 // ba.hip: the lineariser with its finalize kernel storing the rank's reduced system into the peers' buffers (push != null)
 int mqs_ba_linearize_push(const double *poses, const double *calib, const double *sigma, int C, const double *points,
                           const double *obs, const uint8_t *mask, const double *prior_w, const double *prior_xyz, int64_t N,
                           double lambda, double *out, void *workspace, int64_t workspace_bytes, hipStream_t stream,
                           const mqs_peer_push *push);
 int mqs_ba_finalize_groups(int C);       // workgroups of the finalize kernel = flags a rank sets per reduction
-int mqs_ba_tail_launch(const double *lin, const mqs_peer_recv *peer, int C, const double *poses, const double *calib,
+// the finalize fused into the tail (ba.hip): where the partial rows are, where the quarter sums and their flags go
+constexpr int MQS_FIN_PIECES = 8;                  // pieces the partial rows are cut into (fused finalize: one workgroup per piece and 64 slots)
+constexpr int MQS_PEER_QUARTER_STRIDE = 640;       // doubles between the piece rows (>= (6 * 4)^2 + 6 * 4 + 2); MQS_FIN_PIECES of them = a rank's slot
+struct mqs_ba_fin {
+    const double *partials;
+    int nrows;
+    double *quarters;
+    unsigned long long *flags;
+    unsigned long long epoch;
+    const mqs_peer_push *push;           // non-null: the quarters also go into every rank's receive buffer
+};
+int mqs_ba_linearize_for_fused_tail(const double *poses, const double *calib, const double *sigma, int C, const double *points,
+                                    const double *obs, const uint8_t *mask, const double *prior_w, const double *prior_xyz, int64_t N,
+                                    double lambda, void *workspace, int64_t workspace_bytes, hipStream_t stream, mqs_ba_fin *fin);
+bool mqs_ba_wave_path(int C);            // wave lineariser + fused tail serve this camera count (and are not switched off)
+bool mqs_ba_fused_finalize_enabled();    // MQS_BA_FINALIZE=kernel keeps the finalize launch (A/B)
+int mqs_ba_tail_launch(const double *lin, const mqs_peer_recv *peer, const mqs_ba_fin *fin, int C, const double *poses, const double *calib,
                        const double *sigma, const double *points, const double *obs, const uint8_t *mask, const double *prior_w,
                        const double *prior_xyz, int64_t N, double lambda, const double *prior_poses, const double *prior_sigmas,
                        const uint8_t *prior_mask, double *lin_out, double *dpose, double *poses_out, double *info,

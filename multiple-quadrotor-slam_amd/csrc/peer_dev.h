@@ -23,6 +23,16 @@ __device__ __forceinline__ bool spin_until(const unsigned long long *flag, unsig
     return true;
 }
 
+// Called by every thread of a workgroup: wait until every rank's pieces of reduction rv.seq have landed (bounded spin)
+__device__ __forceinline__ void wait_flags(const mqs_peer_recv &rv, int tid, int nthreads)
+{
+    bool ok = true;
+    for (int f = tid; f < rv.world * rv.flags_per_rank; f += nthreads)
+        ok = spin_until(rv.flags + (f / rv.flags_per_rank) * rv.flags_stride + f % rv.flags_per_rank, rv.seq) && ok;
+    if (!ok) *rv.timeout_flag = 1;
+    __syncthreads();                     // also keeps the compiler from moving the data loads above the flag loads
+}
+
 // Called by every thread of a workgroup: wait for every rank's row of reduction rv.seq, then out[i] = sum over ranks, in rank
 // order, of row[rank][i] for i < n (the same bits on every rank).  `out` may be LDS or global.
 __device__ __forceinline__ void wait_and_sum(double *out, int n, const mqs_peer_recv &rv, int tid, int nthreads)

@@ -71,6 +71,7 @@ def compile_asm(src, defines):
         out = os.path.join(td, "k.s")
         cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", src, "-o", out]
         cmd += ["-D" + d for d in defines]
+        cmd += os.environ.get("MQS_ISA_MIX_FLAGS", "").split()          # extra compiler flags for what-if counts
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(r.stderr[-3000:])
