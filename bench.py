@@ -538,7 +538,7 @@ def main():
         hbm["frac"] = round(hbm["achieved"] / HBM_PEAK_GBPS, 4)
         if flop:
             tf = flop * N / (ms_lin * 1e-3) / 1e12
-            roofline = {"bound": "fp64_valu", "kernel": "ba_linearize_wave_kernel<%d>" % C, "achieved": round(tf, 2),
+            roofline = {"bound": "fp64_valu", "kernel": "ba_linearize_wave_kernel<%d, true>" % C, "achieved": round(tf, 2),
                         "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / FP64_VALU_PEAK_TFLOPS, 4),
                         "traffic": hbm["traffic"], "avg_launch_ms": round(ms_lin, 5), "fp64_flop_per_landmark": flop,
                         "valu_instructions_per_landmark": kf.get("valu_instructions_per_landmark"),
@@ -549,7 +549,7 @@ def main():
                                 "`hbm` is the same launch against the 8 TB/s roof SURVEY 8(d) assigns it"}
         else:
             # no current flop count for this tree's kernel (profiles/kernel_flops.json is stale or missing): the HBM view only
-            roofline = dict(rooflines["ba_linearize_schur"], kernel="ba_linearize_wave_kernel<%d>" % C, traffic=hbm["traffic"], hbm=hbm,
+            roofline = dict(rooflines["ba_linearize_schur"], kernel="ba_linearize_wave_kernel<%d, true>" % C, traffic=hbm["traffic"], hbm=hbm,
                             avg_launch_ms=round(ms_lin, 5), fp64_flop_per_landmark=None,
                             stale="profiles/kernel_flops.json does not match the kernel sources (tools/evidence_stamp.py)")
         roofline["static_evidence_stale"] = pmc_stale or None

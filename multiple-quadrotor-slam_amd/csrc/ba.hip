@@ -30,6 +30,7 @@
 #include "peer_dev.h"
 #include <stdlib.h>
 #include <atomic>
+#include <type_traits>
 
 namespace {
 
@@ -330,8 +331,8 @@ __device__ __forceinline__ void a_add(AReg &r, double v) { a_put(r, a_get(r) + v
 // make_factor of ba_math.h with ONE select where that one has sixteen: an unused factor (masked, or behind its camera) gets
 // the scale 0, which makes E, F and f exact zeros, and its x, y, Z -- finite by construction: a point behind the camera is
 // divided by 1 -- then only ever multiply zeros downstream (Uh = F PR L^-T = 0, k = 0, T = 0).  u, v must be finite.
-template <bool NODIST>
-__device__ __forceinline__ Factor wl_make_factor(const double *cam, double px, double py, double pz, double u, double v, bool seen)
+template <bool NODIST, class CamPtr>
+__device__ __forceinline__ Factor wl_make_factor(const CamPtr cam, double px, double py, double pz, double u, double v, bool seen)
 {
     Factor o;
     const double dx = px - cam[9], dy = py - cam[10], dz = pz - cam[11];
@@ -378,23 +379,80 @@ __device__ __forceinline__ Factor wl_make_factor(const double *cam, double px, d
     }
     o.F11 = fma(E01, E01, E11 * E11);
     o.f1 = fma(E01, eu, E11 * ev);
+    // two selects (the values are finite on every path: u, v are zeros for an unseen factor, Z is 1 behind the camera); as
+    // nested conditionals the compiler built two divergent regions of ~10 scalar instructions per factor around them
     const double ce = cam[22];
-    o.half_e2 = seen ? (front ? 0.5 * fma(eu, eu, ev * ev) : ce * ce) : 0.0;
+    double he = 0.5 * fma(eu, eu, ev * ev), ce2 = ce * ce;
+    asm volatile("" : "+v"(he), "+v"(ce2));
+    he = front ? he : ce2;
+    o.half_e2 = seen ? he : 0.0;
     o.valid = ok;
     return o;
+}
+
+template <class CamPtr>
+__device__ __forceinline__ void wl_make_PR(const CamPtr cam, double x, double y, double PR[2][3])   // make_PR of ba_math.h
+{
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        PR[0][k] = fma(-x, cam[3 * k + 2], cam[3 * k + 0]);
+        PR[1][k] = fma(-y, cam[3 * k + 2], cam[3 * k + 1]);
+    }
 }
 
 // Makes a value materialise HERE: without it the compiler sinks the landmark-block sums of pass A (and every product that
 // feeds them: 4 cameras x 3 landmarks x 15 doubles) down to their first use after the loop and parks them in between.
 __device__ __forceinline__ void wl_pin(double &x) { asm volatile("" : "+v"(x)); }
 
-template <int C, int L, bool NODIST>
-__device__ __forceinline__ void wl_chunk(const double *sCam, const WlStash stash, const double *__restrict__ points,
+// The staged camera blocks as the wave lineariser reads them: through the CONSTANT address space at a wave-uniform address, i.e.
+// with scalar loads into scalar registers (s_load_dwordx16), which fp64 instructions take as an operand for free.  From LDS a
+// camera's 23 constants cost ten ds_read_b128 and as many waits per FACTOR (the compiler did not keep them over a camera's four
+// landmarks at this register pressure): ~470 of the chunk's instructions.  The kernel writes the blocks to a slice of its
+// workspace first (wl_publish_cams).
+typedef const __attribute__((address_space(4))) double *WlCam;
+// Both forms are built (the kernel's SCALAR parameter): the scalar one costs a prologue (publish, wait for the stores, empty the
+// scalar cache) and a scalar-load round trip per camera and chunk, ~1.3 us that a wave with ONE short chunk does not earn back
+// (125 k landmarks: 19.0 against 17.8 us); with four chunks it is 3.6 - 5 us ahead (1e6: 100.0 against 103.6 us on one box).
+// The launcher picks by landmarks per wave (kWlScalarMinLandmarks).
+#ifndef MQS_WL_SCALAR_CAMS
+#define MQS_WL_SCALAR_CAMS -1               // A/B: 0 = always from LDS, 1 = always scalar, -1 = by size
+#endif
+constexpr int64_t kWlScalarMinLandmarks = 400000;      // ~1.5 chunks of 256 landmarks per wave at 1 024 waves
+
+#if defined(MQS_WL_PROBE_WAIT)               // timing probe builds only (tools/probes/wl_wait_probe.py): shader cycles a wave spends in waits
+__device__ unsigned long long g_wl_probe[4][1024];
+#define MQS_WL_PROBE(slot, what)                                                                    \
+    {                                                                                               \
+        const unsigned long long t0_ = __builtin_readcyclecounter();                                \
+        asm volatile(what ::: "memory");                                                            \
+        const unsigned long long t1_ = __builtin_readcyclecounter();                                \
+        if (lane == 0) g_wl_probe[slot][(blockIdx.x * 4 + (threadIdx.x >> 6)) & 1023] += t1_ - t0_; \
+    }
+extern "C" int mqs_debug_wl_probe(unsigned long long *out, int clear)
+{
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wl_probe), sizeof(g_wl_probe)) != hipSuccess) return -1;
+    if (clear) { static unsigned long long z[4][1024]; if (hipMemcpyToSymbol(HIP_SYMBOL(g_wl_probe), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#else
+#define MQS_WL_PROBE(slot, what) {}
+#endif
+
+// the scalar loads of a camera's block are issued HERE (per chunk and camera; hoisted out of the chunk loop, four cameras' worth of
+// scalar registers spilled into vector lanes and came back through v_readlane)
+__device__ __forceinline__ void wl_cam_here(WlCam &cam) { asm volatile("" : "+s"(cam)); }
+__device__ __forceinline__ void wl_cam_here(const double *&) {}
+
+template <int C, int L, bool NODIST, class WlCamPtr>
+__device__ __forceinline__ void wl_chunk(const WlCamPtr sCam, const WlStash stash, const double *__restrict__ points,
                                          const double2 *__restrict__ obs2, const uint8_t *__restrict__ mask,
                                          const double *__restrict__ prior_w, const double *__restrict__ prior_xyz, int64_t N,
                                          double lambda, int64_t row0, int lane, double *tot)
 {
     using LT = Layout<C>;
+#if defined(MQS_WL_PROBE_WAIT)
+    const unsigned long long chunk_t0 = __builtin_readcyclecounter();
+#endif
     // the stash of landmark l, camera c: LDS for the first kWaveLinLdsL landmarks, accumulation registers for the fourth (the
     // LDS holds three landmarks' worth; l, c, k are compile-time after unrolling, so the choice costs nothing)
     AReg a3[C][6];
@@ -416,17 +474,34 @@ __device__ __forceinline__ void wl_chunk(const double *sCam, const WlStash stash
         const int64_t i = (row0 + l) * 64 + lane;
         live[l] = i < N;
         idx[l] = live[l] ? i : 0;
+#if defined(MQS_WL_EXPERIMENT_NOLOAD)      // timing experiment only: what the exposed memory latency of a chunk costs (wrong results)
+        px[l] = 0.01 * lane + (double)l; py[l] = 0.02 * lane - 0.5; pz[l] = 0.25 * (double)(i & 7);
+#else
         px[l] = points[3 * idx[l] + 0]; py[l] = points[3 * idx[l] + 1]; pz[l] = points[3 * idx[l] + 2];
+#endif
     }
     double2 ob[2][L];                       // this camera's and the next one's measurements
+    uint8_t mk[2][L];                       // and their mask bytes: loaded with the measurements, never behind a wait of their own
+    double pwl[L];                          // the prior weights: all loads of the chunk's head are in flight before the first wait
 #pragma unroll
-    for (int l = 0; l < L; ++l) ob[0][l] = obs2[idx[l]];
+    for (int l = 0; l < L; ++l) {
+#if defined(MQS_WL_EXPERIMENT_NOLOAD)
+        ob[0][l] = make_double2(300.0 + lane, 200.0 + (double)l);
+        mk[0][l] = 1;
+        pwl[l] = 0.0;
+#else
+        ob[0][l] = obs2[idx[l]];
+        mk[0][l] = mask ? mask[idx[l]] : (uint8_t)1;
+        pwl[l] = prior_w ? prior_w[idx[l]] : 0.0;
+#endif
+    }
+    MQS_WL_PROBE(0, "s_waitcnt vmcnt(0)")
 #pragma unroll
     for (int l = 0; l < L; ++l) {
         // PriorFactor<Point3>: enters the landmark block at its start (H = w I, g = -w (p - p0)), so nothing of it stays live
         double pw = 0.0, ddx = 0.0, ddy = 0.0, ddz = 0.0;
         if (prior_w) {
-            const double w = prior_w[idx[l]];
+            const double w = pwl[l];
             if (live[l] && w > 0.0) {
                 pw = w;
                 ddx = px[l] - prior_xyz[3 * idx[l] + 0];
@@ -443,19 +518,32 @@ __device__ __forceinline__ void wl_chunk(const double *sCam, const WlStash stash
     AReg X[L][C], Y[L][C], Z[L][C];
 #pragma unroll
     for (int c = 0; c < C; ++c) {
-        const double *cam = sCam + kCamStride * c;
+        WlCamPtr cam = sCam + kCamStride * c;
+        wl_cam_here(cam);
         if (c + 1 < C) {
 #pragma unroll
-            for (int l = 0; l < L; ++l) ob[(c + 1) & 1][l] = obs2[(int64_t)(c + 1) * N + idx[l]];
+            for (int l = 0; l < L; ++l) {
+#if defined(MQS_WL_EXPERIMENT_NOLOAD)
+                ob[(c + 1) & 1][l] = make_double2(300.0 + lane + c, 200.0 + (double)l);
+                mk[(c + 1) & 1][l] = 1;
+#else
+                ob[(c + 1) & 1][l] = obs2[(int64_t)(c + 1) * N + idx[l]];
+                mk[(c + 1) & 1][l] = mask ? mask[(int64_t)(c + 1) * N + idx[l]] : (uint8_t)1;
+#endif
+            }
         }
+        if (c > 0 && c + 1 < C) MQS_WL_PROBE(1, "s_waitcnt vmcnt(4)")      // camera c's measurements (the 4 loads of camera c + 1 may stay out; L = 4, no mask)
+        if (c > 0 && c + 1 == C) MQS_WL_PROBE(1, "s_waitcnt vmcnt(0)")
 #pragma unroll
         for (int l = 0; l < L; ++l) {
-            const bool seen = live[l] && (mask ? mask[(int64_t)c * N + idx[l]] != 0 : true);
+            unsigned mbyte = mk[c & 1][l];
+            asm volatile("" : "+v"(mbyte));           // compared HERE: at the load the compare is a wait for one byte, per factor
+            const bool seen = live[l] && mbyte != 0;
             // a masked slot may hold NaN: selects, not products
             const double u = seen ? ob[c & 1][l].x : 0.0, v = seen ? ob[c & 1][l].y : 0.0;
             const Factor fc = wl_make_factor<NODIST>(cam, px[l], py[l], pz[l], u, v, seen);
             double PR[2][3];
-            make_PR(cam, fc.x, fc.y, PR);
+            wl_make_PR(cam, fc.x, fc.y, PR);
             point_add_factor(ps[l], fc, PR);
             a_put(X[l][c], fc.x); a_put(Y[l][c], fc.y); a_put(Z[l][c], fc.Z);
             sput(l, c, 0, fc.F00, fc.F01);
@@ -489,7 +577,8 @@ __device__ __forceinline__ void wl_chunk(const double *sCam, const WlStash stash
     for (int k = 0; k < 3; ++k) dq[0][k] = sget(0, 0, k);
 #pragma unroll
     for (int c = 0; c < C; ++c) {
-        const double *cam = sCam + kCamStride * c;
+WlCamPtr cam = sCam + kCamStride * c;
+        wl_cam_here(cam);
         double buf[32];
 #pragma unroll
         for (int l = 0; l < L; ++l) {
@@ -503,7 +592,7 @@ __device__ __forceinline__ void wl_chunk(const double *sCam, const WlStash stash
             const double F00 = s0.x, F01 = s0.y, F11 = s1.x, f0 = s1.y, f1 = s2.x;
             const double xc = a_get(X[l][c]), yc = a_get(Y[l][c]), zc = a_get(Z[l][c]);
             double PR[2][3];
-            make_PR(cam, xc, yc, PR);
+            wl_make_PR(cam, xc, yc, PR);
             double U[2][3];
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
@@ -624,9 +713,13 @@ __device__ __forceinline__ void wl_chunk(const double *sCam, const WlStash stash
             MQS_SCHED_FENCE();
         }
     }
+#if defined(MQS_WL_PROBE_WAIT)
+    if (lane == 0) g_wl_probe[3][(blockIdx.x * 4 + (threadIdx.x >> 6)) & 1023] += __builtin_readcyclecounter() - chunk_t0;
+#endif
 }
 
-template <int C>
+template <int C> constexpr int kWlCamSlice = (C * kCamStride + 15) / 16 * 16;      // doubles per workgroup: whole 128-byte lines
+template <int C, bool SCALAR>
 __global__ __launch_bounds__(kBlock, kWaveLinOcc) void ba_linearize_wave_kernel(
     const double *__restrict__ poses, const double *__restrict__ calib, const double *__restrict__ sigma,
     const double *__restrict__ points, const double *__restrict__ obs, const uint8_t *__restrict__ mask,
@@ -642,8 +735,25 @@ __global__ __launch_bounds__(kBlock, kWaveLinOcc) void ba_linearize_wave_kernel(
     extern __shared__ __attribute__((aligned(16))) unsigned char wl_smem[];
     double2 *sStash = reinterpret_cast<double2 *>(wl_smem);                                // [kWaveLinLdsL * C * 3][kBlock]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // the row walk is scalar
     stage_cams<C>(poses, calib, sigma, sCam, tid);
+    WlCam cams_scalar = nullptr;
+    if (SCALAR) {
+    // this workgroup's copy of the camera blocks in global memory (a 128-byte-aligned slice of the workspace behind the rows of
+    // partials: no other workgroup's bytes share a cache line with it), for the scalar loads of wl_chunk.  Write-through stores,
+    // acknowledged (mqs_stores_landed) before the barrier; the scalar cache is emptied of what an earlier launch may have left
+    // for these addresses; the address reaches the loads through an opaque register, so that no load is scheduled above this.
+    double *cam_slice = partials + (int64_t)256 * kRow + (int64_t)blockIdx.x * kWlCamSlice<C>;
+    for (int k = tid; k < C * kCamStride; k += kBlock) __hip_atomic_store(cam_slice + k, sCam[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    mqs_stores_landed();
+    __syncthreads();
+    __builtin_amdgcn_s_dcache_inv();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    cams_scalar = (WlCam)(cam_slice);
+    asm volatile("" : "+s"(cams_scalar) : : "memory");
+    }
+    typename std::conditional<SCALAR, WlCam, const double *>::type cams;
+    if constexpr (SCALAR) cams = cams_scalar; else cams = sCam;
 
     // window totals of this wave: a row in Layout<C> numbering behind the stash (entry j of a window lives in lanes 2j, 2j+1)
     double *sTot = reinterpret_cast<double *>(wl_smem + sizeof(double2) * kWaveLinLdsL * C * 3 * kBlock);   // [kWaves][kRow]
@@ -667,8 +777,8 @@ __global__ __launch_bounds__(kBlock, kWaveLinOcc) void ba_linearize_wave_kernel(
         // model; the bodies are whole chunks, so the instruction stream of a launch never contains the other variant
 #define MQS_WL_CALL(LL)                                                                                                   \
     do {                                                                                                                  \
-        if (nodist) wl_chunk<C, LL, true>(sCam, stash, points, obs2, mask, prior_w, prior_xyz, N, lambda, r, lane, tot);  \
-        else wl_chunk<C, LL, false>(sCam, stash, points, obs2, mask, prior_w, prior_xyz, N, lambda, r, lane, tot);        \
+        if (nodist) wl_chunk<C, LL, true>(cams, stash, points, obs2, mask, prior_w, prior_xyz, N, lambda, r, lane, tot);  \
+        else wl_chunk<C, LL, false>(cams, stash, points, obs2, mask, prior_w, prior_xyz, N, lambda, r, lane, tot);        \
     } while (0)
         // Which GPU test reaches which chunk body (tests/test_ba_gpu.py): wl_chunk<C, 1..4, true> (no lens distortion):
         // test_wave_lineariser_every_chunk_size_against_the_c_oracle, the four cases without `dist` (N = 70 000 / 150 000 / 180 001 /
@@ -677,7 +787,7 @@ __global__ __launch_bounds__(kBlock, kWaveLinOcc) void ba_linearize_wave_kernel(
         // masked and unmasked; wl_chunk<C, 1, *> alone: every small case of test_linearize_and_backsub_parity.  All against the C
         // oracle at 1e-10 on S, g, cost, count and, from the same linearisation point, a back-substitution.
 #if defined(MQS_WL_ONLY_L4)      // ISA counting only (tools/isa_mix.py --define MQS_WL_ONLY_L4 [--define MQS_WL_ONLY_NODIST=1]): one body
-        wl_chunk<C, 4, MQS_WL_ONLY_NODIST>(sCam, stash, points, obs2, mask, prior_w, prior_xyz, N, lambda, r, lane, tot);
+        wl_chunk<C, 4, MQS_WL_ONLY_NODIST>(cams, stash, points, obs2, mask, prior_w, prior_xyz, N, lambda, r, lane, tot);
 #else
 #if MQS_WL_MAXL >= 4
         if (nl == 4) MQS_WL_CALL(4); else
@@ -756,7 +866,8 @@ __global__ __launch_bounds__(kFinThreads) void ba_finalize_kernel(const double *
         if (o2 >= 0) mqs::peer::push_entry(push, o2, r);
     }
     if (push.world > 0) {
-        __syncthreads();                              // the stores above have landed (vmcnt(0) rides in the barrier)
+        mqs_stores_landed();
+        __syncthreads();                              // every wave's stores above have landed, in this GPU and in the peers
         if (wave == 0) mqs::peer::publish_piece(push, blockIdx.x, lane);
     }
 }
@@ -1357,7 +1468,8 @@ __global__ __launch_bounds__(kBlock, 4) void ba_tail_kernel(
                 if (o1 >= 0) mqs::peer::push_entry(fin.push, q * kQuarterStride + o1, qs);
                 if (o2 >= 0) mqs::peer::push_entry(fin.push, q * kQuarterStride + o2, qs);
             }
-            __syncthreads();                          // vmcnt(0) + barrier: the quarter's entries have landed, here and in the peers
+            mqs_stores_landed();
+            __syncthreads();                          // the piece's entries have landed, here and in the peers
             if (tid == 0) __hip_atomic_store(fin.flags + blockIdx.x, fin.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             mqs::peer::publish_piece(fin.push, blockIdx.x, tid);      // lanes 0 .. world - 1 (none on a single GPU)
         }
@@ -1565,13 +1677,18 @@ static int ba_linearize_parts(const double *poses, const double *calib, const do
         if (grid < 1) grid = 1;
         if (grid > 256 * kWaveLinOcc) grid = 256 * kWaveLinOcc;
         const size_t lds = (size_t)kWaveLinLdsL * C * 3 * kBlock * sizeof(double2) + (size_t)kWaves * 352 * sizeof(double);   // 352 = Layout<4>'s row, the largest here
+        const bool scalar_cams = MQS_WL_SCALAR_CAMS < 0 ? N >= kWlScalarMinLandmarks : MQS_WL_SCALAR_CAMS != 0;
         switch (C) {
 #define MQS_CASE(c)                                                                                        \
     case c: {                                                                                              \
-        static mqs_lds_opt_in opt;                      /* per device: dynamic LDS above 64 KiB needs the opt-in */ \
-        MQS_HIP_CHECK(mqs_lds_opt_in_once(opt, reinterpret_cast<const void *>(ba_linearize_wave_kernel<c>), lds));             \
-        if (parts & 1)                                                                                     \
-            hipLaunchKernelGGL((ba_linearize_wave_kernel<c>), dim3(grid), dim3(kBlock), lds, stream, poses, calib, sigma, \
+        static mqs_lds_opt_in opt, opt_s;               /* per device: dynamic LDS above 64 KiB needs the opt-in */ \
+        MQS_HIP_CHECK(mqs_lds_opt_in_once(opt, reinterpret_cast<const void *>(ba_linearize_wave_kernel<c, false>), lds));      \
+        MQS_HIP_CHECK(mqs_lds_opt_in_once(opt_s, reinterpret_cast<const void *>(ba_linearize_wave_kernel<c, true>), lds));     \
+        if ((parts & 1) && scalar_cams)                                                                    \
+            hipLaunchKernelGGL((ba_linearize_wave_kernel<c, true>), dim3(grid), dim3(kBlock), lds, stream, poses, calib, sigma, \
+                               points, obs, mask, prior_w, prior_xyz, N, lambda, partials);                \
+        else if (parts & 1)                                                                                \
+            hipLaunchKernelGGL((ba_linearize_wave_kernel<c, false>), dim3(grid), dim3(kBlock), lds, stream, poses, calib, sigma, \
                                points, obs, mask, prior_w, prior_xyz, N, lambda, partials);                \
         if (parts & 2)                                                                                     \
             hipLaunchKernelGGL((ba_finalize_kernel<c>), dim3((Layout<c>::kChunks * 32 + 63) / 64), dim3(kFinThreads), 0, stream, partials, grid, out, pp);   \

@@ -120,7 +120,8 @@ __global__ __launch_bounds__(256) void peer_all_reduce_kernel(double *__restrict
 {
     const int tid = threadIdx.x;
     for (int i = tid; i < n; i += 256) mqs::peer::push_entry(push, i, buf[i]);
-    __syncthreads();                     // vmcnt(0) + barrier: the row has landed everywhere before its flags go up (peer_dev.h)
+    mqs_stores_landed();
+    __syncthreads();                     // the row has landed everywhere before its flags go up (peer_dev.h)
     if (tid < push.world * recv.flags_per_rank)
         __hip_atomic_store(push.flag[tid / recv.flags_per_rank] + tid % recv.flags_per_rank, push.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     mqs::peer::wait_and_sum(buf, n, recv, tid, 256);

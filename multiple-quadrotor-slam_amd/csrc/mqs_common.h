@@ -149,6 +149,13 @@ __device__ __forceinline__ void mqs_wave_lds_sync()
     __builtin_amdgcn_wave_barrier();
 }
 
+// Every global store this wavefront has issued so far has been acknowledged by the memory it went to.  A __syncthreads() does
+// NOT bring this about on this target: outside threadgroup-split mode a workgroup-scope release needs no s_waitcnt vmcnt(0) (the
+// waves of a workgroup share their CU's vector cache), and the compiler emits none -- 0 of the 146 barriers of ba.hip carry one.
+// Whoever publishes data to ANOTHER workgroup, GPU or cache (the scalar cache included) with plain or relaxed-atomic stores and
+// then raises a flag calls this between the two (then a barrier, if other waves' stores are covered by the same flag).
+__device__ __forceinline__ void mqs_stores_landed() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 // Dynamic LDS above 64 KiB needs hipFuncSetAttribute once per (kernel, device): `flags` is that kernel's per-device record.
 struct mqs_lds_opt_in { bool done[64] = {}; };
 static inline hipError_t mqs_lds_opt_in_once(mqs_lds_opt_in &flags, const void *kernel, size_t bytes)

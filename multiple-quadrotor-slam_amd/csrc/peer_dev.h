@@ -10,9 +10,9 @@ constexpr long long kSpinTicks = 200000000ll;       // 2 s of the 100 MHz wall c
 
 // Every access to a receive buffer is a relaxed system-scope atomic: the buffers are fine-grained memory (not cached by this
 // GPU), so coherence is per access and no cache-wide write-back / invalidate (what a system-scope FENCE costs on this part: the
-// whole L2, serialised per XCD) is ever needed; ordering comes from completion: the sender's stores are acknowledged (s_waitcnt
-// vmcnt(0), which the barrier carries) before it stores the flag, the receiver issues its data loads after its flag loads have
-// returned the sequence number.
+// whole L2, serialised per XCD) is ever needed; ordering comes from completion: the sender's stores are acknowledged (an explicit
+// s_waitcnt vmcnt(0), mqs_stores_landed(): a barrier alone does not wait for stores) before it stores the flag, the receiver
+// issues its data loads after its flag loads have returned the sequence number.
 __device__ __forceinline__ bool spin_until(const unsigned long long *flag, unsigned long long seq)
 {
     const long long t0 = wall_clock64();
@@ -56,7 +56,7 @@ __device__ __forceinline__ void push_entry(const mqs_peer_push &push, int i, dou
     for (int q = 0; q < push.world; ++q) __hip_atomic_store(push.dst[q] + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// after a barrier behind the stores of a piece of the row (s_waitcnt vmcnt(0) + s_barrier: they have landed): raise the
+// after mqs_stores_landed() + a barrier behind the stores of a piece of the row (they have landed): raise the
 // piece's flag in every rank (lanes 0 .. world-1 of one wave)
 __device__ __forceinline__ void publish_piece(const mqs_peer_push &push, int piece, int lane)
 {

@@ -49,12 +49,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--copy", help="also write the record to this path (e.g. profiles/r03/01_kernel_flops.json)")
     args = ap.parse_args()
-    nodist = per_landmark(*count(["MQS_WL_ONLY_L4", "MQS_WL_ONLY_NODIST=1"], "ba_linearize_wave_kernel<4>"), landmarks=4)
-    dist = per_landmark(*count(["MQS_WL_ONLY_L4", "MQS_WL_ONLY_NODIST=0"], "ba_linearize_wave_kernel<4>"), landmarks=4)
+    nodist = per_landmark(*count(["MQS_WL_ONLY_L4", "MQS_WL_ONLY_NODIST=1"], "ba_linearize_wave_kernel<4, true>"), landmarks=4)
+    dist = per_landmark(*count(["MQS_WL_ONLY_L4", "MQS_WL_ONLY_NODIST=0"], "ba_linearize_wave_kernel<4, true>"), landmarks=4)
     rec = {
         "ba_linearize_kernel<4>": dict(
             nodist,
-            kernel="ba_linearize_wave_kernel<4>, the four-landmark chunk body for cameras without lens distortion (the benchmark's "
+            kernel="ba_linearize_wave_kernel<4, true>, the four-landmark chunk body for cameras without lens distortion (the benchmark's "
                    "Cal3DS2(480,480,0,320,240,0,0,0,0); 15 of the 15.26 rows per wave at 1e6 x 4 run in it)",
             with_lens_distortion={k: dist[k] for k in ("fp64_flop_per_landmark", "fp64_instructions_per_landmark",
                                                         "valu_instructions_per_landmark", "instructions_per_chunk")},

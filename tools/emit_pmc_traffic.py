@@ -41,10 +41,10 @@ def main():
            "linear_eigen": find(hbm, "tri_kernel<4", "2, false")}
     for name, rec in tri.items():
         out["%s_hbm_bytes_per_launch" % name] = traffic(rec)
-    out["ba_linearize_hbm_bytes_per_launch"] = traffic(find(hbm, "ba_linearize_wave_kernel<4>"))
+    out["ba_linearize_hbm_bytes_per_launch"] = traffic(find(hbm, "ba_linearize_wave_kernel<4, true>"))
     out["ba_backsub_hbm_bytes_per_launch"] = traffic(find(hbm, "ba_backsub_kernel<4>"))
     out["ba_tail_hbm_bytes_per_launch"] = traffic(find(hbm, "ba_tail_kernel<4>"))
-    lin = find(valu, "ba_linearize_wave_kernel<4>")
+    lin = find(valu, "ba_linearize_wave_kernel<4, true>")
     if lin:
         out["valu"] = {"ba_linearize_schur": {"valu_instructions_per_launch": lin["counters"].get("SQ_INSTS_VALU"),
                                               "valu_instructions_per_wave": lin.get("valu_insts_per_wave"),
