@@ -618,7 +618,11 @@ __global__ __launch_bounds__(NW * 64) void knn2_mfma_kernel(const typename TP::e
                     close_window((s / kWindowStages - 1) * (int64_t)(kWindowTiles * 32));
             }
         }
+#if defined(MQS_MATCH_EXPERIMENT_NOBARRIER)      // timing experiment only (races): what the per-stage workgroup barrier costs
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#else
         __syncthreads();
+#endif
     }
     // scan of the last step, last window
     if (nstages > 0) {
