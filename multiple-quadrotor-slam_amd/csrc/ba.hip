@@ -785,7 +785,10 @@ __global__ __launch_bounds__(kBlock, kWaveLinOcc) void ba_linearize_wave_kernel(
         // 262 207: a wave owns 1 to 5 rows, i.e. chunks of 1, 2, 3, 4) and test_full_size_properties_1e6x4 (chunks of 4 and 3);
         // wl_chunk<C, 1..4, false> (k1 = 0.3, or the full Cal3DS2 coefficient set): the ten `-dist` cases of the same test, C = 2, 3, 4,
         // masked and unmasked; wl_chunk<C, 1, *> alone: every small case of test_linearize_and_backsub_parity.  All against the C
-        // oracle at 1e-10 on S, g, cost, count and, from the same linearisation point, a back-substitution.
+        // oracle at 1e-10 on S, g, cost, count and, from the same linearisation point, a back-substitution.  Those sizes run the
+        // kernel's LDS form (SCALAR = false); the scalar-load form (N >= kWlScalarMinLandmarks) is walked by the six cases of the
+        // same test at N = 400 001 .. 610 000 (chunks of 4 + 2, 4 + 3, 4 + 4 + 1, 4 + 4 + 2; C = 2, 3, 4; with and without
+        // distortion and mask; their two shards take the LDS form, so shard additivity compares the forms) and by the 1e6 test.
 #if defined(MQS_WL_ONLY_L4)      // ISA counting only (tools/isa_mix.py --define MQS_WL_ONLY_L4 [--define MQS_WL_ONLY_NODIST=1]): one body
         wl_chunk<C, 4, MQS_WL_ONLY_NODIST>(cams, stash, points, obs2, mask, prior_w, prior_xyz, N, lambda, r, lane, tot);
 #else

@@ -376,6 +376,12 @@ WAVE_CASES += [dict(N=n, C=c, masked=m, dist=d) for n, c, m, d in [
     (70_000, 4, False, DIST_K1), (70_000, 2, True, DIST_ALL), (150_000, 3, False, DIST_ALL), (150_000, 4, True, DIST_K1),
     (180_001, 4, False, DIST_ALL), (180_001, 2, False, DIST_K1), (180_001, 3, True, DIST_K1),
     (262_144 + 63, 4, True, DIST_ALL), (262_144 + 63, 3, False, DIST_K1), (262_144 + 63, 2, True, DIST_ALL)]]
+# from 400 000 landmarks on the launcher takes ba_linearize_wave_kernel<C, SCALAR = true> (camera blocks through scalar loads): a wave
+# owns 6-7 rows at 400 k (chunks of 4 + 2 and 4 + 3) and 9-10 at 600 k (4 + 4 + 1, 4 + 4 + 2): every chunk size of that form too,
+# C = 2, 3, 4, with and without lens distortion and mask (test_full_size_properties_1e6x4 is its C = 4 no-distortion run)
+WAVE_CASES += [dict(N=n, C=c, masked=m, dist=d) for n, c, m, d in [
+    (400_001, 2, True, DIST_ALL), (410_000, 3, False, DIST_K1), (420_003, 4, True, DIST_ALL), (600_001, 4, False, None),
+    (600_001, 3, True, None), (610_000, 2, False, DIST_K1)]]
 
 
 @pytest.mark.parametrize("case", WAVE_CASES, ids=lambda c: "N%d-C%d%s%s" % (c["N"], c["C"], "-masked" if c.get("masked") else "",
