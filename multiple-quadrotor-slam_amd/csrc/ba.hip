@@ -86,6 +86,21 @@ struct DevObs {
     }
 };
 
+// Measurement access for the fused tail's back-substitution: the C measurements of the thread's landmark were brought into LDS
+// by LDS-DMA loads that were all in flight at once (ba_tail_kernel), the rolled camera loop indexes them there; the mask bytes
+// ride in one register.
+struct StagedObs {
+    const double2 *s;          // this thread's column: camera c at s[c * kBlock]
+    unsigned mbits;            // byte c = the mask byte of camera c (C <= 4)
+    bool live, masked;
+    __device__ __forceinline__ void get(int c, double &u, double &v, bool &seen) const
+    {
+        const double2 t = s[c * kBlock];
+        seen = live && (!masked || ((mbits >> (8 * c)) & 0xffu) != 0u);
+        u = seen ? t.x : 0.0; v = seen ? t.y : 0.0;           // a masked slot may hold NaN
+    }
+};
+
 // F = E^T E and f = E^T e of every camera between the two passes of the lineariser: this thread's LDS column.
 struct LdsFactorStash {
     static constexpr bool kEnabled = true;
@@ -1440,6 +1455,9 @@ struct TailFin {
 };
 constexpr int kQuarterStride = MQS_PEER_QUARTER_STRIDE;
 
+#ifndef MQS_TAIL_STAGED_OBS
+#define MQS_TAIL_STAGED_OBS 1               // A/B: 0 = the measurements are loaded inside the rolled camera loop
+#endif
 template <int C>
 __global__ __launch_bounds__(kBlock, 4) void ba_tail_kernel(
     const double *__restrict__ lin, mqs_peer_recv pr, TailFin fin, const double *__restrict__ poses, const double *__restrict__ calib,
@@ -1552,6 +1570,11 @@ __global__ __launch_bounds__(kBlock, 4) void ba_tail_kernel(
     if (publisher) return;
     __syncthreads();
 
+    // the staging area of the measurements: the solve's starting vectors, column buffer and system (dead behind the barrier above)
+    static_assert(sizeof(double2) * C * kBlock <= sizeof(sm.m) + sizeof(sm.col) + sizeof(sm.lin), "staged measurements fit the solve's LDS");
+    double2 *sObs = reinterpret_cast<double2 *>(sm.m);
+    const double2 *o2 = reinterpret_cast<const double2 *>(obs);
+    const int wave64 = __builtin_amdgcn_readfirstlane(tid & ~63);
     const int64_t rows64 = (N + 63) / 64;
     const int64_t nwg = gridDim.x - 1;
     const int64_t r_begin = rows64 * blockIdx.x / nwg, r_end = rows64 * (blockIdx.x + 1) / nwg;
@@ -1563,9 +1586,27 @@ __global__ __launch_bounds__(kBlock, 4) void ba_tail_kernel(
         const int64_t ii = live ? i : 0;
         double px = points[3 * ii + 0], py = points[3 * ii + 1], pz = points[3 * ii + 2];
         if (!live) { px = 0.0; py = 0.0; pz = 0.0; }
+#if MQS_TAIL_STAGED_OBS
+        // the landmark's C measurements: one LDS-DMA load per camera, all in flight together with the point's loads above (a
+        // measurement loaded inside the rolled camera loop costs a memory latency per camera: one 1 KB load in flight per wave)
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(o2 + (int64_t)c * N + ii),
+                                             (__attribute__((address_space(3))) void *)(sObs + c * kBlock + wave64), 16, 0, 0);
+        unsigned mbits = 0u;
+        if (mask) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) mbits |= (unsigned)mask[(int64_t)c * N + ii] << (8 * c);
+        }
+        double pw, dx, dy, dz;
+        load_prior(prior_w, prior_xyz, i, live, px, py, pz, pw, dx, dy, dz);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the DMA has landed in LDS (and everything else has arrived)
+        const StagedObs ob = {sObs + tid, mbits, live, mask != nullptr};
+#else
         const DevObs ob = {reinterpret_cast<const double2 *>(obs), mask, i, N, live};
         double pw, dx, dy, dz;
         load_prior(prior_w, prior_xyz, i, live, px, py, pz, pw, dx, dy, dz);
+#endif
         const mqs::Vec3 dp = landmark_backsub<C>(sCam, ob, px, py, pz, pw, dx, dy, dz, lambda, sm.x);
         if (live) {
             points_out[3 * i + 0] = px + dp.x;
