@@ -544,13 +544,17 @@ int64_t mqs_fast_workspace_bytes(int W, int H);
  *                    after the top-up, [27] landmarks, [28..39] refined pose.  mqs_slam_flush: that block once the stream
  *                    has drained (after the last frame).
  *   mqs_slam_read_tracks / _read_map   the state, for recorders and tests (synchronise the handle's stream).
+ *   mqs_slam_set_thresholds   the gates of slam2.py:1070-1098 and max_homography_points: keyframe_test's random sample of the
+ *                    tracks (slam2.py:48) -- 0 (the default after mqs_slam_create): the homography is fitted to ALL kept
+ *                    tracks; k >= 4: to a uniformly random k of them, drawn from the handle's counter-based generator
+ *                    (the reference's rule is k = max(4, target_keypoints / 4), slam2.py:1088-1089).
  * ------------------------------------------------------------------------------------- */
 typedef struct mqs_slam mqs_slam;
 int mqs_slam_create(int device, int W, int H, const double *intr, int target_keypoints, double coverage_radius,
                     double quality_level, int max_landmarks, uint64_t seed, mqs_slam **out);
 void mqs_slam_destroy(mqs_slam *s);
 int mqs_slam_set_thresholds(mqs_slam *s, double max_of_error, double max_lost_tracks_ratio, double max_reproj_error,
-                            double max_outlier_ratio, double homography_condition_threshold);
+                            double max_outlier_ratio, double homography_condition_threshold, int max_homography_points);
 int mqs_slam_start(mqs_slam *s, const uint8_t *img_dev, const float *objp0, const float *imgp0, int n0, double *pose_out);
 int mqs_slam_track(mqs_slam *s, const uint8_t *prev_img_dev, const uint8_t *img_dev, double *result);
 int mqs_slam_flush(mqs_slam *s, double *result);

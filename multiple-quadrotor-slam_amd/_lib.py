@@ -167,7 +167,7 @@ SIGNATURES = {
     "mqs_slam_create": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_f64p, ctypes.c_int, ctypes.c_double, ctypes.c_double,
                                        ctypes.c_int, ctypes.c_uint64, ctypes.POINTER(c_vp)]),
     "mqs_slam_destroy": (None, [c_vp]),
-    "mqs_slam_set_thresholds": (ctypes.c_int, [c_vp] + [ctypes.c_double] * 5),
+    "mqs_slam_set_thresholds": (ctypes.c_int, [c_vp] + [ctypes.c_double] * 5 + [ctypes.c_int]),
     "mqs_slam_start": (ctypes.c_int, [c_vp, c_vp, c_f32p, c_f32p, ctypes.c_int, c_f64p]),
     "mqs_slam_track": (ctypes.c_int, [c_vp, c_vp, c_vp, c_f64p]),
     "mqs_slam_flush": (ctypes.c_int, [c_vp, c_f64p]),

@@ -15,8 +15,8 @@
 // host's share is one call and one wait.
 //
 // Deviations from the reference, as in slam_loop.py (no image set / OpenCV run of the reference exists to compare with): the
-// homography of the keyframe test is the normalised DLT over ALL kept tracks (cv2.findHomography on a random quarter of them
-// there), RANSAC samples come from a counter-based generator on the device (splitmix64 of seed, frame, hypothesis).
+// homography of the keyframe test is the normalised DLT over ALL kept tracks by default (cv2.findHomography on a random quarter of
+// them there: mqs_slam_set_thresholds(.., max_homography_points) switches that on, drawn from the device generator), RANSAC samples come from a counter-based generator on the device (splitmix64 of seed, frame, hypothesis).
 #include "mqs_common.h"
 #include "pnp_math.h"
 #include "cam_math.h"
@@ -68,6 +68,7 @@ struct SlamParams {
     double radius, quality;
     double max_of_error, max_lost_ratio, max_reproj, max_outlier_ratio, homography_threshold;
     unsigned long long seed;
+    int max_homography_points;      // keyframe_test's random sample (slam2.py:48; the reference: max(4, target / 4), :1088-1089); 0 = all tracks (default)
 };
 
 // rank of this thread among the flagged threads of the workgroup (thread order), and their number; two barriers
@@ -337,9 +338,46 @@ __global__ __launch_bounds__(256) void frame_decide_kernel(SlamDev d, SlamParams
     if (tid < 12) d.pose_prev[tid] = sP[tid];
     if (tid == 0) d.cnt[C_N] = n_acc;
 
-    // normalised DLT homography u2 ~ H u1 over all kept tracks
+    // keyframe_test's random sample of the kept tracks (slam2.py:48: np.random.permutation(n)[:max_num_homography_points]): a
+    // counter-based hash of (seed, frame, track position) per track, the tracks with the max_homography_points smallest hashes are
+    // the sample (a uniformly random subset; ties by position).  The sample is compacted to the front of sU1 / sU2 in track order.
+    int n_hom = n_acc;
+    if (p.max_homography_points > 0 && n_acc > p.max_homography_points) {
+        __shared__ unsigned sHash[kMaxTracks];
+        __shared__ uint8_t sPick[kMaxTracks];
+        const unsigned long long frame = (unsigned long long)d.cnt[C_FRAME];
+        for (int k = tid; k < n_acc; k += 256) {
+            unsigned long long st = p.seed ^ (frame << 24) ^ ((unsigned long long)(k + 1) * 0x9e3779b97f4a7c15ull) ^ 0x5851f42d4c957f2dull;
+            sHash[k] = (unsigned)(splitmix64(st) >> 32);
+        }
+        __syncthreads();
+        for (int k = tid; k < n_acc; k += 256) {
+            const unsigned hk = sHash[k];
+            int rank = 0;
+            for (int j = 0; j < n_acc; ++j) rank += (sHash[j] < hk || (sHash[j] == hk && j < k)) ? 1 : 0;
+            sPick[k] = rank < p.max_homography_points ? 1 : 0;
+        }
+        __syncthreads();
+        int n_sel = 0;
+        for (int b = 0; b < n_acc; b += 256) {                       // ordered compaction, in place (the target never runs ahead of the source)
+            const int k = b + tid;
+            const bool in = k < n_acc && sPick[k] != 0;
+            double a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+            if (in) { a0 = sU1[2 * k]; a1 = sU1[2 * k + 1]; b0 = sU2[2 * k]; b1 = sU2[2 * k + 1]; }
+            int tot;
+            const int r = n_sel + block_rank(in, tid, sWave, tot);
+            if (in) { sU1[2 * r] = a0; sU1[2 * r + 1] = a1; sU2[2 * r] = b0; sU2[2 * r + 1] = b1; }
+            n_sel += tot;
+            __syncthreads();
+        }
+        n_hom = n_sel;
+    }
+    // normalised DLT homography u2 ~ H u1 over the sample
     double ratio = 1.0;
     if (n_acc >= 4) {
+        const int n_acc_all = n_acc;
+        const int n_acc = n_hom;                                      // (shadows: the loops below run over the sample)
+        (void)n_acc_all;
         double c1x = 0, c1y = 0, c2x = 0, c2y = 0;
         for (int k = tid; k < n_acc; k += 256) { c1x += sU1[2 * k]; c1y += sU1[2 * k + 1]; c2x += sU2[2 * k]; c2y += sU2[2 * k + 1]; }
         const double inv_n = 1.0 / (double)n_acc;
@@ -581,7 +619,7 @@ int mqs_slam_create(int device, int W, int H, const double *intr, int target_key
     s->device = device;
     s->started = false;
     s->p = SlamParams{W, H, target_keypoints, max_landmarks, coverage_radius, quality_level,
-                      12.0, 0.5, 2.0, 0.33, 1.04, (unsigned long long)seed};        // slam2.py:1070-1098
+                      12.0, 0.5, 2.0, 0.33, 1.04, (unsigned long long)seed, 0};     // slam2.py:1070-1098; keyframe test on ALL tracks
     s->ws_lk_bytes = mqs_lk_workspace_bytes(W, H, 3);
     s->ws_gftt_bytes = mqs_gftt_workspace_bytes(W, H);
     const int64_t ws_pnp_bytes = mqs_pnp_workspace_bytes(kMaxTracks, kHyp);
@@ -640,9 +678,11 @@ void mqs_slam_destroy(mqs_slam *s)
 }
 
 int mqs_slam_set_thresholds(mqs_slam *s, double max_of_error, double max_lost_tracks_ratio, double max_reproj_error,
-                            double max_outlier_ratio, double homography_condition_threshold)
+                            double max_outlier_ratio, double homography_condition_threshold, int max_homography_points)
 {
     MQS_ARG_CHECK(s != nullptr, "handle must not be null");
+    MQS_ARG_CHECK(max_homography_points == 0 || max_homography_points >= 4, "max_homography_points: 0 (all tracks) or >= 4");
+    s->p.max_homography_points = max_homography_points;
     s->p.max_of_error = max_of_error; s->p.max_lost_ratio = max_lost_tracks_ratio; s->p.max_reproj = max_reproj_error;
     s->p.max_outlier_ratio = max_outlier_ratio; s->p.homography_threshold = homography_condition_threshold;
     return MQS_OK;

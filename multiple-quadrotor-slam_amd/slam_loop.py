@@ -14,10 +14,12 @@ The reference's monocular per-frame loop (Work/SLAM/application/own/slam2.py:360
                mask of the current points (:657-672) and make this frame the new base keyframe.
 
 Bookkeeping is restated with plain arrays (track id -> landmark id or -1) instead of the reference's index sets; the
-decisions and their thresholds are the reference's (:1070-1098).  Deviations, all because no image set / OpenCV run
-of the reference exists to compare with: the homography of the keyframe test is a normalised DLT over ALL tracked
-points (the reference: cv2.findHomography on a random quarter of them), RANSAC draws come from a seeded numpy
-generator.  Every numeric step runs on the GPU library (features, pnp, camera, triangulation); nothing falls back.
+decisions and their thresholds are the reference's (:1070-1098).  Deviations, because no image set / OpenCV run of the
+reference exists to compare with: the homography of the keyframe test is a normalised DLT (the estimator behind
+cv2.findHomography(method=0)) over ALL tracked points by default -- the reference's random quarter of them (:48,
+1088-1089) is `max_homography_points="reference"`, drawn with the reference's call from a seeded legacy generator; it
+makes the outcome depend on the draw (profiles/r03/12_keyframe_sample_study.json) -- and RANSAC draws come from a
+seeded numpy generator.  Every numeric step runs on the GPU library (features, pnp, camera, triangulation); nothing falls back.
 """
 import time
 
@@ -76,19 +78,28 @@ def homography_dlt(p1, p2):
     return H / H[2, 2]
 
 
-def keyframe_test(points1, points2, K, dist):
-    """slam2.py:43-59."""
+def keyframe_test(points1, points2, K, dist, max_points=None, rng=None):
+    """slam2.py:43-59.  max_points / rng: the reference's random sample of the input points (:48,
+    `np.random.permutation(len(points1))[:max_num_homography_points]`); rng is a `numpy.random.RandomState` -- the legacy
+    generator behind `np.random.permutation`, seeded here where the reference leaves the global one unseeded."""
     if len(points1) < 4:
         return False
-    u1 = camera.undistort_points(np.asarray(points1, dtype=np.float64), K, dist)
-    u2 = camera.undistort_points(np.asarray(points2, dtype=np.float64), K, dist)
+    points1 = np.asarray(points1, dtype=np.float64)
+    points2 = np.asarray(points2, dtype=np.float64)
+    if max_points is not None and max_points > 0:
+        idxs = (rng if rng is not None else np.random).permutation(len(points1))[:max_points]
+        points1, points2 = points1[idxs], points2[idxs]
+    u1 = camera.undistort_points(points1, K, dist)
+    u2 = camera.undistort_points(points2, K, dist)
     w = np.linalg.svd(homography_dlt(u1, u2), compute_uv=False)
     return w[0] / w[2] > HOMOGRAPHY_CONDITION_THRESHOLD
 
 
 class MonoSlam:
-    def __init__(self, cameraMatrix, distCoeffs, image_shape, seed=0, verbose=False, ba_info=None):
-        """ba_info: an optional `ba_io.BundleAdjustmentInfoContainer`; the loop then records what the reference records
+    def __init__(self, cameraMatrix, distCoeffs, image_shape, seed=0, verbose=False, ba_info=None, max_homography_points=0):
+        """max_homography_points: keyframe_test's random sample of the tracks (slam2.py:48): 0 = all tracks (default; see
+        slam_device.DeviceMonoSlam for the measurement behind it), "reference" = max(4, target_amount_keypoints / 4) (:1088-1089).
+        ba_info: an optional `ba_io.BundleAdjustmentInfoContainer`; the loop then records what the reference records
         for the bundle adjuster (slam2.py:519-522, 634-641, 681-687, 1167-1169, 1204)."""
         self.K = np.asarray(cameraMatrix, dtype=np.float64)
         self.dist = np.asarray(distCoeffs, dtype=np.float64).reshape(-1)[:4]
@@ -97,6 +108,11 @@ class MonoSlam:
         target = int(round(W * H / (np.pi * KEYPOINT_COVERAGE_RADIUS ** 2)))         # slam2.py:1081
         self.target_keypoints = min(MAX_AMOUNT_KEYPOINTS, target)
         self.rng = np.random.default_rng(seed)
+        # keyframe_test's random sample (slam2.py:1088-1089: target_amount_keypoints / 4, at least 4), drawn like the reference
+        # draws it (np.random.permutation) from a seeded legacy generator
+        self.max_homography_points = (max(4, self.target_keypoints // 4) if max_homography_points == "reference"
+                                      else int(max_homography_points))
+        self.legacy_rng = np.random.RandomState(seed)
         self.verbose = verbose
         self.objp = np.zeros((0, 3), dtype=np.float32)       # the map (float32 like slam2.py:19)
         self.poses = []                                      # per frame: (rvec, tvec) or None when rejected
@@ -196,7 +212,7 @@ class MonoSlam:
             self.history.append((frame_idx, tid.copy(), pts.copy()))
             self.ba_info.add_points2D_3Dassoc(pts[tri], lm[tri], frame_idx)
         result = 1
-        if keyframe_test(base, pts, K, dist):
+        if keyframe_test(base, pts, K, dist, self.max_homography_points, self.legacy_rng):
             result = 2
             non = np.nonzero(~tri)[0]
             if len(non):

@@ -24,6 +24,37 @@ def test_keypoint_mask_and_homography_helpers(mqs):
     assert np.abs(L.homography_dlt(p1, q[:, :2] / q[:, 2:]) - Ht).max() < 1e-12
 
 
+def test_keyframe_test_random_sample_is_the_reference_draw(mqs, monkeypatch):
+    """keyframe_test's random sample of the tracks (slam2.py:48): `np.random.permutation(n)[:max_points]` from a seeded legacy
+    generator -- the same indices as the reference's call draws after np.random.seed; a sample as large as the input is the
+    all-points test; the decision is the singular-value ratio of the sampled homography."""
+    L = mqs.slam_loop
+    rng = np.random.default_rng(1)
+    p1 = rng.uniform(100, 500, (120, 2))
+    Ht = np.array([[1.0, 0.02, 3.0], [-0.01, 1.0, -2.0], [1e-5, 2e-5, 1.0]])
+    q = np.c_[p1, np.ones(len(p1))] @ Ht.T
+    p2 = q[:, :2] / q[:, 2:] + rng.normal(0, 0.2, (120, 2))
+    K = np.array([[500.0, 0, 320], [0, 500.0, 240], [0, 0, 1]])
+    dist = np.zeros(4)
+    seen = {}
+
+    def record(p, K_, d_):                                       # stands in for the undistortion: what the test is given
+        seen[len(seen)] = np.array(p)
+        return np.array(p)
+    monkeypatch.setattr(L.camera, "undistort_points", record)
+    L.keyframe_test(p1, p2, K, dist, 30, np.random.RandomState(5))
+    np.random.seed(5)
+    idxs = np.random.permutation(120)[:30]                       # the reference's line, verbatim in effect
+    np.testing.assert_array_equal(seen[0], p1[idxs])
+    np.testing.assert_array_equal(seen[1], p2[idxs])
+    seen.clear()
+    a = L.keyframe_test(p1, p2, K, dist)
+    b = L.keyframe_test(p1, p2, K, dist, 0)
+    assert a == b and len(seen[0]) == 120
+    m = L.MonoSlam(K, dist, (480, 640), max_homography_points="reference")
+    assert m.max_homography_points == max(4, m.target_keypoints // 4) and L.MonoSlam(K, dist, (480, 640)).max_homography_points == 0
+
+
 def test_rendered_sequence_is_consistent(mqs):
     seq = mqs.synthetic.PlaneSequence(frames=5)
     img = seq.render(0)
@@ -186,6 +217,42 @@ def test_device_resident_loop_on_rendered_sequence(gpu):
     assert abs(dev["keyframes"] - host["keyframes"]) <= 2
     assert abs(dev["trajectory_rmse"] - host["trajectory_rmse"]) < 0.002 * dev["path_length"]
     assert dev["tracks_at_the_end"] >= 100
+
+
+@pytest.mark.gpu
+def test_device_loop_with_the_reference_keyframe_sample(gpu):
+    """max_homography_points="reference": the keyframe test on a random quarter of the tracks (slam2.py:48, 1088-1089), drawn on the
+    device.  The loop still accepts every frame and stays on the path; which keyframes it takes depends on the draw (the study
+    in profiles/r03/12_keyframe_sample_study.json: RMSE 0.3 % or 1.1 % of the path depending on the seed), so the bar is wider
+    than the default's."""
+    import torch
+    seq = gpu.synthetic.PlaneSequence(frames=40)
+    gx, gy = np.meshgrid(np.linspace(-4.5, 1.0, 8), np.linspace(-2.5, 2.0, 6))
+    objp = np.stack([gx.ravel(), gy.ravel(), np.zeros(gx.size)], axis=1)
+    imgp = seq.project(0, objp)
+    vis = (imgp[:, 0] > 15) & (imgp[:, 0] < seq.W - 15) & (imgp[:, 1] > 15) & (imgp[:, 1] < seq.H - 15)
+    objp, imgp = objp[vis], imgp[vis]
+    imgs = [torch.from_numpy(seq.render(k)).cuda() for k in range(40)]
+    gt = seq.centres()
+    path = float(np.linalg.norm(np.diff(gt, axis=0), axis=1).sum())
+
+    def run(seed, mh):
+        slam = gpu.slam_device.DeviceMonoSlam(seq.K, seq.dist, (seq.H, seq.W), seed=seed, max_homography_points=mh)
+        slam.start(imgs[0], objp, imgp)
+        rets = [2] + [slam.handle_new_frame(imgs[k]) for k in range(1, 40)]
+        traj = slam.trajectory()
+        ratios = list(slam.homography_ratios) if hasattr(slam, "homography_ratios") else None
+        slam.close()
+        return rets, traj, ratios
+
+    ref_runs = [run(seed, "reference") for seed in (0, 1, 2)]
+    for rets, traj, _ in ref_runs:
+        assert all(r in (1, 2) for r in rets) and sum(r == 2 for r in rets) >= 8
+        assert np.sqrt(np.mean(np.linalg.norm(traj - gt, axis=1) ** 2)) < 0.02 * path
+    assert any(not np.array_equal(ref_runs[0][1], r[1]) for r in ref_runs[1:])   # the run depends on the draw
+    # all tracks (the default): the seed only moves the RANSAC draws, the trajectories stay within 0.1 % of the path of each other
+    rm = [np.sqrt(np.mean(np.linalg.norm(run(seed, 0)[1] - gt, axis=1) ** 2)) for seed in (0, 2)]
+    assert abs(rm[0] - rm[1]) < 1e-3 * path and max(rm) < 0.01 * path
 
 
 @pytest.mark.gpu
