@@ -23,6 +23,7 @@
 //     gradients in registers), all pyramid levels and all iterations inside one launch; window sums in fp64.
 #include <cstring>
 #include "mqs_common.h"
+#include "wave_reduce.h"
 
 #pragma clang fp contract(off)
 
@@ -536,11 +537,31 @@ struct LkLevels {
     int levels;                                // highest level index
 };
 
+// Sums of x and of y over the 64 lanes, the same on every lane, with the additions of the xor butterfly (v += v[lane ^ 32],
+// ^ 16, ^ 8, ^ 4, ^ 2, ^ 1: the same pairs, hence the same bits as a __shfl_xor loop) but without its twelve dependent
+// ds_bpermute round trips per value pair, which were a quarter of a Lucas-Kanade iteration: the two values share the first stage
+// (v_permlane32_swap leaves x's pair sums in lanes 0..31 and y's in lanes 32..63), the row-of-16 exchange is a
+// v_permlane16_swap of the value with itself, the rest DPP moves; the totals come back through v_readlane.
+__device__ __forceinline__ void wave_sum2_d(double x, double y, double &sx, double &sy)
+{
+    mqs::wave::swap32(x, y);                   // lanes 0..31: (x, x[l + 32]);  lanes 32..63: (y[l - 32], y)
+    double t = x + y;
+    double a = t, b = t;
+    mqs::wave::swap16(a, b);                   // even rows: (t, t[l + 16]);  odd rows: (t[l - 16], t)
+    t = a + b;
+    t += mqs::wave::xor_lane<8>(t);
+    t += mqs::wave::xor_lane<4>(t);
+    t += mqs::wave::xor_lane<2>(t);
+    t += mqs::wave::xor_lane<1>(t);
+    const int lo = __double2loint(t), hi = __double2hiint(t);
+    sx = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+    sy = __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32));
+}
 __device__ __forceinline__ double wave_sum_d(double v)
 {
-#pragma unroll
-    for (int h = 32; h >= 1; h >>= 1) v += __shfl_xor(v, h);
-    return v;
+    double s, unused;
+    wave_sum2_d(v, 0.0, s, unused);
+    return s;
 }
 
 __device__ __forceinline__ float bilinear_u8(const uint8_t *__restrict__ a, int W, int x, int y, float w00, float w01, float w10, float w11)
@@ -597,8 +618,9 @@ __global__ __launch_bounds__(64) void lk_kernel(LkLevels L, const float *__restr
                 }
             }
         }
-        const float A11 = (float)wave_sum_d(a11) * kFltScale, A12 = (float)wave_sum_d(a12) * kFltScale,
-                    A22 = (float)wave_sum_d(a22) * kFltScale;
+        double s11, s12;
+        wave_sum2_d(a11, a12, s11, s12);
+        const float A11 = (float)s11 * kFltScale, A12 = (float)s12 * kFltScale, A22 = (float)wave_sum_d(a22) * kFltScale;
         float D = A11 * A22 - A12 * A12;
         const float min_eig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.0f * A12 * A12)) / (float)(2 * ww * wh);
         if (min_eig < min_eig_threshold || D < 1.1920929e-07f) {
@@ -627,7 +649,9 @@ __global__ __launch_bounds__(64) void lk_kernel(LkLevels L, const float *__restr
                     b2 += (double)diff * (double)Iyw[t];
                 }
             }
-            const float B1 = (float)wave_sum_d(b1) * kFltScale, B2 = (float)wave_sum_d(b2) * kFltScale;
+            double sb1, sb2;
+            wave_sum2_d(b1, b2, sb1, sb2);
+            const float B1 = (float)sb1 * kFltScale, B2 = (float)sb2 * kFltScale;
             const float dx = (A12 * B2 - A22 * B1) * D, dy = (A12 * B1 - A11 * B2) * D;
             nx += dx; ny += dy;
             if (dx * dx + dy * dy <= eps * eps) break;
