@@ -23,12 +23,7 @@ using namespace mqs::pnp;
 
 constexpr int kWave = 64;
 
-__device__ __forceinline__ double wave_sum(double v)
-{
-#pragma unroll
-    for (int h = 32; h >= 1; h >>= 1) v += __shfl_xor(v, h);
-    return v;
-}
+__device__ __forceinline__ double wave_sum(double v) { return mqs::wave::sum1(v); }     // the butterfly's pairs, no ds_bpermute
 
 // K sums over the wavefront, every lane ending with all of them: chunks of 32 through the transposed reduction of
 // wave_reduce.h (32 exchange-and-add steps per chunk; lane 2 e ends with entry e), then through 32 doubles of LDS (`scr`, the

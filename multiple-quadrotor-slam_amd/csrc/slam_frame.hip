@@ -198,8 +198,7 @@ __device__ void jacobi9(double *A, double *V, int lane)
 #pragma unroll
             for (int j = 0; j < 9; ++j) { const double a = A[k * 9 + j]; if (g == 0) { if (j == k) dia += a * a; else off += a * a; } }
         }
-#pragma unroll
-        for (int h = 32; h >= 1; h >>= 1) { off += __shfl_xor(off, h); dia += __shfl_xor(dia, h); }
+        mqs::wave::sum2(off, dia, off, dia);                       // (the butterfly's pairs, without its ds_bpermute round trips)
         if (off <= 1e-30 * dia) break;
         for (int r = 0; r < 9; ++r) {
             // round-robin round r of 9 players: slot g pairs (r + g + 1, r - g - 1) mod 9, player r rests
@@ -253,8 +252,7 @@ __device__ void jacobi3(double *a, double *w)
 // sum over the workgroup, the same value in every thread, fixed order (wave butterflies, then the four waves in order)
 __device__ __forceinline__ double block_sum(double v, int tid, double *sRed /*[4]*/)
 {
-#pragma unroll
-    for (int h = 32; h >= 1; h >>= 1) v += __shfl_xor(v, h);
+    v = mqs::wave::sum1(v);
     if ((tid & 63) == 0) sRed[tid >> 6] = v;
     __syncthreads();
     const double t = ((sRed[0] + sRed[1]) + sRed[2]) + sRed[3];

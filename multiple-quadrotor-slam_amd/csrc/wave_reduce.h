@@ -82,5 +82,32 @@ __device__ __forceinline__ double wave_reduce32(double (&v)[32], int lane)
     return v[0] + xor_lane<1>(v[0]);
 }
 
+// Sums of x and of y over the 64 lanes, the same on every lane, with the additions of the xor butterfly (v += v[lane ^ 32],
+// ^ 16, ^ 8, ^ 4, ^ 2, ^ 1: the same pairs, hence the same bits as a __shfl_xor loop) but without its twelve dependent
+// ds_bpermute round trips per value: the two values share the first stage (v_permlane32_swap leaves x's pair sums in lanes
+// 0..31 and y's in lanes 32..63), the row-of-16 exchange is a v_permlane16_swap of the value with itself (a + b is the pair sum in
+// every lane), the rest DPP moves; the totals come back through v_readlane.
+__device__ __forceinline__ void sum2(double x, double y, double &sx, double &sy)
+{
+    swap32(x, y);                              // lanes 0..31: (x, x[l + 32]);  lanes 32..63: (y[l - 32], y)
+    double t = x + y;
+    double a = t, b = t;
+    swap16(a, b);                              // even rows: (t, t[l + 16]);  odd rows: (t[l - 16], t)
+    t = a + b;
+    t += xor_lane<8>(t);
+    t += xor_lane<4>(t);
+    t += xor_lane<2>(t);
+    t += xor_lane<1>(t);
+    const int lo = __double2loint(t), hi = __double2hiint(t);
+    sx = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+    sy = __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32));
+}
+__device__ __forceinline__ double sum1(double v)
+{
+    double s, unused;
+    sum2(v, 0.0, s, unused);
+    return s;
+}
+
 }  // namespace wave
 }  // namespace mqs
