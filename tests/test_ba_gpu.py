@@ -448,3 +448,28 @@ def test_wave_lineariser_every_chunk_size_against_the_c_oracle(case, gpu, c_orac
     pts_o = c_oracle.ba_backsub(h(ba.poses), h(ba.calib), h(ba.sigma), h(ba.points), obs_h, dpose, mask, h(ba.prior_w),
                                 h(ba.prior_xyz), lam, use_omp=True)
     assert np.abs(pts_new - pts_o).max() <= 1e-9 * max(1.0, np.abs(pts_o - h(ba.points)).max())
+
+
+@pytest.mark.gpu
+def test_fused_finalize_hand_over_under_changing_linearisation_points(gpu):
+    """The flag-after-data hand-over inside the fused tail (the finalizer workgroups' piece sums, published with relaxed stores,
+    an explicit store-acknowledge wait and an epoch flag): 300 one-call iterations, each from a different linearisation point so
+    that a piece read before it landed -- the previous iteration's -- changes the result, fingerprinted and compared with the
+    same run with the finalize as a launch of its own (MQS_BA_FINALIZE=kernel, read once per process: two processes)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = os.path.join(root, "tools", "probes", "fused_finalize_stress.py")
+    outs = []
+    for mode in (None, "kernel"):
+        env = {k: v for k, v in os.environ.items() if k != "MQS_BA_FINALIZE"}
+        if mode:
+            env["MQS_BA_FINALIZE"] = mode
+        r = subprocess.run([sys.executable, script, "300", "90000"], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    assert outs[0]["mode"] == "fused" and outs[1]["mode"] == "kernel"
+    assert outs[0]["sha256_16"] == outs[1]["sha256_16"]
+
