@@ -473,3 +473,31 @@ def test_fused_finalize_hand_over_under_changing_linearisation_points(gpu):
     assert outs[0]["mode"] == "fused" and outs[1]["mode"] == "kernel"
     assert outs[0]["sha256_16"] == outs[1]["sha256_16"]
 
+
+@pytest.mark.gpu
+def test_scalar_camera_blocks_follow_the_poses(gpu):
+    """The wave lineariser's scalar-load form (N >= 400 000) reads the camera blocks from a copy every workgroup publishes to the
+    workspace and pulls through the scalar cache: the same adjuster (same workspace, same addresses) linearised at 40 different
+    pose sets in a row must see each of them -- a stale line in the scalar cache or the L2 would be the PREVIOUS poses.  Checked
+    against the sum of two shards, which are small enough to take the LDS form and have workspaces of their own."""
+    import torch
+    N, C = 430_000, 4
+    u, P, pts = gpu.synthetic.triangulation_problem(N, C)
+    ba = gpu.bundle_adjustment.make_benchmark_problem(u, P, pts + 0.02, torch.device("cuda", 0), seed=3)
+    BA = gpu.bundle_adjustment.BundleAdjuster
+    cut = N // 2 + 33
+    subs = [BA(ba.poses, ba.calib, ba.sigma, ba.points[sl].clone(), ba.obs[:, sl].clone(), None, ba.prior_w[sl].clone(),
+               ba.prior_xyz[sl].clone()) for sl in (slice(0, cut), slice(cut, N))]
+    poses0 = ba.poses.clone()
+    g = torch.Generator(device="cuda").manual_seed(11)
+    worst = 0.0
+    for k in range(40):
+        noise = torch.zeros_like(poses0)
+        noise[:, 9:] = 0.05 * torch.randn((C, 3), generator=g, device="cuda", dtype=torch.float64)
+        for b in [ba] + subs:
+            b.poses.copy_(poses0 + noise)
+        whole = ba.linearize(0.0).clone()
+        parts = subs[0].linearize(0.0).clone() + subs[1].linearize(0.0)
+        worst = max(worst, float((whole - parts).abs().max() / whole.abs().max()))
+    assert worst <= 1e-10, worst
+
