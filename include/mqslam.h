@@ -44,6 +44,7 @@ extern "C" {
 #define MQS_E_NOMEM    -3   /* device or host allocation failed */
 #define MQS_E_NODEVICE -4   /* no gfx950 device visible */
 #define MQS_E_RCCL     -5   /* RCCL missing or a collective failed (message in mqs_last_error) */
+#define MQS_E_TIMEOUT  -6   /* a bounded device-side wait gave up (a peer's row, or the finalizer pieces of an iteration): results invalid */
 
 #define MQS_MAX_CAMS    8
 #define MQS_TRI_MAX_ITER_DEFAULT 10        /* triangulation.c:125 */
@@ -258,7 +259,7 @@ int mqs_comm_init_rank(mqs_ctx *ctx, const uint8_t *id128, int rank, int world);
 int mqs_comm_world_size(const mqs_ctx *ctx);
 int mqs_comm_destroy(mqs_ctx *ctx);
 /* in-place sum over the ranks of buf[n] (device pointer), asynchronous on `stream`.  With a peer transport (below) and
- * n <= 2560 the sum is the peers' rows added in rank order by one small kernel; otherwise ncclAllReduce. */
+ * n <= 5120 the sum is the peers' rows added in rank order by one small kernel; otherwise ncclAllReduce. */
 int mqs_comm_all_reduce_sum_f64_dev(mqs_ctx *ctx, double *buf, int64_t n, void *stream);
 
 /* Peer transport: the same collective as plain stores over xGMI into receive buffers the ranks map from each other
@@ -292,6 +293,14 @@ int mqs_comm_peer_timed_out(mqs_ctx *ctx, void *stream, int *timed_out);
  *                             them (another transport) or decides acceptance (accept = 0: the step stays a trial in the
  *                             other buffers -- Levenberg-Marquardt).
  *   mqs_ba_gn_iterations_dev  `iters` iterations back to back.
+ *   mqs_ba_problem_status     the iteration's kernels hand data over between workgroups (the finalize inside the tail) and
+ *                             between GPUs (peer transport) behind flags, with BOUNDED waits (2 s): a GPU must never hang on a
+ *                             rank that does not arrive.  A wait that gives up is an error, not a wrong answer: the waiting
+ *                             workgroups read nothing of what they waited for and publish nothing (no poses, no landmarks;
+ *                             info[1] = 2), and a sticky status word of the problem is raised.  mqs_ba_problem_status
+ *                             synchronises `stream` and returns MQS_OK or MQS_E_TIMEOUT; mqs_ba_gn_iteration(s)_dev return
+ *                             MQS_E_TIMEOUT themselves (without synchronising) once an earlier iteration's failure has become
+ *                             visible.  Call it wherever the host consumes the estimate.
  * ------------------------------------------------------------------------------------- */
 typedef struct mqs_ba_problem mqs_ba_problem;
 int mqs_ba_problem_create(mqs_ctx *ctx, int C, int64_t N, double *poses_a, double *poses_b, const double *calib,
@@ -306,6 +315,10 @@ int mqs_ba_gn_begin_dev(mqs_ba_problem *p, double lambda, void *stream);
 int mqs_ba_gn_finish_dev(mqs_ba_problem *p, double lambda, int accept, void *stream);
 int mqs_ba_gn_iteration_dev(mqs_ba_problem *p, double lambda, void *stream);
 int mqs_ba_gn_iterations_dev(mqs_ba_problem *p, int iters, double lambda, void *stream);
+int mqs_ba_problem_status(mqs_ba_problem *p, void *stream);
+/* Test hook: the finalizer piece (0 .. 47) of the fused tail that does not raise its flag in launches issued from now on, so
+ * that tests can reach the time-out path (-1 = none, the default).  Never set in production code. */
+int mqs_debug_ba_withhold_flag(int piece);
 
 /* Timing helper used by bench.py: average duration (ms) of `reps` back-to-back launches of ONE kernel of the iteration,
  * hipEvents on `stream` (what: 0 = the lineariser kernel alone, 1 = its finalize kernel alone, 2 = solve + retract,
@@ -450,6 +463,9 @@ int64_t mqs_project_workspace_bytes(void);
  *   mqs_pnp_refine_dev: B independent problems in one launch (one wavefront each).  Problem b uses the
  *       correspondences idx[ptr[b] .. ptr[b+1]) (idx == NULL: the points ptr[b] .. ptr[b+1] themselves;
  *       ptr == NULL with B == 1: all N points).  poses_in / poses_out [B][12], info [B][4] (may be NULL).
+ *       A problem with fewer than 3 correspondences is not solved: poses_out[b] = poses_in[b] (the identity pose
+ *       without poses_in) and info[b] = {0, 0, 0, 2} (flags bit 1) -- what the device-resident loop relies on for
+ *       a rejected frame; mqs_solve_pnp (host entry) keeps refusing N < 3 with MQS_E_ARG.
  *   mqs_solve_pnp_ransac: replaces cv2.solvePnPRansac(objp, imgp, K, dist, minInliersCount=..,
  *       reprojectionError=..) (slam2.py:453-454).  The caller draws the minimal samples
  *       (samples [B][sample_size] int32 point indices, sample_size >= 6) so that runs are repeatable; all B
@@ -533,6 +549,10 @@ int64_t mqs_fast_workspace_bytes(int W, int H);
  * step (triangulate the free tracks, refine the pose, re-triangulate), the map update, the coverage mask, goodFeaturesToTrack
  * and the top-up of the tracks.  Thresholds default to slam2.py:1070-1098.  Images are DEVICE pointers (8-bit, W x H, dense)
  * that must stay valid until the next call returns.  csrc/slam_frame.hip.
+ * Streams: the handle works on a private non-blocking stream and takes no event from the caller, so the images must be
+ * COMPLETE in device memory when mqs_slam_start / mqs_slam_track is called -- an upload still in flight on another stream
+ * (torch's current stream, say) is not ordered against the library's reads: synchronise that stream (or the device) first.
+ * n0 <= max_landmarks (the start-up points are the first entries of the map).
  *   mqs_slam_start   first frame: pose from n0 known 3-D points (HOST float32 objp0 [n0][3], imgp0 [n0][2]), which become
  *                    the first landmarks and tracks; the other tracks from goodFeaturesToTrack.  pose_out [12] host.
  *   mqs_slam_track   result [40] host doubles: [0] decision (0 rejected, 1 frame, 2 keyframe), [1] rejection reason (1 lost

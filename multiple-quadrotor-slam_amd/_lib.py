@@ -102,6 +102,8 @@ SIGNATURES = {
     "mqs_ba_gn_finish_dev": (ctypes.c_int, [c_vp, ctypes.c_double, ctypes.c_int, c_vp]),
     "mqs_ba_gn_iteration_dev": (ctypes.c_int, [c_vp, ctypes.c_double, c_vp]),
     "mqs_ba_gn_iterations_dev": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_double, c_vp]),
+    "mqs_ba_problem_status": (ctypes.c_int, [c_vp, c_vp]),
+    "mqs_debug_ba_withhold_flag": (ctypes.c_int, [ctypes.c_int]),
     "mqs_sba_workspace_bytes": (c_i64, [c_i64, c_i64, c_i64]),
     "mqs_sba_linearize_dev": (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp,
                                              c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_int, ctypes.c_double,

@@ -197,6 +197,15 @@ class BundleAdjuster:
         return self.cost_out
 
     # ---- iterations --------------------------------------------------------------------
+    def check(self):
+        """Raises RuntimeError when a bounded device-side wait of an iteration gave up (the finalizer pieces of the fused tail,
+        or a peer's row of the reduced system: csrc/ba.hip, csrc/peer_dev.h) -- the estimate is then not valid.  Synchronises
+        the current stream.  Called wherever this class hands results to the host (`total_cost`, `optimize`,
+        `gauss_newton_iterations`); call it yourself after a run of bare `gauss_newton_iteration`s."""
+        _lib.check(_lib.lib().mqs_ba_problem_status(self._h, _sp()))
+        if self.ccomm is not None and self.ccomm.peer_state() and self.ccomm.peer_timed_out():
+            raise RuntimeError("a rank's row of the reduced camera system did not arrive within 2 s (peer transport)")
+
     def gauss_newton_iteration(self, lam=0.0, overlap=None):
         """One undamped (lam = 0) or fixed-damping iteration, fully asynchronous.  `overlap`: a callable that
         enqueues work independent of this problem on the current stream; it is issued between the start of the
@@ -215,17 +224,21 @@ class BundleAdjuster:
             work.wait()
         _lib.check(L.mqs_ba_gn_finish_dev(self._h, float(lam), 1, _sp()))
 
-    def gauss_newton_iterations(self, iters, lam=0.0):
-        """`iters` iterations enqueued by one library call (single GPU or the C-level communicator)."""
+    def gauss_newton_iterations(self, iters, lam=0.0, check=True):
+        """`iters` iterations enqueued by one library call (single GPU or the C-level communicator).  check=True (default):
+        waits for them and raises if one of their bounded waits gave up (`check`); check=False leaves the call asynchronous."""
         if self.pg is not None:
             for _ in range(iters):
                 self.gauss_newton_iteration(lam)
-            return
-        _lib.check(_lib.lib().mqs_ba_gn_iterations_dev(self._h, int(iters), float(lam), _sp()))
+        else:
+            _lib.check(_lib.lib().mqs_ba_gn_iterations_dev(self._h, int(iters), float(lam), _sp()))
+        if check:
+            self.check()
 
     def total_cost(self, poses=None, points=None):
         """Host float: projection + point-prior cost summed over ranks, plus pose-prior cost."""
         torch = _torch()
+        self.check()                                             # never a cost of an estimate a timed-out iteration left behind
         c = self.cost(poses, points).clone()
         if self.ccomm is not None:
             self.ccomm.all_reduce_sum_(c)
@@ -389,9 +402,10 @@ def time_iterations(ba, iters=200, warm=60):
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    ba.gauss_newton_iterations(iters)
+    ba.gauss_newton_iterations(iters, check=False)                  # the check synchronises: after the second event
     e1.record()
     e1.synchronize()
+    ba.check()
     return e0.elapsed_time(e1) / iters
 
 

@@ -347,7 +347,7 @@ __device__ __forceinline__ void a_add(AReg &r, double v) { a_put(r, a_get(r) + v
 // the scale 0, which makes E, F and f exact zeros, and its x, y, Z -- finite by construction: a point behind the camera is
 // divided by 1 -- then only ever multiply zeros downstream (Uh = F PR L^-T = 0, k = 0, T = 0).  u, v must be finite.
 template <bool NODIST, class CamPtr>
-__device__ __forceinline__ Factor wl_make_factor(const CamPtr cam, double px, double py, double pz, double u, double v, bool seen)
+__device__ __forceinline__ Factor wl_make_factor(const CamPtr &cam, double px, double py, double pz, double u, double v, bool seen)
 {
     Factor o;
     const double dx = px - cam[9], dy = py - cam[10], dz = pz - cam[11];
@@ -406,7 +406,7 @@ __device__ __forceinline__ Factor wl_make_factor(const CamPtr cam, double px, do
 }
 
 template <class CamPtr>
-__device__ __forceinline__ void wl_make_PR(const CamPtr cam, double x, double y, double PR[2][3])   // make_PR of ba_math.h
+__device__ __forceinline__ void wl_make_PR(const CamPtr &cam, double x, double y, double PR[2][3])   // make_PR of ba_math.h
 {
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -458,6 +458,113 @@ extern "C" int mqs_debug_wl_probe(unsigned long long *out, int clear)
 __device__ __forceinline__ void wl_cam_here(WlCam &cam) { asm volatile("" : "+s"(cam)); }
 __device__ __forceinline__ void wl_cam_here(const double *&) {}
 
+// A camera block as wl_chunk's two passes see it.  LDS form: the pointer.  Scalar form: the pointer again (the compiler issues the
+// scalar loads where the first use is and waits on the spot, twice per camera where it is short of scalar registers) -- or, in the
+// A/B build MQS_WL_EARLY_CAMS=1, the block IN scalar registers, brought there by s_load instructions this file issues itself and
+// EARLY: the block of camera c + 1 is requested inside camera c's LAST landmark, right behind the last use of camera c's registers
+// (the same registers serve both), and waited for at its first use, a landmark's worth of arithmetic later.  Round 4 built this
+// because the round-3 verdict suspected those round trips (8 camera visits per chunk x 1-2 dependent scalar loads) behind the
+// lineariser's SQ_WAIT_ANY quarter; measured on one device, interleaved (profiles/r04/03_lineariser_ab.json): 90.3 us with the
+// early loads against 90.0 us without -- the scalar cache answers fast enough that the waits were never exposed.  Kept as the
+// A/B form, off.  (The compiler does not know such loads are in flight; that is safe: its own counted lgkmcnt waits only become
+// more conservative with one more operation in the counter, and every use of the registers is behind wait().)
+#ifndef MQS_WL_EARLY_CAMS
+#define MQS_WL_EARLY_CAMS 0                 // A/B: 1 = the scalar loads issued early by hand (below); 0 = the compiler's own, at the first use
+#endif
+#ifndef MQS_WL_TOT_ATOMIC
+#define MQS_WL_TOT_ATOMIC 1                 // A/B: 0 = read + add + write of the window totals (round 3)
+#endif
+typedef int wl_i16 __attribute__((ext_vector_type(16)));
+typedef int wl_i8 __attribute__((ext_vector_type(8)));
+typedef int wl_i4 __attribute__((ext_vector_type(4)));
+typedef int wl_i2 __attribute__((ext_vector_type(2)));
+#define MQS_WL_D(v, k) __hiloint2double((v)[2 * (k) + 1], (v)[2 * (k)])
+
+template <bool NODIST, class P> struct WlCamA;             // pass A: cam[0..16], cam[21], cam[22] (+ cam[17..20] with distortion)
+template <bool NODIST> struct WlCamA<NODIST, const double *> {
+    const double *p;
+    __device__ __forceinline__ void issue(const double *b) { p = b; }
+    __device__ __forceinline__ void wait() {}
+    __device__ __forceinline__ double operator[](int k) const { return p[k]; }
+};
+#if !MQS_WL_EARLY_CAMS
+template <bool NODIST> struct WlCamA<NODIST, WlCam> {
+    WlCam p;
+    __device__ __forceinline__ void issue(WlCam b) { p = b; wl_cam_here(p); }
+    __device__ __forceinline__ void wait() {}
+    __device__ __forceinline__ double operator[](int k) const { return p[k]; }
+};
+#else
+template <bool NODIST> struct WlCamA<NODIST, WlCam> {
+    wl_i16 q0, q1;          // cam[0..7], cam[8..15]
+    wl_i2 q2;               // cam[16]
+    wl_i4 q3;               // cam[21], cam[22]
+    wl_i8 q4;               // cam[17..20] (distortion only)
+    __device__ __forceinline__ void issue(WlCam b)
+    {
+        if (NODIST)
+            asm volatile("s_load_dwordx16 %0, %4, 0x0\n\ts_load_dwordx16 %1, %4, 0x40\n\ts_load_dwordx2 %2, %4, 0x80\n\ts_load_dwordx4 %3, %4, 0xa8"
+                         : "=&s"(q0), "=&s"(q1), "=&s"(q2), "=&s"(q3) : "s"(b) : "memory");
+        else
+            asm volatile("s_load_dwordx16 %0, %5, 0x0\n\ts_load_dwordx16 %1, %5, 0x40\n\ts_load_dwordx2 %2, %5, 0x80\n\ts_load_dwordx4 %3, %5, 0xa8\n\t"
+                         "s_load_dwordx8 %4, %5, 0x88"
+                         : "=&s"(q0), "=&s"(q1), "=&s"(q2), "=&s"(q3), "=&s"(q4) : "s"(b) : "memory");
+    }
+    __device__ __forceinline__ void wait()
+    {
+        if (NODIST) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(q0), "+s"(q1), "+s"(q2), "+s"(q3) : : "memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(q0), "+s"(q1), "+s"(q2), "+s"(q3), "+s"(q4) : : "memory");
+    }
+    __device__ __forceinline__ double operator[](int k) const
+    {
+        if (k < 8) return MQS_WL_D(q0, k);
+        if (k < 16) return MQS_WL_D(q1, k - 8);
+        if (k == 16) return MQS_WL_D(q2, 0);
+        if (k < 21) return MQS_WL_D(q4, k - 17);
+        return MQS_WL_D(q3, k - 21);
+    }
+};
+#endif
+template <class P> struct WlCamR;                          // diagonal pass: the rotation, cam[0..8]
+template <> struct WlCamR<const double *> {
+    const double *p;
+    __device__ __forceinline__ void issue(const double *b) { p = b; }
+    __device__ __forceinline__ void wait() {}
+    __device__ __forceinline__ double operator[](int k) const { return p[k]; }
+};
+#if !MQS_WL_EARLY_CAMS
+template <> struct WlCamR<WlCam> {
+    WlCam p;
+    __device__ __forceinline__ void issue(WlCam b) { p = b; wl_cam_here(p); }
+    __device__ __forceinline__ void wait() {}
+    __device__ __forceinline__ double operator[](int k) const { return p[k]; }
+};
+#else
+template <> struct WlCamR<WlCam> {
+    wl_i16 q0;
+    wl_i2 q1;
+    __device__ __forceinline__ void issue(WlCam b)
+    {
+        asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx2 %1, %2, 0x40" : "=&s"(q0), "=&s"(q1) : "s"(b) : "memory");
+    }
+    __device__ __forceinline__ void wait() { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(q0), "+s"(q1) : : "memory"); }
+    __device__ __forceinline__ double operator[](int k) const { return k < 8 ? MQS_WL_D(q0, k) : MQS_WL_D(q1, 0); }
+};
+#endif
+
+// A window total into the wave's row of totals: ds_add_f64 without return -- the LDS does the read-modify-write, the wave neither
+// reads the old total nor waits for anything (the read + wait + add + write it replaces sat ~100 cycles per window in s_waitcnt:
+// the compiler sank the read of the old total down to its use).  One lane per entry and one wave per row, in program order: the
+// same sums in the same order as before, bitwise reproducible.
+__device__ __forceinline__ void wl_tot_add(double *p, double v)
+{
+#if MQS_WL_TOT_ATOMIC
+    (void)__hip_atomic_fetch_add((__attribute__((address_space(3))) double *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+#else
+    *p += v;
+#endif
+}
+
 template <int C, int L, bool NODIST, class WlCamPtr>
 __device__ __forceinline__ void wl_chunk(const WlCamPtr sCam, const WlStash stash, const double *__restrict__ points,
                                          const double2 *__restrict__ obs2, const uint8_t *__restrict__ mask,
@@ -495,6 +602,8 @@ __device__ __forceinline__ void wl_chunk(const WlCamPtr sCam, const WlStash stas
         px[l] = points[3 * idx[l] + 0]; py[l] = points[3 * idx[l] + 1]; pz[l] = points[3 * idx[l] + 2];
 #endif
     }
+    WlCamA<NODIST, WlCamPtr> camA;          // the camera of pass A: camera 0's block is requested with the chunk's head loads
+    camA.issue(sCam);
     double2 ob[2][L];                       // this camera's and the next one's measurements
     uint8_t mk[2][L];                       // and their mask bytes: loaded with the measurements, never behind a wait of their own
     double pwl[L];                          // the prior weights: all loads of the chunk's head are in flight before the first wait
@@ -533,8 +642,6 @@ __device__ __forceinline__ void wl_chunk(const WlCamPtr sCam, const WlStash stas
     AReg X[L][C], Y[L][C], Z[L][C];
 #pragma unroll
     for (int c = 0; c < C; ++c) {
-        WlCamPtr cam = sCam + kCamStride * c;
-        wl_cam_here(cam);
         if (c + 1 < C) {
 #pragma unroll
             for (int l = 0; l < L; ++l) {
@@ -549,6 +656,7 @@ __device__ __forceinline__ void wl_chunk(const WlCamPtr sCam, const WlStash stas
         }
         if (c > 0 && c + 1 < C) MQS_WL_PROBE(1, "s_waitcnt vmcnt(4)")      // camera c's measurements (the 4 loads of camera c + 1 may stay out; L = 4, no mask)
         if (c > 0 && c + 1 == C) MQS_WL_PROBE(1, "s_waitcnt vmcnt(0)")
+        camA.wait();                                                        // camera c's block (requested a landmark ago)
 #pragma unroll
         for (int l = 0; l < L; ++l) {
             unsigned mbyte = mk[c & 1][l];
@@ -556,14 +664,24 @@ __device__ __forceinline__ void wl_chunk(const WlCamPtr sCam, const WlStash stas
             const bool seen = live[l] && mbyte != 0;
             // a masked slot may hold NaN: selects, not products
             const double u = seen ? ob[c & 1][l].x : 0.0, v = seen ? ob[c & 1][l].y : 0.0;
-            const Factor fc = wl_make_factor<NODIST>(cam, px[l], py[l], pz[l], u, v, seen);
+            const Factor fc = wl_make_factor<NODIST>(camA, px[l], py[l], pz[l], u, v, seen);
             double PR[2][3];
-            wl_make_PR(cam, fc.x, fc.y, PR);
-            point_add_factor(ps[l], fc, PR);
-            a_put(X[l][c], fc.x); a_put(Y[l][c], fc.y); a_put(Z[l][c], fc.Z);
+            wl_make_PR(camA, fc.x, fc.y, PR);
+            // the stash stores first: the wait for the next camera's block (an lgkmcnt(0), a landmark further on) then finds them done
             sput(l, c, 0, fc.F00, fc.F01);
             sput(l, c, 1, fc.F11, fc.f0);
             sput(l, c, 2, fc.f1, 0.0);
+            a_put(X[l][c], fc.x); a_put(Y[l][c], fc.y); a_put(Z[l][c], fc.Z);
+            if (l == L - 1 && c + 1 < C) {
+                // camera c's registers are dead from here: the next camera's block is requested into them now and lands while
+                // this landmark's block sums issue
+                double keep = PR[1][2];
+                asm volatile("" : "+v"(keep));        // every use of camera c above this line
+                PR[1][2] = keep;
+                MQS_SCHED_FENCE();
+                camA.issue(sCam + kCamStride * (c + 1));
+            }
+            point_add_factor(ps[l], fc, PR);
             cost += fc.half_e2;
             count += fc.valid ? 1.0 : 0.0;
             wl_pin(ps[l].H.xx); wl_pin(ps[l].H.xy); wl_pin(ps[l].H.xz); wl_pin(ps[l].H.yy); wl_pin(ps[l].H.yz); wl_pin(ps[l].H.zz);
@@ -573,6 +691,8 @@ __device__ __forceinline__ void wl_chunk(const WlCamPtr sCam, const WlStash stas
         }
     }
     asm volatile("; MQS_MARK pass_a_done");
+    WlCamR<WlCamPtr> camR;                  // the camera of the diagonal pass: camera 0's rotation lands under the landmark solves below
+    camR.issue(sCam);
     double w0[L], w1[L], w2[L];
 #pragma unroll
     for (int l = 0; l < L; ++l) {
@@ -590,10 +710,9 @@ __device__ __forceinline__ void wl_chunk(const WlCamPtr sCam, const WlStash stas
     double2 dq[2][3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) dq[0][k] = sget(0, 0, k);
+    camR.wait();
 #pragma unroll
     for (int c = 0; c < C; ++c) {
-WlCamPtr cam = sCam + kCamStride * c;
-        wl_cam_here(cam);
         double buf[32];
 #pragma unroll
         for (int l = 0; l < L; ++l) {
@@ -607,7 +726,14 @@ WlCamPtr cam = sCam + kCamStride * c;
             const double F00 = s0.x, F01 = s0.y, F11 = s1.x, f0 = s1.y, f1 = s2.x;
             const double xc = a_get(X[l][c]), yc = a_get(Y[l][c]), zc = a_get(Z[l][c]);
             double PR[2][3];
-            wl_make_PR(cam, xc, yc, PR);
+            wl_make_PR(camR, xc, yc, PR);
+            if (l == L - 1 && c + 1 < C) {          // as in pass A: the next camera's rotation into the registers this one has just left
+                double keep = PR[1][2];
+                asm volatile("" : "+v"(keep));
+                PR[1][2] = keep;
+                MQS_SCHED_FENCE();
+                camR.issue(sCam + kCamStride * (c + 1));
+            }
             double U[2][3];
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
@@ -656,14 +782,16 @@ WlCamPtr cam = sCam + kCamStride * c;
         buf[27] = (c == 0) ? cost : 0.0;
         buf[28] = (c == 0) ? count : 0.0;
         buf[29] = 0.0; buf[30] = 0.0; buf[31] = 0.0;
+        // the next camera's rotation (requested a landmark ago: landed) is collected HERE, before the window total goes to the LDS:
+        // the wait is an lgkmcnt(0) and would sit out the LDS add behind it otherwise
+        if (c + 1 < C) camR.wait();
         {
-            // window total -> this wave's row of totals in LDS (Layout<C> numbering; lanes 2j and 2j+1 hold entry j); the old
-            // total is read before the reduction so that its latency hides under it
+            // window total -> this wave's row of totals in LDS (Layout<C> numbering; lanes 2j and 2j+1 hold entry j), added
+            // there by the LDS itself (wl_tot_add)
             const int j = lane >> 1;
             const int slot = (j < LT::kDiagUsed) ? LT::diag_off(c) + j : ((c == 0 && j == 27) ? LT::kCost : ((c == 0 && j == 28) ? LT::kCount : LT::kCount + 1));
-            const double old = tot[slot];                            // kCount + 1: a spare word of the row
-            const double t = wave_reduce32(buf, lane);
-            if ((lane & 1) == 0) tot[slot] = old + t;
+            const double t = wave_reduce32(buf, lane);               // kCount + 1: a spare word of the row
+            if ((lane & 1) == 0) wl_tot_add(tot + slot, t);
         }
         MQS_SCHED_FENCE();
     }
@@ -719,10 +847,9 @@ WlCamPtr cam = sCam + kCamStride * c;
             }
             asm volatile("; MQS_MARK pair_entries_done");
             {
-                const double old32 = tot[LT::pair_off(c, d) + (lane >> 1)], old4 = tot[LT::pair_off(c, d) + 32 + (lane >> 4)];
                 const double t32 = wave_reduce32(buf, lane), t4 = wave_reduce4(b4, lane);
-                if ((lane & 1) == 0) tot[LT::pair_off(c, d) + (lane >> 1)] = old32 + t32;
-                if ((lane & 15) == 0) tot[LT::pair_off(c, d) + 32 + (lane >> 4)] = old4 + t4;
+                if ((lane & 1) == 0) wl_tot_add(tot + LT::pair_off(c, d) + (lane >> 1), t32);
+                if ((lane & 15) == 0) wl_tot_add(tot + LT::pair_off(c, d) + 32 + (lane >> 4), t4);
             }
             asm volatile("; MQS_MARK pair_reduced");
             MQS_SCHED_FENCE();
@@ -1452,8 +1579,26 @@ struct TailFin {
     unsigned long long *flags;        // [kFinPieces * slot groups]
     unsigned long long epoch;
     mqs_peer_push push;               // world = 0: single GPU
+    int *status;                      // null, or the problem's host-visible status word: set when the wait for the finalizers gives up
+    int withhold;                     // test hook: the finalizer piece that does not raise its flag (-1: none)
 };
 constexpr int kQuarterStride = MQS_PEER_QUARTER_STRIDE;
+
+// How the wave lineariser and the fused tail share the caller's workspace (512 rows of kRow doubles, ws_doubles):
+//   rows [0, grid)                                     the lineariser's partial rows, grid <= 256 * kWaveLinOcc
+//   [256 rows, + 256 * kWlCamSlice<C>)                 the workgroups' camera blocks for the scalar loads (SCALAR form)
+//   the last kFinPieces * kQuarterStride + 64 doubles  the fused finalize's piece sums and flags
+// The three must not meet: checked per camera count; more than one workgroup per CU (the A/B build MQS_WL_OCC=2: 512 rows)
+// would run the partial rows into the other two, so that build keeps to the LDS form and the finalize as a launch of its own.
+template <int C>
+struct WlWorkspaceCheck {
+    static constexpr int64_t kRow = Layout<C>::kChunks * 32;
+    static_assert((int64_t)256 * kWlCamSlice<C> + kFinPieces * kQuarterStride + 64 <= (int64_t)256 * kRow,
+                  "camera slices + quarter sums + flags fit behind the 256 rows of partial sums");
+    static_assert(kWaveLinOcc == 1 || MQS_WL_SCALAR_CAMS == 0, "two workgroups per CU: 512 partial rows leave no room for the camera slices");
+    static constexpr bool ok = true;
+};
+static_assert(WlWorkspaceCheck<2>::ok && WlWorkspaceCheck<3>::ok && WlWorkspaceCheck<4>::ok, "workspace regions");
 
 #ifndef MQS_TAIL_STAGED_OBS
 #define MQS_TAIL_STAGED_OBS 1               // A/B: 0 = the measurements are loaded inside the rolled camera loop
@@ -1470,7 +1615,10 @@ __global__ __launch_bounds__(kBlock, 4) void ba_tail_kernel(
     constexpr int n = 6 * C, nlin = n * n + n + 2;
     __shared__ double sCam[C * kCamStride];
     __shared__ SolveLds<C> sm;
+    __shared__ int sTimedOut;          // a bounded wait of this workgroup gave up: nothing it waited for is read, nothing is published
     const int tid = threadIdx.x;
+    if (tid == 0) sTimedOut = 0;
+    __syncthreads();
     double v[3] = {0.0, 0.0, 0.0};
     constexpr int kRowT = Layout<C>::kChunks * 32, kSlotGroups = (kRowT + 63) / 64, kFinalizers = kFinPieces * kSlotGroups;
     if (fin.partials) {
@@ -1491,12 +1639,14 @@ __global__ __launch_bounds__(kBlock, 4) void ba_tail_kernel(
             }
             mqs_stores_landed();
             __syncthreads();                          // the piece's entries have landed, here and in the peers
-            if (tid == 0) __hip_atomic_store(fin.flags + blockIdx.x, fin.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            mqs::peer::publish_piece(fin.push, blockIdx.x, tid);      // lanes 0 .. world - 1 (none on a single GPU)
+            if ((int)blockIdx.x != fin.withhold) {
+                if (tid == 0) __hip_atomic_store(fin.flags + blockIdx.x, fin.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                mqs::peer::publish_piece(fin.push, blockIdx.x, tid);  // lanes 0 .. world - 1 (none on a single GPU)
+            }
         }
     } else if (pr.rows) {
-        mqs::peer::wait_and_sum(sm.lin, nlin, pr, tid, kBlock);
-        if (blockIdx.x == gridDim.x - 1 && lin_out) {
+        const bool arrived = mqs::peer::wait_and_sum(sm.lin, nlin, pr, tid, kBlock, &sTimedOut);
+        if (arrived && blockIdx.x == gridDim.x - 1 && lin_out) {
             __syncthreads();
             for (int k = tid; k < nlin; k += kBlock) lin_out[k] = sm.lin[k];
         }
@@ -1512,17 +1662,30 @@ __global__ __launch_bounds__(kBlock, 4) void ba_tail_kernel(
     if (fin.partials) {
         // the quarters of this launch (and, over the peer transport, of every rank's): wait, then add in the fixed order
         if (fin.push.world > 0) {
-            mqs::peer::wait_flags(pr, tid, kBlock);
+            mqs::peer::wait_flags(pr, tid, kBlock, &sTimedOut);
         } else {
+            // Forward progress rests on the finalizers (the lowest workgroup indices) being dispatched before the workgroups that
+            // wait for them fill the chip: in-order dispatch, which the hardware does and HIP does not promise.  Hence the bound,
+            // and a wait that gives up is an ERROR the host sees (status word, info[1] = 2), never a sum of stale quarters.
             if (tid < kFinalizers) {
                 const long long t0 = wall_clock64();
                 while (__hip_atomic_load(fin.flags + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != fin.epoch) {
-                    if (wall_clock64() - t0 > mqs::peer::kSpinTicks) break;           // never expected: the finalizers run first
+                    if (wall_clock64() - t0 > mqs::peer::kSpinTicks) {
+                        sTimedOut = 1;
+                        if (fin.status) __hip_atomic_store(fin.status, MQS_STATUS_FINALIZE_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        break;
+                    }
                     __builtin_amdgcn_s_sleep(1);
                 }
             }
             __syncthreads();
         }
+    }
+    if (sTimedOut) {                                              // workgroup-uniform (written before the barriers above)
+        if (blockIdx.x == gridDim.x - 1 && tid == 0 && info) info[1] = 2.0;
+        return;
+    }
+    if (fin.partials) {
 #pragma unroll
         for (int q3 = 0; q3 < 3; ++q3) {
             const int k = tid + kBlock * q3;
@@ -1775,12 +1938,21 @@ int mqs_ba_linearize_push(const double *poses, const double *calib, const double
 // The wave lineariser alone (C in 2..4), and where the fused tail finds its partial rows, writes its quarters and raises its flags
 // (all inside the caller's workspace; the epoch is unique per call, so nothing needs initialising).
 std::atomic<unsigned long long> g_fin_epoch{1};
+// test hook (tests/test_ba_gpu.py): the finalizer piece of the fused tail that does NOT raise its flag, so that the wait for it runs
+// into its bound -- the only way to reach the time-out path of a protocol whose producers always arrive
+std::atomic<int> g_withhold_flag{-1};
+extern "C" int mqs_debug_ba_withhold_flag(int piece)
+{
+    g_withhold_flag.store(piece);
+    return MQS_OK;
+}
 
 int mqs_ba_linearize_for_fused_tail(const double *poses, const double *calib, const double *sigma, int C, const double *points,
                                     const double *obs, const uint8_t *mask, const double *prior_w, const double *prior_xyz, int64_t N,
                                     double lambda, void *workspace, int64_t workspace_bytes, hipStream_t stream, mqs_ba_fin *fin)
 {
     MQS_ARG_CHECK(mqs_ba_wave_path(C), "the fused finalize serves the wave lineariser (2..4 cameras)");
+    MQS_ARG_CHECK(kWaveLinOcc == 1, "the fused finalize keeps its piece sums behind 256 partial rows: not with two workgroups per CU (MQS_WL_OCC)");
     int rc = ba_linearize_parts(poses, calib, sigma, C, points, obs, mask, prior_w, prior_xyz, N, lambda, nullptr, workspace,
                                 workspace_bytes, stream, 1, nullptr);
     if (rc != MQS_OK) return rc;
@@ -1797,17 +1969,20 @@ int mqs_ba_linearize_for_fused_tail(const double *poses, const double *calib, co
     fin->flags = reinterpret_cast<unsigned long long *>(tail + kFinPieces * kQuarterStride);
     fin->epoch = g_fin_epoch.fetch_add(1);
     fin->push = nullptr;
+    fin->status = nullptr;
+    fin->withhold = g_withhold_flag.load();
     return MQS_OK;
 }
 
 bool mqs_ba_wave_path(int C) { return C >= 2 && C <= 4 && wave_lineariser_enabled() && tail_fusion_enabled(); }
+// (MQS_WL_OCC=2 builds: the fused finalize is off, WlWorkspaceCheck)
 
 bool mqs_ba_fused_finalize_enabled()
 {
     static int v = -1;
     if (v < 0) {
         const char *e = getenv("MQS_BA_FINALIZE");
-        v = (e && strcmp(e, "kernel") == 0) ? 0 : 1;
+        v = ((e && strcmp(e, "kernel") == 0) || kWaveLinOcc != 1) ? 0 : 1;
     }
     return v == 1;
 }
@@ -1920,6 +2095,8 @@ int mqs_ba_tail_launch(const double *lin, const mqs_peer_recv *peer, const mqs_b
         fin.partials = fin_->partials; fin.nrows = fin_->nrows; fin.quarters = fin_->quarters; fin.flags = fin_->flags;
         fin.epoch = fin_->epoch;
         if (fin_->push) fin.push = *fin_->push;
+        fin.status = fin_->status;
+        fin.withhold = fin_->withhold;
     }
     // persistent grid: at most 4 workgroups per CU (each solves the reduced system once), one batch of 256 landmarks per
     // workgroup below that; plus the publishing workgroup

@@ -6,6 +6,7 @@
 // At 125 k landmarks per GPU (BASELINE configs[3], 1e6 landmarks sharded 8-way) the kernels of an iteration take ~50 us:
 // five ctypes calls and a torch.distributed call per iteration would set the iteration time, this call does not.
 #include "mqs_common.h"
+#include "peer_dev.h"
 #include <new>
 
 struct mqs_ba_problem {
@@ -19,7 +20,32 @@ struct mqs_ba_problem {
     void *ws;
     int64_t ws_bytes;
     int cur;                // which of poses[] / points[] holds the current estimate
+    int *status_host;       // pinned host word the kernels of an iteration set when a bounded wait gives up (sticky; 0 = healthy)
+    int *status_dev;        // the same word as the device addresses it
+    long long peer_reductions;   // reductions of this problem that went over the peer transport so far (the first one waits differently)
 };
+
+namespace {
+
+const char *status_text(int s)
+{
+    switch (s) {
+    case MQS_STATUS_FINALIZE_TIMEOUT: return "the tail of an iteration gave up waiting (2 s) for the finalizer workgroups of its own launch";
+    case MQS_STATUS_PEER_TIMEOUT: return "a rank's row of the reduced camera system did not arrive within 2 s (peer transport)";
+    }
+    return "unknown status";
+}
+
+// the sticky status of the problem and of its context's peer transport WITHOUT touching the stream: what has been seen so far
+int status_so_far(const mqs_ba_problem *p)
+{
+    const int s = p->status_host ? __atomic_load_n(p->status_host, __ATOMIC_RELAXED) : 0;
+    if (s == 0) return MQS_OK;
+    mqs_set_error("bundle adjustment iteration failed: %s; the estimate of this problem is not valid any more", status_text(s));
+    return MQS_E_TIMEOUT;
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -51,11 +77,44 @@ int mqs_ba_problem_create(mqs_ctx *ctx, int C, int64_t N, double *poses_a, doubl
     p->prior_poses = prior_poses; p->prior_sigmas = prior_sigmas; p->prior_mask = prior_mask;
     p->lin = lin; p->dpose = dpose; p->info = info; p->ws = workspace; p->ws_bytes = workspace_bytes;
     p->cur = 0;
+    // the status word lives in pinned host memory the GPU writes over the fabric: the host reads it without a copy, and
+    // mqs_ba_gn_iteration_dev checks it on entry without synchronising anything
+    void *h = nullptr;
+    if (hipHostMalloc(&h, 64, hipHostMallocMapped) != hipSuccess) {
+        (void)hipGetLastError();
+        delete p;
+        mqs_set_error("the problem's status word could not be allocated (hipHostMalloc)");
+        return MQS_E_NOMEM;
+    }
+    memset(h, 0, 64);
+    p->status_host = static_cast<int *>(h);
+    void *d = nullptr;
+    if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipHostFree(h);
+        delete p;
+        mqs_set_error("the problem's status word could not be mapped (hipHostGetDevicePointer)");
+        return MQS_E_HIP;
+    }
+    p->status_dev = static_cast<int *>(d);
     *out = p;
     return MQS_OK;
 }
 
-void mqs_ba_problem_destroy(mqs_ba_problem *p) { delete p; }
+void mqs_ba_problem_destroy(mqs_ba_problem *p)
+{
+    if (p && p->status_host) (void)hipHostFree(p->status_host);
+    delete p;
+}
+
+// MQS_OK, or MQS_E_TIMEOUT when a bounded wait inside an iteration of this problem gave up (sticky: the estimate is not valid
+// any more).  Synchronises `stream` first, so that it speaks for everything enqueued on it.
+int mqs_ba_problem_status(mqs_ba_problem *p, void *stream)
+{
+    MQS_ARG_CHECK(p != nullptr, "problem must not be null");
+    MQS_HIP_CHECK(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    return status_so_far(p);
+}
 
 int mqs_ba_problem_current(const mqs_ba_problem *p) { return p ? p->cur : -1; }
 
@@ -92,6 +151,10 @@ int mqs_ba_gn_finish_dev(mqs_ba_problem *p, double lambda, int accept, void *str
 int mqs_ba_gn_iteration_dev(mqs_ba_problem *p, double lambda, void *stream_)
 {
     MQS_ARG_CHECK(p != nullptr, "problem must not be null");
+    {
+        const int rc = status_so_far(p);      // an earlier iteration's wait gave up: do not build on its output
+        if (rc != MQS_OK) return rc;
+    }
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int64_t nlin = (int64_t)36 * p->C * p->C + 6 * p->C + 2;
     const int c = p->cur, o = 1 - c;
@@ -105,13 +168,16 @@ int mqs_ba_gn_iteration_dev(mqs_ba_problem *p, double lambda, void *stream_)
     // receive buffer and every workgroup waits for all ranks' pieces -- the all-reduce without any launch of its own.
     if (mqs_ba_wave_path(p->C) && mqs_ba_fused_finalize_enabled()) {
         const int pieces = MQS_FIN_PIECES * mqs_ba_finalize_groups(p->C);
-        const bool peer = has_comm && mqs_comm_peer_fused(p->ctx) && mqs_comm_peer_next(p->ctx, MQS_FIN_PIECES * MQS_PEER_QUARTER_STRIDE, pieces, &push, &recv, &fused_wait);
+        // (the first reduction of a problem over the peer transport takes the path below: a one-workgroup wait with a long bound)
+        const bool peer = has_comm && mqs_comm_peer_fused(p->ctx) && p->peer_reductions > 0 && mqs_comm_peer_next(p->ctx, MQS_FIN_PIECES * MQS_PEER_QUARTER_STRIDE, pieces, &push, &recv, &fused_wait);
+        if (peer) ++p->peer_reductions;
         if (!has_comm || peer) {
             mqs_ba_fin fin;
             int rc = mqs_ba_linearize_for_fused_tail(p->poses[c], p->calib, p->sigma, p->C, p->points[c], p->obs, p->mask, p->prior_w,
                                                      p->prior_xyz, p->N, lambda, p->ws, p->ws_bytes, stream, &fin);
             if (rc != MQS_OK) return rc;
-            if (peer) fin.push = &push;
+            if (peer) { fin.push = &push; recv.status = p->status_dev; }
+            fin.status = p->status_dev;
             rc = mqs_ba_tail_launch(nullptr, peer ? &recv : nullptr, &fin, p->C, p->poses[c], p->calib, p->sigma, p->points[c], p->obs,
                                     p->mask, p->prior_w, p->prior_xyz, p->N, lambda, p->prior_poses, p->prior_sigmas, p->prior_mask, p->lin,
                                     p->dpose, p->poses[o], p->info, p->points[o], stream);
@@ -123,6 +189,9 @@ int mqs_ba_gn_iteration_dev(mqs_ba_problem *p, double lambda, void *stream_)
     // Peer transport with ranks that share a GPU (tests), or the finalize kept as a launch: the finalize kernel stores this rank's
     // reduced system into every rank's receive buffer, a one-workgroup kernel (or, MQS_PEER_FUSED=1, the tail) waits and adds.
     if (p->ctx && mqs_comm_peer_next(p->ctx, nlin, mqs_ba_finalize_groups(p->C), &push, &recv, &fused_wait)) {
+        recv.status = p->status_dev;
+        const bool first = p->peer_reductions++ == 0;
+        if (first) { recv.spin_ticks = mqs::peer::kSpinTicksFirst; fused_wait = 0; }
         int rc = mqs_ba_linearize_push(p->poses[c], p->calib, p->sigma, p->C, p->points[c], p->obs, p->mask, p->prior_w,
                                        p->prior_xyz, p->N, lambda, p->lin, p->ws, p->ws_bytes, stream, &push);
         if (rc != MQS_OK) return rc;

@@ -25,6 +25,7 @@
 #include "chol_block.h"
 #include <algorithm>
 #include <list>
+#include <memory>
 #include <map>
 #include <mutex>
 #include <tuple>
@@ -734,7 +735,10 @@ std::mutex g_plan_mutex;
 // used plan's device memory is freed when a new shape arrives (kMaxPlans shapes alive at a time; a bundle adjustment calls
 // the solve tens of times per shape, the plan costs ~1 ms of host work to rebuild).
 constexpr size_t kMaxPlans = 8;
-struct PlanEntry { std::tuple<int, void *, int, int, int> key; Plan *plan; };
+// plans are shared_ptrs: a solve holds its plan while it enqueues from it, so an eviction by another host thread (a ninth shape)
+// only drops the cache's reference; the device memory goes (hipFree: waits for the device) with the last holder
+struct PlanDeleter { void operator()(Plan *p) const { if (p) { free_plan_device(*p); delete p; } } };
+struct PlanEntry { std::tuple<int, void *, int, int, int> key; std::shared_ptr<Plan> plan; };
 std::list<PlanEntry> g_plans;                     // most recently used first
 
 bool xcd_pin_enabled()
@@ -751,7 +755,7 @@ int parts_from_env()
     return v < 0 ? 0 : v;
 }
 
-Plan *get_plan(int n, int hb, hipStream_t stream)
+std::shared_ptr<Plan> get_plan(int n, int hb, hipStream_t stream)
 {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
@@ -763,13 +767,8 @@ Plan *get_plan(int n, int hb, hipStream_t stream)
             g_plans.splice(g_plans.begin(), g_plans, it);
             return g_plans.front().plan;
         }
-    while (g_plans.size() >= kMaxPlans) {
-        Plan *old = g_plans.back().plan;
-        g_plans.pop_back();
-        free_plan_device(*old);
-        delete old;
-    }
-    Plan *p = new Plan();
+    while (g_plans.size() >= kMaxPlans) g_plans.pop_back();
+    std::shared_ptr<Plan> p(new Plan(), PlanDeleter());
     if (!build_plan(*p, n, hb, parts)) p->usable = false;
     g_plans.push_front({key, p});
     return p;
@@ -791,7 +790,7 @@ int mqs_chol_nd_solve(double *S, double *x, int n, int hb, int *bad, hipStream_t
 {
     using namespace mqs::chol;
     *done = false;
-    Plan *plan = get_plan(n, hb, stream);
+    const std::shared_ptr<Plan> plan = get_plan(n, hb, stream);         // held until every launch below is enqueued
     if (!plan || !plan->usable) return MQS_OK;
     static mqs_lds_opt_in opt_f, opt_b;                 // per device
     MQS_HIP_CHECK(mqs_lds_opt_in_once(opt_f, reinterpret_cast<const void *>(nd_fwd_front_kernel), 150 * 1024));

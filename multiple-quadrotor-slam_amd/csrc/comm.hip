@@ -118,19 +118,24 @@ size_t peer_bytes(int world) { return peer_timeout_off(world) + 256; }
 // the whole reduction in one workgroup: push `buf` to every rank, wait for every rank's row, sum in rank order into `buf`
 __global__ __launch_bounds__(256) void peer_all_reduce_kernel(double *__restrict__ buf, int n, mqs_peer_push push, mqs_peer_recv recv)
 {
+    __shared__ int timed_out;
     const int tid = threadIdx.x;
+    if (tid == 0) timed_out = 0;
     for (int i = tid; i < n; i += 256) mqs::peer::push_entry(push, i, buf[i]);
     mqs_stores_landed();
     __syncthreads();                     // the row has landed everywhere before its flags go up (peer_dev.h)
     if (tid < push.world * recv.flags_per_rank)
         __hip_atomic_store(push.flag[tid / recv.flags_per_rank] + tid % recv.flags_per_rank, push.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    mqs::peer::wait_and_sum(buf, n, recv, tid, 256);
+    mqs::peer::wait_and_sum(buf, n, recv, tid, 256, &timed_out);      // after a wait that gave up `buf` keeps this rank's row
 }
 
 // the wait + sum alone (the rows were pushed by the lineariser's finalize kernel): a launch of its own for ranks that share a GPU
 __global__ __launch_bounds__(256) void peer_gather_kernel(double *__restrict__ out, int n, mqs_peer_recv recv)
 {
-    mqs::peer::wait_and_sum(out, n, recv, threadIdx.x, 256);
+    __shared__ int timed_out;
+    if (threadIdx.x == 0) timed_out = 0;
+    __syncthreads();
+    mqs::peer::wait_and_sum(out, n, recv, threadIdx.x, 256, &timed_out);
 }
 
 PeerComm *peer_of(const mqs_ctx *ctx) { return ctx ? static_cast<PeerComm *>(ctx->peer) : nullptr; }
@@ -181,6 +186,8 @@ int mqs_comm_peer_next(mqs_ctx *ctx, int64_t n, int flags_used, mqs_peer_push *p
     recv->flags_stride = kPeerFlagsPerRank;
     recv->seq = seq;
     recv->timeout_flag = reinterpret_cast<int *>(pc->mine + peer_timeout_off(pc->world));
+    recv->status = nullptr;
+    recv->spin_ticks = mqs::peer::kSpinTicks;
     if (fused_wait) {
         const char *e = getenv("MQS_PEER_FUSED");
         *fused_wait = (e && *e) ? (e[0] != '0') : !pc->shared_device;

@@ -52,7 +52,12 @@ struct mqs_peer_recv {
     int world, row_stride, flags_per_rank, flags_stride;
     unsigned long long seq;
     int *timeout_flag;                   // device int, set when a row did not arrive within the spin bound
+    int *status;                         // null, or the host-visible status word of the problem this reduction belongs to (ba_iter.hip)
+    long long spin_ticks;                // bound of the wait in ticks of the 100 MHz wall clock (peer_dev.h: kSpinTicks)
 };
+// values of a problem's status word (sticky; mqs_ba_problem_status): which bounded wait of an iteration gave up
+constexpr int MQS_STATUS_FINALIZE_TIMEOUT = 1;     // the fused tail, for its own launch's finalizer workgroups
+constexpr int MQS_STATUS_PEER_TIMEOUT = 2;         // a consumer of the peer transport, for another rank's row
 int mqs_comm_peer_next(mqs_ctx *ctx, int64_t n, int flags_used, mqs_peer_push *push, mqs_peer_recv *recv, int *fused_wait);
 int mqs_comm_peer_gather(const mqs_peer_recv *recv, double *out, int64_t n, hipStream_t stream);
 // an open peer transport whose consumers may wait inside their own kernel (no two ranks share a GPU; MQS_PEER_FUSED overrides)
@@ -73,6 +78,8 @@ struct mqs_ba_fin {
     unsigned long long *flags;
     unsigned long long epoch;
     const mqs_peer_push *push;           // non-null: the quarters also go into every rank's receive buffer
+    int *status;                         // null, or the problem's host-visible status word (set when the wait for the finalizers gives up)
+    int withhold;                        // test hook (mqs_debug_ba_withhold_flag): the finalizer piece whose flag is NOT raised; -1 = none
 };
 int mqs_ba_linearize_for_fused_tail(const double *poses, const double *calib, const double *sigma, int C, const double *points,
                                     const double *obs, const uint8_t *mask, const double *prior_w, const double *prior_xyz, int64_t N,

@@ -692,6 +692,7 @@ int mqs_slam_start(mqs_slam *s, const uint8_t *img_dev, const float *objp0, cons
 {
     MQS_ARG_CHECK(s != nullptr && img_dev && objp0 && imgp0 && pose_out, "pointers must not be null");
     MQS_ARG_CHECK(n0 >= 6 && n0 <= s->p.target, "6 <= n0 <= target_keypoints");
+    MQS_ARG_CHECK(n0 <= s->p.max_landmarks, "n0 <= max_landmarks (the start-up landmarks go into the map)");
     MQS_HIP_CHECK(hipSetDevice(s->device));
     // staged through the keyframe-step output arrays (free at this point)
     float *o_dev = reinterpret_cast<float *>(s->d.kf_x), *i_dev = reinterpret_cast<float *>(s->d.kf_scratch);

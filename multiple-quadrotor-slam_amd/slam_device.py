@@ -86,11 +86,15 @@ class DeviceMonoSlam:
             pass
 
     @staticmethod
-    def _img_ptr(img, shape):
+    def _img_ptr(img, shape, sync=True):
         import torch
         if not (isinstance(img, torch.Tensor) and img.is_cuda and img.dtype == torch.uint8 and img.is_contiguous()
                 and tuple(img.shape) == tuple(shape)):
             raise ValueError("images are contiguous uint8 device tensors of shape %r" % (tuple(shape),))
+        # the library reads the image on its own stream and takes no event (include/mqslam.h, "Streams"): whatever the caller
+        # enqueued on torch's current stream to produce it (an upload, a render) has to be complete first
+        if sync:
+            torch.cuda.current_stream(img.device).synchronize()
         return ctypes.c_void_p(img.data_ptr())
 
     def start(self, img, init_objp, init_imgp):
@@ -122,7 +126,7 @@ class DeviceMonoSlam:
         t0 = time.perf_counter()
         if self.ba_info is not None:
             self.ba_info.next_step()                         # slam2.py:1204: one step per frame, rejected ones included
-        rc = self._track(self._h, self._img_ptr(self._prev, self.shape), self._img_ptr(img, self.shape), self._pres)
+        rc = self._track(self._h, self._img_ptr(self._prev, self.shape, sync=False), self._img_ptr(img, self.shape), self._pres)
         if rc != 0:
             _lib.check(rc)
         r = self._res

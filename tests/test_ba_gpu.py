@@ -501,3 +501,38 @@ def test_scalar_camera_blocks_follow_the_poses(gpu):
         worst = max(worst, float((whole - parts).abs().max() / whole.abs().max()))
     assert worst <= 1e-10, worst
 
+
+
+@pytest.mark.gpu
+def test_a_finalizer_flag_that_never_comes_is_an_error_not_an_answer(gpu):
+    """The fused tail waits (bounded, 2 s) for the finalizer workgroups of its own launch.  A wait that gives up must not fold
+    whatever sits in the piece sums: with one flag withheld (the library's test hook) the iteration publishes nothing -- the
+    poses and landmarks of the next estimate keep the poison they were filled with, info[1] = 2 -- and the host gets a
+    RuntimeError from the calls that hand results over (`gauss_newton_iterations`, `total_cost`, `check`) and from the next
+    iteration's entry; a healthy problem next to it is not affected."""
+    import torch
+    L = gpu._lib.lib()
+    sc = make_scene(70_000, 4, seed=5)
+    ba = adjuster(gpu, sc)
+    ok = adjuster(gpu, sc)
+    ba.gauss_newton_iterations(2)                                     # healthy: no error, estimate advances
+    poison = 12345.678
+    ba.poses_new.fill_(poison)
+    ba.points_new.fill_(poison)
+    assert L.mqs_debug_ba_withhold_flag(17) == 0
+    try:
+        with pytest.raises(RuntimeError, match="gave up waiting"):
+            ba.gauss_newton_iterations(1)
+    finally:
+        assert L.mqs_debug_ba_withhold_flag(-1) == 0
+    # nothing was published by the iteration that timed out (its outputs are the `current` buffers now: the handle flipped)
+    assert bool((ba.poses == poison).all()) and bool((ba.points == poison).all())
+    assert float(ba.info[1].item()) == 2.0
+    with pytest.raises(RuntimeError, match="gave up waiting"):
+        ba.total_cost()
+    with pytest.raises(RuntimeError, match="gave up waiting"):
+        ba.gauss_newton_iteration()                                   # sticky: the entry point refuses to build on it
+    with pytest.raises(RuntimeError, match="gave up waiting"):
+        ba.check()
+    ok.gauss_newton_iterations(2)                                     # the hook is off again and other problems never saw it
+    assert np.isfinite(ok.total_cost())

@@ -303,3 +303,64 @@ def test_peer_transport_single_rank_is_the_plain_iteration(gpu):
         assert not cc.peer_timed_out()
     finally:
         cc.close()
+
+
+PEER_TIMEOUT_WORKER = """
+import os, sys, time
+import numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import torch
+import mqslam_amd
+from ba_util import make_scene
+sh = mqslam_amd.sharding
+rank, local_rank, world = sh.init_from_env()
+dev = torch.device("cuda", 0)
+cc = sh.init_peer_comm(rank, world, 0)
+sc = make_scene(4001, 4, seed=11)
+pts, obs, mask, pw, px = sh.shard_arrays(rank, world, sc["points"], sc["obs"], sc["mask"], sc["prior_w"], sc["prior_xyz"])
+t = lambda a, dt=torch.float64: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev).to(dt)
+ba = mqslam_amd.bundle_adjustment.BundleAdjuster(t(sc["poses"]), t(sc["calib"]), t(sc["sigma"]), t(pts), t(obs), None,
+                                                 t(pw), t(px), None, cc)
+ba.gauss_newton_iterations(2)              # both ranks: healthy (the first reduction of a problem waits in a kernel of its own)
+torch.distributed.barrier()
+if rank == 0:
+    poison = 4321.5
+    ba.poses_new.fill_(poison); ba.points_new.fill_(poison)
+    t0 = time.time()
+    try:
+        ba.gauss_newton_iterations(1)      # rank 1 never issues this one: its row does not arrive
+        print("no-error")
+    except RuntimeError as e:
+        assert "did not arrive" in str(e), str(e)
+        assert 1.5 < time.time() - t0 < 20.0, time.time() - t0
+        # the rows were never read: nothing was published on top of the poison (wait inside the tail), or NaN was (the solve
+        # enqueued behind the stand-alone wait kernel ran on a system that kernel had set to NaN)
+        for tns in (ba.poses, ba.points):
+            assert bool((tns == poison).all()) or bool(torch.isnan(tns).all()), tns
+        assert cc.peer_timed_out()
+        try:
+            ba.gauss_newton_iteration()
+            print("not-sticky")
+        except RuntimeError:
+            print("timeout-ok")
+else:
+    time.sleep(6.0)
+    print("timeout-ok")
+torch.distributed.barrier()
+cc.close()
+torch.distributed.destroy_process_group()
+"""
+
+
+def test_peer_row_that_never_arrives_is_an_error(gpu, tmp_path):
+    """A rank that does not issue its iteration: the waiting rank's bounded wait (2 s) gives up, and that is a RuntimeError from
+    `gauss_newton_iterations` -- not poses computed from a half-empty receive buffer -- with the stand-alone wait kernel and with
+    the wait inside the fused tail."""
+    for tag, fused in (("gather", "0"), ("fused", "1")):
+        script = tmp_path / ("peer_timeout_%s.py" % tag)
+        script.write_text(PEER_TIMEOUT_WORKER.format(root=ROOT))
+        env = dict(os.environ, MQS_DIST_BACKEND="gloo", MQS_SHARED_GPU="1", MASTER_ADDR="127.0.0.1", MQS_PEER_FUSED=fused)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+               "127.0.0.1", "--master-port", str(29600 + os.getpid() % 250), str(script)]
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and r.stdout.count("timeout-ok") == 2, r.stdout[-2000:] + r.stderr[-4000:]

@@ -96,10 +96,10 @@ float run(int iters, double *d)
     return ms;
 }
 
-int main()
+int main(int argc, char **argv)
 {
     double *d; hipMalloc(&d, 4096);
-    const int iters = 20000;
+    const int iters = argc > 1 ? atoi(argv[1]) : 20000;       // under rocprofv3 --pmc: 100000 (dispatches long enough for GRBM_GUI_ACTIVE to give the clock)
     const double insts = 64.0 * iters;
     const char *names[] = {"fma_s 1 chain", "fma_s 8 chains", "fma_v 8 chains", "mul_v 8 chains", "add_v 8 chains", "accvgpr r/w", "cndmask", "permlane32_swap", "mov dpp", "fma_v + accvgpr_read 1:1", "cndmask sgpr-pair mask", "bfi", "cndmask vcc, far sources, separate dst", "and_b32", "cndmask e64 encoding, vcc mask", "v_cmp e32 (writes vcc)", "v_cmp e64 (writes an sgpr pair)", "v_cmp e32 -> v_cndmask e32 through vcc, 1:1", "v_cmp e64 -> v_cndmask e64 through an sgpr pair, 1:1"};
     float one[] = {run<FMA_S1, 1>(iters, d), run<FMA_S8, 1>(iters, d), run<FMA_V, 1>(iters, d), run<MUL_V, 1>(iters, d), run<ADD_V, 1>(iters, d),
