@@ -101,6 +101,28 @@ struct StagedObs {
     }
 };
 
+// the same for the second form of the tail (kTail2Block-thread workgroups: camera c at s[c * kTail2Block]).  The ring is read with ds_read
+// instructions the compiler cannot see through: it knows the ring is written by LDS-DMA and, unable to tell the two halves of the
+// ring apart, would put an s_waitcnt vmcnt(0) in front of every read -- draining the NEXT batch's loads, which are in flight into
+// the other half on purpose.  That the half read here has landed is the loop's own explicit wait (ba_tail2_kernel).
+// 12 waves per workgroup and CU = 3 per SIMD = 168 registers each: with 16 (128 registers) the solve wave and the batch loop, which
+// holds the next batch's loads in registers while it computes, both spilled -- and a scratch reload is a vector memory operation
+// whose wait also drains the prefetch it stands behind
+constexpr int kTail2Block = 768;
+typedef double wl_d2 __attribute__((ext_vector_type(2)));
+struct StagedObs2 {
+    unsigned s;                // LDS byte address of this thread's measurement of camera 0
+    unsigned mbits;
+    bool live, masked;
+    __device__ __forceinline__ void get(int c, double &u, double &v, bool &seen) const
+    {
+        wl_d2 t;
+        asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(t) : "v"(s + (unsigned)c * (unsigned)(kTail2Block * 16)) : "memory");
+        seen = live && (!masked || ((mbits >> (8 * c)) & 0xffu) != 0u);
+        u = seen ? t.x : 0.0; v = seen ? t.y : 0.0;
+    }
+};
+
 // F = E^T E and f = E^T e of every camera between the two passes of the lineariser: this thread's LDS column.
 struct LdsFactorStash {
     static constexpr bool kEnabled = true;
@@ -1779,6 +1801,237 @@ __global__ __launch_bounds__(kBlock, 4) void ba_tail_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The tail, second form (round 4): ONE workgroup of 12 waves per CU instead of four of 4 waves.
+//
+// What the form above pays at 1e6 x 4 (profiles/r04/02: 13.6 M vector instructions per launch, the SIMDs' vector units 74 % busy
+// summed over their four waves -- the launch is bound by vector issue as much as by latency): every one of its 1 024 workgroups
+// builds and solves the 24 x 24 system (~2 500 wave-instructions each: 2.6 M of the 13.6 M, and 4-5 us at the head of every
+// workgroup during which it streams nothing), and a batch's loads are issued, waited for and only then computed on.  Here
+//   * 256 workgroups (one per CU) of 768 threads: the system is solved ONCE per CU, by wave 0, while every wave already has its
+//     first batch's loads in flight;
+//   * the measurements of batch b + 1 (LDS-DMA into the other half of a two-deep ring) and its points / prior weights / mask
+//     bytes (registers) are requested BEFORE batch b's arithmetic, so a wave never sits out a memory latency after the first;
+//   * the finalize pieces (fused finalize) are folded by the first 16 workgroups, three pieces each, in the order of
+//     ba_finalize_kernel: the same bits.
+// Same arithmetic per landmark (landmark_backsub), same solve (reduced_solve_wave): bit-identical outputs to the first form.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(kTail2Block) void ba_tail2_kernel(
+    const double *__restrict__ lin, mqs_peer_recv pr, TailFin fin, const double *__restrict__ poses, const double *__restrict__ calib,
+    const double *__restrict__ sigma, const double *__restrict__ points, const double *__restrict__ obs,
+    const uint8_t *__restrict__ mask, const double *__restrict__ prior_w, const double *__restrict__ prior_xyz, int64_t N,
+    double lambda, const double *__restrict__ prior_poses, const double *__restrict__ prior_sigmas,
+    const uint8_t *__restrict__ prior_mask, double *__restrict__ lin_out, double *__restrict__ dpose,
+    double *__restrict__ poses_out, double *__restrict__ info, double *__restrict__ points_out)
+{
+    constexpr int n = 6 * C, nlin = n * n + n + 2;
+    constexpr int TB = kTail2Block;
+    __shared__ double sCam[C * kCamStride];
+    __shared__ SolveLds<C> sm;
+    __shared__ int sTimedOut;
+    extern __shared__ __attribute__((aligned(16))) unsigned char tail2_smem[];
+    double2 *sRing = reinterpret_cast<double2 *>(tail2_smem);           // [2][C][TB] measurements: this batch's and the next one's
+    const int tid = threadIdx.x;
+    if (tid == 0) sTimedOut = 0;
+    __syncthreads();
+
+    // ---- this workgroup's landmarks, and the first batch's loads (in flight under everything up to the solve) ----
+    // the last workgroup also publishes dpose, the retracted poses and info: its wave 0 alone, ~1 us behind the other fifteen
+    // (the loop below has no workgroup barrier, nobody waits for it)
+    const bool publisher = blockIdx.x == gridDim.x - 1;
+    const double2 *o2 = reinterpret_cast<const double2 *>(obs);
+    const int wave64 = __builtin_amdgcn_readfirstlane(tid & ~63);
+    const int64_t rows64 = (N + 63) / 64;
+    const int64_t nwg = gridDim.x;
+    const int64_t r_begin = rows64 * blockIdx.x / nwg, r_end = rows64 * (blockIdx.x + 1) / nwg;
+    int64_t end = r_end * 64;
+    if (end > N) end = N;
+    struct Batch { double px, py, pz, pw; unsigned mb[C]; };          // mask bytes kept apart until used: combining them is a wait
+    auto request = [&](int64_t base, int slot, Batch &b) {
+        const int64_t i = base + tid;
+        const int64_t ii = i < end ? i : (end > 0 ? end - 1 : 0);
+        b.px = points[3 * ii + 0]; b.py = points[3 * ii + 1]; b.pz = points[3 * ii + 2];
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(o2 + (int64_t)c * N + ii),
+                                             (__attribute__((address_space(3))) void *)(sRing + (slot * C + c) * TB + wave64), 16, 0, 0);
+#pragma unroll
+        for (int c = 0; c < C; ++c) b.mb[c] = mask ? (unsigned)mask[(int64_t)c * N + ii] : 1u;
+        b.pw = prior_w ? prior_w[ii] : 0.0;
+    };
+    Batch cur;
+    cur.px = cur.py = cur.pz = cur.pw = 0.0;
+#pragma unroll
+    for (int c = 0; c < C; ++c) cur.mb[c] = 0u;
+    const int64_t base0 = r_begin * 64;
+    if (base0 < end) request(base0, 0, cur);
+    // The first batch's registers are PARKED in LDS across the solve (ring half 1 and beyond: unused before the loop): the solve
+    // wave needs all 128 registers, and what is live across it would go to scratch memory -- on the serial chain of every CU.
+    // Parking waits for the loads; that costs nothing: every wave has to meet the barrier in front of the solve anyway, and by
+    // then (finalizer pieces, flags) the loads have long landed.
+    double *sPark = reinterpret_cast<double *>(sRing + C * TB);          // [4][TB] doubles, then [C][TB] unsigned
+    unsigned *sParkM = reinterpret_cast<unsigned *>(sPark + 4 * TB);
+    auto park = [&]() {
+        sPark[tid] = cur.px; sPark[TB + tid] = cur.py; sPark[2 * TB + tid] = cur.pz; sPark[3 * TB + tid] = cur.pw;
+#pragma unroll
+        for (int c = 0; c < C; ++c) sParkM[c * TB + tid] = cur.mb[c];
+    };
+    auto unpark = [&]() {
+        cur.px = sPark[tid]; cur.py = sPark[TB + tid]; cur.pz = sPark[2 * TB + tid]; cur.pw = sPark[3 * TB + tid];
+#pragma unroll
+        for (int c = 0; c < C; ++c) cur.mb[c] = sParkM[c * TB + tid];
+    };
+
+    // ---- the reduced system: finalize pieces / the peers' rows / the caller's `lin` ----
+    double v[3] = {0.0, 0.0, 0.0};
+    constexpr int kRowT = Layout<C>::kChunks * 32, kSlotGroups = (kRowT + 63) / 64, kFinalizers = kFinPieces * kSlotGroups;
+    constexpr int kVirt = TB / kBlock;                                    // finalizer pieces one workgroup folds (four waves each)
+    if (fin.partials) {
+        const int vb = (int)blockIdx.x * kVirt + tid / kBlock;           // the piece, numbered as the first form's workgroups
+        if ((int)blockIdx.x * kVirt < kFinalizers) {                      // workgroup-uniform
+            double (*sQ)[4][64] = reinterpret_cast<double (*)[4][64]>(sRing + C * TB);   // ring slot 1: not in use before the loop
+            static_assert(sizeof(double) * kVirt * 4 * 64 <= sizeof(double2) * C * TB, "the piece sums fit a ring slot");
+            const int t4 = tid % kBlock, lane = t4 & 63, wave = t4 >> 6, vq = tid / kBlock;
+            const bool mine = vb < kFinalizers;
+            const int sg = vb % kSlotGroups, q = vb / kSlotGroups;
+            const int slot = 64 * sg + lane;
+            sQ[vq][wave][lane] = (mine && slot < kRowT) ? piece_part_sum(fin.partials, fin.nrows, kRowT, q, wave, slot) : 0.0;
+            __syncthreads();
+            if (mine && wave == 0 && slot < Layout<C>::kSlots) {
+                const double qs = ((sQ[vq][0][lane] + sQ[vq][1][lane]) + sQ[vq][2][lane]) + sQ[vq][3][lane];
+                int o1, o2i;
+                slot_to_out<C>(slot, o1, o2i);
+                if (o1 >= 0) __hip_atomic_store(fin.quarters + q * kQuarterStride + o1, qs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (o2i >= 0) __hip_atomic_store(fin.quarters + q * kQuarterStride + o2i, qs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (o1 >= 0) mqs::peer::push_entry(fin.push, q * kQuarterStride + o1, qs);
+                if (o2i >= 0) mqs::peer::push_entry(fin.push, q * kQuarterStride + o2i, qs);
+            }
+            mqs_stores_landed();          // (also drains this wave's first-batch loads: the finalizer workgroups are 12 of 256)
+            __syncthreads();                          // the pieces' entries have landed, here and in the peers
+            if (mine && vb != fin.withhold) {
+                if (t4 == 0) __hip_atomic_store(fin.flags + vb, fin.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                mqs::peer::publish_piece(fin.push, vb, t4);          // lanes 0 .. world - 1 of the piece's first wave
+            }
+        }
+    } else if (pr.rows) {
+        const bool arrived = mqs::peer::wait_and_sum(sm.lin, nlin, pr, tid, TB, &sTimedOut);
+        if (arrived && publisher && lin_out) {
+            __syncthreads();
+            for (int k = tid; k < nlin; k += TB) lin_out[k] = sm.lin[k];
+        }
+    } else if (tid < kBlock) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) v[q] = (tid + kBlock * q < nlin) ? lin[tid + kBlock * q] : 0.0;
+    }
+    stage_cams<C>(poses, calib, sigma, sCam, tid);                  // ends in a workgroup barrier
+    if (tid < 64) pose_prior_terms<C>(poses, prior_poses, prior_sigmas, prior_mask, tid, sm.e, sm.w, sm.info);
+    __syncthreads();
+    if (fin.partials) {
+        if (fin.push.world > 0) {
+            mqs::peer::wait_flags(pr, tid, TB, &sTimedOut);
+        } else {
+            // (forward progress: the finalizers are the lowest workgroup indices of a grid of one workgroup per CU -- all resident)
+            if (tid < kFinalizers) {
+                const long long t0 = wall_clock64();
+                while (__hip_atomic_load(fin.flags + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != fin.epoch) {
+                    if (wall_clock64() - t0 > mqs::peer::kSpinTicks) {
+                        sTimedOut = 1;
+                        if (fin.status) __hip_atomic_store(fin.status, MQS_STATUS_FINALIZE_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (sTimedOut) {                                              // workgroup-uniform: nothing waited for is read, nothing is published
+        if (publisher && tid == 0 && info) info[1] = 2.0;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the first batch's LDS-DMA must not land in a released LDS
+        return;
+    }
+    if (fin.partials) {
+        if (tid < kBlock) {
+#pragma unroll
+            for (int q3 = 0; q3 < 3; ++q3) {
+                const int k = tid + kBlock * q3;
+                if (k < nlin) {
+                    if (fin.push.world > 0) {
+                        double t = 0.0;
+                        for (int rk = 0; rk < pr.world; ++rk) {            // rank order; a rank's pieces folded in the finalize's order
+                            const double *row = pr.rows + (size_t)rk * pr.row_stride + k;
+                            double pv[kFinPieces];
+#pragma unroll
+                            for (int q = 0; q < kFinPieces; ++q) pv[q] = __hip_atomic_load(row + q * kQuarterStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            double r = pv[0];
+#pragma unroll
+                            for (int q = 1; q < kFinPieces; ++q) r += pv[q];
+                            t += r;
+                        }
+                        v[q3] = t;
+                    } else {
+                        double pv[kFinPieces];
+#pragma unroll
+                        for (int q = 0; q < kFinPieces; ++q) pv[q] = __hip_atomic_load(fin.quarters + q * kQuarterStride + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        double r = pv[0];
+#pragma unroll
+                        for (int q = 1; q < kFinPieces; ++q) r += pv[q];
+                        v[q3] = r;
+                    }
+                    if (publisher && lin_out) lin_out[k] = v[q3];
+                }
+            }
+            build_solve_matrix_from_registers<C>(sm, v, lambda, tid);
+        }
+    } else if (pr.rows) {
+        build_solve_matrix<C>(sm, lambda, tid, TB);
+    } else if (tid < kBlock) {
+        build_solve_matrix_from_registers<C>(sm, v, lambda, tid);
+    }
+    park();
+    __syncthreads();
+    bool bad = false;
+    if (tid < 64) reduced_solve_wave<C>(sm.m, sm.col, sm.y, sm.x, tid, bad);
+    __syncthreads();
+    if (publisher && tid < 64) publish_solution<C>(sm, poses, bad, tid, dpose, poses_out, info);      // behind the barrier: nobody waits for the retraction
+    unpark();
+
+    // ---- back-substitution: batch b's arithmetic with batch b + 1's loads in flight ----
+    int slot = 0;
+    for (int64_t base = base0; base < end; base += TB, slot ^= 1) {
+        Batch nxt = cur;
+        const bool more = base + TB < end;                       // workgroup-uniform
+        // this batch's loads have landed (DMA in LDS, registers); only then is the next batch requested: vmcnt counts in order,
+        // and the ring half the next batch lands in was read by the batch before this one
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (more) request(base + TB, slot ^ 1, nxt);
+        const int64_t i = base + tid;
+        const bool live = i < end;
+        double px = cur.px, py = cur.py, pz = cur.pz;
+        if (!live) { px = 0.0; py = 0.0; pz = 0.0; }
+        double pw = 0.0, dx = 0.0, dy = 0.0, dz = 0.0;
+        if (live && prior_w && cur.pw > 0.0) {
+            pw = cur.pw;
+            dx = px - prior_xyz[3 * i + 0];
+            dy = py - prior_xyz[3 * i + 1];
+            dz = pz - prior_xyz[3 * i + 2];
+        }
+        unsigned mbits = 0u;
+#pragma unroll
+        for (int c = 0; c < C; ++c) mbits |= cur.mb[c] << (8 * c);
+        const unsigned ring_addr = (unsigned)(size_t)(__attribute__((address_space(3))) double2 *)(sRing + slot * C * TB + tid);
+        const StagedObs2 ob = {ring_addr, mbits, live, mask != nullptr};
+        const mqs::Vec3 dp = landmark_backsub<C>(sCam, ob, px, py, pz, pw, dx, dy, dz, lambda, sm.x);
+        if (live) {
+            points_out[3 * i + 0] = px + dp.x;
+            points_out[3 * i + 1] = py + dp.y;
+            points_out[3 * i + 2] = pz + dp.z;
+        }
+        cur = nxt;
+    }
+}
+
 // Grid: persistent workgroups, 2 per CU at <= 256 VGPRs (each keeps its partial sums in registers).
 int ba_grid(int64_t N)
 {
@@ -1810,6 +2063,19 @@ bool wave_lineariser_enabled()
         v = (e && strcmp(e, "lane") == 0) ? 0 : 1;
     }
     return v == 1;
+}
+
+// A/B switch for measurements: MQS_BA_TAIL_FORM=2 selects the second form of the fused tail (one twelve-wave workgroup per CU: built
+// in round 4, bit-identical, and SLOWER -- 38.9 against 36.1 us at 1e6, 11.5 against 10.3 us at 125 k, profiles/r04/05 -- because
+// 3 072 resident waves quantise 15 625 rows worse than 4 092 do and three waves per SIMD hide less than four)
+int tail_form()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("MQS_BA_TAIL_FORM");
+        v = (e && e[0] == '2') ? 2 : 1;
+    }
+    return v;
 }
 
 // A/B switch for measurements: MQS_BA_TAIL=split issues solve and back-substitution as two launches for every C
@@ -2091,6 +2357,7 @@ int mqs_ba_tail_launch(const double *lin, const mqs_peer_recv *peer, const mqs_b
     mqs_peer_recv pr = {};
     if (peer) pr = *peer;
     TailFin fin = {};
+    fin.withhold = -1;
     if (fin_) {
         fin.partials = fin_->partials; fin.nrows = fin_->nrows; fin.quarters = fin_->quarters; fin.flags = fin_->flags;
         fin.epoch = fin_->epoch;
@@ -2098,9 +2365,42 @@ int mqs_ba_tail_launch(const double *lin, const mqs_peer_recv *peer, const mqs_b
         fin.status = fin_->status;
         fin.withhold = fin_->withhold;
     }
-    // persistent grid: at most 4 workgroups per CU (each solves the reduced system once), one batch of 256 landmarks per
-    // workgroup below that; plus the publishing workgroup
     const int64_t rows64 = (N + 63) / 64;
+    if (tail_form() == 2) {
+        // second form: one workgroup of 12 waves per CU (the system is solved once per CU); below a chip's worth of landmarks one
+        // workgroup per four rows; the finalizer pieces are the first ceil(kFinPieces * ceil(kRow / 64) / 3) <= 16 workgroups
+        int64_t g = (rows64 + 3) / 4;
+        if (g < 1) g = 1;
+        const int64_t gfin = (kFinPieces * mqs_ba_finalize_groups(C) + kTail2Block / kBlock - 1) / (kTail2Block / kBlock);
+        if (fin_ && g < gfin) g = gfin;
+        if (g > 256) g = 256;
+        switch (C) {
+#define MQS_CASE(c)                                                                                                      \
+    case c: {                                                                                                            \
+        static mqs_lds_opt_in opt;                                                                                       \
+        const size_t ring = (size_t)c * kTail2Block * sizeof(double2), park = (size_t)kTail2Block * (32 + 4 * c);       \
+        const size_t lds = ring + (ring > park ? ring : park);      /* two ring halves; the parked batch lies over the second */ \
+        MQS_HIP_CHECK(mqs_lds_opt_in_once(opt, reinterpret_cast<const void *>(ba_tail2_kernel<c>), lds));                \
+        hipLaunchKernelGGL((ba_tail2_kernel<c>), dim3((unsigned)g), dim3(kTail2Block), lds, stream, lin, pr, fin, poses, calib, sigma, points, obs, \
+                           mask, prior_w, prior_xyz, N, lambda, prior_poses, prior_sigmas, prior_mask, lin_out, dpose, poses_out, \
+                           info, points_out);                                                                            \
+        break;                                                                                                           \
+    }
+            MQS_CASE(1) MQS_CASE(2) MQS_CASE(3) MQS_CASE(4)
+#undef MQS_CASE
+        default:
+            mqs_set_error("the fused tail serves 1..4 cameras");
+            return MQS_E_ARG;
+        }
+        MQS_HIP_CHECK(hipGetLastError());
+        return MQS_OK;
+    }
+    // first form: persistent grid, at most 4 workgroups per CU (each solves the reduced system once), one batch of 256 landmarks per
+    // workgroup below that; plus the publishing workgroup.  (Round 4 measured the alternative for large problems -- only eight
+    // workgroups, one per XCD, solve and hand dpose to the others behind a flag: the redundant solves are 2.6 M of the launch's
+    // 13.6 M vector instructions -- and it is SLOWER, 132.6 against 131.9 us per iteration at 1e6 and 75.5 against 74.2 us at
+    // 400 k, profiles/r04/05: the solves of the four workgroups of a CU run side by side on its four SIMDs at the head of the
+    // launch, when nothing else could use them, and the hand-over adds a hop to every workgroup's serial head.)
     int64_t g = (rows64 + 3) / 4;
     if (g < 1) g = 1;
     if (g > 1023) g = 1023;
