@@ -389,6 +389,15 @@ int64_t mqs_sba_group_pairs_workspace_bytes(int64_t Q);
 int mqs_sba_group_pairs_dev(const int64_t *obs_ptr, const int32_t *obs_pose, int64_t N, const int64_t *pair_off, int64_t Q, int64_t P,
                             int64_t *pair_a, int64_t *pair_b, int64_t *group_ptr, int64_t group_cap, int64_t *n_groups,
                             void *workspace, int64_t workspace_bytes, void *stream);
+/* The observations sorted by pose index inside every landmark (stable), on the device: the order mqs_sba_group_pairs_dev and
+ * the sparse linearisers assume.  obs_ptr [N + 1] CSR by landmark; obs_pose_in [M] / obs_uv_in [M][2] in any order inside a
+ * landmark; obs_pose_out / obs_uv_out distinct from the inputs; order_out [M] int32 (may be NULL): the input index of every
+ * output observation.  Replaces the host-side lexsort of the set-up (the recorder of slam2.py:743-865 and IO.hpp:366-406 hand
+ * observations over in step order, not pose order). */
+int64_t mqs_sba_sort_observations_workspace_bytes(int64_t M);
+int mqs_sba_sort_observations_dev(const int64_t *obs_ptr, const int32_t *obs_pose_in, const double *obs_uv_in, int64_t N, int64_t M, int64_t P,
+                                  int32_t *obs_pose_out, double *obs_uv_out, int32_t *order_out, void *workspace, int64_t workspace_bytes,
+                                  void *stream);
 int mqs_sba_solve_dev(double *S, double *x, int64_t P, double lambda, const double *poses, double *poses_out,
                       int *bad, void *stream);
 /* The same solve for a reduced camera system known to be banded: S[i][j] == 0 for |i - j| > half_bandwidth (a

@@ -113,6 +113,8 @@ SIGNATURES = {
                                                      ctypes.c_double, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "mqs_sba_group_pairs_workspace_bytes": (c_i64, [c_i64]),
     "mqs_sba_group_pairs_dev": (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp]),
+    "mqs_sba_sort_observations_workspace_bytes": (c_i64, [c_i64]),
+    "mqs_sba_sort_observations_dev": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "mqs_sba_solve_dev": (ctypes.c_int, [c_vp, c_vp, c_i64, ctypes.c_double, c_vp, c_vp, c_vp, c_vp]),
     "mqs_sba_solve_banded_dev": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i64, ctypes.c_double, c_vp, c_vp, c_vp, c_vp]),
     "mqs_sba_solve_plan_dump": (ctypes.c_int64, [c_i64, c_i64, ctypes.c_int, c_vp, c_i64]),

@@ -221,6 +221,36 @@ __global__ __launch_bounds__(kThreads) void group_write_kernel(const unsigned lo
         if (mask & (1u << j)) { if (g < cap) group_ptr[g] = base + j; ++g; }
 }
 
+// ---- observations sorted by pose inside every landmark (the order the pair enumeration above and the linearisers assume) ----
+// key = landmark * P + pose (the CSR already groups the observations by landmark: the landmark by binary search in obs_ptr),
+// value = the observation's index; the radix passes above sort (stable); the poses and the measurements are then gathered.
+__global__ __launch_bounds__(kThreads) void obs_keys_kernel(const int64_t *__restrict__ obs_ptr, const int32_t *__restrict__ obs_pose,
+                                                            int64_t N, int64_t M, unsigned long long P,
+                                                            unsigned long long *__restrict__ key, unsigned int *__restrict__ val)
+{
+    const int64_t m = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (m >= M) return;
+    int64_t lo = 0, hi = N;                              // landmark lo with obs_ptr[lo] <= m < obs_ptr[lo + 1] (empty landmarks skipped)
+    while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (obs_ptr[mid] <= m) lo = mid; else hi = mid;
+    }
+    key[m] = (unsigned long long)lo * P + (unsigned long long)obs_pose[m];
+    val[m] = (unsigned int)m;
+}
+
+__global__ __launch_bounds__(kThreads) void obs_gather_kernel(const unsigned int *__restrict__ val, int64_t M, const int32_t *__restrict__ pose_in,
+                                                              const double2 *__restrict__ uv_in, int32_t *__restrict__ pose_out,
+                                                              double2 *__restrict__ uv_out, int32_t *__restrict__ order_out)
+{
+    const int64_t m = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (m >= M) return;
+    const unsigned int src = val[m];
+    pose_out[m] = pose_in[src];
+    uv_out[m] = uv_in[src];
+    if (order_out) order_out[m] = (int32_t)src;
+}
+
 int64_t tiles_of(int64_t Q) { return (Q + kTile - 1) / kTile; }
 
 }  // namespace
@@ -281,6 +311,55 @@ int mqs_sba_group_pairs_dev(const int64_t *obs_ptr, const int32_t *obs_pose, int
     hipLaunchKernelGGL(gather_flags_kernel, dim3(tiles), dim3(kThreads), 0, stream, key[cur], val[cur], Q, pa, pb, pair_a, pair_b, hist);
     hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(1024), 0, stream, hist, tiles, Q, group_ptr, group_cap, n_groups);
     hipLaunchKernelGGL(group_write_kernel, dim3(tiles), dim3(kThreads), 0, stream, key[cur], Q, hist, group_ptr, group_cap);
+    MQS_HIP_CHECK(hipGetLastError());
+    return MQS_OK;
+}
+
+int64_t mqs_sba_sort_observations_workspace_bytes(int64_t M)
+{
+    if (M < 0) return 0;
+    auto up = [](int64_t v) { return (v + 255) & ~int64_t(255); };
+    return 2 * (up(M * 8) + up(M * 4)) + up((int64_t)kDigits * tiles_of(M > 0 ? M : 1) * 4) + 256;
+}
+
+// The observations of a CSR-by-landmark problem (obs_ptr [N + 1]; obs_pose_in [M], obs_uv_in [M][2] in ANY order inside a
+// landmark) sorted by pose index inside every landmark, stably: obs_pose_out / obs_uv_out (distinct from the inputs), and --
+// order_out [M] int32, may be NULL -- which input observation each output one is.  Same result as a stable per-landmark
+// argsort (sparse_ba.sort_observations_by_pose, the numpy statement of it: 7 ms of host time at 231 k observations).
+int mqs_sba_sort_observations_dev(const int64_t *obs_ptr, const int32_t *obs_pose_in, const double *obs_uv_in, int64_t N, int64_t M, int64_t P,
+                                  int32_t *obs_pose_out, double *obs_uv_out, int32_t *order_out, void *workspace, int64_t workspace_bytes,
+                                  void *stream_)
+{
+    MQS_ARG_CHECK(N >= 0 && M >= 0 && P >= 1 && M < 0x7fffffffll && P < (1ll << 31), "sizes (M < 2^31 observations)");
+    if (M == 0) return MQS_OK;
+    MQS_ARG_CHECK(obs_ptr && obs_pose_in && obs_uv_in && obs_pose_out && obs_uv_out && workspace, "pointers must not be null");
+    MQS_ARG_CHECK(obs_pose_out != obs_pose_in && obs_uv_out != obs_uv_in, "the sort is not in place");
+    MQS_ARG_CHECK(workspace_bytes >= mqs_sba_sort_observations_workspace_bytes(M), "workspace too small (mqs_sba_sort_observations_workspace_bytes)");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    auto up = [](int64_t v) { return (v + 255) & ~int64_t(255); };
+    char *w = static_cast<char *>(workspace);
+    unsigned long long *key[2];
+    unsigned int *val[2];
+    key[0] = reinterpret_cast<unsigned long long *>(w); w += up(M * 8);
+    key[1] = reinterpret_cast<unsigned long long *>(w); w += up(M * 8);
+    val[0] = reinterpret_cast<unsigned int *>(w); w += up(M * 4);
+    val[1] = reinterpret_cast<unsigned int *>(w); w += up(M * 4);
+    unsigned int *hist = reinterpret_cast<unsigned int *>(w);
+    const int tiles = (int)tiles_of(M);
+    const unsigned grid = (unsigned)((M + kThreads - 1) / kThreads);
+    hipLaunchKernelGGL(obs_keys_kernel, dim3(grid), dim3(kThreads), 0, stream, obs_ptr, obs_pose_in, N, M, (unsigned long long)P, key[0], val[0]);
+    int bits = 0;
+    for (unsigned long long m = (unsigned long long)(N > 0 ? N : 1) * (unsigned long long)P - 1ull; m; m >>= 1) ++bits;
+    int cur = 0;
+    for (int shift = 0; shift < bits; shift += kDigitBits) {
+        hipLaunchKernelGGL(radix_hist_kernel, dim3(tiles), dim3(kThreads), 0, stream, key[cur], M, shift, tiles, hist);
+        hipLaunchKernelGGL(radix_scan_kernel, dim3(1), dim3(1024), 0, stream, hist, kDigits * tiles);
+        hipLaunchKernelGGL(radix_scatter_kernel, dim3(tiles), dim3(kThreads), 0, stream, key[cur], val[cur], M, shift, tiles, hist, key[1 - cur],
+                           val[1 - cur]);
+        cur = 1 - cur;
+    }
+    hipLaunchKernelGGL(obs_gather_kernel, dim3(grid), dim3(kThreads), 0, stream, val[cur], M, obs_pose_in, reinterpret_cast<const double2 *>(obs_uv_in),
+                       obs_pose_out, reinterpret_cast<double2 *>(obs_uv_out), order_out);
     MQS_HIP_CHECK(hipGetLastError());
     return MQS_OK;
 }

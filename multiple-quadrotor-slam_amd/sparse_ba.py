@@ -74,6 +74,20 @@ def sort_observations_by_pose(problem):
     return problem._replace(obs_pose=op[order].copy(), obs_uv=np.asarray(problem.obs_uv)[order].copy())
 
 
+def sort_observations_dev(obs_ptr, obs_pose, obs_uv, n_landmarks, n_poses, want_order=False):
+    """`sort_observations_by_pose` on the device (csrc/pair_group.hip: key = landmark * P + pose, the stable radix sort of the pair
+    grouping, one gather): device tensors in, (obs_pose, obs_uv[, order]) sorted by pose inside every landmark out."""
+    torch = _torch()
+    M = int(obs_pose.numel())
+    pose_out, uv_out = torch.empty_like(obs_pose), torch.empty_like(obs_uv)
+    order = torch.empty(M, dtype=torch.int32, device=obs_pose.device) if want_order else None
+    if M:
+        ws = torch.empty(int(_lib.lib().mqs_sba_sort_observations_workspace_bytes(M)), dtype=torch.uint8, device=obs_pose.device)
+        _lib.check(_lib.lib().mqs_sba_sort_observations_dev(_p(obs_ptr), _p(obs_pose), _p(obs_uv), int(n_landmarks), M, int(n_poses),
+                                                            _p(pose_out), _p(uv_out), _p(order), _p(ws), ws.numel(), _sp()))
+    return (pose_out, uv_out, order) if want_order else (pose_out, uv_out)
+
+
 def group_pairs_dev(obs_ptr_host, obs_ptr, obs_pose, n_poses):
     """The grouped pair list of `group_pairs(build_pairs(...))`, built on the device (csrc/pair_group.hip): obs_ptr_host the
     CSR offsets as numpy (for the pair counts: Q must be known to size the outputs), obs_ptr / obs_pose their device tensors
@@ -99,7 +113,7 @@ def group_pairs_dev(obs_ptr_host, obs_ptr, obs_pose, n_poses):
 class SparseBundleAdjuster:
     def __init__(self, problem, device="cuda:0"):
         torch = _torch()
-        pr = sort_observations_by_pose(problem)
+        pr = problem                           # observations in the order they came (recorder / file order inside a landmark)
         self.problem = pr
         dev = torch.device(device)
         self.dev = dev
@@ -112,11 +126,12 @@ class SparseBundleAdjuster:
         self.sigma = t(pr.sigma, f64)
         self.points = t(pr.points, f64)
         self.obs_ptr = t(pr.obs_ptr, i64)
-        self.obs_pose = t(pr.obs_pose, i32)
-        self.obs_uv = t(pr.obs_uv, f64)
-        # every pair of observations of a landmark, grouped by pose pair: built and sorted on the device (numpy twins
-        # `build_pairs` / `group_pairs` above: the same lists, 0.2 s at the kt2 shape)
+        # the observations sorted by pose inside every landmark, and every pair of observations of a landmark grouped by pose
+        # pair: both built on the device (numpy twins `sort_observations_by_pose`, `build_pairs` / `group_pairs` above: the same
+        # lists; the host sort alone was 7 ms of a 9 ms set-up at the kt2 shape, round 3)
         with torch.cuda.device(dev):
+            self.obs_pose, self.obs_uv = sort_observations_dev(self.obs_ptr, t(pr.obs_pose, i32), t(np.asarray(pr.obs_uv).reshape(-1, 2), f64),
+                                                               len(pr.points), len(pr.poses))
             self.pair_a, self.pair_b, self.group_ptr = group_pairs_dev(pr.obs_ptr, self.obs_ptr, self.obs_pose, len(pr.poses))
         self.Q, self.G = int(self.pair_a.numel()), int(self.group_ptr.numel()) - 1
         has_prior = pr.prior_w is not None and np.any(pr.prior_w > 0)
@@ -128,9 +143,14 @@ class SparseBundleAdjuster:
         self.pp_sigmas = t(pr.pose_prior_sigmas, f64) if self.npp else None
         # half bandwidth of the reduced camera system: poses coupled by a common landmark or an odometry link are at
         # most `dmax` apart in pose index (observations are sorted by pose inside a landmark)
-        ptr = np.asarray(pr.obs_ptr)
+        ptr = np.asarray(pr.obs_ptr, dtype=np.int64)
         has = ptr[1:] > ptr[:-1]
-        dmax = int((pr.obs_pose[ptr[1:][has] - 1] - pr.obs_pose[ptr[:-1][has]]).max()) if has.any() else 0
+        if has.any():                                            # largest pose-index span of a landmark (observations in any order)
+            op_h = np.asarray(pr.obs_pose, dtype=np.int64)
+            starts = ptr[:-1][has]
+            dmax = int((np.maximum.reduceat(op_h, starts) - np.minimum.reduceat(op_h, starts)).max())
+        else:
+            dmax = 0
         if len(pr.odo_from):
             dmax = max(dmax, int(np.abs(np.asarray(pr.odo_from, dtype=np.int64) - np.asarray(pr.odo_to, dtype=np.int64)).max()))
         self.half_bandwidth = 6 * (dmax + 1) - 1

@@ -582,3 +582,42 @@ def test_observation_sort_is_the_stable_per_landmark_sort(mqs):
         o = np.argsort(op[a:b], kind="stable")
         np.testing.assert_array_equal(out.obs_pose[a:b], op[a:b][o])
         np.testing.assert_array_equal(out.obs_uv[a:b], uv[a:b][o])
+
+
+@pytest.mark.gpu
+def test_observation_sort_on_the_device_equals_numpy(gpu):
+    """mqs_sba_sort_observations_dev (key = landmark * P + pose, stable radix sort, one gather) against the numpy statement of the
+    same sort: random CSR problems with empty landmarks and repeated poses inside a landmark (stability decides the order of the
+    measurements), from a handful to 300 k observations, and the reversed SVO problem."""
+    import collections
+    import torch
+    Pr = collections.namedtuple("Pr", "obs_ptr obs_pose obs_uv")
+    rng = np.random.default_rng(5)
+    cases = [(1, 3, 5), (7, 5, 3), (400, 12, 9), (5000, 300, 40), (20000, 881, 31)]
+    for N, P, kmax in cases:
+        k = rng.integers(0, kmax, N)
+        k[rng.integers(0, N, max(1, N // 10))] = 0                                  # empty landmarks
+        ptr = np.concatenate([[0], np.cumsum(k)]).astype(np.int64)
+        M = int(ptr[-1])
+        op = rng.integers(0, P, M).astype(np.int32)
+        uv = rng.standard_normal((M, 2))
+        want = gpu.sparse_ba.sort_observations_by_pose(Pr(ptr, op, uv))
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+        got_pose, got_uv, order = gpu.sparse_ba.sort_observations_dev(t(ptr), t(op), t(uv), N, P, want_order=True)
+        np.testing.assert_array_equal(got_pose.cpu().numpy(), want.obs_pose)
+        np.testing.assert_array_equal(got_uv.cpu().numpy(), want.obs_uv)
+        o = order.cpu().numpy()
+        np.testing.assert_array_equal(op[o], want.obs_pose)
+        assert sorted(o.tolist()) == list(range(M))
+    # a recorded problem handed over in REVERSE pose order inside every landmark: the adjuster sorts it on the device and
+    # linearises to the same reduced system as from the file order
+    fn, data = load(gpu, SVO, "slam2", 1, 50)
+    pr = gpu.ba_io.build_sparse_problem(data)
+    ptr = np.asarray(pr.obs_ptr)
+    rev = np.concatenate([np.arange(int(ptr[i + 1]) - 1, int(ptr[i]) - 1, -1) for i in range(len(ptr) - 1)]).astype(np.int64)
+    pr_rev = pr._replace(obs_pose=np.asarray(pr.obs_pose)[rev].copy(), obs_uv=np.asarray(pr.obs_uv)[rev].copy())
+    a, b = gpu.sparse_ba.SparseBundleAdjuster(pr), gpu.sparse_ba.SparseBundleAdjuster(pr_rev)
+    assert torch.equal(a.obs_pose, b.obs_pose) and torch.equal(a.obs_uv, b.obs_uv)
+    Sa, ga = a.linearize(0.0)
+    Sb, gb = b.linearize(0.0)
+    assert torch.equal(Sa, Sb) and torch.equal(ga, gb)
