@@ -644,6 +644,11 @@ def main():
             frontend_out["end_to_end_loop"] = run_slam_loop.run_with_ba(60)
             # the same loop with its state resident on the device, one library call per frame (csrc/slam_frame.hip)
             frontend_out["end_to_end_loop_device_resident"] = run_slam_loop.run_device(60, repeats=3)
+            # BASELINE configs[4] as written -- detect -> match -> triangulate -> BA per keyframe: the same loop with the bundle
+            # adjustment of everything so far behind every keyframe (observation log on the device, sparse LM, the adjusted map and
+            # poses written back into the live state) and the matcher re-associating the top-up's corners with lost landmarks
+            frontend_out["end_to_end_loop_device_resident_ba_per_keyframe"] = run_slam_loop.run_device(
+                60, repeats=2, bundle_adjust="keyframe", reassociate=True)
         except Exception as e:                                  # noqa: BLE001 -- a secondary leg must not cost the bench line
             frontend_out = {"error": "%s: %s" % (type(e).__name__, e)}
 

@@ -584,6 +584,29 @@ int mqs_slam_create(int device, int W, int H, const double *intr, int target_key
 void mqs_slam_destroy(mqs_slam *s);
 int mqs_slam_set_thresholds(mqs_slam *s, double max_of_error, double max_lost_tracks_ratio, double max_reproj_error,
                             double max_outlier_ratio, double homography_condition_threshold, int max_homography_points);
+ /* Bundle adjustment inside the loop (BASELINE configs[4]: detect -> track -> triangulate -> BA per keyframe).  The reference
+ * records what its bundle adjuster needs in BundleAdjustmentInfoContainer (slam2.py:519-522, 634-641, 1167-1169) and runs the
+ * adjuster as a separate program afterwards; here the record is a flat log in device memory, appended by the frame's own
+ * kernels, and the result of an adjustment goes back into the live state:
+ *   mqs_slam_log_enable   before mqs_slam_start: capacity in observations.  Every accepted frame appends (landmark, pose index,
+ *                         pixel) for every track it keeps -- a free track under its track id, resolved to its landmark once a
+ *                         keyframe has triangulated it (a new landmark so brings along its image points of every frame since
+ *                         the base keyframe, slam2.py:634-641) -- and every keyframe appends the new landmarks' pixels in the
+ *                         base keyframe.  Pose index = rank among the accepted frames.
+ *   mqs_slam_read_log     the log so far into host arrays (lm, pose int32 [n]; uv float64 [n][2]); n = entries logged;
+ *                         lm = -1 for the observations of tracks that have not (yet) become landmarks.
+ *   mqs_slam_write_back   the first n landmarks of the map and the poses of the last accepted frame / the base keyframe
+ *                         ([R | t] 3x4 world -> camera, NULL = unchanged) replaced by adjusted values. */
+ /*   mqs_slam_reassociate  behind a keyframe (after the mqs_slam_track that reported it): the reference's match_OF_based
+ *                         (slam.py:81-127) inside this loop -- BFMatcher.radiusMatch on pixel coordinates
+ *                         (mqs_match_knn2_f32_dev), ratio test and one match per keypoint (mqs_match_ratio_unique_dev) between
+ *                         the projections of the landmarks that are in the map but not tracked any more and the corners the
+ *                         keyframe's top-up has just detected; a matched corner continues its landmark (and the observation
+ *                         is logged) instead of starting a new one.  *n_matched: corners re-associated. */
+int mqs_slam_reassociate(mqs_slam *s, float max_radius, double max_dist_ratio, int32_t *n_matched);
+int mqs_slam_log_enable(mqs_slam *s, int64_t capacity);
+int mqs_slam_read_log(mqs_slam *s, int32_t *lm, int32_t *pose, double *uv, int64_t cap, int64_t *n);
+int mqs_slam_write_back(mqs_slam *s, const double *map, int n, const double *pose_prev, const double *pose_key);
 int mqs_slam_start(mqs_slam *s, const uint8_t *img_dev, const float *objp0, const float *imgp0, int n0, double *pose_out);
 int mqs_slam_track(mqs_slam *s, const uint8_t *prev_img_dev, const uint8_t *img_dev, double *result);
 int mqs_slam_flush(mqs_slam *s, double *result);

@@ -172,6 +172,10 @@ SIGNATURES = {
                                        ctypes.c_int, ctypes.c_uint64, ctypes.POINTER(c_vp)]),
     "mqs_slam_destroy": (None, [c_vp]),
     "mqs_slam_set_thresholds": (ctypes.c_int, [c_vp] + [ctypes.c_double] * 5 + [ctypes.c_int]),
+    "mqs_slam_reassociate": (ctypes.c_int, [c_vp, ctypes.c_float, ctypes.c_double, c_i32p]),
+    "mqs_slam_log_enable": (ctypes.c_int, [c_vp, c_i64]),
+    "mqs_slam_read_log": (ctypes.c_int, [c_vp, c_i32p, c_i32p, c_f64p, c_i64, ctypes.POINTER(c_i64)]),
+    "mqs_slam_write_back": (ctypes.c_int, [c_vp, c_f64p, ctypes.c_int, c_f64p, c_f64p]),
     "mqs_slam_start": (ctypes.c_int, [c_vp, c_vp, c_f32p, c_f32p, ctypes.c_int, c_f64p]),
     "mqs_slam_track": (ctypes.c_int, [c_vp, c_vp, c_vp, c_f64p]),
     "mqs_slam_flush": (ctypes.c_int, [c_vp, c_f64p]),

@@ -32,7 +32,7 @@ constexpr double kPnpEps = 1e-10;
 constexpr int kRes = 40;                        // doubles in the result block
 
 // counters in device memory
-enum { C_N = 0, C_NLAND, C_NEXT_TID, C_FRAME, C_NTRI, C_NKEEP, C_KF_PENDING, C_SPARE, C_COUNT };
+enum { C_N = 0, C_NLAND, C_NEXT_TID, C_FRAME, C_NTRI, C_NKEEP, C_KF_PENDING, C_NLOG, C_COUNT };
 // result block (doubles)
 enum { R_DECISION = 0, R_REASON, R_NTRACKS, R_NTRI, R_NINL, R_NOLD, R_NNEW, R_LOST, R_OUTLIER, R_REPROJ, R_HOMOGRAPHY, R_NLAND,
        R_POSE = 12, R_KF_VALID = 24, R_KF_NGOOD, R_KF_NTRACKS, R_KF_NLAND, R_KF_POSE = 28 };
@@ -61,6 +61,15 @@ struct SlamDev {
     float *gf_xy;
     int32_t *gf_n;
     double *res;
+    // the observation log for the bundle adjuster (mqs_slam_log_enable; null: off): what slam2.py's BundleAdjustmentInfoContainer is
+    // handed (:519-522, 634-641), as flat device arrays -- (landmark, pose index of the accepted frame, pixel) per observation
+    int32_t *log_lm, *log_pose;
+    double *log_uv;
+    int log_cap;
+    // a FREE track's observation is logged under -2 - (track id); when the track becomes a landmark, tid2lm[track id] says which
+    // (slam2.py:634-641: a new landmark brings its image points of every frame since the base keyframe along)
+    int32_t *tid2lm;
+    int tid_cap;
 };
 
 struct SlamParams {
@@ -69,6 +78,7 @@ struct SlamParams {
     double max_of_error, max_lost_ratio, max_reproj, max_outlier_ratio, homography_threshold;
     unsigned long long seed;
     int max_homography_points;      // keyframe_test's random sample (slam2.py:48; the reference: max(4, target / 4), :1088-1089); 0 = all tracks (default)
+    int pose_index, base_pose_index; // index this frame gets among the ACCEPTED frames if it is accepted; that of the base keyframe
 };
 
 // rank of this thread among the flagged threads of the workgroup (thread order), and their number; two barriers
@@ -304,6 +314,7 @@ __global__ __launch_bounds__(256) void frame_decide_kernel(SlamDev d, SlamParams
     for (int j = tid; j < n_tri; j += 256) sInl[d.tri_pos[j]] = d.inl_mask[j];
     __syncthreads();
     int n_acc = 0, n_old = 0, n_new = 0;
+    const int nlog0 = d.log_lm ? d.cnt[C_NLOG] : 0;
     for (int b = 0; b < n_keep; b += 256) {
         const int k = b + tid;
         const bool in = k < n_keep && sInl[k] != 0;
@@ -317,6 +328,10 @@ __global__ __launch_bounds__(256) void frame_decide_kernel(SlamDev d, SlamParams
             d.pts[2 * r] = px; d.pts[2 * r + 1] = py;
             d.base[2 * r] = bx; d.base[2 * r + 1] = by;
             d.lm[r] = d.t_lm[k]; d.tid[r] = d.t_tid[k];
+            if (d.log_lm && nlog0 + r < d.log_cap) {              // slam2.py:519-522 (landmark tracks) and :634-641 (free tracks, resolved later)
+                d.log_lm[nlog0 + r] = tri ? d.t_lm[k] : -2 - d.t_tid[k]; d.log_pose[nlog0 + r] = p.pose_index;
+                d.log_uv[2 * (nlog0 + r)] = (double)px; d.log_uv[2 * (nlog0 + r) + 1] = (double)py;
+            }
             if (tri) {
                 const int l = d.t_lm[k];
                 d.kf_objp[3 * ro] = d.map[3 * l]; d.kf_objp[3 * ro + 1] = d.map[3 * l + 1]; d.kf_objp[3 * ro + 2] = d.map[3 * l + 2];
@@ -335,6 +350,7 @@ __global__ __launch_bounds__(256) void frame_decide_kernel(SlamDev d, SlamParams
     __syncthreads();
     if (tid < 12) d.pose_prev[tid] = sP[tid];
     if (tid == 0) d.cnt[C_N] = n_acc;
+    if (tid == 0 && d.log_lm) d.cnt[C_NLOG] = min(nlog0 + n_acc, d.log_cap);
 
     // keyframe_test's random sample of the kept tracks (slam2.py:48: np.random.permutation(n)[:max_num_homography_points]): a
     // counter-based hash of (seed, frame, track position) per track, the tracks with the max_homography_points smallest hashes are
@@ -471,6 +487,7 @@ __global__ __launch_bounds__(256) void keyframe_commit_kernel(SlamDev d, SlamPar
     __shared__ int sWave[4];
     const int tid = threadIdx.x;
     const int n = d.cnt[C_N], nl = d.cnt[C_NLAND];
+    const int nlog0 = d.log_lm ? d.cnt[C_NLOG] : 0;
     int n_good = 0;
     for (int b = 0; b < n_new; b += 256) {
         const int j = b + tid;
@@ -482,10 +499,20 @@ __global__ __launch_bounds__(256) void keyframe_commit_kernel(SlamDev d, SlamPar
             d.map[3 * id] = (double)(float)d.kf_x[3 * j]; d.map[3 * id + 1] = (double)(float)d.kf_x[3 * j + 1];
             d.map[3 * id + 2] = (double)(float)d.kf_x[3 * j + 2];
             d.lm[d.kf_pos[j]] = id;
+            // slam2.py:634-641: a new landmark brings its image points along: the frames since the base keyframe are in the log
+            // under the track's id (resolved through tid2lm), the base keyframe's point -- the track was born behind that frame's
+            // own log entries -- is added here
+            const int e = nlog0 + r;
+            if (d.log_lm && e < d.log_cap) {
+                d.log_lm[e] = id; d.log_pose[e] = p.base_pose_index; d.log_uv[2 * e] = d.kf_p0[2 * j]; d.log_uv[2 * e + 1] = d.kf_p0[2 * j + 1];
+            }
+            const int t = d.tid[d.kf_pos[j]];
+            if (d.tid2lm && t >= 0 && t < d.tid_cap) d.tid2lm[t] = id;
         }
         n_good += tot;
     }
     if (nl + n_good > p.max_landmarks) n_good = p.max_landmarks - nl;
+    if (tid == 0 && d.log_lm) d.cnt[C_NLOG] = min(nlog0 + n_good, d.log_cap);
     __threadfence_block();
     __syncthreads();
     // drop the free tracks that did not become landmarks: through the temporaries, back in order
@@ -558,10 +585,14 @@ __global__ __launch_bounds__(256) void start_kernel(SlamDev d, const float *objp
         d.map[3 * k] = (double)objp0[3 * k]; d.map[3 * k + 1] = (double)objp0[3 * k + 1]; d.map[3 * k + 2] = (double)objp0[3 * k + 2];
         d.kf_objp[3 * k] = (double)objp0[3 * k]; d.kf_objp[3 * k + 1] = (double)objp0[3 * k + 1]; d.kf_objp[3 * k + 2] = (double)objp0[3 * k + 2];
         d.kf_imgp[2 * k] = (double)imgp0[2 * k]; d.kf_imgp[2 * k + 1] = (double)imgp0[2 * k + 1];
+        if (d.log_lm && k < d.log_cap) {                          // slam2.py:1167-1169: the first frame's associations
+            d.log_lm[k] = k; d.log_pose[k] = 0; d.log_uv[2 * k] = (double)imgp0[2 * k]; d.log_uv[2 * k + 1] = (double)imgp0[2 * k + 1];
+        }
     }
     if (tid == 0) {
         d.cnt[C_N] = n0; d.cnt[C_NLAND] = n0; d.cnt[C_NEXT_TID] = n0; d.cnt[C_FRAME] = 1; d.cnt[C_NTRI] = 0; d.cnt[C_NKEEP] = 0;
         d.cnt[C_KF_PENDING] = 0;
+        d.cnt[C_NLOG] = d.log_lm ? min(n0, d.log_cap) : 0;
     }
 }
 
@@ -569,6 +600,71 @@ __global__ void start_pose_kernel(SlamDev d)
 {
     const int tid = threadIdx.x;
     if (tid < 12) { const double v = d.pose_r[tid]; d.pose_prev[tid] = v; d.pose_key[tid] = v; d.res[R_POSE + tid] = v; }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Re-association behind a keyframe's top-up: the reference's match_OF_based (slam.py:81-127) -- predicted positions matched to
+// freshly detected keypoints by BFMatcher.radiusMatch on PIXEL coordinates (cv2_helpers.py:296-339), ratio test, one match per
+// keypoint -- with the projections of the landmarks that are in the map but no longer tracked as the predictions and the
+// top-up's new corners as the keypoints.  A matched corner takes its landmark up again instead of starting a new one.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr float kFar = 1.0e9f;                   // coordinates of a row that must match nothing
+
+// queries: row l = the projection of landmark l under the frame's pose, or (far, far) when the landmark is tracked, behind the
+// camera or outside the image; trains: row k = track k's position, or (-far, -far) beyond the live tracks
+__global__ __launch_bounds__(256) void reassoc_rows_kernel(SlamDev d, SlamParams p, float *q_xy, int nq, float *t_xy, uint8_t *tracked)
+{
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    const int n = d.cnt[C_N], nl = d.cnt[C_NLAND];
+    if (g < kMaxTracks) {
+        t_xy[2 * g] = g < n ? d.pts[2 * g] : -kFar;
+        t_xy[2 * g + 1] = g < n ? d.pts[2 * g + 1] : -kFar;
+    }
+    if (g < nq) {
+        float u = kFar, v = kFar;
+        if (g < nl && !tracked[g]) {
+            double pu, pv;
+            const double Z = mqs::cam::project(d.pose_prev, d.intr, d.map[3 * g], d.map[3 * g + 1], d.map[3 * g + 2], pu, pv);
+            if (Z > 0.0 && pu >= 0.0 && pv >= 0.0 && pu <= (double)(p.W - 1) && pv <= (double)(p.H - 1)) { u = (float)pu; v = (float)pv; }
+        }
+        q_xy[2 * g] = u; q_xy[2 * g + 1] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void reassoc_mark_kernel(SlamDev d, uint8_t *tracked)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k < d.cnt[C_N] && d.lm[k] >= 0) tracked[d.lm[k]] = 1;
+}
+
+// a free track whose corner matched a lost landmark's projection becomes that landmark's track (and its observation is logged)
+__global__ __launch_bounds__(256) void reassoc_apply_kernel(SlamDev d, SlamParams p, const int32_t *query_of_train, int32_t *n_out)
+{
+    __shared__ int sWave[4];
+    const int tid = threadIdx.x;
+    const int n = d.cnt[C_N];
+    const int nlog0 = d.log_lm ? d.cnt[C_NLOG] : 0;
+    int done = 0;
+    for (int b = 0; b < n; b += 256) {
+        const int k = b + tid;
+        const bool hit = k < n && d.lm[k] < 0 && query_of_train[k] >= 0;
+        int tot;
+        const int r = done + block_rank(hit, tid, sWave, tot);
+        if (hit) {
+            const int l = query_of_train[k];
+            d.lm[k] = l;
+            const int e = nlog0 + r;
+            if (d.log_lm && e < d.log_cap) {
+                d.log_lm[e] = l; d.log_pose[e] = p.pose_index;
+                d.log_uv[2 * e] = (double)d.pts[2 * k]; d.log_uv[2 * e + 1] = (double)d.pts[2 * k + 1];
+            }
+        }
+        done += tot;
+    }
+    if (tid == 0) {
+        n_out[0] = done;
+        if (d.log_lm) d.cnt[C_NLOG] = min(nlog0 + done, d.log_cap);
+    }
 }
 
 }  // namespace
@@ -583,6 +679,9 @@ struct mqs_slam {
     void *ws_lk, *ws_gftt, *ws_pnp;
     int64_t ws_lk_bytes, ws_gftt_bytes;
     bool started;
+    int accepted, base_pose;         // accepted frames so far (= the next accepted frame's pose index); pose index of the base keyframe
+    char *log_arena;
+    char *re_arena;                  // re-association scratch (allocated on first use)
 };
 
 namespace {
@@ -616,6 +715,7 @@ int mqs_slam_create(int device, int W, int H, const double *intr, int target_key
     if (!s) { mqs_set_error("out of host memory"); return MQS_E_NOMEM; }
     s->device = device;
     s->started = false;
+    s->accepted = 0; s->base_pose = 0; s->log_arena = nullptr; s->re_arena = nullptr;
     s->p = SlamParams{W, H, target_keypoints, max_landmarks, coverage_radius, quality_level,
                       12.0, 0.5, 2.0, 0.33, 1.04, (unsigned long long)seed, 0};     // slam2.py:1070-1098; keyframe test on ALL tracks
     s->ws_lk_bytes = mqs_lk_workspace_bytes(W, H, 3);
@@ -670,9 +770,90 @@ void mqs_slam_destroy(mqs_slam *s)
     (void)hipSetDevice(s->device);
     (void)hipStreamSynchronize(s->stream);
     (void)hipFree(s->arena);
+    if (s->log_arena) (void)hipFree(s->log_arena);
+    if (s->re_arena) (void)hipFree(s->re_arena);
     if (s->res_host) (void)hipHostFree(s->res_host);
     (void)hipStreamDestroy(s->stream);
     delete s;
+}
+
+// The observation log (off by default): capacity in observations; before mqs_slam_start.
+int mqs_slam_log_enable(mqs_slam *s, int64_t capacity)
+{
+    MQS_ARG_CHECK(s != nullptr && capacity >= 64 && capacity < (1ll << 30), "handle; 64 <= capacity < 2^30");
+    MQS_ARG_CHECK(!s->started && s->log_arena == nullptr, "before mqs_slam_start, once");
+    MQS_HIP_CHECK(hipSetDevice(s->device));
+    const size_t bytes = (size_t)capacity * (4 + 4 + 16 + 4);
+    hipError_t e = hipMalloc((void **)&s->log_arena, bytes);
+    if (e != hipSuccess) { s->log_arena = nullptr; mqs_set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); return MQS_E_NOMEM; }
+    s->d.log_uv = reinterpret_cast<double *>(s->log_arena);
+    s->d.log_lm = reinterpret_cast<int32_t *>(s->log_arena + (size_t)capacity * 16);
+    s->d.log_pose = s->d.log_lm + capacity;
+    s->d.tid2lm = s->d.log_pose + capacity;         // track ids never outnumber the observations
+    s->d.log_cap = (int)capacity;
+    s->d.tid_cap = (int)capacity;
+    MQS_HIP_CHECK(hipMemsetAsync(s->d.tid2lm, 0xff, (size_t)capacity * 4, s->stream));
+    MQS_HIP_CHECK(hipStreamSynchronize(s->stream));
+    return MQS_OK;
+}
+
+// the log so far (synchronises the handle's stream): lm / pose [n] int32, uv [n][2] float64 into host arrays of capacity `cap`
+int mqs_slam_read_log(mqs_slam *s, int32_t *lm, int32_t *pose, double *uv, int64_t cap, int64_t *n)
+{
+    MQS_ARG_CHECK(s != nullptr && n != nullptr && cap >= 0, "handle, n");
+    MQS_ARG_CHECK(s->log_arena != nullptr, "mqs_slam_log_enable first");
+    MQS_HIP_CHECK(hipSetDevice(s->device));
+    int32_t cnt[C_COUNT];
+    MQS_HIP_CHECK(hipMemcpyAsync(cnt, s->d.cnt, sizeof(cnt), hipMemcpyDeviceToHost, s->stream));
+    MQS_HIP_CHECK(hipStreamSynchronize(s->stream));
+    *n = cnt[C_NLOG];
+    const int64_t m = cnt[C_NLOG] < cap ? cnt[C_NLOG] : cap;
+    if (m > 0) {
+        if (lm) MQS_HIP_CHECK(hipMemcpyAsync(lm, s->d.log_lm, (size_t)m * 4, hipMemcpyDeviceToHost, s->stream));
+        if (pose) MQS_HIP_CHECK(hipMemcpyAsync(pose, s->d.log_pose, (size_t)m * 4, hipMemcpyDeviceToHost, s->stream));
+        if (uv) MQS_HIP_CHECK(hipMemcpyAsync(uv, s->d.log_uv, (size_t)m * 16, hipMemcpyDeviceToHost, s->stream));
+        MQS_HIP_CHECK(hipStreamSynchronize(s->stream));
+        if (lm) {
+            // free-track entries (-2 - track id): the landmark the track became, or -1 while / if it has not
+            const int nt = cnt[C_NEXT_TID] < s->d.tid_cap ? cnt[C_NEXT_TID] : s->d.tid_cap;
+            int32_t *map = new (std::nothrow) int32_t[nt > 0 ? nt : 1];
+            if (!map) { mqs_set_error("out of host memory"); return MQS_E_NOMEM; }
+            hipError_t e = nt > 0 ? hipMemcpyAsync(map, s->d.tid2lm, (size_t)nt * 4, hipMemcpyDeviceToHost, s->stream) : hipSuccess;
+            if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+            if (e == hipSuccess)
+                for (int64_t k = 0; k < m; ++k)
+                    if (lm[k] <= -2) { const int t = -2 - lm[k]; lm[k] = t < nt ? map[t] : -1; }
+            delete[] map;
+            MQS_HIP_CHECK(e);
+        }
+    }
+    return MQS_OK;
+}
+
+// What a bundle adjustment hands back to the loop: the first n landmarks of the map (float64 host array, stored as float32
+// values like every landmark, slam2.py:19), the pose of the last accepted frame and of the base keyframe ([R | t] 3x4 world ->
+// camera, host; NULL: unchanged).  Waits for the handle's stream first (a keyframe branch may still be writing the map).
+int mqs_slam_write_back(mqs_slam *s, const double *map, int n, const double *pose_prev, const double *pose_key)
+{
+    MQS_ARG_CHECK(s != nullptr && s->started && n >= 0 && (n == 0 || map != nullptr), "handle (started), map");
+    MQS_HIP_CHECK(hipSetDevice(s->device));
+    int32_t cnt[C_COUNT];
+    MQS_HIP_CHECK(hipMemcpyAsync(cnt, s->d.cnt, sizeof(cnt), hipMemcpyDeviceToHost, s->stream));
+    MQS_HIP_CHECK(hipStreamSynchronize(s->stream));
+    MQS_ARG_CHECK(n <= cnt[C_NLAND], "n <= landmarks in the map");
+    if (n > 0) {
+        double *tmp = new (std::nothrow) double[(size_t)n * 3];
+        if (!tmp) { mqs_set_error("out of host memory"); return MQS_E_NOMEM; }
+        for (size_t k = 0; k < (size_t)n * 3; ++k) tmp[k] = (double)(float)map[k];
+        hipError_t e = hipMemcpyAsync(s->d.map, tmp, (size_t)n * 24, hipMemcpyHostToDevice, s->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+        delete[] tmp;
+        MQS_HIP_CHECK(e);
+    }
+    if (pose_prev) MQS_HIP_CHECK(hipMemcpyAsync(s->d.pose_prev, pose_prev, 96, hipMemcpyHostToDevice, s->stream));
+    if (pose_key) MQS_HIP_CHECK(hipMemcpyAsync(s->d.pose_key, pose_key, 96, hipMemcpyHostToDevice, s->stream));
+    MQS_HIP_CHECK(hipStreamSynchronize(s->stream));
+    return MQS_OK;
 }
 
 int mqs_slam_set_thresholds(mqs_slam *s, double max_of_error, double max_lost_tracks_ratio, double max_reproj_error,
@@ -709,6 +890,8 @@ int mqs_slam_start(mqs_slam *s, const uint8_t *img_dev, const float *objp0, cons
     MQS_HIP_CHECK(hipStreamSynchronize(s->stream));
     memcpy(pose_out, s->res_host + R_POSE, 96);
     s->started = true;
+    s->accepted = 1;                  // the first frame is pose 0 and the first base keyframe
+    s->base_pose = 0;
     return MQS_OK;
 }
 
@@ -724,6 +907,8 @@ int mqs_slam_track(mqs_slam *s, const uint8_t *prev_img_dev, const uint8_t *img_
     MQS_ARG_CHECK(s->started, "mqs_slam_start first");
     MQS_HIP_CHECK(hipSetDevice(s->device));
     SlamDev &d = s->d;
+    s->p.pose_index = s->accepted;
+    s->p.base_pose_index = s->base_pose;
     int rc = mqs_lk_launch(prev_img_dev, img_dev, s->p.W, s->p.H, d.pts, kMaxTracks, d.cnt + C_N, 21, 21, 3, 30, 0.01, 1e-4, d.lk_pts,
                            d.lk_st, d.lk_err, s->ws_lk, s->ws_lk_bytes, s->stream);
     if (rc != MQS_OK) return rc;
@@ -738,7 +923,9 @@ int mqs_slam_track(mqs_slam *s, const uint8_t *prev_img_dev, const uint8_t *img_
     MQS_HIP_CHECK(hipMemsetAsync(d.res + R_KF_VALID, 0, 8, s->stream));
     MQS_HIP_CHECK(hipStreamSynchronize(s->stream));
     memcpy(result, s->res_host, kRes * 8);
+    if (result[R_DECISION] >= 1.0) s->accepted += 1;
     if (result[R_DECISION] == 2.0) {
+        s->base_pose = s->p.pose_index;                 // (the kernels below still get the OLD base through s->p.base_pose_index)
         const int n_old = (int)result[R_NOLD], n_new = (int)result[R_NNEW];
         if (n_new > 0) {
             rc = mqs_keyframe_step_launch(d.kf_objp, d.kf_imgp, n_old, d.kf_p0, d.kf_p1, n_new, d.intr, d.pose_prev, d.pose_key, 3.e-5,
@@ -749,6 +936,43 @@ int mqs_slam_track(mqs_slam *s, const uint8_t *prev_img_dev, const uint8_t *img_
         rc = topup(s, img_dev);
         if (rc != MQS_OK) return rc;
     }
+    return MQS_OK;
+}
+
+// Behind a keyframe (its top-up is enqueued on the handle's stream): the new corners matched against the projections of the
+// landmarks that are no longer tracked -- mqs_match_knn2_f32_dev on pixel coordinates, then mqs_match_ratio_unique_dev
+// (radius, ratio test, one landmark per corner; slam.py:101-125) -- and the matched free tracks given their landmark back.
+// *n_matched: how many (synchronises the stream).
+int mqs_slam_reassociate(mqs_slam *s, float max_radius, double max_dist_ratio, int32_t *n_matched)
+{
+    MQS_ARG_CHECK(s != nullptr && s->started && n_matched != nullptr, "handle (started), n_matched");
+    MQS_ARG_CHECK(max_radius > 0.f && max_dist_ratio > 0.0, "max_radius, max_dist_ratio > 0");
+    MQS_HIP_CHECK(hipSetDevice(s->device));
+    const int nq = s->p.max_landmarks, nt = kMaxTracks;
+    auto up = [](size_t v) { return (v + 255) & ~size_t(255); };
+    const size_t o_q = 0, o_t = up((size_t)nq * 8), o_idx = o_t + up((size_t)nt * 8), o_dist = o_idx + up((size_t)nq * 8),
+                 o_qot = o_dist + up((size_t)nq * 8), o_trk = o_qot + up((size_t)nt * 4), o_n = o_trk + up((size_t)nq),
+                 o_ws = o_n + 256, ws_bytes = (size_t)mqs_match_ratio_unique_workspace_bytes(nt), total = o_ws + up(ws_bytes);
+    if (!s->re_arena) {
+        hipError_t e = hipMalloc((void **)&s->re_arena, total);
+        if (e != hipSuccess) { s->re_arena = nullptr; mqs_set_error("hipMalloc(%zu) failed: %s", total, hipGetErrorString(e)); return MQS_E_NOMEM; }
+    }
+    char *a = s->re_arena;
+    float *q_xy = (float *)(a + o_q), *t_xy = (float *)(a + o_t), *dist = (float *)(a + o_dist);
+    int32_t *idx = (int32_t *)(a + o_idx), *qot = (int32_t *)(a + o_qot), *n_dev = (int32_t *)(a + o_n);
+    uint8_t *tracked = (uint8_t *)(a + o_trk);
+    s->p.pose_index = s->accepted - 1;              // the keyframe this call stands behind
+    MQS_HIP_CHECK(hipMemsetAsync(tracked, 0, (size_t)nq, s->stream));
+    hipLaunchKernelGGL(reassoc_mark_kernel, dim3((kMaxTracks + 255) / 256), dim3(256), 0, s->stream, s->d, tracked);
+    hipLaunchKernelGGL(reassoc_rows_kernel, dim3((unsigned)((nq > nt ? nq : nt) + 255) / 256), dim3(256), 0, s->stream, s->d, s->p, q_xy, nq, t_xy, tracked);
+    int rc = mqs_match_knn2_f32_dev(q_xy, nq, t_xy, nt, 2, idx, dist, s->stream);
+    if (rc != MQS_OK) return rc;
+    rc = mqs_match_ratio_unique_dev(idx, dist, nq, nt, max_radius, max_dist_ratio, nullptr, qot, nullptr, a + o_ws, (int64_t)ws_bytes, s->stream);
+    if (rc != MQS_OK) return rc;
+    hipLaunchKernelGGL(reassoc_apply_kernel, dim3(1), dim3(256), 0, s->stream, s->d, s->p, qot, n_dev);
+    MQS_HIP_CHECK(hipGetLastError());
+    MQS_HIP_CHECK(hipMemcpyAsync(n_matched, n_dev, 4, hipMemcpyDeviceToHost, s->stream));
+    MQS_HIP_CHECK(hipStreamSynchronize(s->stream));
     return MQS_OK;
 }
 

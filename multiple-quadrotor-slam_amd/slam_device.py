@@ -26,17 +26,49 @@ from .camera import _intr
 from .slam_loop import (CORNER_QUALITY_LEVEL, HOMOGRAPHY_CONDITION_THRESHOLD, KEYPOINT_COVERAGE_RADIUS, MAX_AMOUNT_KEYPOINTS,
                         MAX_LOST_TRACKS_RATIO, MAX_OF_ERROR, MAX_SOLVEPNP_OUTLIER_RATIO, MAX_SOLVEPNP_REPROJ_ERROR)
 
+REASSOCIATE_RADIUS = 3.0         # pixels: a re-detected corner within this distance of a lost landmark's projection (slam.py's max_radius_OF_to_FAST role)
+REASSOCIATE_RATIO = 0.8          # slam.py:94 max_dist_ratio
+
 REASONS = {0: "", 1: "lost track of too many points", 2: "fewer than 8 triangulated tracks", 3: "no RANSAC model",
            4: "PnP outlier ratio", 5: "reprojection error"}
 
 
+def _reprojection_residuals(poses_c2w, points, calib, lm, pose_idx, uv):
+    """|projection - measurement| in pixels per observation; poses camera-to-world pose12, calib = fx fy s u0 v0 k1 k2 p1 p2
+    (the Cal3DS2 model of csrc/ba_math.h), vectorised numpy: the screen of the in-loop adjustment, not a product kernel."""
+    R = poses_c2w[pose_idx, :9].reshape(-1, 3, 3)
+    d = points[lm] - poses_c2w[pose_idx, 9:]
+    X = np.einsum("nji,nj->ni", R, d)                                  # R^T (p - c)
+    z = np.where(X[:, 2] > 1e-9, X[:, 2], 1e-9)
+    x, y = X[:, 0] / z, X[:, 1] / z
+    fx, fy, sk, u0, v0, k1, k2, p1, p2 = calib
+    r2 = x * x + y * y
+    g = 1.0 + k1 * r2 + k2 * r2 * r2
+    xd = g * x + 2.0 * p1 * x * y + p2 * (r2 + 2.0 * x * x)
+    yd = g * y + 2.0 * p2 * x * y + p1 * (r2 + 2.0 * y * y)
+    return np.hypot(fx * xd + sk * yd + u0 - uv[:, 0], fy * yd + v0 - uv[:, 1])
+
+
 class DeviceMonoSlam:
     def __init__(self, cameraMatrix, distCoeffs, image_shape, seed=0, device=0, max_landmarks=1 << 16, verbose=False,
-                 ba_info=None, max_homography_points=0):
+                 ba_info=None, max_homography_points=0, bundle_adjust=None, ba_iterations=10, ba_log_capacity=1 << 20,
+                 reassociate=False):
         """max_homography_points: size of keyframe_test's random sample of the tracks (slam2.py:48): 0 = every track (default),
         "reference" = the reference's max(4, target_amount_keypoints / 4) (:1088-1089).  On the rendered test sequence the quarter
         makes the run depend on the draw -- trajectory RMSE 0.017-0.020 for half of the seeds, 0.057-0.068 for the other half,
         against 0.020 for every seed with all tracks (profiles/r03/12_keyframe_sample_study.json) -- hence the default.
+        bundle_adjust="keyframe": BASELINE configs[4] as written -- detect -> track -> triangulate -> BUNDLE-ADJUST per keyframe,
+        inside the loop: the frame kernels log every observation the reference's recorder is handed (slam2.py:519-522, 634-641,
+        1167-1169) in device memory; behind every keyframe the log becomes a `ba_io.SparseProblem` (all accepted frames so far, all
+        landmarks; gauge as the reference's tool fixes it, bundle_adjust.cpp:268-282: a pose prior on the first frame, point priors
+        on the first frame's landmarks), `sparse_ba.SparseBundleAdjuster` runs Levenberg-Marquardt on it (<= ba_iterations), and
+        the adjusted landmarks and poses go back into the loop's live state (`mqs_slam_write_back`), so the next frames are
+        tracked against the adjusted map.  `poses` then holds the ADJUSTED pose of every accepted frame up to the last
+        keyframe; `poses_online` keeps each frame's pose as it was first estimated.
+        reassociate=True: behind every keyframe's top-up the new corners are matched (BFMatcher.radiusMatch on pixel positions +
+        ratio test + one match per corner: the reference's match_OF_based, slam.py:81-127, cv2_helpers.py:296-339) against the
+        PROJECTIONS of the landmarks that are in the map but not tracked any more; a matched corner takes its landmark up again
+        instead of starting a new one (`mqs_slam_reassociate`).
         ba_info: an optional `ba_io.BundleAdjustmentInfoContainer`; the loop then records what the reference records for
         the bundle adjuster (slam2.py:519-522, 634-641, 681-687, 1167-1169, 1204).  Recording reads the live tracks back
         after every frame (one more synchronisation per frame): the recorder's lists live on the host."""
@@ -49,6 +81,7 @@ class DeviceMonoSlam:
         self.verbose = verbose
         self._intr = np.ascontiguousarray(_intr(self.K, self.dist), dtype=np.float64)
         self._h = ctypes.c_void_p()
+        self._device = int(device)
         L = _lib.lib()
         _lib.check(L.mqs_slam_create(int(device), W, H, self._intr.ctypes.data_as(_lib.c_f64p), self.target_keypoints,
                                      float(KEYPOINT_COVERAGE_RADIUS), float(CORNER_QUALITY_LEVEL), int(max_landmarks),
@@ -69,6 +102,22 @@ class DeviceMonoSlam:
         self._prev = None
         self._max_landmarks = int(max_landmarks)
         self.ba_info = ba_info
+        if bundle_adjust not in (None, "keyframe"):
+            raise ValueError("bundle_adjust: None or 'keyframe'")
+        self.bundle_adjust = bundle_adjust
+        self.ba_iterations = int(ba_iterations)
+        self.ba_min_observations = 3
+        self.ba_outlier_pixels = 4.0     # a landmark with a residual beyond this after an adjustment is a mistracked corner
+        self._ba_bad = np.zeros(0, bool)
+        self.reassociate = bool(reassociate)
+        self.poses_online = []           # with bundle_adjust: the pose of each frame as first estimated (poses: adjusted)
+        self._accepted = []              # frame index of every accepted frame, in order (= the log's pose indices)
+        self.ba_reports = []
+        self._odo = []                   # (from pose index, to pose index, measured relative pose12): one edge per keyframe
+        self.reassociated = 0
+        if bundle_adjust:
+            _lib.check(L.mqs_slam_log_enable(self._h, int(ba_log_capacity)))
+            self._log_cap = int(ba_log_capacity)
         self.history = []                # since the base keyframe: (frame, track ids, image points)
         self._key_pose = None
         if ba_info is not None:
@@ -105,6 +154,11 @@ class DeviceMonoSlam:
         _lib.check(_lib.lib().mqs_slam_start(self._h, self._img_ptr(img, self.shape), o.ctypes.data_as(_lib.c_f32p),
                                              m.ctypes.data_as(_lib.c_f32p), len(o), pose.ctypes.data_as(_lib.c_f64p)))
         self.poses.append(pose.reshape(3, 4).copy())
+        self.poses_online.append(pose.reshape(3, 4).copy())
+        self._accepted.append(0)
+        self._n0 = len(o)
+        self._objp0 = o.astype(np.float64)               # where the gauge is anchored: the KNOWN start-up points and the first pose,
+        self._pose0 = pose.reshape(3, 4).copy()          # never their adjusted values (an anchor that follows the estimate drifts)
         self.keyframes.append(0)
         self._prev = img
         if self.ba_info is not None:                         # slam2.py:1167-1169, 1184-1185
@@ -145,11 +199,18 @@ class DeviceMonoSlam:
             if self.verbose:
                 print("REJECTED:", REASONS.get(int(r[1]), "?"))
             self.poses.append(None)
+            self.poses_online.append(None)
         else:
             self.poses.append(r[12:24].reshape(3, 4).copy())
+            self.poses_online.append(self.poses[-1].copy())
+            self._accepted.append(len(self.poses) - 1)
             if decision == 2:
                 self._pending_keyframe = len(self.poses) - 1
                 self.keyframes.append(len(self.poses) - 1)
+                if self.reassociate:
+                    self._reassociate(img)
+                if self.bundle_adjust:
+                    self._bundle_adjust()
             self._prev = img             # slam2.py keeps the previous image of a rejected frame
         self.reports.append(r[:12].copy())
         self.timing.append(time.perf_counter() - t0)
@@ -185,10 +246,111 @@ class DeviceMonoSlam:
         self.history = [(frame_idx, tid.copy(), pts.copy())]
         self._key_pose = self.poses[frame_idx]
 
+    # ---- bundle adjustment inside the loop ---------------------------------------------
+    def read_log(self):
+        """The observation log so far: (landmark (n,), pose index (n,), pixel (n, 2))."""
+        n = _lib.c_i64(0)
+        L = _lib.lib()
+        _lib.check(L.mqs_slam_read_log(self._h, None, None, None, 0, ctypes.byref(n)))
+        m = int(n.value)
+        lm, ps, uv = np.zeros(m, np.int32), np.zeros(m, np.int32), np.zeros((m, 2), np.float64)
+        if m:
+            _lib.check(L.mqs_slam_read_log(self._h, lm.ctypes.data_as(_lib.c_i32p), ps.ctypes.data_as(_lib.c_i32p),
+                                           uv.ctypes.data_as(_lib.c_f64p), m, ctypes.byref(n)))
+        return lm, ps, uv
+
+    def _bundle_adjust(self):
+        """Behind a keyframe: the whole history so far through the sparse bundle adjuster, the result back into the live state."""
+        from . import ba_io, sparse_ba
+        from .bundle_adjustment import pose_from_world_to_camera
+        t0 = time.perf_counter()
+        rep = np.zeros(40)
+        _lib.check(_lib.lib().mqs_slam_flush(self._h, rep.ctypes.data_as(_lib.c_f64p)))          # the keyframe branch has run
+        if rep[24] != 0.0 and self._pending_keyframe is not None:
+            self.poses[self._pending_keyframe] = rep[28:40].reshape(3, 4).copy()
+            self.poses_online[self._pending_keyframe] = self.poses[self._pending_keyframe].copy()
+            self._pending_keyframe = None
+        # the odometry edge of this keyframe (slam2.py:681-687: base keyframe -> keyframe, from the poses as estimated now)
+        kf = self._accepted[-1]
+        if self.keyframes and self.keyframes[-1] == kf and len(self.keyframes) >= 2 and (not self._odo or self._odo[-1][1] != len(self._accepted) - 1):
+            base = self.keyframes[-2]
+            P1, P0 = np.vstack([self.poses[kf], [0, 0, 0, 1.0]]), np.vstack([self.poses[base], [0, 0, 0, 1.0]])
+            self._odo.append((self._accepted.index(base), len(self._accepted) - 1, pose_from_world_to_camera((P1 @ np.linalg.inv(P0))[:3])))
+        lm, ps, uv = self.read_log()
+        known = lm >= 0                                               # (free tracks that have not become landmarks)
+        lm, ps, uv = lm[known], ps[known], uv[known]
+        pts = self.objp.astype(np.float64)
+        N, P = len(pts), len(self._accepted)
+        if len(self._ba_bad) < N:
+            self._ba_bad = np.concatenate([self._ba_bad, np.zeros(N - len(self._ba_bad), bool)])
+        poses = np.stack([pose_from_world_to_camera(self.poses[f]) for f in self._accepted])
+        poses[0] = pose_from_world_to_camera(self._pose0)             # the pose prior sits at the initial value of pose 0 (bundle_adjust.cpp:273)
+        prior_xyz = pts.copy()
+        prior_xyz[:self._n0] = self._objp0
+        calib = np.array([[self.K[0, 0], self.K[1, 1], self.K[0, 1], self.K[0, 2], self.K[1, 2], self.dist[0], self.dist[1],
+                           self.dist[2], self.dist[3]]])
+        prior_w = np.where(np.arange(N) < self._n0, 1.0 / 0.25 ** 2, 0.0)                        # noise.point3D of the reference's runs
+        per_lm = np.bincount(lm, minlength=N)
+        t1 = time.perf_counter()
+        passes, dropped, hist_all = 0, 0, None
+        while True:
+            # a landmark joins the adjustment once it has been seen from a THIRD frame (fresh from its triangulation it constrains
+            # nothing but the relative pose of its two keyframes), and sits out for good once an adjustment has shown it to be a
+            # mistracked corner: GTSAM's factors are plain least squares (bundle_adjust.cpp:289-298: no robust kernel), the
+            # reference runs them once over a finished recording -- inside the loop one bad track that passed the depth checks
+            # drags the two keyframes it was triangulated from by centimetres before anything else has seen it
+            use = ((per_lm >= self.ba_min_observations) | (np.arange(N) < self._n0)) & ~self._ba_bad[:N]
+            keep = use[lm]
+            l2, p2, u2 = lm[keep], ps[keep], uv[keep]
+            order = np.argsort(l2, kind="stable")
+            ptr = np.concatenate([[0], np.cumsum(np.bincount(l2, minlength=N))]).astype(np.int64)
+            problem = ba_io.SparseProblem(
+                poses=poses, pose_cam=np.zeros(P, np.int32), pose_key=[(0, f) for f in self._accepted], calib=calib, sigma=np.array([1.0]),
+                points=pts.copy(), obs_ptr=ptr, obs_pose=p2[order].astype(np.int32), obs_uv=u2[order], prior_w=prior_w, prior_xyz=prior_xyz,
+                pose_prior_idx=np.array([0], np.int32), pose_prior_sigmas=np.array([[0.002] * 3 + [0.001] * 3]),
+                odo_from=np.array([o[0] for o in self._odo], np.int32), odo_to=np.array([o[1] for o in self._odo], np.int32),
+                odo_meas=np.array([o[2] for o in self._odo]).reshape(-1, 12), odo_sigmas=np.tile([0.05, 0.05, 0.05, 0.2, 0.2, 0.2], (len(self._odo), 1)))
+            ba = sparse_ba.SparseBundleAdjuster(problem, device="cuda:%d" % self._device)
+            hist = ba.optimize(iters=self.ba_iterations, mode="lm")
+            hist_all = hist if hist_all is None else hist_all[:1] + hist[1:]
+            new_poses, new_pts = ba.poses.cpu().numpy(), ba.points.cpu().numpy()
+            passes += 1
+            # the screen: pixel residuals of the adjusted estimate; a landmark with one beyond the bound sits out from now on
+            res = _reprojection_residuals(new_poses, new_pts, calib[0], l2, p2, u2)
+            worst = np.zeros(N)
+            np.maximum.at(worst, l2, res)
+            bad = (worst > self.ba_outlier_pixels) & (np.arange(N) >= self._n0)
+            if passes >= 2 or not bad.any():
+                break
+            self._ba_bad[:N] |= bad
+            dropped += int(bad.sum())
+        new_pts[~use] = pts[~use]                                    # landmarks that sat out keep their values
+        t2 = time.perf_counter()
+        for k, f in enumerate(self._accepted):                       # camera-to-world pose12 -> [R | t] world -> camera
+            R, c = new_poses[k, :9].reshape(3, 3), new_poses[k, 9:]
+            self.poses[f] = np.hstack([R.T, (-R.T @ c)[:, None]])
+        last = np.ascontiguousarray(self.poses[self._accepted[-1]], dtype=np.float64)
+        _lib.check(_lib.lib().mqs_slam_write_back(self._h, np.ascontiguousarray(new_pts).ctypes.data_as(_lib.c_f64p), N,
+                                                  last.ctypes.data_as(_lib.c_f64p), last.ctypes.data_as(_lib.c_f64p)))
+        self.ba_reports.append({"frame": self._accepted[-1], "poses": P, "landmarks": N, "landmarks_adjusted": int(use.sum()),
+                                "observations": int(keep.sum()), "passes": passes, "landmarks_screened_out": dropped,
+                                "lm_iterations": len(hist_all) - 1, "cost_before": hist_all[0], "cost_after": hist_all[-1],
+                                "build_ms": round(1e3 * (t1 - t0), 3), "adjust_ms": round(1e3 * (t2 - t1), 3),
+                                "write_back_ms": round(1e3 * (time.perf_counter() - t2), 3)})
+
+    def _reassociate(self, img):
+        n = ctypes.c_int32(0)
+        _lib.check(_lib.lib().mqs_slam_reassociate(self._h, ctypes.c_float(REASSOCIATE_RADIUS), ctypes.c_double(REASSOCIATE_RATIO),
+                                                   ctypes.byref(n)))
+        self.reassociated += int(n.value)
+
     def finish(self):
-        """Waits for the last keyframe branch and takes its report."""
+        """Waits for the last keyframe branch and takes its report; with bundle_adjust, one last adjustment over everything
+        (the frames behind the last keyframe included)."""
         _lib.check(_lib.lib().mqs_slam_flush(self._h, self._pres))
         self._take_keyframe_report()
+        if self.bundle_adjust and self.keyframes and self._accepted and self._accepted[-1] != self.keyframes[-1]:
+            self._bundle_adjust()
 
     # ---- state read-back (tests, recorders) --------------------------------------------
     def tracks(self):

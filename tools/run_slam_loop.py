@@ -38,7 +38,7 @@ def run(frames=60, verbose=False, ba_info=None, out_files=None):
             "frames_per_s": round((frames - 1) / sum(slam.timing), 1)}
 
 
-def run_device(frames=60, verbose=False, repeats=1, ba_info=None, out_files=None):
+def run_device(frames=60, verbose=False, repeats=1, ba_info=None, out_files=None, bundle_adjust=None, reassociate=False):
     """The same sequence through slam_device.DeviceMonoSlam: the loop's state resident on the GPU, one library call per frame
     (images uploaded beforehand, as a capture thread would have them).  `repeats` > 1: the run is repeated on a fresh handle and
     the fastest pass is timed (the first pass pays the first-launch costs of every kernel)."""
@@ -53,7 +53,8 @@ def run_device(frames=60, verbose=False, repeats=1, ba_info=None, out_files=None
     torch.cuda.synchronize()
     best = None
     for _ in range(max(1, repeats)):
-        slam = mqslam_amd.slam_device.DeviceMonoSlam(seq.K, seq.dist, (seq.H, seq.W), seed=1, verbose=verbose, ba_info=ba_info)
+        slam = mqslam_amd.slam_device.DeviceMonoSlam(seq.K, seq.dist, (seq.H, seq.W), seed=1, verbose=verbose, ba_info=ba_info,
+                                                     bundle_adjust=bundle_adjust, reassociate=reassociate)
         slam.start(imgs[0], objp, imgp)
         t0 = time.perf_counter()
         rets = [2]
@@ -82,6 +83,20 @@ def run_device(frames=60, verbose=False, repeats=1, ba_info=None, out_files=None
            "map_plane_p90_abs_z": float(np.percentile(np.abs(new[:, 2]), 90)) if len(new) else None,
            "frames_per_s": round((frames - 1) / dt, 1), "ms_per_frame_median": round(1e3 * float(np.median(slam.timing)), 4),
            "tracks_at_the_end": int(len(slam.tracks()[0]))}
+    if bundle_adjust:
+        on = np.full((len(slam.poses_online), 3), np.nan)
+        for i, P in enumerate(slam.poses_online):
+            if P is not None:
+                on[i] = -P[:, :3].T @ P[:, 3]
+        e_on = np.linalg.norm(on[ok] - gt[ok], axis=1)
+        r = slam.ba_reports
+        out["bundle_adjust_per_keyframe"] = {
+            "adjustments": len(r), "trajectory_rmse_online": float(np.sqrt(np.mean(e_on ** 2))),
+            "trajectory_rmse_adjusted": out["trajectory_rmse"],
+            "last": r[-1] if r else None,
+            "ms_per_adjustment_median": {k: round(float(np.median([x[k] for x in r])), 3) for k in ("build_ms", "adjust_ms", "write_back_ms")} if r else None}
+    if reassociate:
+        out["corners_reassociated_with_lost_landmarks"] = int(slam.reassociated)
     slam.close()
     return out
 
@@ -117,6 +132,7 @@ def run_with_ba(frames=60, work_dir=None):
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 60
     if "--device" in sys.argv:
-        print(json.dumps(run_device(n, verbose="-v" in sys.argv, repeats=3)))
+        print(json.dumps(run_device(n, verbose="-v" in sys.argv, repeats=3, bundle_adjust="keyframe" if "--ba" in sys.argv else None,
+                                    reassociate="--reassociate" in sys.argv)))
     else:
         print(json.dumps(run_with_ba(n) if "--ba" in sys.argv else run(n, verbose="-v" in sys.argv)))
