@@ -417,6 +417,19 @@ def main():
     ba_out = None
     if ba is not None:
         ba_out = ba.benchmark_report(world, dist)
+        if rank == 0 and world == 1:
+            # "initial poses = truth o Exp(N(0, diag(0.02 rad, 0.1))), 10 GN iterations, no damping" -- a FRESH problem,
+            # timed from that perturbed start (the `ba` above has long converged under the timed steps)
+            fresh = mqslam_amd.bundle_adjustment.make_benchmark_problem(u, P, x_it, dev, seed=syn.RSEED)
+            cf0 = fresh.total_cost()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fresh.gauss_newton_iterations(10)
+            torch.cuda.synchronize()
+            dtf = time.perf_counter() - t0
+            ba_out["from_perturbed_start"] = {"iterations": 10, "ms_per_iter": round(1e2 * dtf, 4), "gn_iters_per_s": round(10 / dtf, 1),
+                                              "cost_before": cf0, "cost_after": fresh.total_cost()}
+            del fresh
         if rank == 0 and world == 1 and N >= 8 and not args.no_shard_proxy:
             # what ONE rank of the 8-way sharded configs[3] run holds, on this GPU alone: the serial floor of strong scaling
             ns = N // 8
@@ -522,6 +535,34 @@ def main():
                                            "note": "fp64 VALU issue binds before HBM (DESIGN.md)"}
         rooflines["ba_backsub"] = {"bound": "hbm", "achieved": round(back_gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                    "frac": round(back_gbps / HBM_PEAK_GBPS, 4)}
+    # the launches the timed step actually runs besides the lineariser: the fused linear-LS + iterative-LS pass (second stream) and
+    # the tail of the Gauss-Newton iteration (finalize pieces + 24 x 24 solve + retraction + back-substitution in one launch)
+    def timed_ms(fn, reps=20):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / reps
+    ms_fused = timed_ms(triangulate)
+    bytes_fused = N * (16 * C + 24 + 24 + 4)
+    rooflines["tri_ls_and_iterative_fused"] = {"bound": "hbm", "kernel": "tri_kernel<%d, 3> (the step's triangulation launch)" % C,
+                                               "achieved": round(bytes_fused / (ms_fused * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                               "frac": round(bytes_fused / (ms_fused * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                                               "algorithmic_bytes_per_launch": bytes_fused, "avg_launch_ms": round(ms_fused, 5),
+                                               "note": "fp64 VALU issue binds before HBM (DESIGN.md)"}
+    if ba_out is not None and "solve_retract_backsub_one_launch" in ba_out["kernels_ms"]:
+        ms_tail = ba_out["kernels_ms"]["solve_retract_backsub_one_launch"]
+        bytes_tail = N * (24 + 16 * C + 24) + (8 * N if ba.prior_w is not None else 0)
+        rooflines["ba_tail"] = {"bound": "hbm", "kernel": "ba_tail_kernel<%d> (the step's second BA launch: solve + retraction + back-substitution)" % C,
+                                "achieved": round(bytes_tail / (ms_tail * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                "frac": round(bytes_tail / (ms_tail * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                                "algorithmic_bytes_per_launch": bytes_tail, "avg_launch_ms": round(ms_tail, 5),
+                                "note": "13.6 M vector instructions per launch at 1e6 x 4: the SIMDs' vector units are 74 % busy (profiles/r04/02); "
+                                        "two restructurings measured slower (profiles/r04/05)"}
     rooflines["iterative_ls_standalone"] = roofline_it
     roofline = roofline_it
     if ba_out is not None and C == 4:
@@ -544,6 +585,13 @@ def main():
                         "valu_instructions_per_landmark": kf.get("valu_instructions_per_landmark"),
                         "valu_issue_slots_per_landmark": kf.get("valu_issue_slots_per_landmark"), "hbm": hbm,
                         "share_of_step": round(ms_lin / ms_per_step, 3),
+                        "fp64_fma_rate_with_register_operands": {
+                            "TFLOPs": 61.0, "frac_of_it": round(tf / 61.0, 4),
+                            "source": "profiles/r04/04_valu_streams_under_pmc.json: a v_fma_f64 with three VGPR-pair sources issues every "
+                                      "5.1-5.4 cycles (2.21-2.33 ns), not 4 -- what an all-FMA stream of register operands reaches on this part"},
+                        "sq_wait_any_reading": "SQ_WAIT_ANY is 0.25 of this kernel's wave cycles (profiles/r03/09); straight-line fp64 streams "
+                                               "WITHOUT any s_waitcnt read 0.11-0.31 by themselves (profiles/r04/04): the counter includes "
+                                               "issue-side waiting, there is no hidden quarter of memory waits",
                         "note": "largest kernel of the timed step (hipEvents on the launch stream, stand-alone launches); bound by "
                                 "fp64 vector issue, not HBM: `frac` = counted fp64 flop / time against the 78.6 TFLOP/s vector peak; "
                                 "`hbm` is the same launch against the 8 TB/s roof SURVEY 8(d) assigns it"}

@@ -383,6 +383,9 @@ class BundleAdjuster:
             "launches_per_iteration": _launches_per_iteration(C),
             "algorithmic_GBps_per_gpu": round(bytes_iter / (1e-3 * (ms_lin + ms_back)) / 1e9, 1),
             "cost_before": c0, "cost_after_%d_more_iterations" % reps: c1,
+            "timed_at": "the optimum: the problem has been iterated by the timed steps before this report (cost_before == cost_after); the "
+                        "kernels' work does not depend on the values (no data-dependent branch on the hot path), and "
+                        "`from_perturbed_start` below is the same count of iterations timed from SURVEY 8(d)'s perturbed start",
         }
 
 

@@ -101,6 +101,19 @@ struct StagedObs {
     }
 };
 
+// the same with one wave's 64 measurements per camera side by side (ba_iterate_kernel: camera c at s[c * 64])
+struct StagedObs64 {
+    const double2 *s;
+    unsigned mbits;
+    bool live, masked;
+    __device__ __forceinline__ void get(int c, double &u, double &v, bool &seen) const
+    {
+        const double2 t = s[c * 64];
+        seen = live && (!masked || ((mbits >> (8 * c)) & 0xffu) != 0u);
+        u = seen ? t.x : 0.0; v = seen ? t.y : 0.0;           // a masked slot may hold NaN
+    }
+};
+
 // the same for the second form of the tail (kTail2Block-thread workgroups: camera c at s[c * kTail2Block]).  The ring is read with ds_read
 // instructions the compiler cannot see through: it knows the ring is written by LDS-DMA and, unable to tell the two halves of the
 // ring apart, would put an s_waitcnt vmcnt(0) in front of every read -- draining the NEXT batch's loads, which are in flight into
@@ -2032,6 +2045,258 @@ __global__ __launch_bounds__(kTail2Block) void ba_tail2_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Back-to-back Gauss-Newton iterations (round 4): the TAIL of iteration k and the LINEARISER of iteration k + 1 in ONE launch.
+//
+// An iteration by itself is two launches -- lineariser, tail -- and on a shard the size one rank of BASELINE configs[3] holds
+// (125 k landmarks) their boundaries and prologues are a fifth of it: 15.7 + 10.3 us of kernels, 31.9 us per iteration.  Inside a
+// run of iterations (mqs_ba_gn_iterations_dev) nothing needs the host between the back-substitution of one iteration and the
+// linearisation of the next, and both walk the same landmarks: here every wave
+//   1. takes part in the tail's head exactly as ba_tail_kernel does (finalizer pieces of the previous launch's partial rows in
+//      the first workgroups, flags, the pieces folded in order, the 6C x 6C solve in wave 0 of every workgroup; over the peer
+//      transport the pieces also go to every rank and the wait is for all ranks' flags),
+//   2. back-substitutes ITS rows of 64 landmarks (the lineariser's partition: the wave that linearises a row next is the wave
+//      that has just written it) into the other landmark buffer,
+//   3. retracts the poses itself (wave 0; the last workgroup also publishes dpose, poses, info), stages the new camera blocks,
+//   4. linearises its rows at the new estimate (wl_chunk, LDS form) and leaves the workgroup's partial row for the next launch.
+// A run of K iterations is lineariser, K - 1 of these, tail: K + 1 launches instead of 2 K.  Same arithmetic, same summation
+// orders as the two-launch iteration: bit-identical estimates (tests/test_ba_gpu.py).  One workgroup per CU (the lineariser's
+// geometry and LDS); shards below kWlScalarMinLandmarks landmarks (beyond, the lineariser's scalar-load form and the
+// four-waves-per-SIMD tail are the faster pair, and the launch boundary is 2 % of an iteration).
+// ---------------------------------------------------------------------------------------------------------------------
+#if defined(MQS_ITERATE_PROBE)          // timing probe builds only (tools/probes/iterate_phases.py): 100 MHz wall-clock stamps per workgroup and phase
+__device__ long long g_it_probe[8][256];
+#define MQS_IT_STAMP(k) { if (threadIdx.x == 0) g_it_probe[k][blockIdx.x & 255] = wall_clock64(); }
+extern "C" int mqs_debug_iterate_probe(long long *out)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_it_probe), sizeof(g_it_probe)) == hipSuccess ? 0 : -1;
+}
+#else
+#define MQS_IT_STAMP(k) {}
+#endif
+template <int C>
+__global__ __launch_bounds__(kBlock, 1) void ba_iterate_kernel(
+    mqs_peer_recv pr, TailFin fin, const double *__restrict__ poses, const double *__restrict__ calib, const double *__restrict__ sigma,
+    const double *__restrict__ points, const double *__restrict__ obs, const uint8_t *__restrict__ mask,
+    const double *__restrict__ prior_w, const double *__restrict__ prior_xyz, int64_t N, double lambda,
+    const double *__restrict__ prior_poses, const double *__restrict__ prior_sigmas, const uint8_t *__restrict__ prior_mask,
+    double *__restrict__ lin_out, double *__restrict__ dpose, double *__restrict__ poses_out, double *__restrict__ info,
+    double *__restrict__ points_out, double *__restrict__ partials_out)
+{
+    using L = Layout<C>;
+    constexpr int n = 6 * C, nlin = n * n + n + 2;
+    constexpr int kRow = L::kChunks * 32, kSlotGroups = (kRow + 63) / 64, kFinalizers = kFinPieces * kSlotGroups;
+    __shared__ double sCam[C * kCamStride];
+    __shared__ double sPoseNew[C * 12];
+    __shared__ int sTimedOut;
+    extern __shared__ __attribute__((aligned(16))) unsigned char wl_smem[];
+    // the solve's LDS and the finalizers' piece sums lie over the lineariser's stash: dead before the first chunk is linearised
+    SolveLds<C> &sm = *reinterpret_cast<SolveLds<C> *>(wl_smem);
+    static_assert(sizeof(SolveLds<C>) + 4 * 64 * sizeof(double) <= sizeof(double2) * kWaveLinLdsL * C * 3 * kBlock, "the solve fits the stash");
+    double (*sQ)[64] = reinterpret_cast<double (*)[64]>(wl_smem + ((sizeof(SolveLds<C>) + 255) & ~size_t(255)));
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (tid == 0) sTimedOut = 0;
+    __syncthreads();
+    MQS_IT_STAMP(0)
+
+    // ---- 1. the tail's head (ba_tail_kernel) ----
+    if ((int)blockIdx.x < kFinalizers) {
+        const int sg = blockIdx.x % kSlotGroups, q = blockIdx.x / kSlotGroups;
+        const int slot = 64 * sg + lane;
+        sQ[wave][lane] = (slot < kRow) ? piece_part_sum(fin.partials, fin.nrows, kRow, q, wave, slot) : 0.0;
+        __syncthreads();
+        if (wave == 0 && slot < L::kSlots) {
+            const double qs = ((sQ[0][lane] + sQ[1][lane]) + sQ[2][lane]) + sQ[3][lane];
+            int o1, o2;
+            slot_to_out<C>(slot, o1, o2);
+            if (o1 >= 0) __hip_atomic_store(fin.quarters + q * kQuarterStride + o1, qs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (o2 >= 0) __hip_atomic_store(fin.quarters + q * kQuarterStride + o2, qs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (o1 >= 0) mqs::peer::push_entry(fin.push, q * kQuarterStride + o1, qs);
+            if (o2 >= 0) mqs::peer::push_entry(fin.push, q * kQuarterStride + o2, qs);
+        }
+        mqs_stores_landed();
+        __syncthreads();                          // the piece's entries have landed, here and in the peers
+        if ((int)blockIdx.x != fin.withhold) {
+            if (tid == 0) __hip_atomic_store(fin.flags + blockIdx.x, fin.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            mqs::peer::publish_piece(fin.push, blockIdx.x, tid);
+        }
+    }
+    MQS_IT_STAMP(1)
+    stage_cams<C>(poses, calib, sigma, sCam, tid);                  // ends in a workgroup barrier
+    if (tid < 64) pose_prior_terms<C>(poses, prior_poses, prior_sigmas, prior_mask, tid, sm.e, sm.w, sm.info);
+    __syncthreads();
+    if (fin.push.world > 0) {
+        mqs::peer::wait_flags(pr, tid, kBlock, &sTimedOut);
+    } else {
+        if (tid < kFinalizers) {
+            const long long t0 = wall_clock64();
+            while (__hip_atomic_load(fin.flags + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != fin.epoch) {
+                if (wall_clock64() - t0 > mqs::peer::kSpinTicks) {
+                    sTimedOut = 1;
+                    if (fin.status) __hip_atomic_store(fin.status, MQS_STATUS_FINALIZE_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        __syncthreads();
+    }
+    MQS_IT_STAMP(2)
+    const bool publisher = blockIdx.x == gridDim.x - 1;
+    if (sTimedOut) {                                              // nothing waited for is read, nothing is published
+        if (publisher && tid == 0 && info) info[1] = 2.0;
+        return;
+    }
+    {
+        double v[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+        for (int q3 = 0; q3 < 3; ++q3) {
+            const int k = tid + kBlock * q3;
+            if (k < nlin) {
+                if (fin.push.world > 0) {
+                    double t = 0.0;
+                    for (int rk = 0; rk < pr.world; ++rk) {            // rank order; a rank's pieces folded in the finalize's order
+                        const double *row = pr.rows + (size_t)rk * pr.row_stride + k;
+                        double pv[kFinPieces];
+#pragma unroll
+                        for (int q = 0; q < kFinPieces; ++q) pv[q] = __hip_atomic_load(row + q * kQuarterStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        double r = pv[0];
+#pragma unroll
+                        for (int q = 1; q < kFinPieces; ++q) r += pv[q];
+                        t += r;
+                    }
+                    v[q3] = t;
+                } else {
+                    double pv[kFinPieces];
+#pragma unroll
+                    for (int q = 0; q < kFinPieces; ++q) pv[q] = __hip_atomic_load(fin.quarters + q * kQuarterStride + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    double r = pv[0];
+#pragma unroll
+                    for (int q = 1; q < kFinPieces; ++q) r += pv[q];
+                    v[q3] = r;
+                }
+                if (publisher && lin_out) lin_out[k] = v[q3];
+            }
+        }
+        build_solve_matrix_from_registers<C>(sm, v, lambda, tid);
+    }
+    __syncthreads();
+    bool bad = false;
+    if (tid < 64) reduced_solve_wave<C>(sm.m, sm.col, sm.y, sm.x, tid, bad);
+    __syncthreads();
+    MQS_IT_STAMP(3)
+    // the retraction (wave 0, one lane per camera): into LDS for this workgroup's next linearisation; the last workgroup publishes
+    if (tid < C) retract_pose_dev(poses + 12 * tid, sm.x + 6 * tid, sPoseNew + 12 * tid);
+    if (publisher && tid < 64) publish_solution<C>(sm, poses, bad, tid, dpose, poses_out, info);
+
+    // ---- 2. back-substitution of this wave's rows (the lineariser's partition) ----
+    // A wave alone on its SIMD hides no latency: the measurements of up to kAhead of its rows are requested at once by LDS-DMA
+    // (one 1 KB piece per camera and row into the wave's own slice of the stash area, beyond the solve's LDS), the next row's
+    // point while the current row's arithmetic issues.  (With the measurements loaded inside the rolled camera loop the launch
+    // took as long as the two it replaces: four dependent HBM latencies per row.)
+    const int64_t rows = (N + 63) / 64;
+    const int64_t nw = (int64_t)gridDim.x * kWaves, gw = (int64_t)blockIdx.x * kWaves + wave;
+    const int64_t r_begin = rows * gw / nw, r_end = rows * (gw + 1) / nw;
+    {
+        constexpr int kAhead = 7;
+        constexpr size_t kStageOff = 24 * 1024;
+        static_assert(sizeof(SolveLds<C>) + 4 * 64 * sizeof(double) + 256 <= kStageOff, "the staged measurements lie beyond the solve's LDS");
+        static_assert(kStageOff + sizeof(double2) * kWaves * kAhead * C * 64 <= sizeof(double2) * kWaveLinLdsL * C * 3 * kBlock + sizeof(double) * kWaves * 352,
+                      "and inside the launch's dynamic LDS (the stash and the rows of totals behind it: zeroed only when the linearisation starts)");
+        double2 *sObs = reinterpret_cast<double2 *>(wl_smem + kStageOff) + (size_t)wave * kAhead * C * 64;      // [kAhead][C][64]
+        const double2 *o2 = reinterpret_cast<const double2 *>(obs);
+        for (int64_t rg = r_begin; rg < r_end; rg += kAhead) {
+            const int nr = (int)((r_end - rg) < kAhead ? (r_end - rg) : kAhead);
+            for (int k = 0; k < nr; ++k) {
+                const int64_t i = (rg + k) * 64 + lane;
+                const int64_t ii = i < N ? i : N - 1;
+#pragma unroll
+                for (int c = 0; c < C; ++c)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(o2 + (int64_t)c * N + ii),
+                                                     (__attribute__((address_space(3))) void *)(sObs + (k * C + c) * 64), 16, 0, 0);
+            }
+            int64_t i0 = rg * 64 + lane;
+            int64_t ii0 = i0 < N ? i0 : N - 1;
+            double npx = points[3 * ii0 + 0], npy = points[3 * ii0 + 1], npz = points[3 * ii0 + 2];
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the measurements of these rows are in LDS, the first point has arrived
+            for (int k = 0; k < nr; ++k) {
+                const int64_t i = (rg + k) * 64 + lane;
+                const bool live = i < N;
+                double px = npx, py = npy, pz = npz;
+                if (k + 1 < nr) {                                    // the next row's point, in flight under this row's arithmetic
+                    const int64_t j = (rg + k + 1) * 64 + lane;
+                    const int64_t jj = j < N ? j : N - 1;
+                    npx = points[3 * jj + 0]; npy = points[3 * jj + 1]; npz = points[3 * jj + 2];
+                }
+                if (!live) { px = 0.0; py = 0.0; pz = 0.0; }
+                unsigned mbits = 0u;
+                if (mask) {
+                    const int64_t ii = live ? i : 0;
+#pragma unroll
+                    for (int c = 0; c < C; ++c) mbits |= (unsigned)mask[(int64_t)c * N + ii] << (8 * c);
+                }
+                double pw, dx, dy, dz;
+                load_prior(prior_w, prior_xyz, i, live, px, py, pz, pw, dx, dy, dz);
+                const StagedObs64 ob = {sObs + k * C * 64 + lane, mbits, live, mask != nullptr};
+                const mqs::Vec3 dp = landmark_backsub<C>(sCam, ob, px, py, pz, pw, dx, dy, dz, lambda, sm.x);
+                if (live) {
+                    points_out[3 * i + 0] = px + dp.x;
+                    points_out[3 * i + 1] = py + dp.y;
+                    points_out[3 * i + 2] = pz + dp.z;
+                }
+            }
+        }
+    }
+    __syncthreads();                                  // every wave is done with the old camera blocks and with dpose (sm.x lies in the stash)
+    MQS_IT_STAMP(4)
+
+    // ---- 3. the new camera blocks ----
+    if (tid < C) stage_camera(sCam + kCamStride * tid, sPoseNew + 12 * tid, calib + 9 * tid, sigma[tid]);
+    __syncthreads();
+
+    MQS_IT_STAMP(5)
+    // ---- 4. linearisation of the same rows at the new estimate (ba_linearize_wave_kernel, LDS form) ----
+    double2 *sStash = reinterpret_cast<double2 *>(wl_smem);
+    double *sTot = reinterpret_cast<double *>(wl_smem + sizeof(double2) * kWaveLinLdsL * C * 3 * kBlock);   // [kWaves][kRow]
+    double *tot = sTot + wave * kRow;
+    for (int k = lane; k < kRow; k += 64) tot[k] = 0.0;
+    mqs_wave_lds_sync();
+    const WlStash stash = {sStash + tid};
+    const double2 *obs2 = reinterpret_cast<const double2 *>(obs);
+    const double *cams = sCam;
+    bool nodist = true;
+#pragma unroll
+    for (int c = 0; c < C; ++c) nodist = nodist && camera_without_distortion(sCam + kCamStride * c);
+    for (int64_t r = r_begin; r < r_end;) {
+        const int64_t left = r_end - r;
+        const int nl = left >= kWaveLinMaxL ? kWaveLinMaxL : (int)left;
+#define MQS_WL_CALL(LL)                                                                                                       \
+    do {                                                                                                                      \
+        if (nodist) wl_chunk<C, LL, true>(cams, stash, points_out, obs2, mask, prior_w, prior_xyz, N, lambda, r, lane, tot);  \
+        else wl_chunk<C, LL, false>(cams, stash, points_out, obs2, mask, prior_w, prior_xyz, N, lambda, r, lane, tot);        \
+    } while (0)
+#if MQS_WL_MAXL >= 4
+        if (nl == 4) MQS_WL_CALL(4); else
+#endif
+#if MQS_WL_MAXL >= 3
+        if (nl == 3) MQS_WL_CALL(3); else
+#endif
+        if (nl == 2) MQS_WL_CALL(2);
+        else MQS_WL_CALL(1);
+#undef MQS_WL_CALL
+        r += nl;
+    }
+    __syncthreads();
+    MQS_IT_STAMP(6)
+    for (int s = tid; s < kRow; s += kBlock) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) t += sTot[w * kRow + s];
+        partials_out[(int64_t)blockIdx.x * kRow + s] = t;
+    }
+    MQS_IT_STAMP(7)
+}
+
 // Grid: persistent workgroups, 2 per CU at <= 256 VGPRs (each keeps its partial sums in registers).
 int ba_grid(int64_t N)
 {
@@ -2419,6 +2684,64 @@ int mqs_ba_tail_launch(const double *lin, const mqs_peer_recv *peer, const mqs_b
         return MQS_E_ARG;
     }
     MQS_HIP_CHECK(hipGetLastError());
+    return MQS_OK;
+}
+
+// A run of iterations, one launch each (ba_iterate_kernel): is this problem served?
+bool mqs_ba_iterate_eligible(int C, int64_t N)
+{
+    static const bool off = [] { const char *e = getenv("MQS_BA_ITERATE"); return e && e[0] == '0'; }();      // A/B: the two-launch iteration
+    if (off || !mqs_ba_wave_path(C) || !mqs_ba_fused_finalize_enabled() || kWaveLinOcc != 1 || tail_form() != 1) return false;
+    if (N >= kWlScalarMinLandmarks) return false;
+    const int64_t rows = (N + 63) / 64;
+    const int64_t grid = (rows + kWaves - 1) / kWaves;
+    return grid >= MQS_FIN_PIECES * mqs_ba_finalize_groups(C);           // the finalizer pieces are the first workgroups
+}
+
+// The tail of the iteration whose partial rows `fin` describes, and the linearisation of the next one at the new estimate
+// (poses_out / points_out), into the same workspace: *fin_next describes the new rows (a new epoch; its push is the caller's).
+int mqs_ba_iterate_launch(const mqs_peer_recv *peer, const mqs_ba_fin *fin_, int C, const double *poses, const double *calib, const double *sigma,
+                          const double *points, const double *obs, const uint8_t *mask, const double *prior_w, const double *prior_xyz,
+                          int64_t N, double lambda, const double *prior_poses, const double *prior_sigmas, const uint8_t *prior_mask,
+                          double *lin_out, double *dpose, double *poses_out, double *info, double *points_out, void *workspace,
+                          hipStream_t stream, mqs_ba_fin *fin_next)
+{
+    MQS_ARG_CHECK(fin_ != nullptr && fin_next != nullptr && mqs_ba_iterate_eligible(C, N), "not a problem the one-launch iteration serves");
+    mqs_peer_recv pr = {};
+    if (peer) pr = *peer;
+    TailFin fin = {};
+    fin.partials = fin_->partials; fin.nrows = fin_->nrows; fin.quarters = fin_->quarters; fin.flags = fin_->flags;
+    fin.epoch = fin_->epoch;
+    if (fin_->push) fin.push = *fin_->push;
+    fin.status = fin_->status;
+    fin.withhold = fin_->withhold;
+    const int64_t rows = (N + 63) / 64;
+    int grid = (int)((rows + kWaves - 1) / kWaves);
+    if (grid > 256) grid = 256;
+    MQS_ARG_CHECK(grid == fin_->nrows, "the rows of the previous launch come from the same grid");
+    const size_t lds = (size_t)kWaveLinLdsL * C * 3 * kBlock * sizeof(double2) + (size_t)kWaves * 352 * sizeof(double);
+    double *partials = static_cast<double *>(workspace);
+    switch (C) {
+#define MQS_CASE(c)                                                                                                          \
+    case c: {                                                                                                                \
+        static mqs_lds_opt_in opt;                                                                                           \
+        MQS_HIP_CHECK(mqs_lds_opt_in_once(opt, reinterpret_cast<const void *>(ba_iterate_kernel<c>), lds));                  \
+        hipLaunchKernelGGL((ba_iterate_kernel<c>), dim3(grid), dim3(kBlock), lds, stream, pr, fin, poses, calib, sigma, points, obs, mask, \
+                           prior_w, prior_xyz, N, lambda, prior_poses, prior_sigmas, prior_mask, lin_out, dpose, poses_out, info,   \
+                           points_out, partials);                                                                            \
+        break;                                                                                                               \
+    }
+        MQS_CASE(2) MQS_CASE(3) MQS_CASE(4)
+#undef MQS_CASE
+    default:
+        mqs_set_error("the one-launch iteration serves 2..4 cameras");
+        return MQS_E_ARG;
+    }
+    MQS_HIP_CHECK(hipGetLastError());
+    *fin_next = *fin_;
+    fin_next->epoch = g_fin_epoch.fetch_add(1);
+    fin_next->push = nullptr;
+    fin_next->withhold = g_withhold_flag.load();
     return MQS_OK;
 }
 

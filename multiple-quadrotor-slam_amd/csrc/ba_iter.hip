@@ -218,12 +218,63 @@ int mqs_ba_gn_iteration_dev(mqs_ba_problem *p, double lambda, void *stream_)
     return mqs_ba_gn_finish_dev(p, lambda, 1, stream_);
 }
 
-// `iters` iterations back to back (the benchmark's and the GN driver's inner loop): still no host synchronisation.
-int mqs_ba_gn_iterations_dev(mqs_ba_problem *p, int iters, double lambda, void *stream)
+// `iters` iterations back to back (the benchmark's and the GN driver's inner loop): still no host synchronisation.  Where the
+// problem allows (mqs_ba_iterate_eligible: a shard below 400 k landmarks, 2..4 cameras; a single GPU, or the peer transport with
+// the wait inside the kernels) the run is lineariser, iters - 1 launches that each finish one iteration and linearise the next
+// (ba_iterate_kernel), tail: iters + 1 launches instead of 2 iters, bit-identical estimates.
+int mqs_ba_gn_iterations_dev(mqs_ba_problem *p, int iters, double lambda, void *stream_)
 {
     MQS_ARG_CHECK(p != nullptr && iters >= 0, "problem must not be null, iters >= 0");
-    for (int k = 0; k < iters; ++k) {
-        const int rc = mqs_ba_gn_iteration_dev(p, lambda, stream);
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    int done = 0;
+    const bool has_comm = p->ctx && mqs_comm_world_size(p->ctx) >= 1;
+    const bool peer_fused = has_comm && mqs_comm_peer_fused(p->ctx);
+    if (iters >= 2 && mqs_ba_iterate_eligible(p->C, p->N) && (!has_comm || peer_fused)) {
+        {
+            const int rc = status_so_far(p);
+            if (rc != MQS_OK) return rc;
+        }
+        // over the peer transport the first reduction of a problem waits in a kernel of its own (mqs_ba_gn_iteration_dev)
+        if (peer_fused && p->peer_reductions == 0) {
+            const int rc = mqs_ba_gn_iteration_dev(p, lambda, stream_);
+            if (rc != MQS_OK) return rc;
+            done = 1;
+        }
+        if (iters - done >= 2) {
+            const int pieces = MQS_FIN_PIECES * mqs_ba_finalize_groups(p->C);
+            mqs_ba_fin fin;
+            int rc = mqs_ba_linearize_for_fused_tail(p->poses[p->cur], p->calib, p->sigma, p->C, p->points[p->cur], p->obs, p->mask, p->prior_w,
+                                                     p->prior_xyz, p->N, lambda, p->ws, p->ws_bytes, stream, &fin);
+            if (rc != MQS_OK) return rc;
+            for (int k = done; k < iters; ++k) {
+                const int c = p->cur, o = 1 - c;
+                mqs_peer_push push;
+                mqs_peer_recv recv;
+                int fused_wait = 0;
+                const bool peer = peer_fused && mqs_comm_peer_next(p->ctx, MQS_FIN_PIECES * MQS_PEER_QUARTER_STRIDE, pieces, &push, &recv, &fused_wait);
+                if (peer_fused && !peer) { mqs_set_error("the peer transport refused a reduction"); return MQS_E_RCCL; }
+                if (peer) { ++p->peer_reductions; fin.push = &push; recv.status = p->status_dev; }
+                fin.status = p->status_dev;
+                if (k + 1 < iters) {
+                    mqs_ba_fin next;
+                    rc = mqs_ba_iterate_launch(peer ? &recv : nullptr, &fin, p->C, p->poses[c], p->calib, p->sigma, p->points[c], p->obs, p->mask,
+                                               p->prior_w, p->prior_xyz, p->N, lambda, p->prior_poses, p->prior_sigmas, p->prior_mask, p->lin,
+                                               p->dpose, p->poses[o], p->info, p->points[o], p->ws, stream, &next);
+                    if (rc != MQS_OK) return rc;
+                    fin = next;
+                } else {
+                    rc = mqs_ba_tail_launch(nullptr, peer ? &recv : nullptr, &fin, p->C, p->poses[c], p->calib, p->sigma, p->points[c], p->obs,
+                                            p->mask, p->prior_w, p->prior_xyz, p->N, lambda, p->prior_poses, p->prior_sigmas, p->prior_mask, p->lin,
+                                            p->dpose, p->poses[o], p->info, p->points[o], stream);
+                    if (rc != MQS_OK) return rc;
+                }
+                p->cur = o;
+            }
+            return MQS_OK;
+        }
+    }
+    for (int k = done; k < iters; ++k) {
+        const int rc = mqs_ba_gn_iteration_dev(p, lambda, stream_);
         if (rc != MQS_OK) return rc;
     }
     return MQS_OK;

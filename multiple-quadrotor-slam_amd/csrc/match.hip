@@ -167,6 +167,9 @@ using float16v = __attribute__((ext_vector_type(16))) float;
 #ifndef MQS_MATCH_STAGE_ROWS
 #define MQS_MATCH_STAGE_ROWS 128
 #endif
+#ifndef MQS_MATCH_STAGGER
+#define MQS_MATCH_STAGGER 0            // A/B: s_sleep argument (x 64 cycles) by which the second wave of every SIMD trails the first behind each stage barrier
+#endif
 // Train rows per LDS stage (a whole number of 32-row MFMA tiles): the largest of MQS_MATCH_STAGE_ROWS, its half, .. 64 of
 // which two stages fit the LDS.  Every stage ends in a workgroup barrier behind which all eight waves start again with the
 // latency of their first fragment reads exposed; at 64 rows (64 MFMAs per wave and stage) that was 8 % of the fp16 kernel's
@@ -622,6 +625,11 @@ __global__ __launch_bounds__(NW * 64) void knn2_mfma_kernel(const typename TP::e
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #else
         __syncthreads();
+#endif
+#if MQS_MATCH_STAGGER > 0
+        // waves w and w + NW / 2 share a SIMD and run the same program: behind the barrier both would sit out the latency of their
+        // first start-value and fragment reads together, and meet every later step boundary together too
+        if (wave >= NW / 2) __builtin_amdgcn_s_sleep(MQS_MATCH_STAGGER);
 #endif
     }
     // scan of the last step, last window

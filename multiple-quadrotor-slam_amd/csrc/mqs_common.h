@@ -84,6 +84,13 @@ struct mqs_ba_fin {
 int mqs_ba_linearize_for_fused_tail(const double *poses, const double *calib, const double *sigma, int C, const double *points,
                                     const double *obs, const uint8_t *mask, const double *prior_w, const double *prior_xyz, int64_t N,
                                     double lambda, void *workspace, int64_t workspace_bytes, hipStream_t stream, mqs_ba_fin *fin);
+// a run of iterations with ONE launch per iteration (ba.hip: ba_iterate_kernel = the tail of iteration k + the lineariser of k + 1)
+bool mqs_ba_iterate_eligible(int C, int64_t N);
+int mqs_ba_iterate_launch(const mqs_peer_recv *peer, const mqs_ba_fin *fin, int C, const double *poses, const double *calib, const double *sigma,
+                          const double *points, const double *obs, const uint8_t *mask, const double *prior_w, const double *prior_xyz,
+                          int64_t N, double lambda, const double *prior_poses, const double *prior_sigmas, const uint8_t *prior_mask,
+                          double *lin_out, double *dpose, double *poses_out, double *info, double *points_out, void *workspace,
+                          hipStream_t stream, mqs_ba_fin *fin_next);
 bool mqs_ba_wave_path(int C);            // wave lineariser + fused tail serve this camera count (and are not switched off)
 bool mqs_ba_fused_finalize_enabled();    // MQS_BA_FINALIZE=kernel keeps the finalize launch (A/B)
 int mqs_ba_tail_launch(const double *lin, const mqs_peer_recv *peer, const mqs_ba_fin *fin, int C, const double *poses, const double *calib,

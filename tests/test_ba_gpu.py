@@ -294,6 +294,36 @@ def test_one_call_iteration_equals_the_four_launches(gpu):
     assert torch.equal(a.poses, before) and not torch.equal(a.poses_new, before)
 
 
+@pytest.mark.parametrize("case", [dict(N=70_000, C=4), dict(N=150_000, C=4, distortion=True, masked_frac=0.2), dict(N=131_000, C=3, distortion=True),
+                                  dict(N=262_207, C=2), dict(N=10_000, C=4)])
+def test_a_run_of_iterations_in_one_launch_each_equals_the_two_launch_iterations(case, gpu):
+    """mqs_ba_gn_iterations_dev on a shard-sized problem: lineariser, K - 1 launches that each finish one iteration and linearise
+    the next (ba_iterate_kernel), tail -- against the same K iterations issued one by one (two launches each): bit-identical
+    poses, landmarks, reduced system and dpose, with priors, masks and distortion, for 2, 3 and 4 cameras, chunks of 1 to 4 rows per
+    wave, and for a problem too small for the one-launch form (10 000 landmarks: fewer workgroups than finalizer pieces), where
+    the call falls back to the two-launch iteration."""
+    import torch
+    kw = dict(case)
+    N, C = kw.pop("N"), kw.pop("C")
+    sc = make_scene(N, C, seed=N % 97 + C, **kw)
+    pp = (sc["poses_true"], np.tile([0.02, 0.02, 0.02, 0.1, 0.1, 0.1], (C, 1)), np.array([1] + [0] * (C - 1), dtype=np.uint8))
+    a, b = adjuster(gpu, sc, pp), adjuster(gpu, sc, pp)
+    K = 5
+    for _ in range(K):
+        a.gauss_newton_iteration(0.0)
+    b.gauss_newton_iterations(K)
+    torch.cuda.synchronize()
+    assert a._cur == b._cur == K % 2
+    assert torch.equal(a.poses, b.poses) and torch.equal(a.points, b.points)
+    assert torch.equal(a.lin, b.lin) and torch.equal(a.dpose, b.dpose) and torch.equal(a.info, b.info)
+    assert b.total_cost() < 1.001 * a.total_cost() and np.isfinite(b.total_cost())
+    # an even count and a damped run continue from there
+    a.gauss_newton_iteration(-1e-3); a.gauss_newton_iteration(-1e-3)
+    b.gauss_newton_iterations(2, lam=-1e-3)
+    torch.cuda.synchronize()
+    assert torch.equal(a.poses, b.poses) and torch.equal(a.points, b.points)
+
+
 def test_c_abi_communicator_single_rank(gpu):
     """The library's RCCL communicator (mqs_comm_*) with one rank: the all-reduce is the identity, and a BundleAdjuster bound
     to it runs the one-call iteration with the collective issued from C (the N-rank case needs N GPUs: bench.py --gpus N)."""
