@@ -553,7 +553,9 @@ def main():
                                                "achieved": round(bytes_fused / (ms_fused * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                                "frac": round(bytes_fused / (ms_fused * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                                                "algorithmic_bytes_per_launch": bytes_fused, "avg_launch_ms": round(ms_fused, 5),
-                                               "note": "fp64 VALU issue binds before HBM (DESIGN.md)"}
+                                               "valu_pmc": (valu or {}).get("tri_ls_and_iterative_fused"),
+                                               "note": "fp64 VALU issue binds before HBM (DESIGN.md): on this data 99 % of the landmarks run all ten "
+                                                       "re-weighting iterations (noise-limited depths never settle within 3e-5)"}
     if ba_out is not None and "solve_retract_backsub_one_launch" in ba_out["kernels_ms"]:
         ms_tail = ba_out["kernels_ms"]["solve_retract_backsub_one_launch"]
         bytes_tail = N * (24 + 16 * C + 24) + (8 * N if ba.prior_w is not None else 0)
@@ -561,6 +563,7 @@ def main():
                                 "achieved": round(bytes_tail / (ms_tail * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                 "frac": round(bytes_tail / (ms_tail * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                                 "algorithmic_bytes_per_launch": bytes_tail, "avg_launch_ms": round(ms_tail, 5),
+                                "valu_pmc": (valu or {}).get("ba_tail"),
                                 "note": "13.6 M vector instructions per launch at 1e6 x 4: the SIMDs' vector units are 74 % busy (profiles/r04/02); "
                                         "two restructurings measured slower (profiles/r04/05)"}
     rooflines["iterative_ls_standalone"] = roofline_it

@@ -13,4 +13,15 @@ for rnd in range(3):
     for k in ("linear_ls", "iterative_ls", "linear_eigen"):
         ms = D.time_triangulation(k, ud, Pd, reps=30)
         out.setdefault(k, []).append(round(ms * 1e3, 2))
+# the step's fused linear-LS + iterative-LS launch (tri_kernel<C, 3>), torch events around 30 calls
+x_ls = torch.empty((N, 3), dtype=torch.float64, device="cuda"); x_it = torch.empty_like(x_ls); st = torch.empty((N,), dtype=torch.int32, device="cuda")
+for rnd in range(3):
+    D.linear_and_iterative_LS_triangulation(ud, Pd, out_ls=x_ls, out_it=x_it, out_status=st)
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(30):
+        D.linear_and_iterative_LS_triangulation(ud, Pd, out_ls=x_ls, out_it=x_it, out_status=st)
+    e1.record(); e1.synchronize()
+    out.setdefault("ls_and_iterative_fused", []).append(round(e0.elapsed_time(e1) / 30 * 1e3, 2))
 print(json.dumps(out))

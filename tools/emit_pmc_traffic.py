@@ -51,6 +51,16 @@ def main():
                                               "valu_issue_us_at_2.4GHz": lin.get("valu_issue_us_at_2.4GHz"),
                                               "launch_us_under_profiler": lin.get("median_duration_us"), "waves_per_simd": 1,
                                               "active_inst_valu_over_wave_cycles": lin.get("active_inst_valu_over_wave_cycles")}}
+    def valu_of(rec, waves_per_simd):
+        c = rec["counters"]
+        return {"valu_instructions_per_launch": c.get("SQ_INSTS_VALU"), "valu_instructions_per_landmark_lane": round(c.get("SQ_INSTS_VALU", 0) * 64 / 1e6, 1),
+                "valu_issue_us_at_2.4GHz": rec.get("valu_issue_us_at_2.4GHz"), "launch_us_under_profiler": rec.get("median_duration_us"),
+                "waves_per_simd": waves_per_simd, "active_inst_valu_over_wave_cycles": rec.get("active_inst_valu_over_wave_cycles")}
+    for key, needles, w in (("iterative_ls", ("tri_kernel<4", "1, false"), 3), ("tri_ls_and_iterative_fused", ("tri_kernel<4", "3, false"), 3),
+                            ("ba_tail", ("ba_tail_kernel<4>",), 4)):
+        rec = find(valu, *needles)
+        if rec and "SQ_INSTS_VALU" in rec["counters"]:
+            out.setdefault("valu", {})[key] = valu_of(rec, w)
     out["sources"] = {"ba": evidence_stamp.source_record("ba"), "tri": evidence_stamp.source_record("tri")}
     json.dump(out, open(path, "w"), indent=1)
     print(json.dumps({k: v for k, v in out.items() if k.endswith("per_launch")}))

@@ -18,10 +18,12 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAVES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv \
     -d "$ROOT/$OUT/pmc_valu_ba" -- python3 "$ROOT/tools/bench_ba.py" > /dev/null 2> "$ROOT/$OUT/pmc_valu_ba.err"
+rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAVES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv \
+    -d "$ROOT/$OUT/pmc_valu_tri" -- python3 "$ROOT/tools/bench_tri.py" > /dev/null 2> "$ROOT/$OUT/pmc_valu_tri.err"
 cd "$ROOT"
 python3 tools/pmc_summary.py "$OUT/pmc_FETCH_SIZE_ba" "$OUT/pmc_WRITE_SIZE_ba" "$OUT/pmc_FETCH_SIZE_tri" "$OUT/pmc_WRITE_SIZE_tri" > "$OUT/pmc_hbm_traffic_summary.json"
-python3 tools/pmc_summary.py "$OUT/pmc_valu_ba" > "$OUT/pmc_valu_summary.json"
+python3 tools/pmc_summary.py "$OUT/pmc_valu_ba" "$OUT/pmc_valu_tri" > "$OUT/pmc_valu_summary.json"
 find "$OUT/kt" -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} "$OUT/bench_one_stream_kernel_stats.csv"
 # keep the merge small: the raw traces stay on the box
-rm -rf "$OUT"/kt "$OUT"/pmc_FETCH_SIZE_* "$OUT"/pmc_WRITE_SIZE_* "$OUT"/pmc_valu_ba
+rm -rf "$OUT"/kt "$OUT"/pmc_FETCH_SIZE_* "$OUT"/pmc_WRITE_SIZE_* "$OUT"/pmc_valu_ba "$OUT"/pmc_valu_tri
 ls -la "$OUT"
