@@ -364,3 +364,69 @@ def test_peer_row_that_never_arrives_is_an_error(gpu, tmp_path):
                "127.0.0.1", "--master-port", str(29600 + os.getpid() % 250), str(script)]
         r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and r.stdout.count("timeout-ok") == 2, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+PEER_RUN_WORKER = """
+import os, sys
+import numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import torch
+import mqslam_amd
+from ba_util import make_scene
+sh = mqslam_amd.sharding
+rank, local_rank, world = sh.init_from_env()
+dev = torch.device("cuda", 0)
+cc = sh.init_peer_comm(rank, world, 0)
+sc = make_scene(26_000, 4, seed=13, distortion=True, masked_frac=0.1)
+pts, obs, mask, pw, px = sh.shard_arrays(rank, world, sc["points"], sc["obs"], sc["mask"], sc["prior_w"], sc["prior_xyz"])
+t = lambda a, dt=torch.float64: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev).to(dt)
+C = 4
+pose_prior = (t(sc["poses_true"]), t(np.tile([0.02, 0.02, 0.02, 0.1, 0.1, 0.1], (C, 1))), t(np.array([1, 0, 0, 0], dtype=np.uint8), torch.uint8))
+ba = mqslam_amd.bundle_adjustment.BundleAdjuster(t(sc["poses"]), t(sc["calib"]), t(sc["sigma"]), t(pts), t(obs), t(mask, torch.uint8),
+                                                 t(pw), t(px), pose_prior, cc)
+c0 = ba.total_cost()
+ba.gauss_newton_iterations(5)          # first reduction: one-workgroup wait; then lineariser, 3 x ba_iterate_kernel, tail -- all over the peer transport
+c1 = ba.total_cost()
+torch.cuda.synchronize()
+assert not cc.peer_timed_out()
+np.savez(os.path.join({out!r}, "peerrun_r%d_of_%d.npz" % (rank, world)), poses=ba.poses.cpu().numpy(), points=ba.points.cpu().numpy(),
+         costs=np.array([c0, c1]), lin=ba.lin.cpu().numpy())
+if world > 1:
+    torch.distributed.barrier()
+cc.close()
+if world > 1:
+    torch.distributed.destroy_process_group()
+print("peer-run-ok")
+"""
+
+
+def test_run_of_iterations_over_the_peer_transport_two_processes(gpu, tmp_path):
+    """mqs_ba_gn_iterations_dev with its one-launch iterations (ba_iterate_kernel) between two PROCESSES that share the test box's
+    GPU, the wait for the peers' finalizer pieces inside the kernels (MQS_PEER_FUSED=1: 2 x 51 workgroups, one per CU -- all
+    resident): the finalizer pieces of every launch go to both receive buffers, both ranks fold them in rank order.  Identical
+    bits on both ranks; the one-process solve of the whole scene to 1e-9; the two-launch iteration (MQS_BA_ITERATE=0) gives the
+    same bits as the one-launch form."""
+    script = tmp_path / "peer_run.py"
+    script.write_text(PEER_RUN_WORKER.format(root=ROOT, out=str(tmp_path)))
+    res = {}
+    for tag, extra in (("one_launch", {}), ("two_launch", {"MQS_BA_ITERATE": "0"})):
+        env = dict(os.environ, MQS_DIST_BACKEND="gloo", MQS_SHARED_GPU="1", MASTER_ADDR="127.0.0.1", MQS_PEER_FUSED="1", **extra)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(29900 + os.getpid() % 90), str(script)]
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and r.stdout.count("peer-run-ok") == 2, r.stdout[-2000:] + r.stderr[-4000:]
+        res[tag] = [dict(np.load(tmp_path / ("peerrun_r%d_of_2.npz" % k))) for k in range(2)]
+    e1 = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, str(script)], env=dict(e1, MQS_DIST_BACKEND="gloo", MQS_SHARED_GPU="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "peer-run-ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+    one = np.load(tmp_path / "peerrun_r0_of_1.npz")
+    two = res["one_launch"]
+    np.testing.assert_array_equal(two[0]["poses"], two[1]["poses"])
+    np.testing.assert_array_equal(two[0]["lin"], two[1]["lin"])
+    assert np.abs(two[0]["poses"] - one["poses"]).max() <= 1e-9
+    pts = np.concatenate([two[0]["points"], two[1]["points"]])
+    assert np.abs(pts - one["points"]).max() <= 1e-9 * max(1.0, np.abs(one["points"]).max())
+    assert two[0]["costs"][1] < two[0]["costs"][0]
+    for k in range(2):
+        for key in ("poses", "points", "lin"):
+            np.testing.assert_array_equal(res["one_launch"][k][key], res["two_launch"][k][key])
