@@ -55,6 +55,32 @@ def test_keyframe_test_random_sample_is_the_reference_draw(mqs, monkeypatch):
     assert m.max_homography_points == max(4, m.target_keypoints // 4) and L.MonoSlam(K, dist, (480, 640)).max_homography_points == 0
 
 
+def test_adjuster_screen_residuals_equal_the_oracle_projection(mqs):
+    """slam_device._reprojection_residuals (the in-loop adjuster's outlier screen, vectorised numpy) against the BA oracle's
+    per-factor projection (oracle/ba_np.project, the Cal3DS2 model of bundle_adjust.cpp:289-298) on random poses, landmarks and a
+    full distortion set."""
+    from oracle import ba_np
+    rng = np.random.default_rng(4)
+    P, N, M = 7, 40, 300
+    poses = np.zeros((P, 12))
+    for k in range(P):
+        w = 0.2 * rng.standard_normal(3)
+        th = np.linalg.norm(w)
+        Kx = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+        R = np.eye(3) + np.sin(th) / th * Kx + (1 - np.cos(th)) / th ** 2 * Kx @ Kx
+        poses[k, :9] = R.reshape(-1)
+        poses[k, 9:] = rng.standard_normal(3) * 0.5
+    pts = rng.standard_normal((N, 3)) + [0, 0, 8.0]
+    calib = np.array([470.0, 481.0, 0.7, 320.0, 240.0, 0.08, -0.02, 0.001, -0.0015])
+    lm, ps = rng.integers(0, N, M), rng.integers(0, P, M)
+    uv = rng.uniform(0, 640, (M, 2))
+    got = mqs.slam_device._reprojection_residuals(poses, pts, calib, lm, ps, uv)
+    for k in range(M):
+        uvh, _, _, valid = ba_np.project(poses[ps[k]], calib, pts[lm[k]])
+        assert valid
+        assert got[k] == pytest.approx(np.linalg.norm(uvh - uv[k]), rel=1e-12)
+
+
 def test_rendered_sequence_is_consistent(mqs):
     seq = mqs.synthetic.PlaneSequence(frames=5)
     img = seq.render(0)
