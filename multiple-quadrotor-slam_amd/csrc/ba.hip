@@ -2007,8 +2007,12 @@ __global__ __launch_bounds__(kTail2Block) void ba_tail2_kernel(
     bool bad = false;
     if (tid < 64) reduced_solve_wave<C>(sm.m, sm.col, sm.y, sm.x, tid, bad);
     __syncthreads();
-    if (publisher && tid < 64) publish_solution<C>(sm, poses, bad, tid, dpose, poses_out, info);      // behind the barrier: nobody waits for the retraction
     unpark();
+    // Every wave has its parked batch back BEFORE any wave requests the next one: the parking area IS ring half 1, the half the
+    // first request of the loop lands in, and one wave's slice of the ring is another wave's parked registers (the publisher's
+    // wave 0, a microsecond late out of the retraction, used to find its points overwritten: tools/probes/tail_form_diff.py).
+    __syncthreads();
+    if (publisher && tid < 64) publish_solution<C>(sm, poses, bad, tid, dpose, poses_out, info);      // behind the barriers: nobody waits for the retraction
 
     // ---- back-substitution: batch b's arithmetic with batch b + 1's loads in flight ----
     int slot = 0;

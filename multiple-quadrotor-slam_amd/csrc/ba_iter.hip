@@ -80,7 +80,7 @@ int mqs_ba_problem_create(mqs_ctx *ctx, int C, int64_t N, double *poses_a, doubl
     // the status word lives in pinned host memory the GPU writes over the fabric: the host reads it without a copy, and
     // mqs_ba_gn_iteration_dev checks it on entry without synchronising anything
     void *h = nullptr;
-    if (hipHostMalloc(&h, 64, hipHostMallocMapped) != hipSuccess) {
+    if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) {
         (void)hipGetLastError();
         delete p;
         mqs_set_error("the problem's status word could not be allocated (hipHostMalloc)");

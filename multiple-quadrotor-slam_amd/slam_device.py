@@ -26,8 +26,8 @@ from .camera import _intr
 from .slam_loop import (CORNER_QUALITY_LEVEL, HOMOGRAPHY_CONDITION_THRESHOLD, KEYPOINT_COVERAGE_RADIUS, MAX_AMOUNT_KEYPOINTS,
                         MAX_LOST_TRACKS_RATIO, MAX_OF_ERROR, MAX_SOLVEPNP_OUTLIER_RATIO, MAX_SOLVEPNP_REPROJ_ERROR)
 
-REASSOCIATE_RADIUS = 3.0         # pixels: a re-detected corner within this distance of a lost landmark's projection (slam.py's max_radius_OF_to_FAST role)
-REASSOCIATE_RATIO = 0.8          # slam.py:94 max_dist_ratio
+REASSOCIATE_RADIUS = 2.0         # pixels: a re-detected corner within this distance of a lost landmark's projection (slam.py:29 max_radius_OF_to_FAST["FAST"])
+REASSOCIATE_RATIO = 0.7          # slam.py:30 max_dist_ratio["FAST"]
 
 REASONS = {0: "", 1: "lost track of too many points", 2: "fewer than 8 triangulated tracks", 3: "no RANSAC model",
            4: "PnP outlier ratio", 5: "reprojection error"}
@@ -108,6 +108,8 @@ class DeviceMonoSlam:
         self.ba_iterations = int(ba_iterations)
         self.ba_min_observations = 3
         self.ba_outlier_pixels = 4.0     # a landmark with a residual beyond this after an adjustment is a mistracked corner
+        self.ba_gross_pixels = 40.0      # ... and with one beyond this BEFORE the adjustment it does not enter it
+        self.ba_max_passes = 4           # adjust, screen, adjust again from the same start: at most this many adjustments
         self._ba_bad = np.zeros(0, bool)
         self.reassociate = bool(reassociate)
         self.poses_online = []           # with bundle_adjust: the pose of each frame as first estimated (poses: adjusted)
@@ -293,6 +295,16 @@ class DeviceMonoSlam:
         per_lm = np.bincount(lm, minlength=N)
         t1 = time.perf_counter()
         passes, dropped, hist_all = 0, 0, None
+        # before anything is adjusted: an observation that misses the CURRENT estimate by tens of pixels is not noise the
+        # adjustment could average out (the loop's own estimate is good to a pixel or two) -- its landmark sits out at once,
+        # before ten LM iterations have spread a 1e7 cost over every pose it touches
+        if self.ba_gross_pixels:
+            res0 = _reprojection_residuals(poses, pts, calib[0], lm, ps, uv)
+            worst0 = np.zeros(N)
+            np.maximum.at(worst0, lm, res0)
+            gross = ~(worst0 <= self.ba_gross_pixels) & (np.arange(N) >= self._n0) & ~self._ba_bad[:N] & (per_lm >= self.ba_min_observations)
+            self._ba_bad[:N] |= gross
+            dropped += int(gross.sum())
         while True:
             # a landmark joins the adjustment once it has been seen from a THIRD frame (fresh from its triangulation it constrains
             # nothing but the relative pose of its two keyframes), and sits out for good once an adjustment has shown it to be a
@@ -319,8 +331,8 @@ class DeviceMonoSlam:
             res = _reprojection_residuals(new_poses, new_pts, calib[0], l2, p2, u2)
             worst = np.zeros(N)
             np.maximum.at(worst, l2, res)
-            bad = (worst > self.ba_outlier_pixels) & (np.arange(N) >= self._n0)
-            if passes >= 2 or not bad.any():
+            bad = ~(worst <= self.ba_outlier_pixels) & (np.arange(N) >= self._n0)
+            if passes >= self.ba_max_passes or not bad.any():
                 break
             self._ba_bad[:N] |= bad
             dropped += int(bad.sum())

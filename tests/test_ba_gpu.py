@@ -505,6 +505,28 @@ def test_fused_finalize_hand_over_under_changing_linearisation_points(gpu):
 
 
 @pytest.mark.gpu
+def test_second_form_of_the_tail_gives_the_same_bits(gpu):
+    """MQS_BA_TAIL_FORM=2 (one twelve-wave workgroup per CU, the system solved once per CU, the next batch's loads in flight under
+    the current one's arithmetic: built in round 4, measured slower, kept as an A/B form) against the default form: the same
+    fingerprint over 60 one-call iterations from 60 linearisation points (the form is read once per process: two processes)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = os.path.join(root, "tools", "probes", "fused_finalize_stress.py")
+    outs = []
+    for form in (None, "2"):
+        env = {k: v for k, v in os.environ.items() if k not in ("MQS_BA_TAIL_FORM", "MQS_BA_FINALIZE")}
+        if form:
+            env["MQS_BA_TAIL_FORM"] = form
+        r = subprocess.run([sys.executable, script, "60", "270000"], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    assert outs[0]["sha256_16"] == outs[1]["sha256_16"]
+
+
+@pytest.mark.gpu
 def test_scalar_camera_blocks_follow_the_poses(gpu):
     """The wave lineariser's scalar-load form (N >= 400 000) reads the camera blocks from a copy every workgroup publishes to the
     workspace and pulls through the scalar cache: the same adjuster (same workspace, same addresses) linearised at 40 different

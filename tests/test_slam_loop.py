@@ -271,6 +271,24 @@ def test_device_loop_with_bundle_adjustment_per_keyframe(gpu):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("seed", [1, 3])
+def test_adjustment_in_the_loop_survives_a_grossly_mistracked_corner(gpu, seed):
+    """The same rendering in 40 frames (half again the image motion per frame).  At frame 16 a corner that slid along an edge
+    enters the adjustment with a residual of thousands of pixels (cost 1.9e7 against ~60): with these two RANSAC seeds the
+    round's first version let Levenberg-Marquardt spread it over the poses before the screen saw it, wrote the result back, and
+    never recovered (trajectory RMSE 0.037 / 0.043, worse than the plain loop's 0.032; profiles/r04/15).  The screen in front of
+    the adjustment (ba_gross_pixels) keeps such a landmark out; the adjusted trajectory is then the same for every seed."""
+    import run_slam_loop
+    plain = run_slam_loop.run_device(40, seed=seed)
+    ba = run_slam_loop.run_device(40, seed=seed, bundle_adjust="keyframe")
+    rep = ba["bundle_adjust_per_keyframe"]
+    assert ba["accepted"] == 40
+    assert rep["trajectory_rmse_adjusted"] < 0.012 and rep["trajectory_rmse_adjusted"] < 0.4 * plain["trajectory_rmse"]
+    assert rep["trajectory_rmse_online"] < plain["trajectory_rmse"]
+    assert rep["last"]["cost_after"] < 400.0                                           # (the stuck runs ended at 420-460)
+
+
+@pytest.mark.gpu
 def test_observation_log_of_the_device_loop(gpu):
     """The log the frame kernels keep for the adjuster (csrc/slam_frame.hip): one entry per kept track and accepted frame, pose
     indices = ranks among the accepted frames, a new landmark's entries reach back to its base keyframe (slam2.py:634-641), and
