@@ -430,6 +430,15 @@ int mqs_sba_cost_dev(const double *poses, const int32_t *pose_cam, int64_t P, co
                      const double *prior_xyz, double *out, void *workspace, int64_t workspace_bytes,
                      void *stream);
 
+/* Per landmark the largest reprojection residual of its observations in PIXELS at the estimate (poses, points):
+ * worst [N] (0 for a landmark without observations, +inf when one of its observations lies behind its camera) -- the outlier
+ * screen either side of an adjustment (slam_device.py; the reference's tool has none: bundle_adjust.cpp:289-298 are plain
+ * least-squares factors over a finished recording). */
+int mqs_sba_worst_residual_dev(const double *poses, const int32_t *pose_cam, int64_t P, const double *calib,
+                               const double *sigma, const double *points, int64_t N, const int64_t *obs_ptr,
+                               const int32_t *obs_pose, const double *obs_uv, int64_t M, double *worst, void *workspace,
+                               int64_t workspace_bytes, void *stream);
+
 /* Odometry: BetweenFactor<Pose3> (bundle_adjust.cpp:301-309, `useOdometry`), GTSAM 3.2.1 conventions: error
  * measured.localCoordinates(T_from^-1 T_to) = (Log(Rm^T Rh), Rm^T (th - tm)), Jacobians of `between`
  * (-Ad(h^-1), I), whitened by odo_sigmas [n_odo][6] (rotation 3, translation 3).  odo_meas [n_odo][12] =
@@ -438,6 +447,51 @@ int mqs_sba_cost_dev(const double *poses, const int32_t *pose_cam, int64_t P, co
 int mqs_sba_between_dev(const double *poses, int64_t P, const int32_t *odo_from, const int32_t *odo_to,
                         const double *odo_meas, const double *odo_sigmas, int64_t n_odo, double *S, double *g,
                         double *cost, void *stream);
+
+/* Levenberg-Marquardt over the sparse problem in ONE call: what `LevenbergMarquardtOptimizer(graph, initial).optimize()` is to
+ * the reference's tool (bundle_adjust.cpp:323-324), with GTSAM 3.2.1's default schedule (LevenbergMarquardtParams: lambdaInitial
+ * 1e-5, lambdaFactor 10, lambdaUpperBound 1e5, maxIterations 100, absoluteErrorTol / relativeErrorTol 1e-5; a failed trial
+ * multiplies lambda and is repeated from the same linearisation point).  The driver issues the entry points above
+ * (linearize_grouped, between, solve_banded, backsub, cost) on `stream` and synchronises ONCE per trial (the trial's total
+ * cost and the factorisation's verdict come back together).  All pointers are device pointers of the layouts documented at
+ * those entry points; `poses` / `points` hold the initial estimate on entry and the adjusted one on return (`poses_new`,
+ * `points_new`, `S` [(6P)^2], `g` [6P] and `workspace` are scratch).  pair_a / pair_b / group_ptr: mqs_sba_group_pairs_dev's
+ * lists (G > 0 required when Q > 0 for the atomics-free pair stage; G == 0 selects the atomic one).  Optional parts:
+ * prior_w / prior_xyz (NULL: none), n_pose_prior == 0, n_odo == 0.
+ * cost_history[0] = cost of the initial estimate, then one entry per ACCEPTED iteration; *n_history entries written
+ * (at most history_cap; max_iterations + 1 suffices).  damping: MQS_SBA_DAMPING_GTSAM adds lambda * I (GTSAM's default,
+ * diagonalDamping = false), MQS_SBA_DAMPING_MARQUARDT scales the diagonals by (1 + lambda). */
+#define MQS_SBA_DAMPING_GTSAM     0
+#define MQS_SBA_DAMPING_MARQUARDT 1
+typedef struct mqs_sba_problem_dev {
+    int64_t P, N, M, Q, G;
+    double *poses, *poses_new;                    /* [P][12] camera-to-world R row-major + centre */
+    double *points, *points_new;                  /* [N][3] */
+    const int32_t *pose_cam;                      /* [P] camera (calibration) of every pose */
+    const double *calib, *sigma;                  /* [n_cams][9], [n_cams] */
+    const int64_t *obs_ptr;                       /* [N + 1] */
+    const int32_t *obs_pose;                      /* [M] sorted by pose inside a landmark (mqs_sba_sort_observations_dev) */
+    const double *obs_uv;                         /* [M][2] */
+    const int64_t *pair_a, *pair_b, *group_ptr;   /* [Q], [Q], [G + 1] */
+    const double *prior_w, *prior_xyz;            /* [N], [N][3] or NULL */
+    const int32_t *pose_prior_idx;                /* [n_pose_prior] */
+    const double *pose_prior_poses, *pose_prior_sigmas;   /* [n_pose_prior][12], [n_pose_prior][6] */
+    const int32_t *odo_from, *odo_to;             /* [n_odo] */
+    const double *odo_meas, *odo_sigmas;          /* [n_odo][12], [n_odo][6] */
+    int64_t n_odo;
+    int64_t half_bandwidth;                       /* of the reduced camera system (6 (dmax + 1) - 1; >= 6P: dense) */
+    double *S, *g;
+    void *workspace;
+    int64_t workspace_bytes;                      /* >= mqs_sba_lm_workspace_bytes(P, N, M) */
+    int32_t n_pose_prior, reserved;
+} mqs_sba_problem_dev;
+typedef struct mqs_sba_lm_params {
+    double lambda_initial, lambda_factor, lambda_upper, abs_tol, rel_tol;
+    int32_t max_iterations, damping;
+} mqs_sba_lm_params;
+int64_t mqs_sba_lm_workspace_bytes(int64_t P, int64_t N, int64_t M);
+int mqs_sba_optimize_lm_dev(const mqs_sba_problem_dev *problem, const mqs_sba_lm_params *lm, double *cost_history,
+                            int32_t history_cap, int32_t *n_history, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * Camera model either side of triangulation (the published OpenCV 2.4 pinhole + distortion model):

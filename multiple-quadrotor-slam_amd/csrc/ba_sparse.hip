@@ -357,8 +357,10 @@ __global__ void sparse_priors_kernel(double *__restrict__ S, double *__restrict_
         double c = 0.0;
         for (int a = 0; a < 6; ++a) {
             const double wi = 1.0 / (sg[a] * sg[a]);
-            atomic_add_f64(S + (int64_t)(6 * j + a) * n6 + 6 * j + a, wi);
-            atomic_add_f64(g + 6 * j + a, -wi * e[a]);
+            if (S) {                                                   // S == nullptr: the factors' cost only (LM trial evaluation)
+                atomic_add_f64(S + (int64_t)(6 * j + a) * n6 + 6 * j + a, wi);
+                atomic_add_f64(g + 6 * j + a, -wi * e[a]);
+            }
             c += 0.5 * wi * e[a] * e[a];
         }
         atomic_add_f64(prior_cost, c);
@@ -543,6 +545,26 @@ __global__ __launch_bounds__(kBlock) void sparse_cost_kernel(
         cost_partials[2 * blockIdx.x] = c;
         cost_partials[2 * blockIdx.x + 1] = n;
     }
+}
+
+// The screen of an adjustment (slam_device.py: a landmark whose worst observation misses the estimate by more than a bound
+// sits out): per landmark the largest PIXEL residual of its observations; +inf when one of them lies behind its camera.
+__global__ __launch_bounds__(kBlock) void sparse_worst_residual_kernel(
+    const double *__restrict__ cams, const double *__restrict__ points, const int64_t *__restrict__ obs_ptr,
+    const int32_t *__restrict__ obs_pose, const double *__restrict__ obs_uv, const int32_t *__restrict__ pose_cam,
+    const double *__restrict__ sigma, int64_t N, double *__restrict__ worst)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= N) return;
+    const double px = points[3 * i], py = points[3 * i + 1], pz = points[3 * i + 2];
+    double w = 0.0;
+    for (int64_t k = obs_ptr[i]; k < obs_ptr[i + 1]; ++k) {
+        const int j = obs_pose[k];
+        const Factor fc = make_factor(cams + (int64_t)j * kCamStride, px, py, pz, obs_uv[2 * k], obs_uv[2 * k + 1], true);
+        const double r = fc.valid ? sqrt(2.0 * fc.half_e2) * sigma[pose_cam[j]] : HUGE_VAL;       // the factor is whitened by sigma
+        w = fmax(w, r);
+    }
+    worst[i] = w;
 }
 
 __global__ __launch_bounds__(kBlock) void sum_cost_partials_kernel(const double *__restrict__ partials, int n,
@@ -1338,6 +1360,25 @@ int mqs_sba_cost_dev(const double *poses, const int32_t *pose_cam, int64_t P, co
     return MQS_OK;
 }
 
+int mqs_sba_worst_residual_dev(const double *poses, const int32_t *pose_cam, int64_t P, const double *calib, const double *sigma,
+                               const double *points, int64_t N, const int64_t *obs_ptr, const int32_t *obs_pose,
+                               const double *obs_uv, int64_t M, double *worst, void *workspace, int64_t workspace_bytes,
+                               void *stream_)
+{
+    MQS_ARG_CHECK(P >= 1 && N >= 0 && M >= 0 && workspace, "arguments");
+    MQS_ARG_CHECK(workspace_bytes >= mqs_sba_workspace_bytes(P, N, M), "workspace too small");
+    if (N == 0) return MQS_OK;
+    MQS_ARG_CHECK(poses && pose_cam && calib && sigma && points && obs_ptr && worst && (M == 0 || (obs_pose && obs_uv)), "pointers must not be null");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    double *cams = static_cast<double *>(workspace);
+    hipLaunchKernelGGL(stage_pose_cams_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, stream, poses, pose_cam,
+                       calib, sigma, (int)P, cams);
+    hipLaunchKernelGGL(sparse_worst_residual_kernel, dim3((unsigned)((N + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, cams,
+                       points, obs_ptr, obs_pose, obs_uv, pose_cam, sigma, N, worst);
+    MQS_HIP_CHECK(hipGetLastError());
+    return MQS_OK;
+}
+
 // Adds the odometry BetweenFactors to a linearised (mirrored) system; S == NULL: only cost[0] += their cost.
 int mqs_sba_between_dev(const double *poses, int64_t P, const int32_t *odo_from, const int32_t *odo_to,
                         const double *odo_meas, const double *odo_sigmas, int64_t n_odo, double *S, double *g,
@@ -1351,6 +1392,137 @@ int mqs_sba_between_dev(const double *poses, int64_t P, const int32_t *odo_from,
     hipLaunchKernelGGL(sparse_between_kernel, dim3((unsigned)((n_odo + 63) / 64)), dim3(64), 0, stream, S, g, (int)(6 * P),
                        poses, odo_from, odo_to, odo_meas, odo_sigmas, (int)n_odo, cost);
     MQS_HIP_CHECK(hipGetLastError());
+    return MQS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Levenberg-Marquardt over the sparse problem, driven from here (round 4): what `LevenbergMarquardtOptimizer(graph,
+// initial).optimize()` is to bundle_adjust.cpp:323-324.  The schedule is GTSAM 3.2.1's default (lambda 1e-5, factor 10, upper
+// bound 1e5, a failed trial multiplies lambda and tries again from the same linearisation point, stop on absolute / relative
+// cost decrease) -- the loop `sparse_ba.SparseBundleAdjuster.optimize_host_loop` runs from Python over the same entry points;
+// here a trial is ONE host synchronisation (the trial's landmark cost, pose-prior cost, odometry cost and the factorisation's
+// `bad` word come back together through a pinned buffer) and no interpreter between the launches: at the sizes the SLAM loop
+// adjusts behind a keyframe (<= 60 poses, 10-15 k observations) the kernels are microseconds and the Python loop's four
+// synchronisations and dozen ctypes calls per trial were the cost.
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+// the driver's words: the last 16 doubles of the workspace (mqs_sba_workspace_bytes leaves them free), read back in one copy
+struct LmSums {
+    double lin_info[4];          // of the last linearisation: {cost, valid, pose-prior cost, pair groups out of canonical order}
+    double lin_odo_cost;         // (the odometry factors' cost at the linearisation point: not used)
+    double spare[3];
+    double landmark_cost, valid, prior_cost, odo_cost;          // of the estimate last evaluated (lm_enqueue_cost)
+    int bad, pad;                // the factorisation's verdict
+    double spare2[3];
+};
+static_assert(sizeof(LmSums) == 16 * sizeof(double), "the driver's words are the workspace's spare 16 doubles");
+
+// the cost of the estimate (poses, points) into `sums` (device: LmSums::landmark_cost ...): three small launches
+int lm_enqueue_cost(const mqs_sba_problem_dev *p, const double *poses, const double *points, double *sums, hipStream_t stream)
+{
+    int rc = mqs_sba_cost_dev(poses, p->pose_cam, p->P, p->calib, p->sigma, points, p->N, p->obs_ptr, p->obs_pose, p->obs_uv, p->M,
+                              p->prior_w, p->prior_xyz, sums, p->workspace, p->workspace_bytes, stream);      // zeroes sums[0..1]
+    if (rc != MQS_OK) return rc;
+    MQS_HIP_CHECK(hipMemsetAsync(sums + 2, 0, 2 * sizeof(double), stream));
+    if (p->n_pose_prior > 0)
+        hipLaunchKernelGGL(sparse_priors_kernel, dim3((p->n_pose_prior + 63) / 64), dim3(64), 0, stream, nullptr, nullptr, (int)(6 * p->P),
+                           poses, p->pose_prior_idx, p->pose_prior_poses, p->pose_prior_sigmas, p->n_pose_prior, 0.0, sums + 2);
+    if (p->n_odo > 0)
+        hipLaunchKernelGGL(sparse_between_kernel, dim3((unsigned)((p->n_odo + 63) / 64)), dim3(64), 0, stream, nullptr, nullptr,
+                           (int)(6 * p->P), poses, p->odo_from, p->odo_to, p->odo_meas, p->odo_sigmas, (int)p->n_odo, sums + 3);
+    MQS_HIP_CHECK(hipGetLastError());
+    return MQS_OK;
+}
+
+LmSums *lm_pinned()
+{
+    static thread_local LmSums *h = nullptr;                // one per calling thread, for the life of the process
+    if (!h && hipHostMalloc(reinterpret_cast<void **>(&h), sizeof(LmSums), hipHostMallocPortable) != hipSuccess) h = nullptr;
+    return h;
+}
+
+}  // namespace
+
+int64_t mqs_sba_lm_workspace_bytes(int64_t P, int64_t N, int64_t M) { return mqs_sba_workspace_bytes(P, N, M); }
+
+int mqs_sba_optimize_lm_dev(const mqs_sba_problem_dev *p, const mqs_sba_lm_params *lm, double *cost_history, int32_t history_cap,
+                            int32_t *n_history, void *stream_)
+{
+    MQS_ARG_CHECK(p && lm && cost_history && n_history && history_cap >= 1, "arguments must not be null");
+    MQS_ARG_CHECK(p->P >= 1 && p->N >= 0 && p->M >= 0 && p->Q >= 0 && p->G >= 0 && p->n_odo >= 0 && p->n_pose_prior >= 0, "sizes");
+    MQS_ARG_CHECK(p->poses && p->poses_new && p->S && p->g && p->workspace, "poses, poses_new, S, g, workspace must not be null");
+    MQS_ARG_CHECK(p->N == 0 || (p->points && p->points_new), "points, points_new must not be null");
+    MQS_ARG_CHECK(p->workspace_bytes >= mqs_sba_workspace_bytes(p->P, p->N, p->M), "workspace too small (mqs_sba_lm_workspace_bytes)");
+    MQS_ARG_CHECK(lm->lambda_factor > 1.0 && lm->lambda_initial > 0.0 && lm->max_iterations >= 0, "LM parameters");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    LmSums *host = lm_pinned();
+    MQS_ARG_CHECK(host != nullptr, "pinned host buffer for the trial results could not be allocated");
+    double *blk = static_cast<double *>(p->workspace) + mqs_sba_workspace_bytes(p->P, p->N, p->M) / (int64_t)sizeof(double) - 16;
+    double *sums = blk + 8;
+    int *bad = reinterpret_cast<int *>(blk + 12);
+    const double sgn = lm->damping == MQS_SBA_DAMPING_MARQUARDT ? 1.0 : -1.0;
+    auto total = [&](bool with_bad, double &out, bool &ok) -> int {
+        if (!with_bad) MQS_HIP_CHECK(hipMemsetAsync(bad, 0, sizeof(int), stream));
+        MQS_HIP_CHECK(hipMemcpyAsync(host, blk, sizeof(LmSums), hipMemcpyDeviceToHost, stream));
+        MQS_HIP_CHECK(hipStreamSynchronize(stream));
+        ok = host->bad == 0;
+        out = host->landmark_cost;                          // the order the host loop adds them in
+        if (p->n_pose_prior > 0) out += host->prior_cost;
+        if (p->n_odo > 0) out += host->odo_cost;
+        return MQS_OK;
+    };
+    int rc = lm_enqueue_cost(p, p->poses, p->points, sums, stream);
+    if (rc != MQS_OK) return rc;
+    double cur = 0.0;
+    bool ok = true;
+    if ((rc = total(false, cur, ok)) != MQS_OK) return rc;
+    int nh = 0;
+    cost_history[nh++] = cur;
+    double lam = lm->lambda_initial;
+    for (int it = 0; it < lm->max_iterations; ++it) {
+        bool improved = false;
+        double fresh = 0.0;
+        while (lam <= lm->lambda_upper) {
+            const double l = sgn * lam;
+            rc = mqs_sba_linearize_grouped_dev(p->poses, p->pose_cam, p->P, p->calib, p->sigma, p->points, p->N, p->obs_ptr, p->obs_pose,
+                                               p->obs_uv, p->M, p->pair_a, p->pair_b, p->Q, p->group_ptr, p->G, p->prior_w, p->prior_xyz,
+                                               p->pose_prior_idx, p->pose_prior_poses, p->pose_prior_sigmas, p->n_pose_prior, l, p->S, p->g,
+                                               blk, p->workspace, p->workspace_bytes, stream);
+            if (rc != MQS_OK) return rc;
+            if (p->n_odo > 0) {
+                rc = mqs_sba_between_dev(p->poses, p->P, p->odo_from, p->odo_to, p->odo_meas, p->odo_sigmas, p->n_odo, p->S, p->g, blk + 4, stream);
+                if (rc != MQS_OK) return rc;
+            }
+            rc = mqs_sba_solve_banded_dev(p->S, p->g, p->P, p->half_bandwidth, l, p->poses, p->poses_new, bad, stream);
+            if (rc != MQS_OK) return rc;
+            rc = mqs_sba_backsub_dev(p->poses, p->pose_cam, p->P, p->calib, p->sigma, p->points, p->N, p->obs_ptr, p->obs_pose, p->obs_uv, p->M,
+                                     p->prior_w, p->prior_xyz, l, p->g, p->points_new, p->workspace, p->workspace_bytes, stream);
+            if (rc != MQS_OK) return rc;
+            rc = lm_enqueue_cost(p, p->poses_new, p->N > 0 ? p->points_new : p->points, sums, stream);
+            if (rc != MQS_OK) return rc;
+            if ((rc = total(true, fresh, ok)) != MQS_OK) return rc;
+            MQS_ARG_CHECK(host->lin_info[3] == 0.0, "pair groups are not in canonical order (mqs_sba_group_pairs_dev builds them)");
+            if (!ok) fresh = HUGE_VAL;
+            if (fresh <= cur) {
+                MQS_HIP_CHECK(hipMemcpyAsync(p->poses, p->poses_new, (size_t)p->P * 12 * sizeof(double), hipMemcpyDeviceToDevice, stream));
+                if (p->N > 0)
+                    MQS_HIP_CHECK(hipMemcpyAsync(p->points, p->points_new, (size_t)p->N * 3 * sizeof(double), hipMemcpyDeviceToDevice, stream));
+                lam = lam / lm->lambda_factor;
+                if (lam < 1e-20) lam = 1e-20;
+                improved = true;
+                break;
+            }
+            lam *= lm->lambda_factor;
+        }
+        if (!improved) break;
+        if (nh < history_cap) cost_history[nh++] = fresh;
+        const double dec = fabs(cur - fresh);
+        const bool done = dec < lm->abs_tol || dec / (cur > 1e-300 ? cur : 1e-300) < lm->rel_tol;
+        cur = fresh;
+        if (done) break;
+    }
+    *n_history = nh;
     return MQS_OK;
 }
 

@@ -295,23 +295,15 @@ class DeviceMonoSlam:
         per_lm = np.bincount(lm, minlength=N)
         t1 = time.perf_counter()
         passes, dropped, hist_all = 0, 0, None
-        # before anything is adjusted: an observation that misses the CURRENT estimate by tens of pixels is not noise the
-        # adjustment could average out (the loop's own estimate is good to a pixel or two) -- its landmark sits out at once,
-        # before ten LM iterations have spread a 1e7 cost over every pose it touches
-        if self.ba_gross_pixels:
-            res0 = _reprojection_residuals(poses, pts, calib[0], lm, ps, uv)
-            worst0 = np.zeros(N)
-            np.maximum.at(worst0, lm, res0)
-            gross = ~(worst0 <= self.ba_gross_pixels) & (np.arange(N) >= self._n0) & ~self._ba_bad[:N] & (per_lm >= self.ba_min_observations)
-            self._ba_bad[:N] |= gross
-            dropped += int(gross.sum())
+        movable = np.arange(N) >= self._n0
+        screened_at_start = not self.ba_gross_pixels
         while True:
             # a landmark joins the adjustment once it has been seen from a THIRD frame (fresh from its triangulation it constrains
             # nothing but the relative pose of its two keyframes), and sits out for good once an adjustment has shown it to be a
             # mistracked corner: GTSAM's factors are plain least squares (bundle_adjust.cpp:289-298: no robust kernel), the
             # reference runs them once over a finished recording -- inside the loop one bad track that passed the depth checks
             # drags the two keyframes it was triangulated from by centimetres before anything else has seen it
-            use = ((per_lm >= self.ba_min_observations) | (np.arange(N) < self._n0)) & ~self._ba_bad[:N]
+            use = ((per_lm >= self.ba_min_observations) | ~movable) & ~self._ba_bad[:N]
             keep = use[lm]
             l2, p2, u2 = lm[keep], ps[keep], uv[keep]
             order = np.argsort(l2, kind="stable")
@@ -323,19 +315,27 @@ class DeviceMonoSlam:
                 odo_from=np.array([o[0] for o in self._odo], np.int32), odo_to=np.array([o[1] for o in self._odo], np.int32),
                 odo_meas=np.array([o[2] for o in self._odo]).reshape(-1, 12), odo_sigmas=np.tile([0.05, 0.05, 0.05, 0.2, 0.2, 0.2], (len(self._odo), 1)))
             ba = sparse_ba.SparseBundleAdjuster(problem, device="cuda:%d" % self._device)
+            if not screened_at_start:
+                # before anything is adjusted: an observation that misses the CURRENT estimate by tens of pixels is not noise the
+                # adjustment could average out (the loop's own estimate is good to a pixel or two) -- its landmark sits out at
+                # once, before ten LM iterations have spread a 1e7 cost over every pose it touches
+                screened_at_start = True
+                gross = ~(ba.worst_residuals() <= self.ba_gross_pixels) & movable & use
+                if gross.any():
+                    self._ba_bad[:N] |= gross
+                    dropped += int(gross.sum())
+                    continue
             hist = ba.optimize(iters=self.ba_iterations, mode="lm")
             hist_all = hist if hist_all is None else hist_all[:1] + hist[1:]
-            new_poses, new_pts = ba.poses.cpu().numpy(), ba.points.cpu().numpy()
             passes += 1
-            # the screen: pixel residuals of the adjusted estimate; a landmark with one beyond the bound sits out from now on
-            res = _reprojection_residuals(new_poses, new_pts, calib[0], l2, p2, u2)
-            worst = np.zeros(N)
-            np.maximum.at(worst, l2, res)
-            bad = ~(worst <= self.ba_outlier_pixels) & (np.arange(N) >= self._n0)
+            # the screen: pixel residuals of the adjusted estimate (`mqs_sba_worst_residual_dev`; `_reprojection_residuals` above is
+            # its numpy twin); a landmark with one beyond the bound sits out from now on and the adjustment is redone from the start
+            bad = ~(ba.worst_residuals() <= self.ba_outlier_pixels) & movable & use
             if passes >= self.ba_max_passes or not bad.any():
                 break
             self._ba_bad[:N] |= bad
             dropped += int(bad.sum())
+        new_poses, new_pts = ba.poses.cpu().numpy(), ba.points.cpu().numpy()
         new_pts[~use] = pts[~use]                                    # landmarks that sat out keep their values
         t2 = time.perf_counter()
         for k, f in enumerate(self._accepted):                       # camera-to-world pose12 -> [R | t] world -> camera

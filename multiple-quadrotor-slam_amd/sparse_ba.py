@@ -110,6 +110,27 @@ def group_pairs_dev(obs_ptr_host, obs_ptr, obs_pose, n_poses):
     return pa[:Q], pb[:Q], gp[:G + 1]
 
 
+def _make_structs():
+    import ctypes
+    vp, i64, i32, f64 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_double
+
+    class ProblemDev(ctypes.Structure):                     # include/mqslam.h: mqs_sba_problem_dev
+        _fields_ = ([(k, i64) for k in ("P", "N", "M", "Q", "G")] +
+                    [(k, vp) for k in ("poses", "poses_new", "points", "points_new", "pose_cam", "calib", "sigma", "obs_ptr", "obs_pose",
+                                       "obs_uv", "pair_a", "pair_b", "group_ptr", "prior_w", "prior_xyz", "pose_prior_idx",
+                                       "pose_prior_poses", "pose_prior_sigmas", "odo_from", "odo_to", "odo_meas", "odo_sigmas")] +
+                    [("n_odo", i64), ("half_bandwidth", i64), ("S", vp), ("g", vp), ("workspace", vp), ("workspace_bytes", i64),
+                     ("n_pose_prior", i32), ("reserved", i32)])
+
+    class LmParams(ctypes.Structure):                       # mqs_sba_lm_params
+        _fields_ = [(k, f64) for k in ("lambda_initial", "lambda_factor", "lambda_upper", "abs_tol", "rel_tol")] + \
+                   [("max_iterations", i32), ("damping", i32)]
+    return ProblemDev, LmParams
+
+
+_ProblemDev, _LmParams = _make_structs()
+
+
 class SparseBundleAdjuster:
     def __init__(self, problem, device="cuda:0"):
         torch = _torch()
@@ -117,30 +138,53 @@ class SparseBundleAdjuster:
         self.problem = pr
         dev = torch.device(device)
         self.dev = dev
-        t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(dev).to(dt)
         f64, i32, i64 = torch.float64, torch.int32, torch.int64
+        # every host array of the problem in ONE upload (a problem behind a keyframe of the SLAM loop is ~20 arrays of a few KB:
+        # one copy each was half of the set-up's time): laid out back to back, 16-byte aligned, then viewed per array
+        np_dt = {f64: np.float64, i32: np.int32, i64: np.int64}
+        staged, blobs, off = {}, [], 0
+        def stage(name, a, dt):
+            nonlocal off
+            a = np.ascontiguousarray(np.asarray(a), dtype=np_dt[dt])
+            staged[name] = (off, a.shape, dt, a.nbytes)
+            blobs.append(a.reshape(-1).view(np.uint8))
+            pad = (-a.nbytes) % 16
+            if pad:
+                blobs.append(np.zeros(pad, np.uint8))
+            off += a.nbytes + pad
+        def uploaded():
+            flat = torch.from_numpy(np.concatenate(blobs) if blobs else np.zeros(16, np.uint8)).to(dev)
+            out = {}
+            for name, (o, shape, dt, nbytes) in staged.items():
+                out[name] = flat[o:o + nbytes].view(dt).view(*shape) if nbytes else torch.empty(shape, dtype=dt, device=dev)
+            return out
         self.P, self.N, self.M = len(pr.poses), len(pr.points), len(pr.obs_pose)
-        self.poses = t(pr.poses, f64)
-        self.pose_cam = t(pr.pose_cam, i32)
-        self.calib = t(pr.calib, f64)
-        self.sigma = t(pr.sigma, f64)
-        self.points = t(pr.points, f64)
-        self.obs_ptr = t(pr.obs_ptr, i64)
+        has_prior = pr.prior_w is not None and np.any(pr.prior_w > 0)
+        self.npp = len(pr.pose_prior_idx)
+        self.n_odo = len(pr.odo_from)
+        stage("poses", pr.poses, f64); stage("pose_cam", pr.pose_cam, i32); stage("calib", pr.calib, f64); stage("sigma", pr.sigma, f64)
+        stage("points", pr.points, f64); stage("obs_ptr", pr.obs_ptr, i64); stage("obs_pose", pr.obs_pose, i32)
+        stage("obs_uv", np.asarray(pr.obs_uv).reshape(-1, 2), f64)
+        if has_prior:
+            stage("prior_w", pr.prior_w, f64); stage("prior_xyz", pr.prior_xyz, f64)
+        if self.npp:
+            stage("pp_idx", pr.pose_prior_idx, i32); stage("pp_poses", pr.poses[pr.pose_prior_idx], f64)      # prior = initial pose (:273)
+            stage("pp_sigmas", pr.pose_prior_sigmas, f64)
+        if self.n_odo:
+            stage("odo_from", pr.odo_from, i32); stage("odo_to", pr.odo_to, i32); stage("odo_meas", pr.odo_meas, f64)
+            stage("odo_sigmas", pr.odo_sigmas, f64)
+        up = uploaded()
+        self.poses, self.pose_cam, self.calib, self.sigma = up["poses"], up["pose_cam"], up["calib"], up["sigma"]
+        self.points, self.obs_ptr = up["points"], up["obs_ptr"]
         # the observations sorted by pose inside every landmark, and every pair of observations of a landmark grouped by pose
         # pair: both built on the device (numpy twins `sort_observations_by_pose`, `build_pairs` / `group_pairs` above: the same
         # lists; the host sort alone was 7 ms of a 9 ms set-up at the kt2 shape, round 3)
         with torch.cuda.device(dev):
-            self.obs_pose, self.obs_uv = sort_observations_dev(self.obs_ptr, t(pr.obs_pose, i32), t(np.asarray(pr.obs_uv).reshape(-1, 2), f64),
-                                                               len(pr.points), len(pr.poses))
+            self.obs_pose, self.obs_uv = sort_observations_dev(self.obs_ptr, up["obs_pose"], up["obs_uv"], len(pr.points), len(pr.poses))
             self.pair_a, self.pair_b, self.group_ptr = group_pairs_dev(pr.obs_ptr, self.obs_ptr, self.obs_pose, len(pr.poses))
         self.Q, self.G = int(self.pair_a.numel()), int(self.group_ptr.numel()) - 1
-        has_prior = pr.prior_w is not None and np.any(pr.prior_w > 0)
-        self.prior_w = t(pr.prior_w, f64) if has_prior else None
-        self.prior_xyz = t(pr.prior_xyz, f64) if has_prior else None
-        self.npp = len(pr.pose_prior_idx)
-        self.pp_idx = t(pr.pose_prior_idx, i32) if self.npp else None
-        self.pp_poses = t(pr.poses[pr.pose_prior_idx], f64) if self.npp else None      # prior = initial pose (:273)
-        self.pp_sigmas = t(pr.pose_prior_sigmas, f64) if self.npp else None
+        self.prior_w, self.prior_xyz = up.get("prior_w"), up.get("prior_xyz")
+        self.pp_idx, self.pp_poses, self.pp_sigmas = up.get("pp_idx"), up.get("pp_poses"), up.get("pp_sigmas")
         # half bandwidth of the reduced camera system: poses coupled by a common landmark or an odometry link are at
         # most `dmax` apart in pose index (observations are sorted by pose inside a landmark)
         ptr = np.asarray(pr.obs_ptr, dtype=np.int64)
@@ -154,10 +198,9 @@ class SparseBundleAdjuster:
         if len(pr.odo_from):
             dmax = max(dmax, int(np.abs(np.asarray(pr.odo_from, dtype=np.int64) - np.asarray(pr.odo_to, dtype=np.int64)).max()))
         self.half_bandwidth = 6 * (dmax + 1) - 1
-        self.n_odo = len(pr.odo_from)
         if self.n_odo:
-            self.odo_from, self.odo_to = t(pr.odo_from, i32), t(pr.odo_to, i32)
-            self.odo_meas, self.odo_sigmas = t(pr.odo_meas, f64), t(pr.odo_sigmas, f64)
+            self.odo_from, self.odo_to = up["odo_from"], up["odo_to"]
+            self.odo_meas, self.odo_sigmas = up["odo_meas"], up["odo_sigmas"]
             self.odo_cost = torch.zeros(1, dtype=f64, device=dev)
         n6 = 6 * self.P
         self.n6 = n6
@@ -215,6 +258,17 @@ class SparseBundleAdjuster:
             c += float(self.odo_cost.item())
         return c
 
+    def worst_residuals(self, poses=None, points=None):
+        """Per landmark the largest pixel residual of its observations at (poses, points) (default: the current estimate);
+        +inf when an observation lies behind its camera.  numpy [N]."""
+        poses = self.poses if poses is None else poses
+        points = self.points if points is None else points
+        out = _torch().empty(max(self.N, 1), dtype=_torch().float64, device=self.dev)
+        _lib.check(_lib.lib().mqs_sba_worst_residual_dev(
+            _p(poses), _p(self.pose_cam), self.P, _p(self.calib), _p(self.sigma), _p(points), self.N, _p(self.obs_ptr),
+            _p(self.obs_pose), _p(self.obs_uv), self.M, _p(out), _p(self.ws), self.ws.numel(), _sp()))
+        return out[:self.N].cpu().numpy()
+
     def _pose_prior_cost(self, poses):
         P = poses.cpu().numpy()
         pr = self.problem
@@ -239,13 +293,44 @@ class SparseBundleAdjuster:
         self.poses, self.poses_new = self.poses_new, self.poses
         self.points, self.points_new = self.points_new, self.points
 
+    def _problem_struct(self):
+        """The problem as the C ABI's `mqs_sba_problem_dev` (include/mqslam.h): device pointers of the tensors this object holds."""
+        z = lambda t: _p(t) if t is not None else None
+        return _ProblemDev(
+            P=self.P, N=self.N, M=self.M, Q=self.Q, G=self.G, poses=_p(self.poses), poses_new=_p(self.poses_new), points=_p(self.points),
+            points_new=_p(self.points_new), pose_cam=_p(self.pose_cam), calib=_p(self.calib), sigma=_p(self.sigma), obs_ptr=_p(self.obs_ptr),
+            obs_pose=_p(self.obs_pose), obs_uv=_p(self.obs_uv), pair_a=_p(self.pair_a), pair_b=_p(self.pair_b), group_ptr=_p(self.group_ptr),
+            prior_w=z(self.prior_w), prior_xyz=z(self.prior_xyz), pose_prior_idx=z(self.pp_idx), pose_prior_poses=z(self.pp_poses),
+            pose_prior_sigmas=z(self.pp_sigmas), odo_from=_p(self.odo_from) if self.n_odo else None, odo_to=_p(self.odo_to) if self.n_odo else None,
+            odo_meas=_p(self.odo_meas) if self.n_odo else None, odo_sigmas=_p(self.odo_sigmas) if self.n_odo else None, n_odo=self.n_odo,
+            half_bandwidth=self.half_bandwidth, S=_p(self.S), g=_p(self.g), workspace=_p(self.ws), workspace_bytes=self.ws.numel(),
+            n_pose_prior=self.npp, reserved=0)
+
     def optimize(self, iters=LM_MAX_ITERATIONS, mode="lm", verbose=False, damping="gtsam"):
         """mode "lm": GTSAM 3.2.1's default Levenberg-Marquardt schedule (bundle_adjust.cpp:323-324);
         mode "gn": plain Gauss-Newton.  damping: "gtsam" (default) adds lambda * I to the landmark blocks and to the reduced
         system, as GTSAM 3.2.1's default LevenbergMarquardtParams do (diagonalDamping = false) -- what the optimiser of
         bundle_adjust.cpp:323-324 runs; "marquardt" scales the diagonals by (1 + lambda) instead (invariant to the units of
         the variables; this build's default until round 3): the same optimum by a different iterate path.
-        Returns the cost history."""
+        Returns the cost history.
+        The LM loop itself runs inside the library (`mqs_sba_optimize_lm_dev`, csrc/ba_sparse.hip: one host synchronisation per
+        trial); `optimize_host_loop` is the same schedule driven from here over the individual entry points (verbose runs, and
+        the comparison in tests/test_ba_files.py)."""
+        if mode != "lm" or verbose:
+            return self.optimize_host_loop(iters, mode, verbose, damping)
+        import ctypes
+        lm = _LmParams(lambda_initial=LM_LAMBDA_INITIAL, lambda_factor=LM_LAMBDA_FACTOR, lambda_upper=LM_LAMBDA_UPPER, abs_tol=LM_ABS_TOL,
+                       rel_tol=LM_REL_TOL, max_iterations=int(min(iters, LM_MAX_ITERATIONS)), damping={"gtsam": 0, "marquardt": 1}[damping])
+        pr = self._problem_struct()
+        hist = np.zeros(lm.max_iterations + 1)
+        n = ctypes.c_int32(0)
+        with _torch().cuda.device(self.dev):
+            _lib.check(_lib.lib().mqs_sba_optimize_lm_dev(ctypes.byref(pr), ctypes.byref(lm), hist.ctypes.data_as(_lib.c_f64p), len(hist),
+                                                          ctypes.byref(n), _sp()))
+        return [float(v) for v in hist[:n.value]]
+
+    def optimize_host_loop(self, iters=LM_MAX_ITERATIONS, mode="lm", verbose=False, damping="gtsam"):
+        """The optimiser's loop driven from Python over the library's entry points (see `optimize`)."""
         sgn = {"marquardt": 1.0, "gtsam": -1.0}[damping]
         hist = [self.cost()]
         if mode == "gn":

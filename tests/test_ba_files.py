@@ -443,6 +443,61 @@ def test_sparse_equals_dense_kernels(gpu):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case", [("example", True, "gtsam"), ("example", False, "marquardt"), ("svo", False, "gtsam")])
+def test_the_optimiser_inside_the_library_takes_the_host_loop_s_steps(case, gpu):
+    """`mqs_sba_optimize_lm_dev` (the LM loop of bundle_adjust.cpp:323-324 inside the library, one synchronisation per trial)
+    against the same schedule driven from Python over the individual entry points: the same accepted costs, the same estimate.
+    (Not bit for bit: the atomics of the odometry and pose-prior kernels order their sums differently from run to run, and the
+    host loop evaluates the pose prior's cost in numpy.)"""
+    which, odo, damping = case
+    if which == "example":
+        fn, data = load(gpu, EX, "synthetic", 2, 1)
+    else:
+        fn, data = load(gpu, SVO, "slam2", 1, 50)
+    pr = gpu.ba_io.build_sparse_problem(data, use_odometry=odo)
+    rng = np.random.default_rng(5)
+    pr = pr._replace(points=pr.points + 0.005 * rng.standard_normal(pr.points.shape))
+    a, b = gpu.sparse_ba.SparseBundleAdjuster(pr), gpu.sparse_ba.SparseBundleAdjuster(pr)
+    ha = a.optimize(mode="lm", damping=damping)
+    hb = b.optimize_host_loop(mode="lm", damping=damping)
+    assert len(ha) == len(hb) >= 3
+    np.testing.assert_allclose(ha, hb, rtol=1e-9)
+    assert ha[-1] < ha[0]
+    pa, pb = a.poses.cpu().numpy(), b.poses.cpu().numpy()
+    assert np.abs(pa - pb).max() <= 1e-8 * max(1.0, np.abs(pb).max())
+    assert np.abs(a.points.cpu().numpy() - b.points.cpu().numpy()).max() <= 1e-7 * max(1.0, np.abs(b.points.cpu().numpy()).max())
+    # a second call continues from the adjusted estimate: its first cost is the last one of the first call
+    assert a.optimize(mode="lm", damping=damping)[0] == pytest.approx(ha[-1], rel=1e-12)
+    assert a.cost() == pytest.approx(ha[-1], rel=1e-9) or a.cost() <= ha[-1]
+
+
+@pytest.mark.gpu
+def test_worst_residual_per_landmark_equals_the_host_projection(gpu):
+    """`mqs_sba_worst_residual_dev` (the screen either side of an adjustment in the SLAM loop) against the numpy projection that
+    tests/test_slam_loop.py pins to the oracle: per landmark the largest pixel residual; +inf behind a camera; 0 without observations."""
+    fn, data = load(gpu, SVO, "slam2", 1, 50)
+    pr = gpu.ba_io.build_sparse_problem(data)
+    rng = np.random.default_rng(2)
+    pts = pr.points + 0.02 * rng.standard_normal(pr.points.shape)
+    ptr = np.asarray(pr.obs_ptr)
+    i_behind = int(np.argmax(np.diff(ptr) > 0))                               # a landmark with observations: put it behind its first camera
+    j = int(pr.obs_pose[ptr[i_behind]])
+    R, c = pr.poses[j, :9].reshape(3, 3), pr.poses[j, 9:]
+    pts[i_behind] = c - 2.0 * R[:, 2]
+    pr = pr._replace(points=pts, sigma=np.full_like(pr.sigma, 1.7))
+    ba = gpu.sparse_ba.SparseBundleAdjuster(pr)
+    got = ba.worst_residuals()
+    lm = np.repeat(np.arange(len(pts)), np.diff(ptr))
+    res = gpu.slam_device._reprojection_residuals(pr.poses, pts, pr.calib[0], lm, np.asarray(pr.obs_pose), np.asarray(pr.obs_uv).reshape(-1, 2))
+    want = np.zeros(len(pts))
+    np.maximum.at(want, lm, res)
+    assert np.isinf(got[i_behind])                                            # (the numpy twin clamps the depth instead)
+    ok = np.arange(len(pts)) != i_behind
+    np.testing.assert_allclose(got[ok], want[ok], rtol=1e-9, atol=1e-9)
+    assert np.all(got[np.diff(ptr) == 0] == 0.0)
+
+
+@pytest.mark.gpu
 def test_example_converges_near_committed_reference_output(gpu):
     """Loose anchor: the committed *-BA outputs were produced with odometry + iSAM2 and
     6-digit inputs, so only 'same basin' is asserted: the optimised map is the 20-unit cube and the
