@@ -711,6 +711,13 @@ def main():
             # poses written back into the live state) and the matcher re-associating the top-up's corners with lost landmarks
             frontend_out["end_to_end_loop_device_resident_ba_per_keyframe"] = run_slam_loop.run_device(
                 60, repeats=2, bundle_adjust="keyframe", reassociate=True)
+            # the reference's OWN example run (slam2.py:924-933: ICL-NUIM living room, real 640 x 480 frames) against the trajectory
+            # slam2.py committed for it and against the renderer's exact one (tests/golden/icl_nuim_traj3n: the first 80 frames)
+            import run_icl_nuim
+            if os.path.exists(run_icl_nuim.FIX):
+                run_icl_nuim.run(80)                                              # first-launch costs
+                frontend_out["reference_example_sequence_icl_nuim_80_frames"] = {
+                    "plain": run_icl_nuim.run(80), "ba_per_keyframe": run_icl_nuim.run(80, bundle_adjust="keyframe")}
         except Exception as e:                                  # noqa: BLE001 -- a secondary leg must not cost the bench line
             frontend_out = {"error": "%s: %s" % (type(e).__name__, e)}
 

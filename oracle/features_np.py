@@ -8,12 +8,21 @@ per-frame loop calls through OpenCV 2.4 (an external dependency, not vendored, n
                           minEigThreshold 1e-4)
     FastFeatureDetector   Work/SLAM/application/own/slam.py:34 (FAST-9/16, threshold 10, non-max suppression)
 
-PARITY UNPINNED: the reference holds no images and no golden output for these calls, and OpenCV cannot be run
-here; what is restated is the published method of OpenCV 2.4 (cornerMinEigenVal / goodFeaturesToTrack,
-lkpyramid.cpp, fast.cpp) with float32 arithmetic in a fixed, documented order.  Where OpenCV works in fixed point
-(bilinear weights in 14 bits, rounding descale) this restatement uses float32; results agree with OpenCV's to
-its quantisation, not bit for bit.  The GPU kernels are tested against THIS file and against analytic properties
-of synthetic frames (known shifts, known corner positions).
+PARITY: pinned loosely on reference-held data, not call by call.  The reference holds no recorded OUTPUT of these three calls
+(no corner lists, no tracked positions) and OpenCV cannot be run here; what is restated is the published method of OpenCV 2.4
+(cornerMinEigenVal / goodFeaturesToTrack, lkpyramid.cpp, fast.cpp) with float32 arithmetic in a fixed, documented order.  Where
+OpenCV works in fixed point (bilinear weights in 14 bits, rounding descale) this restatement uses float32; results agree with
+OpenCV's to its quantisation, not bit for bit.  What the reference DOES hold (found in round 4) is its own example run on real
+images: 200 frames of the ICL-NUIM living-room sequence, the initial pose and 23 known 3-D corners, the renderer's exact
+trajectory, and the trajectory slam2.py wrote for these frames with the real OpenCV calls inside (slam2.py:924-933;
+Work/SLAM/datasets/ICL_NUIM/living_room_traj3n_frei_png).  Against that (tests/test_icl_nuim.py, fixture by
+tests/golden/make_icl_nuim.py):
+  * calc_optical_flow_pyr_lk tracks the 23 known corners through the real, noisy frames to where the exact trajectory projects
+    them: median 0.03-0.05 px, 90th percentile 0.09-0.16 px over five frames;
+  * the loop built on the GPU twins of these functions reproduces the reference's committed trajectory frame by frame within
+    what either keeps from the exact one (3.9-8.7 mm rmse over the 80 frames of the fixture; the reference's own 4.4 mm).
+goodFeaturesToTrack and FAST stay unpinned individually.  The GPU kernels are tested against THIS file (synthetic frames and the
+real ones) and against analytic properties of synthetic frames (known shifts, known corner positions).
 """
 import numpy as np
 

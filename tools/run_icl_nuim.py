@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""The reference's own SLAM example run (slam2.py:924-933: the ICL-NUIM living-room sequence, 4th trajectory) through this
+build's device-resident loop, against what the reference COMMITTED as that run's output (traj_out.cam0-slam2.txt, written by
+slam2.py with OpenCV 2.4's goodFeaturesToTrack / calcOpticalFlowPyrLK / solvePnPRansac) and against the renderer's exact
+trajectory.  Reads the fixture tests/golden/icl_nuim_traj3n/sequence.npz (tests/golden/make_icl_nuim.py).
+
+    python tools/run_icl_nuim.py [frames] [--ba] [--host] [--seed S]
+"""
+import os, sys, json, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import mqslam_amd
+
+FIX = os.environ.get("MQS_ICL_FIXTURE") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden",
+                                                       "icl_nuim_traj3n", "sequence.npz")      # 80 frames committed; `make_icl_nuim.py 200` for more
+
+
+def centres_from_tum(rows):
+    """TUM rows: timestamp tx ty tz qx qy qz qw with (t, q) the camera's pose IN the world (slam2.py:698-741 writes the inverse of P)."""
+    return np.asarray(rows)[:, 1:4].copy()
+
+
+def start_points(K, shape, P_init, pts):
+    """slam2.py:1054-1059: the predefined points projected through the initial pose, the visible ones kept (no rounding)."""
+    X = np.c_[pts, np.ones(len(pts))] @ P_init[:3].T @ K.T
+    uv = X[:, :2] / X[:, 2:3]
+    vis = (X[:, 2] > 0) & (uv[:, 0] >= 0) & (uv[:, 0] < shape[1]) & (uv[:, 1] >= 0) & (uv[:, 1] < shape[0])
+    return uv, vis
+
+
+def run(frames=None, bundle_adjust=None, seed=0, device=True, reassociate=False):
+    import torch
+    d = np.load(FIX)
+    imgs_h = d["frames"] if frames is None else d["frames"][:frames]
+    n = len(imgs_h)
+    K, dist, P_init, pts = d["K"], d["dist"], d["init_pose"], d["init_points"]
+    H, W = imgs_h.shape[1:]
+    uv, vis = start_points(K, (H, W), P_init, pts)
+    objp, imgp = pts[vis], uv[vis]
+    t0 = time.perf_counter()
+    if device:
+        imgs = [torch.from_numpy(np.ascontiguousarray(f)).cuda() for f in imgs_h]
+        torch.cuda.synchronize()
+        slam = mqslam_amd.slam_device.DeviceMonoSlam(K, dist, (H, W), seed=seed, bundle_adjust=bundle_adjust, reassociate=reassociate,
+                                                     max_homography_points="reference")
+        t0 = time.perf_counter()
+        slam.start(imgs[0], objp, imgp)
+        rets = [2]
+        for k in range(1, n):
+            rets.append(slam.handle_new_frame(imgs[k]))
+        slam.finish()
+    else:
+        slam = mqslam_amd.slam_loop.MonoSlam(K, dist, (H, W), seed=seed)
+        slam.start(imgs_h[0], objp, imgp)
+        rets = [2]
+        for k in range(1, n):
+            rets.append(slam.handle_new_frame(imgs_h[k]))
+    dt = time.perf_counter() - t0
+    c = np.array([(-P[:, :3].T @ P[:, 3]) if P is not None else [np.nan] * 3 for P in slam.poses])
+    ok = np.isfinite(c[:, 0])
+    ref, gt = centres_from_tum(d["traj_slam2"][:n]), centres_from_tum(d["traj_groundtruth"][:n])
+    err = lambda a, b: np.linalg.norm(a - b, axis=1)
+    path = float(np.sum(np.linalg.norm(np.diff(gt, axis=0), axis=1)))
+    out = {"frames": n, "accepted": int(ok.sum()), "keyframes": int(sum(1 for r in rets if r == 2)), "landmarks": int(len(slam.objp)),
+           "path_length_m": round(path, 4), "frames_per_s": round(n / dt, 1),
+           "ours_vs_groundtruth_rmse_m": round(float(np.sqrt(np.mean(err(c[ok], gt[ok]) ** 2))), 5),
+           "ours_vs_groundtruth_max_m": round(float(err(c[ok], gt[ok]).max()), 5),
+           "reference_vs_groundtruth_rmse_m": round(float(np.sqrt(np.mean(err(ref, gt) ** 2))), 5),
+           "reference_vs_groundtruth_max_m": round(float(err(ref, gt).max()), 5),
+           "ours_vs_reference_rmse_m": round(float(np.sqrt(np.mean(err(c[ok], ref[ok]) ** 2))), 5),
+           "ours_vs_reference_max_m": round(float(err(c[ok], ref[ok]).max()), 5),
+           "every_10th_frame_ours_ref_gt_error_mm": [[k, round(1e3 * float(err(c[k:k + 1], gt[k:k + 1])[0]), 2), round(1e3 * float(err(ref[k:k + 1], gt[k:k + 1])[0]), 2)]
+                                                     for k in range(0, n, 10) if ok[k]]}
+    if device and bundle_adjust:
+        co = np.array([(-P[:, :3].T @ P[:, 3]) if P is not None else [np.nan] * 3 for P in slam.poses_online])
+        out["online_vs_groundtruth_rmse_m"] = round(float(np.sqrt(np.mean(err(co[ok], gt[ok]) ** 2))), 5)
+        out["landmarks_screened_out"] = int(slam._ba_bad.sum())
+    if hasattr(slam, "close"):
+        slam.close()
+    return out
+
+
+if __name__ == "__main__":
+    a = [x for x in sys.argv[1:] if not x.startswith("--")]
+    seed = int(sys.argv[sys.argv.index("--seed") + 1]) if "--seed" in sys.argv else 0
+    if "--seed" in sys.argv:
+        a = [x for x in a if x != str(seed)] if len(a) > 1 else a
+    print(json.dumps(run(int(a[0]) if a else None, "keyframe" if "--ba" in sys.argv else None, seed, "--host" not in sys.argv,
+                         "--reassociate" in sys.argv)))
