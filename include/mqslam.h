@@ -431,13 +431,14 @@ int mqs_sba_cost_dev(const double *poses, const int32_t *pose_cam, int64_t P, co
                      void *stream);
 
 /* Per landmark the largest reprojection residual of its observations in PIXELS at the estimate (poses, points):
- * worst [N] (0 for a landmark without observations, +inf when one of its observations lies behind its camera) -- the outlier
+ * worst [N] (0 for a landmark without observations, +inf when one of its observations lies behind its camera); min_depth [N]
+ * (may be NULL): its smallest depth along the optical axes of the cameras that see it (+inf without observations) -- the outlier
  * screen either side of an adjustment (slam_device.py; the reference's tool has none: bundle_adjust.cpp:289-298 are plain
  * least-squares factors over a finished recording). */
 int mqs_sba_worst_residual_dev(const double *poses, const int32_t *pose_cam, int64_t P, const double *calib,
                                const double *sigma, const double *points, int64_t N, const int64_t *obs_ptr,
-                               const int32_t *obs_pose, const double *obs_uv, int64_t M, double *worst, void *workspace,
-                               int64_t workspace_bytes, void *stream);
+                               const int32_t *obs_pose, const double *obs_uv, int64_t M, double *worst, double *min_depth,
+                               void *workspace, int64_t workspace_bytes, void *stream);
 
 /* Odometry: BetweenFactor<Pose3> (bundle_adjust.cpp:301-309, `useOdometry`), GTSAM 3.2.1 conventions: error
  * measured.localCoordinates(T_from^-1 T_to) = (Log(Rm^T Rh), Rm^T (th - tm)), Jacobians of `between`
@@ -571,6 +572,7 @@ int64_t mqs_pnp_workspace_bytes(int64_t N, int B);
  *
  *   mqs_good_features_to_track: replaces cv2.goodFeaturesToTrack(img, maxCorners, qualityLevel, minDistance, None,
  *       mask) (cv2_helpers.py:34-37; slam2.py:665, 1174): Shi-Tomasi minimum-eigenvalue response (Sobel 3, block 3),
+ *       threshold = qualityLevel x the largest response among the UNMASKED pixels (featureselect.cpp: minMaxLoc(eig, ..., mask)),
  *       candidates = thresholded 3x3 maxima under `mask` (may be NULL) off the 1-pixel border, ordered by response
  *       (ties: row-major position), greedy minimum-distance selection.  out_xy [out_capacity][2] float32 (x, y),
  *       out_n = number written (<= max_corners when max_corners > 0).

@@ -124,7 +124,7 @@ SIGNATURES = {
     "mqs_sba_cost_dev": (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp,
                                         c_vp, c_vp, c_i64, c_vp]),
     "mqs_sba_between_dev": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
-    "mqs_sba_worst_residual_dev": (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp]),
+    "mqs_sba_worst_residual_dev": (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "mqs_sba_lm_workspace_bytes": (c_i64, [c_i64, c_i64, c_i64]),
     "mqs_sba_optimize_lm_dev": (ctypes.c_int, [c_vp, c_vp, c_f64p, ctypes.c_int32, c_vp, c_vp]),
     "mqs_undistort_points": (ctypes.c_int, [c_vp, c_f64p, c_f64p, c_i64, c_f64p]),

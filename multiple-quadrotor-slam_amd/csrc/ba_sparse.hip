@@ -552,19 +552,23 @@ __global__ __launch_bounds__(kBlock) void sparse_cost_kernel(
 __global__ __launch_bounds__(kBlock) void sparse_worst_residual_kernel(
     const double *__restrict__ cams, const double *__restrict__ points, const int64_t *__restrict__ obs_ptr,
     const int32_t *__restrict__ obs_pose, const double *__restrict__ obs_uv, const int32_t *__restrict__ pose_cam,
-    const double *__restrict__ sigma, int64_t N, double *__restrict__ worst)
+    const double *__restrict__ sigma, int64_t N, double *__restrict__ worst, double *__restrict__ min_depth)
 {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= N) return;
     const double px = points[3 * i], py = points[3 * i + 1], pz = points[3 * i + 2];
-    double w = 0.0;
+    double w = 0.0, zmin = HUGE_VAL;
     for (int64_t k = obs_ptr[i]; k < obs_ptr[i + 1]; ++k) {
         const int j = obs_pose[k];
-        const Factor fc = make_factor(cams + (int64_t)j * kCamStride, px, py, pz, obs_uv[2 * k], obs_uv[2 * k + 1], true);
+        const double *cam = cams + (int64_t)j * kCamStride;
+        const Factor fc = make_factor(cam, px, py, pz, obs_uv[2 * k], obs_uv[2 * k + 1], true);
         const double r = fc.valid ? sqrt(2.0 * fc.half_e2) * sigma[pose_cam[j]] : HUGE_VAL;       // the factor is whitened by sigma
         w = fmax(w, r);
+        // depth along the optical axis (make_factor's Z; a factor behind its camera reports Z = 1, hence again from the block)
+        zmin = fmin(zmin, fma(cam[2], px - cam[9], fma(cam[5], py - cam[10], cam[8] * (pz - cam[11]))));
     }
     worst[i] = w;
+    if (min_depth) min_depth[i] = zmin;
 }
 
 __global__ __launch_bounds__(kBlock) void sum_cost_partials_kernel(const double *__restrict__ partials, int n,
@@ -1362,8 +1366,8 @@ int mqs_sba_cost_dev(const double *poses, const int32_t *pose_cam, int64_t P, co
 
 int mqs_sba_worst_residual_dev(const double *poses, const int32_t *pose_cam, int64_t P, const double *calib, const double *sigma,
                                const double *points, int64_t N, const int64_t *obs_ptr, const int32_t *obs_pose,
-                               const double *obs_uv, int64_t M, double *worst, void *workspace, int64_t workspace_bytes,
-                               void *stream_)
+                               const double *obs_uv, int64_t M, double *worst, double *min_depth, void *workspace,
+                               int64_t workspace_bytes, void *stream_)
 {
     MQS_ARG_CHECK(P >= 1 && N >= 0 && M >= 0 && workspace, "arguments");
     MQS_ARG_CHECK(workspace_bytes >= mqs_sba_workspace_bytes(P, N, M), "workspace too small");
@@ -1374,7 +1378,7 @@ int mqs_sba_worst_residual_dev(const double *poses, const int32_t *pose_cam, int
     hipLaunchKernelGGL(stage_pose_cams_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, stream, poses, pose_cam,
                        calib, sigma, (int)P, cams);
     hipLaunchKernelGGL(sparse_worst_residual_kernel, dim3((unsigned)((N + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, cams,
-                       points, obs_ptr, obs_pose, obs_uv, pose_cam, sigma, N, worst);
+                       points, obs_ptr, obs_pose, obs_uv, pose_cam, sigma, N, worst, min_depth);
     MQS_HIP_CHECK(hipGetLastError());
     return MQS_OK;
 }

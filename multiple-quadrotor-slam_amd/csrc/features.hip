@@ -68,8 +68,10 @@ __device__ __forceinline__ float float_from_order_key(unsigned int k)
 // as order keys whose maximum is the frame's largest response: one atomic per workgroup, spread over kMaxSlots words -- 1 200
 // atomics on ONE word took 11 of this kernel's 17 us (same-address atomics retire one every ~10 ns).
 constexpr int kMaxSlots = 256;
+// Under a mask the maximum is that of the UNMASKED pixels (OpenCV 2.4 featureselect.cpp: `minMaxLoc(eig, 0, &maxVal, 0, 0, mask)`;
+// the reference always hands a mask over -- slam2.py:1173-1174, 662-665 -- and the strongest corners are the ones it covers).
 __global__ __launch_bounds__(kBlock) void min_eig_kernel(const uint8_t *__restrict__ img, int W, int H, float *__restrict__ eig,
-                                                        unsigned int *__restrict__ maxkey)
+                                                        const uint8_t *__restrict__ mask, unsigned int *__restrict__ maxkey)
 {
     // A 32 x 8 pixel tile per workgroup.  The gradient products of the tile and its one-pixel halo (34 x 10) are formed once,
     // in LDS: one Sobel evaluation per halo pixel (1.33 per thread) instead of nine per pixel (72 image loads per thread,
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(kBlock) void min_eig_kernel(const uint8_t *__restri
         const float d = a - c;
         const float e = (a + c) - sqrtf(d * d + b * b);
         eig[y * W + x] = e;
-        key = float_order_key(e);
+        if (!mask || mask[y * W + x] != 0) key = float_order_key(e);
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
@@ -834,7 +836,7 @@ int mqs_good_features_to_track_dev(const uint8_t *img, int W, int H, int max_cor
 
     // four launches: clear, response (+ maximum), candidates, gather + sort + selection
     MQS_HIP_CHECK(hipMemsetAsync(maxkey, 0, kMaxSlots * 4, stream));
-    hipLaunchKernelGGL(min_eig_kernel, grid2d(W, H), dim3(kBlock), 0, stream, img, W, H, eig, maxkey);
+    hipLaunchKernelGGL(min_eig_kernel, grid2d(W, H), dim3(kBlock), 0, stream, img, W, H, eig, mask, maxkey);
     hipLaunchKernelGGL(candidates_kernel, grid2d(W, H), dim3(kBlock), 0, stream, eig, W, H, maxkey, (float)quality_level, mask,
                        keys_seg, wg_count);
     const int cell = min_distance >= 1.0 ? (int)rint(min_distance) : 1;

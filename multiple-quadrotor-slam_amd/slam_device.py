@@ -110,6 +110,7 @@ class DeviceMonoSlam:
         self.ba_outlier_pixels = 4.0     # a landmark with a residual beyond this after an adjustment is a mistracked corner
         self.ba_gross_pixels = 40.0      # ... and with one beyond this BEFORE the adjustment it does not enter it
         self.ba_max_passes = 4           # adjust, screen, adjust again from the same start: at most this many adjustments
+        self.ba_min_depth_ratio = 0.02   # a landmark closer to one of its cameras than this fraction of the median landmark depth sits out
         self._ba_bad = np.zeros(0, bool)
         self.reassociate = bool(reassociate)
         self.poses_online = []           # with bundle_adjust: the pose of each frame as first estimated (poses: adjusted)
@@ -320,12 +321,30 @@ class DeviceMonoSlam:
                 # adjustment could average out (the loop's own estimate is good to a pixel or two) -- its landmark sits out at
                 # once, before ten LM iterations have spread a 1e7 cost over every pose it touches
                 screened_at_start = True
-                gross = ~(ba.worst_residuals() <= self.ba_gross_pixels) & movable & use
+                worst0, zmin = ba.worst_residuals(with_min_depth=True)
+                gross = ~(worst0 <= self.ba_gross_pixels) & movable & use
+                # ... and a landmark triangulated AT a camera centre (two views a millimetre apart: the reference's filters -- converged,
+                # in front of both cameras, slam2.py:556-590 -- let it through) has a depth of ~0 in the cameras that see it: the first
+                # step of an adjustment moves it behind one of them, GTSAM's cheirality cost (2 fx per component) makes every trial at
+                # every lambda a million times worse than the start, and nothing is ever adjusted again (the ICL-NUIM run, seed 3)
+                seen = np.isfinite(zmin) & use
+                if seen.any():
+                    gross |= (zmin < self.ba_min_depth_ratio * np.median(zmin[seen])) & movable & use
                 if gross.any():
                     self._ba_bad[:N] |= gross
                     dropped += int(gross.sum())
                     continue
             hist = ba.optimize(iters=self.ba_iterations, mode="lm")
+            if len(hist) == 1 and passes + 1 < self.ba_max_passes:
+                # no trial at any lambda was accepted: if that is cheirality -- a first step that puts a landmark behind one of its
+                # cameras -- the landmark is found at the trial estimate and sits out; the adjustment is redone without it
+                ba.step(-sparse_ba.LM_LAMBDA_INITIAL)
+                flipped = np.isinf(ba.worst_residuals(ba.poses_new, ba.points_new)) & movable & use
+                if flipped.any():
+                    self._ba_bad[:N] |= flipped
+                    dropped += int(flipped.sum())
+                    passes += 1
+                    continue
             hist_all = hist if hist_all is None else hist_all[:1] + hist[1:]
             passes += 1
             # the screen: pixel residuals of the adjusted estimate (`mqs_sba_worst_residual_dev`; `_reprojection_residuals` above is

@@ -258,16 +258,18 @@ class SparseBundleAdjuster:
             c += float(self.odo_cost.item())
         return c
 
-    def worst_residuals(self, poses=None, points=None):
+    def worst_residuals(self, poses=None, points=None, with_min_depth=False):
         """Per landmark the largest pixel residual of its observations at (poses, points) (default: the current estimate);
-        +inf when an observation lies behind its camera.  numpy [N]."""
+        +inf when an observation lies behind its camera.  numpy [N]; with_min_depth: also the landmark's smallest depth along the
+        optical axes of the cameras that see it."""
         poses = self.poses if poses is None else poses
         points = self.points if points is None else points
-        out = _torch().empty(max(self.N, 1), dtype=_torch().float64, device=self.dev)
+        out = _torch().empty((2, max(self.N, 1)), dtype=_torch().float64, device=self.dev)
         _lib.check(_lib.lib().mqs_sba_worst_residual_dev(
             _p(poses), _p(self.pose_cam), self.P, _p(self.calib), _p(self.sigma), _p(points), self.N, _p(self.obs_ptr),
-            _p(self.obs_pose), _p(self.obs_uv), self.M, _p(out), _p(self.ws), self.ws.numel(), _sp()))
-        return out[:self.N].cpu().numpy()
+            _p(self.obs_pose), _p(self.obs_uv), self.M, _p(out[0]), _p(out[1]) if with_min_depth else None, _p(self.ws), self.ws.numel(), _sp()))
+        h = out[:, :self.N].cpu().numpy()
+        return (h[0], h[1]) if with_min_depth else h[0]
 
     def _pose_prior_cost(self, poses):
         P = poses.cpu().numpy()

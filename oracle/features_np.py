@@ -20,8 +20,10 @@ tests/golden/make_icl_nuim.py):
   * calc_optical_flow_pyr_lk tracks the 23 known corners through the real, noisy frames to where the exact trajectory projects
     them: median 0.03-0.05 px, 90th percentile 0.09-0.16 px over five frames;
   * the loop built on the GPU twins of these functions reproduces the reference's committed trajectory frame by frame within
-    what either keeps from the exact one (3.9-8.7 mm rmse over the 80 frames of the fixture; the reference's own 4.4 mm).
-goodFeaturesToTrack and FAST stay unpinned individually.  The GPU kernels are tested against THIS file (synthetic frames and the
+    what either keeps from the exact one (4.1-6.3 mm rmse over the 80 frames of the fixture; the reference's own 4.4 mm);
+  * good_features_to_track fills the reference's quota on frame 0 (277 corners beside the 23 initial points: the reference's record
+    shows 296 tracked points there) -- which it did not before its threshold was taken from the maximum under the mask.
+FAST stays unpinned.  The GPU kernels are tested against THIS file (synthetic frames and the
 real ones) and against analytic properties of synthetic frames (known shifts, known corner positions).
 """
 import numpy as np
@@ -64,12 +66,15 @@ def corner_min_eigenval(img):
 
 
 def good_features_to_track(img, max_corners, quality_level, min_distance, mask=None):
-    """Returns (n, 2) float32 (x, y).  Candidates: response >= quality * max, equal to the 3x3 dilation, not on
+    """Returns (n, 2) float32 (x, y).  Candidates: response > quality * max (the max over the unmasked pixels), equal to the 3x3 dilation, not on
     the 1-pixel border, mask != 0; ordered by response (descending; ties: row-major position -- OpenCV's
     std::sort leaves ties unspecified); greedy minimum-distance selection, at most max_corners (0: no limit)."""
     eig = corner_min_eigenval(img)
     H, W = eig.shape
-    thr = F(eig.max()) * F(quality_level)
+    # the maximum under the mask: featureselect.cpp (2.4) `minMaxLoc(eig, 0, &maxVal, 0, 0, mask)` -- found from the reference's own
+    # example run (round 4): with the whole image's maximum frame 0 of the ICL-NUIM sequence yields 216 corners where slam2.py's
+    # record shows the full quota of 277 (tests/test_icl_nuim.py)
+    thr = F(eig.max() if mask is None else (eig[mask != 0].max() if np.any(mask != 0) else 0.0)) * F(quality_level)
     e = np.where(eig > thr, eig, F(0))                       # threshold(..., THRESH_TOZERO)
     q = np.pad(e, 1, mode="constant", constant_values=-np.inf)   # dilate ignores pixels outside the image
     dil = np.max(np.stack([q[1 + oy:1 + oy + H, 1 + ox:1 + ox + W] for oy in (-1, 0, 1) for ox in (-1, 0, 1)]), axis=0)

@@ -486,7 +486,8 @@ def test_worst_residual_per_landmark_equals_the_host_projection(gpu):
     pts[i_behind] = c - 2.0 * R[:, 2]
     pr = pr._replace(points=pts, sigma=np.full_like(pr.sigma, 1.7))
     ba = gpu.sparse_ba.SparseBundleAdjuster(pr)
-    got = ba.worst_residuals()
+    got, zmin = ba.worst_residuals(with_min_depth=True)
+    np.testing.assert_array_equal(got, ba.worst_residuals())
     lm = np.repeat(np.arange(len(pts)), np.diff(ptr))
     res = gpu.slam_device._reprojection_residuals(pr.poses, pts, pr.calib[0], lm, np.asarray(pr.obs_pose), np.asarray(pr.obs_uv).reshape(-1, 2))
     want = np.zeros(len(pts))
@@ -495,6 +496,13 @@ def test_worst_residual_per_landmark_equals_the_host_projection(gpu):
     ok = np.arange(len(pts)) != i_behind
     np.testing.assert_allclose(got[ok], want[ok], rtol=1e-9, atol=1e-9)
     assert np.all(got[np.diff(ptr) == 0] == 0.0)
+    # the smallest depth of a landmark in the cameras that see it
+    Rz = pr.poses[:, :9].reshape(-1, 3, 3)[:, :, 2]
+    depth = np.einsum("nk,nk->n", Rz[np.asarray(pr.obs_pose)], pts[lm] - pr.poses[np.asarray(pr.obs_pose), 9:])
+    want_z = np.full(len(pts), np.inf)
+    np.minimum.at(want_z, lm, depth)
+    np.testing.assert_allclose(zmin[np.isfinite(want_z)], want_z[np.isfinite(want_z)], rtol=1e-12, atol=1e-12)
+    assert np.all(np.isinf(zmin[np.diff(ptr) == 0])) and zmin[i_behind] < 0
 
 
 @pytest.mark.gpu

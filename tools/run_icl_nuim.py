@@ -62,6 +62,7 @@ def run(frames=None, bundle_adjust=None, seed=0, device=True, reassociate=False)
     err = lambda a, b: np.linalg.norm(a - b, axis=1)
     path = float(np.sum(np.linalg.norm(np.diff(gt, axis=0), axis=1)))
     out = {"frames": n, "accepted": int(ok.sum()), "keyframes": int(sum(1 for r in rets if r == 2)), "landmarks": int(len(slam.objp)),
+           "keyframe_frames": [k for k, r in enumerate(rets) if r == 2],
            "path_length_m": round(path, 4), "frames_per_s": round(n / dt, 1),
            "ours_vs_groundtruth_rmse_m": round(float(np.sqrt(np.mean(err(c[ok], gt[ok]) ** 2))), 5),
            "ours_vs_groundtruth_max_m": round(float(err(c[ok], gt[ok]).max()), 5),
