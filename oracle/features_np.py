@@ -21,8 +21,8 @@ tests/golden/make_icl_nuim.py):
     them: median 0.03-0.05 px, 90th percentile 0.09-0.16 px over five frames;
   * the loop built on the GPU twins of these functions reproduces the reference's committed trajectory frame by frame within
     what either keeps from the exact one (4.1-6.3 mm rmse over the 80 frames of the fixture; the reference's own 4.4 mm);
-  * good_features_to_track fills the reference's quota on frame 0 (277 corners beside the 23 initial points: the reference's record
-    shows 296 tracked points there) -- which it did not before its threshold was taken from the maximum under the mask.
+  * good_features_to_track fills slam2.py's quota on frame 0 (277 corners beside the 23 initial points: the reference's record of
+    a run on this sequence shows 296 tracked points there, i.e. at least 273 corners) -- which it did not before its threshold was taken from the maximum under the mask.
 FAST stays unpinned.  The GPU kernels are tested against THIS file (synthetic frames and the
 real ones) and against analytic properties of synthetic frames (known shifts, known corner positions).
 """
@@ -73,7 +73,7 @@ def good_features_to_track(img, max_corners, quality_level, min_distance, mask=N
     H, W = eig.shape
     # the maximum under the mask: featureselect.cpp (2.4) `minMaxLoc(eig, 0, &maxVal, 0, 0, mask)` -- found from the reference's own
     # example run (round 4): with the whole image's maximum frame 0 of the ICL-NUIM sequence yields 216 corners where slam2.py's
-    # record shows the full quota of 277 (tests/test_icl_nuim.py)
+    # record shows at least 273 (tests/test_icl_nuim.py)
     thr = F(eig.max() if mask is None else (eig[mask != 0].max() if np.any(mask != 0) else 0.0)) * F(quality_level)
     e = np.where(eig > thr, eig, F(0))                       # threshold(..., THRESH_TOZERO)
     q = np.pad(e, 1, mode="constant", constant_values=-np.inf)   # dilate ignores pixels outside the image

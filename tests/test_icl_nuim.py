@@ -91,8 +91,8 @@ def start_mask(seq):
 
 def test_oracle_detector_fills_the_reference_s_quota_on_the_first_frame(seq):
     """slam2.py:1172-1174 asks goodFeaturesToTrack for 300 - 23 = 277 corners outside the discs around the 23 initial points, and
-    the reference's record of this run (BA_info.measurements.point2D3DAssocs: 296 tracked points in frame 0, the 23 initial ones
-    among them) shows it got at least 273.  The quality threshold is relative to the largest response UNDER THE MASK (OpenCV 2.4
+    the reference's record of a run on this sequence (BA_info.measurements.point2D3DAssocs: 296 tracked points in frame 0, the 23
+    initial ones among them) shows it got at least 273.  The quality threshold is relative to the largest response UNDER THE MASK (OpenCV 2.4
     featureselect.cpp: minMaxLoc(eig, 0, &maxVal, 0, 0, mask)); relative to the whole image's maximum -- the strongest corners are
     the masked ones -- this frame has 216 candidates at the 12 px spacing."""
     from oracle import features_np as Fn
