@@ -632,7 +632,9 @@ int64_t mqs_fast_workspace_bytes(int W, int H);
  *   mqs_slam_set_thresholds   the gates of slam2.py:1070-1098 and max_homography_points: keyframe_test's random sample of the
  *                    tracks (slam2.py:48) -- 0 (the default after mqs_slam_create): the homography is fitted to ALL kept
  *                    tracks; k >= 4: to a uniformly random k of them, drawn from the handle's counter-based generator
- *                    (the reference's rule is k = max(4, target_keypoints / 4), slam2.py:1088-1089).
+ *                    (the reference's rule is k = max(4, target_keypoints / 4), slam2.py:1088-1089).  The homography itself is
+ *                    cv2.findHomography(method = 0) (slam2.py:54): normalised DLT, then -- with more than four pairs -- the
+ *                    Levenberg-Marquardt refinement of the transfer error (OpenCV 2.4 fundam.cpp: estimator.refine(M, m, H, 10)).
  * ------------------------------------------------------------------------------------- */
 typedef struct mqs_slam mqs_slam;
 int mqs_slam_create(int device, int W, int H, const double *intr, int target_keypoints, double coverage_radius,

@@ -77,6 +77,7 @@ struct SlamParams {
     double radius, quality;
     double max_of_error, max_lost_ratio, max_reproj, max_outlier_ratio, homography_threshold;
     unsigned long long seed;
+    int homography_refine;          // 1 (default): DLT + the LM refinement, as cv2.findHomography(method = 0); 0: the DLT alone (A/B)
     int max_homography_points;      // keyframe_test's random sample (slam2.py:48; the reference: max(4, target / 4), :1088-1089); 0 = all tracks (default)
     int pose_index, base_pose_index; // index this frame gets among the ACCEPTED frames if it is accepted; that of the base keyframe
 };
@@ -260,6 +261,132 @@ __device__ void jacobi3(double *a, double *w)
 }
 
 // sum over the workgroup, the same value in every thread, fixed order (wave butterflies, then the four waves in order)
+// The second half of cv2.findHomography(method = 0) (OpenCV 2.4 fundam.cpp: `estimator.refine(M, m, &matH, 10)` whenever there are
+// more than four pairs): Levenberg-Marquardt on the eight free entries of H (h33 = 1) over the transfer error
+// sum |u2 - proj(H u1)|^2 with CvLevMarq's schedule -- lambda 1e-3, J^T J with its diagonal scaled by (1 + lambda), a step that
+// raises the error retried with lambda x 10, an accepted one divides lambda by 10, at most ten accepted steps (OpenCV stops
+// early only below DBL_EPSILON; here below 1e-12 relative: slam_loop.homography_refine, the host twin).  ONE wavefront: the pairs
+// dealt over the lanes, the 29 distinct sums of J^T J, J^T r in one transposed wave reduction, the 8 x 8 system solved by every
+// lane (uniform control flow, no barrier).  sH [9]: H on entry (h33 = 1) and on return; sT [32]: scratch.
+__device__ void homography_refine_wave(const double *__restrict__ u1, const double *__restrict__ u2, int n, double *sH, double *sT, int lane)
+{
+    double h[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) h[i] = sH[i];
+    auto transfer_error = [&](const double (&g)[8]) {
+        double e = 0.0;
+        for (int k = lane; k < n; k += 64) {
+            const double ax = u1[2 * k], ay = u1[2 * k + 1];
+            const double w = 1.0 / fma(g[6], ax, fma(g[7], ay, 1.0));
+            const double rx = fma(g[0], ax, fma(g[1], ay, g[2])) * w - u2[2 * k], ry = fma(g[3], ax, fma(g[4], ay, g[5])) * w - u2[2 * k + 1];
+            e = fma(rx, rx, fma(ry, ry, e));
+        }
+        double s, unused;
+        mqs::wave::sum2(e, 0.0, s, unused);
+        return s;
+    };
+    double err = transfer_error(h);
+    int lam = -3;
+    for (int it = 0; it < 10; ++it) {
+        double v[32];
+#pragma unroll
+        for (int e = 0; e < 32; ++e) v[e] = 0.0;
+        for (int k = lane; k < n; k += 64) {
+            const double ax = u1[2 * k], ay = u1[2 * k + 1];
+            const double w = 1.0 / fma(h[6], ax, fma(h[7], ay, 1.0));
+            const double x = fma(h[0], ax, fma(h[1], ay, h[2])) * w, y = fma(h[3], ax, fma(h[4], ay, h[5])) * w;
+            const double rx = x - u2[2 * k], ry = y - u2[2 * k + 1];
+            // rows of J: [a0 a1 a2 0 0 0 c0 c1] (x) and [0 0 0 a0 a1 a2 d0 d1] (y)
+            const double a0 = ax * w, a1 = ay * w, a2 = w, c0 = -a0 * x, c1 = -a1 * x, d0 = -a0 * y, d1 = -a1 * y;
+            v[0] = fma(a0, a0, v[0]); v[1] = fma(a0, a1, v[1]); v[2] = fma(a0, a2, v[2]);
+            v[3] = fma(a1, a1, v[3]); v[4] = fma(a1, a2, v[4]); v[5] = fma(a2, a2, v[5]);
+            v[6] = fma(a0, c0, v[6]); v[7] = fma(a0, c1, v[7]); v[8] = fma(a1, c0, v[8]);
+            v[9] = fma(a1, c1, v[9]); v[10] = fma(a2, c0, v[10]); v[11] = fma(a2, c1, v[11]);
+            v[12] = fma(a0, d0, v[12]); v[13] = fma(a0, d1, v[13]); v[14] = fma(a1, d0, v[14]);
+            v[15] = fma(a1, d1, v[15]); v[16] = fma(a2, d0, v[16]); v[17] = fma(a2, d1, v[17]);
+            v[18] = fma(c0, c0, fma(d0, d0, v[18])); v[19] = fma(c0, c1, fma(d0, d1, v[19])); v[20] = fma(c1, c1, fma(d1, d1, v[20]));
+            v[21] = fma(a0, rx, v[21]); v[22] = fma(a1, rx, v[22]); v[23] = fma(a2, rx, v[23]);
+            v[24] = fma(a0, ry, v[24]); v[25] = fma(a1, ry, v[25]); v[26] = fma(a2, ry, v[26]);
+            v[27] = fma(c0, rx, fma(d0, ry, v[27])); v[28] = fma(c1, rx, fma(d1, ry, v[28]));
+        }
+        const double t = mqs::wave::wave_reduce32(v, lane);
+        mqs_wave_lds_sync();                                  // (the previous round's readers of sT are done)
+        if (!(lane & 1)) sT[lane >> 1] = t;
+        mqs_wave_lds_sync();
+        double A[8][8], g[8];
+        {
+            const double S[3][3] = {{sT[0], sT[1], sT[2]}, {sT[1], sT[3], sT[4]}, {sT[2], sT[4], sT[5]}};
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) { A[i][j] = S[i][j]; A[3 + i][3 + j] = S[i][j]; A[i][3 + j] = 0.0; A[3 + i][j] = 0.0; }
+                A[i][6] = A[6][i] = sT[6 + 2 * i]; A[i][7] = A[7][i] = sT[7 + 2 * i];
+                A[3 + i][6] = A[6][3 + i] = sT[12 + 2 * i]; A[3 + i][7] = A[7][3 + i] = sT[13 + 2 * i];
+            }
+            A[6][6] = sT[18]; A[6][7] = A[7][6] = sT[19]; A[7][7] = sT[20];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) g[i] = sT[21 + i];
+        }
+        bool accepted = false;
+        double hn[8], err2 = 0.0, dn = 0.0;
+        while (lam <= 16) {
+            double scale = 1.0;
+            for (int q = 0; q < (lam < 0 ? -lam : lam); ++q) scale *= 10.0;
+            const double damp = 1.0 + (lam < 0 ? 1.0 / scale : scale);
+            // Cholesky of A with the diagonal scaled, in place in a copy; the step solves (A + lambda diag A) step = g
+            double Lm[8][8], yv[8], st[8];
+            bool pd = true;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+#pragma unroll
+                for (int j = 0; j <= i; ++j) {
+                    double sacc = (i == j) ? A[i][i] * damp : A[i][j];
+#pragma unroll
+                    for (int q = 0; q < j; ++q) sacc = fma(-Lm[i][q], Lm[j][q], sacc);
+                    if (i == j) { pd = pd && (sacc > 0.0); Lm[i][i] = sqrt(sacc > 0.0 ? sacc : 1.0); }
+                    else Lm[i][j] = sacc / Lm[j][j];
+                }
+            }
+            if (!pd) { ++lam; continue; }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                double sacc = g[i];
+#pragma unroll
+                for (int q = 0; q < i; ++q) sacc = fma(-Lm[i][q], yv[q], sacc);
+                yv[i] = sacc / Lm[i][i];
+            }
+#pragma unroll
+            for (int i = 7; i >= 0; --i) {
+                double sacc = yv[i];
+#pragma unroll
+                for (int q = i + 1; q < 8; ++q) sacc = fma(-Lm[q][i], st[q], sacc);
+                st[i] = sacc / Lm[i][i];
+            }
+            dn = 0.0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { hn[i] = h[i] - st[i]; dn = fma(st[i], st[i], dn); }
+            err2 = transfer_error(hn);
+            if (!(err2 <= err)) { ++lam; continue; }
+            accepted = true;
+            break;
+        }
+        if (!accepted) break;
+        double hh = 0.0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { hh = fma(h[i], h[i], hh); h[i] = hn[i]; }
+        err = err2;
+        lam = lam - 1 < -16 ? -16 : lam - 1;
+        if (dn < 1e-24 * hh) break;                           // relative step below 1e-12
+    }
+    mqs_wave_lds_sync();
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sH[i] = h[i];
+        sH[8] = 1.0;
+    }
+    mqs_wave_lds_sync();
+}
+
 __device__ __forceinline__ double block_sum(double v, int tid, double *sRed /*[4]*/)
 {
     v = mqs::wave::sum1(v);
@@ -281,7 +408,7 @@ __global__ __launch_bounds__(256) void frame_decide_kernel(SlamDev d, SlamParams
     __shared__ double sU1[kMaxTracks * 2], sU2[kMaxTracks * 2];
     __shared__ double sAcc[4][48];
     __shared__ double sA[81], sV[81];
-    __shared__ double sI[9], sP[12];
+    __shared__ double sI[9], sP[12], sH[9];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) { d.res[R_NTRACKS] = (double)d.cnt[C_N]; d.res[R_NLAND] = (double)d.cnt[C_NLAND]; d.cnt[C_FRAME] += 1; }
     if (d.res[R_DECISION] == 0.0) return;                          // rejected by the filter: the state is untouched
@@ -457,6 +584,15 @@ __global__ __launch_bounds__(256) void frame_decide_kernel(SlamDev d, SlamParams
                     h[3 + c] = t[3 + c] / s2 + c2y * t[6 + c];
                     h[6 + c] = t[6 + c];
                 }
+                const double i8 = 1.0 / h[8];                           // cvConvertScale(&_H0, H, 1. / _H0.data.db[8])
+                for (int i = 0; i < 9; ++i) sH[i] = h[i] * i8;
+            }
+            mqs_wave_lds_sync();
+            // ... then the refinement of the transfer error (findHomography's second half), the whole wave
+            if (n_acc > 4 && p.homography_refine) homography_refine_wave(sU1, sU2, n_acc, sH, sA, lane);
+            if (lane == 0) {
+                double h[9];
+                for (int i = 0; i < 9; ++i) h[i] = sH[i];
                 double gm[9], w[3];
                 for (int i = 0; i < 3; ++i)
                     for (int j = 0; j < 3; ++j) gm[3 * i + j] = h[i] * h[j] + h[3 + i] * h[3 + j] + h[6 + i] * h[6 + j];
@@ -717,7 +853,8 @@ int mqs_slam_create(int device, int W, int H, const double *intr, int target_key
     s->started = false;
     s->accepted = 0; s->base_pose = 0; s->log_arena = nullptr; s->re_arena = nullptr;
     s->p = SlamParams{W, H, target_keypoints, max_landmarks, coverage_radius, quality_level,
-                      12.0, 0.5, 2.0, 0.33, 1.04, (unsigned long long)seed, 0};     // slam2.py:1070-1098; keyframe test on ALL tracks
+                      12.0, 0.5, 2.0, 0.33, 1.04, (unsigned long long)seed, 1, 0};  // slam2.py:1070-1098; keyframe test on ALL tracks
+    if (const char *e = getenv("MQS_SLAM_HOMOGRAPHY_REFINE")) s->p.homography_refine = e[0] != '0';        // A/B: 0 = the DLT alone
     s->ws_lk_bytes = mqs_lk_workspace_bytes(W, H, 3);
     s->ws_gftt_bytes = mqs_gftt_workspace_bytes(W, H);
     const int64_t ws_pnp_bytes = mqs_pnp_workspace_bytes(kMaxTracks, kHyp);

@@ -59,7 +59,7 @@ def keypoint_mask(shape, points, radius=KEYPOINT_COVERAGE_RADIUS):
 
 
 def homography_dlt(p1, p2):
-    """Normalised DLT (least squares over all pairs): the estimator behind cv2.findHomography(method=0)."""
+    """Normalised DLT (least squares over all pairs): the first half of cv2.findHomography(method=0) (`find_homography`)."""
     def norm(p):
         c = p.mean(axis=0)
         s = np.sqrt(2.0) / max(np.mean(np.linalg.norm(p - c, axis=1)), 1e-12)
@@ -78,6 +78,71 @@ def homography_dlt(p1, p2):
     return H / H[2, 2]
 
 
+HOMOGRAPHY_REFINE_ITERATIONS = 10        # fundam.cpp (2.4): estimator.refine(M, m, &matH, 10)
+HOMOGRAPHY_REFINE_STOP = 1e-12           # relative step below which the remaining iterations change nothing that matters
+
+
+def homography_refine(H, p1, p2, max_iter=HOMOGRAPHY_REFINE_ITERATIONS):
+    """The second half of cv2.findHomography(method=0) (OpenCV 2.4 fundam.cpp: `estimator.refine(M, m, &matH, 10)` whenever there
+    are more than four pairs): Levenberg-Marquardt on the eight free entries of H (h33 = 1) over the transfer error
+    sum |p2 - proj(H p1)|^2, with CvLevMarq's schedule -- lambda 1e-3, (J^T J) with its diagonal scaled by (1 + lambda), a step
+    that raises the error is retried with lambda x 10, an accepted one divides lambda by 10, at most `max_iter` accepted steps.
+    OpenCV stops early only when the relative step falls below DBL_EPSILON (in practice never); here at 1e-12: the steps left
+    over move H by less than that.  With parallax between the two views the least-squares homography is a compromise, and the
+    algebraic (DLT) and geometric minimisers differ in the third digit of w0 / w2 -- the digit keyframe_test's 1.04 looks at."""
+    p1, p2 = np.asarray(p1, dtype=np.float64), np.asarray(p2, dtype=np.float64)
+    if len(p1) <= 4:
+        return H / H[2, 2]
+    h = (H / H[2, 2]).ravel()[:8].copy()
+
+    def transfer(h):
+        Hm = np.append(h, 1.0).reshape(3, 3)
+        q = np.c_[p1, np.ones(len(p1))] @ Hm.T
+        return q, (q[:, :2] / q[:, 2:3] - p2)
+
+    q, r = transfer(h)
+    err = float(np.sum(r * r))
+    lam_lg10 = -3
+    for _ in range(max_iter):
+        w = 1.0 / q[:, 2]
+        x, y = q[:, 0] * w, q[:, 1] * w
+        J = np.zeros((2 * len(p1), 8))
+        J[0::2, 0:2], J[0::2, 2] = p1 * w[:, None], w
+        J[0::2, 6:8] = -p1 * (x * w)[:, None]
+        J[1::2, 3:5], J[1::2, 5] = p1 * w[:, None], w
+        J[1::2, 6:8] = -p1 * (y * w)[:, None]
+        A, g = J.T @ J, J.T @ r.ravel()
+        accepted = False
+        while lam_lg10 <= 16:
+            An = A.copy()
+            An[np.diag_indices(8)] *= 1.0 + 10.0 ** lam_lg10
+            try:
+                step = np.linalg.solve(An, g)
+            except np.linalg.LinAlgError:
+                lam_lg10 += 1
+                continue
+            q2, r2 = transfer(h - step)
+            err2 = float(np.sum(r2 * r2))
+            if err2 > err:
+                lam_lg10 += 1
+                continue
+            accepted = True
+            break
+        if not accepted:
+            break
+        rel = float(np.linalg.norm(step) / max(np.linalg.norm(h), 1e-300))
+        h, q, r, err = h - step, q2, r2, err2
+        lam_lg10 = max(lam_lg10 - 1, -16)
+        if rel < HOMOGRAPHY_REFINE_STOP:
+            break
+    return np.append(h, 1.0).reshape(3, 3)
+
+
+def find_homography(p1, p2):
+    """cv2.findHomography(p1, p2) with method = 0 (slam2.py:54): normalised DLT, then the LM refinement of the transfer error."""
+    return homography_refine(homography_dlt(p1, p2), p1, p2)
+
+
 def keyframe_test(points1, points2, K, dist, max_points=None, rng=None):
     """slam2.py:43-59.  max_points / rng: the reference's random sample of the input points (:48,
     `np.random.permutation(len(points1))[:max_num_homography_points]`); rng is a `numpy.random.RandomState` -- the legacy
@@ -91,7 +156,7 @@ def keyframe_test(points1, points2, K, dist, max_points=None, rng=None):
         points1, points2 = points1[idxs], points2[idxs]
     u1 = camera.undistort_points(points1, K, dist)
     u2 = camera.undistort_points(points2, K, dist)
-    w = np.linalg.svd(homography_dlt(u1, u2), compute_uv=False)
+    w = np.linalg.svd(find_homography(u1, u2), compute_uv=False)
     return w[0] / w[2] > HOMOGRAPHY_CONDITION_THRESHOLD
 
 

