@@ -333,18 +333,23 @@ __device__ void homography_refine_wave(const double *__restrict__ u1, const doub
             double scale = 1.0;
             for (int q = 0; q < (lam < 0 ? -lam : lam); ++q) scale *= 10.0;
             const double damp = 1.0 + (lam < 0 ? 1.0 / scale : scale);
-            // Cholesky of A with the diagonal scaled, in place in a copy; the step solves (A + lambda diag A) step = g
-            double Lm[8][8], yv[8], st[8];
+            // Cholesky of A with the diagonal scaled; the step solves (A + lambda diag A) step = g.  Reciprocal square roots of the
+            // pivots, no division anywhere: the fifty fp64 divisions of the textbook form were most of the refinement's 30 us
+            double Lm[8][8], ri[8], yv[8], st[8];
             bool pd = true;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int j = 0; j < 8; ++j) {
+                double piv = A[j][j] * damp;
 #pragma unroll
-                for (int j = 0; j <= i; ++j) {
-                    double sacc = (i == j) ? A[i][i] * damp : A[i][j];
+                for (int q = 0; q < j; ++q) piv = fma(-Lm[j][q], Lm[j][q], piv);
+                pd = pd && (piv > 0.0);
+                ri[j] = rsqrt(piv > 0.0 ? piv : 1.0);
+#pragma unroll
+                for (int i = j + 1; i < 8; ++i) {
+                    double sacc = A[i][j];
 #pragma unroll
                     for (int q = 0; q < j; ++q) sacc = fma(-Lm[i][q], Lm[j][q], sacc);
-                    if (i == j) { pd = pd && (sacc > 0.0); Lm[i][i] = sqrt(sacc > 0.0 ? sacc : 1.0); }
-                    else Lm[i][j] = sacc / Lm[j][j];
+                    Lm[i][j] = sacc * ri[j];
                 }
             }
             if (!pd) { ++lam; continue; }
@@ -353,14 +358,14 @@ __device__ void homography_refine_wave(const double *__restrict__ u1, const doub
                 double sacc = g[i];
 #pragma unroll
                 for (int q = 0; q < i; ++q) sacc = fma(-Lm[i][q], yv[q], sacc);
-                yv[i] = sacc / Lm[i][i];
+                yv[i] = sacc * ri[i];
             }
 #pragma unroll
             for (int i = 7; i >= 0; --i) {
                 double sacc = yv[i];
 #pragma unroll
                 for (int q = i + 1; q < 8; ++q) sacc = fma(-Lm[q][i], st[q], sacc);
-                st[i] = sacc / Lm[i][i];
+                st[i] = sacc * ri[i];
             }
             dn = 0.0;
 #pragma unroll

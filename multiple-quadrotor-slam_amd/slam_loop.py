@@ -104,14 +104,17 @@ def homography_refine(H, p1, p2, max_iter=HOMOGRAPHY_REFINE_ITERATIONS):
     err = float(np.sum(r * r))
     lam_lg10 = -3
     for _ in range(max_iter):
+        # J^T J and J^T r from their 29 distinct sums (rows of J: [a 0 c] for x, [0 a d] for y with a = (p1, 1) / z, c = -a_xy x, d = -a_xy y)
         w = 1.0 / q[:, 2]
         x, y = q[:, 0] * w, q[:, 1] * w
-        J = np.zeros((2 * len(p1), 8))
-        J[0::2, 0:2], J[0::2, 2] = p1 * w[:, None], w
-        J[0::2, 6:8] = -p1 * (x * w)[:, None]
-        J[1::2, 3:5], J[1::2, 5] = p1 * w[:, None], w
-        J[1::2, 6:8] = -p1 * (y * w)[:, None]
-        A, g = J.T @ J, J.T @ r.ravel()
+        a = np.c_[p1 * w[:, None], w]
+        c, dd = -a[:, :2] * x[:, None], -a[:, :2] * y[:, None]
+        A = np.zeros((8, 8))
+        A[0:3, 0:3] = A[3:6, 3:6] = a.T @ a
+        A[0:3, 6:8], A[3:6, 6:8] = a.T @ c, a.T @ dd
+        A[6:8, 0:3], A[6:8, 3:6] = A[0:3, 6:8].T, A[3:6, 6:8].T
+        A[6:8, 6:8] = c.T @ c + dd.T @ dd
+        g = np.concatenate([a.T @ r[:, 0], a.T @ r[:, 1], c.T @ r[:, 0] + dd.T @ r[:, 1]])
         accepted = False
         while lam_lg10 <= 16:
             An = A.copy()
