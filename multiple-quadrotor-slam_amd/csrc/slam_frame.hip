@@ -688,7 +688,9 @@ __global__ __launch_bounds__(64) void coverage_disc_kernel(SlamDev d, SlamParams
 {
     const int k = blockIdx.x, lane = threadIdx.x;
     if (k >= d.cnt[C_N]) return;
-    const int cx = (int)rintf(d.pts[2 * k]), cy = (int)rintf(d.pts[2 * k + 1]);
+    // the centre as cv2.circle gets it from the reference's `tuple(p)` of float32 (cv2_helpers.py:26-27): the Python 2 binding parses
+    // a Point with "ii", which takes a float through __int__ -- truncation, not rounding
+    const int cx = (int)d.pts[2 * k], cy = (int)d.pts[2 * k + 1];
     const int r = (int)p.radius, side = 2 * r + 1;
     for (int e = lane; e < side * side; e += 64) {
         const int dy = e / side - r, dx = e % side - r;

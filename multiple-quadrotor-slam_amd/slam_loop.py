@@ -42,10 +42,12 @@ MAX_SOLVEPNP_OUTLIER_RATIO = 0.33
 
 
 def keypoint_mask(shape, points, radius=KEYPOINT_COVERAGE_RADIUS):
-    """slam2.py:29-40: ones with a filled disc of zeros around every point."""
+    """slam2.py:29-40: ones with a filled disc of zeros around every point.  The centre is truncated, as the Python 2 binding of
+    cv2.circle does with the float32 pair it is handed (a Point is parsed with "ii": a float goes through __int__); OpenCV's
+    filled circle of radius 12 (drawing.cpp: the midpoint algorithm) covers exactly the pixels with dx^2 + dy^2 <= 144."""
     H, W = shape
     mask = np.ones((H, W), dtype=np.uint8)
-    p = np.rint(np.asarray(points, dtype=np.float64).reshape(-1, 2)).astype(np.int64)
+    p = np.trunc(np.asarray(points, dtype=np.float64).reshape(-1, 2)).astype(np.int64)
     if len(p) == 0:
         return mask
     r = int(radius)

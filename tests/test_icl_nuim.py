@@ -85,7 +85,7 @@ def start_mask(seq):
     yy, xx = np.mgrid[0:H, 0:W]
     mask = np.ones((H, W), np.uint8)
     for p in uv:
-        mask[(xx - int(round(p[0]))) ** 2 + (yy - int(round(p[1]))) ** 2 <= 12 * 12] = 0
+        mask[(xx - int(p[0])) ** 2 + (yy - int(p[1])) ** 2 <= 12 * 12] = 0          # cv2.circle through the Python 2 binding: truncated centre
     return mask
 
 
