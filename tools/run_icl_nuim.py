@@ -56,7 +56,7 @@ def run(frames=None, bundle_adjust=None, seed=0, device=True, reassociate=False)
         for k in range(1, n):
             rets.append(slam.handle_new_frame(imgs_h[k]))
     dt = time.perf_counter() - t0
-    c = np.array([(-P[:, :3].T @ P[:, 3]) if P is not None else [np.nan] * 3 for P in slam.poses])
+    c = np.array([(-P[:, :3].T @ P[:, 3]) if P is not None else [np.nan] * 3 for P in slam.projection_matrices()])
     ok = np.isfinite(c[:, 0])
     ref, gt = centres_from_tum(d["traj_slam2"][:n]), centres_from_tum(d["traj_groundtruth"][:n])
     err = lambda a, b: np.linalg.norm(a - b, axis=1)
