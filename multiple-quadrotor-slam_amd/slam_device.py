@@ -111,6 +111,12 @@ class DeviceMonoSlam:
         self.ba_gross_pixels = 40.0      # ... and with one beyond this BEFORE the adjustment it does not enter it
         self.ba_max_passes = 4           # adjust, screen, adjust again from the same start: at most this many adjustments
         self.ba_min_depth_ratio = 0.02   # a landmark closer to one of its cameras than this fraction of the median landmark depth sits out
+        # the noise models of the adjustment (the reference keeps them in the four BA_info.noise.* files beside a recording; its
+        # ICL-NUIM run: point3D 0.2, pose (0.02 x 3, 0.1 x 3), odometry (0.05 x 3, 0.2 x 3), point2D 1.0)
+        self.ba_point_sigma = 0.25                                  # prior on the start-up landmarks (bundle_adjust.cpp:277-281)
+        self.ba_pose_sigmas = (0.002, 0.002, 0.002, 0.001, 0.001, 0.001)     # prior on the first pose (:273), rotation then translation
+        self.ba_odometry_sigmas = (0.05, 0.05, 0.05, 0.2, 0.2, 0.2)  # between-factors keyframe -> keyframe (:301-309)
+        self.ba_pixel_sigma = 1.0
         self._ba_bad = np.zeros(0, bool)
         self.reassociate = bool(reassociate)
         self.poses_online = []           # with bundle_adjust: the pose of each frame as first estimated (poses: adjusted)
@@ -292,7 +298,7 @@ class DeviceMonoSlam:
         prior_xyz[:self._n0] = self._objp0
         calib = np.array([[self.K[0, 0], self.K[1, 1], self.K[0, 1], self.K[0, 2], self.K[1, 2], self.dist[0], self.dist[1],
                            self.dist[2], self.dist[3]]])
-        prior_w = np.where(np.arange(N) < self._n0, 1.0 / 0.25 ** 2, 0.0)                        # noise.point3D of the reference's runs
+        prior_w = np.where(np.arange(N) < self._n0, 1.0 / self.ba_point_sigma ** 2, 0.0)        # noise.point3D of the reference's runs
         per_lm = np.bincount(lm, minlength=N)
         t1 = time.perf_counter()
         passes, dropped, hist_all = 0, 0, None
@@ -310,11 +316,11 @@ class DeviceMonoSlam:
             order = np.argsort(l2, kind="stable")
             ptr = np.concatenate([[0], np.cumsum(np.bincount(l2, minlength=N))]).astype(np.int64)
             problem = ba_io.SparseProblem(
-                poses=poses, pose_cam=np.zeros(P, np.int32), pose_key=[(0, f) for f in self._accepted], calib=calib, sigma=np.array([1.0]),
+                poses=poses, pose_cam=np.zeros(P, np.int32), pose_key=[(0, f) for f in self._accepted], calib=calib, sigma=np.array([float(self.ba_pixel_sigma)]),
                 points=pts.copy(), obs_ptr=ptr, obs_pose=p2[order].astype(np.int32), obs_uv=u2[order], prior_w=prior_w, prior_xyz=prior_xyz,
-                pose_prior_idx=np.array([0], np.int32), pose_prior_sigmas=np.array([[0.002] * 3 + [0.001] * 3]),
+                pose_prior_idx=np.array([0], np.int32), pose_prior_sigmas=np.array([list(self.ba_pose_sigmas)], dtype=np.float64),
                 odo_from=np.array([o[0] for o in self._odo], np.int32), odo_to=np.array([o[1] for o in self._odo], np.int32),
-                odo_meas=np.array([o[2] for o in self._odo]).reshape(-1, 12), odo_sigmas=np.tile([0.05, 0.05, 0.05, 0.2, 0.2, 0.2], (len(self._odo), 1)))
+                odo_meas=np.array([o[2] for o in self._odo]).reshape(-1, 12), odo_sigmas=np.tile(np.asarray(self.ba_odometry_sigmas, dtype=np.float64), (len(self._odo), 1)))
             ba = sparse_ba.SparseBundleAdjuster(problem, device="cuda:%d" % self._device)
             if not screened_at_start:
                 # before anything is adjusted: an observation that misses the CURRENT estimate by tens of pixels is not noise the

@@ -20,6 +20,20 @@ def centres_from_tum(rows):
     return np.asarray(rows)[:, 1:4].copy()
 
 
+def rotations_from_tum(rows):
+    """World -> camera rotation of every TUM row (the file holds the camera's orientation IN the world: the transpose)."""
+    q = np.asarray(rows)[:, 4:8]
+    x, y, z, w = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    R = np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w), 2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+                  2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], axis=1).reshape(-1, 3, 3)
+    return np.transpose(R, (0, 2, 1))
+
+
+def angle_deg(Ra, Rb):
+    c = (np.einsum("nij,nij->n", Ra, Rb) - 1.0) / 2.0
+    return np.degrees(np.arccos(np.clip(c, -1.0, 1.0)))
+
+
 def start_points(K, shape, P_init, pts):
     """slam2.py:1054-1059: the predefined points projected through the initial pose, the visible ones kept (no rounding)."""
     X = np.c_[pts, np.ones(len(pts))] @ P_init[:3].T @ K.T
@@ -60,6 +74,8 @@ def run(frames=None, bundle_adjust=None, seed=0, device=True, reassociate=False)
     ok = np.isfinite(c[:, 0])
     ref, gt = centres_from_tum(d["traj_slam2"][:n]), centres_from_tum(d["traj_groundtruth"][:n])
     err = lambda a, b: np.linalg.norm(a - b, axis=1)
+    Rs = np.array([P[:, :3] if P is not None else np.eye(3) for P in slam.projection_matrices()])
+    Rref, Rgt = rotations_from_tum(d["traj_slam2"][:n]), rotations_from_tum(d["traj_groundtruth"][:n])
     path = float(np.sum(np.linalg.norm(np.diff(gt, axis=0), axis=1)))
     out = {"frames": n, "accepted": int(ok.sum()), "keyframes": int(sum(1 for r in rets if r == 2)), "landmarks": int(len(slam.objp)),
            "keyframe_frames": [k for k, r in enumerate(rets) if r == 2],
@@ -68,6 +84,9 @@ def run(frames=None, bundle_adjust=None, seed=0, device=True, reassociate=False)
            "ours_vs_groundtruth_max_m": round(float(err(c[ok], gt[ok]).max()), 5),
            "reference_vs_groundtruth_rmse_m": round(float(np.sqrt(np.mean(err(ref, gt) ** 2))), 5),
            "reference_vs_groundtruth_max_m": round(float(err(ref, gt).max()), 5),
+           "orientation_rmse_deg": {"ours_vs_groundtruth": round(float(np.sqrt(np.mean(angle_deg(Rs[ok], Rgt[ok]) ** 2))), 4),
+                                    "reference_vs_groundtruth": round(float(np.sqrt(np.mean(angle_deg(Rref, Rgt) ** 2))), 4),
+                                    "ours_vs_reference": round(float(np.sqrt(np.mean(angle_deg(Rs[ok], Rref[ok]) ** 2))), 4)},
            "ours_vs_reference_rmse_m": round(float(np.sqrt(np.mean(err(c[ok], ref[ok]) ** 2))), 5),
            "ours_vs_reference_max_m": round(float(err(c[ok], ref[ok]).max()), 5),
            "every_10th_frame_ours_ref_gt_error_mm": [[k, round(1e3 * float(err(c[k:k + 1], gt[k:k + 1])[0]), 2), round(1e3 * float(err(ref[k:k + 1], gt[k:k + 1])[0]), 2)]
