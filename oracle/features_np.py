@@ -20,8 +20,8 @@ tests/golden/make_icl_nuim.py):
   * calc_optical_flow_pyr_lk tracks the 23 known corners through the real, noisy frames to where the exact trajectory projects
     them: median 0.03-0.05 px, 90th percentile 0.09-0.16 px over five frames;
   * the loop built on the GPU twins of these functions reproduces the reference's committed trajectory frame by frame within
-    what either keeps from the exact one for two of four RANSAC seeds (4.2-4.4 mm rmse over the 80 frames of the fixture; the
-    reference's own 4.4 mm), and with the bundle adjustment per keyframe for all four;
+    about what either keeps from the exact one (4.3-10.9 mm rmse over the 80 frames of the fixture across four RANSAC seeds;
+    the reference's own 4.4 mm);
   * good_features_to_track fills slam2.py's quota on frame 0 (277 corners beside the 23 initial points: the reference's record of
     a run on this sequence shows 296 tracked points there, i.e. at least 273 corners) -- which it did not before its threshold was taken from the maximum under the mask.
 FAST stays unpinned.  The GPU kernels are tested against THIS file (synthetic frames and the
