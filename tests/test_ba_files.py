@@ -472,6 +472,50 @@ def test_the_optimiser_inside_the_library_takes_the_host_loop_s_steps(case, gpu)
 
 
 @pytest.mark.gpu
+def test_the_optimiser_inside_the_library_at_its_edges(gpu):
+    """mqs_sba_optimize_lm_dev with nothing to do and with parts of the problem absent: zero iterations return the start cost and
+    move nothing; a converged estimate is left where it is; no odometry, no pose prior (the gauge then rests on the point priors),
+    a landmark without observations -- each equals the host loop; a non-positive lambda factor is refused."""
+    import ctypes
+    fn, data = load(gpu, EX, "synthetic", 2, 1)
+    pr = gpu.ba_io.build_sparse_problem(data, use_odometry=True)
+    SB = gpu.sparse_ba.SparseBundleAdjuster
+    a = SB(pr)
+    p0, x0 = a.poses.clone(), a.points.clone()
+    c0 = a.cost()
+    assert a.optimize(iters=0, mode="lm") == [pytest.approx(c0, rel=1e-12)]
+    assert bool((a.poses == p0).all()) and bool((a.points == x0).all())
+    h = a.optimize(mode="lm")
+    again = a.optimize(mode="lm")                                                # converged: at most one more small step
+    assert len(again) <= 2 and again[-1] <= h[-1] * (1 + 1e-9)
+    # parts absent
+    ptr = np.asarray(pr.obs_ptr).copy()
+    variants = {
+        "no odometry": pr._replace(odo_from=pr.odo_from[:0], odo_to=pr.odo_to[:0], odo_meas=pr.odo_meas[:0], odo_sigmas=pr.odo_sigmas[:0]),
+        "no pose prior": pr._replace(pose_prior_idx=pr.pose_prior_idx[:0], pose_prior_sigmas=pr.pose_prior_sigmas[:0]),
+        "a landmark nobody sees": pr._replace(points=np.vstack([pr.points, [[1.0, 2.0, 3.0]]]), obs_ptr=np.append(ptr, ptr[-1]),
+                                              prior_w=None if pr.prior_w is None else np.append(pr.prior_w, 0.0),
+                                              prior_xyz=None if pr.prior_xyz is None else np.vstack([pr.prior_xyz, [[0.0, 0.0, 0.0]]])),
+    }
+    rng = np.random.default_rng(9)
+    for name, q in variants.items():
+        q = q._replace(points=q.points + 0.004 * rng.standard_normal(q.points.shape))
+        u, v = SB(q), SB(q)
+        hu, hv = u.optimize(mode="lm"), v.optimize_host_loop(mode="lm")
+        assert len(hu) == len(hv) and len(hu) >= 2, name
+        np.testing.assert_allclose(hu, hv, rtol=1e-9, err_msg=name)
+        assert np.abs(u.poses.cpu().numpy() - v.poses.cpu().numpy()).max() < 1e-8, name
+    assert np.abs(u.points.cpu().numpy()[-1] - q.points[-1]).max() == 0.0        # the unseen landmark stays where it was
+    # refused arguments
+    lm = gpu.sparse_ba._LmParams(lambda_initial=1e-5, lambda_factor=1.0, lambda_upper=1e5, abs_tol=1e-5, rel_tol=1e-5, max_iterations=10, damping=0)
+    prd = a._problem_struct()
+    hist = np.zeros(11)
+    n = ctypes.c_int32(0)
+    rc = gpu._lib.lib().mqs_sba_optimize_lm_dev(ctypes.byref(prd), ctypes.byref(lm), hist.ctypes.data_as(gpu._lib.c_f64p), 11, ctypes.byref(n), None)
+    assert rc == -1                                                               # MQS_E_ARG
+
+
+@pytest.mark.gpu
 def test_worst_residual_per_landmark_equals_the_host_projection(gpu):
     """`mqs_sba_worst_residual_dev` (the screen either side of an adjustment in the SLAM loop) against the numpy projection that
     tests/test_slam_loop.py pins to the oracle: per landmark the largest pixel residual; +inf behind a camera; 0 without observations."""
