@@ -52,7 +52,7 @@ def _reprojection_residuals(poses_c2w, points, calib, lm, pose_idx, uv):
 class DeviceMonoSlam:
     def __init__(self, cameraMatrix, distCoeffs, image_shape, seed=0, device=0, max_landmarks=1 << 16, verbose=False,
                  ba_info=None, max_homography_points=0, bundle_adjust=None, ba_iterations=10, ba_log_capacity=1 << 20,
-                 reassociate=False):
+                 reassociate=False, ba_window_keyframes=None):
         """max_homography_points: size of keyframe_test's random sample of the tracks (slam2.py:48): 0 = every track (default),
         "reference" = the reference's max(4, target_amount_keypoints / 4) (:1088-1089).  On the rendered test sequence the quarter
         makes the run depend on the draw -- trajectory RMSE 0.017-0.020 for half of the seeds, 0.057-0.068 for the other half,
@@ -65,6 +65,8 @@ class DeviceMonoSlam:
         the adjusted landmarks and poses go back into the loop's live state (`mqs_slam_write_back`), so the next frames are
         tracked against the adjusted map.  `poses` then holds the ADJUSTED pose of every accepted frame up to the last
         keyframe; `poses_online` keeps each frame's pose as it was first estimated.
+        ba_window_keyframes=K (>= 2): the adjustment takes the frames since the K-th keyframe from the end instead of every frame so
+        far, anchored by tight pose priors on the window's first two keyframes -- the cost of an adjustment stops growing with the run.
         reassociate=True: behind every keyframe's top-up the new corners are matched (BFMatcher.radiusMatch on pixel positions +
         ratio test + one match per corner: the reference's match_OF_based, slam.py:81-127, cv2_helpers.py:296-339) against the
         PROJECTIONS of the landmarks that are in the map but not tracked any more; a matched corner takes its landmark up again
@@ -117,6 +119,8 @@ class DeviceMonoSlam:
         self.ba_pose_sigmas = (0.002, 0.002, 0.002, 0.001, 0.001, 0.001)     # prior on the first pose (:273), rotation then translation
         self.ba_odometry_sigmas = (0.05, 0.05, 0.05, 0.2, 0.2, 0.2)  # between-factors keyframe -> keyframe (:301-309)
         self.ba_pixel_sigma = 1.0
+        self.ba_window_keyframes = ba_window_keyframes              # None: every frame so far; K >= 2: the frames since the K-th keyframe from the end
+        self.ba_window_point_sigma = 0.02                           # windowed: prior on a landmark the frames in front of the window have seen
         self._ba_bad = np.zeros(0, bool)
         self.reassociate = bool(reassociate)
         self.poses_online = []           # with bundle_adjust: the pose of each frame as first estimated (poses: adjusted)
@@ -292,17 +296,38 @@ class DeviceMonoSlam:
         N, P = len(pts), len(self._accepted)
         if len(self._ba_bad) < N:
             self._ba_bad = np.concatenate([self._ba_bad, np.zeros(N - len(self._ba_bad), bool)])
-        poses = np.stack([pose_from_world_to_camera(self.poses[f]) for f in self._accepted])
-        poses[0] = pose_from_world_to_camera(self._pose0)             # the pose prior sits at the initial value of pose 0 (bundle_adjust.cpp:273)
+        # the window: everything so far (the default: what the reference's tool adjusts), or -- ba_window_keyframes = K -- the frames
+        # since the K-th keyframe from the end, held in place by tight priors on the poses of the window's first two keyframes (their
+        # values are the previous adjustments' results; two poses fix the seven gauge freedoms of a monocular map, scale included).
+        # The cost of an adjustment then stops growing with the length of the run.
+        w0, anchors, seen_before = 0, [0], None
+        K_w = self.ba_window_keyframes
+        if K_w and len(self.keyframes) > K_w:
+            w0 = self._accepted.index(self.keyframes[-K_w])
+            anchors = [0, self._accepted.index(self.keyframes[-K_w + 1]) - w0] if K_w >= 2 else [0]
+            inside = ps >= w0
+            seen_before = np.bincount(lm[~inside], minlength=len(pts)) > 0           # landmarks the frames in front of the window have seen
+            lm, ps, uv = lm[inside], ps[inside] - w0, uv[inside]
+        P = P - w0
+        accepted_w = self._accepted[w0:]
+        poses = np.stack([pose_from_world_to_camera(self.poses[f]) for f in accepted_w])
+        if w0 == 0:
+            poses[0] = pose_from_world_to_camera(self._pose0)         # the pose prior sits at the initial value of pose 0 (bundle_adjust.cpp:273)
         prior_xyz = pts.copy()
         prior_xyz[:self._n0] = self._objp0
         calib = np.array([[self.K[0, 0], self.K[1, 1], self.K[0, 1], self.K[0, 2], self.K[1, 2], self.dist[0], self.dist[1],
                            self.dist[2], self.dist[3]]])
-        prior_w = np.where(np.arange(N) < self._n0, 1.0 / self.ba_point_sigma ** 2, 0.0)        # noise.point3D of the reference's runs
+        n0_w = self._n0 if w0 == 0 else 0                            # the start-up landmarks are the gauge only while frame 0 is in the window
+        prior_w = np.where(np.arange(N) < n0_w, 1.0 / self.ba_point_sigma ** 2, 0.0)             # noise.point3D of the reference's runs
+        if seen_before is not None and self.ba_window_point_sigma:
+            # what the frames in front of the window know about a landmark stays with it as a prior at its adjusted value: two anchor
+            # poses alone leave the scale of a monocular window to drift (measured: 54-97 mm over 200 frames against 5 mm)
+            prior_w = np.where(seen_before[:N], 1.0 / self.ba_window_point_sigma ** 2, prior_w)
         per_lm = np.bincount(lm, minlength=N)
+        odo = [(a - w0, b - w0, m) for a, b, m in self._odo if a >= w0 and b >= w0]
         t1 = time.perf_counter()
         passes, dropped, hist_all = 0, 0, None
-        movable = np.arange(N) >= self._n0
+        movable = np.arange(N) >= n0_w
         screened_at_start = not self.ba_gross_pixels
         while True:
             # a landmark joins the adjustment once it has been seen from a THIRD frame (fresh from its triangulation it constrains
@@ -316,11 +341,11 @@ class DeviceMonoSlam:
             order = np.argsort(l2, kind="stable")
             ptr = np.concatenate([[0], np.cumsum(np.bincount(l2, minlength=N))]).astype(np.int64)
             problem = ba_io.SparseProblem(
-                poses=poses, pose_cam=np.zeros(P, np.int32), pose_key=[(0, f) for f in self._accepted], calib=calib, sigma=np.array([float(self.ba_pixel_sigma)]),
+                poses=poses, pose_cam=np.zeros(P, np.int32), pose_key=[(0, f) for f in accepted_w], calib=calib, sigma=np.array([float(self.ba_pixel_sigma)]),
                 points=pts.copy(), obs_ptr=ptr, obs_pose=p2[order].astype(np.int32), obs_uv=u2[order], prior_w=prior_w, prior_xyz=prior_xyz,
-                pose_prior_idx=np.array([0], np.int32), pose_prior_sigmas=np.array([list(self.ba_pose_sigmas)], dtype=np.float64),
-                odo_from=np.array([o[0] for o in self._odo], np.int32), odo_to=np.array([o[1] for o in self._odo], np.int32),
-                odo_meas=np.array([o[2] for o in self._odo]).reshape(-1, 12), odo_sigmas=np.tile(np.asarray(self.ba_odometry_sigmas, dtype=np.float64), (len(self._odo), 1)))
+                pose_prior_idx=np.array(anchors, np.int32), pose_prior_sigmas=np.tile(np.asarray(self.ba_pose_sigmas, dtype=np.float64), (len(anchors), 1)),
+                odo_from=np.array([o[0] for o in odo], np.int32), odo_to=np.array([o[1] for o in odo], np.int32),
+                odo_meas=np.array([o[2] for o in odo]).reshape(-1, 12), odo_sigmas=np.tile(np.asarray(self.ba_odometry_sigmas, dtype=np.float64), (len(odo), 1)))
             ba = sparse_ba.SparseBundleAdjuster(problem, device="cuda:%d" % self._device)
             if not screened_at_start:
                 # before anything is adjusted: an observation that misses the CURRENT estimate by tens of pixels is not noise the
@@ -363,13 +388,13 @@ class DeviceMonoSlam:
         new_poses, new_pts = ba.poses.cpu().numpy(), ba.points.cpu().numpy()
         new_pts[~use] = pts[~use]                                    # landmarks that sat out keep their values
         t2 = time.perf_counter()
-        for k, f in enumerate(self._accepted):                       # camera-to-world pose12 -> [R | t] world -> camera
+        for k, f in enumerate(accepted_w):                           # camera-to-world pose12 -> [R | t] world -> camera
             R, c = new_poses[k, :9].reshape(3, 3), new_poses[k, 9:]
             self.poses[f] = np.hstack([R.T, (-R.T @ c)[:, None]])
         last = np.ascontiguousarray(self.poses[self._accepted[-1]], dtype=np.float64)
         _lib.check(_lib.lib().mqs_slam_write_back(self._h, np.ascontiguousarray(new_pts).ctypes.data_as(_lib.c_f64p), N,
                                                   last.ctypes.data_as(_lib.c_f64p), last.ctypes.data_as(_lib.c_f64p)))
-        self.ba_reports.append({"frame": self._accepted[-1], "poses": P, "landmarks": N, "landmarks_adjusted": int(use.sum()),
+        self.ba_reports.append({"frame": self._accepted[-1], "poses": P, "first_pose_of_the_window": w0, "landmarks": N, "landmarks_adjusted": int(use.sum()),
                                 "observations": int(keep.sum()), "passes": passes, "landmarks_screened_out": dropped,
                                 "lm_iterations": len(hist_all) - 1, "cost_before": hist_all[0], "cost_after": hist_all[-1],
                                 "build_ms": round(1e3 * (t1 - t0), 3), "adjust_ms": round(1e3 * (t2 - t1), 3),

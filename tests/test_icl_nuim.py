@@ -169,6 +169,20 @@ def test_loop_with_adjustment_per_keyframe_on_the_example_sequence(gpu):
 
 
 @pytest.mark.gpu
+def test_windowed_adjustment_on_the_example_sequence(gpu):
+    """ba_window_keyframes: the adjustment over the frames since the K-th keyframe from the end (anchored by pose priors on the
+    window's first two keyframes and by priors on the landmarks the frames in front of it have seen) instead of over every frame so
+    far -- bounded cost per keyframe; measured over 200 frames with K = 10: 5.0-9.6 mm from the exact trajectory against 5.1-6.1 mm
+    for the full adjustment, 4-5 ms per adjustment at the end of the run against 11-35 (profiles/r04/20)."""
+    import run_icl_nuim
+    full = run_icl_nuim.run(80, bundle_adjust="keyframe", seed=3)
+    win = run_icl_nuim.run(80, bundle_adjust="keyframe", seed=3, window=3)
+    assert win["accepted"] == 80 and win["keyframes"] >= 5
+    assert win["poses_in_the_last_adjustment"] < 0.7 * full["poses_in_the_last_adjustment"]
+    assert win["ours_vs_groundtruth_rmse_m"] < 0.02 and win["ours_vs_groundtruth_rmse_m"] < full["ours_vs_groundtruth_rmse_m"] + 0.01
+
+
+@pytest.mark.gpu
 def test_keyframe_test_ratio_of_the_device_loop_is_find_homography_s(seq, gpu, monkeypatch):
     """keyframe_test (slam2.py:43-59) inside the device loop on the real tracks: the ratio w0 / w2 the decision kernel reports is
     that of cv2.findHomography(method = 0) as restated on the host -- normalised DLT, then the Levenberg-Marquardt refinement of the

@@ -4,7 +4,7 @@ build's device-resident loop, against what the reference COMMITTED as that run's
 slam2.py with OpenCV 2.4's goodFeaturesToTrack / calcOpticalFlowPyrLK / solvePnPRansac) and against the renderer's exact
 trajectory.  Reads the fixture tests/golden/icl_nuim_traj3n/sequence.npz (tests/golden/make_icl_nuim.py).
 
-    python tools/run_icl_nuim.py [frames] [--ba] [--host] [--seed S]
+    python tools/run_icl_nuim.py [frames] [--ba [--window K]] [--host] [--seed S]
 """
 import os, sys, json, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -42,7 +42,7 @@ def start_points(K, shape, P_init, pts):
     return uv, vis
 
 
-def run(frames=None, bundle_adjust=None, seed=0, device=True, reassociate=False):
+def run(frames=None, bundle_adjust=None, seed=0, device=True, reassociate=False, window=None):
     import torch
     d = np.load(FIX)
     imgs_h = d["frames"] if frames is None else d["frames"][:frames]
@@ -56,7 +56,7 @@ def run(frames=None, bundle_adjust=None, seed=0, device=True, reassociate=False)
         imgs = [torch.from_numpy(np.ascontiguousarray(f)).cuda() for f in imgs_h]
         torch.cuda.synchronize()
         slam = mqslam_amd.slam_device.DeviceMonoSlam(K, dist, (H, W), seed=seed, bundle_adjust=bundle_adjust, reassociate=reassociate,
-                                                     max_homography_points="reference")
+                                                     max_homography_points="reference", ba_window_keyframes=window)
         t0 = time.perf_counter()
         slam.start(imgs[0], objp, imgp)
         rets = [2]
@@ -92,6 +92,8 @@ def run(frames=None, bundle_adjust=None, seed=0, device=True, reassociate=False)
            "every_10th_frame_ours_ref_gt_error_mm": [[k, round(1e3 * float(err(c[k:k + 1], gt[k:k + 1])[0]), 2), round(1e3 * float(err(ref[k:k + 1], gt[k:k + 1])[0]), 2)]
                                                      for k in range(0, n, 10) if ok[k]]}
     if device and bundle_adjust:
+        out["ms_per_adjustment_first_to_last"] = [round(r["build_ms"] + r["adjust_ms"] + r["write_back_ms"], 2) for r in slam.ba_reports][::max(1, len(slam.ba_reports) // 8)]
+        out["poses_in_the_last_adjustment"] = slam.ba_reports[-1]["poses"] if slam.ba_reports else 0
         co = np.array([(-P[:, :3].T @ P[:, 3]) if P is not None else [np.nan] * 3 for P in slam.poses_online])
         out["online_vs_groundtruth_rmse_m"] = round(float(np.sqrt(np.mean(err(co[ok], gt[ok]) ** 2))), 5)
         out["landmarks_screened_out"] = int(slam._ba_bad.sum())
@@ -103,7 +105,7 @@ def run(frames=None, bundle_adjust=None, seed=0, device=True, reassociate=False)
 if __name__ == "__main__":
     a = [x for x in sys.argv[1:] if not x.startswith("--")]
     seed = int(sys.argv[sys.argv.index("--seed") + 1]) if "--seed" in sys.argv else 0
-    if "--seed" in sys.argv:
-        a = [x for x in a if x != str(seed)] if len(a) > 1 else a
+    window = int(sys.argv[sys.argv.index("--window") + 1]) if "--window" in sys.argv else None
+    a = [x for i, x in enumerate(sys.argv[1:], 1) if not x.startswith("--") and sys.argv[i - 1] not in ("--seed", "--window")]
     print(json.dumps(run(int(a[0]) if a else None, "keyframe" if "--ba" in sys.argv else None, seed, "--host" not in sys.argv,
-                         "--reassociate" in sys.argv)))
+                         "--reassociate" in sys.argv, window)))
