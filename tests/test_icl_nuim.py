@@ -227,3 +227,47 @@ def test_keyframe_test_ratio_of_the_device_loop_is_find_homography_s(seq, gpu, m
     got0 = np.array([r[1] for r in without if r[1] is not None])
     dlt0 = np.array([r[2] for r in without if r[1] is not None])
     assert np.abs(got0 - dlt0).max() < 1e-9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pair", [(10, 11), (60, 62)])
+def test_detect_track_match_step_of_slam_py_on_the_real_frames(pair, seq, gpu):
+    """slam.py's frame step (main_loop :57-226: FAST corners of the new frame, LK flow of the old frame's corners, match_OF_based =
+    radiusMatch of the flow points against the FAST points + ratio test + one match per FAST point) on two real frames: the GPU
+    path returns the oracle's matches -- same (query, train) pairs, the match indices bit for bit -- and the matched pairs obey
+    the epipolar geometry of the EXACT poses of the two frames (the matcher itself has no fixture in the reference: this is what
+    real data can say about it)."""
+    from oracle import features_np as Fn, matching_np as Mn
+    a, b = pair
+    I, J = seq["frames"][a], seq["frames"][b]
+    F = gpu.slam_frontend
+    left, _ = gpu.features.FastFeatureDetector().detect_arrays(I)
+    assert len(left) > 300
+    right_fast, matches, _, mean_flow, _, _ = F.main_loop(left, I, J, set())
+    # the oracle's statements over the same frames
+    np.testing.assert_array_equal(Fn.fast_detect(I)[0], left)
+    np.testing.assert_array_equal(Fn.fast_detect(J)[0], right_fast)
+    flow, st, err = Fn.calc_optical_flow_pyr_lk(I, J, left)
+    ref = Mn.match_OF_based(flow, right_fast, err.reshape(-1), st.reshape(-1), 2.0, 0.7)
+    assert len(ref) > 150
+    got_pairs = sorted((m.queryIdx, t) for t, m in matches.items())
+    ref_pairs = sorted((m.queryIdx, t) for t, m in ref.items())
+    # the two LK implementations differ by < 5e-3 px: a flow point that sits within that of the 2 px radius or of the ratio bound
+    # may fall on either side; everything else is the same pair
+    common = set(got_pairs) & set(ref_pairs)
+    assert len(common) >= 0.995 * max(len(got_pairs), len(ref_pairs))               # measured: every pair (406-490 per frame pair)
+    # epipolar geometry from the exact trajectory: x2^T E x1 = 0 with E = [t]x R for the relative pose
+    K = seq["K"]
+    Ra, Rb = quat_to_R(seq["traj_groundtruth"][a, 4:8]).T, quat_to_R(seq["traj_groundtruth"][b, 4:8]).T
+    ca, cb = seq["traj_groundtruth"][a, 1:4], seq["traj_groundtruth"][b, 1:4]
+    R = Rb @ Ra.T
+    t = Rb @ (ca - cb)
+    E = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]]) @ R
+    Fm = np.linalg.inv(K).T @ E @ np.linalg.inv(K)
+    q = np.array([left[i] for i, _ in got_pairs], dtype=np.float64)
+    r = np.array([right_fast[j] for _, j in got_pairs], dtype=np.float64)
+    x1, x2 = np.c_[q, np.ones(len(q))], np.c_[r, np.ones(len(r))]
+    l2, l1 = x1 @ Fm.T, x2 @ Fm
+    sampson = np.abs(np.sum(x2 * l2, axis=1)) / np.sqrt(l2[:, 0] ** 2 + l2[:, 1] ** 2 + l1[:, 0] ** 2 + l1[:, 1] ** 2)
+    assert np.median(sampson) < 0.3 and np.mean(sampson < 1.5) > 0.95        # FAST corners are integer pixels
+    assert np.abs(mean_flow).max() < 20
