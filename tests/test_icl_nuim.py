@@ -105,6 +105,40 @@ def test_oracle_detector_fills_the_reference_s_quota_on_the_first_frame(seq):
     assert len(Fn.good_features_to_track(I, 277, 0.01 * float(eig.max() / eig[mask != 0].max()), 12.0, mask)) < 230
 
 
+def fundamental_from_exact_poses(seq, a, b):
+    """x_b^T F x_a = 0 for the exact poses of frames a and b (pixels)."""
+    K = seq["K"]
+    Ra, Rb = quat_to_R(seq["traj_groundtruth"][a, 4:8]).T, quat_to_R(seq["traj_groundtruth"][b, 4:8]).T
+    ca, cb = seq["traj_groundtruth"][a, 1:4], seq["traj_groundtruth"][b, 1:4]
+    t = Rb @ (ca - cb)
+    E = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]]) @ (Rb @ Ra.T)
+    return np.linalg.inv(K).T @ E @ np.linalg.inv(K)
+
+
+def sampson_distance(Fm, pa, pb):
+    x1, x2 = np.c_[pa, np.ones(len(pa))], np.c_[pb, np.ones(len(pb))]
+    l2, l1 = x1 @ Fm.T, x2 @ Fm
+    return np.abs(np.sum(x2 * l2, axis=1)) / np.sqrt(l2[:, 0] ** 2 + l2[:, 1] ** 2 + l1[:, 0] ** 2 + l1[:, 1] ** 2)
+
+
+def test_oracle_detector_and_tracker_obey_the_exact_epipolar_geometry(seq):
+    """The oracle's corners of frame 30 (goodFeaturesToTrack as slam2.py calls it) tracked through four real frames by the oracle's
+    Lucas-Kanade (slam2.py:381-382: status and err < max_OF_error kept): start and end of every surviving track against the
+    epipolar geometry of the two frames' EXACT poses (13 mm of baseline) -- measured median 0.04 px, 90 % within 0.33 px; the
+    few per cent beyond a pixel are corners sliding along edges, which the loop's RANSAC is there for."""
+    from oracle import features_np as Fn
+    a, b = 30, 34
+    p0 = Fn.good_features_to_track(seq["frames"][a], 300, 0.01, 12.0)
+    cur, alive = p0.copy(), np.ones(len(p0), bool)
+    for k in range(a, b):
+        nxt, st, err = Fn.calc_optical_flow_pyr_lk(seq["frames"][k], seq["frames"][k + 1], cur)
+        alive &= st.astype(bool).ravel() & (err.ravel() < 12.0)
+        cur = nxt.astype(np.float32)
+    assert len(p0) >= 150 and alive.mean() > 0.85
+    s = sampson_distance(fundamental_from_exact_poses(seq, a, b), p0[alive].astype(np.float64), cur[alive].astype(np.float64))
+    assert np.median(s) < 0.1 and np.percentile(s, 90) < 0.6
+
+
 @pytest.mark.gpu
 def test_detector_and_tracker_equal_the_oracle_on_the_real_images(seq, gpu):
     from oracle import features_np as Fn
@@ -257,17 +291,8 @@ def test_detect_track_match_step_of_slam_py_on_the_real_frames(pair, seq, gpu):
     common = set(got_pairs) & set(ref_pairs)
     assert len(common) >= 0.995 * max(len(got_pairs), len(ref_pairs))               # measured: every pair (406-490 per frame pair)
     # epipolar geometry from the exact trajectory: x2^T E x1 = 0 with E = [t]x R for the relative pose
-    K = seq["K"]
-    Ra, Rb = quat_to_R(seq["traj_groundtruth"][a, 4:8]).T, quat_to_R(seq["traj_groundtruth"][b, 4:8]).T
-    ca, cb = seq["traj_groundtruth"][a, 1:4], seq["traj_groundtruth"][b, 1:4]
-    R = Rb @ Ra.T
-    t = Rb @ (ca - cb)
-    E = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]]) @ R
-    Fm = np.linalg.inv(K).T @ E @ np.linalg.inv(K)
     q = np.array([left[i] for i, _ in got_pairs], dtype=np.float64)
     r = np.array([right_fast[j] for _, j in got_pairs], dtype=np.float64)
-    x1, x2 = np.c_[q, np.ones(len(q))], np.c_[r, np.ones(len(r))]
-    l2, l1 = x1 @ Fm.T, x2 @ Fm
-    sampson = np.abs(np.sum(x2 * l2, axis=1)) / np.sqrt(l2[:, 0] ** 2 + l2[:, 1] ** 2 + l1[:, 0] ** 2 + l1[:, 1] ** 2)
+    sampson = sampson_distance(fundamental_from_exact_poses(seq, a, b), q, r)
     assert np.median(sampson) < 0.3 and np.mean(sampson < 1.5) > 0.95        # FAST corners are integer pixels
     assert np.abs(mean_flow).max() < 20
