@@ -191,6 +191,21 @@ def test_host_driven_loop_on_the_example_sequence(gpu):
 
 
 @pytest.mark.gpu
+def test_example_run_leaves_the_reference_s_output_files(gpu, tmp_path):
+    """--out: what slam2.py's write_output leaves behind (:698-741) -- the trajectory in TUM format and the map as PCD, readable by
+    the reference-format readers, the trajectory's first row the initial pose like the reference's own file."""
+    import run_icl_nuim
+    out = run_icl_nuim.run(20, seed=0, out_dir=str(tmp_path))
+    io = gpu.ba_io
+    traj = io.load_trajectory(out["written"][0])
+    pts = io.load_map(out["written"][1])
+    d = np.load(run_icl_nuim.FIX)
+    assert len(traj) == 20 and len(pts) == out["landmarks"]
+    assert abs(traj[0][0] - 1.0 / 30) < 1e-9 and np.abs(np.asarray(traj[0][1])[9:] - d["traj_slam2"][0, 1:4]).max() < 1e-4
+    assert np.abs(np.asarray(traj[10][1])[9:] - d["traj_slam2"][10, 1:4]).max() < 0.01
+
+
+@pytest.mark.gpu
 def test_loop_with_adjustment_per_keyframe_on_the_example_sequence(gpu):
     """... and with the bundle adjustment per keyframe EVERY seed stays within a centimetre of the exact trajectory (measured 4-10 mm
     rmse over 80 frames, 4-6 mm over 200 where the reference's committed run has drifted to 171 mm)."""

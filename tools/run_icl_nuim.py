@@ -4,7 +4,7 @@ build's device-resident loop, against what the reference COMMITTED as that run's
 slam2.py with OpenCV 2.4's goodFeaturesToTrack / calcOpticalFlowPyrLK / solvePnPRansac) and against the renderer's exact
 trajectory.  Reads the fixture tests/golden/icl_nuim_traj3n/sequence.npz (tests/golden/make_icl_nuim.py).
 
-    python tools/run_icl_nuim.py [frames] [--ba [--window K]] [--host] [--seed S]
+    python tools/run_icl_nuim.py [frames] [--ba [--window K]] [--host] [--seed S] [--out DIR]     (--out: trajectory and map in the reference's formats)
 """
 import os, sys, json, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -42,7 +42,7 @@ def start_points(K, shape, P_init, pts):
     return uv, vis
 
 
-def run(frames=None, bundle_adjust=None, seed=0, device=True, reassociate=False, window=None):
+def run(frames=None, bundle_adjust=None, seed=0, device=True, reassociate=False, window=None, out_dir=None):
     import torch
     d = np.load(FIX)
     imgs_h = d["frames"] if frames is None else d["frames"][:frames]
@@ -97,6 +97,13 @@ def run(frames=None, bundle_adjust=None, seed=0, device=True, reassociate=False,
         co = np.array([(-P[:, :3].T @ P[:, 3]) if P is not None else [np.nan] * 3 for P in slam.poses_online])
         out["online_vs_groundtruth_rmse_m"] = round(float(np.sqrt(np.mean(err(co[ok], gt[ok]) ** 2))), 5)
         out["landmarks_screened_out"] = int(slam._ba_bad.sum())
+    if out_dir:
+        # what slam2.py's write_output leaves behind (:698-741): traj_out.cam0-<name>.txt in TUM format (30 fps, as the reference's
+        # run) and map_out-<name>.pcd -- the inputs of the reference's own evaluation scripts
+        os.makedirs(out_dir, exist_ok=True)
+        fn = mqslam_amd.ba_io.create_filenames(out_dir, "mqslam", 1)
+        mqslam_amd.ba_io.save_slam_output(fn, 30, slam.projection_matrices(), np.asarray(slam.objp, dtype=np.float64))
+        out["written"] = [fn.trajectories_in[0], fn.map_in]
     if hasattr(slam, "close"):
         slam.close()
     return out
@@ -106,6 +113,8 @@ if __name__ == "__main__":
     a = [x for x in sys.argv[1:] if not x.startswith("--")]
     seed = int(sys.argv[sys.argv.index("--seed") + 1]) if "--seed" in sys.argv else 0
     window = int(sys.argv[sys.argv.index("--window") + 1]) if "--window" in sys.argv else None
-    a = [x for i, x in enumerate(sys.argv[1:], 1) if not x.startswith("--") and sys.argv[i - 1] not in ("--seed", "--window")]
+    a = [x for i, x in enumerate(sys.argv[1:], 1) if not x.startswith("--") and sys.argv[i - 1] not in ("--seed", "--window", "--out")]
+    out_dir = sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else None
+    a = [x for x in a if x != out_dir]
     print(json.dumps(run(int(a[0]) if a else None, "keyframe" if "--ba" in sys.argv else None, seed, "--host" not in sys.argv,
-                         "--reassociate" in sys.argv, window)))
+                         "--reassociate" in sys.argv, window, out_dir)))
