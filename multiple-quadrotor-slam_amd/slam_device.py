@@ -75,13 +75,18 @@ class DeviceMonoSlam:
         the bundle adjuster (slam2.py:519-522, 634-641, 681-687, 1167-1169, 1204).  Recording reads the live tracks back
         after every frame (one more synchronisation per frame): the recorder's lists live on the host."""
         self.K = np.asarray(cameraMatrix, dtype=np.float64)
-        self.dist = np.asarray(distCoeffs, dtype=np.float64).reshape(-1)[:4]
+        d5 = np.zeros(5)
+        dc = np.asarray(distCoeffs, dtype=np.float64).reshape(-1)
+        d5[:min(5, dc.size)] = dc[:5]
+        self.dist = d5[:4]                       # k1 k2 p1 p2: the bundle adjuster's camera model (IO.hpp:230-236 has no k3)
+        if bundle_adjust and d5[4] != 0.0:
+            raise ValueError("bundle_adjust: the adjuster's camera model (fx fy s u0 v0 k1 k2 p1 p2, IO.hpp:230-236) has no k3; got k3 = %g" % d5[4])
         self.shape = tuple(image_shape)
         H, W = self.shape
         target = int(round(W * H / (np.pi * KEYPOINT_COVERAGE_RADIUS ** 2)))         # slam2.py:1081
         self.target_keypoints = min(MAX_AMOUNT_KEYPOINTS, target)
         self.verbose = verbose
-        self._intr = np.ascontiguousarray(_intr(self.K, self.dist), dtype=np.float64)
+        self._intr = np.ascontiguousarray(_intr(self.K, d5), dtype=np.float64)          # the frame kernels take k3 as well
         self._h = ctypes.c_void_p()
         self._device = int(device)
         L = _lib.lib()
