@@ -2,7 +2,7 @@
 """slam.py's detect -> track -> match frame step on real frames of the reference's example sequence: GPU path against the oracle,
 and the matches against the epipolar geometry of the exact poses."""
 import os, sys, json
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))          # (under tests/: it uses the oracle as the checker)
 sys.path.insert(0, os.path.join(ROOT, "tools")); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, mqslam_amd, run_icl_nuim
 from oracle import features_np as Fn, matching_np as Mn
