@@ -516,6 +516,37 @@ def test_the_optimiser_inside_the_library_at_its_edges(gpu):
 
 
 @pytest.mark.gpu
+def test_the_optimiser_on_a_problem_without_landmarks(gpu):
+    """N = 0: a pose graph -- a prior on the first pose and odometry factors between neighbours (bundle_adjust.cpp:301-309) -- goes
+    through the same entry points (no landmark kernels run): the chain, started from perturbed poses, settles where the factors
+    cost three orders of magnitude less; library driver and host loop agree, and the oracle prices the result the same."""
+    fn, data = load(gpu, EX, "synthetic", 2, 1)
+    full = gpu.ba_io.build_sparse_problem(data, use_odometry=True)
+    keep = [i for i, k in enumerate(full.pose_key) if k[0] == 0]                # camera 0's poses: a chain of odometry factors
+    idx = {i: j for j, i in enumerate(keep)}
+    odo = [k for k in range(len(full.odo_from)) if int(full.odo_from[k]) in idx and int(full.odo_to[k]) in idx]
+    assert len(odo) >= len(keep) - 1
+    truth = full.poses[keep]
+    rng = np.random.default_rng(4)
+    start = truth.copy()
+    start[1:, 9:] += 0.05 * rng.standard_normal((len(keep) - 1, 3))
+    pr = full._replace(poses=start, pose_cam=full.pose_cam[keep], pose_key=[full.pose_key[i] for i in keep], points=np.zeros((0, 3)),
+                       obs_ptr=np.zeros(1, np.int64), obs_pose=np.zeros(0, np.int32), obs_uv=np.zeros((0, 2)), prior_w=None, prior_xyz=None,
+                       pose_prior_idx=np.array([0], np.int32), pose_prior_sigmas=np.array([[1e-3] * 6]),
+                       odo_from=np.array([idx[int(full.odo_from[k])] for k in odo], np.int32),
+                       odo_to=np.array([idx[int(full.odo_to[k])] for k in odo], np.int32), odo_meas=full.odo_meas[odo], odo_sigmas=full.odo_sigmas[odo])
+    SB = gpu.sparse_ba.SparseBundleAdjuster
+    a, b = SB(pr), SB(pr)
+    ha, hb = a.optimize(mode="lm"), b.optimize_host_loop(mode="lm")
+    assert len(ha) == len(hb) >= 2 and ha[-1] < 1e-3 * ha[0]
+    np.testing.assert_allclose(ha, hb, rtol=1e-8, atol=1e-12)
+    # what is left is the oracle's cost of the odometry factors at the result (the prior on the first pose costs next to nothing)
+    Hb, gb, cb = ba_np.sparse_between_terms(a.poses.cpu().numpy(), pr.odo_from, pr.odo_to, pr.odo_meas, pr.odo_sigmas)
+    assert cb <= ha[-1] * (1 + 1e-9) + 1e-12 and cb >= 0.9 * ha[-1] - 1e-9
+    assert a.cost() == pytest.approx(ha[-1], rel=1e-9, abs=1e-12)
+
+
+@pytest.mark.gpu
 def test_worst_residual_per_landmark_equals_the_host_projection(gpu):
     """`mqs_sba_worst_residual_dev` (the screen either side of an adjustment in the SLAM loop) against the numpy projection that
     tests/test_slam_loop.py pins to the oracle: per landmark the largest pixel residual; +inf behind a camera; 0 without observations."""
