@@ -637,6 +637,13 @@ int64_t mqs_fast_workspace_bytes(int W, int H);
  *                    Levenberg-Marquardt refinement of the transfer error (OpenCV 2.4 fundam.cpp: estimator.refine(M, m, H, 10)).
  * ------------------------------------------------------------------------------------- */
 typedef struct mqs_slam mqs_slam;
+/* OPTIONAL, off by default (not in slam2.py's flow): at a keyframe, a freshly triangulated point whose reprojection error in the
+ * current frame -- under the pose it was triangulated with -- exceeds `max_reproj_error_px` is dropped instead of being handed to the
+ * second solvePnP (slam2.py:576-577).  The reference defines the bound for exactly this place (slam2.py:1092:
+ * max_2nd_solvePnP_reproj_error = max_solvePnP_reproj_error / 2 = 1 px, "used in 2nd iteration, after 1st pass of triangulation")
+ * and never uses it; without it one gross two-view point (status 1 = converged and in front of both cameras, nothing about its
+ * residual) throws the keyframe's pose centimetres off.  0 switches the screen off again. */
+int mqs_slam_set_second_pass_screen(mqs_slam *s, double max_reproj_error_px);
 int mqs_slam_create(int device, int W, int H, const double *intr, int target_keypoints, double coverage_radius,
                     double quality_level, int max_landmarks, uint64_t seed, mqs_slam **out);
 void mqs_slam_destroy(mqs_slam *s);

@@ -175,6 +175,7 @@ SIGNATURES = {
                                        ctypes.c_int, ctypes.c_uint64, ctypes.POINTER(c_vp)]),
     "mqs_slam_destroy": (None, [c_vp]),
     "mqs_slam_set_thresholds": (ctypes.c_int, [c_vp] + [ctypes.c_double] * 5 + [ctypes.c_int]),
+    "mqs_slam_set_second_pass_screen": (ctypes.c_int, [c_vp, ctypes.c_double]),
     "mqs_slam_reassociate": (ctypes.c_int, [c_vp, ctypes.c_float, ctypes.c_double, c_i32p]),
     "mqs_slam_log_enable": (ctypes.c_int, [c_vp, c_i64]),
     "mqs_slam_read_log": (ctypes.c_int, [c_vp, c_i32p, c_i32p, c_f64p, c_i64, ctypes.POINTER(c_i64)]),

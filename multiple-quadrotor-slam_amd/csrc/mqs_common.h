@@ -110,7 +110,8 @@ int mqs_pnp_ransac_launch(const double *objp, const double *imgp, int N, const i
                           hipStream_t stream);
 int mqs_keyframe_step_launch(const double *objp, const double *imgp, int n_old, const double *p0, const double *p1, int n_new,
                              const double *intr, const double *P_prev, const double *P0, double tolerance, int max_iter, double eps,
-                             double *scratch, double *pose_out, double *x_out, int32_t *status_out, double *info, hipStream_t stream);
+                             double second_pass_screen_px, double *scratch, double *pose_out, double *x_out, int32_t *status_out, double *info,
+                             hipStream_t stream);
 
 // comm.hip: releases ctx->comm (called by mqs_destroy)
 void mqs_comm_release(mqs_ctx *ctx);

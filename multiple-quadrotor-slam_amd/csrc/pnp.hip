@@ -376,7 +376,7 @@ struct KfEval {
 __global__ __launch_bounds__(kKfThreads) void keyframe_step_kernel(
     const double *objp, const double *imgp, int n_old, const double *__restrict__ p0,
     const double *__restrict__ p1, int n_new, const double *__restrict__ intr, const double *__restrict__ P_prev,
-    const double *__restrict__ P0, double tol, int max_iter, double eps, int lds_ok, double *scratch /* 9 n_new + 1 doubles */,
+    const double *__restrict__ P0, double tol, int max_iter, double eps, double screen_px, int lds_ok, double *scratch /* 9 n_new + 1 doubles */,
     double *__restrict__ pose_out /* 24: first pose, final pose */, double *__restrict__ x_out, int32_t *__restrict__ status_out,
     double *__restrict__ info /* 8: the two solves' info */)
 {
@@ -429,6 +429,17 @@ __global__ __launch_bounds__(kKfThreads) void keyframe_step_kernel(
             int32_t st;
             x = mqs::iterative_ls_point<2>(uv, sP, tol, MQS_TRI_MAX_ITER_DEFAULT, st);
             ok = st == 1;
+            if (ok && screen_px > 0.0) {
+                // OPTIONAL (off in the reference's flow: slam2.py:1092 defines max_2nd_solvePnP_reproj_error "used in 2nd iteration,
+                // after 1st pass of triangulation" and never uses it): a fresh point that misses its own measurement in THIS frame by
+                // more than the bound, under the pose it was triangulated with, is not handed to the second solvePnP -- status 1 says
+                // converged and in front of both cameras, not small residuals (a point at a camera centre has both and any residual)
+                double a28[kAcc];
+#pragma unroll
+                for (int q = 0; q < kAcc; ++q) a28[q] = 0.0;
+                accumulate_point(sP + 12, sI, (double)(float)x.x, (double)(float)x.y, (double)(float)x.z, p1[2 * k], p1[2 * k + 1], a28);
+                ok = a28[27] <= screen_px * screen_px;             // (NaN: dropped)
+            }
             if (!ok) {
                 status_out[k] = kKfDropped;
                 x_out[3 * k] = x_out[3 * k + 1] = x_out[3 * k + 2] = __builtin_nan("");
@@ -548,12 +559,13 @@ int mqs_pnp_ransac_launch(const double *objp, const double *imgp, int N, const i
 // the keyframe step on device-resident inputs (scratch: 9 n_new + 1 doubles + n_new ints when the step does not fit the LDS)
 int mqs_keyframe_step_launch(const double *objp, const double *imgp, int n_old, const double *p0, const double *p1, int n_new,
                              const double *intr, const double *P_prev, const double *P0, double tolerance, int max_iter, double eps,
-                             double *scratch, double *pose_out, double *x_out, int32_t *status_out, double *info, hipStream_t stream)
+                             double second_pass_screen_px, double *scratch, double *pose_out, double *x_out, int32_t *status_out, double *info,
+                             hipStream_t stream)
 {
     const size_t lds_bytes = ((size_t)5 * n_old + (size_t)9 * n_new + 2) * 8 + (size_t)n_new * 4;
     const bool lds_ok = lds_bytes <= 56 * 1024;
     hipLaunchKernelGGL(keyframe_step_kernel, dim3(1), dim3(kKfThreads), lds_ok ? lds_bytes : 0, stream, objp, imgp, n_old, p0, p1, n_new,
-                       intr, P_prev, P0, tolerance, max_iter, eps, (int)lds_ok, scratch, pose_out, x_out, status_out, info);
+                       intr, P_prev, P0, tolerance, max_iter, eps, second_pass_screen_px, (int)lds_ok, scratch, pose_out, x_out, status_out, info);
     MQS_HIP_CHECK(hipGetLastError());
     return MQS_OK;
 }
@@ -653,7 +665,7 @@ int mqs_keyframe_step(mqs_ctx *ctx, const double *objp, const double *imgp, int6
         hipLaunchKernelGGL(keyframe_step_kernel, dim3(1), dim3(kKfThreads), lds_ok ? lds_bytes : 0, s, (const double *)(inb + o_obj),
                            (const double *)(inb + o_img), (int)n_old, (const double *)(inb + o_p0), (const double *)(inb + o_p1), (int)n_new,
                            (const double *)(inb + o_intr), (const double *)(inb + o_pp), (const double *)(inb + o_pb), tolerance, max_iter,
-                           eps, (int)lds_ok, (double *)(d + o_scr), (double *)(outb + o_pose), (double *)(outb + o_x),
+                           eps, 0.0 /* no screen: slam2.py's flow */, (int)lds_ok, (double *)(d + o_scr), (double *)(outb + o_pose), (double *)(outb + o_x),
                            (int32_t *)(outb + o_st), (double *)(outb + o_info));
     };
     if (st.zero_copy) {

@@ -76,6 +76,7 @@ struct SlamParams {
     int W, H, target, max_landmarks;
     double radius, quality;
     double max_of_error, max_lost_ratio, max_reproj, max_outlier_ratio, homography_threshold;
+    double second_pass_screen_px;   // 0 (default): slam2.py's flow; > 0: mqs_slam_set_second_pass_screen
     unsigned long long seed;
     int homography_refine;          // 1 (default): DLT + the LM refinement, as cv2.findHomography(method = 0); 0: the DLT alone (A/B)
     int max_homography_points;      // keyframe_test's random sample (slam2.py:48; the reference: max(4, target / 4), :1088-1089); 0 = all tracks (default)
@@ -860,7 +861,7 @@ int mqs_slam_create(int device, int W, int H, const double *intr, int target_key
     s->started = false;
     s->accepted = 0; s->base_pose = 0; s->log_arena = nullptr; s->re_arena = nullptr;
     s->p = SlamParams{W, H, target_keypoints, max_landmarks, coverage_radius, quality_level,
-                      12.0, 0.5, 2.0, 0.33, 1.04, (unsigned long long)seed, 1, 0};  // slam2.py:1070-1098; keyframe test on ALL tracks
+                      12.0, 0.5, 2.0, 0.33, 1.04, 0.0, (unsigned long long)seed, 1, 0};  // slam2.py:1070-1098; keyframe test on ALL tracks
     if (const char *e = getenv("MQS_SLAM_HOMOGRAPHY_REFINE")) s->p.homography_refine = e[0] != '0';        // A/B: 0 = the DLT alone
     s->ws_lk_bytes = mqs_lk_workspace_bytes(W, H, 3);
     s->ws_gftt_bytes = mqs_gftt_workspace_bytes(W, H);
@@ -1011,6 +1012,13 @@ int mqs_slam_set_thresholds(mqs_slam *s, double max_of_error, double max_lost_tr
     return MQS_OK;
 }
 
+int mqs_slam_set_second_pass_screen(mqs_slam *s, double max_reproj_error_px)
+{
+    MQS_ARG_CHECK(s != nullptr && max_reproj_error_px >= 0.0, "handle must not be null, bound >= 0 (0: off)");
+    s->p.second_pass_screen_px = max_reproj_error_px;
+    return MQS_OK;
+}
+
 // first frame (slam2.py:1136-1180): pose from n0 known 3-D points, those points become the first landmarks and tracks, the rest
 // of the tracks come from goodFeaturesToTrack under their coverage mask.  objp0 [n0][3], imgp0 [n0][2]: HOST float32.
 int mqs_slam_start(mqs_slam *s, const uint8_t *img_dev, const float *objp0, const float *imgp0, int n0, double *pose_out)
@@ -1073,7 +1081,8 @@ int mqs_slam_track(mqs_slam *s, const uint8_t *prev_img_dev, const uint8_t *img_
         const int n_old = (int)result[R_NOLD], n_new = (int)result[R_NNEW];
         if (n_new > 0) {
             rc = mqs_keyframe_step_launch(d.kf_objp, d.kf_imgp, n_old, d.kf_p0, d.kf_p1, n_new, d.intr, d.pose_prev, d.pose_key, 3.e-5,
-                                          kPnpIters, kPnpEps, d.kf_scratch, d.kf_pose, d.kf_x, d.kf_status, d.kf_info, s->stream);
+                                          kPnpIters, kPnpEps, s->p.second_pass_screen_px, d.kf_scratch, d.kf_pose, d.kf_x, d.kf_status, d.kf_info,
+                                          s->stream);
             if (rc != MQS_OK) return rc;
         }
         hipLaunchKernelGGL(keyframe_commit_kernel, dim3(1), dim3(256), 0, s->stream, d, s->p, n_new);

@@ -52,7 +52,7 @@ def _reprojection_residuals(poses_c2w, points, calib, lm, pose_idx, uv):
 class DeviceMonoSlam:
     def __init__(self, cameraMatrix, distCoeffs, image_shape, seed=0, device=0, max_landmarks=1 << 16, verbose=False,
                  ba_info=None, max_homography_points=0, bundle_adjust=None, ba_iterations=10, ba_log_capacity=1 << 20,
-                 reassociate=False, ba_window_keyframes=None):
+                 reassociate=False, ba_window_keyframes=None, second_pass_screen=None):
         """max_homography_points: size of keyframe_test's random sample of the tracks (slam2.py:48): 0 = every track (default),
         "reference" = the reference's max(4, target_amount_keypoints / 4) (:1088-1089).  On the rendered test sequence the quarter
         makes the run depend on the draw -- trajectory RMSE 0.017-0.020 for half of the seeds, 0.057-0.068 for the other half,
@@ -67,6 +67,9 @@ class DeviceMonoSlam:
         keyframe; `poses_online` keeps each frame's pose as it was first estimated.
         ba_window_keyframes=K (>= 2): the adjustment takes the frames since the K-th keyframe from the end instead of every frame so
         far, anchored by tight pose priors on the window's first two keyframes -- the cost of an adjustment stops growing with the run.
+        second_pass_screen=px (None / 0: off, the reference's flow): at a keyframe a freshly triangulated point whose reprojection error
+        in the current frame exceeds px is not handed to the second solvePnP (slam2.py:576-577) -- the use slam2.py:1092 announces for
+        max_2nd_solvePnP_reproj_error (= 1 px) and never makes; see mqs_slam_set_second_pass_screen.
         reassociate=True: behind every keyframe's top-up the new corners are matched (BFMatcher.radiusMatch on pixel positions +
         ratio test + one match per corner: the reference's match_OF_based, slam.py:81-127, cv2_helpers.py:296-339) against the
         PROJECTIONS of the landmarks that are in the map but not tracked any more; a matched corner takes its landmark up again
@@ -98,6 +101,8 @@ class DeviceMonoSlam:
                                       else int(max_homography_points))
         _lib.check(L.mqs_slam_set_thresholds(self._h, MAX_OF_ERROR, MAX_LOST_TRACKS_RATIO, MAX_SOLVEPNP_REPROJ_ERROR,
                                              MAX_SOLVEPNP_OUTLIER_RATIO, HOMOGRAPHY_CONDITION_THRESHOLD, self.max_homography_points))
+        if second_pass_screen:
+            _lib.check(L.mqs_slam_set_second_pass_screen(self._h, float(second_pass_screen)))
         self._track = L.mqs_slam_track
         self._res = np.zeros(40)
         self._pres = self._res.ctypes.data_as(_lib.c_f64p)

@@ -166,7 +166,8 @@ def keyframe_test(points1, points2, K, dist, max_points=None, rng=None):
 
 
 class MonoSlam:
-    def __init__(self, cameraMatrix, distCoeffs, image_shape, seed=0, verbose=False, ba_info=None, max_homography_points=0):
+    def __init__(self, cameraMatrix, distCoeffs, image_shape, seed=0, verbose=False, ba_info=None, max_homography_points=0,
+                 second_pass_screen=None):
         """max_homography_points: keyframe_test's random sample of the tracks (slam2.py:48): 0 = all tracks (default; see
         slam_device.DeviceMonoSlam for the measurement behind it), "reference" = max(4, target_amount_keypoints / 4) (:1088-1089).
         ba_info: an optional `ba_io.BundleAdjustmentInfoContainer`; the loop then records what the reference records
@@ -180,6 +181,7 @@ class MonoSlam:
         self.rng = np.random.default_rng(seed)
         # keyframe_test's random sample (slam2.py:1088-1089: target_amount_keypoints / 4, at least 4), drawn like the reference
         # draws it (np.random.permutation) from a seeded legacy generator
+        self.second_pass_screen = float(second_pass_screen) if second_pass_screen else 0.0
         self.max_homography_points = (max(4, self.target_keypoints // 4) if max_homography_points == "reference"
                                       else int(max_homography_points))
         self.legacy_rng = np.random.RandomState(seed)
@@ -291,6 +293,11 @@ class MonoSlam:
                 P0 = self._P(self.rvec_keyfr, self.tvec_keyfr)
                 x1, s1 = triangulation.iterative_LS_triangulation(u0, P0, u1, self._P(rvec, tvec))
                 ok = np.nonzero(np.asarray(s1) == 1)[0]
+                if self.second_pass_screen and len(ok):
+                    # optional, not in slam2.py's flow (its :1092 max_2nd_solvePnP_reproj_error is defined for this place and unused):
+                    # fresh points that miss their own measurement in this frame by more than the bound stay out of the second solvePnP
+                    uvp, _, _ = camera.project_points(np.asarray(x1)[ok].astype(np.float32).astype(np.float64), K, dist, self._P(rvec, tvec), imgp1[ok])
+                    ok = ok[np.linalg.norm(uvp - imgp1[ok], axis=1) <= self.second_pass_screen]
                 if len(ok):
                     obj_all = np.concatenate([objp_i, np.asarray(x1)[ok].astype(np.float32)])
                     img_all = np.concatenate([imgp_i, imgp1[ok].astype(np.float32)])

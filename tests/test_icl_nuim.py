@@ -218,6 +218,25 @@ def test_loop_with_adjustment_per_keyframe_on_the_example_sequence(gpu):
 
 
 @pytest.mark.gpu
+def test_optional_second_pass_screen_on_the_example_sequence(gpu):
+    """Off by default, because it is not in slam2.py's flow: `second_pass_screen` (mqs_slam_set_second_pass_screen) keeps a freshly
+    triangulated point whose reprojection error in the current frame exceeds the bound out of the keyframe's second solvePnP -- the
+    use slam2.py:1092 announces for max_2nd_solvePnP_reproj_error (1 px) and never makes.  Seeds 9 and 12 take their first keyframe
+    at frame 36, where ONE of 215 points carries 325 px of error into the plain least squares (profiles/r04/17): 43 mm without the
+    screen, 5-6 mm with it; over 32 seeds 2.6-6.6 mm with it (plain: 3.0-46 mm; the reference's own run: 4.4 mm).  The host-driven
+    loop takes the same option."""
+    import run_icl_nuim
+    for seed in (9, 12):
+        plain = run_icl_nuim.run(80, seed=seed)
+        screened = run_icl_nuim.run(80, seed=seed, screen=1.0)
+        assert plain["keyframe_frames"][1] == 36 and plain["ours_vs_groundtruth_rmse_m"] > 0.03        # slam2.py's flow, faithfully
+        assert screened["accepted"] == 80 and screened["ours_vs_groundtruth_rmse_m"] < 0.009
+        assert screened["orientation_rmse_deg"]["ours_vs_groundtruth"] < 0.2
+    host = run_icl_nuim.run(80, seed=9, device=False, screen=1.0)
+    assert host["accepted"] == 80 and host["ours_vs_groundtruth_rmse_m"] < 0.012
+
+
+@pytest.mark.gpu
 def test_windowed_adjustment_on_the_example_sequence(gpu):
     """ba_window_keyframes: the adjustment over the frames since the K-th keyframe from the end (anchored by pose priors on the
     window's first two keyframes and by priors on the landmarks the frames in front of it have seen) instead of over every frame so

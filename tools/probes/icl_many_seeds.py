@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools")); sys.path.insert(0, ROOT)
 import numpy as np, run_icl_nuim
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 out = {}
-for name, kw in (("plain", {}), ("ba_per_keyframe", {"bundle_adjust": "keyframe"})):
+for name, kw in (("plain", {}), ("ba_per_keyframe", {"bundle_adjust": "keyframe"}), ("plain_with_second_pass_screen_1px", {"screen": 1.0})):
     rows = [run_icl_nuim.run(80, seed=s, **kw) for s in range(n)]
     q = lambda key, f=lambda r: r: [round(float(v), 5) for v in np.percentile([f(r)[key] if f is not None else r[key] for r in rows], [0, 25, 50, 75, 100])]
     out[name] = {"seeds": n, "accepted_every_frame": all(r["accepted"] == 80 for r in rows),

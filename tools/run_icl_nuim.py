@@ -42,7 +42,7 @@ def start_points(K, shape, P_init, pts):
     return uv, vis
 
 
-def run(frames=None, bundle_adjust=None, seed=0, device=True, reassociate=False, window=None, out_dir=None):
+def run(frames=None, bundle_adjust=None, seed=0, device=True, reassociate=False, window=None, out_dir=None, screen=None):
     import torch
     d = np.load(FIX)
     imgs_h = d["frames"] if frames is None else d["frames"][:frames]
@@ -56,7 +56,7 @@ def run(frames=None, bundle_adjust=None, seed=0, device=True, reassociate=False,
         imgs = [torch.from_numpy(np.ascontiguousarray(f)).cuda() for f in imgs_h]
         torch.cuda.synchronize()
         slam = mqslam_amd.slam_device.DeviceMonoSlam(K, dist, (H, W), seed=seed, bundle_adjust=bundle_adjust, reassociate=reassociate,
-                                                     max_homography_points="reference", ba_window_keyframes=window)
+                                                     max_homography_points="reference", ba_window_keyframes=window, second_pass_screen=screen)
         t0 = time.perf_counter()
         slam.start(imgs[0], objp, imgp)
         rets = [2]
@@ -64,7 +64,7 @@ def run(frames=None, bundle_adjust=None, seed=0, device=True, reassociate=False,
             rets.append(slam.handle_new_frame(imgs[k]))
         slam.finish()
     else:
-        slam = mqslam_amd.slam_loop.MonoSlam(K, dist, (H, W), seed=seed)
+        slam = mqslam_amd.slam_loop.MonoSlam(K, dist, (H, W), seed=seed, second_pass_screen=screen)
         slam.start(imgs_h[0], objp, imgp)
         rets = [2]
         for k in range(1, n):
@@ -113,8 +113,9 @@ if __name__ == "__main__":
     a = [x for x in sys.argv[1:] if not x.startswith("--")]
     seed = int(sys.argv[sys.argv.index("--seed") + 1]) if "--seed" in sys.argv else 0
     window = int(sys.argv[sys.argv.index("--window") + 1]) if "--window" in sys.argv else None
-    a = [x for i, x in enumerate(sys.argv[1:], 1) if not x.startswith("--") and sys.argv[i - 1] not in ("--seed", "--window", "--out")]
+    screen = float(sys.argv[sys.argv.index("--screen") + 1]) if "--screen" in sys.argv else None
+    a = [x for i, x in enumerate(sys.argv[1:], 1) if not x.startswith("--") and sys.argv[i - 1] not in ("--seed", "--window", "--out", "--screen")]
     out_dir = sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else None
     a = [x for x in a if x != out_dir]
     print(json.dumps(run(int(a[0]) if a else None, "keyframe" if "--ba" in sys.argv else None, seed, "--host" not in sys.argv,
-                         "--reassociate" in sys.argv, window, out_dir)))
+                         "--reassociate" in sys.argv, window, out_dir, screen)))
