@@ -717,7 +717,8 @@ def main():
             if os.path.exists(run_icl_nuim.FIX):
                 run_icl_nuim.run(80)                                              # first-launch costs
                 frontend_out["reference_example_sequence_icl_nuim_80_frames"] = {
-                    "plain": run_icl_nuim.run(80), "ba_per_keyframe": run_icl_nuim.run(80, bundle_adjust="keyframe")}
+                    "plain": run_icl_nuim.run(80), "ba_per_keyframe": run_icl_nuim.run(80, bundle_adjust="keyframe"),
+                    "plain_with_the_optional_second_pass_screen_1px": run_icl_nuim.run(80, screen=1.0)}
         except Exception as e:                                  # noqa: BLE001 -- a secondary leg must not cost the bench line
             frontend_out = {"error": "%s: %s" % (type(e).__name__, e)}
 
