@@ -238,6 +238,18 @@ def test_optional_second_pass_screen_on_the_example_sequence(gpu):
 
 
 @pytest.mark.gpu
+def test_the_reference_s_two_program_workflow_on_its_example_sequence(gpu):
+    """slam2.py records, bundle_adjust adjusts the recording (the reference's ReadMe workflow): the device loop with the BA_info
+    recorder, the 12-file set, tools/bundle_adjust.py with the reference's command line, the adjusted trajectory back.  On these 80
+    frames the post-hoc adjustment does not beat the loop (measured 4.9 -> 8.5 mm from the exact trajectory) -- nor does the
+    reference's own: its committed slam2 / slam2-BA trajectories are 4.3 / 6.5 mm from it over the same frames (profiles/r04/17)."""
+    import run_icl_nuim
+    out = run_icl_nuim.run_posthoc(80, seed=0)
+    assert out["tool_return_code"] == 0 and out["poses_in_the_adjusted_file"] == 80
+    assert out["loop_vs_groundtruth_rmse_m"] < 0.01 and out["after_the_tool_vs_groundtruth_rmse_m"] < 0.02
+
+
+@pytest.mark.gpu
 def test_windowed_adjustment_on_the_example_sequence(gpu):
     """ba_window_keyframes: the adjustment over the frames since the K-th keyframe from the end (anchored by pose priors on the
     window's first two keyframes and by priors on the landmarks the frames in front of it have seen) instead of over every frame so

@@ -109,7 +109,47 @@ def run(frames=None, bundle_adjust=None, seed=0, device=True, reassociate=False,
     return out
 
 
+def run_posthoc(frames=80, seed=0, screen=None):
+    """The reference's two-program workflow on its own data with this build's drop-ins: the loop records what slam2.py records for
+    the bundle adjuster (BA_info.* files, trajectory, map: slam2.py:743-865, 698-741), `tools/bundle_adjust.py` -- the counterpart of
+    the reference's C++ tool, same command line -- adjusts the recording, and both trajectories are held against the exact one."""
+    import tempfile, torch
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import bundle_adjust as ba_tool
+    io = mqslam_amd.ba_io
+    d = np.load(FIX)
+    n = frames
+    K, dist, P_init, pts = d["K"], d["dist"], d["init_pose"], d["init_points"]
+    H, W = d["frames"].shape[1:]
+    uv, vis = start_points(K, (H, W), P_init, pts)
+    gt = centres_from_tum(d["traj_groundtruth"][:n])
+    with tempfile.TemporaryDirectory() as tmp:
+        info = io.BundleAdjustmentInfoContainer(tmp, "mqslam", 1)
+        slam = mqslam_amd.slam_device.DeviceMonoSlam(K, dist, (H, W), seed=seed, ba_info=info, max_homography_points="reference", second_pass_screen=screen)
+        imgs = [torch.from_numpy(np.ascontiguousarray(f)).cuda() for f in d["frames"][:n]]
+        slam.start(imgs[0], pts[vis], uv[vis])
+        for k in range(1, n):
+            slam.handle_new_frame(imgs[k])
+        slam.finish()
+        info.write_all()
+        info.write_noise(point2D=1.0)
+        fn = io.create_filenames(tmp, "mqslam", 1)
+        io.save_slam_output(fn, 30, slam.projection_matrices(), slam.objp)
+        c0 = np.array([-P[:, :3].T @ P[:, 3] for P in slam.projection_matrices()])
+        slam.close()
+        rc = ba_tool.main(["bundle_adjust.py", tmp, "mqslam", "1", "30", "1", "0", "0", "1", "0"])       # odometry on, full optimisation
+        traj = io.load_trajectory(os.path.join(tmp, "traj_out.cam0-mqslam-BA.txt"))
+        c1 = np.array([np.asarray(p)[9:] for _, p in traj])
+    e = lambda c: float(np.sqrt(np.mean(np.sum((c - gt[:len(c)]) ** 2, axis=1))))
+    return {"frames": n, "tool_return_code": rc, "loop_vs_groundtruth_rmse_m": round(e(c0), 5), "after_the_tool_vs_groundtruth_rmse_m": round(e(c1), 5),
+            "poses_in_the_adjusted_file": len(c1)}
+
+
 if __name__ == "__main__":
+    if "--posthoc" in sys.argv:
+        a = [x for x in sys.argv[1:] if not x.startswith("--")]
+        print(json.dumps(run_posthoc(int(a[0]) if a else 80)))
+        sys.exit(0)
     a = [x for x in sys.argv[1:] if not x.startswith("--")]
     seed = int(sys.argv[sys.argv.index("--seed") + 1]) if "--seed" in sys.argv else 0
     window = int(sys.argv[sys.argv.index("--window") + 1]) if "--window" in sys.argv else None
