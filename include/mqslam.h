@@ -578,8 +578,9 @@ int64_t mqs_pnp_workspace_bytes(int64_t N, int B);
  *       out_n = number written (<= max_corners when max_corners > 0).
  *   mqs_calc_optical_flow_pyr_lk: replaces cv2.calcOpticalFlowPyrLK(prev, next, prevPts) (slam2.py:381; defaults
  *       21 x 21, maxLevel 3, 30 iterations, eps 0.01, minEigThreshold 1e-4).  next_pts [n][2], status [n] (1 = tracked),
- *       err [n] (mean absolute window difference at level 0).  Points whose window leaves the image are reported lost
- *       (OpenCV reads a replicated border there).
+ *       err [n] (mean absolute window difference at level 0).  A window may leave the image by up to its own size (lkpyramid.cpp's
+ *       test); it is then read as OpenCV reads its border-extended pyramid: intensities reflected (BORDER_REFLECT_101), the
+ *       derivative image zero outside (BORDER_CONSTANT).
  * ------------------------------------------------------------------------------------- */
 int mqs_good_features_to_track(mqs_ctx *ctx, const uint8_t *img, int W, int H, int max_corners, double quality_level,
                                double min_distance, const uint8_t *mask, float *out_xy, int out_capacity, int32_t *out_n);

@@ -531,13 +531,43 @@ __global__ __launch_bounds__(kBlock) void pyr_level_kernel(const uint8_t *__rest
 constexpr int kMaxLevels = 8;
 constexpr int kMaxWinPixelsPerLane = 16;      // windows up to 31 x 31 (961 pixels / 64 lanes)
 
+// The tracker reads BORDER-EXTENDED copies of the pyramid levels, as OpenCV 2.4's does (lkpyramid.cpp: buildOpticalFlowPyramid pads
+// every level by winSize with BORDER_REFLECT_101, the derivative image with BORDER_CONSTANT zeros): a window may leave the image by
+// up to its own size, and every read is a plain one.  I / J / dI point at the INTERIOR origin of a level's padded copy, P is its
+// row pitch (W + 2 kLkBorder).
+constexpr int kLkBorder = 32;                  // >= the largest window (31) + 1 for the bilinear neighbour
 struct LkLevels {
     const uint8_t *I[kMaxLevels];
     const uint8_t *J[kMaxLevels];
     const short2 *dI[kMaxLevels];
-    int W[kMaxLevels], H[kMaxLevels];
+    int W[kMaxLevels], H[kMaxLevels], P[kMaxLevels];
     int levels;                                // highest level index
 };
+
+// what the pyramid build leaves (tight level images, level 0 the caller's) -> the padded copies: one launch over all levels
+struct LkPadJob {
+    const uint8_t *I[kMaxLevels], *J[kMaxLevels];
+    const short2 *dI[kMaxLevels];
+    uint8_t *Ip[kMaxLevels], *Jp[kMaxLevels];  // padded buffers' ORIGINS (top-left of the border)
+    short2 *dIp[kMaxLevels];
+    int W[kMaxLevels], H[kMaxLevels];
+};
+__global__ __launch_bounds__(kBlock) void lk_pad_levels_kernel(LkPadJob job)
+{
+    const int l = blockIdx.z;
+    const int W = job.W[l], H = job.H[l], P = W + 2 * kLkBorder, Hp = H + 2 * kLkBorder;
+    const int xp = blockIdx.x * 32 + (threadIdx.x & 31), yp = blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (xp >= P || yp >= Hp) return;
+    const int x = xp - kLkBorder, y = yp - kLkBorder;
+    const bool inside = x >= 0 && x < W && y >= 0 && y < H;
+    // BORDER_REFLECT_101, one reflection then clamped (levels narrower than the border: the far part of the border is never read by
+    // a window that passes the tracker's own test)
+    int xr = x < 0 ? -x : x; xr = xr >= W ? 2 * (W - 1) - xr : xr; xr = xr < 0 ? 0 : (xr > W - 1 ? W - 1 : xr);
+    int yr = y < 0 ? -y : y; yr = yr >= H ? 2 * (H - 1) - yr : yr; yr = yr < 0 ? 0 : (yr > H - 1 ? H - 1 : yr);
+    job.Ip[l][yp * P + xp] = job.I[l][yr * W + xr];
+    job.Jp[l][yp * P + xp] = job.J[l][yr * W + xr];
+    job.dIp[l][yp * P + xp] = inside ? job.dI[l][y * W + x] : short2{0, 0};
+}
 
 // wave sums with the butterfly's pairs, without its ds_bpermute round trips (a quarter of a Lucas-Kanade iteration): wave_reduce.h
 __device__ __forceinline__ void wave_sum2_d(double x, double y, double &sx, double &sy) { mqs::wave::sum2(x, y, sx, sy); }
@@ -570,10 +600,11 @@ __global__ __launch_bounds__(64) void lk_kernel(LkLevels L, const float *__restr
         if (level == L.levels) { nx = px; ny = py; } else { nx = nx * 2.0f; ny = ny * 2.0f; }
         px -= halfx; py -= halfy;
         const int ipx = (int)floorf(px), ipy = (int)floorf(py);
-        if (ipx < -ww || ipx >= W || ipy < -wh || ipy >= H || ipx < 0 || ipy < 0 || ipx + ww + 1 > W || ipy + wh + 1 > H) {
+        if (ipx < -ww || ipx >= W || ipy < -wh || ipy >= H) {     // lkpyramid.cpp's test: the window may leave the image by its own size
             if (level == 0) { ok = false; errv = 0.0f; }
             continue;
         }
+        const int P = L.P[level];
         float Iw[kMaxWinPixelsPerLane], Ixw[kMaxWinPixelsPerLane], Iyw[kMaxWinPixelsPerLane];
         double a11 = 0.0, a12 = 0.0, a22 = 0.0;
         {
@@ -587,8 +618,8 @@ __global__ __launch_bounds__(64) void lk_kernel(LkLevels L, const float *__restr
                 Iw[t] = 0.0f; Ixw[t] = 0.0f; Iyw[t] = 0.0f;
                 if (p < npix) {
                     const int x = ipx + p % ww, y = ipy + p / ww;
-                    Iw[t] = bilinear_u8(I, W, x, y, w00, w01, w10, w11) * 32.0f;
-                    const short2 d00 = dI[y * W + x], d01 = dI[y * W + x + 1], d10 = dI[(y + 1) * W + x], d11 = dI[(y + 1) * W + x + 1];
+                    Iw[t] = bilinear_u8(I, P, x, y, w00, w01, w10, w11) * 32.0f;
+                    const short2 d00 = dI[y * P + x], d01 = dI[y * P + x + 1], d10 = dI[(y + 1) * P + x], d11 = dI[(y + 1) * P + x + 1];
                     Ixw[t] = (((float)d00.x * w00 + (float)d01.x * w01) + (float)d10.x * w10) + (float)d11.x * w11;
                     Iyw[t] = (((float)d00.y * w00 + (float)d01.y * w01) + (float)d10.y * w10) + (float)d11.y * w11;
                     a11 += (double)Ixw[t] * (double)Ixw[t];
@@ -612,7 +643,7 @@ __global__ __launch_bounds__(64) void lk_kernel(LkLevels L, const float *__restr
         const uint8_t *J = L.J[level];
         for (int j = 0; j < max_iter; ++j) {
             const int inx = (int)floorf(nx), iny = (int)floorf(ny);
-            if (inx < 0 || iny < 0 || inx + ww + 1 > W || iny + wh + 1 > H) {
+            if (inx < -ww || inx >= W || iny < -wh || iny >= H) {
                 if (level == 0) ok = false;
                 break;
             }
@@ -623,7 +654,7 @@ __global__ __launch_bounds__(64) void lk_kernel(LkLevels L, const float *__restr
             for (int t = 0; t < kMaxWinPixelsPerLane; ++t) {
                 const int p = lane + 64 * t;
                 if (p < npix) {
-                    const float diff = bilinear_u8(J, W, inx + p % ww, iny + p / ww, w00, w01, w10, w11) * 32.0f - Iw[t];
+                    const float diff = bilinear_u8(J, P, inx + p % ww, iny + p / ww, w00, w01, w10, w11) * 32.0f - Iw[t];
                     b1 += (double)diff * (double)Ixw[t];
                     b2 += (double)diff * (double)Iyw[t];
                 }
@@ -644,7 +675,7 @@ __global__ __launch_bounds__(64) void lk_kernel(LkLevels L, const float *__restr
         if (ok && level == 0) {
             const float qx = nx - halfx, qy = ny - halfy;
             const int inx = (int)floorf(qx), iny = (int)floorf(qy);
-            if (inx < 0 || iny < 0 || inx + ww + 1 > W || iny + wh + 1 > H) {
+            if (inx < -ww || inx >= W || iny < -wh || iny >= H) {
                 ok = false;
             } else {
                 const float a = qx - (float)inx, b = qy - (float)iny;
@@ -654,7 +685,7 @@ __global__ __launch_bounds__(64) void lk_kernel(LkLevels L, const float *__restr
                 for (int t = 0; t < kMaxWinPixelsPerLane; ++t) {
                     const int p = lane + 64 * t;
                     if (p < npix)
-                        e += fabs((double)(bilinear_u8(J, W, inx + p % ww, iny + p / ww, w00, w01, w10, w11) * 32.0f - Iw[t]));
+                        e += fabs((double)(bilinear_u8(J, P, inx + p % ww, iny + p / ww, w00, w01, w10, w11) * 32.0f - Iw[t]));
                 }
                 errv = (float)(wave_sum_d(e) / (32.0 * (double)ww * (double)wh));
             }
@@ -869,6 +900,9 @@ int64_t mqs_lk_workspace_bytes(int W, int H, int max_level)
         // prev / next level images (level 0 is the caller's) and the derivative image of prev
         if (l > 0) total += 2 * align_up((size_t)w * h);
         total += align_up((size_t)w * h * 4);
+        // ... and their border-extended copies (what the tracker reads)
+        const size_t padded = (size_t)(w + 2 * kLkBorder) * (h + 2 * kLkBorder);
+        total += 2 * align_up(padded) + align_up(padded * 4);
         if (w <= 2 || h <= 2) break;
         w = (w + 1) / 2; h = (h + 1) / 2;
     }
@@ -897,15 +931,25 @@ int mqs_lk_launch(const uint8_t *prev_img, const uint8_t *next_img, int W, int H
     MQS_ARG_CHECK(win_w >= 3 && win_h >= 3 && win_w * win_h <= 64 * kMaxWinPixelsPerLane, "3 <= window, at most 1024 pixels");
     MQS_ARG_CHECK(max_iter >= 1 && eps >= 0.0, "max_iter >= 1, eps >= 0");
     MQS_ARG_CHECK(workspace_bytes >= mqs_lk_workspace_bytes(W, H, max_level), "workspace too small (mqs_lk_workspace_bytes)");
+    MQS_ARG_CHECK(win_w + 1 <= kLkBorder && win_h + 1 <= kLkBorder, "window larger than the border the pyramid copies carry (31 x 31)");
     LkLevels L;
+    LkPadJob job;
     char *wsp = static_cast<char *>(workspace);
     int w = W, h = H;
     L.levels = 0;
-    L.I[0] = prev_img; L.J[0] = next_img;
+    job.I[0] = prev_img; job.J[0] = next_img;
     for (int l = 0; l <= max_level; ++l) {
-        L.W[l] = w; L.H[l] = h;
+        L.W[l] = w; L.H[l] = h; L.P[l] = w + 2 * kLkBorder;
+        job.W[l] = w; job.H[l] = h;
         short2 *d = reinterpret_cast<short2 *>(wsp); wsp += align_up((size_t)w * h * 4);
-        L.dI[l] = d;
+        job.dI[l] = d;
+        {
+            const size_t padded = (size_t)(w + 2 * kLkBorder) * (h + 2 * kLkBorder), origin = (size_t)kLkBorder * L.P[l] + kLkBorder;
+            job.Ip[l] = reinterpret_cast<uint8_t *>(wsp); wsp += align_up(padded);
+            job.Jp[l] = reinterpret_cast<uint8_t *>(wsp); wsp += align_up(padded);
+            job.dIp[l] = reinterpret_cast<short2 *>(wsp); wsp += align_up(padded * 4);
+            L.I[l] = job.Ip[l] + origin; L.J[l] = job.Jp[l] + origin; L.dI[l] = job.dIp[l] + origin;
+        }
         L.levels = l;
         const bool last = l == max_level || w <= 2 || h <= 2;
         const int wd = (w + 1) / 2, hd = (h + 1) / 2;
@@ -913,14 +957,19 @@ int mqs_lk_launch(const uint8_t *prev_img, const uint8_t *next_img, int W, int H
         if (!last) {
             pi = reinterpret_cast<uint8_t *>(wsp); wsp += align_up((size_t)wd * hd);
             pj = reinterpret_cast<uint8_t *>(wsp); wsp += align_up((size_t)wd * hd);
-            L.I[l + 1] = pi; L.J[l + 1] = pj;
+            job.I[l + 1] = pi; job.J[l + 1] = pj;
         }
         // derivatives of this level and, beside them, both images' next level: one launch
         dim3 g = grid2d(w, h);
         g.z = last ? 1 : 3;
-        hipLaunchKernelGGL(pyr_level_kernel, g, dim3(kBlock), 0, stream, L.I[l], L.J[l], w, h, d, pi, pj, wd, hd);
+        hipLaunchKernelGGL(pyr_level_kernel, g, dim3(kBlock), 0, stream, job.I[l], job.J[l], w, h, d, pi, pj, wd, hd);
         if (last) break;
         w = wd; h = hd;
+    }
+    {
+        dim3 g = grid2d(W + 2 * kLkBorder, H + 2 * kLkBorder);            // sized for level 0; the other levels use its first part
+        g.z = (unsigned)(L.levels + 1);
+        hipLaunchKernelGGL(lk_pad_levels_kernel, g, dim3(kBlock), 0, stream, job);
     }
     if (n > 0)
         hipLaunchKernelGGL(lk_kernel, dim3(n), dim3(64), 0, stream, L, prev_pts, n, n_dev, win_w, win_h, max_iter, (float)eps,

@@ -122,6 +122,7 @@ class DeviceMonoSlam:
         self.ba_outlier_pixels = 4.0     # a landmark with a residual beyond this after an adjustment is a mistracked corner
         self.ba_gross_pixels = 40.0      # ... and with one beyond this BEFORE the adjustment it does not enter it
         self.ba_max_passes = 4           # adjust, screen, adjust again from the same start: at most this many adjustments
+        self.ba_border_margin = 10.0     # observations nearer to the image border than half a 21 x 21 tracker window stay out of the adjustment
         self.ba_min_depth_ratio = 0.02   # a landmark closer to one of its cameras than this fraction of the median landmark depth sits out
         # the noise models of the adjustment (the reference keeps them in the four BA_info.noise.* files beside a recording; its
         # ICL-NUIM run: point3D 0.2, pose (0.02 x 3, 0.1 x 3), odometry (0.05 x 3, 0.2 x 3), point2D 1.0)
@@ -301,6 +302,13 @@ class DeviceMonoSlam:
             self._odo.append((self._accepted.index(base), len(self._accepted) - 1, pose_from_world_to_camera((P1 @ np.linalg.inv(P0))[:3])))
         lm, ps, uv = self.read_log()
         known = lm >= 0                                               # (free tracks that have not become landmarks)
+        if self.ba_border_margin:
+            # an observation closer to the image border than half a tracker window was measured on a window that reads the
+            # border-extended pyramid -- mirrored content (OpenCV's tracker, and this one since round 4, follows a point until its
+            # window has left the image altogether): good enough for RANSAC to sort out, not for a least-squares adjustment
+            H_, W_ = self.shape
+            m = self.ba_border_margin
+            known &= (uv[:, 0] >= m) & (uv[:, 0] <= W_ - 1 - m) & (uv[:, 1] >= m) & (uv[:, 1] <= H_ - 1 - m)
         lm, ps, uv = lm[known], ps[known], uv[known]
         pts = self.objp.astype(np.float64)
         N, P = len(pts), len(self._accepted)

@@ -162,6 +162,34 @@ def _bilinear_window(a, ix, iy, fx, fy, w, h):
     return ((v[:-1, :-1] * w00 + v[:-1, 1:] * w01) + v[1:, :-1] * w10) + v[1:, 1:] * w11
 
 
+def _refl101(idx, n):
+    """BORDER_REFLECT_101 index (one reflection, then clamped: a window reaches at most win + 1 pixels beyond the image)."""
+    idx = np.abs(idx)
+    idx = np.where(idx >= n, 2 * (n - 1) - idx, idx)
+    return np.clip(idx, 0, n - 1)
+
+
+def _bilinear_window_border(a, ix, iy, fx, fy, w, h, zero_outside):
+    """_bilinear_window for a window that leaves the image, read as OpenCV 2.4's tracker reads it from the border-extended
+    pyramid (lkpyramid.cpp: buildOpticalFlowPyramid pads every level by winSize with BORDER_REFLECT_101; the derivative image is
+    padded with BORDER_CONSTANT zeros): zero_outside=False reflects, True reads 0 outside the image."""
+    H, W = a.shape
+    xs, ys = ix + np.arange(w + 1), iy + np.arange(h + 1)
+    v = a[_refl101(ys, H)][:, _refl101(xs, W)].astype(F)
+    if zero_outside:
+        v = v * (((ys >= 0) & (ys < H))[:, None] & ((xs >= 0) & (xs < W))[None, :]).astype(F)
+    w00, w01 = F((1 - fx) * (1 - fy)), F(fx * (1 - fy))
+    w10, w11 = F((1 - fx) * fy), F(fx * fy)
+    return ((v[:-1, :-1] * w00 + v[:-1, 1:] * w01) + v[1:, :-1] * w10) + v[1:, 1:] * w11
+
+
+def _window(a, ix, iy, fx, fy, w, h, zero_outside=False):
+    H, W = a.shape
+    if ix >= 0 and iy >= 0 and ix + w + 1 <= W and iy + h + 1 <= H:
+        return _bilinear_window(a, ix, iy, fx, fy, w, h)
+    return _bilinear_window_border(a, ix, iy, fx, fy, w, h, zero_outside)
+
+
 def calc_optical_flow_pyr_lk(prev_img, next_img, prev_pts, win_size=(21, 21), max_level=3, max_iter=30, eps=0.01,
                              min_eig_threshold=1e-4):
     """Returns next_pts (n, 2) float32, status (n,) uint8, err (n,) float32 (mean absolute intensity difference
@@ -193,17 +221,15 @@ def calc_optical_flow_pyr_lk(prev_img, next_img, prev_pts, win_size=(21, 21), ma
                     status[k] = 0
                     err[k] = 0
                 continue
-            # the window must lie inside the image (OpenCV reads a (w+1) x (h+1) patch through the border-extended
-            # pyramid; this restatement requires the patch inside and otherwise treats the point as lost)
-            if ipx < 0 or ipy < 0 or ipx + ww + 1 > W or ipy + wh + 1 > H:
-                if level == 0:
-                    status[k] = 0
-                    err[k] = 0
-                continue
+            # a window may leave the image by up to its own size (the test above is OpenCV's): it is read through the
+            # border-extended pyramid -- intensities reflected (BORDER_REFLECT_101), derivatives zero outside the image
+            # (BORDER_CONSTANT).  (Until round 4 this restatement required the window inside the image and lost every corner
+            # within half a window of the border: 28 of 277 on frame 0 of the reference's example sequence, where the reference's
+            # own record shows next to none lost.)
             a, b = F(prev[0] - ipx), F(prev[1] - ipy)
-            Iw = _bilinear_window(I, ipx, ipy, a, b, ww, wh) * F(32.0)
-            Ixw = _bilinear_window(dIx, ipx, ipy, a, b, ww, wh)
-            Iyw = _bilinear_window(dIy, ipx, ipy, a, b, ww, wh)
+            Iw = _window(I, ipx, ipy, a, b, ww, wh) * F(32.0)
+            Ixw = _window(dIx, ipx, ipy, a, b, ww, wh, zero_outside=True)
+            Iyw = _window(dIy, ipx, ipy, a, b, ww, wh, zero_outside=True)
             A11 = F(np.sum(Ixw.astype(np.float64) * Ixw)) * FLT_SCALE
             A12 = F(np.sum(Ixw.astype(np.float64) * Iyw)) * FLT_SCALE
             A22 = F(np.sum(Iyw.astype(np.float64) * Iyw)) * FLT_SCALE
@@ -218,12 +244,12 @@ def calc_optical_flow_pyr_lk(prev_img, next_img, prev_pts, win_size=(21, 21), ma
             prev_delta = np.zeros(2, dtype=F)
             for j in range(max_iter):
                 inx, iny = int(np.floor(nxt[0])), int(np.floor(nxt[1]))
-                if inx < 0 or iny < 0 or inx + ww + 1 > W or iny + wh + 1 > H:
+                if inx < -ww or inx >= W or iny < -wh or iny >= H:
                     if level == 0:
                         status[k] = 0
                     break
                 a, b = F(nxt[0] - inx), F(nxt[1] - iny)
-                Jw = _bilinear_window(J, inx, iny, a, b, ww, wh) * F(32.0)
+                Jw = _window(J, inx, iny, a, b, ww, wh) * F(32.0)
                 diff = Jw - Iw
                 b1 = F(np.sum(diff.astype(np.float64) * Ixw)) * FLT_SCALE
                 b2 = F(np.sum(diff.astype(np.float64) * Iyw)) * FLT_SCALE
@@ -239,11 +265,11 @@ def calc_optical_flow_pyr_lk(prev_img, next_img, prev_pts, win_size=(21, 21), ma
             if status[k] and level == 0:
                 p = next_pts[k] - half
                 inx, iny = int(np.floor(p[0])), int(np.floor(p[1]))
-                if inx < 0 or iny < 0 or inx + ww + 1 > W or iny + wh + 1 > H:
+                if inx < -ww or inx >= W or iny < -wh or iny >= H:
                     status[k] = 0
                 else:
                     a, b = F(p[0] - inx), F(p[1] - iny)
-                    Jw = _bilinear_window(J, inx, iny, a, b, ww, wh) * F(32.0)
+                    Jw = _window(J, inx, iny, a, b, ww, wh) * F(32.0)
                     err[k] = F(np.sum(np.abs((Jw - Iw).astype(np.float64))) / (32.0 * ww * wh))
     return next_pts, status, err
 

@@ -326,6 +326,37 @@ def test_adjustment_in_the_loop_survives_a_grossly_mistracked_corner(gpu, seed):
 
 
 @pytest.mark.gpu
+def test_windowed_adjustment_in_the_device_loop(gpu):
+    """ba_window_keyframes: the adjustment over the frames since the K-th keyframe from the end (anchored by pose priors on the
+    window's first two keyframes and by priors on the landmarks the frames in front of it have seen) instead of over every frame so
+    far -- bounded cost per keyframe.  On 200 frames of the reference's example sequence with K = 10: 5.0-9.6 mm from the exact
+    trajectory against 5.1-6.1 mm for the full adjustment, 4-5 ms per adjustment at the end of the run against 11-35
+    (profiles/r04/20); here the rendered 60-frame sequence with K = 5."""
+    import torch
+    seq = gpu.synthetic.PlaneSequence(frames=60)
+    gx, gy = np.meshgrid(np.linspace(-4.5, 1.0, 8), np.linspace(-2.5, 2.0, 6))
+    objp = np.stack([gx.ravel(), gy.ravel(), np.zeros(gx.size)], axis=1)
+    imgp = seq.project(0, objp)
+    vis = (imgp[:, 0] > 15) & (imgp[:, 0] < seq.W - 15) & (imgp[:, 1] > 15) & (imgp[:, 1] < seq.H - 15)
+    imgs = [torch.from_numpy(seq.render(k)).cuda() for k in range(60)]
+    gt = seq.centres()
+
+    def run(**kw):
+        s = gpu.slam_device.DeviceMonoSlam(seq.K, seq.dist, (seq.H, seq.W), seed=1, bundle_adjust="keyframe", **kw)
+        s.start(imgs[0], objp[vis], imgp[vis])
+        rets = [s.handle_new_frame(imgs[k]) for k in range(1, 60)]
+        s.finish()
+        c = np.array([-P[:, :3].T @ P[:, 3] for P in s.poses])
+        out = (all(r in (1, 2) for r in rets), float(np.sqrt(np.mean(np.sum((c - gt) ** 2, axis=1)))), s.ba_reports[-1]["poses"], len(s.keyframes))
+        s.close()
+        return out
+    full, win = run(), run(ba_window_keyframes=5)
+    assert full[0] and win[0] and win[3] >= 10
+    assert win[2] < 0.5 * full[2]                                                     # poses in the last adjustment
+    assert win[1] < 0.008 and win[1] < full[1] + 0.004                                # measured 0.0040 against 0.0029
+
+
+@pytest.mark.gpu
 def test_observation_log_of_the_device_loop(gpu):
     """The log the frame kernels keep for the adjuster (csrc/slam_frame.hip): one entry per kept track and accepted frame, pose
     indices = ranks among the accepted frames, a new landmark's entries reach back to its base keyframe (slam2.py:634-641), and
