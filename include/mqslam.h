@@ -670,6 +670,50 @@ int mqs_slam_set_thresholds(mqs_slam *s, double max_of_error, double max_lost_tr
  *                         keyframe's top-up has just detected; a matched corner continues its landmark (and the observation
  *                         is logged) instead of starting a new one.  *n_matched: corners re-associated. */
 int mqs_slam_reassociate(mqs_slam *s, float max_radius, double max_dist_ratio, int32_t *n_matched);
+ /*   mqs_slam_bundle_adjust   the adjustment behind a keyframe as ONE call on the resident state (round 5): what
+ *                         `performBundleAdjustment` (bundle_adjust.cpp:190-330, iSAM_version 0: the whole graph, one batch
+ *                         LevenbergMarquardtOptimizer::optimize()) does with the reference's recording, done with the log,
+ *                         the map and the trajectory where they are.  One persistent launch on the handle's stream builds the
+ *                         sparse problem from the log (every accepted frame so far, every landmark seen from at least
+ *                         `min_observations` frames; gauge as bundle_adjust.cpp:268-282: a pose prior on the first frame at
+ *                         its start-up estimate, point priors on the start-up landmarks at their given positions; odometry
+ *                         BetweenFactors keyframe -> keyframe, :301-309), runs GTSAM 3.2.1's default Levenberg-Marquardt
+ *                         schedule (<= max_iterations) -- landmark elimination, reduced camera system, Cholesky, back-
+ *                         substitution, trial cost, accept / reject all inside the launch, workgroups meeting at grid-wide
+ *                         barriers -- screens mistracked landmarks (a landmark whose worst residual exceeds `gross_px`
+ *                         before, `outlier_px` after an adjustment, or that lies closer to one of its cameras than
+ *                         `min_depth_ratio` x the median depth, sits out from then on; the adjustment is redone from its
+ *                         start, <= max_passes) and writes the adjusted landmarks (float32 values, slam2.py:19), the poses of
+ *                         all accepted frames and the live state's two poses back.  Nothing is copied to the host but the
+ *                         report and, if asked for, the adjusted poses.
+ *                         add_odometry_edge != 0: the call stands behind a keyframe; the edge (edge_from = the previous base
+ *                         keyframe's pose index, edge_to = this keyframe's) is measured from the trajectory as it stands
+ *                         (slam2.py:681-687) and kept for this and all later adjustments.
+ *                         report [MQS_SLAM_BA_REPORT] doubles: [0] status (0 done; 1 a grid-wide wait gave up -> MQS_E_TIMEOUT;
+ *                         2 capacity: more than 256 poses, or a pose with more observations than a list holds -> MQS_E_ARG;
+ *                         3 the log overflowed -> MQS_E_ARG), [1] poses, [2] landmarks, [3] landmarks adjusted, [4] observations
+ *                         used, [5] passes, [6] landmarks screened out by this call, [7] LM iterations of the last pass,
+ *                         [8] cost before, [9] cost after, [10] LM trials (linearise + solve) in all, [11] observations
+ *                         that repeat a (landmark, frame) pair and were left out, [12] odometry edges, [13] grid barriers
+ *                         passed.  poses_out (host, may be NULL): the adjusted [R | t] world -> camera of the first
+ *                         min(poses, poses_cap) accepted frames. */
+#define MQS_SLAM_BA_REPORT 16
+#define MQS_SLAM_BA_MAX_POSES 256
+typedef struct mqs_slam_ba_params {
+    int32_t max_iterations, min_observations, max_passes;
+    int32_t add_odometry_edge, edge_from, edge_to;
+    int32_t damping;                                  /* MQS_SBA_DAMPING_GTSAM / _MARQUARDT */
+    int32_t workgroups;                               /* 0: the library's choice */
+    double outlier_px, gross_px, border_margin_px, min_depth_ratio;
+    double point_sigma, pixel_sigma;
+    double pose_sigmas[6], odometry_sigmas[6];        /* rotation (3) then translation (3), as the reference's noise files */
+    double lambda_initial, lambda_factor, lambda_upper, abs_tol, rel_tol;
+} mqs_slam_ba_params;
+int mqs_slam_bundle_adjust(mqs_slam *s, const mqs_slam_ba_params *params, double *report, double *poses_out, int32_t poses_cap);
+/* the landmarks the in-loop adjuster has retired so far (1) / not (0): host uint8 [cap]; *n = landmarks in the map */
+int mqs_slam_read_ba_flags(mqs_slam *s, uint8_t *retired, int cap, int32_t *n);
+/* profiling hook: phase stamps of the adjuster's last launch (see csrc/slam_ba.hip); the first call switches them on */
+int mqs_debug_slam_ba_stamps(mqs_slam *s, int64_t *out, int cap, int32_t *n);
 int mqs_slam_log_enable(mqs_slam *s, int64_t capacity);
 int mqs_slam_read_log(mqs_slam *s, int32_t *lm, int32_t *pose, double *uv, int64_t cap, int64_t *n);
 int mqs_slam_write_back(mqs_slam *s, const double *map, int n, const double *pose_prev, const double *pose_key);

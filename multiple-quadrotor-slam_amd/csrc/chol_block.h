@@ -88,7 +88,9 @@ __device__ __forceinline__ void factor_diag_block_from_lds(const double *sT, dou
 // per factor step (linearise + solve 0.73 -> 0.707 ms chunked, 3.33 -> 3.21 ms in natural order); the barrier per pivot is what
 // is left, and scaling the next pivot's column ahead of the other updates did not shorten it (0.713-0.724 ms).  Same operations
 // on every element in the same order: the result is bit-identical to the single-wave version.
-template <int w>                                             // the wavefront's index in the workgroup: compile time, so that
+// kSc1: the factor is stored write-through (relaxed agent-scope stores: global_store ... sc1), for kernels whose other workgroups
+// read it later in the SAME launch (slam_ba.hip).
+template <int w, bool kSc1 = false>                          // the wavefront's index in the workgroup: compile time, so that
 __device__ __forceinline__ void factor_diag_block_4w_wave(const double *sT, double *__restrict__ A, int n, int t0,    // j > k folds
                                                           int *__restrict__ bad, int lane, double *sM)
 {
@@ -125,26 +127,33 @@ __device__ __forceinline__ void factor_diag_block_4w_wave(const double *sT, doub
             }
         }
     }
-    if (lane == 0 && notpd) *bad = 1;
+    if (lane == 0 && notpd) {
+        if (kSc1) __hip_atomic_store(bad, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else *bad = 1;
+    }
     if (live) {
         double *Arow = A + (int64_t)(t0 + r) * n + t0;
 #pragma unroll
         for (int jj = 0; jj < NB / 4; ++jj) {
             const int j = 4 * jj + w;
-            if (j < nb2 && (upper ? j > r : j <= r)) Arow[j] = v[jj];        // upper half: v = inv(L)[j][r], j > r
+            if (j < nb2 && (upper ? j > r : j <= r)) {                       // upper half: v = inv(L)[j][r], j > r
+                if (kSc1) __hip_atomic_store(Arow + j, v[jj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else Arow[j] = v[jj];
+            }
         }
     }
 }
 
+template <bool kSc1 = false>
 __device__ __forceinline__ void factor_diag_block_from_lds_4w(const double *sT, double *__restrict__ A, int n, int t0,
                                                               int *__restrict__ bad, int tid, double *sM)
 {
     // (the four instances reach their barriers at different addresses: s_barrier counts arrivals, not program counters)
     switch (tid >> 6) {
-    case 0: factor_diag_block_4w_wave<0>(sT, A, n, t0, bad, tid & 63, sM); break;
-    case 1: factor_diag_block_4w_wave<1>(sT, A, n, t0, bad, tid & 63, sM); break;
-    case 2: factor_diag_block_4w_wave<2>(sT, A, n, t0, bad, tid & 63, sM); break;
-    default: factor_diag_block_4w_wave<3>(sT, A, n, t0, bad, tid & 63, sM); break;
+    case 0: factor_diag_block_4w_wave<0, kSc1>(sT, A, n, t0, bad, tid & 63, sM); break;
+    case 1: factor_diag_block_4w_wave<1, kSc1>(sT, A, n, t0, bad, tid & 63, sM); break;
+    case 2: factor_diag_block_4w_wave<2, kSc1>(sT, A, n, t0, bad, tid & 63, sM); break;
+    default: factor_diag_block_4w_wave<3, kSc1>(sT, A, n, t0, bad, tid & 63, sM); break;
     }
 }
 

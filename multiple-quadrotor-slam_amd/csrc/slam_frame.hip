@@ -21,67 +21,12 @@
 #include "pnp_math.h"
 #include "cam_math.h"
 #include "wave_reduce.h"
+#include "slam_state.h"
 #include <new>
 
 namespace {
 
-constexpr int kMaxTracks = 512;                 // capacity of the live-track arrays (the reference tops up to <= 300)
-constexpr int kHyp = 256, kSample = 6;          // RANSAC: hypotheses per frame, points per minimal sample (pnp.py)
-constexpr int kSampleIters = 5, kPnpIters = 100;
-constexpr double kPnpEps = 1e-10;
-constexpr int kRes = 40;                        // doubles in the result block
-
-// counters in device memory
-enum { C_N = 0, C_NLAND, C_NEXT_TID, C_FRAME, C_NTRI, C_NKEEP, C_KF_PENDING, C_NLOG, C_COUNT };
-// result block (doubles)
-enum { R_DECISION = 0, R_REASON, R_NTRACKS, R_NTRI, R_NINL, R_NOLD, R_NNEW, R_LOST, R_OUTLIER, R_REPROJ, R_HOMOGRAPHY, R_NLAND,
-       R_POSE = 12, R_KF_VALID = 24, R_KF_NGOOD, R_KF_NTRACKS, R_KF_NLAND, R_KF_POSE = 28 };
-
-struct SlamDev {
-    int32_t *cnt;
-    float *pts, *base;
-    int32_t *lm, *tid;
-    double *map;
-    double *pose_key, *pose_prev, *intr;
-    float *lk_pts, *lk_err;
-    uint8_t *lk_st;
-    float *t_pts, *t_base;
-    int32_t *t_lm, *t_tid;
-    double *objp_t, *imgp_t;
-    int32_t *tri_pos, *samples;
-    double *pose_r;
-    int32_t *sel;
-    uint8_t *inl_mask;
-    double *pnp_info;
-    double *kf_objp, *kf_imgp, *kf_p0, *kf_p1;
-    int32_t *kf_pos;
-    double *kf_scratch, *kf_pose, *kf_x, *kf_info;
-    int32_t *kf_status;
-    uint8_t *mask;
-    float *gf_xy;
-    int32_t *gf_n;
-    double *res;
-    // the observation log for the bundle adjuster (mqs_slam_log_enable; null: off): what slam2.py's BundleAdjustmentInfoContainer is
-    // handed (:519-522, 634-641), as flat device arrays -- (landmark, pose index of the accepted frame, pixel) per observation
-    int32_t *log_lm, *log_pose;
-    double *log_uv;
-    int log_cap;
-    // a FREE track's observation is logged under -2 - (track id); when the track becomes a landmark, tid2lm[track id] says which
-    // (slam2.py:634-641: a new landmark brings its image points of every frame since the base keyframe along)
-    int32_t *tid2lm;
-    int tid_cap;
-};
-
-struct SlamParams {
-    int W, H, target, max_landmarks;
-    double radius, quality;
-    double max_of_error, max_lost_ratio, max_reproj, max_outlier_ratio, homography_threshold;
-    double second_pass_screen_px;   // 0 (default): slam2.py's flow; > 0: mqs_slam_set_second_pass_screen
-    unsigned long long seed;
-    int homography_refine;          // 1 (default): DLT + the LM refinement, as cv2.findHomography(method = 0); 0: the DLT alone (A/B)
-    int max_homography_points;      // keyframe_test's random sample (slam2.py:48; the reference: max(4, target / 4), :1088-1089); 0 = all tracks (default)
-    int pose_index, base_pose_index; // index this frame gets among the ACCEPTED frames if it is accepted; that of the base keyframe
-};
+using namespace mqs::slamst;
 
 // rank of this thread among the flagged threads of the workgroup (thread order), and their number; two barriers
 __device__ __forceinline__ int block_rank(bool flag, int tid, int *sWave, int &total)
@@ -483,7 +428,8 @@ __global__ __launch_bounds__(256) void frame_decide_kernel(SlamDev d, SlamParams
     __syncthreads();
     if (tid < 12) d.pose_prev[tid] = sP[tid];
     if (tid == 0) d.cnt[C_N] = n_acc;
-    if (tid == 0 && d.log_lm) d.cnt[C_NLOG] = min(nlog0 + n_acc, d.log_cap);
+    if (tid == 0 && d.log_lm) { d.cnt[C_NLOG] = min(nlog0 + n_acc, d.log_cap); if (nlog0 + n_acc > d.log_cap) d.cnt[C_LOG_OVERFLOW] = 1; }
+    if (d.traj && tid < 12 && p.pose_index < d.traj_cap) d.traj[12 * (size_t)p.pose_index + tid] = sP[tid];
 
     // keyframe_test's random sample of the kept tracks (slam2.py:48: np.random.permutation(n)[:max_num_homography_points]): a
     // counter-based hash of (seed, frame, track position) per track, the tracks with the max_homography_points smallest hashes are
@@ -654,7 +600,7 @@ __global__ __launch_bounds__(256) void keyframe_commit_kernel(SlamDev d, SlamPar
         n_good += tot;
     }
     if (nl + n_good > p.max_landmarks) n_good = p.max_landmarks - nl;
-    if (tid == 0 && d.log_lm) d.cnt[C_NLOG] = min(nlog0 + n_good, d.log_cap);
+    if (tid == 0 && d.log_lm) { d.cnt[C_NLOG] = min(nlog0 + n_good, d.log_cap); if (nlog0 + n_good > d.log_cap) d.cnt[C_LOG_OVERFLOW] = 1; }
     __threadfence_block();
     __syncthreads();
     // drop the free tracks that did not become landmarks: through the temporaries, back in order
@@ -677,7 +623,10 @@ __global__ __launch_bounds__(256) void keyframe_commit_kernel(SlamDev d, SlamPar
     const double *pf = n_new > 0 ? d.kf_pose + 12 : d.pose_prev;
     double v = tid < 12 ? pf[tid] : 0.0;
     __syncthreads();
-    if (tid < 12) { d.pose_prev[tid] = v; d.pose_key[tid] = v; d.res[R_KF_POSE + tid] = v; }
+    if (tid < 12) {
+        d.pose_prev[tid] = v; d.pose_key[tid] = v; d.res[R_KF_POSE + tid] = v;
+        if (d.traj && p.pose_index < d.traj_cap) d.traj[12 * (size_t)p.pose_index + tid] = v;
+    }
     if (tid == 0) {
         d.cnt[C_N] = n2; d.cnt[C_NLAND] = nl + n_good;
         d.res[R_KF_VALID] = 1.0; d.res[R_KF_NGOOD] = (double)n_good; d.res[R_KF_NLAND] = (double)(nl + n_good);
@@ -737,13 +686,14 @@ __global__ __launch_bounds__(256) void start_kernel(SlamDev d, const float *objp
         d.cnt[C_N] = n0; d.cnt[C_NLAND] = n0; d.cnt[C_NEXT_TID] = n0; d.cnt[C_FRAME] = 1; d.cnt[C_NTRI] = 0; d.cnt[C_NKEEP] = 0;
         d.cnt[C_KF_PENDING] = 0;
         d.cnt[C_NLOG] = d.log_lm ? min(n0, d.log_cap) : 0;
+        d.cnt[C_LOG_OVERFLOW] = (d.log_lm && n0 > d.log_cap) ? 1 : 0;
     }
 }
 
 __global__ void start_pose_kernel(SlamDev d)
 {
     const int tid = threadIdx.x;
-    if (tid < 12) { const double v = d.pose_r[tid]; d.pose_prev[tid] = v; d.pose_key[tid] = v; d.res[R_POSE + tid] = v; }
+    if (tid < 12) { const double v = d.pose_r[tid]; d.pose_prev[tid] = v; d.pose_key[tid] = v; d.res[R_POSE + tid] = v; if (d.traj) d.traj[tid] = v; }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -807,26 +757,12 @@ __global__ __launch_bounds__(256) void reassoc_apply_kernel(SlamDev d, SlamParam
     }
     if (tid == 0) {
         n_out[0] = done;
-        if (d.log_lm) d.cnt[C_NLOG] = min(nlog0 + done, d.log_cap);
+        if (d.log_lm) { d.cnt[C_NLOG] = min(nlog0 + done, d.log_cap); if (nlog0 + done > d.log_cap) d.cnt[C_LOG_OVERFLOW] = 1; }
     }
 }
 
 }  // namespace
 
-struct mqs_slam {
-    int device;
-    hipStream_t stream;
-    SlamDev d;
-    SlamParams p;
-    char *arena;
-    double *res_host;                // pinned
-    void *ws_lk, *ws_gftt, *ws_pnp;
-    int64_t ws_lk_bytes, ws_gftt_bytes;
-    bool started;
-    int accepted, base_pose;         // accepted frames so far (= the next accepted frame's pose index); pose index of the base keyframe
-    char *log_arena;
-    char *re_arena;                  // re-association scratch (allocated on first use)
-};
 
 namespace {
 
@@ -859,7 +795,7 @@ int mqs_slam_create(int device, int W, int H, const double *intr, int target_key
     if (!s) { mqs_set_error("out of host memory"); return MQS_E_NOMEM; }
     s->device = device;
     s->started = false;
-    s->accepted = 0; s->base_pose = 0; s->log_arena = nullptr; s->re_arena = nullptr;
+    s->accepted = 0; s->base_pose = 0; s->log_arena = nullptr; s->re_arena = nullptr; s->ba = nullptr; s->land_ub = 0; s->key_pose = 0;
     s->p = SlamParams{W, H, target_keypoints, max_landmarks, coverage_radius, quality_level,
                       12.0, 0.5, 2.0, 0.33, 1.04, 0.0, (unsigned long long)seed, 1, 0};  // slam2.py:1070-1098; keyframe test on ALL tracks
     if (const char *e = getenv("MQS_SLAM_HOMOGRAPHY_REFINE")) s->p.homography_refine = e[0] != '0';        // A/B: 0 = the DLT alone
@@ -915,6 +851,7 @@ void mqs_slam_destroy(mqs_slam *s)
     (void)hipSetDevice(s->device);
     (void)hipStreamSynchronize(s->stream);
     (void)hipFree(s->arena);
+    mqs_slam_ba_release(s);
     if (s->log_arena) (void)hipFree(s->log_arena);
     if (s->re_arena) (void)hipFree(s->re_arena);
     if (s->res_host) (void)hipHostFree(s->res_host);
@@ -928,7 +865,9 @@ int mqs_slam_log_enable(mqs_slam *s, int64_t capacity)
     MQS_ARG_CHECK(s != nullptr && capacity >= 64 && capacity < (1ll << 30), "handle; 64 <= capacity < 2^30");
     MQS_ARG_CHECK(!s->started && s->log_arena == nullptr, "before mqs_slam_start, once");
     MQS_HIP_CHECK(hipSetDevice(s->device));
-    const size_t bytes = (size_t)capacity * (4 + 4 + 16 + 4);
+    const int traj_cap = 65536;                     // accepted frames whose pose is kept for the in-loop adjuster (96 bytes each)
+    const size_t traj_off = ((size_t)capacity * (4 + 4 + 16 + 4) + 255) & ~size_t(255);
+    const size_t bytes = traj_off + (size_t)traj_cap * 96;
     hipError_t e = hipMalloc((void **)&s->log_arena, bytes);
     if (e != hipSuccess) { s->log_arena = nullptr; mqs_set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); return MQS_E_NOMEM; }
     s->d.log_uv = reinterpret_cast<double *>(s->log_arena);
@@ -937,6 +876,8 @@ int mqs_slam_log_enable(mqs_slam *s, int64_t capacity)
     s->d.tid2lm = s->d.log_pose + capacity;         // track ids never outnumber the observations
     s->d.log_cap = (int)capacity;
     s->d.tid_cap = (int)capacity;
+    s->d.traj = reinterpret_cast<double *>(s->log_arena + traj_off);
+    s->d.traj_cap = traj_cap;
     MQS_HIP_CHECK(hipMemsetAsync(s->d.tid2lm, 0xff, (size_t)capacity * 4, s->stream));
     MQS_HIP_CHECK(hipStreamSynchronize(s->stream));
     return MQS_OK;
@@ -952,6 +893,10 @@ int mqs_slam_read_log(mqs_slam *s, int32_t *lm, int32_t *pose, double *uv, int64
     MQS_HIP_CHECK(hipMemcpyAsync(cnt, s->d.cnt, sizeof(cnt), hipMemcpyDeviceToHost, s->stream));
     MQS_HIP_CHECK(hipStreamSynchronize(s->stream));
     *n = cnt[C_NLOG];
+    if (cnt[C_LOG_OVERFLOW]) {
+        mqs_set_error("the observation log is full (%d entries, mqs_slam_log_enable's capacity): observations have been dropped", s->d.log_cap);
+        return MQS_E_ARG;
+    }
     const int64_t m = cnt[C_NLOG] < cap ? cnt[C_NLOG] : cap;
     if (m > 0) {
         if (lm) MQS_HIP_CHECK(hipMemcpyAsync(lm, s->d.log_lm, (size_t)m * 4, hipMemcpyDeviceToHost, s->stream));
@@ -1038,12 +983,16 @@ int mqs_slam_start(mqs_slam *s, const uint8_t *img_dev, const float *objp0, cons
     hipLaunchKernelGGL(start_pose_kernel, dim3(1), dim3(64), 0, s->stream, s->d);
     rc = topup(s, img_dev);
     if (rc != MQS_OK) return rc;
+    rc = mqs_slam_ba_anchor(s, n0);                    // with the log on: where the in-loop adjuster's gauge sits
+    if (rc != MQS_OK) return rc;
     MQS_HIP_CHECK(hipMemcpyAsync(s->res_host, s->d.res, kRes * 8, hipMemcpyDeviceToHost, s->stream));
     MQS_HIP_CHECK(hipStreamSynchronize(s->stream));
     memcpy(pose_out, s->res_host + R_POSE, 96);
     s->started = true;
     s->accepted = 1;                  // the first frame is pose 0 and the first base keyframe
     s->base_pose = 0;
+    s->land_ub = n0;
+    s->key_pose = 0;
     return MQS_OK;
 }
 
@@ -1078,7 +1027,10 @@ int mqs_slam_track(mqs_slam *s, const uint8_t *prev_img_dev, const uint8_t *img_
     if (result[R_DECISION] >= 1.0) s->accepted += 1;
     if (result[R_DECISION] == 2.0) {
         s->base_pose = s->p.pose_index;                 // (the kernels below still get the OLD base through s->p.base_pose_index)
+        s->key_pose = s->p.pose_index;
         const int n_old = (int)result[R_NOLD], n_new = (int)result[R_NNEW];
+        s->land_ub = (int)result[R_NLAND] + n_new;      // the keyframe step adds at most its free tracks
+        if (s->land_ub > s->p.max_landmarks) s->land_ub = s->p.max_landmarks;
         if (n_new > 0) {
             rc = mqs_keyframe_step_launch(d.kf_objp, d.kf_imgp, n_old, d.kf_p0, d.kf_p1, n_new, d.intr, d.pose_prev, d.pose_key, 3.e-5,
                                           kPnpIters, kPnpEps, s->p.second_pass_screen_px, d.kf_scratch, d.kf_pose, d.kf_x, d.kf_status, d.kf_info,

@@ -1,0 +1,93 @@
+// State of the device-resident frame loop (slam_frame.hip) shared with its in-loop bundle adjuster (slam_ba.hip).
+#pragma once
+#include "mqs_common.h"
+
+namespace mqs {
+namespace slamst {
+
+constexpr int kMaxTracks = 512;                 // capacity of the live-track arrays (the reference tops up to <= 300)
+constexpr int kHyp = 256, kSample = 6;          // RANSAC: hypotheses per frame, points per minimal sample (pnp.py)
+constexpr int kSampleIters = 5, kPnpIters = 100;
+constexpr double kPnpEps = 1e-10;
+constexpr int kRes = 40;                        // doubles in the result block
+
+// counters in device memory
+enum { C_N = 0, C_NLAND, C_NEXT_TID, C_FRAME, C_NTRI, C_NKEEP, C_KF_PENDING, C_NLOG, C_LOG_OVERFLOW, C_COUNT };   // C_LOG_OVERFLOW: sticky, an observation did not fit the log
+// result block (doubles)
+enum { R_DECISION = 0, R_REASON, R_NTRACKS, R_NTRI, R_NINL, R_NOLD, R_NNEW, R_LOST, R_OUTLIER, R_REPROJ, R_HOMOGRAPHY, R_NLAND,
+       R_POSE = 12, R_KF_VALID = 24, R_KF_NGOOD, R_KF_NTRACKS, R_KF_NLAND, R_KF_POSE = 28 };
+
+struct SlamDev {
+    int32_t *cnt;
+    float *pts, *base;
+    int32_t *lm, *tid;
+    double *map;
+    double *pose_key, *pose_prev, *intr;
+    float *lk_pts, *lk_err;
+    uint8_t *lk_st;
+    float *t_pts, *t_base;
+    int32_t *t_lm, *t_tid;
+    double *objp_t, *imgp_t;
+    int32_t *tri_pos, *samples;
+    double *pose_r;
+    int32_t *sel;
+    uint8_t *inl_mask;
+    double *pnp_info;
+    double *kf_objp, *kf_imgp, *kf_p0, *kf_p1;
+    int32_t *kf_pos;
+    double *kf_scratch, *kf_pose, *kf_x, *kf_info;
+    int32_t *kf_status;
+    uint8_t *mask;
+    float *gf_xy;
+    int32_t *gf_n;
+    double *res;
+    // the observation log for the bundle adjuster (mqs_slam_log_enable; null: off): what slam2.py's BundleAdjustmentInfoContainer is
+    // handed (:519-522, 634-641), as flat device arrays -- (landmark, pose index of the accepted frame, pixel) per observation
+    int32_t *log_lm, *log_pose;
+    double *log_uv;
+    int log_cap;
+    // a FREE track's observation is logged under -2 - (track id); when the track becomes a landmark, tid2lm[track id] says which
+    // (slam2.py:634-641: a new landmark brings its image points of every frame since the base keyframe along)
+    int32_t *tid2lm;
+    int tid_cap;
+    // with the log: the pose of every accepted frame ([R | t] world -> camera, 12 doubles; index = its number among the accepted
+    // frames), as first estimated -- a keyframe's refined pose replaces its first one -- and as the in-loop adjuster rewrites it
+    double *traj;
+    int traj_cap;
+};
+
+struct SlamParams {
+    int W, H, target, max_landmarks;
+    double radius, quality;
+    double max_of_error, max_lost_ratio, max_reproj, max_outlier_ratio, homography_threshold;
+    double second_pass_screen_px;   // 0 (default): slam2.py's flow; > 0: mqs_slam_set_second_pass_screen
+    unsigned long long seed;
+    int homography_refine;          // 1 (default): DLT + the LM refinement, as cv2.findHomography(method = 0); 0: the DLT alone (A/B)
+    int max_homography_points;      // keyframe_test's random sample (slam2.py:48; the reference: max(4, target / 4), :1088-1089); 0 = all tracks (default)
+    int pose_index, base_pose_index; // index this frame gets among the ACCEPTED frames if it is accepted; that of the base keyframe
+};
+
+}  // namespace slamst
+}  // namespace mqs
+
+struct mqs_slam_ba;                  // slam_ba.hip: the in-loop adjuster's resident state
+
+struct mqs_slam {
+    int device;
+    hipStream_t stream;
+    mqs::slamst::SlamDev d;
+    mqs::slamst::SlamParams p;
+    char *arena;
+    double *res_host;                // pinned
+    void *ws_lk, *ws_gftt, *ws_pnp;
+    int64_t ws_lk_bytes, ws_gftt_bytes;
+    bool started;
+    int accepted, base_pose;         // accepted frames so far (= the next accepted frame's pose index); pose index of the base keyframe
+    char *log_arena;
+    char *re_arena;                  // re-association scratch (allocated on first use)
+    mqs_slam_ba *ba;                 // the in-loop bundle adjuster's resident state (slam_ba.hip; allocated on first use)
+    int land_ub;                     // upper bound of the landmarks in the map once the stream has drained (known without waiting)
+    int key_pose;                    // pose index of the base keyframe of the live tracks
+};
+void mqs_slam_ba_release(mqs_slam *s);          // slam_ba.hip
+int mqs_slam_ba_anchor(mqs_slam *s, int n0);     // slam_ba.hip: at the end of mqs_slam_start, with the log on

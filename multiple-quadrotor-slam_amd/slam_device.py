@@ -29,6 +29,16 @@ from .slam_loop import (CORNER_QUALITY_LEVEL, HOMOGRAPHY_CONDITION_THRESHOLD, KE
 REASSOCIATE_RADIUS = 2.0         # pixels: a re-detected corner within this distance of a lost landmark's projection (slam.py:29 max_radius_OF_to_FAST["FAST"])
 REASSOCIATE_RATIO = 0.7          # slam.py:30 max_dist_ratio["FAST"]
 
+
+
+class _BaParams(ctypes.Structure):                       # include/mqslam.h: mqs_slam_ba_params
+    _fields_ = ([(k, ctypes.c_int32) for k in ("max_iterations", "min_observations", "max_passes", "add_odometry_edge", "edge_from", "edge_to",
+                                                "damping", "workgroups")] +
+                [(k, ctypes.c_double) for k in ("outlier_px", "gross_px", "border_margin_px", "min_depth_ratio", "point_sigma", "pixel_sigma")] +
+                [("pose_sigmas", ctypes.c_double * 6), ("odometry_sigmas", ctypes.c_double * 6)] +
+                [(k, ctypes.c_double) for k in ("lambda_initial", "lambda_factor", "lambda_upper", "abs_tol", "rel_tol")])
+
+
 REASONS = {0: "", 1: "lost track of too many points", 2: "fewer than 8 triangulated tracks", 3: "no RANSAC model",
            4: "PnP outlier ratio", 5: "reprojection error"}
 
@@ -52,7 +62,7 @@ def _reprojection_residuals(poses_c2w, points, calib, lm, pose_idx, uv):
 class DeviceMonoSlam:
     def __init__(self, cameraMatrix, distCoeffs, image_shape, seed=0, device=0, max_landmarks=1 << 16, verbose=False,
                  ba_info=None, max_homography_points=0, bundle_adjust=None, ba_iterations=10, ba_log_capacity=1 << 20,
-                 reassociate=False, ba_window_keyframes=None, second_pass_screen=None):
+                 reassociate=False, ba_window_keyframes=None, second_pass_screen=None, ba_engine="device", ba_check=False):
         """max_homography_points: size of keyframe_test's random sample of the tracks (slam2.py:48): 0 = every track (default),
         "reference" = the reference's max(4, target_amount_keypoints / 4) (:1088-1089).  On the rendered test sequence the quarter
         makes the run depend on the draw -- trajectory RMSE 0.017-0.020 for half of the seeds, 0.057-0.068 for the other half,
@@ -65,6 +75,12 @@ class DeviceMonoSlam:
         the adjusted landmarks and poses go back into the loop's live state (`mqs_slam_write_back`), so the next frames are
         tracked against the adjusted map.  `poses` then holds the ADJUSTED pose of every accepted frame up to the last
         keyframe; `poses_online` keeps each frame's pose as it was first estimated.
+        ba_engine: "device" (default) -- the adjustment is ONE library call on the resident state (`mqs_slam_bundle_adjust`,
+        csrc/slam_ba.hip: a persistent launch builds the problem from the device log, runs every Levenberg-Marquardt trial and the
+        screens, writes the result back; the host sees a 16-double report and the adjusted poses); "host" -- round 4's path, kept as
+        its twin for the tests and for ba_window_keyframes: the log comes to the host, numpy builds the problem, `sparse_ba.
+        SparseBundleAdjuster` adjusts it, `mqs_slam_write_back` returns it.  ba_check=True runs the host twin first WITHOUT writing
+        anything back and keeps (host, device) result pairs in `ba_checks`.
         ba_window_keyframes=K (>= 2): the adjustment takes the frames since the K-th keyframe from the end instead of every frame so
         far, anchored by tight pose priors on the window's first two keyframes -- the cost of an adjustment stops growing with the run.
         second_pass_screen=px (None / 0: off, the reference's flow): at a keyframe a freshly triangulated point whose reprojection error
@@ -133,11 +149,19 @@ class DeviceMonoSlam:
         self.ba_window_keyframes = ba_window_keyframes              # None: every frame so far; K >= 2: the frames since the K-th keyframe from the end
         self.ba_window_point_sigma = 0.02                           # windowed: prior on a landmark the frames in front of the window have seen
         self._ba_bad = np.zeros(0, bool)
+        if ba_engine not in ("device", "host"):
+            raise ValueError("ba_engine: 'device' or 'host'")
+        self.ba_engine = "host" if ba_window_keyframes else ba_engine
+        self.ba_check = bool(ba_check)
+        self.ba_checks = []
+        self.ba_workgroups = 0           # 0: the library's choice
+        self._pending_online = None      # keyframe whose refined (pre-adjustment) pose arrives with the next result block
         self.reassociate = bool(reassociate)
         self.poses_online = []           # with bundle_adjust: the pose of each frame as first estimated (poses: adjusted)
         self._accepted = []              # frame index of every accepted frame, in order (= the log's pose indices)
         self.ba_reports = []
         self._odo = []                   # (from pose index, to pose index, measured relative pose12): one edge per keyframe
+        self._odo_last_to = -1           # device engine: pose index the last odometry edge ends at
         self.reassociated = 0
         if bundle_adjust:
             _lib.check(L.mqs_slam_log_enable(self._h, int(ba_log_capacity)))
@@ -198,6 +222,9 @@ class DeviceMonoSlam:
         if r[24] != 0.0 and self._pending_keyframe is not None:
             self.poses[self._pending_keyframe] = r[28:40].reshape(3, 4).copy()
             self._pending_keyframe = None
+        if r[24] != 0.0 and self._pending_online is not None:      # the device adjuster ran behind this keyframe: `poses` is adjusted already
+            self.poses_online[self._pending_online] = r[28:40].reshape(3, 4).copy()
+            self._pending_online = None
 
     def handle_new_frame(self, img):
         """Returns 0 (rejected), 1 (frame) or 2 (keyframe), like the reference's `ret`."""
@@ -284,7 +311,72 @@ class DeviceMonoSlam:
         return lm, ps, uv
 
     def _bundle_adjust(self):
-        """Behind a keyframe: the whole history so far through the sparse bundle adjuster, the result back into the live state."""
+        if self.ba_engine == "host":
+            return self._bundle_adjust_host()
+        if self.ba_check:
+            host = self._bundle_adjust_host(write_back=False)
+        rep = self._bundle_adjust_device()
+        if self.ba_check:
+            self.ba_checks.append({"frame": self._accepted[-1], "host_poses": host[0], "host_points": host[1], "host_report": host[2],
+                                   "device_poses": np.stack([self.poses[f] for f in self._accepted]), "device_points": self.objp.astype(np.float64),
+                                   "device_report": rep, "host_retired": host[3], "device_retired": self.retired_landmarks()})
+
+    def _ba_params(self, add_edge, e_from, e_to):
+        from .bundle_adjustment import LM_ABS_TOL, LM_LAMBDA_FACTOR, LM_LAMBDA_INITIAL, LM_LAMBDA_UPPER, LM_REL_TOL
+        q = _BaParams()
+        q.max_iterations, q.min_observations, q.max_passes = int(self.ba_iterations), int(self.ba_min_observations), int(self.ba_max_passes)
+        q.add_odometry_edge, q.edge_from, q.edge_to = int(add_edge), int(e_from), int(e_to)
+        q.damping, q.workgroups = 0, int(self.ba_workgroups)
+        q.outlier_px, q.gross_px = float(self.ba_outlier_pixels), float(self.ba_gross_pixels or 0.0)
+        q.border_margin_px, q.min_depth_ratio = float(self.ba_border_margin or 0.0), float(self.ba_min_depth_ratio)
+        q.point_sigma, q.pixel_sigma = float(self.ba_point_sigma), float(self.ba_pixel_sigma)
+        for k in range(6):
+            q.pose_sigmas[k] = float(self.ba_pose_sigmas[k])
+            q.odometry_sigmas[k] = float(self.ba_odometry_sigmas[k])
+        q.lambda_initial, q.lambda_factor, q.lambda_upper = LM_LAMBDA_INITIAL, LM_LAMBDA_FACTOR, LM_LAMBDA_UPPER
+        q.abs_tol, q.rel_tol = LM_ABS_TOL, LM_REL_TOL
+        return q
+
+    def _bundle_adjust_device(self):
+        """Behind a keyframe: `mqs_slam_bundle_adjust` -- one persistent launch on the handle's stream (behind the keyframe branch it
+        does not wait for from here), one wait for its report and the adjusted poses."""
+        t0 = time.perf_counter()
+        kf = self._accepted[-1]
+        add_edge, e_from, e_to = False, 0, 0
+        if self.keyframes and self.keyframes[-1] == kf and len(self.keyframes) >= 2 and self._odo_last_to != len(self._accepted) - 1:
+            add_edge, e_from, e_to = True, self._accepted.index(self.keyframes[-2]), len(self._accepted) - 1
+            self._odo_last_to = e_to
+        q = self._ba_params(add_edge, e_from, e_to)
+        P = len(self._accepted)
+        rep, poses = np.zeros(16), np.zeros((P, 12))
+        _lib.check(_lib.lib().mqs_slam_bundle_adjust(self._h, ctypes.byref(q), rep.ctypes.data_as(_lib.c_f64p), poses.ctypes.data_as(_lib.c_f64p), P))
+        if self._pending_keyframe is not None:                       # its refined pose as first estimated comes with the next result block
+            self._pending_online, self._pending_keyframe = self._pending_keyframe, None
+        for k, f in enumerate(self._accepted):
+            self.poses[f] = poses[k].reshape(3, 4).copy()
+        out = {"frame": kf, "poses": int(rep[1]), "first_pose_of_the_window": 0, "landmarks": int(rep[2]), "landmarks_adjusted": int(rep[3]),
+               "observations": int(rep[4]), "passes": int(rep[5]), "landmarks_screened_out": int(rep[6]), "lm_iterations": int(rep[7]),
+               "cost_before": float(rep[8]), "cost_after": float(rep[9]), "lm_trials": int(rep[10]), "repeated_observations_left_out": int(rep[11]),
+               "odometry_edges": int(rep[12]), "grid_barriers": int(rep[13]), "engine": "device",
+               "build_ms": 0.0, "adjust_ms": round(1e3 * (time.perf_counter() - t0), 3), "write_back_ms": 0.0}
+        self.ba_reports.append(out)
+        return out
+
+    def retired_landmarks(self):
+        """bool (landmarks,): the landmarks the in-loop adjuster has retired (mistracked corners, points at a camera centre)."""
+        if self.ba_engine == "host":
+            return self._ba_bad.copy()
+        n = ctypes.c_int32(0)
+        L = _lib.lib()
+        _lib.check(L.mqs_slam_read_ba_flags(self._h, None, 0, ctypes.byref(n)))
+        out = np.zeros(max(n.value, 1), np.uint8)
+        _lib.check(L.mqs_slam_read_ba_flags(self._h, out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), n.value, ctypes.byref(n)))
+        return out[:n.value].astype(bool)
+
+    def _bundle_adjust_host(self, write_back=True):
+        """Behind a keyframe: the whole history so far through the sparse bundle adjuster, the result back into the live state
+        (write_back=False: the live state and `poses` stay as they are;
+        returns (adjusted [R | t] of the accepted frames, adjusted landmarks, report, retired flags): the device engine's twin)."""
         from . import ba_io, sparse_ba
         from .bundle_adjustment import pose_from_world_to_camera
         t0 = time.perf_counter()
@@ -296,10 +388,13 @@ class DeviceMonoSlam:
             self._pending_keyframe = None
         # the odometry edge of this keyframe (slam2.py:681-687: base keyframe -> keyframe, from the poses as estimated now)
         kf = self._accepted[-1]
+        odo_all = list(self._odo)
         if self.keyframes and self.keyframes[-1] == kf and len(self.keyframes) >= 2 and (not self._odo or self._odo[-1][1] != len(self._accepted) - 1):
             base = self.keyframes[-2]
             P1, P0 = np.vstack([self.poses[kf], [0, 0, 0, 1.0]]), np.vstack([self.poses[base], [0, 0, 0, 1.0]])
-            self._odo.append((self._accepted.index(base), len(self._accepted) - 1, pose_from_world_to_camera((P1 @ np.linalg.inv(P0))[:3])))
+            odo_all.append((self._accepted.index(base), len(self._accepted) - 1, pose_from_world_to_camera((P1 @ np.linalg.inv(P0))[:3])))
+            if write_back or self.ba_check:
+                self._odo = odo_all                                   # (the twin keeps its own edge list: measured once, like the device's)
         lm, ps, uv = self.read_log()
         known = lm >= 0                                               # (free tracks that have not become landmarks)
         if self.ba_border_margin:
@@ -342,7 +437,7 @@ class DeviceMonoSlam:
             # poses alone leave the scale of a monocular window to drift (measured: 54-97 mm over 200 frames against 5 mm)
             prior_w = np.where(seen_before[:N], 1.0 / self.ba_window_point_sigma ** 2, prior_w)
         per_lm = np.bincount(lm, minlength=N)
-        odo = [(a - w0, b - w0, m) for a, b, m in self._odo if a >= w0 and b >= w0]
+        odo = [(a - w0, b - w0, m) for a, b, m in odo_all if a >= w0 and b >= w0]
         t1 = time.perf_counter()
         passes, dropped, hist_all = 0, 0, None
         movable = np.arange(N) >= n0_w
@@ -406,17 +501,27 @@ class DeviceMonoSlam:
         new_poses, new_pts = ba.poses.cpu().numpy(), ba.points.cpu().numpy()
         new_pts[~use] = pts[~use]                                    # landmarks that sat out keep their values
         t2 = time.perf_counter()
+        adjusted = []
         for k, f in enumerate(accepted_w):                           # camera-to-world pose12 -> [R | t] world -> camera
             R, c = new_poses[k, :9].reshape(3, 3), new_poses[k, 9:]
-            self.poses[f] = np.hstack([R.T, (-R.T @ c)[:, None]])
-        last = np.ascontiguousarray(self.poses[self._accepted[-1]], dtype=np.float64)
-        _lib.check(_lib.lib().mqs_slam_write_back(self._h, np.ascontiguousarray(new_pts).ctypes.data_as(_lib.c_f64p), N,
-                                                  last.ctypes.data_as(_lib.c_f64p), last.ctypes.data_as(_lib.c_f64p)))
-        self.ba_reports.append({"frame": self._accepted[-1], "poses": P, "first_pose_of_the_window": w0, "landmarks": N, "landmarks_adjusted": int(use.sum()),
+            adjusted.append(np.hstack([R.T, (-R.T @ c)[:, None]]))
+        report = {"frame": self._accepted[-1], "poses": P, "first_pose_of_the_window": w0, "landmarks": N, "landmarks_adjusted": int(use.sum()),
                                 "observations": int(keep.sum()), "passes": passes, "landmarks_screened_out": dropped,
                                 "lm_iterations": len(hist_all) - 1, "cost_before": hist_all[0], "cost_after": hist_all[-1],
-                                "build_ms": round(1e3 * (t1 - t0), 3), "adjust_ms": round(1e3 * (t2 - t1), 3),
-                                "write_back_ms": round(1e3 * (time.perf_counter() - t2), 3)})
+                                "build_ms": round(1e3 * (t1 - t0), 3), "adjust_ms": round(1e3 * (t2 - t1), 3), "engine": "host"}
+        if not write_back:
+            retired = self._ba_bad.copy()                             # (the twin's retired set lives on, as the device's does)
+            return np.stack(adjusted), np.asarray(new_pts, dtype=np.float32).astype(np.float64), report, retired
+        for f, M in zip(accepted_w, adjusted):
+            self.poses[f] = M
+        # the live state's two poses: the last accepted frame's, and the base keyframe's of the live tracks (behind a keyframe the
+        # same frame; in finish() behind plain frames it is the last KEYFRAME's -- the tracks' base points belong to that frame)
+        last = np.ascontiguousarray(self.poses[self._accepted[-1]], dtype=np.float64)
+        key = np.ascontiguousarray(self.poses[self.keyframes[-1]], dtype=np.float64)
+        _lib.check(_lib.lib().mqs_slam_write_back(self._h, np.ascontiguousarray(new_pts).ctypes.data_as(_lib.c_f64p), N,
+                                                  last.ctypes.data_as(_lib.c_f64p), key.ctypes.data_as(_lib.c_f64p)))
+        report["write_back_ms"] = round(1e3 * (time.perf_counter() - t2), 3)
+        self.ba_reports.append(report)
 
     def _reassociate(self, img):
         n = ctypes.c_int32(0)

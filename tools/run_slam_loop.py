@@ -38,7 +38,7 @@ def run(frames=60, verbose=False, ba_info=None, out_files=None):
             "frames_per_s": round((frames - 1) / sum(slam.timing), 1)}
 
 
-def run_device(frames=60, verbose=False, repeats=1, ba_info=None, out_files=None, bundle_adjust=None, reassociate=False, seed=1):
+def run_device(frames=60, verbose=False, repeats=1, ba_info=None, out_files=None, bundle_adjust=None, reassociate=False, seed=1, keep=False, **slam_kw):
     """The same sequence through slam_device.DeviceMonoSlam: the loop's state resident on the GPU, one library call per frame
     (images uploaded beforehand, as a capture thread would have them).  `repeats` > 1: the run is repeated on a fresh handle and
     the fastest pass is timed (the first pass pays the first-launch costs of every kernel)."""
@@ -54,7 +54,7 @@ def run_device(frames=60, verbose=False, repeats=1, ba_info=None, out_files=None
     best = None
     for _ in range(max(1, repeats)):
         slam = mqslam_amd.slam_device.DeviceMonoSlam(seq.K, seq.dist, (seq.H, seq.W), seed=seed, verbose=verbose, ba_info=ba_info,
-                                                     bundle_adjust=bundle_adjust, reassociate=reassociate)
+                                                     bundle_adjust=bundle_adjust, reassociate=reassociate, **slam_kw)
         slam.start(imgs[0], objp, imgp)
         t0 = time.perf_counter()
         rets = [2]
@@ -94,9 +94,13 @@ def run_device(frames=60, verbose=False, repeats=1, ba_info=None, out_files=None
             "adjustments": len(r), "trajectory_rmse_online": float(np.sqrt(np.mean(e_on ** 2))),
             "trajectory_rmse_adjusted": out["trajectory_rmse"],
             "last": r[-1] if r else None,
-            "ms_per_adjustment_median": {k: round(float(np.median([x[k] for x in r])), 3) for k in ("build_ms", "adjust_ms", "write_back_ms")} if r else None}
+            "engine": slam.ba_engine,
+            "ms_per_adjustment_median": {k: round(float(np.median([x.get(k, 0.0) for x in r])), 3) for k in ("build_ms", "adjust_ms", "write_back_ms")} if r else None}
     if reassociate:
         out["corners_reassociated_with_lost_landmarks"] = int(slam.reassociated)
+    if keep:                                             # the caller looks at the loop object (and closes it)
+        out["slam"] = slam
+        return out
     slam.close()
     return out
 
