@@ -70,8 +70,14 @@ struct BaDev {
     int32_t *lm_res;                   // [log_cap] landmark of a log entry, -1: not part of the problem
     int32_t *T;                        // [P][N]
     int32_t *per_lm, *use, *pmin, *pmax, *cand;   // [N_cap]
-    int32_t *plist, *pcount, *pl_lo, *pl_hi;      // [kMaxPoses][kListCap], [kMaxPoses] x 3
-    double *rec;                       // [log_cap][kRec]
+    long long *plist;                  // [kMaxPoses][kListCap] a pose's observations in landmark order: log index | landmark << 32
+    int32_t *pcount, *pl_lo, *pl_hi;   // [kMaxPoses] x 3
+    long long *hits;                   // [hits_cap] per pose pair (ja < jb): the observations of a common landmark, log index in ja | in jb << 32
+    int32_t *blk_off, *blk_cnt;        // [kMaxPoses (kMaxPoses + 1) / 2] where a pose pair's hits lie
+    double *rec;                       // [kRec][rec_stride]: field q of log entry e at rec[q * rec_stride + e] -- the entries a wavefront gathers
+                                       // (one pose's observations in landmark order) are nearly consecutive log indices, so a field's
+                                       // 64 loads fall into a few lines; entry-major, every lane touched a line of its own per field
+    long long rec_stride;
     double *poses_a, *poses_b, *poses_init;       // [kMaxPoses][12]
     double *pts_a, *pts_b, *pts_init;  // [N_cap][3]
     double *worst, *zmin;              // [N_cap]
@@ -84,6 +90,7 @@ struct BaDev {
     int32_t *ctr;                      // [kCtr]
     double *report;                    // [MQS_SLAM_BA_REPORT]
     int N_cap, P_cap, ntile_cap, n0;
+    long long hits_cap;
     long long *stamps;                 // null, or [kStamps][2] (phase id, 100 MHz wall clock) written by workgroup 0 (mqs_debug_slam_ba_stamps)
 };
 
@@ -322,23 +329,26 @@ __device__ __forceinline__ void extras_records(Cx &c, const double *sC)
 }
 
 // ---- landmark phases: kLanes lanes per landmark, each takes every kLanes-th pose of the landmark's [pmin, pmax] ---------------
-struct LmWalk { int i, l8, p0, p1; bool live; double px, py, pz, pw, dx, dy, dz; };
+struct LmWalk { int i, l8, p0, p1, q0, q1; bool in, live; double px, py, pz, pw, dx, dy, dz; };   // [p0, p1]: poses of a landmark in use; [q0, q1]: of any landmark
 
 __device__ __forceinline__ LmWalk lm_begin(const Cx &c, int base, const double *pts)
 {
     LmWalk w;
     w.i = base + c.tid / kLanes;
     w.l8 = c.tid % kLanes;
-    w.live = w.i < c.N && ldg(c.b.use + (w.i < c.N ? w.i : 0)) != 0;
-    const int ii = w.i < c.N ? w.i : 0;
+    w.in = w.i < c.N;
+    w.live = w.in && ldg(c.b.use + (w.in ? w.i : 0)) != 0;
+    const int ii = w.in ? w.i : 0;
     w.px = ldg(pts + 3 * ii); w.py = ldg(pts + 3 * ii + 1); w.pz = ldg(pts + 3 * ii + 2);
     w.pw = 0.0; w.dx = w.dy = w.dz = 0.0;
     if (w.live && w.i < c.b.n0) {
         w.pw = c.p.prior_w;
         w.dx = w.px - c.b.objp0[3 * w.i]; w.dy = w.py - c.b.objp0[3 * w.i + 1]; w.dz = w.pz - c.b.objp0[3 * w.i + 2];
     }
-    w.p0 = w.live ? ldg(c.b.pmin + ii) : 0;
-    w.p1 = w.live ? ldg(c.b.pmax + ii) : -1;
+    w.q1 = w.in ? ldg(c.b.pmax + ii) : -1;
+    w.q0 = (w.in && w.q1 >= 0) ? ldg(c.b.pmin + ii) : 0;            // (a landmark nobody observes: pmin is still INT_MAX)
+    w.p0 = w.live ? w.q0 : 0;
+    w.p1 = w.live ? w.q1 : -1;
     return w;
 }
 
@@ -367,6 +377,17 @@ __device__ __forceinline__ void phase_records(Cx &c, const double *pts, double l
 {
     for (int base = c.wg * (kT / kLanes); base < c.N; base += c.G * (kT / kLanes)) {
         const LmWalk w = lm_begin(c, base, pts);
+        if (w.in && !w.live) {
+            // a landmark that sits out: records that contribute nothing (the system phase does not look at `use`)
+            for (int pp = w.q0 + w.l8; pp <= w.q1; pp += kLanes) {
+                const int e = ldg(c.b.T + (size_t)pp * c.N + w.i);
+                if (e < 0) continue;
+                double *o = c.b.rec + e;
+                const long long rs = c.b.rec_stride;
+                stg(o, 0.0); stg(o + rs, 0.0); stg(o + 2 * rs, 1.0);
+                for (int k = 3; k < kRec; ++k) stg(o + k * rs, 0.0);
+            }
+        }
         PointSystem ps;
         ps.H = mqs::Sym3{0, 0, 0, 0, 0, 0};
         ps.g = mqs::Vec3{0, 0, 0};
@@ -404,14 +425,15 @@ __device__ __forceinline__ void phase_records(Cx &c, const double *pts, double l
                 apply_LinvT(ps, u0, u1, u2);
                 U[r][0] = m * u0; U[r][1] = m * u1; U[r][2] = m * u2;
             }
-            double *o = c.b.rec + (size_t)e * kRec;
-            stg(o + 0, fc.x); stg(o + 1, fc.y); stg(o + 2, fc.Z);
-            stg(o + 3, U[0][0]); stg(o + 4, U[0][1]); stg(o + 5, U[0][2]); stg(o + 6, U[1][0]); stg(o + 7, U[1][1]); stg(o + 8, U[1][2]);
-            stg(o + 9, fc.F00 - (U[0][0] * U[0][0] + U[0][1] * U[0][1] + U[0][2] * U[0][2]));
-            stg(o + 10, fc.F01 - (U[0][0] * U[1][0] + U[0][1] * U[1][1] + U[0][2] * U[1][2]));
-            stg(o + 11, fc.F11 - (U[1][0] * U[1][0] + U[1][1] * U[1][1] + U[1][2] * U[1][2]));
-            stg(o + 12, -fc.f0 - (U[0][0] * w0 + U[0][1] * w1 + U[0][2] * w2));
-            stg(o + 13, -fc.f1 - (U[1][0] * w0 + U[1][1] * w1 + U[1][2] * w2));
+            double *o = c.b.rec + e;
+            const long long rs = c.b.rec_stride;
+            stg(o, fc.x); stg(o + rs, fc.y); stg(o + 2 * rs, fc.Z);
+            stg(o + 3 * rs, U[0][0]); stg(o + 4 * rs, U[0][1]); stg(o + 5 * rs, U[0][2]); stg(o + 6 * rs, U[1][0]); stg(o + 7 * rs, U[1][1]); stg(o + 8 * rs, U[1][2]);
+            stg(o + 9 * rs, fc.F00 - (U[0][0] * U[0][0] + U[0][1] * U[0][1] + U[0][2] * U[0][2]));
+            stg(o + 10 * rs, fc.F01 - (U[0][0] * U[1][0] + U[0][1] * U[1][1] + U[0][2] * U[1][2]));
+            stg(o + 11 * rs, fc.F11 - (U[1][0] * U[1][0] + U[1][1] * U[1][1] + U[1][2] * U[1][2]));
+            stg(o + 12 * rs, -fc.f0 - (U[0][0] * w0 + U[0][1] * w1 + U[0][2] * w2));
+            stg(o + 13 * rs, -fc.f1 - (U[1][0] * w0 + U[1][1] * w1 + U[1][2] * w2));
         }
     }
 }
@@ -435,8 +457,9 @@ __device__ __forceinline__ double phase_cost(Cx &c, const double *pts, const dou
 
 // worst pixel residual (+inf: an observation behind its camera) and smallest depth per landmark at (sC, pts) (ba_sparse.hip:
 // sparse_worst_residual_kernel); landmarks not in use: 0 / +inf
-__device__ __forceinline__ void phase_worst(Cx &c, const double *pts, const double *sC, bool with_depth)
+__device__ __forceinline__ double phase_worst(Cx &c, const double *pts, const double *sC, bool with_depth, bool with_cost = false)
 {
+    double cost = 0.0;
     for (int base = c.wg * (kT / kLanes); base < c.N; base += c.G * (kT / kLanes)) {
         const LmWalk w = lm_begin(c, base, pts);
         double worst = 0.0, zmin = HUGE_VAL;
@@ -447,7 +470,9 @@ __device__ __forceinline__ void phase_worst(Cx &c, const double *pts, const doub
             const Factor fc = make_factor(cam, w.px, w.py, w.pz, c.d.log_uv[2 * e], c.d.log_uv[2 * e + 1], true);
             worst = fmax(worst, fc.valid ? sqrt(2.0 * fc.half_e2) * c.p.sigma_px : HUGE_VAL);
             zmin = fmin(zmin, fma(cam[2], w.px - cam[9], fma(cam[5], w.py - cam[10], cam[8] * (w.pz - cam[11]))));
+            cost += fc.half_e2;
         }
+        if (w.l8 == 0 && w.live) cost += 0.5 * w.pw * (w.dx * w.dx + w.dy * w.dy + w.dz * w.dz);
         worst = half_max(worst);
         zmin = -half_max(-zmin);
         if (w.l8 == 0 && w.i < c.N) {
@@ -455,10 +480,87 @@ __device__ __forceinline__ void phase_worst(Cx &c, const double *pts, const doub
             if (with_depth) stg(c.b.zmin + w.i, zmin);
         }
     }
+    return with_cost ? block_sum(c, cost) : 0.0;
 }
 
-// B: the reduced camera system.  Task (ja <= jb) = one wavefront: the block from the records of pose ja's observations whose
-// landmark pose jb sees too.  Lower triangle of the augmented matrix, tile-major; row n = the right-hand side.
+// The hit lists (once per adjustment, behind the per-pose lists): for every pose pair ja < jb the observations of the landmarks both
+// see, as (log index in ja, log index in jb) in landmark order.  One wavefront per pair walks ja's list and looks jb's cell of the
+// table up -- twice: to count, then (a segment of the hit array taken with ONE atomic add) to write.  The segments lie in the order
+// the wavefronts arrive; inside a segment the order is the list's, so every sum over a segment is reproducible.
+__device__ __forceinline__ void build_hits(Cx &c, int32_t *cursor, int32_t *overflow)
+{
+    const int P = c.P, N = c.N;
+    const int ntask = P * (P + 1) / 2;
+    for (int t = c.wg * 4 + c.wave; t < ntask; t += c.G * 4) {
+        int jb = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+        while (jb * (jb + 1) / 2 > t) --jb;
+        while ((jb + 1) * (jb + 2) / 2 <= t) ++jb;
+        const int ja = t - jb * (jb + 1) / 2;
+        if (ja == jb) continue;
+        const int na = ldg(c.b.pcount + ja);
+        const bool overlap = na > 0 && ldg(c.b.pcount + jb) > 0 && ldg(c.b.pl_lo + ja) <= ldg(c.b.pl_hi + jb) && ldg(c.b.pl_lo + jb) <= ldg(c.b.pl_hi + ja);
+        const long long *list = c.b.plist + (size_t)ja * kListCap;
+        constexpr int kB = 8;                                       // entries per lane held in registers: 512 observations of pose ja
+        if (na <= 64 * kB) {
+            // the usual case: the whole list and its look-ups in flight together (straight-line, clamped indices), one atomic add, the
+            // hits written from registers -- three dependent round trips instead of ~20
+            long long el[kB];
+            int eb[kB];
+            int total = 0;
+            if (overlap) {
+#pragma unroll
+                for (int u = 0; u < kB; ++u) { const int k = 64 * u + c.lane; el[u] = ldg(list + (k < na ? k : na - 1)); }
+#pragma unroll
+                for (int u = 0; u < kB; ++u) eb[u] = ldg(c.b.T + (size_t)jb * N + (int)(el[u] >> 32));
+#pragma unroll
+                for (int u = 0; u < kB; ++u) {
+                    if (64 * u + c.lane >= na) eb[u] = -1;
+                    total += __popcll(__ballot(eb[u] >= 0));
+                }
+            }
+            int off = 0;
+            if (c.lane == 0 && total > 0) off = atomicAdd(cursor, total);
+            off = __builtin_amdgcn_readfirstlane(off);
+            if (total > 0 && (long long)off + total > c.b.hits_cap) { if (c.lane == 0) atomicAdd(overflow, 1); total = 0; }
+            if (c.lane == 0) { stg(c.b.blk_off + t, off); stg(c.b.blk_cnt + t, total); }
+            if (total == 0) continue;
+            int w = off;
+#pragma unroll
+            for (int u = 0; u < kB; ++u) {
+                const unsigned long long bal = __ballot(eb[u] >= 0);
+                if (eb[u] >= 0) stg(c.b.hits + w + __popcll(bal & ((1ull << c.lane) - 1ull)), (long long)(unsigned)(int)(el[u] & 0xffffffffll) | ((long long)eb[u] << 32));
+                w += __popcll(bal);
+            }
+            continue;
+        }
+        int total = 0;
+        if (overlap)
+            for (int k0 = 0; k0 < na; k0 += 64) {
+                const int k = k0 + c.lane;
+                int eb = -1;
+                if (k < na) eb = ldg(c.b.T + (size_t)jb * N + (int)(ldg(list + k) >> 32));
+                total += __popcll(__ballot(eb >= 0));
+            }
+        int off = 0;
+        if (c.lane == 0 && total > 0) off = atomicAdd(cursor, total);
+        off = __builtin_amdgcn_readfirstlane(off);
+        if (total > 0 && (long long)off + total > c.b.hits_cap) { if (c.lane == 0) atomicAdd(overflow, 1); total = 0; }
+        if (c.lane == 0) { stg(c.b.blk_off + t, off); stg(c.b.blk_cnt + t, total); }
+        if (total == 0) continue;
+        int w = off;
+        for (int k0 = 0; k0 < na; k0 += 64) {
+            const int k = k0 + c.lane;
+            int ea = -1, eb = -1;
+            if (k < na) { const long long el = ldg(list + k); ea = (int)(el & 0xffffffffll); eb = ldg(c.b.T + (size_t)jb * N + (int)(el >> 32)); }
+            const unsigned long long bal = __ballot(eb >= 0);
+            if (eb >= 0) stg(c.b.hits + w + __popcll(bal & ((1ull << c.lane) - 1ull)), (long long)(unsigned)ea | ((long long)eb << 32));
+            w += __popcll(bal);
+        }
+    }
+}
+
+// B: the reduced camera system.  Task (ja <= jb) = one wavefront: the block from the records of the pair's hit list (ja < jb) or of
+// the pose's own observations (ja == jb).  Lower triangle of the augmented matrix, tile-major; row n = the right-hand side.
 __device__ __forceinline__ double *s_entry(const Cx &c, int r, int q)      // r >= q
 {
     return c.b.S + (size_t)tix(r >> 5, q >> 5) * (TB * TB) + (r & 31) * TB + (q & 31);
@@ -466,52 +568,115 @@ __device__ __forceinline__ double *s_entry(const Cx &c, int r, int q)      // r 
 
 __device__ __forceinline__ void phase_system(Cx &c, double lambda)
 {
-    const int P = c.P, N = c.N;
+    const int P = c.P;
     const int ntask = P * (P + 1) / 2;
-    for (int t = c.wg * 4 + c.wave; t < ntask; t += c.G * 4) {
+    // what a task looks up about its poses -- the odometry edge that starts / ends there, that edge's other end, the length of the
+    // pose's list -- once per workgroup into LDS: fetched per task these were up to three DEPENDENT round trips behind the block's sums
+    int *sEo = reinterpret_cast<int *>(lds_cam_new()), *sEi = sEo + kMaxPoses, *sTo = sEi + kMaxPoses, *sCnt = sTo + kMaxPoses;
+    __syncthreads();
+    for (int j = c.tid; j < P; j += kT) {
+        const int eo = ldg(c.b.e_out + j), ei = ldg(c.b.e_in + j);
+        sEo[j] = (eo >= 0 && eo < c.p.n_odo) ? eo : -1;
+        sEi[j] = (ei >= 0 && ei < c.p.n_odo) ? ei : -1;
+        sTo[j] = (eo >= 0 && eo < c.p.n_odo) ? ldg(c.b.odo_to + eo) : -1;
+        sCnt[j] = ldg(c.b.pcount + j);
+    }
+    __syncthreads();
+    int t = c.wg * 4 + c.wave;
+    int off_next = 0, cnt_next = 0;
+    if (t < ntask) { off_next = ldg(c.b.blk_off + t); cnt_next = ldg(c.b.blk_cnt + t); }      // (a diagonal task's pair is not used)
+    for (; t < ntask; t += c.G * 4) {
         // t -> (jb, ja), ja <= jb: t = jb (jb + 1) / 2 + ja
         int jb = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
         while (jb * (jb + 1) / 2 > t) --jb;
         while ((jb + 1) * (jb + 2) / 2 <= t) ++jb;
         const int ja = t - jb * (jb + 1) / 2;
-        const int na = ldg(c.b.pcount + ja);
-        const bool overlap = ja == jb || (na > 0 && ldg(c.b.pcount + jb) > 0 && ldg(c.b.pl_lo + ja) <= ldg(c.b.pl_hi + jb) &&
-                                          ldg(c.b.pl_lo + jb) <= ldg(c.b.pl_hi + ja));
+        stamp(c, 20);
+        const int off = off_next, cnt = cnt_next;
+        if (t + c.G * 4 < ntask) { off_next = ldg(c.b.blk_off + t + c.G * 4); cnt_next = ldg(c.b.blk_cnt + t + c.G * 4); }
+        // the entries this lane will add to its sums from the odometry / prior records: requested now, used behind the reduction
+        const int e_mine = (c.lane & 1) ? 32 + (c.lane >> 1) : (c.lane >> 1);
+        const int mi = e_mine / 6, mj = e_mine % 6;
+        double x_add = 0.0, x_gadd = 0.0;
+        if (ja == jb) {
+            if (sEo[ja] >= 0) x_add += ldg(c.b.erec + (size_t)sEo[ja] * kERec + 6 * mi + mj);
+            if (sEi[ja] >= 0 && mi == mj) x_add += ldg(c.b.erec + (size_t)sEi[ja] * kERec + 72 + mi);
+            if (ja == 0 && mi == mj) x_add += ldg(c.b.prec + mi);
+            if (c.lane < 6) {
+                if (sEo[ja] >= 0) x_gadd += ldg(c.b.erec + (size_t)sEo[ja] * kERec + 78 + c.lane);
+                if (sEi[ja] >= 0) x_gadd += ldg(c.b.erec + (size_t)sEi[ja] * kERec + 84 + c.lane);
+                if (ja == 0) x_gadd += ldg(c.b.prec + 6 + c.lane);
+            }
+        } else if (sEo[ja] >= 0 && sTo[ja] == jb) x_add += ldg(c.b.erec + (size_t)sEo[ja] * kERec + 36 + 6 * mi + mj);
         double acc[36], gacc[6];
 #pragma unroll
         for (int e = 0; e < 36; ++e) acc[e] = 0.0;
 #pragma unroll
         for (int e = 0; e < 6; ++e) gacc[e] = 0.0;
-        if (overlap) {
-            const int32_t *list = c.b.plist + (size_t)ja * kListCap;
-            for (int k = c.lane; k < na; k += 64) {
-                const int ea = ldg(list + k);
-                const int l = ldg(c.b.lm_res + ea);
-                if (ldg(c.b.use + l) == 0) continue;
-                const double *ra = c.b.rec + (size_t)ea * kRec;
-                const JgA A = make_JgA(ldg(ra + 0), ldg(ra + 1), ldg(ra + 2));
-                double Tm[2][6];
-                if (ja == jb) {
-                    const double k00 = ldg(ra + 9), k01 = ldg(ra + 10), k11 = ldg(ra + 11);
+        // Loads are issued unconditionally and in straight-line batches (an index beyond the segment is clamped to its last entry, the
+        // lane's contribution dropped afterwards): a load inside a divergent branch makes the wait-count bookkeeping give up and
+        // every batch waited for the one before it (vmcnt(0) between them, seen in the listing) -- 8.8 us per task where the
+        // arithmetic is 1
+        constexpr int kU = 4;
+        if (ja == jb) {
+            // the pose's own observations: Jg^T (F - U U^T) Jg and the right-hand side
+            const int na = sCnt[ja];
+            const long long *list = c.b.plist + (size_t)ja * kListCap;
+            for (int k0 = 0; k0 < na; k0 += 64 * kU) {
+                int ea[kU];
+#pragma unroll
+                for (int u = 0; u < kU; ++u) { const int k = k0 + 64 * u + c.lane; ea[u] = (int)(ldg(list + (k < na ? k : na - 1)) & 0xffffffffll); }
+                double r[kU][8];
+#pragma unroll
+                for (int u = 0; u < kU; ++u) {
+                    const double *pa = c.b.rec + ea[u];
+                    const long long rs = c.b.rec_stride;
+                    r[u][0] = ldg(pa); r[u][1] = ldg(pa + rs); r[u][2] = ldg(pa + 2 * rs);
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) r[u][3 + q] = ldg(pa + (9 + q) * rs);
+                }
+#pragma unroll
+                for (int u = 0; u < kU; ++u) {
+                    if (k0 + 64 * u >= na) break;                       // (wave-uniform)
+                    const bool mine = k0 + 64 * u + c.lane < na;
+                    const JgA A = make_JgA(r[u][0], r[u][1], r[u][2]);
+                    const double k00 = mine ? r[u][3] : 0.0, k01 = mine ? r[u][4] : 0.0, k11 = mine ? r[u][5] : 0.0;
+                    const double r0 = mine ? r[u][6] : 0.0, r1 = mine ? r[u][7] : 0.0;
+                    double Tm[2][6];
                     k_times_Jg(k00, k01, k01, k11, A, Tm);
 #pragma unroll
                     for (int i = 0; i < 6; ++i)
 #pragma unroll
                         for (int j = i; j < 6; ++j) acc[i * 6 + j] += JgT_T(A, Tm, i, j);
-                    const double r0 = ldg(ra + 12), r1 = ldg(ra + 13);
 #pragma unroll
                     for (int i = 0; i < 6; ++i) gacc[i] += JgT_r(A, r0, r1, i);
-                } else {
-                    const int eb = ldg(c.b.T + (size_t)jb * N + l);
-                    if (eb < 0) continue;
-                    const double *rb = c.b.rec + (size_t)eb * kRec;
-                    const JgA B = make_JgA(ldg(rb + 0), ldg(rb + 1), ldg(rb + 2));
-                    const double a3 = ldg(ra + 3), a4 = ldg(ra + 4), a5 = ldg(ra + 5), a6 = ldg(ra + 6), a7 = ldg(ra + 7), a8 = ldg(ra + 8);
-                    const double b3 = ldg(rb + 3), b4 = ldg(rb + 4), b5 = ldg(rb + 5), b6 = ldg(rb + 6), b7 = ldg(rb + 7), b8 = ldg(rb + 8);
-                    const double k00 = -(a3 * b3 + a4 * b4 + a5 * b5);
-                    const double k01 = -(a3 * b6 + a4 * b7 + a5 * b8);
-                    const double k10 = -(a6 * b3 + a7 * b4 + a8 * b5);
-                    const double k11 = -(a6 * b6 + a7 * b7 + a8 * b8);
+                }
+            }
+        } else {
+            // the landmarks both poses see: -Jg_a^T (U_a U_b^T) Jg_b over the pair's hit list (built once per adjustment), four hits per
+            // lane at a time: their index pairs, then all their records, in flight together
+            for (int k0 = 0; k0 < cnt; k0 += 64 * kU) {
+                long long h[kU];
+#pragma unroll
+                for (int u = 0; u < kU; ++u) { const int k = k0 + 64 * u + c.lane; h[u] = ldg(c.b.hits + off + (k < cnt ? k : cnt - 1)); }
+                double ra[kU][9], rb[kU][9];
+#pragma unroll
+                for (int u = 0; u < kU; ++u) {
+                    const double *pa = c.b.rec + (int)(h[u] & 0xffffffffll), *pb = c.b.rec + (int)(h[u] >> 32);
+                    const long long rs = c.b.rec_stride;
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) { ra[u][q] = ldg(pa + q * rs); rb[u][q] = ldg(pb + q * rs); }
+                }
+#pragma unroll
+                for (int u = 0; u < kU; ++u) {
+                    if (k0 + 64 * u >= cnt) break;                      // (wave-uniform)
+                    const bool mine = k0 + 64 * u + c.lane < cnt;
+                    const JgA A = make_JgA(ra[u][0], ra[u][1], ra[u][2]), B = make_JgA(rb[u][0], rb[u][1], rb[u][2]);
+                    const double k00 = mine ? -(ra[u][3] * rb[u][3] + ra[u][4] * rb[u][4] + ra[u][5] * rb[u][5]) : 0.0;
+                    const double k01 = mine ? -(ra[u][3] * rb[u][6] + ra[u][4] * rb[u][7] + ra[u][5] * rb[u][8]) : 0.0;
+                    const double k10 = mine ? -(ra[u][6] * rb[u][3] + ra[u][7] * rb[u][4] + ra[u][8] * rb[u][5]) : 0.0;
+                    const double k11 = mine ? -(ra[u][6] * rb[u][6] + ra[u][7] * rb[u][7] + ra[u][8] * rb[u][8]) : 0.0;
+                    double Tm[2][6];
                     k_times_Jg(k00, k01, k10, k11, B, Tm);
 #pragma unroll
                     for (int i = 0; i < 6; ++i)
@@ -520,6 +685,7 @@ __device__ __forceinline__ void phase_system(Cx &c, double lambda)
                 }
             }
         }
+        stamp(c, 21);
         // 36 sums over the wavefront (ba_sparse.hip: sparse_pair_groups_kernel): lane l ends with entry l >> 1 of the first 32,
         // the last four by butterflies
         double first32[32];
@@ -541,18 +707,11 @@ __device__ __forceinline__ void phase_system(Cx &c, double lambda)
             for (int e = 33; e < 36; ++e) v = (e_out == e) ? acc[e] : v;
         }
         const int i = writer ? e_out / 6 : 0, j = writer ? e_out % 6 : 0;
-        // odometry edges and the pose prior (their records were written in the phase before)
+        stamp(c, 22);
+        // odometry edges and the pose prior (their records were written in the phase before; requested at the task's start), damping
         if (writer) {
-            if (ja == jb) {
-                const int eo = ldg(c.b.e_out + ja), ei = ldg(c.b.e_in + ja);
-                if (eo >= 0 && eo < c.p.n_odo) v += ldg(c.b.erec + (size_t)eo * kERec + 6 * i + j);
-                if (ei >= 0 && ei < c.p.n_odo && i == j) v += ldg(c.b.erec + (size_t)ei * kERec + 72 + i);
-                if (ja == 0 && i == j) v += ldg(c.b.prec + i);
-                if (i == j) v = (lambda >= 0.0) ? v * (1.0 + lambda) : v - lambda;
-            } else {
-                const int eo = ldg(c.b.e_out + ja);
-                if (eo >= 0 && eo < c.p.n_odo && ldg(c.b.odo_to + eo) == jb) v += ldg(c.b.erec + (size_t)eo * kERec + 36 + 6 * i + j);
-            }
+            v += x_add;
+            if (ja == jb && i == j) v = (lambda >= 0.0) ? v * (1.0 + lambda) : v - lambda;
             // entry (6 ja + i, 6 jb + j) of the symmetric system; kept: the lower triangle
             if (ja != jb) stg(s_entry(c, 6 * jb + j, 6 * ja + i), v);
             else if (i <= j) stg(s_entry(c, 6 * ja + j, 6 * ja + i), v);
@@ -561,11 +720,7 @@ __device__ __forceinline__ void phase_system(Cx &c, double lambda)
             double gv = gacc[0];
 #pragma unroll
             for (int e = 1; e < 6; ++e) gv = (c.lane == e) ? gacc[e] : gv;
-            const int eo = ldg(c.b.e_out + ja), ei = ldg(c.b.e_in + ja);
-            if (eo >= 0 && eo < c.p.n_odo) gv += ldg(c.b.erec + (size_t)eo * kERec + 78 + c.lane);
-            if (ei >= 0 && ei < c.p.n_odo) gv += ldg(c.b.erec + (size_t)ei * kERec + 84 + c.lane);
-            if (ja == 0) gv += ldg(c.b.prec + 6 + c.lane);
-            stg(s_entry(c, c.n, 6 * ja + c.lane), gv);
+            stg(s_entry(c, c.n, 6 * ja + c.lane), gv + x_gadd);
         }
     }
     if (c.wg == 0 && c.tid == 0) stg(s_entry(c, c.n, c.n), kAugDiag);
@@ -824,14 +979,27 @@ __device__ __forceinline__ double phase_backsub_cost(Cx &c, const double *poses,
     return want_cost ? block_sum(c, cost) : 0.0;
 }
 
+// every workgroup's cost piece (published in front of a barrier that has been passed) added in one fixed order: lane g takes the
+// pieces g, g + 64, ..., the lanes' sums go through the wavefront butterfly; on every thread
+__device__ __forceinline__ double sum_partials(Cx &c)
+{
+    double s = 0.0;
+    if (c.wave == 0) {
+        for (int g = c.lane; g < c.G; g += 64) s += ldg(c.b.partials + 4 * g);
+        s = mqs::wave::sum1(s);
+    }
+    __syncthreads();
+    if (c.tid == 0) lds_red()[8] = s;
+    __syncthreads();
+    return lds_red()[8];
+}
+
 // this workgroup's cost piece published, the barrier, every workgroup's pieces added in the same order
 __device__ __forceinline__ bool reduce_cost(Cx &c, double mine, double &total)
 {
     if (c.tid == 0) stg(c.b.partials + 4 * c.wg, mine);
     if (!grid_barrier(c)) return false;
-    double s = 0.0;
-    for (int g = 0; g < c.G; ++g) s += ldg(c.b.partials + 4 * g);
-    total = s;
+    total = sum_partials(c);
     return true;
 }
 
@@ -971,7 +1139,7 @@ __global__ __launch_bounds__(kT) void slam_ba_kernel(BaDev b, SlamDev d, BaParam
             const int e = l < N ? ldg(b.T + (size_t)pj * N + l) : -1;
             const unsigned long long bal = __ballot(e >= 0);
             const int r = cnt + __popcll(bal & ((1ull << c.lane) - 1ull));
-            if (e >= 0 && r < kListCap) stg(b.plist + (size_t)pj * kListCap + r, e);
+            if (e >= 0 && r < kListCap) stg(b.plist + (size_t)pj * kListCap + r, (long long)(unsigned)e | ((long long)l << 32));
             if (bal) { if (lo == 0x7fffffff) lo = l0 + __ffsll((long long)bal) - 1; hi = l0 + 63 - __clzll((long long)bal); }
             cnt += __popcll(bal);
         }
@@ -985,12 +1153,21 @@ __global__ __launch_bounds__(kT) void slam_ba_kernel(BaDev b, SlamDev d, BaParam
     if (ldg(cap_ctr) != 0) { if (gtid == 0) { b.report[0] = 2.0; b.report[1] = (double)P; b.report[2] = (double)N; } return; }
     const int dups = ldg(dup_ctr);
     stamp(c, 3);
+    {
+        int32_t *cursor = fresh_counter(c), *overflow = fresh_counter(c);
+        build_hits(c, cursor, overflow);
+        if (!grid_barrier(c)) { if (c.tid == 0 && c.wg == 0) b.report[0] = 1.0; return; }
+        barriers += 1;
+        if (ldg(overflow) != 0) { if (gtid == 0) { b.report[0] = 2.0; b.report[1] = (double)P; b.report[2] = (double)N; b.report[3] = -1.0; } return; }
+    }
+    stamp(c, 8);
 
     // ---- the passes ---------------------------------------------------------------------------------------------------------------
     const double sgn = p.damping == MQS_SBA_DAMPING_MARQUARDT ? 1.0 : -1.0;
     double *poses_cur = b.poses_a, *poses_new = b.poses_b, *pts_cur = b.pts_a, *pts_new = b.pts_b;
     int passes = 0, dropped = 0, trials = 0, lm_iters = 0;
-    bool screened = !(p.gross_px > 0.0), dirty = false, have_before = false;
+    bool screened = !(p.gross_px > 0.0), dirty = false, have_before = false, have_start_cost = false;
+    double start_cost = 0.0;
     double cost_before = 0.0, cost_after = 0.0;
     bool failed = false;
     for (;;) {
@@ -1007,17 +1184,49 @@ __global__ __launch_bounds__(kT) void slam_ba_kernel(BaDev b, SlamDev d, BaParam
             // before anything is adjusted: an observation that misses the current estimate by tens of pixels is not noise an
             // adjustment averages out; a landmark at a camera centre has no depth to adjust (slam_device.py, round 4)
             screened = true;
-            phase_worst(c, pts_cur, lds_cam(), true);
+            double mine = phase_worst(c, pts_cur, lds_cam(), true, true);       // ... and the cost, should nothing be dropped
+            if (c.wg == c.G - 1) mine += extras_cost(c, lds_cam());
+            if (c.tid == 0) stg(b.partials + 4 * c.wg, mine);
             if (!grid_barrier(c)) { failed = true; break; }
             barriers += 1;
-            // the median depth of the landmarks in use that have one: by rank counting against a copy in LDS (a chunk at a time; NaN =
-            // not a candidate), every workgroup its share of the candidates
-            {
+            // the median depth of the landmarks in use that have one, by rank counting against a copy in LDS (NaN = not a candidate):
+            // every workgroup for itself while the map is small, each its share of the candidates (and one more barrier) beyond
+            const bool local_median = N <= 4096;
+            double med = NAN;
+            if (local_median) {
+                // every workgroup for itself: the candidates (+inf for the rest, padded to a power of two) sorted in LDS by a bitonic
+                // network -- 55 compare-exchange stages at 1 024 entries; ranking every candidate against every other was 28 us
+                double *sZ = lds_cam_new();
+                int n2 = 64;
+                while (n2 < N) n2 *= 2;
+                __syncthreads();
+                int mine_cnt = 0;
+                for (int j = c.tid; j < n2; j += kT) {
+                    double z = HUGE_VAL;
+                    if (j < N) { const double zz = ldg(b.zmin + j); if (ldg(b.use + j) != 0 && isfinite(zz)) { z = zz; mine_cnt += 1; } }
+                    sZ[j] = z;
+                }
+                const int cnt = (int)(block_sum(c, (double)mine_cnt) + 0.5);
+                for (int k2 = 2; k2 <= n2; k2 <<= 1)
+                    for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
+                        __syncthreads();
+                        for (int i = c.tid; i < n2; i += kT) {
+                            const int ix = i ^ j2;
+                            if (ix > i) {
+                                const double a = sZ[i], bq = sZ[ix];
+                                const bool up = (i & k2) == 0;
+                                if ((a > bq) == up) { sZ[i] = bq; sZ[ix] = a; }
+                            }
+                        }
+                    }
+                __syncthreads();
+                if (cnt > 0) med = 0.5 * (sZ[(cnt - 1) / 2] + sZ[cnt / 2]);
+                __syncthreads();
+            } else {
                 double *sZ = lds_cam_new();
                 constexpr int kChunk = kMaxPoses * kCamStride;
-                const int i = gtid;                              // (N <= the grid's threads is the usual case; the loop below covers the rest)
-                for (int i0 = 0; i0 < N; i0 += gthreads) {
-                    const int ii = i0 + i;
+                for (int i0 = gtid; i0 < ((N + kT - 1) / kT) * kT; i0 += gthreads) {
+                    const int ii = i0;
                     double zi = NAN;
                     if (ii < N) { const double z = ldg(b.zmin + ii); if (ldg(b.use + ii) != 0 && isfinite(z)) zi = z; }
                     int rank = 0, cnt = 0;
@@ -1029,6 +1238,7 @@ __global__ __launch_bounds__(kT) void slam_ba_kernel(BaDev b, SlamDev d, BaParam
                             sZ[j] = (ldg(b.use + j0 + j) != 0 && isfinite(z)) ? z : (double)NAN;
                         }
                         __syncthreads();
+#pragma unroll 8
                         for (int j = 0; j < m; ++j) {
                             const double zj = sZ[j];
                             cnt += (zj == zj) ? 1 : 0;
@@ -1040,10 +1250,11 @@ __global__ __launch_bounds__(kT) void slam_ba_kernel(BaDev b, SlamDev d, BaParam
                         if (rank == cnt / 2) stg(b.med + 1, zi);
                     }
                 }
+                if (!grid_barrier(c)) { failed = true; break; }
+                barriers += 1;
+                med = 0.5 * (ldg(b.med + 0) + ldg(b.med + 1));
             }
-            if (!grid_barrier(c)) { failed = true; break; }
-            barriers += 1;
-            const double med = 0.5 * (ldg(b.med + 0) + ldg(b.med + 1));          // NaN while no landmark has a depth: no depth screen then
+            // (NaN while no landmark has a depth: no depth screen then)
             int32_t *gross_ctr = fresh_counter(c);
             for (int l = gtid; l < N; l += gthreads) {
                 if (ldg(b.use + l) == 0 || l < b.n0) continue;
@@ -1055,11 +1266,14 @@ __global__ __launch_bounds__(kT) void slam_ba_kernel(BaDev b, SlamDev d, BaParam
             if (!count_barrier(c, gross_ctr, ng)) { failed = true; break; }
             barriers += 1;
             if (ng > 0) { dropped += ng; continue; }
+            start_cost = sum_partials(c);
+            have_start_cost = true;
         }
         // Levenberg-Marquardt, GTSAM 3.2.1's default schedule (ba_sparse.hip: mqs_sba_optimize_lm_dev)
         stamp(c, 4);
         double cur = 0.0;
-        {
+        if (have_start_cost) { cur = start_cost; have_start_cost = false; }      // the screen's sweep has it
+        else {
             double mine = phase_cost(c, pts_cur, lds_cam());
             if (c.wg == c.G - 1) mine += extras_cost(c, lds_cam());
             if (!reduce_cost(c, mine, cur)) { failed = true; break; }
@@ -1199,7 +1413,8 @@ int ba_fixed_alloc(mqs_slam *s)
                  o_med = take(64), o_part = take(256 * 32), o_dp = take((6 * kMaxPoses + 32) * 8),
                  o_pa = take(kMaxPoses * 96), o_pb = take(kMaxPoses * 96), o_pi = take(kMaxPoses * 96),
                  o_pc = take(kMaxPoses * 4), o_lo = take(kMaxPoses * 4), o_hi = take(kMaxPoses * 4),
-                 o_pl = take((size_t)kMaxPoses * kListCap * 4), o_lr = take((size_t)s->d.log_cap * 4), o_rec = take((size_t)s->d.log_cap * kRec * 8);
+                 o_pl = take((size_t)kMaxPoses * kListCap * 8), o_bo = take((size_t)kMaxPoses * (kMaxPoses + 1) / 2 * 4),
+                 o_bc = take((size_t)kMaxPoses * (kMaxPoses + 1) / 2 * 4), o_lr = take((size_t)s->d.log_cap * 4), o_rec = take((size_t)s->d.log_cap * kRec * 8);
     hipError_t e = hipMalloc((void **)&ba->fixed, off);
     if (e != hipSuccess) { delete ba; mqs_set_error("hipMalloc(%zu) failed: %s", off, hipGetErrorString(e)); return MQS_E_NOMEM; }
     e = hipHostMalloc((void **)&ba->host, (MQS_SLAM_BA_REPORT + 12 * (size_t)kMaxPoses) * 8, hipHostMallocDefault);
@@ -1211,8 +1426,8 @@ int ba_fixed_alloc(mqs_slam *s)
     b.odo_meas = (double *)(a + o_om); b.e_in = (int32_t *)(a + o_ei); b.e_out = (int32_t *)(a + o_eo); b.erec = (double *)(a + o_er);
     b.prec = (double *)(a + o_pr); b.med = (double *)(a + o_med); b.partials = (double *)(a + o_part); b.dpose = (double *)(a + o_dp);
     b.poses_a = (double *)(a + o_pa); b.poses_b = (double *)(a + o_pb); b.poses_init = (double *)(a + o_pi);
-    b.pcount = (int32_t *)(a + o_pc); b.pl_lo = (int32_t *)(a + o_lo); b.pl_hi = (int32_t *)(a + o_hi); b.plist = (int32_t *)(a + o_pl);
-    b.lm_res = (int32_t *)(a + o_lr); b.rec = (double *)(a + o_rec);
+    b.pcount = (int32_t *)(a + o_pc); b.pl_lo = (int32_t *)(a + o_lo); b.pl_hi = (int32_t *)(a + o_hi); b.plist = (long long *)(a + o_pl);
+    b.lm_res = (int32_t *)(a + o_lr); b.rec = (double *)(a + o_rec); b.rec_stride = s->d.log_cap; b.blk_off = (int32_t *)(a + o_bo); b.blk_cnt = (int32_t *)(a + o_bc);
     b.N_cap = 0; b.P_cap = 0; b.ntile_cap = 0; b.n0 = 0;
     ba->arena = nullptr; ba->arena_bytes = 0; ba->n_odo = 0; ba->stamps = nullptr; b.stamps = nullptr;
     // retired flags 0, no edges
@@ -1243,6 +1458,9 @@ int ba_reserve(mqs_slam *s, int P, int N_ub)
                  o_mx = take((size_t)N_cap * 4), o_cd = take((size_t)N_cap * 4), o_a = take((size_t)N_cap * 24), o_b = take((size_t)N_cap * 24),
                  o_i = take((size_t)N_cap * 24), o_w = take((size_t)N_cap * 8), o_z = take((size_t)N_cap * 8),
                  o_S = take((size_t)ntile_cap * TB * TB * 8), o_L = take((size_t)ntile_cap * TB * TB * 8);
+    // hit lists: a landmark seen from k poses has k (k - 1) / 2 of them; ~300 tracks per frame living ~30 frames: 4 500 P
+    const long long hits_cap = (long long)160 * P_cap * P_cap > 262144 ? (long long)160 * P_cap * P_cap : 262144;
+    const size_t o_h = take((size_t)hits_cap * 8);
     MQS_HIP_CHECK(hipStreamSynchronize(s->stream));
     if (ba->arena) { (void)hipFree(ba->arena); ba->arena = nullptr; }
     hipError_t e = hipMalloc((void **)&ba->arena, off);
@@ -1253,6 +1471,7 @@ int ba_reserve(mqs_slam *s, int P, int N_ub)
     b.T = (int32_t *)(a + o_T); b.per_lm = (int32_t *)(a + o_pl); b.use = (int32_t *)(a + o_use); b.pmin = (int32_t *)(a + o_mn); b.pmax = (int32_t *)(a + o_mx);
     b.cand = (int32_t *)(a + o_cd); b.pts_a = (double *)(a + o_a); b.pts_b = (double *)(a + o_b); b.pts_init = (double *)(a + o_i);
     b.worst = (double *)(a + o_w); b.zmin = (double *)(a + o_z); b.S = (double *)(a + o_S); b.Lp = (double *)(a + o_L);
+    b.hits = (long long *)(a + o_h); b.hits_cap = hits_cap;
     b.N_cap = N_cap; b.P_cap = P_cap; b.ntile_cap = ntile_cap;
     return MQS_OK;
 }
@@ -1320,7 +1539,7 @@ int mqs_slam_bundle_adjust(mqs_slam *s, const mqs_slam_ba_params *q, double *rep
     }
     int rc = ba_reserve(s, P, s->land_ub > 0 ? s->land_ub : 1);
     if (rc != MQS_OK) return rc;
-    int G = q->workgroups > 0 ? q->workgroups : 64;
+    int G = q->workgroups > 0 ? q->workgroups : 128;
     if (const char *e = getenv("MQS_SLAM_BA_GROUPS")) { const int g = atoi(e); if (g > 0) G = g; }
     if (G > 256) G = 256;
     p.P = P; p.G = G; p.key_pose = s->key_pose;
@@ -1351,7 +1570,7 @@ int mqs_slam_bundle_adjust(mqs_slam *s, const mqs_slam_ba_params *q, double *rep
     if (!(report[0] == 0.0)) {
         if (report[0] == 1.0) { mqs_set_error("mqs_slam_bundle_adjust: a grid-wide wait of the adjustment gave up (2 s); nothing was written back"); return MQS_E_TIMEOUT; }
         if (report[0] == 3.0) { mqs_set_error("mqs_slam_bundle_adjust: the observation log is full (%d entries): observations have been dropped", s->d.log_cap); return MQS_E_ARG; }
-        mqs_set_error("mqs_slam_bundle_adjust: capacity (poses %g of %d, landmarks %g, or a frame with more than %d observations)", report[1], kMaxPoses, report[2], kListCap);
+        mqs_set_error("mqs_slam_bundle_adjust: capacity (poses %g of %d, landmarks %g, a frame with more than %d observations, or more co-observations than the hit lists hold)", report[1], kMaxPoses, report[2], kListCap);
         return MQS_E_ARG;
     }
     return MQS_OK;
