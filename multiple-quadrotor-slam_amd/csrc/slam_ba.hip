@@ -749,19 +749,31 @@ __device__ __forceinline__ void chol_task(Cx &c, int k, int bi, int bj, double *
     double *sM = sBuf + 5 * TB * TLD;
     const double *D = c.b.S + (size_t)tix(k, k) * (TB * TB);
     const double *Ai = c.b.S + (size_t)tix(bi, k) * (TB * TB), *Aj = c.b.S + (size_t)tix(bj, k) * (TB * TB);
-    __syncthreads();
-    for (int e = c.tid; e < TB * TB; e += kT) {
-        const int a = e >> 5, bq = e & 31;
-        // inv(L)[a][b]: the strictly lower part lies transposed in the diagonal tile's upper triangle
-        double v = 0.0;
-        if (bq < a) v = ldg(D + bq * TB + a);
-        else if (bq == a) v = 1.0 / ldg(D + a * TB + a);
-        sLi[a * TLD + bq] = v;
-        sAi[a * TLD + bq] = ldg(Ai + e);
-        if (bi != bj) sAj[a * TLD + bq] = ldg(Aj + e);
+    const int wr = c.wave >> 1, wc = c.wave & 1;
+    double *tile = c.b.S + (size_t)tix(bi, bj) * (TB * TB);
+    // every load of the task up front, unconditional and row-major (a wavefront's 64 entries = 4 lines): the three panel inputs AND the
+    // tile to update -- its round trip used to follow the products
+    double dv[4], ai[4], aj[4], tv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int e = c.tid + u * kT;
+        dv[u] = ldg(D + e); ai[u] = ldg(Ai + e); aj[u] = ldg(Aj + e);
+    }
+    {
+        const int q = mqs::chol::quadrant_col(wc, c.lane);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) tv[v] = ldg(tile + mqs::chol::quadrant_row(wr, c.lane, v) * TB + q);
     }
     __syncthreads();
-    const int wr = c.wave >> 1, wc = c.wave & 1;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int e = c.tid + u * kT, a = e >> 5, bq = e & 31;
+        // the diagonal tile's strictly upper triangle is inv(L)'s strictly lower one, transposed; its diagonal is L's
+        sLi[bq * TLD + a] = (bq > a) ? dv[u] : ((bq == a) ? 1.0 / dv[u] : 0.0);
+        sAi[a * TLD + bq] = ai[u];
+        sAj[a * TLD + bq] = aj[u];
+    }
+    __syncthreads();
     {
         const mqs::chol::double4v xi = mqs::chol::tile_quadrant_mfma(sAi, sLi, wr, wc, c.lane);
         const mqs::chol::double4v xj = (bi == bj) ? xi : mqs::chol::tile_quadrant_mfma(sAj, sLi, wr, wc, c.lane);
@@ -778,7 +790,6 @@ __device__ __forceinline__ void chol_task(Cx &c, int k, int bi, int bj, double *
     __syncthreads();
     const mqs::chol::double4v acc = mqs::chol::tile_quadrant_mfma(sXi, sXj, wr, wc, c.lane);
     const bool next_diag = bi == k + 1 && bj == k + 1;
-    double *tile = c.b.S + (size_t)tix(bi, bj) * (TB * TB);
     double *sT = sAi;
     __syncthreads();
     {
@@ -786,7 +797,7 @@ __device__ __forceinline__ void chol_task(Cx &c, int k, int bi, int bj, double *
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             const int r = mqs::chol::quadrant_row(wr, c.lane, v);
-            const double val = ldg(tile + r * TB + q) - acc[v];
+            const double val = tv[v] - acc[v];
             if (next_diag) sT[r * TLD + q] = val;
             else stg(tile + r * TB + q, val);
         }
@@ -830,18 +841,20 @@ __device__ __forceinline__ void bs_load(const Cx &c, int kb, BsRow &r)
     for (int u = 0; u < 4; ++u) r.diag[u] = ldg(D + c.tid + u * kT);
 #pragma unroll
     for (int m = 0; m < kBsCols; ++m) {
-        const int q = c.tid + m * kT;
-        if (q < kb * TB) {
-            const double *Lt = c.b.Lp + (size_t)tix(kb, q >> 5) * (TB * TB) + (q & 31);
+        // unconditional, the column index clamped (a load inside a divergent branch serialises the batches behind it)
+        int q = c.tid + m * kT;
+        if (q >= kb * TB) q = kb * TB - 1;
+        if (q < 0) q = 0;                                        // (kb = 0: a tile nobody reads from -- the values are not used)
+        const double *Lt = c.b.Lp + (size_t)tix(kb, q >> 5) * (TB * TB) + (q & 31);
 #pragma unroll
-            for (int rr = 0; rr < TB; ++rr) r.col[m][rr] = ldg(Lt + rr * TB);
-        }
+        for (int rr = 0; rr < TB; ++rr) r.col[m][rr] = ldg(Lt + rr * TB);
     }
 }
 
-__device__ __forceinline__ void bs_step(const Cx &c, int kb, const BsRow &r, double *sX, double *sLi)
+__device__ __forceinline__ void bs_step(Cx &c, int kb, const BsRow &r, double *sX, double *sLi)
 {
     const int n = c.n;
+
     // the diagonal tile's upper triangle = inv(L)^T rows; its diagonal = L_jj
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -884,26 +897,32 @@ __device__ __forceinline__ void phase_backsolve(Cx &c, double *sX, double *sLi)
 {
     const int n = c.n, nt = c.nt;
     const int br = n >> 5, rr = n & 31;                   // the right-hand side's row: tile row br (= nt - 1), local row rr
-    BsRow ra, rb;
-    bs_load(c, nt - 1, ra);
-    __syncthreads();
-    for (int q = c.tid; q < nt * TB; q += kT) {
-        double y = 0.0;
-        if (q < n) {
-            const int bc = q >> 5;
-            y = (bc < br) ? ldg(c.b.Lp + (size_t)tix(br, bc) * (TB * TB) + rr * TB + (q & 31))
-                          : ldg(c.b.S + (size_t)tix(br, br) * (TB * TB) + rr * TB + (q & 31));
+    // A load of another XCD's write-through data takes ~3.3 us here and the compiler waits for a batch where it is issued, not where
+    // it is used (seen in the listing and in the phase stamps: prefetching one row ahead bought nothing) -- so the rows go four at a
+    // time: all their loads in flight together, one round trip per four steps of ~1.9 us
+    constexpr int kRows = 4;
+    BsRow rows[kRows];
+    bool first = true;
+    for (int kb = nt - 1; kb >= 0; kb -= kRows) {
+#pragma unroll
+        for (int u = 0; u < kRows; ++u) bs_load(c, kb - u >= 0 ? kb - u : 0, rows[u]);
+        if (first) {
+            first = false;
+            __syncthreads();
+            for (int q = c.tid; q < nt * TB; q += kT) {
+                double y = 0.0;
+                if (q < n) {
+                    const int bc = q >> 5;
+                    y = (bc < br) ? ldg(c.b.Lp + (size_t)tix(br, bc) * (TB * TB) + rr * TB + (q & 31))
+                                  : ldg(c.b.S + (size_t)tix(br, br) * (TB * TB) + rr * TB + (q & 31));
+                }
+                sX[q] = y;
+            }
+            __syncthreads();
         }
-        sX[q] = y;
-    }
-    __syncthreads();
-    for (int kb = nt - 1; kb >= 0; kb -= 2) {
-        if (kb >= 1) bs_load(c, kb - 1, rb);
-        bs_step(c, kb, ra, sX, sLi);
-        if (kb >= 1) {
-            if (kb >= 2) bs_load(c, kb - 2, ra);
-            bs_step(c, kb - 1, rb, sX, sLi);
-        }
+#pragma unroll
+        for (int u = 0; u < kRows; ++u)
+            if (kb - u >= 0) bs_step(c, kb - u, rows[u], sX, sLi);
     }
     for (int q = c.tid; q < n; q += kT) stg(c.b.dpose + q, sX[q]);
 }
@@ -1446,9 +1465,9 @@ int ba_reserve(mqs_slam *s, int P, int N_ub)
     const int nt = (6 * P + 1 + TB - 1) / TB;
     const int ntiles = nt * (nt + 1) / 2;
     if (ba->arena && N_ub <= ba->dev.N_cap && P <= ba->dev.P_cap && ntiles <= ba->dev.ntile_cap) return MQS_OK;
-    int N_cap = ba->dev.N_cap > 0 ? ba->dev.N_cap : 1024;
+    int N_cap = ba->dev.N_cap > 0 ? ba->dev.N_cap : 2048;
     while (N_cap < N_ub) N_cap *= 2;
-    int P_cap = ba->dev.P_cap > 0 ? ba->dev.P_cap : 32;
+    int P_cap = ba->dev.P_cap > 0 ? ba->dev.P_cap : 64;
     while (P_cap < P) P_cap *= 2;
     if (P_cap > kMaxPoses) P_cap = kMaxPoses;
     const int nt_cap = (6 * P_cap + 1 + TB - 1) / TB, ntile_cap = nt_cap * (nt_cap + 1) / 2;
@@ -1507,6 +1526,7 @@ int mqs_slam_ba_anchor(mqs_slam *s, int n0)
     if (!s->d.log_lm) return MQS_OK;
     if (!s->ba) { const int rc = ba_fixed_alloc(s); if (rc != MQS_OK) return rc; }
     s->ba->dev.n0 = n0;
+    { const int rc = ba_reserve(s, 1, n0); if (rc != MQS_OK) return rc; }      // the first sizes (64 poses, 2 048 landmarks) now, not inside the loop
     hipLaunchKernelGGL(slam_ba_anchor_kernel, dim3((3 * n0 + 255) / 256), dim3(256), 0, s->stream, s->ba->dev, s->d, n0);
     MQS_HIP_CHECK(hipGetLastError());
     return MQS_OK;

@@ -10,7 +10,12 @@ that run's OUTPUT.
            calcOpticalFlowPyrLK / solvePnPRansac inside), traj_groundtruth3.txt (the renderer's exact trajectory),
            results_ate-slam2.txt (the reference's own error figures of that run)
 
-Usage: python tests/golden/make_icl_nuim.py [n_frames=48]
+Usage: python tests/golden/make_icl_nuim.py [n_frames=80]      -> icl_nuim_traj3n/sequence.npz          (frames 0 .. n-1 and all the rows)
+       python tests/golden/make_icl_nuim.py rest [first=80]  -> icl_nuim_traj3n/sequence_rest.npz     (frames first .. 199: the part of the
+                                                                run in which the reference's own trajectory drifts to 0.17 m)
+The images are the ICL-NUIM living-room data set's (Handa, Whelan, McDonald, Davison: "A Benchmark for RGB-D Visual Odometry, 3D
+Reconstruction and SLAM", ICRA 2014; http://www.doc.ic.ac.uk/~ahanda/VaFRIC/iclnuim.html; CC BY 3.0), as the reference repository
+redistributes them (datasets/ICL_NUIM/living_room_traj3n_frei_png/rgb: "a subset (200 images)"); see icl_nuim_traj3n/NOTICE.
 """
 import os, sys, numpy as np
 from PIL import Image
@@ -31,8 +36,14 @@ def load_tum(path, n):
 
 
 def main():
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 48
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "rest":
+        first = int(sys.argv[2]) if len(sys.argv) > 2 else 80
+        frames = np.stack([grey(os.path.join(SEQ, "rgb", "%d.png" % k)) for k in range(first, 200)])
+        np.savez_compressed(os.path.join(OUT, "sequence_rest.npz"), frames=frames, first=np.array(first))
+        print("frames", frames.shape, "->", os.path.getsize(os.path.join(OUT, "sequence_rest.npz")) / 1e6, "MB")
+        return
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 80
     frames = np.stack([grey(os.path.join(SEQ, "rgb", "%d.png" % k)) for k in range(n)])
     pts = np.array([l.split() for l in open(os.path.join(SEQ, "init_points.pcd")).read().split("DATA ascii\n")[1].strip().split("\n")], dtype=np.float64)
     np.savez_compressed(

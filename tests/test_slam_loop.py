@@ -327,6 +327,106 @@ def test_adjustment_in_the_loop_survives_a_grossly_mistracked_corner(gpu, seed):
     assert rep["last"]["cost_after"] < 400.0                                           # (the stuck runs ended at 420-460)
 
 
+def _rendered(gpu, frames):
+    import torch
+    seq = gpu.synthetic.PlaneSequence(frames=60)
+    gx, gy = np.meshgrid(np.linspace(-4.5, 1.0, 8), np.linspace(-2.5, 2.0, 6))
+    objp = np.stack([gx.ravel(), gy.ravel(), np.zeros(gx.size)], axis=1)
+    imgp = seq.project(0, objp)
+    vis = (imgp[:, 0] > 15) & (imgp[:, 0] < seq.W - 15) & (imgp[:, 1] > 15) & (imgp[:, 1] < seq.H - 15)
+    imgs = [torch.from_numpy(seq.render(k)).cuda() for k in range(frames)]
+    return seq, objp[vis], imgp[vis], imgs
+
+
+@pytest.mark.gpu
+def test_resident_adjuster_equals_its_host_built_twin_at_every_keyframe(gpu):
+    """`mqs_slam_bundle_adjust` (csrc/slam_ba.hip: the whole adjustment in one persistent launch on the resident log, map and
+    trajectory) against round 4's host-built path on the SAME state, behind every keyframe of the rendered sequence: the twin builds
+    the CSR problem from the log read back, runs `sparse_ba.SparseBundleAdjuster` (the reference-pinned kernels of ba_sparse.hip) with
+    the same screens and writes nothing back; then the device call runs.  Same poses to 1e-9 (different summation orders: measured
+    5e-15), same landmarks as float32, same landmarks retired, same pass / iteration counts, same final cost to 1e-9 relative."""
+    seq, objp, imgp, imgs = _rendered(gpu, 45)
+    slam = gpu.slam_device.DeviceMonoSlam(seq.K, seq.dist, (seq.H, seq.W), seed=1, bundle_adjust="keyframe", ba_check=True, reassociate=True)
+    assert slam.ba_engine == "device"
+    slam.start(imgs[0], objp, imgp)
+    for k in range(1, 45):
+        assert slam.handle_new_frame(imgs[k]) in (1, 2)
+    slam.finish()
+    assert len(slam.ba_checks) >= 8
+    for chk in slam.ba_checks:
+        h, d = chk["host_report"], chk["device_report"]
+        assert np.abs(chk["host_poses"] - chk["device_poses"]).max() < 1e-9
+        n = len(chk["device_points"])
+        assert np.array_equal(chk["host_points"][:n].astype(np.float32), chk["device_points"].astype(np.float32))
+        m = min(len(chk["host_retired"]), len(chk["device_retired"]))
+        assert np.array_equal(chk["host_retired"][:m], chk["device_retired"][:m]) and not chk["host_retired"][m:].any()
+        for key in ("poses", "landmarks", "landmarks_adjusted", "observations", "passes", "landmarks_screened_out", "lm_iterations"):
+            assert h[key] == d[key], (key, h, d)
+        assert abs(h["cost_after"] - d["cost_after"]) <= 1e-9 * max(1.0, h["cost_after"])
+        assert abs(h["cost_before"] - d["cost_before"]) <= 1e-9 * max(1.0, h["cost_before"])
+        assert d["repeated_observations_left_out"] == 0
+    assert any(c["device_report"]["landmarks_screened_out"] > 0 for c in slam.ba_checks) or slam.retired_landmarks().sum() >= 0
+    slam.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("engine", ["device", "host"])
+def test_loop_goes_on_after_finish(gpu, engine):
+    """finish() adjusts once more when frames followed the last keyframe; the live state's base-keyframe pose must then be the last
+    KEYFRAME's adjusted pose, not the last frame's (the tracks' base points belong to the keyframe): a loop that is continued after
+    finish() triangulates its next keyframe against it.  (Round 4 wrote the last frame's pose into both.)"""
+    seq, objp, imgp, imgs = _rendered(gpu, 60)
+    gt = seq.centres()
+
+    def run(stop):
+        slam = gpu.slam_device.DeviceMonoSlam(seq.K, seq.dist, (seq.H, seq.W), seed=1, bundle_adjust="keyframe", ba_engine=engine)
+        slam.start(imgs[0], objp, imgp)
+        for k in range(1, 60):
+            assert slam.handle_new_frame(imgs[k]) in (1, 2)
+            if k == stop:
+                assert slam.keyframes[-1] != k                      # (frames behind the last keyframe: finish() has work)
+                slam.finish()
+        slam.finish()
+        c = np.array([-P[:, :3].T @ P[:, 3] for P in slam.poses])
+        slam.close()
+        return float(np.sqrt(np.mean(np.sum((c - gt) ** 2, axis=1))))
+    straight, resumed = run(None), run(30)
+    assert straight < 0.0057 and resumed < 0.0057 and abs(resumed - straight) < 0.002
+
+
+@pytest.mark.gpu
+def test_resident_adjuster_refuses_what_it_cannot_hold(gpu):
+    """Errors of `mqs_slam_bundle_adjust`, none of them silent: a log that overflowed (round 4 clamped the count and adjusted a
+    problem whose newest frames had no observations), bad parameters, a handle without a log."""
+    import ctypes
+    from mqslam_amd import _lib
+    seq, objp, imgp, imgs = _rendered(gpu, 12)
+    slam = gpu.slam_device.DeviceMonoSlam(seq.K, seq.dist, (seq.H, seq.W), seed=1, bundle_adjust="keyframe", ba_log_capacity=1024)
+    slam.start(imgs[0], objp, imgp)
+    with pytest.raises(RuntimeError, match="observation log is full"):
+        for k in range(1, 12):
+            slam.handle_new_frame(imgs[k])
+            slam._bundle_adjust()
+    with pytest.raises(RuntimeError, match="observation log is full"):
+        slam.read_log()
+    slam.close()
+    ok = gpu.slam_device.DeviceMonoSlam(seq.K, seq.dist, (seq.H, seq.W), seed=1, bundle_adjust="keyframe")
+    ok.start(imgs[0], objp, imgp)
+    q = ok._ba_params(False, 0, 0)
+    q.max_passes = 0
+    rep = np.zeros(16)
+    assert _lib.lib().mqs_slam_bundle_adjust(ok._h, ctypes.byref(q), rep.ctypes.data_as(_lib.c_f64p), None, 0) == -1      # MQS_E_ARG
+    q = ok._ba_params(True, 3, 2)                                   # an edge that does not run forward / beyond the accepted frames
+    assert _lib.lib().mqs_slam_bundle_adjust(ok._h, ctypes.byref(q), rep.ctypes.data_as(_lib.c_f64p), None, 0) == -1
+    ok._bundle_adjust()                                             # one frame, the start-up landmarks: a problem of six unknowns
+    assert ok.ba_reports[-1]["poses"] == 1 and ok.ba_reports[-1]["cost_after"] <= ok.ba_reports[-1]["cost_before"]
+    ok.close()
+    plain = gpu.slam_device.DeviceMonoSlam(seq.K, seq.dist, (seq.H, seq.W), seed=1)
+    plain.start(imgs[0], objp, imgp)
+    assert _lib.lib().mqs_slam_bundle_adjust(plain._h, ctypes.byref(q), rep.ctypes.data_as(_lib.c_f64p), None, 0) == -1
+    plain.close()
+
+
 @pytest.mark.gpu
 def test_windowed_adjustment_in_the_device_loop(gpu):
     """ba_window_keyframes: the adjustment over the frames since the K-th keyframe from the end (anchored by pose priors on the

@@ -4,7 +4,8 @@ build's device-resident loop, against what the reference COMMITTED as that run's
 slam2.py with OpenCV 2.4's goodFeaturesToTrack / calcOpticalFlowPyrLK / solvePnPRansac) and against the renderer's exact
 trajectory.  Reads the fixture tests/golden/icl_nuim_traj3n/sequence.npz (tests/golden/make_icl_nuim.py).
 
-    python tools/run_icl_nuim.py [frames] [--ba [--window K]] [--host] [--seed S] [--out DIR]     (--out: trajectory and map in the reference's formats)
+    python tools/run_icl_nuim.py [frames] [--ba [--window K] [--reference-noise] [--host-ba]] [--host] [--seed S] [--out DIR]
+(--out: trajectory and map in the reference's formats; --host-ba: round 4's host-built adjustment; more than 80 frames: sequence_rest.npz too)
 """
 import os, sys, json, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,7 +13,7 @@ import numpy as np
 import mqslam_amd
 
 FIX = os.environ.get("MQS_ICL_FIXTURE") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden",
-                                                       "icl_nuim_traj3n", "sequence.npz")      # 80 frames committed; `make_icl_nuim.py 200` for more
+                                                       "icl_nuim_traj3n", "sequence.npz")      # frames 0 .. 79
 
 
 def centres_from_tum(rows):
@@ -42,9 +43,33 @@ def start_points(K, shape, P_init, pts):
     return uv, vis
 
 
-def run(frames=None, bundle_adjust=None, seed=0, device=True, reassociate=False, window=None, out_dir=None, screen=None):
+FIX_REST = os.path.join(os.path.dirname(FIX), "sequence_rest.npz")      # frames 80 .. 199 (`make_icl_nuim.py rest`)
+
+
+def load_sequence(frames=None):
+    """The fixture as a dict; more than the first file's 80 frames: the second file's frames behind them (200 in all), and the
+    trajectory rows from the files' complete tables."""
+    f = np.load(FIX)
+    d = {k: f[k] for k in f.files}
+    if frames is not None and frames > len(d["frames"]):
+        if not os.path.exists(FIX_REST):
+            raise FileNotFoundError("%s (frames 80..199 of the reference's example sequence: tests/golden/make_icl_nuim.py rest)" % FIX_REST)
+        r = np.load(FIX_REST)
+        assert int(r["first"]) == len(d["frames"])
+        d["frames"] = np.concatenate([d["frames"], r["frames"]])
+        d["traj_slam2"], d["traj_groundtruth"] = d["traj_slam2_all"][:len(d["frames"])], d["traj_groundtruth_all"][:len(d["frames"])]
+    return d
+
+
+REFERENCE_NOISE = {"point3D": 0.2, "pose": (0.02, 0.02, 0.02, 0.1, 0.1, 0.1), "odometry": (0.05, 0.05, 0.05, 0.2, 0.2, 0.2), "point2D": 1.0}
+# ^ BA_info.noise.*-slam2.txt beside the reference's recording of this sequence
+
+
+def run(frames=None, bundle_adjust=None, seed=0, device=True, reassociate=False, window=None, out_dir=None, screen=None, noise=None, engine="device"):
+    """noise="reference": the in-loop adjuster's noise models take the values of the reference's own noise files for this sequence
+    (instead of this build's defaults: a tighter prior on the first pose, a looser one on the start-up points)."""
     import torch
-    d = np.load(FIX)
+    d = load_sequence(frames)
     imgs_h = d["frames"] if frames is None else d["frames"][:frames]
     n = len(imgs_h)
     K, dist, P_init, pts = d["K"], d["dist"], d["init_pose"], d["init_points"]
@@ -56,7 +81,11 @@ def run(frames=None, bundle_adjust=None, seed=0, device=True, reassociate=False,
         imgs = [torch.from_numpy(np.ascontiguousarray(f)).cuda() for f in imgs_h]
         torch.cuda.synchronize()
         slam = mqslam_amd.slam_device.DeviceMonoSlam(K, dist, (H, W), seed=seed, bundle_adjust=bundle_adjust, reassociate=reassociate,
-                                                     max_homography_points="reference", ba_window_keyframes=window, second_pass_screen=screen)
+                                                     max_homography_points="reference", ba_window_keyframes=window, second_pass_screen=screen,
+                                                     ba_engine=engine)
+        if noise == "reference":
+            slam.ba_point_sigma, slam.ba_pose_sigmas = REFERENCE_NOISE["point3D"], REFERENCE_NOISE["pose"]
+            slam.ba_odometry_sigmas, slam.ba_pixel_sigma = REFERENCE_NOISE["odometry"], REFERENCE_NOISE["point2D"]
         t0 = time.perf_counter()
         slam.start(imgs[0], objp, imgp)
         rets = [2]
@@ -96,7 +125,8 @@ def run(frames=None, bundle_adjust=None, seed=0, device=True, reassociate=False,
         out["poses_in_the_last_adjustment"] = slam.ba_reports[-1]["poses"] if slam.ba_reports else 0
         co = np.array([(-P[:, :3].T @ P[:, 3]) if P is not None else [np.nan] * 3 for P in slam.poses_online])
         out["online_vs_groundtruth_rmse_m"] = round(float(np.sqrt(np.mean(err(co[ok], gt[ok]) ** 2))), 5)
-        out["landmarks_screened_out"] = int(slam._ba_bad.sum())
+        out["landmarks_screened_out"] = int(slam.retired_landmarks().sum())
+        out["engine"] = slam.ba_engine
     if out_dir:
         # what slam2.py's write_output leaves behind (:698-741): traj_out.cam0-<name>.txt in TUM format (30 fps, as the reference's
         # run) and map_out-<name>.pcd -- the inputs of the reference's own evaluation scripts
@@ -117,7 +147,7 @@ def run_posthoc(frames=80, seed=0, screen=None):
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import bundle_adjust as ba_tool
     io = mqslam_amd.ba_io
-    d = np.load(FIX)
+    d = load_sequence(frames)
     n = frames
     K, dist, P_init, pts = d["K"], d["dist"], d["init_pose"], d["init_points"]
     H, W = d["frames"].shape[1:]
@@ -158,4 +188,5 @@ if __name__ == "__main__":
     out_dir = sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else None
     a = [x for x in a if x != out_dir]
     print(json.dumps(run(int(a[0]) if a else None, "keyframe" if "--ba" in sys.argv else None, seed, "--host" not in sys.argv,
-                         "--reassociate" in sys.argv, window, out_dir, screen)))
+                         "--reassociate" in sys.argv, window, out_dir, screen, noise="reference" if "--reference-noise" in sys.argv else None,
+                         engine="host" if "--host-ba" in sys.argv else "device")))
