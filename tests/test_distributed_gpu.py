@@ -84,6 +84,15 @@ def test_two_ranks_equal_one_rank(gpu, tmp_path):
     np.testing.assert_array_equal(two[0]["x"], one["x"])                         # the overlapped work is untouched
 
 
+def _bench_lines(r):
+    """bench.py's output: (the ONE compact contract line of stdout, every leg in full from the one JSON line of stderr)."""
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    full = [l for l in r.stderr.splitlines() if l.startswith('{"metric"')]
+    assert len(full) == 1, r.stderr[-2000:]
+    return json.loads(lines[0]), json.loads(full[0])
+
+
 @pytest.mark.parametrize("scaling", ["weak", "strong"])
 def test_bench_contract_two_ranks(gpu, tmp_path, scaling):
     """Plain `python bench.py --gpus 2` (no launcher around it): the bench starts its own two ranks, rank 0 prints ONE
@@ -95,9 +104,8 @@ def test_bench_contract_two_ranks(gpu, tmp_path, scaling):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + cmd, env=env, capture_output=True, text=True,
                        timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1                                                       # rank 0 prints ONE line
-    out = json.loads(lines[0])
+    head, out = _bench_lines(r)                                                  # rank 0 prints ONE line on stdout; the legs in full on stderr
+    assert head["n_gpus"] == 2 and head["scaling"] == scaling and head["ba_strong"]["ok"] is True
     assert out["n_gpus"] == 2 and out["scaling"] == scaling and out["steps"] == 3 and out["warmup"] == 1
     assert out["value"] > 0
     if scaling == "weak":
@@ -120,9 +128,12 @@ def test_bench_contract_single_gpu(gpu):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--landmarks", "50000",
                         "--descriptors", "4096", "--no-replay", "--no-frontend"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1
-    out = json.loads(lines[0])
+    head, out = _bench_lines(r)
+    assert len(json.dumps(head)) < 6000                                          # the driver keeps an 8 KB tail: the contract line fits whole
+    for key in ("metric", "value", "value_cold", "ms_per_step", "ms_per_step_cold", "config", "dtype", "roofline", "cpu_baseline", "ba", "match", "loop"):
+        assert key in head, key
+    assert head["value"] == out["value"] and head["roofline"]["frac"] == out["roofline"]["frac"] and head["cpu_baseline"]["value"] == out["cpu_baseline"]["value"]
+    assert head["cpu_baseline"]["ba_gn_iters_per_s_all_cores"] > 0 and "all 50000 landmarks" in out["cpu_baseline"]["ba"]["sample"]
     for key, val in (("n_gpus", 1), ("steps", 3), ("warmup", 1), ("higher_is_better", True), ("scaling", "weak"), ("vs_baseline", None),
                      ("dtype", "f64"), ("data", "synthetic"), ("unit", "landmarks/s")):
         assert out[key] == val, key
@@ -189,11 +200,17 @@ def test_bench_multi_gpu_code_path_on_the_real_backend(gpu):
                         "--strong-landmarks", "30001", "--no-match", "--no-replay", "--no-frontend", "--no-cpu-baseline"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    head, out = _bench_lines(r)
     assert out["n_gpus"] == 1 and out["transport"].startswith("peer stores over xGMI via the C ABI"), out["transport"]
     bs = out["ba_strong"]
     assert bs["ok"] is True and bs["backend"] == "nccl" and bs["rccl_world_size"] == 1 and bs["all_reduce_us"] > 0
     assert bs["max_abs_pose_diff_vs_one_rank"] == 0.0          # one rank: the sharded run IS the one-rank run
+    # both transports of the sharded leg timed in the same run, each verified: the peer stores and the RCCL all-reduce north_star names
+    tr = bs["ba_strong_transports"]
+    assert tr["peer_stores"]["verified"] and tr["rccl_all_reduce"]["verified"] and tr["chosen"] in ("peer_stores", "rccl_all_reduce")
+    assert tr["peer_stores"]["ms_per_iter"] > 0 and tr["rccl_all_reduce"]["ms_per_iter"] > 0
+    assert bs["ms_per_iter"] == min(tr["peer_stores"]["ms_per_iter"], tr["rccl_all_reduce"]["ms_per_iter"])
+    assert head["ba_strong"]["ba_strong_transports"] == tr
 
 
 PEER_WORKER = r"""

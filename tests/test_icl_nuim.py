@@ -171,11 +171,14 @@ def test_loop_reproduces_the_reference_s_trajectory_on_its_example_sequence(gpu)
     for out in outs:
         assert out["accepted"] == 80 and 2 <= out["keyframes"] <= 10
         assert out["reference_vs_groundtruth_rmse_m"] < 0.005
-        assert out["ours_vs_reference_rmse_m"] < 0.08 and out["ours_vs_groundtruth_rmse_m"] < 0.08
+        # within twice the worst of the 32-seed study (22 mm from the reference's trajectory, 23 mm from the exact one; round 5, 8 seeds:
+        # 2.8-7.0 mm from the exact one, profiles/r05): a regression to 30 mm on any seed fails
+        assert out["ours_vs_reference_rmse_m"] < 0.03 and out["ours_vs_groundtruth_rmse_m"] < 0.03
         assert out["frames_per_s"] > 500
     d_ref = sorted(o["ours_vs_reference_rmse_m"] for o in outs)
     d_gt = sorted(o["ours_vs_groundtruth_rmse_m"] for o in outs)
     assert d_ref[1] < 0.008 and d_gt[1] < 0.008                                  # at least two of the four agree with the reference to millimetres
+    assert 0.5 * (d_ref[1] + d_ref[2]) < 0.008 and 0.5 * (d_gt[1] + d_gt[2]) < 0.008          # the median of the four (measured 4.1 / 3.5 mm)
     assert min(o["ours_vs_reference_max_m"] for o in outs) < 0.02
     assert sorted(o["orientation_rmse_deg"]["ours_vs_reference"] for o in outs)[1] < 0.2          # measured 0.09, 0.09, 0.18, 0.25 degrees
 
@@ -212,9 +215,48 @@ def test_loop_with_adjustment_per_keyframe_on_the_example_sequence(gpu):
     import run_icl_nuim
     for seed in range(4):
         out = run_icl_nuim.run(80, bundle_adjust="keyframe", seed=seed)
-        assert out["accepted"] == 80
+        assert out["accepted"] == 80 and out["engine"] == "device"
         assert out["ours_vs_groundtruth_rmse_m"] < 0.015 and out["ours_vs_groundtruth_max_m"] < 0.035
         assert out["ours_vs_reference_rmse_m"] < 0.018
+    # round 4's host-built adjustment on the same frames: the resident adjuster IS that adjustment (same trajectory to the digits printed)
+    dev, host = run_icl_nuim.run(80, bundle_adjust="keyframe", seed=0), run_icl_nuim.run(80, bundle_adjust="keyframe", seed=0, engine="host")
+    assert host["engine"] == "host" and abs(dev["ours_vs_groundtruth_rmse_m"] - host["ours_vs_groundtruth_rmse_m"]) < 2e-4
+    assert dev["keyframe_frames"] == host["keyframe_frames"]
+
+
+def test_reference_s_committed_run_drifts_over_the_200_frames():
+    """The golden vector of the longer run: over the 200 frames the reference commits, the trajectory slam2.py wrote for them leaves
+    the exact one by 0.171 m rmse (0.31 m at the worst frame) -- 4.3 mm over the first 80.  (results_ate-slam2.txt says 0.134 m for the
+    run as a whole: that figure is after evaluate_ate.py's rigid alignment, this one before it.)"""
+    d = np.load(FIX)
+    a, g = d["traj_slam2_all"][:200], d["traj_groundtruth_all"][:200]
+    e = np.linalg.norm(a[:, 1:4] - g[:, 1:4], axis=1)
+    assert abs(np.sqrt(np.mean(e ** 2)) - 0.17097) < 2e-4 and abs(e.max() - 0.31047) < 2e-4
+    assert np.sqrt(np.mean(e[:80] ** 2)) < 0.0044 and np.argmax(e > 0.02) > 80          # the drift starts behind frame 85
+    rest = os.path.join(os.path.dirname(FIX), "sequence_rest.npz")
+    r = np.load(rest)
+    assert int(r["first"]) == 80 and r["frames"].shape == (120, 480, 640) and r["frames"].dtype == np.uint8
+
+
+@pytest.mark.gpu
+def test_all_200_frames_of_the_example_sequence(gpu):
+    """The part of the reference's example run its 80-frame fixture does not see: frames 85-199, where the reference's committed
+    trajectory drifts to 0.171 m.  The plain loop -- slam2.py's flow -- drifts as well (52-205 mm over 8 seeds, a median of 81);
+    with the bundle adjustment per keyframe (the resident adjuster: ~20 adjustments of up to 200 poses) every seed stays within 3.5-7.1
+    mm of the exact trajectory (profiles/r05).  Bars within twice the measurements."""
+    import run_icl_nuim
+    plain = run_icl_nuim.run(200, seed=0)
+    assert plain["accepted"] == 200 and plain["keyframes"] >= 10
+    assert abs(plain["reference_vs_groundtruth_rmse_m"] - 0.17097) < 2e-4
+    assert 0.02 < plain["ours_vs_groundtruth_rmse_m"] < 0.41                     # it drifts, like the reference's run (measured 52 mm at this seed)
+    errs = []
+    for seed in range(4):
+        out = run_icl_nuim.run(200, bundle_adjust="keyframe", seed=seed)
+        assert out["accepted"] == 200 and out["engine"] == "device" and out["poses_in_the_last_adjustment"] == 200
+        assert out["ours_vs_groundtruth_rmse_m"] < 0.010 and out["ours_vs_groundtruth_max_m"] < 0.03
+        assert out["orientation_rmse_deg"]["ours_vs_groundtruth"] < 0.5
+        errs.append(out["ours_vs_groundtruth_rmse_m"])
+    assert max(errs) < 0.06 * plain["reference_vs_groundtruth_rmse_m"]           # a thirtieth of the reference's drift
 
 
 @pytest.mark.gpu
