@@ -188,13 +188,13 @@ def headline(out, details_path):
                                "adjust_ms_median": g(ba60, "bundle_adjust_per_keyframe", "ms_per_adjustment_median", "adjust_ms"),
                                "rmse_plain": g(f, "end_to_end_loop_device_resident", "trajectory_rmse"), "rmse_ba": ba60.get("trajectory_rmse")},
         "icl_nuim_80_frames": {"plain_frames_per_s": g(icl, "plain", "frames_per_s"), "ba_per_keyframe_frames_per_s": g(icl, "ba_per_keyframe", "frames_per_s"),
-                               "rmse_mm_plain_ba_reference": [g(icl, "plain", "ours_vs_groundtruth_rmse_m"), g(icl, "ba_per_keyframe", "ours_vs_groundtruth_rmse_m"),
+                               "rmse_m_plain_ba_reference": [g(icl, "plain", "ours_vs_groundtruth_rmse_m"), g(icl, "ba_per_keyframe", "ours_vs_groundtruth_rmse_m"),
                                                               g(icl, "plain", "reference_vs_groundtruth_rmse_m")]},
         "icl_nuim_200_frames": {"plain_frames_per_s": g(icl200, "plain", "frames_per_s"), "ba_per_keyframe_frames_per_s": g(icl200, "ba_per_keyframe", "frames_per_s"),
-                                "rmse_mm_plain_ba_reference": [g(icl200, "plain", "ours_vs_groundtruth_rmse_m"), g(icl200, "ba_per_keyframe", "ours_vs_groundtruth_rmse_m"),
+                                "rmse_m_plain_ba_reference": [g(icl200, "plain", "ours_vs_groundtruth_rmse_m"), g(icl200, "ba_per_keyframe", "ours_vs_groundtruth_rmse_m"),
                                                                g(icl200, "plain", "reference_vs_groundtruth_rmse_m")]} if icl200 else None,
         "error": f.get("error")}
-    h["sparse_ba_ms"] = g(out, "sparse_ba", "linearize_plus_solve_ms")
+    h["sparse_ba"] = {"linearize_plus_solve_ms": g(out, "sparse_ba", "linearize+solve_ms"), "lm_ms": g(out, "sparse_ba", "lm_ms"), "n": g(out, "sparse_ba", "n")}
     t = out.get("transport")
     h["transport"] = t if t is None or len(t) <= 160 else t[:157] + "..."
     st = out.get("ba_strong")

@@ -316,8 +316,9 @@ int mqs_ba_gn_finish_dev(mqs_ba_problem *p, double lambda, int accept, void *str
 int mqs_ba_gn_iteration_dev(mqs_ba_problem *p, double lambda, void *stream);
 int mqs_ba_gn_iterations_dev(mqs_ba_problem *p, int iters, double lambda, void *stream);
 int mqs_ba_problem_status(mqs_ba_problem *p, void *stream);
-/* Test hook: the finalizer piece (0 .. 47) of the fused tail that does not raise its flag in launches issued from now on, so
- * that tests can reach the time-out path (-1 = none, the default).  Never set in production code. */
+/* Test hook: the finalizer piece (0 .. 47) of the fused tail that does not raise its flag in launches the CALLING THREAD issues from
+ * now on, so that tests can reach the time-out path (-1 = none, the default; other threads' problems never see it).  Never set in
+ * production code. */
 int mqs_debug_ba_withhold_flag(int piece);
 
 /* Timing helper used by bench.py: average duration (ms) of `reps` back-to-back launches of ONE kernel of the iteration,

@@ -204,7 +204,7 @@ class BundleAdjuster:
         `gauss_newton_iterations`); call it yourself after a run of bare `gauss_newton_iteration`s."""
         _lib.check(_lib.lib().mqs_ba_problem_status(self._h, _sp()))
         if self.ccomm is not None and self.ccomm.peer_state() and self.ccomm.peer_timed_out():
-            raise RuntimeError("a rank's row of the reduced camera system did not arrive within 2 s (peer transport)")
+            raise RuntimeError("a rank's row of the reduced camera system did not arrive within the wait's bound (peer transport: 30 s for a problem's first reduction, 2 s afterwards)")
 
     def gauss_newton_iteration(self, lam=0.0, overlap=None):
         """One undamped (lam = 0) or fixed-damping iteration, fully asynchronous.  `overlap`: a callable that

@@ -2474,11 +2474,13 @@ int mqs_ba_linearize_push(const double *poses, const double *calib, const double
 // (all inside the caller's workspace; the epoch is unique per call, so nothing needs initialising).
 std::atomic<unsigned long long> g_fin_epoch{1};
 // test hook (tests/test_ba_gpu.py): the finalizer piece of the fused tail that does NOT raise its flag, so that the wait for it runs
-// into its bound -- the only way to reach the time-out path of a protocol whose producers always arrive
-std::atomic<int> g_withhold_flag{-1};
+// into its bound -- the only way to reach the time-out path of a protocol whose producers always arrive.  Per CALLING THREAD: only the
+// launches the setting thread issues afterwards see it (a process-wide switch would make every other thread's problems time out too,
+// and a problem's status word is sticky)
+thread_local int g_withhold_flag = -1;
 extern "C" int mqs_debug_ba_withhold_flag(int piece)
 {
-    g_withhold_flag.store(piece);
+    g_withhold_flag = piece;
     return MQS_OK;
 }
 
@@ -2505,7 +2507,7 @@ int mqs_ba_linearize_for_fused_tail(const double *poses, const double *calib, co
     fin->epoch = g_fin_epoch.fetch_add(1);
     fin->push = nullptr;
     fin->status = nullptr;
-    fin->withhold = g_withhold_flag.load();
+    fin->withhold = g_withhold_flag;
     return MQS_OK;
 }
 
@@ -2745,7 +2747,7 @@ int mqs_ba_iterate_launch(const mqs_peer_recv *peer, const mqs_ba_fin *fin_, int
     *fin_next = *fin_;
     fin_next->epoch = g_fin_epoch.fetch_add(1);
     fin_next->push = nullptr;
-    fin_next->withhold = g_withhold_flag.load();
+    fin_next->withhold = g_withhold_flag;
     return MQS_OK;
 }
 

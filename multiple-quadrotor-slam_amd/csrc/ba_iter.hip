@@ -31,7 +31,7 @@ const char *status_text(int s)
 {
     switch (s) {
     case MQS_STATUS_FINALIZE_TIMEOUT: return "the tail of an iteration gave up waiting (2 s) for the finalizer workgroups of its own launch";
-    case MQS_STATUS_PEER_TIMEOUT: return "a rank's row of the reduced camera system did not arrive within 2 s (peer transport)";
+    case MQS_STATUS_PEER_TIMEOUT: return "a rank's row of the reduced camera system did not arrive within the wait's bound (peer transport: 30 s for a problem's first reduction, 2 s afterwards)";
     }
     return "unknown status";
 }

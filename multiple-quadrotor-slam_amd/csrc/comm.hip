@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void peer_all_reduce_kernel(double *__restrict
     __syncthreads();                     // the row has landed everywhere before its flags go up (peer_dev.h)
     if (tid < push.world * recv.flags_per_rank)
         __hip_atomic_store(push.flag[tid / recv.flags_per_rank] + tid % recv.flags_per_rank, push.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    mqs::peer::wait_and_sum(buf, n, recv, tid, 256, &timed_out);      // after a wait that gave up `buf` keeps this rank's row
+    mqs::peer::wait_and_sum(buf, n, recv, tid, 256, &timed_out);      // a wait that gave up leaves NaN in `buf` (wait_and_sum): nothing that looks like a sum
 }
 
 // the wait + sum alone (the rows were pushed by the lineariser's finalize kernel): a launch of its own for ranks that share a GPU

@@ -135,11 +135,14 @@ __device__ __forceinline__ bool grid_barrier(Cx &c)
     if (c.tid == 0) {
         atomicAdd(c.b.sync, 1u);
         const uint32_t target = c.epoch * (uint32_t)c.G;
-        const long long t0 = wall_clock64();
+        // the poll is ONE sc1 load per round; the abort word and the clock (a scalar-memory round trip of its own) only every 64th
+        long long t0 = 0;
         int ok = 1;
-        while (ldg(c.b.sync) < target) {
-            __builtin_amdgcn_s_sleep(1);
-            if (ldg(c.b.sync + 1) != 0u || wall_clock64() - t0 > kSpinTicks) { ok = 0; break; }
+        for (unsigned spins = 0; ldg(c.b.sync) < target; ++spins) {
+            if ((spins & 63u) == 63u) {
+                if (t0 == 0) t0 = wall_clock64();
+                if (ldg(c.b.sync + 1) != 0u || wall_clock64() - t0 > kSpinTicks) { ok = 0; break; }
+            }
         }
         if (!ok) stg(c.b.sync + 1, 1u);
         *lds_flag() = ok;

@@ -357,8 +357,9 @@ class DeviceMonoSlam:
         _lib.check(_lib.lib().mqs_slam_bundle_adjust(self._h, ctypes.byref(q), rep.ctypes.data_as(_lib.c_f64p), poses.ctypes.data_as(_lib.c_f64p), P))
         if self._pending_keyframe is not None:                       # its refined pose as first estimated comes with the next result block
             self._pending_online, self._pending_keyframe = self._pending_keyframe, None
-        for k, f in enumerate(self._accepted):
-            self.poses[f] = poses[k].reshape(3, 4).copy()
+        P34 = poses.reshape(P, 3, 4)
+        for k, f in enumerate(self._accepted):                       # (views of this call's own array: nothing else writes it)
+            self.poses[f] = P34[k]
         out = {"frame": kf, "poses": int(rep[1]), "first_pose_of_the_window": 0, "landmarks": int(rep[2]), "landmarks_adjusted": int(rep[3]),
                "observations": int(rep[4]), "passes": int(rep[5]), "landmarks_screened_out": int(rep[6]), "lm_iterations": int(rep[7]),
                "cost_before": float(rep[8]), "cost_after": float(rep[9]), "lm_trials": int(rep[10]), "repeated_observations_left_out": int(rep[11]),
