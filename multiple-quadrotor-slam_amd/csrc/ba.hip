@@ -2202,8 +2202,10 @@ __global__ __launch_bounds__(kBlock, 1) void ba_iterate_kernel(
     const int64_t nw = (int64_t)gridDim.x * kWaves, gw = (int64_t)blockIdx.x * kWaves + wave;
     const int64_t r_begin = rows * gw / nw, r_end = rows * (gw + 1) / nw;
     {
-        constexpr int kAhead = 7;
         constexpr size_t kStageOff = 24 * 1024;
+        constexpr size_t kStageRoom = sizeof(double2) * kWaveLinLdsL * C * 3 * kBlock + sizeof(double) * kWaves * 352 - kStageOff;
+        constexpr int kAheadFit = (int)(kStageRoom / (sizeof(double2) * kWaves * C * 64));
+        constexpr int kAhead = kAheadFit >= 7 ? 7 : (kAheadFit >= 1 ? kAheadFit : 1);    // seven rows ahead (A/B builds with a smaller stash: what fits)
         static_assert(sizeof(SolveLds<C>) + 4 * 64 * sizeof(double) + 256 <= kStageOff, "the staged measurements lie beyond the solve's LDS");
         static_assert(kStageOff + sizeof(double2) * kWaves * kAhead * C * 64 <= sizeof(double2) * kWaveLinLdsL * C * 3 * kBlock + sizeof(double) * kWaves * 352,
                       "and inside the launch's dynamic LDS (the stash and the rows of totals behind it: zeroed only when the linearisation starts)");

@@ -741,6 +741,9 @@ __device__ __forceinline__ void chol_diag0(Cx &c, double *sT, double *sM, int32_
     __syncthreads();
     load_tile(c, tile, sT);
     __syncthreads();
+    // (a single-wavefront factor without a barrier per pivot -- the column through wave-private LDS, the next pivot's entry by
+    // v_readlane -- was built and measured in round 5: 10.8 us per block against this form's 6.3; one wave alone issues a dependent
+    // fp64 instruction every ~16 cycles and the 32 reciprocal square roots sit on that chain)
     mqs::chol::factor_diag_block_from_lds_4w<true>(sT, tile, TB, 0, badw, c.tid, sM);
 }
 

@@ -19,7 +19,7 @@ vis = (imgp[:, 0] > 15) & (imgp[:, 0] < seq.W - 15) & (imgp[:, 1] > 15) & (imgp[
 objp, imgp = objp[vis], imgp[vis]
 imgs = [torch.from_numpy(seq.render(k)).cuda() for k in range(frames)]
 names = {0: "start", 1: "cleared", 2: "log->table", 3: "lists", 8: "hit-lists", 4: "lm-begin", 5: "screen", 6: "write-back", 7: "end", 10: "trial", 11: "records",
-         12: "barrier", 13: "system", 14: "barrier", 15: "cholesky", 16: "backsolve", 17: "barrier", 18: "landmarks+cost", 19: "cost-reduced", 20: "sys-task-begin", 21: "sys-accumulated", 22: "sys-reduced", 30: "bs-step-begin", 31: "bs-diag-in-lds", 32: "bs-x", 33: "bs-cols"}
+         12: "barrier", 13: "system", 14: "barrier", 15: "cholesky", 16: "backsolve", 17: "barrier", 18: "landmarks+cost", 19: "cost-reduced", 20: "sys-task-begin", 21: "sys-accumulated", 22: "sys-reduced", 40: "chol-task-begin", 41: "chol-loaded", 42: "chol-updated", 43: "chol-factored", 44: "chol-barrier", 30: "bs-step-begin", 31: "bs-diag-in-lds", 32: "bs-x", 33: "bs-cols"}
 for rep in range(2):
     slam = mqslam_amd.slam_device.DeviceMonoSlam(seq.K, seq.dist, (seq.H, seq.W), seed=1, bundle_adjust="keyframe")
     slam.ba_workgroups = groups
