@@ -82,7 +82,7 @@ struct BaDev {
     double *pts_a, *pts_b, *pts_init;  // [N_cap][3]
     double *worst, *zmin;              // [N_cap]
     double *S, *Lp;                    // tiles [ntile_cap][32 x 32]: the system (factored in place) / the finished panel blocks
-    double *dpose;                     // [6 kMaxPoses + 32]
+    double *dpose, *ysol;              // [6 kMaxPoses + 64] the step; the right-hand side as the back-substitution's super-blocks leave it
     double *erec, *prec;               // [kMaxEdges][kERec], [16]
     double *partials;                  // [G][4]
     double *med;                       // [4]
@@ -487,77 +487,101 @@ __device__ __forceinline__ double phase_worst(Cx &c, const double *pts, const do
 }
 
 // The hit lists (once per adjustment, behind the per-pose lists): for every pose pair ja < jb the observations of the landmarks both
-// see, as (log index in ja, log index in jb) in landmark order.  One wavefront per pair walks ja's list and looks jb's cell of the
-// table up -- twice: to count, then (a segment of the hit array taken with ONE atomic add) to write.  The segments lie in the order
-// the wavefronts arrive; inside a segment the order is the list's, so every sum over a segment is reproducible.
+// see, as (log index in ja, log index in jb) in landmark order.  A task is pose ja with up to 32 consecutive poses jb: one wavefront
+// loads ja's list ONCE (registers: 8 entries per lane), then looks the cells of eight jb at a time up in the table -- 64 loads in flight --
+// counts their hits, takes the eight segments of the hit array with ONE atomic add and writes them from the registers.  (The first form
+// -- one pair per task, one atomic add per pair -- spent 240 us of a 200-pose adjustment serialised on the cursor: 20 100 adds to one
+// address at ~12 ns.)  The segments lie in the order the wavefronts arrive; inside a segment the order is the list's, so every sum over a
+// segment is reproducible.  A pose with more than 512 observations: the slower pair-by-pair walk below.
+__device__ __forceinline__ void build_hits_pair_slow(Cx &c, int ja, int jb, int na, int32_t *cursor, int32_t *overflow)
+{
+    const int N = c.N;
+    const int t = jb * (jb + 1) / 2 + ja;
+    const long long *list = c.b.plist + (size_t)ja * kListCap;
+    int total = 0;
+    for (int k0 = 0; k0 < na; k0 += 64) {
+        const int k = k0 + c.lane;
+        int eb = -1;
+        if (k < na) eb = ldg(c.b.T + (size_t)jb * N + (int)(ldg(list + k) >> 32));
+        total += __popcll(__ballot(eb >= 0));
+    }
+    int off = 0;
+    if (c.lane == 0 && total > 0) off = atomicAdd(cursor, total);
+    off = __builtin_amdgcn_readfirstlane(off);
+    if (total > 0 && (long long)off + total > c.b.hits_cap) { if (c.lane == 0) atomicAdd(overflow, 1); total = 0; }
+    if (c.lane == 0) { stg(c.b.blk_off + t, off); stg(c.b.blk_cnt + t, total); }
+    if (total == 0) return;
+    int w = off;
+    for (int k0 = 0; k0 < na; k0 += 64) {
+        const int k = k0 + c.lane;
+        int ea = -1, eb = -1;
+        if (k < na) { const long long el = ldg(list + k); ea = (int)(el & 0xffffffffll); eb = ldg(c.b.T + (size_t)jb * N + (int)(el >> 32)); }
+        const unsigned long long bal = __ballot(eb >= 0);
+        if (eb >= 0) stg(c.b.hits + w + __popcll(bal & ((1ull << c.lane) - 1ull)), (long long)(unsigned)ea | ((long long)eb << 32));
+        w += __popcll(bal);
+    }
+}
+
 __device__ __forceinline__ void build_hits(Cx &c, int32_t *cursor, int32_t *overflow)
 {
     const int P = c.P, N = c.N;
-    const int ntask = P * (P + 1) / 2;
+    constexpr int kChunk = 32, kB = 8, kJ = 8;           // jb per task; list entries per lane in registers; jb per look-up batch
+    // task -> (ja, chunk): pose ja has ceil((P - 1 - ja) / kChunk) chunks
+    int ntask = 0;
+    for (int ja = 0; ja + 1 < P; ++ja) ntask += (P - 1 - ja + kChunk - 1) / kChunk;
     for (int t = c.wg * 4 + c.wave; t < ntask; t += c.G * 4) {
-        int jb = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
-        while (jb * (jb + 1) / 2 > t) --jb;
-        while ((jb + 1) * (jb + 2) / 2 <= t) ++jb;
-        const int ja = t - jb * (jb + 1) / 2;
-        if (ja == jb) continue;
+        int ja = 0, rem = t;
+        for (;; ++ja) { const int nc = (P - 1 - ja + kChunk - 1) / kChunk; if (rem < nc) break; rem -= nc; }
+        const int jb0 = ja + 1 + rem * kChunk, jb1 = (jb0 + kChunk < P) ? jb0 + kChunk : P;
         const int na = ldg(c.b.pcount + ja);
-        const bool overlap = na > 0 && ldg(c.b.pcount + jb) > 0 && ldg(c.b.pl_lo + ja) <= ldg(c.b.pl_hi + jb) && ldg(c.b.pl_lo + jb) <= ldg(c.b.pl_hi + ja);
+        if (na > 64 * kB) {
+            for (int jb = jb0; jb < jb1; ++jb) build_hits_pair_slow(c, ja, jb, na, cursor, overflow);
+            continue;
+        }
         const long long *list = c.b.plist + (size_t)ja * kListCap;
-        constexpr int kB = 8;                                       // entries per lane held in registers: 512 observations of pose ja
-        if (na <= 64 * kB) {
-            // the usual case: the whole list and its look-ups in flight together (straight-line, clamped indices), one atomic add, the
-            // hits written from registers -- three dependent round trips instead of ~20
-            long long el[kB];
-            int eb[kB];
-            int total = 0;
-            if (overlap) {
+        long long el[kB];
 #pragma unroll
-                for (int u = 0; u < kB; ++u) { const int k = 64 * u + c.lane; el[u] = ldg(list + (k < na ? k : na - 1)); }
+        for (int u = 0; u < kB; ++u) { const int k = 64 * u + c.lane; el[u] = ldg(list + (k < na ? k : (na > 0 ? na - 1 : 0))); }
+        for (int jq = jb0; jq < jb1; jq += kJ) {
+            int eb[kJ][kB];
 #pragma unroll
-                for (int u = 0; u < kB; ++u) eb[u] = ldg(c.b.T + (size_t)jb * N + (int)(el[u] >> 32));
+            for (int v = 0; v < kJ; ++v) {
+                const int jb = jq + v < jb1 ? jq + v : jb1 - 1;          // (clamped: straight-line loads; the surplus is dropped below)
+#pragma unroll
+                for (int u = 0; u < kB; ++u) eb[v][u] = ldg(c.b.T + (size_t)jb * N + (int)(el[u] >> 32));
+            }
+            int cnt[kJ], total = 0;
+#pragma unroll
+            for (int v = 0; v < kJ; ++v) {
+                cnt[v] = 0;
 #pragma unroll
                 for (int u = 0; u < kB; ++u) {
-                    if (64 * u + c.lane >= na) eb[u] = -1;
-                    total += __popcll(__ballot(eb[u] >= 0));
+                    if (64 * u + c.lane >= na || jq + v >= jb1) eb[v][u] = -1;
+                    cnt[v] += __popcll(__ballot(eb[v][u] >= 0));
                 }
+                total += cnt[v];
             }
             int off = 0;
             if (c.lane == 0 && total > 0) off = atomicAdd(cursor, total);
             off = __builtin_amdgcn_readfirstlane(off);
-            if (total > 0 && (long long)off + total > c.b.hits_cap) { if (c.lane == 0) atomicAdd(overflow, 1); total = 0; }
-            if (c.lane == 0) { stg(c.b.blk_off + t, off); stg(c.b.blk_cnt + t, total); }
-            if (total == 0) continue;
+            const bool fits = (long long)off + total <= c.b.hits_cap;
+            if (total > 0 && !fits && c.lane == 0) atomicAdd(overflow, 1);
             int w = off;
 #pragma unroll
-            for (int u = 0; u < kB; ++u) {
-                const unsigned long long bal = __ballot(eb[u] >= 0);
-                if (eb[u] >= 0) stg(c.b.hits + w + __popcll(bal & ((1ull << c.lane) - 1ull)), (long long)(unsigned)(int)(el[u] & 0xffffffffll) | ((long long)eb[u] << 32));
-                w += __popcll(bal);
+            for (int v = 0; v < kJ; ++v) {
+                const int jb = jq + v;
+                if (jb < jb1) {                                          // (wave-uniform)
+                    if (c.lane == 0) { stg(c.b.blk_off + jb * (jb + 1) / 2 + ja, w); stg(c.b.blk_cnt + jb * (jb + 1) / 2 + ja, fits ? cnt[v] : 0); }
+                    if (fits) {
+#pragma unroll
+                        for (int u = 0; u < kB; ++u) {
+                            const unsigned long long bal = __ballot(eb[v][u] >= 0);
+                            if (eb[v][u] >= 0) stg(c.b.hits + w + __popcll(bal & ((1ull << c.lane) - 1ull)), (long long)(unsigned)(int)(el[u] & 0xffffffffll) | ((long long)eb[v][u] << 32));
+                            w += __popcll(bal);
+                        }
+                    }
+                }
             }
-            continue;
-        }
-        int total = 0;
-        if (overlap)
-            for (int k0 = 0; k0 < na; k0 += 64) {
-                const int k = k0 + c.lane;
-                int eb = -1;
-                if (k < na) eb = ldg(c.b.T + (size_t)jb * N + (int)(ldg(list + k) >> 32));
-                total += __popcll(__ballot(eb >= 0));
-            }
-        int off = 0;
-        if (c.lane == 0 && total > 0) off = atomicAdd(cursor, total);
-        off = __builtin_amdgcn_readfirstlane(off);
-        if (total > 0 && (long long)off + total > c.b.hits_cap) { if (c.lane == 0) atomicAdd(overflow, 1); total = 0; }
-        if (c.lane == 0) { stg(c.b.blk_off + t, off); stg(c.b.blk_cnt + t, total); }
-        if (total == 0) continue;
-        int w = off;
-        for (int k0 = 0; k0 < na; k0 += 64) {
-            const int k = k0 + c.lane;
-            int ea = -1, eb = -1;
-            if (k < na) { const long long el = ldg(list + k); ea = (int)(el & 0xffffffffll); eb = ldg(c.b.T + (size_t)jb * N + (int)(el >> 32)); }
-            const unsigned long long bal = __ballot(eb >= 0);
-            if (eb >= 0) stg(c.b.hits + w + __popcll(bal & ((1ull << c.lane) - 1ull)), (long long)(unsigned)ea | ((long long)eb << 32));
-            w += __popcll(bal);
         }
     }
 }
@@ -832,35 +856,40 @@ __device__ __forceinline__ bool phase_cholesky(Cx &c, double *sBuf, int32_t *bad
     return true;
 }
 
-// D (workgroup 0): L^T x = y, y = the augmented row of the factor; x -> dpose (global).  Block rows from the last to the first:
-//   x_kb = inv(L_kb)^T y_kb (the inverse lies in the diagonal tile's upper triangle), then y_j -= L(kb, j)^T x_kb for the blocks left
-// of it, one column per thread.  Nothing of a block row's factor entries depends on x, so the NEXT row's loads are issued before
-// this row is worked on (two register sets, the loop unrolled by two): the L2 round trip of a step leaves the serial chain.
-constexpr int kBsCols = 1;                       // columns per thread with prefetch: 256 columns left of a block (42 poses); beyond: the tail loop
+// D: L^T x = y, y = the augmented row of the factor; x -> dpose (global).
+// Block rows from the last to the first, in SUPER-BLOCKS of kSuper tile rows (256 unknowns):
+//   * inside a super-block workgroup 0 substitutes: x_kb = inv(L_kb)^T y_kb (the inverse lies in the diagonal tile's upper triangle), then
+//     y_j -= L(kb, j)^T x_kb for the blocks of the SAME super-block left of it -- at most 224 columns, one per thread.  A load of another
+//     XCD's write-through data takes ~3.3 us here and the compiler waits for a batch where it is issued, not where it is used (listing and
+//     phase stamps: prefetching one row ahead bought nothing), so the rows go four at a time: all their loads in flight together;
+//   * the super-block's x then goes to global memory, and ALL workgroups apply it to the columns left of the super-block -- one 32-column
+//     tile column per workgroup, its eight tiles (64 KB) in flight at once, the eight partial sums added in a fixed order -- between two
+//     grid barriers.  (Round 5's first form did everything in workgroup 0: at 200 poses the columns beyond the first 256 were fetched in
+//     a loop of dependent round trips, 15 us per block row, 581 us per solve -- more than the factorisation.)
+// Systems of up to 256 unknowns (42 poses) are one super-block: no barrier inside.
+constexpr int kSuper = 8;
 
-struct BsRow { double diag[4]; double col[kBsCols][TB]; };
+struct BsRow { double diag[4]; double col[TB]; };
 
-__device__ __forceinline__ void bs_load(const Cx &c, int kb, BsRow &r)
+__device__ __forceinline__ void bs_load(const Cx &c, int kb, int lo, BsRow &r)
 {
     const double *D = c.b.S + (size_t)tix(kb, kb) * (TB * TB);
 #pragma unroll
     for (int u = 0; u < 4; ++u) r.diag[u] = ldg(D + c.tid + u * kT);
+    // unconditional, the column index clamped (a load inside a divergent branch serialises the batches behind it); kb = lo: a tile
+    // nobody needs -- the values are not used
+    int q = lo * TB + c.tid;
+    if (q >= kb * TB) q = kb * TB - 1;
+    if (q < 0) q = 0;
+    const double *Lt = c.b.Lp + (size_t)tix(kb > 0 ? kb : 1, q >> 5) * (TB * TB) + (q & 31);
 #pragma unroll
-    for (int m = 0; m < kBsCols; ++m) {
-        // unconditional, the column index clamped (a load inside a divergent branch serialises the batches behind it)
-        int q = c.tid + m * kT;
-        if (q >= kb * TB) q = kb * TB - 1;
-        if (q < 0) q = 0;                                        // (kb = 0: a tile nobody reads from -- the values are not used)
-        const double *Lt = c.b.Lp + (size_t)tix(kb, q >> 5) * (TB * TB) + (q & 31);
-#pragma unroll
-        for (int rr = 0; rr < TB; ++rr) r.col[m][rr] = ldg(Lt + rr * TB);
-    }
+    for (int rr = 0; rr < TB; ++rr) r.col[rr] = ldg(Lt + rr * TB);
 }
 
-__device__ __forceinline__ void bs_step(Cx &c, int kb, const BsRow &r, double *sX, double *sLi)
+// sX: this super-block's y -> x, indexed from the super-block's first row (lo * TB)
+__device__ __forceinline__ void bs_step(Cx &c, int kb, int lo, const BsRow &r, double *sX, double *sLi)
 {
     const int n = c.n;
-
     // the diagonal tile's upper triangle = inv(L)^T rows; its diagonal = L_jj
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -872,65 +901,101 @@ __device__ __forceinline__ void bs_step(Cx &c, int kb, const BsRow &r, double *s
         const int a = c.tid;
         double xa = 0.0;
 #pragma unroll 8
-        for (int bq = 0; bq < TB; ++bq) xa = fma(sLi[a * TLD + bq], sX[kb * TB + bq], xa);      // zero below the diagonal
+        for (int bq = 0; bq < TB; ++bq) xa = fma(sLi[a * TLD + bq], sX[(kb - lo) * TB + bq], xa);      // zero below the diagonal
         if (kb * TB + a >= n) xa = 0.0;
         sLi[TB * TLD + a] = xa;
     }
     __syncthreads();
-    if (c.tid < TB) sX[kb * TB + c.tid] = sLi[TB * TLD + c.tid];
-#pragma unroll
-    for (int m = 0; m < kBsCols; ++m) {
-        const int q = c.tid + m * kT;
-        if (q < kb * TB) {
-            double sacc = 0.0;
-#pragma unroll
-            for (int rr = 0; rr < TB; ++rr) sacc = fma(r.col[m][rr], sLi[TB * TLD + rr], sacc);
-            sX[q] -= sacc;
-        }
-    }
-    // columns beyond the prefetched ones (systems of more than kBsCols * 256 unknowns left of the block)
-    for (int q = c.tid + kBsCols * kT; q < kb * TB; q += kT) {
-        const double *Lt = c.b.Lp + (size_t)tix(kb, q >> 5) * (TB * TB) + (q & 31);
+    if (c.tid < TB) sX[(kb - lo) * TB + c.tid] = sLi[TB * TLD + c.tid];
+    if (lo * TB + c.tid < kb * TB) {
         double sacc = 0.0;
-#pragma unroll 8
-        for (int rr = 0; rr < TB; ++rr) sacc = fma(ldg(Lt + rr * TB), sLi[TB * TLD + rr], sacc);
-        sX[q] -= sacc;
+#pragma unroll
+        for (int rr = 0; rr < TB; ++rr) sacc = fma(r.col[rr], sLi[TB * TLD + rr], sacc);
+        sX[c.tid] -= sacc;
     }
     __syncthreads();
 }
 
-__device__ __forceinline__ void phase_backsolve(Cx &c, double *sX, double *sLi)
+__device__ __forceinline__ bool phase_backsolve(Cx &c, double *sX, double *sLi, int &barriers)
 {
     const int n = c.n, nt = c.nt;
     const int br = n >> 5, rr = n & 31;                   // the right-hand side's row: tile row br (= nt - 1), local row rr
-    // A load of another XCD's write-through data takes ~3.3 us here and the compiler waits for a batch where it is issued, not where
-    // it is used (seen in the listing and in the phase stamps: prefetching one row ahead bought nothing) -- so the rows go four at a
-    // time: all their loads in flight together, one round trip per four steps of ~1.9 us
     constexpr int kRows = 4;
-    BsRow rows[kRows];
-    bool first = true;
-    for (int kb = nt - 1; kb >= 0; kb -= kRows) {
+    for (int hi = nt; hi > 0;) {
+        const int lo = hi > kSuper ? hi - kSuper : 0;
+        if (c.wg == 0) {
+            BsRow rows[kRows];
+            bool first = true;
+            for (int kb = hi - 1; kb >= lo; kb -= kRows) {
 #pragma unroll
-        for (int u = 0; u < kRows; ++u) bs_load(c, kb - u >= 0 ? kb - u : 0, rows[u]);
-        if (first) {
-            first = false;
-            __syncthreads();
-            for (int q = c.tid; q < nt * TB; q += kT) {
-                double y = 0.0;
-                if (q < n) {
-                    const int bc = q >> 5;
-                    y = (bc < br) ? ldg(c.b.Lp + (size_t)tix(br, bc) * (TB * TB) + rr * TB + (q & 31))
-                                  : ldg(c.b.S + (size_t)tix(br, br) * (TB * TB) + rr * TB + (q & 31));
+                for (int u = 0; u < kRows; ++u) bs_load(c, kb - u >= lo ? kb - u : lo, lo, rows[u]);
+                if (first) {
+                    first = false;
+                    __syncthreads();
+                    // this super-block's right-hand side: the factor's augmented row (the last super-block: nothing has touched it yet; it also
+                    // seeds the global copy the other workgroups will subtract from), else the global copy
+                    if (hi == nt) {
+                        for (int q = c.tid; q < nt * TB; q += kT) {
+                            double y = 0.0;
+                            if (q < n) {
+                                const int bc = q >> 5;
+                                y = (bc < br) ? ldg(c.b.Lp + (size_t)tix(br, bc) * (TB * TB) + rr * TB + (q & 31))
+                                              : ldg(c.b.S + (size_t)tix(br, br) * (TB * TB) + rr * TB + (q & 31));
+                            }
+                            if (q >= lo * TB) sX[q - lo * TB] = y;
+                            else stg(c.b.ysol + q, y);
+                        }
+                    } else {
+                        for (int q = c.tid; q < (hi - lo) * TB; q += kT) sX[q] = ldg(c.b.ysol + lo * TB + q);
+                    }
+                    __syncthreads();
                 }
-                sX[q] = y;
-            }
-            __syncthreads();
-        }
 #pragma unroll
-        for (int u = 0; u < kRows; ++u)
-            if (kb - u >= 0) bs_step(c, kb - u, rows[u], sX, sLi);
+                for (int u = 0; u < kRows; ++u)
+                    if (kb - u >= lo) bs_step(c, kb - u, lo, rows[u], sX, sLi);
+            }
+            for (int q = c.tid; q < (hi - lo) * TB; q += kT)
+                if (lo * TB + q < n) stg(c.b.dpose + lo * TB + q, sX[q]);
+        }
+        if (lo == 0) break;
+        if (!grid_barrier(c)) return false;
+        barriers += 1;
+        // the super-block applied to the columns left of it: workgroup -> tile column j, thread -> (tile row lo + g, column cc)
+        {
+            double *sXs = sX;                             // [kSuper * TB] the super-block's x
+            double *sPart = sLi;                          // [kSuper][TB]
+            __syncthreads();
+            for (int q = c.tid; q < (hi - lo) * TB; q += kT) sXs[q] = (lo * TB + q < n) ? ldg(c.b.dpose + lo * TB + q) : 0.0;
+            __syncthreads();
+            const int g = c.tid >> 5, cc = c.tid & 31;
+            for (int j = c.wg; j < lo; j += c.G) {
+                double part = 0.0;
+                const int i = lo + g;
+                if (i < hi) {
+                    const double *Lt = c.b.Lp + (size_t)tix(i, j) * (TB * TB) + cc;
+                    double lv[TB];
+#pragma unroll
+                    for (int r2 = 0; r2 < TB; ++r2) lv[r2] = ldg(Lt + r2 * TB);
+#pragma unroll
+                    for (int r2 = 0; r2 < TB; ++r2) part = fma(lv[r2], sXs[g * TB + r2], part);
+                }
+                __syncthreads();
+                sPart[g * TB + cc] = part;
+                __syncthreads();
+                if (c.tid < TB) {
+                    double t = 0.0;
+#pragma unroll
+                    for (int g2 = 0; g2 < kSuper; ++g2) t += sPart[g2 * TB + c.tid];
+                    const int q = j * TB + c.tid;
+                    stg(c.b.ysol + q, ldg(c.b.ysol + q) - t);
+                }
+            }
+        }
+        if (!grid_barrier(c)) return false;
+        barriers += 1;
+        hi = lo;
     }
-    for (int q = c.tid; q < n; q += kT) stg(c.b.dpose + q, sX[q]);
+    return true;
 }
 
 // E: landmarks back-substituted at the linearisation point (sCam, pts), the step's poses retracted by every workgroup for itself
@@ -1054,7 +1119,7 @@ __device__ __forceinline__ bool lm_trial(Cx &c, const double *poses, const doubl
     stamp(c, 14);
     if (!phase_cholesky(c, lds_cam_new(), badw)) return false;
     stamp(c, 15);
-    if (c.wg == 0) phase_backsolve(c, lds_cam_new(), lds_cam_new() + kMaxPoses * 6 + 64);
+    if (!phase_backsolve(c, lds_cam_new(), lds_cam_new() + kMaxPoses * 6 + 64, barriers)) return false;
     stamp(c, 16);
     if (!grid_barrier(c)) return false;
     stamp(c, 17);
@@ -1435,7 +1500,7 @@ int ba_fixed_alloc(mqs_slam *s)
     const size_t o_sync = take(64), o_ctr = take(kCtr * 4), o_rep = take(MQS_SLAM_BA_REPORT * 8), o_p0 = take(96), o_o0 = take(kMaxTracks * 24),
                  o_bad = take(L * 4), o_of = take(kMaxEdges * 4), o_ot = take(kMaxEdges * 4), o_om = take(kMaxEdges * 96),
                  o_ei = take(kMaxPoses * 4), o_eo = take(kMaxPoses * 4), o_er = take((size_t)kMaxEdges * kERec * 8), o_pr = take(128),
-                 o_med = take(64), o_part = take(256 * 32), o_dp = take((6 * kMaxPoses + 32) * 8),
+                 o_med = take(64), o_part = take(256 * 32), o_dp = take((6 * kMaxPoses + 64) * 8), o_ys = take((6 * kMaxPoses + 64) * 8),
                  o_pa = take(kMaxPoses * 96), o_pb = take(kMaxPoses * 96), o_pi = take(kMaxPoses * 96),
                  o_pc = take(kMaxPoses * 4), o_lo = take(kMaxPoses * 4), o_hi = take(kMaxPoses * 4),
                  o_pl = take((size_t)kMaxPoses * kListCap * 8), o_bo = take((size_t)kMaxPoses * (kMaxPoses + 1) / 2 * 4),
@@ -1449,7 +1514,7 @@ int ba_fixed_alloc(mqs_slam *s)
     b.sync = (uint32_t *)(a + o_sync); b.ctr = (int32_t *)(a + o_ctr); b.report = (double *)(a + o_rep); b.pose0 = (double *)(a + o_p0);
     b.objp0 = (double *)(a + o_o0); b.bad = (int32_t *)(a + o_bad); b.odo_from = (int32_t *)(a + o_of); b.odo_to = (int32_t *)(a + o_ot);
     b.odo_meas = (double *)(a + o_om); b.e_in = (int32_t *)(a + o_ei); b.e_out = (int32_t *)(a + o_eo); b.erec = (double *)(a + o_er);
-    b.prec = (double *)(a + o_pr); b.med = (double *)(a + o_med); b.partials = (double *)(a + o_part); b.dpose = (double *)(a + o_dp);
+    b.prec = (double *)(a + o_pr); b.med = (double *)(a + o_med); b.partials = (double *)(a + o_part); b.dpose = (double *)(a + o_dp); b.ysol = (double *)(a + o_ys);
     b.poses_a = (double *)(a + o_pa); b.poses_b = (double *)(a + o_pb); b.poses_init = (double *)(a + o_pi);
     b.pcount = (int32_t *)(a + o_pc); b.pl_lo = (int32_t *)(a + o_lo); b.pl_hi = (int32_t *)(a + o_hi); b.plist = (long long *)(a + o_pl);
     b.lm_res = (int32_t *)(a + o_lr); b.rec = (double *)(a + o_rec); b.rec_stride = s->d.log_cap; b.blk_off = (int32_t *)(a + o_bo); b.blk_cnt = (int32_t *)(a + o_bc);
@@ -1565,7 +1630,7 @@ int mqs_slam_bundle_adjust(mqs_slam *s, const mqs_slam_ba_params *q, double *rep
     }
     int rc = ba_reserve(s, P, s->land_ub > 0 ? s->land_ub : 1);
     if (rc != MQS_OK) return rc;
-    int G = q->workgroups > 0 ? q->workgroups : 128;
+    int G = q->workgroups > 0 ? q->workgroups : (P > 96 ? 256 : 128);     // the pose-pair phases have P^2 / 2 tasks; the chain of block factors does not care
     if (const char *e = getenv("MQS_SLAM_BA_GROUPS")) { const int g = atoi(e); if (g > 0) G = g; }
     if (G > 256) G = 256;
     p.P = P; p.G = G; p.key_pose = s->key_pose;

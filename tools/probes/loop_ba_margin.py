@@ -22,5 +22,5 @@ for margin, minobs in ((1e-6, 3), (3.0, 3), (6.0, 3), (10.0, 3)):
     co = np.array([-P[:, :3].T @ P[:, 3] for P in s.poses_online])
     r = lambda c: round(float(np.sqrt(np.mean(np.sum((c - gt) ** 2, axis=1)))), 5)
     first = s.ba_reports[0]
-    print(json.dumps({"margin": margin, "min_obs": minobs, "rmse": r(c), "online": r(co), "screened": int(s._ba_bad.sum()), "first_adjustment": [first["frame"], first["landmarks_adjusted"], first["observations"]]}))
+    print(json.dumps({"margin": margin, "min_obs": minobs, "rmse": r(c), "online": r(co), "screened": int(s.retired_landmarks().sum()), "first_adjustment": [first["frame"], first["landmarks_adjusted"], first["observations"]]}))
     s.close()

@@ -30,7 +30,7 @@ for frames in (40, 60, 90):
             row[name] = {"rmse": round(r, 5), "accepted": acc, "keyframes": len(s.keyframes), "landmarks": int(len(s.objp))}
             if kw:
                 row[name]["rmse_online"] = round(rmse(s.poses_online)[0], 5)
-                row[name]["screened_out"] = int(s._ba_bad.sum())
+                row[name]["screened_out"] = int(s.retired_landmarks().sum())
                 row[name]["reassociated"] = int(s.reassociated)
             s.close()
         out.append(row)
