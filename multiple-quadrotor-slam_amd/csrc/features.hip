@@ -579,11 +579,33 @@ __device__ __forceinline__ float bilinear_u8(const uint8_t *__restrict__ a, int 
     return (((float)p[0] * w00 + (float)p[1] * w01) + (float)p[W] * w10) + (float)p[W + 1] * w11;
 }
 
-__global__ __launch_bounds__(64) void lk_kernel(LkLevels L, const float *__restrict__ prev_pts, int n, const int32_t *__restrict__ n_dev,
-                                               int ww, int wh, int max_iter, float eps, float min_eig_threshold,
-                                               float *__restrict__ next_pts, uint8_t *__restrict__ status, float *__restrict__ err)
+// NW wavefronts per feature (round 5: four): a feature's track is a serial chain of ~80 iterations, each a window sum and a 2 x 2 solve; with
+// one wavefront the chain's length IS the launch's (300 features on 256 CUs: one wave per CU, 73 us); four wavefronts take a quarter of the
+// window each and meet in LDS once per sum (parity-alternating slots: one workgroup barrier per sum).
+template <int NW>
+__device__ __forceinline__ void lk_block_sum2(double x, double y, double &sx, double &sy, double *sRed, int &slot, int wave, int lane)
 {
-    const int k = blockIdx.x, lane = threadIdx.x;
+    mqs::wave::sum2(x, y, sx, sy);
+    if (NW > 1) {
+        double *r = sRed + (slot & 1) * 2 * NW;
+        slot += 1;
+        if (lane == 0) { r[2 * wave] = sx; r[2 * wave + 1] = sy; }
+        __syncthreads();
+        sx = 0.0; sy = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { sx += r[2 * w]; sy += r[2 * w + 1]; }
+    }
+}
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void lk_kernel(LkLevels L, const float *__restrict__ prev_pts, int n, const int32_t *__restrict__ n_dev,
+                                                    int ww, int wh, int max_iter, float eps, float min_eig_threshold,
+                                                    float *__restrict__ next_pts, uint8_t *__restrict__ status, float *__restrict__ err)
+{
+    __shared__ double sRed[4 * NW];
+    int slot = 0;
+    constexpr int kPix = (kMaxWinPixelsPerLane + NW - 1) / NW;       // window pixels per thread
+    const int k = blockIdx.x, lane = threadIdx.x, wave = threadIdx.x >> 6;
     if (n_dev) n = min(n, *n_dev);                  // the device-resident loop: the number of live tracks is device state
     if (k >= n) return;
     const int npix = ww * wh;
@@ -605,32 +627,43 @@ __global__ __launch_bounds__(64) void lk_kernel(LkLevels L, const float *__restr
             continue;
         }
         const int P = L.P[level];
-        float Iw[kMaxWinPixelsPerLane], Ixw[kMaxWinPixelsPerLane], Iyw[kMaxWinPixelsPerLane];
+        float Iw[kPix], Ixw[kPix], Iyw[kPix];
+        // Every window load below is issued UNCONDITIONALLY (a lane's pixel index beyond the window is clamped to the window's last pixel and
+        // its weight is zero): a load inside a divergent branch makes the wait-count bookkeeping serialise the seven pixel groups of an
+        // iteration -- seven dependent L1 round trips where one suffices (round 5; found on the resident adjuster).  The pixel's offset inside
+        // the padded level (two integer divisions by the runtime window width) is computed once per level, not once per iteration.
+        int woff[kPix];
+        bool win[kPix];
+#pragma unroll
+        for (int t = 0; t < kPix; ++t) {
+            const int p = lane + 64 * NW * t;
+            win[t] = p < npix;
+            const int pc = win[t] ? p : npix - 1;
+            woff[t] = (pc / ww) * P + pc % ww;
+        }
         double a11 = 0.0, a12 = 0.0, a22 = 0.0;
         {
             const float a = px - (float)ipx, b = py - (float)ipy;
             const float w00 = (1.0f - a) * (1.0f - b), w01 = a * (1.0f - b), w10 = (1.0f - a) * b, w11 = a * b;
-            const uint8_t *I = L.I[level];
-            const short2 *dI = L.dI[level];
+            const uint8_t *I = L.I[level] + ipy * P + ipx;
+            const short2 *dI = L.dI[level] + ipy * P + ipx;
 #pragma unroll
-            for (int t = 0; t < kMaxWinPixelsPerLane; ++t) {
-                const int p = lane + 64 * t;
-                Iw[t] = 0.0f; Ixw[t] = 0.0f; Iyw[t] = 0.0f;
-                if (p < npix) {
-                    const int x = ipx + p % ww, y = ipy + p / ww;
-                    Iw[t] = bilinear_u8(I, P, x, y, w00, w01, w10, w11) * 32.0f;
-                    const short2 d00 = dI[y * P + x], d01 = dI[y * P + x + 1], d10 = dI[(y + 1) * P + x], d11 = dI[(y + 1) * P + x + 1];
-                    Ixw[t] = (((float)d00.x * w00 + (float)d01.x * w01) + (float)d10.x * w10) + (float)d11.x * w11;
-                    Iyw[t] = (((float)d00.y * w00 + (float)d01.y * w01) + (float)d10.y * w10) + (float)d11.y * w11;
-                    a11 += (double)Ixw[t] * (double)Ixw[t];
-                    a12 += (double)Ixw[t] * (double)Iyw[t];
-                    a22 += (double)Iyw[t] * (double)Iyw[t];
-                }
+            for (int t = 0; t < kPix; ++t) {
+                const uint8_t *q = I + woff[t];
+                const float iv = ((((float)q[0] * w00 + (float)q[1] * w01) + (float)q[P] * w10) + (float)q[P + 1] * w11) * 32.0f;
+                const short2 d00 = dI[woff[t]], d01 = dI[woff[t] + 1], d10 = dI[woff[t] + P], d11 = dI[woff[t] + P + 1];
+                const float ix = (((float)d00.x * w00 + (float)d01.x * w01) + (float)d10.x * w10) + (float)d11.x * w11;
+                const float iy = (((float)d00.y * w00 + (float)d01.y * w01) + (float)d10.y * w10) + (float)d11.y * w11;
+                Iw[t] = win[t] ? iv : 0.0f; Ixw[t] = win[t] ? ix : 0.0f; Iyw[t] = win[t] ? iy : 0.0f;
+                a11 += (double)Ixw[t] * (double)Ixw[t];
+                a12 += (double)Ixw[t] * (double)Iyw[t];
+                a22 += (double)Iyw[t] * (double)Iyw[t];
             }
         }
-        double s11, s12;
-        wave_sum2_d(a11, a12, s11, s12);
-        const float A11 = (float)s11 * kFltScale, A12 = (float)s12 * kFltScale, A22 = (float)wave_sum_d(a22) * kFltScale;
+        double s11, s12, s22, unused;
+        lk_block_sum2<NW>(a11, a12, s11, s12, sRed, slot, wave, lane & 63);
+        lk_block_sum2<NW>(a22, 0.0, s22, unused, sRed, slot, wave, lane & 63);
+        const float A11 = (float)s11 * kFltScale, A12 = (float)s12 * kFltScale, A22 = (float)s22 * kFltScale;
         float D = A11 * A22 - A12 * A12;
         const float min_eig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.0f * A12 * A12)) / (float)(2 * ww * wh);
         if (min_eig < min_eig_threshold || D < 1.1920929e-07f) {
@@ -649,18 +682,18 @@ __global__ __launch_bounds__(64) void lk_kernel(LkLevels L, const float *__restr
             }
             const float a = nx - (float)inx, b = ny - (float)iny;
             const float w00 = (1.0f - a) * (1.0f - b), w01 = a * (1.0f - b), w10 = (1.0f - a) * b, w11 = a * b;
+            const uint8_t *Jw = J + iny * P + inx;
             double b1 = 0.0, b2 = 0.0;
 #pragma unroll
-            for (int t = 0; t < kMaxWinPixelsPerLane; ++t) {
-                const int p = lane + 64 * t;
-                if (p < npix) {
-                    const float diff = bilinear_u8(J, P, inx + p % ww, iny + p / ww, w00, w01, w10, w11) * 32.0f - Iw[t];
-                    b1 += (double)diff * (double)Ixw[t];
-                    b2 += (double)diff * (double)Iyw[t];
-                }
+            for (int t = 0; t < kPix; ++t) {
+                const uint8_t *q = Jw + woff[t];
+                const float jv = (((float)q[0] * w00 + (float)q[1] * w01) + (float)q[P] * w10) + (float)q[P + 1] * w11;
+                const float diff = win[t] ? jv * 32.0f - Iw[t] : 0.0f;
+                b1 += (double)diff * (double)Ixw[t];
+                b2 += (double)diff * (double)Iyw[t];
             }
             double sb1, sb2;
-            wave_sum2_d(b1, b2, sb1, sb2);
+            lk_block_sum2<NW>(b1, b2, sb1, sb2, sRed, slot, wave, lane & 63);
             const float B1 = (float)sb1 * kFltScale, B2 = (float)sb2 * kFltScale;
             const float dx = (A12 * B2 - A22 * B1) * D, dy = (A12 * B1 - A11 * B2) * D;
             nx += dx; ny += dy;
@@ -680,14 +713,17 @@ __global__ __launch_bounds__(64) void lk_kernel(LkLevels L, const float *__restr
             } else {
                 const float a = qx - (float)inx, b = qy - (float)iny;
                 const float w00 = (1.0f - a) * (1.0f - b), w01 = a * (1.0f - b), w10 = (1.0f - a) * b, w11 = a * b;
+                const uint8_t *Jw = J + iny * P + inx;
                 double e = 0.0;
 #pragma unroll
-                for (int t = 0; t < kMaxWinPixelsPerLane; ++t) {
-                    const int p = lane + 64 * t;
-                    if (p < npix)
-                        e += fabs((double)(bilinear_u8(J, P, inx + p % ww, iny + p / ww, w00, w01, w10, w11) * 32.0f - Iw[t]));
+                for (int t = 0; t < kPix; ++t) {
+                    const uint8_t *q = Jw + woff[t];
+                    const float jv = (((float)q[0] * w00 + (float)q[1] * w01) + (float)q[P] * w10) + (float)q[P + 1] * w11;
+                    if (win[t]) e += fabs((double)(jv * 32.0f - Iw[t]));
                 }
-                errv = (float)(wave_sum_d(e) / (32.0 * (double)ww * (double)wh));
+                double se, unused2;
+                lk_block_sum2<NW>(e, 0.0, se, unused2, sRed, slot, wave, lane & 63);
+                errv = (float)(se / (32.0 * (double)ww * (double)wh));
             }
         }
     }
@@ -972,7 +1008,7 @@ int mqs_lk_launch(const uint8_t *prev_img, const uint8_t *next_img, int W, int H
         hipLaunchKernelGGL(lk_pad_levels_kernel, g, dim3(kBlock), 0, stream, job);
     }
     if (n > 0)
-        hipLaunchKernelGGL(lk_kernel, dim3(n), dim3(64), 0, stream, L, prev_pts, n, n_dev, win_w, win_h, max_iter, (float)eps,
+        hipLaunchKernelGGL(lk_kernel<4>, dim3(n), dim3(256), 0, stream, L, prev_pts, n, n_dev, win_w, win_h, max_iter, (float)eps,
                            (float)min_eig_threshold, next_pts, status, err);
     MQS_HIP_CHECK(hipGetLastError());
     return MQS_OK;

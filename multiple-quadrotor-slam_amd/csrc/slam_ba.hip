@@ -1599,6 +1599,18 @@ int mqs_slam_ba_anchor(mqs_slam *s, int n0)
     s->ba->dev.n0 = n0;
     { const int rc = ba_reserve(s, 1, n0); if (rc != MQS_OK) return rc; }      // the first sizes (64 poses, 2 048 landmarks) now, not inside the loop
     hipLaunchKernelGGL(slam_ba_anchor_kernel, dim3((3 * n0 + 255) / 256), dim3(256), 0, s->stream, s->ba->dev, s->d, n0);
+    // The adjuster's first launch in a process costs ~8 ms beyond its work (the queue's scratch for its few spilled registers, the
+    // 112 KB LDS opt-in): paid here, at start-up, by a launch that returns at once (zero poses: status 2, nothing touched), not behind
+    // the run's first keyframe
+    {
+        BaParams p;
+        memset(&p, 0, sizeof(p));
+        p.G = 1;
+        const size_t lds = ((size_t)2 * kMaxPoses * kCamStride + 6 * kMaxPoses + 32 + 64) * sizeof(double);
+        static mqs_lds_opt_in opt;
+        MQS_HIP_CHECK(mqs_lds_opt_in_once(opt, reinterpret_cast<const void *>(slam_ba_kernel), lds));
+        hipLaunchKernelGGL(slam_ba_kernel, dim3(1), dim3(kT), lds, s->stream, s->ba->dev, s->d, p);
+    }
     MQS_HIP_CHECK(hipGetLastError());
     return MQS_OK;
 }
