@@ -713,6 +713,9 @@ typedef struct mqs_slam_ba_params {
 int mqs_slam_bundle_adjust(mqs_slam *s, const mqs_slam_ba_params *params, double *report, double *poses_out, int32_t poses_cap);
 /* the landmarks the in-loop adjuster has retired so far (1) / not (0): host uint8 [cap]; *n = landmarks in the map */
 int mqs_slam_read_ba_flags(mqs_slam *s, uint8_t *retired, int cap, int32_t *n);
+/* the odometry edges the adjuster holds (pose indices, measured relative pose12 [cap][12]): what a caller needs to take the adjustment over
+ * beyond MQS_SLAM_BA_MAX_POSES accepted frames; *n = edges held */
+int mqs_slam_read_ba_edges(mqs_slam *s, int32_t *from, int32_t *to, double *meas, int cap, int32_t *n);
 /* profiling hook: phase stamps of the adjuster's last launch (see csrc/slam_ba.hip); the first call switches them on */
 int mqs_debug_slam_ba_stamps(mqs_slam *s, int64_t *out, int cap, int32_t *n);
 int mqs_slam_log_enable(mqs_slam *s, int64_t capacity);

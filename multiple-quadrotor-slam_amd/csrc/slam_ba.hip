@@ -1703,6 +1703,25 @@ int mqs_debug_slam_ba_stamps(mqs_slam *s, int64_t *out, int cap, int32_t *n)
     return MQS_OK;
 }
 
+// The odometry edges the adjuster holds (one per keyframe it stood behind): pose indices and the measured relative pose (camera-to-world
+// pose12 of P_to inv(P_from)), for a caller that takes the adjustment over (slam_device.py beyond MQS_SLAM_BA_MAX_POSES frames).
+int mqs_slam_read_ba_edges(mqs_slam *s, int32_t *from, int32_t *to, double *meas, int cap, int32_t *n)
+{
+    MQS_ARG_CHECK(s != nullptr && n != nullptr && cap >= 0, "handle, n");
+    MQS_ARG_CHECK(s->ba != nullptr, "mqs_slam_log_enable before mqs_slam_start");
+    MQS_HIP_CHECK(hipSetDevice(s->device));
+    *n = s->ba->n_odo;
+    const int m = s->ba->n_odo < cap ? s->ba->n_odo : cap;
+    if (m > 0) {
+        MQS_ARG_CHECK(from && to && meas, "from, to, meas must not be null");
+        MQS_HIP_CHECK(hipStreamSynchronize(s->stream));
+        MQS_HIP_CHECK(hipMemcpy(from, s->ba->dev.odo_from, (size_t)m * 4, hipMemcpyDeviceToHost));
+        MQS_HIP_CHECK(hipMemcpy(to, s->ba->dev.odo_to, (size_t)m * 4, hipMemcpyDeviceToHost));
+        MQS_HIP_CHECK(hipMemcpy(meas, s->ba->dev.odo_meas, (size_t)m * 96, hipMemcpyDeviceToHost));
+    }
+    return MQS_OK;
+}
+
 int mqs_slam_read_ba_flags(mqs_slam *s, uint8_t *retired, int cap, int32_t *n)
 {
     MQS_ARG_CHECK(s != nullptr && n != nullptr && cap >= 0 && (cap == 0 || retired != nullptr), "handle, n, retired");

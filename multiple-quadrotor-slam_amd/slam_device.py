@@ -315,7 +315,25 @@ class DeviceMonoSlam:
                                            uv.ctypes.data_as(_lib.c_f64p), m, ctypes.byref(n)))
         return lm, ps, uv
 
+    BA_DEVICE_MAX_POSES = 256            # include/mqslam.h: MQS_SLAM_BA_MAX_POSES (the resident adjuster stages every camera in LDS)
+
+    def _hand_over_to_the_host_engine(self):
+        """Beyond 256 accepted frames the resident adjuster does not apply: the host-built path takes over where it stands -- the retired
+        landmarks and the odometry edges (measured when their keyframes were taken) come from the device, once."""
+        L = _lib.lib()
+        self._ba_bad = self.retired_landmarks()
+        n = ctypes.c_int32(0)
+        _lib.check(L.mqs_slam_read_ba_edges(self._h, None, None, None, 0, ctypes.byref(n)))
+        m = n.value
+        fr, to, meas = np.zeros(max(m, 1), np.int32), np.zeros(max(m, 1), np.int32), np.zeros((max(m, 1), 12))
+        if m:
+            _lib.check(L.mqs_slam_read_ba_edges(self._h, fr.ctypes.data_as(_lib.c_i32p), to.ctypes.data_as(_lib.c_i32p), meas.ctypes.data_as(_lib.c_f64p), m, ctypes.byref(n)))
+        self._odo = [(int(fr[k]), int(to[k]), meas[k].copy()) for k in range(m)]
+        self.ba_engine = "host"
+
     def _bundle_adjust(self):
+        if self.ba_engine == "device" and len(self._accepted) > self.BA_DEVICE_MAX_POSES:
+            self._hand_over_to_the_host_engine()
         if self.ba_engine == "host":
             return self._bundle_adjust_host()
         if self.ba_check:

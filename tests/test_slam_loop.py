@@ -395,6 +395,30 @@ def test_loop_goes_on_after_finish(gpu, engine):
 
 
 @pytest.mark.gpu
+def test_adjustment_is_handed_to_the_host_engine_beyond_the_resident_adjusters_reach(gpu):
+    """The resident adjuster stages every camera in LDS: 256 accepted frames at most.  Beyond, the host-built engine takes the
+    adjustment over where it stands -- retired landmarks and the odometry edges (measured when their keyframes were taken) come from
+    the device once -- and the run goes on.  Here with the reach set to 25 frames on the 60-frame rendering: same accuracy as either
+    engine alone."""
+    seq, objp, imgp, imgs = _rendered(gpu, 60)
+    gt = seq.centres()
+    slam = gpu.slam_device.DeviceMonoSlam(seq.K, seq.dist, (seq.H, seq.W), seed=1, bundle_adjust="keyframe")
+    slam.BA_DEVICE_MAX_POSES = 25
+    slam.start(imgs[0], objp, imgp)
+    for k in range(1, 60):
+        assert slam.handle_new_frame(imgs[k]) in (1, 2)
+    slam.finish()
+    engines = [r["engine"] for r in slam.ba_reports]
+    assert engines[0] == "device" and engines[-1] == "host" and slam.ba_engine == "host"
+    first_host = engines.index("host")
+    assert all(e == "device" for e in engines[:first_host]) and all(e == "host" for e in engines[first_host:])
+    assert slam.ba_reports[first_host]["poses"] > 25 and len(slam._odo) == len(slam.keyframes) - 1       # every keyframe's edge, device's and host's
+    c = np.array([-P[:, :3].T @ P[:, 3] for P in slam.poses])
+    assert float(np.sqrt(np.mean(np.sum((c - gt) ** 2, axis=1)))) < 0.0057
+    slam.close()
+
+
+@pytest.mark.gpu
 def test_resident_adjuster_refuses_what_it_cannot_hold(gpu):
     """Errors of `mqs_slam_bundle_adjust`, none of them silent: a log that overflowed (round 4 clamped the count and adjusted a
     problem whose newest frames had no observations), bad parameters, a handle without a log."""
