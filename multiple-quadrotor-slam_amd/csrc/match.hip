@@ -155,6 +155,9 @@ using float16v = __attribute__((ext_vector_type(16))) float;
 #ifndef MQS_MATCH_F4_REJECT16
 #define MQS_MATCH_F4_REJECT16 0        // A/B: early reject per accumulator (16 values) instead of per four values (group_step)
 #endif
+#ifndef MQS_MATCH_F16_GROUP
+#define MQS_MATCH_F16_GROUP 1          // A/B: query tiles per train-fragment read on the fp16 path (group_step when > 1)
+#endif
 #ifndef MQS_MATCH_F4_GROUP
 #define MQS_MATCH_F4_GROUP 2
 #endif
@@ -228,7 +231,7 @@ struct F16Path {
     // 2560, windows of 128 tiles, tile and row both in the start value -- removes the v_or3 but measured the same 1.342 ms on the
     // same box: at 3 vector instructions per MFMA the fp16 kernel is not bound by vector issue.)
     static constexpr bool kPrune = MQS_MATCH_PRUNE_F16 != 0;
-    static constexpr int kGroup = 1;
+    static constexpr int kGroup = MQS_MATCH_F16_GROUP;
     static constexpr int kStageRowsMax = MQS_MATCH_STAGE_ROWS;
     // smallest key a value at distance part >= d can have (positive floats order like their bit patterns)
     static __device__ __forceinline__ unsigned key_floor(float d) { return __float_as_uint(d); }

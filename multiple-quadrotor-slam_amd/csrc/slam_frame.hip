@@ -183,6 +183,108 @@ __device__ void jacobi9(double *A, double *V, int lane)
     }
 }
 
+// The same null vector by inverse iteration, every lane for itself (uniform control flow, no LDS traffic beyond reading A): LDL^T of
+// A (positive semi-definite; the last pivot kept away from zero), a few plain steps from L^-T e_8, then -- the homography fits a
+// non-planar scene badly and the two smallest eigenvalues may lie within a factor of two -- Rayleigh-quotient shifts (A - mu (1 - 2^-10) I
+// factored again, two steps per shift).  Settled = the direction changes by less than 1e-11 between two steps, which at the shifted
+// phase's rate bounds the error near 1e-14.  Returns false (clustered smallest eigenvalues, a leading pivot that is not positive):
+// the caller falls back to jacobi9.  2-5 us where the Jacobi sweeps take 26 (phase stamps of frame_decide_kernel, round 5).
+struct Ldlt9 { double l[36]; double inv[9]; bool ok; };           // l: unit lower factor, row-major over the strict lower triangle
+
+__device__ __forceinline__ constexpr int ltri(int i, int j) { return i * (i - 1) / 2 + j; }      // i > j
+
+__device__ __forceinline__ void ldlt9_shifted(const double *A, double shift, double tiny, Ldlt9 &f)
+{
+    double t[36];                                                  // t(i, q) = l(i, q) d_q
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        double dj = A[j * 9 + j] - shift;
+#pragma unroll
+        for (int q = 0; q < j; ++q) dj = fma(-f.l[ltri(j, q)], t[ltri(j, q)], dj);
+        if (j < 8) ok = ok && (dj > 0.0);
+        else if (!(fabs(dj) > tiny)) dj = tiny;                    // exact data: the smallest eigenvalue is zero to rounding
+        const double ij = mqs::rcp(dj);
+        f.inv[j] = ij;
+#pragma unroll
+        for (int i = j + 1; i < 9; ++i) {
+            double a = A[i * 9 + j];
+#pragma unroll
+            for (int q = 0; q < j; ++q) a = fma(-f.l[ltri(i, q)], t[ltri(j, q)], a);
+            t[ltri(i, j)] = a;
+            f.l[ltri(i, j)] = a * ij;
+        }
+    }
+    f.ok = ok;
+}
+
+// one step v <- (L D L^T)^-1 v on the power-of-two normalised iterate; true when the direction has settled
+__device__ __forceinline__ bool invit9_step(const Ldlt9 &f, double (&v)[9])
+{
+    double m = 0.0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) m = fmax(m, fabs(v[i]));
+    const double sc = ldexp(1.0, -ilogb(m));
+    double p[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { v[i] *= sc; p[i] = v[i]; }
+#pragma unroll
+    for (int i = 1; i < 9; ++i)
+#pragma unroll
+        for (int q = 0; q < i; ++q) v[i] = fma(-f.l[ltri(i, q)], v[q], v[i]);
+#pragma unroll
+    for (int i = 8; i >= 0; --i) {
+        double a = v[i] * f.inv[i];
+#pragma unroll
+        for (int q = i + 1; q < 9; ++q) a = fma(-f.l[ltri(q, i)], v[q], a);
+        v[i] = a;
+    }
+    double pp = 0.0, vp = 0.0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { pp = fma(p[i], p[i], pp); vp = fma(v[i], p[i], vp); }
+    const double a = vp * mqs::rcp(pp);
+    double err = 0.0, mag = 0.0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { err = fmax(err, fabs(fma(-a, p[i], v[i]))); mag = fmax(mag, fabs(v[i])); }
+    return err <= 1e-11 * mag;
+}
+
+__device__ bool null_vector9_invit(const double *A /*LDS [9][9]*/, double (&v)[9])
+{
+    double tr = 0.0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) tr += A[i * 9 + i];
+    const double tiny = 1e-30 * tr;
+    Ldlt9 f;
+    ldlt9_shifted(A, 0.0, tiny, f);
+    if (!f.ok) return false;
+    // first iterate: the direction of A^-1 e_8 = L^-T e_8 / d_8
+#pragma unroll
+    for (int i = 8; i >= 0; --i) {
+        double a = (i == 8) ? 1.0 : 0.0;
+#pragma unroll
+        for (int q = i + 1; q < 9; ++q) a = fma(-f.l[ltri(q, i)], v[q], a);
+        v[i] = a;
+    }
+    bool done = false;
+    for (int it = 0; it < 3 && !done; ++it) done = invit9_step(f, v);
+    for (int round = 0; round < 4 && !done; ++round) {
+        double vv = 0.0, vav = 0.0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            double w = 0.0;
+#pragma unroll
+            for (int j = 0; j < 9; ++j) w = fma(A[i * 9 + j], v[j], w);
+            vv = fma(v[i], v[i], vv); vav = fma(v[i], w, vav);
+        }
+        const double mu = vav * mqs::rcp(vv);
+        ldlt9_shifted(A, mu * (1.0 - 0x1p-10), tiny, f);
+        if (!f.ok) return false;
+        for (int it = 0; it < 2 && !done; ++it) done = invit9_step(f, v);
+    }
+    return done;
+}
+
 // eigenvalues of a symmetric 3 x 3 (a: 9 doubles, destroyed), single thread
 __device__ void jacobi3(double *a, double *w)
 {
@@ -351,8 +453,18 @@ __device__ __forceinline__ double block_sum(double v, int tid, double *sRed /*[4
 // ---------------------------------------------------------------------------------------------------------------------
 // after the pose: gates (slam2.py:461-468, 493-497), commit of the kept tracks (:499-522), keyframe test (:43-59)
 // ---------------------------------------------------------------------------------------------------------------------
+// A/B builds only (-DMQS_DECIDE_STAMPS): the kernel's phases in 100 MHz ticks over the keyframe-pose slots of the result block
+// (tools/probes/decide_phases.py reads them behind frames that are no keyframes)
+#ifdef MQS_DECIDE_STAMPS
+#define MQS_DSTAMP(i) do { if (tid == 0) d.res[R_KF_POSE + (i)] = (double)(long long)(wall_clock64() - dst0); } while (0)
+#else
+#define MQS_DSTAMP(i) do { } while (0)
+#endif
 __global__ __launch_bounds__(256) void frame_decide_kernel(SlamDev d, SlamParams p)
 {
+#ifdef MQS_DECIDE_STAMPS
+    const unsigned long long dst0 = wall_clock64();
+#endif
     __shared__ int sWave[4];
     __shared__ double sRed[4];
     __shared__ uint8_t sInl[kMaxTracks];
@@ -385,6 +497,7 @@ __global__ __launch_bounds__(256) void frame_decide_kernel(SlamDev d, SlamParams
         if (reason) { d.res[R_DECISION] = 0.0; d.res[R_REASON] = (double)reason; }
     }
     if (reason) return;
+    MQS_DSTAMP(0);
 
     // commit: inlier landmark tracks and the free tracks stay, in order; the keyframe step's two point sets beside them
     for (int k = tid; k < n_keep; k += 256) sInl[k] = 1;
@@ -431,6 +544,7 @@ __global__ __launch_bounds__(256) void frame_decide_kernel(SlamDev d, SlamParams
     if (tid == 0 && d.log_lm) { d.cnt[C_NLOG] = min(nlog0 + n_acc, d.log_cap); if (nlog0 + n_acc > d.log_cap) d.cnt[C_LOG_OVERFLOW] = 1; }
     if (d.traj && tid < 12 && p.pose_index < d.traj_cap) d.traj[12 * (size_t)p.pose_index + tid] = sP[tid];
 
+    MQS_DSTAMP(1);
     // keyframe_test's random sample of the kept tracks (slam2.py:48: np.random.permutation(n)[:max_num_homography_points]): a
     // counter-based hash of (seed, frame, track position) per track, the tracks with the max_homography_points smallest hashes are
     // the sample (a uniformly random subset; ties by position).  The sample is compacted to the front of sU1 / sU2 in track order.
@@ -465,6 +579,7 @@ __global__ __launch_bounds__(256) void frame_decide_kernel(SlamDev d, SlamParams
         }
         n_hom = n_sel;
     }
+    MQS_DSTAMP(2);
     // normalised DLT homography u2 ~ H u1 over the sample
     double ratio = 1.0;
     if (n_acc >= 4) {
@@ -518,13 +633,18 @@ __global__ __launch_bounds__(256) void frame_decide_kernel(SlamDev d, SlamParams
             sA[i * 9 + j] = t; sA[j * 9 + i] = t;
         }
         __syncthreads();
+        MQS_DSTAMP(3);
         if (wave == 0) {
-            jacobi9(sA, sV, lane);
-            if (lane == 0) {
+            double hn[9];
+            if (p.null_vector_jacobi || !null_vector9_invit(sA, hn)) {                          // (wave-uniform: every lane computed the same)
+                jacobi9(sA, sV, lane);
                 int im = 0;
                 for (int i = 1; i < 9; ++i) if (sA[i * 9 + i] < sA[im * 9 + im]) im = i;
-                double hn[9], h[9], t[9];
                 for (int i = 0; i < 9; ++i) hn[i] = sV[i * 9 + im];
+            }
+            MQS_DSTAMP(4);
+            if (lane == 0) {
+                double h[9], t[9];
                 // H = inv(Tb) Hn Ta,  Ta = [s1 0 -s1 c1x; 0 s1 -s1 c1y; 0 0 1],  inv(Tb) = [1/s2 0 c2x; 0 1/s2 c2y; 0 0 1]
                 for (int r = 0; r < 3; ++r) {
                     t[3 * r + 0] = hn[3 * r + 0] * s1;
@@ -541,7 +661,9 @@ __global__ __launch_bounds__(256) void frame_decide_kernel(SlamDev d, SlamParams
             }
             mqs_wave_lds_sync();
             // ... then the refinement of the transfer error (findHomography's second half), the whole wave
+            MQS_DSTAMP(5);
             if (n_acc > 4 && p.homography_refine) homography_refine_wave(sU1, sU2, n_acc, sH, sA, lane);
+            MQS_DSTAMP(6);
             if (lane == 0) {
                 double h[9];
                 for (int i = 0; i < 9; ++i) h[i] = sH[i];
@@ -555,6 +677,7 @@ __global__ __launch_bounds__(256) void frame_decide_kernel(SlamDev d, SlamParams
         }
         __syncthreads();
         ratio = sRed[0];
+        MQS_DSTAMP(7);
     }
     if (tid == 0) {
         const bool key = n_acc >= 4 && ratio > p.homography_threshold;
@@ -797,8 +920,9 @@ int mqs_slam_create(int device, int W, int H, const double *intr, int target_key
     s->started = false;
     s->accepted = 0; s->base_pose = 0; s->log_arena = nullptr; s->re_arena = nullptr; s->ba = nullptr; s->land_ub = 0; s->key_pose = 0;
     s->p = SlamParams{W, H, target_keypoints, max_landmarks, coverage_radius, quality_level,
-                      12.0, 0.5, 2.0, 0.33, 1.04, 0.0, (unsigned long long)seed, 1, 0};  // slam2.py:1070-1098; keyframe test on ALL tracks
+                      12.0, 0.5, 2.0, 0.33, 1.04, 0.0, (unsigned long long)seed, 1, 0, 0};  // slam2.py:1070-1098; keyframe test on ALL tracks
     if (const char *e = getenv("MQS_SLAM_HOMOGRAPHY_REFINE")) s->p.homography_refine = e[0] != '0';        // A/B: 0 = the DLT alone
+    if (const char *e = getenv("MQS_SLAM_NULL_VECTOR_JACOBI")) s->p.null_vector_jacobi = e[0] != '0';      // A/B: 1 = the Jacobi sweeps always
     s->ws_lk_bytes = mqs_lk_workspace_bytes(W, H, 3);
     s->ws_gftt_bytes = mqs_gftt_workspace_bytes(W, H);
     const int64_t ws_pnp_bytes = mqs_pnp_workspace_bytes(kMaxTracks, kHyp);

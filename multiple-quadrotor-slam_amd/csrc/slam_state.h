@@ -63,6 +63,7 @@ struct SlamParams {
     double second_pass_screen_px;   // 0 (default): slam2.py's flow; > 0: mqs_slam_set_second_pass_screen
     unsigned long long seed;
     int homography_refine;          // 1 (default): DLT + the LM refinement, as cv2.findHomography(method = 0); 0: the DLT alone (A/B)
+    int null_vector_jacobi;         // 0 (default): the DLT's null vector by inverse iteration, Jacobi sweeps only when that does not settle; 1: always Jacobi (A/B, tests)
     int max_homography_points;      // keyframe_test's random sample (slam2.py:48; the reference: max(4, target / 4), :1088-1089); 0 = all tracks (default)
     int pose_index, base_pose_index; // index this frame gets among the ACCEPTED frames if it is accepted; that of the base keyframe
 };

@@ -306,8 +306,9 @@ def test_keyframe_test_ratio_of_the_device_loop_is_find_homography_s(seq, gpu, m
     uv, vis = run_icl_nuim.start_points(K, (H, W), seq["init_pose"], seq["init_points"])
     imgs = [torch.from_numpy(np.ascontiguousarray(f)).cuda() for f in seq["frames"][:80]]
 
-    def ratios(refine):
+    def ratios(refine, jacobi=False):
         monkeypatch.setenv("MQS_SLAM_HOMOGRAPHY_REFINE", "1" if refine else "0")
+        monkeypatch.setenv("MQS_SLAM_NULL_VECTOR_JACOBI", "1" if jacobi else "0")
         s = gpu.slam_device.DeviceMonoSlam(K, dist, (H, W), seed=0)
         s.start(imgs[0], seq["init_points"][vis], uv[vis])
         out = []
@@ -338,6 +339,10 @@ def test_keyframe_test_ratio_of_the_device_loop_is_find_homography_s(seq, gpu, m
     got0 = np.array([r[1] for r in without if r[1] is not None])
     dlt0 = np.array([r[2] for r in without if r[1] is not None])
     assert np.abs(got0 - dlt0).max() < 1e-9
+    # the DLT's null vector: inverse iteration (the default) against the Jacobi sweeps it falls back to when it does not settle
+    sweeps = ratios(False, jacobi=True)
+    assert [r[0] for r in sweeps if r[1] is not None] == [r[0] for r in without if r[1] is not None]
+    assert np.abs(np.array([r[1] for r in sweeps if r[1] is not None]) - got0).max() < 1e-9
 
 
 @pytest.mark.gpu
