@@ -460,7 +460,7 @@ __device__ __forceinline__ double block_sum(double v, int tid, double *sRed /*[4
 #else
 #define MQS_DSTAMP(i) do { } while (0)
 #endif
-__global__ __launch_bounds__(256) void frame_decide_kernel(SlamDev d, SlamParams p)
+__device__ __forceinline__ void frame_decide_body(const SlamDev &d, const SlamParams &p)
 {
 #ifdef MQS_DECIDE_STAMPS
     const unsigned long long dst0 = wall_clock64();
@@ -688,6 +688,20 @@ __global__ __launch_bounds__(256) void frame_decide_kernel(SlamDev d, SlamParams
         d.cnt[C_KF_PENDING] = key ? 1 : 0;
     }
     if (tid < 12) d.res[R_POSE + tid] = sP[tid];
+}
+
+// The decision, then the frame's result block straight into the caller's pinned host memory (every return path of the body is uniform
+// over the workgroup): the previous keyframe's report rides along and its flag is cleared for the next one -- what a device-to-host
+// copy and a fill launch per frame did before (5 + 4 us of the frame's ~230).
+__global__ __launch_bounds__(256) void frame_decide_kernel(SlamDev d, SlamParams p)
+{
+    frame_decide_body(d, p);
+    __syncthreads();
+    const int tid = threadIdx.x;
+    if (tid < kRes) {
+        d.res_out[tid] = d.res[tid];
+        if (tid == R_KF_VALID) d.res[R_KF_VALID] = 0.0;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -956,6 +970,7 @@ int mqs_slam_create(int device, int W, int H, const double *intr, int target_key
     s->ws_lk = a + o_wl; s->ws_gftt = a + o_wg; s->ws_pnp = a + o_wp;
     e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipHostMalloc((void **)&s->res_host, kRes * 8, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&d.res_out, s->res_host, 0);
     if (e == hipSuccess) e = hipMemsetAsync(s->arena, 0, o_wl, s->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d.intr, intr, 72, hipMemcpyHostToDevice, s->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
@@ -1143,9 +1158,7 @@ int mqs_slam_track(mqs_slam *s, const uint8_t *prev_img_dev, const uint8_t *img_
     if (rc != MQS_OK) return rc;
     hipLaunchKernelGGL(frame_decide_kernel, dim3(1), dim3(256), 0, s->stream, d, s->p);
     MQS_HIP_CHECK(hipGetLastError());
-    MQS_HIP_CHECK(hipMemcpyAsync(s->res_host, d.res, kRes * 8, hipMemcpyDeviceToHost, s->stream));
-    // the previous keyframe's report has been copied with this block: clear its flag on the device for the next one
-    MQS_HIP_CHECK(hipMemsetAsync(d.res + R_KF_VALID, 0, 8, s->stream));
+    // (the decision kernel has written the result block into s->res_host and cleared the previous keyframe's flag on the device)
     MQS_HIP_CHECK(hipStreamSynchronize(s->stream));
     memcpy(result, s->res_host, kRes * 8);
     if (result[R_DECISION] >= 1.0) s->accepted += 1;

@@ -41,6 +41,7 @@ struct SlamDev {
     float *gf_xy;
     int32_t *gf_n;
     double *res;
+    double *res_out;                 // the pinned host block the decision kernel leaves a copy of `res` in (no copy / fill launches per frame)
     // the observation log for the bundle adjuster (mqs_slam_log_enable; null: off): what slam2.py's BundleAdjustmentInfoContainer is
     // handed (:519-522, 634-641), as flat device arrays -- (landmark, pose index of the accepted frame, pixel) per observation
     int32_t *log_lm, *log_pose;
