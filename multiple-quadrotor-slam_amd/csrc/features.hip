@@ -569,6 +569,141 @@ __global__ __launch_bounds__(kBlock) void lk_pad_levels_kernel(LkPadJob job)
     job.dIp[l][yp * P + xp] = inside ? job.dI[l][y * W + x] : short2{0, 0};
 }
 
+// The same pyramid -- every level of both images, the derivative images of the previous one, the border-extended copies -- in ONE
+// launch (round 5; the per-level kernels above: four dependent launches + the padding launch, 27 us of a VGA frame's ~210, nearly all
+// of it launch latency).  A workgroup owns an 8 x 8 tile of the top level and the tiles under it (16 x 16, 32 x 32, 64 x 64 at level
+// 0) and computes the whole chain for them in LDS: level l's patch carries the halo the levels above need, h_top = 1 (the Scharr
+// neighbours), h_l = 2 h_(l+1) + 2 (pyrDown's five taps) -- 22 pixels at level 0 of a four-level pyramid, 108 x 108 bytes.  A patch
+// holds IN-IMAGE pixels only; every read reflects its coordinate first (BORDER_REFLECT_101, as the per-level kernels do on the whole
+// image), and a reflected coordinate lies at most two pixels inside the border, inside the patch of the tile that asks (h_l >= 2 below
+// the top level).  Integer arithmetic throughout: bit-identical to the per-level path (tests/test_features.py compares the tracker's
+// outputs of both).  The owner of an in-image pixel also writes the border positions that reflect to it (levels at least 33 pixels
+// wide and high: one reflection, no clamping; smaller pyramids take the per-level path).
+#ifndef MQS_LK_PYRAMID_THREADS
+#define MQS_LK_PYRAMID_THREADS 1024
+#endif
+#ifndef MQS_LK_PYRAMID_TOP_TILE
+#define MQS_LK_PYRAMID_TOP_TILE 8
+#endif
+constexpr int kPyrTopTile = MQS_LK_PYRAMID_TOP_TILE;       // a workgroup's tile of the top level
+constexpr int kPyrThreads = MQS_LK_PYRAMID_THREADS;       // sixteen wavefronts on a tile's chain: with four the launch took as long as the five it replaces (28 us)
+template <int LTOP>
+struct PyrGeom {
+    static constexpr int halo(int l) { return l >= LTOP ? 1 : 2 * halo(l + 1) + 2; }
+    static constexpr int tile(int l) { return kPyrTopTile << (LTOP - l); }
+    static constexpr int side(int l) { return tile(l) + 2 * halo(l); }
+    static constexpr int offset(int l) { return l == 0 ? 0 : offset(l - 1) + (side(l - 1) * side(l - 1) + 15) / 16 * 16; }
+    static constexpr int total = offset(LTOP) + side(LTOP) * side(LTOP);
+};
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+template <int LTOP, int L>
+__device__ __forceinline__ void pyr_down_in_lds(const LkPadJob &job, uint8_t *sP, int tx, int ty, int tid)
+{
+    using G = PyrGeom<LTOP>;
+    constexpr int S = G::side(L), Hh = G::halo(L), T = G::tile(L), Sp = G::side(L - 1), Hp = G::halo(L - 1), Tp = G::tile(L - 1);
+    const int W = job.W[L], H = job.H[L], Wp = job.W[L - 1], Hpv = job.H[L - 1];
+    const int x0 = tx * T - Hh, y0 = ty * T - Hh, xp0 = tx * Tp - Hp, yp0 = ty * Tp - Hp;
+    constexpr int kOffSrc = G::offset(L - 1), kOffDst = G::offset(L);
+    const uint8_t *src = sP + kOffSrc;
+    uint8_t *dst = sP + kOffDst;
+    const int k5[5] = {1, 4, 6, 4, 1};
+    for (int e = tid; e < S * S; e += kPyrThreads) {
+        const int py = e / S, px = e - py * S, cx = x0 + px, cy = y0 + py;
+        if (cx < 0 || cx >= W || cy < 0 || cy >= H) continue;             // never read
+        int acc = 0, xi[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) xi[i] = clampi(reflect101(2 * cx + i - 2, Wp) - xp0, 0, Sp - 1);
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const uint8_t *row = src + clampi(reflect101(2 * cy + j - 2, Hpv) - yp0, 0, Sp - 1) * Sp;
+            int r = 0;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) r += k5[i] * (int)row[xi[i]];
+            acc += k5[j] * r;
+        }
+        dst[e] = (uint8_t)((acc + 128) >> 8);
+    }
+}
+
+template <int LTOP, int L>
+__device__ __forceinline__ void pyr_store_level(const LkPadJob &job, const uint8_t *sP, int tx, int ty, int tid, bool prev)
+{
+    using G = PyrGeom<LTOP>;
+    constexpr int S = G::side(L), Hh = G::halo(L), T = G::tile(L);
+    const int W = job.W[L], H = job.H[L], P = W + 2 * kLkBorder;
+    const int x0 = tx * T - Hh, y0 = ty * T - Hh;
+    constexpr int kOff = G::offset(L);
+    const uint8_t *lev = sP + kOff;
+    uint8_t *out = prev ? job.Ip[L] : job.Jp[L];
+    short2 *dout = job.dIp[L];
+    for (int e = tid; e < T * T; e += kPyrThreads) {
+        const int ly = e / T, lx = e - ly * T, x = tx * T + lx, y = ty * T + ly;
+        if (x >= W || y >= H) continue;
+        const uint8_t v = lev[(ly + Hh) * S + lx + Hh];
+        short2 d = make_short2(0, 0);
+        if (prev) {
+            const int xm = reflect101(x - 1, W) - x0, xq = reflect101(x + 1, W) - x0, xc = x - x0;
+            const uint8_t *rm = lev + (reflect101(y - 1, H) - y0) * S, *rc = lev + (y - y0) * S, *rp = lev + (reflect101(y + 1, H) - y0) * S;
+            const int a = rm[xm], b = rm[xc], c = rm[xq], ee = rc[xm], f = rc[xq], g = rp[xm], h = rp[xc], k = rp[xq];
+            d = make_short2((short)(3 * (c - a) + 10 * (f - ee) + 3 * (k - g)), (short)(3 * (g - a) + 10 * (h - b) + 3 * (k - c)));
+        }
+        // the padded positions this pixel fills: its own, and the border's that reflect to it
+        int xs[3], ys[3], nx = 1, ny = 1;
+        xs[0] = x + kLkBorder; ys[0] = y + kLkBorder;
+        if (x >= 1 && x <= kLkBorder) xs[nx++] = kLkBorder - x;
+        if (x >= W - 1 - kLkBorder && x <= W - 2) xs[nx++] = kLkBorder + 2 * (W - 1) - x;
+        if (y >= 1 && y <= kLkBorder) ys[ny++] = kLkBorder - y;
+        if (y >= H - 1 - kLkBorder && y <= H - 2) ys[ny++] = kLkBorder + 2 * (H - 1) - y;
+        for (int yi = 0; yi < ny; ++yi)
+            for (int xi2 = 0; xi2 < nx; ++xi2) {
+                const int pos = ys[yi] * P + xs[xi2];
+                out[pos] = v;
+                if (prev) dout[pos] = (yi == 0 && xi2 == 0) ? d : make_short2(0, 0);
+            }
+    }
+}
+
+template <int LTOP>
+__global__ __launch_bounds__(kPyrThreads) void lk_pyramid_kernel(LkPadJob job)
+{
+    using G = PyrGeom<LTOP>;
+    __shared__ __attribute__((aligned(16))) uint8_t sP[G::total];
+    const int tid = threadIdx.x, tx = blockIdx.x, ty = blockIdx.y;
+    const bool prev = blockIdx.z == 0;
+    {
+        constexpr int S = G::side(0), Hh = G::halo(0), T = G::tile(0), kLoads = (S * S + kPyrThreads - 1) / kPyrThreads;
+        const uint8_t *src = prev ? job.I[0] : job.J[0];
+        const int W = job.W[0], H = job.H[0], x0 = tx * T - Hh, y0 = ty * T - Hh;
+        // every load of the patch issued before the first is waited for (unconditional, the index clamped: written as a loop of
+        // load + store the compiler waits for each byte's round trip in turn -- twelve of them were 12 us of the launch's 18)
+        uint8_t v[kLoads];
+#pragma unroll
+        for (int u = 0; u < kLoads; ++u) {
+            int e = tid + u * kPyrThreads;
+            e = e < S * S ? e : S * S - 1;
+            const int py = e / S, px = e - py * S;
+            v[u] = src[clampi(reflect101(y0 + py, H), 0, H - 1) * W + clampi(reflect101(x0 + px, W), 0, W - 1)];
+        }
+#pragma unroll
+        for (int u = 0; u < kLoads; ++u) {
+            const int e = tid + u * kPyrThreads;
+            if (e < S * S) sP[e] = v[u];
+        }
+    }
+    __syncthreads();
+    if constexpr (LTOP >= 1) { pyr_down_in_lds<LTOP, 1>(job, sP, tx, ty, tid); __syncthreads(); }
+    if constexpr (LTOP >= 2) { pyr_down_in_lds<LTOP, 2>(job, sP, tx, ty, tid); __syncthreads(); }
+    if constexpr (LTOP >= 3) { pyr_down_in_lds<LTOP, 3>(job, sP, tx, ty, tid); __syncthreads(); }
+    pyr_store_level<LTOP, 0>(job, sP, tx, ty, tid, prev);
+    if constexpr (LTOP >= 1) pyr_store_level<LTOP, 1>(job, sP, tx, ty, tid, prev);
+    if constexpr (LTOP >= 2) pyr_store_level<LTOP, 2>(job, sP, tx, ty, tid, prev);
+    if constexpr (LTOP >= 3) pyr_store_level<LTOP, 3>(job, sP, tx, ty, tid, prev);
+    // (measured and not kept: a level's stores issued before the next level is computed, + 0.8 us; a reflection-free path for the
+    // tiles off the rim, + 0.3 us; 4 x 4 top tiles, + 2.3 us; 512 / 256 threads, + 3 / + 11 us.  An empty launch of this shape: 4.3 us)
+}
+
 // wave sums with the butterfly's pairs, without its ds_bpermute round trips (a quarter of a Lucas-Kanade iteration): wave_reduce.h
 __device__ __forceinline__ void wave_sum2_d(double x, double y, double &sx, double &sy) { mqs::wave::sum2(x, y, sx, sy); }
 __device__ __forceinline__ double wave_sum_d(double v) { return mqs::wave::sum1(v); }
@@ -974,11 +1109,13 @@ int mqs_lk_launch(const uint8_t *prev_img, const uint8_t *next_img, int W, int H
     int w = W, h = H;
     L.levels = 0;
     job.I[0] = prev_img; job.J[0] = next_img;
+    uint8_t *down_i[kMaxLevels] = {}, *down_j[kMaxLevels] = {};
+    short2 *deriv[kMaxLevels] = {};
     for (int l = 0; l <= max_level; ++l) {
         L.W[l] = w; L.H[l] = h; L.P[l] = w + 2 * kLkBorder;
         job.W[l] = w; job.H[l] = h;
         short2 *d = reinterpret_cast<short2 *>(wsp); wsp += align_up((size_t)w * h * 4);
-        job.dI[l] = d;
+        job.dI[l] = d; deriv[l] = d;
         {
             const size_t padded = (size_t)(w + 2 * kLkBorder) * (h + 2 * kLkBorder), origin = (size_t)kLkBorder * L.P[l] + kLkBorder;
             job.Ip[l] = reinterpret_cast<uint8_t *>(wsp); wsp += align_up(padded);
@@ -988,21 +1125,31 @@ int mqs_lk_launch(const uint8_t *prev_img, const uint8_t *next_img, int W, int H
         }
         L.levels = l;
         const bool last = l == max_level || w <= 2 || h <= 2;
-        const int wd = (w + 1) / 2, hd = (h + 1) / 2;
-        uint8_t *pi = nullptr, *pj = nullptr;
-        if (!last) {
-            pi = reinterpret_cast<uint8_t *>(wsp); wsp += align_up((size_t)wd * hd);
-            pj = reinterpret_cast<uint8_t *>(wsp); wsp += align_up((size_t)wd * hd);
-            job.I[l + 1] = pi; job.J[l + 1] = pj;
-        }
-        // derivatives of this level and, beside them, both images' next level: one launch
-        dim3 g = grid2d(w, h);
-        g.z = last ? 1 : 3;
-        hipLaunchKernelGGL(pyr_level_kernel, g, dim3(kBlock), 0, stream, job.I[l], job.J[l], w, h, d, pi, pj, wd, hd);
         if (last) break;
+        const int wd = (w + 1) / 2, hd = (h + 1) / 2;
+        down_i[l] = reinterpret_cast<uint8_t *>(wsp); wsp += align_up((size_t)wd * hd);
+        down_j[l] = reinterpret_cast<uint8_t *>(wsp); wsp += align_up((size_t)wd * hd);
+        job.I[l + 1] = down_i[l]; job.J[l + 1] = down_j[l];
         w = wd; h = hd;
     }
-    {
+    // one launch for the whole pyramid where the top level is at least a border wide and high (a VGA frame's four levels: 80 x 60);
+    // MQS_LK_PYRAMID_PER_LEVEL=1 keeps the per-level launches (A/B, tests)
+    const char *per_level = getenv("MQS_LK_PYRAMID_PER_LEVEL");
+    const bool fused = L.levels >= 1 && L.levels <= 3 && L.W[L.levels] > kLkBorder && L.H[L.levels] > kLkBorder && !(per_level && per_level[0] == '1');
+    if (fused) {
+        const dim3 g((unsigned)((L.W[L.levels] + kPyrTopTile - 1) / kPyrTopTile), (unsigned)((L.H[L.levels] + kPyrTopTile - 1) / kPyrTopTile), 2);
+        if (L.levels == 1) hipLaunchKernelGGL(lk_pyramid_kernel<1>, g, dim3(kPyrThreads), 0, stream, job);
+        else if (L.levels == 2) hipLaunchKernelGGL(lk_pyramid_kernel<2>, g, dim3(kPyrThreads), 0, stream, job);
+        else hipLaunchKernelGGL(lk_pyramid_kernel<3>, g, dim3(kPyrThreads), 0, stream, job);
+    } else {
+        for (int l = 0; l <= L.levels; ++l) {
+            // derivatives of this level and, beside them, both images' next level: one launch
+            const bool last = l == L.levels;
+            dim3 g = grid2d(L.W[l], L.H[l]);
+            g.z = last ? 1 : 3;
+            hipLaunchKernelGGL(pyr_level_kernel, g, dim3(kBlock), 0, stream, job.I[l], job.J[l], L.W[l], L.H[l], deriv[l], last ? nullptr : down_i[l],
+                               last ? nullptr : down_j[l], last ? 0 : L.W[l + 1], last ? 0 : L.H[l + 1]);
+        }
         dim3 g = grid2d(W + 2 * kLkBorder, H + 2 * kLkBorder);            // sized for level 0; the other levels use its first part
         g.z = (unsigned)(L.levels + 1);
         hipLaunchKernelGGL(lk_pad_levels_kernel, g, dim3(kBlock), 0, stream, job);

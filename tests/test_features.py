@@ -165,6 +165,28 @@ def test_gpu_lk_equals_oracle_and_truth(shape, shift, gpu):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shape,max_level", [((480, 640), 3), ((481, 643), 3), ((531, 777), 3), ((300, 404), 2), ((135, 150), 1)])
+def test_gpu_lk_pyramid_in_one_launch_equals_the_per_level_launches(shape, max_level, gpu, monkeypatch):
+    """The pyramid of both images, the derivative images and the border-extended copies the tracker reads come out of ONE launch where
+    the top level is at least a border (32 pixels) wide and high; MQS_LK_PYRAMID_PER_LEVEL=1 keeps the launch per level + the padding
+    launch.  Integer images: the tracker must return the same bits from both -- features at the image border included (windows that
+    reach into the reflected border), odd sizes at every level."""
+    H, W = shape
+    I = texture(H, W, seed=5, blobs=300 * H * W // (240 * 320))
+    J = texture(H, W, shift=(2.4, -1.3), seed=5, blobs=300 * H * W // (240 * 320))
+    pts = Fn.good_features_to_track(I, 200, 0.01, 8.0)
+    rim = np.array([[x, y] for x in (1.0, 9.5, W / 2, W - 11.0, W - 2.0) for y in (1.0, 8.0, H / 2, H - 9.5, H - 2.0)], np.float32)
+    pts = np.concatenate([pts, rim])
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("MQS_LK_PYRAMID_PER_LEVEL", mode)
+        out[mode] = gpu.features.calcOpticalFlowPyrLK(I, J, pts, maxLevel=max_level)
+    for a, b in zip(out["0"], out["1"]):
+        np.testing.assert_array_equal(a, b)
+    assert out["0"][1].sum() > 50
+
+
+@pytest.mark.gpu
 def test_gpu_detect_then_track_loop(gpu):
     """slam2.py's front-end cycle on rendered frames: detect, track over 5 frames of accumulating motion, top up under
     the coverage mask."""
