@@ -118,19 +118,11 @@ __device__ bool wave_dlt(const Problem &pr, const double *intr, int lane, double
             mqs::cam::undistort_pixel(intr, pr.imgp[2 * i], pr.imgp[2 * i + 1], x, y);
             hom_accumulate((E[0] * dx + E[1] * dy + E[2] * dz) * is, (E[3] * dx + E[4] * dy + E[5] * dz) * is, x, y, hacc);
         }
-        wave_sum_all(hacc, lane, sA);                      // sA is free until hom_assemble fills it
-        double *sb = sA + 64;
-        if (lane == 0) {
-            hom_assemble(hacc, sA, sb);
-            const bool ok = chol_solve_small(sA, sb, 8);
-            sA[0] = ok ? 1.0 : 0.0;
-        }
-        mqs_wave_lds_sync();
-        double hv[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) hv[k] = sb[k];
-        const bool solved = sA[0] != 0.0;
-        __builtin_amdgcn_wave_barrier();
+        wave_sum_all(hacc, lane, sA);
+        // 8 x 8 solve: every lane for itself, the system in registers (chol_solve_fixed)
+        double A8[64], hv[8];
+        hom_assemble(hacc, A8, hv);
+        const bool solved = chol_solve_fixed<8>(A8, hv);
         const bool posed = pose_from_homography(hv, E, c, sigma, P);
         return solved && posed;
     }
@@ -143,20 +135,11 @@ __device__ bool wave_dlt(const Problem &pr, const double *intr, int lane, double
         mqs::cam::undistort_pixel(intr, pr.imgp[2 * i], pr.imgp[2 * i + 1], x, y);
         dlt_accumulate((pr.objp[3 * i] - c[0]) * is, (pr.objp[3 * i + 1] - c[1]) * is, (pr.objp[3 * i + 2] - c[2]) * is, x, y, acc);
     }
-    wave_sum_all(acc, lane, sA);                           // sA is free until dlt_assemble fills it
-    // 11 x 11 solve: serial, one lane, matrix in LDS (dynamic indexing), result broadcast through LDS
-    double *sb = sA + 121;
-    if (lane == 0) {
-        dlt_assemble(acc, sA, sb);
-        const bool ok = chol_solve_small(sA, sb, 11);
-        sA[0] = ok ? 1.0 : 0.0;
-    }
-    mqs_wave_lds_sync();
-    double p[11];
-#pragma unroll
-    for (int k = 0; k < 11; ++k) p[k] = sb[k];
-    const bool solved = sA[0] != 0.0;
-    __builtin_amdgcn_wave_barrier();
+    wave_sum_all(acc, lane, sA);
+    // 11 x 11 solve: every lane for itself, the system in registers (chol_solve_fixed)
+    double A11[121], p[11];
+    dlt_assemble(acc, A11, p);
+    const bool solved = chol_solve_fixed<11>(A11, p);
     const bool posed = pose_from_dlt(p, c, sigma, P);
     return solved && posed;
 }

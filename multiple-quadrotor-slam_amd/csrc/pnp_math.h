@@ -239,23 +239,32 @@ MQS_HD void dlt_accumulate(double X, double Y, double Z, double x, double y, dou
 // Expands the sums into the dense 11 x 11 system (A row-major, b).
 MQS_HD void dlt_assemble(const double *acc, double *A, double *b)
 {
+#pragma unroll
     for (int k = 0; k < 121; ++k) A[k] = 0.0;
     int s = 0;
+#pragma unroll
     for (int i = 0; i < 4; ++i)
+#pragma unroll
         for (int j = i; j < 4; ++j) {
             A[i * 11 + j] = A[j * 11 + i] = acc[s];
             A[(4 + i) * 11 + 4 + j] = A[(4 + j) * 11 + 4 + i] = acc[s];
             ++s;
         }
+#pragma unroll
     for (int i = 0; i < 4; ++i)
+#pragma unroll
         for (int j = 0; j < 3; ++j) {
             A[i * 11 + 8 + j] = A[(8 + j) * 11 + i] = -acc[10 + 3 * i + j];
             A[(4 + i) * 11 + 8 + j] = A[(8 + j) * 11 + 4 + i] = -acc[22 + 3 * i + j];
         }
     s = 34;
+#pragma unroll
     for (int i = 0; i < 3; ++i)
+#pragma unroll
         for (int j = i; j < 3; ++j) { A[(8 + i) * 11 + 8 + j] = A[(8 + j) * 11 + 8 + i] = acc[s]; ++s; }
+#pragma unroll
     for (int i = 0; i < 4; ++i) { b[i] = acc[40 + i]; b[4 + i] = acc[44 + i]; }
+#pragma unroll
     for (int i = 0; i < 3; ++i) b[8 + i] = -acc[48 + i];
 }
 
@@ -284,6 +293,47 @@ MQS_HD bool chol_solve_small(double *A, double *b, int n)
         double v = b[i];
         for (int m = i + 1; m < n; ++m) v -= A[m * n + i] * b[m];
         b[i] = v * A[i * n + i];
+    }
+    return ok;
+}
+
+// The same solve for a size known at compile time, every loop unrolled: on the device the matrix then lives in registers (static
+// indices), and every lane of a wavefront solves for itself -- the round-4 form handed the system to ONE lane that walked it in
+// LDS with dynamic indices, a chain of dependent LDS round trips (most of a RANSAC hypothesis' 28 us).  Same operations in the
+// same order as chol_solve_small: the same bits.
+template <int N>
+MQS_HD bool chol_solve_fixed(double (&A)[N * N], double (&b)[N])
+{
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        double dkk = A[k * N + k];
+#pragma unroll
+        for (int m = 0; m < k; ++m) dkk -= A[k * N + m] * A[k * N + m];
+        ok = ok && (dkk > 0.0);
+        const double r = 1.0 / sqrt(dkk > 0.0 ? dkk : 1.0);
+        A[k * N + k] = r;
+#pragma unroll
+        for (int i = k + 1; i < N; ++i) {
+            double v = A[i * N + k];
+#pragma unroll
+            for (int m = 0; m < k; ++m) v -= A[i * N + m] * A[k * N + m];
+            A[i * N + k] = v * r;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        double v = b[i];
+#pragma unroll
+        for (int m = 0; m < i; ++m) v -= A[i * N + m] * b[m];
+        b[i] = v * A[i * N + i];
+    }
+#pragma unroll
+    for (int i = N - 1; i >= 0; --i) {
+        double v = b[i];
+#pragma unroll
+        for (int m = i + 1; m < N; ++m) v -= A[m * N + i] * b[m];
+        b[i] = v * A[i * N + i];
     }
     return ok;
 }
@@ -358,13 +408,22 @@ MQS_HD void sym3_eigen(const double *S, double *w, double *V)
                 }
             }
     }
-    int o[3] = {0, 1, 2};
-    if (a[o[0]][o[0]] < a[o[1]][o[1]]) { const int t = o[0]; o[0] = o[1]; o[1] = t; }
-    if (a[o[1]][o[1]] < a[o[2]][o[2]]) { const int t = o[1]; o[1] = o[2]; o[2] = t; }
-    if (a[o[0]][o[0]] < a[o[1]][o[1]]) { const int t = o[0]; o[0] = o[1]; o[1] = t; }
+    // eigenvalues in descending order, the eigenvectors with them: three compare-and-swaps on values (static indices: registers on
+    // the device; sorting an index array put `a` and `v` into scratch memory, a dependent round trip per comparison)
+    double d[3] = {a[0][0], a[1][1], a[2][2]};
+    double c[3][3] = {{v[0][0], v[1][0], v[2][0]}, {v[0][1], v[1][1], v[2][1]}, {v[0][2], v[1][2], v[2][2]}};
+#define MQS_SWAP_IF_LESS(i, j)                                                                   \
+    if (d[i] < d[j]) {                                                                           \
+        const double td = d[i]; d[i] = d[j]; d[j] = td;                                          \
+        for (int k = 0; k < 3; ++k) { const double tc = c[i][k]; c[i][k] = c[j][k]; c[j][k] = tc; } \
+    }
+    MQS_SWAP_IF_LESS(0, 1)
+    MQS_SWAP_IF_LESS(1, 2)
+    MQS_SWAP_IF_LESS(0, 1)
+#undef MQS_SWAP_IF_LESS
     for (int k = 0; k < 3; ++k) {
-        w[k] = a[o[k]][o[k]];
-        for (int i = 0; i < 3; ++i) V[3 * k + i] = v[i][o[k]];
+        w[k] = d[k];
+        for (int i = 0; i < 3; ++i) V[3 * k + i] = c[k][i];
     }
     // right-handed: third axis = first x second
     V[6] = V[1] * V[5] - V[2] * V[4];
@@ -407,20 +466,26 @@ MQS_HD void hom_accumulate(double a, double b, double x, double y, double *acc)
 
 MQS_HD void hom_assemble(const double *acc, double *A, double *rhs)
 {
+#pragma unroll
     for (int k = 0; k < 64; ++k) A[k] = 0.0;
     int s = 0;
+#pragma unroll
     for (int i = 0; i < 3; ++i)
+#pragma unroll
         for (int j = i; j < 3; ++j) {
             A[i * 8 + j] = A[j * 8 + i] = acc[s];
             A[(3 + i) * 8 + 3 + j] = A[(3 + j) * 8 + 3 + i] = acc[s];
             ++s;
         }
+#pragma unroll
     for (int i = 0; i < 3; ++i)
+#pragma unroll
         for (int j = 0; j < 2; ++j) {
             A[i * 8 + 6 + j] = A[(6 + j) * 8 + i] = -acc[6 + 2 * i + j];
             A[(3 + i) * 8 + 6 + j] = A[(6 + j) * 8 + 3 + i] = -acc[12 + 2 * i + j];
         }
     A[6 * 8 + 6] = acc[18]; A[6 * 8 + 7] = A[7 * 8 + 6] = acc[19]; A[7 * 8 + 7] = acc[20];
+#pragma unroll
     for (int i = 0; i < 3; ++i) { rhs[i] = acc[21 + i]; rhs[3 + i] = acc[24 + i]; }
     rhs[6] = -acc[27]; rhs[7] = -acc[28];
 }
