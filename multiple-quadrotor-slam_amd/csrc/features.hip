@@ -716,7 +716,12 @@ __device__ __forceinline__ float bilinear_u8(const uint8_t *__restrict__ a, int 
 
 // NW wavefronts per feature (round 5: four): a feature's track is a serial chain of ~80 iterations, each a window sum and a 2 x 2 solve; with
 // one wavefront the chain's length IS the launch's (300 features on 256 CUs: one wave per CU, 73 us); four wavefronts take a quarter of the
-// window each and meet in LDS once per sum (parity-alternating slots: one workgroup barrier per sum).
+// window each and meet in LDS once per sum (parity-alternating slots: one workgroup barrier per sum).  Two wavefronts: 55.8 us, four: 47.1,
+// eight: 47.4 -- beyond four the chain is the iteration's own dependent instructions (weights, bilinear taps, the wave sum, the 2 x 2 solve).
+#ifndef MQS_LK_WAVES
+#define MQS_LK_WAVES 4
+#endif
+constexpr int kLkWaves = MQS_LK_WAVES;
 template <int NW>
 __device__ __forceinline__ void lk_block_sum2(double x, double y, double &sx, double &sy, double *sRed, int &slot, int wave, int lane)
 {
@@ -1155,7 +1160,7 @@ int mqs_lk_launch(const uint8_t *prev_img, const uint8_t *next_img, int W, int H
         hipLaunchKernelGGL(lk_pad_levels_kernel, g, dim3(kBlock), 0, stream, job);
     }
     if (n > 0)
-        hipLaunchKernelGGL(lk_kernel<4>, dim3(n), dim3(256), 0, stream, L, prev_pts, n, n_dev, win_w, win_h, max_iter, (float)eps,
+        hipLaunchKernelGGL(lk_kernel<kLkWaves>, dim3(n), dim3(64 * kLkWaves), 0, stream, L, prev_pts, n, n_dev, win_w, win_h, max_iter, (float)eps,
                            (float)min_eig_threshold, next_pts, status, err);
     MQS_HIP_CHECK(hipGetLastError());
     return MQS_OK;
