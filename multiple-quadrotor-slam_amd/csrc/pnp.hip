@@ -229,19 +229,71 @@ __global__ __launch_bounds__(kWave) void pnp_hypothesis_kernel(const double *__r
     if (lane == 0) counts[h] = count;
 }
 
-// Picks the hypothesis with the most inliers (lowest index on ties), marks and compacts its inliers.
-// out_sel: [0] best hypothesis (-1: none valid), [1] inlier count; ptr2 = {0, inlier count}.
-constexpr int kSelBlock = 256;
-__global__ __launch_bounds__(kSelBlock) void pnp_select_kernel(const double *__restrict__ objp, const double *__restrict__ imgp,
-                                                              int N, const int32_t *__restrict__ n_dev,
-                                                              const double *__restrict__ intr,
-                                                              const double *__restrict__ poses, const int32_t *__restrict__ counts,
-                                                              int B, double thr2, double *__restrict__ best_pose,
-                                                              int32_t *__restrict__ out_sel, int32_t *__restrict__ ptr2,
-                                                              int32_t *__restrict__ inlier_idx, uint8_t *__restrict__ mask)
+constexpr int kKfThreads = 256;                   // four waves share a frame: <= 300 correspondences are one or two sweeps
+constexpr int kKfWaves = kKfThreads / kWave;
+
+// The 28 sums of an evaluation over the WORKGROUP (kKfThreads threads), in a fixed order; every thread ends with the same sums, so the
+// Levenberg-Marquardt loop around it runs redundantly and in step in all of them.  Per wave the transposed reduction of wave_reduce.h
+// (32 exchange-and-add steps, lane 2 e ends with entry e) instead of 28 butterflies of six steps each: with one or two points per
+// thread the butterflies were three quarters of an evaluation's instructions.  red: LDS [kKfWaves][kAcc].
+__device__ __forceinline__ void block_sum_acc(double *acc, double *red, int tid)
+{
+    double v[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) v[k] = k < kAcc ? acc[k] : 0.0;
+    const double tot = mqs::wave::wave_reduce32(v, tid & 63);
+    __syncthreads();                              // the previous call's sums have been read by everyone
+    if (!(tid & 1) && ((tid & 63) >> 1) < kAcc) red[(tid >> 6) * kAcc + ((tid & 63) >> 1)] = tot;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kAcc; ++k) {
+        double t = red[k];
+#pragma unroll
+        for (int w = 1; w < kKfWaves; ++w) t += red[w * kAcc + k];
+        acc[k] = t;
+    }
+}
+
+// eval over the points idx[0..n) of (objp, imgp) -- idx null: 0..n -- by the whole workgroup
+struct BlockEval {
+    const double *objp, *imgp;
+    const int32_t *idx;
+    int n;
+    const double *intr;
+    double *red;
+    int tid;
+    __device__ __forceinline__ void operator()(const double *P, double *acc) const
+    {
+#pragma unroll
+        for (int k = 0; k < kAcc; ++k) acc[k] = 0.0;
+        for (int k = tid; k < n; k += kKfThreads) {
+            const int i = idx ? idx[k] : k;
+            accumulate_point(P, intr, objp[3 * i], objp[3 * i + 1], objp[3 * i + 2], imgp[2 * i], imgp[2 * i + 1], acc);
+        }
+        block_sum_acc(acc, red, tid);
+    }
+};
+
+// The end of solvePnPRansac in ONE launch of one workgroup (round 5; a 256-thread selection kernel and a one-wave refinement kernel
+// before: 4.8 + 20.8 us and a launch gap per frame): picks the hypothesis with the most inliers (lowest index on ties), marks and
+// compacts its inliers in index order -- into LDS when they fit (lds_ok: 40 bytes per correspondence), else as an index list in
+// global memory -- and refines the pose on them (OpenCV 2.4: solvePnP on the inliers, started from the best model) with the sums
+// of an evaluation taken by four wavefronts (block_sum_acc; the keyframe step's form).
+// out_sel: [0] best hypothesis (-1: none valid), [1] inlier count.  info: as pnp_refine_kernel's.
+constexpr int kSelBlock = kKfThreads;
+__global__ __launch_bounds__(kSelBlock) void pnp_select_refine_kernel(const double *__restrict__ objp, const double *__restrict__ imgp,
+                                                                     int N, const int32_t *__restrict__ n_dev,
+                                                                     const double *__restrict__ intr,
+                                                                     const double *__restrict__ poses, const int32_t *__restrict__ counts,
+                                                                     int B, double thr2, int max_iter, double eps, int lds_ok,
+                                                                     double *__restrict__ pose_out, int32_t *__restrict__ out_sel,
+                                                                     int32_t *__restrict__ inlier_idx, uint8_t *__restrict__ mask,
+                                                                     double *__restrict__ info)
 {
     __shared__ double sI[9], sP[12];
+    __shared__ double sRed[kKfWaves * kAcc];
     __shared__ int sBestC[kSelBlock], sBestH[kSelBlock], sWave[kSelBlock / 64], sBase;
+    extern __shared__ __attribute__((aligned(16))) double sel_lds[];     // the inliers' coordinates when they fit (lds_ok)
     const int tid = threadIdx.x;
     if (n_dev) N = *n_dev;
     if (tid < 9) sI[tid] = intr[tid];
@@ -263,12 +315,15 @@ __global__ __launch_bounds__(kSelBlock) void pnp_select_kernel(const double *__r
     if (tid < 12) sP[tid] = best >= 0 ? poses[12 * best + tid] : ((tid % 5 == 0) ? 1.0 : 0.0);
     if (tid == 0) sBase = 0;
     __syncthreads();
+    double *so = sel_lds, *si = sel_lds + 3 * (size_t)(lds_ok ? N : 0);
     for (int base = 0; base < N; base += kSelBlock) {
         const int i = base + tid;
         bool in = false;
+        double X = 0, Y = 0, Z = 0, u = 0, v = 0;
         if (i < N && best >= 0) {
-            const double Zc = fma(sP[8], objp[3 * i], fma(sP[9], objp[3 * i + 1], fma(sP[10], objp[3 * i + 2], sP[11])));
-            const double e2 = reproj_sqerr(sP, sI, objp[3 * i], objp[3 * i + 1], objp[3 * i + 2], imgp[2 * i], imgp[2 * i + 1]);
+            X = objp[3 * i]; Y = objp[3 * i + 1]; Z = objp[3 * i + 2]; u = imgp[2 * i]; v = imgp[2 * i + 1];
+            const double Zc = fma(sP[8], X, fma(sP[9], Y, fma(sP[10], Z, sP[11])));
+            const double e2 = reproj_sqerr(sP, sI, X, Y, Z, u, v);
             in = Zc > 0.0 && e2 <= thr2;
         }
         if (i < N && mask) mask[i] = in ? 1 : 0;
@@ -279,13 +334,36 @@ __global__ __launch_bounds__(kSelBlock) void pnp_select_kernel(const double *__r
         __syncthreads();
         int off = sBase;
         for (int w = 0; w < wave; ++w) off += sWave[w];
-        if (in) inlier_idx[off + before] = i;
+        if (in) {
+            const int r = off + before;
+            if (lds_ok) { so[3 * r] = X; so[3 * r + 1] = Y; so[3 * r + 2] = Z; si[2 * r] = u; si[2 * r + 1] = v; }
+            else inlier_idx[r] = i;
+        }
         __syncthreads();
         if (tid == 0) sBase += sWave[0] + sWave[1] + sWave[2] + sWave[3];
         __syncthreads();
     }
-    if (tid < 12) best_pose[tid] = sP[tid];
-    if (tid == 0) { out_sel[0] = best; out_sel[1] = sBase; ptr2[0] = 0; ptr2[1] = sBase; }
+    const int n_in = sBase;
+    if (tid == 0) { out_sel[0] = best; out_sel[1] = n_in; }
+    double P[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) P[k] = sP[k];
+    if (n_in < 3) {                                  // no problem (no valid model, or a rejected frame of the device-resident loop): the start pose
+        if (tid < 12) pose_out[tid] = P[tid];
+        if (info && tid < 4) info[tid] = tid == 3 ? 2.0 : 0.0;
+        return;
+    }
+    if (!lds_ok) __threadfence_block();              // the index list written above is read below by other threads of the workgroup
+    __syncthreads();
+    BlockEval ev = {lds_ok ? so : objp, lds_ok ? si : imgp, lds_ok ? nullptr : inlier_idx, n_in, sI, sRed, tid};
+    const LmResult r = lm_refine(ev, P, max_iter, eps);
+    if (tid < 12) pose_out[tid] = P[tid];
+    if (info && tid == 0) {
+        info[0] = r.sqerr;
+        info[1] = (double)r.iters;
+        info[2] = (double)n_in;
+        info[3] = r.converged ? 1.0 : 0.0;
+    }
 }
 
 int check_points(const double *objp, const double *imgp, int64_t N, const double *intr)
@@ -312,9 +390,6 @@ int check_points(const double *objp, const double *imgp, int64_t N, const double
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int32_t kKfDropped = -128;              // status of a point the first pass did not keep
 
-constexpr int kKfThreads = 256;                   // four waves share a frame: <= 300 correspondences are one or two sweeps
-constexpr int kKfWaves = kKfThreads / kWave;
-
 // eval over two segments (the tracked landmarks, then the compacted new points), summed over the WORKGROUP in a fixed order:
 // every thread ends with the same sums, so the Levenberg-Marquardt loop around it runs redundantly and in step in all of them
 struct KfEval {
@@ -336,23 +411,7 @@ struct KfEval {
             const double *U = old ? imgp + 2 * k : cuv + 2 * (k - n_old);
             accumulate_point(P, intr, X[0], X[1], X[2], U[0], U[1], acc);
         }
-        // the wave's 28 sums by the transposed reduction (wave_reduce.h: 32 exchange-and-add steps, lane 2 e ends with entry e)
-        // instead of 28 butterflies of six steps each: with one or two points per thread the butterflies were three quarters of
-        // an evaluation's instructions
-        double v[32];
-#pragma unroll
-        for (int k = 0; k < 32; ++k) v[k] = k < kAcc ? acc[k] : 0.0;
-        const double tot = mqs::wave::wave_reduce32(v, tid & 63);
-        __syncthreads();                          // the previous call's sums have been read by everyone
-        if (!(tid & 1) && ((tid & 63) >> 1) < kAcc) red[(tid >> 6) * kAcc + ((tid & 63) >> 1)] = tot;
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < kAcc; ++k) {
-            double t = red[k];
-#pragma unroll
-            for (int w = 1; w < kKfWaves; ++w) t += red[w * kAcc + k];
-            acc[k] = t;
-        }
+        block_sum_acc(acc, red, tid);
     }
 };
 
@@ -529,12 +588,13 @@ int mqs_pnp_ransac_launch(const double *objp, const double *imgp, int N, const i
     const double thr2 = reproj_error * reproj_error;
     hipLaunchKernelGGL(pnp_hypothesis_kernel, dim3(B), dim3(kWave), 0, stream, objp, imgp, N, n_dev, intr, samples,
                        sample_size, sample_iters, thr2, poses, counts);
-    // best hypothesis -> pose_out (used as the start of the final refinement), inliers -> inl / mask
-    hipLaunchKernelGGL(pnp_select_kernel, dim3(1), dim3(kSelBlock), 0, stream, objp, imgp, N, n_dev, intr, poses, counts, B,
-                       thr2, pose_out, sel_out, ptr2, inl, mask);
-    // OpenCV 2.4 solvePnPRansac ends with solvePnP on the inliers, started from the best model
-    hipLaunchKernelGGL(pnp_refine_kernel, dim3(1), dim3(kWave), 0, stream, objp, imgp, N, inl, ptr2, intr, pose_out, 1,
-                       max_iter, eps, pose_out, info);
+    // best hypothesis, its inliers (-> mask), and OpenCV 2.4 solvePnPRansac's end -- solvePnP on the inliers, started from the best model --
+    // in one launch; the inliers' coordinates in LDS when N correspondences fit (40 bytes each)
+    const size_t lds_bytes = (size_t)N * 40;
+    const bool lds_ok = lds_bytes <= 40 * 1024;
+    (void)ptr2;
+    hipLaunchKernelGGL(pnp_select_refine_kernel, dim3(1), dim3(kSelBlock), lds_ok ? lds_bytes : 0, stream, objp, imgp, N, n_dev, intr, poses,
+                       counts, B, thr2, max_iter, eps, (int)lds_ok, pose_out, sel_out, inl, mask, info);
     MQS_HIP_CHECK(hipGetLastError());
     return MQS_OK;
 }
