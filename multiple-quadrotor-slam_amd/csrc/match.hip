@@ -170,6 +170,9 @@ using float16v = __attribute__((ext_vector_type(16))) float;
 #ifndef MQS_MATCH_STAGE_ROWS
 #define MQS_MATCH_STAGE_ROWS 128
 #endif
+#ifndef MQS_MATCH_MIN_BLOCKS
+#define MQS_MATCH_MIN_BLOCKS 1           // A/B: workgroups per CU the register budget is cut for (2 with MQS_MATCH_NW256=4, MQS_MATCH_STAGE_ROWS=64)
+#endif
 #ifndef MQS_MATCH_STAGGER
 #define MQS_MATCH_STAGGER 0            // A/B: s_sleep argument (x 64 cycles) by which the second wave of every SIMD trails the first behind each stage barrier
 #endif
@@ -276,7 +279,7 @@ struct F4Path : F16Path {
 
 template <class TP /* F16Path or F4Path */, int KS /* MFMAs per (train tile, query tile) = D / TP::kPerMfma */,
           int QT /* 32-query column tiles per wave */, int NW /* waves per workgroup */>
-__global__ __launch_bounds__(NW * 64) void knn2_mfma_kernel(const typename TP::elem *__restrict__ query, int64_t Nq,
+__global__ __launch_bounds__(NW * 64, MQS_MATCH_MIN_BLOCKS) void knn2_mfma_kernel(const typename TP::elem *__restrict__ query, int64_t Nq,
                                                            const typename TP::elem *__restrict__ train, int64_t Nt,
                                                           const float *__restrict__ qnorm,
                                                           const float *__restrict__ tnorm,
