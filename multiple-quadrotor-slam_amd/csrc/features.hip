@@ -737,14 +737,13 @@ __device__ __forceinline__ void lk_block_sum2(double x, double y, double &sx, do
     }
 }
 
-template <int NW>
+template <int NW, int kPix /* window pixels per thread: ceil(ww * wh / (64 NW)) -- two for the loop's 21 x 21 window on four wavefronts */>
 __global__ __launch_bounds__(64 * NW) void lk_kernel(LkLevels L, const float *__restrict__ prev_pts, int n, const int32_t *__restrict__ n_dev,
                                                     int ww, int wh, int max_iter, float eps, float min_eig_threshold,
                                                     float *__restrict__ next_pts, uint8_t *__restrict__ status, float *__restrict__ err)
 {
     __shared__ double sRed[4 * NW];
     int slot = 0;
-    constexpr int kPix = (kMaxWinPixelsPerLane + NW - 1) / NW;       // window pixels per thread
     const int k = blockIdx.x, lane = threadIdx.x, wave = threadIdx.x >> 6;
     if (n_dev) n = min(n, *n_dev);                  // the device-resident loop: the number of live tracks is device state
     if (k >= n) return;
@@ -755,6 +754,9 @@ __global__ __launch_bounds__(64 * NW) void lk_kernel(LkLevels L, const float *__
     float nx = 0.0f, ny = 0.0f;
     bool ok = true;
     float errv = 0.0f;
+#ifdef MQS_LK_COUNT_ITERS                                  // (A/B builds: err[] returns the feature's iteration count over all levels)
+    int iters_total = 0;
+#endif
     for (int level = L.levels; level >= 0; --level) {
         const int W = L.W[level], H = L.H[level];
         const float sc = 1.0f / (float)(1 << level);
@@ -837,6 +839,9 @@ __global__ __launch_bounds__(64 * NW) void lk_kernel(LkLevels L, const float *__
             const float B1 = (float)sb1 * kFltScale, B2 = (float)sb2 * kFltScale;
             const float dx = (A12 * B2 - A22 * B1) * D, dy = (A12 * B1 - A11 * B2) * D;
             nx += dx; ny += dy;
+#ifdef MQS_LK_COUNT_ITERS
+            iters_total += 1;
+#endif
             if (dx * dx + dy * dy <= eps * eps) break;
             if (j > 0 && fabsf(dx + pdx) < 0.01f && fabsf(dy + pdy) < 0.01f) {
                 nx -= dx * 0.5f; ny -= dy * 0.5f;
@@ -872,6 +877,9 @@ __global__ __launch_bounds__(64 * NW) void lk_kernel(LkLevels L, const float *__
         next_pts[2 * k + 1] = ny;
         status[k] = ok ? 1 : 0;
         err[k] = ok ? errv : 0.0f;
+#ifdef MQS_LK_COUNT_ITERS
+        err[k] = (float)iters_total;
+#endif
     }
 }
 
@@ -1159,9 +1167,18 @@ int mqs_lk_launch(const uint8_t *prev_img, const uint8_t *next_img, int W, int H
         g.z = (unsigned)(L.levels + 1);
         hipLaunchKernelGGL(lk_pad_levels_kernel, g, dim3(kBlock), 0, stream, job);
     }
-    if (n > 0)
-        hipLaunchKernelGGL(lk_kernel<kLkWaves>, dim3(n), dim3(64 * kLkWaves), 0, stream, L, prev_pts, n, n_dev, win_w, win_h, max_iter, (float)eps,
-                           (float)min_eig_threshold, next_pts, status, err);
+    if (n > 0) {
+        // (a thread's pixels beyond the window carry weight zero: instantiated per count so that the loop's window does not pay for the largest)
+        const int per_thread = (win_w * win_h + 64 * kLkWaves - 1) / (64 * kLkWaves);
+#define MQS_LK_LAUNCH(KP)                                                                                                             \
+        hipLaunchKernelGGL((lk_kernel<kLkWaves, KP>), dim3(n), dim3(64 * kLkWaves), 0, stream, L, prev_pts, n, n_dev, win_w, win_h, max_iter,   \
+                           (float)eps, (float)min_eig_threshold, next_pts, status, err)
+        constexpr int kPixMax = (kMaxWinPixelsPerLane + kLkWaves - 1) / kLkWaves;
+        if (per_thread <= 1) MQS_LK_LAUNCH(1);
+        else if (per_thread <= 2) MQS_LK_LAUNCH(2);
+        else MQS_LK_LAUNCH(kPixMax);
+#undef MQS_LK_LAUNCH
+    }
     MQS_HIP_CHECK(hipGetLastError());
     return MQS_OK;
 }
