@@ -296,6 +296,10 @@ __global__ __launch_bounds__(kSelThreads) void sort_select_kernel(unsigned long 
         }
         __syncthreads();                                   // the sorted keys are in global memory; the LDS is free
     }
+#ifdef MQS_GFTT_EXPERIMENT_SORT_ONLY                        // (timing only: the gather and the sort, no selection)
+    if (threadIdx.x == 0) out_n[0] = (int)sTotal;
+    if (W > 0) return;
+#endif
     constexpr int kBuckets = 2048;                         // hash table of the round's survivors by grid cell
     __shared__ unsigned int sSurv[kSelThreads];            // survivors of the pre-filter, in candidate order: x | y << 16
     __shared__ int sState[kSelThreads];                    // 0 undecided, 1 accepted, 2 rejected
@@ -344,44 +348,70 @@ __global__ __launch_bounds__(kSelThreads) void sort_select_kernel(unsigned long 
     //   3. the accepted ones, in order, up to the limit, go to the output and into the grid.
     // (History: one wavefront walking the sorted list seven candidates at a time, 85 us for the ~1100 candidates a VGA frame
     // needs for 300 corners; the pre-filter alone changed nothing, the strongest 1024 all survive an empty grid.)
-    for (unsigned int base = 0; base < n && accepted < limit; base += kSelThreads) {
-        const unsigned int ci = base + threadIdx.x;
-        bool survive = false;
-        unsigned int pos = 0u;
-        int x = 0, y = 0, cxx = 0, cyy = 0;
-        if (ci < n) {
-            pos = 0xFFFFFFFFu - (unsigned int)(keys[ci] & 0xFFFFFFFFull);
-            x = (int)(pos & 0xFFFFu); y = (int)(pos >> 16);
-            cxx = cell_of(x); cyy = cell_of(y);
-            bool clash = false;
+    // A round's kSelThreads places go to SURVIVORS of the pre-filter, gathered in order from as many candidates as it takes (round 5: a
+    // round took the next kSelThreads candidates, and on a real frame -- thousands of candidates, most of them next to a corner accepted
+    // in the first rounds -- eight rounds of barriers and sweeps decided a handful each: 151 us of a detection's 242).  A candidate the
+    // pre-filter rejects is out for good (the accepted set only grows), so the order of the decisions is the greedy rule's as before.
+    __shared__ unsigned int sNextBase;
+    unsigned int base = 0;
+    while (base < n && accepted < limit) {
+        int nsurv = 0;
+        unsigned int next_base = base;
+        for (unsigned int c0 = base; c0 < n && nsurv < kSelThreads; c0 += kSelThreads) {
+            const unsigned int ci = c0 + threadIdx.x;
+            bool sv = false;
+            unsigned int cpos = 0u;
+            if (ci < n) {
+                cpos = 0xFFFFFFFFu - (unsigned int)(keys[ci] & 0xFFFFFFFFull);
+                const int px = (int)(cpos & 0xFFFFu), py = (int)(cpos >> 16);
+                const int pcx = cell_of(px), pcy = cell_of(py);
+                bool clash = false;
 #pragma unroll
-            for (int k = 0; k < 9; ++k) {
-                const int xx = cxx + k % 3 - 1, yy = cyy + k / 3 - 1;
-                if (yy >= 0 && yy < gh && xx >= 0 && xx < gw) {
+                for (int k = 0; k < 9; ++k) {
+                    const int xx = pcx + k % 3 - 1, yy = pcy + k / 3 - 1;
+                    if (yy >= 0 && yy < gh && xx >= 0 && xx < gw) {
 #pragma unroll
-                    for (int slot = 0; slot < 4; ++slot) {
-                        const unsigned int v = *slot_ptr((yy * gw + xx) * 4 + slot);
-                        if (v != 0xFFFFFFFFu) {
-                            const float dx = (float)(x - (int)(v & 0xFFFFu)), dy = (float)(y - (int)(v >> 16));
-                            clash = clash || (dx * dx + dy * dy < md2);
+                        for (int slot = 0; slot < 4; ++slot) {
+                            const unsigned int v = *slot_ptr((yy * gw + xx) * 4 + slot);
+                            if (v != 0xFFFFFFFFu) {
+                                const float dx = (float)(px - (int)(v & 0xFFFFu)), dy = (float)(py - (int)(v >> 16));
+                                clash = clash || (dx * dx + dy * dy < md2);
+                            }
                         }
                     }
                 }
+                sv = !clash;
             }
-            survive = !clash;
-        }
-        for (int b = threadIdx.x; b < kBuckets; b += kSelThreads) sHead[b] = -1;
-        const unsigned long long mask = __ballot(survive);
-        if (lane == 0) sWaveCount[wave] = __popcll(mask);
-        __syncthreads();
-        int offset = 0;
+            const unsigned long long smask = __ballot(sv);
+            if (lane == 0) sWaveCount[wave] = __popcll(smask);
+            __syncthreads();
+            int soff = 0, stotal = 0;
 #pragma unroll
-        for (int w2 = 0; w2 < kSelThreads / 64; ++w2) offset += w2 < wave ? sWaveCount[w2] : 0;
-        const int me = offset + __popcll(mask & ((1ull << lane) - 1ull));      // this survivor's rank = its priority in the round
+            for (int w2 = 0; w2 < kSelThreads / 64; ++w2) {
+                const int cnt = sWaveCount[w2];
+                soff += w2 < wave ? cnt : 0;
+                stotal += cnt;
+            }
+            const int rank = nsurv + soff + __popcll(smask & ((1ull << lane) - 1ull));
+            if (sv && rank < kSelThreads) sSurv[rank] = cpos;
+            if (sv && rank == kSelThreads) sNextBase = ci;             // the first survivor that does not fit: the next round starts with it
+            __syncthreads();
+            if (nsurv + stotal > kSelThreads) { next_base = sNextBase; nsurv = kSelThreads; }
+            else { next_base = c0 + kSelThreads < n ? c0 + kSelThreads : n; nsurv += stotal; }
+        }
+        base = next_base;
+        // thread t decides survivor t (its rank = its priority in the round)
+        const bool survive = (int)threadIdx.x < nsurv;
+        const int me = (int)threadIdx.x;
+        unsigned int pos = 0u;
+        int x = 0, y = 0, cxx = 0, cyy = 0;
         if (survive) {
-            sSurv[me] = pos;
+            pos = sSurv[me];
+            x = (int)(pos & 0xFFFFu); y = (int)(pos >> 16);
+            cxx = cell_of(x); cyy = cell_of(y);
             sState[me] = 0;
         }
+        for (int b = threadIdx.x; b < kBuckets; b += kSelThreads) sHead[b] = -1;
         __syncthreads();
         // chain the survivors of a bucket: lists are built by one thread per bucket walking nobody -- instead every survivor
         // pushes itself with an atomic exchange on the bucket head (int heads would double the table; the exchange is on the
@@ -426,40 +456,51 @@ __global__ __launch_bounds__(kSelThreads) void sort_select_kernel(unsigned long 
                 }
             }
         }
-        // sweeps
+        // The decisions, without a barrier (round 5): an undecided survivor polls the states of the stronger survivors near it in LDS until
+        // one of them is accepted (-> rejected) or all of them are rejected (-> accepted), then publishes its own.  A state changes once,
+        // from undecided, so a mixed snapshot can only say "wait"; the strongest undecided survivor never waits, so everybody ends; and
+        // the fixed point is the greedy rule's, whatever the order of the polls.  (The synchronous form -- every survivor looks, a
+        // workgroup barrier, every survivor writes, a second barrier with a vote -- cost three barriers of sixteen wavefronts per LEVEL of
+        // the dependency chain; on a real frame, where candidates line up along edges, the chains are ~100 deep: 151 us of a detection's
+        // 242.  A poll is an LDS round trip.)
+        // The loop is left by the WAVEFRONT as a whole (a vote): a lane that left on its own would publish its state only where the
+        // wavefront's lanes meet again behind the loop -- which the lanes waiting for that state never reach (measured: the launch hangs).
         int state = survive ? 0 : 2;
-        for (;;) {
-            if (state == 0) {
-                bool rejected = false, pending = false;
-                for (int t = 0; t < nnbr; ++t) {
-                    const int sj = sState[sNbr[me * kNbr + t]];
-                    rejected = rejected || sj == 1;
-                    pending = pending || sj == 0;
-                }
-                if (overflow) {
+        {
+            volatile int *vState = sState;
+            for (;;) {
+                if (state == 0) {
+                    bool rejected = false, pending = false;
+                    for (int t = 0; t < nnbr; ++t) {
+                        const int sj = vState[sNbr[me * kNbr + t]];
+                        rejected = rejected || sj == 1;
+                        pending = pending || sj == 0;
+                    }
+                    if (overflow) {
 #pragma unroll 1
-                    for (int k = 0; k < 9; ++k) {
-                        const int xx = cxx + k % 3 - 1, yy = cyy + k / 3 - 1;
-                        if (yy < 0 || yy >= gh || xx < 0 || xx >= gw) continue;
-                        for (int j = sHead[bucket_of(xx, yy)]; j >= 0; j = sNext[j]) {
-                            if (j >= me) continue;
-                            const unsigned int pj = sSurv[j];
-                            const float dx = (float)(x - (int)(pj & 0xFFFFu)), dy = (float)(y - (int)(pj >> 16));
-                            if (dx * dx + dy * dy < md2) {
-                                const int sj = sState[j];
-                                rejected = rejected || sj == 1;
-                                pending = pending || sj == 0;
+                        for (int k = 0; k < 9; ++k) {
+                            const int xx = cxx + k % 3 - 1, yy = cyy + k / 3 - 1;
+                            if (yy < 0 || yy >= gh || xx < 0 || xx >= gw) continue;
+                            for (int j = sHead[bucket_of(xx, yy)]; j >= 0; j = sNext[j]) {
+                                if (j >= me) continue;
+                                const unsigned int pj = sSurv[j];
+                                const float dx = (float)(x - (int)(pj & 0xFFFFu)), dy = (float)(y - (int)(pj >> 16));
+                                if (dx * dx + dy * dy < md2) {
+                                    const int sj = vState[j];
+                                    rejected = rejected || sj == 1;
+                                    pending = pending || sj == 0;
+                                }
                             }
                         }
                     }
+                    if (rejected) state = 2;
+                    else if (!pending) state = 1;
+                    if (state != 0) vState[me] = state;
                 }
-                if (rejected) state = 2;
-                else if (!pending) state = 1;
+                if (__builtin_amdgcn_ballot_w64(state == 0) == 0ull) break;
             }
-            __syncthreads();                                     // every read of this sweep has happened
-            if (survive) sState[me] = state;
-            if (!__syncthreads_or(state == 0)) break;
         }
+        __syncthreads();
         // the accepted survivors in order
         const bool acc = survive && state == 1;
         const unsigned long long amask = __ballot(acc);
