@@ -85,13 +85,14 @@ __device__ bool wave_dlt(const Problem &pr, const double *intr, int lane, double
         const int i = pr.point(k);
         cx += pr.objp[3 * i]; cy += pr.objp[3 * i + 1]; cz += pr.objp[3 * i + 2];
     }
-    const double inv_n = 1.0 / (double)n;
+    const double inv_n = mqs::rcp((double)n);
     const double c[3] = {wave_sum(cx) * inv_n, wave_sum(cy) * inv_n, wave_sum(cz) * inv_n};
     double dist = 0.0;
     for (int k = pr.begin + lane; k < pr.end; k += kWave) {
         const int i = pr.point(k);
         const double dx = pr.objp[3 * i] - c[0], dy = pr.objp[3 * i + 1] - c[1], dz = pr.objp[3 * i + 2] - c[2];
-        dist += sqrt(fma(dx, dx, fma(dy, dy, dz * dz)));
+        const double d2 = fma(dx, dx, fma(dy, dy, dz * dz));
+        dist += d2 > 0.0 ? d2 * mqs::rsqrt_d(d2) : 0.0;
     }
     double cov[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     for (int k = pr.begin + lane; k < pr.end; k += kWave) {
@@ -103,7 +104,7 @@ __device__ bool wave_dlt(const Problem &pr, const double *intr, int lane, double
     for (int k = 0; k < 6; ++k) cov[k] = wave_sum(cov[k]);
     double sigma = wave_sum(dist) * inv_n;
     if (!(sigma > 0.0)) sigma = 1.0;
-    const double is = 1.0 / sigma;
+    const double is = mqs::rcp(sigma);
     double ew[3], E[9];
     sym3_eigen(cov, ew, E);
     if (ew[2] < 1e-3 * ew[1]) {

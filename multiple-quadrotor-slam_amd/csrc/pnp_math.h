@@ -24,7 +24,7 @@ MQS_HD void accumulate_point(const double *P, const double *intr, double X, doub
     const double Xc = fma(P[0], X, fma(P[1], Y, fma(P[2], Z, P[3])));
     const double Yc = fma(P[4], X, fma(P[5], Y, fma(P[6], Z, P[7])));
     const double Zc = fma(P[8], X, fma(P[9], Y, fma(P[10], Z, P[11])));
-    const double iz = 1.0 / Zc;
+    const double iz = mqs::rcp(Zc);                    // (device: v_rcp_f64 + two Newton steps, five dependent instructions where the IEEE division has ~15)
     const double x = Xc * iz, y = Yc * iz;
     const double fx = intr[0], fy = intr[1], cx = intr[2], cy = intr[3];
     const double k1 = intr[4], k2 = intr[5], p1 = intr[6], p2 = intr[7], k3 = intr[8];
@@ -85,7 +85,7 @@ MQS_HD bool solve_step(const double *acc, double lambda, double *delta)
 #pragma unroll
         for (int m = 0; m < k; ++m) dkk = fma(-L[k][m], L[k][m], dkk);
         ok = ok && (dkk > 0.0);
-        const double r = 1.0 / sqrt(dkk > 0.0 ? dkk : 1.0);
+        const double r = mqs::rsqrt_d(dkk > 0.0 ? dkk : 1.0);      // (device: v_rsq_f64 + two Newton steps; the IEEE square root and division are ~25 dependent instructions per pivot)
         inv[k] = r;
 #pragma unroll
         for (int i = k + 1; i < 6; ++i) {
@@ -116,10 +116,19 @@ MQS_HD bool solve_step(const double *acc, double lambda, double *delta)
 MQS_HD void so3_exp(const double *w, double *E)
 {
     const double th2 = fma(w[0], w[0], fma(w[1], w[1], w[2] * w[2]));
-    const double th = sqrt(th2);
     double a, b;
-    if (th < 1e-8) { a = 1.0 - th2 / 6.0; b = 0.5 - th2 / 24.0; }
-    else { a = sin(th) / th; b = (1.0 - cos(th)) / th2; }
+    if (th2 < 0.25) {
+        // sin(th) / th and (1 - cos(th)) / th^2 as series in th^2 (a Levenberg-Marquardt step is a small rotation: this is the branch
+        // taken; truncation below 1e-19 at th = 0.5, and no cancellation in 1 - cos).  The library's sin and cos with their argument
+        // reduction were ~1 us of every iteration of the one-wave refinements (round 5).
+        a = fma(th2, fma(th2, fma(th2, fma(th2, fma(th2, fma(th2, fma(th2, -1.0 / 1307674368000.0, 1.0 / 6227020800.0), -1.0 / 39916800.0),
+                1.0 / 362880.0), -1.0 / 5040.0), 1.0 / 120.0), -1.0 / 6.0), 1.0);
+        b = fma(th2, fma(th2, fma(th2, fma(th2, fma(th2, fma(th2, fma(th2, -1.0 / 20922789888000.0, 1.0 / 87178291200.0), -1.0 / 479001600.0),
+                1.0 / 3628800.0), -1.0 / 40320.0), 1.0 / 720.0), -1.0 / 24.0), 0.5);
+    } else {
+        const double th = sqrt(th2);
+        a = sin(th) / th; b = (1.0 - cos(th)) / th2;
+    }
     const double K[9] = {0.0, -w[2], w[1], w[2], 0.0, -w[0], -w[1], w[0], 0.0};
 #pragma unroll
     for (int i = 0; i < 3; ++i)
@@ -276,7 +285,7 @@ MQS_HD bool chol_solve_small(double *A, double *b, int n)
         double dkk = A[k * n + k];
         for (int m = 0; m < k; ++m) dkk -= A[k * n + m] * A[k * n + m];
         ok = ok && (dkk > 0.0);
-        const double r = 1.0 / sqrt(dkk > 0.0 ? dkk : 1.0);
+        const double r = mqs::rsqrt_d(dkk > 0.0 ? dkk : 1.0);      // (device: v_rsq_f64 + two Newton steps; the IEEE square root and division are ~25 dependent instructions per pivot)
         A[k * n + k] = r;                                  // inverse diagonal
         for (int i = k + 1; i < n; ++i) {
             double v = A[i * n + k];
@@ -311,7 +320,7 @@ MQS_HD bool chol_solve_fixed(double (&A)[N * N], double (&b)[N])
 #pragma unroll
         for (int m = 0; m < k; ++m) dkk -= A[k * N + m] * A[k * N + m];
         ok = ok && (dkk > 0.0);
-        const double r = 1.0 / sqrt(dkk > 0.0 ? dkk : 1.0);
+        const double r = mqs::rsqrt_d(dkk > 0.0 ? dkk : 1.0);      // (device: v_rsq_f64 + two Newton steps; the IEEE square root and division are ~25 dependent instructions per pivot)
         A[k * N + k] = r;
 #pragma unroll
         for (int i = k + 1; i < N; ++i) {
@@ -344,9 +353,9 @@ MQS_HD bool chol_solve_fixed(double (&A)[N * N], double (&b)[N])
 MQS_HD bool pose_from_dlt(const double *p, const double *centroid, double sigma, double *P)
 {
     double M[9] = {p[0], p[1], p[2], p[4], p[5], p[6], p[8], p[9], p[10]};
-    const double n3 = sqrt(fma(M[6], M[6], fma(M[7], M[7], M[8] * M[8])));
-    if (!(n3 > 0.0)) return false;
-    const double s = 1.0 / n3;
+    const double n3sq = fma(M[6], M[6], fma(M[7], M[7], M[8] * M[8]));
+    if (!(n3sq > 0.0)) return false;
+    const double s = mqs::rsqrt_d(n3sq);
 #pragma unroll
     for (int k = 0; k < 9; ++k) M[k] *= s;
     double tv[3] = {s * sigma * p[3], s * sigma * p[7], s * sigma};
@@ -355,7 +364,7 @@ MQS_HD bool pose_from_dlt(const double *p, const double *centroid, double sigma,
         const double c00 = fma(M[4], M[8], -M[5] * M[7]), c01 = fma(M[5], M[6], -M[3] * M[8]), c02 = fma(M[3], M[7], -M[4] * M[6]);
         const double det = fma(M[0], c00, fma(M[1], c01, M[2] * c02));
         if (!(det > 1e-12)) { ok = false; break; }
-        const double id = 0.5 / det;
+        const double id = 0.5 * mqs::rcp(det);
         // cofactor matrix = det * M^-T
         const double C[9] = {c00, c01, c02,
                              fma(M[2], M[7], -M[1] * M[8]), fma(M[0], M[8], -M[2] * M[6]), fma(M[1], M[6], -M[0] * M[7]),
@@ -391,9 +400,12 @@ MQS_HD void sym3_eigen(const double *S, double *w, double *V)
         for (int p = 0; p < 2; ++p)
             for (int q = p + 1; q < 3; ++q) {
                 if (a[p][q] == 0.0) continue;
-                const double theta = (a[q][q] - a[p][p]) / (2.0 * a[p][q]);
-                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+                const double theta = (a[q][q] - a[p][p]) * mqs::rcp(2.0 * a[p][q]);
+                // tan of the rotation angle: sgn / (|theta| + sqrt(theta^2 + 1)); beyond 1e100 the square root is |theta| to rounding
+                const double q1 = fma(theta, theta, 1.0);
+                const double t = fabs(theta) > 1e100 ? 0.5 * mqs::rcp(theta)
+                                                     : (theta >= 0.0 ? 1.0 : -1.0) * mqs::rcp(fabs(theta) + q1 * mqs::rsqrt_d(q1));
+                const double c = mqs::rsqrt_d(fma(t, t, 1.0)), sn = t * c;
                 for (int k = 0; k < 3; ++k) {                       // A <- A G
                     const double kp = a[k][p], kq = a[k][q];
                     a[k][p] = c * kp - sn * kq; a[k][q] = sn * kp + c * kq;
@@ -495,21 +507,21 @@ MQS_HD void hom_assemble(const double *acc, double *A, double *rhs)
 MQS_HD bool pose_from_homography(const double *h, const double *E, const double *centroid, double sigma, double *P)
 {
     const double h1[3] = {h[0], h[3], h[6]}, h2[3] = {h[1], h[4], h[7]}, h3[3] = {h[2], h[5], 1.0};
-    const double n1 = sqrt(h1[0] * h1[0] + h1[1] * h1[1] + h1[2] * h1[2]);
-    const double n2 = sqrt(h2[0] * h2[0] + h2[1] * h2[1] + h2[2] * h2[2]);
-    if (!(n1 > 0.0) || !(n2 > 0.0)) return false;
+    const double n1sq = h1[0] * h1[0] + h1[1] * h1[1] + h1[2] * h1[2], n2sq = h2[0] * h2[0] + h2[1] * h2[1] + h2[2] * h2[2];
+    if (!(n1sq > 0.0) || !(n2sq > 0.0)) return false;
+    const double i1 = mqs::rsqrt_d(n1sq), i2 = mqs::rsqrt_d(n2sq), n1 = n1sq * i1, n2 = n2sq * i2;      // (no division, no square root: Newton steps)
     double M[9];                                           // [r1 r2 r3] as columns
-    for (int i = 0; i < 3; ++i) { M[3 * i] = h1[i] / n1; M[3 * i + 1] = h2[i] / n2; }
+    for (int i = 0; i < 3; ++i) { M[3 * i] = h1[i] * i1; M[3 * i + 1] = h2[i] * i2; }
     M[2] = M[3] * M[7] - M[6] * M[4];                      // r3 = r1 x r2
     M[5] = M[6] * M[1] - M[0] * M[7];
     M[8] = M[0] * M[4] - M[3] * M[1];
-    const double sc = 2.0 * sigma / (n1 + n2);
+    const double sc = 2.0 * sigma * mqs::rcp(n1 + n2);
     const double tp[3] = {h3[0] * sc, h3[1] * sc, h3[2] * sc};
     for (int it = 0; it < 12; ++it) {                      // polar decomposition (Newton)
         const double c00 = M[4] * M[8] - M[5] * M[7], c01 = M[5] * M[6] - M[3] * M[8], c02 = M[3] * M[7] - M[4] * M[6];
         const double det = M[0] * c00 + M[1] * c01 + M[2] * c02;
         if (!(det > 1e-12)) return false;
-        const double id = 0.5 / det;
+        const double id = 0.5 * mqs::rcp(det);
         const double C[9] = {c00, c01, c02,
                              M[2] * M[7] - M[1] * M[8], M[0] * M[8] - M[2] * M[6], M[1] * M[6] - M[0] * M[7],
                              M[1] * M[5] - M[2] * M[4], M[2] * M[3] - M[0] * M[5], M[0] * M[4] - M[1] * M[3]};

@@ -134,9 +134,11 @@ __global__ __launch_bounds__(256) void frame_filter_kernel(SlamDev d, SlamParams
 __device__ __forceinline__ void jacobi_angle(double app, double aqq, double apq, double &c, double &s)
 {
     if (fabs(apq) <= 1e-300) { c = 1.0; s = 0.0; return; }
-    const double tau = (aqq - app) / (2.0 * apq);
-    const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
-    c = 1.0 / sqrt(1.0 + t * t);
+    // (reciprocal and reciprocal square root by Newton steps: the IEEE divisions and square roots were most of a rotation's chain)
+    const double tau = (aqq - app) * mqs::rcp(2.0 * apq);
+    const double q1 = fma(tau, tau, 1.0);
+    const double t = fabs(tau) > 1e100 ? 0.5 * mqs::rcp(tau) : (tau >= 0.0 ? 1.0 : -1.0) * mqs::rcp(fabs(tau) + q1 * mqs::rsqrt_d(q1));
+    c = mqs::rsqrt_d(fma(t, t, 1.0));
     s = t * c;
 }
 
@@ -325,7 +327,7 @@ __device__ void homography_refine_wave(const double *__restrict__ u1, const doub
         double e = 0.0;
         for (int k = lane; k < n; k += 64) {
             const double ax = u1[2 * k], ay = u1[2 * k + 1];
-            const double w = 1.0 / fma(g[6], ax, fma(g[7], ay, 1.0));
+            const double w = mqs::rcp(fma(g[6], ax, fma(g[7], ay, 1.0)));
             const double rx = fma(g[0], ax, fma(g[1], ay, g[2])) * w - u2[2 * k], ry = fma(g[3], ax, fma(g[4], ay, g[5])) * w - u2[2 * k + 1];
             e = fma(rx, rx, fma(ry, ry, e));
         }
@@ -341,7 +343,7 @@ __device__ void homography_refine_wave(const double *__restrict__ u1, const doub
         for (int e = 0; e < 32; ++e) v[e] = 0.0;
         for (int k = lane; k < n; k += 64) {
             const double ax = u1[2 * k], ay = u1[2 * k + 1];
-            const double w = 1.0 / fma(h[6], ax, fma(h[7], ay, 1.0));
+            const double w = mqs::rcp(fma(h[6], ax, fma(h[7], ay, 1.0)));
             const double x = fma(h[0], ax, fma(h[1], ay, h[2])) * w, y = fma(h[3], ax, fma(h[4], ay, h[5])) * w;
             const double rx = x - u2[2 * k], ry = y - u2[2 * k + 1];
             // rows of J: [a0 a1 a2 0 0 0 c0 c1] (x) and [0 0 0 a0 a1 a2 d0 d1] (y)
@@ -651,12 +653,13 @@ __device__ __forceinline__ void frame_decide_body(const SlamDev &d, const SlamPa
                     t[3 * r + 1] = hn[3 * r + 1] * s1;
                     t[3 * r + 2] = hn[3 * r + 2] - s1 * (hn[3 * r + 0] * c1x + hn[3 * r + 1] * c1y);
                 }
+                const double is2 = mqs::rcp(s2);
                 for (int c = 0; c < 3; ++c) {
-                    h[c] = t[c] / s2 + c2x * t[6 + c];
-                    h[3 + c] = t[3 + c] / s2 + c2y * t[6 + c];
+                    h[c] = t[c] * is2 + c2x * t[6 + c];
+                    h[3 + c] = t[3 + c] * is2 + c2y * t[6 + c];
                     h[6 + c] = t[6 + c];
                 }
-                const double i8 = 1.0 / h[8];                           // cvConvertScale(&_H0, H, 1. / _H0.data.db[8])
+                const double i8 = mqs::rcp(h[8]);                       // cvConvertScale(&_H0, H, 1. / _H0.data.db[8])
                 for (int i = 0; i < 9; ++i) sH[i] = h[i] * i8;
             }
             mqs_wave_lds_sync();
