@@ -18,6 +18,7 @@
 // The reduced system is then factored by the blocked Cholesky below (own kernels, fp64).
 // The atomic form is not bitwise reproducible (summation order); the grouped form is.
 #include "mqs_common.h"
+#include "so3_math.h"
 #include <map>
 #include <mutex>
 #include "ba_math.h"
@@ -320,11 +321,9 @@ __global__ __launch_bounds__(kBlock) void sparse_check_groups_kernel(const int32
 
 __device__ void so3_log_s(const double *R, double w[3])
 {
-    double c = 0.5 * (R[0] + R[4] + R[8] - 1.0);
-    c = fmin(1.0, fmax(-1.0, c));
-    const double th = acos(c);
-    const double k = (th < 1e-10) ? 0.5 : th / (2.0 * sin(th));
-    w[0] = k * (R[7] - R[5]); w[1] = k * (R[2] - R[6]); w[2] = k * (R[3] - R[1]);
+    const double vx = R[7] - R[5], vy = R[2] - R[6], vz = R[3] - R[1];
+    const double k = mqs::so3_log_factor(0.5 * (R[0] + R[4] + R[8] - 1.0), 0.25 * fma(vx, vx, fma(vy, vy, vz * vz)));
+    w[0] = k * vx; w[1] = k * vy; w[2] = k * vz;
 }
 
 // mirror upper -> lower, then pose priors (thread per prior) and damping on the diagonal
@@ -592,9 +591,9 @@ __global__ void sparse_retract_kernel(const double *__restrict__ poses, const do
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= P) return;
     const double *T = poses + 12 * (int64_t)j, *d = dpose + 6 * (int64_t)j;
-    const double th2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2], th = sqrt(th2);
+    const double th2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
     double a, b;
-    if (th < 1e-10) { a = 1.0; b = 0.5; } else { a = sin(th) / th; b = (1.0 - cos(th)) / th2; }
+    mqs::so3_exp_factors(th2, a, b);
     const double K[9] = {0, -d[2], d[1], d[2], 0, -d[0], -d[1], d[0], 0};
     double E[9];
     for (int r = 0; r < 3; ++r)

@@ -11,6 +11,7 @@
 // MQS_HD: compiled for the host by tests/host_math.cpp (test-only).
 #pragma once
 #include "cam_math.h"
+#include "so3_math.h"
 
 namespace mqs {
 namespace pnp {
@@ -117,18 +118,7 @@ MQS_HD void so3_exp(const double *w, double *E)
 {
     const double th2 = fma(w[0], w[0], fma(w[1], w[1], w[2] * w[2]));
     double a, b;
-    if (th2 < 0.25) {
-        // sin(th) / th and (1 - cos(th)) / th^2 as series in th^2 (a Levenberg-Marquardt step is a small rotation: this is the branch
-        // taken; truncation below 1e-19 at th = 0.5, and no cancellation in 1 - cos).  The library's sin and cos with their argument
-        // reduction were ~1 us of every iteration of the one-wave refinements (round 5).
-        a = fma(th2, fma(th2, fma(th2, fma(th2, fma(th2, fma(th2, fma(th2, -1.0 / 1307674368000.0, 1.0 / 6227020800.0), -1.0 / 39916800.0),
-                1.0 / 362880.0), -1.0 / 5040.0), 1.0 / 120.0), -1.0 / 6.0), 1.0);
-        b = fma(th2, fma(th2, fma(th2, fma(th2, fma(th2, fma(th2, fma(th2, -1.0 / 20922789888000.0, 1.0 / 87178291200.0), -1.0 / 479001600.0),
-                1.0 / 3628800.0), -1.0 / 40320.0), 1.0 / 720.0), -1.0 / 24.0), 0.5);
-    } else {
-        const double th = sqrt(th2);
-        a = sin(th) / th; b = (1.0 - cos(th)) / th2;
-    }
+    mqs::so3_exp_factors(th2, a, b);               // series for a step's small rotation (so3_math.h)
     const double K[9] = {0.0, -w[2], w[1], w[2], 0.0, -w[0], -w[1], w[0], 0.0};
 #pragma unroll
     for (int i = 0; i < 3; ++i)

@@ -30,6 +30,7 @@
 // which the 112 KB of LDS per workgroup enforces).  No fence anywhere.  Every wait is bounded (2 s) and a wait that gives up
 // ends the launch with status 1.
 #include "mqs_common.h"
+#include "so3_math.h"
 #include "ba_math.h"
 #include "chol_block.h"
 #include "wave_reduce.h"
@@ -190,18 +191,16 @@ __device__ __forceinline__ void pose12_to_w2c(const double *q, double *M)
 
 __device__ __forceinline__ void so3_log(const double *R, double w[3])
 {
-    double cs = 0.5 * (R[0] + R[4] + R[8] - 1.0);
-    cs = fmin(1.0, fmax(-1.0, cs));
-    const double th = acos(cs);
-    const double k = (th < 1e-10) ? 0.5 : th / (2.0 * sin(th));
-    w[0] = k * (R[7] - R[5]); w[1] = k * (R[2] - R[6]); w[2] = k * (R[3] - R[1]);
+    const double vx = R[7] - R[5], vy = R[2] - R[6], vz = R[3] - R[1];
+    const double k = mqs::so3_log_factor(0.5 * (R[0] + R[4] + R[8] - 1.0), 0.25 * fma(vx, vx, fma(vy, vy, vz * vz)));
+    w[0] = k * vx; w[1] = k * vy; w[2] = k * vz;
 }
 
 __device__ __forceinline__ void retract_pose(const double *T, const double *dp, double *O)
 {
-    const double th2 = dp[0] * dp[0] + dp[1] * dp[1] + dp[2] * dp[2], th = sqrt(th2);
+    const double th2 = dp[0] * dp[0] + dp[1] * dp[1] + dp[2] * dp[2];
     double a, bq;
-    if (th < 1e-10) { a = 1.0; bq = 0.5; } else { a = sin(th) / th; bq = (1.0 - cos(th)) / th2; }
+    mqs::so3_exp_factors(th2, a, bq);
     const double K[9] = {0, -dp[2], dp[1], dp[2], 0, -dp[0], -dp[1], dp[0], 0};
     double E[9];
     for (int r = 0; r < 3; ++r)
