@@ -380,9 +380,14 @@ __device__ void homography_refine_wave(const double *__restrict__ u1, const doub
         bool accepted = false;
         double hn[8], err2 = 0.0, dn = 0.0;
         while (lam <= 16) {
-            double scale = 1.0;
-            for (int q = 0; q < (lam < 0 ? -lam : lam); ++q) scale *= 10.0;
-            const double damp = 1.0 + (lam < 0 ? 1.0 / scale : scale);
+            // 10^|lam| by its binary digits (|lam| <= 16; every factor and product exact, as the loop of |lam| multiplications was)
+            const int al = lam < 0 ? -lam : lam;
+            double scale = (al & 1) ? 10.0 : 1.0;
+            if (al & 2) scale *= 100.0;
+            if (al & 4) scale *= 1e4;
+            if (al & 8) scale *= 1e8;
+            if (al & 16) scale *= 1e16;
+            const double damp = 1.0 + (lam < 0 ? mqs::rcp(scale) : scale);
             // Cholesky of A with the diagonal scaled; the step solves (A + lambda diag A) step = g.  Reciprocal square roots of the
             // pivots, no division anywhere: the fifty fp64 divisions of the textbook form were most of the refinement's 30 us
             double Lm[8][8], ri[8], yv[8], st[8];
