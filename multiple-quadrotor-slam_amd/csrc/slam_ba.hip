@@ -125,6 +125,8 @@ __device__ __forceinline__ double *lds_red() { return g_sm + 2 * kMaxPoses * kCa
 __device__ __forceinline__ int *lds_flag() { return reinterpret_cast<int *>(g_sm + 2 * kMaxPoses * kCamStride + 6 * kMaxPoses + 32 + 32); }
 
 __device__ __forceinline__ int tix(int bi, int bj) { return bi * (bi + 1) / 2 + bj; }
+// square root for the triangular-index decodes (x >= 1; the callers correct the last unit): x * rsqrt(x) by Newton steps
+__device__ __forceinline__ double tri_root(double x) { return x * mqs::rsqrt_d(x); }
 
 // every workgroup of the launch has arrived (and everything it stored with stg before is visible to ldg afterwards); false: a
 // wait gave up somewhere -- the caller returns
@@ -613,7 +615,7 @@ __device__ __forceinline__ void phase_system(Cx &c, double lambda)
     if (t < ntask) { off_next = ldg(c.b.blk_off + t); cnt_next = ldg(c.b.blk_cnt + t); }      // (a diagonal task's pair is not used)
     for (; t < ntask; t += c.G * 4) {
         // t -> (jb, ja), ja <= jb: t = jb (jb + 1) / 2 + ja
-        int jb = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+        int jb = (int)((tri_root(8.0 * (double)t + 1.0) - 1.0) * 0.5);
         while (jb * (jb + 1) / 2 > t) --jb;
         while ((jb + 1) * (jb + 2) / 2 <= t) ++jb;
         const int ja = t - jb * (jb + 1) / 2;
@@ -798,7 +800,7 @@ __device__ __forceinline__ void chol_task(Cx &c, int k, int bi, int bj, double *
     for (int u = 0; u < 4; ++u) {
         const int e = c.tid + u * kT, a = e >> 5, bq = e & 31;
         // the diagonal tile's strictly upper triangle is inv(L)'s strictly lower one, transposed; its diagonal is L's
-        sLi[bq * TLD + a] = (bq > a) ? dv[u] : ((bq == a) ? 1.0 / dv[u] : 0.0);
+        sLi[bq * TLD + a] = (bq > a) ? dv[u] : ((bq == a) ? mqs::rcp(dv[u]) : 0.0);      // (Newton reciprocal: the IEEE division sat in front of every task's first product)
         sAi[a * TLD + bq] = ai[u];
         sAj[a * TLD + bq] = aj[u];
     }
@@ -844,7 +846,7 @@ __device__ __forceinline__ bool phase_cholesky(Cx &c, double *sBuf, int32_t *bad
         const int m = c.nt - 1 - k, ntask = m * (m + 1) / 2;
         // task 0 = the next diagonal tile (the long one: it ends with a factorisation) on workgroup 0 alone, the others spread
         for (int t = (c.G == 1 ? 0 : (c.wg == 0 ? 0 : c.wg)); t < ntask; t += (c.G == 1 ? 1 : (c.wg == 0 ? ntask : c.G - 1))) {
-            int a = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+            int a = (int)((tri_root(8.0 * (double)t + 1.0) - 1.0) * 0.5);
             while (a * (a + 1) / 2 > t) --a;
             while ((a + 1) * (a + 2) / 2 <= t) ++a;
             const int bq = t - a * (a + 1) / 2;
@@ -893,7 +895,7 @@ __device__ __forceinline__ void bs_step(Cx &c, int kb, int lo, const BsRow &r, d
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int e = c.tid + u * kT, a = e >> 5, bq = e & 31;
-        sLi[a * TLD + bq] = (bq > a) ? r.diag[u] : ((bq == a) ? 1.0 / r.diag[u] : 0.0);
+        sLi[a * TLD + bq] = (bq > a) ? r.diag[u] : ((bq == a) ? mqs::rcp(r.diag[u]) : 0.0);
     }
     __syncthreads();
     if (c.tid < TB) {
