@@ -105,8 +105,18 @@ __global__ __launch_bounds__(256) void frame_filter_kernel(SlamDev d, SlamParams
         d.res[R_NTRI] = (double)n_tri;
     }
     if (reason) return;
-    // minimal samples without replacement, one hypothesis per thread and pass
+    // minimal samples without replacement, one hypothesis per thread and pass.  x mod n_tri of the 64-bit draws through three exact
+    // small remainders in double arithmetic (n_tri <= kMaxTracks: every operand below 2^33) -- the same values as the 64-bit `%`, whose
+    // software division was ~150 instructions per pick on each thread's chain.
     const int frame = d.cnt[C_FRAME];
+    const double inv_nt = 1.0 / (double)n_tri;
+    auto small_mod = [&](unsigned long long y) {                   // y < 2^53
+        long long r = (long long)y - (long long)((unsigned long long)((double)y * inv_nt)) * (long long)n_tri;
+        r += r < 0 ? n_tri : 0;
+        r -= r >= n_tri ? n_tri : 0;
+        return (unsigned long long)r;
+    };
+    const unsigned long long two32_mod = small_mod(1ull << 32);
     for (int h = tid; h < kHyp; h += 256) {
         unsigned long long s = p.seed ^ ((unsigned long long)frame << 24) ^ ((unsigned long long)h * 0x632be59bd9b4e019ull);
         int pick[kSample];
@@ -115,7 +125,8 @@ __global__ __launch_bounds__(256) void frame_filter_kernel(SlamDev d, SlamParams
             int v;
             bool dup;
             do {
-                v = (int)(splitmix64(s) % (unsigned long long)n_tri);
+                const unsigned long long x = splitmix64(s);
+                v = (int)small_mod(small_mod(x >> 32) * two32_mod + small_mod(x & 0xffffffffull));
                 dup = false;
 #pragma unroll
                 for (int q = 0; q < kSample; ++q) dup = dup || (q < j && pick[q] == v);
