@@ -763,14 +763,31 @@ __device__ __forceinline__ float bilinear_u8(const uint8_t *__restrict__ a, int 
 #define MQS_LK_WAVES 4
 #endif
 constexpr int kLkWaves = MQS_LK_WAVES;
+// wave_reduce.h's sum2 without its last step: the sum of x in every lane 0..31, the sum of y in every lane 32..63 (same pairs, same bits)
+__device__ __forceinline__ double lk_sum2_halves(double x, double y)
+{
+    mqs::wave::swap32(x, y);
+    double t = x + y;
+    double a = t, b = t;
+    mqs::wave::swap16(a, b);
+    t = a + b;
+    t += mqs::wave::xor_lane<8>(t);
+    t += mqs::wave::xor_lane<4>(t);
+    t += mqs::wave::xor_lane<2>(t);
+    t += mqs::wave::xor_lane<1>(t);
+    return t;
+}
+
 template <int NW>
 __device__ __forceinline__ void lk_block_sum2(double x, double y, double &sx, double &sy, double *sRed, int &slot, int wave, int lane)
 {
-    mqs::wave::sum2(x, y, sx, sy);
-    if (NW > 1) {
+    if (NW == 1) { mqs::wave::sum2(x, y, sx, sy); return; }
+    {
+        // lanes 0 and 32 hold the wavefront's two totals after the butterfly: they store them themselves (no v_readlane round trip)
+        const double t = lk_sum2_halves(x, y);
         double *r = sRed + (slot & 1) * 2 * NW;
         slot += 1;
-        if (lane == 0) { r[2 * wave] = sx; r[2 * wave + 1] = sy; }
+        if ((lane & 31) == 0) r[2 * wave + (lane >> 5)] = t;
         __syncthreads();
         sx = 0.0; sy = 0.0;
 #pragma unroll
@@ -830,11 +847,24 @@ __global__ __launch_bounds__(64 * NW) void lk_kernel(LkLevels L, const float *__
             const float w00 = (1.0f - a) * (1.0f - b), w01 = a * (1.0f - b), w10 = (1.0f - a) * b, w11 = a * b;
             const uint8_t *I = L.I[level] + ipy * P + ipx;
             const short2 *dI = L.dI[level] + ipy * P + ipx;
+            // (as in the iterations below: every load of the set-up in flight before the first is used)
+            int i00[kPix], i01[kPix], i10[kPix], i11[kPix];
+            int e00[kPix], e01[kPix], e10[kPix], e11[kPix];        // the four derivative pairs as their 32-bit words
 #pragma unroll
             for (int t = 0; t < kPix; ++t) {
                 const uint8_t *q = I + woff[t];
-                const float iv = ((((float)q[0] * w00 + (float)q[1] * w01) + (float)q[P] * w10) + (float)q[P + 1] * w11) * 32.0f;
-                const short2 d00 = dI[woff[t]], d01 = dI[woff[t] + 1], d10 = dI[woff[t] + P], d11 = dI[woff[t] + P + 1];
+                i00[t] = q[0]; i01[t] = q[1]; i10[t] = q[P]; i11[t] = q[P + 1];
+                const int *dw = reinterpret_cast<const int *>(dI + woff[t]);
+                e00[t] = dw[0]; e01[t] = dw[1]; e10[t] = dw[P]; e11[t] = dw[P + 1];
+            }
+#pragma unroll
+            for (int t = 0; t < kPix; ++t)
+                asm volatile("" : "+v"(i00[t]), "+v"(i01[t]), "+v"(i10[t]), "+v"(i11[t]), "+v"(e00[t]), "+v"(e01[t]), "+v"(e10[t]), "+v"(e11[t]));
+#pragma unroll
+            for (int t = 0; t < kPix; ++t) {
+                const float iv = ((((float)i00[t] * w00 + (float)i01[t] * w01) + (float)i10[t] * w10) + (float)i11[t] * w11) * 32.0f;
+                const short2 d00 = make_short2((short)(e00[t] & 0xffff), (short)(e00[t] >> 16)), d01 = make_short2((short)(e01[t] & 0xffff), (short)(e01[t] >> 16));
+                const short2 d10 = make_short2((short)(e10[t] & 0xffff), (short)(e10[t] >> 16)), d11 = make_short2((short)(e11[t] & 0xffff), (short)(e11[t] >> 16));
                 const float ix = (((float)d00.x * w00 + (float)d01.x * w01) + (float)d10.x * w10) + (float)d11.x * w11;
                 const float iy = (((float)d00.y * w00 + (float)d01.y * w01) + (float)d10.y * w10) + (float)d11.y * w11;
                 Iw[t] = win[t] ? iv : 0.0f; Ixw[t] = win[t] ? ix : 0.0f; Iyw[t] = win[t] ? iy : 0.0f;
@@ -867,10 +897,19 @@ __global__ __launch_bounds__(64 * NW) void lk_kernel(LkLevels L, const float *__
             const float w00 = (1.0f - a) * (1.0f - b), w01 = a * (1.0f - b), w10 = (1.0f - a) * b, w11 = a * b;
             const uint8_t *Jw = J + iny * P + inx;
             double b1 = 0.0, b2 = 0.0;
+            // all of the iteration's window bytes requested before the first is used: the compiler otherwise sinks each pixel's loads into
+            // the branch its `win` select becomes and waits for them there, one L1 round trip per pixel of the thread (ISA listing, round 5)
+            int j00[kPix], j01[kPix], j10[kPix], j11[kPix];
 #pragma unroll
             for (int t = 0; t < kPix; ++t) {
                 const uint8_t *q = Jw + woff[t];
-                const float jv = (((float)q[0] * w00 + (float)q[1] * w01) + (float)q[P] * w10) + (float)q[P + 1] * w11;
+                j00[t] = q[0]; j01[t] = q[1]; j10[t] = q[P]; j11[t] = q[P + 1];
+            }
+#pragma unroll
+            for (int t = 0; t < kPix; ++t) asm volatile("" : "+v"(j00[t]), "+v"(j01[t]), "+v"(j10[t]), "+v"(j11[t]));
+#pragma unroll
+            for (int t = 0; t < kPix; ++t) {
+                const float jv = (((float)j00[t] * w00 + (float)j01[t] * w01) + (float)j10[t] * w10) + (float)j11[t] * w11;
                 const float diff = win[t] ? jv * 32.0f - Iw[t] : 0.0f;
                 b1 += (double)diff * (double)Ixw[t];
                 b2 += (double)diff * (double)Iyw[t];
