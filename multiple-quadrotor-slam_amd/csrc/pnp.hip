@@ -208,8 +208,17 @@ __global__ __launch_bounds__(kWave) void pnp_hypothesis_kernel(const double *__r
         }
     }
     if (lane < 9) sI[lane] = intr[lane];
+    // the sample's correspondences into LDS once: the DLT's four passes and every evaluation of the refinement then read LDS instead
+    // of going to the vector cache for the same six points (a round trip on the hypothesis' chain each time)
+    __shared__ double sObj[3 * kWave], sImg[2 * kWave];
+    const bool staged = sample_size <= kWave;
+    if (staged && lane < sample_size) {
+        const int i = samples[h * sample_size + lane];
+        sObj[3 * lane] = objp[3 * i]; sObj[3 * lane + 1] = objp[3 * i + 1]; sObj[3 * lane + 2] = objp[3 * i + 2];
+        sImg[2 * lane] = imgp[2 * i]; sImg[2 * lane + 1] = imgp[2 * i + 1];
+    }
     __syncthreads();
-    const Problem pr = {objp, imgp, samples, h * sample_size, (h + 1) * sample_size};
+    const Problem pr = staged ? Problem{sObj, sImg, nullptr, 0, sample_size} : Problem{objp, imgp, samples, h * sample_size, (h + 1) * sample_size};
     double P[12];
     int count = -1;
     if (wave_dlt(pr, sI, lane, sA, P)) {
