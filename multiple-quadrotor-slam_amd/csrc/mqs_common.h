@@ -107,7 +107,8 @@ int mqs_lk_launch(const uint8_t *prev_img, const uint8_t *next_img, int W, int H
 int mqs_pnp_ransac_launch(const double *objp, const double *imgp, int N, const int32_t *n_dev, const double *intr,
                           const int32_t *samples, int B, int sample_size, double reproj_error, int sample_iters, int max_iter,
                           double eps, double *pose_out, int32_t *sel_out, uint8_t *mask, double *info, void *workspace,
-                          hipStream_t stream);
+                          hipStream_t stream, int end_in_caller);
+void mqs_pnp_workspace_layout(void *workspace, int B, double **poses, int32_t **counts, int32_t **inlier_idx);
 int mqs_keyframe_step_launch(const double *objp, const double *imgp, int n_old, const double *p0, const double *p1, int n_new,
                              const double *intr, const double *P_prev, const double *P0, double tolerance, int max_iter, double eps,
                              double second_pass_screen_px, double *scratch, double *pose_out, double *x_out, int32_t *status_out, double *info,

@@ -15,6 +15,7 @@
 #include "mqs_common.h"
 #include "pnp_math.h"
 #include "wave_reduce.h"
+#include "pnp_block.h"
 #include "cam_math.h"
 
 namespace {
@@ -239,58 +240,8 @@ __global__ __launch_bounds__(kWave) void pnp_hypothesis_kernel(const double *__r
     if (lane == 0) counts[h] = count;
 }
 
-constexpr int kKfThreads = 256;                   // four waves share a frame: <= 300 correspondences are one or two sweeps
-constexpr int kKfWaves = kKfThreads / kWave;
+using namespace mqs::pnpblk;          // kKfThreads, block_sum_acc, BlockEval, select_refine_block (pnp_block.h)
 
-// The 28 sums of an evaluation over the WORKGROUP (kKfThreads threads), in a fixed order; every thread ends with the same sums, so the
-// Levenberg-Marquardt loop around it runs redundantly and in step in all of them.  Per wave the transposed reduction of wave_reduce.h
-// (32 exchange-and-add steps, lane 2 e ends with entry e) instead of 28 butterflies of six steps each: with one or two points per
-// thread the butterflies were three quarters of an evaluation's instructions.  red: LDS [kKfWaves][kAcc].
-__device__ __forceinline__ void block_sum_acc(double *acc, double *red, int tid)
-{
-    double v[32];
-#pragma unroll
-    for (int k = 0; k < 32; ++k) v[k] = k < kAcc ? acc[k] : 0.0;
-    const double tot = mqs::wave::wave_reduce32(v, tid & 63);
-    __syncthreads();                              // the previous call's sums have been read by everyone
-    if (!(tid & 1) && ((tid & 63) >> 1) < kAcc) red[(tid >> 6) * kAcc + ((tid & 63) >> 1)] = tot;
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < kAcc; ++k) {
-        double t = red[k];
-#pragma unroll
-        for (int w = 1; w < kKfWaves; ++w) t += red[w * kAcc + k];
-        acc[k] = t;
-    }
-}
-
-// eval over the points idx[0..n) of (objp, imgp) -- idx null: 0..n -- by the whole workgroup
-struct BlockEval {
-    const double *objp, *imgp;
-    const int32_t *idx;
-    int n;
-    const double *intr;
-    double *red;
-    int tid;
-    __device__ __forceinline__ void operator()(const double *P, double *acc) const
-    {
-#pragma unroll
-        for (int k = 0; k < kAcc; ++k) acc[k] = 0.0;
-        for (int k = tid; k < n; k += kKfThreads) {
-            const int i = idx ? idx[k] : k;
-            accumulate_point(P, intr, objp[3 * i], objp[3 * i + 1], objp[3 * i + 2], imgp[2 * i], imgp[2 * i + 1], acc);
-        }
-        block_sum_acc(acc, red, tid);
-    }
-};
-
-// The end of solvePnPRansac in ONE launch of one workgroup (round 5; a 256-thread selection kernel and a one-wave refinement kernel
-// before: 4.8 + 20.8 us and a launch gap per frame): picks the hypothesis with the most inliers (lowest index on ties), marks and
-// compacts its inliers in index order -- into LDS when they fit (lds_ok: 40 bytes per correspondence), else as an index list in
-// global memory -- and refines the pose on them (OpenCV 2.4: solvePnP on the inliers, started from the best model) with the sums
-// of an evaluation taken by four wavefronts (block_sum_acc; the keyframe step's form).
-// out_sel: [0] best hypothesis (-1: none valid), [1] inlier count.  info: as pnp_refine_kernel's.
-constexpr int kSelBlock = kKfThreads;
 __global__ __launch_bounds__(kSelBlock) void pnp_select_refine_kernel(const double *__restrict__ objp, const double *__restrict__ imgp,
                                                                      int N, const int32_t *__restrict__ n_dev,
                                                                      const double *__restrict__ intr,
@@ -300,80 +251,8 @@ __global__ __launch_bounds__(kSelBlock) void pnp_select_refine_kernel(const doub
                                                                      int32_t *__restrict__ inlier_idx, uint8_t *__restrict__ mask,
                                                                      double *__restrict__ info)
 {
-    __shared__ double sI[9], sP[12];
-    __shared__ double sRed[kKfWaves * kAcc];
-    __shared__ int sBestC[kSelBlock], sBestH[kSelBlock], sWave[kSelBlock / 64], sBase;
     extern __shared__ __attribute__((aligned(16))) double sel_lds[];     // the inliers' coordinates when they fit (lds_ok)
-    const int tid = threadIdx.x;
-    if (n_dev) N = *n_dev;
-    if (tid < 9) sI[tid] = intr[tid];
-    int bc = -1, bh = -1;
-    for (int h = tid; h < B; h += kSelBlock)
-        if (counts[h] > bc) { bc = counts[h]; bh = h; }
-    sBestC[tid] = bc; sBestH[tid] = bh;
-    __syncthreads();
-    for (int s = kSelBlock / 2; s >= 1; s >>= 1) {
-        if (tid < s) {
-            const int c2 = sBestC[tid + s], h2 = sBestH[tid + s];
-            if (c2 > sBestC[tid] || (c2 == sBestC[tid] && h2 >= 0 && (sBestH[tid] < 0 || h2 < sBestH[tid]))) {
-                sBestC[tid] = c2; sBestH[tid] = h2;
-            }
-        }
-        __syncthreads();
-    }
-    const int best = sBestH[0];
-    if (tid < 12) sP[tid] = best >= 0 ? poses[12 * best + tid] : ((tid % 5 == 0) ? 1.0 : 0.0);
-    if (tid == 0) sBase = 0;
-    __syncthreads();
-    double *so = sel_lds, *si = sel_lds + 3 * (size_t)(lds_ok ? N : 0);
-    for (int base = 0; base < N; base += kSelBlock) {
-        const int i = base + tid;
-        bool in = false;
-        double X = 0, Y = 0, Z = 0, u = 0, v = 0;
-        if (i < N && best >= 0) {
-            X = objp[3 * i]; Y = objp[3 * i + 1]; Z = objp[3 * i + 2]; u = imgp[2 * i]; v = imgp[2 * i + 1];
-            const double Zc = fma(sP[8], X, fma(sP[9], Y, fma(sP[10], Z, sP[11])));
-            const double e2 = reproj_sqerr(sP, sI, X, Y, Z, u, v);
-            in = Zc > 0.0 && e2 <= thr2;
-        }
-        if (i < N && mask) mask[i] = in ? 1 : 0;
-        const unsigned long long bal = __ballot(in);
-        const int lane = tid & 63, wave = tid >> 6;
-        const int before = __popcll(bal & ((1ull << lane) - 1ull));
-        if (lane == 0) sWave[wave] = __popcll(bal);
-        __syncthreads();
-        int off = sBase;
-        for (int w = 0; w < wave; ++w) off += sWave[w];
-        if (in) {
-            const int r = off + before;
-            if (lds_ok) { so[3 * r] = X; so[3 * r + 1] = Y; so[3 * r + 2] = Z; si[2 * r] = u; si[2 * r + 1] = v; }
-            else inlier_idx[r] = i;
-        }
-        __syncthreads();
-        if (tid == 0) sBase += sWave[0] + sWave[1] + sWave[2] + sWave[3];
-        __syncthreads();
-    }
-    const int n_in = sBase;
-    if (tid == 0) { out_sel[0] = best; out_sel[1] = n_in; }
-    double P[12];
-#pragma unroll
-    for (int k = 0; k < 12; ++k) P[k] = sP[k];
-    if (n_in < 3) {                                  // no problem (no valid model, or a rejected frame of the device-resident loop): the start pose
-        if (tid < 12) pose_out[tid] = P[tid];
-        if (info && tid < 4) info[tid] = tid == 3 ? 2.0 : 0.0;
-        return;
-    }
-    if (!lds_ok) __threadfence_block();              // the index list written above is read below by other threads of the workgroup
-    __syncthreads();
-    BlockEval ev = {lds_ok ? so : objp, lds_ok ? si : imgp, lds_ok ? nullptr : inlier_idx, n_in, sI, sRed, tid};
-    const LmResult r = lm_refine(ev, P, max_iter, eps);
-    if (tid < 12) pose_out[tid] = P[tid];
-    if (info && tid == 0) {
-        info[0] = r.sqerr;
-        info[1] = (double)r.iters;
-        info[2] = (double)n_in;
-        info[3] = r.converged ? 1.0 : 0.0;
-    }
+    select_refine_block(objp, imgp, N, n_dev, intr, poses, counts, B, thr2, max_iter, eps, lds_ok, pose_out, out_sel, inlier_idx, mask, info, sel_lds);
 }
 
 int check_points(const double *objp, const double *imgp, int64_t N, const double *intr)
@@ -578,33 +457,43 @@ int mqs_pnp_ransac_dev(const double *objp, const double *imgp, int64_t N, const 
     MQS_ARG_CHECK(pose_out && sel_out, "pose_out, sel_out must not be null");
     MQS_ARG_CHECK(workspace && workspace_bytes >= mqs_pnp_workspace_bytes(N, B), "workspace too small (mqs_pnp_workspace_bytes)");
     return mqs_pnp_ransac_launch(objp, imgp, (int)N, nullptr, intr, samples, B, sample_size, reproj_error, sample_iters, max_iter, eps,
-                                 pose_out, sel_out, mask, info, workspace, static_cast<hipStream_t>(stream_));
+                                 pose_out, sel_out, mask, info, workspace, static_cast<hipStream_t>(stream_), 0);
 }
 
 }  // extern "C"
 
 // N = capacity (workspace sized for it); n_dev (device, may be null): the live number of correspondences
-int mqs_pnp_ransac_launch(const double *objp, const double *imgp, int N, const int32_t *n_dev, const double *intr,
-                          const int32_t *samples, int B, int sample_size, double reproj_error, int sample_iters, int max_iter,
-                          double eps, double *pose_out, int32_t *sel_out, uint8_t *mask, double *info, void *workspace,
-                          hipStream_t stream)
+void mqs_pnp_workspace_layout(void *workspace, int B, double **poses, int32_t **counts, int32_t **inlier_idx)
 {
     auto up = [](int64_t v) { return (v + 255) & ~int64_t(255); };
     char *w = static_cast<char *>(workspace);
-    double *poses = reinterpret_cast<double *>(w); w += up((int64_t)B * 96);
-    int32_t *counts = reinterpret_cast<int32_t *>(w); w += up((int64_t)B * 4);
-    int32_t *ptr2 = reinterpret_cast<int32_t *>(w); w += up(8);
-    int32_t *inl = reinterpret_cast<int32_t *>(w);
+    *poses = reinterpret_cast<double *>(w); w += up((int64_t)B * 96);
+    *counts = reinterpret_cast<int32_t *>(w); w += up((int64_t)B * 4);
+    w += up(8);
+    *inlier_idx = reinterpret_cast<int32_t *>(w);
+}
+
+// end_in_caller: only the hypotheses are launched; the caller runs select_refine_block (pnp_block.h) in a kernel of its own (the
+// device-resident loop: inside its decision kernel)
+int mqs_pnp_ransac_launch(const double *objp, const double *imgp, int N, const int32_t *n_dev, const double *intr,
+                          const int32_t *samples, int B, int sample_size, double reproj_error, int sample_iters, int max_iter,
+                          double eps, double *pose_out, int32_t *sel_out, uint8_t *mask, double *info, void *workspace,
+                          hipStream_t stream, int end_in_caller)
+{
+    double *poses;
+    int32_t *counts, *inl;
+    mqs_pnp_workspace_layout(workspace, B, &poses, &counts, &inl);
     const double thr2 = reproj_error * reproj_error;
     hipLaunchKernelGGL(pnp_hypothesis_kernel, dim3(B), dim3(kWave), 0, stream, objp, imgp, N, n_dev, intr, samples,
                        sample_size, sample_iters, thr2, poses, counts);
-    // best hypothesis, its inliers (-> mask), and OpenCV 2.4 solvePnPRansac's end -- solvePnP on the inliers, started from the best model --
-    // in one launch; the inliers' coordinates in LDS when N correspondences fit (40 bytes each)
-    const size_t lds_bytes = (size_t)N * 40;
-    const bool lds_ok = lds_bytes <= 40 * 1024;
-    (void)ptr2;
-    hipLaunchKernelGGL(pnp_select_refine_kernel, dim3(1), dim3(kSelBlock), lds_ok ? lds_bytes : 0, stream, objp, imgp, N, n_dev, intr, poses,
-                       counts, B, thr2, max_iter, eps, (int)lds_ok, pose_out, sel_out, inl, mask, info);
+    if (!end_in_caller) {
+        // best hypothesis, its inliers (-> mask), and OpenCV 2.4 solvePnPRansac's end -- solvePnP on the inliers, started from the best model --
+        // in one launch; the inliers' coordinates in LDS when N correspondences fit (40 bytes each)
+        const size_t lds_bytes = (size_t)N * 40;
+        const bool lds_ok = lds_bytes <= 40 * 1024;
+        hipLaunchKernelGGL(pnp_select_refine_kernel, dim3(1), dim3(kSelBlock), lds_ok ? lds_bytes : 0, stream, objp, imgp, N, n_dev, intr, poses,
+                           counts, B, thr2, max_iter, eps, (int)lds_ok, pose_out, sel_out, inl, mask, info);
+    }
     MQS_HIP_CHECK(hipGetLastError());
     return MQS_OK;
 }

@@ -19,6 +19,7 @@
 // them there: mqs_slam_set_thresholds(.., max_homography_points) switches that on, drawn from the device generator), RANSAC samples come from a counter-based generator on the device (splitmix64 of seed, frame, hypothesis).
 #include "mqs_common.h"
 #include "pnp_math.h"
+#include "pnp_block.h"
 #include "cam_math.h"
 #include "wave_reduce.h"
 #include "slam_state.h"
@@ -714,6 +715,13 @@ __device__ __forceinline__ void frame_decide_body(const SlamDev &d, const SlamPa
 // copy and a fill launch per frame did before (5 + 4 us of the frame's ~230).
 __global__ __launch_bounds__(256) void frame_decide_kernel(SlamDev d, SlamParams p)
 {
+    // the end of solvePnPRansac first (pnp_block.h: best hypothesis, its inliers into LDS, refinement by four wavefronts) -- a launch
+    // of its own before, with a launch gap on either side
+    extern __shared__ __attribute__((aligned(16))) double decide_lds[];
+    mqs::pnpblk::select_refine_block(d.objp_t, d.imgp_t, kMaxTracks, d.cnt + C_NTRI, d.intr, d.pnp_poses, d.pnp_counts, kHyp, p.max_reproj * p.max_reproj,
+                                     kPnpIters, kPnpEps, 1, d.pose_r, d.sel, d.pnp_inl, d.inl_mask, d.pnp_info, decide_lds);
+    __threadfence_block();
+    __syncthreads();
     frame_decide_body(d, p);
     __syncthreads();
     const int tid = threadIdx.x;
@@ -987,6 +995,7 @@ int mqs_slam_create(int device, int W, int H, const double *intr, int target_key
     d.kf_info = (double *)(a + o_kinfo); d.kf_status = (int32_t *)(a + o_kst); d.mask = (uint8_t *)(a + o_mask); d.gf_xy = (float *)(a + o_gxy);
     d.gf_n = (int32_t *)(a + o_gn); d.res = (double *)(a + o_res);
     s->ws_lk = a + o_wl; s->ws_gftt = a + o_wg; s->ws_pnp = a + o_wp;
+    mqs_pnp_workspace_layout(s->ws_pnp, kHyp, &d.pnp_poses, &d.pnp_counts, &d.pnp_inl);
     e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipHostMalloc((void **)&s->res_host, kRes * 8, hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&d.res_out, s->res_host, 0);
@@ -1173,9 +1182,9 @@ int mqs_slam_track(mqs_slam *s, const uint8_t *prev_img_dev, const uint8_t *img_
     if (rc != MQS_OK) return rc;
     hipLaunchKernelGGL(frame_filter_kernel, dim3(1), dim3(256), 0, s->stream, d, s->p);
     rc = mqs_pnp_ransac_launch(d.objp_t, d.imgp_t, kMaxTracks, d.cnt + C_NTRI, d.intr, d.samples, kHyp, kSample, s->p.max_reproj,
-                               kSampleIters, kPnpIters, kPnpEps, d.pose_r, d.sel, d.inl_mask, d.pnp_info, s->ws_pnp, s->stream);
+                               kSampleIters, kPnpIters, kPnpEps, d.pose_r, d.sel, d.inl_mask, d.pnp_info, s->ws_pnp, s->stream, 1);
     if (rc != MQS_OK) return rc;
-    hipLaunchKernelGGL(frame_decide_kernel, dim3(1), dim3(256), 0, s->stream, d, s->p);
+    hipLaunchKernelGGL(frame_decide_kernel, dim3(1), dim3(256), (size_t)kMaxTracks * 40, s->stream, d, s->p);
     MQS_HIP_CHECK(hipGetLastError());
     // (the decision kernel has written the result block into s->res_host and cleared the previous keyframe's flag on the device)
     MQS_HIP_CHECK(hipStreamSynchronize(s->stream));

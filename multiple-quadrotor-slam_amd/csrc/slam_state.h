@@ -40,6 +40,8 @@ struct SlamDev {
     uint8_t *mask;
     float *gf_xy;
     int32_t *gf_n;
+    double *pnp_poses;               // the RANSAC workspace's pieces the decision kernel reads (mqs_pnp_workspace_layout)
+    int32_t *pnp_counts, *pnp_inl;
     double *res;
     double *res_out;                 // the pinned host block the decision kernel leaves a copy of `res` in (no copy / fill launches per frame)
     // the observation log for the bundle adjuster (mqs_slam_log_enable; null: off): what slam2.py's BundleAdjustmentInfoContainer is
