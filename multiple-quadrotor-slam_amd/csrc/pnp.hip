@@ -23,128 +23,7 @@ namespace {
 using namespace mqs::pnp;
 
 constexpr int kWave = 64;
-
-__device__ __forceinline__ double wave_sum(double v) { return mqs::wave::sum1(v); }     // the butterfly's pairs, no ds_bpermute
-
-// K sums over the wavefront, every lane ending with all of them: chunks of 32 through the transposed reduction of
-// wave_reduce.h (32 exchange-and-add steps per chunk; lane 2 e ends with entry e), then through 32 doubles of LDS (`scr`, the
-// wave's own) back to every lane as broadcast reads -- against K butterflies of six exchange steps each.  (Broadcasting with
-// v_readlane pairs instead kept up to 102 scalar registers alive: 177 spilled SGPRs in the refinement kernel.)
-template <int K>
-__device__ __forceinline__ void wave_sum_all(double (&acc)[K], int lane, double *scr)
-{
-#pragma unroll
-    for (int c0 = 0; c0 < K; c0 += 32) {
-        double v[32];
-#pragma unroll
-        for (int k = 0; k < 32; ++k) v[k] = (c0 + k < K) ? acc[c0 + k] : 0.0;
-        const double tot = mqs::wave::wave_reduce32(v, lane);
-        mqs_wave_lds_sync();                              // earlier readers of scr are done
-        if (!(lane & 1)) scr[lane >> 1] = tot;
-        mqs_wave_lds_sync();
-#pragma unroll
-        for (int k = 0; k < 32; ++k)
-            if (c0 + k < K) acc[c0 + k] = scr[k];
-    }
-}
-
-// One problem's correspondences: points idx[begin..end) of (objp, imgp), or begin..end directly.
-struct Problem {
-    const double *objp, *imgp;
-    const int32_t *idx;
-    int begin, end;
-    __device__ __forceinline__ int point(int k) const { return idx ? idx[k] : k; }
-};
-
-// eval(P, acc): sums of pnp_math.h accumulate_point over the problem, identical in every lane.
-struct WaveEval {
-    Problem pr;
-    const double *intr;     // LDS
-    int lane;
-    double *scr;            // LDS, 32 doubles of the wave's own (wave_sum_all)
-    __device__ __forceinline__ void operator()(const double *P, double *acc) const
-    {
-#pragma unroll
-        for (int k = 0; k < kAcc; ++k) acc[k] = 0.0;
-        for (int k = pr.begin + lane; k < pr.end; k += kWave) {
-            const int i = pr.point(k);
-            accumulate_point(P, intr, pr.objp[3 * i], pr.objp[3 * i + 1], pr.objp[3 * i + 2], pr.imgp[2 * i],
-                             pr.imgp[2 * i + 1], acc);
-        }
-        // (on a six-point RANSAC hypothesis 28 butterflies were most of an evaluation)
-        wave_sum_all(*reinterpret_cast<double (*)[kAcc]>(acc), lane, scr);
-    }
-};
-
-// Direct linear transform start over the problem's points (>= 6); sA: 121 + 11 doubles of LDS per wave.
-// Returns false (in every lane) for a degenerate configuration.
-__device__ bool wave_dlt(const Problem &pr, const double *intr, int lane, double *sA, double *P)
-{
-    const int n = pr.end - pr.begin;
-    double cx = 0.0, cy = 0.0, cz = 0.0;
-    for (int k = pr.begin + lane; k < pr.end; k += kWave) {
-        const int i = pr.point(k);
-        cx += pr.objp[3 * i]; cy += pr.objp[3 * i + 1]; cz += pr.objp[3 * i + 2];
-    }
-    const double inv_n = mqs::rcp((double)n);
-    const double c[3] = {wave_sum(cx) * inv_n, wave_sum(cy) * inv_n, wave_sum(cz) * inv_n};
-    double dist = 0.0;
-    for (int k = pr.begin + lane; k < pr.end; k += kWave) {
-        const int i = pr.point(k);
-        const double dx = pr.objp[3 * i] - c[0], dy = pr.objp[3 * i + 1] - c[1], dz = pr.objp[3 * i + 2] - c[2];
-        const double d2 = fma(dx, dx, fma(dy, dy, dz * dz));
-        dist += d2 > 0.0 ? d2 * mqs::rsqrt_d(d2) : 0.0;
-    }
-    double cov[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    for (int k = pr.begin + lane; k < pr.end; k += kWave) {
-        const int i = pr.point(k);
-        const double dx = pr.objp[3 * i] - c[0], dy = pr.objp[3 * i + 1] - c[1], dz = pr.objp[3 * i + 2] - c[2];
-        cov[0] += dx * dx; cov[1] += dx * dy; cov[2] += dx * dz; cov[3] += dy * dy; cov[4] += dy * dz; cov[5] += dz * dz;
-    }
-#pragma unroll
-    for (int k = 0; k < 6; ++k) cov[k] = wave_sum(cov[k]);
-    double sigma = wave_sum(dist) * inv_n;
-    if (!(sigma > 0.0)) sigma = 1.0;
-    const double is = mqs::rcp(sigma);
-    double ew[3], E[9];
-    sym3_eigen(cov, ew, E);
-    if (ew[2] < 1e-3 * ew[1]) {
-        // planar (OpenCV: W[2] / W[1] < 1e-3): start from the plane-to-image homography (needs >= 4 points)
-        double hacc[kHomAcc];
-#pragma unroll
-        for (int k = 0; k < kHomAcc; ++k) hacc[k] = 0.0;
-        for (int k = pr.begin + lane; k < pr.end; k += kWave) {
-            const int i = pr.point(k);
-            const double dx = pr.objp[3 * i] - c[0], dy = pr.objp[3 * i + 1] - c[1], dz = pr.objp[3 * i + 2] - c[2];
-            double x, y;
-            mqs::cam::undistort_pixel(intr, pr.imgp[2 * i], pr.imgp[2 * i + 1], x, y);
-            hom_accumulate((E[0] * dx + E[1] * dy + E[2] * dz) * is, (E[3] * dx + E[4] * dy + E[5] * dz) * is, x, y, hacc);
-        }
-        wave_sum_all(hacc, lane, sA);
-        // 8 x 8 solve: every lane for itself, the system in registers (chol_solve_fixed)
-        double A8[64], hv[8];
-        hom_assemble(hacc, A8, hv);
-        const bool solved = chol_solve_fixed<8>(A8, hv);
-        const bool posed = pose_from_homography(hv, E, c, sigma, P);
-        return solved && posed;
-    }
-    double acc[kDltAcc];
-#pragma unroll
-    for (int k = 0; k < kDltAcc; ++k) acc[k] = 0.0;
-    for (int k = pr.begin + lane; k < pr.end; k += kWave) {
-        const int i = pr.point(k);
-        double x, y;
-        mqs::cam::undistort_pixel(intr, pr.imgp[2 * i], pr.imgp[2 * i + 1], x, y);
-        dlt_accumulate((pr.objp[3 * i] - c[0]) * is, (pr.objp[3 * i + 1] - c[1]) * is, (pr.objp[3 * i + 2] - c[2]) * is, x, y, acc);
-    }
-    wave_sum_all(acc, lane, sA);
-    // 11 x 11 solve: every lane for itself, the system in registers (chol_solve_fixed)
-    double A11[121], p[11];
-    dlt_assemble(acc, A11, p);
-    const bool solved = chol_solve_fixed<11>(A11, p);
-    const bool posed = pose_from_dlt(p, c, sigma, P);
-    return solved && posed;
-}
+using namespace mqs::pnpblk;          // wave_sum_all, Problem, WaveEval, wave_dlt, hypothesis_wave, block_sum_acc, BlockEval, select_refine_block (pnp_block.h)
 
 // info per problem: [sum of squared residuals, LM iterations, number of correspondences, flags]
 //   flags bit 0: LM stopped on its convergence test; bit 1: DLT start failed (pose_in used instead)
@@ -221,26 +100,10 @@ __global__ __launch_bounds__(kWave) void pnp_hypothesis_kernel(const double *__r
     __syncthreads();
     const Problem pr = staged ? Problem{sObj, sImg, nullptr, 0, sample_size} : Problem{objp, imgp, samples, h * sample_size, (h + 1) * sample_size};
     double P[12];
-    int count = -1;
-    if (wave_dlt(pr, sI, lane, sA, P)) {
-        WaveEval ev = {pr, sI, lane, sA};
-        lm_refine(ev, P, sample_iters, 1e-10);
-        int c = 0;
-        for (int i = lane; i < N; i += kWave) {
-            // behind the camera: never an inlier
-            const double Zc = fma(P[8], objp[3 * i], fma(P[9], objp[3 * i + 1], fma(P[10], objp[3 * i + 2], P[11])));
-            const double e2 = reproj_sqerr(P, sI, objp[3 * i], objp[3 * i + 1], objp[3 * i + 2], imgp[2 * i], imgp[2 * i + 1]);
-            c += (Zc > 0.0 && e2 <= thr2) ? 1 : 0;
-        }
-#pragma unroll
-        for (int s = 32; s >= 1; s >>= 1) c += __shfl_xor(c, s);
-        count = c;
-    }
+    const int count = hypothesis_wave(pr, objp, imgp, N, sI, sample_iters, thr2, sA, lane, P);
     if (lane < 12) poses[12 * h + lane] = P[lane];
     if (lane == 0) counts[h] = count;
 }
-
-using namespace mqs::pnpblk;          // kKfThreads, block_sum_acc, BlockEval, select_refine_block (pnp_block.h)
 
 __global__ __launch_bounds__(kSelBlock) void pnp_select_refine_kernel(const double *__restrict__ objp, const double *__restrict__ imgp,
                                                                      int N, const int32_t *__restrict__ n_dev,

@@ -140,6 +140,111 @@ __global__ __launch_bounds__(256) void frame_filter_kernel(SlamDev d, SlamParams
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// The same filter and the RANSAC hypotheses in ONE launch (round 5): every hypothesis' wavefront compacts the tracked points for
+// itself into LDS -- 300 tracks are five ballots -- instead of waiting for a one-workgroup kernel to do it once (8 us + a launch gap on
+// a frame of ~160), draws its own sample, and counts its inliers on its LDS copy.  Workgroup 0 alone writes the frame's state (the kept
+// tracks, the pose problem, the counters, the result block): the same arrays frame_filter_kernel leaves.  MQS_SLAM_FUSED_FILTER=0 keeps
+// the two launches (A/B, tests).
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void frame_hypothesis_kernel(SlamDev d, SlamParams p)
+{
+    __shared__ double sI[9];
+    __shared__ double sA[132];
+    __shared__ double sObjAll[3 * kMaxTracks], sImgAll[2 * kMaxTracks];
+    __shared__ double sObj[3 * 64], sImg[2 * 64];
+    __shared__ int sPick[kSample];
+    const int lane = threadIdx.x, h = blockIdx.x;
+    const bool writer = h == 0;
+    const int n = d.cnt[C_N];
+    if (lane < 9) sI[lane] = d.intr[lane];
+    int n_keep = 0, n_tri = 0;
+    for (int b = 0; b < n; b += 64) {
+        const int i = b + lane;
+        const bool keep = i < n && d.lk_st[i] == 1 && d.lk_err[i] < (float)p.max_of_error;
+        const int l = keep ? d.lm[i] : -1;
+        const bool tri = l >= 0;
+        const unsigned long long km = __ballot(keep), tm = __ballot(tri), below = (1ull << lane) - 1ull;
+        const int r = n_keep + __popcll(km & below), j = n_tri + __popcll(tm & below);
+        if (keep) {
+            const float px = d.lk_pts[2 * i], py = d.lk_pts[2 * i + 1];
+            if (writer) {
+                d.t_pts[2 * r] = px; d.t_pts[2 * r + 1] = py;
+                d.t_base[2 * r] = d.base[2 * i]; d.t_base[2 * r + 1] = d.base[2 * i + 1];
+                d.t_lm[r] = l; d.t_tid[r] = d.tid[i];
+            }
+            if (tri) {
+                const double X = d.map[3 * l], Y = d.map[3 * l + 1], Z = d.map[3 * l + 2];
+                sObjAll[3 * j] = X; sObjAll[3 * j + 1] = Y; sObjAll[3 * j + 2] = Z;
+                sImgAll[2 * j] = (double)px; sImgAll[2 * j + 1] = (double)py;
+                if (writer) {
+                    d.objp_t[3 * j] = X; d.objp_t[3 * j + 1] = Y; d.objp_t[3 * j + 2] = Z;
+                    d.imgp_t[2 * j] = (double)px; d.imgp_t[2 * j + 1] = (double)py;
+                    d.tri_pos[j] = r;
+                }
+            }
+        }
+        n_keep += __popcll(km); n_tri += __popcll(tm);
+    }
+    const double lost = n > 0 ? 1.0 - (double)n_keep / (double)n : 1.0;
+    int reason = 0;
+    if (lost > p.max_lost_ratio) reason = 1;                       // "lost track of too many points"
+    else if (n_tri < 8) reason = 2;                                // fewer than 8 triangulated tracks
+    if (writer && lane == 0) {
+        d.cnt[C_NKEEP] = n_keep;
+        d.cnt[C_NTRI] = reason ? 0 : n_tri;                        // 0 switches the pose step off
+        d.res[R_DECISION] = reason ? 0.0 : -1.0;                   // -1: undecided
+        d.res[R_REASON] = (double)reason;
+        d.res[R_LOST] = lost;
+        d.res[R_NTRI] = (double)n_tri;
+    }
+    if (reason) {
+        if (lane == 0) d.pnp_counts[h] = -1;
+        return;
+    }
+    // this hypothesis' minimal sample without replacement (the generator and the picks of frame_filter_kernel)
+    if (lane == 0) {
+        const int frame = d.cnt[C_FRAME];
+        const double inv_nt = 1.0 / (double)n_tri;
+        auto small_mod = [&](unsigned long long y) {
+            long long r = (long long)y - (long long)((unsigned long long)((double)y * inv_nt)) * (long long)n_tri;
+            r += r < 0 ? n_tri : 0;
+            r -= r >= n_tri ? n_tri : 0;
+            return (unsigned long long)r;
+        };
+        const unsigned long long two32_mod = small_mod(1ull << 32);
+        unsigned long long s = p.seed ^ ((unsigned long long)frame << 24) ^ ((unsigned long long)h * 0x632be59bd9b4e019ull);
+        int pick[kSample];
+#pragma unroll
+        for (int j = 0; j < kSample; ++j) {
+            int v;
+            bool dup;
+            do {
+                const unsigned long long x = splitmix64(s);
+                v = (int)small_mod(small_mod(x >> 32) * two32_mod + small_mod(x & 0xffffffffull));
+                dup = false;
+#pragma unroll
+                for (int q = 0; q < kSample; ++q) dup = dup || (q < j && pick[q] == v);
+            } while (dup);
+            pick[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < kSample; ++j) { sPick[j] = pick[j]; d.samples[h * kSample + j] = pick[j]; }
+    }
+    mqs_wave_lds_sync();
+    if (lane < kSample) {
+        const int i = sPick[lane];
+        sObj[3 * lane] = sObjAll[3 * i]; sObj[3 * lane + 1] = sObjAll[3 * i + 1]; sObj[3 * lane + 2] = sObjAll[3 * i + 2];
+        sImg[2 * lane] = sImgAll[2 * i]; sImg[2 * lane + 1] = sImgAll[2 * i + 1];
+    }
+    mqs_wave_lds_sync();
+    const mqs::pnpblk::Problem pr = {sObj, sImg, nullptr, 0, kSample};
+    double P[12];
+    const int count = mqs::pnpblk::hypothesis_wave(pr, sObjAll, sImgAll, n_tri, sI, kSampleIters, p.max_reproj * p.max_reproj, sA, lane, P);
+    if (lane < 12) d.pnp_poses[12 * h + lane] = P[lane];
+    if (lane == 0) d.pnp_counts[h] = count;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // 9 x 9 symmetric eigen-decomposition by parallel cyclic Jacobi (one wavefront; lanes = 4 disjoint rotations x 9 rows), for the
 // null vector of the homography system; 3 x 3 by a single lane for the singular values of the homography.
 // ---------------------------------------------------------------------------------------------------------------------
@@ -964,6 +1069,8 @@ int mqs_slam_create(int device, int W, int H, const double *intr, int target_key
                       12.0, 0.5, 2.0, 0.33, 1.04, 0.0, (unsigned long long)seed, 1, 0, 0};  // slam2.py:1070-1098; keyframe test on ALL tracks
     if (const char *e = getenv("MQS_SLAM_HOMOGRAPHY_REFINE")) s->p.homography_refine = e[0] != '0';        // A/B: 0 = the DLT alone
     if (const char *e = getenv("MQS_SLAM_NULL_VECTOR_JACOBI")) s->p.null_vector_jacobi = e[0] != '0';      // A/B: 1 = the Jacobi sweeps always
+    s->fused_filter = true;
+    if (const char *e = getenv("MQS_SLAM_FUSED_FILTER")) s->fused_filter = e[0] != '0';                    // A/B: 0 = filter and hypotheses as two launches
     s->ws_lk_bytes = mqs_lk_workspace_bytes(W, H, 3);
     s->ws_gftt_bytes = mqs_gftt_workspace_bytes(W, H);
     const int64_t ws_pnp_bytes = mqs_pnp_workspace_bytes(kMaxTracks, kHyp);
@@ -1180,10 +1287,14 @@ int mqs_slam_track(mqs_slam *s, const uint8_t *prev_img_dev, const uint8_t *img_
     int rc = mqs_lk_launch(prev_img_dev, img_dev, s->p.W, s->p.H, d.pts, kMaxTracks, d.cnt + C_N, 21, 21, 3, 30, 0.01, 1e-4, d.lk_pts,
                            d.lk_st, d.lk_err, s->ws_lk, s->ws_lk_bytes, s->stream);
     if (rc != MQS_OK) return rc;
-    hipLaunchKernelGGL(frame_filter_kernel, dim3(1), dim3(256), 0, s->stream, d, s->p);
-    rc = mqs_pnp_ransac_launch(d.objp_t, d.imgp_t, kMaxTracks, d.cnt + C_NTRI, d.intr, d.samples, kHyp, kSample, s->p.max_reproj,
-                               kSampleIters, kPnpIters, kPnpEps, d.pose_r, d.sel, d.inl_mask, d.pnp_info, s->ws_pnp, s->stream, 1);
-    if (rc != MQS_OK) return rc;
+    if (s->fused_filter) {
+        hipLaunchKernelGGL(frame_hypothesis_kernel, dim3(kHyp), dim3(64), 0, s->stream, d, s->p);
+    } else {
+        hipLaunchKernelGGL(frame_filter_kernel, dim3(1), dim3(256), 0, s->stream, d, s->p);
+        rc = mqs_pnp_ransac_launch(d.objp_t, d.imgp_t, kMaxTracks, d.cnt + C_NTRI, d.intr, d.samples, kHyp, kSample, s->p.max_reproj,
+                                   kSampleIters, kPnpIters, kPnpEps, d.pose_r, d.sel, d.inl_mask, d.pnp_info, s->ws_pnp, s->stream, 1);
+        if (rc != MQS_OK) return rc;
+    }
     hipLaunchKernelGGL(frame_decide_kernel, dim3(1), dim3(256), (size_t)kMaxTracks * 40, s->stream, d, s->p);
     MQS_HIP_CHECK(hipGetLastError());
     // (the decision kernel has written the result block into s->res_host and cleared the previous keyframe's flag on the device)

@@ -83,6 +83,7 @@ struct mqs_slam {
     mqs::slamst::SlamParams p;
     char *arena;
     double *res_host;                // pinned
+    bool fused_filter;               // the filter inside the hypotheses' launch (default; MQS_SLAM_FUSED_FILTER=0: two launches)
     void *ws_lk, *ws_gftt, *ws_pnp;
     int64_t ws_lk_bytes, ws_gftt_bytes;
     bool started;

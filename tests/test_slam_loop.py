@@ -339,6 +339,41 @@ def _rendered(gpu, frames):
 
 
 @pytest.mark.gpu
+def test_device_loop_launch_forms_give_the_same_run(gpu, monkeypatch):
+    """The loop's fused launches against the forms they replaced, on the rendered sequence incl. one broken frame (a rejection): the
+    track filter inside the RANSAC hypotheses' launch (every hypothesis' wavefront compacts the tracks for itself; workgroup 0 writes
+    the frame's state) against the one-workgroup filter kernel + the hypotheses (MQS_SLAM_FUSED_FILTER=0); the tracker's pyramid in
+    one launch against one per level (MQS_LK_PYRAMID_PER_LEVEL=1).  Same decisions, same poses bit for bit, same tracks."""
+    import torch
+    seq, objp, imgp, imgs = _rendered(gpu, 30)
+    imgs = list(imgs)
+    imgs[17] = torch.zeros_like(imgs[17])                        # a frame the tracker loses: rejected, the loop goes on
+
+    def run(**env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        slam = gpu.slam_device.DeviceMonoSlam(seq.K, seq.dist, (seq.H, seq.W), seed=3)
+        slam.start(imgs[0], objp, imgp)
+        rets = [slam.handle_new_frame(imgs[k]) for k in range(1, 30)]
+        slam.finish()
+        poses = [None if P is None else np.array(P) for P in slam.poses]
+        tracks = [np.array(a) for a in slam.tracks()]
+        slam.close()
+        for k in env:
+            monkeypatch.delenv(k)
+        return rets, poses, tracks
+    base = run()
+    assert 0 in base[0] and 2 in base[0]
+    for env in ({"MQS_SLAM_FUSED_FILTER": "0"}, {"MQS_LK_PYRAMID_PER_LEVEL": "1"}):
+        other = run(**env)
+        assert other[0] == base[0], env
+        for a, b in zip(base[1], other[1]):
+            assert (a is None) == (b is None) and (a is None or np.array_equal(a, b)), env
+        for a, b in zip(base[2], other[2]):
+            np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.gpu
 def test_resident_adjuster_equals_its_host_built_twin_at_every_keyframe(gpu):
     """`mqs_slam_bundle_adjust` (csrc/slam_ba.hip: the whole adjustment in one persistent launch on the resident log, map and
     trajectory) against round 4's host-built path on the SAME state, behind every keyframe of the rendered sequence: the twin builds
