@@ -757,8 +757,9 @@ __device__ __forceinline__ float bilinear_u8(const uint8_t *__restrict__ a, int 
 
 // NW wavefronts per feature (round 5: four): a feature's track is a serial chain of ~80 iterations, each a window sum and a 2 x 2 solve; with
 // one wavefront the chain's length IS the launch's (300 features on 256 CUs: one wave per CU, 73 us); four wavefronts take a quarter of the
-// window each and meet in LDS once per sum (parity-alternating slots: one workgroup barrier per sum).  Two wavefronts: 55.8 us, four: 47.1,
-// eight: 47.4 -- beyond four the chain is the iteration's own dependent instructions (weights, bilinear taps, the wave sum, the 2 x 2 solve).
+// window each and meet in LDS once per sum (parity-alternating slots: one workgroup barrier per sum).  Two wavefronts: 40.8 us, four: 38.5,
+// eight: 41.4 (with the loads of an iteration batched; 55.8 / 47.1 / 47.4 before) -- the chain is the iteration's own dependent instructions
+// (weights, bilinear taps, the wave sum, the 2 x 2 solve).
 #ifndef MQS_LK_WAVES
 #define MQS_LK_WAVES 4
 #endif
@@ -1254,8 +1255,10 @@ int mqs_lk_launch(const uint8_t *prev_img, const uint8_t *next_img, int W, int H
         hipLaunchKernelGGL((lk_kernel<kLkWaves, KP>), dim3(n), dim3(64 * kLkWaves), 0, stream, L, prev_pts, n, n_dev, win_w, win_h, max_iter,   \
                            (float)eps, (float)min_eig_threshold, next_pts, status, err)
         constexpr int kPixMax = (kMaxWinPixelsPerLane + kLkWaves - 1) / kLkWaves;
+        constexpr int kPix4 = 4 < kPixMax ? 4 : kPixMax;
         if (per_thread <= 1) MQS_LK_LAUNCH(1);
         else if (per_thread <= 2) MQS_LK_LAUNCH(2);
+        else if (per_thread <= 4) MQS_LK_LAUNCH(kPix4);
         else MQS_LK_LAUNCH(kPixMax);
 #undef MQS_LK_LAUNCH
     }
