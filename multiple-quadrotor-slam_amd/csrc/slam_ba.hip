@@ -87,9 +87,12 @@ struct BaDev {
     double *erec, *prec;               // [kMaxEdges][kERec], [16]
     double *partials;                  // [G][4]
     double *med;                       // [4]
-    uint32_t *sync;                    // [0] barrier counter, [1] abort word (zeroed by the host in front of every launch)
+    uint32_t *sync;                    // [0] barrier counter, [1] abort word: one of two 64-byte blocks, alternating by launch
+    uint32_t *sync_next;               // the other block: zeroed by this launch for the next one (no fill launch in front of a launch)
+    double *poses_host;                // pinned host memory the write-back phase leaves the adjusted poses in as well ([R | t], 12 each); cap below
+    int poses_host_cap;
     int32_t *ctr;                      // [kCtr]
-    double *report;                    // [MQS_SLAM_BA_REPORT]
+    double *report;                    // [MQS_SLAM_BA_REPORT], in pinned host memory (NaN-filled by the host in front of a launch)
     int N_cap, P_cap, ntile_cap, n0;
     long long hits_cap;
     long long *stamps;                 // null, or [kStamps][2] (phase id, 100 MHz wall clock) written by workgroup 0 (mqs_debug_slam_ba_stamps)
@@ -1138,6 +1141,7 @@ __device__ __forceinline__ bool lm_trial(Cx &c, const double *poses, const doubl
 
 __global__ __launch_bounds__(kT) void slam_ba_kernel(BaDev b, SlamDev d, BaParams p)
 {
+    if (blockIdx.x == 0 && threadIdx.x == 0) { stg(b.sync_next, 0u); stg(b.sync_next + 1, 0u); }      // the next launch's barrier words
     Cx c;
     c.b = b; c.d = d; c.p = p;
     c.tid = threadIdx.x; c.lane = c.tid & 63; c.wave = c.tid >> 6; c.wg = blockIdx.x; c.G = gridDim.x;
@@ -1457,6 +1461,7 @@ __global__ __launch_bounds__(kT) void slam_ba_kernel(BaDev b, SlamDev d, BaParam
         for (int k = 0; k < 12; ++k) q[k] = ldg(poses_cur + 12 * j + k);
         pose12_to_w2c(q, M);
         for (int k = 0; k < 12; ++k) d.traj[12 * (size_t)j + k] = M[k];
+        if (j < b.poses_host_cap) for (int k = 0; k < 12; ++k) b.poses_host[12 * (size_t)j + k] = M[k];
         if (j == P - 1) for (int k = 0; k < 12; ++k) d.pose_prev[k] = M[k];
         if (j == p.key_pose) for (int k = 0; k < 12; ++k) d.pose_key[k] = M[k];
     }
@@ -1482,7 +1487,10 @@ struct mqs_slam_ba {
     size_t arena_bytes;
     BaDev dev;
     int n_odo;
-    double *host;                       // pinned: report + poses
+    double *host;                       // pinned: report + poses (the kernel writes both; host_dev: the device's view of it)
+    double *host_dev;
+    uint32_t *sync_base;                // two 64-byte blocks of barrier words, used alternately (parity)
+    int parity;
     char *fixed;                        // the part of the state that lives across re-allocations of the arena
     long long *stamps;                  // device, allocated by mqs_debug_slam_ba_stamps
 };
@@ -1498,7 +1506,7 @@ int ba_fixed_alloc(mqs_slam *s)
     const size_t L = (size_t)s->p.max_landmarks;
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t o = off; off = up256(off + bytes); return o; };
-    const size_t o_sync = take(64), o_ctr = take(kCtr * 4), o_rep = take(MQS_SLAM_BA_REPORT * 8), o_p0 = take(96), o_o0 = take(kMaxTracks * 24),
+    const size_t o_sync = take(128), o_ctr = take(kCtr * 4), o_rep = take(MQS_SLAM_BA_REPORT * 8), o_p0 = take(96), o_o0 = take(kMaxTracks * 24),
                  o_bad = take(L * 4), o_of = take(kMaxEdges * 4), o_ot = take(kMaxEdges * 4), o_om = take(kMaxEdges * 96),
                  o_ei = take(kMaxPoses * 4), o_eo = take(kMaxPoses * 4), o_er = take((size_t)kMaxEdges * kERec * 8), o_pr = take(128),
                  o_med = take(64), o_part = take(256 * 32), o_dp = take((6 * kMaxPoses + 64) * 8), o_ys = take((6 * kMaxPoses + 64) * 8),
@@ -1512,7 +1520,13 @@ int ba_fixed_alloc(mqs_slam *s)
     if (e != hipSuccess) { (void)hipFree(ba->fixed); delete ba; mqs_set_error("hipHostMalloc failed: %s", hipGetErrorString(e)); return MQS_E_NOMEM; }
     char *a = ba->fixed;
     BaDev &b = ba->dev;
-    b.sync = (uint32_t *)(a + o_sync); b.ctr = (int32_t *)(a + o_ctr); b.report = (double *)(a + o_rep); b.pose0 = (double *)(a + o_p0);
+    ba->sync_base = (uint32_t *)(a + o_sync); ba->parity = 0;
+    e = hipHostGetDevicePointer((void **)&ba->host_dev, ba->host, 0);
+    if (e == hipSuccess) e = hipMemsetAsync(ba->sync_base, 0, 128, s->stream);
+    if (e != hipSuccess) { (void)hipFree(ba->fixed); (void)hipHostFree(ba->host); delete ba; mqs_set_error("mqs_slam_bundle_adjust: %s", hipGetErrorString(e)); return MQS_E_HIP; }
+    (void)o_rep;
+    b.sync = ba->sync_base; b.sync_next = ba->sync_base + 16; b.poses_host = ba->host_dev + MQS_SLAM_BA_REPORT; b.poses_host_cap = 0;
+    b.ctr = (int32_t *)(a + o_ctr); b.report = ba->host_dev; b.pose0 = (double *)(a + o_p0);
     b.objp0 = (double *)(a + o_o0); b.bad = (int32_t *)(a + o_bad); b.odo_from = (int32_t *)(a + o_of); b.odo_to = (int32_t *)(a + o_ot);
     b.odo_meas = (double *)(a + o_om); b.e_in = (int32_t *)(a + o_ei); b.e_out = (int32_t *)(a + o_eo); b.erec = (double *)(a + o_er);
     b.prec = (double *)(a + o_pr); b.med = (double *)(a + o_med); b.partials = (double *)(a + o_part); b.dpose = (double *)(a + o_dp); b.ysol = (double *)(a + o_ys);
@@ -1661,17 +1675,23 @@ int mqs_slam_bundle_adjust(mqs_slam *s, const mqs_slam_ba_params *q, double *rep
     const size_t lds = ((size_t)2 * kMaxPoses * kCamStride + 6 * kMaxPoses + 32 + 64) * sizeof(double);
     static mqs_lds_opt_in opt;
     MQS_HIP_CHECK(mqs_lds_opt_in_once(opt, reinterpret_cast<const void *>(slam_ba_kernel), lds));
-    MQS_HIP_CHECK(hipMemsetAsync(ba->dev.sync, 0, 64, s->stream));
-    MQS_HIP_CHECK(hipMemsetAsync(ba->dev.report, 0xff, MQS_SLAM_BA_REPORT * 8, s->stream));       // NaN: a launch that wrote no report
+    // No fill or copy launch around the adjustment: the barrier words alternate between two blocks (a launch zeroes the next one's), the
+    // report and the adjusted poses are written by the kernel into pinned host memory (NaN there: a launch that wrote no report).
+    const int np = poses_out ? (P < poses_cap ? P : poses_cap) : 0;
+    memset(ba->host, 0xff, MQS_SLAM_BA_REPORT * 8);
+    ba->dev.sync = ba->sync_base + 16 * ba->parity; ba->dev.sync_next = ba->sync_base + 16 * (1 - ba->parity);
+    ba->dev.poses_host_cap = np;
+    ba->parity ^= 1;
     hipLaunchKernelGGL(slam_ba_kernel, dim3(G), dim3(kT), lds, s->stream, ba->dev, s->d, p);
     MQS_HIP_CHECK(hipGetLastError());
-    MQS_HIP_CHECK(hipMemcpyAsync(ba->host, ba->dev.report, MQS_SLAM_BA_REPORT * 8, hipMemcpyDeviceToHost, s->stream));
-    const int np = poses_out ? (P < poses_cap ? P : poses_cap) : 0;
-    if (np > 0) MQS_HIP_CHECK(hipMemcpyAsync(ba->host + MQS_SLAM_BA_REPORT, s->d.traj, (size_t)np * 96, hipMemcpyDeviceToHost, s->stream));
     MQS_HIP_CHECK(hipStreamSynchronize(s->stream));
     memcpy(report, ba->host, MQS_SLAM_BA_REPORT * 8);
     if (np > 0) memcpy(poses_out, ba->host + MQS_SLAM_BA_REPORT, (size_t)np * 96);
     if (!(report[0] == 0.0)) {
+        // (a launch that gave up leaves its barrier words as they were: both blocks start from zero again)
+        (void)hipMemsetAsync(ba->sync_base, 0, 128, s->stream);
+        (void)hipStreamSynchronize(s->stream);
+        ba->parity = 0;
         if (report[0] == 1.0) { mqs_set_error("mqs_slam_bundle_adjust: a grid-wide wait of the adjustment gave up (2 s); nothing was written back"); return MQS_E_TIMEOUT; }
         if (report[0] == 3.0) { mqs_set_error("mqs_slam_bundle_adjust: the observation log is full (%d entries): observations have been dropped", s->d.log_cap); return MQS_E_ARG; }
         mqs_set_error("mqs_slam_bundle_adjust: capacity (poses %g of %d, landmarks %g, a frame with more than %d observations, or more co-observations than the hit lists hold)", report[1], kMaxPoses, report[2], kListCap);
