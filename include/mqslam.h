@@ -45,6 +45,7 @@ extern "C" {
 #define MQS_E_NODEVICE -4   /* no gfx950 device visible */
 #define MQS_E_RCCL     -5   /* RCCL missing or a collective failed (message in mqs_last_error) */
 #define MQS_E_TIMEOUT  -6   /* a bounded device-side wait gave up (a peer's row, or the finalizer pieces of an iteration): results invalid */
+#define MQS_E_CAPACITY -7   /* a resident working set does not hold the problem (mqs_slam_bundle_adjust: a list or table is full); nothing was written, the caller may take another path */
 
 #define MQS_MAX_CAMS    8
 #define MQS_TRI_MAX_ITER_DEFAULT 10        /* triangulation.c:125 */
@@ -691,13 +692,34 @@ int mqs_slam_reassociate(mqs_slam *s, float max_radius, double max_dist_ratio, i
  *                         keyframe's pose index, edge_to = this keyframe's) is measured from the trajectory as it stands
  *                         (slam2.py:681-687) and kept for this and all later adjustments.
  *                         report [MQS_SLAM_BA_REPORT] doubles: [0] status (0 done; 1 a grid-wide wait gave up -> MQS_E_TIMEOUT;
- *                         2 capacity: more than 256 poses, or a pose with more observations than a list holds -> MQS_E_ARG;
- *                         3 the log overflowed -> MQS_E_ARG), [1] poses, [2] landmarks, [3] landmarks adjusted, [4] observations
+ *                         2 capacity: a pose with more observations than a list holds, more co-observations than the hit lists
+ *                         hold -> MQS_E_CAPACITY; 3 the log overflowed -> MQS_E_ARG), [1] poses of the problem, [2] landmarks,
+ *                         [3] landmarks adjusted, [4] observations
  *                         used, [5] passes, [6] landmarks screened out by this call, [7] LM iterations of the last pass,
  *                         [8] cost before, [9] cost after, [10] LM trials (linearise + solve) in all, [11] observations
  *                         that repeat a (landmark, frame) pair and were left out, [12] odometry edges, [13] grid barriers
- *                         passed.  poses_out (host, may be NULL): the adjusted [R | t] world -> camera of the first
- *                         min(poses, poses_cap) accepted frames. */
+ *                         passed, [14] first accepted frame whose pose this call rewrote (0 for the plain call), [15] frames from
+ *                         there to the last accepted one.  poses_out (host, may be NULL): the adjusted [R | t] world -> camera
+ *                         of the accepted frames [report[14], report[14] + min(report[15], poses_cap)).
+ *                         More than MQS_SLAM_BA_MAX_POSES accepted frames: MQS_E_ARG -- mqs_slam_bundle_adjust_window selects.
+ *                         The launch's workgroups meet at spinning barriers, so all of them have to be resident at once: the
+ *                         library sizes the grid from the device (mqs_slam_ba_resident_groups: compute units x workgroups of
+ *                         this kernel per unit), an explicit `workgroups` (or MQS_SLAM_BA_GROUPS) beyond that is MQS_E_ARG at
+ *                         once, and launches of one process on one device are serialised.
+ *   mqs_slam_bundle_adjust_window   the same adjustment over a SELECTION of the accepted frames -- what keeps the cost of an
+ *                         adjustment bounded on runs of the reference's lengths (its committed runs: 376 and 881 poses, its tool
+ *                         adjusts whatever the recording holds, bundle_adjust.cpp:190-330).  `poses`: n_poses ascending indices
+ *                         of accepted frames (<= MQS_SLAM_BA_MAX_POSES; the last one = the last accepted frame; the base
+ *                         keyframe of the live tracks among them) become the poses of the problem -- typically the keyframes of
+ *                         the run so far and every frame since the K-th keyframe from the end.  Observations at other frames
+ *                         are not factors of the problem; they count towards `min_observations`, and with seen_outside_sigma
+ *                         > 0 a landmark that has any keeps a prior of that sigma at the value this adjustment found it with.
+ *                         Gauge: while frame 0 is selected, as the plain call (prior on pose 0 at its start-up estimate, on the
+ *                         start-up landmarks at their given positions); otherwise a prior (`pose_sigmas`) on the first selected
+ *                         pose at its current value, and -- second_anchor >= 0 -- on that frame's as well (two poses fix the
+ *                         scale of a monocular window).  Odometry edges count when both ends are selected.  carry_unselected:
+ *                         every accepted frame behind poses[0] that is not selected keeps its pose RELATIVE to the last
+ *                         selected pose in front of it (M_j <- M_j inv(A_before) A_after); 0: it stays where it was. */
 #define MQS_SLAM_BA_REPORT 16
 #define MQS_SLAM_BA_MAX_POSES 256
 typedef struct mqs_slam_ba_params {
@@ -711,6 +733,21 @@ typedef struct mqs_slam_ba_params {
     double lambda_initial, lambda_factor, lambda_upper, abs_tol, rel_tol;
 } mqs_slam_ba_params;
 int mqs_slam_bundle_adjust(mqs_slam *s, const mqs_slam_ba_params *params, double *report, double *poses_out, int32_t poses_cap);
+typedef struct mqs_slam_ba_window {
+    int32_t n_poses;                                  /* 0: every accepted frame (= mqs_slam_bundle_adjust) */
+    int32_t second_anchor;                            /* accepted-frame index, or -1 */
+    int32_t carry_unselected;
+    int32_t reserved;
+    const int32_t *poses;                             /* host */
+    double seen_outside_sigma;                        /* 0: no such prior */
+} mqs_slam_ba_window;
+int mqs_slam_bundle_adjust_window(mqs_slam *s, const mqs_slam_ba_params *params, const mqs_slam_ba_window *window, double *report,
+                                  double *poses_out, int32_t poses_cap);
+/* workgroups of the adjuster's persistent launch the device can hold at once (its grid is never larger) */
+int mqs_slam_ba_resident_groups(mqs_slam *s, int32_t *groups);
+/* test hook: the NEXT mqs_slam_bundle_adjust(_window) on this handle returns `code` (MQS_E_TIMEOUT or MQS_E_CAPACITY; 0 clears) without
+ * launching or writing anything -- what a caller's fall-back path is tested with */
+int mqs_debug_slam_ba_fail_next(mqs_slam *s, int code);
 /* the landmarks the in-loop adjuster has retired so far (1) / not (0): host uint8 [cap]; *n = landmarks in the map */
 int mqs_slam_read_ba_flags(mqs_slam *s, uint8_t *retired, int cap, int32_t *n);
 /* the odometry edges the adjuster holds (pose indices, measured relative pose12 [cap][12]): what a caller needs to take the adjustment over

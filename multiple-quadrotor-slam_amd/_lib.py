@@ -178,6 +178,9 @@ SIGNATURES = {
     "mqs_slam_set_second_pass_screen": (ctypes.c_int, [c_vp, ctypes.c_double]),
     "mqs_slam_reassociate": (ctypes.c_int, [c_vp, ctypes.c_float, ctypes.c_double, c_i32p]),
     "mqs_slam_bundle_adjust": (ctypes.c_int, [c_vp, c_vp, c_f64p, c_f64p, ctypes.c_int32]),
+    "mqs_slam_bundle_adjust_window": (ctypes.c_int, [c_vp, c_vp, c_vp, c_f64p, c_f64p, ctypes.c_int32]),
+    "mqs_slam_ba_resident_groups": (ctypes.c_int, [c_vp, c_i32p]),
+    "mqs_debug_slam_ba_fail_next": (ctypes.c_int, [c_vp, ctypes.c_int]),
     "mqs_slam_read_ba_flags": (ctypes.c_int, [c_vp, ctypes.POINTER(ctypes.c_uint8), ctypes.c_int, c_i32p]),
     "mqs_slam_read_ba_edges": (ctypes.c_int, [c_vp, c_i32p, c_i32p, c_f64p, ctypes.c_int, c_i32p]),
     "mqs_debug_slam_ba_stamps": (ctypes.c_int, [c_vp, ctypes.POINTER(c_i64), ctypes.c_int, c_i32p]),

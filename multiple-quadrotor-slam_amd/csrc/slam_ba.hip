@@ -36,6 +36,7 @@
 #include "wave_reduce.h"
 #include "slam_state.h"
 #include <new>
+#include <mutex>
 
 namespace {
 
@@ -50,8 +51,9 @@ constexpr int kERec = 96;                        // doubles per odometry-edge re
 constexpr int kLanes = 32;                       // lanes per landmark in the landmark phases: half a wavefront
 constexpr int TB = mqs::chol::NB, TLD = mqs::chol::kLd;
 constexpr int kCtr = 4096;                       // one-shot counters (a fresh one per use)
-constexpr int kMaxEdges = 1024;
+constexpr int kMaxEdges = 4096;
 constexpr int kStamps = 2048;
+constexpr int kMaxGroups = 256;                    // workgroups of a launch at most (partials)
 constexpr long long kSpinTicks = 200000000ll;    // 2 s of the 100 MHz wall clock
 constexpr double kAugDiag = 1e200;               // diagonal entry of the right-hand side's row in the augmented matrix
 
@@ -66,11 +68,14 @@ struct BaDev {
     int32_t *bad;                      // [max_landmarks] 1: retired
     int32_t *odo_from, *odo_to;        // [kMaxEdges]
     double *odo_meas;                  // [kMaxEdges][12] measured relative pose (R row-major, t)
-    int32_t *e_in, *e_out;             // [kMaxPoses] the edge that ends / starts at a pose, or -1
+    int32_t *e_in, *e_out;             // [traj_cap] the edge that ends / starts at a trajectory pose, or -1
     // per adjustment
     int32_t *lm_res;                   // [log_cap] landmark of a log entry, -1: not part of the problem
     int32_t *T;                        // [P][N]
     int32_t *per_lm, *use, *pmin, *pmax, *cand;   // [N_cap]
+    int32_t *out_cnt;                  // [N_cap] a landmark's observations at accepted frames that are NOT poses of this problem (a selection)
+    double *traj_old;                  // [kMaxPoses][12] the trajectory rows of the problem's poses as this launch found them (the carry of the rest)
+    const int32_t *sel_host;           // pinned host memory: the selection (trajectory index of problem pose k), read once by every workgroup
     long long *plist;                  // [kMaxPoses][kListCap] a pose's observations in landmark order: log index | landmark << 32
     int32_t *pcount, *pl_lo, *pl_hi;   // [kMaxPoses] x 3
     long long *hits;                   // [hits_cap] per pose pair (ja < jb): the observations of a common landmark, log index in ja | in jb << 32
@@ -99,7 +104,13 @@ struct BaDev {
 };
 
 struct BaParams {
-    int P, G, key_pose;
+    int P, G, key_pose;                              // P: poses of the PROBLEM (<= kMaxPoses)
+    // the selection (mqs_slam_bundle_adjust_window): problem pose k = trajectory pose sel[k] (ascending, the last = the last accepted
+    // frame); identity: sel[k] = k, P = P_all -- the plain call
+    int P_all, sel0, identity;                       // accepted frames; sel[0]
+    int anchor2;                                     // trajectory index of a second pose held by a prior at its current value, or -1
+    int carry;                                       // the accepted frames behind sel[0] that are not poses of the problem keep their pose RELATIVE to the nearest problem pose in front of them
+    double out_prior_w;                              // 1 / sigma^2 of the prior on a landmark that frames outside the problem have seen, at its current value; 0: none
     int max_iterations, min_observations, max_passes, damping;
     int add_edge, edge_from, edge_to, n_odo;         // n_odo: edges AFTER this call's has been appended
     double outlier_px, gross_px, border, min_depth_ratio;
@@ -115,6 +126,8 @@ struct Cx {                                          // per-thread view of the l
     BaDev b; SlamDev d; BaParams p;
     int tid, lane, wave, wg, G;
     int P, N, nlog, n, nt;                           // n = 6 P unknowns; nt tiles per dimension of the augmented (n + 1) matrix
+    int n0;                                          // start-up landmarks that are the gauge of THIS problem (0 when frame 0 is not one of its poses)
+    int a2;                                          // problem index of the second anchored pose, or -1
     uint32_t epoch;
     int ctr_next, n_stamp;
 };
@@ -126,6 +139,30 @@ __device__ __forceinline__ double *lds_cam_new() { return g_sm + kMaxPoses * kCa
 __device__ __forceinline__ double *lds_step() { return g_sm + 2 * kMaxPoses * kCamStride; }
 __device__ __forceinline__ double *lds_red() { return g_sm + 2 * kMaxPoses * kCamStride + 6 * kMaxPoses + 32; }
 __device__ __forceinline__ int *lds_flag() { return reinterpret_cast<int *>(g_sm + 2 * kMaxPoses * kCamStride + 6 * kMaxPoses + 32 + 32); }
+__device__ __forceinline__ int *lds_sel() { return reinterpret_cast<int *>(g_sm + 2 * kMaxPoses * kCamStride + 6 * kMaxPoses + 32 + 64); }      // [kMaxPoses] the selection
+constexpr size_t kLdsBytes = ((size_t)2 * kMaxPoses * kCamStride + 6 * kMaxPoses + 32 + 64) * sizeof(double) + kMaxPoses * sizeof(int);
+
+// problem pose k -> trajectory pose; trajectory pose j -> problem pose or -1 (binary search of the ascending selection in LDS);
+// the last problem pose at or in front of trajectory pose j (j >= sel[0])
+__device__ __forceinline__ int pose_of(const Cx &c, int k) { return c.p.identity ? k : lds_sel()[k]; }
+__device__ __forceinline__ int sel_lower(const Cx &c, int j)
+{
+    int lo = 0, hi = c.P;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (lds_sel()[mid] < j) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+__device__ __forceinline__ int map_pose(const Cx &c, int j)
+{
+    if (c.p.identity) return (j >= 0 && j < c.P) ? j : -1;
+    if (j < 0) return -1;
+    const int lo = sel_lower(c, j);
+    return (lo < c.P && lds_sel()[lo] == j) ? lo : -1;
+}
+__device__ __forceinline__ int anchor_of(const Cx &c, int j)
+{
+    const int lo = sel_lower(c, j);
+    return (lo < c.P && lds_sel()[lo] == j) ? lo : lo - 1;
+}
 
 __device__ __forceinline__ int tix(int bi, int bj) { return bi * (bi + 1) / 2 + bj; }
 // square root for the triangular-index decodes (x >= 1; the callers correct the last unit): x * rsqrt(x) by Newton steps
@@ -272,20 +309,31 @@ __device__ __forceinline__ void prior_error(const double *T0, const double *T, d
     }
 }
 
-// the pose-dependent factors' cost at the poses in `sC` (LDS: a staged camera begins with its pose12): odometry edges + the prior on
-// pose 0; every thread of the workgroup gets the sum
+// the pose-dependent factors' cost at the poses in `sC` (LDS: a staged camera begins with its pose12): the odometry edges whose two
+// ends are poses of the problem + the prior on its first pose (+ on the second anchor); every thread of the workgroup gets the sum
+__device__ __forceinline__ const double *anchor_target(const Cx &c, int which)      // where an anchor's prior sits
+{
+    // pose 0 of the run: at its start-up estimate (bundle_adjust.cpp:273); any other pose: where this adjustment found it
+    if (which == 0) return c.p.sel0 == 0 ? c.b.pose0 : c.b.poses_init;
+    return c.b.poses_init + 12 * c.a2;
+}
+
 __device__ __forceinline__ double extras_cost(Cx &c, const double *sC)
 {
     double v = 0.0;
     for (int t = c.tid; t < c.p.n_odo; t += kT) {
+        const int kf = map_pose(c, ldg(c.b.odo_from + t)), kt = map_pose(c, ldg(c.b.odo_to + t));
+        if (kf < 0 || kt < 0) continue;
         double Tm[12], e[6], Rh[9], th[3];
         for (int k = 0; k < 12; ++k) Tm[k] = ldg(c.b.odo_meas + 12 * t + k);
-        between_error(sC + ldg(c.b.odo_from + t) * kCamStride, sC + ldg(c.b.odo_to + t) * kCamStride, Tm, e, Rh, th);
+        between_error(sC + kf * kCamStride, sC + kt * kCamStride, Tm, e, Rh, th);
         for (int i = 0; i < 6; ++i) v += 0.5 * c.p.odo_w[i] * e[i] * e[i];
     }
-    if (c.tid == 0) {
-        double e[6];
-        prior_error(c.b.pose0, sC, e);
+    if (c.tid == 0 || (c.tid == 1 && c.a2 > 0)) {
+        double e[6], T0[12];
+        const double *tg = anchor_target(c, c.tid);
+        for (int k = 0; k < 12; ++k) T0[k] = ldg(tg + k);
+        prior_error(T0, sC + (c.tid == 0 ? 0 : c.a2) * kCamStride, e);
         for (int a = 0; a < 6; ++a) v += 0.5 * c.p.pose_w[a] * e[a] * e[a];
     }
     return block_sum(c, v);
@@ -293,13 +341,15 @@ __device__ __forceinline__ double extras_cost(Cx &c, const double *sC)
 
 // their blocks at the poses in `sC`, for the system phase: per edge [0..35] H1^T W H1 (from, from), [36..71] H1^T W (from, to),
 // [72..77] W (to, to: diagonal), [78..83] -H1^T W e (g, from), [84..89] -W e (g, to), H1 = -Ad(h^-1) (the Jacobians of `between` only,
-// as GTSAM 3.2.1 has them); the prior: [0..5] 1 / sigma^2, [6..11] -w e
+// as GTSAM 3.2.1 has them); the priors: [0..5] 1 / sigma^2, [6..11] -w e (first pose), [12..23] the same for the second anchor
 __device__ __forceinline__ void extras_records(Cx &c, const double *sC)
 {
     for (int t = c.tid; t < c.p.n_odo; t += kT) {
+        const int kf = map_pose(c, ldg(c.b.odo_from + t)), kt = map_pose(c, ldg(c.b.odo_to + t));
+        if (kf < 0 || kt < 0) continue;
         double Tm[12], e[6], Rh[9], th[3];
         for (int k = 0; k < 12; ++k) Tm[k] = ldg(c.b.odo_meas + 12 * t + k);
-        between_error(sC + ldg(c.b.odo_from + t) * kCamStride, sC + ldg(c.b.odo_to + t) * kCamStride, Tm, e, Rh, th);
+        between_error(sC + kf * kCamStride, sC + kt * kCamStride, Tm, e, Rh, th);
         double Rt[9], tp[3], H1[36];
         for (int i = 0; i < 3; ++i) {
             for (int j = 0; j < 3; ++j) Rt[3 * i + j] = Rh[3 * j + i];
@@ -328,15 +378,18 @@ __device__ __forceinline__ void extras_records(Cx &c, const double *sC)
             }
         }
     }
-    if (c.tid == 0) {
-        double e[6];
-        prior_error(c.b.pose0, sC, e);
-        for (int a = 0; a < 6; ++a) { stg(c.b.prec + a, c.p.pose_w[a]); stg(c.b.prec + 6 + a, -c.p.pose_w[a] * e[a]); }
+    if (c.tid == 0 || (c.tid == 1 && c.a2 > 0)) {
+        double e[6], T0[12];
+        const double *tg = anchor_target(c, c.tid);
+        for (int k = 0; k < 12; ++k) T0[k] = ldg(tg + k);
+        prior_error(T0, sC + (c.tid == 0 ? 0 : c.a2) * kCamStride, e);
+        double *o = c.b.prec + 12 * c.tid;
+        for (int a = 0; a < 6; ++a) { stg(o + a, c.p.pose_w[a]); stg(o + 6 + a, -c.p.pose_w[a] * e[a]); }
     }
 }
 
 // ---- landmark phases: kLanes lanes per landmark, each takes every kLanes-th pose of the landmark's [pmin, pmax] ---------------
-struct LmWalk { int i, l8, p0, p1, q0, q1; bool in, live; double px, py, pz, pw, dx, dy, dz; };   // [p0, p1]: poses of a landmark in use; [q0, q1]: of any landmark
+struct LmWalk { int i, l8, p0, p1, q0, q1; bool in, live; double px, py, pz, pw, dx, dy, dz, tx, ty, tz; };   // (tx, ty, tz): where the landmark's prior sits (pw > 0)   // [p0, p1]: poses of a landmark in use; [q0, q1]: of any landmark
 
 __device__ __forceinline__ LmWalk lm_begin(const Cx &c, int base, const double *pts)
 {
@@ -347,10 +400,18 @@ __device__ __forceinline__ LmWalk lm_begin(const Cx &c, int base, const double *
     w.live = w.in && ldg(c.b.use + (w.in ? w.i : 0)) != 0;
     const int ii = w.in ? w.i : 0;
     w.px = ldg(pts + 3 * ii); w.py = ldg(pts + 3 * ii + 1); w.pz = ldg(pts + 3 * ii + 2);
-    w.pw = 0.0; w.dx = w.dy = w.dz = 0.0;
-    if (w.live && w.i < c.b.n0) {
+    w.pw = 0.0; w.dx = w.dy = w.dz = 0.0; w.tx = w.ty = w.tz = 0.0;
+    if (w.live && w.i < c.n0) {
+        // a start-up landmark: the gauge, at its given position (bundle_adjust.cpp:277-281)
         w.pw = c.p.prior_w;
-        w.dx = w.px - c.b.objp0[3 * w.i]; w.dy = w.py - c.b.objp0[3 * w.i + 1]; w.dz = w.pz - c.b.objp0[3 * w.i + 2];
+        w.tx = c.b.objp0[3 * w.i]; w.ty = c.b.objp0[3 * w.i + 1]; w.tz = c.b.objp0[3 * w.i + 2];
+        w.dx = w.px - w.tx; w.dy = w.py - w.ty; w.dz = w.pz - w.tz;
+    } else if (w.live && c.p.out_prior_w > 0.0 && ldg(c.b.out_cnt + w.i) > 0) {
+        // a selection: what the frames that are not poses of this problem know about the landmark stays with it as a prior at the
+        // value this adjustment found it with
+        w.pw = c.p.out_prior_w;
+        w.tx = ldg(c.b.pts_init + 3 * w.i); w.ty = ldg(c.b.pts_init + 3 * w.i + 1); w.tz = ldg(c.b.pts_init + 3 * w.i + 2);
+        w.dx = w.px - w.tx; w.dy = w.py - w.ty; w.dz = w.pz - w.tz;
     }
     w.q1 = w.in ? ldg(c.b.pmax + ii) : -1;
     w.q0 = (w.in && w.q1 >= 0) ? ldg(c.b.pmin + ii) : 0;            // (a landmark nobody observes: pmin is still INT_MAX)
@@ -606,10 +667,15 @@ __device__ __forceinline__ void phase_system(Cx &c, double lambda)
     int *sEo = reinterpret_cast<int *>(lds_cam_new()), *sEi = sEo + kMaxPoses, *sTo = sEi + kMaxPoses, *sCnt = sTo + kMaxPoses;
     __syncthreads();
     for (int j = c.tid; j < P; j += kT) {
-        const int eo = ldg(c.b.e_out + j), ei = ldg(c.b.e_in + j);
-        sEo[j] = (eo >= 0 && eo < c.p.n_odo) ? eo : -1;
-        sEi[j] = (ei >= 0 && ei < c.p.n_odo) ? ei : -1;
-        sTo[j] = (eo >= 0 && eo < c.p.n_odo) ? ldg(c.b.odo_to + eo) : -1;
+        // (an edge counts when both its ends are poses of the problem; e_in / e_out are kept per trajectory pose)
+        const int tj = pose_of(c, j);
+        int eo = ldg(c.b.e_out + tj), ei = ldg(c.b.e_in + tj);
+        int to = -1;
+        if (eo >= 0 && eo < c.p.n_odo) { to = map_pose(c, ldg(c.b.odo_to + eo)); if (to < 0) eo = -1; } else eo = -1;
+        if (ei >= 0 && ei < c.p.n_odo) { if (map_pose(c, ldg(c.b.odo_from + ei)) < 0) ei = -1; } else ei = -1;
+        sEo[j] = eo;
+        sEi[j] = ei;
+        sTo[j] = to;
         sCnt[j] = ldg(c.b.pcount + j);
     }
     __syncthreads();
@@ -633,10 +699,12 @@ __device__ __forceinline__ void phase_system(Cx &c, double lambda)
             if (sEo[ja] >= 0) x_add += ldg(c.b.erec + (size_t)sEo[ja] * kERec + 6 * mi + mj);
             if (sEi[ja] >= 0 && mi == mj) x_add += ldg(c.b.erec + (size_t)sEi[ja] * kERec + 72 + mi);
             if (ja == 0 && mi == mj) x_add += ldg(c.b.prec + mi);
+            if (ja == c.a2 && mi == mj) x_add += ldg(c.b.prec + 12 + mi);
             if (c.lane < 6) {
                 if (sEo[ja] >= 0) x_gadd += ldg(c.b.erec + (size_t)sEo[ja] * kERec + 78 + c.lane);
                 if (sEi[ja] >= 0) x_gadd += ldg(c.b.erec + (size_t)sEi[ja] * kERec + 84 + c.lane);
                 if (ja == 0) x_gadd += ldg(c.b.prec + 6 + c.lane);
+                if (ja == c.a2) x_gadd += ldg(c.b.prec + 18 + c.lane);
             }
         } else if (sEo[ja] >= 0 && sTo[ja] == jb) x_add += ldg(c.b.erec + (size_t)sEo[ja] * kERec + 36 + 6 * mi + mj);
         double acc[36], gacc[6];
@@ -1065,8 +1133,8 @@ __device__ __forceinline__ double phase_backsub_cost(Cx &c, const double *poses,
             const Factor fc = make_factor(lds_cam_new() + pp * kCamStride, nx, ny, nz, c.d.log_uv[2 * e], c.d.log_uv[2 * e + 1], true);
             cost += fc.half_e2;
         }
-        if (w.l8 == 0 && w.live && w.i < c.b.n0) {
-            const double ex = nx - c.b.objp0[3 * w.i], ey = ny - c.b.objp0[3 * w.i + 1], ez = nz - c.b.objp0[3 * w.i + 2];
+        if (w.l8 == 0 && w.live && w.pw > 0.0) {
+            const double ex = nx - w.tx, ey = ny - w.ty, ez = nz - w.tz;
             cost += 0.5 * w.pw * (ex * ex + ey * ey + ez * ez);
         }
     }
@@ -1149,10 +1217,19 @@ __global__ __launch_bounds__(kT) void slam_ba_kernel(BaDev b, SlamDev d, BaParam
     const int P = p.P;
     const int N = d.cnt[C_NLAND], nlog = d.cnt[C_NLOG];
     c.P = P; c.N = N; c.nlog = nlog; c.n = 6 * P; c.nt = (6 * P + 1 + TB - 1) / TB;
+    c.n0 = p.sel0 == 0 ? b.n0 : 0;
+    c.a2 = -1;
     const int gtid = c.wg * kT + c.tid, gthreads = c.G * kT;
     int status = 0;
     if (d.cnt[C_LOG_OVERFLOW]) status = 3;
     else if (P < 1 || P > kMaxPoses || P > b.P_cap || N > b.N_cap || tix(c.nt - 1, c.nt - 1) >= b.ntile_cap || N < 1) status = 2;
+    if (!status && !p.identity) {
+        // the selection, from the pinned host block into this workgroup's LDS (1 KB over the fabric, once)
+        for (int k = c.tid; k < P; k += kT) lds_sel()[k] = b.sel_host[k];
+        __syncthreads();
+        if (p.anchor2 >= 0) c.a2 = map_pose(c, p.anchor2);
+        if (c.a2 == 0) c.a2 = -1;
+    }
     if (status) {
         if (gtid == 0) { b.report[0] = (double)status; b.report[1] = (double)P; b.report[2] = (double)N; }
         return;
@@ -1163,16 +1240,17 @@ __global__ __launch_bounds__(kT) void slam_ba_kernel(BaDev b, SlamDev d, BaParam
     // ---- 0: clear the tables, the working estimate, the new odometry edge ------------------------------------------------------
     for (int64_t e = gtid; e < (int64_t)P * N; e += gthreads) stg(b.T + e, -1);
     for (int l = gtid; l < N; l += gthreads) {
-        stg(b.per_lm + l, 0); stg(b.pmin + l, 0x7fffffff); stg(b.pmax + l, -1);
+        stg(b.per_lm + l, 0); stg(b.pmin + l, 0x7fffffff); stg(b.pmax + l, -1); stg(b.out_cnt + l, 0);
         for (int k = 0; k < 3; ++k) { const double v = d.map[3 * l + k]; stg(b.pts_a + 3 * l + k, v); stg(b.pts_init + 3 * l + k, v); }
     }
     for (int k = gtid; k < kCtr; k += gthreads) stg(b.ctr + k, 0);
     if (gtid < 2) stg(b.med + gtid, (double)NAN);
     for (int j = gtid; j < P; j += gthreads) {
         double q[12];
-        if (j == 0) for (int k = 0; k < 12; ++k) q[k] = b.pose0[k];       // the prior sits at the start-up estimate (bundle_adjust.cpp:273)
-        else w2c_to_pose12(d.traj + 12 * (size_t)j, q);
-        for (int k = 0; k < 12; ++k) { stg(b.poses_a + 12 * j + k, q[k]); stg(b.poses_init + 12 * j + k, q[k]); }
+        const double *row = d.traj + 12 * (size_t)pose_of(c, j);
+        if (j == 0 && p.sel0 == 0) for (int k = 0; k < 12; ++k) q[k] = b.pose0[k];       // the prior sits at the start-up estimate (bundle_adjust.cpp:273)
+        else w2c_to_pose12(row, q);
+        for (int k = 0; k < 12; ++k) { stg(b.poses_a + 12 * j + k, q[k]); stg(b.poses_init + 12 * j + k, q[k]); stg(b.traj_old + 12 * j + k, row[k]); }
     }
     {
         // the system's tiles: zero, ones on the diagonal beyond the augmented row (rows that act as identity)
@@ -1206,12 +1284,14 @@ __global__ __launch_bounds__(kT) void slam_ba_kernel(BaDev b, SlamDev d, BaParam
     for (int e = gtid; e < nlog; e += gthreads) {
         int lm = d.log_lm[e];
         if (lm <= -2) { const int t = -2 - lm; lm = t < d.tid_cap ? d.tid2lm[t] : -1; }
-        const int pj = d.log_pose[e];
+        const int tj = d.log_pose[e];
+        const int pj = map_pose(c, tj);
+        if (pj < 0 && tj >= 0 && tj < p.P_all && lm >= 0 && lm < N) atomicAdd(b.out_cnt + lm, 1);      // seen from a frame that is not a pose of this problem
         const double u = d.log_uv[2 * e], v = d.log_uv[2 * e + 1];
         // an observation nearer to the image border than the margin was tracked on a window that read the border-extended
         // pyramid: good enough for RANSAC, not for least squares (slam_device.py)
         const bool inside = p.border <= 0.0 || (u >= p.border && u <= p.W - 1 - p.border && v >= p.border && v <= p.H - 1 - p.border);
-        const bool known = lm >= 0 && lm < N && pj >= 0 && pj < P && inside;
+        const bool known = lm >= 0 && lm < N && pj >= 0 && inside;
         stg(b.lm_res + e, known ? lm : -1);
         if (known) {
             const int old = atomicMax(b.T + (size_t)pj * N + lm, e);
@@ -1224,7 +1304,9 @@ __global__ __launch_bounds__(kT) void slam_ba_kernel(BaDev b, SlamDev d, BaParam
     stamp(c, 2);
     // ---- 2: which landmarks take part; every pose's observations compacted in landmark order --------------------------------------
     for (int l = gtid; l < N; l += gthreads) {
-        const bool use = (ldg(b.per_lm + l) >= p.min_observations || l < b.n0) && ldg(b.bad + l) == 0;
+        // (a selection: the observations at frames outside the problem count towards "seen often enough", one inside it is needed)
+        const int n_in = ldg(b.per_lm + l);
+        const bool use = ((n_in >= 1 && n_in + ldg(b.out_cnt + l) >= p.min_observations) || l < c.n0) && ldg(b.bad + l) == 0;
         stg(b.use + l, use ? 1 : 0);
     }
     for (int pj = c.wg * 4 + c.wave; pj < P; pj += c.G * 4) {
@@ -1352,7 +1434,7 @@ __global__ __launch_bounds__(kT) void slam_ba_kernel(BaDev b, SlamDev d, BaParam
             // (NaN while no landmark has a depth: no depth screen then)
             int32_t *gross_ctr = fresh_counter(c);
             for (int l = gtid; l < N; l += gthreads) {
-                if (ldg(b.use + l) == 0 || l < b.n0) continue;
+                if (ldg(b.use + l) == 0 || l < c.n0) continue;
                 const double wv = ldg(b.worst + l), zv = ldg(b.zmin + l);
                 const bool gross = !(wv <= p.gross_px) || (isfinite(zv) && zv < p.min_depth_ratio * med);
                 if (gross) { stg(b.bad + l, 1); stg(b.use + l, 0); atomicAdd(gross_ctr, 1); }
@@ -1416,7 +1498,7 @@ __global__ __launch_bounds__(kT) void slam_ba_kernel(BaDev b, SlamDev d, BaParam
             barriers += 1;
             int32_t *flip_ctr = fresh_counter(c);
             for (int l = gtid; l < N; l += gthreads) {
-                if (ldg(b.use + l) == 0 || l < b.n0) continue;
+                if (ldg(b.use + l) == 0 || l < c.n0) continue;
                 if (isinf(ldg(b.worst + l))) { stg(b.bad + l, 1); stg(b.use + l, 0); atomicAdd(flip_ctr, 1); }
             }
             int nf = 0;
@@ -1433,7 +1515,7 @@ __global__ __launch_bounds__(kT) void slam_ba_kernel(BaDev b, SlamDev d, BaParam
         barriers += 1;
         int32_t *bad_ctr = fresh_counter(c);
         for (int l = gtid; l < N; l += gthreads) {
-            const bool cand = ldg(b.use + l) != 0 && l >= b.n0 && !(ldg(b.worst + l) <= p.outlier_px);
+            const bool cand = ldg(b.use + l) != 0 && l >= c.n0 && !(ldg(b.worst + l) <= p.outlier_px);
             stg(b.cand + l, cand ? 1 : 0);
             if (cand) atomicAdd(bad_ctr, 1);
         }
@@ -1460,10 +1542,38 @@ __global__ __launch_bounds__(kT) void slam_ba_kernel(BaDev b, SlamDev d, BaParam
         double q[12], M[12];
         for (int k = 0; k < 12; ++k) q[k] = ldg(poses_cur + 12 * j + k);
         pose12_to_w2c(q, M);
-        for (int k = 0; k < 12; ++k) d.traj[12 * (size_t)j + k] = M[k];
-        if (j < b.poses_host_cap) for (int k = 0; k < 12; ++k) b.poses_host[12 * (size_t)j + k] = M[k];
+        const int tj = pose_of(c, j), row = tj - p.sel0;
+        for (int k = 0; k < 12; ++k) d.traj[12 * (size_t)tj + k] = M[k];
+        if (row < b.poses_host_cap) for (int k = 0; k < 12; ++k) b.poses_host[12 * (size_t)row + k] = M[k];
         if (j == P - 1) for (int k = 0; k < 12; ++k) d.pose_prev[k] = M[k];
-        if (j == p.key_pose) for (int k = 0; k < 12; ++k) d.pose_key[k] = M[k];
+        if (tj == p.key_pose) for (int k = 0; k < 12; ++k) d.pose_key[k] = M[k];
+    }
+    if (!p.identity) {
+        // the accepted frames behind sel[0] that are not poses of this problem: each keeps its pose RELATIVE to the last problem pose
+        // in front of it (M_j <- M_j inv(A_old) A_new, A = that pose's [R | t] before / after this adjustment) -- or stays (carry off);
+        // either way its row goes to the host with the others
+        for (int tj = p.sel0 + gtid; tj < p.P_all; tj += gthreads) {
+            const int a = anchor_of(c, tj);
+            if (lds_sel()[a] == tj) continue;
+            double M[12];
+            for (int k = 0; k < 12; ++k) M[k] = d.traj[12 * (size_t)tj + k];
+            if (p.carry) {
+                double Ao[12], q[12], An[12], Rr[9], tr[3];
+                for (int k = 0; k < 12; ++k) { Ao[k] = ldg(b.traj_old + 12 * a + k); q[k] = ldg(poses_cur + 12 * a + k); }
+                pose12_to_w2c(q, An);
+                // D = M inv(Ao): rotation R_m R_o^T, translation t_m - D_R t_o; then M' = D An
+                for (int r = 0; r < 3; ++r)
+                    for (int s2 = 0; s2 < 3; ++s2) Rr[3 * r + s2] = M[4 * r] * Ao[4 * s2] + M[4 * r + 1] * Ao[4 * s2 + 1] + M[4 * r + 2] * Ao[4 * s2 + 2];
+                for (int r = 0; r < 3; ++r) tr[r] = M[4 * r + 3] - (Rr[3 * r] * Ao[3] + Rr[3 * r + 1] * Ao[7] + Rr[3 * r + 2] * Ao[11]);
+                for (int r = 0; r < 3; ++r) {
+                    for (int s2 = 0; s2 < 3; ++s2) M[4 * r + s2] = Rr[3 * r] * An[s2] + Rr[3 * r + 1] * An[4 + s2] + Rr[3 * r + 2] * An[8 + s2];
+                    M[4 * r + 3] = Rr[3 * r] * An[3] + Rr[3 * r + 1] * An[7] + Rr[3 * r + 2] * An[11] + tr[r];
+                }
+                for (int k = 0; k < 12; ++k) d.traj[12 * (size_t)tj + k] = M[k];
+            }
+            const int row = tj - p.sel0;
+            if (row < b.poses_host_cap) for (int k = 0; k < 12; ++k) b.poses_host[12 * (size_t)row + k] = M[k];
+        }
     }
     if (c.wg == 0) {
         for (int l = c.tid; l < N; l += kT)
@@ -1473,7 +1583,7 @@ __global__ __launch_bounds__(kT) void slam_ba_kernel(BaDev b, SlamDev d, BaParam
             double *r = b.report;
             r[0] = 0.0; r[1] = (double)P; r[2] = (double)N; r[3] = su; r[4] = so; r[5] = (double)passes; r[6] = (double)dropped;
             r[7] = (double)lm_iters; r[8] = cost_before; r[9] = cost_after; r[10] = (double)trials; r[11] = (double)dups;
-            r[12] = (double)p.n_odo; r[13] = (double)barriers;
+            r[12] = (double)p.n_odo; r[13] = (double)barriers; r[14] = (double)p.sel0; r[15] = (double)(p.P_all - p.sel0);
         }
         stamp(c, 7);
     }
@@ -1487,8 +1597,10 @@ struct mqs_slam_ba {
     size_t arena_bytes;
     BaDev dev;
     int n_odo;
-    double *host;                       // pinned: report + poses (the kernel writes both; host_dev: the device's view of it)
-    double *host_dev;
+    double *host;                       // pinned: report [MQS_SLAM_BA_REPORT], the selection [kMaxPoses int32], poses [host_rows][12] (the kernel writes report and poses,
+    double *host_dev;                   // reads the selection; host_dev: the device's view of it)
+    int host_rows;
+    int fail_next;                      // test hook (mqs_debug_slam_ba_fail_next): the next adjustment returns this code, nothing launched
     uint32_t *sync_base;                // two 64-byte blocks of barrier words, used alternately (parity)
     int parity;
     char *fixed;                        // the part of the state that lives across re-allocations of the arena
@@ -1498,6 +1610,7 @@ struct mqs_slam_ba {
 namespace {
 
 constexpr size_t up256(size_t v) { return (v + 255) & ~size_t(255); }
+constexpr size_t kHostPoses = MQS_SLAM_BA_REPORT + kMaxPoses / 2;      // doubles in front of the pose rows of the pinned block: report, selection
 
 int ba_fixed_alloc(mqs_slam *s)
 {
@@ -1508,15 +1621,17 @@ int ba_fixed_alloc(mqs_slam *s)
     auto take = [&](size_t bytes) { const size_t o = off; off = up256(off + bytes); return o; };
     const size_t o_sync = take(128), o_ctr = take(kCtr * 4), o_rep = take(MQS_SLAM_BA_REPORT * 8), o_p0 = take(96), o_o0 = take(kMaxTracks * 24),
                  o_bad = take(L * 4), o_of = take(kMaxEdges * 4), o_ot = take(kMaxEdges * 4), o_om = take(kMaxEdges * 96),
-                 o_ei = take(kMaxPoses * 4), o_eo = take(kMaxPoses * 4), o_er = take((size_t)kMaxEdges * kERec * 8), o_pr = take(128),
-                 o_med = take(64), o_part = take(256 * 32), o_dp = take((6 * kMaxPoses + 64) * 8), o_ys = take((6 * kMaxPoses + 64) * 8),
+                 o_ei = take((size_t)s->d.traj_cap * 4), o_eo = take((size_t)s->d.traj_cap * 4), o_er = take((size_t)kMaxEdges * kERec * 8), o_pr = take(256),
+                 o_to = take(kMaxPoses * 96),
+                 o_med = take(64), o_part = take(kMaxGroups * 32), o_dp = take((6 * kMaxPoses + 64) * 8), o_ys = take((6 * kMaxPoses + 64) * 8),
                  o_pa = take(kMaxPoses * 96), o_pb = take(kMaxPoses * 96), o_pi = take(kMaxPoses * 96),
                  o_pc = take(kMaxPoses * 4), o_lo = take(kMaxPoses * 4), o_hi = take(kMaxPoses * 4),
                  o_pl = take((size_t)kMaxPoses * kListCap * 8), o_bo = take((size_t)kMaxPoses * (kMaxPoses + 1) / 2 * 4),
                  o_bc = take((size_t)kMaxPoses * (kMaxPoses + 1) / 2 * 4), o_lr = take((size_t)s->d.log_cap * 4), o_rec = take((size_t)s->d.log_cap * kRec * 8);
     hipError_t e = hipMalloc((void **)&ba->fixed, off);
     if (e != hipSuccess) { delete ba; mqs_set_error("hipMalloc(%zu) failed: %s", off, hipGetErrorString(e)); return MQS_E_NOMEM; }
-    e = hipHostMalloc((void **)&ba->host, (MQS_SLAM_BA_REPORT + 12 * (size_t)kMaxPoses) * 8, hipHostMallocDefault);
+    ba->host_rows = 1024; ba->fail_next = 0;
+    e = hipHostMalloc((void **)&ba->host, (kHostPoses + 12 * (size_t)ba->host_rows) * 8, hipHostMallocDefault);
     if (e != hipSuccess) { (void)hipFree(ba->fixed); delete ba; mqs_set_error("hipHostMalloc failed: %s", hipGetErrorString(e)); return MQS_E_NOMEM; }
     char *a = ba->fixed;
     BaDev &b = ba->dev;
@@ -1525,7 +1640,8 @@ int ba_fixed_alloc(mqs_slam *s)
     if (e == hipSuccess) e = hipMemsetAsync(ba->sync_base, 0, 128, s->stream);
     if (e != hipSuccess) { (void)hipFree(ba->fixed); (void)hipHostFree(ba->host); delete ba; mqs_set_error("mqs_slam_bundle_adjust: %s", hipGetErrorString(e)); return MQS_E_HIP; }
     (void)o_rep;
-    b.sync = ba->sync_base; b.sync_next = ba->sync_base + 16; b.poses_host = ba->host_dev + MQS_SLAM_BA_REPORT; b.poses_host_cap = 0;
+    b.sync = ba->sync_base; b.sync_next = ba->sync_base + 16; b.poses_host = ba->host_dev + kHostPoses; b.poses_host_cap = 0;
+    b.sel_host = reinterpret_cast<const int32_t *>(ba->host_dev + MQS_SLAM_BA_REPORT); b.traj_old = (double *)(a + o_to);
     b.ctr = (int32_t *)(a + o_ctr); b.report = ba->host_dev; b.pose0 = (double *)(a + o_p0);
     b.objp0 = (double *)(a + o_o0); b.bad = (int32_t *)(a + o_bad); b.odo_from = (int32_t *)(a + o_of); b.odo_to = (int32_t *)(a + o_ot);
     b.odo_meas = (double *)(a + o_om); b.e_in = (int32_t *)(a + o_ei); b.e_out = (int32_t *)(a + o_eo); b.erec = (double *)(a + o_er);
@@ -1537,8 +1653,8 @@ int ba_fixed_alloc(mqs_slam *s)
     ba->arena = nullptr; ba->arena_bytes = 0; ba->n_odo = 0; ba->stamps = nullptr; b.stamps = nullptr;
     // retired flags 0, no edges
     e = hipMemsetAsync(b.bad, 0, L * 4, s->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(b.e_in, 0xff, kMaxPoses * 4, s->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(b.e_out, 0xff, kMaxPoses * 4, s->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(b.e_in, 0xff, (size_t)s->d.traj_cap * 4, s->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(b.e_out, 0xff, (size_t)s->d.traj_cap * 4, s->stream);
     if (e != hipSuccess) { (void)hipFree(ba->fixed); (void)hipHostFree(ba->host); delete ba; mqs_set_error("mqs_slam_bundle_adjust: %s", hipGetErrorString(e)); return MQS_E_HIP; }
     s->ba = ba;
     return MQS_OK;
@@ -1560,7 +1676,7 @@ int ba_reserve(mqs_slam *s, int P, int N_ub)
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t o = off; off = up256(off + bytes); return o; };
     const size_t o_T = take((size_t)P_cap * N_cap * 4), o_pl = take((size_t)N_cap * 4), o_use = take((size_t)N_cap * 4), o_mn = take((size_t)N_cap * 4),
-                 o_mx = take((size_t)N_cap * 4), o_cd = take((size_t)N_cap * 4), o_a = take((size_t)N_cap * 24), o_b = take((size_t)N_cap * 24),
+                 o_mx = take((size_t)N_cap * 4), o_cd = take((size_t)N_cap * 4), o_oc = take((size_t)N_cap * 4), o_a = take((size_t)N_cap * 24), o_b = take((size_t)N_cap * 24),
                  o_i = take((size_t)N_cap * 24), o_w = take((size_t)N_cap * 8), o_z = take((size_t)N_cap * 8),
                  o_S = take((size_t)ntile_cap * TB * TB * 8), o_L = take((size_t)ntile_cap * TB * TB * 8);
     // hit lists: a landmark seen from k poses has k (k - 1) / 2 of them; ~300 tracks per frame living ~30 frames: 4 500 P
@@ -1574,12 +1690,14 @@ int ba_reserve(mqs_slam *s, int P, int N_ub)
     char *a = ba->arena;
     BaDev &b = ba->dev;
     b.T = (int32_t *)(a + o_T); b.per_lm = (int32_t *)(a + o_pl); b.use = (int32_t *)(a + o_use); b.pmin = (int32_t *)(a + o_mn); b.pmax = (int32_t *)(a + o_mx);
-    b.cand = (int32_t *)(a + o_cd); b.pts_a = (double *)(a + o_a); b.pts_b = (double *)(a + o_b); b.pts_init = (double *)(a + o_i);
+    b.cand = (int32_t *)(a + o_cd); b.out_cnt = (int32_t *)(a + o_oc); b.pts_a = (double *)(a + o_a); b.pts_b = (double *)(a + o_b); b.pts_init = (double *)(a + o_i);
     b.worst = (double *)(a + o_w); b.zmin = (double *)(a + o_z); b.S = (double *)(a + o_S); b.Lp = (double *)(a + o_L);
     b.hits = (long long *)(a + o_h); b.hits_cap = hits_cap;
     b.N_cap = N_cap; b.P_cap = P_cap; b.ntile_cap = ntile_cap;
     return MQS_OK;
 }
+
+mqs_lds_opt_in g_ba_lds_opt;
 
 __global__ void slam_ba_anchor_kernel(BaDev b, SlamDev d, int n0)
 {
@@ -1621,18 +1739,55 @@ int mqs_slam_ba_anchor(mqs_slam *s, int n0)
         BaParams p;
         memset(&p, 0, sizeof(p));
         p.G = 1;
-        const size_t lds = ((size_t)2 * kMaxPoses * kCamStride + 6 * kMaxPoses + 32 + 64) * sizeof(double);
-        static mqs_lds_opt_in opt;
-        MQS_HIP_CHECK(mqs_lds_opt_in_once(opt, reinterpret_cast<const void *>(slam_ba_kernel), lds));
-        hipLaunchKernelGGL(slam_ba_kernel, dim3(1), dim3(kT), lds, s->stream, s->ba->dev, s->d, p);
+        p.identity = 1;
+        MQS_HIP_CHECK(mqs_lds_opt_in_once(g_ba_lds_opt, reinterpret_cast<const void *>(slam_ba_kernel), kLdsBytes));
+        hipLaunchKernelGGL(slam_ba_kernel, dim3(1), dim3(kT), kLdsBytes, s->stream, s->ba->dev, s->d, p);
     }
     MQS_HIP_CHECK(hipGetLastError());
     return MQS_OK;
 }
 
-extern "C" {
+namespace {
 
-int mqs_slam_bundle_adjust(mqs_slam *s, const mqs_slam_ba_params *q, double *report, double *poses_out, int32_t poses_cap)
+// How many workgroups of the adjuster can be RESIDENT at once on this device: its grid-wide barriers spin, so a workgroup that is
+// never dispatched is a launch that waits 2 s and gives up.  One workgroup per CU (the LDS enforces it); cached per device.
+int ba_resident_groups(int device, int *out)
+{
+    static int cached[64];
+    if (device >= 0 && device < 64 && cached[device] > 0) { *out = cached[device]; return MQS_OK; }
+    hipDeviceProp_t prop;
+    MQS_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    int per_cu = 0;
+    MQS_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, slam_ba_kernel, kT, kLdsBytes));
+    const long long g = (long long)per_cu * prop.multiProcessorCount;
+    *out = g > kMaxGroups ? kMaxGroups : (int)g;                      // (the kernel's own bound: its per-workgroup cost pieces)
+    if (device >= 0 && device < 64) cached[device] = *out;
+    return MQS_OK;
+}
+
+// one adjuster launch at a time per device in this process: two launches whose workgroups wait for each other's CUs would both spin
+std::mutex g_ba_launch_mutex[64];
+
+int ba_grow_host(mqs_slam *s, int rows)
+{
+    mqs_slam_ba *ba = s->ba;
+    if (rows <= ba->host_rows) return MQS_OK;
+    int cap = ba->host_rows;
+    while (cap < rows) cap *= 2;
+    MQS_HIP_CHECK(hipStreamSynchronize(s->stream));
+    double *h = nullptr, *hd = nullptr;
+    hipError_t e = hipHostMalloc((void **)&h, (kHostPoses + 12 * (size_t)cap) * 8, hipHostMallocDefault);
+    if (e != hipSuccess) { mqs_set_error("hipHostMalloc failed: %s", hipGetErrorString(e)); return MQS_E_NOMEM; }
+    e = hipHostGetDevicePointer((void **)&hd, h, 0);
+    if (e != hipSuccess) { (void)hipHostFree(h); mqs_set_error("hipHostGetDevicePointer failed: %s", hipGetErrorString(e)); return MQS_E_HIP; }
+    (void)hipHostFree(ba->host);
+    ba->host = h; ba->host_dev = hd; ba->host_rows = cap;
+    ba->dev.report = hd; ba->dev.poses_host = hd + kHostPoses;
+    ba->dev.sel_host = reinterpret_cast<const int32_t *>(hd + MQS_SLAM_BA_REPORT);
+    return MQS_OK;
+}
+
+int ba_run(mqs_slam *s, const mqs_slam_ba_params *q, const mqs_slam_ba_window *w, double *report, double *poses_out, int32_t poses_cap)
 {
     MQS_ARG_CHECK(s != nullptr && q != nullptr && report != nullptr, "handle, params, report must not be null");
     MQS_ARG_CHECK(s->started && s->log_arena != nullptr && s->ba != nullptr, "mqs_slam_log_enable before mqs_slam_start");
@@ -1640,64 +1795,152 @@ int mqs_slam_bundle_adjust(mqs_slam *s, const mqs_slam_ba_params *q, double *rep
                   "max_iterations in [0, 100], min_observations >= 1, max_passes in [1, 16]");
     MQS_ARG_CHECK(q->point_sigma > 0.0 && q->pixel_sigma > 0.0 && q->outlier_px > 0.0 && q->lambda_factor > 1.0 && q->lambda_initial > 0.0, "sigmas, bounds, LM parameters");
     MQS_ARG_CHECK(poses_out == nullptr || poses_cap >= 0, "poses_cap >= 0");
+    for (int k = 0; k < 6; ++k) MQS_ARG_CHECK(q->pose_sigmas[k] > 0.0 && q->odometry_sigmas[k] > 0.0, "sigmas > 0");
     MQS_HIP_CHECK(hipSetDevice(s->device));
-    const int P = s->accepted;
-    if (P > kMaxPoses) {
-        mqs_set_error("mqs_slam_bundle_adjust: %d accepted frames; the resident adjuster takes at most %d (a windowed or host-built adjustment beyond)", P, kMaxPoses);
-        return MQS_E_ARG;
-    }
+    const int P_all = s->accepted;
+    const bool windowed = w != nullptr && w->n_poses > 0;
+    const int P = windowed ? w->n_poses : P_all;
     mqs_slam_ba *ba = s->ba;
     BaParams p;
     memset(&p, 0, sizeof(p));
+    p.anchor2 = -1;
+    if (windowed) {
+        MQS_ARG_CHECK(w->poses != nullptr && w->n_poses <= P_all, "window: poses must not be null, n_poses <= accepted frames");
+        MQS_ARG_CHECK(w->seen_outside_sigma >= 0.0, "window: seen_outside_sigma >= 0");
+        if (P > kMaxPoses) {
+            mqs_set_error("mqs_slam_bundle_adjust_window: %d poses selected; the resident adjuster takes at most %d", P, kMaxPoses);
+            return MQS_E_ARG;
+        }
+        bool asc = w->poses[0] >= 0, has_key = false;
+        for (int k = 0; k < P; ++k) {
+            if (k > 0 && w->poses[k] <= w->poses[k - 1]) asc = false;
+            if (w->poses[k] == s->key_pose) has_key = true;
+        }
+        MQS_ARG_CHECK(asc && w->poses[P - 1] == P_all - 1, "window: pose indices ascending, the last one = the last accepted frame");
+        MQS_ARG_CHECK(has_key, "window: the base keyframe of the live tracks must be one of the poses");
+        MQS_ARG_CHECK(w->second_anchor < P_all, "window: second_anchor < accepted frames");
+        bool ident = true;
+        for (int k = 0; k < P && ident; ++k) ident = w->poses[k] == k;
+        p.identity = (ident && P == P_all) ? 1 : 0;
+        p.sel0 = w->poses[0];
+        p.anchor2 = w->second_anchor >= 0 ? w->second_anchor : -1;
+        p.carry = w->carry_unselected != 0;
+        p.out_prior_w = w->seen_outside_sigma > 0.0 ? 1.0 / (w->seen_outside_sigma * w->seen_outside_sigma) : 0.0;
+    } else {
+        if (P > kMaxPoses) {
+            mqs_set_error("mqs_slam_bundle_adjust: %d accepted frames; the resident adjuster takes at most %d poses (mqs_slam_bundle_adjust_window selects them)", P, kMaxPoses);
+            return MQS_E_ARG;
+        }
+        p.identity = 1;
+    }
     if (q->add_odometry_edge) {
-        MQS_ARG_CHECK(q->edge_from >= 0 && q->edge_from < q->edge_to && q->edge_to < P, "0 <= edge_from < edge_to < accepted frames");
+        MQS_ARG_CHECK(q->edge_from >= 0 && q->edge_from < q->edge_to && q->edge_to < P_all, "0 <= edge_from < edge_to < accepted frames");
         MQS_ARG_CHECK(ba->n_odo < kMaxEdges, "too many odometry edges");
-        ba->n_odo += 1;
         p.add_edge = 1; p.edge_from = q->edge_from; p.edge_to = q->edge_to;
+    }
+    if (ba->fail_next) {
+        const int code = ba->fail_next;
+        ba->fail_next = 0;
+        mqs_set_error("mqs_slam_bundle_adjust: failure injected by mqs_debug_slam_ba_fail_next (%d); nothing was launched or written", code);
+        return code;
     }
     int rc = ba_reserve(s, P, s->land_ub > 0 ? s->land_ub : 1);
     if (rc != MQS_OK) return rc;
+    rc = ba_grow_host(s, P_all - p.sel0);
+    if (rc != MQS_OK) return rc;
     int G = q->workgroups > 0 ? q->workgroups : (P > 96 ? 256 : 128);     // the pose-pair phases have P^2 / 2 tasks; the chain of block factors does not care
+    const bool g_forced = q->workgroups > 0;
     if (const char *e = getenv("MQS_SLAM_BA_GROUPS")) { const int g = atoi(e); if (g > 0) G = g; }
-    if (G > 256) G = 256;
-    p.P = P; p.G = G; p.key_pose = s->key_pose;
+    // every workgroup has to be resident (the barriers spin): the library's own choice is clamped to what the device holds, a
+    // caller's explicit request beyond that is an error at once -- not a 2 s wait that gives up
+    int resident = 0;
+    rc = ba_resident_groups(s->device, &resident);
+    if (rc != MQS_OK) return rc;
+    if (resident < 1) { mqs_set_error("mqs_slam_bundle_adjust: no workgroup of the adjuster fits a compute unit of device %d (%zu bytes of LDS)", s->device, kLdsBytes); return MQS_E_ARG; }
+    if (G > resident) {
+        if (g_forced || getenv("MQS_SLAM_BA_GROUPS")) {
+            mqs_set_error("mqs_slam_bundle_adjust: %d workgroups requested, device %d holds %d of them at once (one per compute unit: %zu bytes of LDS each); "
+                          "the adjustment's grid-wide barriers need all of them resident", G, s->device, resident, kLdsBytes);
+            return MQS_E_ARG;
+        }
+        G = resident;
+    }
+    p.P = P; p.P_all = P_all; p.G = G; p.key_pose = s->key_pose;
     p.max_iterations = q->max_iterations; p.min_observations = q->min_observations; p.max_passes = q->max_passes; p.damping = q->damping;
-    p.n_odo = ba->n_odo;
+    p.n_odo = ba->n_odo + (p.add_edge ? 1 : 0);
     p.outlier_px = q->outlier_px; p.gross_px = q->gross_px; p.border = q->border_margin_px; p.min_depth_ratio = q->min_depth_ratio;
     p.prior_w = 1.0 / (q->point_sigma * q->point_sigma); p.sigma_px = q->pixel_sigma; p.isigma_px = 1.0 / q->pixel_sigma;
     for (int k = 0; k < 6; ++k) {
-        MQS_ARG_CHECK(q->pose_sigmas[k] > 0.0 && q->odometry_sigmas[k] > 0.0, "sigmas > 0");
         p.pose_w[k] = 1.0 / (q->pose_sigmas[k] * q->pose_sigmas[k]);
         p.odo_w[k] = 1.0 / (q->odometry_sigmas[k] * q->odometry_sigmas[k]);
     }
     p.lam0 = q->lambda_initial; p.lam_factor = q->lambda_factor; p.lam_upper = q->lambda_upper; p.abs_tol = q->abs_tol; p.rel_tol = q->rel_tol;
     p.W = s->p.W; p.H = s->p.H;
-    const size_t lds = ((size_t)2 * kMaxPoses * kCamStride + 6 * kMaxPoses + 32 + 64) * sizeof(double);
-    static mqs_lds_opt_in opt;
-    MQS_HIP_CHECK(mqs_lds_opt_in_once(opt, reinterpret_cast<const void *>(slam_ba_kernel), lds));
+    MQS_HIP_CHECK(mqs_lds_opt_in_once(g_ba_lds_opt, reinterpret_cast<const void *>(slam_ba_kernel), kLdsBytes));
     // No fill or copy launch around the adjustment: the barrier words alternate between two blocks (a launch zeroes the next one's), the
-    // report and the adjusted poses are written by the kernel into pinned host memory (NaN there: a launch that wrote no report).
-    const int np = poses_out ? (P < poses_cap ? P : poses_cap) : 0;
+    // report and the adjusted poses are written by the kernel into pinned host memory (NaN there: a launch that wrote no report), the
+    // selection is read from it.
+    const int rows = P_all - p.sel0;
+    const int np = poses_out ? (rows < poses_cap ? rows : poses_cap) : 0;
     memset(ba->host, 0xff, MQS_SLAM_BA_REPORT * 8);
-    ba->dev.sync = ba->sync_base + 16 * ba->parity; ba->dev.sync_next = ba->sync_base + 16 * (1 - ba->parity);
-    ba->dev.poses_host_cap = np;
-    ba->parity ^= 1;
-    hipLaunchKernelGGL(slam_ba_kernel, dim3(G), dim3(kT), lds, s->stream, ba->dev, s->d, p);
-    MQS_HIP_CHECK(hipGetLastError());
-    MQS_HIP_CHECK(hipStreamSynchronize(s->stream));
+    if (!p.identity) memcpy(ba->host + MQS_SLAM_BA_REPORT, w->poses, (size_t)P * 4);
+    {
+        std::lock_guard<std::mutex> lock(g_ba_launch_mutex[(s->device >= 0 && s->device < 64) ? s->device : 0]);
+        ba->dev.sync = ba->sync_base + 16 * ba->parity; ba->dev.sync_next = ba->sync_base + 16 * (1 - ba->parity);
+        ba->dev.poses_host_cap = np;
+        ba->parity ^= 1;
+        hipLaunchKernelGGL(slam_ba_kernel, dim3(G), dim3(kT), kLdsBytes, s->stream, ba->dev, s->d, p);
+        MQS_HIP_CHECK(hipGetLastError());
+        MQS_HIP_CHECK(hipStreamSynchronize(s->stream));
+    }
     memcpy(report, ba->host, MQS_SLAM_BA_REPORT * 8);
-    if (np > 0) memcpy(poses_out, ba->host + MQS_SLAM_BA_REPORT, (size_t)np * 96);
+    if (np > 0) memcpy(poses_out, ba->host + kHostPoses, (size_t)np * 96);
     if (!(report[0] == 0.0)) {
-        // (a launch that gave up leaves its barrier words as they were: both blocks start from zero again)
+        // (a launch that gave up leaves its barrier words as they were: both blocks start from zero again; an edge this call brought is
+        // not kept -- the kernel may have returned before writing it)
         (void)hipMemsetAsync(ba->sync_base, 0, 128, s->stream);
         (void)hipStreamSynchronize(s->stream);
         ba->parity = 0;
         if (report[0] == 1.0) { mqs_set_error("mqs_slam_bundle_adjust: a grid-wide wait of the adjustment gave up (2 s); nothing was written back"); return MQS_E_TIMEOUT; }
         if (report[0] == 3.0) { mqs_set_error("mqs_slam_bundle_adjust: the observation log is full (%d entries): observations have been dropped", s->d.log_cap); return MQS_E_ARG; }
         mqs_set_error("mqs_slam_bundle_adjust: capacity (poses %g of %d, landmarks %g, a frame with more than %d observations, or more co-observations than the hit lists hold)", report[1], kMaxPoses, report[2], kListCap);
-        return MQS_E_ARG;
+        return MQS_E_CAPACITY;
     }
+    if (p.add_edge) ba->n_odo += 1;
     return MQS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mqs_slam_bundle_adjust(mqs_slam *s, const mqs_slam_ba_params *q, double *report, double *poses_out, int32_t poses_cap)
+{
+    return ba_run(s, q, nullptr, report, poses_out, poses_cap);
+}
+
+int mqs_slam_bundle_adjust_window(mqs_slam *s, const mqs_slam_ba_params *q, const mqs_slam_ba_window *w, double *report, double *poses_out, int32_t poses_cap)
+{
+    MQS_ARG_CHECK(w != nullptr, "window must not be null");
+    return ba_run(s, q, w, report, poses_out, poses_cap);
+}
+
+int mqs_debug_slam_ba_fail_next(mqs_slam *s, int code)
+{
+    MQS_ARG_CHECK(s != nullptr && s->ba != nullptr, "handle (started with the log on)");
+    MQS_ARG_CHECK(code == MQS_E_TIMEOUT || code == MQS_E_CAPACITY || code == 0, "code: MQS_E_TIMEOUT, MQS_E_CAPACITY or 0");
+    s->ba->fail_next = code;
+    return MQS_OK;
+}
+
+int mqs_slam_ba_resident_groups(mqs_slam *s, int32_t *groups)
+{
+    MQS_ARG_CHECK(s != nullptr && groups != nullptr, "handle, groups must not be null");
+    MQS_HIP_CHECK(hipSetDevice(s->device));
+    int g = 0;
+    const int rc = ba_resident_groups(s->device, &g);
+    *groups = g;
+    return rc;
 }
 
 // Profiling hook: switches the phase stamps of the adjuster's launches on (the first call allocates them) and returns those of the

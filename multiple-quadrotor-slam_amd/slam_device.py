@@ -39,6 +39,14 @@ class _BaParams(ctypes.Structure):                       # include/mqslam.h: mqs
                 [(k, ctypes.c_double) for k in ("lambda_initial", "lambda_factor", "lambda_upper", "abs_tol", "rel_tol")])
 
 
+class _BaWindow(ctypes.Structure):                       # include/mqslam.h: mqs_slam_ba_window
+    _fields_ = [("n_poses", ctypes.c_int32), ("second_anchor", ctypes.c_int32), ("carry_unselected", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("poses", ctypes.POINTER(ctypes.c_int32)), ("seen_outside_sigma", ctypes.c_double)]
+
+
+MQS_E_TIMEOUT, MQS_E_CAPACITY = -6, -7                   # include/mqslam.h
+
+
 REASONS = {0: "", 1: "lost track of too many points", 2: "fewer than 8 triangulated tracks", 3: "no RANSAC model",
            4: "PnP outlier ratio", 5: "reprojection error"}
 
@@ -59,10 +67,91 @@ def _reprojection_residuals(poses_c2w, points, calib, lm, pose_idx, uv):
     return np.hypot(fx * xd + sk * yd + u0 - uv[:, 0], fy * yd + v0 - uv[:, 1])
 
 
+class FrameUploader:
+    """Frame ingest of the device-resident loop: the reference reads every frame INSIDE its loop (slam2.py:1209-1213: cv2.imread per
+    iteration); here a frame arrives in host memory and goes to the device on a SIDE stream while the loop's kernels work on the frames
+    before it.  Iterating yields the device images in order, each uploaded completely (its event waited for) -- ready for
+    `DeviceMonoSlam.start` / `handle_new_frame(img, uploaded=True)`, which then skips the wait for torch's current stream.
+
+    frames: a sequence of H x W uint8 arrays (numpy; copied into a pinned staging slot by the uploader's thread -- the copy releases
+    the interpreter lock and runs beside the loop's library calls, which release it too), or ONE pinned uint8 torch tensor
+    [n, H, W] (a capture buffer the driver delivers into: no staging copy).  depth: uploads in flight ahead of the loop.
+    Every frame gets a device tensor of its own (the loop holds on to the previous image, and to a rejected frame's predecessor)."""
+
+    def __init__(self, frames, device=0, depth=4):
+        import threading, queue
+        import torch
+        self._torch = torch
+        self._frames = frames
+        self._n = len(frames)
+        self._dev = torch.device("cuda", int(device))
+        self._stream = torch.cuda.Stream(device=self._dev)
+        self._q = queue.Queue(maxsize=max(1, int(depth)))
+        self._pinned_source = isinstance(frames, torch.Tensor)
+        if self._pinned_source and not (frames.dtype == torch.uint8 and frames.is_pinned() and frames.dim() == 3 and frames.is_contiguous()):
+            raise ValueError("a torch source is one pinned contiguous uint8 tensor [n, H, W]")
+        shape = tuple(frames.shape[1:]) if self._pinned_source else tuple(np.asarray(frames[0]).shape)
+        self._stage = None if self._pinned_source else [torch.empty(shape, dtype=torch.uint8).pin_memory() for _ in range(max(1, int(depth)) + 2)]
+        self._stage_ev = [None] * (0 if self._pinned_source else len(self._stage))
+        self._stop = False
+        self._error = None
+        self._thread = threading.Thread(target=self._run, name="mqs-frame-uploader", daemon=True)
+        self._thread.start()
+
+    def _run(self):
+        torch = self._torch
+        try:
+            with torch.cuda.device(self._dev), torch.cuda.stream(self._stream):
+                for k in range(self._n):
+                    if self._stop:
+                        break
+                    if self._pinned_source:
+                        src = self._frames[k]
+                    else:
+                        slot = k % len(self._stage)
+                        if self._stage_ev[slot] is not None:
+                            self._stage_ev[slot].synchronize()              # the slot's last upload has left it
+                        src = self._stage[slot]
+                        np.copyto(src.numpy(), np.asarray(self._frames[k], dtype=np.uint8))
+                    img = torch.empty(src.shape, dtype=torch.uint8, device=self._dev)
+                    img.copy_(src, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(self._stream)
+                    if not self._pinned_source:
+                        self._stage_ev[k % len(self._stage)] = ev
+                    self._q.put((img, ev))
+        except Exception as e:                                              # noqa: BLE001 -- handed to the consumer
+            self._error = e
+        self._q.put(None)
+
+    def __len__(self):
+        return self._n
+
+    def __iter__(self):
+        while True:
+            item = self._q.get()
+            if item is None:
+                if self._error is not None:
+                    raise self._error
+                return
+            img, ev = item
+            ev.synchronize()
+            yield img
+
+    def close(self):
+        self._stop = True
+        try:
+            while self._q.get_nowait() is not None:
+                pass
+        except Exception:
+            pass
+
+
 class DeviceMonoSlam:
     def __init__(self, cameraMatrix, distCoeffs, image_shape, seed=0, device=0, max_landmarks=1 << 16, verbose=False,
                  ba_info=None, max_homography_points=0, bundle_adjust=None, ba_iterations=10, ba_log_capacity=1 << 20,
-                 reassociate=False, ba_window_keyframes=None, second_pass_screen=None, ba_engine="device", ba_check=False):
+                 reassociate=False, ba_window_keyframes=3, second_pass_screen=None, ba_engine="device", ba_check=False,
+                 ba_history_keyframes=None):
         """max_homography_points: size of keyframe_test's random sample of the tracks (slam2.py:48): 0 = every track (default),
         "reference" = the reference's max(4, target_amount_keypoints / 4) (:1088-1089).  On the rendered test sequence the quarter
         makes the run depend on the draw -- trajectory RMSE 0.017-0.020 for half of the seeds, 0.057-0.068 for the other half,
@@ -81,8 +170,17 @@ class DeviceMonoSlam:
         its twin for the tests and for ba_window_keyframes: the log comes to the host, numpy builds the problem, `sparse_ba.
         SparseBundleAdjuster` adjusts it, `mqs_slam_write_back` returns it.  ba_check=True runs the host twin first WITHOUT writing
         anything back and keeps (host, device) result pairs in `ba_checks`.
-        ba_window_keyframes=K (>= 2): the adjustment takes the frames since the K-th keyframe from the end instead of every frame so
-        far, anchored by tight pose priors on the window's first two keyframes -- the cost of an adjustment stops growing with the run.
+        ba_window_keyframes=K (>= 1; default 3; None / 0: every accepted frame -- what the reference's tool does with a finished recording,
+        bundle_adjust.cpp:190-330): the problem's poses are a SELECTION of the accepted frames (`mqs_slam_bundle_adjust_window`) --
+        every frame since the K-th keyframe from the end, and of the frames in front of those the KEYFRAMES only (all of them;
+        ba_history_keyframes=H: the last H).  The frames left out keep their pose relative to the keyframe in front of them; what they
+        saw of a landmark counts towards its three sightings and -- `ba_window_point_sigma` -- stays with it as a prior at its current
+        value.  While frame 0 is selected the gauge is the plain adjustment's; once it is not, the first selected pose and the next
+        selected keyframe are held by priors at their current values.  The cost of an adjustment then grows with the keyframes of the
+        run (or, with H, not at all) instead of with its frames, and runs of any length stay on the device engine: beyond 256
+        accepted frames a selection is made in any case (every keyframe + the latest frames that fit).  On the 200 frames of the
+        reference's example sequence, 16 seeds (profiles/r06): every frame 5.1 mm median / 8.0 worst at 1 575 frames/s; K = 3:
+        4.8 / 7.2 at 3 130; K = 2: 5.1 / 9.4 at 3 440; K = 4: 4.5 / 7.3 at 2 890.
         second_pass_screen=px (None / 0: off, the reference's flow): at a keyframe a freshly triangulated point whose reprojection error
         in the current frame exceeds px is not handed to the second solvePnP (slam2.py:576-577) -- the use slam2.py:1092 announces for
         max_2nd_solvePnP_reproj_error (= 1 px) and never makes; see mqs_slam_set_second_pass_screen.
@@ -151,14 +249,18 @@ class DeviceMonoSlam:
         self.ba_pose_sigmas = (0.002, 0.002, 0.002, 0.001, 0.001, 0.001)     # prior on the first pose (:273), rotation then translation
         self.ba_odometry_sigmas = (0.05, 0.05, 0.05, 0.2, 0.2, 0.2)  # between-factors keyframe -> keyframe (:301-309)
         self.ba_pixel_sigma = 1.0
-        self.ba_window_keyframes = ba_window_keyframes              # None: every frame so far; K >= 2: the frames since the K-th keyframe from the end
-        self.ba_window_point_sigma = 0.02                           # windowed: prior on a landmark the frames in front of the window have seen
+        self.ba_window_keyframes = ba_window_keyframes              # None: every frame so far; K >= 1: every frame since the K-th keyframe from the end + the keyframes in front
+        self.ba_history_keyframes = ba_history_keyframes            # None: every keyframe in front of the dense part; H >= 0: the last H of them
+        self.ba_window_point_sigma = 0.02                           # selection: prior on a landmark that frames outside the problem have seen (0 / None: none)
+        self.ba_carry = True                                        # selection: frames left out keep their pose relative to the selected pose in front of them
+        self._kf_pose = [0]                                         # pose index (rank among the accepted frames) of every keyframe
         self._ba_bad = np.zeros(0, bool)
         if ba_engine not in ("device", "host"):
             raise ValueError("ba_engine: 'device' or 'host'")
-        self.ba_engine = "host" if ba_window_keyframes else ba_engine
+        self.ba_engine = ba_engine
         self.ba_check = bool(ba_check)
         self.ba_checks = []
+        self.ba_fallbacks = []           # adjustments the resident adjuster gave up on (timeout / capacity): the host-built path took over
         self.ba_workgroups = 0           # 0: the library's choice
         self._pending_online = None      # keyframe whose refined (pre-adjustment) pose arrives with the next result block
         self.reassociate = bool(reassociate)
@@ -199,12 +301,13 @@ class DeviceMonoSlam:
             torch.cuda.current_stream(img.device).synchronize()
         return ctypes.c_void_p(img.data_ptr())
 
-    def start(self, img, init_objp, init_imgp):
-        """slam2.py:1136-1180: pose of the first frame from known 3-D points, then the first batch of free tracks."""
+    def start(self, img, init_objp, init_imgp, uploaded=False):
+        """slam2.py:1136-1180: pose of the first frame from known 3-D points, then the first batch of free tracks.
+        uploaded=True: the caller knows the image is complete on the device (`FrameUploader`): no wait for torch's current stream."""
         o = np.ascontiguousarray(init_objp, dtype=np.float32).reshape(-1, 3)
         m = np.ascontiguousarray(init_imgp, dtype=np.float32).reshape(-1, 2)
         pose = np.zeros(12)
-        _lib.check(_lib.lib().mqs_slam_start(self._h, self._img_ptr(img, self.shape), o.ctypes.data_as(_lib.c_f32p),
+        _lib.check(_lib.lib().mqs_slam_start(self._h, self._img_ptr(img, self.shape, sync=not uploaded), o.ctypes.data_as(_lib.c_f32p),
                                              m.ctypes.data_as(_lib.c_f32p), len(o), pose.ctypes.data_as(_lib.c_f64p)))
         self.poses.append(pose.reshape(3, 4).copy())
         self.poses_online.append(pose.reshape(3, 4).copy())
@@ -231,12 +334,14 @@ class DeviceMonoSlam:
             self.poses_online[self._pending_online] = r[28:40].reshape(3, 4).copy()
             self._pending_online = None
 
-    def handle_new_frame(self, img):
-        """Returns 0 (rejected), 1 (frame) or 2 (keyframe), like the reference's `ret`."""
+    def handle_new_frame(self, img, uploaded=False):
+        """Returns 0 (rejected), 1 (frame) or 2 (keyframe), like the reference's `ret`.
+        uploaded=True: the caller knows the image is complete on the device (`FrameUploader` waits for each frame's upload event on
+        its side stream): no wait for torch's current stream here."""
         t0 = time.perf_counter()
         if self.ba_info is not None:
             self.ba_info.next_step()                         # slam2.py:1204: one step per frame, rejected ones included
-        rc = self._track(self._h, self._img_ptr(self._prev, self.shape, sync=False), self._img_ptr(img, self.shape), self._pres)
+        rc = self._track(self._h, self._img_ptr(self._prev, self.shape, sync=False), self._img_ptr(img, self.shape, sync=not uploaded), self._pres)
         if rc != 0:
             _lib.check(rc)
         r = self._res
@@ -263,6 +368,7 @@ class DeviceMonoSlam:
             if decision == 2:
                 self._pending_keyframe = len(self.poses) - 1
                 self.keyframes.append(len(self.poses) - 1)
+                self._kf_pose.append(len(self._accepted) - 1)
                 if self.reassociate:
                     self._reassociate(img)
                 if self.bundle_adjust:
@@ -315,11 +421,46 @@ class DeviceMonoSlam:
                                            uv.ctypes.data_as(_lib.c_f64p), m, ctypes.byref(n)))
         return lm, ps, uv
 
-    BA_DEVICE_MAX_POSES = 256            # include/mqslam.h: MQS_SLAM_BA_MAX_POSES (the resident adjuster stages every camera in LDS)
+    BA_DEVICE_MAX_POSES = 256            # include/mqslam.h: MQS_SLAM_BA_MAX_POSES (the resident adjuster stages every camera of the PROBLEM in LDS)
+
+    def _select_poses(self):
+        """The poses of this adjustment's problem: None (every accepted frame), or ascending pose indices -- the keyframes in front of
+        the dense part (the last `ba_history_keyframes` of them) and every frame since the `ba_window_keyframes`-th keyframe from the
+        end.  More than the adjuster holds: the oldest plain frames go first, then the oldest keyframes."""
+        P, cap = len(self._accepted), self.BA_DEVICE_MAX_POSES
+        Kw, H, kp = self.ba_window_keyframes, self.ba_history_keyframes, self._kf_pose
+        if not Kw and P <= cap:
+            return None
+        dense_start = (kp[-Kw] if len(kp) >= Kw else 0) if Kw else max(0, P - cap // 2)
+        hist = [k for k in kp if k < dense_start]
+        if H is not None:
+            hist = hist[max(0, len(hist) - H):] if H > 0 else []
+        sel = hist + list(range(dense_start, P))
+        over = len(sel) - cap
+        if over > 0:
+            kset, keep = set(kp), []
+            for j in sel:
+                if over > 0 and j not in kset and j != P - 1:
+                    over -= 1
+                    continue
+                keep.append(j)
+            sel = keep[over:] if over > 0 else keep
+        if len(sel) == P:
+            return None
+        return np.asarray(sel, dtype=np.int32)
+
+    def _second_anchor(self, sel):
+        """Once frame 0 is not a pose of the problem: the next selected keyframe behind the first selected pose (two poses held by
+        priors fix the seven gauge freedoms of a monocular window, scale included)."""
+        if sel is None or sel[0] == 0:
+            return -1
+        kset = set(self._kf_pose)
+        return next((int(j) for j in sel[1:] if int(j) in kset), -1)
 
     def _hand_over_to_the_host_engine(self):
-        """Beyond 256 accepted frames the resident adjuster does not apply: the host-built path takes over where it stands -- the retired
-        landmarks and the odometry edges (measured when their keyframes were taken) come from the device, once."""
+        """The host-built path takes the adjustment over where it stands (after a launch of the resident adjuster that gave up or did
+        not hold the problem) -- the retired landmarks and the odometry edges (measured when their keyframes were taken) come from the
+        device, once."""
         L = _lib.lib()
         self._ba_bad = self.retired_landmarks()
         n = ctypes.c_int32(0)
@@ -332,13 +473,14 @@ class DeviceMonoSlam:
         self.ba_engine = "host"
 
     def _bundle_adjust(self):
-        if self.ba_engine == "device" and len(self._accepted) > self.BA_DEVICE_MAX_POSES:
-            self._hand_over_to_the_host_engine()
         if self.ba_engine == "host":
             return self._bundle_adjust_host()
         if self.ba_check:
             host = self._bundle_adjust_host(write_back=False)
         rep = self._bundle_adjust_device()
+        if rep is None:                                              # the launch gave up or did not hold the problem; nothing was written
+            self._hand_over_to_the_host_engine()
+            return self._bundle_adjust_host()
         if self.ba_check:
             self.ba_checks.append({"frame": self._accepted[-1], "host_poses": host[0], "host_points": host[1], "host_report": host[2],
                                    "device_poses": np.stack([self.poses[f] for f in self._accepted]), "device_points": self.objp.astype(np.float64),
@@ -361,27 +503,45 @@ class DeviceMonoSlam:
         return q
 
     def _bundle_adjust_device(self):
-        """Behind a keyframe: `mqs_slam_bundle_adjust` -- one persistent launch on the handle's stream (behind the keyframe branch it
-        does not wait for from here), one wait for its report and the adjusted poses."""
+        """Behind a keyframe: `mqs_slam_bundle_adjust(_window)` -- one persistent launch on the handle's stream (behind the keyframe
+        branch it does not wait for from here), one wait for its report and the adjusted poses.  None: the launch gave up (a grid-wide
+        wait) or its resident lists do not hold the problem -- nothing was written back, the caller takes the host-built path."""
         t0 = time.perf_counter()
         kf = self._accepted[-1]
         add_edge, e_from, e_to = False, 0, 0
         if self.keyframes and self.keyframes[-1] == kf and len(self.keyframes) >= 2 and self._odo_last_to != len(self._accepted) - 1:
-            add_edge, e_from, e_to = True, self._accepted.index(self.keyframes[-2]), len(self._accepted) - 1
-            self._odo_last_to = e_to
+            add_edge, e_from, e_to = True, self._kf_pose[-2], len(self._accepted) - 1
         q = self._ba_params(add_edge, e_from, e_to)
         P = len(self._accepted)
-        rep, poses = np.zeros(16), np.zeros((P, 12))
-        _lib.check(_lib.lib().mqs_slam_bundle_adjust(self._h, ctypes.byref(q), rep.ctypes.data_as(_lib.c_f64p), poses.ctypes.data_as(_lib.c_f64p), P))
+        sel = self._select_poses()
+        first = 0 if sel is None else int(sel[0])
+        rep, poses = np.zeros(16), np.zeros((P - first, 12))
+        L = _lib.lib()
+        if sel is None:
+            rc = L.mqs_slam_bundle_adjust(self._h, ctypes.byref(q), rep.ctypes.data_as(_lib.c_f64p), poses.ctypes.data_as(_lib.c_f64p), P)
+        else:
+            w = _BaWindow()
+            w.n_poses, w.second_anchor, w.carry_unselected = len(sel), self._second_anchor(sel), int(bool(self.ba_carry))
+            w.poses = sel.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
+            w.seen_outside_sigma = float(self.ba_window_point_sigma or 0.0) if sel[0] != 0 else 0.0      # (while frame 0 is a pose the gauge is the plain adjustment's: no such prior)
+            rc = L.mqs_slam_bundle_adjust_window(self._h, ctypes.byref(q), ctypes.byref(w), rep.ctypes.data_as(_lib.c_f64p),
+                                                 poses.ctypes.data_as(_lib.c_f64p), P - first)
+        if rc in (MQS_E_TIMEOUT, MQS_E_CAPACITY):
+            msg = L.mqs_last_error()
+            self.ba_fallbacks.append({"frame": kf, "code": int(rc), "message": msg.decode() if msg else ""})
+            return None
+        _lib.check(rc)
+        if add_edge:
+            self._odo_last_to = e_to
         if self._pending_keyframe is not None:                       # its refined pose as first estimated comes with the next result block
             self._pending_online, self._pending_keyframe = self._pending_keyframe, None
-        P34 = poses.reshape(P, 3, 4)
-        for k, f in enumerate(self._accepted):                       # (views of this call's own array: nothing else writes it)
+        P34 = poses.reshape(P - first, 3, 4)
+        for k, f in enumerate(self._accepted[first:]):               # (views of this call's own array: nothing else writes it)
             self.poses[f] = P34[k]
-        out = {"frame": kf, "poses": int(rep[1]), "first_pose_of_the_window": 0, "landmarks": int(rep[2]), "landmarks_adjusted": int(rep[3]),
+        out = {"frame": kf, "poses": int(rep[1]), "first_pose_of_the_window": first, "landmarks": int(rep[2]), "landmarks_adjusted": int(rep[3]),
                "observations": int(rep[4]), "passes": int(rep[5]), "landmarks_screened_out": int(rep[6]), "lm_iterations": int(rep[7]),
                "cost_before": float(rep[8]), "cost_after": float(rep[9]), "lm_trials": int(rep[10]), "repeated_observations_left_out": int(rep[11]),
-               "odometry_edges": int(rep[12]), "grid_barriers": int(rep[13]), "engine": "device",
+               "odometry_edges": int(rep[12]), "grid_barriers": int(rep[13]), "engine": "device", "accepted_frames": P,
                "build_ms": 0.0, "adjust_ms": round(1e3 * (time.perf_counter() - t0), 3), "write_back_ms": 0.0}
         self.ba_reports.append(out)
         return out
@@ -420,7 +580,18 @@ class DeviceMonoSlam:
             if write_back or self.ba_check:
                 self._odo = odo_all                                   # (the twin keeps its own edge list: measured once, like the device's)
         lm, ps, uv = self.read_log()
-        known = lm >= 0                                               # (free tracks that have not become landmarks)
+        pts = self.objp.astype(np.float64)
+        N, P_all = len(pts), len(self._accepted)
+        # the poses of the problem: every accepted frame, or the selection (`_select_poses`; csrc/slam_ba.hip is this path's twin)
+        sel = self._select_poses()
+        sel = np.arange(P_all, dtype=np.int32) if sel is None else sel
+        w0, P = int(sel[0]), len(sel)
+        pmap = np.full(P_all, -1, np.int64)
+        pmap[sel] = np.arange(P)
+        has_lm = (lm >= 0) & (lm < N)
+        outside = has_lm & (ps >= 0) & (ps < P_all) & (pmap[np.clip(ps, 0, P_all - 1)] < 0)
+        out_cnt = np.bincount(lm[outside], minlength=N)             # sightings from accepted frames that are not poses of the problem
+        known = has_lm & ~outside                                    # (free tracks that have not become landmarks: lm < 0)
         if self.ba_border_margin:
             # an observation closer to the image border than half a tracker window was measured on a window that reads the
             # border-extended pyramid -- mirrored content (OpenCV's tracker, and this one since round 4, follows a point until its
@@ -428,40 +599,32 @@ class DeviceMonoSlam:
             H_, W_ = self.shape
             m = self.ba_border_margin
             known &= (uv[:, 0] >= m) & (uv[:, 0] <= W_ - 1 - m) & (uv[:, 1] >= m) & (uv[:, 1] <= H_ - 1 - m)
-        lm, ps, uv = lm[known], ps[known], uv[known]
-        pts = self.objp.astype(np.float64)
-        N, P = len(pts), len(self._accepted)
+        lm, ps, uv = lm[known], pmap[ps[known]], uv[known]
         if len(self._ba_bad) < N:
             self._ba_bad = np.concatenate([self._ba_bad, np.zeros(N - len(self._ba_bad), bool)])
-        # the window: everything so far (the default: what the reference's tool adjusts), or -- ba_window_keyframes = K -- the frames
-        # since the K-th keyframe from the end, held in place by tight priors on the poses of the window's first two keyframes (their
-        # values are the previous adjustments' results; two poses fix the seven gauge freedoms of a monocular map, scale included).
-        # The cost of an adjustment then stops growing with the length of the run.
-        w0, anchors, seen_before = 0, [0], None
-        K_w = self.ba_window_keyframes
-        if K_w and len(self.keyframes) > K_w:
-            w0 = self._accepted.index(self.keyframes[-K_w])
-            anchors = [0, self._accepted.index(self.keyframes[-K_w + 1]) - w0] if K_w >= 2 else [0]
-            inside = ps >= w0
-            seen_before = np.bincount(lm[~inside], minlength=len(pts)) > 0           # landmarks the frames in front of the window have seen
-            lm, ps, uv = lm[inside], ps[inside] - w0, uv[inside]
-        P = P - w0
-        accepted_w = self._accepted[w0:]
+        # the gauge: while frame 0 is a pose of the problem, the reference's (bundle_adjust.cpp:268-282: a prior on pose 0 at its start-up
+        # estimate, priors on the start-up landmarks); once it is not, priors on the first selected pose and on the next selected keyframe
+        # at their current values (two poses fix the seven gauge freedoms of a monocular map, scale included)
+        anchors = [0]
+        a2 = self._second_anchor(sel)
+        if a2 >= 0 and pmap[a2] > 0:
+            anchors.append(int(pmap[a2]))
+        accepted_w = [self._accepted[j] for j in sel]
         poses = np.stack([pose_from_world_to_camera(self.poses[f]) for f in accepted_w])
         if w0 == 0:
             poses[0] = pose_from_world_to_camera(self._pose0)         # the pose prior sits at the initial value of pose 0 (bundle_adjust.cpp:273)
-        prior_xyz = pts.copy()
-        prior_xyz[:self._n0] = self._objp0
         calib = np.array([[self.K[0, 0], self.K[1, 1], self.K[0, 1], self.K[0, 2], self.K[1, 2], self.dist[0], self.dist[1],
                            self.dist[2], self.dist[3]]])
-        n0_w = self._n0 if w0 == 0 else 0                            # the start-up landmarks are the gauge only while frame 0 is in the window
+        n0_w = self._n0 if w0 == 0 else 0                            # the start-up landmarks are the gauge only while frame 0 is a pose of the problem
+        prior_xyz = pts.copy()
+        prior_xyz[:n0_w] = self._objp0[:n0_w]
         prior_w = np.where(np.arange(N) < n0_w, 1.0 / self.ba_point_sigma ** 2, 0.0)             # noise.point3D of the reference's runs
-        if seen_before is not None and self.ba_window_point_sigma:
-            # what the frames in front of the window know about a landmark stays with it as a prior at its adjusted value: two anchor
+        if self.ba_window_point_sigma and len(sel) < P_all and w0 != 0:
+            # what the frames outside the problem know about a landmark stays with it as a prior at its adjusted value: two anchor
             # poses alone leave the scale of a monocular window to drift (measured: 54-97 mm over 200 frames against 5 mm)
-            prior_w = np.where(seen_before[:N], 1.0 / self.ba_window_point_sigma ** 2, prior_w)
+            prior_w = np.where((out_cnt[:N] > 0) & (np.arange(N) >= n0_w), 1.0 / self.ba_window_point_sigma ** 2, prior_w)
         per_lm = np.bincount(lm, minlength=N)
-        odo = [(a - w0, b - w0, m) for a, b, m in odo_all if a >= w0 and b >= w0]
+        odo = [(int(pmap[a]), int(pmap[b]), m) for a, b, m in odo_all if pmap[a] >= 0 and pmap[b] >= 0]
         t1 = time.perf_counter()
         passes, dropped, hist_all = 0, 0, None
         movable = np.arange(N) >= n0_w
@@ -472,7 +635,7 @@ class DeviceMonoSlam:
             # mistracked corner: GTSAM's factors are plain least squares (bundle_adjust.cpp:289-298: no robust kernel), the
             # reference runs them once over a finished recording -- inside the loop one bad track that passed the depth checks
             # drags the two keyframes it was triangulated from by centimetres before anything else has seen it
-            use = ((per_lm >= self.ba_min_observations) | ~movable) & ~self._ba_bad[:N]
+            use = (((per_lm >= 1) & (per_lm + out_cnt[:N] >= self.ba_min_observations)) | ~movable) & ~self._ba_bad[:N]
             keep = use[lm]
             l2, p2, u2 = lm[keep], ps[keep], uv[keep]
             order = np.argsort(l2, kind="stable")
@@ -525,18 +688,30 @@ class DeviceMonoSlam:
         new_poses, new_pts = ba.poses.cpu().numpy(), ba.points.cpu().numpy()
         new_pts[~use] = pts[~use]                                    # landmarks that sat out keep their values
         t2 = time.perf_counter()
-        adjusted = []
+        adjusted = {}
         for k, f in enumerate(accepted_w):                           # camera-to-world pose12 -> [R | t] world -> camera
             R, c = new_poses[k, :9].reshape(3, 3), new_poses[k, 9:]
-            adjusted.append(np.hstack([R.T, (-R.T @ c)[:, None]]))
+            adjusted[f] = np.hstack([R.T, (-R.T @ c)[:, None]])
+        if P < P_all - w0 and self.ba_carry:
+            # the accepted frames behind the first selected pose that are not poses of the problem keep their pose RELATIVE to the last
+            # selected pose in front of them: M_j <- M_j inv(A_before) A_after
+            h = lambda M: np.vstack([M, [0, 0, 0, 1.0]])
+            a = 0
+            for j in range(w0, P_all):
+                if pmap[j] >= 0:
+                    a = int(pmap[j])
+                    continue
+                f, fa = self._accepted[j], accepted_w[a]
+                adjusted[f] = (h(self.poses[f]) @ np.linalg.inv(h(self.poses[fa])) @ h(adjusted[fa]))[:3]
         report = {"frame": self._accepted[-1], "poses": P, "first_pose_of_the_window": w0, "landmarks": N, "landmarks_adjusted": int(use.sum()),
                                 "observations": int(keep.sum()), "passes": passes, "landmarks_screened_out": dropped,
-                                "lm_iterations": len(hist_all) - 1, "cost_before": hist_all[0], "cost_after": hist_all[-1],
+                                "lm_iterations": len(hist_all) - 1, "cost_before": hist_all[0], "cost_after": hist_all[-1], "accepted_frames": P_all,
                                 "build_ms": round(1e3 * (t1 - t0), 3), "adjust_ms": round(1e3 * (t2 - t1), 3), "engine": "host"}
         if not write_back:
             retired = self._ba_bad.copy()                             # (the twin's retired set lives on, as the device's does)
-            return np.stack(adjusted), np.asarray(new_pts, dtype=np.float32).astype(np.float64), report, retired
-        for f, M in zip(accepted_w, adjusted):
+            every = np.stack([adjusted.get(f, self.poses[f]) for f in self._accepted])
+            return every, np.asarray(new_pts, dtype=np.float32).astype(np.float64), report, retired
+        for f, M in adjusted.items():
             self.poses[f] = M
         # the live state's two poses: the last accepted frame's, and the base keyframe's of the live tracks (behind a keyframe the
         # same frame; in finish() behind plain frames it is the last KEYFRAME's -- the tracks' base points belong to that frame)

@@ -257,8 +257,11 @@ def dense_reference_step(poses, calib, sigma, points, obs):
 # ---------------------------------------------------------------------------------------------
 
 def sparse_linearize(poses, pose_cam, calib, sigma, points, obs_ptr, obs_pose, obs_uv, prior_w=None, prior_xyz=None,
-                     lam=0.0):
-    """Returns S (6P,6P), g (6P,), cost, n_valid and per-landmark pieces for the back-substitution."""
+                     lam=0.0, additive=False):
+    """Returns S (6P,6P), g (6P,), cost, n_valid and per-landmark pieces for the back-substitution.
+    lam damps the landmark blocks before they are eliminated: lam * diag(H_ll) (Marquardt), or -- additive=True -- lam * I, what
+    GTSAM 3.2.1's LevenbergMarquardtParams default (diagonalDamping = false) adds to every variable; the caller damps the pose block
+    of the reduced system the same way."""
     P, N = len(poses), len(points)
     S = np.zeros((6 * P, 6 * P))
     g = np.zeros(6 * P)
@@ -287,7 +290,7 @@ def sparse_linearize(poses, pose_cam, calib, sigma, points, obs_ptr, obs_pose, o
             cost += 0.5 * prior_w[i] * d.dot(d)
             constrained = True
         if lam:
-            Hll = Hll + lam * np.diag(np.diag(Hll))
+            Hll = Hll + (lam * np.eye(3) if additive else lam * np.diag(np.diag(Hll)))
         if constrained and np.linalg.eigvalsh(Hll)[0] > 1e-13 * np.trace(Hll):
             Hi = np.linalg.inv(Hll)
         else:

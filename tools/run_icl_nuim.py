@@ -4,7 +4,7 @@ build's device-resident loop, against what the reference COMMITTED as that run's
 slam2.py with OpenCV 2.4's goodFeaturesToTrack / calcOpticalFlowPyrLK / solvePnPRansac) and against the renderer's exact
 trajectory.  Reads the fixture tests/golden/icl_nuim_traj3n/sequence.npz (tests/golden/make_icl_nuim.py).
 
-    python tools/run_icl_nuim.py [frames] [--ba [--window K] [--reference-noise] [--host-ba]] [--host] [--seed S] [--out DIR]
+    python tools/run_icl_nuim.py [frames] [--ba [--window K [--history H]] [--reference-noise] [--host-ba]] [--host] [--seed S] [--out DIR]
 (--out: trajectory and map in the reference's formats; --host-ba: round 4's host-built adjustment; more than 80 frames: sequence_rest.npz too)
 """
 import os, sys, json, time
@@ -65,8 +65,12 @@ REFERENCE_NOISE = {"point3D": 0.2, "pose": (0.02, 0.02, 0.02, 0.1, 0.1, 0.1), "o
 # ^ BA_info.noise.*-slam2.txt beside the reference's recording of this sequence
 
 
-def run(frames=None, bundle_adjust=None, seed=0, device=True, reassociate=False, window=None, out_dir=None, screen=None, noise=None, engine="device"):
-    """noise="reference": the in-loop adjuster's noise models take the values of the reference's own noise files for this sequence
+def run(frames=None, bundle_adjust=None, seed=0, device=True, reassociate=False, window=None, out_dir=None, screen=None, noise=None, engine="device",
+        history=None, window_point_sigma="default", carry=True, check=False, upload=None):
+    """upload: None -- every frame is on the device before the clock starts (the loop's kernels alone); "pinned" -- the frames lie in ONE pinned host
+    buffer and go to the device inside the timed loop, on a side stream under the previous frames' kernels (`slam_device.FrameUploader`);
+    "pageable" -- they lie in ordinary numpy arrays and pass through pinned staging slots on the uploader's thread.
+    noise="reference": the in-loop adjuster's noise models take the values of the reference's own noise files for this sequence
     (instead of this build's defaults: a tighter prior on the first pose, a looser one on the start-up points)."""
     import torch
     d = load_sequence(frames)
@@ -78,19 +82,37 @@ def run(frames=None, bundle_adjust=None, seed=0, device=True, reassociate=False,
     objp, imgp = pts[vis], uv[vis]
     t0 = time.perf_counter()
     if device:
-        imgs = [torch.from_numpy(np.ascontiguousarray(f)).cuda() for f in imgs_h]
+        if upload is None:
+            imgs = [torch.from_numpy(np.ascontiguousarray(f)).cuda() for f in imgs_h]
+        elif upload == "pinned":
+            src = torch.from_numpy(np.ascontiguousarray(imgs_h)).pin_memory()
+        else:
+            src = [np.ascontiguousarray(f) for f in imgs_h]
         torch.cuda.synchronize()
         slam = mqslam_amd.slam_device.DeviceMonoSlam(K, dist, (H, W), seed=seed, bundle_adjust=bundle_adjust, reassociate=reassociate,
                                                      max_homography_points="reference", ba_window_keyframes=window, second_pass_screen=screen,
-                                                     ba_engine=engine)
+                                                     ba_engine=engine, ba_history_keyframes=history, ba_check=check)
+        if window_point_sigma != "default":
+            slam.ba_window_point_sigma = window_point_sigma
+        slam.ba_carry = carry
         if noise == "reference":
             slam.ba_point_sigma, slam.ba_pose_sigmas = REFERENCE_NOISE["point3D"], REFERENCE_NOISE["pose"]
             slam.ba_odometry_sigmas, slam.ba_pixel_sigma = REFERENCE_NOISE["odometry"], REFERENCE_NOISE["point2D"]
         t0 = time.perf_counter()
-        slam.start(imgs[0], objp, imgp)
-        rets = [2]
-        for k in range(1, n):
-            rets.append(slam.handle_new_frame(imgs[k]))
+        if upload is None:
+            slam.start(imgs[0], objp, imgp)
+            rets = [2]
+            for k in range(1, n):
+                rets.append(slam.handle_new_frame(imgs[k]))
+        else:
+            up = mqslam_amd.slam_device.FrameUploader(src)
+            rets = []
+            for k, img in enumerate(up):
+                if k == 0:
+                    slam.start(img, objp, imgp, uploaded=True)
+                    rets.append(2)
+                else:
+                    rets.append(slam.handle_new_frame(img, uploaded=True))
         slam.finish()
     else:
         slam = mqslam_amd.slam_loop.MonoSlam(K, dist, (H, W), seed=seed, second_pass_screen=screen)
@@ -106,7 +128,7 @@ def run(frames=None, bundle_adjust=None, seed=0, device=True, reassociate=False,
     Rs = np.array([P[:, :3] if P is not None else np.eye(3) for P in slam.projection_matrices()])
     Rref, Rgt = rotations_from_tum(d["traj_slam2"][:n]), rotations_from_tum(d["traj_groundtruth"][:n])
     path = float(np.sum(np.linalg.norm(np.diff(gt, axis=0), axis=1)))
-    out = {"frames": n, "accepted": int(ok.sum()), "keyframes": int(sum(1 for r in rets if r == 2)), "landmarks": int(len(slam.objp)),
+    out = {"frames": n, "frame_ingest": upload or "resident before the clock starts", "accepted": int(ok.sum()), "keyframes": int(sum(1 for r in rets if r == 2)), "landmarks": int(len(slam.objp)),
            "keyframe_frames": [k for k, r in enumerate(rets) if r == 2],
            "path_length_m": round(path, 4), "frames_per_s": round(n / dt, 1),
            "ours_vs_groundtruth_rmse_m": round(float(np.sqrt(np.mean(err(c[ok], gt[ok]) ** 2))), 5),
@@ -127,6 +149,11 @@ def run(frames=None, bundle_adjust=None, seed=0, device=True, reassociate=False,
         out["online_vs_groundtruth_rmse_m"] = round(float(np.sqrt(np.mean(err(co[ok], gt[ok]) ** 2))), 5)
         out["landmarks_screened_out"] = int(slam.retired_landmarks().sum())
         out["engine"] = slam.ba_engine
+        out["engines"] = sorted(set(r["engine"] for r in slam.ba_reports))
+        out["poses_per_adjustment"] = [r["poses"] for r in slam.ba_reports]
+        out["fallbacks"] = slam.ba_fallbacks
+        if check:
+            out["twin_max_pose_difference"] = float(max(np.abs(c["host_poses"] - c["device_poses"]).max() for c in slam.ba_checks))
     if out_dir:
         # what slam2.py's write_output leaves behind (:698-741): traj_out.cam0-<name>.txt in TUM format (30 fps, as the reference's
         # run) and map_out-<name>.pcd -- the inputs of the reference's own evaluation scripts
@@ -183,10 +210,11 @@ if __name__ == "__main__":
     a = [x for x in sys.argv[1:] if not x.startswith("--")]
     seed = int(sys.argv[sys.argv.index("--seed") + 1]) if "--seed" in sys.argv else 0
     window = int(sys.argv[sys.argv.index("--window") + 1]) if "--window" in sys.argv else None
+    history = int(sys.argv[sys.argv.index("--history") + 1]) if "--history" in sys.argv else None
     screen = float(sys.argv[sys.argv.index("--screen") + 1]) if "--screen" in sys.argv else None
-    a = [x for i, x in enumerate(sys.argv[1:], 1) if not x.startswith("--") and sys.argv[i - 1] not in ("--seed", "--window", "--out", "--screen")]
+    a = [x for i, x in enumerate(sys.argv[1:], 1) if not x.startswith("--") and sys.argv[i - 1] not in ("--seed", "--window", "--out", "--screen", "--history")]
     out_dir = sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else None
     a = [x for x in a if x != out_dir]
     print(json.dumps(run(int(a[0]) if a else None, "keyframe" if "--ba" in sys.argv else None, seed, "--host" not in sys.argv,
                          "--reassociate" in sys.argv, window, out_dir, screen, noise="reference" if "--reference-noise" in sys.argv else None,
-                         engine="host" if "--host-ba" in sys.argv else "device")))
+                         engine="host" if "--host-ba" in sys.argv else "device", history=history)))
