@@ -6,7 +6,7 @@ SRCS  := $(wildcard $(PKG)/csrc/*.hip)
 HDRS  := $(wildcard $(PKG)/csrc/*.h) include/mqslam.h
 LIB   := $(PKG)/libmqslam_hip.so
 HIPFLAGS ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-function -Wl,-rpath,/opt/rocm/lib
-LIBS     ?= -L/opt/rocm/lib
+LIBS     ?= -L/opt/rocm/lib -pthread
 
 all: $(LIB) oracle
 

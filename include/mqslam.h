@@ -755,6 +755,23 @@ int mqs_slam_read_ba_flags(mqs_slam *s, uint8_t *retired, int cap, int32_t *n);
 int mqs_slam_read_ba_edges(mqs_slam *s, int32_t *from, int32_t *to, double *meas, int cap, int32_t *n);
 /* profiling hook: phase stamps of the adjuster's last launch (see csrc/slam_ba.hip); the first call switches them on */
 int mqs_debug_slam_ba_stamps(mqs_slam *s, int64_t *out, int cap, int32_t *n);
+/* Frame ingest (csrc/slam_ingest.hip): the reference reads every frame inside its loop (slam2.py:1209-1213); here a frame goes from
+ * host memory to the device on a stream of its own while the loop's kernels work on the frames before it.
+ *   mqs_slam_ingest_enable  a ring of `slots` device images (W x H bytes each) owned by the handle, an upload stream, one worker
+ *                         thread of the library.
+ *   mqs_slam_upload       posts the upload of `host_img` (W x H bytes) into ring slot `slot` and returns at once; the worker
+ *                         enqueues the copy on the upload stream -- straight from `host_img` (pinned != 0: page-locked memory
+ *                         that stays valid until the frame has been processed) or through the slot's pinned staging buffer
+ *                         (pinned == 0: ordinary memory, valid until mqs_slam_wait_upload of the slot has returned).
+ *                         The caller reuses a slot only once the loop is done with the image in it (the previous image of the
+ *                         next mqs_slam_track call is still in use).
+ *   mqs_slam_wait_upload  makes the handle's stream wait (on the device; the host does not block beyond the worker's hand-off)
+ *                         for the slot's upload and returns the slot's device image, to be passed to mqs_slam_start /
+ *                         mqs_slam_track. */
+#define MQS_SLAM_INGEST_MAX_SLOTS 16
+int mqs_slam_ingest_enable(mqs_slam *s, int slots);
+int mqs_slam_upload(mqs_slam *s, int slot, const uint8_t *host_img, int pinned);
+int mqs_slam_wait_upload(mqs_slam *s, int slot, const uint8_t **image_dev);
 int mqs_slam_log_enable(mqs_slam *s, int64_t capacity);
 int mqs_slam_read_log(mqs_slam *s, int32_t *lm, int32_t *pose, double *uv, int64_t cap, int64_t *n);
 int mqs_slam_write_back(mqs_slam *s, const double *map, int n, const double *pose_prev, const double *pose_key);

@@ -1064,7 +1064,7 @@ int mqs_slam_create(int device, int W, int H, const double *intr, int target_key
     if (!s) { mqs_set_error("out of host memory"); return MQS_E_NOMEM; }
     s->device = device;
     s->started = false;
-    s->accepted = 0; s->base_pose = 0; s->log_arena = nullptr; s->re_arena = nullptr; s->ba = nullptr; s->land_ub = 0; s->key_pose = 0;
+    s->accepted = 0; s->base_pose = 0; s->log_arena = nullptr; s->re_arena = nullptr; s->ba = nullptr; s->land_ub = 0; s->key_pose = 0; s->ingest = nullptr;
     s->p = SlamParams{W, H, target_keypoints, max_landmarks, coverage_radius, quality_level,
                       12.0, 0.5, 2.0, 0.33, 1.04, 0.0, (unsigned long long)seed, 1, 0, 0};  // slam2.py:1070-1098; keyframe test on ALL tracks
     if (const char *e = getenv("MQS_SLAM_HOMOGRAPHY_REFINE")) s->p.homography_refine = e[0] != '0';        // A/B: 0 = the DLT alone
@@ -1123,6 +1123,7 @@ void mqs_slam_destroy(mqs_slam *s)
 {
     if (!s) return;
     (void)hipSetDevice(s->device);
+    mqs_slam_ingest_release(s);
     (void)hipStreamSynchronize(s->stream);
     (void)hipFree(s->arena);
     mqs_slam_ba_release(s);

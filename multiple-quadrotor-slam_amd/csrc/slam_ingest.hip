@@ -1,0 +1,157 @@
+// Frame ingest of the device-resident loop (BASELINE configs[4]): the reference reads every frame INSIDE its loop
+// (Work/SLAM/application/own/slam2.py:1209-1213: cv2.imread per iteration); here a frame arrives in host memory and goes to the device
+// on a stream of its own while the loop's kernels work on the frames before it.
+//
+// A ring of device images owned by the handle, and ONE worker thread of the library: `mqs_slam_upload` only posts a job (a mutex and
+// a notification -- the calling thread goes straight on to mqs_slam_track, which blocks for the frame's result); the worker stages a
+// pageable source through the slot's pinned staging buffer, enqueues the copy on the upload stream and records the slot's event.
+// `mqs_slam_wait_upload` makes the LOOP'S STREAM wait for that event (hipStreamWaitEvent: a device-side wait, the host does not block)
+// -- the caller then passes the slot's device pointer to mqs_slam_start / mqs_slam_track like any other image.
+// (From the interpreter the same thing -- a thread issuing torch copies -- cost 30 % of the plain loop's frame rate: the two threads
+// hand the interpreter lock back and forth.)
+#include "mqs_common.h"
+#include "slam_state.h"
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <new>
+#include <thread>
+
+struct mqs_slam_ingest {
+    int slots;
+    size_t bytes;                       // W * H
+    uint8_t *dev;                       // [slots][bytes]
+    uint8_t *stage;                     // pinned [slots][bytes]
+    hipStream_t up;
+    hipEvent_t ev[MQS_SLAM_INGEST_MAX_SLOTS];
+    unsigned long long posted[MQS_SLAM_INGEST_MAX_SLOTS], done[MQS_SLAM_INGEST_MAX_SLOTS];
+    struct Job { int slot; const uint8_t *host; int pinned; };
+    std::deque<Job> jobs;
+    std::mutex m;
+    std::condition_variable cv_job, cv_done;
+    std::thread worker;
+    bool stop;
+    hipError_t error;
+    int device;
+};
+
+namespace {
+
+void ingest_worker(mqs_slam_ingest *g)
+{
+    (void)hipSetDevice(g->device);
+    for (;;) {
+        mqs_slam_ingest::Job j;
+        {
+            std::unique_lock<std::mutex> lk(g->m);
+            g->cv_job.wait(lk, [g] { return g->stop || !g->jobs.empty(); });
+            if (g->jobs.empty()) return;                                   // (stop, nothing left)
+            j = g->jobs.front();
+            g->jobs.pop_front();
+        }
+        const uint8_t *src = j.host;
+        if (!j.pinned) {
+            memcpy(g->stage + (size_t)j.slot * g->bytes, j.host, g->bytes);
+            src = g->stage + (size_t)j.slot * g->bytes;
+        }
+        hipError_t e = hipMemcpyAsync(g->dev + (size_t)j.slot * g->bytes, src, g->bytes, hipMemcpyHostToDevice, g->up);
+        if (e == hipSuccess) e = hipEventRecord(g->ev[j.slot], g->up);
+        {
+            std::lock_guard<std::mutex> lk(g->m);
+            if (e != hipSuccess && g->error == hipSuccess) g->error = e;
+            g->done[j.slot] += 1;
+        }
+        g->cv_done.notify_all();
+    }
+}
+
+}  // namespace
+
+void mqs_slam_ingest_release(mqs_slam *s)
+{
+    mqs_slam_ingest *g = s ? s->ingest : nullptr;
+    if (!g) return;
+    {
+        std::lock_guard<std::mutex> lk(g->m);
+        g->stop = true;
+    }
+    g->cv_job.notify_all();
+    if (g->worker.joinable()) g->worker.join();
+    (void)hipStreamSynchronize(g->up);
+    for (int k = 0; k < g->slots; ++k) (void)hipEventDestroy(g->ev[k]);
+    (void)hipStreamDestroy(g->up);
+    if (g->dev) (void)hipFree(g->dev);
+    if (g->stage) (void)hipHostFree(g->stage);
+    delete g;
+    s->ingest = nullptr;
+}
+
+extern "C" {
+
+int mqs_slam_ingest_enable(mqs_slam *s, int slots)
+{
+    MQS_ARG_CHECK(s != nullptr && slots >= 2 && slots <= MQS_SLAM_INGEST_MAX_SLOTS, "handle; 2 <= slots <= MQS_SLAM_INGEST_MAX_SLOTS");
+    MQS_ARG_CHECK(s->ingest == nullptr, "once per handle");
+    MQS_HIP_CHECK(hipSetDevice(s->device));
+    mqs_slam_ingest *g = new (std::nothrow) mqs_slam_ingest();
+    if (!g) { mqs_set_error("out of host memory"); return MQS_E_NOMEM; }
+    g->slots = slots; g->bytes = (size_t)s->p.W * s->p.H; g->dev = nullptr; g->stage = nullptr; g->stop = false; g->error = hipSuccess;
+    g->device = s->device;
+    for (int k = 0; k < MQS_SLAM_INGEST_MAX_SLOTS; ++k) { g->posted[k] = 0; g->done[k] = 0; }
+    hipError_t e = hipMalloc((void **)&g->dev, (size_t)slots * g->bytes);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&g->stage, (size_t)slots * g->bytes, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        if (g->dev) (void)hipFree(g->dev);
+        delete g;
+        mqs_set_error("mqs_slam_ingest_enable: %s", hipGetErrorString(e));
+        return MQS_E_NOMEM;
+    }
+    e = hipStreamCreateWithFlags(&g->up, hipStreamNonBlocking);
+    int made = 0;
+    for (; e == hipSuccess && made < slots; ++made) e = hipEventCreateWithFlags(&g->ev[made], hipEventDisableTiming);
+    if (e != hipSuccess) {
+        for (int k = 0; k < made - 1; ++k) (void)hipEventDestroy(g->ev[k]);
+        (void)hipFree(g->dev); (void)hipHostFree(g->stage);
+        delete g;
+        mqs_set_error("mqs_slam_ingest_enable: %s", hipGetErrorString(e));
+        return MQS_E_HIP;
+    }
+    g->worker = std::thread(ingest_worker, g);
+    s->ingest = g;
+    return MQS_OK;
+}
+
+int mqs_slam_upload(mqs_slam *s, int slot, const uint8_t *host_img, int pinned)
+{
+    MQS_ARG_CHECK(s != nullptr && s->ingest != nullptr, "mqs_slam_ingest_enable first");
+    mqs_slam_ingest *g = s->ingest;
+    MQS_ARG_CHECK(slot >= 0 && slot < g->slots && host_img != nullptr, "0 <= slot < slots; image must not be null");
+    {
+        std::lock_guard<std::mutex> lk(g->m);
+        g->posted[slot] += 1;
+        g->jobs.push_back({slot, host_img, pinned});
+    }
+    g->cv_job.notify_one();
+    return MQS_OK;
+}
+
+int mqs_slam_wait_upload(mqs_slam *s, int slot, const uint8_t **image_dev)
+{
+    MQS_ARG_CHECK(s != nullptr && s->ingest != nullptr, "mqs_slam_ingest_enable first");
+    mqs_slam_ingest *g = s->ingest;
+    MQS_ARG_CHECK(slot >= 0 && slot < g->slots && image_dev != nullptr, "0 <= slot < slots; image_dev must not be null");
+    hipError_t err;
+    {
+        std::unique_lock<std::mutex> lk(g->m);
+        MQS_ARG_CHECK(g->posted[slot] > 0, "nothing was uploaded into this slot");
+        g->cv_done.wait(lk, [g, slot] { return g->done[slot] == g->posted[slot]; });       // (the worker has ENQUEUED the copy; usually long ago)
+        err = g->error;
+    }
+    if (err != hipSuccess) { mqs_set_error("mqs_slam_upload: %s", hipGetErrorString(err)); return MQS_E_HIP; }
+    MQS_HIP_CHECK(hipSetDevice(s->device));
+    MQS_HIP_CHECK(hipStreamWaitEvent(s->stream, g->ev[slot], 0));
+    *image_dev = g->dev + (size_t)slot * g->bytes;
+    return MQS_OK;
+}
+
+}  // extern "C"

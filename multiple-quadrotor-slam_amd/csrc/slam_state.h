@@ -75,6 +75,7 @@ struct SlamParams {
 }  // namespace mqs
 
 struct mqs_slam_ba;                  // slam_ba.hip: the in-loop adjuster's resident state
+struct mqs_slam_ingest;              // slam_ingest.hip: the frame-ingest ring, its stream and worker thread
 
 struct mqs_slam {
     int device;
@@ -93,6 +94,8 @@ struct mqs_slam {
     mqs_slam_ba *ba;                 // the in-loop bundle adjuster's resident state (slam_ba.hip; allocated on first use)
     int land_ub;                     // upper bound of the landmarks in the map once the stream has drained (known without waiting)
     int key_pose;                    // pose index of the base keyframe of the live tracks
+    mqs_slam_ingest *ingest;         // null until mqs_slam_ingest_enable
 };
 void mqs_slam_ba_release(mqs_slam *s);          // slam_ba.hip
+void mqs_slam_ingest_release(mqs_slam *s);      // slam_ingest.hip
 int mqs_slam_ba_anchor(mqs_slam *s, int n0);     // slam_ba.hip: at the end of mqs_slam_start, with the log on

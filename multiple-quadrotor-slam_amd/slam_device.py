@@ -67,84 +67,63 @@ def _reprojection_residuals(poses_c2w, points, calib, lm, pose_idx, uv):
     return np.hypot(fx * xd + sk * yd + u0 - uv[:, 0], fy * yd + v0 - uv[:, 1])
 
 
+class _Slot:
+    """An image in the handle's ingest ring (`FrameUploader`): what `DeviceMonoSlam.start` / `handle_new_frame` take instead of a
+    device tensor."""
+    __slots__ = ("index", "source", "ptr")
+
+    def __init__(self, index, source):
+        self.index, self.source, self.ptr = index, source, None      # source: the host array, kept alive until the frame is done
+
+
 class FrameUploader:
     """Frame ingest of the device-resident loop: the reference reads every frame INSIDE its loop (slam2.py:1209-1213: cv2.imread per
-    iteration); here a frame arrives in host memory and goes to the device on a SIDE stream while the loop's kernels work on the frames
-    before it.  Iterating yields the device images in order, each uploaded completely (its event waited for) -- ready for
-    `DeviceMonoSlam.start` / `handle_new_frame(img, uploaded=True)`, which then skips the wait for torch's current stream.
+    iteration); here a frame arrives in host memory and goes to the device on a stream of its own while the loop's kernels work on
+    the frames before it (csrc/slam_ingest.hip: a ring of device images owned by the handle, the library's worker thread enqueues the
+    copies; the loop's stream waits for a frame's upload ON THE DEVICE).  Iterating yields one ring slot per frame, `ahead` uploads
+    posted in front of the one being processed:
 
-    frames: a sequence of H x W uint8 arrays (numpy; copied into a pinned staging slot by the uploader's thread -- the copy releases
-    the interpreter lock and runs beside the loop's library calls, which release it too), or ONE pinned uint8 torch tensor
-    [n, H, W] (a capture buffer the driver delivers into: no staging copy).  depth: uploads in flight ahead of the loop.
-    Every frame gets a device tensor of its own (the loop holds on to the previous image, and to a rejected frame's predecessor)."""
+        for img in FrameUploader(slam, frames):
+            slam.handle_new_frame(img)                  # (the first one: slam.start(img, ...))
 
-    def __init__(self, frames, device=0, depth=4):
-        import threading, queue
-        import torch
-        self._torch = torch
-        self._frames = frames
-        self._n = len(frames)
-        self._dev = torch.device("cuda", int(device))
-        self._stream = torch.cuda.Stream(device=self._dev)
-        self._q = queue.Queue(maxsize=max(1, int(depth)))
-        self._pinned_source = isinstance(frames, torch.Tensor)
-        if self._pinned_source and not (frames.dtype == torch.uint8 and frames.is_pinned() and frames.dim() == 3 and frames.is_contiguous()):
-            raise ValueError("a torch source is one pinned contiguous uint8 tensor [n, H, W]")
-        shape = tuple(frames.shape[1:]) if self._pinned_source else tuple(np.asarray(frames[0]).shape)
-        self._stage = None if self._pinned_source else [torch.empty(shape, dtype=torch.uint8).pin_memory() for _ in range(max(1, int(depth)) + 2)]
-        self._stage_ev = [None] * (0 if self._pinned_source else len(self._stage))
-        self._stop = False
-        self._error = None
-        self._thread = threading.Thread(target=self._run, name="mqs-frame-uploader", daemon=True)
-        self._thread.start()
+    frames: a sequence of H x W uint8 numpy arrays (ordinary memory: staged through the slot's pinned buffer by the worker thread), or
+    ONE pinned uint8 torch tensor [n, H, W] (a capture buffer a driver delivers into: no staging copy)."""
 
-    def _run(self):
-        torch = self._torch
-        try:
-            with torch.cuda.device(self._dev), torch.cuda.stream(self._stream):
-                for k in range(self._n):
-                    if self._stop:
-                        break
-                    if self._pinned_source:
-                        src = self._frames[k]
-                    else:
-                        slot = k % len(self._stage)
-                        if self._stage_ev[slot] is not None:
-                            self._stage_ev[slot].synchronize()              # the slot's last upload has left it
-                        src = self._stage[slot]
-                        np.copyto(src.numpy(), np.asarray(self._frames[k], dtype=np.uint8))
-                    img = torch.empty(src.shape, dtype=torch.uint8, device=self._dev)
-                    img.copy_(src, non_blocking=True)
-                    ev = torch.cuda.Event()
-                    ev.record(self._stream)
-                    if not self._pinned_source:
-                        self._stage_ev[k % len(self._stage)] = ev
-                    self._q.put((img, ev))
-        except Exception as e:                                              # noqa: BLE001 -- handed to the consumer
-            self._error = e
-        self._q.put(None)
+    def __init__(self, slam, frames, ahead=2):
+        self._slam, self._frames, self._n, self._ahead = slam, frames, len(frames), max(1, int(ahead))
+        self._pinned = not isinstance(frames, (list, tuple, np.ndarray))
+        if self._pinned:
+            import torch
+            if not (isinstance(frames, torch.Tensor) and frames.dtype == torch.uint8 and frames.is_pinned() and frames.dim() == 3 and frames.is_contiguous()
+                    and tuple(frames.shape[1:]) == tuple(slam.shape)):
+                raise ValueError("a torch source is one pinned contiguous uint8 tensor [n, H, W]")
+        slam._ingest_enable(self._ahead + 3)            # in use at once: the previous image, the current one, `ahead` uploads, one spare
 
     def __len__(self):
         return self._n
 
-    def __iter__(self):
-        while True:
-            item = self._q.get()
-            if item is None:
-                if self._error is not None:
-                    raise self._error
-                return
-            img, ev = item
-            ev.synchronize()
-            yield img
+    def _post(self, k):
+        s = self._slam
+        if self._pinned:
+            src = self._frames[k]
+            ptr = src.data_ptr()
+        else:
+            src = np.ascontiguousarray(self._frames[k], dtype=np.uint8)
+            if src.shape != tuple(s.shape):
+                raise ValueError("frames are H x W uint8 arrays of shape %r" % (tuple(s.shape),))
+            ptr = src.ctypes.data
+        slot = _Slot(s._ingest_free.pop(), src)
+        _lib.check(_lib.lib().mqs_slam_upload(s._h, slot.index, ctypes.c_void_p(ptr), int(self._pinned)))
+        return slot
 
-    def close(self):
-        self._stop = True
-        try:
-            while self._q.get_nowait() is not None:
-                pass
-        except Exception:
-            pass
+    def __iter__(self):
+        from collections import deque
+        q, k = deque(), 0
+        while k < self._n or q:
+            while k < self._n and len(q) <= self._ahead:
+                q.append(self._post(k))
+                k += 1
+            yield q.popleft()
 
 
 class DeviceMonoSlam:
@@ -226,6 +205,7 @@ class DeviceMonoSlam:
         self.reports = []                # per frame: the first 12 result fields
         self._pending_keyframe = None    # frame index whose refined pose arrives with the next result block
         self._prev = None
+        self._ingest_free = None         # free slots of the ingest ring (FrameUploader), None: no ring
         self._max_landmarks = int(max_landmarks)
         self.ba_info = ba_info
         if bundle_adjust not in (None, "keyframe"):
@@ -289,8 +269,23 @@ class DeviceMonoSlam:
         except Exception:
             pass
 
-    @staticmethod
-    def _img_ptr(img, shape, sync=True):
+    def _ingest_enable(self, slots):
+        if self._ingest_free is None:
+            _lib.check(_lib.lib().mqs_slam_ingest_enable(self._h, int(slots)))
+            self._ingest_free = list(range(int(slots)))
+
+    def _release(self, img):
+        """The loop is done with an image: a ring slot goes back to the free list."""
+        if isinstance(img, _Slot) and self._ingest_free is not None:
+            self._ingest_free.append(img.index)
+
+    def _img_ptr(self, img, shape, sync=True):
+        if isinstance(img, _Slot):
+            if img.ptr is None:                              # first use: the loop's stream waits (on the device) for the slot's upload
+                p = ctypes.c_void_p()
+                _lib.check(_lib.lib().mqs_slam_wait_upload(self._h, img.index, ctypes.byref(p)))
+                img.ptr = p
+            return img.ptr
         import torch
         if not (isinstance(img, torch.Tensor) and img.is_cuda and img.dtype == torch.uint8 and img.is_contiguous()
                 and tuple(img.shape) == tuple(shape)):
@@ -301,13 +296,13 @@ class DeviceMonoSlam:
             torch.cuda.current_stream(img.device).synchronize()
         return ctypes.c_void_p(img.data_ptr())
 
-    def start(self, img, init_objp, init_imgp, uploaded=False):
+    def start(self, img, init_objp, init_imgp):
         """slam2.py:1136-1180: pose of the first frame from known 3-D points, then the first batch of free tracks.
-        uploaded=True: the caller knows the image is complete on the device (`FrameUploader`): no wait for torch's current stream."""
+        img: a contiguous uint8 device tensor, or a slot of the ingest ring (`FrameUploader`)."""
         o = np.ascontiguousarray(init_objp, dtype=np.float32).reshape(-1, 3)
         m = np.ascontiguousarray(init_imgp, dtype=np.float32).reshape(-1, 2)
         pose = np.zeros(12)
-        _lib.check(_lib.lib().mqs_slam_start(self._h, self._img_ptr(img, self.shape, sync=not uploaded), o.ctypes.data_as(_lib.c_f32p),
+        _lib.check(_lib.lib().mqs_slam_start(self._h, self._img_ptr(img, self.shape), o.ctypes.data_as(_lib.c_f32p),
                                              m.ctypes.data_as(_lib.c_f32p), len(o), pose.ctypes.data_as(_lib.c_f64p)))
         self.poses.append(pose.reshape(3, 4).copy())
         self.poses_online.append(pose.reshape(3, 4).copy())
@@ -334,14 +329,13 @@ class DeviceMonoSlam:
             self.poses_online[self._pending_online] = r[28:40].reshape(3, 4).copy()
             self._pending_online = None
 
-    def handle_new_frame(self, img, uploaded=False):
+    def handle_new_frame(self, img):
         """Returns 0 (rejected), 1 (frame) or 2 (keyframe), like the reference's `ret`.
-        uploaded=True: the caller knows the image is complete on the device (`FrameUploader` waits for each frame's upload event on
-        its side stream): no wait for torch's current stream here."""
+        img: a contiguous uint8 device tensor, or a slot of the ingest ring (`FrameUploader`)."""
         t0 = time.perf_counter()
         if self.ba_info is not None:
             self.ba_info.next_step()                         # slam2.py:1204: one step per frame, rejected ones included
-        rc = self._track(self._h, self._img_ptr(self._prev, self.shape, sync=False), self._img_ptr(img, self.shape, sync=not uploaded), self._pres)
+        rc = self._track(self._h, self._img_ptr(self._prev, self.shape, sync=False), self._img_ptr(img, self.shape), self._pres)
         if rc != 0:
             _lib.check(rc)
         r = self._res
@@ -352,6 +346,7 @@ class DeviceMonoSlam:
             if decision == 2:
                 self.keyframes.append(len(self.poses) - 1)
             self._record(decision, int(r[11]))
+            self._release(self._prev)
             self._prev = img
             self.reports.append(r[:12].copy())
             self.timing.append(time.perf_counter() - t0)
@@ -361,6 +356,7 @@ class DeviceMonoSlam:
                 print("REJECTED:", REASONS.get(int(r[1]), "?"))
             self.poses.append(None)
             self.poses_online.append(None)
+            self._release(img)               # (its kernels have run: the call waited for the result block)
         else:
             self.poses.append(r[12:24].reshape(3, 4).copy())
             self.poses_online.append(self.poses[-1].copy())
@@ -373,7 +369,8 @@ class DeviceMonoSlam:
                     self._reassociate(img)
                 if self.bundle_adjust:
                     self._bundle_adjust()
-            self._prev = img             # slam2.py keeps the previous image of a rejected frame
+            self._release(self._prev)        # (ingest ring: the image before this one is not needed any more)
+            self._prev = img                 # slam2.py keeps the previous image of a rejected frame
         self.reports.append(r[:12].copy())
         self.timing.append(time.perf_counter() - t0)
         return decision

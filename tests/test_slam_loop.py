@@ -881,31 +881,40 @@ def test_device_loop_to_bundle_adjustment_files_end_to_end(gpu, tmp_path):
 @pytest.mark.gpu
 @pytest.mark.parametrize("source", ["pinned", "pageable"])
 def test_frame_ingest_on_a_side_stream_gives_the_same_run(gpu, source):
-    """`slam_device.FrameUploader`: the frames go from host memory to the device INSIDE the loop (the reference reads every frame inside
-    its loop, slam2.py:1209-1213), on a side stream while the loop's kernels work on the frames before -- from one pinned capture buffer,
-    or from ordinary arrays through pinned staging slots.  Same decisions and the same poses, bit for bit, as the run whose frames
-    were on the device beforehand."""
+    """`slam_device.FrameUploader` (csrc/slam_ingest.hip): the frames go from host memory to the device INSIDE the loop (the reference
+    reads every frame inside its loop, slam2.py:1209-1213), on a stream of their own while the loop's kernels work on the frames
+    before -- from one pinned capture buffer, or from ordinary arrays through pinned staging slots; the loop's stream waits for a
+    frame's upload on the device.  Same decisions and the same poses, bit for bit, as the run whose frames were on the device
+    beforehand -- with a frame the tracker loses in between (a rejected frame gives its ring slot back at once, its predecessor stays
+    the previous image)."""
     import torch
     seq, objp, imgp, imgs = _rendered(gpu, 30)
+    imgs = list(imgs)
+    imgs[17] = torch.zeros_like(imgs[17])
     host = [im.cpu().numpy() for im in imgs]
 
-    def run(frames):
+    def run(make):
         slam = gpu.slam_device.DeviceMonoSlam(seq.K, seq.dist, (seq.H, seq.W), seed=2, bundle_adjust="keyframe")
         rets = []
-        for k, img in enumerate(frames):
-            up = not isinstance(frames, list)
-            rets.append(slam.start(img, objp, imgp, uploaded=up) is not None and 2 if k == 0 else slam.handle_new_frame(img, uploaded=up))
+        for k, img in enumerate(make(slam)):
+            if k == 0:
+                slam.start(img, objp, imgp)
+                rets.append(2)
+            else:
+                rets.append(slam.handle_new_frame(img))
         slam.finish()
-        poses = [np.array(P) for P in slam.poses]
+        poses = [None if P is None else np.array(P) for P in slam.poses]
+        free = None if slam._ingest_free is None else sorted(slam._ingest_free)
         slam.close()
-        return rets, poses
-    base = run(imgs)
+        return rets, poses, free
+    base = run(lambda slam: imgs)
     src = torch.from_numpy(np.stack(host)).pin_memory() if source == "pinned" else host
-    up = gpu.slam_device.FrameUploader(src, depth=3)
-    assert len(up) == 30
-    other = run(up)
-    assert other[0] == base[0] and 2 in base[0][1:]
+    other = run(lambda slam: gpu.slam_device.FrameUploader(slam, src, ahead=2))
+    assert other[0] == base[0] and 2 in base[0][1:] and 0 in base[0]
     for a, b in zip(base[1], other[1]):
-        assert np.array_equal(a, b)
+        assert (a is None) == (b is None) and (a is None or np.array_equal(a, b))
+    assert len(other[2]) == 4                                                        # of the 5 ring slots only the last image's is still held
+    slam = gpu.slam_device.DeviceMonoSlam(seq.K, seq.dist, (seq.H, seq.W), seed=2)
     with pytest.raises(ValueError):
-        gpu.slam_device.FrameUploader(torch.zeros((2, 4, 4), dtype=torch.uint8))      # a torch source has to be pinned
+        gpu.slam_device.FrameUploader(slam, torch.zeros((2, seq.H, seq.W), dtype=torch.uint8))      # a torch source has to be pinned
+    slam.close()

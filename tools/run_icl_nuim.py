@@ -65,7 +65,7 @@ REFERENCE_NOISE = {"point3D": 0.2, "pose": (0.02, 0.02, 0.02, 0.1, 0.1, 0.1), "o
 # ^ BA_info.noise.*-slam2.txt beside the reference's recording of this sequence
 
 
-def run(frames=None, bundle_adjust=None, seed=0, device=True, reassociate=False, window=None, out_dir=None, screen=None, noise=None, engine="device",
+def run(frames=None, bundle_adjust=None, seed=0, device=True, reassociate=False, window="default", out_dir=None, screen=None, noise=None, engine="device",
         history=None, window_point_sigma="default", carry=True, check=False, upload=None):
     """upload: None -- every frame is on the device before the clock starts (the loop's kernels alone); "pinned" -- the frames lie in ONE pinned host
     buffer and go to the device inside the timed loop, on a side stream under the previous frames' kernels (`slam_device.FrameUploader`);
@@ -90,8 +90,9 @@ def run(frames=None, bundle_adjust=None, seed=0, device=True, reassociate=False,
             src = [np.ascontiguousarray(f) for f in imgs_h]
         torch.cuda.synchronize()
         slam = mqslam_amd.slam_device.DeviceMonoSlam(K, dist, (H, W), seed=seed, bundle_adjust=bundle_adjust, reassociate=reassociate,
-                                                     max_homography_points="reference", ba_window_keyframes=window, second_pass_screen=screen,
-                                                     ba_engine=engine, ba_history_keyframes=history, ba_check=check)
+                                                     max_homography_points="reference", second_pass_screen=screen,
+                                                     ba_engine=engine, ba_history_keyframes=history, ba_check=check,
+                                                     **({} if window == "default" else {"ba_window_keyframes": window}))
         if window_point_sigma != "default":
             slam.ba_window_point_sigma = window_point_sigma
         slam.ba_carry = carry
@@ -105,14 +106,14 @@ def run(frames=None, bundle_adjust=None, seed=0, device=True, reassociate=False,
             for k in range(1, n):
                 rets.append(slam.handle_new_frame(imgs[k]))
         else:
-            up = mqslam_amd.slam_device.FrameUploader(src)
+            up = mqslam_amd.slam_device.FrameUploader(slam, src)
             rets = []
             for k, img in enumerate(up):
                 if k == 0:
-                    slam.start(img, objp, imgp, uploaded=True)
+                    slam.start(img, objp, imgp)
                     rets.append(2)
                 else:
-                    rets.append(slam.handle_new_frame(img, uploaded=True))
+                    rets.append(slam.handle_new_frame(img))
         slam.finish()
     else:
         slam = mqslam_amd.slam_loop.MonoSlam(K, dist, (H, W), seed=seed, second_pass_screen=screen)
@@ -209,7 +210,7 @@ if __name__ == "__main__":
         sys.exit(0)
     a = [x for x in sys.argv[1:] if not x.startswith("--")]
     seed = int(sys.argv[sys.argv.index("--seed") + 1]) if "--seed" in sys.argv else 0
-    window = int(sys.argv[sys.argv.index("--window") + 1]) if "--window" in sys.argv else None
+    window = int(sys.argv[sys.argv.index("--window") + 1]) if "--window" in sys.argv else "default"      # (--window 0: every accepted frame)
     history = int(sys.argv[sys.argv.index("--history") + 1]) if "--history" in sys.argv else None
     screen = float(sys.argv[sys.argv.index("--screen") + 1]) if "--screen" in sys.argv else None
     a = [x for i, x in enumerate(sys.argv[1:], 1) if not x.startswith("--") and sys.argv[i - 1] not in ("--seed", "--window", "--out", "--screen", "--history")]

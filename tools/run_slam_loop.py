@@ -68,12 +68,12 @@ def run_device(frames=60, verbose=False, repeats=1, ba_info=None, out_files=None
             for k in range(1, frames):
                 rets.append(slam.handle_new_frame(imgs[k]))
         else:
-            up = iter(mqslam_amd.slam_device.FrameUploader(src))
-            slam.start(next(up), objp, imgp, uploaded=True)
+            up = iter(mqslam_amd.slam_device.FrameUploader(slam, src))
+            slam.start(next(up), objp, imgp)
             t0 = time.perf_counter()
             rets = [2]
             for img in up:
-                rets.append(slam.handle_new_frame(img, uploaded=True))
+                rets.append(slam.handle_new_frame(img))
         slam.finish()
         dt = time.perf_counter() - t0
         if best is None or dt < best[0]:
