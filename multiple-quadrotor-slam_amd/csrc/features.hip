@@ -232,7 +232,7 @@ __global__ __launch_bounds__(kSelThreads) void sort_select_kernel(unsigned long 
                                                                   const unsigned int *__restrict__ wg_count, unsigned int ntiles, int W,
                                                                   int H, float min_distance, int max_corners, int out_capacity,
                                                                   unsigned int *__restrict__ grid_global, float *__restrict__ out_xy,
-                                                                  int *__restrict__ out_n)
+                                                                  int *__restrict__ out_n, int poll_rounds)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned int sGrid[];
     const unsigned long long *keys = keys_io;
@@ -466,39 +466,53 @@ __global__ __launch_bounds__(kSelThreads) void sort_select_kernel(unsigned long 
         // The loop is left by the WAVEFRONT as a whole (a vote): a lane that left on its own would publish its state only where the
         // wavefront's lanes meet again behind the loop -- which the lanes waiting for that state never reach (measured: the launch hangs).
         int state = survive ? 0 : 2;
-        {
-            volatile int *vState = sState;
-            for (;;) {
-                if (state == 0) {
-                    bool rejected = false, pending = false;
-                    for (int t = 0; t < nnbr; ++t) {
-                        const int sj = vState[sNbr[me * kNbr + t]];
-                        rejected = rejected || sj == 1;
-                        pending = pending || sj == 0;
-                    }
-                    if (overflow) {
+        // what an undecided survivor sees of the stronger survivors near it: 2 (one is accepted: rejected), 1 (all are rejected, or
+        // there are none: accepted), 0 (wait)
+        auto look = [&](volatile int *vState) {
+            bool rejected = false, pending = false;
+            for (int t = 0; t < nnbr; ++t) {
+                const int sj = vState[sNbr[me * kNbr + t]];
+                rejected = rejected || sj == 1;
+                pending = pending || sj == 0;
+            }
+            if (overflow) {
 #pragma unroll 1
-                        for (int k = 0; k < 9; ++k) {
-                            const int xx = cxx + k % 3 - 1, yy = cyy + k / 3 - 1;
-                            if (yy < 0 || yy >= gh || xx < 0 || xx >= gw) continue;
-                            for (int j = sHead[bucket_of(xx, yy)]; j >= 0; j = sNext[j]) {
-                                if (j >= me) continue;
-                                const unsigned int pj = sSurv[j];
-                                const float dx = (float)(x - (int)(pj & 0xFFFFu)), dy = (float)(y - (int)(pj >> 16));
-                                if (dx * dx + dy * dy < md2) {
-                                    const int sj = vState[j];
-                                    rejected = rejected || sj == 1;
-                                    pending = pending || sj == 0;
-                                }
-                            }
+                for (int k = 0; k < 9; ++k) {
+                    const int xx = cxx + k % 3 - 1, yy = cyy + k / 3 - 1;
+                    if (yy < 0 || yy >= gh || xx < 0 || xx >= gw) continue;
+                    for (int j = sHead[bucket_of(xx, yy)]; j >= 0; j = sNext[j]) {
+                        if (j >= me) continue;
+                        const unsigned int pj = sSurv[j];
+                        const float dx = (float)(x - (int)(pj & 0xFFFFu)), dy = (float)(y - (int)(pj >> 16));
+                        if (dx * dx + dy * dy < md2) {
+                            const int sj = vState[j];
+                            rejected = rejected || sj == 1;
+                            pending = pending || sj == 0;
                         }
                     }
-                    if (rejected) state = 2;
-                    else if (!pending) state = 1;
+                }
+            }
+            return rejected ? 2 : (pending ? 0 : 1);
+        };
+        {
+            // (bounded: `poll_rounds` polls per wavefront -- every round some survivor decides, a workgroup's chain is at most
+            // kSelThreads long, so the bound is never reached unless the forward-progress assumption between wavefronts breaks;
+            // what is left undecided then is settled by the synchronous sweeps below, not by a hang)
+            volatile int *vState = sState;
+            for (int round = 0; round < poll_rounds; ++round) {
+                if (state == 0) {
+                    state = look(vState);
                     if (state != 0) vState[me] = state;
                 }
                 if (__builtin_amdgcn_ballot_w64(state == 0) == 0ull) break;
             }
+        }
+        // the net under the polling (and the whole rule when poll_rounds = 0, the A/B form): every undecided survivor looks, a
+        // workgroup barrier, every one that decided writes, a barrier with a vote -- until nobody is undecided
+        while (__syncthreads_or(state == 0)) {
+            const int ns = state == 0 ? look(sState) : state;
+            __syncthreads();
+            if (ns != state) { state = ns; sState[me] = state; }
         }
         __syncthreads();
         // the accepted survivors in order
@@ -1140,17 +1154,21 @@ int mqs_good_features_to_track_dev(const uint8_t *img, int W, int H, int max_cor
     const size_t sort_lds = (size_t)kSortChunk * sizeof(unsigned long long);
     const size_t grid_lds = cells * 16;
     const bool in_lds = min_distance < 1.0 || grid_lds <= sort_lds;      // the grid takes the sort buffer's place
+    // polls per wavefront of the selection's barrier-free decisions before the synchronous sweeps take over (never reached in
+    // practice; MQS_GFTT_POLL_ROUNDS=0 runs the synchronous rule alone: the A/B form the tests compare)
+    int poll_rounds = 1 << 16;
+    if (const char *e = getenv("MQS_GFTT_POLL_ROUNDS")) poll_rounds = atoi(e) < 0 ? 0 : atoi(e);
     const size_t lds = sort_lds;
     if (in_lds) {
         static mqs_lds_opt_in opt;                           // per device
         MQS_HIP_CHECK(mqs_lds_opt_in_once(opt, reinterpret_cast<const void *>(sort_select_kernel<true>), (int)sort_lds));
         hipLaunchKernelGGL(sort_select_kernel<true>, dim3(1), dim3(kSelThreads), lds, stream, keys_seg, keys, wg_count, (unsigned int)ntiles, W,
-                           H, (float)min_distance, max_corners, out_capacity, grid, out_xy, out_n);
+                           H, (float)min_distance, max_corners, out_capacity, grid, out_xy, out_n, poll_rounds);
     } else {
         static mqs_lds_opt_in opt;                           // per device
         MQS_HIP_CHECK(mqs_lds_opt_in_once(opt, reinterpret_cast<const void *>(sort_select_kernel<false>), (int)sort_lds));
         hipLaunchKernelGGL(sort_select_kernel<false>, dim3(1), dim3(kSelThreads), sort_lds, stream, keys_seg, keys, wg_count,
-                           (unsigned int)ntiles, W, H, (float)min_distance, max_corners, out_capacity, grid, out_xy, out_n);
+                           (unsigned int)ntiles, W, H, (float)min_distance, max_corners, out_capacity, grid, out_xy, out_n, poll_rounds);
     }
     MQS_HIP_CHECK(hipGetLastError());
     return MQS_OK;

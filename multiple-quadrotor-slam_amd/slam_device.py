@@ -28,6 +28,8 @@ from .slam_loop import (CORNER_QUALITY_LEVEL, HOMOGRAPHY_CONDITION_THRESHOLD, KE
 
 REASSOCIATE_RADIUS = 2.0         # pixels: a re-detected corner within this distance of a lost landmark's projection (slam.py:29 max_radius_OF_to_FAST["FAST"])
 REASSOCIATE_RATIO = 0.7          # slam.py:30 max_dist_ratio["FAST"]
+# BA_info.noise.*-slam2.txt beside the reference's recording of its ICL-NUIM example sequence (Work/SLAM/datasets/ICL_NUIM/living_room_traj3n_frei_png)
+REFERENCE_NOISE = {"point3D": 0.2, "pose": (0.02, 0.02, 0.02, 0.1, 0.1, 0.1), "odometry": (0.05, 0.05, 0.05, 0.2, 0.2, 0.2), "point2D": 1.0}
 
 
 
@@ -130,7 +132,7 @@ class DeviceMonoSlam:
     def __init__(self, cameraMatrix, distCoeffs, image_shape, seed=0, device=0, max_landmarks=1 << 16, verbose=False,
                  ba_info=None, max_homography_points=0, bundle_adjust=None, ba_iterations=10, ba_log_capacity=1 << 20,
                  reassociate=False, ba_window_keyframes=3, second_pass_screen=None, ba_engine="device", ba_check=False,
-                 ba_history_keyframes=None):
+                 ba_history_keyframes=None, ba_noise=None):
         """max_homography_points: size of keyframe_test's random sample of the tracks (slam2.py:48): 0 = every track (default),
         "reference" = the reference's max(4, target_amount_keypoints / 4) (:1088-1089).  On the rendered test sequence the quarter
         makes the run depend on the draw -- trajectory RMSE 0.017-0.020 for half of the seeds, 0.057-0.068 for the other half,
@@ -163,6 +165,12 @@ class DeviceMonoSlam:
         second_pass_screen=px (None / 0: off, the reference's flow): at a keyframe a freshly triangulated point whose reprojection error
         in the current frame exceeds px is not handed to the second solvePnP (slam2.py:576-577) -- the use slam2.py:1092 announces for
         max_2nd_solvePnP_reproj_error (= 1 px) and never makes; see mqs_slam_set_second_pass_screen.
+        ba_noise: the adjustment's noise models, as the reference keeps them in the four BA_info.noise.* files beside a recording
+        (`ba_io.load_data` reads them: poseNoise, odometryNoise, point3DNoise, point2DNoise) -- a dict with any of "point3D" (sigma of the prior on the start-up landmarks), "pose" (6: prior
+        on the first pose, rotation then translation), "odometry" (6: keyframe -> keyframe between-factors), "point2D" (pixels); or
+        "reference": the values of the reference's ICL-NUIM recording (REFERENCE_NOISE below).  Default: this build's (a 0.05 m
+        start-up prior instead of 0.2 -- inside the loop the start-up points are what the first pose was COMPUTED from; a 2 mrad /
+        1 mm first-pose prior; the reference's odometry and pixel sigmas): profiles/r05/07 has the measurement behind the deviation.
         reassociate=True: behind every keyframe's top-up the new corners are matched (BFMatcher.radiusMatch on pixel positions +
         ratio test + one match per corner: the reference's match_OF_based, slam.py:81-127, cv2_helpers.py:296-339) against the
         PROJECTIONS of the landmarks that are in the map but not tracked any more; a matched corner takes its landmark up again
@@ -229,6 +237,17 @@ class DeviceMonoSlam:
         self.ba_pose_sigmas = (0.002, 0.002, 0.002, 0.001, 0.001, 0.001)     # prior on the first pose (:273), rotation then translation
         self.ba_odometry_sigmas = (0.05, 0.05, 0.05, 0.2, 0.2, 0.2)  # between-factors keyframe -> keyframe (:301-309)
         self.ba_pixel_sigma = 1.0
+        if ba_noise is not None:
+            nz = REFERENCE_NOISE if ba_noise == "reference" else dict(ba_noise)
+            unknown = set(nz) - {"point3D", "pose", "odometry", "point2D"}
+            if unknown:
+                raise ValueError("ba_noise: unknown keys %r (point3D, pose, odometry, point2D)" % sorted(unknown))
+            self.ba_point_sigma = float(nz.get("point3D", self.ba_point_sigma))
+            self.ba_pose_sigmas = tuple(float(v) for v in nz.get("pose", self.ba_pose_sigmas))
+            self.ba_odometry_sigmas = tuple(float(v) for v in nz.get("odometry", self.ba_odometry_sigmas))
+            self.ba_pixel_sigma = float(nz.get("point2D", self.ba_pixel_sigma))
+            if len(self.ba_pose_sigmas) != 6 or len(self.ba_odometry_sigmas) != 6:
+                raise ValueError("ba_noise: pose and odometry sigmas are 6 values (rotation, then translation)")
         self.ba_window_keyframes = ba_window_keyframes              # None: every frame so far; K >= 1: every frame since the K-th keyframe from the end + the keyframes in front
         self.ba_history_keyframes = ba_history_keyframes            # None: every keyframe in front of the dense part; H >= 0: the last H of them
         self.ba_window_point_sigma = 0.02                           # selection: prior on a landmark that frames outside the problem have seen (0 / None: none)

@@ -136,6 +136,23 @@ def test_gpu_good_features_more_candidates_than_one_sort_chunk(md, gpu):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("rounds", ["0", "3"])
+def test_gpu_good_features_selection_with_a_spent_poll_bound(rounds, gpu, monkeypatch):
+    """The selection's decisions propagate by polling LDS states without a workgroup barrier; the polling is BOUNDED (round 6: it was
+    not) and what it leaves undecided is settled by synchronous sweeps (look, barrier, write, barrier with a vote).  With the bound at
+    0 the sweeps are the whole rule, at 3 they take over in the middle of the dependency chains (the noise frame's are long): the same
+    corners in the same order as the oracle either way."""
+    monkeypatch.setenv("MQS_GFTT_POLL_ROUNDS", rounds)
+    rng = np.random.default_rng(12)
+    img = rng.integers(0, 256, (480, 640), dtype=np.uint8)
+    ref = Fn.good_features_to_track(img, 0, 1e-4, 3.0)
+    got = gpu.features.goodFeaturesToTrack(img, 0, 1e-4, 3.0, capacity=len(ref) + 8)
+    np.testing.assert_array_equal(got, ref)
+    tex = texture(240, 320, seed=240)
+    np.testing.assert_array_equal(gpu.features.goodFeaturesToTrack(tex, 300, 0.01, 7.0), Fn.good_features_to_track(tex, 300, 0.01, 7.0))
+
+
+@pytest.mark.gpu
 def test_gpu_good_features_checkerboard_and_flat(gpu):
     pts = gpu.features.goodFeaturesToTrack(checkerboard(96, 128, 16), 0, 0.05, 5.0, capacity=100)
     np.testing.assert_array_equal(pts, Fn.good_features_to_track(checkerboard(96, 128, 16), 0, 0.05, 5.0))

@@ -241,22 +241,28 @@ def test_reference_s_committed_run_drifts_over_the_200_frames():
 @pytest.mark.gpu
 def test_all_200_frames_of_the_example_sequence(gpu):
     """The part of the reference's example run its 80-frame fixture does not see: frames 85-199, where the reference's committed
-    trajectory drifts to 0.171 m.  The plain loop -- slam2.py's flow -- drifts as well (52-205 mm over 8 seeds, a median of 81);
-    with the bundle adjustment per keyframe (the resident adjuster: ~20 adjustments of up to 200 poses) every seed stays within 3.5-7.1
-    mm of the exact trajectory (profiles/r05).  Bars within twice the measurements."""
+    trajectory drifts to 0.171 m.  The plain loop -- slam2.py's flow -- drifts as well (52-205 mm over 8 seeds, a median of 81; 52 mm
+    at seed 0); with the bundle adjustment per keyframe every seed stays within a centimetre of the exact trajectory: the adjustment
+    over EVERY accepted frame (round 5: ~20 adjustments of up to 200 poses) 4.2-8.0 mm over 16 seeds, the default selection (round 6:
+    every keyframe + the frames since the third keyframe from the end, 20-35 poses) 3.4-7.2 mm at twice the frame rate
+    (profiles/r06).  Bars within twice the measurements."""
     import run_icl_nuim
     plain = run_icl_nuim.run(200, seed=0)
     assert plain["accepted"] == 200 and plain["keyframes"] >= 10
     assert abs(plain["reference_vs_groundtruth_rmse_m"] - 0.17097) < 2e-4
-    assert 0.02 < plain["ours_vs_groundtruth_rmse_m"] < 0.41                     # it drifts, like the reference's run (measured 52 mm at this seed)
+    assert 0.026 < plain["ours_vs_groundtruth_rmse_m"] < 0.105                   # it drifts, like the reference's run (measured 52 mm at this seed)
     errs = []
     for seed in range(4):
         out = run_icl_nuim.run(200, bundle_adjust="keyframe", seed=seed)
-        assert out["accepted"] == 200 and out["engine"] == "device" and out["poses_in_the_last_adjustment"] == 200
+        assert out["accepted"] == 200 and out["engines"] == ["device"] and not out["fallbacks"]
+        assert 15 <= out["poses_in_the_last_adjustment"] <= 70 and max(out["poses_per_adjustment"]) <= 100      # (the first adjustment: no keyframes to select from yet)
         assert out["ours_vs_groundtruth_rmse_m"] < 0.010 and out["ours_vs_groundtruth_max_m"] < 0.03
         assert out["orientation_rmse_deg"]["ours_vs_groundtruth"] < 0.5
         errs.append(out["ours_vs_groundtruth_rmse_m"])
     assert max(errs) < 0.06 * plain["reference_vs_groundtruth_rmse_m"]           # a thirtieth of the reference's drift
+    every = run_icl_nuim.run(200, bundle_adjust="keyframe", seed=0, window=None)  # the whole graph behind every keyframe, as the reference's tool adjusts a recording
+    assert every["engines"] == ["device"] and every["poses_in_the_last_adjustment"] == 200
+    assert every["ours_vs_groundtruth_rmse_m"] < 0.010 and every["ours_vs_groundtruth_max_m"] < 0.03
 
 
 @pytest.mark.gpu

@@ -229,6 +229,64 @@ def test_cross_match_all_camera_pairs(gpu):
 
 
 @pytest.mark.gpu
+def test_cross_match_all_camera_pairs_at_full_size_64k(gpu):
+    """BASELINE configs[2] at its full size: 4 cameras x 65 536 descriptors of 256 bits, every unordered camera pair (6), kNN-2 on
+    the FP4 matrix path + the reference's ratio test / one match per train point on the device (what bench.py times and, until
+    round 6, did not check).  Per pair: 200 sampled query rows of the kNN equal the oracle (indices and distances exactly); the
+    whole kNN equals the pair-by-pair call; the filter's output equals the reference's loop (slam.py:101-125 as restated in the
+    oracle) run on the kNN rows of a SUBSET of the train points -- every train point whose nearest queries are all known -- and
+    satisfies the rule's properties on all 65 536: at most one query per train point, every kept match within the radius and
+    passing the ratio test, the kept query the one with the smallest priority among those that claim the train point."""
+    import torch
+    N, D, radius, ratio = 65536, 256, 8.0, 0.8
+    base = gpu.matching.binary_descriptors(N, D, seed=20)
+    bits = [base] + [gpu.matching.binary_descriptors(N, D, seed=20 + c, copies_of=base.astype(np.uint8)) for c in range(1, 4)]
+    packed = [torch.from_numpy(gpu.matching.pack_bits(b)).cuda() for b in bits]
+    res = gpu.matching.cross_match_dev(packed, max_radius=radius, max_dist_ratio=ratio)
+    assert sorted(res) == gpu.matching.camera_pairs(4)
+    dealt = {}
+    for rank in range(4):
+        dealt.update(gpu.matching.cross_match_dev(packed, rank, 4, max_radius=radius, max_dist_ratio=ratio))
+    rng = np.random.default_rng(5)
+    kept_total = 0
+    for (a, b), (idx, dist, qot, dot) in res.items():
+        idx, dist, qot, dot = idx.cpu().numpy(), dist.cpu().numpy(), qot.cpu().numpy(), dot.cpu().numpy()
+        for x, y in zip((idx, dist, qot, dot), dealt[(a, b)]):                       # pairs dealt to ranks: the same arrays
+            np.testing.assert_array_equal(x, y.cpu().numpy())
+        sample = rng.choice(N, 200, replace=False)
+        io, do = M.knn2_hamming_bits(bits[a][sample], bits[b])
+        np.testing.assert_array_equal(idx[sample], io)
+        np.testing.assert_array_equal(dist[sample], do)
+        i2, d2 = gpu.matching.knn2_bits_dev(packed[a], packed[b])                   # the pair-by-pair path
+        np.testing.assert_array_equal(idx, i2.cpu().numpy())
+        np.testing.assert_array_equal(dist, d2.cpu().numpy())
+        # the filter, from the kNN rows (exact by the lines above): the reference's rule vectorised
+        in1 = (idx[:, 1] >= 0) & (dist[:, 1] <= radius)                              # (the division in double, like DMatch.distance's Python floats;
+        with np.errstate(divide="ignore", invalid="ignore"):                         # 0 / 0 -- the reference raises there -- fails like every NaN compare)
+            ok = (idx[:, 0] >= 0) & (dist[:, 0] <= radius) & (~in1 | (dist[:, 0].astype(np.float64) / dist[:, 1].astype(np.float64) < ratio))
+        claim = np.where(ok, idx[:, 0], -1)
+        best = np.full(N, -1)
+        order = np.lexsort((np.arange(N), dist[:, 0]))                               # smallest priority (= first distance), then the earlier query
+        for q in order[::-1]:
+            if claim[q] >= 0:
+                best[claim[q]] = q
+        np.testing.assert_array_equal(qot, best)
+        kept = qot >= 0
+        np.testing.assert_array_equal(dot[kept], dist[qot[kept], 0])
+        assert kept.sum() > (0.25 * N if a == 0 else 1000)                           # half of camera b's descriptors are planted copies of camera 0's; two cameras' copies of the SAME row meet less often
+        kept_total += int(kept.sum())
+        # ... and on a sample of train points against the oracle's statement-by-statement loop
+        tsub = rng.choice(np.nonzero(kept)[0], 50, replace=False)
+        qs = np.nonzero(np.isin(idx[:, 0], tsub))[0]
+        two = [[M.DMatch(n, int(idx[q, k]), float(dist[q, k])) for k in range(2) if idx[q, k] >= 0 and dist[q, k] <= radius] for n, q in enumerate(qs)]
+        two = [ms if not (len(ms) == 2 and ms[1].distance == 0.0) else [] for ms in two]
+        ref = M.ratio_test_and_dedupe(two, dist[qs, 0], ratio)
+        for t in tsub:
+            assert t in ref and qs[ref[t].queryIdx] == qot[t] and ref[t].distance == dot[t]
+    assert kept_total > 3 * 0.25 * N
+
+
+@pytest.mark.gpu
 def test_unique_filter_priority_ordering_edge_values(gpu):
     """The priority key of the de-duplication is an order-preserving image of the float: negative values, zeros of both signs,
     infinities and NaN (ranks last) order as the reference's `<` does; equal priorities keep the earlier query."""

@@ -61,8 +61,7 @@ def load_sequence(frames=None):
     return d
 
 
-REFERENCE_NOISE = {"point3D": 0.2, "pose": (0.02, 0.02, 0.02, 0.1, 0.1, 0.1), "odometry": (0.05, 0.05, 0.05, 0.2, 0.2, 0.2), "point2D": 1.0}
-# ^ BA_info.noise.*-slam2.txt beside the reference's recording of this sequence
+REFERENCE_NOISE = mqslam_amd.slam_device.REFERENCE_NOISE      # BA_info.noise.*-slam2.txt beside the reference's recording of this sequence
 
 
 def run(frames=None, bundle_adjust=None, seed=0, device=True, reassociate=False, window="default", out_dir=None, screen=None, noise=None, engine="device",
@@ -92,13 +91,11 @@ def run(frames=None, bundle_adjust=None, seed=0, device=True, reassociate=False,
         slam = mqslam_amd.slam_device.DeviceMonoSlam(K, dist, (H, W), seed=seed, bundle_adjust=bundle_adjust, reassociate=reassociate,
                                                      max_homography_points="reference", second_pass_screen=screen,
                                                      ba_engine=engine, ba_history_keyframes=history, ba_check=check,
+                                                     ba_noise="reference" if noise == "reference" else None,
                                                      **({} if window == "default" else {"ba_window_keyframes": window}))
         if window_point_sigma != "default":
             slam.ba_window_point_sigma = window_point_sigma
         slam.ba_carry = carry
-        if noise == "reference":
-            slam.ba_point_sigma, slam.ba_pose_sigmas = REFERENCE_NOISE["point3D"], REFERENCE_NOISE["pose"]
-            slam.ba_odometry_sigmas, slam.ba_pixel_sigma = REFERENCE_NOISE["odometry"], REFERENCE_NOISE["point2D"]
         t0 = time.perf_counter()
         if upload is None:
             slam.start(imgs[0], objp, imgp)
