@@ -685,7 +685,10 @@ int mqs_slam_reassociate(mqs_slam *s, float max_radius, double max_dist_ratio, i
  *                         barriers -- screens mistracked landmarks (a landmark whose worst residual exceeds `gross_px`
  *                         before, `outlier_px` after an adjustment, or that lies closer to one of its cameras than
  *                         `min_depth_ratio` x the median depth, sits out from then on; the adjustment is redone from its
- *                         start, <= max_passes) and writes the adjusted landmarks (float32 values, slam2.py:19), the poses of
+ *                         start, <= max_passes; screen_iterations = K > 0: the screen behind an adjustment also looks behind every
+ *                         K of its iterations -- a pass that carries a mistracked corner is thrown away after K trials instead
+ *                         of after max_iterations; a leg of K iterations that finds none goes on from its estimate with the
+ *                         damping back at lambda_initial, like a second optimize() call) and writes the adjusted landmarks (float32 values, slam2.py:19), the poses of
  *                         all accepted frames and the live state's two poses back.  Nothing is copied to the host but the
  *                         report and, if asked for, the adjusted poses.
  *                         add_odometry_edge != 0: the call stands behind a keyframe; the edge (edge_from = the previous base
@@ -727,6 +730,8 @@ typedef struct mqs_slam_ba_params {
     int32_t add_odometry_edge, edge_from, edge_to;
     int32_t damping;                                  /* MQS_SBA_DAMPING_GTSAM / _MARQUARDT */
     int32_t workgroups;                               /* 0: the library's choice */
+    int32_t screen_iterations;                        /* 0: off; K: the residual screen also looks behind every K iterations of an adjustment (see above) */
+    int32_t reserved;
     double outlier_px, gross_px, border_margin_px, min_depth_ratio;
     double point_sigma, pixel_sigma;
     double pose_sigmas[6], odometry_sigmas[6];        /* rotation (3) then translation (3), as the reference's noise files */

@@ -112,6 +112,7 @@ struct BaParams {
     int carry;                                       // the accepted frames behind sel[0] that are not poses of the problem keep their pose RELATIVE to the nearest problem pose in front of them
     double out_prior_w;                              // 1 / sigma^2 of the prior on a landmark that frames outside the problem have seen, at its current value; 0: none
     int max_iterations, min_observations, max_passes, damping;
+    int screen_iters;                                // 0: the residual screen only behind a finished adjustment; K: also behind every K iterations of one (legs)
     int add_edge, edge_from, edge_to, n_odo;         // n_odo: edges AFTER this call's has been appended
     double outlier_px, gross_px, border, min_depth_ratio;
     double prior_w, isigma_px, sigma_px;
@@ -1457,33 +1458,70 @@ __global__ __launch_bounds__(kT) void slam_ba_kernel(BaDev b, SlamDev d, BaParam
             barriers += 1;
         }
         if (!have_before) { cost_before = cur; have_before = true; }
-        double lam = p.lam0;
-        int nh = 1;
-        for (int it = 0; it < p.max_iterations && !failed; ++it) {
-            bool improved = false;
-            double fresh = 0.0;
-            while (lam <= p.lam_upper) {
-                bool ok = true;
-                if (!lm_trial(c, poses_cur, pts_cur, poses_new, pts_new, sgn * lam, true, fresh, ok, barriers)) { failed = true; break; }
-                trials += 1;
-                if (!ok) fresh = HUGE_VAL;
-                if (fresh <= cur) {
-                    double *t1 = poses_cur; poses_cur = poses_new; poses_new = t1;
-                    double *t2 = pts_cur; pts_cur = pts_new; pts_new = t2;
-                    lam = lam / p.lam_factor;
-                    if (lam < 1e-20) lam = 1e-20;
-                    improved = true;
-                    break;
+        // The iterations run in LEGS of at most `screen_iters` (0: one leg of max_iterations -- the adjustment as round 5 ran it).  Behind a
+        // leg that has neither met the stop rule nor used the iterations up, the residual screen looks at the estimate as it stands: a
+        // mistracked corner shows after three or four iterations (its residual stays at tens of pixels while the cost is still falling by
+        // per cent), and a pass that carries one used to run to the iteration cap before the screen behind it threw the pass away --
+        // ten trials where four tell the same.  Outliers found: retired, the adjustment redone from its start (a pass, as behind the
+        // final screen); none: the next leg goes on from the estimate, its damping back at the initial value (GTSAM: a second optimize()).
+        int nh = 1;                                           // accepted iterations of this pass + 1, over its legs
+        bool early_out = false;
+        for (;;) {
+            double lam = p.lam0;
+            const int left = p.max_iterations - (nh - 1);
+            const int leg_cap = (p.screen_iters > 0 && p.screen_iters < left) ? p.screen_iters : left;
+            bool ended = false;                               // the stop rule was met, or no trial at any damping was accepted
+            for (int it = 0; it < leg_cap && !failed; ++it) {
+                bool improved = false;
+                double fresh = 0.0;
+                while (lam <= p.lam_upper) {
+                    bool ok = true;
+                    if (!lm_trial(c, poses_cur, pts_cur, poses_new, pts_new, sgn * lam, true, fresh, ok, barriers)) { failed = true; break; }
+                    trials += 1;
+                    if (!ok) fresh = HUGE_VAL;
+                    if (fresh <= cur) {
+                        double *t1 = poses_cur; poses_cur = poses_new; poses_new = t1;
+                        double *t2 = pts_cur; pts_cur = pts_new; pts_new = t2;
+                        lam = lam / p.lam_factor;
+                        if (lam < 1e-20) lam = 1e-20;
+                        improved = true;
+                        break;
+                    }
+                    lam *= p.lam_factor;
                 }
-                lam *= p.lam_factor;
+                if (failed || !improved) { ended = true; break; }
+                nh += 1;
+                const double dec = fabs(cur - fresh);
+                const bool done = dec < p.abs_tol || dec / (cur > 1e-300 ? cur : 1e-300) < p.rel_tol;
+                cur = fresh;
+                if (done) { ended = true; break; }
             }
-            if (failed || !improved) break;
-            nh += 1;
-            const double dec = fabs(cur - fresh);
-            const bool done = dec < p.abs_tol || dec / (cur > 1e-300 ? cur : 1e-300) < p.rel_tol;
-            cur = fresh;
-            if (done) break;
+            if (failed || ended || nh - 1 >= p.max_iterations || p.screen_iters <= 0) break;
+            if (passes + 1 >= p.max_passes) continue;         // (no pass left to redo the adjustment in: the legs just go on)
+            stage_cams(c, poses_cur, lds_cam());
+            phase_worst(c, pts_cur, lds_cam(), false);
+            if (!grid_barrier(c)) { failed = true; break; }
+            barriers += 1;
+            int32_t *early_ctr = fresh_counter(c);
+            for (int l = gtid; l < N; l += gthreads) {
+                const bool cand = ldg(b.use + l) != 0 && l >= c.n0 && !(ldg(b.worst + l) <= p.outlier_px);
+                stg(b.cand + l, cand ? 1 : 0);
+                if (cand) atomicAdd(early_ctr, 1);
+            }
+            int ne = 0;
+            if (!count_barrier(c, early_ctr, ne)) { failed = true; break; }
+            barriers += 1;
+            if (ne > 0) {
+                for (int l = gtid; l < N; l += gthreads)
+                    if (ldg(b.cand + l) != 0) { stg(b.bad + l, 1); stg(b.use + l, 0); }
+                dropped += ne;
+                early_out = true;
+                break;
+            }
+            if (c.ctr_next >= kCtr - 8) break;
         }
+        if (failed) break;
+        if (early_out) { passes += 1; dirty = true; if (c.ctr_next >= kCtr - 8) break; continue; }
         if (failed) break;
         lm_iters = nh - 1;
         cost_after = cur;
@@ -1867,6 +1905,7 @@ int ba_run(mqs_slam *s, const mqs_slam_ba_params *q, const mqs_slam_ba_window *w
     }
     p.P = P; p.P_all = P_all; p.G = G; p.key_pose = s->key_pose;
     p.max_iterations = q->max_iterations; p.min_observations = q->min_observations; p.max_passes = q->max_passes; p.damping = q->damping;
+    p.screen_iters = q->screen_iterations > 0 ? q->screen_iterations : 0;
     p.n_odo = ba->n_odo + (p.add_edge ? 1 : 0);
     p.outlier_px = q->outlier_px; p.gross_px = q->gross_px; p.border = q->border_margin_px; p.min_depth_ratio = q->min_depth_ratio;
     p.prior_w = 1.0 / (q->point_sigma * q->point_sigma); p.sigma_px = q->pixel_sigma; p.isigma_px = 1.0 / q->pixel_sigma;

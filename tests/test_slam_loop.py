@@ -374,8 +374,8 @@ def test_device_loop_launch_forms_give_the_same_run(gpu, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("window, history", [(None, None), (3, None), (2, 2)], ids=["every frame", "default selection", "bounded history"])
-def test_resident_adjuster_equals_its_host_built_twin_at_every_keyframe(gpu, window, history):
+@pytest.mark.parametrize("window, history, legs", [(None, None, 0), (3, None, 3), (2, 2, 2)], ids=["every frame", "default selection", "bounded history"])
+def test_resident_adjuster_equals_its_host_built_twin_at_every_keyframe(gpu, window, history, legs):
     """`mqs_slam_bundle_adjust(_window)` (csrc/slam_ba.hip: the whole adjustment in one persistent launch on the resident log, map and
     trajectory) against round 4's host-built path on the SAME state, behind every keyframe of the rendered sequence: the twin builds
     the CSR problem from the log read back, runs `sparse_ba.SparseBundleAdjuster` (the reference-pinned kernels of ba_sparse.hip) with
@@ -384,10 +384,11 @@ def test_resident_adjuster_equals_its_host_built_twin_at_every_keyframe(gpu, win
     Three forms: every accepted frame (the reference's whole-graph adjustment); the default SELECTION (round 6: the keyframes so far
     + every frame since the third keyframe from the end, the frames left out carried along with the keyframe in front of them);
     a selection with a bounded history -- frame 0 leaves the problem, the gauge becomes two pose priors at current values and the
-    landmarks seen from frames outside keep a prior."""
+    landmarks seen from frames outside keep a prior.  The residual screen behind a whole adjustment only (round 5's form), behind
+    every three iterations (the default) and behind every two."""
     seq, objp, imgp, imgs = _rendered(gpu, 45)
     slam = gpu.slam_device.DeviceMonoSlam(seq.K, seq.dist, (seq.H, seq.W), seed=1, bundle_adjust="keyframe", ba_check=True, reassociate=True,
-                                          ba_window_keyframes=window, ba_history_keyframes=history)
+                                          ba_window_keyframes=window, ba_history_keyframes=history, ba_screen_iterations=legs)
     assert slam.ba_engine == "device"
     slam.start(imgs[0], objp, imgp)
     for k in range(1, 45):

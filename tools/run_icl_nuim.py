@@ -65,7 +65,7 @@ REFERENCE_NOISE = mqslam_amd.slam_device.REFERENCE_NOISE      # BA_info.noise.*-
 
 
 def run(frames=None, bundle_adjust=None, seed=0, device=True, reassociate=False, window="default", out_dir=None, screen=None, noise=None, engine="device",
-        history=None, window_point_sigma="default", carry=True, check=False, upload=None):
+        history=None, window_point_sigma="default", carry=True, check=False, upload=None, screen_iterations="default"):
     """upload: None -- every frame is on the device before the clock starts (the loop's kernels alone); "pinned" -- the frames lie in ONE pinned host
     buffer and go to the device inside the timed loop, on a side stream under the previous frames' kernels (`slam_device.FrameUploader`);
     "pageable" -- they lie in ordinary numpy arrays and pass through pinned staging slots on the uploader's thread.
@@ -92,7 +92,8 @@ def run(frames=None, bundle_adjust=None, seed=0, device=True, reassociate=False,
                                                      max_homography_points="reference", second_pass_screen=screen,
                                                      ba_engine=engine, ba_history_keyframes=history, ba_check=check,
                                                      ba_noise="reference" if noise == "reference" else None,
-                                                     **({} if window == "default" else {"ba_window_keyframes": window}))
+                                                     **({} if window == "default" else {"ba_window_keyframes": window}),
+                                                     **({} if screen_iterations == "default" else {"ba_screen_iterations": screen_iterations}))
         if window_point_sigma != "default":
             slam.ba_window_point_sigma = window_point_sigma
         slam.ba_carry = carry
