@@ -132,7 +132,7 @@ using float16v = __attribute__((ext_vector_type(16))) float;
 #define MQS_MATCH_QT256 2
 #endif
 #ifndef MQS_MATCH_SCHED
-#define MQS_MATCH_SCHED 0
+#define MQS_MATCH_SCHED 1              // the issue order of a step given to the scheduler as sched_group_barriers (round 6: 1.273 -> 1.264 ms on the fp16 path)
 #endif
 #ifndef MQS_MATCH_NOPEEL
 #define MQS_MATCH_NOPEEL 1
@@ -144,8 +144,8 @@ using float16v = __attribute__((ext_vector_type(16))) float;
 #define MQS_MATCH_PF 4
 #endif
 #ifndef MQS_MATCH_PRUNE_F16
-#define MQS_MATCH_PRUNE_F16 0          // the same on the fp16 path (not bound by vector issue: measured)
-#endif
+#define MQS_MATCH_PRUNE_F16 1          // the same on the fp16 path.  (Rounds 2-5: off -- with the stage fill's ~100 instructions and a load + wait at every stage's start the
+#endif                                 // scan was not what the waves were short of; with those gone, round 6, it is: 1.265 -> 1.192 ms, profiles/r06)
 #ifndef MQS_MATCH_F4_QT
 #define MQS_MATCH_F4_QT 4
 #endif
@@ -158,6 +158,9 @@ using float16v = __attribute__((ext_vector_type(16))) float;
 #ifndef MQS_MATCH_F16_GROUP
 #define MQS_MATCH_F16_GROUP 1          // A/B: query tiles per train-fragment read on the fp16 path (group_step when > 1)
 #endif
+#ifndef MQS_MATCH_F16_SERIAL_SCAN
+#define MQS_MATCH_F16_SERIAL_SCAN 0    // A/B (with MQS_MATCH_F16_GROUP=2): a group's accumulators are scanned right behind its own MFMAs -- one accumulator set, no scan in
+#endif                                 // the next group's shadow: the wave's SIMD partner fills the matrix pipe meanwhile
 #ifndef MQS_MATCH_F4_GROUP
 #define MQS_MATCH_F4_GROUP 2
 #endif
@@ -172,6 +175,20 @@ using float16v = __attribute__((ext_vector_type(16))) float;
 #endif
 #ifndef MQS_MATCH_MIN_BLOCKS
 #define MQS_MATCH_MIN_BLOCKS 1           // A/B: workgroups per CU the register budget is cut for (2 with MQS_MATCH_NW256=4, MQS_MATCH_STAGE_ROWS=64)
+#endif
+#ifndef MQS_MATCH_TN_AHEAD
+#define MQS_MATCH_TN_AHEAD 1           // A/B: a stage's row start values (|t|^2 + bias + tile) are LOADED a stage before they are written to LDS (0: round 5's load + wait + write at the stage's start)
+#endif
+#ifndef MQS_MATCH_BUFFER_DMA
+#define MQS_MATCH_BUFFER_DMA 1         // A/B: the stage fill by buffer_load ... lds (descriptor + per-lane offsets computed once + one scalar per stage) instead of global_load_lds with per-chunk 64-bit address arithmetic
+#endif
+#if MQS_MATCH_BUFFER_DMA && defined(__HIP_DEVICE_COMPILE__)
+#define MQS_MATCH_BUFFER_DMA_DEV 1     // (the buffer builtins exist in the device pass only; a kernel body that does not compile in the host pass loses its launch stub)
+#else
+#define MQS_MATCH_BUFFER_DMA_DEV 0
+#endif
+#ifndef MQS_MATCH_SPREAD_DMA
+#define MQS_MATCH_SPREAD_DMA 1         // A/B: the next stage's fill issued piece by piece between this stage's (tile, query tile) steps instead of all at the stage's start
 #endif
 #ifndef MQS_MATCH_STAGGER
 #define MQS_MATCH_STAGGER 0            // A/B: s_sleep argument (x 64 cycles) by which the second wave of every SIMD trails the first behind each stage barrier
@@ -235,6 +252,7 @@ struct F16Path {
     // same box: at 3 vector instructions per MFMA the fp16 kernel is not bound by vector issue.)
     static constexpr bool kPrune = MQS_MATCH_PRUNE_F16 != 0;
     static constexpr int kGroup = MQS_MATCH_F16_GROUP;
+    static constexpr bool kSerialScan = MQS_MATCH_F16_SERIAL_SCAN != 0;
     static constexpr int kStageRowsMax = MQS_MATCH_STAGE_ROWS;
     // smallest key a value at distance part >= d can have (positive floats order like their bit patterns)
     static __device__ __forceinline__ unsigned key_floor(float d) { return __float_as_uint(d); }
@@ -268,6 +286,7 @@ struct F4Path : F16Path {
     static constexpr int kPerMfma = 32;
     static constexpr bool kPrune = MQS_MATCH_PRUNE_F4 != 0;
     static constexpr int kGroup = MQS_MATCH_F4_GROUP;      // query tiles per train-fragment read (see group_step)
+    static constexpr bool kSerialScan = false;
     static constexpr int kStageRowsMax = 256;              // 36 KB stages (A/B: 128 rows + 3 %, 512 rows + 5 % time)
     static __device__ __forceinline__ frag prep_query(frag v) { return v; }
     static __device__ __forceinline__ accv mfma(frag a, frag b, accv c)
@@ -350,6 +369,7 @@ __global__ __launch_bounds__(NW * 64, MQS_MATCH_MIN_BLOCKS) void knn2_mfma_kerne
     const int64_t s_end = s_end_ < nstages_all ? s_end_ : nstages_all;
     const int64_t nstages = s_end > s_begin ? s_end - s_begin : 0;
     const uint4 *tvec = reinterpret_cast<const uint4 *>(train);
+    (void)tvec;
 
     constexpr int G = (TP::kGroup > 1 && QT % TP::kGroup == 0) ? TP::kGroup : 1;     // query tiles per fragment read (group_step)
 
@@ -360,27 +380,67 @@ __global__ __launch_bounds__(NW * 64, MQS_MATCH_MIN_BLOCKS) void knn2_mfma_kerne
     // bank groups, and their addresses are row base + an immediate: no address arithmetic in the loop);
     // the padding piece of a row re-reads its first piece.  Rows past Nt re-read the last row (their start
     // value keeps them out of the result).
-    auto stage_issue = [&](int64_t s) {
-        const int buf = (int)(s & 1);
+    // Round 6: what a stage's fill costs the waves that issue it.  Round 5 issued all of a wave's pieces at the stage's start (per
+    // piece a 64-bit row address, a clamp to the last row, the LDS address through v_readfirstlane: ~11 instructions, ~100 per
+    // stage, by both waves of every SIMD at once -- the matrix pipe idles meanwhile), and the waves that also write the rows' start
+    // values loaded |t|^2 and WAITED for it there (s_waitcnt vmcnt(0): behind every piece they had just issued -- a DMA round
+    // trip per stage, and the other waves wait for them at the stage's barrier).  Now: a buffer descriptor over the train rows,
+    // the pieces' per-lane byte offsets computed once, one scalar offset per stage (rows beyond the end read as zeros: their start
+    // value keeps them out of the result); the pieces issued one by one between the stage's steps; |t|^2 loaded a stage AHEAD of
+    // its write (it has landed by the barrier in between).
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);          // (the wave index as a scalar: LDS-DMA destinations are wave-uniform)
+    constexpr int64_t kRowBytesG = (int64_t)kVecPerRow * 16;          // bytes of a row in global memory
+    (void)kRowBytesG;
+#if MQS_MATCH_BUFFER_DMA_DEV
+    // the descriptor starts at this part's first stage (a part's rows are < 4 GiB); num_records = the bytes up to the last row
+    const int64_t part_first_row = s_begin * kStageRows;
+    const int64_t part_bytes_ = (Nt - part_first_row) * kRowBytesG;
+    const unsigned part_bytes = part_bytes_ <= 0 ? 0u : (part_bytes_ > 0xFFFFFFFFll ? 0xFFFFFFFFu : (unsigned)part_bytes_);
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(reinterpret_cast<const unsigned char *>(train) + part_first_row * kRowBytesG),
+                                                        (short)0, (int)part_bytes, 0x00020000);
+    int voff[kChunksPerWave];
 #pragma unroll
-        for (int i = 0; i < kChunksPerWave; ++i) {
-            const int chunk = i * NW + wave;
-            if (chunk < kChunks) {
-                const int v = chunk * 64 + lane;
-                const int row = v / kPiecesPerRow, colp = v % kPiecesPerRow;
-                const int col = colp < kVecPerRow ? colp : 0;
-                int64_t grow = s * kStageRows + row;
-                grow = grow < Nt ? grow : Nt - 1;
-                __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void *)(tvec + grow * kVecPerRow + col),
-                    (__attribute__((address_space(3))) void *)(sTile + buf * kStageBytes + chunk * 1024), 16, 0, 0);
-            }
+    for (int i = 0; i < kChunksPerWave; ++i) {
+        const int v = (i * NW + wave) * 64 + lane;
+        const int row = v / kPiecesPerRow, colp = v % kPiecesPerRow;
+        voff[i] = (row * kVecPerRow + (colp < kVecPerRow ? colp : 0)) * 16;
+    }
+#endif
+    // piece i of this wave of stage s's fill
+    auto stage_piece = [&](int64_t s, int i) {
+        const int buf = (int)(s & 1);
+        const int chunk = i * NW + wave_u;
+        if (chunk < kChunks) {
+#if MQS_MATCH_BUFFER_DMA_DEV
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(sTile + buf * kStageBytes + chunk * 1024), 16, voff[i],
+                                                     (int)((s - s_begin) * (kStageRows * kRowBytesG)), 0, 0);
+#else
+            const int v = chunk * 64 + lane;
+            const int row = v / kPiecesPerRow, colp = v % kPiecesPerRow;
+            const int col = colp < kVecPerRow ? colp : 0;
+            int64_t grow = s * kStageRows + row;
+            grow = grow < Nt ? grow : Nt - 1;
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(tvec + grow * kVecPerRow + col),
+                (__attribute__((address_space(3))) void *)(sTile + buf * kStageBytes + chunk * 1024), 16, 0, 0);
+#endif
         }
+    };
+    // the rows' start values of stage s: kBias + |t|^2 + tile / 256 (padding rows: out of the result)
+    float tn_ahead = 0.0f;                                            // |t|^2 of this thread's row of the stage after next (tid < kStageRows)
+    auto tn_fetch = [&](int64_t s) {
+        const int64_t t = s * kStageRows + tid;
+        if (tid < kStageRows && s < s_end && t < Nt) tn_ahead = tnorm[t];
+    };
+    auto tn_write = [&](int64_t s, float tn) {
         if (tid < kStageRows) {
             const int64_t t = s * kStageRows + tid;
-            // accumulator start value of this train row: kBias + |t|^2 + tile / 256
-            sTn[buf * kStageRows + tid] = (t < Nt) ? TP::start(tnorm[t], t) : TP::pad();
+            sTn[(int)(s & 1) * kStageRows + tid] = (t < Nt) ? TP::start(tn, t) : TP::pad();
         }
+    };
+    auto stage_issue = [&](int64_t s) {                               // a whole stage at once (the first one; MQS_MATCH_SPREAD_DMA = 0)
+#pragma unroll
+        for (int i = 0; i < kChunksPerWave; ++i) stage_piece(s, i);
     };
 
     // One step = the KS MFMAs of (train tile, query tile qt) into `acc` (started from the rows' start values
@@ -553,6 +613,37 @@ __global__ __launch_bounds__(NW * 64, MQS_MATCH_MIN_BLOCKS) void knn2_mfma_kerne
         }
     };
 
+    // The same G tiles per fragment read with ONE accumulator set (TP::kSerialScan; G == QT): the group's MFMAs (G independent chains,
+    // interleaved), then the scan of its own 16 G values -- nothing of a previous step is live, so the G-fold sharing costs no second
+    // set of accumulators (the shadowed form above spilled 38 registers on the fp16 path with G = 2 and ran 1.76 against 1.30 ms).
+    // While a wave scans, its SIMD partner's MFMAs keep the matrix pipe busy.
+    auto group_step_serial = [&](const unsigned char *tile, int tt, const accv_t &start, accv_t *acc) {
+        if constexpr (G > 1) {
+        const unsigned char *arow = tile + (tt * 32 + r) * kRowBytes + 16 * h;
+        constexpr int PF = MQS_MATCH_PF < KS ? MQS_MATCH_PF : KS;
+        frag_t a[KS];
+#pragma unroll
+        for (int ks = 0; ks < PF; ++ks) a[ks] = *reinterpret_cast<const frag_t *>(arow + 32 * ks);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if (ks + PF < KS) a[ks + PF] = *reinterpret_cast<const frag_t *>(arow + 32 * (ks + PF));
+#pragma unroll
+            for (int u = 0; u < G; ++u) acc[u] = TP::mfma(a[ks], qf[u][ks], ks == 0 ? start : acc[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < G; ++u)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const unsigned key = TP::key(acc[u][e]) | (unsigned)(4 * h) | (unsigned)(8 * (e >> 2) + (e & 3));
+                unsigned m;
+                asm("v_med3_u32 %0, %1, %2, %3" : "=v"(m) : "v"(best[u]), "v"(second[u]), "v"(key));
+                second[u] = m;
+                best[u] = min(best[u], key);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
     // decode a window key: distance part, row index
     auto push = [&](int qt, unsigned key, int64_t window_base) {
         float d;
@@ -577,11 +668,17 @@ __global__ __launch_bounds__(NW * 64, MQS_MATCH_MIN_BLOCKS) void knn2_mfma_kerne
         }
     };
 
-    if (nstages > 0) stage_issue(s_begin);               // Nt == 0: nothing to read, every key stays invalid
+    if (nstages > 0) {                                   // Nt == 0: nothing to read, every key stays invalid
+        stage_issue(s_begin);
+        tn_fetch(s_begin);
+        tn_write(s_begin, tn_ahead);                     // (the one wait for a start value: the first stage's)
+        tn_fetch(s_begin + 1);                           // lands by the barrier below
+    }
     __syncthreads();                                     // (waits for the LDS-DMA: vmcnt(0) + barrier)
 
     constexpr int NG = QT / G;                           // accumulator groups; one group alone needs a second set to scan
-    constexpr int NSETS = G > 1 ? (NG < 2 ? 2 : NG) : (QT < 2 ? 2 : QT);
+    constexpr bool kSerial = TP::kSerialScan && G > 1 && NG == 1;      // one accumulator set, every step scans its own values
+    constexpr int NSETS = kSerial ? 1 : (G > 1 ? (NG < 2 ? 2 : NG) : (QT < 2 ? 2 : QT));
     constexpr int R = G > 1 ? NSETS * G : NSETS;         // accumulator ring: step j writes set j % NSETS, scans set (j - 1) % NSETS
     static_assert((kStageTiles * (G > 1 ? NG : QT)) % NSETS == 0, "the ring position must repeat every stage");
     accv_t acc[R];
@@ -594,7 +691,28 @@ __global__ __launch_bounds__(NW * 64, MQS_MATCH_MIN_BLOCKS) void knn2_mfma_kerne
 #pragma clang loop unroll(disable)
 #endif
     for (int64_t s = s_begin; s < s_end; ++s) {
-        if (s + 1 < s_end) stage_issue(s + 1);            // lands while this stage is computed
+        // the next stage: its rows' start values from the |t|^2 loaded a stage ago (complete since the last barrier: no wait), the
+        // load for the stage after it, and its fill -- at once, or piece by piece between this stage's steps
+        const bool more = s + 1 < s_end;
+#if MQS_MATCH_TN_AHEAD
+        if (more) { tn_write(s + 1, tn_ahead); tn_fetch(s + 2); }
+#else
+        if (more) { tn_fetch(s + 1); tn_write(s + 1, tn_ahead); }
+#endif
+#if !MQS_MATCH_SPREAD_DMA
+        if (more) stage_issue(s + 1);                     // lands while this stage is computed
+#endif
+        constexpr int kSteps = kStageTiles * ((TP::kGroup > 1 && QT % TP::kGroup == 0) ? QT / TP::kGroup : QT);
+        auto pieces_before_step = [&](int j) {            // step j of kSteps: the pieces [j * n / kSteps, (j + 1) * n / kSteps) of the next stage's fill
+#if MQS_MATCH_SPREAD_DMA
+            if (more) {
+#pragma unroll
+                for (int i = j * kChunksPerWave / kSteps; i < (j + 1) * kChunksPerWave / kSteps; ++i) stage_piece(s + 1, i);
+            }
+#else
+            (void)j;
+#endif
+        };
         const unsigned char *tile = sTile + (int)(s & 1) * kStageBytes;
         const start_t *tn0 = sTn + (int)(s & 1) * kStageRows + 4 * h;
         if constexpr (G > 1) {
@@ -607,12 +725,20 @@ __global__ __launch_bounds__(NW * 64, MQS_MATCH_MIN_BLOCKS) void knn2_mfma_kerne
 #pragma unroll
                     for (int k = 0; k < 4; ++k) start[4 * g4 + k] = t4[k];
                 }
-#pragma unroll
-                for (int gi = 0; gi < NG; ++gi) {
-                    const int j = tt * NG + gi;
-                    group_step(tile, tt, start, acc, (j % NSETS) * G, ((j + NSETS - 1) % NSETS) * G, gi * G, ((gi + NG - 1) % NG) * G);
-                    if (j == 0 && (s & (kWindowStages - 1)) == 0 && s > s_begin)
+                if constexpr (kSerial) {
+                    if (tt == 0 && (s & (kWindowStages - 1)) == 0 && s > s_begin)      // every value of the finished window has been scanned
                         close_window((s / kWindowStages - 1) * (int64_t)(kWindowTiles * 32));
+                    pieces_before_step(tt);
+                    group_step_serial(tile, tt, start, acc);
+                } else {
+#pragma unroll
+                    for (int gi = 0; gi < NG; ++gi) {
+                        const int j = tt * NG + gi;
+                        pieces_before_step(j);
+                        group_step(tile, tt, start, acc, (j % NSETS) * G, ((j + NSETS - 1) % NSETS) * G, gi * G, ((gi + NG - 1) % NG) * G);
+                        if (j == 0 && (s & (kWindowStages - 1)) == 0 && s > s_begin)
+                            close_window((s / kWindowStages - 1) * (int64_t)(kWindowTiles * 32));
+                    }
                 }
             }
         } else {
@@ -621,6 +747,7 @@ __global__ __launch_bounds__(NW * 64, MQS_MATCH_MIN_BLOCKS) void knn2_mfma_kerne
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) {
                 const int j = tt * QT + qt;
+                pieces_before_step(j);
                 tile_step(tile, tt, qt, acc[j % R], acc[(j + R - 1) % R], (qt + QT - 1) % QT, tn0 + 32 * tt);
                 // step 0 scanned the last (tile, query tile) of the previous stage: a window may end there
                 if (j == 0 && (s & (kWindowStages - 1)) == 0 && s > s_begin)
@@ -642,6 +769,7 @@ __global__ __launch_bounds__(NW * 64, MQS_MATCH_MIN_BLOCKS) void knn2_mfma_kerne
     if (nstages > 0) {
         // the last step's accumulators: set (steps per stage - 1) % NSETS, query tiles QT - G ..
         constexpr int jl = kStageTiles * (G > 1 ? NG : QT) - 1;
+        if constexpr (!kSerial) {
 #pragma unroll
         for (int u = 0; u < G; ++u) {
             const accv_t &last = acc[G > 1 ? (jl % NSETS) * G + u : jl % R];
@@ -653,6 +781,8 @@ __global__ __launch_bounds__(NW * 64, MQS_MATCH_MIN_BLOCKS) void knn2_mfma_kerne
                 best[qt] = min(best[qt], key);
             }
         }
+        }
+        (void)jl;
         close_window(((s_end - 1) / kWindowStages) * (int64_t)(kWindowTiles * 32));
     }
 

@@ -64,7 +64,32 @@ __device__ __forceinline__ double wave_reduce32(double (&v)[32], int lane)
     for (int i = 0; i < 16; ++i) { swap32(v[i], v[i + 16]); v[i] += v[i + 16]; }   // lane bit 5 selects i (+16)
 #pragma unroll
     for (int i = 0; i < 8; ++i) { swap16(v[i], v[i + 8]); v[i] += v[i + 8]; }      // lane bit 4 selects i (+8)
-    const bool b3 = lane & 8, b2 = lane & 4, b1 = lane & 2;
+    const bool b1 = lane & 2;
+    // Lane bits 3 and 2: the half that keeps entry i adds its partner's i, the other half its partner's i + 4 (i + 2).  The halves are
+    // whole DPP banks (four lanes each: bit 3 = banks {2, 3}, bit 2 = banks {1, 3}), so the exchange AND the choice are two DPP moves
+    // per 32-bit half with complementary bank masks -- the lanes a move does not write keep `old`, their own other entry -- and one
+    // addition of the two results: 5 instructions per entry where select + exchange + add took 7 (9 at stride 4).  The same two
+    // operands meet in every lane as before (own + partner's): the same bits.
+#if !defined(MQS_WAVE_REDUCE_SELECTS)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned alo = __double2loint(v[i]), ahi = __double2hiint(v[i]), blo = __double2loint(v[i + 4]), bhi = __double2hiint(v[i + 4]);
+        // lanes with bit 3 clear (banks 0, 1): the partner's entry i; the others keep their own entry i + 4
+        const double p = __hiloint2double(dpp_mov<0x128, 0x3>(bhi, ahi), dpp_mov<0x128, 0x3>(blo, alo));
+        // lanes with bit 3 set (banks 2, 3): the partner's entry i + 4; the others keep their own entry i
+        const double q = __hiloint2double(dpp_mov<0x128, 0xc>(ahi, bhi), dpp_mov<0x128, 0xc>(alo, blo));
+        v[i] = p + q;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const unsigned alo = __double2loint(v[i]), ahi = __double2hiint(v[i]), blo = __double2loint(v[i + 2]), bhi = __double2hiint(v[i + 2]);
+        // bit 2 clear (banks 0, 2): entry i of lane + 4 (row_shl:4); bit 2 set (banks 1, 3): entry i + 2 of lane - 4 (row_shr:4)
+        const double p = __hiloint2double(dpp_mov<0x104, 0x5>(bhi, ahi), dpp_mov<0x104, 0x5>(blo, alo));
+        const double q = __hiloint2double(dpp_mov<0x114, 0xa>(ahi, bhi), dpp_mov<0x114, 0xa>(alo, blo));
+        v[i] = p + q;
+    }
+#else
+    const bool b3 = lane & 8, b2 = lane & 4;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const double send = b3 ? v[i] : v[i + 4], keep = b3 ? v[i + 4] : v[i];
@@ -75,6 +100,7 @@ __device__ __forceinline__ double wave_reduce32(double (&v)[32], int lane)
         const double send = b2 ? v[i] : v[i + 2], keep = b2 ? v[i + 2] : v[i];
         v[i] = keep + xor_lane<4>(send);
     }
+#endif
     {
         const double send = b1 ? v[0] : v[1], keep = b1 ? v[1] : v[0];
         v[0] = keep + xor_lane<2>(send);
