@@ -11,7 +11,7 @@ ROOT=$(pwd)
 mkdir -p "$ROOT/$OUT"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/kt" -- python3 "$ROOT/bench.py" --one-stream --steps 30 --warmup 5 \
-    --no-cpu-baseline --no-shard-proxy --no-replay --no-frontend > "$ROOT/$OUT/bench_one_stream_under_rocprof.json" 2> "$ROOT/$OUT/kt.err"
+    --no-cpu-baseline --no-shard-proxy --no-replay --no-frontend --no-asymptote > "$ROOT/$OUT/bench_one_stream_under_rocprof.json" 2> "$ROOT/$OUT/kt.err"
 for c in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$ROOT/$OUT/pmc_${c}_ba" -- python3 "$ROOT/tools/bench_ba.py" > /dev/null 2> "$ROOT/$OUT/pmc_${c}_ba.err"
     rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$ROOT/$OUT/pmc_${c}_tri" -- python3 "$ROOT/tools/bench_tri.py" > /dev/null 2> "$ROOT/$OUT/pmc_${c}_tri.err"
