@@ -11,7 +11,7 @@ import run_icl_nuim as R
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 seeds = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 R.run(frames, "keyframe", 0, window=3)            # warm: code objects, allocations
-configs = [("plain", None), ("full", {})]
+configs = [("plain", None), ("every frame", {"window": None})]
 for kw in (2, 3, 4, 6):
     for sig in (0.02, 0.0):
         configs.append(("window %d, every keyframe in front, landmark prior %g" % (kw, sig), {"window": kw, "window_point_sigma": sig}))

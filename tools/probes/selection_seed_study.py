@@ -11,7 +11,7 @@ import run_slam_loop as L
 
 seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 R.run(200, "keyframe", 0, window=3)
-for name, kw in (("full", {}), ("window 2", {"window": 2}), ("window 3", {"window": 3}), ("window 4", {"window": 4}), ("window 3, history 6", {"window": 3, "history": 6}),
+for name, kw in (("every frame", {"window": None}), ("window 2", {"window": 2}), ("window 3", {"window": 3}), ("window 4", {"window": 4}), ("window 3, history 6", {"window": 3, "history": 6}),
                  ("window 4, history 8", {"window": 4, "history": 8})):
     runs = [R.run(200, "keyframe", seed, **kw) for seed in range(seeds)]
     e = [1e3 * r["ours_vs_groundtruth_rmse_m"] for r in runs]
@@ -19,12 +19,12 @@ for name, kw in (("full", {}), ("window 2", {"window": 2}), ("window 3", {"windo
                       "rmse_mm_max": round(max(e), 2), "median_frames_per_s": float(np.median([r["frames_per_s"] for r in runs])),
                       "poses_in_the_last_adjustment": [r["poses_in_the_last_adjustment"] for r in runs][:4], "fallbacks": sum(len(r["fallbacks"]) for r in runs)}), flush=True)
 for frames in (60, 90):
-    for name, kw in (("full", {}), ("window 3", {"ba_window_keyframes": 3}), ("window 4", {"ba_window_keyframes": 4}), ("window 3, history 6", {"ba_window_keyframes": 3, "ba_history_keyframes": 6})):
+    for name, kw in (("every frame", {"ba_window_keyframes": None}), ("window 3", {"ba_window_keyframes": 3}), ("window 4", {"ba_window_keyframes": 4}), ("window 3, history 6", {"ba_window_keyframes": 3, "ba_history_keyframes": 6})):
         runs = [L.run_device(frames, bundle_adjust="keyframe", reassociate=True, seed=seed, repeats=2, **kw) for seed in range(4)]
         print(json.dumps({"sequence": "rendered %d" % frames, "config": name, "rmse_mm": [round(1e3 * r["trajectory_rmse"], 2) for r in runs],
                           "median_frames_per_s": float(np.median([r["frames_per_s"] for r in runs])), "keyframes": runs[0]["keyframes"],
                           "poses_in_the_last_adjustment": runs[0]["bundle_adjust_per_keyframe"]["last"]["poses"]}), flush=True)
-for name, kw in (("default beyond 256 frames (every keyframe + the latest frames)", {}), ("window 3", {"ba_window_keyframes": 3}), ("window 3, history 6", {"ba_window_keyframes": 3, "ba_history_keyframes": 6})):
+for name, kw in (("every frame asked for: beyond 256 frames every keyframe + the latest frames", {"ba_window_keyframes": None}), ("window 3", {"ba_window_keyframes": 3}), ("window 3, history 6", {"ba_window_keyframes": 3, "ba_history_keyframes": 6})):
     r = L.run_device(400, bundle_adjust="keyframe", reassociate=True, seed=1, keep=True, **kw)
     s = r.pop("slam")
     print(json.dumps({"sequence": "rendered 400", "config": name, "accepted": r["accepted"], "keyframes": r["keyframes"], "rmse_mm": round(1e3 * r["trajectory_rmse"], 2),
