@@ -158,9 +158,6 @@ using float16v = __attribute__((ext_vector_type(16))) float;
 #ifndef MQS_MATCH_F16_GROUP
 #define MQS_MATCH_F16_GROUP 1          // A/B: query tiles per train-fragment read on the fp16 path (group_step when > 1)
 #endif
-#ifndef MQS_MATCH_F16_SERIAL_SCAN
-#define MQS_MATCH_F16_SERIAL_SCAN 0    // A/B (with MQS_MATCH_F16_GROUP=2): a group's accumulators are scanned right behind its own MFMAs -- one accumulator set, no scan in
-#endif                                 // the next group's shadow: the wave's SIMD partner fills the matrix pipe meanwhile
 #ifndef MQS_MATCH_F4_GROUP
 #define MQS_MATCH_F4_GROUP 2
 #endif
@@ -252,7 +249,6 @@ struct F16Path {
     // same box: at 3 vector instructions per MFMA the fp16 kernel is not bound by vector issue.)
     static constexpr bool kPrune = MQS_MATCH_PRUNE_F16 != 0;
     static constexpr int kGroup = MQS_MATCH_F16_GROUP;
-    static constexpr bool kSerialScan = MQS_MATCH_F16_SERIAL_SCAN != 0;
     static constexpr int kStageRowsMax = MQS_MATCH_STAGE_ROWS;
     // smallest key a value at distance part >= d can have (positive floats order like their bit patterns)
     static __device__ __forceinline__ unsigned key_floor(float d) { return __float_as_uint(d); }
@@ -286,7 +282,6 @@ struct F4Path : F16Path {
     static constexpr int kPerMfma = 32;
     static constexpr bool kPrune = MQS_MATCH_PRUNE_F4 != 0;
     static constexpr int kGroup = MQS_MATCH_F4_GROUP;      // query tiles per train-fragment read (see group_step)
-    static constexpr bool kSerialScan = false;
     static constexpr int kStageRowsMax = 256;              // 36 KB stages (A/B: 128 rows + 3 %, 512 rows + 5 % time)
     static __device__ __forceinline__ frag prep_query(frag v) { return v; }
     static __device__ __forceinline__ accv mfma(frag a, frag b, accv c)
@@ -613,37 +608,6 @@ __global__ __launch_bounds__(NW * 64, MQS_MATCH_MIN_BLOCKS) void knn2_mfma_kerne
         }
     };
 
-    // The same G tiles per fragment read with ONE accumulator set (TP::kSerialScan; G == QT): the group's MFMAs (G independent chains,
-    // interleaved), then the scan of its own 16 G values -- nothing of a previous step is live, so the G-fold sharing costs no second
-    // set of accumulators (the shadowed form above spilled 38 registers on the fp16 path with G = 2 and ran 1.76 against 1.30 ms).
-    // While a wave scans, its SIMD partner's MFMAs keep the matrix pipe busy.
-    auto group_step_serial = [&](const unsigned char *tile, int tt, const accv_t &start, accv_t *acc) {
-        if constexpr (G > 1) {
-        const unsigned char *arow = tile + (tt * 32 + r) * kRowBytes + 16 * h;
-        constexpr int PF = MQS_MATCH_PF < KS ? MQS_MATCH_PF : KS;
-        frag_t a[KS];
-#pragma unroll
-        for (int ks = 0; ks < PF; ++ks) a[ks] = *reinterpret_cast<const frag_t *>(arow + 32 * ks);
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            if (ks + PF < KS) a[ks + PF] = *reinterpret_cast<const frag_t *>(arow + 32 * (ks + PF));
-#pragma unroll
-            for (int u = 0; u < G; ++u) acc[u] = TP::mfma(a[ks], qf[u][ks], ks == 0 ? start : acc[u]);
-        }
-#pragma unroll
-        for (int u = 0; u < G; ++u)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const unsigned key = TP::key(acc[u][e]) | (unsigned)(4 * h) | (unsigned)(8 * (e >> 2) + (e & 3));
-                unsigned m;
-                asm("v_med3_u32 %0, %1, %2, %3" : "=v"(m) : "v"(best[u]), "v"(second[u]), "v"(key));
-                second[u] = m;
-                best[u] = min(best[u], key);
-            }
-        __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-
     // decode a window key: distance part, row index
     auto push = [&](int qt, unsigned key, int64_t window_base) {
         float d;
@@ -677,8 +641,7 @@ __global__ __launch_bounds__(NW * 64, MQS_MATCH_MIN_BLOCKS) void knn2_mfma_kerne
     __syncthreads();                                     // (waits for the LDS-DMA: vmcnt(0) + barrier)
 
     constexpr int NG = QT / G;                           // accumulator groups; one group alone needs a second set to scan
-    constexpr bool kSerial = TP::kSerialScan && G > 1 && NG == 1;      // one accumulator set, every step scans its own values
-    constexpr int NSETS = kSerial ? 1 : (G > 1 ? (NG < 2 ? 2 : NG) : (QT < 2 ? 2 : QT));
+    constexpr int NSETS = G > 1 ? (NG < 2 ? 2 : NG) : (QT < 2 ? 2 : QT);
     constexpr int R = G > 1 ? NSETS * G : NSETS;         // accumulator ring: step j writes set j % NSETS, scans set (j - 1) % NSETS
     static_assert((kStageTiles * (G > 1 ? NG : QT)) % NSETS == 0, "the ring position must repeat every stage");
     accv_t acc[R];
@@ -725,20 +688,13 @@ __global__ __launch_bounds__(NW * 64, MQS_MATCH_MIN_BLOCKS) void knn2_mfma_kerne
 #pragma unroll
                     for (int k = 0; k < 4; ++k) start[4 * g4 + k] = t4[k];
                 }
-                if constexpr (kSerial) {
-                    if (tt == 0 && (s & (kWindowStages - 1)) == 0 && s > s_begin)      // every value of the finished window has been scanned
-                        close_window((s / kWindowStages - 1) * (int64_t)(kWindowTiles * 32));
-                    pieces_before_step(tt);
-                    group_step_serial(tile, tt, start, acc);
-                } else {
 #pragma unroll
-                    for (int gi = 0; gi < NG; ++gi) {
-                        const int j = tt * NG + gi;
-                        pieces_before_step(j);
-                        group_step(tile, tt, start, acc, (j % NSETS) * G, ((j + NSETS - 1) % NSETS) * G, gi * G, ((gi + NG - 1) % NG) * G);
-                        if (j == 0 && (s & (kWindowStages - 1)) == 0 && s > s_begin)
-                            close_window((s / kWindowStages - 1) * (int64_t)(kWindowTiles * 32));
-                    }
+                for (int gi = 0; gi < NG; ++gi) {
+                    const int j = tt * NG + gi;
+                    pieces_before_step(j);
+                    group_step(tile, tt, start, acc, (j % NSETS) * G, ((j + NSETS - 1) % NSETS) * G, gi * G, ((gi + NG - 1) % NG) * G);
+                    if (j == 0 && (s & (kWindowStages - 1)) == 0 && s > s_begin)
+                        close_window((s / kWindowStages - 1) * (int64_t)(kWindowTiles * 32));
                 }
             }
         } else {
@@ -769,7 +725,6 @@ __global__ __launch_bounds__(NW * 64, MQS_MATCH_MIN_BLOCKS) void knn2_mfma_kerne
     if (nstages > 0) {
         // the last step's accumulators: set (steps per stage - 1) % NSETS, query tiles QT - G ..
         constexpr int jl = kStageTiles * (G > 1 ? NG : QT) - 1;
-        if constexpr (!kSerial) {
 #pragma unroll
         for (int u = 0; u < G; ++u) {
             const accv_t &last = acc[G > 1 ? (jl % NSETS) * G + u : jl % R];
@@ -781,8 +736,6 @@ __global__ __launch_bounds__(NW * 64, MQS_MATCH_MIN_BLOCKS) void knn2_mfma_kerne
                 best[qt] = min(best[qt], key);
             }
         }
-        }
-        (void)jl;
         close_window(((s_end - 1) / kWindowStages) * (int64_t)(kWindowTiles * 32));
     }
 

@@ -21,8 +21,6 @@ V[f4_reject16]="-DMQS_MATCH_F4_REJECT16=1"
 V[f4_group4]="-DMQS_MATCH_F4_GROUP=4"
 V[f4_group1]="-DMQS_MATCH_F4_GROUP=1"
 V[stage64]="-DMQS_MATCH_STAGE_ROWS=64"
-V[serial_g2]="-DMQS_MATCH_F16_GROUP=2 -DMQS_MATCH_F16_SERIAL_SCAN=1"
-V[serial_g2_pf8]="-DMQS_MATCH_F16_GROUP=2 -DMQS_MATCH_F16_SERIAL_SCAN=1 -DMQS_MATCH_PF=8"
 if [ "$1" = build ]; then
     mkdir -p build/ab6
     for v in ${ONLY:-"${!V[@]}"}; do
