@@ -8,7 +8,7 @@ PKG=multiple-quadrotor-slam_amd
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function"
 declare -A V
 V[tree]=""
-V[round5]="-DMQS_MATCH_TN_AHEAD=0 -DMQS_MATCH_BUFFER_DMA=0 -DMQS_MATCH_SPREAD_DMA=0 -DMQS_MATCH_SCHED=0 -DMQS_MATCH_PRUNE_F16=0"
+V[round5]="-DMQS_MATCH_TN_AHEAD=0 -DMQS_MATCH_BUFFER_DMA=0 -DMQS_MATCH_SPREAD_DMA=0 -DMQS_MATCH_SCHED=0 -DMQS_MATCH_PRUNE_F16=0 -DMQS_MATCH_F4_REJECT8=0"
 V[only_tn_ahead]="-DMQS_MATCH_TN_AHEAD=1 -DMQS_MATCH_BUFFER_DMA=0 -DMQS_MATCH_SPREAD_DMA=0"
 V[no_spread]="-DMQS_MATCH_SPREAD_DMA=0"
 V[no_buffer]="-DMQS_MATCH_BUFFER_DMA=0"
@@ -18,6 +18,7 @@ V[pf8]="-DMQS_MATCH_PF=8"
 V[no_sched]="-DMQS_MATCH_SCHED=0"
 V[no_prune16]="-DMQS_MATCH_PRUNE_F16=0"
 V[f4_reject16]="-DMQS_MATCH_F4_REJECT16=1"
+V[f4_reject4]="-DMQS_MATCH_F4_REJECT8=0"
 V[f4_group4]="-DMQS_MATCH_F4_GROUP=4"
 V[f4_group1]="-DMQS_MATCH_F4_GROUP=1"
 V[stage64]="-DMQS_MATCH_STAGE_ROWS=64"
