@@ -159,7 +159,11 @@ using float16v = __attribute__((ext_vector_type(16))) float;
 #define MQS_MATCH_F4_REJECT8 1         // early reject per eight values in the grouped step (FP4 path; round 6: 0.4326 -> 0.428 ms; per four: 0)
 #endif
 #ifndef MQS_MATCH_F16_GROUP
-#define MQS_MATCH_F16_GROUP 1          // A/B: query tiles per train-fragment read on the fp16 path (group_step when > 1)
+#define MQS_MATCH_F16_GROUP 2          // query tiles per train-fragment read on the fp16 path (group_step when > 1).  Round 6: 2 -- a fragment feeds the two query tiles' MFMAs, two
+#endif                                 // INDEPENDENT chains per wave (one dependent chain on a lone wave issues an MFMA every 52-56 cycles, tools/probes/mfma_peak.hip) and half
+                                       // the LDS reads -- with the early reject on and the fragment prefetch at 2 the four accumulator sets fit (rounds 3-5: 38 spilled registers, 1.76 ms)
+#ifndef MQS_MATCH_F16_PF
+#define MQS_MATCH_F16_PF 2             // fragment reads in flight ahead of their MFMA in the grouped step of the fp16 path (4: 64 bytes of scratch, 1.32 ms; 2: none, 1.095)
 #endif
 #ifndef MQS_MATCH_F4_GROUP
 #define MQS_MATCH_F4_GROUP 2
@@ -252,6 +256,7 @@ struct F16Path {
     // same box: at 3 vector instructions per MFMA the fp16 kernel is not bound by vector issue.)
     static constexpr bool kPrune = MQS_MATCH_PRUNE_F16 != 0;
     static constexpr int kGroup = MQS_MATCH_F16_GROUP;
+    static constexpr int kGroupPF = MQS_MATCH_F16_PF;      // fragment prefetch depth of the grouped step
     static constexpr int kStageRowsMax = MQS_MATCH_STAGE_ROWS;
     // smallest key a value at distance part >= d can have (positive floats order like their bit patterns)
     static __device__ __forceinline__ unsigned key_floor(float d) { return __float_as_uint(d); }
@@ -285,6 +290,7 @@ struct F4Path : F16Path {
     static constexpr int kPerMfma = 32;
     static constexpr bool kPrune = MQS_MATCH_PRUNE_F4 != 0;
     static constexpr int kGroup = MQS_MATCH_F4_GROUP;      // query tiles per train-fragment read (see group_step)
+    static constexpr int kGroupPF = MQS_MATCH_PF;
     static constexpr int kStageRowsMax = 256;              // 36 KB stages (A/B: 128 rows + 3 %, 512 rows + 5 % time)
     static __device__ __forceinline__ frag prep_query(frag v) { return v; }
     static __device__ __forceinline__ accv mfma(frag a, frag b, accv c)
@@ -522,7 +528,7 @@ __global__ __launch_bounds__(NW * 64, MQS_MATCH_MIN_BLOCKS) void knn2_mfma_kerne
     auto group_step = [&](const unsigned char *tile, int tt, const accv_t &start, accv_t *acc, int cur0, int prev0, int curq0, int prevq0) {
         if constexpr (G > 1) {
         const unsigned char *arow = tile + (tt * 32 + r) * kRowBytes + 16 * h;
-        constexpr int PF = MQS_MATCH_PF < KS ? MQS_MATCH_PF : KS;
+        constexpr int PF = TP::kGroupPF < KS ? TP::kGroupPF : KS;
         frag_t a[KS];
 #pragma unroll
         for (int ks = 0; ks < PF; ++ks) a[ks] = *reinterpret_cast<const frag_t *>(arow + 32 * ks);
@@ -533,7 +539,7 @@ __global__ __launch_bounds__(NW * 64, MQS_MATCH_MIN_BLOCKS) void knn2_mfma_kerne
             for (int u = 0; u < G; ++u) acc[cur0 + u] = TP::mfma(a[ks], qf[curq0 + u][ks], ks == 0 ? start : acc[cur0 + u]);
             // the previous group's 16 G values, 16 G / KS behind each k-step
             constexpr int kPer = 16 * G / KS;
-            static_assert(16 * G % KS == 0 && (!TP::kPrune || kPer % 4 == 0), "scan shares");
+            static_assert(16 * G % KS == 0 && (!TP::kPrune || kPer % 4 == 0 || 4 % kPer == 0), "scan shares");
             if constexpr (TP::kPrune && MQS_MATCH_F4_REJECT16 && KS % G == 0) {
                 // one early-reject test per ACCUMULATOR of the previous group (16 values: a tree of five v_min3, two v_min3, one
                 // v_min -- 8 instructions + the compare, where four tests of four values cost 16), behind the k-step at which its
@@ -591,6 +597,28 @@ __global__ __launch_bounds__(NW * 64, MQS_MATCH_MIN_BLOCKS) void knn2_mfma_kerne
                     if (__builtin_amdgcn_ballot_w64(m8 < thr[pq]) != 0) {
 #pragma unroll
                         for (int e = e0; e < e0 + 8; ++e) {
+                            const unsigned key = TP::key(prev[e]) | (unsigned)(4 * h) | (unsigned)(8 * (e >> 2) + (e & 3));
+                            unsigned m;
+                            asm("v_med3_u32 %0, %1, %2, %3" : "=v"(m) : "v"(best[pq]), "v"(second[pq]), "v"(key));
+                            second[pq] = m;
+                            best[pq] = min(best[pq], key);
+                        }
+                        thr[pq] = min(second[pq], TP::key_floor(gd1[pq]));
+                    }
+                }
+            } else if constexpr (TP::kPrune && kPer < 4) {
+                // fewer than four values per k-step (the fp16 path with G = 2: two): one test of four every 4 / kPer steps
+                constexpr int kEvery = 4 / kPer;
+                if (ks % kEvery == kEvery - 1) {
+                    const int v0 = (ks - (kEvery - 1)) * kPer, which = v0 >> 4, e0 = v0 & 15, pq = prevq0 + which;
+                    const accv_t &prev = acc[prev0 + which];
+                    const unsigned k0 = TP::key(prev[e0]), k1 = TP::key(prev[e0 + 1]), k2 = TP::key(prev[e0 + 2]), k3 = TP::key(prev[e0 + 3]);
+                    unsigned m3;
+                    asm("v_min3_u32 %0, %1, %2, %3" : "=v"(m3) : "v"(k0), "v"(k1), "v"(k2));
+                    const unsigned m4 = min(m3, k3);
+                    if (__builtin_amdgcn_ballot_w64(m4 < thr[pq]) != 0) {
+#pragma unroll
+                        for (int e = e0; e < e0 + 4; ++e) {
                             const unsigned key = TP::key(prev[e]) | (unsigned)(4 * h) | (unsigned)(8 * (e >> 2) + (e & 3));
                             unsigned m;
                             asm("v_med3_u32 %0, %1, %2, %3" : "=v"(m) : "v"(best[pq]), "v"(second[pq]), "v"(key));
