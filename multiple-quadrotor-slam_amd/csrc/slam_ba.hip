@@ -23,6 +23,12 @@
 //             F  every workgroup adds the cost pieces in the same order and takes the same accept / reject decision
 //   screens   worst residual / smallest depth per landmark, the median depth by rank counting, all inside the launch
 //
+// Round 6: the poses of the problem are a SELECTION of the accepted frames (mqs_slam_bundle_adjust_window: typically every keyframe so
+// far + every frame since the third keyframe from the end), read once per workgroup from the pinned report block into LDS; a log entry's
+// frame maps to its problem pose by binary search there; frames left out keep their pose relative to the selected pose in front of them.
+// The reference's committed runs are 376 and 881 poses long (Work/SLAM/datasets/ICL_NUIM/*/traj_out.cam0-slam2.txt): the 256 cameras the LDS
+// holds bound ONE problem now, not the run.  And the residual screen also looks behind every `screen_iters` iterations (legs).
+//
 // Inter-workgroup visibility: every byte one workgroup writes and another reads inside the launch is stored write-through and
 // loaded past the vector L1 (relaxed agent-scope atomics: global_store / global_load ... sc1), every storing wave drains its
 // stores (s_waitcnt vmcnt(0)) in front of the workgroup barrier behind which one lane adds to the barrier counter, and the
