@@ -777,6 +777,20 @@ int mqs_debug_slam_ba_stamps(mqs_slam *s, int64_t *out, int cap, int32_t *n);
 int mqs_slam_ingest_enable(mqs_slam *s, int slots);
 int mqs_slam_upload(mqs_slam *s, int slot, const uint8_t *host_img, int pinned);
 int mqs_slam_wait_upload(mqs_slam *s, int slot, const uint8_t **image_dev);
+/*   mqs_slam_prepare_next   the tracker's pyramid of the NEXT image pair (levels, derivatives, border-extended copies of both images),
+ *                         enqueued on a stream of its own so that it runs under the CURRENT frame's pose kernels (RANSAC hypotheses,
+ *                         selection, decision: ~90 us of one to 256 small workgroups).  Call it before the mqs_slam_track of the
+ *                         current frame; the mqs_slam_track of the next frame recognises the pair by its two image pointers, waits (on
+ *                         the device) for that launch and runs the tracker alone.  If the pair does not come (the current frame is
+ *                         rejected: its predecessor stays the previous image) the pyramid is built inside the call as always.
+ *                         prev_slot / next_slot >= 0: ring slots of the frame ingest, whose uploads the side stream waits for
+ *                         (next_img_dev may be NULL then); -1: the caller vouches that the image is complete on the device.
+ *                         Results are the same bit for bit. */
+int mqs_slam_prepare_next(mqs_slam *s, const uint8_t *prev_img_dev, int prev_slot, const uint8_t *next_img_dev, int next_slot);
+/*   mqs_slam_set_next     the same, folded into the loop's call: names the frame BEHIND the one the next mqs_slam_track handles (this_slot /
+ *                         next_slot: ring slots or -1, as above); that mqs_slam_track then enqueues the pair's pyramid on the side stream
+ *                         behind its own launches and before it waits for its result -- the host's work for it is off the frame's path too. */
+int mqs_slam_set_next(mqs_slam *s, int this_slot, const uint8_t *next_img_dev, int next_slot);
 int mqs_slam_log_enable(mqs_slam *s, int64_t capacity);
 int mqs_slam_read_log(mqs_slam *s, int32_t *lm, int32_t *pose, double *uv, int64_t cap, int64_t *n);
 int mqs_slam_write_back(mqs_slam *s, const double *map, int n, const double *pose_prev, const double *pose_key);

@@ -1198,16 +1198,21 @@ int mqs_calc_optical_flow_pyr_lk_dev(const uint8_t *prev_img, const uint8_t *nex
                                      int64_t workspace_bytes, void *stream_)
 {
     return mqs_lk_launch(prev_img, next_img, W, H, prev_pts, n, nullptr, win_w, win_h, max_level, max_iter, eps, min_eig_threshold,
-                         next_pts, status, err, workspace, workspace_bytes, static_cast<hipStream_t>(stream_));
+                         next_pts, status, err, workspace, workspace_bytes, static_cast<hipStream_t>(stream_), 3);
 }
 
 }  // extern "C"
 
 // n = capacity of the point arrays (one wavefront each is launched); n_dev (device, may be null): the live count
+// phases: bit 0 -- the pyramid of the image pair (levels, derivatives, border-extended copies) into the workspace; bit 1 -- the tracker on
+// the pyramid the workspace holds.  3 = both (one call); the device loop builds the NEXT pair's pyramid on a side stream under the current
+// frame's pose kernels (mqs_slam_prepare_next) and then runs the tracker alone.
 int mqs_lk_launch(const uint8_t *prev_img, const uint8_t *next_img, int W, int H, const float *prev_pts, int n, const int32_t *n_dev,
                   int win_w, int win_h, int max_level, int max_iter, double eps, double min_eig_threshold, float *next_pts,
-                  uint8_t *status, float *err, void *workspace, int64_t workspace_bytes, hipStream_t stream)
+                  uint8_t *status, float *err, void *workspace, int64_t workspace_bytes, hipStream_t stream, int phases)
 {
+    MQS_ARG_CHECK(phases >= 1 && phases <= 3, "phases: 1 pyramid, 2 tracker, 3 both");
+    if (!(phases & 2)) n = 0;
     MQS_ARG_CHECK(prev_img && next_img && workspace, "pointers must not be null");
     MQS_ARG_CHECK(n >= 0 && (n == 0 || (prev_pts && next_pts && status && err)), "point arrays must not be null");
     MQS_ARG_CHECK(W >= 3 && H >= 3 && max_level >= 0 && max_level < kMaxLevels, "W, H >= 3; 0 <= max_level < 8");
@@ -1248,7 +1253,9 @@ int mqs_lk_launch(const uint8_t *prev_img, const uint8_t *next_img, int W, int H
     // MQS_LK_PYRAMID_PER_LEVEL=1 keeps the per-level launches (A/B, tests)
     const char *per_level = getenv("MQS_LK_PYRAMID_PER_LEVEL");
     const bool fused = L.levels >= 1 && L.levels <= 3 && L.W[L.levels] > kLkBorder && L.H[L.levels] > kLkBorder && !(per_level && per_level[0] == '1');
-    if (fused) {
+    if (!(phases & 1)) {
+        // the pyramid is in the workspace already
+    } else if (fused) {
         const dim3 g((unsigned)((L.W[L.levels] + kPyrTopTile - 1) / kPyrTopTile), (unsigned)((L.H[L.levels] + kPyrTopTile - 1) / kPyrTopTile), 2);
         if (L.levels == 1) hipLaunchKernelGGL(lk_pyramid_kernel<1>, g, dim3(kPyrThreads), 0, stream, job);
         else if (L.levels == 2) hipLaunchKernelGGL(lk_pyramid_kernel<2>, g, dim3(kPyrThreads), 0, stream, job);

@@ -103,7 +103,7 @@ int mqs_ba_tail_launch(const double *lin, const mqs_peer_recv *peer, const mqs_b
 // (grids and workspaces are sized for them); n_dev (device memory, may be null) holds the live count the kernels use.
 int mqs_lk_launch(const uint8_t *prev_img, const uint8_t *next_img, int W, int H, const float *prev_pts, int n, const int32_t *n_dev,
                   int win_w, int win_h, int max_level, int max_iter, double eps, double min_eig_threshold, float *next_pts,
-                  uint8_t *status, float *err, void *workspace, int64_t workspace_bytes, hipStream_t stream);
+                  uint8_t *status, float *err, void *workspace, int64_t workspace_bytes, hipStream_t stream, int phases);   // phases: 1 pyramid, 2 tracker, 3 both
 int mqs_pnp_ransac_launch(const double *objp, const double *imgp, int N, const int32_t *n_dev, const double *intr,
                           const int32_t *samples, int B, int sample_size, double reproj_error, int sample_iters, int max_iter,
                           double eps, double *pose_out, int32_t *sel_out, uint8_t *mask, double *info, void *workspace,

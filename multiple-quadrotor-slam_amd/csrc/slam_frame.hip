@@ -1065,6 +1065,8 @@ int mqs_slam_create(int device, int W, int H, const double *intr, int target_key
     s->device = device;
     s->started = false;
     s->accepted = 0; s->base_pose = 0; s->log_arena = nullptr; s->re_arena = nullptr; s->ba = nullptr; s->land_ub = 0; s->key_pose = 0; s->ingest = nullptr;
+    s->ws_lk2 = nullptr; s->pyr_stream = nullptr; s->ahead.set = false;
+    for (int k = 0; k < 2; ++k) { s->prep[k].valid = false; s->prep[k].prev = nullptr; s->prep[k].next = nullptr; s->prep[k].has_event = false; }
     s->p = SlamParams{W, H, target_keypoints, max_landmarks, coverage_radius, quality_level,
                       12.0, 0.5, 2.0, 0.33, 1.04, 0.0, (unsigned long long)seed, 1, 0, 0};  // slam2.py:1070-1098; keyframe test on ALL tracks
     if (const char *e = getenv("MQS_SLAM_HOMOGRAPHY_REFINE")) s->p.homography_refine = e[0] != '0';        // A/B: 0 = the DLT alone
@@ -1123,6 +1125,13 @@ void mqs_slam_destroy(mqs_slam *s)
 {
     if (!s) return;
     (void)hipSetDevice(s->device);
+    if (s->pyr_stream) {
+        (void)hipStreamSynchronize(s->pyr_stream);
+        for (int k = 0; k < 2; ++k)
+            if (s->prep[k].has_event) (void)hipEventDestroy(s->prep[k].done);
+        (void)hipStreamDestroy(s->pyr_stream);
+    }
+    if (s->ws_lk2) (void)hipFree(s->ws_lk2);
     mqs_slam_ingest_release(s);
     (void)hipStreamSynchronize(s->stream);
     (void)hipFree(s->arena);
@@ -1277,6 +1286,8 @@ int mqs_slam_start(mqs_slam *s, const uint8_t *img_dev, const float *objp0, cons
 // pose [12] (3x4 world -> camera; of a keyframe: before its refinement); from [24]: what the PREVIOUS call's keyframe branch
 // left -- valid flag, landmarks added, tracks after the top-up, landmarks, refined pose [12] -- because that branch runs
 // behind the call that started it.  mqs_slam_flush returns the same block once the stream has drained.
+static int prepare_next_into(mqs_slam *s, const uint8_t *prev_img_dev, int prev_slot, const uint8_t *next_img_dev, int next_slot, int ws_target);
+
 int mqs_slam_track(mqs_slam *s, const uint8_t *prev_img_dev, const uint8_t *img_dev, double *result)
 {
     MQS_ARG_CHECK(s != nullptr && prev_img_dev && img_dev && result, "pointers must not be null");
@@ -1285,8 +1296,17 @@ int mqs_slam_track(mqs_slam *s, const uint8_t *prev_img_dev, const uint8_t *img_
     SlamDev &d = s->d;
     s->p.pose_index = s->accepted;
     s->p.base_pose_index = s->base_pose;
+    // the pair's pyramid: prepared ahead on the side stream (mqs_slam_prepare_next) -- then the loop's stream waits for that launch and runs
+    // the tracker alone -- or built here.  A workspace that holds a pyramid prepared for the FOLLOWING pair is left alone.
+    int ws = -1, phases = 3;
+    for (int k = 0; k < 2; ++k)
+        if (s->prep[k].valid && s->prep[k].prev == prev_img_dev && s->prep[k].next == img_dev) { ws = k; phases = 2; }
+    if (ws < 0) ws = (s->prep[0].valid && s->prep[0].prev == img_dev) ? 1 : 0;
+    if (ws == 1 && !s->ws_lk2) ws = 0;
+    if (s->prep[ws].has_event && (s->prep[ws].valid || phases == 2)) MQS_HIP_CHECK(hipStreamWaitEvent(s->stream, s->prep[ws].done, 0));
+    s->prep[ws].valid = false;
     int rc = mqs_lk_launch(prev_img_dev, img_dev, s->p.W, s->p.H, d.pts, kMaxTracks, d.cnt + C_N, 21, 21, 3, 30, 0.01, 1e-4, d.lk_pts,
-                           d.lk_st, d.lk_err, s->ws_lk, s->ws_lk_bytes, s->stream);
+                           d.lk_st, d.lk_err, ws == 0 ? s->ws_lk : s->ws_lk2, s->ws_lk_bytes, s->stream, phases);
     if (rc != MQS_OK) return rc;
     if (s->fused_filter) {
         hipLaunchKernelGGL(frame_hypothesis_kernel, dim3(kHyp), dim3(64), 0, s->stream, d, s->p);
@@ -1298,6 +1318,13 @@ int mqs_slam_track(mqs_slam *s, const uint8_t *prev_img_dev, const uint8_t *img_
     }
     hipLaunchKernelGGL(frame_decide_kernel, dim3(1), dim3(256), (size_t)kMaxTracks * 40, s->stream, d, s->p);
     MQS_HIP_CHECK(hipGetLastError());
+    // the NEXT pair's pyramid (mqs_slam_set_next): enqueued on the side stream now, behind this frame's launches -- the host's work for it
+    // runs while the device is busy with them, the kernel runs under the pose kernels
+    if (s->ahead.set) {
+        s->ahead.set = false;
+        rc = prepare_next_into(s, img_dev, s->ahead.prev_slot, s->ahead.next, s->ahead.next_slot, 1 - ws);      // (not the workspace this frame's tracker is reading)
+        if (rc != MQS_OK) return rc;
+    }
     // (the decision kernel has written the result block into s->res_host and cleared the previous keyframe's flag on the device)
     MQS_HIP_CHECK(hipStreamSynchronize(s->stream));
     memcpy(result, s->res_host, kRes * 8);
@@ -1318,6 +1345,61 @@ int mqs_slam_track(mqs_slam *s, const uint8_t *prev_img_dev, const uint8_t *img_
         rc = topup(s, img_dev);
         if (rc != MQS_OK) return rc;
     }
+    return MQS_OK;
+}
+
+// The pyramid of the NEXT image pair, ahead of its frame: enqueued on a stream of its own, it runs under the current frame's pose kernels
+// (RANSAC hypotheses, selection, decision: one to 256 small workgroups for ~90 us, most of the chip idle).  Call it BEFORE the
+// mqs_slam_track of the current frame (which blocks for that frame's result); the mqs_slam_track of the next frame finds the pyramid by
+// the two image pointers and runs the tracker alone.  A frame that is rejected in between (its predecessor stays the previous image) simply
+// does not match: the pyramid is built in the call as before.  prev_slot / next_slot >= 0: ring slots of the frame ingest -- the side stream
+// waits for their uploads (next_img_dev may then be NULL); -1: the caller vouches for the image.  Same results either way, bit for bit.
+int mqs_slam_prepare_next(mqs_slam *s, const uint8_t *prev_img_dev, int prev_slot, const uint8_t *next_img_dev, int next_slot)
+{
+    return prepare_next_into(s, prev_img_dev, prev_slot, next_img_dev, next_slot, -1);
+}
+
+// ws_target: the workspace to build into, or -1: the one that is not reserved for the frame about to be tracked
+static int prepare_next_into(mqs_slam *s, const uint8_t *prev_img_dev, int prev_slot, const uint8_t *next_img_dev, int next_slot, int ws_target)
+{
+    MQS_ARG_CHECK(s != nullptr && s->started && prev_img_dev != nullptr, "handle (started), previous image");
+    MQS_ARG_CHECK(next_img_dev != nullptr || next_slot >= 0, "the next image: a device pointer or a ring slot");
+    MQS_HIP_CHECK(hipSetDevice(s->device));
+    if (!s->pyr_stream) {
+        MQS_HIP_CHECK(hipStreamCreateWithFlags(&s->pyr_stream, hipStreamNonBlocking));
+        hipError_t e = hipMalloc(&s->ws_lk2, (size_t)s->ws_lk_bytes);
+        if (e != hipSuccess) { s->ws_lk2 = nullptr; mqs_set_error("hipMalloc(%lld) failed: %s", (long long)s->ws_lk_bytes, hipGetErrorString(e)); return MQS_E_NOMEM; }
+        for (int k = 0; k < 2; ++k) {
+            MQS_HIP_CHECK(hipEventCreateWithFlags(&s->prep[k].done, hipEventDisableTiming));
+            s->prep[k].has_event = true;
+        }
+    }
+    hipEvent_t up;
+    if (prev_slot >= 0) {
+        const uint8_t *p = nullptr;
+        MQS_ARG_CHECK(mqs_slam_ingest_slot(s, prev_slot, &p, &up) && p == prev_img_dev, "prev_slot does not hold the previous image");
+        MQS_HIP_CHECK(hipStreamWaitEvent(s->pyr_stream, up, 0));
+    }
+    if (next_slot >= 0) {
+        MQS_ARG_CHECK(mqs_slam_ingest_slot(s, next_slot, &next_img_dev, &up), "nothing was uploaded into next_slot");
+        MQS_HIP_CHECK(hipStreamWaitEvent(s->pyr_stream, up, 0));
+    }
+    // the workspace that is NOT reserved for the frame about to be tracked (whose image is this pair's previous one); what the loop's
+    // stream last read from it has completed: every mqs_slam_track waits for its frame's result
+    const int ws = ws_target >= 0 ? ws_target : ((s->prep[0].valid && s->prep[0].next == prev_img_dev) ? 1 : 0);
+    int rc = mqs_lk_launch(prev_img_dev, next_img_dev, s->p.W, s->p.H, nullptr, 0, nullptr, 21, 21, 3, 30, 0.01, 1e-4, nullptr, nullptr, nullptr,
+                           ws == 0 ? s->ws_lk : s->ws_lk2, s->ws_lk_bytes, s->pyr_stream, 1);
+    if (rc != MQS_OK) return rc;
+    MQS_HIP_CHECK(hipEventRecord(s->prep[ws].done, s->pyr_stream));
+    s->prep[ws].valid = true; s->prep[ws].prev = prev_img_dev; s->prep[ws].next = next_img_dev;
+    return MQS_OK;
+}
+
+// The frame behind the one the next mqs_slam_track handles: that call then prepares the pair (its image, this one) behind its own launches.
+int mqs_slam_set_next(mqs_slam *s, int this_slot, const uint8_t *next_img_dev, int next_slot)
+{
+    MQS_ARG_CHECK(s != nullptr && (next_img_dev != nullptr || next_slot >= 0), "handle; the next image: a device pointer or a ring slot");
+    s->ahead.set = true; s->ahead.next = next_img_dev; s->ahead.prev_slot = this_slot; s->ahead.next_slot = next_slot;
     return MQS_OK;
 }
 

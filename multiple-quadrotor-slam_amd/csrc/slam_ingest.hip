@@ -86,6 +86,21 @@ void mqs_slam_ingest_release(mqs_slam *s)
     s->ingest = nullptr;
 }
 
+bool mqs_slam_ingest_slot(mqs_slam *s, int slot, const uint8_t **image_dev, hipEvent_t *uploaded)
+{
+    mqs_slam_ingest *g = s ? s->ingest : nullptr;
+    if (!g || slot < 0 || slot >= g->slots) return false;
+    {
+        std::unique_lock<std::mutex> lk(g->m);
+        if (g->posted[slot] == 0) return false;
+        g->cv_done.wait(lk, [g, slot] { return g->done[slot] == g->posted[slot]; });
+        if (g->error != hipSuccess) return false;
+    }
+    *image_dev = g->dev + (size_t)slot * g->bytes;
+    *uploaded = g->ev[slot];
+    return true;
+}
+
 extern "C" {
 
 int mqs_slam_ingest_enable(mqs_slam *s, int slots)
@@ -126,6 +141,17 @@ int mqs_slam_upload(mqs_slam *s, int slot, const uint8_t *host_img, int pinned)
     MQS_ARG_CHECK(s != nullptr && s->ingest != nullptr, "mqs_slam_ingest_enable first");
     mqs_slam_ingest *g = s->ingest;
     MQS_ARG_CHECK(slot >= 0 && slot < g->slots && host_img != nullptr, "0 <= slot < slots; image must not be null");
+    // a pyramid launch that read the slot's last image on the side stream (mqs_slam_prepare_next) has to be over before the slot is written again
+    // (it is: the frame it was prepared for has been tracked or rejected since -- this makes it certain)
+    {
+        const uint8_t *img = g->dev + (size_t)slot * g->bytes;
+        for (int k = 0; k < 2; ++k)
+            if (s->prep[k].has_event && (s->prep[k].prev == img || s->prep[k].next == img)) {
+                MQS_HIP_CHECK(hipEventSynchronize(s->prep[k].done));
+                if (s->prep[k].valid) s->prep[k].valid = false;      // (prepared for a pair that never came)
+                s->prep[k].prev = nullptr; s->prep[k].next = nullptr;
+            }
+    }
     {
         std::lock_guard<std::mutex> lk(g->m);
         g->posted[slot] += 1;

@@ -95,7 +95,15 @@ struct mqs_slam {
     int land_ub;                     // upper bound of the landmarks in the map once the stream has drained (known without waiting)
     int key_pose;                    // pose index of the base keyframe of the live tracks
     mqs_slam_ingest *ingest;         // null until mqs_slam_ingest_enable
+    // the NEXT image pair's pyramid, built ahead on a stream of its own under the current frame's pose kernels (mqs_slam_prepare_next):
+    // two tracker workspaces, each with the pair whose pyramid it holds (or is being given) and the event behind that launch
+    void *ws_lk2;                    // the second tracker workspace (allocated on first use)
+    hipStream_t pyr_stream;
+    struct { bool valid; const uint8_t *prev, *next; hipEvent_t done; bool has_event; } prep[2];
+    struct { bool set; const uint8_t *next; int prev_slot, next_slot; } ahead;      // mqs_slam_set_next: what the next mqs_slam_track prepares behind its own launches
 };
+// slam_ingest.hip: a ring slot's device image and upload event, once the worker has enqueued the copy (false: nothing was uploaded into it)
+bool mqs_slam_ingest_slot(mqs_slam *s, int slot, const uint8_t **image_dev, hipEvent_t *uploaded);
 void mqs_slam_ba_release(mqs_slam *s);          // slam_ba.hip
 void mqs_slam_ingest_release(mqs_slam *s);      // slam_ingest.hip
 int mqs_slam_ba_anchor(mqs_slam *s, int n0);     // slam_ba.hip: at the end of mqs_slam_start, with the log on

@@ -72,10 +72,11 @@ def _reprojection_residuals(poses_c2w, points, calib, lm, pose_idx, uv):
 class _Slot:
     """An image in the handle's ingest ring (`FrameUploader`): what `DeviceMonoSlam.start` / `handle_new_frame` take instead of a
     device tensor."""
-    __slots__ = ("index", "source", "ptr")
+    __slots__ = ("index", "source", "ptr", "next")
 
     def __init__(self, index, source):
         self.index, self.source, self.ptr = index, source, None      # source: the host array, kept alive until the frame is done
+        self.next = None                                             # the slot of the frame behind this one, once posted (FrameUploader)
 
 
 class FrameUploader:
@@ -120,12 +121,18 @@ class FrameUploader:
 
     def __iter__(self):
         from collections import deque
-        q, k = deque(), 0
+        q, k, last = deque(), 0, None
         while k < self._n or q:
             while k < self._n and len(q) <= self._ahead:
-                q.append(self._post(k))
+                slot = self._post(k)
+                if q:
+                    q[-1].next = slot
+                elif last is not None:
+                    last.next = slot
+                q.append(slot)
                 k += 1
-            yield q.popleft()
+            last = q.popleft()
+            yield last
 
 
 class DeviceMonoSlam:
@@ -219,6 +226,7 @@ class DeviceMonoSlam:
         self._pending_keyframe = None    # frame index whose refined pose arrives with the next result block
         self._prev = None
         self._ingest_free = None         # free slots of the ingest ring (FrameUploader), None: no ring
+        self.prepare_next = True         # the next pair's pyramid ahead of its frame, where the next image is known (handle_new_frame)
         self._max_landmarks = int(max_landmarks)
         self.ba_info = ba_info
         if bundle_adjust not in (None, "keyframe"):
@@ -354,13 +362,25 @@ class DeviceMonoSlam:
             self.poses_online[self._pending_online] = r[28:40].reshape(3, 4).copy()
             self._pending_online = None
 
-    def handle_new_frame(self, img):
+    def handle_new_frame(self, img, next_img=None):
         """Returns 0 (rejected), 1 (frame) or 2 (keyframe), like the reference's `ret`.
-        img: a contiguous uint8 device tensor, or a slot of the ingest ring (`FrameUploader`)."""
+        img: a contiguous uint8 device tensor, or a slot of the ingest ring (`FrameUploader`).
+        next_img (device tensors; ring slots know their successor): the frame behind this one, if it is on the device already -- the
+        tracker's pyramid of the pair (img, next_img) is then built on a side stream under this frame's pose kernels
+        (`mqs_slam_prepare_next`; `prepare_next = False` switches it off: same results, bit for bit)."""
         t0 = time.perf_counter()
         if self.ba_info is not None:
             self.ba_info.next_step()                         # slam2.py:1204: one step per frame, rejected ones included
-        rc = self._track(self._h, self._img_ptr(self._prev, self.shape, sync=False), self._img_ptr(img, self.shape), self._pres)
+        p_prev, p_img = self._img_ptr(self._prev, self.shape, sync=False), self._img_ptr(img, self.shape)
+        if self.prepare_next:
+            # the pyramid of the NEXT pair on the library's side stream, under this frame's pose kernels: named here, enqueued by the track call
+            # behind its own launches (mqs_slam_set_next / mqs_slam_prepare_next)
+            nxt = next_img if next_img is not None else getattr(img, "next", None)
+            if isinstance(nxt, _Slot) and isinstance(img, _Slot):
+                _lib.check(_lib.lib().mqs_slam_set_next(self._h, img.index, None, nxt.index))
+            elif nxt is not None and not isinstance(nxt, _Slot) and not isinstance(img, _Slot):
+                _lib.check(_lib.lib().mqs_slam_set_next(self._h, -1, self._img_ptr(nxt, self.shape), -1))
+        rc = self._track(self._h, p_prev, p_img, self._pres)
         if rc != 0:
             _lib.check(rc)
         r = self._res

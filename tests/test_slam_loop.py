@@ -919,3 +919,39 @@ def test_frame_ingest_on_a_side_stream_gives_the_same_run(gpu, source):
     with pytest.raises(ValueError):
         gpu.slam_device.FrameUploader(slam, torch.zeros((2, seq.H, seq.W), dtype=torch.uint8))      # a torch source has to be pinned
     slam.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("frames_from", ["device tensors", "ingest ring"])
+def test_next_pairs_pyramid_ahead_of_its_frame_gives_the_same_run(gpu, frames_from):
+    """`mqs_slam_prepare_next`: the tracker's pyramid of the NEXT image pair is built on a side stream under the current frame's pose
+    kernels; the next `mqs_slam_track` finds it by the two image pointers and runs the tracker alone.  Same decisions, poses and tracks,
+    bit for bit, as with the pyramid built inside every call -- including a frame the tracker loses (its pair was prepared and never
+    comes: the following frame is tracked from the lost frame's predecessor, pyramid built in the call) and the keyframes' top-ups."""
+    import torch
+    seq, objp, imgp, imgs = _rendered(gpu, 34)
+    imgs = list(imgs)
+    imgs[17] = torch.zeros_like(imgs[17])
+    host = [im.cpu().numpy() for im in imgs]
+
+    def run(ahead):
+        slam = gpu.slam_device.DeviceMonoSlam(seq.K, seq.dist, (seq.H, seq.W), seed=2, bundle_adjust="keyframe")
+        slam.prepare_next = ahead
+        rets = []
+        if frames_from == "device tensors":
+            slam.start(imgs[0], objp, imgp)
+            rets = [2] + [slam.handle_new_frame(imgs[k], imgs[k + 1] if k + 1 < len(imgs) else None) for k in range(1, len(imgs))]
+        else:
+            for k, img in enumerate(gpu.slam_device.FrameUploader(slam, host, ahead=2)):
+                rets.append((slam.start(img, objp, imgp) is not None and 2) if k == 0 else slam.handle_new_frame(img))
+        slam.finish()
+        out = (rets, [None if P is None else np.array(P) for P in slam.poses], [np.array(a) for a in slam.tracks()], slam.objp.copy())
+        slam.close()
+        return out
+    plain, ahead = run(False), run(True)
+    assert plain[0] == ahead[0] and 0 in plain[0] and plain[0].count(2) >= 5
+    for a, b in zip(plain[1], ahead[1]):
+        assert (a is None) == (b is None) and (a is None or np.array_equal(a, b))
+    for a, b in zip(plain[2], ahead[2]):
+        np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(plain[3], ahead[3])

@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Round 6: the next pair's pyramid ahead of its frame (mqs_slam_prepare_next) on / off -- frames/s of every loop leg, frames resident and
+arriving inside the timed loop.  One JSON line per leg.    python tools/probes/prepare_next_study.py [repeats=3]"""
+import os, sys, json
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import run_icl_nuim as R
+import run_slam_loop as L
+rep = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+R.run(80, "keyframe", 0)
+for frames in (80, 200):
+    for ba in (None, "keyframe"):
+        row = {"sequence": "icl-nuim %d" % frames, "ba": ba}
+        for up in (None, "pageable"):
+            for ahead in (False, True):
+                runs = [R.run(frames, ba, 0, upload=up, prepare_next=ahead) for _ in range(rep)]
+                row["%s, pyramid %s" % (up or "resident", "ahead" if ahead else "in the call")] = {"best_frames_per_s": max(r["frames_per_s"] for r in runs),
+                                                                                                  "rmse_mm": round(1e3 * runs[0]["ours_vs_groundtruth_rmse_m"], 3)}
+        print(json.dumps(row), flush=True)
+for ba in (None, "keyframe"):
+    row = {"sequence": "rendered 60", "ba": ba}
+    for up in (None, "pageable"):
+        for ahead in (False, True):
+            r = L.run_device(60, repeats=rep, bundle_adjust=ba, reassociate=bool(ba), upload=up, prepare_next=ahead)
+            row["%s, pyramid %s" % (up or "resident", "ahead" if ahead else "in the call")] = {"frames_per_s": r["frames_per_s"], "rmse_mm": round(1e3 * r["trajectory_rmse"], 3)}
+    print(json.dumps(row), flush=True)

@@ -65,7 +65,7 @@ REFERENCE_NOISE = mqslam_amd.slam_device.REFERENCE_NOISE      # BA_info.noise.*-
 
 
 def run(frames=None, bundle_adjust=None, seed=0, device=True, reassociate=False, window="default", out_dir=None, screen=None, noise=None, engine="device",
-        history=None, window_point_sigma="default", carry=True, check=False, upload=None, screen_iterations="default"):
+        history=None, window_point_sigma="default", carry=True, check=False, upload=None, screen_iterations="default", prepare_next=True):
     """upload: None -- every frame is on the device before the clock starts (the loop's kernels alone); "pinned" -- the frames lie in ONE pinned host
     buffer and go to the device inside the timed loop, on a side stream under the previous frames' kernels (`slam_device.FrameUploader`);
     "pageable" -- they lie in ordinary numpy arrays and pass through pinned staging slots on the uploader's thread.
@@ -97,12 +97,13 @@ def run(frames=None, bundle_adjust=None, seed=0, device=True, reassociate=False,
         if window_point_sigma != "default":
             slam.ba_window_point_sigma = window_point_sigma
         slam.ba_carry = carry
+        slam.prepare_next = prepare_next
         t0 = time.perf_counter()
         if upload is None:
             slam.start(imgs[0], objp, imgp)
             rets = [2]
             for k in range(1, n):
-                rets.append(slam.handle_new_frame(imgs[k]))
+                rets.append(slam.handle_new_frame(imgs[k], imgs[k + 1] if k + 1 < n else None))
         else:
             up = mqslam_amd.slam_device.FrameUploader(slam, src)
             rets = []
