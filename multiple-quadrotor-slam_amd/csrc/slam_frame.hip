@@ -67,11 +67,15 @@ __global__ __launch_bounds__(256) void frame_filter_kernel(SlamDev d, SlamParams
     int n_keep = 0;
     for (int b = 0; b < n; b += 256) {
         const int i = b + tid;
-        const bool keep = i < n && d.lk_st[i] == 1 && d.lk_err[i] < (float)p.max_of_error;
+        // (the tracker ran ahead of this frame: its results lie in the frame-before's kept order, spec_map says where)
+        const int ii = (p.spec && i < n) ? d.spec_map[i] : i;
+        const float *lkp = p.spec ? d.lk_pts_b : d.lk_pts, *lke = p.spec ? d.lk_err_b : d.lk_err;
+        const uint8_t *lks = p.spec ? d.lk_st_b : d.lk_st;
+        const bool keep = i < n && lks[ii] == 1 && lke[ii] < (float)p.max_of_error;
         int total;
         const int r = n_keep + block_rank(keep, tid, sWave, total);
         if (keep) {
-            d.t_pts[2 * r] = d.lk_pts[2 * i]; d.t_pts[2 * r + 1] = d.lk_pts[2 * i + 1];
+            d.t_pts[2 * r] = lkp[2 * ii]; d.t_pts[2 * r + 1] = lkp[2 * ii + 1];
             d.t_base[2 * r] = d.base[2 * i]; d.t_base[2 * r + 1] = d.base[2 * i + 1];
             d.t_lm[r] = d.lm[i]; d.t_tid[r] = d.tid[i];
         }
@@ -160,13 +164,16 @@ __global__ __launch_bounds__(64) void frame_hypothesis_kernel(SlamDev d, SlamPar
     int n_keep = 0, n_tri = 0;
     for (int b = 0; b < n; b += 64) {
         const int i = b + lane;
-        const bool keep = i < n && d.lk_st[i] == 1 && d.lk_err[i] < (float)p.max_of_error;
+        const int ii = (p.spec && i < n) ? d.spec_map[i] : i;           // (the tracker ran ahead of this frame: see frame_filter_kernel)
+        const float *lkp = p.spec ? d.lk_pts_b : d.lk_pts, *lke = p.spec ? d.lk_err_b : d.lk_err;
+        const uint8_t *lks = p.spec ? d.lk_st_b : d.lk_st;
+        const bool keep = i < n && lks[ii] == 1 && lke[ii] < (float)p.max_of_error;
         const int l = keep ? d.lm[i] : -1;
         const bool tri = l >= 0;
         const unsigned long long km = __ballot(keep), tm = __ballot(tri), below = (1ull << lane) - 1ull;
         const int r = n_keep + __popcll(km & below), j = n_tri + __popcll(tm & below);
         if (keep) {
-            const float px = d.lk_pts[2 * i], py = d.lk_pts[2 * i + 1];
+            const float px = lkp[2 * ii], py = lkp[2 * ii + 1];
             if (writer) {
                 d.t_pts[2 * r] = px; d.t_pts[2 * r + 1] = py;
                 d.t_base[2 * r] = d.base[2 * i]; d.t_base[2 * r + 1] = d.base[2 * i + 1];
@@ -643,6 +650,7 @@ __device__ __forceinline__ void frame_decide_body(const SlamDev &d, const SlamPa
             d.pts[2 * r] = px; d.pts[2 * r + 1] = py;
             d.base[2 * r] = bx; d.base[2 * r + 1] = by;
             d.lm[r] = d.t_lm[k]; d.tid[r] = d.t_tid[k];
+            d.spec_map[r] = k;                                    // where live track r sits among this frame's kept tracks (the tracker ahead ran on those)
             if (d.log_lm && nlog0 + r < d.log_cap) {              // slam2.py:519-522 (landmark tracks) and :634-641 (free tracks, resolved later)
                 d.log_lm[nlog0 + r] = tri ? d.t_lm[k] : -2 - d.t_tid[k]; d.log_pose[nlog0 + r] = p.pose_index;
                 d.log_uv[2 * (nlog0 + r)] = (double)px; d.log_uv[2 * (nlog0 + r) + 1] = (double)py;
@@ -1065,10 +1073,12 @@ int mqs_slam_create(int device, int W, int H, const double *intr, int target_key
     s->device = device;
     s->started = false;
     s->accepted = 0; s->base_pose = 0; s->log_arena = nullptr; s->re_arena = nullptr; s->ba = nullptr; s->land_ub = 0; s->key_pose = 0; s->ingest = nullptr;
-    s->ws_lk2 = nullptr; s->pyr_stream = nullptr; s->ahead.set = false;
+    s->ws_lk2 = nullptr; s->pyr_stream = nullptr; s->ahead.set = false; s->spec.valid = false; s->last_decision = 0;
+    s->spec_enabled = true;
+    if (const char *e = getenv("MQS_SLAM_TRACK_AHEAD")) s->spec_enabled = e[0] != '0';      // A/B: 0 = the tracker inside its frame's call
     for (int k = 0; k < 2; ++k) { s->prep[k].valid = false; s->prep[k].prev = nullptr; s->prep[k].next = nullptr; s->prep[k].has_event = false; }
     s->p = SlamParams{W, H, target_keypoints, max_landmarks, coverage_radius, quality_level,
-                      12.0, 0.5, 2.0, 0.33, 1.04, 0.0, (unsigned long long)seed, 1, 0, 0};  // slam2.py:1070-1098; keyframe test on ALL tracks
+                      12.0, 0.5, 2.0, 0.33, 1.04, 0.0, (unsigned long long)seed, 1, 0, 0, 0, 0, 0};  // slam2.py:1070-1098; keyframe test on ALL tracks
     if (const char *e = getenv("MQS_SLAM_HOMOGRAPHY_REFINE")) s->p.homography_refine = e[0] != '0';        // A/B: 0 = the DLT alone
     if (const char *e = getenv("MQS_SLAM_NULL_VECTOR_JACOBI")) s->p.null_vector_jacobi = e[0] != '0';      // A/B: 1 = the Jacobi sweeps always
     s->fused_filter = true;
@@ -1082,7 +1092,7 @@ int mqs_slam_create(int device, int W, int H, const double *intr, int target_key
     const size_t T = kMaxTracks;
     const size_t o_cnt = take(C_COUNT * 4), o_pts = take(T * 8), o_base = take(T * 8), o_lm = take(T * 4), o_tid = take(T * 4),
                  o_map = take((size_t)max_landmarks * 24), o_pk = take(96), o_pp = take(96), o_intr = take(72),
-                 o_lkp = take(T * 8), o_lke = take(T * 4), o_lks = take(T), o_tp = take(T * 8), o_tb = take(T * 8), o_tl = take(T * 4),
+                 o_lkp = take(T * 8), o_lke = take(T * 4), o_lks = take(T), o_lkpb = take(T * 8), o_lkeb = take(T * 4), o_lksb = take(T), o_smap = take(T * 4), o_tp = take(T * 8), o_tb = take(T * 8), o_tl = take(T * 4),
                  o_tt = take(T * 4), o_ot = take(T * 24), o_it = take(T * 16), o_tpos = take(T * 4), o_smp = take((size_t)kHyp * kSample * 4),
                  o_pr = take(96), o_sel = take(8), o_im = take(T), o_pi = take(32), o_ko = take(T * 24), o_ki = take(T * 16),
                  o_k0 = take(T * 16), o_k1 = take(T * 16), o_kp = take(T * 4), o_ks = take(T * 80 + 64), o_kpose = take(192),
@@ -1096,6 +1106,7 @@ int mqs_slam_create(int device, int W, int H, const double *intr, int target_key
     d.cnt = (int32_t *)(a + o_cnt); d.pts = (float *)(a + o_pts); d.base = (float *)(a + o_base); d.lm = (int32_t *)(a + o_lm);
     d.tid = (int32_t *)(a + o_tid); d.map = (double *)(a + o_map); d.pose_key = (double *)(a + o_pk); d.pose_prev = (double *)(a + o_pp);
     d.intr = (double *)(a + o_intr); d.lk_pts = (float *)(a + o_lkp); d.lk_err = (float *)(a + o_lke); d.lk_st = (uint8_t *)(a + o_lks);
+    d.lk_pts_b = (float *)(a + o_lkpb); d.lk_err_b = (float *)(a + o_lkeb); d.lk_st_b = (uint8_t *)(a + o_lksb); d.spec_map = (int32_t *)(a + o_smap);
     d.t_pts = (float *)(a + o_tp); d.t_base = (float *)(a + o_tb); d.t_lm = (int32_t *)(a + o_tl); d.t_tid = (int32_t *)(a + o_tt);
     d.objp_t = (double *)(a + o_ot); d.imgp_t = (double *)(a + o_it); d.tri_pos = (int32_t *)(a + o_tpos); d.samples = (int32_t *)(a + o_smp);
     d.pose_r = (double *)(a + o_pr); d.sel = (int32_t *)(a + o_sel); d.inl_mask = (uint8_t *)(a + o_im); d.pnp_info = (double *)(a + o_pi);
@@ -1129,6 +1140,7 @@ void mqs_slam_destroy(mqs_slam *s)
         (void)hipStreamSynchronize(s->pyr_stream);
         for (int k = 0; k < 2; ++k)
             if (s->prep[k].has_event) (void)hipEventDestroy(s->prep[k].done);
+        if (s->prep[0].has_event) { (void)hipEventDestroy(s->spec.done); (void)hipEventDestroy(s->hyp_done); }
         (void)hipStreamDestroy(s->pyr_stream);
     }
     if (s->ws_lk2) (void)hipFree(s->ws_lk2);
@@ -1296,18 +1308,33 @@ int mqs_slam_track(mqs_slam *s, const uint8_t *prev_img_dev, const uint8_t *img_
     SlamDev &d = s->d;
     s->p.pose_index = s->accepted;
     s->p.base_pose_index = s->base_pose;
-    // the pair's pyramid: prepared ahead on the side stream (mqs_slam_prepare_next) -- then the loop's stream waits for that launch and runs
-    // the tracker alone -- or built here.  A workspace that holds a pyramid prepared for the FOLLOWING pair is left alone.
-    int ws = -1, phases = 3;
-    for (int k = 0; k < 2; ++k)
-        if (s->prep[k].valid && s->prep[k].prev == prev_img_dev && s->prep[k].next == img_dev) { ws = k; phases = 2; }
-    if (ws < 0) ws = (s->prep[0].valid && s->prep[0].prev == img_dev) ? 1 : 0;
-    if (ws == 1 && !s->ws_lk2) ws = 0;
-    if (s->prep[ws].has_event && (s->prep[ws].valid || phases == 2)) MQS_HIP_CHECK(hipStreamWaitEvent(s->stream, s->prep[ws].done, 0));
-    s->prep[ws].valid = false;
-    int rc = mqs_lk_launch(prev_img_dev, img_dev, s->p.W, s->p.H, d.pts, kMaxTracks, d.cnt + C_N, 21, 21, 3, 30, 0.01, 1e-4, d.lk_pts,
+    // The tracker's share of this frame:
+    //  * it ran AHEAD (below, behind the frame before's hypotheses, under its decision kernel: 46 of a frame's ~150 us): valid when that
+    //    frame was accepted as a plain frame -- a keyframe's branch rewrites the tracks, a rejected frame's successor is tracked from the
+    //    frame before it -- and this is the pair it ran on.  The loop's stream waits for it; the filter reads its results through the
+    //    commit's map (SlamParams::spec);
+    //  * else the pair's pyramid may have been prepared ahead on the side stream (mqs_slam_prepare_next): the loop's stream waits for
+    //    that launch and runs the tracker alone;
+    //  * else pyramid and tracker here.  A workspace that holds a pyramid prepared for the FOLLOWING pair is left alone.
+    int ws = -1, phases = 3, rc = MQS_OK;
+    const bool use_spec = s->spec.valid && s->spec_enabled && s->last_decision == 1 && s->spec.prev == prev_img_dev && s->spec.next == img_dev;
+    s->spec.valid = false;
+    s->p.spec = use_spec ? 1 : 0;
+    if (use_spec) {
+        ws = s->spec.ws;
+        MQS_HIP_CHECK(hipStreamWaitEvent(s->stream, s->spec.done, 0));
+        s->prep[ws].valid = false;
+    } else {
+        for (int k = 0; k < 2; ++k)
+            if (s->prep[k].valid && s->prep[k].prev == prev_img_dev && s->prep[k].next == img_dev) { ws = k; phases = 2; }
+        if (ws < 0) ws = (s->prep[0].valid && s->prep[0].prev == img_dev) ? 1 : 0;
+        if (ws == 1 && !s->ws_lk2) ws = 0;
+        if (s->prep[ws].has_event && (s->prep[ws].valid || phases == 2)) MQS_HIP_CHECK(hipStreamWaitEvent(s->stream, s->prep[ws].done, 0));
+        s->prep[ws].valid = false;
+        rc = mqs_lk_launch(prev_img_dev, img_dev, s->p.W, s->p.H, d.pts, kMaxTracks, d.cnt + C_N, 21, 21, 3, 30, 0.01, 1e-4, d.lk_pts,
                            d.lk_st, d.lk_err, ws == 0 ? s->ws_lk : s->ws_lk2, s->ws_lk_bytes, s->stream, phases);
-    if (rc != MQS_OK) return rc;
+        if (rc != MQS_OK) return rc;
+    }
     if (s->fused_filter) {
         hipLaunchKernelGGL(frame_hypothesis_kernel, dim3(kHyp), dim3(64), 0, s->stream, d, s->p);
     } else {
@@ -1316,18 +1343,32 @@ int mqs_slam_track(mqs_slam *s, const uint8_t *prev_img_dev, const uint8_t *img_
                                    kSampleIters, kPnpIters, kPnpEps, d.pose_r, d.sel, d.inl_mask, d.pnp_info, s->ws_pnp, s->stream, 1);
         if (rc != MQS_OK) return rc;
     }
+    if (s->pyr_stream) MQS_HIP_CHECK(hipEventRecord(s->hyp_done, s->stream));      // this frame's kept tracks (t_pts, C_NKEEP) are written
     hipLaunchKernelGGL(frame_decide_kernel, dim3(1), dim3(256), (size_t)kMaxTracks * 40, s->stream, d, s->p);
     MQS_HIP_CHECK(hipGetLastError());
     // the NEXT pair's pyramid (mqs_slam_set_next): enqueued on the side stream now, behind this frame's launches -- the host's work for it
     // runs while the device is busy with them, the kernel runs under the pose kernels
     if (s->ahead.set) {
         s->ahead.set = false;
-        rc = prepare_next_into(s, img_dev, s->ahead.prev_slot, s->ahead.next, s->ahead.next_slot, 1 - ws);      // (not the workspace this frame's tracker is reading)
+        const bool had_stream = s->pyr_stream != nullptr;
+        const int wn = 1 - ws;                                       // (not the workspace this frame's tracker is reading)
+        rc = prepare_next_into(s, img_dev, s->ahead.prev_slot, s->ahead.next, s->ahead.next_slot, wn);
         if (rc != MQS_OK) return rc;
+        // ... and the NEXT frame's tracker on that pyramid, from this frame's kept tracks: behind this frame's hypotheses (they wrote the kept
+        // tracks), beside its decision kernel.  Which of these tracks the commit keeps, the next frame's filter learns from spec_map.
+        if (s->spec_enabled && had_stream) {
+            MQS_HIP_CHECK(hipStreamWaitEvent(s->pyr_stream, s->hyp_done, 0));
+            rc = mqs_lk_launch(img_dev, s->prep[wn].next, s->p.W, s->p.H, d.t_pts, kMaxTracks, d.cnt + C_NKEEP, 21, 21, 3, 30, 0.01, 1e-4, d.lk_pts_b,
+                               d.lk_st_b, d.lk_err_b, wn == 0 ? s->ws_lk : s->ws_lk2, s->ws_lk_bytes, s->pyr_stream, 2);
+            if (rc != MQS_OK) return rc;
+            MQS_HIP_CHECK(hipEventRecord(s->spec.done, s->pyr_stream));
+            s->spec.valid = true; s->spec.prev = img_dev; s->spec.next = s->prep[wn].next; s->spec.ws = wn;
+        }
     }
     // (the decision kernel has written the result block into s->res_host and cleared the previous keyframe's flag on the device)
     MQS_HIP_CHECK(hipStreamSynchronize(s->stream));
     memcpy(result, s->res_host, kRes * 8);
+    s->last_decision = (int)result[R_DECISION];
     if (result[R_DECISION] >= 1.0) s->accepted += 1;
     if (result[R_DECISION] == 2.0) {
         s->base_pose = s->p.pose_index;                 // (the kernels below still get the OLD base through s->p.base_pose_index)
@@ -1373,6 +1414,8 @@ static int prepare_next_into(mqs_slam *s, const uint8_t *prev_img_dev, int prev_
             MQS_HIP_CHECK(hipEventCreateWithFlags(&s->prep[k].done, hipEventDisableTiming));
             s->prep[k].has_event = true;
         }
+        MQS_HIP_CHECK(hipEventCreateWithFlags(&s->spec.done, hipEventDisableTiming));
+        MQS_HIP_CHECK(hipEventCreateWithFlags(&s->hyp_done, hipEventDisableTiming));
     }
     hipEvent_t up;
     if (prev_slot >= 0) {

@@ -25,6 +25,11 @@ struct SlamDev {
     double *pose_key, *pose_prev, *intr;
     float *lk_pts, *lk_err;
     uint8_t *lk_st;
+    // the tracker AHEAD of its frame (slam_frame.hip, "speculative tracker"): its results for the frame's kept tracks (n = C_NKEEP of the
+    // frame before, in that frame's kept order) and, written by that frame's commit, where track r of the live state sits among them
+    float *lk_pts_b, *lk_err_b;
+    uint8_t *lk_st_b;
+    int32_t *spec_map;
     float *t_pts, *t_base;
     int32_t *t_lm, *t_tid;
     double *objp_t, *imgp_t;
@@ -69,6 +74,7 @@ struct SlamParams {
     int null_vector_jacobi;         // 0 (default): the DLT's null vector by inverse iteration, Jacobi sweeps only when that does not settle; 1: always Jacobi (A/B, tests)
     int max_homography_points;      // keyframe_test's random sample (slam2.py:48; the reference: max(4, target / 4), :1088-1089); 0 = all tracks (default)
     int pose_index, base_pose_index; // index this frame gets among the ACCEPTED frames if it is accepted; that of the base keyframe
+    int spec;                        // 1: this frame's tracker ran ahead -- its results are lk_*_b[spec_map[i]] for live track i
 };
 
 }  // namespace slamst
@@ -100,6 +106,10 @@ struct mqs_slam {
     void *ws_lk2;                    // the second tracker workspace (allocated on first use)
     hipStream_t pyr_stream;
     struct { bool valid; const uint8_t *prev, *next; hipEvent_t done; bool has_event; } prep[2];
+    struct { bool valid; const uint8_t *prev, *next; int ws; hipEvent_t done; } spec;      // the tracker launched ahead for the pair (prev, next) on the pyramid in workspace ws
+    hipEvent_t hyp_done;             // behind a frame's hypothesis launch: its kept tracks (t_pts, C_NKEEP) are what the tracker ahead starts from
+    bool spec_enabled;               // MQS_SLAM_TRACK_AHEAD=0 switches the tracker ahead off (A/B, tests); the pyramid ahead stays
+    int last_decision;               // of the last mqs_slam_track: 0 rejected, 1 frame, 2 keyframe
     struct { bool set; const uint8_t *next; int prev_slot, next_slot; } ahead;      // mqs_slam_set_next: what the next mqs_slam_track prepares behind its own launches
 };
 // slam_ingest.hip: a ring slot's device image and upload event, once the worker has enqueued the copy (false: nothing was uploaded into it)

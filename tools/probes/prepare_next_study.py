@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Round 6: the next pair's pyramid ahead of its frame (mqs_slam_prepare_next) on / off -- frames/s of every loop leg, frames resident and
+"""Round 6: the next pair's pyramid and tracker ahead of their frame (mqs_slam_set_next; MQS_SLAM_TRACK_AHEAD=0: the pyramid alone) on / off -- frames/s of every loop leg, frames resident and
 arriving inside the timed loop.  One JSON line per leg.    python tools/probes/prepare_next_study.py [repeats=3]"""
 import os, sys, json
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
