@@ -366,8 +366,9 @@ class DeviceMonoSlam:
         """Returns 0 (rejected), 1 (frame) or 2 (keyframe), like the reference's `ret`.
         img: a contiguous uint8 device tensor, or a slot of the ingest ring (`FrameUploader`).
         next_img (device tensors; ring slots know their successor): the frame behind this one, if it is on the device already -- the
-        tracker's pyramid of the pair (img, next_img) is then built on a side stream under this frame's pose kernels
-        (`mqs_slam_prepare_next`; `prepare_next = False` switches it off: same results, bit for bit)."""
+        tracker's pyramid of the pair (img, next_img) is then built on a side stream under this frame's pose kernels, and the
+        pair is tracked there as soon as this frame's hypotheses are out (`mqs_slam_set_next`; `prepare_next = False` switches
+        both off: same results, bit for bit)."""
         t0 = time.perf_counter()
         if self.ba_info is not None:
             self.ba_info.next_step()                         # slam2.py:1204: one step per frame, rejected ones included
