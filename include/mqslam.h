@@ -789,8 +789,19 @@ int mqs_slam_wait_upload(mqs_slam *s, int slot, const uint8_t **image_dev);
 int mqs_slam_prepare_next(mqs_slam *s, const uint8_t *prev_img_dev, int prev_slot, const uint8_t *next_img_dev, int next_slot);
 /*   mqs_slam_set_next     the same, folded into the loop's call: names the frame BEHIND the one the next mqs_slam_track handles (this_slot /
  *                         next_slot: ring slots or -1, as above); that mqs_slam_track then enqueues the pair's pyramid on the side stream
- *                         behind its own launches and before it waits for its result -- the host's work for it is off the frame's path too. */
+ *                         behind its own launches and before it waits for its result -- the host's work for it is off the frame's path too.
+ *                         Where the tracker's side stream exists it also TRACKS the named pair there as soon as the current frame's
+ *                         hypotheses are out (the surviving tracks are known then), beside the current frame's decision kernel; the next
+ *                         mqs_slam_track uses that when the current frame was an ordinary one (MQS_SLAM_TRACK_AHEAD=0: the pyramid alone). */
 int mqs_slam_set_next(mqs_slam *s, int this_slot, const uint8_t *next_img_dev, int next_slot);
+/*   mqs_slam_pipeline     on = 1: the frame named by mqs_slam_set_next is also ENQUEUED -- its hypothesis and decision kernels behind the
+ *                         current frame's decision, before the call waits for the current frame's result.  They read that decision on
+ *                         the device: behind an ordinary frame they run (no host round trip between two ordinary frames), behind a keyframe
+ *                         or a rejected frame they do nothing and the next mqs_slam_track issues the frame as always.  Contract: after a
+ *                         call that reported an ordinary frame the next mqs_slam_track must be for (that image, the named one) --
+ *                         MQS_E_ARG otherwise -- and reads of the handle's state between the two calls may already show the enqueued
+ *                         frame.  slam2.py's loop (:1200-1253) has nothing between two ordinary frames.  Results are the same bit for bit. */
+int mqs_slam_pipeline(mqs_slam *s, int on);
 int mqs_slam_log_enable(mqs_slam *s, int64_t capacity);
 int mqs_slam_read_log(mqs_slam *s, int32_t *lm, int32_t *pose, double *uv, int64_t cap, int64_t *n);
 int mqs_slam_write_back(mqs_slam *s, const double *map, int n, const double *pose_prev, const double *pose_key);

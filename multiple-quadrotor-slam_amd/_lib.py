@@ -189,6 +189,7 @@ SIGNATURES = {
     "mqs_slam_wait_upload": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.POINTER(c_vp)]),
     "mqs_slam_prepare_next": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, c_vp, ctypes.c_int]),
     "mqs_slam_set_next": (ctypes.c_int, [c_vp, ctypes.c_int, c_vp, ctypes.c_int]),
+    "mqs_slam_pipeline": (ctypes.c_int, [c_vp, ctypes.c_int]),
     "mqs_slam_log_enable": (ctypes.c_int, [c_vp, c_i64]),
     "mqs_slam_read_log": (ctypes.c_int, [c_vp, c_i32p, c_i32p, c_f64p, c_i64, ctypes.POINTER(c_i64)]),
     "mqs_slam_write_back": (ctypes.c_int, [c_vp, c_f64p, ctypes.c_int, c_f64p, c_f64p]),

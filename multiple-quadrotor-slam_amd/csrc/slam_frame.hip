@@ -24,6 +24,7 @@
 #include "wave_reduce.h"
 #include "slam_state.h"
 #include <new>
+#include <chrono>
 
 namespace {
 
@@ -159,6 +160,9 @@ __global__ __launch_bounds__(64) void frame_hypothesis_kernel(SlamDev d, SlamPar
     __shared__ int sPick[kSample];
     const int lane = threadIdx.x, h = blockIdx.x;
     const bool writer = h == 0;
+    // enqueued before the frame in front was decided (mqs_slam_pipeline): that frame became a keyframe or was rejected -- nothing to do, the
+    // host issues this frame again behind the keyframe's branch / from the right previous image
+    if (p.gated && d.cnt[C_LAST_DECISION] != 1) return;
     const int n = d.cnt[C_N];
     if (lane < 9) sI[lane] = d.intr[lane];
     int n_keep = 0, n_tri = 0;
@@ -591,7 +595,13 @@ __device__ __forceinline__ double block_sum(double v, int tid, double *sRed /*[4
 #else
 #define MQS_DSTAMP(i) do { } while (0)
 #endif
-__device__ __forceinline__ void frame_decide_body(const SlamDev &d, const SlamParams &p)
+// The keyframe test's number (slam2.py:43-59: the ratio of the largest to the smallest singular value of the homography between the base
+// keyframe's and this frame's positions of the accepted tracks) by ONE workgroup that needs nothing of the refined pose: it picks the best
+// hypothesis and marks its inliers as select_refine_block does (the same comparisons on the same numbers), lists the accepted tracks --
+// kept by the filter, and no outlier of the pose -- in the commit's order, undistorts both ends, and runs findHomography on them.  In the
+// two-workgroup form of frame_decide_kernel this runs BESIDE the pose refinement (30 us) instead of behind it (22 us of the kernel's 63).
+// frame: the frame counter this frame's sample is seeded with.  Returns the ratio (1: fewer than four tracks / no model); n_acc_out: tracks.
+__device__ __forceinline__ double decide_keyframe_ratio(const SlamDev &d, const SlamParams &p, int frame_no, int &n_acc_out)
 {
 #ifdef MQS_DECIDE_STAMPS
     const unsigned long long dst0 = wall_clock64();
@@ -603,79 +613,52 @@ __device__ __forceinline__ void frame_decide_body(const SlamDev &d, const SlamPa
     __shared__ double sAcc[4][48];
     __shared__ double sA[81], sV[81];
     __shared__ double sI[9], sP[12], sH[9];
+    __shared__ int sBestC[256], sBestH[256];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) { d.res[R_NTRACKS] = (double)d.cnt[C_N]; d.res[R_NLAND] = (double)d.cnt[C_NLAND]; d.cnt[C_FRAME] += 1; }
-    if (d.res[R_DECISION] == 0.0) return;                          // rejected by the filter: the state is untouched
     const int n_tri = d.cnt[C_NTRI], n_keep = d.cnt[C_NKEEP];
-    const int best = d.sel[0], ninl = d.sel[1];
+    n_acc_out = 0;
+    if (n_tri <= 0) return 1.0;                                    // rejected by the filter
     if (tid < 9) sI[tid] = d.intr[tid];
-    if (tid < 12) sP[tid] = d.pose_r[tid];
+    // the hypothesis with the most inliers, the lowest index on ties (pnp_block.h: select_refine_block)
+    int bc = -1, bh = -1;
+    for (int h = tid; h < kHyp; h += 256)
+        if (d.pnp_counts[h] > bc) { bc = d.pnp_counts[h]; bh = h; }
+    sBestC[tid] = bc; sBestH[tid] = bh;
     __syncthreads();
-    const double outlier = n_tri > 0 ? (double)(n_tri - ninl) / (double)n_tri : 1.0;
-    int reason = 0;
-    if (best < 0) reason = 3;                                      // no valid RANSAC model
-    else if (outlier > p.max_outlier_ratio || ninl < 8) reason = 4;
-    // reprojection RMS of the inliers under the refined pose (calibration_tools.py:116-124)
-    double e2 = 0.0;
-    for (int j = tid; j < n_tri; j += 256)
-        if (d.inl_mask[j])
-            e2 += mqs::pnp::reproj_sqerr(sP, sI, d.objp_t[3 * j], d.objp_t[3 * j + 1], d.objp_t[3 * j + 2], d.imgp_t[2 * j], d.imgp_t[2 * j + 1]);
-    const double sq = block_sum(e2, tid, sRed);
-    const double rms = ninl > 0 ? sqrt(sq / (double)ninl) : 0.0;
-    if (!reason && !(rms <= p.max_reproj)) reason = 5;
-    if (tid == 0) {
-        d.res[R_NINL] = (double)ninl; d.res[R_OUTLIER] = outlier; d.res[R_REPROJ] = rms;
-        if (reason) { d.res[R_DECISION] = 0.0; d.res[R_REASON] = (double)reason; }
+    for (int st = 128; st >= 1; st >>= 1) {
+        if (tid < st) {
+            const int c2 = sBestC[tid + st], h2 = sBestH[tid + st];
+            if (c2 > sBestC[tid] || (c2 == sBestC[tid] && h2 >= 0 && (sBestH[tid] < 0 || h2 < sBestH[tid]))) { sBestC[tid] = c2; sBestH[tid] = h2; }
+        }
+        __syncthreads();
     }
-    if (reason) return;
-    MQS_DSTAMP(0);
-
-    // commit: inlier landmark tracks and the free tracks stay, in order; the keyframe step's two point sets beside them
+    const int best = sBestH[0];
+    if (best < 0) return 1.0;
+    if (tid < 12) sP[tid] = d.pnp_poses[12 * best + tid];
     for (int k = tid; k < n_keep; k += 256) sInl[k] = 1;
     __syncthreads();
-    for (int j = tid; j < n_tri; j += 256) sInl[d.tri_pos[j]] = d.inl_mask[j];
+    const double thr2 = p.max_reproj * p.max_reproj;
+    for (int j = tid; j < n_tri; j += 256) {
+        const double X = d.objp_t[3 * j], Y = d.objp_t[3 * j + 1], Z = d.objp_t[3 * j + 2], u = d.imgp_t[2 * j], v = d.imgp_t[2 * j + 1];
+        const double Zc = fma(sP[8], X, fma(sP[9], Y, fma(sP[10], Z, sP[11])));
+        const double e2 = mqs::pnp::reproj_sqerr(sP, sI, X, Y, Z, u, v);
+        sInl[d.tri_pos[j]] = (Zc > 0.0 && e2 <= thr2) ? 1 : 0;
+    }
     __syncthreads();
-    int n_acc = 0, n_old = 0, n_new = 0;
-    const int nlog0 = d.log_lm ? d.cnt[C_NLOG] : 0;
+    int n_acc = 0;
     for (int b = 0; b < n_keep; b += 256) {
         const int k = b + tid;
         const bool in = k < n_keep && sInl[k] != 0;
-        const bool tri = in && d.t_lm[k] >= 0, fre = in && d.t_lm[k] < 0;
-        int tot, tot_o, tot_n;
+        int tot;
         const int r = n_acc + block_rank(in, tid, sWave, tot);
-        const int ro = n_old + block_rank(tri, tid, sWave, tot_o);
-        const int rn = n_new + block_rank(fre, tid, sWave, tot_n);
-        if (in) {
-            const float px = d.t_pts[2 * k], py = d.t_pts[2 * k + 1], bx = d.t_base[2 * k], by = d.t_base[2 * k + 1];
-            d.pts[2 * r] = px; d.pts[2 * r + 1] = py;
-            d.base[2 * r] = bx; d.base[2 * r + 1] = by;
-            d.lm[r] = d.t_lm[k]; d.tid[r] = d.t_tid[k];
-            d.spec_map[r] = k;                                    // where live track r sits among this frame's kept tracks (the tracker ahead ran on those)
-            if (d.log_lm && nlog0 + r < d.log_cap) {              // slam2.py:519-522 (landmark tracks) and :634-641 (free tracks, resolved later)
-                d.log_lm[nlog0 + r] = tri ? d.t_lm[k] : -2 - d.t_tid[k]; d.log_pose[nlog0 + r] = p.pose_index;
-                d.log_uv[2 * (nlog0 + r)] = (double)px; d.log_uv[2 * (nlog0 + r) + 1] = (double)py;
-            }
-            if (tri) {
-                const int l = d.t_lm[k];
-                d.kf_objp[3 * ro] = d.map[3 * l]; d.kf_objp[3 * ro + 1] = d.map[3 * l + 1]; d.kf_objp[3 * ro + 2] = d.map[3 * l + 2];
-                d.kf_imgp[2 * ro] = (double)px; d.kf_imgp[2 * ro + 1] = (double)py;
-            } else {
-                d.kf_p0[2 * rn] = (double)bx; d.kf_p0[2 * rn + 1] = (double)by;
-                d.kf_p1[2 * rn] = (double)px; d.kf_p1[2 * rn + 1] = (double)py;
-                d.kf_pos[rn] = r;
-            }
-            // keyframe test inputs: both ends of the track, undistorted
-            mqs::cam::undistort_pixel(sI, (double)bx, (double)by, sU1[2 * r], sU1[2 * r + 1]);
-            mqs::cam::undistort_pixel(sI, (double)px, (double)py, sU2[2 * r], sU2[2 * r + 1]);
+        if (in) {                                                  // keyframe test inputs: both ends of the track, undistorted
+            mqs::cam::undistort_pixel(sI, (double)d.t_base[2 * k], (double)d.t_base[2 * k + 1], sU1[2 * r], sU1[2 * r + 1]);
+            mqs::cam::undistort_pixel(sI, (double)d.t_pts[2 * k], (double)d.t_pts[2 * k + 1], sU2[2 * r], sU2[2 * r + 1]);
         }
-        n_acc += tot; n_old += tot_o; n_new += tot_n;
+        n_acc += tot;
     }
     __syncthreads();
-    if (tid < 12) d.pose_prev[tid] = sP[tid];
-    if (tid == 0) d.cnt[C_N] = n_acc;
-    if (tid == 0 && d.log_lm) { d.cnt[C_NLOG] = min(nlog0 + n_acc, d.log_cap); if (nlog0 + n_acc > d.log_cap) d.cnt[C_LOG_OVERFLOW] = 1; }
-    if (d.traj && tid < 12 && p.pose_index < d.traj_cap) d.traj[12 * (size_t)p.pose_index + tid] = sP[tid];
-
+    n_acc_out = n_acc;
     MQS_DSTAMP(1);
     // keyframe_test's random sample of the kept tracks (slam2.py:48: np.random.permutation(n)[:max_num_homography_points]): a
     // counter-based hash of (seed, frame, track position) per track, the tracks with the max_homography_points smallest hashes are
@@ -684,7 +667,7 @@ __device__ __forceinline__ void frame_decide_body(const SlamDev &d, const SlamPa
     if (p.max_homography_points > 0 && n_acc > p.max_homography_points) {
         __shared__ unsigned sHash[kMaxTracks];
         __shared__ uint8_t sPick[kMaxTracks];
-        const unsigned long long frame = (unsigned long long)d.cnt[C_FRAME];
+        const unsigned long long frame = (unsigned long long)frame_no;
         for (int k = tid; k < n_acc; k += 256) {
             unsigned long long st = p.seed ^ (frame << 24) ^ ((unsigned long long)(k + 1) * 0x9e3779b97f4a7c15ull) ^ 0x5851f42d4c957f2dull;
             sHash[k] = (unsigned)(splitmix64(st) >> 32);
@@ -812,10 +795,92 @@ __device__ __forceinline__ void frame_decide_body(const SlamDev &d, const SlamPa
         ratio = sRed[0];
         MQS_DSTAMP(7);
     }
+    return ratio;
+}
+
+// The pose's share of the decision: gates (slam2.py:461-468, 493-497) on the refined pose.  Returns the reason (0: accepted so far).
+__device__ __forceinline__ int decide_gates(const SlamDev &d, const SlamParams &p, double *sP, double *sI, double *sRed)
+{
+    const int tid = threadIdx.x;
+    if (tid == 0) { d.res[R_NTRACKS] = (double)d.cnt[C_N]; d.res[R_NLAND] = (double)d.cnt[C_NLAND]; }
+    if (d.res[R_DECISION] == 0.0) return -1;                       // rejected by the filter: the state is untouched
+    const int n_tri = d.cnt[C_NTRI];
+    const int best = d.sel[0], ninl = d.sel[1];
+    if (tid < 9) sI[tid] = d.intr[tid];
+    if (tid < 12) sP[tid] = d.pose_r[tid];
+    __syncthreads();
+    const double outlier = n_tri > 0 ? (double)(n_tri - ninl) / (double)n_tri : 1.0;
+    int reason = 0;
+    if (best < 0) reason = 3;                                      // no valid RANSAC model
+    else if (outlier > p.max_outlier_ratio || ninl < 8) reason = 4;
+    // reprojection RMS of the inliers under the refined pose (calibration_tools.py:116-124)
+    double e2 = 0.0;
+    for (int j = tid; j < n_tri; j += 256)
+        if (d.inl_mask[j])
+            e2 += mqs::pnp::reproj_sqerr(sP, sI, d.objp_t[3 * j], d.objp_t[3 * j + 1], d.objp_t[3 * j + 2], d.imgp_t[2 * j], d.imgp_t[2 * j + 1]);
+    const double sq = block_sum(e2, tid, sRed);
+    const double rms = ninl > 0 ? sqrt(sq / (double)ninl) : 0.0;
+    if (!reason && !(rms <= p.max_reproj)) reason = 5;
     if (tid == 0) {
-        const bool key = n_acc >= 4 && ratio > p.homography_threshold;
+        d.res[R_NINL] = (double)ninl; d.res[R_OUTLIER] = outlier; d.res[R_REPROJ] = rms;
+        if (reason) { d.res[R_DECISION] = 0.0; d.res[R_REASON] = (double)reason; }
+    }
+    return reason;
+}
+
+// commit (slam2.py:499-522): inlier landmark tracks and the free tracks stay, in order; the keyframe step's two point sets beside them;
+// then the decision from the keyframe test's ratio.
+__device__ __forceinline__ void decide_commit(const SlamDev &d, const SlamParams &p, const double *sP, double ratio, int n_acc_kf)
+{
+    __shared__ int sWave[4];
+    __shared__ uint8_t sInl[kMaxTracks];
+    const int tid = threadIdx.x;
+    const int n_tri = d.cnt[C_NTRI], n_keep = d.cnt[C_NKEEP];
+    for (int k = tid; k < n_keep; k += 256) sInl[k] = 1;
+    __syncthreads();
+    for (int j = tid; j < n_tri; j += 256) sInl[d.tri_pos[j]] = d.inl_mask[j];
+    __syncthreads();
+    int n_acc = 0, n_old = 0, n_new = 0;
+    const int nlog0 = d.log_lm ? d.cnt[C_NLOG] : 0;
+    for (int b = 0; b < n_keep; b += 256) {
+        const int k = b + tid;
+        const bool in = k < n_keep && sInl[k] != 0;
+        const bool tri = in && d.t_lm[k] >= 0, fre = in && d.t_lm[k] < 0;
+        int tot, tot_o, tot_n;
+        const int r = n_acc + block_rank(in, tid, sWave, tot);
+        const int ro = n_old + block_rank(tri, tid, sWave, tot_o);
+        const int rn = n_new + block_rank(fre, tid, sWave, tot_n);
+        if (in) {
+            const float px = d.t_pts[2 * k], py = d.t_pts[2 * k + 1], bx = d.t_base[2 * k], by = d.t_base[2 * k + 1];
+            d.pts[2 * r] = px; d.pts[2 * r + 1] = py;
+            d.base[2 * r] = bx; d.base[2 * r + 1] = by;
+            d.lm[r] = d.t_lm[k]; d.tid[r] = d.t_tid[k];
+            d.spec_map[r] = k;                                    // where live track r sits among this frame's kept tracks (the tracker ahead ran on those)
+            if (d.log_lm && nlog0 + r < d.log_cap) {              // slam2.py:519-522 (landmark tracks) and :634-641 (free tracks, resolved later)
+                d.log_lm[nlog0 + r] = tri ? d.t_lm[k] : -2 - d.t_tid[k]; d.log_pose[nlog0 + r] = p.pose_index;
+                d.log_uv[2 * (nlog0 + r)] = (double)px; d.log_uv[2 * (nlog0 + r) + 1] = (double)py;
+            }
+            if (tri) {
+                const int l = d.t_lm[k];
+                d.kf_objp[3 * ro] = d.map[3 * l]; d.kf_objp[3 * ro + 1] = d.map[3 * l + 1]; d.kf_objp[3 * ro + 2] = d.map[3 * l + 2];
+                d.kf_imgp[2 * ro] = (double)px; d.kf_imgp[2 * ro + 1] = (double)py;
+            } else {
+                d.kf_p0[2 * rn] = (double)bx; d.kf_p0[2 * rn + 1] = (double)by;
+                d.kf_p1[2 * rn] = (double)px; d.kf_p1[2 * rn + 1] = (double)py;
+                d.kf_pos[rn] = r;
+            }
+        }
+        n_acc += tot; n_old += tot_o; n_new += tot_n;
+    }
+    __syncthreads();
+    if (tid < 12) d.pose_prev[tid] = sP[tid];
+    if (tid == 0) d.cnt[C_N] = n_acc;
+    if (tid == 0 && d.log_lm) { d.cnt[C_NLOG] = min(nlog0 + n_acc, d.log_cap); if (nlog0 + n_acc > d.log_cap) d.cnt[C_LOG_OVERFLOW] = 1; }
+    if (d.traj && tid < 12 && p.pose_index < d.traj_cap) d.traj[12 * (size_t)p.pose_index + tid] = sP[tid];
+    if (tid == 0) {
+        const bool key = n_acc >= 4 && n_acc == n_acc_kf && ratio > p.homography_threshold;
         d.res[R_DECISION] = key ? 2.0 : 1.0;
-        d.res[R_REASON] = 0.0;
+        d.res[R_REASON] = n_acc == n_acc_kf ? 0.0 : 6.0;            // (6 cannot happen: both workgroups list the same tracks)
         d.res[R_NTRACKS] = (double)n_acc; d.res[R_NOLD] = (double)n_old; d.res[R_NNEW] = (double)n_new;
         d.res[R_HOMOGRAPHY] = ratio;
         d.cnt[C_KF_PENDING] = key ? 1 : 0;
@@ -823,25 +888,71 @@ __device__ __forceinline__ void frame_decide_body(const SlamDev &d, const SlamPa
     if (tid < 12) d.res[R_POSE + tid] = sP[tid];
 }
 
-// The decision, then the frame's result block straight into the caller's pinned host memory (every return path of the body is uniform
-// over the workgroup): the previous keyframe's report rides along and its flag is cleared for the next one -- what a device-to-host
-// copy and a fill launch per frame did before (5 + 4 us of the frame's ~230).
+// The decision, then the frame's result block straight into the caller's pinned host memory: the previous keyframe's report rides along
+// and its flag is cleared for the next one -- what a device-to-host copy and a fill launch per frame did before (5 + 4 us of the frame's
+// ~230).  TWO workgroups (round 6): workgroup 0 finishes solvePnPRansac (best hypothesis, refinement on its inliers: 30 us), applies the
+// gates and commits; workgroup 1 computes the keyframe test's ratio meanwhile (22 us) and hands it over through a flag in device memory
+// (agent-scope release / acquire; both workgroups are resident -- a launch of two).  One workgroup (p.decide_split == 0, A/B): the same
+// functions one behind the other.
 __global__ __launch_bounds__(256) void frame_decide_kernel(SlamDev d, SlamParams p)
 {
+    const int tid = threadIdx.x;
+    // the slot of the pinned ring this launch reports into; its ticket goes behind the block with a system-scope release, the host polls for it
+    // (no stream synchronisation per frame: a frame enqueued ahead may already be running behind this launch)
+    double *out = d.res_out + (size_t)(p.ticket & (kResSlots - 1)) * kResStride;
+    if (p.gated && d.cnt[C_LAST_DECISION] != 1) {                 // (uniform; see frame_hypothesis_kernel) -- nobody waits for this ticket
+        if (tid == 0 && blockIdx.x == 0) {
+            out[R_DECISION] = -2.0;
+            __hip_atomic_store((unsigned long long *)(out + kRes), (unsigned long long)p.ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        return;
+    }
+    const int frame_no = d.cnt[C_FRAME] + 1;                       // (workgroup 0 writes the counter behind the hand-over)
+    unsigned long long *kf_word = reinterpret_cast<unsigned long long *>(d.kf_hand);
+    if (blockIdx.x == 1) {
+        int n_acc;
+        const double ratio = decide_keyframe_ratio(d, p, frame_no, n_acc);
+        if (tid == 0) {
+            __hip_atomic_store(d.kf_hand + 1, ratio, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(d.kf_hand + 2, (double)n_acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(kf_word, (unsigned long long)p.ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+    }
     // the end of solvePnPRansac first (pnp_block.h: best hypothesis, its inliers into LDS, refinement by four wavefronts) -- a launch
     // of its own before, with a launch gap on either side
     extern __shared__ __attribute__((aligned(16))) double decide_lds[];
+    __shared__ double sI[9], sP[12], sRed[4], sHand[2];
     mqs::pnpblk::select_refine_block(d.objp_t, d.imgp_t, kMaxTracks, d.cnt + C_NTRI, d.intr, d.pnp_poses, d.pnp_counts, kHyp, p.max_reproj * p.max_reproj,
                                      kPnpIters, kPnpEps, 1, d.pose_r, d.sel, d.pnp_inl, d.inl_mask, d.pnp_info, decide_lds);
     __threadfence_block();
     __syncthreads();
-    frame_decide_body(d, p);
+    const int reason = decide_gates(d, p, sP, sI, sRed);
+    double ratio = 1.0;
+    int n_acc_kf = 0;
+    if (gridDim.x == 1) {
+        if (reason == 0) ratio = decide_keyframe_ratio(d, p, frame_no, n_acc_kf);
+    } else {
+        // the other workgroup's ratio (always waited for: the frame counter below is what it seeds its sample with)
+        if (tid == 0) {
+            while (__hip_atomic_load(kf_word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != (unsigned long long)p.ticket) __builtin_amdgcn_s_sleep(1);
+            sHand[0] = __hip_atomic_load(d.kf_hand + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sHand[1] = __hip_atomic_load(d.kf_hand + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        ratio = sHand[0]; n_acc_kf = (int)sHand[1];
+    }
+    if (reason == 0) decide_commit(d, p, sP, ratio, n_acc_kf);
     __syncthreads();
-    const int tid = threadIdx.x;
+    if (tid == 0) d.cnt[C_FRAME] = frame_no;
     if (tid < kRes) {
-        d.res_out[tid] = d.res[tid];
+        out[tid] = d.res[tid];
         if (tid == R_KF_VALID) d.res[R_KF_VALID] = 0.0;
     }
+    if (tid == 0) d.cnt[C_LAST_DECISION] = (int)d.res[R_DECISION];
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store((unsigned long long *)(out + kRes), (unsigned long long)p.ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1076,9 +1187,12 @@ int mqs_slam_create(int device, int W, int H, const double *intr, int target_key
     s->ws_lk2 = nullptr; s->pyr_stream = nullptr; s->ahead.set = false; s->spec.valid = false; s->last_decision = 0;
     s->spec_enabled = true;
     if (const char *e = getenv("MQS_SLAM_TRACK_AHEAD")) s->spec_enabled = e[0] != '0';      // A/B: 0 = the tracker inside its frame's call
+    s->pipeline = false; s->pre.valid = false; s->ticket = 0;
+    s->decide_grid = 2;
+    if (const char *e = getenv("MQS_SLAM_DECIDE_SPLIT")) s->decide_grid = e[0] != '0' ? 2 : 1;   // A/B: 0 = one workgroup, the keyframe test behind the pose
     for (int k = 0; k < 2; ++k) { s->prep[k].valid = false; s->prep[k].prev = nullptr; s->prep[k].next = nullptr; s->prep[k].has_event = false; }
     s->p = SlamParams{W, H, target_keypoints, max_landmarks, coverage_radius, quality_level,
-                      12.0, 0.5, 2.0, 0.33, 1.04, 0.0, (unsigned long long)seed, 1, 0, 0, 0, 0, 0};  // slam2.py:1070-1098; keyframe test on ALL tracks
+                      12.0, 0.5, 2.0, 0.33, 1.04, 0.0, (unsigned long long)seed, 1, 0, 0, 0, 0, 0, 0, 0u};  // slam2.py:1070-1098; keyframe test on ALL tracks
     if (const char *e = getenv("MQS_SLAM_HOMOGRAPHY_REFINE")) s->p.homography_refine = e[0] != '0';        // A/B: 0 = the DLT alone
     if (const char *e = getenv("MQS_SLAM_NULL_VECTOR_JACOBI")) s->p.null_vector_jacobi = e[0] != '0';      // A/B: 1 = the Jacobi sweeps always
     s->fused_filter = true;
@@ -1097,7 +1211,7 @@ int mqs_slam_create(int device, int W, int H, const double *intr, int target_key
                  o_pr = take(96), o_sel = take(8), o_im = take(T), o_pi = take(32), o_ko = take(T * 24), o_ki = take(T * 16),
                  o_k0 = take(T * 16), o_k1 = take(T * 16), o_kp = take(T * 4), o_ks = take(T * 80 + 64), o_kpose = take(192),
                  o_kx = take(T * 24), o_kinfo = take(64), o_kst = take(T * 4), o_mask = take((size_t)W * H), o_gxy = take(T * 8),
-                 o_gn = take(4), o_res = take(kRes * 8), o_wl = take((size_t)s->ws_lk_bytes), o_wg = take((size_t)s->ws_gftt_bytes),
+                 o_gn = take(4), o_res = take(kRes * 8), o_hand = take(32), o_wl = take((size_t)s->ws_lk_bytes), o_wg = take((size_t)s->ws_gftt_bytes),
                  o_wp = take((size_t)ws_pnp_bytes);
     hipError_t e = hipMalloc((void **)&s->arena, off);
     if (e != hipSuccess) { delete s; mqs_set_error("hipMalloc(%zu) failed: %s", off, hipGetErrorString(e)); return MQS_E_NOMEM; }
@@ -1113,11 +1227,13 @@ int mqs_slam_create(int device, int W, int H, const double *intr, int target_key
     d.kf_objp = (double *)(a + o_ko); d.kf_imgp = (double *)(a + o_ki); d.kf_p0 = (double *)(a + o_k0); d.kf_p1 = (double *)(a + o_k1);
     d.kf_pos = (int32_t *)(a + o_kp); d.kf_scratch = (double *)(a + o_ks); d.kf_pose = (double *)(a + o_kpose); d.kf_x = (double *)(a + o_kx);
     d.kf_info = (double *)(a + o_kinfo); d.kf_status = (int32_t *)(a + o_kst); d.mask = (uint8_t *)(a + o_mask); d.gf_xy = (float *)(a + o_gxy);
-    d.gf_n = (int32_t *)(a + o_gn); d.res = (double *)(a + o_res);
+    d.gf_n = (int32_t *)(a + o_gn); d.res = (double *)(a + o_res); d.kf_hand = (double *)(a + o_hand);
     s->ws_lk = a + o_wl; s->ws_gftt = a + o_wg; s->ws_pnp = a + o_wp;
     mqs_pnp_workspace_layout(s->ws_pnp, kHyp, &d.pnp_poses, &d.pnp_counts, &d.pnp_inl);
     e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipHostMalloc((void **)&s->res_host, kRes * 8, hipHostMallocDefault);
+    // (coherent: the decision kernel's block and ticket must be visible to the polling host while later launches are still running)
+    if (e == hipSuccess) e = hipHostMalloc((void **)&s->res_host, (size_t)kResSlots * kResStride * 8, hipHostMallocCoherent);
+    if (e == hipSuccess) memset(s->res_host, 0xff, (size_t)kResSlots * kResStride * 8);
     if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&d.res_out, s->res_host, 0);
     if (e == hipSuccess) e = hipMemsetAsync(s->arena, 0, o_wl, s->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d.intr, intr, 72, hipMemcpyHostToDevice, s->stream);
@@ -1138,6 +1254,7 @@ void mqs_slam_destroy(mqs_slam *s)
     (void)hipSetDevice(s->device);
     if (s->pyr_stream) {
         (void)hipStreamSynchronize(s->pyr_stream);
+        (void)hipStreamSynchronize(s->stream);                     // (a frame enqueued ahead waits for the side stream's events)
         for (int k = 0; k < 2; ++k)
             if (s->prep[k].has_event) (void)hipEventDestroy(s->prep[k].done);
         if (s->prep[0].has_event) { (void)hipEventDestroy(s->spec.done); (void)hipEventDestroy(s->hyp_done); }
@@ -1285,6 +1402,7 @@ int mqs_slam_start(mqs_slam *s, const uint8_t *img_dev, const float *objp0, cons
     MQS_HIP_CHECK(hipStreamSynchronize(s->stream));
     memcpy(pose_out, s->res_host + R_POSE, 96);
     s->started = true;
+    s->pre.valid = false; s->spec.valid = false; s->last_decision = 0;
     s->accepted = 1;                  // the first frame is pose 0 and the first base keyframe
     s->base_pose = 0;
     s->land_ub = n0;
@@ -1299,6 +1417,32 @@ int mqs_slam_start(mqs_slam *s, const uint8_t *img_dev, const float *objp0, cons
 // left -- valid flag, landmarks added, tracks after the top-up, landmarks, refined pose [12] -- because that branch runs
 // behind the call that started it.  mqs_slam_flush returns the same block once the stream has drained.
 static int prepare_next_into(mqs_slam *s, const uint8_t *prev_img_dev, int prev_slot, const uint8_t *next_img_dev, int next_slot, int ws_target);
+
+// The host's wait for a frame's result: the ticket word behind the block in the pinned ring (written by the decision kernel with a
+// system-scope release).  The stream is looked at every few thousand polls -- a launch that failed never writes its ticket -- and the
+// wait gives up after ten seconds.
+static int wait_result(mqs_slam *s, unsigned ticket)
+{
+    const unsigned long long *word = (const unsigned long long *)(s->res_host + (size_t)(ticket & (kResSlots - 1)) * kResStride + kRes);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 1;; ++spins) {
+        if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == (unsigned long long)ticket) return MQS_OK;
+        if ((spins & 4095u) == 0) {
+            const hipError_t q = hipStreamQuery(s->stream);
+            if (q == hipSuccess) {                                   // drained: the ticket is there, or the launch never ran
+                if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == (unsigned long long)ticket) return MQS_OK;
+                mqs_set_error("mqs_slam_track: the stream drained without the frame's result (ticket %u)", ticket);
+                return MQS_E_HIP;
+            }
+            if (q != hipErrorNotReady) { mqs_set_error("mqs_slam_track: %s", hipGetErrorString(q)); return MQS_E_HIP; }
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(10)) {
+                mqs_set_error("mqs_slam_track: no result after 10 s (ticket %u)", ticket);
+                return MQS_E_TIMEOUT;
+            }
+        }
+        __builtin_ia32_pause();
+    }
+}
 
 int mqs_slam_track(mqs_slam *s, const uint8_t *prev_img_dev, const uint8_t *img_dev, double *result)
 {
@@ -1317,35 +1461,55 @@ int mqs_slam_track(mqs_slam *s, const uint8_t *prev_img_dev, const uint8_t *img_
     //    that launch and runs the tracker alone;
     //  * else pyramid and tracker here.  A workspace that holds a pyramid prepared for the FOLLOWING pair is left alone.
     int ws = -1, phases = 3, rc = MQS_OK;
-    const bool use_spec = s->spec.valid && s->spec_enabled && s->last_decision == 1 && s->spec.prev == prev_img_dev && s->spec.next == img_dev;
-    s->spec.valid = false;
-    s->p.spec = use_spec ? 1 : 0;
-    if (use_spec) {
-        ws = s->spec.ws;
-        MQS_HIP_CHECK(hipStreamWaitEvent(s->stream, s->spec.done, 0));
-        s->prep[ws].valid = false;
-    } else {
-        for (int k = 0; k < 2; ++k)
-            if (s->prep[k].valid && s->prep[k].prev == prev_img_dev && s->prep[k].next == img_dev) { ws = k; phases = 2; }
-        if (ws < 0) ws = (s->prep[0].valid && s->prep[0].prev == img_dev) ? 1 : 0;
-        if (ws == 1 && !s->ws_lk2) ws = 0;
-        if (s->prep[ws].has_event && (s->prep[ws].valid || phases == 2)) MQS_HIP_CHECK(hipStreamWaitEvent(s->stream, s->prep[ws].done, 0));
-        s->prep[ws].valid = false;
-        rc = mqs_lk_launch(prev_img_dev, img_dev, s->p.W, s->p.H, d.pts, kMaxTracks, d.cnt + C_N, 21, 21, 3, 30, 0.01, 1e-4, d.lk_pts,
-                           d.lk_st, d.lk_err, ws == 0 ? s->ws_lk : s->ws_lk2, s->ws_lk_bytes, s->stream, phases);
-        if (rc != MQS_OK) return rc;
+    // Was this frame ENQUEUED by the call before (mqs_slam_pipeline)?  Its kernels ran -- or are running -- if the frame in front was an
+    // ordinary one; else they looked at that frame's decision and did nothing, and the frame is issued here as usual.
+    bool launched = false;
+    unsigned ticket = 0;
+    if (s->pre.valid) {
+        s->pre.valid = false;
+        if (s->last_decision == 1) {
+            if (s->pre.prev != prev_img_dev || s->pre.img != img_dev) {
+                mqs_set_error("mqs_slam_track: with mqs_slam_pipeline on, the frame named by mqs_slam_set_next has been enqueued behind an ordinary frame -- it must be the next one tracked");
+                return MQS_E_ARG;
+            }
+            launched = true; ws = s->pre.ws; ticket = s->pre.ticket;
+            s->spec.valid = false;
+            s->prep[ws].valid = false;                                // (its pyramid has been used: the pair was tracked on the side stream)
+        }
     }
-    if (s->fused_filter) {
-        hipLaunchKernelGGL(frame_hypothesis_kernel, dim3(kHyp), dim3(64), 0, s->stream, d, s->p);
-    } else {
-        hipLaunchKernelGGL(frame_filter_kernel, dim3(1), dim3(256), 0, s->stream, d, s->p);
-        rc = mqs_pnp_ransac_launch(d.objp_t, d.imgp_t, kMaxTracks, d.cnt + C_NTRI, d.intr, d.samples, kHyp, kSample, s->p.max_reproj,
-                                   kSampleIters, kPnpIters, kPnpEps, d.pose_r, d.sel, d.inl_mask, d.pnp_info, s->ws_pnp, s->stream, 1);
-        if (rc != MQS_OK) return rc;
+    if (!launched) {
+        const bool use_spec = s->spec.valid && s->spec_enabled && s->last_decision == 1 && s->spec.prev == prev_img_dev && s->spec.next == img_dev;
+        s->spec.valid = false;
+        s->p.spec = use_spec ? 1 : 0;
+        s->p.gated = 0;
+        s->p.ticket = ticket = ++s->ticket;
+        if (use_spec) {
+            ws = s->spec.ws;
+            MQS_HIP_CHECK(hipStreamWaitEvent(s->stream, s->spec.done, 0));
+            s->prep[ws].valid = false;
+        } else {
+            for (int k = 0; k < 2; ++k)
+                if (s->prep[k].valid && s->prep[k].prev == prev_img_dev && s->prep[k].next == img_dev) { ws = k; phases = 2; }
+            if (ws < 0) ws = (s->prep[0].valid && s->prep[0].prev == img_dev) ? 1 : 0;
+            if (ws == 1 && !s->ws_lk2) ws = 0;
+            if (s->prep[ws].has_event && (s->prep[ws].valid || phases == 2)) MQS_HIP_CHECK(hipStreamWaitEvent(s->stream, s->prep[ws].done, 0));
+            s->prep[ws].valid = false;
+            rc = mqs_lk_launch(prev_img_dev, img_dev, s->p.W, s->p.H, d.pts, kMaxTracks, d.cnt + C_N, 21, 21, 3, 30, 0.01, 1e-4, d.lk_pts,
+                               d.lk_st, d.lk_err, ws == 0 ? s->ws_lk : s->ws_lk2, s->ws_lk_bytes, s->stream, phases);
+            if (rc != MQS_OK) return rc;
+        }
+        if (s->fused_filter) {
+            hipLaunchKernelGGL(frame_hypothesis_kernel, dim3(kHyp), dim3(64), 0, s->stream, d, s->p);
+        } else {
+            hipLaunchKernelGGL(frame_filter_kernel, dim3(1), dim3(256), 0, s->stream, d, s->p);
+            rc = mqs_pnp_ransac_launch(d.objp_t, d.imgp_t, kMaxTracks, d.cnt + C_NTRI, d.intr, d.samples, kHyp, kSample, s->p.max_reproj,
+                                       kSampleIters, kPnpIters, kPnpEps, d.pose_r, d.sel, d.inl_mask, d.pnp_info, s->ws_pnp, s->stream, 1);
+            if (rc != MQS_OK) return rc;
+        }
+        if (s->pyr_stream) MQS_HIP_CHECK(hipEventRecord(s->hyp_done, s->stream));      // this frame's kept tracks (t_pts, C_NKEEP) are written
+        hipLaunchKernelGGL(frame_decide_kernel, dim3(s->decide_grid), dim3(256), (size_t)kMaxTracks * 40, s->stream, d, s->p);
+        MQS_HIP_CHECK(hipGetLastError());
     }
-    if (s->pyr_stream) MQS_HIP_CHECK(hipEventRecord(s->hyp_done, s->stream));      // this frame's kept tracks (t_pts, C_NKEEP) are written
-    hipLaunchKernelGGL(frame_decide_kernel, dim3(1), dim3(256), (size_t)kMaxTracks * 40, s->stream, d, s->p);
-    MQS_HIP_CHECK(hipGetLastError());
     // the NEXT pair's pyramid (mqs_slam_set_next): enqueued on the side stream now, behind this frame's launches -- the host's work for it
     // runs while the device is busy with them, the kernel runs under the pose kernels
     if (s->ahead.set) {
@@ -1363,11 +1527,27 @@ int mqs_slam_track(mqs_slam *s, const uint8_t *prev_img_dev, const uint8_t *img_
             if (rc != MQS_OK) return rc;
             MQS_HIP_CHECK(hipEventRecord(s->spec.done, s->pyr_stream));
             s->spec.valid = true; s->spec.prev = img_dev; s->spec.next = s->prep[wn].next; s->spec.ws = wn;
+            // ... and (mqs_slam_pipeline) the next frame's pose kernels themselves, behind this frame's decision on the loop's stream: they read
+            // that decision on the device and run only behind an ordinary frame.  What the host would pass them then: one more accepted
+            // frame, the same base keyframe, the tracker's results from the side stream.
+            if (s->pipeline && s->fused_filter) {
+                SlamParams pn = s->p;
+                pn.pose_index = s->accepted + 1;
+                pn.spec = 1; pn.gated = 1; pn.ticket = ++s->ticket;
+                MQS_HIP_CHECK(hipStreamWaitEvent(s->stream, s->spec.done, 0));
+                hipLaunchKernelGGL(frame_hypothesis_kernel, dim3(kHyp), dim3(64), 0, s->stream, d, pn);
+                MQS_HIP_CHECK(hipEventRecord(s->hyp_done, s->stream));
+                hipLaunchKernelGGL(frame_decide_kernel, dim3(s->decide_grid), dim3(256), (size_t)kMaxTracks * 40, s->stream, d, pn);
+                MQS_HIP_CHECK(hipGetLastError());
+                s->pre.valid = true; s->pre.prev = img_dev; s->pre.img = s->prep[wn].next; s->pre.ws = wn; s->pre.ticket = pn.ticket;
+            }
         }
     }
-    // (the decision kernel has written the result block into s->res_host and cleared the previous keyframe's flag on the device)
-    MQS_HIP_CHECK(hipStreamSynchronize(s->stream));
-    memcpy(result, s->res_host, kRes * 8);
+    // The decision kernel writes the result block into its slot of the pinned ring and the ticket behind it; the host polls for the ticket
+    // (a stream synchronisation would also wait for the frame enqueued ahead, and wakes up 10-20 us late).
+    rc = wait_result(s, ticket);
+    if (rc != MQS_OK) return rc;
+    memcpy(result, s->res_host + (size_t)(ticket & (kResSlots - 1)) * kResStride, kRes * 8);
     s->last_decision = (int)result[R_DECISION];
     if (result[R_DECISION] >= 1.0) s->accepted += 1;
     if (result[R_DECISION] == 2.0) {
@@ -1435,6 +1615,20 @@ static int prepare_next_into(mqs_slam *s, const uint8_t *prev_img_dev, int prev_
     if (rc != MQS_OK) return rc;
     MQS_HIP_CHECK(hipEventRecord(s->prep[ws].done, s->pyr_stream));
     s->prep[ws].valid = true; s->prep[ws].prev = prev_img_dev; s->prep[ws].next = next_img_dev;
+    return MQS_OK;
+}
+
+// on = 1: a frame named by mqs_slam_set_next is not only prepared (pyramid, tracker) but ENQUEUED -- its hypotheses and decision behind
+// the current frame's decision on the loop's stream, before the call waits for the current frame's result.  The kernels look at the
+// current frame's decision on the device: behind an ordinary frame they run (no host round trip between the two frames: ~30 us of a
+// frame's ~125), behind a keyframe or a rejected frame they do nothing and the next mqs_slam_track issues the frame as usual.  The
+// contract: after a call that returned an ordinary frame, the next mqs_slam_track MUST be for (this image, the named next image)
+// (MQS_E_ARG otherwise), and whatever reads the handle's state between the two calls may already see that frame in it.  Same results.
+int mqs_slam_pipeline(mqs_slam *s, int on)
+{
+    MQS_ARG_CHECK(s != nullptr, "handle");
+    MQS_ARG_CHECK(!(s->pre.valid && s->last_decision == 1), "a frame is enqueued: track it first");
+    s->pipeline = on != 0;
     return MQS_OK;
 }
 

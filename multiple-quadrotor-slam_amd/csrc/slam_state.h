@@ -10,9 +10,10 @@ constexpr int kHyp = 256, kSample = 6;          // RANSAC: hypotheses per frame,
 constexpr int kSampleIters = 5, kPnpIters = 100;
 constexpr double kPnpEps = 1e-10;
 constexpr int kRes = 40;                        // doubles in the result block
+constexpr int kResSlots = 4, kResStride = 64;   // the pinned result ring: a block + its ticket word per launched decision (slot = ticket & 3)
 
 // counters in device memory
-enum { C_N = 0, C_NLAND, C_NEXT_TID, C_FRAME, C_NTRI, C_NKEEP, C_KF_PENDING, C_NLOG, C_LOG_OVERFLOW, C_COUNT };   // C_LOG_OVERFLOW: sticky, an observation did not fit the log
+enum { C_N = 0, C_NLAND, C_NEXT_TID, C_FRAME, C_NTRI, C_NKEEP, C_KF_PENDING, C_NLOG, C_LOG_OVERFLOW, C_LAST_DECISION, C_COUNT };   // C_LOG_OVERFLOW: sticky, an observation did not fit the log; C_LAST_DECISION: of the last frame that was decided (what an enqueued-ahead frame looks at)
 // result block (doubles)
 enum { R_DECISION = 0, R_REASON, R_NTRACKS, R_NTRI, R_NINL, R_NOLD, R_NNEW, R_LOST, R_OUTLIER, R_REPROJ, R_HOMOGRAPHY, R_NLAND,
        R_POSE = 12, R_KF_VALID = 24, R_KF_NGOOD, R_KF_NTRACKS, R_KF_NLAND, R_KF_POSE = 28 };
@@ -48,6 +49,7 @@ struct SlamDev {
     double *pnp_poses;               // the RANSAC workspace's pieces the decision kernel reads (mqs_pnp_workspace_layout)
     int32_t *pnp_counts, *pnp_inl;
     double *res;
+    double *kf_hand;                 // frame_decide_kernel's hand-over between its two workgroups: ticket word, the keyframe test's ratio, its track count
     double *res_out;                 // the pinned host block the decision kernel leaves a copy of `res` in (no copy / fill launches per frame)
     // the observation log for the bundle adjuster (mqs_slam_log_enable; null: off): what slam2.py's BundleAdjustmentInfoContainer is
     // handed (:519-522, 634-641), as flat device arrays -- (landmark, pose index of the accepted frame, pixel) per observation
@@ -75,6 +77,9 @@ struct SlamParams {
     int max_homography_points;      // keyframe_test's random sample (slam2.py:48; the reference: max(4, target / 4), :1088-1089); 0 = all tracks (default)
     int pose_index, base_pose_index; // index this frame gets among the ACCEPTED frames if it is accepted; that of the base keyframe
     int spec;                        // 1: this frame's tracker ran ahead -- its results are lk_*_b[spec_map[i]] for live track i
+    int gated;                       // 1: this frame was enqueued before the frame in front of it was decided (mqs_slam_pipeline): its kernels do
+                                     //    nothing unless that frame was accepted as an ordinary frame (C_LAST_DECISION == 1)
+    unsigned ticket;                 // of this frame's decision launch: the result block goes to slot (ticket & 3) of the pinned ring, the ticket behind it
 };
 
 }  // namespace slamst
@@ -108,9 +113,15 @@ struct mqs_slam {
     struct { bool valid; const uint8_t *prev, *next; hipEvent_t done; bool has_event; } prep[2];
     struct { bool valid; const uint8_t *prev, *next; int ws; hipEvent_t done; } spec;      // the tracker launched ahead for the pair (prev, next) on the pyramid in workspace ws
     hipEvent_t hyp_done;             // behind a frame's hypothesis launch: its kept tracks (t_pts, C_NKEEP) are what the tracker ahead starts from
+    int decide_grid;                 // 2 (default): the keyframe test beside the pose refinement (frame_decide_kernel); MQS_SLAM_DECIDE_SPLIT=0: 1
     bool spec_enabled;               // MQS_SLAM_TRACK_AHEAD=0 switches the tracker ahead off (A/B, tests); the pyramid ahead stays
     int last_decision;               // of the last mqs_slam_track: 0 rejected, 1 frame, 2 keyframe
     struct { bool set; const uint8_t *next; int prev_slot, next_slot; } ahead;      // mqs_slam_set_next: what the next mqs_slam_track prepares behind its own launches
+    // mqs_slam_pipeline: the frame named by mqs_slam_set_next is ENQUEUED (hypotheses + decision, gated on the device) behind the current
+    // one's kernels before the call waits for the current frame's result -- no host round trip between two ordinary frames
+    bool pipeline;
+    struct { bool valid; const uint8_t *prev, *img; int ws; unsigned ticket; } pre;  // the frame whose kernels the previous call enqueued
+    unsigned ticket;                 // decision launches so far
 };
 // slam_ingest.hip: a ring slot's device image and upload event, once the worker has enqueued the copy (false: nothing was uploaded into it)
 bool mqs_slam_ingest_slot(mqs_slam *s, int slot, const uint8_t **image_dev, hipEvent_t *uploaded);

@@ -227,6 +227,8 @@ class DeviceMonoSlam:
         self._prev = None
         self._ingest_free = None         # free slots of the ingest ring (FrameUploader), None: no ring
         self.prepare_next = True         # the next pair's pyramid ahead of its frame, where the next image is known (handle_new_frame)
+        self.pipeline = True             # ... and that frame's pose kernels enqueued behind this frame's (mqs_slam_pipeline): no host round trip
+        self._pipeline_on = False        #     between two ordinary frames; off with the recorder (it reads the tracks after every frame)
         self._max_landmarks = int(max_landmarks)
         self.ba_info = ba_info
         if bundle_adjust not in (None, "keyframe"):
@@ -373,6 +375,10 @@ class DeviceMonoSlam:
         if self.ba_info is not None:
             self.ba_info.next_step()                         # slam2.py:1204: one step per frame, rejected ones included
         p_prev, p_img = self._img_ptr(self._prev, self.shape, sync=False), self._img_ptr(img, self.shape)
+        want = bool(self.pipeline and self.prepare_next and self.ba_info is None)
+        if want != self._pipeline_on:
+            _lib.check(_lib.lib().mqs_slam_pipeline(self._h, 1 if want else 0))
+            self._pipeline_on = want
         if self.prepare_next:
             # the pyramid of the NEXT pair on the library's side stream, under this frame's pose kernels: named here, enqueued by the track call
             # behind its own launches (mqs_slam_set_next / mqs_slam_prepare_next)

@@ -343,7 +343,8 @@ def test_device_loop_launch_forms_give_the_same_run(gpu, monkeypatch):
     """The loop's fused launches against the forms they replaced, on the rendered sequence incl. one broken frame (a rejection): the
     track filter inside the RANSAC hypotheses' launch (every hypothesis' wavefront compacts the tracks for itself; workgroup 0 writes
     the frame's state) against the one-workgroup filter kernel + the hypotheses (MQS_SLAM_FUSED_FILTER=0); the tracker's pyramid in
-    one launch against one per level (MQS_LK_PYRAMID_PER_LEVEL=1).  Same decisions, same poses bit for bit, same tracks."""
+    one launch against one per level (MQS_LK_PYRAMID_PER_LEVEL=1); the decision kernel's two workgroups -- the keyframe test beside the
+    pose refinement -- against one doing both in turn (MQS_SLAM_DECIDE_SPLIT=0).  Same decisions, same poses bit for bit, same tracks."""
     import torch
     seq, objp, imgp, imgs = _rendered(gpu, 30)
     imgs = list(imgs)
@@ -364,7 +365,7 @@ def test_device_loop_launch_forms_give_the_same_run(gpu, monkeypatch):
         return rets, poses, tracks
     base = run()
     assert 0 in base[0] and 2 in base[0]
-    for env in ({"MQS_SLAM_FUSED_FILTER": "0"}, {"MQS_LK_PYRAMID_PER_LEVEL": "1"}):
+    for env in ({"MQS_SLAM_FUSED_FILTER": "0"}, {"MQS_LK_PYRAMID_PER_LEVEL": "1"}, {"MQS_SLAM_DECIDE_SPLIT": "0"}):
         other = run(**env)
         assert other[0] == base[0], env
         for a, b in zip(base[1], other[1]):
@@ -922,12 +923,16 @@ def test_frame_ingest_on_a_side_stream_gives_the_same_run(gpu, source):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("pipeline", [False, True], ids=["prepared", "enqueued"])
 @pytest.mark.parametrize("frames_from", ["device tensors", "ingest ring"])
-def test_next_pairs_pyramid_ahead_of_its_frame_gives_the_same_run(gpu, frames_from):
+def test_next_pairs_pyramid_ahead_of_its_frame_gives_the_same_run(gpu, frames_from, pipeline):
     """`mqs_slam_prepare_next`: the tracker's pyramid of the NEXT image pair is built on a side stream under the current frame's pose
     kernels; the next `mqs_slam_track` finds it by the two image pointers and runs the tracker alone.  Same decisions, poses and tracks,
     bit for bit, as with the pyramid built inside every call -- including a frame the tracker loses (its pair was prepared and never
-    comes: the following frame is tracked from the lost frame's predecessor, pyramid built in the call) and the keyframes' top-ups."""
+    comes: the following frame is tracked from the lost frame's predecessor, pyramid built in the call) and the keyframes' top-ups.
+    The same holds with the pair also TRACKED ahead (behind the current frame's hypotheses; the default wherever the pyramid is ahead) and,
+    `pipeline`, with the next frame's pose kernels ENQUEUED behind the current frame's decision (`mqs_slam_pipeline`: they run behind an
+    ordinary frame and do nothing behind a keyframe or a lost frame -- all three occur here)."""
     import torch
     seq, objp, imgp, imgs = _rendered(gpu, 34)
     imgs = list(imgs)
@@ -937,6 +942,7 @@ def test_next_pairs_pyramid_ahead_of_its_frame_gives_the_same_run(gpu, frames_fr
     def run(ahead):
         slam = gpu.slam_device.DeviceMonoSlam(seq.K, seq.dist, (seq.H, seq.W), seed=2, bundle_adjust="keyframe")
         slam.prepare_next = ahead
+        slam.pipeline = pipeline
         rets = []
         if frames_from == "device tensors":
             slam.start(imgs[0], objp, imgp)
@@ -955,3 +961,19 @@ def test_next_pairs_pyramid_ahead_of_its_frame_gives_the_same_run(gpu, frames_fr
     for a, b in zip(plain[2], ahead[2]):
         np.testing.assert_array_equal(a, b)
     np.testing.assert_array_equal(plain[3], ahead[3])
+
+@pytest.mark.gpu
+def test_a_frame_enqueued_ahead_has_to_be_the_next_one_tracked(gpu):
+    """`mqs_slam_pipeline`'s contract: behind an ordinary frame the frame named by `mqs_slam_set_next` is already running -- tracking
+    another one is MQS_E_ARG (not a silently different run), and so is switching the pipeline off in between."""
+    seq, objp, imgp, imgs = _rendered(gpu, 8)
+    slam = gpu.slam_device.DeviceMonoSlam(seq.K, seq.dist, (seq.H, seq.W), seed=2)
+    slam.start(imgs[0], objp, imgp)
+    k = 1
+    while slam.handle_new_frame(imgs[k], imgs[k + 1]) != 1 or k == 1:       # (the first call creates the side stream: nothing runs ahead of it)
+        k += 1
+    L = gpu._lib.lib()
+    assert L.mqs_slam_pipeline(slam._h, 0) == -1 and b"enqueued" in L.mqs_last_error()
+    with pytest.raises(RuntimeError, match="enqueued"):
+        slam.handle_new_frame(imgs[k + 2])
+    slam.close()

@@ -65,7 +65,7 @@ REFERENCE_NOISE = mqslam_amd.slam_device.REFERENCE_NOISE      # BA_info.noise.*-
 
 
 def run(frames=None, bundle_adjust=None, seed=0, device=True, reassociate=False, window="default", out_dir=None, screen=None, noise=None, engine="device",
-        history=None, window_point_sigma="default", carry=True, check=False, upload=None, screen_iterations="default", prepare_next=True):
+        history=None, window_point_sigma="default", carry=True, check=False, upload=None, screen_iterations="default", prepare_next=True, pipeline=True):
     """upload: None -- every frame is on the device before the clock starts (the loop's kernels alone); "pinned" -- the frames lie in ONE pinned host
     buffer and go to the device inside the timed loop, on a side stream under the previous frames' kernels (`slam_device.FrameUploader`);
     "pageable" -- they lie in ordinary numpy arrays and pass through pinned staging slots on the uploader's thread.
@@ -98,6 +98,7 @@ def run(frames=None, bundle_adjust=None, seed=0, device=True, reassociate=False,
             slam.ba_window_point_sigma = window_point_sigma
         slam.ba_carry = carry
         slam.prepare_next = prepare_next
+        slam.pipeline = pipeline
         t0 = time.perf_counter()
         if upload is None:
             slam.start(imgs[0], objp, imgp)

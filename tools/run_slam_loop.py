@@ -38,7 +38,7 @@ def run(frames=60, verbose=False, ba_info=None, out_files=None):
             "frames_per_s": round((frames - 1) / sum(slam.timing), 1)}
 
 
-def run_device(frames=60, verbose=False, repeats=1, ba_info=None, out_files=None, bundle_adjust=None, reassociate=False, seed=1, keep=False, upload=None, prepare_next=True, **slam_kw):
+def run_device(frames=60, verbose=False, repeats=1, ba_info=None, out_files=None, bundle_adjust=None, reassociate=False, seed=1, keep=False, upload=None, prepare_next=True, pipeline=True, **slam_kw):
     """The same sequence through slam_device.DeviceMonoSlam: the loop's state resident on the GPU, one library call per frame
     (images uploaded beforehand, as a capture thread would have them).  `repeats` > 1: the run is repeated on a fresh handle and
     the fastest pass is timed (the first pass pays the first-launch costs of every kernel)."""
@@ -62,6 +62,7 @@ def run_device(frames=60, verbose=False, repeats=1, ba_info=None, out_files=None
         slam = mqslam_amd.slam_device.DeviceMonoSlam(seq.K, seq.dist, (seq.H, seq.W), seed=seed, verbose=verbose, ba_info=ba_info,
                                                      bundle_adjust=bundle_adjust, reassociate=reassociate, **slam_kw)
         slam.prepare_next = prepare_next
+        slam.pipeline = pipeline
         if upload is None:
             slam.start(imgs[0], objp, imgp)
             t0 = time.perf_counter()
