@@ -226,19 +226,30 @@ __device__ __forceinline__ void merge_runs_desc(const unsigned long long *__rest
     }
 }
 
+// A/B builds only (-DMQS_GFTT_STAMPS): the kernel's phases in 100 MHz ticks, printed by thread 0 (tools/probes: gather, sort, rounds)
+#ifdef MQS_GFTT_STAMPS
+#define MQS_GSTAMP(i) do { if (threadIdx.x == 0) gst[i] = wall_clock64(); } while (0)
+#else
+#define MQS_GSTAMP(i) do { } while (0)
+#endif
 template <bool IN_LDS>
 __global__ __launch_bounds__(kSelThreads) void sort_select_kernel(unsigned long long *__restrict__ keys_seg,
                                                                   unsigned long long *__restrict__ keys_io,
                                                                   const unsigned int *__restrict__ wg_count, unsigned int ntiles, int W,
                                                                   int H, float min_distance, int max_corners, int out_capacity,
                                                                   unsigned int *__restrict__ grid_global, float *__restrict__ out_xy,
-                                                                  int *__restrict__ out_n, int poll_rounds)
+                                                                  int *__restrict__ out_n)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned int sGrid[];
     const unsigned long long *keys = keys_io;
     __shared__ unsigned int sScan[kSelThreads / 64];
     __shared__ unsigned int sTotal;
     unsigned long long *tmp = keys_seg;                    // the segments are free once gathered: merge buffer
+#ifdef MQS_GFTT_STAMPS
+    unsigned long long gst[6] = {0, 0, 0, 0, 0, 0};
+    int n_rounds = 0;
+#endif
+    MQS_GSTAMP(0);
     {
         // gather the tiles' segments into keys_io, tile after tile: thread t owns a contiguous range of tiles
         const int tid = threadIdx.x;
@@ -266,6 +277,7 @@ __global__ __launch_bounds__(kSelThreads) void sort_select_kernel(unsigned long 
         }
         __syncthreads();
     }
+    MQS_GSTAMP(1);
     {
         unsigned long long *sK = reinterpret_cast<unsigned long long *>(sGrid);
         const unsigned int cnt = sTotal;
@@ -296,18 +308,14 @@ __global__ __launch_bounds__(kSelThreads) void sort_select_kernel(unsigned long 
         }
         __syncthreads();                                   // the sorted keys are in global memory; the LDS is free
     }
+    MQS_GSTAMP(2);
 #ifdef MQS_GFTT_EXPERIMENT_SORT_ONLY                        // (timing only: the gather and the sort, no selection)
     if (threadIdx.x == 0) out_n[0] = (int)sTotal;
     if (W > 0) return;
 #endif
-    constexpr int kBuckets = 2048;                         // hash table of the round's survivors by grid cell
-    __shared__ unsigned int sSurv[kSelThreads];            // survivors of the pre-filter, in candidate order: x | y << 16
-    __shared__ int sState[kSelThreads];                    // 0 undecided, 1 accepted, 2 rejected
-    __shared__ short sNext[kSelThreads];
-    __shared__ short sHead[kBuckets];
-    constexpr int kNbr = 8;
-    __shared__ short sNbr[kSelThreads * kNbr];
-    __shared__ int sWaveCount[kSelThreads / 64];
+    __shared__ unsigned long long sMask[kSelThreads];      // a candidate's stronger candidates of its own group of 64 within min_distance
+    __shared__ unsigned int sPos[kSelThreads];
+    __shared__ int sAccepted;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned int n = sTotal;
     int accepted = 0;                                      // the same value in every thread
@@ -336,212 +344,110 @@ __global__ __launch_bounds__(kSelThreads) void sort_select_kernel(unsigned long 
         c += ((c + 1) * cell <= v) - (c * cell > v);
         return c;
     };
-    auto bucket_of = [&](int cxx, int cyy) { return (int)(((unsigned int)(cyy * gw + cxx) * 2654435761u) >> 21); };   // 11 bits
-    // The greedy rule -- a candidate is a corner unless a STRONGER corner lies closer than min_distance -- is sequential as
-    // written, but its result is a fixed point that can be reached in parallel.  kSelThreads candidates per round, one per
-    // thread, in order of strength:
-    //   1. pre-filter: a candidate closer than min_distance to a corner of an EARLIER round is out (the grid of accepted
-    //      corners, four slots per cell, nine cells to look at);
-    //   2. the survivors go into a hash table by cell, and every undecided one looks at the stronger survivors near it: one
-    //      accepted -> rejected; all rejected (or none) -> accepted; otherwise wait.  The strongest undecided survivor always
-    //      decides, so the sweeps end; on images they end after a handful;
-    //   3. the accepted ones, in order, up to the limit, go to the output and into the grid.
-    // (History: one wavefront walking the sorted list seven candidates at a time, 85 us for the ~1100 candidates a VGA frame
-    // needs for 300 corners; the pre-filter alone changed nothing, the strongest 1024 all survive an empty grid.)
-    // A round's kSelThreads places go to SURVIVORS of the pre-filter, gathered in order from as many candidates as it takes (round 5: a
-    // round took the next kSelThreads candidates, and on a real frame -- thousands of candidates, most of them next to a corner accepted
-    // in the first rounds -- eight rounds of barriers and sweeps decided a handful each: 151 us of a detection's 242).  A candidate the
-    // pre-filter rejects is out for good (the accepted set only grows), so the order of the decisions is the greedy rule's as before.
-    __shared__ unsigned int sNextBase;
-    unsigned int base = 0;
-    while (base < n && accepted < limit) {
-        int nsurv = 0;
-        unsigned int next_base = base;
-        for (unsigned int c0 = base; c0 < n && nsurv < kSelThreads; c0 += kSelThreads) {
-            const unsigned int ci = c0 + threadIdx.x;
-            bool sv = false;
-            unsigned int cpos = 0u;
-            if (ci < n) {
-                cpos = 0xFFFFFFFFu - (unsigned int)(keys[ci] & 0xFFFFFFFFull);
-                const int px = (int)(cpos & 0xFFFFu), py = (int)(cpos >> 16);
+    // The greedy rule -- a candidate is a corner unless a STRONGER corner lies closer than min_distance -- walks the sorted list, and a
+    // candidate's fate depends only on candidates in front of it.  The list goes through in GROUPS OF 64, in order:
+    //   A. (all sixteen wavefronts, one group each, 1024 candidates per pass) every candidate finds the stronger candidates OF ITS OWN
+    //      GROUP within min_distance: 64 broadcasts of a packed position (v_readlane), one bit each -> a 64-bit mask per candidate;
+    //   B. (one wavefront, the pass's groups in order) a candidate closer than min_distance to a corner accepted in an EARLIER group is
+    //      out (the grid of accepted corners: four slots per cell, nine cells); the rest of the group is settled on wave-wide masks --
+    //      a stronger member of the group accepted -> rejected; all of them rejected, or none -> accepted; else wait -- which ends
+    //      after at most 64 looks (the strongest undecided member always decides; on images after two or three); the accepted ones, in
+    //      order, up to the limit, go to the output and into the grid, where the next group's look finds them (a wavefront's LDS
+    //      operations execute in order: no barrier inside B).
+    // (History.  Round 2: one wavefront, seven candidates at a time against the grid: 85 us for 1100 candidates.  Rounds 3-5: a parallel
+    // fixed point over 1024 survivors of a pre-filter per round -- hash table of the survivors by cell, per-survivor lists of up to eight
+    // stronger neighbours, the states settled by sweeps with barriers, then by every survivor polling its neighbours in LDS: on the example
+    // sequence 20-45 us per round BEFORE the first decision and 12-80 us of decisions -- along an edge most candidates have more than eight
+    // stronger ones within twelve pixels and walk the buckets at every look -- 25-170 us per detection.  What is looked at here is what
+    // the rule needs: accepted corners, at most 36 slots, and the 63 other members of the group.)
+    for (unsigned int base = 0; base < n && accepted < limit; base += kSelThreads) {
+        const unsigned int ci = base + threadIdx.x;
+        const unsigned int cpos = ci < n ? 0xFFFFFFFFu - (unsigned int)(keys[ci] & 0xFFFFFFFFull) : 0u;
+        {
+            // closeness is symmetric: the wavefront's vote on "closer than min_distance to member j" IS member j's row (no branches, no
+            // 64-bit selects: the compare's mask goes into lane j)
+            const int px = (int)(cpos & 0xFFFFu), py = (int)(cpos >> 16);
+            unsigned int mlo = 0u, mhi = 0u;
+            if (base + 64u * wave < n)                         // (wavefront-uniform: a group beyond the list has nothing to find)
+#pragma unroll
+            for (int j = 0; j < 64; ++j) {
+                const unsigned int pj = (unsigned int)__builtin_amdgcn_readlane((int)cpos, j);
+                const float dx = (float)(px - (int)(pj & 0xFFFFu)), dy = (float)(py - (int)(pj >> 16));
+                const unsigned long long row = __builtin_amdgcn_ballot_w64(dx * dx + dy * dy < md2);
+                mlo = lane == j ? (unsigned int)row : mlo;
+                mhi = lane == j ? (unsigned int)(row >> 32) : mhi;
+            }
+            sMask[threadIdx.x] = (((unsigned long long)mhi << 32) | mlo) & ((1ull << lane) - 1ull);      // the STRONGER members only
+            sPos[threadIdx.x] = cpos;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            const unsigned long long below = (1ull << lane) - 1ull;
+            for (int g = 0; g < kSelThreads / 64 && base + 64u * g < n && accepted < limit; ++g) {
+                const int t = g * 64 + lane;
+                const bool valid = base + t < n;
+                const unsigned int pos = sPos[t];
+                const unsigned long long m = sMask[t];
+                const int px = (int)(pos & 0xFFFFu), py = (int)(pos >> 16);
                 const int pcx = cell_of(px), pcy = cell_of(py);
                 bool clash = false;
 #pragma unroll
                 for (int k = 0; k < 9; ++k) {
+                    // (every cell read, unconditionally -- a cell off the grid reads cell 0 and is ignored: 36 loads in flight together)
                     const int xx = pcx + k % 3 - 1, yy = pcy + k / 3 - 1;
-                    if (yy >= 0 && yy < gh && xx >= 0 && xx < gw) {
+                    const bool inside = yy >= 0 && yy < gh && xx >= 0 && xx < gw;
+                    const unsigned int *cp = slot_ptr(inside ? (yy * gw + xx) * 4 : 0);
+                    unsigned int v[4];
+                    if constexpr (IN_LDS) {
+                        const uint4 q = *reinterpret_cast<const uint4 *>(cp);
+                        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+                    } else {
+                        // the grid in the workspace: written by this wavefront's atomics (at the L2), read past the vector cache
 #pragma unroll
-                        for (int slot = 0; slot < 4; ++slot) {
-                            const unsigned int v = *slot_ptr((yy * gw + xx) * 4 + slot);
-                            if (v != 0xFFFFFFFFu) {
-                                const float dx = (float)(px - (int)(v & 0xFFFFu)), dy = (float)(py - (int)(v >> 16));
-                                clash = clash || (dx * dx + dy * dy < md2);
-                            }
-                        }
+                        for (int slot = 0; slot < 4; ++slot) v[slot] = __hip_atomic_load(cp + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+#pragma unroll
+                    for (int slot = 0; slot < 4; ++slot) {
+                        const float dx = (float)(px - (int)(v[slot] & 0xFFFFu)), dy = (float)(py - (int)(v[slot] >> 16));
+                        clash = clash || (inside && v[slot] != 0xFFFFFFFFu && dx * dx + dy * dy < md2);
                     }
                 }
-                sv = !clash;
-            }
-            const unsigned long long smask = __ballot(sv);
-            if (lane == 0) sWaveCount[wave] = __popcll(smask);
-            __syncthreads();
-            int soff = 0, stotal = 0;
-#pragma unroll
-            for (int w2 = 0; w2 < kSelThreads / 64; ++w2) {
-                const int cnt = sWaveCount[w2];
-                soff += w2 < wave ? cnt : 0;
-                stotal += cnt;
-            }
-            const int rank = nsurv + soff + __popcll(smask & ((1ull << lane) - 1ull));
-            if (sv && rank < kSelThreads) sSurv[rank] = cpos;
-            if (sv && rank == kSelThreads) sNextBase = ci;             // the first survivor that does not fit: the next round starts with it
-            __syncthreads();
-            if (nsurv + stotal > kSelThreads) { next_base = sNextBase; nsurv = kSelThreads; }
-            else { next_base = c0 + kSelThreads < n ? c0 + kSelThreads : n; nsurv += stotal; }
-        }
-        base = next_base;
-        // thread t decides survivor t (its rank = its priority in the round)
-        const bool survive = (int)threadIdx.x < nsurv;
-        const int me = (int)threadIdx.x;
-        unsigned int pos = 0u;
-        int x = 0, y = 0, cxx = 0, cyy = 0;
-        if (survive) {
-            pos = sSurv[me];
-            x = (int)(pos & 0xFFFFu); y = (int)(pos >> 16);
-            cxx = cell_of(x); cyy = cell_of(y);
-            sState[me] = 0;
-        }
-        for (int b = threadIdx.x; b < kBuckets; b += kSelThreads) sHead[b] = -1;
-        __syncthreads();
-        // chain the survivors of a bucket: lists are built by one thread per bucket walking nobody -- instead every survivor
-        // pushes itself with an atomic exchange on the bucket head (int heads would double the table; the exchange is on the
-        // 32-bit word holding two 16-bit heads, so it is done with a CAS loop on that word)
-        if (survive) {
-            const int b = bucket_of(cxx, cyy);
-            unsigned int *word = reinterpret_cast<unsigned int *>(sHead) + (b >> 1);
-            const int shift = (b & 1) * 16;
-            unsigned int old = *word, assumed;
-            do {
-                assumed = old;
-                const unsigned int repl = (assumed & ~(0xFFFFu << shift)) | ((unsigned int)(unsigned short)me << shift);
-                old = atomicCAS(word, assumed, repl);
-            } while (old != assumed);
-            sNext[me] = (short)((old >> shift) & 0xFFFFu);
-        }
-        __syncthreads();
-        // the stronger survivors within min_distance of this one, found once (the sweeps only re-read their states); a
-        // survivor with more than kNbr of them walks the buckets again in every sweep
-        int nnbr = 0;
-        bool overflow = false;
-        if (survive) {
-#pragma unroll 1
-            for (int k = 0; k < 9; ++k) {
-                const int xx = cxx + k % 3 - 1, yy = cyy + k / 3 - 1;
-                if (yy < 0 || yy >= gh || xx < 0 || xx >= gw) continue;
-                const int b = bucket_of(xx, yy);
-                bool seen = false;                                       // two of the nine cells in one bucket: walk it once
-                for (int k2 = 0; k2 < k; ++k2) {
-                    const int x2 = cxx + k2 % 3 - 1, y2 = cyy + k2 / 3 - 1;
-                    seen = seen || (y2 >= 0 && y2 < gh && x2 >= 0 && x2 < gw && bucket_of(x2, y2) == b);
-                }
-                if (seen) continue;
-                for (int j = sHead[b]; j >= 0; j = sNext[j]) {
-                    if (j >= me) continue;                               // only stronger survivors matter
-                    const unsigned int pj = sSurv[j];
-                    const float dx = (float)(x - (int)(pj & 0xFFFFu)), dy = (float)(y - (int)(pj >> 16));
-                    if (dx * dx + dy * dy < md2) {
-                        if (nnbr < kNbr) sNbr[me * kNbr + nnbr++] = (short)j;
-                        else overflow = true;
+                bool rej = !valid || clash, acc = false;
+                unsigned long long A = 0ull, R = __builtin_amdgcn_ballot_w64(rej);
+                for (int look = 0; look < 64 && (A | R) != ~0ull; ++look) {
+                    if (!rej && !acc) {
+                        if (m & A) rej = true;
+                        else if ((m & ~R) == 0ull) acc = true;
                     }
+                    A = __builtin_amdgcn_ballot_w64(acc);
+                    R = __builtin_amdgcn_ballot_w64(rej);
                 }
-            }
-        }
-        // The decisions, without a barrier (round 5): an undecided survivor polls the states of the stronger survivors near it in LDS until
-        // one of them is accepted (-> rejected) or all of them are rejected (-> accepted), then publishes its own.  A state changes once,
-        // from undecided, so a mixed snapshot can only say "wait"; the strongest undecided survivor never waits, so everybody ends; and
-        // the fixed point is the greedy rule's, whatever the order of the polls.  (The synchronous form -- every survivor looks, a
-        // workgroup barrier, every survivor writes, a second barrier with a vote -- cost three barriers of sixteen wavefronts per LEVEL of
-        // the dependency chain; on a real frame, where candidates line up along edges, the chains are ~100 deep: 151 us of a detection's
-        // 242.  A poll is an LDS round trip.)
-        // The loop is left by the WAVEFRONT as a whole (a vote): a lane that left on its own would publish its state only where the
-        // wavefront's lanes meet again behind the loop -- which the lanes waiting for that state never reach (measured: the launch hangs).
-        int state = survive ? 0 : 2;
-        // what an undecided survivor sees of the stronger survivors near it: 2 (one is accepted: rejected), 1 (all are rejected, or
-        // there are none: accepted), 0 (wait)
-        auto look = [&](volatile int *vState) {
-            bool rejected = false, pending = false;
-            for (int t = 0; t < nnbr; ++t) {
-                const int sj = vState[sNbr[me * kNbr + t]];
-                rejected = rejected || sj == 1;
-                pending = pending || sj == 0;
-            }
-            if (overflow) {
-#pragma unroll 1
-                for (int k = 0; k < 9; ++k) {
-                    const int xx = cxx + k % 3 - 1, yy = cyy + k / 3 - 1;
-                    if (yy < 0 || yy >= gh || xx < 0 || xx >= gw) continue;
-                    for (int j = sHead[bucket_of(xx, yy)]; j >= 0; j = sNext[j]) {
-                        if (j >= me) continue;
-                        const unsigned int pj = sSurv[j];
-                        const float dx = (float)(x - (int)(pj & 0xFFFFu)), dy = (float)(y - (int)(pj >> 16));
-                        if (dx * dx + dy * dy < md2) {
-                            const int sj = vState[j];
-                            rejected = rejected || sj == 1;
-                            pending = pending || sj == 0;
-                        }
-                    }
+                const int arank = accepted + __popcll(A & below);
+                if (acc && arank < limit) {
+                    out_xy[2 * arank] = (float)px;
+                    out_xy[2 * arank + 1] = (float)py;
+                    // a free slot of the corner's cell (corners >= cell - 0.5 apart: at most four per cell)
+                    unsigned int *slots = slot_ptr((pcy * gw + pcx) * 4);
+                    for (int slot = 0; slot < 4; ++slot)
+                        if (atomicCAS(slots + slot, 0xFFFFFFFFu, pos) == 0xFFFFFFFFu) break;
                 }
+                accepted += __popcll(A);
+                if (accepted > limit) accepted = limit;
             }
-            return rejected ? 2 : (pending ? 0 : 1);
-        };
-        {
-            // (bounded: `poll_rounds` polls per wavefront -- every round some survivor decides, a workgroup's chain is at most
-            // kSelThreads long, so the bound is never reached unless the forward-progress assumption between wavefronts breaks;
-            // what is left undecided then is settled by the synchronous sweeps below, not by a hang)
-            volatile int *vState = sState;
-            for (int round = 0; round < poll_rounds; ++round) {
-                if (state == 0) {
-                    state = look(vState);
-                    if (state != 0) vState[me] = state;
-                }
-                if (__builtin_amdgcn_ballot_w64(state == 0) == 0ull) break;
-            }
-        }
-        // the net under the polling (and the whole rule when poll_rounds = 0, the A/B form): every undecided survivor looks, a
-        // workgroup barrier, every one that decided writes, a barrier with a vote -- until nobody is undecided
-        while (__syncthreads_or(state == 0)) {
-            const int ns = state == 0 ? look(sState) : state;
-            __syncthreads();
-            if (ns != state) { state = ns; sState[me] = state; }
+            if (lane == 0) sAccepted = accepted;
         }
         __syncthreads();
-        // the accepted survivors in order
-        const bool acc = survive && state == 1;
-        const unsigned long long amask = __ballot(acc);
-        __syncthreads();
-        if (lane == 0) sWaveCount[wave] = __popcll(amask);
-        __syncthreads();
-        int aoff = 0, atotal = 0;
-#pragma unroll
-        for (int w2 = 0; w2 < kSelThreads / 64; ++w2) {
-            const int cnt = sWaveCount[w2];
-            aoff += w2 < wave ? cnt : 0;
-            atotal += cnt;
-        }
-        const int arank = accepted + aoff + __popcll(amask & ((1ull << lane) - 1ull));
-        if (acc && arank < limit) {
-            out_xy[2 * arank] = (float)x;
-            out_xy[2 * arank + 1] = (float)y;
-            // a free slot of the corner's cell (corners >= cell - 0.5 apart: at most four per cell)
-            unsigned int *slots = slot_ptr((cyy * gw + cxx) * 4);
-            for (int slot = 0; slot < 4; ++slot)
-                if (atomicCAS(slots + slot, 0xFFFFFFFFu, pos) == 0xFFFFFFFFu) break;
-        }
-        accepted += atotal;
-        if (accepted > limit) accepted = limit;
-        __syncthreads();                                         // the grid is complete before the next round's pre-filter
+        accepted = sAccepted;
+#ifdef MQS_GFTT_STAMPS
+        n_rounds += 1;
+#endif
     }
     if (threadIdx.x == 0) out_n[0] = accepted;
+#ifdef MQS_GFTT_STAMPS
+    MQS_GSTAMP(3);
+    if (threadIdx.x == 0) printf("GFTT candidates %u accepted %d limit %d passes %d  gather %.1f sort %.1f select %.1f us\n", n, accepted, limit, n_rounds,
+                                 (gst[1] - gst[0]) / 100.0, (gst[2] - gst[1]) / 100.0, (gst[3] - gst[2]) / 100.0);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1156,19 +1062,17 @@ int mqs_good_features_to_track_dev(const uint8_t *img, int W, int H, int max_cor
     const bool in_lds = min_distance < 1.0 || grid_lds <= sort_lds;      // the grid takes the sort buffer's place
     // polls per wavefront of the selection's barrier-free decisions before the synchronous sweeps take over (never reached in
     // practice; MQS_GFTT_POLL_ROUNDS=0 runs the synchronous rule alone: the A/B form the tests compare)
-    int poll_rounds = 1 << 16;
-    if (const char *e = getenv("MQS_GFTT_POLL_ROUNDS")) poll_rounds = atoi(e) < 0 ? 0 : atoi(e);
     const size_t lds = sort_lds;
     if (in_lds) {
         static mqs_lds_opt_in opt;                           // per device
         MQS_HIP_CHECK(mqs_lds_opt_in_once(opt, reinterpret_cast<const void *>(sort_select_kernel<true>), (int)sort_lds));
         hipLaunchKernelGGL(sort_select_kernel<true>, dim3(1), dim3(kSelThreads), lds, stream, keys_seg, keys, wg_count, (unsigned int)ntiles, W,
-                           H, (float)min_distance, max_corners, out_capacity, grid, out_xy, out_n, poll_rounds);
+                           H, (float)min_distance, max_corners, out_capacity, grid, out_xy, out_n);
     } else {
         static mqs_lds_opt_in opt;                           // per device
         MQS_HIP_CHECK(mqs_lds_opt_in_once(opt, reinterpret_cast<const void *>(sort_select_kernel<false>), (int)sort_lds));
         hipLaunchKernelGGL(sort_select_kernel<false>, dim3(1), dim3(kSelThreads), sort_lds, stream, keys_seg, keys, wg_count,
-                           (unsigned int)ntiles, W, H, (float)min_distance, max_corners, out_capacity, grid, out_xy, out_n, poll_rounds);
+                           (unsigned int)ntiles, W, H, (float)min_distance, max_corners, out_capacity, grid, out_xy, out_n);
     }
     MQS_HIP_CHECK(hipGetLastError());
     return MQS_OK;

@@ -136,20 +136,21 @@ def test_gpu_good_features_more_candidates_than_one_sort_chunk(md, gpu):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("rounds", ["0", "3"])
-def test_gpu_good_features_selection_with_a_spent_poll_bound(rounds, gpu, monkeypatch):
-    """The selection's decisions propagate by polling LDS states without a workgroup barrier; the polling is BOUNDED (round 6: it was
-    not) and what it leaves undecided is settled by synchronous sweeps (look, barrier, write, barrier with a vote).  With the bound at
-    0 the sweeps are the whole rule, at 3 they take over in the middle of the dependency chains (the noise frame's are long): the same
-    corners in the same order as the oracle either way."""
-    monkeypatch.setenv("MQS_GFTT_POLL_ROUNDS", rounds)
+@pytest.mark.parametrize("min_distance", [1.0, 2.0, 5.0, 12.0, 30.0, 64.0])
+def test_gpu_good_features_selection_walks_the_list_in_groups_like_the_greedy_rule(min_distance, gpu):
+    """The minimum-distance selection goes through the sorted candidates 64 at a time (round 6): against the corners accepted in earlier
+    groups through the grid, inside a group on wave-wide masks settled by repeated looks.  A frame of noise makes the dependency chains
+    inside a group long at large distances (most of a group lies within 30 or 64 pixels of each other) and the groups many at small
+    ones; the limit cuts a group in the middle.  The same corners in the same order as the oracle's sequential walk."""
     rng = np.random.default_rng(12)
     img = rng.integers(0, 256, (480, 640), dtype=np.uint8)
-    ref = Fn.good_features_to_track(img, 0, 1e-4, 3.0)
-    got = gpu.features.goodFeaturesToTrack(img, 0, 1e-4, 3.0, capacity=len(ref) + 8)
+    ref = Fn.good_features_to_track(img, 0, 1e-4, min_distance)
+    got = gpu.features.goodFeaturesToTrack(img, 0, 1e-4, min_distance, capacity=len(ref) + 8)
     np.testing.assert_array_equal(got, ref)
+    for limit in (1, 37, 64, 65, 300):
+        np.testing.assert_array_equal(gpu.features.goodFeaturesToTrack(img, limit, 1e-4, min_distance), ref[:limit])
     tex = texture(240, 320, seed=240)
-    np.testing.assert_array_equal(gpu.features.goodFeaturesToTrack(tex, 300, 0.01, 7.0), Fn.good_features_to_track(tex, 300, 0.01, 7.0))
+    np.testing.assert_array_equal(gpu.features.goodFeaturesToTrack(tex, 300, 0.01, min_distance), Fn.good_features_to_track(tex, 300, 0.01, min_distance))
 
 
 @pytest.mark.gpu
