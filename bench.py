@@ -842,8 +842,11 @@ def main():
                 run_icl_nuim.run(80)                                              # first-launch costs
                 def both(frames, **kw):
                     """frames resident before the clock starts / arriving inside the timed loop (ordinary host arrays -> FrameUploader)"""
-                    ra, rb = [run_icl_nuim.run(frames, **kw) for _ in range(3)], [run_icl_nuim.run(frames, upload="pageable", **kw) for _ in range(3)]
-                    a, b = max(ra, key=lambda r: r["frames_per_s"]), max(rb, key=lambda r: r["frames_per_s"])      # (the same run three times: the fastest pass, like run_device's `repeats`)
+                    ra, rb = [], []
+                    for _ in range(4):                                            # (interleaved: a host thread that landed badly -- the boxes are shared, load average ~30 -- does not cost ONE form all its passes)
+                        ra.append(run_icl_nuim.run(frames, **kw))
+                        rb.append(run_icl_nuim.run(frames, upload="pageable", **kw))
+                    a, b = max(ra, key=lambda r: r["frames_per_s"]), max(rb, key=lambda r: r["frames_per_s"])      # (the same run four times: the fastest pass, like run_device's `repeats`)
                     a["frames_per_s_with_upload"] = b["frames_per_s"]
                     a["same_trajectory_with_upload"] = a["ours_vs_groundtruth_rmse_m"] == b["ours_vs_groundtruth_rmse_m"]
                     return a
