@@ -760,6 +760,9 @@ def main():
     if rank == 0 and not args.no_frontend:
         try:
             import ctypes
+            import gc
+            if os.environ.get("MQS_BENCH_GC", "off") == "off":
+                gc.collect(); gc.freeze(); gc.disable()     # (the loop legs are host-driven at ~100 us per frame: a collection over this process's objects inside one is not the loop's cost)
             rng = np.random.default_rng(5)
             Hh, Ww = 480, 640
             yy, xx = np.mgrid[0:Hh, 0:Ww].astype(np.float32)

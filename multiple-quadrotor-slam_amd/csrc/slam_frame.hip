@@ -1587,7 +1587,16 @@ static int prepare_next_into(mqs_slam *s, const uint8_t *prev_img_dev, int prev_
     MQS_ARG_CHECK(next_img_dev != nullptr || next_slot >= 0, "the next image: a device pointer or a ring slot");
     MQS_HIP_CHECK(hipSetDevice(s->device));
     if (!s->pyr_stream) {
-        MQS_HIP_CHECK(hipStreamCreateWithFlags(&s->pyr_stream, hipStreamNonBlocking));
+        // A hardware queue of its own: the runtime deals its few hardware queues (four by default) to the streams of a process as they
+        // come and go, and in a process that has created and destroyed many streams this one can land on the SAME queue as the loop's
+        // stream -- everything enqueued "beside" the pose kernels then runs behind them (measured inside bench.py: the loop at the
+        // rate of the form without any of it, results the same).  Queues of different priority are different queues, and the priority is
+        // the right one anyway: the tracker ahead is what the next frame's hypotheses wait for.
+        {
+            int least = 0, greatest = 0;
+            MQS_HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+            MQS_HIP_CHECK(hipStreamCreateWithPriority(&s->pyr_stream, hipStreamNonBlocking, greatest));
+        }
         hipError_t e = hipMalloc(&s->ws_lk2, (size_t)s->ws_lk_bytes);
         if (e != hipSuccess) { s->ws_lk2 = nullptr; mqs_set_error("hipMalloc(%lld) failed: %s", (long long)s->ws_lk_bytes, hipGetErrorString(e)); return MQS_E_NOMEM; }
         for (int k = 0; k < 2; ++k) {
