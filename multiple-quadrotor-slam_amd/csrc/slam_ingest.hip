@@ -121,7 +121,13 @@ int mqs_slam_ingest_enable(mqs_slam *s, int slots)
         mqs_set_error("mqs_slam_ingest_enable: %s", hipGetErrorString(e));
         return MQS_E_NOMEM;
     }
-    e = hipStreamCreateWithFlags(&g->up, hipStreamNonBlocking);
+    {
+        // (the lowest stream priority: a hardware queue that is neither the loop's nor its side stream's -- see mqs_slam_set_next's stream in
+        // slam_frame.hip; the copies are two frames ahead of their use)
+        int least = 0, greatest = 0;
+        e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+        if (e == hipSuccess) e = hipStreamCreateWithPriority(&g->up, hipStreamNonBlocking, least);
+    }
     int made = 0;
     for (; e == hipSuccess && made < slots; ++made) e = hipEventCreateWithFlags(&g->ev[made], hipEventDisableTiming);
     if (e != hipSuccess) {
