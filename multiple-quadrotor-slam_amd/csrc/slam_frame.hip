@@ -930,19 +930,34 @@ __global__ __launch_bounds__(256) void frame_decide_kernel(SlamDev d, SlamParams
     const int reason = decide_gates(d, p, sP, sI, sRed);
     double ratio = 1.0;
     int n_acc_kf = 0;
+    bool timed_out = false;
     if (gridDim.x == 1) {
         if (reason == 0) ratio = decide_keyframe_ratio(d, p, frame_no, n_acc_kf);
     } else {
         // the other workgroup's ratio (always waited for: the frame counter below is what it seeds its sample with)
+        // (bounded like every device-side wait of this library: 0.5 s of the 100 MHz clock, looked at every 64th poll; the two workgroups are
+        // one launch of two, so the other one is resident or about to be)
         if (tid == 0) {
-            while (__hip_atomic_load(kf_word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != (unsigned long long)p.ticket) __builtin_amdgcn_s_sleep(1);
-            sHand[0] = __hip_atomic_load(d.kf_hand + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            sHand[1] = __hip_atomic_load(d.kf_hand + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            bool there = true;
+            long long t0 = 0;
+            for (unsigned spins = 0; __hip_atomic_load(kf_word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != (unsigned long long)p.ticket; ++spins) {
+                __builtin_amdgcn_s_sleep(1);
+                if ((spins & 63u) == 63u) {
+                    if (t0 == 0) t0 = wall_clock64();
+                    if (wall_clock64() - t0 > 50000000ll) { there = false; break; }
+                }
+            }
+            sHand[0] = there ? __hip_atomic_load(d.kf_hand + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1.0;
+            sHand[1] = there ? __hip_atomic_load(d.kf_hand + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1.0;
         }
         __syncthreads();
         ratio = sHand[0]; n_acc_kf = (int)sHand[1];
+        if (n_acc_kf < 0) {                                        // the wait gave up: nothing is committed, the call returns MQS_E_TIMEOUT
+            if (tid == 0) { d.res[R_DECISION] = -3.0; d.res[R_REASON] = 7.0; }
+            timed_out = true;
+        }
     }
-    if (reason == 0) decide_commit(d, p, sP, ratio, n_acc_kf);
+    if (reason == 0 && !timed_out) decide_commit(d, p, sP, ratio, n_acc_kf);
     __syncthreads();
     if (tid == 0) d.cnt[C_FRAME] = frame_no;
     if (tid < kRes) {
@@ -1548,6 +1563,11 @@ int mqs_slam_track(mqs_slam *s, const uint8_t *prev_img_dev, const uint8_t *img_
     rc = wait_result(s, ticket);
     if (rc != MQS_OK) return rc;
     memcpy(result, s->res_host + (size_t)(ticket & (kResSlots - 1)) * kResStride, kRes * 8);
+    if (result[R_DECISION] == -3.0) {
+        s->last_decision = 0; s->pre.valid = false; s->spec.valid = false;
+        mqs_set_error("mqs_slam_track: the decision kernel's keyframe-test workgroup did not report within 0.5 s (nothing was committed)");
+        return MQS_E_TIMEOUT;
+    }
     s->last_decision = (int)result[R_DECISION];
     if (result[R_DECISION] >= 1.0) s->accepted += 1;
     if (result[R_DECISION] == 2.0) {
