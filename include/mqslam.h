@@ -760,6 +760,10 @@ int mqs_slam_read_ba_flags(mqs_slam *s, uint8_t *retired, int cap, int32_t *n);
 int mqs_slam_read_ba_edges(mqs_slam *s, int32_t *from, int32_t *to, double *meas, int cap, int32_t *n);
 /* profiling hook: phase stamps of the adjuster's last launch (see csrc/slam_ba.hip); the first call switches them on */
 int mqs_debug_slam_ba_stamps(mqs_slam *s, int64_t *out, int cap, int32_t *n);
+/* test hook: the adjuster's 32 x 32 diagonal-tile Cholesky factor by itself.  form 0: four wavefronts, a workgroup barrier per pivot; 1: one
+ * wavefront, panels of four pivots on the fp64 matrix pipe (round 6's A/B form: measured slower, 7.7 against 6.3 us per tile).  A, out: host, 32 x 32 row-major; out = L in
+ * the lower triangle (diagonal included), inv(L)'s strictly lower part transposed in the strictly upper triangle. */
+int mqs_debug_factor32(const double *A, double *out, int form, int32_t *not_positive_definite);
 /* Frame ingest (csrc/slam_ingest.hip): the reference reads every frame inside its loop (slam2.py:1209-1213); here a frame goes from
  * host memory to the device on a stream of its own while the loop's kernels work on the frames before it.
  *   mqs_slam_ingest_enable  a ring of `slots` device images (W x H bytes each) owned by the handle, an upload stream, one worker

@@ -184,6 +184,7 @@ SIGNATURES = {
     "mqs_slam_read_ba_flags": (ctypes.c_int, [c_vp, ctypes.POINTER(ctypes.c_uint8), ctypes.c_int, c_i32p]),
     "mqs_slam_read_ba_edges": (ctypes.c_int, [c_vp, c_i32p, c_i32p, c_f64p, ctypes.c_int, c_i32p]),
     "mqs_debug_slam_ba_stamps": (ctypes.c_int, [c_vp, ctypes.POINTER(c_i64), ctypes.c_int, c_i32p]),
+    "mqs_debug_factor32": (ctypes.c_int, [c_f64p, c_f64p, ctypes.c_int, c_i32p]),
     "mqs_slam_ingest_enable": (ctypes.c_int, [c_vp, ctypes.c_int]),
     "mqs_slam_upload": (ctypes.c_int, [c_vp, ctypes.c_int, c_vp, ctypes.c_int]),
     "mqs_slam_wait_upload": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.POINTER(c_vp)]),

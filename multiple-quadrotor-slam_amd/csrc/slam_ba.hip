@@ -838,6 +838,24 @@ __device__ __forceinline__ void load_tile(Cx &c, const double *g, double *sT)   
     for (int e = c.tid; e < TB * TB; e += kT) sT[(e >> 5) * TLD + (e & 31)] = ldg(g + e);
 }
 
+// The diagonal tile's factor: the four-wave form with a barrier per pivot (6.3 us per tile; the default), or one wavefront working in
+// panels of four pivots on the matrix pipe (chol_block.h: factor_diag_block_mfma_wave; -DMQS_SLAM_BA_DIAG_MFMA=1).  The blocked form was
+// built in round 6 and measured on the example sequence's 107 factorisations: 71 against 61.5 us per factorisation (7.7 against 6.3 us per
+// tile) -- a lone wavefront pays ~0.96 us per panel of dependent chain (four reciprocal square roots, three LDS hand-overs, the gather
+// for the inverse) where the four-wave form pays four barriers.  It stays as the A/B form (tools/probes/ab_diag_factor_r06.sh) and under
+// its test (mqs_debug_factor32).
+#ifndef MQS_SLAM_BA_DIAG_MFMA
+#define MQS_SLAM_BA_DIAG_MFMA 0
+#endif
+__device__ __forceinline__ void factor_diag_tile(Cx &c, const double *sT, double *tile, int32_t *badw, double *sM)
+{
+#if MQS_SLAM_BA_DIAG_MFMA
+    if (c.wave == 0) mqs::chol::factor_diag_block_mfma_wave<true>(sT, tile, badw, c.lane, sM);
+#else
+    mqs::chol::factor_diag_block_from_lds_4w<true>(sT, tile, TB, 0, badw, c.tid, sM);
+#endif
+}
+
 __device__ __forceinline__ void chol_diag0(Cx &c, double *sT, double *sM, int32_t *badw)
 {
     double *tile = c.b.S + (size_t)tix(0, 0) * (TB * TB);
@@ -847,7 +865,7 @@ __device__ __forceinline__ void chol_diag0(Cx &c, double *sT, double *sM, int32_
     // (a single-wavefront factor without a barrier per pivot -- the column through wave-private LDS, the next pivot's entry by
     // v_readlane -- was built and measured in round 5: 10.8 us per block against this form's 6.3; one wave alone issues a dependent
     // fp64 instruction every ~16 cycles and the 32 reciprocal square roots sit on that chain)
-    mqs::chol::factor_diag_block_from_lds_4w<true>(sT, tile, TB, 0, badw, c.tid, sM);
+    factor_diag_tile(c, sT, tile, badw, sM);
 }
 
 // tile (bi, bj) of step k (k < bj <= bi): A(bi, bj) -= X_i X_j^T with X = A(., k) inv(L_kk)^T formed here; the tiles of column
@@ -913,7 +931,7 @@ __device__ __forceinline__ void chol_task(Cx &c, int k, int bi, int bj, double *
     }
     if (!next_diag) return;
     __syncthreads();
-    mqs::chol::factor_diag_block_from_lds_4w<true>(sT, tile, TB, 0, badw, c.tid, sM);
+    factor_diag_tile(c, sT, tile, badw, sM);
 }
 
 __device__ __forceinline__ bool phase_cholesky(Cx &c, double *sBuf, int32_t *badw)
@@ -1955,6 +1973,17 @@ int ba_run(mqs_slam *s, const mqs_slam_ba_params *q, const mqs_slam_ba_window *w
     return MQS_OK;
 }
 
+__global__ __launch_bounds__(kT) void debug_factor32_kernel(const double *A, double *out, int32_t *bad, int form)
+{
+    __shared__ double sT[TB * TLD];
+    __shared__ double sM[256];
+    const int tid = threadIdx.x;
+    for (int e = tid; e < TB * TB; e += kT) sT[(e >> 5) * TLD + (e & 31)] = A[e];
+    __syncthreads();
+    if (form == 0) mqs::chol::factor_diag_block_from_lds_4w<true>(sT, out, TB, 0, bad, tid, sM);
+    else if (tid < 64) mqs::chol::factor_diag_block_mfma_wave<true>(sT, out, bad, tid, sM);
+}
+
 }  // namespace
 
 extern "C" {
@@ -1992,6 +2021,26 @@ int mqs_slam_ba_resident_groups(mqs_slam *s, int32_t *groups)
 // LAST mqs_slam_bundle_adjust: out [cap][2] int64 = (phase id, ticks of the 100 MHz wall clock) as workgroup 0 passed them; *n = stamps
 // taken.  Phase ids: 0 start, 1 tables cleared, 2 log in the table, 3 lists built, 4 a pass's LM begins, 10..19 inside a trial (records,
 // barrier, system, barrier, Cholesky, back-substitution, barrier, landmarks + cost, cost reduced), 5 screen, 6 write-back, 7 end.
+// test hook: the 32 x 32 diagonal-tile factor by itself (form 0: four wavefronts, a barrier per pivot; 1: one wavefront, panels of four
+// pivots on the matrix pipe).  A, out: HOST, 32 x 32 row-major; out = L in the lower triangle, inv(L)'s strictly lower part transposed above it.
+int mqs_debug_factor32(const double *A, double *out, int form, int32_t *not_positive_definite)
+{
+    MQS_ARG_CHECK(A != nullptr && out != nullptr && not_positive_definite != nullptr && (form == 0 || form == 1), "A, out, flag; form 0 or 1");
+    double *dA = nullptr;
+    MQS_HIP_CHECK(hipMalloc((void **)&dA, (2 * TB * TB + 8) * sizeof(double)));
+    hipError_t e = hipMemcpy(dA, A, TB * TB * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(dA + TB * TB, 0, (TB * TB + 8) * sizeof(double));
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(debug_factor32_kernel, dim3(1), dim3(kT), 0, nullptr, dA, dA + TB * TB, reinterpret_cast<int32_t *>(dA + 2 * TB * TB), form);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(out, dA + TB * TB, TB * TB * sizeof(double), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(not_positive_definite, dA + 2 * TB * TB, 4, hipMemcpyDeviceToHost);
+    (void)hipFree(dA);
+    MQS_HIP_CHECK(e);
+    return MQS_OK;
+}
+
 int mqs_debug_slam_ba_stamps(mqs_slam *s, int64_t *out, int cap, int32_t *n)
 {
     MQS_ARG_CHECK(s != nullptr && s->ba != nullptr && n != nullptr && cap >= 0, "handle (started with the log on), n");

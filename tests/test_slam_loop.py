@@ -977,3 +977,37 @@ def test_a_frame_enqueued_ahead_has_to_be_the_next_one_tracked(gpu):
     with pytest.raises(RuntimeError, match="enqueued"):
         slam.handle_new_frame(imgs[k + 2])
     slam.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("form", [0, 1], ids=["four wavefronts, a barrier per pivot", "one wavefront, panels of four pivots on the matrix pipe"])
+def test_resident_adjusters_diagonal_tile_factor(gpu, form):
+    """The 32 x 32 diagonal-tile factor of the resident adjuster's Cholesky (`chol_block.h`; `mqs_debug_factor32`): L in the lower
+    triangle, inv(L)'s strictly lower part transposed above it -- both forms against numpy on well- and badly-conditioned matrices, the
+    scales a reduced camera system has (1e-3 .. 1e8 on the diagonal), and the flag on a matrix that is not positive definite."""
+    import ctypes
+    L_ = gpu._lib.lib()
+    rng = np.random.default_rng(7)
+    def run(A):
+        out, bad = np.zeros((32, 32)), ctypes.c_int32(0)
+        gpu._lib.check(L_.mqs_debug_factor32(np.ascontiguousarray(A).ctypes.data_as(gpu._lib.c_f64p), out.ctypes.data_as(gpu._lib.c_f64p), form, ctypes.byref(bad)))
+        return out, bad.value
+    for trial in range(6):
+        M = rng.standard_normal((32, 40))
+        scale = np.diag(10.0 ** rng.uniform(-1.5, 4.0, 32)) if trial % 2 else np.eye(32)
+        A = scale @ (M @ M.T + (1e-6 if trial == 5 else 1.0) * np.eye(32)) @ scale
+        out, bad = run(A)
+        assert bad == 0
+        Lr = np.linalg.cholesky(A)
+        Li = np.linalg.inv(Lr)
+        tol = 1e-12 if trial < 5 else 1e-7                    # (trial 5: condition number ~1e8 and more)
+        np.testing.assert_allclose(np.tril(out), Lr, rtol=0, atol=tol * np.abs(Lr).max())
+        up = np.triu(out, 1)                                  # out[c][j] = inv(L)[j][c], j > c
+        want = np.triu(Li.T, 1)
+        np.testing.assert_allclose(up, want, rtol=0, atol=tol * max(1.0, np.abs(Li).max()) * (1e3 if trial == 5 else 1.0))
+        # what the adjuster does with it: X = B inv(L)^T solves X L^T = B
+        B = rng.standard_normal((32, 32))
+        Linv = np.tril(up.T, -1) + np.diag(1.0 / np.diag(out))
+        np.testing.assert_allclose((B @ Linv.T) @ np.tril(out).T, B, rtol=0, atol=(1e-10 if trial < 5 else 1e-4) * np.abs(B).max())
+    A = rng.standard_normal((32, 32)); A = A + A.T                # symmetric, indefinite
+    assert run(A)[1] == 1
