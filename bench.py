@@ -413,13 +413,23 @@ def main():
     # earlier triangulation): the triangulation goes to its own HIP stream, where it fills what the BA chain leaves idle
     # -- the single-wavefront reduced-system solve (12 us), the 6-workgroup finalize, the all-reduce wait at N > 1, the
     # launch gaps.  Both streams are drained by the device-wide synchronize that brackets the timed region.
-    side = torch.cuda.Stream(device=dev) if (ba is not None and not args.one_stream) else None
+    side_priority = int(os.environ.get("MQS_BENCH_SIDE_PRIORITY", "0"))      # (A/B: -1 = a high-priority stream, i.e. a hardware queue that cannot be the BA chain's)
+    side = torch.cuda.Stream(device=dev, priority=side_priority) if (ba is not None and not args.one_stream) else None
+
+    # The BA chain -- the step's critical path -- on a high-priority stream of its own: streams of different priority never share a hardware
+    # queue, whatever the process has created and destroyed before (two streams on one queue run one behind the
+    # other).  Measured equal to the default stream when the queues do not collide (0.1764 / 0.1765 ms per step; MQS_BENCH_BA_PRIORITY=0: A/B).
+    ba_stream = torch.cuda.Stream(device=dev, priority=-1) if (side is not None and os.environ.get("MQS_BENCH_BA_PRIORITY", "-1") == "-1") else None
 
     def step():
         if side is not None:
             with torch.cuda.stream(side):
                 triangulate()
-            ba.gauss_newton_iteration()
+            if ba_stream is not None:
+                with torch.cuda.stream(ba_stream):
+                    ba.gauss_newton_iteration()
+            else:
+                ba.gauss_newton_iteration()
         elif ba is not None:
             ba.gauss_newton_iteration(overlap=triangulate)     # one stream: issued inside the all-reduce window
         else:
