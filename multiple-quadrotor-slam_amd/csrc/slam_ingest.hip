@@ -121,13 +121,10 @@ int mqs_slam_ingest_enable(mqs_slam *s, int slots)
         mqs_set_error("mqs_slam_ingest_enable: %s", hipGetErrorString(e));
         return MQS_E_NOMEM;
     }
-    {
-        // (the lowest stream priority: a hardware queue that is neither the loop's nor its side stream's -- see mqs_slam_set_next's stream in
-        // slam_frame.hip; the copies are two frames ahead of their use)
-        int least = 0, greatest = 0;
-        e = hipDeviceGetStreamPriorityRange(&least, &greatest);
-        if (e == hipSuccess) e = hipStreamCreateWithPriority(&g->up, hipStreamNonBlocking, least);
-    }
+    // (default priority.  The LOWEST priority -- a hardware queue that is certainly neither the loop's nor its side stream's -- was tried: inside
+    // bench.py the legs with upload lost 10-13 %: the queue's packets, the upload events among them, wait while the other queues have work, and
+    // the pipelined loop always has.  Sharing a queue with the loop's stream costs an upload at most a frame's kernels, and it is two frames ahead.)
+    e = hipStreamCreateWithFlags(&g->up, hipStreamNonBlocking);
     int made = 0;
     for (; e == hipSuccess && made < slots; ++made) e = hipEventCreateWithFlags(&g->ev[made], hipEventDisableTiming);
     if (e != hipSuccess) {
