@@ -774,9 +774,10 @@ int mqs_debug_factor32(const double *A, double *out, int form, int32_t *not_posi
  *                         (pinned == 0: ordinary memory, valid until mqs_slam_wait_upload of the slot has returned).
  *                         The caller reuses a slot only once the loop is done with the image in it (the previous image of the
  *                         next mqs_slam_track call is still in use).
- *   mqs_slam_wait_upload  makes the handle's stream wait (on the device; the host does not block beyond the worker's hand-off)
- *                         for the slot's upload and returns the slot's device image, to be passed to mqs_slam_start /
- *                         mqs_slam_track. */
+ *   mqs_slam_wait_upload  returns the slot's device image, to be passed to mqs_slam_start / mqs_slam_track (and to nothing else: the
+ *                         upload may still be under way).  The handle's streams wait for the upload on the device, each when it is about
+ *                         to read the image -- with the pair tracked ahead (mqs_slam_set_next) that is the side stream; the loop's stream
+ *                         only in front of a tracker or a corner detection of its own.  The host does not block beyond the worker's hand-off. */
 #define MQS_SLAM_INGEST_MAX_SLOTS 16
 int mqs_slam_ingest_enable(mqs_slam *s, int slots);
 int mqs_slam_upload(mqs_slam *s, int slot, const uint8_t *host_img, int pinned);

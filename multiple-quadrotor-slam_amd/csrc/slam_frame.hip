@@ -1171,6 +1171,7 @@ namespace {
 
 int topup(mqs_slam *s, const uint8_t *img)
 {
+    { const int rcw = mqs_slam_ingest_main_wait(s, img); if (rcw != MQS_OK) return rcw; }      // (the corner detector reads the image on the loop's stream)
     MQS_HIP_CHECK(hipMemsetAsync(s->d.mask, 1, (size_t)s->p.W * s->p.H, s->stream));
     hipLaunchKernelGGL(coverage_disc_kernel, dim3(kMaxTracks), dim3(64), 0, s->stream, s->d, s->p);
     int rc = mqs_good_features_to_track_dev(img, s->p.W, s->p.H, s->p.target, s->p.quality, s->p.radius, s->d.mask, s->d.gf_xy,
@@ -1509,6 +1510,9 @@ int mqs_slam_track(mqs_slam *s, const uint8_t *prev_img_dev, const uint8_t *img_
             if (ws == 1 && !s->ws_lk2) ws = 0;
             if (s->prep[ws].has_event && (s->prep[ws].valid || phases == 2)) MQS_HIP_CHECK(hipStreamWaitEvent(s->stream, s->prep[ws].done, 0));
             s->prep[ws].valid = false;
+            rc = mqs_slam_ingest_main_wait(s, prev_img_dev);       // (the tracker inside the call reads both images on the loop's stream)
+            if (rc == MQS_OK) rc = mqs_slam_ingest_main_wait(s, img_dev);
+            if (rc != MQS_OK) return rc;
             rc = mqs_lk_launch(prev_img_dev, img_dev, s->p.W, s->p.H, d.pts, kMaxTracks, d.cnt + C_N, 21, 21, 3, 30, 0.01, 1e-4, d.lk_pts,
                                d.lk_st, d.lk_err, ws == 0 ? s->ws_lk : s->ws_lk2, s->ws_lk_bytes, s->stream, phases);
             if (rc != MQS_OK) return rc;

@@ -5,8 +5,9 @@
 // A ring of device images owned by the handle, and ONE worker thread of the library: `mqs_slam_upload` only posts a job (a mutex and
 // a notification -- the calling thread goes straight on to mqs_slam_track, which blocks for the frame's result); the worker stages a
 // pageable source through the slot's pinned staging buffer, enqueues the copy on the upload stream and records the slot's event.
-// `mqs_slam_wait_upload` makes the LOOP'S STREAM wait for that event (hipStreamWaitEvent: a device-side wait, the host does not block)
-// -- the caller then passes the slot's device pointer to mqs_slam_start / mqs_slam_track like any other image.
+// `mqs_slam_wait_upload` hands out the slot's device pointer; the LOOP'S STREAM waits for that event (hipStreamWaitEvent: a device-side wait,
+// the host does not block) when one of its kernels is about to read the image (mqs_slam_ingest_main_wait) -- the caller passes the pointer to
+// mqs_slam_start / mqs_slam_track like any other image.
 // (From the interpreter the same thing -- a thread issuing torch copies -- cost 30 % of the plain loop's frame rate: the two threads
 // hand the interpreter lock back and forth.)
 #include "mqs_common.h"
@@ -25,6 +26,7 @@ struct mqs_slam_ingest {
     hipStream_t up;
     hipEvent_t ev[MQS_SLAM_INGEST_MAX_SLOTS];
     unsigned long long posted[MQS_SLAM_INGEST_MAX_SLOTS], done[MQS_SLAM_INGEST_MAX_SLOTS];
+    bool main_pending[MQS_SLAM_INGEST_MAX_SLOTS];     // mqs_slam_wait_upload named the slot, the loop's stream has not waited for its upload yet (it does when it reads the image)
     struct Job { int slot; const uint8_t *host; int pinned; };
     std::deque<Job> jobs;
     std::mutex m;
@@ -101,6 +103,21 @@ bool mqs_slam_ingest_slot(mqs_slam *s, int slot, const uint8_t **image_dev, hipE
     return true;
 }
 
+// The loop's stream is about to read `img`: if it is a ring slot the caller took with mqs_slam_wait_upload and the stream has not waited for its
+// upload yet, it does now.  (The wait used to be enqueued by mqs_slam_wait_upload itself -- a cross-queue barrier packet on the loop's stream per
+// frame, between one frame's decision and the next one's hypotheses, although with the pair tracked ahead nothing on that stream reads the image:
+// the side stream does, and waits for the upload itself.  ~10 us of a frame's ~100.)
+int mqs_slam_ingest_main_wait(mqs_slam *s, const uint8_t *img)
+{
+    mqs_slam_ingest *g = s ? s->ingest : nullptr;
+    if (!g || img < g->dev || img >= g->dev + (size_t)g->slots * g->bytes) return MQS_OK;
+    const int slot = (int)((size_t)(img - g->dev) / g->bytes);
+    if (!g->main_pending[slot]) return MQS_OK;
+    MQS_HIP_CHECK(hipStreamWaitEvent(s->stream, g->ev[slot], 0));
+    g->main_pending[slot] = false;
+    return MQS_OK;
+}
+
 extern "C" {
 
 int mqs_slam_ingest_enable(mqs_slam *s, int slots)
@@ -112,7 +129,7 @@ int mqs_slam_ingest_enable(mqs_slam *s, int slots)
     if (!g) { mqs_set_error("out of host memory"); return MQS_E_NOMEM; }
     g->slots = slots; g->bytes = (size_t)s->p.W * s->p.H; g->dev = nullptr; g->stage = nullptr; g->stop = false; g->error = hipSuccess;
     g->device = s->device;
-    for (int k = 0; k < MQS_SLAM_INGEST_MAX_SLOTS; ++k) { g->posted[k] = 0; g->done[k] = 0; }
+    for (int k = 0; k < MQS_SLAM_INGEST_MAX_SLOTS; ++k) { g->posted[k] = 0; g->done[k] = 0; g->main_pending[k] = false; }
     hipError_t e = hipMalloc((void **)&g->dev, (size_t)slots * g->bytes);
     if (e == hipSuccess) e = hipHostMalloc((void **)&g->stage, (size_t)slots * g->bytes, hipHostMallocDefault);
     if (e != hipSuccess) {
@@ -158,6 +175,7 @@ int mqs_slam_upload(mqs_slam *s, int slot, const uint8_t *host_img, int pinned)
     {
         std::lock_guard<std::mutex> lk(g->m);
         g->posted[slot] += 1;
+        g->main_pending[slot] = false;                 // (a new image: mqs_slam_wait_upload names it again)
         g->jobs.push_back({slot, host_img, pinned});
     }
     g->cv_job.notify_one();
@@ -177,8 +195,7 @@ int mqs_slam_wait_upload(mqs_slam *s, int slot, const uint8_t **image_dev)
         err = g->error;
     }
     if (err != hipSuccess) { mqs_set_error("mqs_slam_upload: %s", hipGetErrorString(err)); return MQS_E_HIP; }
-    MQS_HIP_CHECK(hipSetDevice(s->device));
-    MQS_HIP_CHECK(hipStreamWaitEvent(s->stream, g->ev[slot], 0));
+    g->main_pending[slot] = true;                      // (the loop's stream waits when it is about to read the image: mqs_slam_ingest_main_wait)
     *image_dev = g->dev + (size_t)slot * g->bytes;
     return MQS_OK;
 }

@@ -125,6 +125,7 @@ struct mqs_slam {
 };
 // slam_ingest.hip: a ring slot's device image and upload event, once the worker has enqueued the copy (false: nothing was uploaded into it)
 bool mqs_slam_ingest_slot(mqs_slam *s, int slot, const uint8_t **image_dev, hipEvent_t *uploaded);
+int mqs_slam_ingest_main_wait(mqs_slam *s, const uint8_t *img);      // slam_ingest.hip: before a kernel on the loop's stream reads `img` (a ring slot's upload is waited for lazily)
 void mqs_slam_ba_release(mqs_slam *s);          // slam_ba.hip
 void mqs_slam_ingest_release(mqs_slam *s);      // slam_ingest.hip
 int mqs_slam_ba_anchor(mqs_slam *s, int n0);     // slam_ba.hip: at the end of mqs_slam_start, with the log on
