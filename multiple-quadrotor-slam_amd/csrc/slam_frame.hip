@@ -1246,7 +1246,14 @@ int mqs_slam_create(int device, int W, int H, const double *intr, int target_key
     d.gf_n = (int32_t *)(a + o_gn); d.res = (double *)(a + o_res); d.kf_hand = (double *)(a + o_hand);
     s->ws_lk = a + o_wl; s->ws_gftt = a + o_wg; s->ws_pnp = a + o_wp;
     mqs_pnp_workspace_layout(s->ws_pnp, kHyp, &d.pnp_poses, &d.pnp_counts, &d.pnp_inl);
-    e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
+    // (the highest stream priority, like the side stream of mqs_slam_set_next: their hardware queues then come from a pool nothing else in the
+    // process draws from -- a default-priority stream, the ingest's upload stream for one, cannot land on the loop's queue and put its
+    // copy / event packets between the loop's kernels; measured inside bench.py: with-upload / resident 0.87-0.89 -> see DESIGN.md section 0)
+    {
+        int least = 0, greatest = 0;
+        e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+        if (e == hipSuccess) e = hipStreamCreateWithPriority(&s->stream, hipStreamNonBlocking, greatest);
+    }
     // (coherent: the decision kernel's block and ticket must be visible to the polling host while later launches are still running)
     if (e == hipSuccess) e = hipHostMalloc((void **)&s->res_host, (size_t)kResSlots * kResStride * 8, hipHostMallocCoherent);
     if (e == hipSuccess) memset(s->res_host, 0xff, (size_t)kResSlots * kResStride * 8);
