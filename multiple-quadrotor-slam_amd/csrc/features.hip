@@ -16,9 +16,10 @@
 //     dozen launches; the library is gone from the product.)  The response maximum is an atomic max of order-
 //     preserving keys inside the response kernel: no separate reduction launches;
 //   * minimum-distance selection: the greedy rule (a candidate is a corner unless a stronger corner is closer than
-//     min_distance) is sequential as written; its result is reached as a parallel fixed point, 1024 candidates per round:
-//     pre-filter against the corners of earlier rounds (grid of accepted corners, in LDS when it fits), then sweeps in
-//     which every undecided survivor looks at the stronger survivors near it;
+//     min_distance) walks the sorted list, and a candidate depends only on candidates in front of it: the list goes through in
+//     groups of 64 -- every candidate's mask of stronger group members within the distance built by all wavefronts (1024
+//     candidates per pass), then one wavefront settles the groups in order against the grid of accepted corners (in LDS when it
+//     fits) and on wave-wide masks inside a group (round 6; rounds 3-5: a parallel fixed point over pre-filtered survivors);
 //   * Lucas-Kanade: one wavefront per feature, lanes strided over the 21 x 21 window (7 pixels each, template and
 //     gradients in registers), all pyramid levels and all iterations inside one launch; window sums in fp64.
 #include <cstring>
@@ -1060,8 +1061,6 @@ int mqs_good_features_to_track_dev(const uint8_t *img, int W, int H, int max_cor
     const size_t sort_lds = (size_t)kSortChunk * sizeof(unsigned long long);
     const size_t grid_lds = cells * 16;
     const bool in_lds = min_distance < 1.0 || grid_lds <= sort_lds;      // the grid takes the sort buffer's place
-    // polls per wavefront of the selection's barrier-free decisions before the synchronous sweeps take over (never reached in
-    // practice; MQS_GFTT_POLL_ROUNDS=0 runs the synchronous rule alone: the A/B form the tests compare)
     const size_t lds = sort_lds;
     if (in_lds) {
         static mqs_lds_opt_in opt;                           // per device
