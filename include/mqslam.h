@@ -620,6 +620,9 @@ int64_t mqs_fast_workspace_bytes(int W, int H);
  * Streams: the handle works on a private non-blocking stream and takes no event from the caller, so the images must be
  * COMPLETE in device memory when mqs_slam_start / mqs_slam_track is called -- an upload still in flight on another stream
  * (torch's current stream, say) is not ordered against the library's reads: synchronise that stream (or the device) first.
+ * The handle's streams (this one, and the side stream mqs_slam_set_next brings) are created with the HIGHEST stream priority: their hardware
+ * queues then come from a pool no default-priority stream of the process draws from (two streams that share a queue run one behind the other:
+ * csrc/slam_frame.hip), and their kernels are dispatched ahead of default-priority work of the same process on the same device.
  * n0 <= max_landmarks (the start-up points are the first entries of the map).
  *   mqs_slam_start   first frame: pose from n0 known 3-D points (HOST float32 objp0 [n0][3], imgp0 [n0][2]), which become
  *                    the first landmarks and tracks; the other tracks from goodFeaturesToTrack.  pose_out [12] host.
