@@ -940,7 +940,7 @@ def test_next_pairs_pyramid_ahead_of_its_frame_gives_the_same_run(gpu, frames_fr
     host = [im.cpu().numpy() for im in imgs]
 
     def run(ahead):
-        slam = gpu.slam_device.DeviceMonoSlam(seq.K, seq.dist, (seq.H, seq.W), seed=2, bundle_adjust="keyframe")
+        slam = gpu.slam_device.DeviceMonoSlam(seq.K, seq.dist, (seq.H, seq.W), seed=2, bundle_adjust="keyframe", reassociate=True)      # (BA and the matcher's re-association behind every keyframe)
         slam.prepare_next = ahead
         slam.pipeline = pipeline
         rets = []
