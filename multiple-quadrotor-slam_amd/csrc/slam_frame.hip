@@ -1260,7 +1260,9 @@ int mqs_slam_create(int device, int W, int H, const double *intr, int target_key
     {
         int least = 0, greatest = 0;
         e = hipDeviceGetStreamPriorityRange(&least, &greatest);
-        if (e == hipSuccess) e = hipStreamCreateWithPriority(&s->stream, hipStreamNonBlocking, greatest);
+        s->stream_priority = greatest;
+        if (const char *pe = getenv("MQS_SLAM_STREAM_PRIORITY")) s->stream_priority = (pe[0] == 'n' || pe[0] == '0') ? 0 : greatest;      // A/B: "normal"
+        if (e == hipSuccess) e = hipStreamCreateWithPriority(&s->stream, hipStreamNonBlocking, s->stream_priority);
     }
     // (coherent: the decision kernel's block and ticket must be visible to the polling host while later launches are still running)
     if (e == hipSuccess) e = hipHostMalloc((void **)&s->res_host, (size_t)kResSlots * kResStride * 8, hipHostMallocCoherent);
@@ -1634,7 +1636,7 @@ static int prepare_next_into(mqs_slam *s, const uint8_t *prev_img_dev, int prev_
         {
             int least = 0, greatest = 0;
             MQS_HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-            MQS_HIP_CHECK(hipStreamCreateWithPriority(&s->pyr_stream, hipStreamNonBlocking, greatest));
+            MQS_HIP_CHECK(hipStreamCreateWithPriority(&s->pyr_stream, hipStreamNonBlocking, s->stream_priority == 0 ? 0 : greatest));
         }
         hipError_t e = hipMalloc(&s->ws_lk2, (size_t)s->ws_lk_bytes);
         if (e != hipSuccess) { s->ws_lk2 = nullptr; mqs_set_error("hipMalloc(%lld) failed: %s", (long long)s->ws_lk_bytes, hipGetErrorString(e)); return MQS_E_NOMEM; }

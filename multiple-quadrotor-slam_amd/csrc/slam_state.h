@@ -91,6 +91,7 @@ struct mqs_slam_ingest;              // slam_ingest.hip: the frame-ingest ring, 
 struct mqs_slam {
     int device;
     hipStream_t stream;
+    int stream_priority;             // of this stream and the side stream: the device's highest (default), or 0 with MQS_SLAM_STREAM_PRIORITY=normal (A/B)
     mqs::slamst::SlamDev d;
     mqs::slamst::SlamParams p;
     char *arena;

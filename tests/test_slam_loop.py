@@ -1011,3 +1011,42 @@ def test_resident_adjusters_diagonal_tile_factor(gpu, form):
         np.testing.assert_allclose((B @ Linv.T) @ np.tril(out).T, B, rtol=0, atol=(1e-10 if trial < 5 else 1e-4) * np.abs(B).max())
     A = rng.standard_normal((32, 32)); A = A + A.T                # symmetric, indefinite
     assert run(A)[1] == 1
+
+
+@pytest.mark.gpu
+def test_two_cameras_on_one_device_each_run_as_if_alone(gpu):
+    """The reference is a MULTIPLE-quadrotor system: several loops on one device, one handle and one host thread per camera (the library
+    calls release the interpreter lock while they wait).  Two cameras with their own seeds, BA per keyframe and re-association, running
+    at the same time: each reports the run it reports alone -- decisions, poses, tracks, map, bit for bit (the handles share nothing
+    but the device; the adjuster's launches of one device are serialised by the library)."""
+    import threading
+    seq, objp, imgp, imgs = _rendered(gpu, 40)
+
+    def run(seed, out, start=None):
+        slam = gpu.slam_device.DeviceMonoSlam(seq.K, seq.dist, (seq.H, seq.W), seed=seed, bundle_adjust="keyframe", reassociate=True)
+        if start is not None:
+            start.wait()
+        slam.start(imgs[0], objp, imgp)
+        rets = [2] + [slam.handle_new_frame(imgs[k], imgs[k + 1] if k + 1 < len(imgs) else None) for k in range(1, len(imgs))]
+        slam.finish()
+        out[seed] = (rets, [None if P is None else np.array(P) for P in slam.poses], [np.array(a) for a in slam.tracks()], slam.objp.copy())
+        slam.close()
+    alone, both = {}, {}
+    for seed in (3, 4):
+        run(seed, alone)
+    for rep in range(3):
+        start = threading.Event()
+        th = [threading.Thread(target=run, args=(seed, both, start)) for seed in (3, 4)]
+        for t in th:
+            t.start()
+        start.set()
+        for t in th:
+            t.join()
+        for seed in (3, 4):
+            a, b = alone[seed], both[seed]
+            assert a[0] == b[0] and a[0].count(2) >= 5
+            for x, y in zip(a[1], b[1]):
+                assert (x is None) == (y is None) and (x is None or np.array_equal(x, y))
+            for x, y in zip(a[2], b[2]):
+                np.testing.assert_array_equal(x, y)
+            np.testing.assert_array_equal(a[3], b[3])
